@@ -1,0 +1,334 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see ff.hpp header).
+// extern "C" surface over the CPU restatement so that tests/ (ctypes), __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg can drive it.  Every buffer uses the product ABI's data convention:
+// field elements = N x u64 little-endian Montgomery limbs; G1 affine = x||y, G2 affine = x.c0||x.c1||y.c0||y.c1
+// with (0,0) = infinity (the packed zkey encoding, `/root/reference/co-circom/circom-types/src/traits.rs:107-155`).
+#include "pairing.hpp"
+#include <chrono>
+
+using namespace orc;
+
+namespace {
+thread_local std::string g_err;
+template <class F> F ld(const uint64_t* p) { return F::from_mont_limbs(p); }
+template <class F> void st(uint64_t* p, const F& v) { memcpy(p, v.v, sizeof v.v); }
+
+template <class Fq> AffineT<Fq> ld_g1(const uint64_t* p) {
+    Fq x = ld<Fq>(p), y = ld<Fq>(p + Fq::N);
+    if (x.is_zero() && y.is_zero()) return AffineT<Fq>::infinity();
+    return {x, y, false};
+}
+template <class Fq> void st_g1(uint64_t* p, const AffineT<Fq>& a) {
+    if (a.inf) { memset(p, 0, 2 * Fq::N * 8); return; }
+    st(p, a.x); st(p + Fq::N, a.y);
+}
+template <class Fq> AffineT<Fp2T<Fq>> ld_g2(const uint64_t* p) {
+    Fp2T<Fq> x = {ld<Fq>(p), ld<Fq>(p + Fq::N)}, y = {ld<Fq>(p + 2 * Fq::N), ld<Fq>(p + 3 * Fq::N)};
+    if (x.is_zero() && y.is_zero()) return AffineT<Fp2T<Fq>>::infinity();
+    return {x, y, false};
+}
+template <class Fq> void st_g2(uint64_t* p, const AffineT<Fp2T<Fq>>& a) {
+    if (a.inf) { memset(p, 0, 4 * Fq::N * 8); return; }
+    st(p, a.x.c0); st(p + Fq::N, a.x.c1); st(p + 2 * Fq::N, a.y.c0); st(p + 3 * Fq::N, a.y.c1);
+}
+template <class C> void st_proof(uint64_t* p, const Proof<C>& pf) {
+    const int n = C::Fq::N;
+    st_g1<typename C::Fq>(p, pf.a); st_g2<typename C::Fq>(p + 2 * n, pf.b); st_g1<typename C::Fq>(p + 6 * n, pf.c);
+}
+template <class C> Proof<C> ld_proof(const uint64_t* p) {
+    const int n = C::Fq::N;
+    return {ld_g1<typename C::Fq>(p), ld_g2<typename C::Fq>(p + 2 * n), ld_g1<typename C::Fq>(p + 6 * n)};
+}
+
+struct ZKeyHandle { int curve; ZKey<Bn254>* bn = nullptr; ZKey<Bls12_381>* bls = nullptr; };
+
+#define DISPATCH(curve, ...)                                    \
+    try {                                                       \
+        if ((curve) == 0) { typedef Bn254 C; C::init(); __VA_ARGS__; } \
+        else if ((curve) == 1) { typedef Bls12_381 C; C::init(); __VA_ARGS__; } \
+        else { g_err = "bad curve id"; return -1; }             \
+    } catch (const std::exception& e) { g_err = e.what(); return -2; }
+}  // namespace
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+// which: 0 = Fr, 1 = Fq
+int orc_field_limbs(int curve, int which) { return curve == 1 && which == 1 ? 6 : 4; }
+
+int orc_from_dec(int curve, int which, const char* dec, uint64_t* out) {
+    DISPATCH(curve, { if (which == 0) st(out, C::Fr::from_dec(dec)); else st(out, C::Fq::from_dec(dec)); });
+    return 0;
+}
+int orc_to_dec(int curve, int which, const uint64_t* in, char* out, size_t cap) {
+    DISPATCH(curve, {
+        std::string s = which == 0 ? ld<typename C::Fr>(in).to_dec() : ld<typename C::Fq>(in).to_dec();
+        if (s.size() + 1 > cap) { g_err = "buffer too small"; return -3; }
+        memcpy(out, s.c_str(), s.size() + 1);
+    });
+    return 0;
+}
+// op: 0 add, 1 sub, 2 mul (elementwise over n elements of Fr (which=0) or Fq (which=1))
+int orc_field_op(int curve, int which, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    DISPATCH(curve, {
+        auto run = [&](auto tag) {
+            typedef decltype(tag) F;
+            for (size_t i = 0; i < n; i++) {
+                F x = ld<F>(a + i * F::N), y = ld<F>(b + i * F::N);
+                st(out + i * F::N, op == 0 ? x + y : op == 1 ? x - y : x * y);
+            }
+        };
+        if (which == 0) run(typename C::Fr()); else run(typename C::Fq());
+    });
+    return 0;
+}
+int orc_field_inverse(int curve, int which, const uint64_t* a, uint64_t* out) {
+    DISPATCH(curve, { if (which == 0) st(out, ld<typename C::Fr>(a).inverse()); else st(out, ld<typename C::Fq>(a).inverse()); });
+    return 0;
+}
+// out_roots must hold (two_adicity+1) elements; returns two-adicity through *two_adicity
+int orc_roots_of_unity(int curve, uint64_t* out_q, uint64_t* out_roots, int* two_adicity) {
+    DISPATCH(curve, {
+        auto rt = roots_of_unity<typename C::Fr>();
+        st(out_q, rt.q); *two_adicity = rt.two_adicity;
+        for (size_t i = 0; i < rt.roots.size(); i++) st(out_roots + i * 4, rt.roots[i]);
+    });
+    return 0;
+}
+int orc_groth16_domain(int curve, size_t pow, size_t num_constraints, size_t num_inputs, uint64_t* omega, uint64_t* coset_g, size_t* m) {
+    DISPATCH(curve, {
+        auto d = groth16_domain<typename C::Fr>(pow, num_constraints, num_inputs);
+        st(omega, d.omega); st(coset_g, d.coset_g); *m = d.m;
+    });
+    return 0;
+}
+int orc_ntt(int curve, uint64_t* data, size_t n, const uint64_t* omega, int inverse) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr;
+        Fr* v = reinterpret_cast<Fr*>(data);
+        if (inverse) ntt_inverse(v, n, ld<Fr>(omega)); else ntt_forward(v, n, ld<Fr>(omega));
+    });
+    return 0;
+}
+int orc_dft_naive(int curve, const uint64_t* in, uint64_t* out, size_t n, const uint64_t* omega) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr;
+        auto r = dft_naive(reinterpret_cast<const Fr*>(in), n, ld<Fr>(omega));
+        memcpy(out, r.data(), n * sizeof(Fr));
+    });
+    return 0;
+}
+int orc_distribute_powers(int curve, uint64_t* data, size_t n, const uint64_t* g, const uint64_t* c) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr;
+        Fr pw = ld<Fr>(c), gg = ld<Fr>(g);
+        Fr* v = reinterpret_cast<Fr*>(data);
+        for (size_t i = 0; i < n; i++) { v[i] = v[i] * pw; pw = pw * gg; }
+    });
+    return 0;
+}
+// group: 0 = G1, 1 = G2. algo: 0 = arkworks-style Pippenger, 1 = naive double-and-add. out = packed affine.
+int orc_msm(int curve, int group, int algo, const uint64_t* points, const uint64_t* scalars, size_t n, int threads, uint64_t* out_affine) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr; typedef typename C::Fq Fq;
+        const Fr* sc = reinterpret_cast<const Fr*>(scalars);
+        if (group == 0) {
+            std::vector<typename C::G1::Affine> b(n);
+            for (size_t i = 0; i < n; i++) b[i] = ld_g1<Fq>(points + i * 2 * Fq::N);
+            auto r = n == 0 ? C::G1::infinity() : algo == 0 ? msm_pippenger<typename C::G1, Fr>(b.data(), sc, n, threads) : msm_naive<typename C::G1, Fr>(b.data(), sc, n);
+            st_g1<Fq>(out_affine, r.to_affine());
+        } else {
+            std::vector<typename C::G2::Affine> b(n);
+            for (size_t i = 0; i < n; i++) b[i] = ld_g2<Fq>(points + i * 4 * Fq::N);
+            auto r = n == 0 ? C::G2::infinity() : algo == 0 ? msm_pippenger<typename C::G2, Fr>(b.data(), sc, n, threads) : msm_naive<typename C::G2, Fr>(b.data(), sc, n);
+            st_g2<Fq>(out_affine, r.to_affine());
+        }
+    });
+    return 0;
+}
+// Jacobian (X,Y,Z) -> packed affine; Z == 0 -> infinity. Used to normalise the product's MSM output before comparing.
+int orc_jacobian_to_affine(int curve, int group, const uint64_t* jac, uint64_t* out_affine) {
+    DISPATCH(curve, {
+        typedef typename C::Fq Fq; typedef typename C::Fq2 Fq2;
+        if (group == 0) { typename C::G1 p = {ld<Fq>(jac), ld<Fq>(jac + Fq::N), ld<Fq>(jac + 2 * Fq::N)}; st_g1<Fq>(out_affine, p.to_affine()); }
+        else {
+            typename C::G2 p = {Fq2{ld<Fq>(jac), ld<Fq>(jac + Fq::N)}, Fq2{ld<Fq>(jac + 2 * Fq::N), ld<Fq>(jac + 3 * Fq::N)}, Fq2{ld<Fq>(jac + 4 * Fq::N), ld<Fq>(jac + 5 * Fq::N)}};
+            st_g2<Fq>(out_affine, p.to_affine());
+        }
+    });
+    return 0;
+}
+int orc_on_curve(int curve, int group, const uint64_t* pt) {
+    DISPATCH(curve, {
+        typedef typename C::Fq Fq;
+        return group == 0 ? (int)C::G1::on_curve(ld_g1<Fq>(pt)) : (int)C::G2::on_curve(ld_g2<Fq>(pt));
+    });
+    return 0;
+}
+// generator * scalar (packed affine out); used by tests to make valid points
+int orc_generator_mul(int curve, int group, const uint64_t* scalar, uint64_t* out_affine) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr; typedef typename C::Fq Fq;
+        Fr s = ld<Fr>(scalar);
+        if (group == 0) st_g1<Fq>(out_affine, scalar_mul(C::G1::from_affine(C::g1_generator()), s).to_affine());
+        else st_g2<Fq>(out_affine, scalar_mul(C::G2::from_affine(C::g2_generator()), s).to_affine());
+    });
+    return 0;
+}
+// out[i] = point[i] * scalar[i]  (packed affine in/out)
+int orc_points_mul(int curve, int group, const uint64_t* pts, const uint64_t* scalars, size_t n, uint64_t* out_affine) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr; typedef typename C::Fq Fq;
+        for (size_t i = 0; i < n; i++) {
+            Fr s = ld<Fr>(scalars + i * 4);
+            if (group == 0) st_g1<Fq>(out_affine + i * 2 * Fq::N, scalar_mul(C::G1::from_affine(ld_g1<Fq>(pts + i * 2 * Fq::N)), s).to_affine());
+            else st_g2<Fq>(out_affine + i * 4 * Fq::N, scalar_mul(C::G2::from_affine(ld_g2<Fq>(pts + i * 4 * Fq::N)), s).to_affine());
+        }
+    });
+    return 0;
+}
+// out = a + b (packed affine)
+int orc_point_add(int curve, int group, const uint64_t* a, const uint64_t* b, uint64_t* out_affine) {
+    DISPATCH(curve, {
+        typedef typename C::Fq Fq;
+        if (group == 0) st_g1<Fq>(out_affine, C::G1::from_affine(ld_g1<Fq>(a)).add_affine(ld_g1<Fq>(b)).to_affine());
+        else st_g2<Fq>(out_affine, C::G2::from_affine(ld_g2<Fq>(a)).add_affine(ld_g2<Fq>(b)).to_affine());
+    });
+    return 0;
+}
+
+// ---- zkey / wtns ------------------------------------------------------------------------------------
+void* orc_zkey_open(int curve, const char* path) {
+    try {
+        auto* h = new ZKeyHandle{curve};
+        if (curve == 0) { Bn254::init(); h->bn = new ZKey<Bn254>(read_zkey<Bn254>(path)); }
+        else if (curve == 1) { Bls12_381::init(); h->bls = new ZKey<Bls12_381>(read_zkey<Bls12_381>(path)); }
+        else { delete h; g_err = "bad curve id"; return nullptr; }
+        return h;
+    } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void orc_zkey_close(void* hh) { auto* h = (ZKeyHandle*)hh; if (!h) return; delete h->bn; delete h->bls; delete h; }
+
+#define ZK(h, ...) { auto* zh = (ZKeyHandle*)(h); try { if (zh->curve == 0) { typedef Bn254 C; auto& z = *zh->bn; __VA_ARGS__; } else { typedef Bls12_381 C; auto& z = *zh->bls; __VA_ARGS__; } } catch (const std::exception& e) { g_err = e.what(); return -2; } }
+
+// info: n_vars, n_public, domain_size, pow, num_constraints, nnzA, nnzB
+int orc_zkey_info(void* h, size_t* info) {
+    ZK(h, { info[0] = z.n_vars; info[1] = z.n_public; info[2] = z.domain_size; info[3] = z.pow; info[4] = z.num_constraints; info[5] = z.col[0].size(); info[6] = z.col[1].size(); });
+    return 0;
+}
+// which: 0 ic, 1 a_query, 2 b_g1_query, 3 b_g2_query, 4 l_query, 5 h_query, 6 (alpha1,beta1,delta1), 7 (beta2,gamma2,delta2)
+int orc_zkey_points(void* h, int which, uint64_t* out) {
+    ZK(h, {
+        typedef typename C::Fq Fq;
+        auto put1 = [&](const std::vector<typename C::G1::Affine>& v) { for (size_t i = 0; i < v.size(); i++) st_g1<Fq>(out + i * 2 * Fq::N, v[i]); };
+        switch (which) {
+            case 0: put1(z.ic); break; case 1: put1(z.a_query); break; case 2: put1(z.b_g1_query); break;
+            case 3: for (size_t i = 0; i < z.b_g2_query.size(); i++) st_g2<Fq>(out + i * 4 * Fq::N, z.b_g2_query[i]); break;
+            case 4: put1(z.l_query); break; case 5: put1(z.h_query); break;
+            case 6: st_g1<Fq>(out, z.alpha_g1); st_g1<Fq>(out + 2 * Fq::N, z.beta_g1); st_g1<Fq>(out + 4 * Fq::N, z.delta_g1); break;
+            case 7: st_g2<Fq>(out, z.beta_g2); st_g2<Fq>(out + 4 * Fq::N, z.gamma_g2); st_g2<Fq>(out + 8 * Fq::N, z.delta_g2); break;
+            default: g_err = "bad selector"; return -1;
+        }
+    });
+    return 0;
+}
+int orc_zkey_matrix(void* h, int m, uint32_t* row_ptr, uint32_t* col, uint64_t* coeff) {
+    ZK(h, {
+        memcpy(row_ptr, z.row_ptr[m].data(), z.row_ptr[m].size() * 4);
+        memcpy(col, z.col[m].data(), z.col[m].size() * 4);
+        memcpy(coeff, z.coeff[m].data(), z.coeff[m].size() * sizeof(typename C::Fr));
+    });
+    return 0;
+}
+int orc_wtns_read(int curve, const char* path, uint64_t* out, size_t cap, size_t* n) {
+    DISPATCH(curve, {
+        auto w = read_wtns<typename C::Fr>(path);
+        *n = w.size();
+        if (out) { if (w.size() > cap) { g_err = "buffer too small"; return -3; } memcpy(out, w.data(), w.size() * sizeof(typename C::Fr)); }
+    });
+    return 0;
+}
+
+// ---- prover ------------------------------------------------------------------------------------------
+int orc_witness_map_plain(void* h, const uint64_t* full_witness, uint64_t* out_h) {
+    ZK(h, {
+        typedef typename C::Fr Fr;
+        const Fr* w = reinterpret_cast<const Fr*>(full_witness);
+        std::vector<Fr> pub(w, w + z.n_public + 1), wit(w + z.n_public + 1, w + z.n_vars);
+        auto hv = witness_map_plain<C>(z, pub, wit);
+        memcpy(out_h, hv.data(), hv.size() * sizeof(Fr));
+    });
+    return 0;
+}
+// proof layout: A (G1 packed) || B (G2 packed) || C (G1 packed) ; seconds (optional) = wall time of the prove call
+int orc_prove_plain(void* h, const uint64_t* full_witness, const uint64_t* r, const uint64_t* s, int threads, uint64_t* out_proof, double* seconds) {
+    ZK(h, {
+        typedef typename C::Fr Fr;
+        const Fr* w = reinterpret_cast<const Fr*>(full_witness);
+        std::vector<Fr> fw(w, w + z.n_vars);
+        auto t0 = std::chrono::steady_clock::now();
+        auto pf = prove_plain<C>(z, fw, ld<Fr>(r), ld<Fr>(s), threads);
+        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        st_proof<C>(out_proof, pf);
+    });
+    return 0;
+}
+// shares: wit_a[i], wit_b[i] (i = party) each n_vars-n_public-1 elements; streams: s[i] each stream_len elements
+// (needs 2*m + 4).  out_proofs = 3 proofs back to back.  out_h (optional) = party-0 h share: a then b (2*m elements).
+int orc_prove_rep3(void* h, const uint64_t* pub, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
+                   const uint64_t* const* streams, size_t stream_len, int threads, uint64_t* out_proofs, uint64_t* out_h) {
+    ZK(h, {
+        typedef typename C::Fr Fr;
+        const size_t n_aux = z.n_vars - z.n_public - 1;
+        Rep3Sim<C> sim(z);
+        sim.threads = threads;
+        const Fr* p = reinterpret_cast<const Fr*>(pub);
+        sim.pub.assign(p, p + z.n_public + 1);
+        std::vector<Fr> st_[3];
+        for (int i = 0; i < 3; i++) {
+            const Fr* a = reinterpret_cast<const Fr*>(wit_a[i]); const Fr* b = reinterpret_cast<const Fr*>(wit_b[i]);
+            sim.wit[i].a.assign(a, a + n_aux); sim.wit[i].b.assign(b, b + n_aux);
+            const Fr* s = reinterpret_cast<const Fr*>(streams[i]);
+            st_[i].assign(s, s + stream_len);
+            sim.stream[i] = &st_[i];
+        }
+        size_t m = 1; while (m < z.num_constraints + z.n_public + 1) m <<= 1;
+        if (stream_len < 2 * m + 4) { g_err = "randomness stream too short"; return -3; }
+        Proof<C> out[3];
+        ShareVec<Fr> hs[3];
+        sim.prove(out, &hs);
+        const int psz = 8 * C::Fq::N;
+        for (int i = 0; i < 3; i++) st_proof<C>(out_proofs + i * psz, out[i]);
+        if (out_h) { memcpy(out_h, hs[0].a.data(), m * sizeof(Fr)); memcpy(out_h + m * 4, hs[0].b.data(), m * sizeof(Fr)); }
+    });
+    return 0;
+}
+// returns 1 = accept, 0 = reject, <0 error. ic has n_pub+1 packed G1 points.
+int orc_verify(int curve, const uint64_t* alpha1, const uint64_t* beta2, const uint64_t* gamma2, const uint64_t* delta2,
+               const uint64_t* ic, size_t n_pub, const uint64_t* pub, const uint64_t* proof) {
+    DISPATCH(curve, {
+        typedef typename C::Fq Fq; typedef typename C::Fr Fr;
+        std::vector<typename C::G1::Affine> icv(n_pub + 1);
+        for (size_t i = 0; i <= n_pub; i++) icv[i] = ld_g1<Fq>(ic + i * 2 * Fq::N);
+        std::vector<Fr> pv(n_pub);
+        for (size_t i = 0; i < n_pub; i++) pv[i] = ld<Fr>(pub + i * 4);
+        return groth16_verify<C>(ld_g1<Fq>(alpha1), ld_g2<Fq>(beta2), ld_g2<Fq>(gamma2), ld_g2<Fq>(delta2), icv, pv, ld_proof<C>(proof)) ? 1 : 0;
+    });
+    return 0;
+}
+// bilinearity self-check of the pairing: t(aP, bQ) == t(P,Q)^(ab) tested as t(aP,Q) == t(P,aQ); returns 1 if it holds and t != 1
+int orc_pairing_selfcheck(int curve, const uint64_t* scalar) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr;
+        Fr a = ld<Fr>(scalar);
+        auto P = C::g1_generator(); auto Q = C::g2_generator();
+        auto aP = scalar_mul(C::G1::from_affine(P), a).to_affine();
+        auto aQ = scalar_mul(C::G2::from_affine(Q), a).to_affine();
+        auto e1 = tate_pairing<C>(aP, Q); auto e2 = tate_pairing<C>(P, aQ); auto e0 = tate_pairing<C>(P, Q);
+        return (e1 == e2 && !(e0 == Fp12T<C>::one())) ? 1 : 0;
+    });
+    return 0;
+}
+
+}  // extern "C"

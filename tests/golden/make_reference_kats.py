@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Extracts the EXPECTED VALUES (decimal coordinates / field elements) that the reference's own unit tests
+hard-code, and stores them as data in tests/golden/reference_kats.json.  Run in the build container only
+(/root/reference does not exist on the GPU box); the JSON is committed.
+
+Sources (values only, no code is copied):
+  /root/reference/co-circom/circom-types/src/groth16/zkey.rs:336-719   zkey decode KATs (multiplier2, both curves)
+  /root/reference/mpc-core/tests/protocols/rep3.rs:242-350             Fr product KAT (rep3_mul_vec_bn)
+  /root/reference/co-circom/circom-types/src/witness.rs:101-134        witness KAT
+"""
+import json, re, sys, os
+
+REF = "/root/reference"
+out = {}
+
+def let_statements(body):
+    """yield (name, text) for each top-level `let name = ...;` in a Rust test body"""
+    for m in re.finditer(r"let\s+(?:mut\s+)?(\w+)\s*(?::[^=]+)?=\s*(.*?);\s*\n", body, re.S):
+        yield m.group(1), m.group(2)
+
+def tokens(text):
+    toks = []
+    for m in re.finditer(r'identity\(\)|"(\d+)"', text):
+        toks.append("inf" if m.group(0).startswith("identity") else m.group(1))
+    return toks
+
+src = open(f"{REF}/co-circom/circom-types/src/groth16/zkey.rs").read()
+tests = re.split(r"#\[test\]", src)[1:]
+zk = {}
+for t in tests:
+    name = re.search(r"fn\s+(\w+)", t).group(1)
+    path = re.search(r'File::open\("([^"]+)"\)', t)
+    entry = {"file": path.group(1).replace("../../test_vectors/", "") if path else None, "values": {}}
+    for var, text in let_statements(t):
+        tk = tokens(text)
+        if tk:
+            entry["values"][var] = tk
+    if entry["values"]:
+        zk[name] = entry
+out["zkey"] = zk
+
+src = open(f"{REF}/mpc-core/tests/protocols/rep3.rs").read()
+m = re.search(r"fn rep3_mul_vec_bn\(\)(.*?)\n    }\n", src, re.S)
+body = m.group(1)
+vals = {}
+for var, text in let_statements(body):
+    tk = re.findall(r'"(\d+)"', text)
+    if tk:
+        vals[var] = tk
+out["rep3_mul_vec_bn"] = vals
+
+src = open(f"{REF}/co-circom/circom-types/src/witness.rs").read()
+wt = {}
+for t in re.split(r"#\[test\]", src)[1:]:
+    name = re.search(r"fn\s+(\w+)", t).group(1)
+    path = re.search(r'File::open\("([^"]+)"\)', t)
+    nums = re.findall(r'Fr::from\((\d+)\)', t)
+    wt[name] = {"file": path.group(1).replace("../../test_vectors/", "") if path else None, "values": nums}
+out["witness"] = wt
+
+# snarkjs byte dumps of F.one / G1.one / G2.one in Montgomery LE form (zkey.rs:590-640)
+zsrc = open(f"{REF}/co-circom/circom-types/src/groth16/zkey.rs").read()
+bufs = {}
+for name in ("fq_buf", "g1_buf", "g2_buf"):
+    m = re.search(r"fn %s\(\) -> Vec<u8> \{\s*vec!\[(.*?)\]" % name, zsrc, re.S)
+    bufs[name] = [int(x) for x in re.findall(r"\d+", m.group(1))]
+out["bn254_one_bytes"] = bufs
+
+dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")
+json.dump(out, open(dst, "w"), indent=1)
+print({k: (list(v.keys()) if isinstance(v, dict) else len(v)) for k, v in out.items()})
+for k, v in zk.items():
+    print(k, v["file"], {a: len(b) for a, b in v["values"].items()})
+print(out["rep3_mul_vec_bn"].keys(), wt)

@@ -1,0 +1,336 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).  TEST INFRASTRUCTURE: imported only from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg.  All arrays are numpy uint64 in the product ABI's convention
+(little-endian Montgomery limbs; packed affine points, (0,0) = infinity)."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+
+BN254, BLS12_381 = 0, 1
+FR, FQ = 0, 1
+G1, G2 = 0, 1
+CURVE_NAMES = {BN254: "bn254", BLS12_381: "bls12_381"}
+
+
+def build(force=False):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".hpp"))]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB_PATH,
+                           os.path.join(ORACLE_DIR, "oracle_capi.cpp")])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orc_last_error.restype = C.c_char_p
+        _lib.orc_zkey_open.restype = C.c_void_p
+        _lib.orc_zkey_open.argtypes = [C.c_int, C.c_char_p]
+        _lib.orc_zkey_close.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _chk(rc):
+    if rc < 0:
+        raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+    return rc
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def nlimbs(curve, which):
+    return 6 if (curve == BLS12_381 and which == FQ) else 4
+
+
+def from_dec(curve, which, s):
+    out = np.zeros(nlimbs(curve, which), dtype=np.uint64)
+    _chk(lib().orc_from_dec(curve, which, str(s).encode(), _p(out)))
+    return out
+
+
+def to_dec(curve, which, limbs):
+    limbs = np.ascontiguousarray(limbs, dtype=np.uint64)
+    buf = C.create_string_buffer(256)
+    _chk(lib().orc_to_dec(curve, which, _p(limbs), buf, C.c_size_t(256)))
+    return buf.value.decode()
+
+
+def field_op(curve, which, op, a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.empty_like(a)
+    n = a.size // nlimbs(curve, which)
+    _chk(lib().orc_field_op(curve, which, {"add": 0, "sub": 1, "mul": 2}[op], _p(a), _p(b), _p(out), C.c_size_t(n)))
+    return out
+
+
+def field_inverse(curve, which, a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.empty_like(a)
+    _chk(lib().orc_field_inverse(curve, which, _p(a), _p(out)))
+    return out
+
+
+def roots_of_unity(curve):
+    q = np.zeros(4, dtype=np.uint64)
+    roots = np.zeros((40, 4), dtype=np.uint64)
+    ta = C.c_int(0)
+    _chk(lib().orc_roots_of_unity(curve, _p(q), _p(roots), C.byref(ta)))
+    return q, roots[: ta.value + 1].copy(), ta.value
+
+
+def groth16_domain(curve, pow_, num_constraints, num_inputs):
+    omega = np.zeros(4, dtype=np.uint64); g = np.zeros(4, dtype=np.uint64); m = C.c_size_t(0)
+    _chk(lib().orc_groth16_domain(curve, C.c_size_t(pow_), C.c_size_t(num_constraints), C.c_size_t(num_inputs), _p(omega), _p(g), C.byref(m)))
+    return omega, g, m.value
+
+
+def ntt(curve, data, omega, inverse=False):
+    out = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    omega = np.ascontiguousarray(omega, dtype=np.uint64)
+    _chk(lib().orc_ntt(curve, _p(out), C.c_size_t(out.size // 4), _p(omega), int(inverse)))
+    return out
+
+
+def dft_naive(curve, data, omega):
+    data = np.ascontiguousarray(data, dtype=np.uint64)
+    out = np.empty_like(data)
+    _chk(lib().orc_dft_naive(curve, _p(data), _p(out), C.c_size_t(data.size // 4), _p(np.ascontiguousarray(omega, dtype=np.uint64))))
+    return out
+
+
+def distribute_powers(curve, data, g, c):
+    out = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    _chk(lib().orc_distribute_powers(curve, _p(out), C.c_size_t(out.size // 4), _p(np.ascontiguousarray(g)), _p(np.ascontiguousarray(c))))
+    return out
+
+
+def point_words(curve, group):
+    return nlimbs(curve, FQ) * (2 if group == G1 else 4)
+
+
+def msm(curve, group, points, scalars, algo="pippenger", threads=1):
+    points = np.ascontiguousarray(points, dtype=np.uint64); scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    n = scalars.size // 4
+    assert points.size == n * point_words(curve, group)
+    out = np.zeros(point_words(curve, group), dtype=np.uint64)
+    _chk(lib().orc_msm(curve, group, 0 if algo == "pippenger" else 1, _p(points), _p(scalars), C.c_size_t(n), threads, _p(out)))
+    return out
+
+
+def jacobian_to_affine(curve, group, jac):
+    jac = np.ascontiguousarray(jac, dtype=np.uint64)
+    out = np.zeros(point_words(curve, group), dtype=np.uint64)
+    _chk(lib().orc_jacobian_to_affine(curve, group, _p(jac), _p(out)))
+    return out
+
+
+def on_curve(curve, group, pt):
+    return bool(_chk(lib().orc_on_curve(curve, group, _p(np.ascontiguousarray(pt, dtype=np.uint64)))))
+
+
+def generator_mul(curve, group, scalar):
+    out = np.zeros(point_words(curve, group), dtype=np.uint64)
+    _chk(lib().orc_generator_mul(curve, group, _p(np.ascontiguousarray(scalar, dtype=np.uint64)), _p(out)))
+    return out
+
+
+def points_mul(curve, group, pts, scalars):
+    pts = np.ascontiguousarray(pts, dtype=np.uint64); scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    out = np.empty_like(pts)
+    _chk(lib().orc_points_mul(curve, group, _p(pts), _p(scalars), C.c_size_t(scalars.size // 4), _p(out)))
+    return out
+
+
+def point_add(curve, group, a, b):
+    out = np.zeros(point_words(curve, group), dtype=np.uint64)
+    _chk(lib().orc_point_add(curve, group, _p(np.ascontiguousarray(a, dtype=np.uint64)), _p(np.ascontiguousarray(b, dtype=np.uint64)), _p(out)))
+    return out
+
+
+class ZKey:
+    SEL = {"ic": 0, "a_query": 1, "b_g1_query": 2, "b_g2_query": 3, "l_query": 4, "h_query": 5, "vk_g1": 6, "vk_g2": 7}
+
+    def __init__(self, curve, path):
+        self.curve = curve
+        self.h = lib().orc_zkey_open(curve, path.encode())
+        if not self.h:
+            raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+        info = (C.c_size_t * 7)()
+        _chk(lib().orc_zkey_info(C.c_void_p(self.h), info))
+        (self.n_vars, self.n_public, self.domain_size, self.pow, self.num_constraints, self.nnz_a, self.nnz_b) = [int(x) for x in info]
+        self.n_aux = self.n_vars - self.n_public - 1
+
+    def close(self):
+        if self.h:
+            lib().orc_zkey_close(C.c_void_p(self.h)); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def points(self, which):
+        nq = nlimbs(self.curve, FQ)
+        counts = {"ic": (self.n_public + 1, 2), "a_query": (self.n_vars, 2), "b_g1_query": (self.n_vars, 2), "b_g2_query": (self.n_vars, 4),
+                  "l_query": (self.n_aux, 2), "h_query": (self.domain_size, 2), "vk_g1": (3, 2), "vk_g2": (3, 4)}
+        n, w = counts[which]
+        out = np.zeros((n, w * nq), dtype=np.uint64)
+        _chk(lib().orc_zkey_points(C.c_void_p(self.h), self.SEL[which], _p(out)))
+        return out
+
+    def matrix(self, m):
+        nnz = self.nnz_a if m == 0 else self.nnz_b
+        row_ptr = np.zeros(self.num_constraints + 1, dtype=np.uint32)
+        col = np.zeros(nnz, dtype=np.uint32)
+        coeff = np.zeros((nnz, 4), dtype=np.uint64)
+        _chk(lib().orc_zkey_matrix(C.c_void_p(self.h), m, _p(row_ptr), _p(col), _p(coeff)))
+        return row_ptr, col, coeff
+
+    def witness_map_plain(self, full_witness):
+        w = np.ascontiguousarray(full_witness, dtype=np.uint64)
+        out = np.zeros((self.domain_size, 4), dtype=np.uint64)
+        _chk(lib().orc_witness_map_plain(C.c_void_p(self.h), _p(w), _p(out)))
+        return out
+
+    def prove_plain(self, full_witness, r, s, threads=1, timing=False):
+        w = np.ascontiguousarray(full_witness, dtype=np.uint64)
+        out = np.zeros(8 * nlimbs(self.curve, FQ), dtype=np.uint64)
+        secs = C.c_double(0)
+        _chk(lib().orc_prove_plain(C.c_void_p(self.h), _p(w), _p(np.ascontiguousarray(r)), _p(np.ascontiguousarray(s)), threads, _p(out), C.byref(secs)))
+        return (out, secs.value) if timing else out
+
+    def prove_rep3(self, pub, wit_a, wit_b, streams, threads=1, want_h=False):
+        """pub: (n_public+1,4); wit_a/wit_b: lists of 3 arrays (n_aux,4); streams: list of 3 arrays (L,4)."""
+        pub = np.ascontiguousarray(pub, dtype=np.uint64)
+        wa = [np.ascontiguousarray(x, dtype=np.uint64) for x in wit_a]
+        wb = [np.ascontiguousarray(x, dtype=np.uint64) for x in wit_b]
+        st = [np.ascontiguousarray(x, dtype=np.uint64) for x in streams]
+        arr = lambda xs: (C.c_void_p * 3)(*[x.ctypes.data for x in xs])
+        psz = 8 * nlimbs(self.curve, FQ)
+        out = np.zeros((3, psz), dtype=np.uint64)
+        h = np.zeros((2, self.domain_size, 4), dtype=np.uint64) if want_h else None
+        _chk(lib().orc_prove_rep3(C.c_void_p(self.h), _p(pub), arr(wa), arr(wb), arr(st), C.c_size_t(st[0].shape[0]), threads, _p(out), _p(h)))
+        return (out, h) if want_h else out
+
+
+def read_wtns(curve, path):
+    n = C.c_size_t(0)
+    _chk(lib().orc_wtns_read(curve, path.encode(), None, C.c_size_t(0), C.byref(n)))
+    out = np.zeros((n.value, 4), dtype=np.uint64)
+    _chk(lib().orc_wtns_read(curve, path.encode(), _p(out), C.c_size_t(n.value), C.byref(n)))
+    return out
+
+
+def verify(curve, vk, pub, proof):
+    """vk: dict with alpha1, beta2, gamma2, delta2, ic (packed arrays); pub: (n_pub,4); proof: packed A||B||C."""
+    pub = np.ascontiguousarray(pub, dtype=np.uint64).reshape(-1, 4)
+    ic = np.ascontiguousarray(vk["ic"], dtype=np.uint64)
+    return bool(_chk(lib().orc_verify(curve, _p(np.ascontiguousarray(vk["alpha1"])), _p(np.ascontiguousarray(vk["beta2"])),
+                                      _p(np.ascontiguousarray(vk["gamma2"])), _p(np.ascontiguousarray(vk["delta2"])),
+                                      _p(ic), C.c_size_t(pub.shape[0]), _p(pub), _p(np.ascontiguousarray(proof, dtype=np.uint64)))))
+
+
+def pairing_selfcheck(curve, scalar):
+    return bool(_chk(lib().orc_pairing_selfcheck(curve, _p(np.ascontiguousarray(scalar, dtype=np.uint64)))))
+
+
+# ---- snarkjs JSON <-> packed arrays ---------------------------------------------------------------
+def g1_from_json(curve, arr):
+    """["x","y","1"] / ["0","1","0"] (traits.rs:186-233)"""
+    if arr[2] == "0":
+        return np.zeros(2 * nlimbs(curve, FQ), dtype=np.uint64)
+    return np.concatenate([from_dec(curve, FQ, arr[0]), from_dec(curve, FQ, arr[1])])
+
+
+def g2_from_json(curve, arr):
+    if arr[2][0] == "0" and arr[2][1] == "0":
+        return np.zeros(4 * nlimbs(curve, FQ), dtype=np.uint64)
+    return np.concatenate([from_dec(curve, FQ, arr[0][0]), from_dec(curve, FQ, arr[0][1]), from_dec(curve, FQ, arr[1][0]), from_dec(curve, FQ, arr[1][1])])
+
+
+def g1_to_json(curve, pt):
+    nq = nlimbs(curve, FQ)
+    if not pt.any():
+        return ["0", "1", "0"]
+    return [to_dec(curve, FQ, pt[:nq]), to_dec(curve, FQ, pt[nq:2 * nq]), "1"]
+
+
+def g2_to_json(curve, pt):
+    nq = nlimbs(curve, FQ)
+    d = lambda i: to_dec(curve, FQ, pt[i * nq:(i + 1) * nq])
+    return [[d(0), d(1)], [d(2), d(3)], ["1", "0"]]
+
+
+def proof_from_json(curve, path_or_obj):
+    o = json.load(open(path_or_obj)) if isinstance(path_or_obj, str) else path_or_obj
+    return np.concatenate([g1_from_json(curve, o["pi_a"]), g2_from_json(curve, o["pi_b"]), g1_from_json(curve, o["pi_c"])])
+
+
+def proof_to_json(curve, proof):
+    nq = nlimbs(curve, FQ)
+    return {"pi_a": g1_to_json(curve, proof[:2 * nq]), "pi_b": g2_to_json(curve, proof[2 * nq:6 * nq]), "pi_c": g1_to_json(curve, proof[6 * nq:8 * nq]),
+            "protocol": "groth16", "curve": "bn128" if curve == BN254 else "bls12381"}
+
+
+def vk_from_json(curve, path):
+    o = json.load(open(path))
+    return {"alpha1": g1_from_json(curve, o["vk_alpha_1"]), "beta2": g2_from_json(curve, o["vk_beta_2"]), "gamma2": g2_from_json(curve, o["vk_gamma_2"]),
+            "delta2": g2_from_json(curve, o["vk_delta_2"]), "ic": np.stack([g1_from_json(curve, p) for p in o["IC"]]), "n_public": o["nPublic"]}
+
+
+def public_from_json(curve, path):
+    o = json.load(open(path))
+    return np.stack([from_dec(curve, FR, s) for s in o]) if o else np.zeros((0, 4), dtype=np.uint64)
+
+
+# ---- seeded randomness helpers (numpy) --------------------------------------------------------------
+MODULI = {
+    (BN254, FR): 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+    (BN254, FQ): 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+    (BLS12_381, FR): 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+    (BLS12_381, FQ): 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab,
+}
+
+
+def int_to_limbs(x, n):
+    return np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)], dtype=np.uint64)
+
+
+def limbs_to_int(l):
+    return sum(int(v) << (64 * i) for i, v in enumerate(l))
+
+
+def random_field(curve, which, n, rng):
+    """n uniformly random reduced residues, used directly as Montgomery representatives (uniform either way)."""
+    N = nlimbs(curve, which)
+    p = MODULI[(curve, which)]
+    pl = int_to_limbs(p, N)
+    top_bits = p.bit_length() - 64 * (N - 1)
+    out = np.zeros((n, N), dtype=np.uint64)
+    todo = np.arange(n)
+    while todo.size:
+        x = rng.integers(0, 2**64, size=(todo.size, N), dtype=np.uint64)
+        x[:, N - 1] &= np.uint64((1 << top_bits) - 1)
+        ge = np.zeros(todo.size, dtype=bool); eq = np.ones(todo.size, dtype=bool)
+        for l in range(N - 1, -1, -1):
+            ge |= eq & (x[:, l] > pl[l]); eq &= x[:, l] == pl[l]
+        ge |= eq
+        out[todo[~ge]] = x[~ge]
+        todo = todo[ge]
+    return out
