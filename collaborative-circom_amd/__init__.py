@@ -1,0 +1,328 @@
+"""cogroth16-hip: MI355X (gfx950) backend for the co-groth16 prover hot path of TaceoLabs/collaborative-circom.
+
+The product is the C-ABI shared library `libcogroth16_hip.so` (include/cogroth16_hip.h) built from csrc/ with hipcc.
+This module is only a thin ctypes loader over it (directory name contains a hyphen: import it with
+`importlib.import_module("collaborative-circom_amd")`).  There is NO CPU fallback: `load()` raises if the library is
+missing, and `Context()` raises if no HIP device is present.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libcogroth16_hip.so")
+HOST_LIB_PATH = os.path.join(HERE, "libcogroth16_host.so")
+
+BN254, BLS12_381 = 0, 1
+G1, G2 = 0, 1
+
+_lib = None
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def build(bls=True, jobs=8):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "csrc"), f"-j{jobs}", f"BLS={1 if bls else 0}"])
+    if os.path.isdir(os.path.join(HERE, "host")) and os.path.exists(os.path.join(HERE, "host", "Makefile")):
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "host"), f"-j{jobs}"])
+    return LIB_PATH
+
+
+# every symbol include/cogroth16_hip.h declares (checked by tests/test_abi_surface.py)
+ABI_SYMBOLS = [
+    "cg_ctx_create", "cg_ctx_destroy", "cg_ctx_sync", "cg_ctx_stream", "cg_last_error", "cg_version",
+    "cg_dev_alloc", "cg_dev_free", "cg_dev_upload", "cg_dev_download", "cg_dev_memset_zero",
+    "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len",
+    "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_end", "cg_msm_set_window",
+    "cg_ntt", "cg_ntt_dev",
+    "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev",
+    "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
+    "cg_point_add", "cg_point_neg", "cg_point_scalar_mul", "cg_point_to_affine", "cg_point_from_affine", "cg_fr_op",
+    "cg_stats_enable", "cg_stats",
+]
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendError(f"{LIB_PATH} is missing: build it with `make -C collaborative-circom_amd/csrc` "
+                           "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.cg_last_error.restype = C.c_char_p
+    lib.cg_version.restype = C.c_char_p
+    lib.cg_ctx_stream.restype = C.c_void_p
+    lib.cg_ctx_stream.argtypes = [C.c_void_p]
+    lib.cg_bases_len.restype = C.c_size_t
+    lib.cg_bases_len.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise BackendError(f"cogroth16_hip error {rc}: {load().cg_last_error().decode()}")
+
+
+def _hp(a):
+    """host pointer of a numpy array (or None)"""
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dp(x):
+    """device pointer: DevBuf, int, torch tensor (data_ptr) or None"""
+    if x is None:
+        return None
+    if isinstance(x, DevBuf):
+        return C.c_void_p(x.ptr)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    raise TypeError(f"not a device pointer: {type(x)}")
+
+
+def fq_limbs(curve):
+    return 6 if curve == BLS12_381 else 4
+
+
+def point_words(curve, group, coords):
+    return fq_limbs(curve) * (1 if group == G1 else 2) * coords
+
+
+class DevBuf:
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = C.c_void_p()
+        _chk(load().cg_dev_alloc(ctx.h, C.c_size_t(nbytes), C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _chk(load().cg_dev_upload(self.ctx.h, C.c_void_p(self.ptr), _hp(arr), C.c_size_t(arr.nbytes)))
+        return self
+
+    def download(self, shape, dtype=np.uint64):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _chk(load().cg_dev_download(self.ctx.h, _hp(out), C.c_void_p(self.ptr), C.c_size_t(out.nbytes)))
+        return out
+
+    def zero(self):
+        _chk(load().cg_dev_memset_zero(self.ctx.h, C.c_void_p(self.ptr), C.c_size_t(self.nbytes)))
+        return self
+
+    def free(self):
+        if self.ptr:
+            _chk(load().cg_dev_free(self.ctx.h, C.c_void_p(self.ptr)))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Bases:
+    def __init__(self, ctx, curve, group, handle, n):
+        self.ctx, self.curve, self.group, self.h, self.n = ctx, curve, group, handle, n
+
+    def release(self):
+        if self.h:
+            load().cg_bases_release(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class Context:
+    """One per MPC party thread (mirrors `&mut self` of the reference drivers)."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _chk(load().cg_ctx_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            load().cg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _chk(load().cg_ctx_sync(self.h))
+
+    @property
+    def stream(self):
+        return load().cg_ctx_stream(self.h)
+
+    # ---- memory
+    def alloc(self, nbytes):
+        return DevBuf(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DevBuf(self, max(arr.nbytes, 16)).upload(arr)
+
+    # ---- MSM
+    def register_bases(self, curve, group, points, stride=None, infinity_offset=-1):
+        pts = np.ascontiguousarray(points)
+        rec = point_words(curve, group, 2) * 8
+        stride = stride or rec
+        n = pts.nbytes // stride
+        h = C.c_void_p()
+        _chk(load().cg_bases_register(self.h, curve, group, _hp(pts), C.c_size_t(n), C.c_size_t(stride), C.c_int64(infinity_offset), C.byref(h)))
+        return Bases(self, curve, group, h, n)
+
+    def register_bases_device(self, curve, group, d_points, n):
+        h = C.c_void_p()
+        _chk(load().cg_bases_register_device(self.h, curve, group, _dp(d_points), C.c_size_t(n), C.byref(h)))
+        return Bases(self, curve, group, h, n)
+
+    def msm(self, bases, scalars, offset=0, n=None):
+        """host scalars: list of k arrays (n,4) uint64 -> (k, 3*coord_words) Jacobian"""
+        sc = [np.ascontiguousarray(s, dtype=np.uint64) for s in scalars]
+        n = sc[0].size // 4 if n is None else n
+        k = len(sc)
+        out = np.zeros((k, point_words(bases.curve, bases.group, 3)), dtype=np.uint64)
+        ptrs = (C.c_void_p * k)(*[s.ctypes.data for s in sc])
+        _chk(load().cg_msm(self.h, bases.h, C.c_size_t(offset), C.c_size_t(n), ptrs, k, _hp(out)))
+        return out
+
+    def msm_dev(self, bases, d_scalars, n, offset=0):
+        k = len(d_scalars)
+        out = np.zeros((k, point_words(bases.curve, bases.group, 3)), dtype=np.uint64)
+        ptrs = (C.c_void_p * k)(*[_dp(s).value for s in d_scalars])
+        _chk(load().cg_msm_dev(self.h, bases.h, C.c_size_t(offset), C.c_size_t(n), ptrs, k, _hp(out)))
+        return out
+
+    def msm_dev_begin(self, bases, d_scalars, n, offset=0):
+        k = len(d_scalars)
+        ptrs = (C.c_void_p * k)(*[_dp(s).value for s in d_scalars])
+        t = C.c_int32(-1)
+        _chk(load().cg_msm_dev_begin(self.h, bases.h, C.c_size_t(offset), C.c_size_t(n), ptrs, k, C.byref(t)))
+        return (t.value, k, bases.curve, bases.group)
+
+    def msm_end(self, ticket):
+        t, k, curve, group = ticket
+        out = np.zeros((k, point_words(curve, group, 3)), dtype=np.uint64)
+        _chk(load().cg_msm_end(self.h, t, _hp(out)))
+        return out
+
+    def set_msm_window(self, c):
+        _chk(load().cg_msm_set_window(self.h, int(c)))
+
+    # ---- NTT
+    def ntt(self, curve, vecs, group_gen, inverse=False, coset_gen=None):
+        """host vectors (list of (n,4) arrays), transformed copies are returned"""
+        out = [np.ascontiguousarray(v, dtype=np.uint64).copy() for v in vecs]
+        k = len(out)
+        n = out[0].size // 4
+        ptrs = (C.c_void_p * k)(*[v.ctypes.data for v in out])
+        gg = np.ascontiguousarray(group_gen, dtype=np.uint64)
+        cg = None if coset_gen is None else np.ascontiguousarray(coset_gen, dtype=np.uint64)
+        _chk(load().cg_ntt(self.h, curve, ptrs, k, C.c_size_t(n), _hp(gg), int(inverse), _hp(cg)))
+        return out
+
+    def ntt_dev(self, curve, d_vecs, n, group_gen, inverse=False, coset_gen=None):
+        k = len(d_vecs)
+        ptrs = (C.c_void_p * k)(*[_dp(v).value for v in d_vecs])
+        gg = np.ascontiguousarray(group_gen, dtype=np.uint64)
+        cg = None if coset_gen is None else np.ascontiguousarray(coset_gen, dtype=np.uint64)
+        _chk(load().cg_ntt_dev(self.h, curve, ptrs, k, C.c_size_t(n), _hp(gg), int(inverse), _hp(cg)))
+
+    # ---- vector ops (device operands)
+    def vec_add(self, curve, out, a, b, n): _chk(load().cg_vec_add_dev(self.h, curve, _dp(out), _dp(a), _dp(b), C.c_size_t(n)))
+    def vec_sub(self, curve, out, a, b, n): _chk(load().cg_vec_sub_dev(self.h, curve, _dp(out), _dp(a), _dp(b), C.c_size_t(n)))
+    def vec_mul(self, curve, out, a, b, n): _chk(load().cg_vec_mul_dev(self.h, curve, _dp(out), _dp(a), _dp(b), C.c_size_t(n)))
+
+    def vec_rep3_mul_local(self, curve, out, aa, ab, ba, bb, mask, n):
+        _chk(load().cg_vec_rep3_mul_local_dev(self.h, curve, _dp(out), _dp(aa), _dp(ab), _dp(ba), _dp(bb), _dp(mask), C.c_size_t(n)))
+
+    def vec_distribute_powers(self, curve, v, n, g, c):
+        _chk(load().cg_vec_distribute_powers_dev(self.h, curve, _dp(v), C.c_size_t(n), _hp(np.ascontiguousarray(g, dtype=np.uint64)), _hp(np.ascontiguousarray(c, dtype=np.uint64))))
+
+    def spmv_csr(self, curve, row_ptr, col, coeff, n_rows, pub, n_inputs, party, wit_a, wit_b, out_a, out_b):
+        _chk(load().cg_spmv_csr_dev(self.h, curve, _dp(row_ptr), _dp(col), _dp(coeff), C.c_size_t(n_rows), _dp(pub), C.c_uint32(n_inputs), int(party),
+                                    _dp(wit_a), _dp(wit_b), _dp(out_a), _dp(out_b)))
+
+    # ---- host-buffer forms
+    def vec_mul_host(self, curve, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.empty_like(a)
+        _chk(load().cg_vec_mul(self.h, curve, _hp(out), _hp(a), _hp(b), C.c_size_t(a.size // 4)))
+        return out
+
+    def vec_rep3_mul_local_host(self, curve, aa, ab, ba, bb, mask=None):
+        arrs = [np.ascontiguousarray(x, dtype=np.uint64) for x in (aa, ab, ba, bb)]
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint64)
+        out = np.empty_like(arrs[0])
+        _chk(load().cg_vec_rep3_mul_local(self.h, curve, _hp(out), *[_hp(x) for x in arrs], _hp(m), C.c_size_t(arrs[0].size // 4)))
+        return out
+
+    # ---- stats
+    def stats_enable(self, on=True): _chk(load().cg_stats_enable(self.h, int(on)))
+
+    def stats(self, reset=False):
+        class ST(C.Structure):
+            _fields_ = [("msm_ms", C.c_double), ("ntt_ms", C.c_double), ("vec_ms", C.c_double), ("spmv_ms", C.c_double),
+                        ("msm_calls", C.c_uint64), ("ntt_calls", C.c_uint64), ("vec_calls", C.c_uint64), ("spmv_calls", C.c_uint64)]
+        st = ST()
+        _chk(load().cg_stats(self.h, C.byref(st), int(reset)))
+        return {f: getattr(st, f) for f, _ in ST._fields_}
+
+
+# ---- O(1) host helpers (no device needed) --------------------------------------------------------------
+def point_add(curve, group, a, b):
+    out = np.zeros(point_words(curve, group, 3), dtype=np.uint64)
+    _chk(load().cg_point_add(curve, group, _hp(np.ascontiguousarray(a)), _hp(np.ascontiguousarray(b)), _hp(out)))
+    return out
+
+
+def point_neg(curve, group, a):
+    out = np.zeros(point_words(curve, group, 3), dtype=np.uint64)
+    _chk(load().cg_point_neg(curve, group, _hp(np.ascontiguousarray(a)), _hp(out)))
+    return out
+
+
+def point_scalar_mul(curve, group, a, k):
+    out = np.zeros(point_words(curve, group, 3), dtype=np.uint64)
+    _chk(load().cg_point_scalar_mul(curve, group, _hp(np.ascontiguousarray(a)), _hp(np.ascontiguousarray(k)), _hp(out)))
+    return out
+
+
+def point_to_affine(curve, group, a):
+    out = np.zeros(point_words(curve, group, 2), dtype=np.uint64)
+    _chk(load().cg_point_to_affine(curve, group, _hp(np.ascontiguousarray(a)), _hp(out)))
+    return out
+
+
+def point_from_affine(curve, group, a):
+    out = np.zeros(point_words(curve, group, 3), dtype=np.uint64)
+    _chk(load().cg_point_from_affine(curve, group, _hp(np.ascontiguousarray(a)), _hp(out)))
+    return out
+
+
+def fr_op(curve, op, a, b=None):
+    out = np.zeros(4, dtype=np.uint64)
+    _chk(load().cg_fr_op(curve, {"add": 0, "sub": 1, "mul": 2, "inv": 3}[op], _hp(np.ascontiguousarray(a)), _hp(None if b is None else np.ascontiguousarray(b)), _hp(out)))
+    return out

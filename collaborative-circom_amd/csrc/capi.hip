@@ -1,0 +1,608 @@
+// C ABI of the gfx950 co-groth16 backend (declared in include/cogroth16_hip.h).  Host-side launch logic only:
+// every O(n) computation happens in the kernels of vec_kernels.hpp / ntt_kernels.hpp / msm_kernels.hpp.
+// There is deliberately no CPU fallback here: without a HIP device cg_ctx_create fails.
+#include "common.hpp"
+#include "curve.hpp"
+#include "ntt_kernels.hpp"   // NttVecs, plan constants (no kernels are instantiated in this translation unit)
+
+#include <map>
+#include <vector>
+
+using namespace cg;
+
+// launchers living in msm_inst_*.hip / fr_inst_*.hip (explicit instantiations)
+namespace cg {
+template <class F, class Fr> int msm_enqueue(hipStream_t st, const Affine<F>* d_bases, size_t n, const Fr* d_scalars, int c, int nwin, char* arena_base, XYZZ<F>* h_out);
+template <class F> size_t msm_scratch_bytes(size_t n, int c, int nwin);
+template <class F> int pack_bases_launch(hipStream_t st, const uint8_t* d_raw, size_t n, size_t stride, long inf_off, Affine<F>* d_dst);
+template <class Fr> int launch_vec_binary(hipStream_t st, int op, Fr* out, const Fr* a, const Fr* b, size_t n);
+template <class Fr> int launch_rep3_mul_local(hipStream_t st, Fr* out, const Fr* aa, const Fr* ab, const Fr* ba, const Fr* bb, const Fr* mask, size_t n);
+template <class Fr> int launch_distribute_powers(hipStream_t st, Fr* v, size_t n, const Fr* lo, const Fr* hi, int log_lo);
+template <class Fr> int launch_spmv_csr(hipStream_t st, const uint32_t* row_ptr, const uint32_t* col, const Fr* coeff, size_t n_rows, const Fr* pub,
+                                        uint32_t n_inputs, int party, const Fr* wit_a, const Fr* wit_b, Fr* out_a, Fr* out_b);
+template <class Fr> int launch_build_twiddles(hipStream_t st, Fr* tw, size_t m, int log_m, const Fr* lo, const Fr* hi, int log_lo);
+template <class Fr> int launch_ntt_dif_pass(hipStream_t st, NttVecs data, int nvec, size_t n, int log_m, int s0, int k, int t, const Fr* tw);
+template <class Fr> int launch_bitrev_scale(hipStream_t st, NttVecs dst, NttVecs src, int nvec, size_t n, int log_m, const Fr* scale, const Fr* c_lo, const Fr* c_hi, int log_lo);
+}  // namespace cg
+
+namespace {
+
+struct Arena {
+    char* base = nullptr; size_t cap = 0, used = 0;
+    void* take(size_t bytes) { void* p = base + used; used += align_up(bytes); return p; }
+};
+
+struct TwKey { int curve; int log_m; uint32_t gen[8]; bool operator<(const TwKey& o) const { if (curve != o.curve) return curve < o.curve; if (log_m != o.log_m) return log_m < o.log_m; return memcmp(gen, o.gen, sizeof gen) < 0; } };
+struct CosetKey { TwKey k; uint32_t scale[8]; bool operator<(const CosetKey& o) const { if (k < o.k) return true; if (o.k < k) return false; return memcmp(scale, o.scale, sizeof scale) < 0; } };
+struct CosetTables { void* lo; void* hi; int log_lo; };
+
+struct MsmTicket {
+    bool live = false;
+    int curve = 0, group = 0, k = 0, c = 0, nwin = 0;
+    void* h_pinned = nullptr; size_t pinned_bytes = 0;   // k * nwin window sums (XYZZ)
+    hipEvent_t done = nullptr;
+};
+
+}  // namespace
+
+struct cg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Arena arena;
+    std::map<TwKey, void*> twiddles;
+    std::map<CosetKey, CosetTables> cosets;
+    std::vector<MsmTicket> tickets;
+    int msm_window = 0;
+    bool stats_on = false;
+    cg_stage_times stats{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct cg_bases {
+    int device, curve, group;
+    size_t n, pt_bytes;
+    void* d_pts;
+};
+
+namespace {
+
+int ensure_arena(cg_ctx* ctx, size_t bytes) {
+    ctx->arena.used = 0;
+    if (bytes <= ctx->arena.cap) return 0;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->arena.base) HIPCHK(hipFree(ctx->arena.base));
+    ctx->arena.base = nullptr; ctx->arena.cap = 0;
+    size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    HIPCHK(hipMalloc((void**)&ctx->arena.base, want));
+    ctx->arena.cap = want;
+    return 0;
+}
+
+struct StatScope {
+    cg_ctx* ctx; double* ms; uint64_t* calls;
+    StatScope(cg_ctx* c, double* m, uint64_t* n) : ctx(c), ms(m), calls(n) { if (ctx->stats_on) hipEventRecord(ctx->ev0, ctx->stream); }
+    ~StatScope() {
+        if (!ctx->stats_on) return;
+        hipEventRecord(ctx->ev1, ctx->stream); hipEventSynchronize(ctx->ev1);
+        float t = 0; hipEventElapsedTime(&t, ctx->ev0, ctx->ev1); *ms += t; (*calls)++;
+    }
+};
+
+template <class Fn> int with_fr(int curve, Fn&& fn) {
+    if (curve == CG_BN254) return fn(Bn254Fr{});
+#if CG_WITH_BLS
+    if (curve == CG_BLS12_381) return fn(Bls381Fr{});
+#else
+    if (curve == CG_BLS12_381) return fail(CG_ERR_ARG, "library built without BLS12-381 (make BLS=1)");
+#endif
+    return fail(CG_ERR_ARG, "unknown curve id");
+}
+template <class Fn> int with_group(int curve, int group, Fn&& fn) {
+    if (curve == CG_BN254 && group == CG_G1) return fn(Bn254Fq{}, Bn254Fr{});
+    if (curve == CG_BN254 && group == CG_G2) return fn(Fp2<Bn254Fq>{}, Bn254Fr{});
+#if CG_WITH_BLS
+    if (curve == CG_BLS12_381 && group == CG_G1) return fn(Bls381Fq{}, Bls381Fr{});
+    if (curve == CG_BLS12_381 && group == CG_G2) return fn(Fp2<Bls381Fq>{}, Bls381Fr{});
+#else
+    if (curve == CG_BLS12_381) return fail(CG_ERR_ARG, "library built without BLS12-381 (make BLS=1)");
+#endif
+    return fail(CG_ERR_ARG, "unknown curve/group id");
+}
+
+// ------------------------------------------------------------------------------------------------ MSM
+int auto_window(size_t n) {
+    int lg = log2_floor(n);
+    return std::max(3, std::min(16, lg - 5));
+}
+
+template <class F>
+Jacobian<F> msm_fold_windows(const XYZZ<F>* w, int nwin, int c) {
+    XYZZ<F> acc = w[nwin - 1];
+    for (int i = nwin - 2; i >= 0; i--) {
+        for (int d = 0; d < c; d++) acc = xyzz_dbl(acc);
+        acc = xyzz_add(acc, w[i]);
+    }
+    return xyzz_to_jacobian(acc);
+}
+
+int ticket_slot(cg_ctx* ctx) {
+    for (size_t i = 0; i < ctx->tickets.size(); i++) if (!ctx->tickets[i].live) return (int)i;
+    ctx->tickets.emplace_back();
+    return (int)ctx->tickets.size() - 1;
+}
+
+int msm_begin_impl(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* d_scalars, int k, int* ticket_out, size_t extra_arena_off) {
+    if (!ctx || !bases || !ticket_out) return fail(CG_ERR_ARG, "null argument");
+    if (k < 1 || k > 8) return fail(CG_ERR_ARG, "k out of range");
+    if (offset + n > bases->n) return fail(CG_ERR_ARG, "bases slice out of range");
+    if (bases->device != ctx->device) return fail(CG_ERR_ARG, "bases live on another device");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_group(bases->curve, bases->group, [&](auto ftag, auto frtag) -> int {
+        typedef decltype(ftag) F; typedef decltype(frtag) Fr;
+        const int slot = ticket_slot(ctx);
+        MsmTicket& t = ctx->tickets[slot];
+        t.curve = bases->curve; t.group = bases->group; t.k = k;
+        t.c = n ? (ctx->msm_window ? ctx->msm_window : auto_window(n)) : 2;
+        t.nwin = Fr::Params::BITS / t.c + 1;
+        const size_t need = (size_t)k * t.nwin * sizeof(XYZZ<F>);
+        if (t.pinned_bytes < need) {
+            if (t.h_pinned) HIPCHK(hipHostFree(t.h_pinned));
+            t.h_pinned = nullptr; t.pinned_bytes = 0;
+            HIPCHK(hipHostMalloc(&t.h_pinned, need, hipHostMallocDefault));
+            t.pinned_bytes = need;
+        }
+        if (!t.done) HIPCHK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+        XYZZ<F>* h = (XYZZ<F>*)t.h_pinned;
+        if (n == 0) { for (int i = 0; i < k * t.nwin; i++) h[i] = XYZZ<F>::infinity(); }
+        else {
+            StatScope ss(ctx, &ctx->stats.msm_ms, &ctx->stats.msm_calls);
+            const size_t per = msm_scratch_bytes<F>(n, t.c, t.nwin);
+            if (extra_arena_off == 0) { int rc = ensure_arena(ctx, per); if (rc) return rc; }
+            else if (extra_arena_off + per > ctx->arena.cap) return fail(CG_ERR_ARG, "internal: arena too small");
+            const Affine<F>* pts = (const Affine<F>*)bases->d_pts + offset;
+            for (int j = 0; j < k; j++) {
+                int rc = msm_enqueue<F, Fr>(ctx->stream, pts, n, (const Fr*)d_scalars[j], t.c, t.nwin, ctx->arena.base + extra_arena_off, h + (size_t)j * t.nwin);
+                if (rc) return rc;
+            }
+        }
+        HIPCHK(hipEventRecord(t.done, ctx->stream));
+        t.live = true;
+        *ticket_out = slot;
+        return 0;
+    });
+}
+
+int msm_end_impl(cg_ctx* ctx, int ticket, void* h_out) {
+    if (!ctx || !h_out) return fail(CG_ERR_ARG, "null argument");
+    if (ticket < 0 || ticket >= (int)ctx->tickets.size() || !ctx->tickets[ticket].live) return fail(CG_ERR_ARG, "bad MSM ticket");
+    MsmTicket& t = ctx->tickets[ticket];
+    HIPCHK(hipEventSynchronize(t.done));
+    t.live = false;
+    return with_group(t.curve, t.group, [&](auto ftag, auto) -> int {
+        typedef decltype(ftag) F;
+        const XYZZ<F>* h = (const XYZZ<F>*)t.h_pinned;
+        Jacobian<F>* out = (Jacobian<F>*)h_out;
+        for (int j = 0; j < t.k; j++) { Jacobian<F> r = msm_fold_windows<F>(h + (size_t)j * t.nwin, t.nwin, t.c); memcpy(out + j, &r, sizeof r); }
+        return 0;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ NTT
+// lo[j] = first * w^j (j < 2^log_lo), hi[j] = w^(j << log_lo) (j < hi_n): w^e * first = lo[e & mask] * hi[e >> log_lo]
+template <class Fr>
+void host_pow_tables(const Fr& w, const Fr& first, int log_lo, size_t hi_n, std::vector<Fr>& lo, std::vector<Fr>& hi) {
+    lo.resize((size_t)1 << log_lo); hi.resize(hi_n);
+    Fr acc = first, step = Fr::one();
+    for (size_t j = 0; j < lo.size(); j++) { lo[j] = acc; acc = acc * w; step = step * w; }
+    Fr h = Fr::one();
+    for (size_t j = 0; j < hi_n; j++) { hi[j] = h; h = h * step; }
+}
+
+template <class Fr>
+int get_twiddles(cg_ctx* ctx, int curve, int log_m, const Fr& w, const Fr** out) {
+    TwKey key; key.curve = curve; key.log_m = log_m; memcpy(key.gen, w.v, sizeof key.gen);
+    auto it = ctx->twiddles.find(key);
+    if (it != ctx->twiddles.end()) { *out = (const Fr*)it->second; return 0; }
+    const size_t m = (size_t)1 << log_m;
+    const int log_lo = std::min(11, std::max(0, log_m - 1));
+    const size_t hi_n = std::max<size_t>(1, (m / 2) >> log_lo);
+    std::vector<Fr> lo, hi;
+    host_pow_tables(w, Fr::one(), log_lo, hi_n, lo, hi);
+    Fr *d_lo = nullptr, *d_hi = nullptr, *d_tw = nullptr;
+    HIPCHK(hipMalloc((void**)&d_lo, lo.size() * sizeof(Fr)));
+    HIPCHK(hipMalloc((void**)&d_hi, hi.size() * sizeof(Fr)));
+    HIPCHK(hipMalloc((void**)&d_tw, std::max<size_t>(m - 1, 1) * sizeof(Fr)));
+    HIPCHK(hipMemcpyAsync(d_lo, lo.data(), lo.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_hi, hi.data(), hi.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    { int rc = launch_build_twiddles<Fr>(ctx->stream, d_tw, m, log_m, d_lo, d_hi, log_lo); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // lo/hi host vectors and temporaries die here
+    HIPCHK(hipFree(d_lo)); HIPCHK(hipFree(d_hi));
+    ctx->twiddles[key] = d_tw;
+    *out = d_tw;
+    return 0;
+}
+
+// tables with lo[j] = scale * g^j, hi[j] = g^(j << log_lo), covering exponents < 2^log_m
+template <class Fr>
+int get_coset_tables(cg_ctx* ctx, int curve, int log_m, const Fr& g, const Fr& scale, CosetTables* out) {
+    CosetKey key; key.k.curve = curve; key.k.log_m = log_m; memcpy(key.k.gen, g.v, sizeof key.k.gen); memcpy(key.scale, scale.v, sizeof key.scale);
+    auto it = ctx->cosets.find(key);
+    if (it != ctx->cosets.end()) { *out = it->second; return 0; }
+    const size_t m = (size_t)1 << log_m;
+    const int log_lo = std::min(11, log_m);
+    const size_t hi_n = std::max<size_t>(1, m >> log_lo);
+    std::vector<Fr> lo, hi;
+    host_pow_tables(g, scale, log_lo, hi_n, lo, hi);
+    CosetTables t; t.log_lo = log_lo;
+    HIPCHK(hipMalloc(&t.lo, lo.size() * sizeof(Fr)));
+    HIPCHK(hipMalloc(&t.hi, hi.size() * sizeof(Fr)));
+    HIPCHK(hipMemcpy(t.lo, lo.data(), lo.size() * sizeof(Fr), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(t.hi, hi.data(), hi.size() * sizeof(Fr), hipMemcpyHostToDevice));
+    ctx->cosets[key] = t;
+    *out = t;
+    return 0;
+}
+
+struct NttPass { int s0, k, t; };
+std::vector<NttPass> ntt_plan(int log_m) {
+    std::vector<NttPass> plan;
+    const int k_last = std::min(log_m, NTT_TILE_LOG);
+    const int rest = log_m - k_last;
+    int s0 = 0;
+    if (rest > 0) {
+        const int np = (rest + 6) / 7;
+        for (int i = 0; i < np; i++) {
+            int k = rest / np + (i < rest % np ? 1 : 0);
+            plan.push_back({s0, k, NTT_TILE_LOG - k});   // lo_bits >= 11 here, so t = 11 - k fits
+            s0 += k;
+        }
+    }
+    plan.push_back({s0, k_last, 0});
+    return plan;
+}
+
+template <class Fr>
+int ntt_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_t n, const Fr& gen, bool inverse, const Fr* coset, size_t arena_off) {
+    const int log_m = log2_floor(n);
+    if (((size_t)1 << log_m) != n) return fail(CG_ERR_ARG, "NTT length must be a power of two");
+    if (k < 1 || k > NTT_MAX_VECS) return fail(CG_ERR_ARG, "k out of range");
+    if (n == 1) return 0;
+    const Fr w = inverse ? fp_inverse(gen) : gen;
+    const Fr* tw = nullptr;
+    int rc = get_twiddles<Fr>(ctx, curve, log_m, w, &tw);
+    if (rc) return rc;
+    NttVecs data{}, tmp{};
+    for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->arena.base + arena_off + (size_t)j * n * sizeof(Fr); }
+    hipStream_t st = ctx->stream;
+    for (const NttPass& p : ntt_plan(log_m)) { rc = launch_ntt_dif_pass<Fr>(st, data, k, n, log_m, p.s0, p.k, p.t, tw); if (rc) return rc; }
+    const Fr* d_scale = nullptr; const Fr* c_lo = nullptr; const Fr* c_hi = nullptr; int log_lo = 0;
+    if (inverse) {
+        Fr ninv = Fr::one();   // n^-1: halve log_m times  (x/2 = (x + (x odd ? p : 0)) >> 1 in Montgomery form as well)
+        {
+            uint32_t e[Fr::N] = {0}; e[log_m / 32] = 1u << (log_m % 32);
+            Fr nn; for (int i = 0; i < Fr::N; i++) nn.v[i] = e[i];
+            ninv = fp_inverse(nn.to_mont());
+        }
+        CosetTables t;
+        if (coset) { rc = get_coset_tables<Fr>(ctx, curve, log_m, *coset, ninv, &t); if (rc) return rc; c_lo = (const Fr*)t.lo; c_hi = (const Fr*)t.hi; log_lo = t.log_lo; }
+        else { rc = get_coset_tables<Fr>(ctx, curve, 0, Fr::one(), ninv, &t); if (rc) return rc; d_scale = (const Fr*)t.lo; }
+    } else if (coset) return fail(CG_ERR_ARG, "coset_gen is only supported with inverse != 0");
+    // permutation is out of place: data -> tmp -> (copy back).  TODO(perf): DIT second half removes this copy.
+    rc = launch_bitrev_scale<Fr>(st, tmp, data, k, n, log_m, d_scale, c_lo, c_hi, log_lo);
+    if (rc) return rc;
+    for (int j = 0; j < k; j++) HIPCHK(hipMemcpyAsync(data.p[j], tmp.p[j], n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+template <class F> void copy_in(F& dst, const void* src) { memcpy(dst.v, src, sizeof dst.v); }
+
+}  // namespace
+
+template <int OP>
+int32_t vec_binary(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_a, const void* d_b, size_t n) {
+    if (!ctx || !d_out || !d_a || !d_b) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        StatScope ss(ctx, &ctx->stats.vec_ms, &ctx->stats.vec_calls);
+        return launch_vec_binary<Fr>(ctx->stream, OP, (Fr*)d_out, (const Fr*)d_a, (const Fr*)d_b, n);
+    });
+}
+
+// ==================================================================================================== extern "C"
+extern "C" {
+
+const char* cg_last_error(void) { return g_err.c_str(); }
+const char* cg_version(void) { return "cogroth16-hip 0.1 (gfx950)"; }
+
+int32_t cg_ctx_create(int32_t device, cg_ctx** out) {
+    if (!out) return fail(CG_ERR_ARG, "null out");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(CG_ERR_NODEVICE, "no HIP device visible: this backend has no CPU fallback");
+    if (device < 0 || device >= count) return fail(CG_ERR_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    cg_ctx* c = new cg_ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
+    *out = c;
+    return 0;
+}
+int32_t cg_ctx_destroy(cg_ctx* ctx) {
+    if (!ctx) return 0;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->twiddles) hipFree(kv.second);
+    for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
+    for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.done) hipEventDestroy(t.done); }
+    if (ctx->arena.base) hipFree(ctx->arena.base);
+    hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+int32_t cg_ctx_sync(cg_ctx* ctx) { if (!ctx) return fail(CG_ERR_ARG, "null ctx"); HIPCHK(hipStreamSynchronize(ctx->stream)); return 0; }
+void* cg_ctx_stream(cg_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr) {
+    if (!ctx || !d_ptr) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMalloc(d_ptr, std::max<size_t>(bytes, 16)));
+    return 0;
+}
+int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr) {
+    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (d_ptr) HIPCHK(hipFree(d_ptr));
+    return 0;
+}
+int32_t cg_dev_upload(cg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int32_t cg_dev_download(cg_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int32_t cg_dev_memset_zero(cg_ctx* ctx, void* d_dst, size_t bytes) {
+    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
+    HIPCHK(hipMemsetAsync(d_dst, 0, bytes, ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- bases / MSM
+static int32_t bases_register_impl(cg_ctx* ctx, int32_t curve, int32_t group, const void* src, bool src_on_device, size_t n, size_t stride, int64_t inf_off, cg_bases** out) {
+    if (!ctx || !out || (!src && n)) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_group(curve, group, [&](auto ftag, auto) -> int {
+        typedef decltype(ftag) F;
+        const size_t pt = sizeof(Affine<F>);
+        if (stride < pt) return fail(CG_ERR_ARG, "stride smaller than a point record");
+        if (inf_off >= 0 && (size_t)inf_off >= stride) return fail(CG_ERR_ARG, "infinity_offset outside the record");
+        cg_bases* b = new cg_bases{ctx->device, curve, group, n, pt, nullptr};
+        HIPCHK(hipMalloc(&b->d_pts, std::max<size_t>(n * pt, 16)));
+        if (n) {
+            if (src_on_device) HIPCHK(hipMemcpyAsync(b->d_pts, src, n * pt, hipMemcpyDeviceToDevice, ctx->stream));
+            else if (stride == pt && inf_off < 0) HIPCHK(hipMemcpyAsync(b->d_pts, src, n * pt, hipMemcpyHostToDevice, ctx->stream));
+            else {
+                void* d_raw = nullptr;
+                HIPCHK(hipMalloc(&d_raw, n * stride));
+                HIPCHK(hipMemcpyAsync(d_raw, src, n * stride, hipMemcpyHostToDevice, ctx->stream));
+                { int rc = pack_bases_launch<F>(ctx->stream, (const uint8_t*)d_raw, n, stride, (long)inf_off, (Affine<F>*)b->d_pts); if (rc) return rc; }
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                HIPCHK(hipFree(d_raw));
+            }
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        }
+        *out = b;
+        return 0;
+    });
+}
+int32_t cg_bases_register(cg_ctx* ctx, int32_t curve, int32_t group, const void* h_points, size_t n, size_t stride_bytes, int64_t infinity_offset, cg_bases** out) {
+    return bases_register_impl(ctx, curve, group, h_points, false, n, stride_bytes, infinity_offset, out);
+}
+int32_t cg_bases_register_device(cg_ctx* ctx, int32_t curve, int32_t group, const void* d_points_packed, size_t n, cg_bases** out) {
+    size_t pt = 0;
+    int rc = with_group(curve, group, [&](auto ftag, auto) -> int { pt = sizeof(Affine<decltype(ftag)>); return 0; });
+    if (rc) return rc;
+    return bases_register_impl(ctx, curve, group, d_points_packed, true, n, pt, -1, out);
+}
+int32_t cg_bases_release(cg_bases* b) {
+    if (!b) return 0;
+    hipSetDevice(b->device);
+    hipDeviceSynchronize();
+    hipFree(b->d_pts);
+    delete b;
+    return 0;
+}
+size_t cg_bases_len(const cg_bases* b) { return b ? b->n : 0; }
+
+int32_t cg_msm_set_window(cg_ctx* ctx, int32_t c) {
+    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
+    if (c != 0 && (c < 2 || c > 20)) return fail(CG_ERR_ARG, "window size must be 0 (auto) or in [2, 20]");
+    ctx->msm_window = c;
+    return 0;
+}
+int32_t cg_msm_dev_begin(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* d_scalars, int32_t k, int32_t* ticket) {
+    return msm_begin_impl(ctx, bases, offset, n, d_scalars, k, ticket, 0);
+}
+int32_t cg_msm_end(cg_ctx* ctx, int32_t ticket, void* h_out_jacobian) { return msm_end_impl(ctx, ticket, h_out_jacobian); }
+int32_t cg_msm_dev(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* d_scalars, int32_t k, void* h_out) {
+    int32_t t = -1;
+    int rc = msm_begin_impl(ctx, bases, offset, n, d_scalars, k, &t, 0);
+    if (rc) return rc;
+    return msm_end_impl(ctx, t, h_out);
+}
+int32_t cg_msm(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* h_scalars, int32_t k, void* h_out) {
+    if (!ctx || !bases || !h_scalars) return fail(CG_ERR_ARG, "null argument");
+    if (k < 1 || k > 8) return fail(CG_ERR_ARG, "k out of range");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<void*> d(k, nullptr);
+    const size_t bytes = std::max<size_t>(n * 32, 16);
+    for (int j = 0; j < k; j++) {
+        HIPCHK(hipMalloc(&d[j], bytes));
+        if (n) HIPCHK(hipMemcpyAsync(d[j], h_scalars[j], n * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    int rc = cg_msm_dev(ctx, bases, offset, n, (const void* const*)d.data(), k, h_out);
+    hipStreamSynchronize(ctx->stream);
+    for (int j = 0; j < k; j++) hipFree(d[j]);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------- NTT
+int32_t cg_ntt_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, int32_t k, size_t n, const void* h_group_gen, int32_t inverse, const void* h_coset_gen) {
+    if (!ctx || !d_vecs || !h_group_gen) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        Fr gen, cos; copy_in(gen, h_group_gen);
+        if (h_coset_gen) copy_in(cos, h_coset_gen);
+        if (n > 1) { int rc = ensure_arena(ctx, (size_t)k * n * sizeof(Fr)); if (rc) return rc; }
+        StatScope ss(ctx, &ctx->stats.ntt_ms, &ctx->stats.ntt_calls);
+        return ntt_run<Fr>(ctx, curve, d_vecs, k, n, gen, inverse != 0, h_coset_gen ? &cos : nullptr, 0);
+    });
+}
+int32_t cg_ntt(cg_ctx* ctx, int32_t curve, void* const* h_vecs, int32_t k, size_t n, const void* h_group_gen, int32_t inverse, const void* h_coset_gen) {
+    if (!ctx || !h_vecs) return fail(CG_ERR_ARG, "null argument");
+    if (k < 1 || k > NTT_MAX_VECS) return fail(CG_ERR_ARG, "k out of range");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<void*> d(k, nullptr);
+    for (int j = 0; j < k; j++) { HIPCHK(hipMalloc(&d[j], std::max<size_t>(n * 32, 16))); HIPCHK(hipMemcpyAsync(d[j], h_vecs[j], n * 32, hipMemcpyHostToDevice, ctx->stream)); }
+    int rc = cg_ntt_dev(ctx, curve, d.data(), k, n, h_group_gen, inverse, h_coset_gen);
+    if (!rc) for (int j = 0; j < k; j++) { hipError_t e = hipMemcpyAsync(h_vecs[j], d[j], n * 32, hipMemcpyDeviceToHost, ctx->stream); if (e != hipSuccess) rc = fail(CG_ERR_HIP, hipGetErrorString(e)); }
+    hipStreamSynchronize(ctx->stream);
+    for (int j = 0; j < k; j++) hipFree(d[j]);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------- vector ops
+int32_t cg_vec_add_dev(cg_ctx* ctx, int32_t curve, void* o, const void* a, const void* b, size_t n) { return vec_binary<0>(ctx, curve, o, a, b, n); }
+int32_t cg_vec_sub_dev(cg_ctx* ctx, int32_t curve, void* o, const void* a, const void* b, size_t n) { return vec_binary<1>(ctx, curve, o, a, b, n); }
+int32_t cg_vec_mul_dev(cg_ctx* ctx, int32_t curve, void* o, const void* a, const void* b, size_t n) { return vec_binary<2>(ctx, curve, o, a, b, n); }
+
+int32_t cg_vec_rep3_mul_local_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_aa, const void* d_ab, const void* d_ba, const void* d_bb, const void* d_mask, size_t n) {
+    if (!ctx || !d_out || !d_aa || !d_ab || !d_ba || !d_bb) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        StatScope ss(ctx, &ctx->stats.vec_ms, &ctx->stats.vec_calls);
+        return launch_rep3_mul_local<Fr>(ctx->stream, (Fr*)d_out, (const Fr*)d_aa, (const Fr*)d_ab, (const Fr*)d_ba, (const Fr*)d_bb, (const Fr*)d_mask, n);
+    });
+}
+int32_t cg_vec_distribute_powers_dev(cg_ctx* ctx, int32_t curve, void* d_v, size_t n, const void* h_g, const void* h_c) {
+    if (!ctx || !d_v || !h_g || !h_c) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return 0;
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        Fr g, c; copy_in(g, h_g); copy_in(c, h_c);
+        int log_m = log2_floor(n); if (((size_t)1 << log_m) < n) log_m++;
+        CosetTables t;
+        int rc = get_coset_tables<Fr>(ctx, curve, log_m, g, c, &t);
+        if (rc) return rc;
+        StatScope ss(ctx, &ctx->stats.vec_ms, &ctx->stats.vec_calls);
+        return launch_distribute_powers<Fr>(ctx->stream, (Fr*)d_v, n, (const Fr*)t.lo, (const Fr*)t.hi, t.log_lo);
+    });
+}
+int32_t cg_spmv_csr_dev(cg_ctx* ctx, int32_t curve, const uint32_t* d_row_ptr, const uint32_t* d_col, const void* d_coeff, size_t n_rows,
+                        const void* d_pub, uint32_t n_inputs, int32_t party, const void* d_wit_a, const void* d_wit_b, void* d_out_a, void* d_out_b) {
+    if (!ctx || !d_row_ptr || !d_out_a || !d_wit_a) return fail(CG_ERR_ARG, "null argument");
+    if (party < -1 || party > 2) return fail(CG_ERR_ARG, "party must be -1 (single component) or 0..2");
+    if (party >= 0 && (!d_wit_b || !d_out_b)) return fail(CG_ERR_ARG, "REP3 needs both share components");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        StatScope ss(ctx, &ctx->stats.spmv_ms, &ctx->stats.spmv_calls);
+        return launch_spmv_csr<Fr>(ctx->stream, d_row_ptr, d_col, (const Fr*)d_coeff, n_rows, (const Fr*)d_pub, n_inputs, (int)party,
+                                   (const Fr*)d_wit_a, (const Fr*)d_wit_b, (Fr*)d_out_a, (Fr*)d_out_b);
+    });
+}
+
+static int32_t host_vec_call(cg_ctx* ctx, size_t n, int n_in, const void* const* h_in, void* h_out, int (*fn)(cg_ctx*, void* const*, void*, size_t, int), int curve) {
+    if (!ctx || !h_out) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<void*> d(n_in + 1, nullptr);
+    const size_t bytes = std::max<size_t>(n * 32, 16);
+    for (int j = 0; j <= n_in; j++) HIPCHK(hipMalloc(&d[j], bytes));
+    for (int j = 0; j < n_in; j++) if (h_in[j]) HIPCHK(hipMemcpyAsync(d[j], h_in[j], n * 32, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<void*> args(d.begin(), d.begin() + n_in);
+    for (int j = 0; j < n_in; j++) if (!h_in[j]) args[j] = nullptr;
+    int rc = fn(ctx, args.data(), d[n_in], n, curve);
+    if (!rc) { hipError_t e = hipMemcpyAsync(h_out, d[n_in], n * 32, hipMemcpyDeviceToHost, ctx->stream); if (e != hipSuccess) rc = fail(CG_ERR_HIP, hipGetErrorString(e)); }
+    hipStreamSynchronize(ctx->stream);
+    for (auto p : d) hipFree(p);
+    return rc;
+}
+int32_t cg_vec_mul(cg_ctx* ctx, int32_t curve, void* h_out, const void* h_a, const void* h_b, size_t n) {
+    const void* in[2] = {h_a, h_b};
+    return host_vec_call(ctx, n, 2, in, h_out, [](cg_ctx* c, void* const* a, void* o, size_t n, int curve) { return (int)cg_vec_mul_dev(c, curve, o, a[0], a[1], n); }, curve);
+}
+int32_t cg_vec_rep3_mul_local(cg_ctx* ctx, int32_t curve, void* h_out, const void* h_aa, const void* h_ab, const void* h_ba, const void* h_bb, const void* h_mask, size_t n) {
+    const void* in[5] = {h_aa, h_ab, h_ba, h_bb, h_mask};
+    return host_vec_call(ctx, n, 5, in, h_out, [](cg_ctx* c, void* const* a, void* o, size_t n, int curve) { return (int)cg_vec_rep3_mul_local_dev(c, curve, o, a[0], a[1], a[2], a[3], a[4], n); }, curve);
+}
+
+// ---------------------------------------------------------------------------------------------------- O(1) host helpers
+int32_t cg_point_add(int32_t curve, int32_t group, const void* h_a, const void* h_b, void* h_out) {
+    return with_group(curve, group, [&](auto ftag, auto) -> int {
+        typedef decltype(ftag) F;
+        Jacobian<F> a, b; memcpy(&a, h_a, sizeof a); memcpy(&b, h_b, sizeof b);
+        Jacobian<F> r = xyzz_to_jacobian(xyzz_add(jacobian_to_xyzz(a), jacobian_to_xyzz(b)));
+        memcpy(h_out, &r, sizeof r); return 0;
+    });
+}
+int32_t cg_point_neg(int32_t curve, int32_t group, const void* h_a, void* h_out) {
+    return with_group(curve, group, [&](auto ftag, auto) -> int {
+        typedef decltype(ftag) F;
+        Jacobian<F> a; memcpy(&a, h_a, sizeof a); a.y = a.y.neg(); memcpy(h_out, &a, sizeof a); return 0;
+    });
+}
+int32_t cg_point_scalar_mul(int32_t curve, int32_t group, const void* h_a, const void* h_k, void* h_out) {
+    return with_group(curve, group, [&](auto ftag, auto frtag) -> int {
+        typedef decltype(ftag) F; typedef decltype(frtag) Fr;
+        Jacobian<F> a; memcpy(&a, h_a, sizeof a);
+        Fr k; copy_in(k, h_k); k = k.from_mont();
+        Jacobian<F> r = xyzz_to_jacobian(xyzz_scalar_mul(jacobian_to_xyzz(a), k.v, Fr::N));
+        memcpy(h_out, &r, sizeof r); return 0;
+    });
+}
+int32_t cg_point_to_affine(int32_t curve, int32_t group, const void* h_a, void* h_out_affine) {
+    return with_group(curve, group, [&](auto ftag, auto) -> int {
+        typedef decltype(ftag) F;
+        Jacobian<F> a; memcpy(&a, h_a, sizeof a);
+        Affine<F> r = xyzz_to_affine(jacobian_to_xyzz(a));
+        memcpy(h_out_affine, &r, sizeof r); return 0;
+    });
+}
+int32_t cg_point_from_affine(int32_t curve, int32_t group, const void* h_affine, void* h_out) {
+    return with_group(curve, group, [&](auto ftag, auto) -> int {
+        typedef decltype(ftag) F;
+        Affine<F> a; memcpy(&a, h_affine, sizeof a);
+        Jacobian<F> r = xyzz_to_jacobian(XYZZ<F>::from_affine(a));
+        memcpy(h_out, &r, sizeof r); return 0;
+    });
+}
+int32_t cg_fr_op(int32_t curve, int32_t op, const void* h_a, const void* h_b, void* h_out) {
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        Fr a, b = Fr::zero(); copy_in(a, h_a); if (h_b) copy_in(b, h_b);
+        Fr r;
+        switch (op) { case 0: r = a + b; break; case 1: r = a - b; break; case 2: r = a * b; break; case 3: r = fp_inverse(a); break; default: return fail(CG_ERR_ARG, "bad op"); }
+        memcpy(h_out, r.v, sizeof r.v); return 0;
+    });
+}
+
+int32_t cg_stats_enable(cg_ctx* ctx, int32_t on) { if (!ctx) return fail(CG_ERR_ARG, "null ctx"); ctx->stats_on = on != 0; return 0; }
+int32_t cg_stats(cg_ctx* ctx, cg_stage_times* out, int32_t reset) {
+    if (!ctx || !out) return fail(CG_ERR_ARG, "null argument");
+    *out = ctx->stats;
+    if (reset) ctx->stats = cg_stage_times{};
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Launch side of the scalar-field kernels (vec_kernels.hpp, ntt_kernels.hpp); instantiated per field in fr_inst_*.hip.
+#pragma once
+#include "common.hpp"
+#include "ntt_kernels.hpp"
+#include "vec_kernels.hpp"
+
+namespace cg {
+
+template <class Fr> int launch_vec_binary(hipStream_t st, int op, Fr* out, const Fr* a, const Fr* b, size_t n) {
+    if (!n) return 0;
+    if (op == 0) hipLaunchKernelGGL((k_vec_binary<Fr, 0>), dim3(grid_for(n)), dim3(256), 0, st, out, a, b, n);
+    else if (op == 1) hipLaunchKernelGGL((k_vec_binary<Fr, 1>), dim3(grid_for(n)), dim3(256), 0, st, out, a, b, n);
+    else hipLaunchKernelGGL((k_vec_binary<Fr, 2>), dim3(grid_for(n)), dim3(256), 0, st, out, a, b, n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class Fr> int launch_rep3_mul_local(hipStream_t st, Fr* out, const Fr* aa, const Fr* ab, const Fr* ba, const Fr* bb, const Fr* mask, size_t n) {
+    if (!n) return 0;
+    hipLaunchKernelGGL((k_rep3_mul_local<Fr>), dim3(grid_for(n)), dim3(256), 0, st, out, aa, ab, ba, bb, mask, n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class Fr> int launch_distribute_powers(hipStream_t st, Fr* v, size_t n, const Fr* lo, const Fr* hi, int log_lo) {
+    if (!n) return 0;
+    hipLaunchKernelGGL((k_distribute_powers<Fr>), dim3(grid_for(n)), dim3(256), 0, st, v, n, lo, hi, log_lo);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class Fr> int launch_spmv_csr(hipStream_t st, const uint32_t* row_ptr, const uint32_t* col, const Fr* coeff, size_t n_rows, const Fr* pub,
+                                        uint32_t n_inputs, int party, const Fr* wit_a, const Fr* wit_b, Fr* out_a, Fr* out_b) {
+    if (!n_rows) return 0;
+    hipLaunchKernelGGL((k_spmv_csr<Fr>), dim3(grid_for(n_rows)), dim3(256), 0, st, row_ptr, col, coeff, n_rows, pub, n_inputs, party, wit_a, wit_b, out_a, out_b);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class Fr> int launch_build_twiddles(hipStream_t st, Fr* tw, size_t m, int log_m, const Fr* lo, const Fr* hi, int log_lo) {
+    if (m > 1) hipLaunchKernelGGL((k_build_twiddles<Fr>), dim3(grid_for(m - 1)), dim3(256), 0, st, tw, m, log_m, lo, hi, log_lo);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class Fr> int launch_ntt_dif_pass(hipStream_t st, NttVecs data, int nvec, size_t n, int log_m, int s0, int k, int t, const Fr* tw) {
+    static bool attr_set = false;
+    if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_ntt_dif_pass<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_set = true; }
+    const int E = 1 << (k + t);
+    hipLaunchKernelGGL((k_ntt_dif_pass<Fr>), dim3((unsigned)(n / E), nvec), dim3(NTT_THREADS), (size_t)E * 32, st, data, log_m, s0, k, t, tw);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class Fr> int launch_bitrev_scale(hipStream_t st, NttVecs dst, NttVecs src, int nvec, size_t n, int log_m, const Fr* scale, const Fr* c_lo, const Fr* c_hi, int log_lo) {
+    if (log_m >= 2 * BITREV_B)
+        hipLaunchKernelGGL((k_bitrev_scale<Fr>), dim3((unsigned)(n >> (2 * BITREV_B)), nvec), dim3(256), 0, st, dst, src, log_m, scale, c_lo, c_hi, log_lo);
+    else
+        hipLaunchKernelGGL((k_bitrev_scale_small<Fr>), dim3(grid_for(n), nvec), dim3(256), 0, st, dst, src, log_m, scale, c_lo, c_hi, log_lo);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace cg
+
+#define CG_INSTANTIATE_FR(Fr)                                                                                              \
+    namespace cg {                                                                                                         \
+    template int launch_vec_binary<Fr>(hipStream_t, int, Fr*, const Fr*, const Fr*, size_t);                               \
+    template int launch_rep3_mul_local<Fr>(hipStream_t, Fr*, const Fr*, const Fr*, const Fr*, const Fr*, const Fr*, size_t); \
+    template int launch_distribute_powers<Fr>(hipStream_t, Fr*, size_t, const Fr*, const Fr*, int);                        \
+    template int launch_spmv_csr<Fr>(hipStream_t, const uint32_t*, const uint32_t*, const Fr*, size_t, const Fr*, uint32_t, int, const Fr*, const Fr*, Fr*, Fr*); \
+    template int launch_build_twiddles<Fr>(hipStream_t, Fr*, size_t, int, const Fr*, const Fr*, int);                      \
+    template int launch_ntt_dif_pass<Fr>(hipStream_t, NttVecs, int, size_t, int, int, int, int, const Fr*);                \
+    template int launch_bitrev_scale<Fr>(hipStream_t, NttVecs, NttVecs, int, size_t, int, const Fr*, const Fr*, const Fr*, int); \
+    }

@@ -1,0 +1,151 @@
+// Radix-2 NTT over the 256-bit scalar fields (BN254 Fr, BLS12-381 Fr) for gfx950.
+// Replaces ark-poly 0.4.2 `Radix2EvaluationDomain::{fft,ifft}_in_place` as called from
+// `/root/reference/mpc-core/src/protocols/rep3.rs:893-921` (plain.rs:375-406, shamir.rs:826-871) with the generator
+// supplied by the caller (`/root/reference/co-circom/co-groth16/src/groth16.rs:57-77` overrides group_gen).
+//
+// Structure: decimation-in-frequency passes, each pass = up to 11 butterfly stages done inside LDS on a 2^(k+t)-element
+// tile (2^k strided rows x 2^t contiguous elements, 64 KiB), so a 2^22 transform is 3 HBM round trips instead of 22.
+// Twiddles live in HBM in STAGE-MAJOR order (table s holds w^(j*2^s), j < m/2^(s+1), contiguous), so every stage reads a
+// contiguous, coalesced run of its table.  The DIF passes leave the data bit-reversed; a final permutation pass restores
+// natural order and fuses the 1/m scaling and the coset shift g^i (rep3.rs:681-688) into the same HBM round trip.
+#pragma once
+#include "field.hpp"
+#include "vec_kernels.hpp"
+
+namespace cg {
+
+constexpr int NTT_MAX_VECS = 8;
+struct NttVecs { void* p[NTT_MAX_VECS]; };
+
+constexpr int NTT_TILE_LOG = 11;                       // 2048 elements x 32 B = 64 KiB of LDS per workgroup
+constexpr int NTT_THREADS = 256;
+
+__host__ __device__ inline size_t tw_stage_offset(size_t m, int s) { return m - (m >> s); }
+
+// tw_all[off(s) + j] = w^(j << s) via two-level tables lo[e & (2^log_lo-1)] * hi[e >> log_lo]
+template <class F>
+__global__ void __launch_bounds__(256) k_build_twiddles(F* __restrict__ tw_all, size_t m, int log_m, const F* __restrict__ lo, const F* __restrict__ hi, int log_lo) {
+    const size_t total = m - 1;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        // find stage s with off(s) <= idx < off(s+1): m - idx - 1 has its top bit at position (log_m - s - 1)
+        size_t rem = m - 1 - idx;                        // in [1, m-1]; off(s) = m - m/2^s
+        int s = log_m - 1 - (63 - __builtin_clzll((unsigned long long)rem | 1ull));
+        size_t j = idx - tw_stage_offset(m, s);
+        size_t e = j << s;
+        F w = ld_fp(lo + (e & (((size_t)1 << log_lo) - 1))) * ld_fp(hi + (e >> log_lo));
+        st_fp(tw_all + idx, w);
+    }
+}
+
+// One DIF pass: stages [s0, s0+k) on tiles of 2^k rows (stride 2^(log_m-s0-k)) x 2^t contiguous elements.
+// grid.x = tiles per vector, grid.y = vector index.
+template <class F>
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_dif_pass(NttVecs vecs, int log_m, int s0, int k, int t, const F* __restrict__ tw_all) {
+    static_assert(F::N == 8, "NTT is specialised for 256-bit scalar fields");
+    extern __shared__ uint4 lds[];                        // two planes (low/high 16 bytes) -> conflict-free 16-byte accesses
+    const int E = 1 << (k + t);
+    uint4* pl0 = lds;
+    uint4* pl1 = lds + E;
+    F* data = reinterpret_cast<F*>(vecs.p[blockIdx.y]);
+    const size_t m = (size_t)1 << log_m;
+    const int lo_bits = log_m - s0 - k;
+    const size_t tiles_per_hi = (size_t)1 << (lo_bits - t);
+    const size_t hi = blockIdx.x / tiles_per_hi;
+    const size_t lo0 = (blockIdx.x % tiles_per_hi) << t;
+    const size_t base = (hi << (log_m - s0)) + lo0;
+    const int tmask = (1 << t) - 1;
+
+    for (int idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+        const size_t g = base + ((size_t)(idx >> t) << lo_bits) + (idx & tmask);
+        const uint4* q = reinterpret_cast<const uint4*>(data + g);
+        pl0[idx] = q[0]; pl1[idx] = q[1];
+    }
+    __syncthreads();
+    for (int q = 0; q < k; q++) {
+        const int pb = k - 1 - q;
+        const int s = s0 + q;
+        const F* tw = tw_all + tw_stage_offset(m, s);
+        for (int u = threadIdx.x; u < E / 2; u += NTT_THREADS) {
+            const int lo_local = u & tmask;
+            const int mu = u >> t;
+            const int mid0 = ((mu >> pb) << (pb + 1)) | (mu & ((1 << pb) - 1));
+            const int i0 = (mid0 << t) | lo_local;
+            const int i1 = i0 + (1 << (pb + t));
+            const size_t j = ((size_t)(mid0 & ((1 << pb) - 1)) << lo_bits) + lo0 + lo_local;
+            F a, b;
+            { uint4 x = pl0[i0], y = pl1[i0]; a.v[0] = x.x; a.v[1] = x.y; a.v[2] = x.z; a.v[3] = x.w; a.v[4] = y.x; a.v[5] = y.y; a.v[6] = y.z; a.v[7] = y.w; }
+            { uint4 x = pl0[i1], y = pl1[i1]; b.v[0] = x.x; b.v[1] = x.y; b.v[2] = x.z; b.v[3] = x.w; b.v[4] = y.x; b.v[5] = y.y; b.v[6] = y.z; b.v[7] = y.w; }
+            F w = ld_fp(tw + j);
+            F sum = a + b;
+            F dif = (a - b) * w;
+            pl0[i0] = make_uint4(sum.v[0], sum.v[1], sum.v[2], sum.v[3]); pl1[i0] = make_uint4(sum.v[4], sum.v[5], sum.v[6], sum.v[7]);
+            pl0[i1] = make_uint4(dif.v[0], dif.v[1], dif.v[2], dif.v[3]); pl1[i1] = make_uint4(dif.v[4], dif.v[5], dif.v[6], dif.v[7]);
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+        const size_t g = base + ((size_t)(idx >> t) << lo_bits) + (idx & tmask);
+        uint4* q = reinterpret_cast<uint4*>(data + g);
+        q[0] = pl0[idx]; q[1] = pl1[idx];
+    }
+}
+
+// dst[bitrev(i)] = src[i] * (scale) * (coset power of bitrev(i))
+//   scale: optional constant (1/m for the inverse transform), coset: optional two-level tables of g^j.
+// Tiled through LDS so that both the read side and the write side move >= 512 contiguous bytes:
+// i = (hi | mid | lo) with |hi| = |lo| = B bits; a workgroup takes one `mid` and all 2^B x 2^B (hi, lo) pairs.
+constexpr int BITREV_B = 5;
+template <class F>
+__global__ void __launch_bounds__(256) k_bitrev_scale(NttVecs dst, NttVecs src, int log_m, const F* __restrict__ scale,
+                                                      const F* __restrict__ cos_lo, const F* __restrict__ cos_hi, int log_lo) {
+    static_assert(F::N == 8, "");
+    __shared__ uint4 tile0[(1 << BITREV_B) * ((1 << BITREV_B) + 1)];
+    __shared__ uint4 tile1[(1 << BITREV_B) * ((1 << BITREV_B) + 1)];
+    const F* in = reinterpret_cast<const F*>(src.p[blockIdx.y]);
+    F* out = reinterpret_cast<F*>(dst.p[blockIdx.y]);
+    const int B = BITREV_B, S = 1 << B;
+    const int mid_bits = log_m - 2 * B;
+    const size_t mid = blockIdx.x;
+    const size_t rmid = mid_bits > 0 ? (__brevll((unsigned long long)mid) >> (64 - mid_bits)) : 0;
+    F sc = scale ? ld_fp(scale) : F::one();
+    // read: rows = hi (S of them), contiguous in lo
+    for (int e = threadIdx.x; e < S * S; e += 256) {
+        const int h = e >> B, l = e & (S - 1);
+        const size_t i = ((size_t)h << (log_m - B)) | (mid << B) | (size_t)l;
+        const uint4* q = reinterpret_cast<const uint4*>(in + i);
+        tile0[h * (S + 1) + l] = q[0]; tile1[h * (S + 1) + l] = q[1];
+    }
+    __syncthreads();
+    // write: output index o = (rev(lo) | rev(mid) | rev(hi)); rows = rev(lo), contiguous in rev(hi)
+    for (int e = threadIdx.x; e < S * S; e += 256) {
+        const int rl = e >> B, rh = e & (S - 1);
+        const int l = __brev((unsigned)rl) >> (32 - B), h = __brev((unsigned)rh) >> (32 - B);
+        const size_t o = ((size_t)rl << (log_m - B)) | (rmid << B) | (size_t)rh;
+        uint4 x = tile0[h * (S + 1) + l], y = tile1[h * (S + 1) + l];
+        F v; v.v[0] = x.x; v.v[1] = x.y; v.v[2] = x.z; v.v[3] = x.w; v.v[4] = y.x; v.v[5] = y.y; v.v[6] = y.z; v.v[7] = y.w;
+        if (cos_lo) {
+            F w = ld_fp(cos_lo + (o & (((size_t)1 << log_lo) - 1))) * ld_fp(cos_hi + (o >> log_lo));
+            if (scale) w = w * sc;
+            v = v * w;
+        } else if (scale) v = v * sc;
+        st_fp(out + o, v);
+    }
+}
+
+// small-m fallback for the permutation (log_m < 2*BITREV_B): one element per lane
+template <class F>
+__global__ void __launch_bounds__(256) k_bitrev_scale_small(NttVecs dst, NttVecs src, int log_m, const F* __restrict__ scale,
+                                                            const F* __restrict__ cos_lo, const F* __restrict__ cos_hi, int log_lo) {
+    const F* in = reinterpret_cast<const F*>(src.p[blockIdx.y]);
+    F* out = reinterpret_cast<F*>(dst.p[blockIdx.y]);
+    const size_t m = (size_t)1 << log_m;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = log_m ? (__brevll((unsigned long long)i) >> (64 - log_m)) : 0;
+        F v = ld_fp(in + i);
+        if (cos_lo) v = v * (ld_fp(cos_lo + (o & (((size_t)1 << log_lo) - 1))) * ld_fp(cos_hi + (o >> log_lo)));
+        if (scale) v = v * ld_fp(scale);
+        st_fp(out + o, v);
+    }
+}
+
+}  // namespace cg

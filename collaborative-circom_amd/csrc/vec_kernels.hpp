@@ -1,0 +1,92 @@
+// Pointwise secret-shared field arithmetic and the sparse constraint evaluation of the co-groth16 witness map.
+// HBM-bound kernels: one 32-byte element per lane per iteration, loaded as two 16-byte halves (global_load_dwordx4),
+// grid-stride over ~2048 workgroups.  Reference semantics cited per kernel.
+#pragma once
+#include "field.hpp"
+
+namespace cg {
+
+template <class F>
+__device__ __forceinline__ F ld_fp(const F* p) {
+    F r;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    _Pragma("unroll") for (int i = 0; i < F::N / 4; i++) {
+        uint4 w = q[i];
+        r.v[4 * i] = w.x; r.v[4 * i + 1] = w.y; r.v[4 * i + 2] = w.z; r.v[4 * i + 3] = w.w;
+    }
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void st_fp(F* p, const F& r) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    _Pragma("unroll") for (int i = 0; i < F::N / 4; i++) q[i] = make_uint4(r.v[4 * i], r.v[4 * i + 1], r.v[4 * i + 2], r.v[4 * i + 3]);
+}
+
+// op: 0 add, 1 sub, 2 mul   (plain.rs:215-224 add_vec / mul_vec; rep3.rs:672-679 sub_assign_vec per component)
+template <class F, int OP>
+__global__ void __launch_bounds__(256) k_vec_binary(F* __restrict__ out, const F* __restrict__ a, const F* __restrict__ b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        F x = ld_fp(a + i), y = ld_fp(b + i);
+        st_fp(out + i, OP == 0 ? x + y : OP == 1 ? x - y : x * y);
+    }
+}
+
+// REP3 local product (rep3.rs:656-660, fieldshare.rs:161-168): out = aa*ba + aa*bb + ab*ba (+ mask)
+// computed as aa*(ba+bb) + ab*ba: two Montgomery products instead of three.
+template <class F>
+__global__ void __launch_bounds__(256) k_rep3_mul_local(F* __restrict__ out, const F* __restrict__ aa, const F* __restrict__ ab,
+                                                        const F* __restrict__ ba, const F* __restrict__ bb, const F* __restrict__ mask, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        F xa = ld_fp(aa + i), xb = ld_fp(ab + i), ya = ld_fp(ba + i), yb = ld_fp(bb + i);
+        F r = xa * (ya + yb) + xb * ya;
+        if (mask) r = r + ld_fp(mask + i);
+        st_fp(out + i, r);
+    }
+}
+
+// v[i] *= c * g^i  (rep3.rs:681-688 / plain.rs:226-234).  g^i = hi[i >> LOG_LO] * lo[i & (2^LOG_LO - 1)] from two small
+// tables (lo[j] = c*g^j, hi[j] = g^(j << LOG_LO)) that stay in L2: no per-element power chain, no m-entry table in HBM.
+template <class F>
+__global__ void __launch_bounds__(256) k_distribute_powers(F* __restrict__ v, size_t n, const F* __restrict__ lo, const F* __restrict__ hi, int log_lo) {
+    const size_t mask = ((size_t)1 << log_lo) - 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        F w = ld_fp(lo + (i & mask)) * ld_fp(hi + (i >> log_lo));
+        st_fp(v + i, ld_fp(v + i) * w);
+    }
+}
+
+// Constraint evaluation (groth16.rs:159-166 calling rep3.rs:690-708 / plain.rs:243-258) as a CSR sparse mat-vec,
+// one row per lane.  Signal index < n_inputs -> public input (REP3: added to component `a` by party 0, to `b` by party 1,
+// dropped by party 2 — rep3.rs:600-608); otherwise the shared witness at index - n_inputs.
+// party: -1 = single-component driver (plain / Shamir: public inputs are added as they are), 0..2 = REP3 party id.
+template <class F>
+__global__ void __launch_bounds__(256) k_spmv_csr(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const F* __restrict__ coeff,
+                                                  size_t n_rows, const F* __restrict__ pub, uint32_t n_inputs, int party,
+                                                  const F* __restrict__ wit_a, const F* __restrict__ wit_b, F* __restrict__ out_a, F* __restrict__ out_b) {
+    for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < n_rows; row += (size_t)gridDim.x * blockDim.x) {
+        F acc_a = F::zero(), acc_b = F::zero();
+        const uint32_t e = row_ptr[row + 1];
+        for (uint32_t k = row_ptr[row]; k < e; k++) {
+            const uint32_t idx = col[k];
+            const F c = ld_fp(coeff + k);
+            if (idx < n_inputs) {
+                F t = c * ld_fp(pub + idx);
+                if (party <= 0) acc_a = acc_a + t;
+                else if (party == 1) acc_b = acc_b + t;
+            } else {
+                acc_a = acc_a + c * ld_fp(wit_a + (idx - n_inputs));
+                if (wit_b) acc_b = acc_b + c * ld_fp(wit_b + (idx - n_inputs));
+            }
+        }
+        st_fp(out_a + row, acc_a);
+        if (out_b) st_fp(out_b + row, acc_b);
+    }
+}
+
+// dst[i] = src[i] for i < n else 0, for dst of length m (building the zero-padded evaluation vectors, groth16.rs:156-171)
+template <class F>
+__global__ void __launch_bounds__(256) k_zero_tail(F* __restrict__ v, size_t from, size_t to) {
+    for (size_t i = from + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < to; i += (size_t)gridDim.x * blockDim.x) st_fp(v + i, F::zero());
+}
+
+}  // namespace cg

@@ -1,0 +1,133 @@
+/* cogroth16_hip.h — C ABI of the MI355X (gfx950) co-groth16 prover backend.
+ *
+ * This is the drop-in boundary for the ONE data-parallel hot path of TaceoLabs/collaborative-circom:
+ * `CoGroth16::prove` (reference: co-circom/co-groth16/src/groth16.rs:113-326).  Every entry point below replaces an
+ * arkworks call that one of the reference's MPC drivers makes from its implementation of the plug-in traits
+ *   FFTProvider<F>            mpc-core/src/traits.rs:535-558
+ *   MSMProvider<C>            mpc-core/src/traits.rs:561-568
+ *   PrimeFieldMpcProtocol<F>  mpc-core/src/traits.rs:43-223   (the O(n) vector methods only)
+ * and is what a Rust FFI shim (`extern "C"` block) would bind.  Network rounds, correlated
+ * randomness (ChaCha12) and O(1) point algebra stay in the host driver, unchanged.
+ *
+ * DATA CONVENTIONS (identical to the reference's in-memory values, circom-types/src/traits.rs:57-67):
+ *   field element  = N x u64 little-endian limbs in Montgomery form (R = 2^256; BLS12-381 Fq: R = 2^384), fully reduced.
+ *                    N = 4 for BN254 Fr/Fq and BLS12-381 Fr, N = 6 for BLS12-381 Fq.
+ *   G1 affine      = x || y ; G2 affine = x.c0 || x.c1 || y.c0 || y.c1.  Infinity: either a flag byte at
+ *                    `infinity_offset` inside each point record (arkworks `Affine{x,y,infinity}`), or (0,0) when
+ *                    infinity_offset < 0 (the packed zkey encoding, traits.rs:113-115).
+ *   MSM result     = Jacobian (X, Y, Z) in Montgomery form, Z == 0 <=> infinity  (ark-ec short_weierstrass::Projective).
+ *
+ * ERRORS: every function returns 0 on success, non-zero otherwise; cg_last_error() gives the message (thread-local).
+ *   There is NO CPU fallback: if no gfx950 device is present cg_ctx_create fails.
+ * THREADING: a context is used by one thread at a time (mirrors `&mut self`); several contexts may share a GPU.
+ * Pointers named d_* are DEVICE pointers (from cg_dev_alloc or any HIP allocation on the context's device);
+ * pointers named h_* are HOST pointers owned by the caller.
+ */
+#ifndef COGROTH16_HIP_H
+#define COGROTH16_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cg_ctx cg_ctx;       /* one per MPC party thread: HIP stream, scratch arena, twiddle cache */
+typedef struct cg_bases cg_bases;   /* device-resident, immutable point table (a zkey query) */
+
+enum { CG_BN254 = 0, CG_BLS12_381 = 1 };
+enum { CG_G1 = 0, CG_G2 = 1 };
+enum { CG_OK = 0, CG_ERR_ARG = 1, CG_ERR_HIP = 2, CG_ERR_NODEVICE = 3, CG_ERR_OOM = 4 };
+
+/* ---- context ------------------------------------------------------------------------------------------------- */
+int32_t cg_ctx_create(int32_t device, cg_ctx** out);
+int32_t cg_ctx_destroy(cg_ctx* ctx);
+int32_t cg_ctx_sync(cg_ctx* ctx);
+void*   cg_ctx_stream(cg_ctx* ctx);                 /* the hipStream_t every launch of this context goes to */
+const char* cg_last_error(void);
+const char* cg_version(void);
+
+/* ---- device memory (thin wrappers so non-HIP hosts can keep vectors resident between calls) ------------------- */
+int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr);
+int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr);
+int32_t cg_dev_upload(cg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);     /* synchronous */
+int32_t cg_dev_download(cg_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* synchronous */
+int32_t cg_dev_memset_zero(cg_ctx* ctx, void* d_dst, size_t bytes);
+
+/* ---- MSMProvider::msm_public_points  (traits.rs:561-568; rep3.rs:934-947, shamir.rs:1027-1039, plain.rs:408-416) */
+/* Upload a point table once (zkey a/b1/b2/l/h query, zkey.rs:48-71); it is reused by every proof.
+ * `stride_bytes` = distance between records, `infinity_offset` = byte offset of the arkworks infinity flag or -1. */
+int32_t cg_bases_register(cg_ctx* ctx, int32_t curve, int32_t group, const void* h_points, size_t n,
+                          size_t stride_bytes, int64_t infinity_offset, cg_bases** out);
+/* same, source already on the device in packed (x||y, (0,0)=inf) form; the table is copied */
+int32_t cg_bases_register_device(cg_ctx* ctx, int32_t curve, int32_t group, const void* d_points_packed, size_t n, cg_bases** out);
+int32_t cg_bases_release(cg_bases* bases);
+size_t  cg_bases_len(const cg_bases* bases);
+
+/* out_jacobian[j] = sum_i scalars[j][i] * bases[offset + i], j < k (k = share components: REP3 2, Shamir/plain 1).
+ * `offset` lets a caller pass a sub-slice exactly like `&query[1 + pub_len..]` (groth16.rs:221). n == 0 gives infinity. */
+int32_t cg_msm(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n,
+               const void* const* h_scalars, int32_t k, void* h_out_jacobian);
+int32_t cg_msm_dev(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n,
+                   const void* const* d_scalars, int32_t k, void* h_out_jacobian);
+/* asynchronous form: enqueue now, collect later (lets the host overlap the O(1) Horner folds of several MSMs) */
+int32_t cg_msm_dev_begin(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n,
+                         const void* const* d_scalars, int32_t k, int32_t* ticket);
+int32_t cg_msm_end(cg_ctx* ctx, int32_t ticket, void* h_out_jacobian);
+/* window size override (0 = automatic); tuning knob only, never changes results */
+int32_t cg_msm_set_window(cg_ctx* ctx, int32_t c);
+
+/* ---- FFTProvider::{fft,ifft}_in_place  (traits.rs:535-558; rep3.rs:893-921) ------------------------------------
+ * k vectors of n = 2^j scalar-field elements, natural order in and out.  `h_group_gen` = domain.group_gen (the caller
+ * may have overridden it: groth16.rs:63-70).  inverse != 0: uses group_gen^-1 and scales by n^-1.
+ * `h_coset_gen` (optional, inverse only): additionally multiplies element i by coset_gen^i, i.e. fuses
+ * distribute_powers_and_mul_by_const(v, g, 1) (traits.rs:177, rep3.rs:681-688) into the transform. */
+int32_t cg_ntt(cg_ctx* ctx, int32_t curve, void* const* h_vecs, int32_t k, size_t n,
+               const void* h_group_gen, int32_t inverse, const void* h_coset_gen);
+int32_t cg_ntt_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, int32_t k, size_t n,
+                   const void* h_group_gen, int32_t inverse, const void* h_coset_gen);
+
+/* ---- PrimeFieldMpcProtocol vector methods (device-resident operands) ------------------------------------------ */
+/* add_vec traits.rs:161 / sub_assign_vec :67 / plain+Shamir local mul_vec :164 (plain.rs:219-224, shamir.rs:618-621) */
+int32_t cg_vec_add_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_a, const void* d_b, size_t n);
+int32_t cg_vec_sub_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_a, const void* d_b, size_t n);
+int32_t cg_vec_mul_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_a, const void* d_b, size_t n);
+/* REP3 mul_vec local part (rep3.rs:656-660): out = aa*ba + aa*bb + ab*ba + mask ; d_mask may be NULL */
+int32_t cg_vec_rep3_mul_local_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_aa, const void* d_ab,
+                                  const void* d_ba, const void* d_bb, const void* d_mask, size_t n);
+/* distribute_powers_and_mul_by_const (traits.rs:177): v[i] *= c * g^i */
+int32_t cg_vec_distribute_powers_dev(cg_ctx* ctx, int32_t curve, void* d_v, size_t n, const void* h_g, const void* h_c);
+/* evaluate_constraint over all rows (traits.rs:180; groth16.rs:159-166): CSR matrix, signal index < n_inputs = public.
+ * party: -1 = single component (plain / Shamir), 0..2 = REP3 party id (add_with_public asymmetry, rep3.rs:600-608).
+ * d_wit_b / d_out_b may be NULL when party == -1. */
+int32_t cg_spmv_csr_dev(cg_ctx* ctx, int32_t curve, const uint32_t* d_row_ptr, const uint32_t* d_col, const void* d_coeff,
+                        size_t n_rows, const void* d_pub, uint32_t n_inputs, int32_t party,
+                        const void* d_wit_a, const void* d_wit_b, void* d_out_a, void* d_out_b);
+/* host-buffer forms of the two elementwise products (what an unmodified `&mut Vec<F>` caller would use) */
+int32_t cg_vec_mul(cg_ctx* ctx, int32_t curve, void* h_out, const void* h_a, const void* h_b, size_t n);
+int32_t cg_vec_rep3_mul_local(cg_ctx* ctx, int32_t curve, void* h_out, const void* h_aa, const void* h_ab,
+                              const void* h_ba, const void* h_bb, const void* h_mask, size_t n);
+
+/* ---- O(1) point helpers on the host (EcMpcProtocol: scalar_mul_public_point rep3.rs:820-825, add_assign_points :780) */
+/* Jacobian in/out, Montgomery. out = a + b ; out = k * a (k = Montgomery Fr) ; affine = normalise(a) (packed, (0,0)=inf) */
+int32_t cg_point_add(int32_t curve, int32_t group, const void* h_a, const void* h_b, void* h_out);
+int32_t cg_point_neg(int32_t curve, int32_t group, const void* h_a, void* h_out);
+int32_t cg_point_scalar_mul(int32_t curve, int32_t group, const void* h_a, const void* h_k, void* h_out);
+int32_t cg_point_to_affine(int32_t curve, int32_t group, const void* h_a, void* h_out_affine);
+int32_t cg_point_from_affine(int32_t curve, int32_t group, const void* h_affine, void* h_out);
+/* O(1) scalar-field helpers used by the host drivers (Montgomery in/out): op 0 add, 1 sub, 2 mul, 3 inverse(a) */
+int32_t cg_fr_op(int32_t curve, int32_t op, const void* h_a, const void* h_b, void* h_out);
+
+/* ---- statistics (per context, milliseconds of GPU time since the last reset, measured with HIP events) --------- */
+typedef struct cg_stage_times {
+    double msm_ms, ntt_ms, vec_ms, spmv_ms;
+    uint64_t msm_calls, ntt_calls, vec_calls, spmv_calls;
+} cg_stage_times;
+int32_t cg_stats_enable(cg_ctx* ctx, int32_t on);
+int32_t cg_stats(cg_ctx* ctx, cg_stage_times* out, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COGROTH16_HIP_H */

@@ -1,0 +1,78 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds/loads, exports every symbol the header declares,
+refuses to run without a GPU (no CPU fallback), and its O(1) HOST helpers (field / point algebra compiled from the same
+sources as the device code) agree with the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from oracle_lib import BN254, BLS12_381, FR, FQ, G1, G2
+from product import cg, ensure_built, ROOT
+
+
+def test_header_symbols_exported():
+    ensure_built()
+    hdr = open(os.path.join(ROOT, "include", "cogroth16_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(cg_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    lib = ctypes.CDLL(cg.LIB_PATH)
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, f"symbols declared in the header but not exported: {missing}"
+    assert sorted(cg.ABI_SYMBOLS) == declared
+    assert b"gfx950" in cg.load().cg_version()
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    ensure_built()
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(cg.BackendError) as e:
+        cg.Context(0)
+    assert "no HIP device" in str(e.value) or "error" in str(e.value)
+
+
+def jac_of(curve, group, affine):
+    return cg.point_from_affine(curve, group, affine)
+
+
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
+@pytest.mark.parametrize("group", [G1, G2])
+def test_host_point_helpers_match_oracle(curve, group):
+    ensure_built()
+    rng = np.random.default_rng(21 + curve * 2 + group)
+    ks = orc.random_field(curve, FR, 4, rng)
+    P = orc.generator_mul(curve, group, ks[0]); Q = orc.generator_mul(curve, group, ks[1])
+    jp, jq = jac_of(curve, group, P), jac_of(curve, group, Q)
+    np.testing.assert_array_equal(cg.point_to_affine(curve, group, jp), P)
+    # add, double (P+P), P + (-P), P + inf
+    np.testing.assert_array_equal(cg.point_to_affine(curve, group, cg.point_add(curve, group, jp, jq)), orc.point_add(curve, group, P, Q))
+    np.testing.assert_array_equal(cg.point_to_affine(curve, group, cg.point_add(curve, group, jp, jp)), orc.point_add(curve, group, P, P))
+    assert not cg.point_to_affine(curve, group, cg.point_add(curve, group, jp, cg.point_neg(curve, group, jp))).any()
+    inf = jac_of(curve, group, np.zeros_like(P))
+    np.testing.assert_array_equal(cg.point_to_affine(curve, group, cg.point_add(curve, group, inf, jp)), P)
+    # the product's Jacobian output is accepted by the oracle's normaliser too
+    np.testing.assert_array_equal(orc.jacobian_to_affine(curve, group, cg.point_add(curve, group, jp, jq)), orc.point_add(curve, group, P, Q))
+    # scalar mul
+    got = cg.point_to_affine(curve, group, cg.point_scalar_mul(curve, group, jp, ks[2]))
+    np.testing.assert_array_equal(got, orc.points_mul(curve, group, P[None, :], ks[2][None, :])[0])
+    assert not cg.point_to_affine(curve, group, cg.point_scalar_mul(curve, group, jp, np.zeros(4, dtype=np.uint64))).any()
+
+
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
+def test_host_fr_ops_match_oracle(curve):
+    ensure_built()
+    rng = np.random.default_rng(33)
+    a, b = orc.random_field(curve, FR, 2, rng)
+    for op in ("add", "sub", "mul"):
+        np.testing.assert_array_equal(cg.fr_op(curve, op, a, b), orc.field_op(curve, FR, op, a, b))
+    np.testing.assert_array_equal(cg.fr_op(curve, "inv", a), orc.field_inverse(curve, FR, a))
+    # edge values: 0, 1, p-1
+    p1 = orc.from_dec(curve, FR, orc.MODULI[(curve, FR)] - 1)
+    one = orc.from_dec(curve, FR, 1); zero = np.zeros(4, dtype=np.uint64)
+    np.testing.assert_array_equal(cg.fr_op(curve, "add", p1, one), zero)
+    np.testing.assert_array_equal(cg.fr_op(curve, "sub", zero, one), p1)
+    np.testing.assert_array_equal(cg.fr_op(curve, "mul", p1, p1), one)

@@ -1,0 +1,301 @@
+"""GPU parity tests: every kernel of the hot path, called through the C ABI (libcogroth16_hip.so), against the CPU oracle on
+the same seeded inputs.  Bar: bit-exact (integer arithmetic; MSM results compared as affine points, which are unique)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from oracle_lib import BN254, BLS12_381, FR, FQ, G1, G2
+from product import cg, ensure_built
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    ensure_built()
+    c = cg.Context(0)
+    yield c
+    c.close()
+
+
+def dev(ctx, arr):
+    return ctx.to_device(arr)
+
+
+# ------------------------------------------------------------------------------------------------ pointwise
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
+@pytest.mark.parametrize("n", [1, 255, 4099])
+def test_vec_ops(ctx, curve, n):
+    rng = np.random.default_rng(100 + n)
+    a, b, c, d, m = (orc.random_field(curve, FR, n, rng) for _ in range(5))
+    # edge values in the first lanes
+    if n > 3:
+        a[0] = 0; b[1] = 0; a[2] = orc.from_dec(curve, FR, orc.MODULI[(curve, FR)] - 1); b[2] = a[2]
+    da, db, dc, dd, dm = (dev(ctx, x) for x in (a, b, c, d, m))
+    out = ctx.alloc(n * 32)
+    for name, fn in (("add", ctx.vec_add), ("sub", ctx.vec_sub), ("mul", ctx.vec_mul)):
+        fn(curve, out, da, db, n)
+        np.testing.assert_array_equal(out.download((n, 4)), orc.field_op(curve, FR, name, a, b), err_msg=name)
+    # REP3 local product aa*ba + aa*bb + ab*ba (+ mask)   (rep3.rs:656-660)
+    mul = lambda x, y: orc.field_op(curve, FR, "mul", x, y)
+    add = lambda x, y: orc.field_op(curve, FR, "add", x, y)
+    want = add(add(mul(a, c), mul(a, d)), mul(b, c))
+    ctx.vec_rep3_mul_local(curve, out, da, db, dc, dd, None, n)
+    np.testing.assert_array_equal(out.download((n, 4)), want)
+    ctx.vec_rep3_mul_local(curve, out, da, db, dc, dd, dm, n)
+    np.testing.assert_array_equal(out.download((n, 4)), add(want, m))
+    np.testing.assert_array_equal(ctx.vec_rep3_mul_local_host(curve, a, b, c, d, m), add(want, m))
+    np.testing.assert_array_equal(ctx.vec_mul_host(curve, a, b), mul(a, b))
+    # in-place sub_assign (rep3.rs:672-679)
+    ctx.vec_sub(curve, da, da, db, n)
+    np.testing.assert_array_equal(da.download((n, 4)), orc.field_op(curve, FR, "sub", a, b))
+    # distribute_powers_and_mul_by_const (rep3.rs:681-688)
+    g, cst = orc.random_field(curve, FR, 2, rng)
+    ctx.vec_distribute_powers(curve, dc, n, g, cst)
+    np.testing.assert_array_equal(dc.download((n, 4)), orc.distribute_powers(curve, c, g, cst))
+
+
+# ------------------------------------------------------------------------------------------------ SpMV
+def rep3_share(curve, vals, rng):
+    a = orc.random_field(curve, FR, vals.shape[0], rng); b = orc.random_field(curve, FR, vals.shape[0], rng)
+    c = orc.field_op(curve, FR, "sub", orc.field_op(curve, FR, "sub", vals, a), b)
+    return [a, b, c], [c, a, b]
+
+
+def spmv_expected(curve, row_ptr, col, coeff, pub, party, wa, wb):
+    """rep3.rs:690-708 / plain.rs:243-258 evaluated with oracle field ops"""
+    n_rows = len(row_ptr) - 1
+    ninp = pub.shape[0]
+    out_a = np.zeros((n_rows, 4), dtype=np.uint64); out_b = np.zeros((n_rows, 4), dtype=np.uint64)
+    mul = lambda x, y: orc.field_op(curve, FR, "mul", x, y)
+    add = lambda x, y: orc.field_op(curve, FR, "add", x, y)
+    for r in range(n_rows):
+        for k in range(row_ptr[r], row_ptr[r + 1]):
+            idx = int(col[k])
+            if idx < ninp:
+                t = mul(coeff[k], pub[idx])
+                if party <= 0: out_a[r] = add(out_a[r], t)
+                elif party == 1: out_b[r] = add(out_b[r], t)
+            else:
+                out_a[r] = add(out_a[r], mul(coeff[k], wa[idx - ninp]))
+                if wb is not None: out_b[r] = add(out_b[r], mul(coeff[k], wb[idx - ninp]))
+    return out_a, out_b
+
+
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_spmv_poseidon_matrices(ctx, curve_name):
+    curve = {"bn254": BN254, "bls12_381": BLS12_381}[curve_name]
+    z = orc.ZKey(curve, os.path.join(GOLDEN, "groth16", curve_name, "poseidon", "circuit.zkey"))
+    w = orc.read_wtns(curve, os.path.join(GOLDEN, "groth16", curve_name, "poseidon", "witness.wtns"))
+    rng = np.random.default_rng(9)
+    pub = w[:z.n_public + 1]
+    wa, wb = rep3_share(curve, w[z.n_public + 1:], rng)
+    for m in (0, 1):
+        rp, col, co = z.matrix(m)
+        d_rp, d_col, d_co, d_pub = dev(ctx, rp), dev(ctx, col), dev(ctx, co), dev(ctx, pub)
+        oa, ob = ctx.alloc(z.num_constraints * 32), ctx.alloc(z.num_constraints * 32)
+        for party in (0, 1, 2):
+            ctx.spmv_csr(curve, d_rp, d_col, d_co, z.num_constraints, d_pub, z.n_public + 1, party, dev(ctx, wa[party]), dev(ctx, wb[party]), oa, ob)
+            ea, eb = spmv_expected(curve, rp, col, co, pub, party, wa[party], wb[party])
+            np.testing.assert_array_equal(oa.download((z.num_constraints, 4)), ea)
+            np.testing.assert_array_equal(ob.download((z.num_constraints, 4)), eb)
+        # single-component driver (plain / Shamir)
+        ctx.spmv_csr(curve, d_rp, d_col, d_co, z.num_constraints, d_pub, z.n_public + 1, -1, dev(ctx, w[z.n_public + 1:]), None, oa, None)
+        ea, _ = spmv_expected(curve, rp, col, co, pub, -1, w[z.n_public + 1:], None)
+        np.testing.assert_array_equal(oa.download((z.num_constraints, 4)), ea)
+
+
+# ------------------------------------------------------------------------------------------------ NTT
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
+@pytest.mark.parametrize("lg", [0, 1, 2, 5, 9, 10, 11, 12, 13, 16])
+def test_ntt_matches_oracle(ctx, curve, lg):
+    n = 1 << lg
+    rng = np.random.default_rng(200 + lg)
+    _, roots, _ = orc.roots_of_unity(curve)
+    w = roots[lg]
+    x = orc.random_field(curve, FR, n, rng); y = orc.random_field(curve, FR, n, rng)
+    fx, fy = ctx.ntt(curve, [x, y], w)
+    np.testing.assert_array_equal(fx, orc.ntt(curve, x, w)); np.testing.assert_array_equal(fy, orc.ntt(curve, y, w))
+    ix, = ctx.ntt(curve, [x], w, inverse=True)
+    np.testing.assert_array_equal(ix, orc.ntt(curve, x, w, inverse=True))
+    back, = ctx.ntt(curve, [fx], w, inverse=True)
+    np.testing.assert_array_equal(back, x)
+    # inverse fused with the coset shift: ifft then distribute_powers(g, 1)   (groth16.rs:175-186)
+    g = roots[lg + 1]
+    cx, = ctx.ntt(curve, [x], w, inverse=True, coset_gen=g)
+    np.testing.assert_array_equal(cx, orc.distribute_powers(curve, orc.ntt(curve, x, w, inverse=True), g, orc.from_dec(curve, FR, 1)))
+
+
+def test_ntt_large_roundtrip_and_linearity(ctx):
+    """size-independent properties at a BASELINE-scale length (2^20): iNTT(NTT(x)) == x and NTT(x+y) == NTT(x)+NTT(y)"""
+    curve, lg = BN254, 20
+    n = 1 << lg
+    rng = np.random.default_rng(7)
+    _, roots, _ = orc.roots_of_unity(curve)
+    x = orc.random_field(curve, FR, n, rng); y = orc.random_field(curve, FR, n, rng)
+    dx, dy, ds = dev(ctx, x), dev(ctx, y), ctx.alloc(n * 32)
+    ctx.vec_add(curve, ds, dx, dy, n)
+    ctx.ntt_dev(curve, [dx, dy, ds], n, roots[lg])
+    t = ctx.alloc(n * 32)
+    ctx.vec_add(curve, t, dx, dy, n)
+    np.testing.assert_array_equal(t.download((n, 4)), ds.download((n, 4)))
+    # spot-check 64 output positions against the definition sum_j x_j w^(jk), evaluated by the oracle on a decimated problem:
+    # X[k] for k multiple of n/64 equals the size-64 DFT of the 64-way folded input
+    acc = x.reshape(n // 64, 64, 4)
+    while acc.shape[0] > 1:
+        half = acc.shape[0] // 2
+        acc = orc.field_op(curve, FR, "add", acc[:half].reshape(-1, 4), acc[half:].reshape(-1, 4)).reshape(half, 64, 4)
+    acc = acc[0]
+    want = orc.ntt(curve, acc, roots[6])
+    got = dx.download((n, 4))[:: n // 64]
+    np.testing.assert_array_equal(got, want)
+    ctx.ntt_dev(curve, [dx], n, roots[lg], inverse=True)
+    np.testing.assert_array_equal(dx.download((n, 4)), x)
+
+
+# ------------------------------------------------------------------------------------------------ MSM
+def make_points(curve, group, n, rng):
+    ks = orc.random_field(curve, FR, n, rng)
+    return np.stack([orc.generator_mul(curve, group, k) for k in ks]) if n else np.zeros((0, orc.point_words(curve, group)), dtype=np.uint64)
+
+
+def msm_check(ctx, curve, group, pts, scalars_list, window=0):
+    bases = ctx.register_bases(curve, group, pts)
+    ctx.set_msm_window(window)
+    got = ctx.msm(bases, scalars_list)
+    ctx.set_msm_window(0)
+    for j, sc in enumerate(scalars_list):
+        want = orc.msm(curve, group, pts, sc, threads=8)
+        np.testing.assert_array_equal(cg.point_to_affine(curve, group, got[j]), want, err_msg=f"component {j}")
+        np.testing.assert_array_equal(orc.jacobian_to_affine(curve, group, got[j]), want)
+    bases.release()
+
+
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
+@pytest.mark.parametrize("group", [G1, G2])
+@pytest.mark.parametrize("n", [1, 2, 33, 700])
+def test_msm_random(ctx, curve, group, n):
+    rng = np.random.default_rng(300 + n + 10 * group + curve)
+    pts = make_points(curve, group, n, rng)
+    sa, sb = orc.random_field(curve, FR, n, rng), orc.random_field(curve, FR, n, rng)
+    msm_check(ctx, curve, group, pts, [sa, sb])
+
+
+@pytest.mark.parametrize("window", [2, 5, 9, 13, 16])
+def test_msm_window_sizes(ctx, window):
+    rng = np.random.default_rng(window)
+    pts = make_points(BN254, G1, 300, rng)
+    msm_check(ctx, BN254, G1, pts, [orc.random_field(BN254, FR, 300, rng)], window=window)
+
+
+@pytest.mark.parametrize("group", [G1, G2])
+def test_msm_edge_cases(ctx, group):
+    """infinity bases, zero / one / p-1 scalars, repeated and opposite points (zkey queries contain all of these)"""
+    curve = BN254
+    rng = np.random.default_rng(5)
+    n = 64
+    pts = make_points(curve, group, n, rng)
+    sc = orc.random_field(curve, FR, n, rng)
+    pts[3] = 0; pts[10] = 0                        # infinity
+    pts[5] = pts[4]; sc[5] = sc[4]                 # same point, same scalar -> forces the doubling branch in a bucket
+    pts[7] = pts[6]; sc[7] = orc.field_op(curve, FR, "sub", np.zeros(4, dtype=np.uint64), sc[6])   # P*s + P*(-s) = 0
+    sc[8] = 0
+    sc[9] = orc.from_dec(curve, FR, 1)
+    sc[11] = orc.from_dec(curve, FR, orc.MODULI[(curve, FR)] - 1)
+    sc[12] = orc.from_dec(curve, FR, 2**253)
+    msm_check(ctx, curve, group, pts, [sc])
+    # all-zero scalars and all-infinity bases give infinity
+    bases = ctx.register_bases(curve, group, pts)
+    z = ctx.msm(bases, [np.zeros((n, 4), dtype=np.uint64)])
+    assert not cg.point_to_affine(curve, group, z[0]).any()
+    bases.release()
+    bases = ctx.register_bases(curve, group, np.zeros_like(pts))
+    z = ctx.msm(bases, [sc])
+    assert not cg.point_to_affine(curve, group, z[0]).any()
+    # n == 0
+    z = ctx.msm(bases, [np.zeros((0, 4), dtype=np.uint64)], n=0)
+    assert not cg.point_to_affine(curve, group, z[0]).any()
+    bases.release()
+
+
+def test_msm_arkworks_struct_layout(ctx):
+    """bases handed over as arkworks `Affine{x, y, infinity: bool}` records: 72-byte stride, flag at offset 64"""
+    curve, n = BN254, 50
+    rng = np.random.default_rng(12)
+    pts = make_points(curve, G1, n, rng)
+    rec = np.zeros((n, 72), dtype=np.uint8)
+    rec[:, :64] = pts.view(np.uint8).reshape(n, 64)
+    rec[7, 64] = 1            # flagged infinity although coordinates are non-zero
+    pts_ref = pts.copy(); pts_ref[7] = 0
+    sc = orc.random_field(curve, FR, n, rng)
+    bases = ctx.register_bases(curve, G1, rec, stride=72, infinity_offset=64)
+    got = ctx.msm(bases, [sc])
+    np.testing.assert_array_equal(cg.point_to_affine(curve, G1, got[0]), orc.msm(curve, G1, pts_ref, sc))
+    # sub-slice like &query[1 + pub_len..]  (groth16.rs:221)
+    got = ctx.msm(bases, [sc[3:]], offset=3, n=n - 3)
+    np.testing.assert_array_equal(cg.point_to_affine(curve, G1, got[0]), orc.msm(curve, G1, pts_ref[3:], sc[3:]))
+    bases.release()
+
+
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_msm_on_real_zkey_queries(ctx, curve_name):
+    """the five MSMs of create_proof_with_assignment (groth16.rs:248-304) on the poseidon fixture, plain witness as scalars"""
+    curve = {"bn254": BN254, "bls12_381": BLS12_381}[curve_name]
+    z = orc.ZKey(curve, os.path.join(GOLDEN, "groth16", curve_name, "poseidon", "circuit.zkey"))
+    w = orc.read_wtns(curve, os.path.join(GOLDEN, "groth16", curve_name, "poseidon", "witness.wtns"))
+    aux = w[z.n_public + 1:]
+    h = z.witness_map_plain(w)
+    for q, group, sc, off in (("h_query", G1, h, 0), ("l_query", G1, aux, 0), ("a_query", G1, aux, 1 + z.n_public),
+                              ("b_g1_query", G1, aux, 1 + z.n_public), ("b_g2_query", G2, aux, 1 + z.n_public)):
+        pts = z.points(q)
+        bases = ctx.register_bases(curve, group, pts)
+        got = ctx.msm(bases, [sc], offset=off, n=sc.shape[0])
+        np.testing.assert_array_equal(cg.point_to_affine(curve, group, got[0]), orc.msm(curve, group, pts[off:off + sc.shape[0]], sc), err_msg=q)
+        bases.release()
+
+
+def test_msm_medium_and_linearity(ctx):
+    """2^14 points against the oracle, then 2^20 points through size-independent properties:
+    MSM(P, a) + MSM(P, b) == MSM(P, a+b) and MSM over a table of repeated points == (sum of scalars) * P"""
+    curve = BN254
+    rng = np.random.default_rng(77)
+    n = 1 << 14
+    pts = make_points(curve, G1, n, rng)
+    sa, sb = orc.random_field(curve, FR, n, rng), orc.random_field(curve, FR, n, rng)
+    msm_check(ctx, curve, G1, pts, [sa, sb])
+    big = 1 << 20
+    reps = big // n
+    pts_big = np.tile(pts, (reps, 1))
+    a = orc.random_field(curve, FR, big, rng); b = orc.random_field(curve, FR, big, rng)
+    bases = ctx.register_bases(curve, G1, pts_big)
+    da, db, ds = dev(ctx, a), dev(ctx, b), ctx.alloc(big * 32)
+    ctx.vec_add(curve, ds, da, db, big)
+    ra, rb, rs = ctx.msm_dev(bases, [da, db, ds], big)
+    lhs = cg.point_to_affine(curve, G1, cg.point_add(curve, G1, ra, rb))
+    np.testing.assert_array_equal(lhs, cg.point_to_affine(curve, G1, rs))
+    # fold the scalars of identical points on the CPU (oracle field adds) and compare with the 2^14-point oracle MSM
+    folded = a.reshape(reps, n, 4)[0].copy()
+    for r in range(1, reps):
+        folded = orc.field_op(curve, FR, "add", folded, a.reshape(reps, n, 4)[r])
+    np.testing.assert_array_equal(cg.point_to_affine(curve, G1, ra), orc.msm(curve, G1, pts, folded, threads=8))
+    bases.release()
+
+
+def test_msm_async_tickets(ctx):
+    curve = BN254
+    rng = np.random.default_rng(4)
+    n = 500
+    p1, p2 = make_points(curve, G1, n, rng), make_points(curve, G2, n, rng)
+    s = orc.random_field(curve, FR, n, rng)
+    b1, b2 = ctx.register_bases(curve, G1, p1), ctx.register_bases(curve, G2, p2)
+    ds = dev(ctx, s)
+    # NOTE: tickets share the context's scratch arena in stream order, so begin/begin/end/end is legal
+    t1 = ctx.msm_dev_begin(b1, [ds], n)
+    t2 = ctx.msm_dev_begin(b2, [ds], n)
+    r2 = ctx.msm_end(t2); r1 = ctx.msm_end(t1)
+    np.testing.assert_array_equal(cg.point_to_affine(curve, G1, r1[0]), orc.msm(curve, G1, p1, s))
+    np.testing.assert_array_equal(cg.point_to_affine(curve, G2, r2[0]), orc.msm(curve, G2, p2, s))
+    b1.release(); b2.release()
