@@ -36,7 +36,7 @@ def build(bls=True, jobs=8):
 
 # every symbol include/cogroth16_hip.h declares (checked by tests/test_abi_surface.py)
 ABI_SYMBOLS = [
-    "cg_ctx_create", "cg_ctx_destroy", "cg_ctx_sync", "cg_ctx_stream", "cg_last_error", "cg_version",
+    "cg_ctx_create", "cg_ctx_destroy", "cg_ctx_sync", "cg_ctx_stream", "cg_ctx_set_stream", "cg_last_error", "cg_version",
     "cg_dev_alloc", "cg_dev_free", "cg_dev_upload", "cg_dev_download", "cg_dev_memset_zero",
     "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len",
     "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_end", "cg_msm_set_window",
@@ -44,6 +44,8 @@ ABI_SYMBOLS = [
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev",
     "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
     "cg_point_add", "cg_point_neg", "cg_point_scalar_mul", "cg_point_to_affine", "cg_point_from_affine", "cg_fr_op",
+    "cg_fr_from_canonical", "cg_fr_to_canonical", "cg_point_generator",
+    "cg_bases_synth_multiples", "cg_bases_download",
     "cg_stats_enable", "cg_stats",
 ]
 
@@ -175,6 +177,10 @@ class Context:
     def stream(self):
         return load().cg_ctx_stream(self.h)
 
+    def set_stream(self, hip_stream):
+        """launch on a stream owned by the host application (e.g. torch.cuda.Stream().cuda_stream)"""
+        _chk(load().cg_ctx_set_stream(self.h, C.c_void_p(int(hip_stream))))
+
     # ---- memory
     def alloc(self, nbytes):
         return DevBuf(self, nbytes)
@@ -197,6 +203,17 @@ class Context:
         h = C.c_void_p()
         _chk(load().cg_bases_register_device(self.h, curve, group, _dp(d_points), C.c_size_t(n), C.byref(h)))
         return Bases(self, curve, group, h, n)
+
+    def synth_bases(self, curve, group, first, n):
+        """device-side table [(first+i)*G] (bench / test tooling)"""
+        h = C.c_void_p()
+        _chk(load().cg_bases_synth_multiples(self.h, curve, group, C.c_uint64(first), C.c_size_t(n), C.byref(h)))
+        return Bases(self, curve, group, h, n)
+
+    def bases_download(self, bases, offset, n):
+        out = np.zeros((n, point_words(bases.curve, bases.group, 2)), dtype=np.uint64)
+        _chk(load().cg_bases_download(self.h, bases.h, C.c_size_t(offset), C.c_size_t(n), _hp(out)))
+        return out
 
     def msm(self, bases, scalars, offset=0, n=None):
         """host scalars: list of k arrays (n,4) uint64 -> (k, 3*coord_words) Jacobian"""
@@ -285,7 +302,9 @@ class Context:
     def stats(self, reset=False):
         class ST(C.Structure):
             _fields_ = [("msm_ms", C.c_double), ("ntt_ms", C.c_double), ("vec_ms", C.c_double), ("spmv_ms", C.c_double),
-                        ("msm_calls", C.c_uint64), ("ntt_calls", C.c_uint64), ("vec_calls", C.c_uint64), ("spmv_calls", C.c_uint64)]
+                        ("msm_calls", C.c_uint64), ("ntt_calls", C.c_uint64), ("vec_calls", C.c_uint64), ("spmv_calls", C.c_uint64),
+                        ("msm_sort_ms", C.c_double), ("msm_acc_g1_ms", C.c_double), ("msm_acc_g2_ms", C.c_double), ("msm_reduce_ms", C.c_double),
+                        ("msm_sort_calls", C.c_uint64), ("msm_acc_g1_calls", C.c_uint64), ("msm_acc_g2_calls", C.c_uint64), ("msm_reduce_calls", C.c_uint64)]
         st = ST()
         _chk(load().cg_stats(self.h, C.byref(st), int(reset)))
         return {f: getattr(st, f) for f, _ in ST._fields_}

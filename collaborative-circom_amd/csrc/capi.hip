@@ -12,9 +12,10 @@ using namespace cg;
 
 // launchers living in msm_inst_*.hip / fr_inst_*.hip (explicit instantiations)
 namespace cg {
-template <class F, class Fr> int msm_enqueue(hipStream_t st, const Affine<F>* d_bases, size_t n, const Fr* d_scalars, int c, int nwin, char* arena_base, XYZZ<F>* h_out);
+template <class F, class Fr> int msm_enqueue(hipStream_t st, const Affine<F>* d_bases, size_t n, const Fr* d_scalars, int c, int nwin, char* arena_base, XYZZ<F>* h_out, hipEvent_t* evs);
 template <class F> size_t msm_scratch_bytes(size_t n, int c, int nwin);
 template <class F> int pack_bases_launch(hipStream_t st, const uint8_t* d_raw, size_t n, size_t stride, long inf_off, Affine<F>* d_dst);
+template <class F> int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi, int log_t, size_t n, Affine<F>* d_out);
 template <class Fr> int launch_vec_binary(hipStream_t st, int op, Fr* out, const Fr* a, const Fr* b, size_t n);
 template <class Fr> int launch_rep3_mul_local(hipStream_t st, Fr* out, const Fr* aa, const Fr* ab, const Fr* ba, const Fr* bb, const Fr* mask, size_t n);
 template <class Fr> int launch_distribute_powers(hipStream_t st, Fr* v, size_t n, const Fr* lo, const Fr* hi, int log_lo);
@@ -36,6 +37,9 @@ struct TwKey { int curve; int log_m; uint32_t gen[8]; bool operator<(const TwKey
 struct CosetKey { TwKey k; uint32_t scale[8]; bool operator<(const CosetKey& o) const { if (k < o.k) return true; if (o.k < k) return false; return memcmp(scale, o.scale, sizeof scale) < 0; } };
 struct CosetTables { void* lo; void* hi; int log_lo; };
 
+enum { TAG_MSM = 0, TAG_NTT, TAG_VEC, TAG_SPMV, TAG_SORT, TAG_ACC_G1, TAG_ACC_G2, TAG_REDUCE, TAG_COUNT };
+struct EvPair { hipEvent_t a, b; int tag; };
+
 struct MsmTicket {
     bool live = false;
     int curve = 0, group = 0, k = 0, c = 0, nwin = 0;
@@ -48,6 +52,7 @@ struct MsmTicket {
 struct cg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;
     Arena arena;
     std::map<TwKey, void*> twiddles;
     std::map<CosetKey, CosetTables> cosets;
@@ -55,7 +60,7 @@ struct cg_ctx {
     int msm_window = 0;
     bool stats_on = false;
     cg_stage_times stats{};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<EvPair> ev_live, ev_free;
 };
 
 struct cg_bases {
@@ -78,14 +83,20 @@ int ensure_arena(cg_ctx* ctx, size_t bytes) {
     return 0;
 }
 
+// non-blocking timing: a pair of events per measured span, drained in cg_stats()
+hipEvent_t ev_new(cg_ctx* ctx) { hipEvent_t e = nullptr; hipEventCreate(&e); return e; }
+int ev_open(cg_ctx* ctx, int tag) {
+    if (!ctx->stats_on) return -1;
+    EvPair p;
+    if (!ctx->ev_free.empty()) { p = ctx->ev_free.back(); ctx->ev_free.pop_back(); } else { p.a = ev_new(ctx); p.b = ev_new(ctx); }
+    p.tag = tag;
+    ctx->ev_live.push_back(p);
+    return (int)ctx->ev_live.size() - 1;
+}
 struct StatScope {
-    cg_ctx* ctx; double* ms; uint64_t* calls;
-    StatScope(cg_ctx* c, double* m, uint64_t* n) : ctx(c), ms(m), calls(n) { if (ctx->stats_on) hipEventRecord(ctx->ev0, ctx->stream); }
-    ~StatScope() {
-        if (!ctx->stats_on) return;
-        hipEventRecord(ctx->ev1, ctx->stream); hipEventSynchronize(ctx->ev1);
-        float t = 0; hipEventElapsedTime(&t, ctx->ev0, ctx->ev1); *ms += t; (*calls)++;
-    }
+    cg_ctx* ctx; int idx;
+    StatScope(cg_ctx* c, int tag) : ctx(c), idx(ev_open(c, tag)) { if (idx >= 0) hipEventRecord(ctx->ev_live[idx].a, ctx->stream); }
+    ~StatScope() { if (idx >= 0) hipEventRecord(ctx->ev_live[idx].b, ctx->stream); }
 };
 
 template <class Fn> int with_fr(int curve, Fn&& fn) {
@@ -155,14 +166,21 @@ int msm_begin_impl(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, 
         XYZZ<F>* h = (XYZZ<F>*)t.h_pinned;
         if (n == 0) { for (int i = 0; i < k * t.nwin; i++) h[i] = XYZZ<F>::infinity(); }
         else {
-            StatScope ss(ctx, &ctx->stats.msm_ms, &ctx->stats.msm_calls);
+            StatScope ss(ctx, TAG_MSM);
             const size_t per = msm_scratch_bytes<F>(n, t.c, t.nwin);
             if (extra_arena_off == 0) { int rc = ensure_arena(ctx, per); if (rc) return rc; }
             else if (extra_arena_off + per > ctx->arena.cap) return fail(CG_ERR_ARG, "internal: arena too small");
             const Affine<F>* pts = (const Affine<F>*)bases->d_pts + offset;
             for (int j = 0; j < k; j++) {
-                int rc = msm_enqueue<F, Fr>(ctx->stream, pts, n, (const Fr*)d_scalars[j], t.c, t.nwin, ctx->arena.base + extra_arena_off, h + (size_t)j * t.nwin);
-                if (rc) return rc;
+                if (ctx->stats_on) {
+                    const int i0 = ev_open(ctx, TAG_SORT), i1 = ev_open(ctx, bases->group == CG_G1 ? TAG_ACC_G1 : TAG_ACC_G2), i2 = ev_open(ctx, TAG_REDUCE);
+                    hipEvent_t evs[6] = {ctx->ev_live[i0].a, ctx->ev_live[i0].b, ctx->ev_live[i1].a, ctx->ev_live[i1].b, ctx->ev_live[i2].a, ctx->ev_live[i2].b};
+                    int rc = msm_enqueue<F, Fr>(ctx->stream, pts, n, (const Fr*)d_scalars[j], t.c, t.nwin, ctx->arena.base + extra_arena_off, h + (size_t)j * t.nwin, evs);
+                    if (rc) return rc;
+                } else {
+                    int rc = msm_enqueue<F, Fr>(ctx->stream, pts, n, (const Fr*)d_scalars[j], t.c, t.nwin, ctx->arena.base + extra_arena_off, h + (size_t)j * t.nwin, nullptr);
+                    if (rc) return rc;
+                }
             }
         }
         HIPCHK(hipEventRecord(t.done, ctx->stream));
@@ -304,7 +322,7 @@ int32_t vec_binary(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_a, con
     HIPCHK(hipSetDevice(ctx->device));
     return with_fr(curve, [&](auto tag) -> int {
         typedef decltype(tag) Fr;
-        StatScope ss(ctx, &ctx->stats.vec_ms, &ctx->stats.vec_calls);
+        StatScope ss(ctx, TAG_VEC);
         return launch_vec_binary<Fr>(ctx->stream, OP, (Fr*)d_out, (const Fr*)d_a, (const Fr*)d_b, n);
     });
 }
@@ -325,7 +343,6 @@ int32_t cg_ctx_create(int32_t device, cg_ctx** out) {
     cg_ctx* c = new cg_ctx();
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
     *out = c;
     return 0;
 }
@@ -337,13 +354,22 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
     for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.done) hipEventDestroy(t.done); }
     if (ctx->arena.base) hipFree(ctx->arena.base);
-    hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
-    hipStreamDestroy(ctx->stream);
+    for (auto& p : ctx->ev_live) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
+    for (auto& p : ctx->ev_free) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
+    if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
 }
 int32_t cg_ctx_sync(cg_ctx* ctx) { if (!ctx) return fail(CG_ERR_ARG, "null ctx"); HIPCHK(hipStreamSynchronize(ctx->stream)); return 0; }
 void* cg_ctx_stream(cg_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int32_t cg_ctx_set_stream(cg_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->owns_stream) HIPCHK(hipStreamDestroy(ctx->stream));
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->owns_stream = false;
+    return 0;
+}
 
 int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr) {
     if (!ctx || !d_ptr) return fail(CG_ERR_ARG, "null argument");
@@ -422,6 +448,46 @@ int32_t cg_bases_release(cg_bases* b) {
 }
 size_t cg_bases_len(const cg_bases* b) { return b ? b->n : 0; }
 
+int32_t cg_bases_synth_multiples(cg_ctx* ctx, int32_t curve, int32_t group, uint64_t first, size_t n, cg_bases** out) {
+    if (!ctx || !out) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_group(curve, group, [&](auto ftag, auto) -> int {
+        typedef decltype(ftag) F;
+        const uint32_t* src = curve == CG_BN254 ? (group == CG_G1 ? Bn254G1_GEN : Bn254G2_GEN) : (group == CG_G1 ? Bls381G1_GEN : Bls381G2_GEN);
+        Affine<F> ga; memcpy(&ga, src, sizeof ga);
+        const XYZZ<F> G = XYZZ<F>::from_affine(ga);
+        int log_t = 0; while (((size_t)1 << (2 * log_t)) < n) log_t++;          // ~sqrt(n) entries per table
+        const size_t T = (size_t)1 << log_t, H = std::max<size_t>(1, (n + T - 1) >> log_t);
+        std::vector<XYZZ<F>> lo(T), hi(H);
+        uint32_t k[2] = {(uint32_t)first, (uint32_t)(first >> 32)};
+        XYZZ<F> acc = xyzz_scalar_mul(G, k, 2);
+        for (size_t j = 0; j < T; j++) { lo[j] = acc; acc = xyzz_add(acc, G); }
+        uint32_t kt[2] = {(uint32_t)T, (uint32_t)((uint64_t)T >> 32)};
+        const XYZZ<F> step = xyzz_scalar_mul(G, kt, 2);
+        acc = XYZZ<F>::infinity();
+        for (size_t j = 0; j < H; j++) { hi[j] = acc; acc = xyzz_add(acc, step); }
+        XYZZ<F>*d_lo = nullptr, *d_hi = nullptr;
+        HIPCHK(hipMalloc((void**)&d_lo, T * sizeof(XYZZ<F>))); HIPCHK(hipMalloc((void**)&d_hi, H * sizeof(XYZZ<F>)));
+        HIPCHK(hipMemcpy(d_lo, lo.data(), T * sizeof(XYZZ<F>), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_hi, hi.data(), H * sizeof(XYZZ<F>), hipMemcpyHostToDevice));
+        cg_bases* b = new cg_bases{ctx->device, curve, group, n, sizeof(Affine<F>), nullptr};
+        HIPCHK(hipMalloc(&b->d_pts, std::max<size_t>(n * sizeof(Affine<F>), 16)));
+        int rc = synth_points_launch<F>(ctx->stream, d_lo, d_hi, log_t, n, (Affine<F>*)b->d_pts);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(d_lo)); HIPCHK(hipFree(d_hi));
+        *out = b;
+        return 0;
+    });
+}
+int32_t cg_bases_download(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, void* h_out_packed) {
+    if (!ctx || !bases || !h_out_packed) return fail(CG_ERR_ARG, "null argument");
+    if (offset + n > bases->n) return fail(CG_ERR_ARG, "slice out of range");
+    HIPCHK(hipMemcpyAsync(h_out_packed, (const char*)bases->d_pts + offset * bases->pt_bytes, n * bases->pt_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int32_t cg_msm_set_window(cg_ctx* ctx, int32_t c) {
     if (!ctx) return fail(CG_ERR_ARG, "null ctx");
     if (c != 0 && (c < 2 || c > 20)) return fail(CG_ERR_ARG, "window size must be 0 (auto) or in [2, 20]");
@@ -463,7 +529,7 @@ int32_t cg_ntt_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, int32_t k, s
         Fr gen, cos; copy_in(gen, h_group_gen);
         if (h_coset_gen) copy_in(cos, h_coset_gen);
         if (n > 1) { int rc = ensure_arena(ctx, (size_t)k * n * sizeof(Fr)); if (rc) return rc; }
-        StatScope ss(ctx, &ctx->stats.ntt_ms, &ctx->stats.ntt_calls);
+        StatScope ss(ctx, TAG_NTT);
         return ntt_run<Fr>(ctx, curve, d_vecs, k, n, gen, inverse != 0, h_coset_gen ? &cos : nullptr, 0);
     });
 }
@@ -490,7 +556,7 @@ int32_t cg_vec_rep3_mul_local_dev(cg_ctx* ctx, int32_t curve, void* d_out, const
     HIPCHK(hipSetDevice(ctx->device));
     return with_fr(curve, [&](auto tag) -> int {
         typedef decltype(tag) Fr;
-        StatScope ss(ctx, &ctx->stats.vec_ms, &ctx->stats.vec_calls);
+        StatScope ss(ctx, TAG_VEC);
         return launch_rep3_mul_local<Fr>(ctx->stream, (Fr*)d_out, (const Fr*)d_aa, (const Fr*)d_ab, (const Fr*)d_ba, (const Fr*)d_bb, (const Fr*)d_mask, n);
     });
 }
@@ -505,7 +571,7 @@ int32_t cg_vec_distribute_powers_dev(cg_ctx* ctx, int32_t curve, void* d_v, size
         CosetTables t;
         int rc = get_coset_tables<Fr>(ctx, curve, log_m, g, c, &t);
         if (rc) return rc;
-        StatScope ss(ctx, &ctx->stats.vec_ms, &ctx->stats.vec_calls);
+        StatScope ss(ctx, TAG_VEC);
         return launch_distribute_powers<Fr>(ctx->stream, (Fr*)d_v, n, (const Fr*)t.lo, (const Fr*)t.hi, t.log_lo);
     });
 }
@@ -517,7 +583,7 @@ int32_t cg_spmv_csr_dev(cg_ctx* ctx, int32_t curve, const uint32_t* d_row_ptr, c
     HIPCHK(hipSetDevice(ctx->device));
     return with_fr(curve, [&](auto tag) -> int {
         typedef decltype(tag) Fr;
-        StatScope ss(ctx, &ctx->stats.spmv_ms, &ctx->stats.spmv_calls);
+        StatScope ss(ctx, TAG_SPMV);
         return launch_spmv_csr<Fr>(ctx->stream, d_row_ptr, d_col, (const Fr*)d_coeff, n_rows, (const Fr*)d_pub, n_inputs, (int)party,
                                    (const Fr*)d_wit_a, (const Fr*)d_wit_b, (Fr*)d_out_a, (Fr*)d_out_b);
     });
@@ -597,9 +663,58 @@ int32_t cg_fr_op(int32_t curve, int32_t op, const void* h_a, const void* h_b, vo
     });
 }
 
+int32_t cg_fr_from_canonical(int32_t curve, const void* h_in, void* h_out, size_t n) {
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        const uint8_t* in = (const uint8_t*)h_in; uint8_t* out = (uint8_t*)h_out;
+        for (size_t i = 0; i < n; i++) {
+            Fr a; memcpy(a.v, in + i * sizeof a.v, sizeof a.v);
+            // reduce: top limb of r has >= 2 spare... subtract r while a >= r (at most 7 times for 256-bit inputs)
+            for (int it = 0; it < 8; it++) {
+                uint32_t d[Fr::N]; uint32_t borrow = 0;
+                for (int l = 0; l < Fr::N; l++) { uint64_t x = (uint64_t)a.v[l] - Fr::Params::P[l] - borrow; d[l] = (uint32_t)x; borrow = (uint32_t)(x >> 32) & 1u; }
+                if (borrow) break;
+                for (int l = 0; l < Fr::N; l++) a.v[l] = d[l];
+            }
+            Fr m = a.to_mont();
+            memcpy(out + i * sizeof a.v, m.v, sizeof m.v);
+        }
+        return 0;
+    });
+}
+int32_t cg_fr_to_canonical(int32_t curve, const void* h_in, void* h_out, size_t n) {
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        const uint8_t* in = (const uint8_t*)h_in; uint8_t* out = (uint8_t*)h_out;
+        for (size_t i = 0; i < n; i++) { Fr a; memcpy(a.v, in + i * sizeof a.v, sizeof a.v); Fr c = a.from_mont(); memcpy(out + i * sizeof a.v, c.v, sizeof c.v); }
+        return 0;
+    });
+}
+int32_t cg_point_generator(int32_t curve, int32_t group, void* h_out) {
+    return with_group(curve, group, [&](auto ftag, auto) -> int {
+        typedef decltype(ftag) F;
+        const uint32_t* src = curve == CG_BN254 ? (group == CG_G1 ? Bn254G1_GEN : Bn254G2_GEN) : (group == CG_G1 ? Bls381G1_GEN : Bls381G2_GEN);
+        Affine<F> a; memcpy(&a, src, sizeof a);
+        Jacobian<F> r = xyzz_to_jacobian(XYZZ<F>::from_affine(a));
+        memcpy(h_out, &r, sizeof r); return 0;
+    });
+}
+
 int32_t cg_stats_enable(cg_ctx* ctx, int32_t on) { if (!ctx) return fail(CG_ERR_ARG, "null ctx"); ctx->stats_on = on != 0; return 0; }
 int32_t cg_stats(cg_ctx* ctx, cg_stage_times* out, int32_t reset) {
     if (!ctx || !out) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    double* ms[TAG_COUNT] = {&ctx->stats.msm_ms, &ctx->stats.ntt_ms, &ctx->stats.vec_ms, &ctx->stats.spmv_ms,
+                             &ctx->stats.msm_sort_ms, &ctx->stats.msm_acc_g1_ms, &ctx->stats.msm_acc_g2_ms, &ctx->stats.msm_reduce_ms};
+    uint64_t* calls[TAG_COUNT] = {&ctx->stats.msm_calls, &ctx->stats.ntt_calls, &ctx->stats.vec_calls, &ctx->stats.spmv_calls,
+                                  &ctx->stats.msm_sort_calls, &ctx->stats.msm_acc_g1_calls, &ctx->stats.msm_acc_g2_calls, &ctx->stats.msm_reduce_calls};
+    for (size_t i = 0; i < ctx->ev_live.size(); i++) {
+        EvPair& p = ctx->ev_live[i];
+        float t = 0;
+        if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { *ms[p.tag] += t; (*calls[p.tag])++; }
+    }
+    for (auto& p : ctx->ev_live) ctx->ev_free.push_back(p);
+    ctx->ev_live.clear();
     *out = ctx->stats;
     if (reset) ctx->stats = cg_stage_times{};
     return 0;

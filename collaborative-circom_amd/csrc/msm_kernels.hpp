@@ -176,4 +176,18 @@ __global__ void __launch_bounds__(256) k_pack_bases(const uint8_t* __restrict__ 
     }
 }
 
+
+// Synthetic point tables (bench / test tooling, not on the prover path): out[i] = affine(hi[i >> log_t] + lo[i & (2^log_t-1)]).
+// With lo[j] = (first+j)*P and hi[j] = (j << log_t)*P this yields the consecutive multiples (first+i)*P — valid, pairwise
+// distinct curve points whose discrete logs are known, so an MSM over them can be checked at any size:
+// sum_i s_i (first+i) P = (sum_i s_i (first+i)) P.
+template <class F>
+__global__ void __launch_bounds__(256) k_synth_points(const XYZZ<F>* __restrict__ lo, const XYZZ<F>* __restrict__ hi, int log_t, size_t n, Affine<F>* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        XYZZ<F> a = ld_struct(lo + (i & (((size_t)1 << log_t) - 1)));
+        XYZZ<F> b = ld_struct(hi + (i >> log_t));
+        st_struct(out + i, xyzz_to_affine(xyzz_add(a, b)));
+    }
+}
+
 }  // namespace cg

@@ -45,6 +45,9 @@ int32_t cg_ctx_create(int32_t device, cg_ctx** out);
 int32_t cg_ctx_destroy(cg_ctx* ctx);
 int32_t cg_ctx_sync(cg_ctx* ctx);
 void*   cg_ctx_stream(cg_ctx* ctx);                 /* the hipStream_t every launch of this context goes to */
+/* make the context launch on a stream owned by the host application (e.g. the stream its other GPU work runs on), so that
+ * no cross-stream synchronisation is needed between the host's own kernels/copies and this library's. */
+int32_t cg_ctx_set_stream(cg_ctx* ctx, void* hip_stream);
 const char* cg_last_error(void);
 const char* cg_version(void);
 
@@ -118,11 +121,27 @@ int32_t cg_point_to_affine(int32_t curve, int32_t group, const void* h_a, void* 
 int32_t cg_point_from_affine(int32_t curve, int32_t group, const void* h_affine, void* h_out);
 /* O(1) scalar-field helpers used by the host drivers (Montgomery in/out): op 0 add, 1 sub, 2 mul, 3 inverse(a) */
 int32_t cg_fr_op(int32_t curve, int32_t op, const void* h_a, const void* h_b, void* h_out);
+/* canonical little-endian integers (wtns values, circom-types/src/witness.rs:51-91) <-> Montgomery form; n elements, host.
+ * cg_fr_from_canonical reduces mod r first (from_le_bytes_mod_order, traits.rs:50-54). */
+int32_t cg_fr_from_canonical(int32_t curve, const void* h_in, void* h_out, size_t n);
+int32_t cg_fr_to_canonical(int32_t curve, const void* h_in, void* h_out, size_t n);
+/* generator of G1/G2 as a Jacobian point (ark-bn254 / ark-bls12-381 constants) */
+int32_t cg_point_generator(int32_t curve, int32_t group, void* h_out);
 
-/* ---- statistics (per context, milliseconds of GPU time since the last reset, measured with HIP events) --------- */
+/* ---- tooling (bench / tests; not on the prover path) ----------------------------------------------------------- */
+/* Builds, on the device, the table [(first + i) * G]_{i<n} of consecutive multiples of the group generator: valid,
+ * pairwise distinct points with known discrete logs, used as synthetic zkey-sized bases. */
+int32_t cg_bases_synth_multiples(cg_ctx* ctx, int32_t curve, int32_t group, uint64_t first, size_t n, cg_bases** out);
+/* copies n packed affine points of a table back to the host */
+int32_t cg_bases_download(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, void* h_out_packed);
+
+/* ---- statistics: GPU time per kernel class since the last reset, from HIP event pairs recorded on the context's stream
+ * (non-blocking while running; cg_stats() synchronises the stream and drains them).  *_ms are sums, *_calls are counts. */
 typedef struct cg_stage_times {
-    double msm_ms, ntt_ms, vec_ms, spmv_ms;
+    double msm_ms, ntt_ms, vec_ms, spmv_ms;                 /* whole calls */
     uint64_t msm_calls, ntt_calls, vec_calls, spmv_calls;
+    double msm_sort_ms, msm_acc_g1_ms, msm_acc_g2_ms, msm_reduce_ms;   /* inside the MSM: digits+scan+scatter / bucket accumulation / bucket reduction */
+    uint64_t msm_sort_calls, msm_acc_g1_calls, msm_acc_g2_calls, msm_reduce_calls;
 } cg_stage_times;
 int32_t cg_stats_enable(cg_ctx* ctx, int32_t on);
 int32_t cg_stats(cg_ctx* ctx, cg_stage_times* out, int32_t reset);

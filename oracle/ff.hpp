@@ -163,31 +163,39 @@ struct Fp {
     Fp operator-() const { if (is_zero()) return *this; Fp r; raw_sub<N>(r.v, K.p, v); return r; }
     Fp dbl() const { return *this + *this; }
 
-    // Montgomery product: full 2N-limb schoolbook product, then N rounds of word REDC.
+    // Montgomery product: full 2N-limb schoolbook product, then N rounds of word REDC (loops fully unrolled by the
+    // compiler for the fixed N; p < 2^(64N-1) so the running value never needs more than 2N limbs + the final compare).
     Fp operator*(const Fp& o) const {
-        uint64_t t[2 * N + 1];
-        memset(t, 0, sizeof t);
+        uint64_t t[2 * N];
+#pragma GCC unroll 16
+        for (int j = 0; j < 2 * N; j++) t[j] = 0;
+#pragma GCC unroll 16
         for (int i = 0; i < N; i++) {
-            u128 c = 0;
+            uint64_t c = 0;
+#pragma GCC unroll 16
             for (int j = 0; j < N; j++) {
-                c += (u128)v[i] * o.v[j] + t[i + j];
-                t[i + j] = (uint64_t)c; c >>= 64;
+                u128 x = (u128)v[i] * o.v[j] + t[i + j] + c;
+                t[i + j] = (uint64_t)x; c = (uint64_t)(x >> 64);
             }
-            t[i + N] = (uint64_t)c;
+            t[i + N] = c;
         }
+        uint64_t carry = 0;
+#pragma GCC unroll 16
         for (int i = 0; i < N; i++) {
             uint64_t m = t[i] * K.inv;
-            u128 c = 0;
+            uint64_t c = 0;
+#pragma GCC unroll 16
             for (int j = 0; j < N; j++) {
-                c += (u128)m * K.p[j] + t[i + j];
-                t[i + j] = (uint64_t)c; c >>= 64;
+                u128 x = (u128)m * K.p[j] + t[i + j] + c;
+                t[i + j] = (uint64_t)x; c = (uint64_t)(x >> 64);
             }
-            for (int k = i + N; c && k <= 2 * N; k++) {
-                c += t[k]; t[k] = (uint64_t)c; c >>= 64;
-            }
+            u128 x = (u128)t[i + N] + c + carry;
+            t[i + N] = (uint64_t)x; carry = (uint64_t)(x >> 64);
         }
-        Fp r; memcpy(r.v, t + N, sizeof r.v);
-        if (t[2 * N] || raw_cmp<N>(r.v, K.p) >= 0) raw_sub<N>(r.v, r.v, K.p);
+        Fp r;
+#pragma GCC unroll 16
+        for (int j = 0; j < N; j++) r.v[j] = t[N + j];
+        if (carry || raw_cmp<N>(r.v, K.p) >= 0) raw_sub<N>(r.v, r.v, K.p);
         return r;
     }
     Fp sqr() const { return (*this) * (*this); }

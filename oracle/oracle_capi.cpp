@@ -4,6 +4,7 @@
 // field elements = N x u64 little-endian Montgomery limbs; G1 affine = x||y, G2 affine = x.c0||x.c1||y.c0||y.c1
 // with (0,0) = infinity (the packed zkey encoding, `/root/reference/co-circom/circom-types/src/traits.rs:107-155`).
 #include "pairing.hpp"
+#include "bench.hpp"
 #include <chrono>
 
 using namespace orc;
@@ -329,6 +330,15 @@ int orc_pairing_selfcheck(int curve, const uint64_t* scalar) {
         return (e1 == e2 && !(e0 == Fp12T<C>::one())) ? 1 : 0;
     });
     return 0;
+}
+
+// bench.py cpu_baseline leg: seconds for one REP3 party's prove compute at m = 2^log_m (stage = 4 doubles, optional)
+double orc_bench_rep3_party(int curve, int log_m, int threads, uint64_t seed, double* stage) {
+    try {
+        if (curve == 0) return bench_rep3_party<Bn254>(log_m, threads, seed, stage);
+        if (curve == 1) return bench_rep3_party<Bls12_381>(log_m, threads, seed, stage);
+        g_err = "bad curve id"; return -1.0;
+    } catch (const std::exception& e) { g_err = e.what(); return -2.0; }
 }
 
 }  // extern "C"

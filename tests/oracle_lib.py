@@ -23,7 +23,7 @@ def build(force=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB_PATH,
+    subprocess.check_call(["g++", "-O3", "-mbmi2", "-madx", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB_PATH,
                            os.path.join(ORACLE_DIR, "oracle_capi.cpp")])
     return LIB_PATH
 
@@ -248,6 +248,16 @@ def verify(curve, vk, pub, proof):
 
 def pairing_selfcheck(curve, scalar):
     return bool(_chk(lib().orc_pairing_selfcheck(curve, _p(np.ascontiguousarray(scalar, dtype=np.uint64)))))
+
+
+def bench_rep3_party(curve, log_m, threads, seed=1):
+    """cpu_baseline workload: seconds for one REP3 party's prove compute at m = 2^log_m (+ per-stage seconds)"""
+    lib().orc_bench_rep3_party.restype = C.c_double
+    stage = (C.c_double * 4)()
+    t = lib().orc_bench_rep3_party(curve, int(log_m), int(threads), C.c_uint64(seed), stage)
+    if t < 0:
+        raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+    return t, {"spmv_pointwise_s": stage[0], "ntt_s": stage[1], "msm_g1_s": stage[2], "msm_g2_s": stage[3]}
 
 
 # ---- snarkjs JSON <-> packed arrays ---------------------------------------------------------------
