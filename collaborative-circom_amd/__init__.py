@@ -345,3 +345,63 @@ def fr_op(curve, op, a, b=None):
     out = np.zeros(4, dtype=np.uint64)
     _chk(load().cg_fr_op(curve, {"add": 0, "sub": 1, "mul": 2, "inv": 3}[op], _hp(np.ascontiguousarray(a)), _hp(None if b is None else np.ascontiguousarray(b)), _hp(out)))
     return out
+
+
+# ---- host-side mirror of the reference prover interface (libcogroth16_host.so, C++ over the C ABI) -----------------------
+_host = None
+
+
+def load_host():
+    global _host
+    if _host is None:
+        load()
+        if not os.path.exists(HOST_LIB_PATH):
+            raise BackendError(f"{HOST_LIB_PATH} is missing: build it with `make -C collaborative-circom_amd/host`")
+        _host = C.CDLL(HOST_LIB_PATH)
+        _host.cgh_last_error.restype = C.c_char_p
+    return _host
+
+
+def _hchk(rc):
+    if rc != 0:
+        raise BackendError("cogroth16_host: " + load_host().cgh_last_error().decode())
+
+
+def host_zkey_info(curve, path):
+    info = (C.c_size_t * 7)()
+    _hchk(load_host().cgh_zkey_info(curve, path.encode(), info))
+    keys = ("n_vars", "n_public", "domain_size", "pow", "num_constraints", "nnz_a", "nnz_b")
+    return dict(zip(keys, [int(x) for x in info]))
+
+
+def host_read_wtns(curve, path):
+    n = C.c_size_t(0)
+    _hchk(load_host().cgh_read_wtns(curve, path.encode(), None, C.c_size_t(0), C.byref(n)))
+    out = np.zeros((n.value, 4), dtype=np.uint64)
+    _hchk(load_host().cgh_read_wtns(curve, path.encode(), _hp(out), C.c_size_t(n.value), C.byref(n)))
+    return out
+
+
+def prove_plain(curve, zkey_path, full_witness, r, s, device=0, want_h=False):
+    """PlainHipDriver + CoGroth16::prove; returns packed proof A||B||C (and the h vector)"""
+    info = host_zkey_info(curve, zkey_path)
+    w = np.ascontiguousarray(full_witness, dtype=np.uint64)
+    out = np.zeros(8 * fq_limbs(curve), dtype=np.uint64)
+    h = np.zeros((info["domain_size"], 4), dtype=np.uint64) if want_h else None
+    _hchk(load_host().cgh_prove_plain(int(device), curve, zkey_path.encode(), _hp(w), _hp(np.ascontiguousarray(r, dtype=np.uint64)),
+                                      _hp(np.ascontiguousarray(s, dtype=np.uint64)), _hp(out), _hp(h)))
+    return (out, h) if want_h else out
+
+
+def prove_rep3(curve, zkey_path, pub, wit_a, wit_b, streams, device=0, want_h=False):
+    """three Rep3HipProtocol parties on three threads over the in-process network; returns the three proofs"""
+    info = host_zkey_info(curve, zkey_path)
+    pub = np.ascontiguousarray(pub, dtype=np.uint64)
+    wa = [np.ascontiguousarray(x, dtype=np.uint64) for x in wit_a]
+    wb = [np.ascontiguousarray(x, dtype=np.uint64) for x in wit_b]
+    st = [np.ascontiguousarray(x, dtype=np.uint64) for x in streams]
+    arr = lambda xs: (C.c_void_p * 3)(*[x.ctypes.data for x in xs])
+    out = np.zeros((3, 8 * fq_limbs(curve)), dtype=np.uint64)
+    h = np.zeros((2, info["domain_size"], 4), dtype=np.uint64) if want_h else None
+    _hchk(load_host().cgh_prove_rep3(int(device), curve, zkey_path.encode(), _hp(pub), arr(wa), arr(wb), arr(st), C.c_size_t(st[0].shape[0]), _hp(out), _hp(h)))
+    return (out, h) if want_h else out

@@ -1,0 +1,551 @@
+// Host-side mirror of the reference's prover interface for the co-groth16 path, written ONLY against the C ABI
+// (include/cogroth16_hip.h) — i.e. it does what a Rust driver crate bound to that ABI would do:
+//
+//   HipDriver  (modes Plain / Rep3)  ~  PlainDriver `mpc-core/src/protocols/plain.rs`, Rep3Protocol `mpc-core/src/protocols/rep3.rs`
+//       method names, argument meaning and party-id asymmetries follow the traits of `mpc-core/src/traits.rs`
+//       (PrimeFieldMpcProtocol :43, EcMpcProtocol :472, PairingEcMpcProtocol :525, FFTProvider :535, MSMProvider :561);
+//       vectors are DEVICE-resident share vectors (SoA, like Rep3PrimeFieldShareVec `rep3/fieldshare.rs:233-236`).
+//   CoGroth16::prove                 ~  `co-circom/co-groth16/src/groth16.rs:113-326` (same call sequence, line refs inline)
+//   Rep3Network / InProcNetwork      ~  `mpc-core/src/protocols/rep3/network.rs:30-64` and the in-process test network
+//                                       `tests/src/rep3_network.rs` (three parties on three threads, one queue per edge)
+//   read_zkey / read_wtns            ~  `circom-types/src/groth16/zkey.rs:139-316`, `binfile.rs:52-97`, `witness.rs:51-91`
+//
+// Everything O(n) runs on the GPU through the ABI; this file only sequences calls, moves the two `mul_vec` messages and the
+// O(1) points between parties, and does O(1) scalar/point algebra through the ABI's host helpers.  No CPU fallback exists.
+#include "cogroth16_hip.h"
+
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace cgh {
+
+typedef std::vector<uint8_t> Bytes;
+struct Fr { uint64_t v[4]; };
+
+[[noreturn]] static void die(const std::string& what) { throw std::runtime_error(what + ": " + cg_last_error()); }
+#define CG(call) do { if ((call) != 0) die(#call); } while (0)
+
+struct Curve {
+    int id;
+    size_t fq() const { return id == CG_BLS12_381 ? 48 : 32; }
+    size_t aff(int g) const { return fq() * (g == CG_G1 ? 2 : 4); }
+    size_t jac(int g) const { return fq() * (g == CG_G1 ? 3 : 6); }
+};
+
+// ---- O(1) algebra through the ABI's host helpers ----------------------------------------------------------------
+static Fr fr_op(const Curve& c, int op, const Fr& a, const Fr* b = nullptr) { Fr r; CG(cg_fr_op(c.id, op, a.v, b ? b->v : nullptr, r.v)); return r; }
+static Fr fr_add(const Curve& c, const Fr& a, const Fr& b) { return fr_op(c, 0, a, &b); }
+static Fr fr_sub(const Curve& c, const Fr& a, const Fr& b) { return fr_op(c, 1, a, &b); }
+static Fr fr_mul(const Curve& c, const Fr& a, const Fr& b) { return fr_op(c, 2, a, &b); }
+static Fr fr_inv(const Curve& c, const Fr& a) { return fr_op(c, 3, a); }
+static Fr fr_from_u64(const Curve& c, uint64_t x) { Fr raw = {{x, 0, 0, 0}}, r; CG(cg_fr_from_canonical(c.id, raw.v, r.v, 1)); return r; }
+static bool fr_eq(const Fr& a, const Fr& b) { return memcmp(a.v, b.v, 32) == 0; }
+static Fr fr_pow(const Curve& c, Fr base, const uint64_t* e, int nlimbs) {
+    Fr r = fr_from_u64(c, 1);
+    for (int i = nlimbs * 64 - 1; i >= 0; i--) { r = fr_mul(c, r, r); if ((e[i / 64] >> (i % 64)) & 1) r = fr_mul(c, r, base); }
+    return r;
+}
+
+struct Point { Bytes b; int group; };   // Jacobian, Montgomery
+static Point pt_from_affine(const Curve& c, int g, const uint8_t* aff) { Point p{Bytes(c.jac(g)), g}; CG(cg_point_from_affine(c.id, g, aff, p.b.data())); return p; }
+static Point pt_inf(const Curve& c, int g) { Bytes z(c.aff(g), 0); return pt_from_affine(c, g, z.data()); }
+static Point pt_add(const Curve& c, const Point& a, const Point& b) { Point r{Bytes(a.b.size()), a.group}; CG(cg_point_add(c.id, a.group, a.b.data(), b.b.data(), r.b.data())); return r; }
+static Point pt_neg(const Curve& c, const Point& a) { Point r{Bytes(a.b.size()), a.group}; CG(cg_point_neg(c.id, a.group, a.b.data(), r.b.data())); return r; }
+static Point pt_sub(const Curve& c, const Point& a, const Point& b) { return pt_add(c, a, pt_neg(c, b)); }
+static Point pt_mul(const Curve& c, const Point& a, const Fr& k) { Point r{Bytes(a.b.size()), a.group}; CG(cg_point_scalar_mul(c.id, a.group, a.b.data(), k.v, r.b.data())); return r; }
+static Bytes pt_to_affine(const Curve& c, const Point& a) { Bytes r(c.aff(a.group)); CG(cg_point_to_affine(c.id, a.group, a.b.data(), r.data())); return r; }
+static Point pt_generator(const Curve& c, int g) { Point p{Bytes(c.jac(g)), g}; CG(cg_point_generator(c.id, g, p.b.data())); return p; }
+
+// ---- file formats ----------------------------------------------------------------------------------------------------
+struct Cursor {
+    const uint8_t* p; size_t n, off = 0;
+    void need(size_t k) const { if (off + k > n) throw std::runtime_error("unexpected end of section"); }
+    uint32_t u32() { need(4); uint32_t x; memcpy(&x, p + off, 4); off += 4; return x; }
+    uint64_t u64() { need(8); uint64_t x; memcpy(&x, p + off, 8); off += 8; return x; }
+    void bytes(void* d, size_t k) { need(k); memcpy(d, p + off, k); off += k; }
+};
+static Bytes slurp(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    Bytes b((size_t)n);
+    if (n && fread(b.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); throw std::runtime_error("short read"); }
+    fclose(f);
+    return b;
+}
+static const uint64_t MOD_R[2][4] = {{0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull},
+                                     {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull}};
+static const uint64_t MOD_Q[2][6] = {{0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull, 0, 0},
+                                     {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull, 0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull}};
+
+struct ZKey {   // zkey.rs:48-71; points kept in the packed on-disk form (x||y Montgomery, (0,0) = infinity) the ABI accepts directly
+    Curve curve;
+    size_t n_vars = 0, n_public = 0, domain_size = 0, pow = 0, num_constraints = 0;
+    Bytes alpha_g1, beta_g1, delta_g1, beta_g2, gamma_g2, delta_g2;
+    Bytes ic, a_query, b_g1_query, b_g2_query, l_query, h_query;
+    std::vector<uint32_t> row_ptr[2], col[2];
+    std::vector<Fr> coeff[2];
+};
+
+static ZKey read_zkey(int curve_id, const std::string& path) {
+    Curve c{curve_id};
+    Bytes buf = slurp(path);
+    Cursor cur{buf.data(), buf.size()};
+    char magic[5] = {0}; cur.bytes(magic, 4);
+    if (std::string(magic) != "zkey") throw std::runtime_error("not a zkey file");
+    cur.u32();
+    uint32_t ns = cur.u32();
+    std::map<uint32_t, std::pair<size_t, size_t>> sec;
+    for (uint32_t i = 0; i < ns; i++) { uint32_t id = cur.u32(); uint64_t len = cur.u64(); cur.need(len); sec[id] = {cur.off, (size_t)len}; cur.off += len; }
+    auto section = [&](uint32_t id) { auto it = sec.find(id); if (it == sec.end()) throw std::runtime_error("missing zkey section"); return Cursor{buf.data() + it->second.first, it->second.second}; };
+    ZKey z; z.curve = c;
+    {   // header, zkey.rs:258-316
+        Cursor h = section(2);
+        if (h.u32() != c.fq()) throw std::runtime_error("unexpected base field byte size");
+        uint64_t q[6] = {0}; h.bytes(q, c.fq());
+        if (memcmp(q, MOD_Q[curve_id], c.fq())) throw std::runtime_error("invalid base prime in header");
+        if (h.u32() != 32) throw std::runtime_error("unexpected scalar field byte size");
+        uint64_t r[4]; h.bytes(r, 32);
+        if (memcmp(r, MOD_R[curve_id], 32)) throw std::runtime_error("invalid scalar prime in header");
+        z.n_vars = h.u32(); z.n_public = h.u32(); z.domain_size = h.u32();
+        if (!z.domain_size || (z.domain_size & (z.domain_size - 1))) throw std::runtime_error("domain size must be a power of two");
+        while (((size_t)1 << z.pow) < z.domain_size) z.pow++;
+        auto g = [&](int grp) { Bytes b(c.aff(grp)); h.bytes(b.data(), b.size()); return b; };
+        z.alpha_g1 = g(CG_G1); z.beta_g1 = g(CG_G1); z.beta_g2 = g(CG_G2); z.gamma_g2 = g(CG_G2); z.delta_g1 = g(CG_G1); z.delta_g2 = g(CG_G2);
+    }
+    auto pts = [&](uint32_t id, size_t n, int grp) { Cursor s = section(id); Bytes b(n * c.aff(grp)); s.bytes(b.data(), b.size()); return b; };
+    z.ic = pts(3, z.n_public + 1, CG_G1); z.a_query = pts(5, z.n_vars, CG_G1); z.b_g1_query = pts(6, z.n_vars, CG_G1);
+    z.b_g2_query = pts(7, z.n_vars, CG_G2); z.l_query = pts(8, z.n_vars - z.n_public - 1, CG_G1); z.h_query = pts(9, z.domain_size, CG_G1);
+    {   // section 4, zkey.rs:184-204: value on disk = v*R^2; one Montgomery reduction gives the Montgomery form of v (traits.rs:65-67)
+        Cursor s = section(4);
+        uint32_t ncoef = s.u32();
+        struct E { uint32_t m, row, sig; Fr v; };
+        std::vector<E> es(ncoef);
+        uint32_t max_row = 0;
+        const Fr raw_one = {{1, 0, 0, 0}};
+        for (auto& e : es) {
+            e.m = s.u32(); e.row = s.u32(); e.sig = s.u32();
+            Fr disk; s.bytes(disk.v, 32);
+            e.v = fr_mul(c, disk, raw_one);
+            if (e.m > 1) throw std::runtime_error("bad matrix id");
+            if (e.row > max_row) max_row = e.row;
+        }
+        z.num_constraints = (size_t)max_row - z.n_public;
+        for (int m = 0; m < 2; m++) {
+            z.row_ptr[m].assign(z.num_constraints + 1, 0);
+            for (auto& e : es) if (e.m == (uint32_t)m && e.row < z.num_constraints) z.row_ptr[m][e.row + 1]++;
+            for (size_t i = 0; i < z.num_constraints; i++) z.row_ptr[m][i + 1] += z.row_ptr[m][i];
+            z.col[m].resize(z.row_ptr[m].back()); z.coeff[m].resize(z.col[m].size());
+            std::vector<uint32_t> fill(z.row_ptr[m].begin(), z.row_ptr[m].end() - 1);
+            for (auto& e : es) if (e.m == (uint32_t)m && e.row < z.num_constraints) { uint32_t k = fill[e.row]++; z.col[m][k] = e.sig; z.coeff[m][k] = e.v; }
+        }
+    }
+    return z;
+}
+
+static std::vector<Fr> read_wtns(int curve_id, const std::string& path) {   // witness.rs:51-91
+    Bytes buf = slurp(path);
+    Cursor c{buf.data(), buf.size()};
+    char magic[5] = {0}; c.bytes(magic, 4);
+    if (std::string(magic) != "wtns") throw std::runtime_error("not a wtns file");
+    if (c.u32() > 2) throw std::runtime_error("wtns version not supported");
+    if (c.u32() > 2) throw std::runtime_error("invalid section number");
+    c.u32(); c.u64();
+    if (c.u32() != 32) throw std::runtime_error("wrong scalar field");
+    uint64_t mod[4]; c.bytes(mod, 32);
+    if (memcmp(mod, MOD_R[curve_id], 32)) throw std::runtime_error("wrong scalar field");
+    uint32_t n = c.u32();
+    c.u32(); c.u64();
+    std::vector<Fr> raw(n), out(n);
+    c.bytes(raw.data(), (size_t)n * 32);
+    CG(cg_fr_from_canonical(curve_id, raw.data(), out.data(), n));
+    return out;
+}
+
+// co-circom-snarks/src/lib.rs:208-221 + groth16.rs:57-77
+struct Domain { size_t m; int log_m; Fr omega, coset_g; };
+static Domain groth16_domain(const Curve& c, size_t pow, size_t num_constraints, size_t num_inputs) {
+    const uint64_t* r = MOD_R[c.id];
+    uint64_t t[4] = {r[0] - 1, r[1], r[2], r[3]};
+    int s = 0;
+    while (!(t[0] & 1)) { for (int i = 0; i < 4; i++) t[i] = (t[i] >> 1) | (i < 3 ? t[i + 1] << 63 : 0); s++; }
+    uint64_t half[4] = {r[0] - 1, r[1], r[2], r[3]};
+    for (int i = 0; i < 4; i++) half[i] = (half[i] >> 1) | (i < 3 ? half[i + 1] << 63 : 0);
+    const Fr one = fr_from_u64(c, 1), minus_one = fr_sub(c, fr_from_u64(c, 0), one);
+    Fr q = one;
+    while (!fr_eq(fr_pow(c, q, half, 4), minus_one)) q = fr_add(c, q, one);       // smallest quadratic non-residue
+    std::vector<Fr> roots(s + 1);
+    roots[0] = fr_pow(c, q, t, 4);
+    for (int i = 1; i <= s; i++) roots[i] = fr_mul(c, roots[i - 1], roots[i - 1]);
+    std::vector<Fr> rev(roots.rbegin(), roots.rend());
+    Domain d; d.m = 1; d.log_m = 0;
+    while (d.m < num_constraints + num_inputs) { d.m <<= 1; d.log_m++; }
+    d.omega = rev[pow];
+    d.coset_g = s == d.log_m ? fr_mul(c, q, q) : rev[d.log_m + 1];
+    return d;
+}
+
+// ---- network -----------------------------------------------------------------------------------------------------------
+struct Rep3Network {   // rep3/network.rs:30-64
+    virtual ~Rep3Network() {}
+    virtual int id() const = 0;
+    virtual void send_next(const void* data, size_t bytes) = 0;
+    virtual void recv_prev(void* data, size_t bytes) = 0;
+};
+struct InProcHub {
+    std::mutex mu; std::condition_variable cv;
+    std::deque<Bytes> q[3];   // q[i] = messages travelling from party i to party i+1
+};
+struct InProcNetwork : Rep3Network {
+    InProcHub* hub; int me;
+    InProcNetwork(InProcHub* h, int i) : hub(h), me(i) {}
+    int id() const override { return me; }
+    void send_next(const void* data, size_t bytes) override {
+        { std::lock_guard<std::mutex> l(hub->mu); hub->q[me].emplace_back((const uint8_t*)data, (const uint8_t*)data + bytes); }
+        hub->cv.notify_all();
+    }
+    void recv_prev(void* data, size_t bytes) override {
+        const int from = (me + 2) % 3;
+        std::unique_lock<std::mutex> l(hub->mu);
+        hub->cv.wait(l, [&] { return !hub->q[from].empty(); });
+        Bytes m = std::move(hub->q[from].front()); hub->q[from].pop_front();
+        if (m.size() != bytes) throw std::runtime_error("During execution of MPC: invalid number of bytes received");   // rep3.rs:663-668
+        memcpy(data, m.data(), bytes);
+    }
+};
+
+// ---- driver ------------------------------------------------------------------------------------------------------------
+struct ShareVec { void* c[2] = {nullptr, nullptr}; size_t n = 0; };   // device; REP3 uses c[0] = a, c[1] = b; plain only c[0]
+struct FieldShare { Fr c[2]; };
+struct PointShare { Point c[2]; };
+struct DeviceMatrix { uint32_t* row_ptr; uint32_t* col; void* coeff; size_t rows; };
+
+struct DeviceZKey {   // bases uploaded once and reused by every proof / party (ownership of host buffers stays with ZKey)
+    const ZKey* z;
+    cg_bases *a = nullptr, *b1 = nullptr, *b2 = nullptr, *l = nullptr, *h = nullptr;
+    DeviceMatrix mat[2];
+    void* pub_dev = nullptr;
+};
+
+enum class Mode { Plain, Rep3 };
+
+class HipDriver {
+public:
+    cg_ctx* ctx; Curve curve; Mode mode; Rep3Network* net;
+    const Fr* rng1 = nullptr; const Fr* rng2 = nullptr; size_t rng_len = 0, cursor = 0;   // rngs.rs:25-46 streams (inputs)
+    int k() const { return mode == Mode::Rep3 ? 2 : 1; }
+    int party() const { return mode == Mode::Rep3 ? net->id() : -1; }
+
+    HipDriver(cg_ctx* c, Curve cv, Mode m, Rep3Network* n) : ctx(c), curve(cv), mode(m), net(n) {}
+
+    void* dalloc(size_t bytes) { void* p; CG(cg_dev_alloc(ctx, bytes, &p)); return p; }
+    ShareVec alloc_vec(size_t n) { ShareVec v; v.n = n; for (int j = 0; j < k(); j++) { v.c[j] = dalloc(n * 32); CG(cg_dev_memset_zero(ctx, v.c[j], n * 32)); } return v; }
+    void free_vec(ShareVec& v) { for (int j = 0; j < 2; j++) if (v.c[j]) { CG(cg_dev_free(ctx, v.c[j])); v.c[j] = nullptr; } }
+    ShareVec upload_vec(const Fr* a, const Fr* b, size_t n) {
+        ShareVec v; v.n = n;
+        v.c[0] = dalloc(n * 32); CG(cg_dev_upload(ctx, v.c[0], a, n * 32));
+        if (k() == 2) { v.c[1] = dalloc(n * 32); CG(cg_dev_upload(ctx, v.c[1], b, n * 32)); }
+        return v;
+    }
+    Fr draw(const Fr* s) const { if (cursor >= rng_len) throw std::runtime_error("randomness stream exhausted"); return s[cursor]; }
+
+    // evaluate_constraint for every row (traits.rs:180; plain.rs:243-258, rep3.rs:690-708) into a zero-padded length-m vector
+    ShareVec evaluate_constraints(const DeviceMatrix& mt, const void* d_pub, uint32_t n_inputs, const ShareVec& wit, size_t m) {
+        ShareVec out = alloc_vec(m);
+        CG(cg_spmv_csr_dev(ctx, curve.id, mt.row_ptr, mt.col, mt.coeff, mt.rows, d_pub, n_inputs, party(), wit.c[0], wit.c[1], out.c[0], out.c[1]));
+        return out;
+    }
+    // promote_to_trivial_shares (fieldshare.rs:262-283) + clone_from_slice (rep3.rs:710-725)
+    void clone_public_into(ShareVec& dst, size_t dst_off, const std::vector<Fr>& pub) {
+        const int holder = mode == Mode::Plain ? 0 : (party() == 0 ? 0 : party() == 1 ? 1 : -1);   // ID0 -> a, ID1 -> b, ID2 -> nothing
+        if (holder >= 0) CG(cg_dev_upload(ctx, (uint8_t*)dst.c[holder] + dst_off * 32, pub.data(), pub.size() * 32));
+    }
+    // mul_vec (traits.rs:164): plain.rs:219-224 ; rep3.rs:650-670 (local product + mask, send to next, receive from prev)
+    ShareVec mul_vec(const ShareVec& a, const ShareVec& b) {
+        ShareVec out; out.n = a.n;
+        out.c[0] = dalloc(a.n * 32);
+        if (mode == Mode::Plain) { CG(cg_vec_mul_dev(ctx, curve.id, out.c[0], a.c[0], b.c[0], a.n)); return out; }
+        if (cursor + a.n > rng_len) throw std::runtime_error("randomness stream exhausted");
+        void* m1 = dalloc(a.n * 32); void* m2 = dalloc(a.n * 32);
+        CG(cg_dev_upload(ctx, m1, rng1 + cursor, a.n * 32)); CG(cg_dev_upload(ctx, m2, rng2 + cursor, a.n * 32));
+        cursor += a.n;
+        CG(cg_vec_sub_dev(ctx, curve.id, m1, m1, m2, a.n));                         // masking_field_element = rand(rng1) - rand(rng2)
+        CG(cg_vec_rep3_mul_local_dev(ctx, curve.id, out.c[0], a.c[0], a.c[1], b.c[0], b.c[1], m1, a.n));
+        std::vector<Fr> local(a.n), recv(a.n);
+        CG(cg_dev_download(ctx, local.data(), out.c[0], a.n * 32));
+        net->send_next(local.data(), a.n * 32);
+        net->recv_prev(recv.data(), a.n * 32);
+        out.c[1] = dalloc(a.n * 32);
+        CG(cg_dev_upload(ctx, out.c[1], recv.data(), a.n * 32));
+        CG(cg_dev_free(ctx, m1)); CG(cg_dev_free(ctx, m2));
+        return out;
+    }
+    // FFTProvider (traits.rs:535-558): both share components in one launch
+    void fft_in_place(ShareVec& v, const Fr& group_gen) { CG(cg_ntt_dev(ctx, curve.id, v.c, k(), v.n, group_gen.v, 0, nullptr)); }
+    void ifft_in_place(ShareVec& v, const Fr& group_gen) { CG(cg_ntt_dev(ctx, curve.id, v.c, k(), v.n, group_gen.v, 1, nullptr)); }
+    void distribute_powers_and_mul_by_const(ShareVec& v, const Fr& g, const Fr& c) { for (int j = 0; j < k(); j++) CG(cg_vec_distribute_powers_dev(ctx, curve.id, v.c[j], v.n, g.v, c.v)); }
+    // fused ifft_in_place + distribute_powers_and_mul_by_const(g, 1): one HBM round trip less per vector
+    void ifft_coset_in_place(ShareVec& v, const Fr& group_gen, const Fr& g) { CG(cg_ntt_dev(ctx, curve.id, v.c, k(), v.n, group_gen.v, 1, g.v)); }
+    void sub_assign_vec(ShareVec& a, const ShareVec& b) { for (int j = 0; j < k(); j++) CG(cg_vec_sub_dev(ctx, curve.id, a.c[j], a.c[j], b.c[j], a.n)); }
+
+    // MSMProvider::msm_public_points (traits.rs:561-568) on a sub-slice of a registered table
+    PointShare msm_public_points(const cg_bases* bases, int group, size_t off, size_t n, const ShareVec& s) {
+        Bytes out(curve.jac(group) * k());
+        const void* sc[2] = {s.c[0], s.c[1]};
+        CG(cg_msm_dev(ctx, bases, off, n, sc, k(), out.data()));
+        PointShare r;
+        for (int j = 0; j < k(); j++) r.c[j] = Point{Bytes(out.begin() + j * curve.jac(group), out.begin() + (j + 1) * curve.jac(group)), group};
+        if (k() == 1) r.c[1] = pt_inf(curve, group);
+        return r;
+    }
+    // rand (rep3.rs:595-598; plain: supplied by the caller)
+    FieldShare rand() { FieldShare f; f.c[0] = draw(rng1); f.c[1] = draw(rng2); cursor++; return f; }
+    // mul (rep3.rs:503-511 / plain a*b)
+    FieldShare mul(const FieldShare& a, const FieldShare& b) {
+        FieldShare r;
+        if (mode == Mode::Plain) { r.c[0] = fr_mul(curve, a.c[0], b.c[0]); r.c[1] = r.c[0]; return r; }
+        Fr local = fr_add(curve, fr_add(curve, fr_mul(curve, a.c[0], b.c[0]), fr_mul(curve, a.c[0], b.c[1])), fr_mul(curve, a.c[1], b.c[0]));
+        local = fr_add(curve, local, fr_sub(curve, draw(rng1), draw(rng2))); cursor++;
+        net->send_next(local.v, 32);
+        Fr prev; net->recv_prev(prev.v, 32);
+        r.c[0] = local; r.c[1] = prev;
+        return r;
+    }
+    PointShare scalar_mul_public_point(const Point& p, const FieldShare& s) {   // rep3.rs:820-825
+        PointShare r; for (int j = 0; j < 2; j++) r.c[j] = j < k() ? pt_mul(curve, p, s.c[j]) : pt_inf(curve, p.group); return r;
+    }
+    PointShare scalar_mul(const PointShare& a, const FieldShare& b) {           // rep3.rs:835-847, pointshare.rs:117-124
+        PointShare r;
+        if (mode == Mode::Plain) { r.c[0] = pt_mul(curve, a.c[0], b.c[0]); r.c[1] = pt_inf(curve, a.c[0].group); return r; }
+        Point local = pt_add(curve, pt_add(curve, pt_mul(curve, a.c[0], b.c[0]), pt_mul(curve, a.c[1], b.c[0])), pt_mul(curve, a.c[0], b.c[1]));
+        const Point gen = pt_generator(curve, a.c[0].group);       // masking_ec_element: G*rand(rng1) - G*rand(rng2)
+        local = pt_add(curve, local, pt_sub(curve, pt_mul(curve, gen, draw(rng1)), pt_mul(curve, gen, draw(rng2)))); cursor++;
+        Bytes aff = pt_to_affine(curve, local);                    // points cross the wire in affine form (ark-serialize)
+        net->send_next(aff.data(), aff.size());
+        Bytes prev(aff.size()); net->recv_prev(prev.data(), prev.size());
+        r.c[0] = local; r.c[1] = pt_from_affine(curve, local.group, prev.data());
+        return r;
+    }
+    void add_assign_points(PointShare& a, const PointShare& b) { for (int j = 0; j < k(); j++) a.c[j] = pt_add(curve, a.c[j], b.c[j]); }
+    void sub_assign_points(PointShare& a, const PointShare& b) { for (int j = 0; j < k(); j++) a.c[j] = pt_sub(curve, a.c[j], b.c[j]); }
+    void add_assign_points_public(PointShare& a, const Point& b) {              // rep3.rs:804-818: ID0 -> a, ID1 -> b, ID2 -> nothing
+        if (mode == Mode::Plain || party() == 0) a.c[0] = pt_add(curve, a.c[0], b);
+        else if (party() == 1) a.c[1] = pt_add(curve, a.c[1], b);
+    }
+    Point open_point(const PointShare& a) {                                      // rep3.rs:849-853
+        if (mode == Mode::Plain) return a.c[0];
+        Bytes mine = pt_to_affine(curve, a.c[1]);
+        net->send_next(mine.data(), mine.size());
+        Bytes prev(mine.size()); net->recv_prev(prev.data(), prev.size());
+        return pt_add(curve, pt_add(curve, a.c[0], a.c[1]), pt_from_affine(curve, a.c[0].group, prev.data()));
+    }
+    std::pair<Point, Point> open_two_points(const PointShare& a, const PointShare& b) {   // rep3.rs:865-877
+        if (mode == Mode::Plain) return {a.c[0], b.c[0]};
+        Bytes m1 = pt_to_affine(curve, a.c[1]), m2 = pt_to_affine(curve, b.c[1]);
+        Bytes msg(m1); msg.insert(msg.end(), m2.begin(), m2.end());
+        net->send_next(msg.data(), msg.size());
+        Bytes prev(msg.size()); net->recv_prev(prev.data(), prev.size());
+        Point r1 = pt_add(curve, pt_from_affine(curve, CG_G1, prev.data()), pt_add(curve, a.c[0], a.c[1]));
+        Point r2 = pt_add(curve, pt_from_affine(curve, CG_G2, prev.data() + m1.size()), pt_add(curve, b.c[0], b.c[1]));
+        return {r1, r2};
+    }
+};
+
+// ---- prover --------------------------------------------------------------------------------------------------------------
+struct Proof { Bytes a, b, c; };   // packed affine, (0,0) = infinity  (Groth16Proof, groth16/proof.rs:8-29)
+
+class CoGroth16 {
+public:
+    HipDriver& driver;
+    explicit CoGroth16(HipDriver& d) : driver(d) {}
+
+    // groth16.rs:141-204
+    ShareVec witness_map_from_matrices(const DeviceZKey& dz, const std::vector<Fr>& public_inputs, const ShareVec& private_witness) {
+        const ZKey& z = *dz.z;
+        const size_t num_inputs = z.n_public + 1, num_constraints = z.num_constraints;
+        const Domain dom = groth16_domain(driver.curve, z.pow, num_constraints, num_inputs);          // :150-153
+        ShareVec a = driver.evaluate_constraints(dz.mat[0], dz.pub_dev, (uint32_t)num_inputs, private_witness, dom.m);   // :156-166
+        ShareVec b = driver.evaluate_constraints(dz.mat[1], dz.pub_dev, (uint32_t)num_inputs, private_witness, dom.m);
+        driver.clone_public_into(a, num_constraints, public_inputs);                                   // :168-171
+        ShareVec c = driver.mul_vec(a, b);                                                             // :174
+        driver.ifft_coset_in_place(a, dom.omega, dom.coset_g);                                         // :175,177-181
+        driver.ifft_coset_in_place(b, dom.omega, dom.coset_g);                                         // :176,182-186
+        driver.fft_in_place(a, dom.omega); driver.fft_in_place(b, dom.omega);                          // :187-188
+        ShareVec ab = driver.mul_vec(a, b);                                                            // :190
+        driver.free_vec(a); driver.free_vec(b);
+        driver.ifft_coset_in_place(c, dom.omega, dom.coset_g);                                         // :194-199
+        driver.fft_in_place(c, dom.omega);                                                             // :200
+        driver.sub_assign_vec(ab, c);                                                                  // :202
+        driver.free_vec(c);
+        return ab;
+    }
+
+    // groth16.rs:206-235
+    PointShare calculate_coeff(PointShare initial, const cg_bases* query, const Bytes& query_host, int group, const Bytes& vk_param,
+                               const std::vector<Fr>& input_assignment, const ShareVec& aux_assignment) {
+        const Curve& c = driver.curve;
+        const size_t pub_len = input_assignment.size(), rec = c.aff(group);
+        Point pub_acc = pt_inf(c, group);                                                              // :220 (tiny, plain scalars)
+        for (size_t i = 0; i < pub_len; i++) pub_acc = pt_add(c, pub_acc, pt_mul(c, pt_from_affine(c, group, query_host.data() + (1 + i) * rec), input_assignment[i]));
+        PointShare priv_acc = driver.msm_public_points(query, group, 1 + pub_len, aux_assignment.n, aux_assignment);   // :221
+        PointShare res = initial;
+        driver.add_assign_points_public(res, pt_from_affine(c, group, query_host.data()));             // :227
+        driver.add_assign_points_public(res, pt_from_affine(c, group, vk_param.data()));               // :228
+        driver.add_assign_points_public(res, pub_acc);                                                 // :229
+        driver.add_assign_points(res, priv_acc);                                                       // :230
+        return res;
+    }
+
+    // groth16.rs:113-139 + :237-326
+    Proof prove(const DeviceZKey& dz, const std::vector<Fr>& public_inputs, const ShareVec& private_witness, const FieldShare* rs_plain, ShareVec* h_out = nullptr) {
+        const ZKey& z = *dz.z; const Curve& c = driver.curve;
+        ShareVec h = witness_map_from_matrices(dz, public_inputs, private_witness);
+        FieldShare r = rs_plain ? rs_plain[0] : driver.rand();                                         // :134-135
+        FieldShare s = rs_plain ? rs_plain[1] : driver.rand();
+        std::vector<Fr> input_assignment(public_inputs.begin() + 1, public_inputs.end());
+        PointShare h_acc = driver.msm_public_points(dz.h, CG_G1, 0, h.n, h);                           // :248
+        PointShare l_aux_acc = driver.msm_public_points(dz.l, CG_G1, 0, private_witness.n, private_witness);   // :251
+        const Point delta_g1 = pt_from_affine(c, CG_G1, z.delta_g1.data());
+        FieldShare rs = driver.mul(r, s);                                                              // :258
+        PointShare r_s_delta_g1 = driver.scalar_mul_public_point(delta_g1, rs);                        // :259
+        PointShare r_g1 = driver.scalar_mul_public_point(delta_g1, r);                                 // :265
+        PointShare g_a = calculate_coeff(r_g1, dz.a, z.a_query, CG_G1, z.alpha_g1, input_assignment, private_witness);   // :267
+        Point g_a_opened = driver.open_point(g_a);                                                     // :276
+        PointShare s_g_a = driver.scalar_mul_public_point(g_a_opened, s);                              // :277
+        PointShare s_g1 = driver.scalar_mul_public_point(delta_g1, s);                                 // :283
+        PointShare g1_b = calculate_coeff(s_g1, dz.b1, z.b_g1_query, CG_G1, z.beta_g1, input_assignment, private_witness);   // :284
+        PointShare r_g1_b = driver.scalar_mul(g1_b, r);                                                // :291
+        const Point delta_g2 = pt_from_affine(c, CG_G2, z.delta_g2.data());
+        PointShare s_g2 = driver.scalar_mul_public_point(delta_g2, s);                                 // :297
+        PointShare g2_b = calculate_coeff(s_g2, dz.b2, z.b_g2_query, CG_G2, z.beta_g2, input_assignment, private_witness);   // :298
+        PointShare g_c = s_g_a;                                                                        // :308-312
+        driver.add_assign_points(g_c, r_g1_b);
+        driver.sub_assign_points(g_c, r_s_delta_g1);
+        driver.add_assign_points(g_c, l_aux_acc);
+        driver.add_assign_points(g_c, h_acc);
+        auto opened = driver.open_two_points(g_c, g2_b);                                               // :316
+        if (h_out) *h_out = h; else driver.free_vec(h);
+        return Proof{pt_to_affine(c, g_a_opened), pt_to_affine(c, opened.second), pt_to_affine(c, opened.first)};   // :319-325
+    }
+};
+
+static DeviceZKey upload_zkey(cg_ctx* ctx, const ZKey& z, const std::vector<Fr>& public_inputs) {
+    DeviceZKey d; d.z = &z;
+    const Curve& c = z.curve;
+    auto reg = [&](const Bytes& pts, int group) { cg_bases* b; CG(cg_bases_register(ctx, c.id, group, pts.data(), pts.size() / c.aff(group), c.aff(group), -1, &b)); return b; };
+    d.a = reg(z.a_query, CG_G1); d.b1 = reg(z.b_g1_query, CG_G1); d.b2 = reg(z.b_g2_query, CG_G2); d.l = reg(z.l_query, CG_G1); d.h = reg(z.h_query, CG_G1);
+    auto up = [&](const void* src, size_t bytes) { void* p; CG(cg_dev_alloc(ctx, bytes, &p)); if (bytes) CG(cg_dev_upload(ctx, p, src, bytes)); return p; };
+    for (int m = 0; m < 2; m++) {
+        d.mat[m].row_ptr = (uint32_t*)up(z.row_ptr[m].data(), z.row_ptr[m].size() * 4);
+        d.mat[m].col = (uint32_t*)up(z.col[m].data(), z.col[m].size() * 4);
+        d.mat[m].coeff = up(z.coeff[m].data(), z.coeff[m].size() * 32);
+        d.mat[m].rows = z.num_constraints;
+    }
+    d.pub_dev = up(public_inputs.data(), public_inputs.size() * 32);
+    return d;
+}
+static void release_zkey(cg_ctx* ctx, DeviceZKey& d) {
+    for (cg_bases* b : {d.a, d.b1, d.b2, d.l, d.h}) cg_bases_release(b);
+    for (int m = 0; m < 2; m++) { cg_dev_free(ctx, d.mat[m].row_ptr); cg_dev_free(ctx, d.mat[m].col); cg_dev_free(ctx, d.mat[m].coeff); }
+    cg_dev_free(ctx, d.pub_dev);
+}
+
+static void store_proof(const Proof& p, uint8_t* out) { memcpy(out, p.a.data(), p.a.size()); memcpy(out + p.a.size(), p.b.data(), p.b.size()); memcpy(out + p.a.size() + p.b.size(), p.c.data(), p.c.size()); }
+
+}  // namespace cgh
+
+// ==================================================================================================== C entry points (tests / tools)
+static thread_local std::string g_host_err;
+extern "C" {
+
+const char* cgh_last_error(void) { return g_host_err.c_str(); }
+
+// info: n_vars, n_public, domain_size, pow, num_constraints, nnzA, nnzB
+int32_t cgh_zkey_info(int32_t curve, const char* path, size_t* info) {
+    try {
+        cgh::ZKey z = cgh::read_zkey(curve, path);
+        info[0] = z.n_vars; info[1] = z.n_public; info[2] = z.domain_size; info[3] = z.pow; info[4] = z.num_constraints; info[5] = z.col[0].size(); info[6] = z.col[1].size();
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+int32_t cgh_read_wtns(int32_t curve, const char* path, uint64_t* out, size_t cap, size_t* n) {
+    try {
+        auto w = cgh::read_wtns(curve, path);
+        *n = w.size();
+        if (out) { if (w.size() > cap) { g_host_err = "buffer too small"; return 1; } memcpy(out, w.data(), w.size() * 32); }
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+// PlainHipDriver: full_witness = n_vars Montgomery elements; proof = A || B || C packed affine
+int32_t cgh_prove_plain(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* full_witness, const uint64_t* r, const uint64_t* s, uint64_t* out_proof, uint64_t* out_h) {
+    cg_ctx* ctx = nullptr;
+    try {
+        using namespace cgh;
+        ZKey z = read_zkey(curve, zkey_path);
+        if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
+        const Fr* w = (const Fr*)full_witness;
+        std::vector<Fr> pub(w, w + z.n_public + 1);
+        DeviceZKey dz = upload_zkey(ctx, z, pub);
+        HipDriver driver(ctx, z.curve, Mode::Plain, nullptr);
+        ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_public - 1);
+        FieldShare rs[2]; memcpy(rs[0].c[0].v, r, 32); rs[0].c[1] = rs[0].c[0]; memcpy(rs[1].c[0].v, s, 32); rs[1].c[1] = rs[1].c[0];
+        CoGroth16 prover(driver);
+        ShareVec h;
+        Proof p = prover.prove(dz, pub, wit, rs, &h);
+        store_proof(p, (uint8_t*)out_proof);
+        if (out_h) CG(cg_dev_download(ctx, out_h, h.c[0], h.n * 32));
+        driver.free_vec(h); driver.free_vec(wit);
+        release_zkey(ctx, dz);
+        cg_ctx_destroy(ctx);
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
+}
+// Rep3HipProtocol x 3 on three threads over the in-process network; streams[i] = S_i (party i: rng1 = S_i, rng2 = S_{i-1})
+int32_t cgh_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
+                       const uint64_t* const* streams, size_t stream_len, uint64_t* out_proofs, uint64_t* out_h) {
+    try {
+        using namespace cgh;
+        ZKey z = read_zkey(curve, zkey_path);
+        const size_t n_aux = z.n_vars - z.n_public - 1;
+        std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
+        cg_ctx* ctx0 = nullptr;
+        if (cg_ctx_create(device, &ctx0)) die("cg_ctx_create");
+        DeviceZKey dz = upload_zkey(ctx0, z, pub);            // one device-resident zkey shared by the three co-located parties
+        InProcHub hub;
+        const size_t psz = 8 * z.curve.fq();
+        std::string errs[3];
+        std::vector<std::thread> th;
+        for (int i = 0; i < 3; i++) th.emplace_back([&, i] {
+            cg_ctx* ctx = nullptr;
+            try {
+                if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
+                InProcNetwork net(&hub, i);
+                HipDriver driver(ctx, z.curve, Mode::Rep3, &net);
+                driver.rng1 = (const Fr*)streams[i]; driver.rng2 = (const Fr*)streams[(i + 2) % 3]; driver.rng_len = stream_len;
+                ShareVec wit = driver.upload_vec((const Fr*)wit_a[i], (const Fr*)wit_b[i], n_aux);
+                CoGroth16 prover(driver);
+                ShareVec h;
+                Proof p = prover.prove(dz, pub, wit, nullptr, &h);
+                store_proof(p, (uint8_t*)out_proofs + i * psz);
+                if (out_h && i == 0) { CG(cg_dev_download(ctx, out_h, h.c[0], h.n * 32)); CG(cg_dev_download(ctx, out_h + h.n * 4, h.c[1], h.n * 32)); }
+                driver.free_vec(h); driver.free_vec(wit);
+                cg_ctx_destroy(ctx);
+            } catch (const std::exception& e) { errs[i] = e.what(); if (ctx) cg_ctx_destroy(ctx); }
+        });
+        for (auto& t : th) t.join();
+        release_zkey(ctx0, dz);
+        cg_ctx_destroy(ctx0);
+        for (int i = 0; i < 3; i++) if (!errs[i].empty()) { g_host_err = "party " + std::to_string(i) + ": " + errs[i]; return 1; }
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+"""Host-side mirror of the reference interface (libcogroth16_host.so: HipDriver in Plain / Rep3 mode + CoGroth16::prove).
+CPU part: its own zkey / wtns readers against the oracle and the reference KATs.  GPU part (-m gpu): complete proofs,
+bit-identical to the oracle's on the same (zkey, witness, randomness), three REP3 parties agreeing, pairing-verified."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from oracle_lib import BN254, BLS12_381, FR
+from product import cg, ensure_built
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CURVES = {"bn254": BN254, "bls12_381": BLS12_381}
+FIXTURES = [(c, k) for c in ("bn254", "bls12_381") for k in ("multiplier2", "poseidon")]
+
+
+def fx(curve_name, circuit, f):
+    return os.path.join(GOLDEN, "groth16", curve_name, circuit, f)
+
+
+@pytest.mark.parametrize("curve_name,circuit", FIXTURES)
+def test_host_readers_match_oracle(curve_name, circuit):
+    ensure_built()
+    curve = CURVES[curve_name]
+    z = orc.ZKey(curve, fx(curve_name, circuit, "circuit.zkey"))
+    info = cg.host_zkey_info(curve, fx(curve_name, circuit, "circuit.zkey"))
+    assert (info["n_vars"], info["n_public"], info["domain_size"], info["pow"], info["num_constraints"], info["nnz_a"], info["nnz_b"]) == \
+           (z.n_vars, z.n_public, z.domain_size, z.pow, z.num_constraints, z.nnz_a, z.nnz_b)
+    np.testing.assert_array_equal(cg.host_read_wtns(curve, fx(curve_name, circuit, "witness.wtns")), orc.read_wtns(curve, fx(curve_name, circuit, "witness.wtns")))
+
+
+def test_host_reader_errors():
+    ensure_built()
+    with pytest.raises(cg.BackendError):
+        cg.host_zkey_info(BN254, fx("bls12_381", "multiplier2", "circuit.zkey"))     # InvalidPrimeInHeader (zkey.rs:262-284)
+    with pytest.raises(cg.BackendError):
+        cg.host_read_wtns(BN254, fx("bls12_381", "multiplier2", "witness.wtns"))     # WrongScalarField (witness.rs:75-78)
+    with pytest.raises(cg.BackendError):
+        cg.host_zkey_info(BN254, fx("bn254", "multiplier2", "witness.wtns"))         # not a zkey
+
+
+def rep3_share(curve, vals, rng):
+    a = orc.random_field(curve, FR, vals.shape[0], rng); b = orc.random_field(curve, FR, vals.shape[0], rng)
+    c = orc.field_op(curve, FR, "sub", orc.field_op(curve, FR, "sub", vals, a), b)
+    return [a, b, c], [c, a, b]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name,circuit", FIXTURES)
+def test_plain_proof_bit_identical_and_verifies(curve_name, circuit):
+    """co-groth16/src/lib.rs:27-53,76-101,143-206 with the PlainHipDriver"""
+    ensure_built()
+    curve = CURVES[curve_name]
+    zpath = fx(curve_name, circuit, "circuit.zkey")
+    z = orc.ZKey(curve, zpath)
+    w = orc.read_wtns(curve, fx(curve_name, circuit, "witness.wtns"))
+    rng = np.random.default_rng(3)
+    r, s = orc.random_field(curve, FR, 2, rng)
+    proof, h = cg.prove_plain(curve, zpath, w, r, s, want_h=True)
+    np.testing.assert_array_equal(h, z.witness_map_plain(w))
+    np.testing.assert_array_equal(proof, z.prove_plain(w, r, s))
+    vk = orc.vk_from_json(curve, fx(curve_name, circuit, "verification_key.json"))
+    assert orc.verify(curve, vk, w[1:1 + z.n_public], proof)
+    # snarkjs-style JSON round trip of our proof
+    j = orc.proof_to_json(curve, proof)
+    np.testing.assert_array_equal(orc.proof_from_json(curve, json.loads(json.dumps(j))), proof)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name,circuit", FIXTURES)
+def test_rep3_three_parties_bit_identical_and_verify(curve_name, circuit):
+    """tests/tests/circom/e2e_tests/mod.rs:33-82 with three Rep3HipProtocol parties sharing one GPU"""
+    ensure_built()
+    curve = CURVES[curve_name]
+    zpath = fx(curve_name, circuit, "circuit.zkey")
+    z = orc.ZKey(curve, zpath)
+    w = orc.read_wtns(curve, fx(curve_name, circuit, "witness.wtns"))
+    rng = np.random.default_rng(5)
+    pub = w[:z.n_public + 1]
+    wa, wb = rep3_share(curve, w[z.n_public + 1:], rng)
+    streams = [orc.random_field(curve, FR, 2 * z.domain_size + 4, rng) for _ in range(3)]
+    proofs, h = cg.prove_rep3(curve, zpath, pub, wa, wb, streams, want_h=True)
+    np.testing.assert_array_equal(proofs[0], proofs[1]); np.testing.assert_array_equal(proofs[1], proofs[2])
+    want, want_h = z.prove_rep3(pub, wa, wb, streams, want_h=True)
+    np.testing.assert_array_equal(h, want_h)                  # party 0's h share (both components)
+    np.testing.assert_array_equal(proofs, want)               # identical to the oracle's three proofs
+    vk = orc.vk_from_json(curve, fx(curve_name, circuit, "verification_key.json"))
+    assert orc.verify(curve, vk, w[1:1 + z.n_public], proofs[0])
