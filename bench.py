@@ -128,13 +128,10 @@ def step(w):
     ctx.vec_sub(C, w.hb, w.hb, w.cb, m)
     # MSMs (groth16.rs:248-304); scalars sliced to this rank's point range
     h0, h1 = w.h_rng; a0, a1 = w.aux_rng
-    tickets = [
-        ctx.msm_dev_begin(w.h_q, [w.ha[h0:h1], w.hb[h0:h1]], h1 - h0),
-        ctx.msm_dev_begin(w.l_q, [w.wa[a0:a1], w.wb[a0:a1]], a1 - a0),
-        ctx.msm_dev_begin(w.a_q, [w.wa[a0:a1], w.wb[a0:a1]], a1 - a0),
-        ctx.msm_dev_begin(w.b1_q, [w.wa[a0:a1], w.wb[a0:a1]], a1 - a0),
-        ctx.msm_dev_begin(w.b2_q, [w.wa[a0:a1], w.wb[a0:a1]], a1 - a0),
-    ]
+    aux = [w.wa[a0:a1], w.wb[a0:a1]]
+    tickets = [ctx.msm_dev_begin(w.h_q, [w.ha[h0:h1], w.hb[h0:h1]], h1 - h0)]
+    # l, a, b1 (G1) and b2 (G2) all multiply the aux-witness shares: one digit/sort schedule per share component, four tables
+    tickets += ctx.msm_dev_begin_multi([w.l_q, w.a_q, w.b1_q, w.b2_q], aux, a1 - a0)
     return [ctx.msm_end(t) for t in tickets]
 
 

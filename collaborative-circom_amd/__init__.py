@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "cg_ctx_create", "cg_ctx_destroy", "cg_ctx_sync", "cg_ctx_stream", "cg_ctx_set_stream", "cg_last_error", "cg_version",
     "cg_dev_alloc", "cg_dev_free", "cg_dev_upload", "cg_dev_download", "cg_dev_memset_zero",
     "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len",
-    "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_end", "cg_msm_set_window",
+    "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window",
     "cg_ntt", "cg_ntt_dev",
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev",
     "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
@@ -238,6 +238,16 @@ class Context:
         t = C.c_int32(-1)
         _chk(load().cg_msm_dev_begin(self.h, bases.h, C.c_size_t(offset), C.c_size_t(n), ptrs, k, C.byref(t)))
         return (t.value, k, bases.curve, bases.group)
+
+    def msm_dev_begin_multi(self, bases_list, d_scalars, n, offsets=None):
+        """several tables x the same scalar vectors: one digit/sort schedule per vector shared by all tables"""
+        nb, k = len(bases_list), len(d_scalars)
+        tabs = (C.c_void_p * nb)(*[b.h.value for b in bases_list])
+        offs = (C.c_size_t * nb)(*([0] * nb if offsets is None else offsets))
+        ptrs = (C.c_void_p * k)(*[_dp(s).value for s in d_scalars])
+        tk = (C.c_int32 * nb)()
+        _chk(load().cg_msm_dev_begin_multi(self.h, nb, tabs, offs, C.c_size_t(n), ptrs, k, tk))
+        return [(tk[i], k, bases_list[i].curve, bases_list[i].group) for i in range(nb)]
 
     def msm_end(self, ticket):
         t, k, curve, group = ticket

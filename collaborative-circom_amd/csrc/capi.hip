@@ -12,8 +12,12 @@ using namespace cg;
 
 // launchers living in msm_inst_*.hip / fr_inst_*.hip (explicit instantiations)
 namespace cg {
-template <class F, class Fr> int msm_enqueue(hipStream_t st, const Affine<F>* d_bases, size_t n, const Fr* d_scalars, int c, int nwin, char* arena_base, XYZZ<F>* h_out, hipEvent_t* evs);
-template <class F> size_t msm_scratch_bytes(size_t n, int c, int nwin);
+struct MsmSortPtrs { const uint32_t* sorted; const uint32_t* offsets; const uint32_t* counts; };
+template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, size_t n, int c, int nwin, char* scratch, MsmSortPtrs* out, hipEvent_t* evs);
+template <class F> int msm_accumulate_reduce(hipStream_t st, const Affine<F>* d_bases, size_t n, int c, int nwin, const uint32_t* sorted, const uint32_t* offsets,
+                                             const uint32_t* counts, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs);
+template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin);
+inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) { const size_t nbuckets = (size_t)nwin << (c - 1); return 2 * align_up((size_t)nwin * n * 4) + 3 * align_up(nbuckets * 4); }
 template <class F> int pack_bases_launch(hipStream_t st, const uint8_t* d_raw, size_t n, size_t stride, long inf_off, Affine<F>* d_dst);
 template <class F> int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi, int log_t, size_t n, Affine<F>* d_out);
 template <class Fr> int launch_vec_binary(hipStream_t st, int op, Fr* out, const Fr* a, const Fr* b, size_t n);
@@ -142,52 +146,87 @@ int ticket_slot(cg_ctx* ctx) {
     return (int)ctx->tickets.size() - 1;
 }
 
-int msm_begin_impl(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* d_scalars, int k, int* ticket_out, size_t extra_arena_off) {
-    if (!ctx || !bases || !ticket_out) return fail(CG_ERR_ARG, "null argument");
+template <class Fn> int with_coord_field(int curve, int group, Fn&& fn) {   // group-only dispatch (the scalar field is fixed by the curve)
+    return with_group(curve, group, [&](auto ftag, auto) -> int { return fn(ftag); });
+}
+
+// One digit/sort schedule per scalar vector, then one accumulate+reduce per base table: `nb` tables (same curve, any groups)
+// multiplied by the SAME k scalar vectors.  tickets_out[b] collects the k results for table b.
+int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, const size_t* offsets, size_t n, const void* const* d_scalars, int k, int* tickets_out) {
+    if (!ctx || !bases || !tickets_out || (n && !d_scalars)) return fail(CG_ERR_ARG, "null argument");
+    if (nb < 1 || nb > 16) return fail(CG_ERR_ARG, "number of base tables out of range");
     if (k < 1 || k > 8) return fail(CG_ERR_ARG, "k out of range");
-    if (offset + n > bases->n) return fail(CG_ERR_ARG, "bases slice out of range");
-    if (bases->device != ctx->device) return fail(CG_ERR_ARG, "bases live on another device");
+    for (int b = 0; b < nb; b++) {
+        if (!bases[b]) return fail(CG_ERR_ARG, "null bases");
+        if ((offsets ? offsets[b] : 0) + n > bases[b]->n) return fail(CG_ERR_ARG, "bases slice out of range");
+        if (bases[b]->device != ctx->device) return fail(CG_ERR_ARG, "bases live on another device");
+        if (bases[b]->curve != bases[0]->curve) return fail(CG_ERR_ARG, "all tables of one call must be on the same curve");
+    }
     HIPCHK(hipSetDevice(ctx->device));
-    return with_group(bases->curve, bases->group, [&](auto ftag, auto frtag) -> int {
-        typedef decltype(ftag) F; typedef decltype(frtag) Fr;
-        const int slot = ticket_slot(ctx);
-        MsmTicket& t = ctx->tickets[slot];
-        t.curve = bases->curve; t.group = bases->group; t.k = k;
-        t.c = n ? (ctx->msm_window ? ctx->msm_window : auto_window(n)) : 2;
-        t.nwin = Fr::Params::BITS / t.c + 1;
-        const size_t need = (size_t)k * t.nwin * sizeof(XYZZ<F>);
-        if (t.pinned_bytes < need) {
-            if (t.h_pinned) HIPCHK(hipHostFree(t.h_pinned));
-            t.h_pinned = nullptr; t.pinned_bytes = 0;
-            HIPCHK(hipHostMalloc(&t.h_pinned, need, hipHostMallocDefault));
-            t.pinned_bytes = need;
-        }
+    const int curve = bases[0]->curve;
+    const int c = n ? (ctx->msm_window ? ctx->msm_window : auto_window(n)) : 2;
+    int nwin = 0;
+    { int rc = with_fr(curve, [&](auto tag) -> int { nwin = decltype(tag)::Params::BITS / c + 1; return 0; }); if (rc) return rc; }
+    // tickets + pinned result buffers
+    std::vector<int> slots(nb);
+    size_t acc_bytes = 0;
+    for (int b = 0; b < nb; b++) {
+        slots[b] = ticket_slot(ctx);
+        MsmTicket& t = ctx->tickets[slots[b]];
+        t.live = true;   // reserve before asking for the next slot
+        t.curve = curve; t.group = bases[b]->group; t.k = k; t.c = c; t.nwin = nwin;
+        int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
+            typedef decltype(ftag) F;
+            const size_t need = (size_t)k * nwin * sizeof(XYZZ<F>);
+            if (t.pinned_bytes < need) {
+                if (t.h_pinned) HIPCHK(hipHostFree(t.h_pinned));
+                t.h_pinned = nullptr; t.pinned_bytes = 0;
+                HIPCHK(hipHostMalloc(&t.h_pinned, need, hipHostMallocDefault));
+                t.pinned_bytes = need;
+            }
+            if (n == 0) { XYZZ<F>* h = (XYZZ<F>*)t.h_pinned; for (int i = 0; i < k * nwin; i++) h[i] = XYZZ<F>::infinity(); }
+            else acc_bytes = std::max(acc_bytes, msm_acc_scratch_bytes<F>(n, c, nwin));
+            return 0;
+        });
+        if (rc) return rc;
         if (!t.done) HIPCHK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
-        XYZZ<F>* h = (XYZZ<F>*)t.h_pinned;
-        if (n == 0) { for (int i = 0; i < k * t.nwin; i++) h[i] = XYZZ<F>::infinity(); }
-        else {
-            StatScope ss(ctx, TAG_MSM);
-            const size_t per = msm_scratch_bytes<F>(n, t.c, t.nwin);
-            if (extra_arena_off == 0) { int rc = ensure_arena(ctx, per); if (rc) return rc; }
-            else if (extra_arena_off + per > ctx->arena.cap) return fail(CG_ERR_ARG, "internal: arena too small");
-            const Affine<F>* pts = (const Affine<F>*)bases->d_pts + offset;
-            for (int j = 0; j < k; j++) {
+    }
+    if (n) {
+        StatScope ss(ctx, TAG_MSM);
+        const size_t sort_bytes = align_up(msm_sort_scratch_bytes(n, c, nwin));
+        { int rc = ensure_arena(ctx, sort_bytes + acc_bytes); if (rc) return rc; }
+        char* sort_scratch = ctx->arena.base; char* acc_scratch = ctx->arena.base + sort_bytes;
+        for (int j = 0; j < k; j++) {
+            MsmSortPtrs sp{};
+            {   // scalar side: once per scalar vector
+                hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
+                if (ctx->stats_on) { const int i0 = ev_open(ctx, TAG_SORT); evs[0] = ctx->ev_live[i0].a; evs[1] = ctx->ev_live[i0].b; pev = evs; }
+                int rc = with_fr(curve, [&](auto tag) -> int { typedef decltype(tag) Fr; return msm_sort_launch<Fr>(ctx->stream, (const Fr*)d_scalars[j], n, c, nwin, sort_scratch, &sp, pev); });
+                if (rc) return rc;
+            }
+            for (int b = 0; b < nb; b++) {   // group side: once per table, reusing the schedule
+                MsmTicket& t = ctx->tickets[slots[b]];
+                hipEvent_t evs[4]; hipEvent_t* pev = nullptr;
                 if (ctx->stats_on) {
-                    const int i0 = ev_open(ctx, TAG_SORT), i1 = ev_open(ctx, bases->group == CG_G1 ? TAG_ACC_G1 : TAG_ACC_G2), i2 = ev_open(ctx, TAG_REDUCE);
-                    hipEvent_t evs[6] = {ctx->ev_live[i0].a, ctx->ev_live[i0].b, ctx->ev_live[i1].a, ctx->ev_live[i1].b, ctx->ev_live[i2].a, ctx->ev_live[i2].b};
-                    int rc = msm_enqueue<F, Fr>(ctx->stream, pts, n, (const Fr*)d_scalars[j], t.c, t.nwin, ctx->arena.base + extra_arena_off, h + (size_t)j * t.nwin, evs);
-                    if (rc) return rc;
-                } else {
-                    int rc = msm_enqueue<F, Fr>(ctx->stream, pts, n, (const Fr*)d_scalars[j], t.c, t.nwin, ctx->arena.base + extra_arena_off, h + (size_t)j * t.nwin, nullptr);
-                    if (rc) return rc;
+                    const int i1 = ev_open(ctx, t.group == CG_G1 ? TAG_ACC_G1 : TAG_ACC_G2), i2 = ev_open(ctx, TAG_REDUCE);
+                    evs[0] = ctx->ev_live[i1].a; evs[1] = ctx->ev_live[i1].b; evs[2] = ctx->ev_live[i2].a; evs[3] = ctx->ev_live[i2].b; pev = evs;
                 }
+                int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
+                    typedef decltype(ftag) F;
+                    const Affine<F>* pts = (const Affine<F>*)bases[b]->d_pts + (offsets ? offsets[b] : 0);
+                    return msm_accumulate_reduce<F>(ctx->stream, pts, n, c, nwin, sp.sorted, sp.offsets, sp.counts, acc_scratch, (XYZZ<F>*)t.h_pinned + (size_t)j * nwin, pev);
+                });
+                if (rc) return rc;
             }
         }
-        HIPCHK(hipEventRecord(t.done, ctx->stream));
-        t.live = true;
-        *ticket_out = slot;
-        return 0;
-    });
+    }
+    for (int b = 0; b < nb; b++) { HIPCHK(hipEventRecord(ctx->tickets[slots[b]].done, ctx->stream)); tickets_out[b] = slots[b]; }
+    return 0;
+}
+
+int msm_begin_impl(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* d_scalars, int k, int* ticket_out) {
+    if (!ticket_out) return fail(CG_ERR_ARG, "null argument");
+    return msm_begin_multi_impl(ctx, 1, &bases, &offset, n, d_scalars, k, ticket_out);
 }
 
 int msm_end_impl(cg_ctx* ctx, int ticket, void* h_out) {
@@ -495,12 +534,16 @@ int32_t cg_msm_set_window(cg_ctx* ctx, int32_t c) {
     return 0;
 }
 int32_t cg_msm_dev_begin(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* d_scalars, int32_t k, int32_t* ticket) {
-    return msm_begin_impl(ctx, bases, offset, n, d_scalars, k, ticket, 0);
+    return msm_begin_impl(ctx, bases, offset, n, d_scalars, k, ticket);
+}
+int32_t cg_msm_dev_begin_multi(cg_ctx* ctx, int32_t n_tables, const cg_bases* const* bases, const size_t* offsets, size_t n,
+                               const void* const* d_scalars, int32_t k, int32_t* tickets) {
+    return msm_begin_multi_impl(ctx, n_tables, bases, offsets, n, d_scalars, k, tickets);
 }
 int32_t cg_msm_end(cg_ctx* ctx, int32_t ticket, void* h_out_jacobian) { return msm_end_impl(ctx, ticket, h_out_jacobian); }
 int32_t cg_msm_dev(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* d_scalars, int32_t k, void* h_out) {
     int32_t t = -1;
-    int rc = msm_begin_impl(ctx, bases, offset, n, d_scalars, k, &t, 0);
+    int rc = msm_begin_impl(ctx, bases, offset, n, d_scalars, k, &t);
     if (rc) return rc;
     return msm_end_impl(ctx, t, h_out);
 }

@@ -12,6 +12,17 @@
 
 #define CG_HD __host__ __device__ __forceinline__
 #define CG_HD_NOINLINE __host__ __device__ __attribute__((noinline))
+// build-time experiment knobs (scripts/microbench.hip): how Fq2 products and base-field products are emitted
+#if defined(CG_FP2_INLINE)
+#define CG_FP2_OP CG_HD
+#else
+#define CG_FP2_OP CG_HD_NOINLINE
+#endif
+#if defined(CG_FPMUL_NOINLINE)
+#define CG_FPMUL_OP CG_HD_NOINLINE
+#else
+#define CG_FPMUL_OP CG_HD
+#endif
 
 namespace cg {
 
@@ -56,7 +67,7 @@ struct alignas(16) Fp {
     CG_HD Fp dbl() const { return *this + *this; }
 
     // Montgomery product, coarsely integrated operand scanning on 32-bit limbs.
-    CG_HD Fp operator*(const Fp& b) const {
+    CG_FPMUL_OP Fp operator*(const Fp& b) const {
         // Invariant: the running value t stays < 2p < 2^(32N) between rounds (p < 2^(32N-1)), so N limbs hold it.
         uint32_t t[N];
         _Pragma("unroll") for (int j = 0; j < N; j++) t[j] = 0;
@@ -123,12 +134,12 @@ struct alignas(16) Fp2 {
     CG_HD Fp2 neg() const { return {c0.neg(), c1.neg()}; }
     CG_HD Fp2 dbl() const { return {c0.dbl(), c1.dbl()}; }
     // out of line: three base-field products per call; G2 formulas call this 8-12 times
-    CG_HD_NOINLINE Fp2 operator*(const Fp2& b) const {
+    CG_FP2_OP Fp2 operator*(const Fp2& b) const {
         F a = c0 * b.c0, d = c1 * b.c1;
         F e = (c0 + c1) * (b.c0 + b.c1);
         return {a - d, e - a - d};
     }
-    CG_HD_NOINLINE Fp2 sqr() const {
+    CG_FP2_OP Fp2 sqr() const {
         F s = c0 + c1, d = c0 - c1, m = c0 * c1;
         return {s * d, m.dbl()};
     }

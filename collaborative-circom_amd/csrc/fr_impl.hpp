@@ -3,6 +3,7 @@
 #include "common.hpp"
 #include "ntt_kernels.hpp"
 #include "vec_kernels.hpp"
+#include "msm_sort_kernels.hpp"
 
 namespace cg {
 
@@ -55,6 +56,33 @@ template <class Fr> int launch_bitrev_scale(hipStream_t st, NttVecs dst, NttVecs
     return 0;
 }
 
+// scalar-dependent half of the MSM: digits, histogram, scan, scatter.  Scratch layout (must match msm_sort_scratch_bytes):
+// digits | sorted | counts | cursors | offsets.   evs (optional, 2 events) bracket the stage.
+struct MsmSortPtrs { const uint32_t* sorted; const uint32_t* offsets; const uint32_t* counts; };
+inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) {
+    const size_t nbuckets = (size_t)nwin << (c - 1);
+    return 2 * align_up((size_t)nwin * n * 4) + 3 * align_up(nbuckets * 4);
+}
+template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, size_t n, int c, int nwin, char* scratch, MsmSortPtrs* out, hipEvent_t* evs) {
+    const size_t nbuckets = (size_t)nwin << (c - 1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void* p = scratch + off; off += align_up(bytes); return p; };
+    int32_t* digits = (int32_t*)take((size_t)nwin * n * 4);
+    uint32_t* sorted = (uint32_t*)take((size_t)nwin * n * 4);
+    uint32_t* counts = (uint32_t*)take(nbuckets * 4);
+    uint32_t* cursors = (uint32_t*)take(nbuckets * 4);
+    uint32_t* offsets = (uint32_t*)take(nbuckets * 4);
+    if (evs) HIPCHK(hipEventRecord(evs[0], st));
+    HIPCHK(hipMemsetAsync(counts, 0, align_up(nbuckets * 4) * 2, st));   // counts + cursors are adjacent
+    hipLaunchKernelGGL((k_msm_digits<Fr>), dim3(grid_for(n)), dim3(256), 0, st, d_scalars, n, c, nwin, digits, counts);
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, counts, offsets, nbuckets);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(grid_for((size_t)nwin * n)), dim3(256), 0, st, digits, n, c, nwin, offsets, cursors, sorted);
+    if (evs) HIPCHK(hipEventRecord(evs[1], st));
+    HIPCHK(hipGetLastError());
+    out->sorted = sorted; out->offsets = offsets; out->counts = counts;
+    return 0;
+}
+
 }  // namespace cg
 
 #define CG_INSTANTIATE_FR(Fr)                                                                                              \
@@ -66,4 +94,5 @@ template <class Fr> int launch_bitrev_scale(hipStream_t st, NttVecs dst, NttVecs
     template int launch_build_twiddles<Fr>(hipStream_t, Fr*, size_t, int, const Fr*, const Fr*, int);                      \
     template int launch_ntt_dif_pass<Fr>(hipStream_t, NttVecs, int, size_t, int, int, int, int, const Fr*);                \
     template int launch_bitrev_scale<Fr>(hipStream_t, NttVecs, NttVecs, int, size_t, int, const Fr*, const Fr*, const Fr*, int); \
+    template int msm_sort_launch<Fr>(hipStream_t, const Fr*, size_t, int, int, char*, MsmSortPtrs*, hipEvent_t*);          \
     }

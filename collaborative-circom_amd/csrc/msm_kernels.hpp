@@ -8,8 +8,9 @@
 //                        histogram with global atomics.                                   [reads 32 B/scalar]
 //   2. k_scan_exclusive  bucket offsets.
 //   3. k_msm_scatter     counting sort of point indices by (window, bucket).
-//   4. k_msm_accumulate  one lane per bucket: gather its points (64/128 B each, one contiguous run per lane) and fold them
-//                        with XYZZ mixed additions (8M+2S).  This is where the time goes: integer VALU bound.
+//   4. k_msm_accumulate  one lane per CHUNK of 128 consecutive sorted entries (balanced work per lane whatever the bucket sizes):
+//                        gather the points (64/128 B each) and fold them with XYZZ mixed additions (8M+2S); pieces of a bucket
+//                        that straddle chunks are merged by k_msm_merge_cont.  This is where the time goes: integer VALU bound.
 //   5. k_msm_reduce_segments / k_msm_window_sum   running-sum bucket reduction, split into 2^15/L independent segments per
 //                        window (segment result = sum (b-lo+1) B_b + lo * sum B_b), then a per-window tree sum in LDS.
 //   6. host: Horner fold of the <= 64 window sums (c doublings each) — O(1) work, kept on the host.
@@ -17,6 +18,7 @@
 #pragma once
 #include "curve.hpp"
 #include "vec_kernels.hpp"
+#include "msm_sort_kernels.hpp"
 
 namespace cg {
 
@@ -36,80 +38,58 @@ __device__ __forceinline__ void st_struct(A* p, const A& r) {
     _Pragma("unroll") for (int i = 0; i < (int)(sizeof(A) / 16); i++) q[i] = d[i];
 }
 
-// digits[w*n + i] = signed digit of scalar i in window w; counts[w*nb + |d|-1]++
-template <class Fr>
-__global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scalars, size_t n, int c, int nwin,
-                                                    int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
-    const uint32_t nb = 1u << (c - 1);
-    const uint32_t mask = (1u << c) - 1;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        Fr s = ld_fp(scalars + i).from_mont();
-        uint32_t carry = 0;
-        for (int w = 0; w < nwin; w++) {
-            uint32_t d = (s.v[0] & mask) + carry;
-            _Pragma("unroll") for (int l = 0; l < Fr::N; l++) {
-                uint64_t two = ((uint64_t)(l + 1 < Fr::N ? s.v[l + 1] : 0u) << 32) | s.v[l];
-                s.v[l] = (uint32_t)(two >> c);
-            }
-            int32_t dig;
-            if (d > nb) { dig = (int32_t)d - (int32_t)(1u << c); carry = 1; } else { dig = (int32_t)d; carry = 0; }
-            digits[(size_t)w * n + i] = dig;
-            if (dig != 0) atomicAdd(&counts[(size_t)w * nb + (uint32_t)(dig < 0 ? -dig : dig) - 1], 1u);
-        }
-    }
-}
-
-// exclusive prefix sum of `total` counters, single workgroup of 1024 lanes (total <= a few million)
-static __global__ void __launch_bounds__(1024) k_scan_exclusive(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t total) {
-    __shared__ uint32_t part[1024];
-    const size_t chunk = (total + 1023) / 1024;
-    const size_t lo = (size_t)threadIdx.x * chunk, hi = lo + chunk < total ? lo + chunk : total;
-    uint32_t s = 0;
-    for (size_t i = lo; i < hi; i++) s += in[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-    for (size_t i = lo; i < hi; i++) { uint32_t v = in[i]; out[i] = run; run += v; }
-}
-
-// sorted[offsets[bucket] + k] = point index | sign << 31
-static __global__ void __launch_bounds__(256) k_msm_scatter(const int32_t* __restrict__ digits, size_t n, int c, int nwin, const uint32_t* __restrict__ offsets,
-                                                     uint32_t* __restrict__ cursors, uint32_t* __restrict__ sorted) {
-    const uint32_t nb = 1u << (c - 1);
-    const size_t total = (size_t)nwin * n;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int32_t dig = digits[idx];
-        if (dig == 0) continue;
-        const size_t w = idx / n;
-        const uint32_t i = (uint32_t)(idx - w * n);
-        const size_t bucket = w * nb + (uint32_t)(dig < 0 ? -dig : dig) - 1;
-        const uint32_t pos = offsets[bucket] + atomicAdd(&cursors[bucket], 1u);
-        sorted[pos] = i | (dig < 0 ? 0x80000000u : 0u);
-    }
-}
-
-// one lane per bucket
+// Bucket accumulation, chunk-balanced: lane q folds the L consecutive entries sorted[q*L, (q+1)*L) of the (window, bucket)-
+// sorted index list, whatever buckets they belong to, so every lane of a wave does the same number of mixed additions
+// (one lane per bucket wastes ~20 % of the wave on the Poisson spread of bucket sizes, and serialises skewed buckets).
+//   * a bucket whose first entry lies in this chunk gets its partial sum written to buckets[b];
+//   * the leading piece of the chunk that continues a bucket begun in an earlier chunk goes to cont[q] (tagged cont_bucket[q]);
+// k_msm_merge_cont then adds the continuation pieces into their buckets (one lane per bucket run, no atomics).
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_accumulate(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                                                        size_t nbuckets, XYZZ<F>* __restrict__ buckets) {
-    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbuckets) return;
+                                                        uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks,
+                                                        XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ cont, uint32_t* __restrict__ cont_bucket) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nchunks) return;
+    const uint32_t total = offsets[nbuckets - 1] + counts[nbuckets - 1];
+    uint32_t pos = q * chunk_len;
+    if (pos >= total) { cont_bucket[q] = 0xffffffffu; return; }
+    const uint32_t end = min(pos + chunk_len, total);
+    // bucket containing entry `pos`: last b with offsets[b] <= pos (empty buckets share an offset with their successor; skip them)
+    uint32_t lo = 0, hi = nbuckets - 1;
+    while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (offsets[mid] <= pos) lo = mid; else hi = mid - 1; }
+    uint32_t b = lo;
+    uint32_t bend = offsets[b] + counts[b];
+    bool continuation = offsets[b] != pos;
+    cont_bucket[q] = continuation ? b : 0xffffffffu;
     XYZZ<F> acc = XYZZ<F>::infinity();
-    const uint32_t off = offsets[b], cnt = counts[b];
-    for (uint32_t k = 0; k < cnt; k++) {
-        const uint32_t e = sorted[off + k];
+    while (pos < end) {
+        if (pos == bend) {                                   // finished bucket b inside this chunk
+            if (continuation) { st_struct(cont + q, acc); continuation = false; } else st_struct(buckets + b, acc);
+            acc = XYZZ<F>::infinity();
+            do { b++; } while (counts[b] == 0);
+            bend = offsets[b] + counts[b];
+        }
+        const uint32_t e = sorted[pos++];
         Affine<F> p = ld_struct(bases + (e & 0x7fffffffu));
         if (p.is_inf()) continue;
         if (e >> 31) p.y = p.y.neg();
         acc = xyzz_madd(acc, p.x, p.y);
     }
+    if (continuation) st_struct(cont + q, acc); else st_struct(buckets + b, acc);
+}
+
+// lane q: if chunk q holds the FIRST continuation piece of its bucket, fold all consecutive continuation pieces of that bucket
+// (chunks q, q+1, ... with the same tag) into buckets[b].  With uniform scalars a bucket spans at most 2-3 chunks.
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_merge_cont(XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ cont, const uint32_t* __restrict__ cont_bucket, uint32_t nchunks) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nchunks) return;
+    const uint32_t b = cont_bucket[q];
+    if (b == 0xffffffffu) return;
+    if (q > 0 && cont_bucket[q - 1] == b) return;
+    XYZZ<F> acc = ld_struct(buckets + b);
+    for (uint32_t r = q; r < nchunks && cont_bucket[r] == b; r++) acc = xyzz_add(acc, ld_struct(cont + r));
     st_struct(buckets + b, acc);
 }
 

@@ -86,7 +86,7 @@ __global__ void k_fpadd(uint32_t* out, uint32_t seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 template <class F>
-__global__ void k_madd(uint32_t* out, uint32_t seed) {
+__global__ void __launch_bounds__(256) k_madd(uint32_t* out, uint32_t seed) {
     XYZZ<F> acc; F x, y;
     uint32_t* xw = reinterpret_cast<uint32_t*>(&x); uint32_t* yw = reinterpret_cast<uint32_t*>(&y);
     for (int i = 0; i < (int)(sizeof(F) / 4); i++) { xw[i] = (threadIdx.x * 2654435761u + i + seed) & 0x0fffffffu; yw[i] = (threadIdx.x * 40503u + i * 3 + seed) & 0x0fffffffu; }
@@ -120,6 +120,7 @@ int run(const char* name, double ops_per_thread, int blocks, int threads, K kern
 int main() {
     const int B = 256 * 8, T = 256;
     const double n8 = 8.0 * ITERS;
+#ifndef CG_MADD_ONLY
     run("v_mad_u64_u32", n8, B, T, k_mad64, 12345u, 777u);
     run("v_mul_lo_u32", n8, B, T, k_mullo, 12345u, 777u);
     run("v_mul_hi_u32(+add)", n8, B, T, k_mulhi, 12345u, 777u);
@@ -136,6 +137,7 @@ int main() {
     run("Fq254 mont_mul x4 chains", 4.0 * (ITERS / 8), B, T, k_fpmul<Bn254Fq, 4>, 1u);
     run("Fq381 mont_mul x1 chain", ITERS / 8, B, T, k_fpmul<Bls381Fq, 1>, 1u);
     run("Fq254 add+sub", 2.0 * ITERS, B, T, k_fpadd<Bn254Fq>, 1u);
+#endif
     run("G1 bn254 xyzz_madd", ITERS / 16, B, T, k_madd<Bn254Fq>, 1u);
     run("G1 bn254 xyzz_madd (occ/2)", ITERS / 16, 256 * 2, T, k_madd<Bn254Fq>, 1u);
     run("G2 bn254 xyzz_madd", ITERS / 16, B, T, k_madd<Fp2<Bn254Fq>>, 1u);

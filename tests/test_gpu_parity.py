@@ -299,3 +299,38 @@ def test_msm_async_tickets(ctx):
     np.testing.assert_array_equal(cg.point_to_affine(curve, G1, r1[0]), orc.msm(curve, G1, p1, s))
     np.testing.assert_array_equal(cg.point_to_affine(curve, G2, r2[0]), orc.msm(curve, G2, p2, s))
     b1.release(); b2.release()
+
+
+def test_msm_multi_table_shared_schedule(ctx):
+    """cg_msm_dev_begin_multi: l/a/b1 (G1) and b2 (G2) tables times the same two share vectors (groth16.rs:251,267,284,298)"""
+    curve, n = BN254, 1500
+    rng = np.random.default_rng(41)
+    tabs = [(G1, make_points(curve, G1, n + 3, rng)), (G1, make_points(curve, G1, n, rng)), (G2, make_points(curve, G2, n + 1, rng))]
+    offs = [3, 0, 1]
+    sa, sb = orc.random_field(curve, FR, n, rng), orc.random_field(curve, FR, n, rng)
+    bases = [ctx.register_bases(curve, g, p) for g, p in tabs]
+    tickets = ctx.msm_dev_begin_multi(bases, [dev(ctx, sa), dev(ctx, sb)], n, offsets=offs)
+    for (g, p), o, t in zip(tabs, offs, tickets):
+        got = ctx.msm_end(t)
+        for j, sc in enumerate((sa, sb)):
+            np.testing.assert_array_equal(cg.point_to_affine(curve, g, got[j]), orc.msm(curve, g, p[o:o + n], sc, threads=8))
+    for b in bases:
+        b.release()
+
+
+@pytest.mark.parametrize("group", [G1, G2])
+def test_msm_skewed_scalars(ctx, group):
+    """non-uniform digits: thousands of entries in a handful of buckets, so one bucket spans many work chunks
+    (plain-driver witnesses look like this: many 0 / 1 / small values)"""
+    curve, n = BN254, 6000
+    rng = np.random.default_rng(8)
+    pts = make_points(curve, group, 64, rng)
+    pts = np.tile(pts, (n // 64 + 1, 1))[:n]
+    small = np.zeros((n, 4), dtype=np.uint64)
+    vals = rng.integers(0, 4, size=n)                    # scalars in {0,1,2,3}
+    table = [orc.from_dec(curve, FR, v) for v in range(4)]
+    for i in range(n):
+        small[i] = table[vals[i]]
+    same = np.tile(orc.random_field(curve, FR, 1, rng), (n, 1))   # every scalar identical: every window has ONE busy bucket
+    msm_check(ctx, curve, group, pts, [small, same])
+    msm_check(ctx, curve, group, pts, [same], window=7)
