@@ -26,7 +26,7 @@ template <class Fr> int launch_distribute_powers(hipStream_t st, Fr* v, size_t n
 template <class Fr> int launch_spmv_csr(hipStream_t st, const uint32_t* row_ptr, const uint32_t* col, const Fr* coeff, size_t n_rows, const Fr* pub,
                                         uint32_t n_inputs, int party, const Fr* wit_a, const Fr* wit_b, Fr* out_a, Fr* out_b);
 template <class Fr> int launch_build_twiddles(hipStream_t st, Fr* tw, size_t m, int log_m, const Fr* lo, const Fr* hi, int log_lo);
-template <class Fr> int launch_ntt_dif_pass(hipStream_t st, NttVecs data, int nvec, size_t n, int log_m, int s0, int k, int t, const Fr* tw);
+template <class Fr> int launch_ntt_dif_pass(hipStream_t st, NttVecs src, NttVecs dst, int nvec, size_t n, int log_m, int s0, int k, int t, const Fr* tw);
 template <class Fr> int launch_bitrev_scale(hipStream_t st, NttVecs dst, NttVecs src, int nvec, size_t n, int log_m, const Fr* scale, const Fr* c_lo, const Fr* c_hi, int log_lo);
 }  // namespace cg
 
@@ -331,7 +331,10 @@ int ntt_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_t n, const 
     NttVecs data{}, tmp{};
     for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->arena.base + arena_off + (size_t)j * n * sizeof(Fr); }
     hipStream_t st = ctx->stream;
-    for (const NttPass& p : ntt_plan(log_m)) { rc = launch_ntt_dif_pass<Fr>(st, data, k, n, log_m, p.s0, p.k, p.t, tw); if (rc) return rc; }
+    {   // first pass reads the caller's vectors and writes the scratch copies; later passes run in the scratch copies
+        bool first = true;
+        for (const NttPass& p : ntt_plan(log_m)) { rc = launch_ntt_dif_pass<Fr>(st, first ? data : tmp, tmp, k, n, log_m, p.s0, p.k, p.t, tw); if (rc) return rc; first = false; }
+    }
     const Fr* d_scale = nullptr; const Fr* c_lo = nullptr; const Fr* c_hi = nullptr; int log_lo = 0;
     if (inverse) {
         Fr ninv = Fr::one();   // n^-1: halve log_m times  (x/2 = (x + (x odd ? p : 0)) >> 1 in Montgomery form as well)
@@ -344,11 +347,8 @@ int ntt_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_t n, const 
         if (coset) { rc = get_coset_tables<Fr>(ctx, curve, log_m, *coset, ninv, &t); if (rc) return rc; c_lo = (const Fr*)t.lo; c_hi = (const Fr*)t.hi; log_lo = t.log_lo; }
         else { rc = get_coset_tables<Fr>(ctx, curve, 0, Fr::one(), ninv, &t); if (rc) return rc; d_scale = (const Fr*)t.lo; }
     } else if (coset) return fail(CG_ERR_ARG, "coset_gen is only supported with inverse != 0");
-    // permutation is out of place: data -> tmp -> (copy back).  TODO(perf): DIT second half removes this copy.
-    rc = launch_bitrev_scale<Fr>(st, tmp, data, k, n, log_m, d_scale, c_lo, c_hi, log_lo);
-    if (rc) return rc;
-    for (int j = 0; j < k; j++) HIPCHK(hipMemcpyAsync(data.p[j], tmp.p[j], n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    return 0;
+    // the permutation brings the result back: tmp -> data (natural order), fused with 1/m and the coset powers
+    return launch_bitrev_scale<Fr>(st, data, tmp, k, n, log_m, d_scale, c_lo, c_hi, log_lo);
 }
 
 template <class F> void copy_in(F& dst, const void* src) { memcpy(dst.v, src, sizeof dst.v); }

@@ -39,11 +39,11 @@ template <class Fr> int launch_build_twiddles(hipStream_t st, Fr* tw, size_t m, 
     HIPCHK(hipGetLastError());
     return 0;
 }
-template <class Fr> int launch_ntt_dif_pass(hipStream_t st, NttVecs data, int nvec, size_t n, int log_m, int s0, int k, int t, const Fr* tw) {
+template <class Fr> int launch_ntt_dif_pass(hipStream_t st, NttVecs src, NttVecs dst, int nvec, size_t n, int log_m, int s0, int k, int t, const Fr* tw) {
     static bool attr_set = false;
     if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_ntt_dif_pass<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_set = true; }
     const int E = 1 << (k + t);
-    hipLaunchKernelGGL((k_ntt_dif_pass<Fr>), dim3((unsigned)(n / E), nvec), dim3(NTT_THREADS), (size_t)E * 32, st, data, log_m, s0, k, t, tw);
+    hipLaunchKernelGGL((k_ntt_dif_pass<Fr>), dim3((unsigned)(n / E), nvec), dim3(NTT_THREADS), (size_t)E * 32, st, src, dst, log_m, s0, k, t, tw);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -92,7 +92,7 @@ template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, siz
     template int launch_distribute_powers<Fr>(hipStream_t, Fr*, size_t, const Fr*, const Fr*, int);                        \
     template int launch_spmv_csr<Fr>(hipStream_t, const uint32_t*, const uint32_t*, const Fr*, size_t, const Fr*, uint32_t, int, const Fr*, const Fr*, Fr*, Fr*); \
     template int launch_build_twiddles<Fr>(hipStream_t, Fr*, size_t, int, const Fr*, const Fr*, int);                      \
-    template int launch_ntt_dif_pass<Fr>(hipStream_t, NttVecs, int, size_t, int, int, int, int, const Fr*);                \
+    template int launch_ntt_dif_pass<Fr>(hipStream_t, NttVecs, NttVecs, int, size_t, int, int, int, int, const Fr*);                \
     template int launch_bitrev_scale<Fr>(hipStream_t, NttVecs, NttVecs, int, size_t, int, const Fr*, const Fr*, const Fr*, int); \
     template int msm_sort_launch<Fr>(hipStream_t, const Fr*, size_t, int, int, char*, MsmSortPtrs*, hipEvent_t*);          \
     }

@@ -38,15 +38,16 @@ __global__ void __launch_bounds__(256) k_build_twiddles(F* __restrict__ tw_all, 
 }
 
 // One DIF pass: stages [s0, s0+k) on tiles of 2^k rows (stride 2^(log_m-s0-k)) x 2^t contiguous elements.
-// grid.x = tiles per vector, grid.y = vector index.
+// grid.x = tiles per vector, grid.y = vector index.  src and dst may be the same buffers (in place) or different ones.
 template <class F>
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_dif_pass(NttVecs vecs, int log_m, int s0, int k, int t, const F* __restrict__ tw_all) {
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_dif_pass(NttVecs src_vecs, NttVecs dst_vecs, int log_m, int s0, int k, int t, const F* __restrict__ tw_all) {
     static_assert(F::N == 8, "NTT is specialised for 256-bit scalar fields");
     extern __shared__ uint4 lds[];                        // two planes (low/high 16 bytes) -> conflict-free 16-byte accesses
     const int E = 1 << (k + t);
     uint4* pl0 = lds;
     uint4* pl1 = lds + E;
-    F* data = reinterpret_cast<F*>(vecs.p[blockIdx.y]);
+    const F* src = reinterpret_cast<const F*>(src_vecs.p[blockIdx.y]);
+    F* dst = reinterpret_cast<F*>(dst_vecs.p[blockIdx.y]);
     const size_t m = (size_t)1 << log_m;
     const int lo_bits = log_m - s0 - k;
     const size_t tiles_per_hi = (size_t)1 << (lo_bits - t);
@@ -57,7 +58,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_dif_pass(NttVecs vecs, int 
 
     for (int idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
         const size_t g = base + ((size_t)(idx >> t) << lo_bits) + (idx & tmask);
-        const uint4* q = reinterpret_cast<const uint4*>(data + g);
+        const uint4* q = reinterpret_cast<const uint4*>(src + g);
         pl0[idx] = q[0]; pl1[idx] = q[1];
     }
     __syncthreads();
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_dif_pass(NttVecs vecs, int 
     }
     for (int idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
         const size_t g = base + ((size_t)(idx >> t) << lo_bits) + (idx & tmask);
-        uint4* q = reinterpret_cast<uint4*>(data + g);
+        uint4* q = reinterpret_cast<uint4*>(dst + g);
         q[0] = pl0[idx]; q[1] = pl1[idx];
     }
 }
