@@ -46,8 +46,18 @@ int msm_accumulate_reduce(hipStream_t st, const Affine<F>* d_bases, size_t n, in
     XYZZ<F>* wsums = (XYZZ<F>*)take((size_t)nwin * sizeof(XYZZ<F>));
     if (evs) HIPCHK(hipEventRecord(evs[0], st));
     HIPCHK(hipMemsetAsync(buckets, 0, g.nbuckets * sizeof(XYZZ<F>), st));          // all-zero XYZZ = infinity (empty buckets are never written)
-    hipLaunchKernelGGL((k_msm_accumulate<F>), dim3((g.nchunks + 255) / 256), dim3(256), 0, st, d_bases, sorted, offsets, counts,
-                       (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, buckets, cont, cont_bucket);
+    if constexpr (sizeof(F) > 48) {      // G2 (and BLS12-381 G1 would not fit either way): accumulator in LDS, 128-lane workgroups
+        constexpr int T = 128;
+        const size_t lds = (size_t)T * sizeof(XYZZ<F>);
+        static bool attr_set = false;
+        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_msm_accumulate<F, LdsAcc<F>, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+        hipLaunchKernelGGL((k_msm_accumulate<F, LdsAcc<F>, T>), dim3((g.nchunks + T - 1) / T), dim3(T), lds, st, d_bases, sorted, offsets, counts,
+                           (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, buckets, cont, cont_bucket);
+    } else {
+        constexpr int T = 256;
+        hipLaunchKernelGGL((k_msm_accumulate<F, RegAcc<F>, T>), dim3((g.nchunks + T - 1) / T), dim3(T), 0, st, d_bases, sorted, offsets, counts,
+                           (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, buckets, cont, cont_bucket);
+    }
     hipLaunchKernelGGL((k_msm_merge_cont<F>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, buckets, cont, cont_bucket, g.nchunks);
     if (evs) { HIPCHK(hipEventRecord(evs[1], st)); HIPCHK(hipEventRecord(evs[2], st)); }
     const size_t nseg_threads = (size_t)nwin * g.segs;

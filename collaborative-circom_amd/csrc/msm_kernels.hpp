@@ -38,18 +38,77 @@ __device__ __forceinline__ void st_struct(A* p, const A& r) {
     _Pragma("unroll") for (int i = 0; i < (int)(sizeof(A) / 16); i++) q[i] = d[i];
 }
 
+// Accumulator storage policy of the bucket-accumulation kernel.
+//  * RegAcc: the XYZZ accumulator lives in VGPRs (G1: 32 dwords, 3 waves/SIMD).
+//  * LdsAcc: the accumulator lives in LDS, one 16-byte column per lane (G2: 64..96 dwords per lane would otherwise push the
+//    kernel to 1 wave/SIMD; in LDS it costs ~32 ds_read/ds_write_b128 per mixed addition, nothing next to ~13k VALU ops).
+template <class F>
+struct RegAcc {
+    static constexpr bool USES_LDS = false;
+    XYZZ<F> v;
+    bool inf;
+    __device__ __forceinline__ void init(uint4*, int, int) { inf = true; }
+    __device__ __forceinline__ F get(int f) const { return f == 0 ? v.x : f == 1 ? v.y : f == 2 ? v.zz : v.zzz; }
+    __device__ __forceinline__ void set(int f, const F& x) { if (f == 0) v.x = x; else if (f == 1) v.y = x; else if (f == 2) v.zz = x; else v.zzz = x; }
+};
+template <class F>
+struct LdsAcc {
+    static constexpr bool USES_LDS = true;
+    static constexpr int Q = sizeof(F) / 16;          // 16-byte quads per coordinate
+    uint4* base; int stride;                           // quad e of this lane at base[e * stride]
+    bool inf;
+    __device__ __forceinline__ void init(uint4* lds, int tid, int nthreads) { base = lds + tid; stride = nthreads; inf = true; }
+    __device__ __forceinline__ F get(int f) const {
+        F r; uint4* d = reinterpret_cast<uint4*>(&r);
+        _Pragma("unroll") for (int i = 0; i < Q; i++) d[i] = base[(f * Q + i) * stride];
+        return r;
+    }
+    __device__ __forceinline__ void set(int f, const F& x) {
+        const uint4* d = reinterpret_cast<const uint4*>(&x);
+        _Pragma("unroll") for (int i = 0; i < Q; i++) base[(f * Q + i) * stride] = d[i];
+    }
+};
+
+// acc += (x2, y2), formulas of xyzz_madd scheduled so that each accumulator coordinate is fetched right before its use
+template <class F, class Acc>
+__device__ __forceinline__ void acc_madd(Acc& acc, const F& x2, const F& y2) {
+    if (acc.inf) { acc.set(0, x2); acc.set(1, y2); acc.set(2, F::one()); acc.set(3, F::one()); acc.inf = false; return; }
+    F P = x2 * acc.get(2) - acc.get(0);
+    F R = y2 * acc.get(3) - acc.get(1);
+    if (P.is_zero()) {
+        if (R.is_zero()) { XYZZ<F> d = xyzz_dbl_affine(x2, y2); acc.inf = d.is_inf(); acc.set(0, d.x); acc.set(1, d.y); acc.set(2, d.zz); acc.set(3, d.zzz); }
+        else acc.inf = true;
+        return;
+    }
+    F PP = P.sqr();
+    acc.set(2, acc.get(2) * PP);
+    F PPP = P * PP;
+    acc.set(3, acc.get(3) * PPP);
+    F Q = acc.get(0) * PP;
+    F X3 = R.sqr() - PPP - Q.dbl();
+    acc.set(0, X3);
+    acc.set(1, R * (Q - X3) - acc.get(1) * PPP);
+}
+template <class F, class Acc>
+__device__ __forceinline__ void acc_flush(Acc& acc, XYZZ<F>* dst) {
+    XYZZ<F> r = acc.inf ? XYZZ<F>::infinity() : XYZZ<F>{acc.get(0), acc.get(1), acc.get(2), acc.get(3)};
+    st_struct(dst, r);
+    acc.inf = true;
+}
+
 // Bucket accumulation, chunk-balanced: lane q folds the L consecutive entries sorted[q*L, (q+1)*L) of the (window, bucket)-
 // sorted index list, whatever buckets they belong to, so every lane of a wave does the same number of mixed additions
 // (one lane per bucket wastes ~20 % of the wave on the Poisson spread of bucket sizes, and serialises skewed buckets).
 //   * a bucket whose first entry lies in this chunk gets its partial sum written to buckets[b];
 //   * the leading piece of the chunk that continues a bucket begun in an earlier chunk goes to cont[q] (tagged cont_bucket[q]);
 // k_msm_merge_cont then adds the continuation pieces into their buckets (one lane per bucket run, no atomics).
-template <class F>
-__global__ void __launch_bounds__(256) k_msm_accumulate(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                                        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                                                        uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks,
-                                                        XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ cont, uint32_t* __restrict__ cont_bucket) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+template <class F, class Acc, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_msm_accumulate(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                            uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks,
+                                                            XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ cont, uint32_t* __restrict__ cont_bucket) {
+    extern __shared__ uint4 acc_lds[];
+    const uint32_t q = blockIdx.x * THREADS + threadIdx.x;
     if (q >= nchunks) return;
     const uint32_t total = offsets[nbuckets - 1] + counts[nbuckets - 1];
     uint32_t pos = q * chunk_len;
@@ -62,11 +121,11 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const Affine<F>* __restr
     uint32_t bend = offsets[b] + counts[b];
     bool continuation = offsets[b] != pos;
     cont_bucket[q] = continuation ? b : 0xffffffffu;
-    XYZZ<F> acc = XYZZ<F>::infinity();
+    Acc acc;
+    acc.init(acc_lds, threadIdx.x, THREADS);
     while (pos < end) {
         if (pos == bend) {                                   // finished bucket b inside this chunk
-            if (continuation) { st_struct(cont + q, acc); continuation = false; } else st_struct(buckets + b, acc);
-            acc = XYZZ<F>::infinity();
+            if (continuation) { acc_flush(acc, cont + q); continuation = false; } else acc_flush(acc, buckets + b);
             do { b++; } while (counts[b] == 0);
             bend = offsets[b] + counts[b];
         }
@@ -74,9 +133,9 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const Affine<F>* __restr
         Affine<F> p = ld_struct(bases + (e & 0x7fffffffu));
         if (p.is_inf()) continue;
         if (e >> 31) p.y = p.y.neg();
-        acc = xyzz_madd(acc, p.x, p.y);
+        acc_madd(acc, p.x, p.y);
     }
-    if (continuation) st_struct(cont + q, acc); else st_struct(buckets + b, acc);
+    if (continuation) acc_flush(acc, cont + q); else acc_flush(acc, buckets + b);
 }
 
 // lane q: if chunk q holds the FIRST continuation piece of its bucket, fold all consecutive continuation pieces of that bucket
