@@ -55,8 +55,12 @@ int msm_accumulate_reduce(hipStream_t st, const Affine<F>* d_bases, size_t n, in
                            (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, buckets, cont, cont_bucket);
     } else {
         constexpr int T = 256;
-        hipLaunchKernelGGL((k_msm_accumulate<F, RegAcc<F>, T>), dim3((g.nchunks + T - 1) / T), dim3(T), 0, st, d_bases, sorted, offsets, counts,
-                           (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, buckets, cont, cont_bucket);
+        if constexpr (sizeof(F) == 32)       // 256-bit base field (BN254 G1): signed lazy 29-bit-limb pipeline
+            hipLaunchKernelGGL((k_msm_accumulate<F, RegAcc29<F>, T>), dim3((g.nchunks + T - 1) / T), dim3(T), 0, st, d_bases, sorted, offsets, counts,
+                               (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, buckets, cont, cont_bucket);
+        else
+            hipLaunchKernelGGL((k_msm_accumulate<F, RegAcc<F>, T>), dim3((g.nchunks + T - 1) / T), dim3(T), 0, st, d_bases, sorted, offsets, counts,
+                               (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, buckets, cont, cont_bucket);
     }
     hipLaunchKernelGGL((k_msm_merge_cont<F>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, buckets, cont, cont_bucket, g.nchunks);
     if (evs) { HIPCHK(hipEventRecord(evs[1], st)); HIPCHK(hipEventRecord(evs[2], st)); }

@@ -96,14 +96,169 @@ __device__ __forceinline__ void acc_flush(Acc& acc, XYZZ<F>* dst) {
     acc.inf = true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Signed lazy-reduction arithmetic on 9 limbs of 29 bits, used INSIDE the G1 bucket-accumulation kernel only.
+//   value = sum l[k] * 2^(29k), limbs 0..7 nominally in [0, 2^29) ("normalised"), limb 8 signed; the value itself is only
+//   known modulo p and lies in a small multiple of (-p, p) — no conditional subtractions anywhere in the mixed addition.
+//   l29_mul(a, b) = (a*b + M*p) / 2^261 with 0 <= M < 2^261: result in (a*b/2^261, a*b/2^261 + p), normalised limbs.
+//   Column accumulators are int64: <= 18 signed products of magnitude < 2^58 (+ carry) never overflow as long as every
+//   multiplication operand has |limb| <= 2^29; differences of two normalised values satisfy that, sums of three do not and
+//   are normalised first.  Internally values live in the 2^261 Montgomery domain (a loaded coordinate a*2^256 is unpacked
+//   shifted left by 5 bits); l29_to_fp multiplies by 2^256/2^261 on the way out.
+// Bounds for the mixed addition below (d = 0.2, all in units of p): products in (-d, 1+d); X in (-4, 2); Y in (-1.5, 1.5);
+// P = U2 - X in (-2.3, 5.3); R = S2 - Y in (-1.8, 2.8); every |a*b| < 31 p^2 = 0.18 p * 2^261.
+template <class F>
+struct L29 {
+    typedef typename F::Params P;
+    static constexpr uint32_t MASK = (1u << 29) - 1;
+    int32_t l[9];
+
+    static constexpr int32_t pl(int k) { return (int32_t)F::p29(k); }
+    // unpack a canonical field element (value < 2^256), optionally times 2^5
+    template <int SHIFT>
+    __device__ __forceinline__ static L29 unpack(const F& a) {
+        L29 r;
+        _Pragma("unroll") for (int k = 0; k < 9; k++) {
+            const int bit = 29 * k - SHIFT;
+            if (bit < 0) { r.l[k] = (int32_t)((a.v[0] << SHIFT) & MASK); continue; }
+            const int w = bit >> 5, sh = bit & 31;
+            uint64_t two = (uint64_t)a.v[w] | (w + 1 < F::N ? (uint64_t)a.v[w + 1] << 32 : 0);
+            r.l[k] = (int32_t)((uint32_t)(two >> sh) & MASK);
+        }
+        if (SHIFT) r.l[8] = (int32_t)(a.v[7] >> (29 * 8 - SHIFT - 32 * 7));   // top limb keeps all remaining bits
+        return r;
+    }
+    __device__ __forceinline__ L29 operator+(const L29& b) const { L29 r; _Pragma("unroll") for (int k = 0; k < 9; k++) r.l[k] = l[k] + b.l[k]; return r; }
+    __device__ __forceinline__ L29 operator-(const L29& b) const { L29 r; _Pragma("unroll") for (int k = 0; k < 9; k++) r.l[k] = l[k] - b.l[k]; return r; }
+    __device__ __forceinline__ L29 neg() const { L29 r; _Pragma("unroll") for (int k = 0; k < 9; k++) r.l[k] = -l[k]; return r; }
+    __device__ __forceinline__ L29 dbl() const { L29 r; _Pragma("unroll") for (int k = 0; k < 9; k++) r.l[k] = l[k] * 2; return r; }
+    // carry propagation: limbs 0..7 into [0, 2^29), limb 8 signed
+    __device__ __forceinline__ L29 norm() const {
+        L29 r; int32_t c = 0;
+        _Pragma("unroll") for (int k = 0; k < 8; k++) { int32_t t = l[k] + c; r.l[k] = t & (int32_t)MASK; c = t >> 29; }
+        r.l[8] = l[8] + c;
+        return r;
+    }
+    __device__ __forceinline__ static L29 mul(const L29& a, const L29& b) {
+        int64_t T[18];
+        _Pragma("unroll") for (int k = 0; k < 18; k++) T[k] = 0;
+        _Pragma("unroll") for (int i = 0; i < 9; i++) {
+            _Pragma("unroll") for (int j = 0; j < 9; j++) T[i + j] += (int64_t)a.l[i] * b.l[j];
+            const int32_t m = (int32_t)(((uint32_t)T[i] * (P::INV & MASK)) & MASK);
+            _Pragma("unroll") for (int j = 0; j < 9; j++) T[i + j] += (int64_t)m * pl(j);
+            T[i + 1] += T[i] >> 29;                       // exact: T[i] is a multiple of 2^29
+        }
+        L29 r;
+        _Pragma("unroll") for (int k = 0; k < 8; k++) { r.l[k] = (int32_t)((uint32_t)T[9 + k] & MASK); T[10 + k] += T[9 + k] >> 29; }
+        r.l[8] = (int32_t)T[17];
+        return r;
+    }
+    // k*p in normalised limbs, k in [-2, 5]: the residues a normalised value in (-3p, 6p) takes when it is 0 mod p
+    __device__ __forceinline__ static bool is_zero_mod_p(const L29& x /* normalised */) {
+        // cheap filter on the lowest limb (a non-zero residue matches one of the 8 candidates with probability 8 / 2^29)
+        bool maybe = false;
+        _Pragma("unroll") for (int kk = -2; kk <= 5; kk++) maybe = maybe || (x.l[0] == (int32_t)(((int64_t)kk * pl(0)) & MASK));
+        if (!maybe) return false;
+        bool any = false;
+        _Pragma("unroll") for (int kk = -2; kk <= 5; kk++) {
+            // limbs of kk*p: carry-normalise kk * p29(j) on the fly (compile-time constants after unrolling)
+            bool eq = true; int64_t c = 0;
+            _Pragma("unroll") for (int j = 0; j < 9; j++) {
+                int64_t t = (int64_t)kk * pl(j) + c;
+                int32_t limb = j < 8 ? (int32_t)(t & MASK) : (int32_t)t;
+                c = t >> 29;
+                eq = eq && (x.l[j] == limb);
+            }
+            any = any || eq;
+        }
+        return any;
+    }
+    // small representative (0.5p .. 1.6p) of 1 in the 2^261 domain: (32 R1) * (32 R1) / 2^261 = 2^261 (mod p), R1 = 2^256 mod p
+    __device__ __forceinline__ static L29 one() { const L29 o = unpack<5>(F::one()); return mul(o, o); }
+    // back to a canonical field element in the ABI's 2^256 Montgomery domain; |value| < 8p
+    __device__ __forceinline__ static F to_fp(const L29& x) {
+        L29 c; _Pragma("unroll") for (int k = 0; k < 9; k++) c.l[k] = 0;
+        c.l[8] = 1 << 24;                                  // 2^256 as an integer: x * 2^256 / 2^261 = x / 32
+        L29 y = mul(x, c);                                 // in (-0.3p, 1.3p), normalised
+        // add p if negative, subtract p if >= p (sign of the top limb after normalisation decides)
+        L29 pp; _Pragma("unroll") for (int k = 0; k < 9; k++) pp.l[k] = pl(k);
+        L29 t = (y + pp).norm();
+        if (y.l[8] < 0) y = t;
+        t = (y - pp).norm();
+        if (t.l[8] >= 0) y = t;
+        F r;
+        _Pragma("unroll") for (int w = 0; w < F::N; w++) {
+            const int k = (32 * w) / 29, sh = 32 * w - 29 * k;
+            r.v[w] = ((uint32_t)y.l[k] >> sh) | ((uint32_t)y.l[k + 1] << (29 - sh));
+        }
+        return r;
+    }
+};
+
+template <class F>
+struct RegAcc29 {
+    L29<F> x, y, zz, zzz;
+    bool inf;
+    __device__ __forceinline__ void init(uint4*, int, int) { inf = true; }
+};
+
+// acc += (x2, y2): madd-2008-s on lazy signed limbs (see the bounds above)
+template <class F>
+__device__ __forceinline__ void acc_madd(RegAcc29<F>& acc, const F& x2f, const F& y2f, bool negate) {
+    typedef L29<F> L;
+    L x2 = L::template unpack<5>(x2f), y2 = L::template unpack<5>(y2f);     // 32*x2, 32*y2: the 2^261 domain
+    if (negate) y2 = y2.neg();
+    if (acc.inf) {
+        // bring the coordinates into the small range first: (32 a) * one / 2^261 = 32 a (mod p), magnitude < 1.3p
+        const L one = L::one();
+        acc.x = L::mul(x2, one); acc.y = L::mul(y2, one); acc.zz = one; acc.zzz = one; acc.inf = false;
+        return;
+    }
+    L P = L::mul(x2, acc.zz) - acc.x;
+    L R = L::mul(y2, acc.zzz) - acc.y;
+    if (L::is_zero_mod_p(P.norm())) {                      // same x: doubling or cancellation (rare)
+        if (L::is_zero_mod_p(R.norm())) {
+            F yy = negate ? y2f.neg() : y2f;
+            XYZZ<F> d = xyzz_dbl_affine(x2f, yy);
+            acc.inf = d.is_inf();
+            if (!acc.inf) {
+                const L one = L::one();
+                acc.x = L::mul(L::template unpack<5>(d.x), one); acc.y = L::mul(L::template unpack<5>(d.y), one);
+                acc.zz = L::mul(L::template unpack<5>(d.zz), one); acc.zzz = L::mul(L::template unpack<5>(d.zzz), one);
+            }
+        } else acc.inf = true;
+        return;
+    }
+    L PP = L::mul(P, P);
+    L PPP = L::mul(P, PP);
+    L Q = L::mul(acc.x, PP);
+    acc.zz = L::mul(acc.zz, PP);
+    acc.zzz = L::mul(acc.zzz, PPP);
+    L X3 = (L::mul(R, R) - PPP - Q.dbl()).norm();
+    acc.y = (L::mul(R, Q - X3) - L::mul(acc.y, PPP)).norm();
+    acc.x = X3;
+}
+template <class F>
+__device__ __forceinline__ void acc_flush(RegAcc29<F>& acc, XYZZ<F>* dst) {
+    XYZZ<F> r = XYZZ<F>::infinity();
+    if (!acc.inf) { r.x = L29<F>::to_fp(acc.x); r.y = L29<F>::to_fp(acc.y); r.zz = L29<F>::to_fp(acc.zz); r.zzz = L29<F>::to_fp(acc.zzz); }
+    st_struct(dst, r);
+    acc.inf = true;
+}
+// generic accumulators take the (already negated) point
+template <class F, class Acc>
+__device__ __forceinline__ void acc_madd(Acc& acc, const F& x2, const F& y2, bool negate) {
+    acc_madd(acc, x2, negate ? y2.neg() : y2);
+}
+
 // Bucket accumulation, chunk-balanced: lane q folds the L consecutive entries sorted[q*L, (q+1)*L) of the (window, bucket)-
 // sorted index list, whatever buckets they belong to, so every lane of a wave does the same number of mixed additions
 // (one lane per bucket wastes ~20 % of the wave on the Poisson spread of bucket sizes, and serialises skewed buckets).
 //   * a bucket whose first entry lies in this chunk gets its partial sum written to buckets[b];
 //   * the leading piece of the chunk that continues a bucket begun in an earlier chunk goes to cont[q] (tagged cont_bucket[q]);
 // k_msm_merge_cont then adds the continuation pieces into their buckets (one lane per bucket run, no atomics).
-template <class F, class Acc, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_msm_accumulate(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+template <class F, class Acc, int THREADS, int MINW = 1>
+__global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                             uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks,
                                                             XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ cont, uint32_t* __restrict__ cont_bucket) {
@@ -132,8 +287,7 @@ __global__ void __launch_bounds__(THREADS) k_msm_accumulate(const Affine<F>* __r
         const uint32_t e = sorted[pos++];
         Affine<F> p = ld_struct(bases + (e & 0x7fffffffu));
         if (p.is_inf()) continue;
-        if (e >> 31) p.y = p.y.neg();
-        acc_madd(acc, p.x, p.y);
+        acc_madd(acc, p.x, p.y, (e >> 31) != 0);
     }
     if (continuation) acc_flush(acc, cont + q); else acc_flush(acc, buckets + b);
 }
