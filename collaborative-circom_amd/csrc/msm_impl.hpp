@@ -46,22 +46,22 @@ int msm_accumulate_reduce(hipStream_t st, const Affine<F>* d_bases, size_t n, in
     XYZZ<F>* wsums = (XYZZ<F>*)take((size_t)nwin * sizeof(XYZZ<F>));
     if (evs) HIPCHK(hipEventRecord(evs[0], st));
     HIPCHK(hipMemsetAsync(buckets, 0, g.nbuckets * sizeof(XYZZ<F>), st));          // all-zero XYZZ = infinity (empty buckets are never written)
-    if constexpr (sizeof(F) > 48) {      // G2 (and BLS12-381 G1 would not fit either way): accumulator in LDS, 128-lane workgroups
-        constexpr int T = 128;
-        const size_t lds = (size_t)T * sizeof(XYZZ<F>);
-        static bool attr_set = false;
-        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_msm_accumulate<F, LdsAcc<F>, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
-        hipLaunchKernelGGL((k_msm_accumulate<F, LdsAcc<F>, T>), dim3((g.nchunks + T - 1) / T), dim3(T), lds, st, d_bases, sorted, offsets, counts,
+    auto launch_acc = [&](auto kern, int T, size_t lds) -> int {
+        if (lds > 0) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((g.nchunks + T - 1) / T), dim3(T), lds, st, d_bases, sorted, offsets, counts,
                            (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, buckets, cont, cont_bucket);
-    } else {
-        constexpr int T = 256;
-        if constexpr (sizeof(F) == 32)       // 256-bit base field (BN254 G1): signed lazy 29-bit-limb pipeline
-            hipLaunchKernelGGL((k_msm_accumulate<F, RegAcc29<F>, T>), dim3((g.nchunks + T - 1) / T), dim3(T), 0, st, d_bases, sorted, offsets, counts,
-                               (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, buckets, cont, cont_bucket);
-        else
-            hipLaunchKernelGGL((k_msm_accumulate<F, RegAcc<F>, T>), dim3((g.nchunks + T - 1) / T), dim3(T), 0, st, d_bases, sorted, offsets, counts,
-                               (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, buckets, cont, cont_bucket);
-    }
+        return 0;
+    };
+    // accumulator policy per coordinate field:
+    //   32 B  (BN254 Fq)        lazy 29-bit limbs in VGPRs
+    //   64 B  (BN254 Fq2)       lazy 29-bit limbs, accumulator in LDS (72 dwords per lane), 128-lane workgroups
+    //   48 B  (BLS12-381 Fq)    saturated limbs in VGPRs          96 B (BLS12-381 Fq2)  saturated limbs, accumulator in LDS
+    int rc_acc;
+    if constexpr (sizeof(F) == 32) rc_acc = launch_acc(k_msm_accumulate<F, RegAcc29<F>, 256>, 256, 0);
+    else if constexpr (sizeof(F) == 64) rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc29<F>, 128>, 128, (size_t)128 * 4 * sizeof(typename LazyOf<F>::type));
+    else if constexpr (sizeof(F) > 64) rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc<F>, 128>, 128, (size_t)128 * sizeof(XYZZ<F>));
+    else rc_acc = launch_acc(k_msm_accumulate<F, RegAcc<F>, 256>, 256, 0);
+    if (rc_acc) return rc_acc;
     hipLaunchKernelGGL((k_msm_merge_cont<F>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, buckets, cont, cont_bucket, g.nchunks);
     if (evs) { HIPCHK(hipEventRecord(evs[1], st)); HIPCHK(hipEventRecord(evs[2], st)); }
     const size_t nseg_threads = (size_t)nwin * g.segs;

@@ -44,6 +44,7 @@ __device__ __forceinline__ void st_struct(A* p, const A& r) {
 //    kernel to 1 wave/SIMD; in LDS it costs ~32 ds_read/ds_write_b128 per mixed addition, nothing next to ~13k VALU ops).
 template <class F>
 struct RegAcc {
+    typedef uint4 LdsT;
     static constexpr bool USES_LDS = false;
     XYZZ<F> v;
     bool inf;
@@ -53,6 +54,7 @@ struct RegAcc {
 };
 template <class F>
 struct LdsAcc {
+    typedef uint4 LdsT;
     static constexpr bool USES_LDS = true;
     static constexpr int Q = sizeof(F) / 16;          // 16-byte quads per coordinate
     uint4* base; int stride;                           // quad e of this lane at base[e * stride]
@@ -153,14 +155,14 @@ struct L29 {
         r.l[8] = (int32_t)T[17];
         return r;
     }
-    // k*p in normalised limbs, k in [-2, 5]: the residues a normalised value in (-3p, 6p) takes when it is 0 mod p
+    // k*p in normalised limbs, k in [-3, 6]: the residues a normalised value in (-4p, 7p) takes when it is 0 mod p
     __device__ __forceinline__ static bool is_zero_mod_p(const L29& x /* normalised */) {
-        // cheap filter on the lowest limb (a non-zero residue matches one of the 8 candidates with probability 8 / 2^29)
+        // cheap filter on the lowest limb (a non-zero residue matches one of the candidates with probability ~10 / 2^29)
         bool maybe = false;
-        _Pragma("unroll") for (int kk = -2; kk <= 5; kk++) maybe = maybe || (x.l[0] == (int32_t)(((int64_t)kk * pl(0)) & MASK));
+        _Pragma("unroll") for (int kk = -3; kk <= 6; kk++) maybe = maybe || (x.l[0] == (int32_t)(((int64_t)kk * pl(0)) & MASK));
         if (!maybe) return false;
         bool any = false;
-        _Pragma("unroll") for (int kk = -2; kk <= 5; kk++) {
+        _Pragma("unroll") for (int kk = -3; kk <= 6; kk++) {
             // limbs of kk*p: carry-normalise kk * p29(j) on the fly (compile-time constants after unrolling)
             bool eq = true; int64_t c = 0;
             _Pragma("unroll") for (int j = 0; j < 9; j++) {
@@ -173,6 +175,8 @@ struct L29 {
         }
         return any;
     }
+    __device__ __forceinline__ static L29 sqr(const L29& a) { return mul(a, a); }
+    __device__ __forceinline__ static XYZZ<F> dbl_affine(const F& x, const F& y) { return xyzz_dbl_affine(x, y); }
     // small representative (0.5p .. 1.6p) of 1 in the 2^261 domain: (32 R1) * (32 R1) / 2^261 = 2^261 (mod p), R1 = 2^256 mod p
     __device__ __forceinline__ static L29 one() { const L29 o = unpack<5>(F::one()); return mul(o, o); }
     // back to a canonical field element in the ABI's 2^256 Montgomery domain; |value| < 8p
@@ -195,60 +199,143 @@ struct L29 {
     }
 };
 
-template <class F>
-struct RegAcc29 {
-    L29<F> x, y, zz, zzz;
-    bool inf;
-    __device__ __forceinline__ void init(uint4*, int, int) { inf = true; }
+// Fp2 = Fp[u]/(u^2+1) on lazy limbs.  Products are accumulated FUSED: c0 = a0 b0 - a1 b1 and c1 = a0 b1 + a1 b0 are each one
+// column accumulation (18 signed products + 9 reduction products per column: < 27 * 2^58 < 2^63) followed by ONE reduction,
+// i.e. the same 486 multiplies as Karatsuba but no pre/post additions and 2 instead of 3 reductions.
+// Bounds (d = 0.45, units of p, per component): products in (-d, 1+d); X in (-4.8, 2.8); Y in (-1.9, 1.9); P in (-3.3, 6.3).
+#ifndef CG_L29X2_INLINE
+#define CG_L29X2_INLINE __forceinline__
+#endif
+template <class F2>
+struct L29x2 {
+    typedef typename F2::Base F;
+    typedef L29<F> L;
+    L c0, c1;
+    template <int SHIFT> __device__ __forceinline__ static L29x2 unpack(const F2& a) { return {L::template unpack<SHIFT>(a.c0), L::template unpack<SHIFT>(a.c1)}; }
+    __device__ __forceinline__ L29x2 operator+(const L29x2& b) const { return {c0 + b.c0, c1 + b.c1}; }
+    __device__ __forceinline__ L29x2 operator-(const L29x2& b) const { return {c0 - b.c0, c1 - b.c1}; }
+    __device__ __forceinline__ L29x2 neg() const { return {c0.neg(), c1.neg()}; }
+    __device__ __forceinline__ L29x2 dbl() const { return {c0.dbl(), c1.dbl()}; }
+    __device__ __forceinline__ L29x2 norm() const { return {c0.norm(), c1.norm()}; }
+    // r = (a*b + s*c*d + M p) / 2^261, s = +1 or -1: the fused two-product Montgomery step
+    template <int SIGN>
+    __device__ __forceinline__ static L mul2(const L& a, const L& b, const L& c, const L& d) {
+        typedef typename F::Params P;
+        int64_t T[18];
+        _Pragma("unroll") for (int k = 0; k < 18; k++) T[k] = 0;
+        _Pragma("unroll") for (int i = 0; i < 9; i++) {
+            _Pragma("unroll") for (int j = 0; j < 9; j++) T[i + j] += (int64_t)a.l[i] * b.l[j];
+            _Pragma("unroll") for (int j = 0; j < 9; j++) T[i + j] += (int64_t)(SIGN > 0 ? c.l[i] : -c.l[i]) * d.l[j];
+            const int32_t m = (int32_t)(((uint32_t)T[i] * (P::INV & L::MASK)) & L::MASK);
+            _Pragma("unroll") for (int j = 0; j < 9; j++) T[i + j] += (int64_t)m * L::pl(j);
+            T[i + 1] += T[i] >> 29;
+        }
+        L r;
+        _Pragma("unroll") for (int k = 0; k < 8; k++) { r.l[k] = (int32_t)((uint32_t)T[9 + k] & L::MASK); T[10 + k] += T[9 + k] >> 29; }
+        r.l[8] = (int32_t)T[17];
+        return r;
+    }
+    static __device__ CG_L29X2_INLINE L29x2 mul(const L29x2& a, const L29x2& b) {
+        return {mul2<-1>(a.c0, b.c0, a.c1, b.c1), mul2<+1>(a.c0, b.c1, a.c1, b.c0)};
+    }
+    static __device__ CG_L29X2_INLINE L29x2 sqr(const L29x2& a) {
+        L s = (a.c0 + a.c1).norm(), d = (a.c0 - a.c1).norm();     // limb magnitude back to 2^29 before multiplying
+        return {L::mul(s, d), L::mul(a.c0.dbl(), a.c1)};
+    }
+    __device__ __forceinline__ static bool is_zero_mod_p(const L29x2& x) { return L::is_zero_mod_p(x.c0) && L::is_zero_mod_p(x.c1); }
+    __device__ __forceinline__ static L29x2 one() { L z; _Pragma("unroll") for (int k = 0; k < 9; k++) z.l[k] = 0; return {L::one(), z}; }
+    __device__ __forceinline__ static F2 to_fp(const L29x2& x) { return {L::to_fp(x.c0), L::to_fp(x.c1)}; }
+    __device__ __forceinline__ static XYZZ<F2> dbl_affine(const F2& x, const F2& y) { return xyzz_dbl_affine(x, y); }
 };
 
-// acc += (x2, y2): madd-2008-s on lazy signed limbs (see the bounds above)
+template <class F> struct LazyOf { typedef L29<F> type; };
+template <class B> struct LazyOf<Fp2<B>> { typedef L29x2<Fp2<B>> type; };
+
+// lazy accumulator in VGPRs (G1) or LDS (G2: 72 dwords per lane)
 template <class F>
-__device__ __forceinline__ void acc_madd(RegAcc29<F>& acc, const F& x2f, const F& y2f, bool negate) {
-    typedef L29<F> L;
+struct RegAcc29 {
+    typedef uint32_t LdsT;
+    typedef typename LazyOf<F>::type L;
+    L c[4];
+    bool inf;
+    __device__ __forceinline__ void init(uint32_t*, int, int) { inf = true; }
+    __device__ __forceinline__ L get(int f) const { return c[f]; }
+    __device__ __forceinline__ void set(int f, const L& x) { c[f] = x; }
+};
+template <class F>
+struct LdsAcc29 {
+    typedef uint32_t LdsT;
+    typedef typename LazyOf<F>::type L;
+    static constexpr int W = sizeof(L) / 4;               // dwords per coordinate
+    uint32_t* base; int stride; bool inf;
+    __device__ __forceinline__ void init(uint32_t* lds, int tid, int nthreads) { base = lds + tid; stride = nthreads; inf = true; }
+    __device__ __forceinline__ L get(int f) const {
+        L r; uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+        _Pragma("unroll") for (int i = 0; i < W; i++) d[i] = base[(f * W + i) * stride];
+        return r;
+    }
+    __device__ __forceinline__ void set(int f, const L& x) {
+        const uint32_t* d = reinterpret_cast<const uint32_t*>(&x);
+        _Pragma("unroll") for (int i = 0; i < W; i++) base[(f * W + i) * stride] = d[i];
+    }
+};
+template <class Acc> struct IsLazyAcc { static constexpr bool value = false; };
+template <class F> struct IsLazyAcc<RegAcc29<F>> { static constexpr bool value = true; };
+template <class F> struct IsLazyAcc<LdsAcc29<F>> { static constexpr bool value = true; };
+
+// acc += (x2, y2): madd-2008-s on lazy signed limbs (see the bounds above); coordinates 0..3 = X, Y, ZZ, ZZZ
+template <class F, class Acc>
+__device__ __forceinline__ void acc_madd_lazy(Acc& acc, const F& x2f, const F& y2f, bool negate) {
+    typedef typename LazyOf<F>::type L;
     L x2 = L::template unpack<5>(x2f), y2 = L::template unpack<5>(y2f);     // 32*x2, 32*y2: the 2^261 domain
     if (negate) y2 = y2.neg();
     if (acc.inf) {
-        // bring the coordinates into the small range first: (32 a) * one / 2^261 = 32 a (mod p), magnitude < 1.3p
+        // bring the coordinates into the small range first: (32 a) * one / 2^261 = 32 a (mod p), magnitude < 1.5p
         const L one = L::one();
-        acc.x = L::mul(x2, one); acc.y = L::mul(y2, one); acc.zz = one; acc.zzz = one; acc.inf = false;
+        acc.set(0, L::mul(x2, one)); acc.set(1, L::mul(y2, one)); acc.set(2, one); acc.set(3, one); acc.inf = false;
         return;
     }
-    L P = L::mul(x2, acc.zz) - acc.x;
-    L R = L::mul(y2, acc.zzz) - acc.y;
+    L P = L::mul(x2, acc.get(2)) - acc.get(0);
+    L R = L::mul(y2, acc.get(3)) - acc.get(1);
     if (L::is_zero_mod_p(P.norm())) {                      // same x: doubling or cancellation (rare)
         if (L::is_zero_mod_p(R.norm())) {
-            F yy = negate ? y2f.neg() : y2f;
-            XYZZ<F> d = xyzz_dbl_affine(x2f, yy);
+            XYZZ<F> d = L::dbl_affine(x2f, negate ? y2f.neg() : y2f);
             acc.inf = d.is_inf();
             if (!acc.inf) {
                 const L one = L::one();
-                acc.x = L::mul(L::template unpack<5>(d.x), one); acc.y = L::mul(L::template unpack<5>(d.y), one);
-                acc.zz = L::mul(L::template unpack<5>(d.zz), one); acc.zzz = L::mul(L::template unpack<5>(d.zzz), one);
+                acc.set(0, L::mul(L::template unpack<5>(d.x), one)); acc.set(1, L::mul(L::template unpack<5>(d.y), one));
+                acc.set(2, L::mul(L::template unpack<5>(d.zz), one)); acc.set(3, L::mul(L::template unpack<5>(d.zzz), one));
             }
         } else acc.inf = true;
         return;
     }
-    L PP = L::mul(P, P);
+    L PP = L::sqr(P);
     L PPP = L::mul(P, PP);
-    L Q = L::mul(acc.x, PP);
-    acc.zz = L::mul(acc.zz, PP);
-    acc.zzz = L::mul(acc.zzz, PPP);
-    L X3 = (L::mul(R, R) - PPP - Q.dbl()).norm();
-    acc.y = (L::mul(R, Q - X3) - L::mul(acc.y, PPP)).norm();
-    acc.x = X3;
+    L Q = L::mul(acc.get(0), PP);
+    acc.set(2, L::mul(acc.get(2), PP));
+    acc.set(3, L::mul(acc.get(3), PPP));
+    L X3 = (L::sqr(R) - PPP - Q.dbl()).norm();
+    acc.set(1, (L::mul(R, Q - X3) - L::mul(acc.get(1), PPP)).norm());
+    acc.set(0, X3);
 }
-template <class F>
-__device__ __forceinline__ void acc_flush(RegAcc29<F>& acc, XYZZ<F>* dst) {
+template <class F, class Acc>
+__device__ __forceinline__ void acc_flush_lazy(Acc& acc, XYZZ<F>* dst) {
+    typedef typename LazyOf<F>::type L;
     XYZZ<F> r = XYZZ<F>::infinity();
-    if (!acc.inf) { r.x = L29<F>::to_fp(acc.x); r.y = L29<F>::to_fp(acc.y); r.zz = L29<F>::to_fp(acc.zz); r.zzz = L29<F>::to_fp(acc.zzz); }
+    if (!acc.inf) { r.x = L::to_fp(acc.get(0)); r.y = L::to_fp(acc.get(1)); r.zz = L::to_fp(acc.get(2)); r.zzz = L::to_fp(acc.get(3)); }
     st_struct(dst, r);
     acc.inf = true;
 }
-// generic accumulators take the (already negated) point
+// dispatch on the accumulator kind
 template <class F, class Acc>
 __device__ __forceinline__ void acc_madd(Acc& acc, const F& x2, const F& y2, bool negate) {
-    acc_madd(acc, x2, negate ? y2.neg() : y2);
+    if constexpr (IsLazyAcc<Acc>::value) acc_madd_lazy<F>(acc, x2, y2, negate);
+    else acc_madd(acc, x2, negate ? y2.neg() : y2);
+}
+template <class F, class Acc>
+__device__ __forceinline__ void acc_store(Acc& acc, XYZZ<F>* dst) {
+    if constexpr (IsLazyAcc<Acc>::value) acc_flush_lazy<F>(acc, dst);
+    else acc_flush(acc, dst);
 }
 
 // Bucket accumulation, chunk-balanced: lane q folds the L consecutive entries sorted[q*L, (q+1)*L) of the (window, bucket)-
@@ -277,10 +364,10 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
     bool continuation = offsets[b] != pos;
     cont_bucket[q] = continuation ? b : 0xffffffffu;
     Acc acc;
-    acc.init(acc_lds, threadIdx.x, THREADS);
+    acc.init(reinterpret_cast<typename Acc::LdsT*>(acc_lds), threadIdx.x, THREADS);
     while (pos < end) {
         if (pos == bend) {                                   // finished bucket b inside this chunk
-            if (continuation) { acc_flush(acc, cont + q); continuation = false; } else acc_flush(acc, buckets + b);
+            if (continuation) { acc_store(acc, cont + q); continuation = false; } else acc_store(acc, buckets + b);
             do { b++; } while (counts[b] == 0);
             bend = offsets[b] + counts[b];
         }
@@ -289,7 +376,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
         if (p.is_inf()) continue;
         acc_madd(acc, p.x, p.y, (e >> 31) != 0);
     }
-    if (continuation) acc_flush(acc, cont + q); else acc_flush(acc, buckets + b);
+    if (continuation) acc_store(acc, cont + q); else acc_store(acc, buckets + b);
 }
 
 // lane q: if chunk q holds the FIRST continuation piece of its bucket, fold all consecutive continuation pieces of that bucket
