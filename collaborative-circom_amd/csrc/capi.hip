@@ -17,7 +17,7 @@ template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, siz
 template <class F> int msm_accumulate_reduce(hipStream_t st, const Affine<F>* d_bases, size_t n, int c, int nwin, const uint32_t* sorted, const uint32_t* offsets,
                                              const uint32_t* counts, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs);
 template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin);
-inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) { const size_t nbuckets = (size_t)nwin << (c - 1); return 2 * align_up((size_t)nwin * n * 4) + 3 * align_up(nbuckets * 4); }
+inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) { const size_t nbuckets = (size_t)nwin << (c - 1); return 2 * align_up((size_t)nwin * n * 4) + 3 * align_up(nbuckets * 4) + align_up(((nbuckets + 2047) / 2048) * 4); }
 template <class F> int pack_bases_launch(hipStream_t st, const uint8_t* d_raw, size_t n, size_t stride, long inf_off, Affine<F>* d_dst);
 template <class F> int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi, int log_t, size_t n, Affine<F>* d_out);
 template <class Fr> int launch_vec_binary(hipStream_t st, int op, Fr* out, const Fr* a, const Fr* b, size_t n);

@@ -61,7 +61,7 @@ template <class Fr> int launch_bitrev_scale(hipStream_t st, NttVecs dst, NttVecs
 struct MsmSortPtrs { const uint32_t* sorted; const uint32_t* offsets; const uint32_t* counts; };
 inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) {
     const size_t nbuckets = (size_t)nwin << (c - 1);
-    return 2 * align_up((size_t)nwin * n * 4) + 3 * align_up(nbuckets * 4);
+    return 2 * align_up((size_t)nwin * n * 4) + 3 * align_up(nbuckets * 4) + align_up(((nbuckets + SCAN_TILE - 1) / SCAN_TILE) * 4);
 }
 template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, size_t n, int c, int nwin, char* scratch, MsmSortPtrs* out, hipEvent_t* evs) {
     const size_t nbuckets = (size_t)nwin << (c - 1);
@@ -72,10 +72,14 @@ template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, siz
     uint32_t* counts = (uint32_t*)take(nbuckets * 4);
     uint32_t* cursors = (uint32_t*)take(nbuckets * 4);
     uint32_t* offsets = (uint32_t*)take(nbuckets * 4);
+    const size_t ntiles = (nbuckets + SCAN_TILE - 1) / SCAN_TILE;
+    uint32_t* tile_sums = (uint32_t*)take(ntiles * 4);
     if (evs) HIPCHK(hipEventRecord(evs[0], st));
     HIPCHK(hipMemsetAsync(counts, 0, align_up(nbuckets * 4) * 2, st));   // counts + cursors are adjacent
     hipLaunchKernelGGL((k_msm_digits<Fr>), dim3(grid_for(n)), dim3(256), 0, st, d_scalars, n, c, nwin, digits, counts);
-    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, counts, offsets, nbuckets);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)ntiles), dim3(256), 0, st, counts, tile_sums, nbuckets);
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, tile_sums, tile_sums, ntiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(256), 0, st, counts, tile_sums, offsets, nbuckets);
     hipLaunchKernelGGL(k_msm_scatter, dim3(grid_for((size_t)nwin * n)), dim3(256), 0, st, digits, n, c, nwin, offsets, cursors, sorted);
     if (evs) HIPCHK(hipEventRecord(evs[1], st));
     HIPCHK(hipGetLastError());

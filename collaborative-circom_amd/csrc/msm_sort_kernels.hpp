@@ -31,8 +31,20 @@ __global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scala
     }
 }
 
-// exclusive prefix sum of `total` counters, single workgroup of 1024 lanes (total <= a few million)
-static __global__ void __launch_bounds__(1024) k_scan_exclusive(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t total) {
+// exclusive prefix sum of `total` counters in three launches: per-tile sums, scan of the tile sums, per-tile scan + base.
+constexpr int SCAN_TILE = 2048;     // counters per workgroup (256 lanes x 8)
+static __global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t* __restrict__ in, uint32_t* __restrict__ tile_sums, size_t total) {
+    __shared__ uint32_t red[256];
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE;
+    uint32_t s = 0;
+    for (int k = 0; k < SCAN_TILE / 256; k++) { size_t i = base + (size_t)k * 256 + threadIdx.x; if (i < total) s += in[i]; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = red[0];
+}
+// single workgroup: in-place exclusive scan of up to 1024 * per-lane-chunk tile sums
+static __global__ void __launch_bounds__(1024) k_scan_exclusive(const uint32_t* in, uint32_t* out, size_t total) {   // in may alias out
     __shared__ uint32_t part[1024];
     const size_t chunk = (total + 1023) / 1024;
     const size_t lo = (size_t)threadIdx.x * chunk, hi = lo + chunk < total ? lo + chunk : total;
@@ -48,6 +60,22 @@ static __global__ void __launch_bounds__(1024) k_scan_exclusive(const uint32_t* 
     }
     uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
     for (size_t i = lo; i < hi; i++) { uint32_t v = in[i]; out[i] = run; run += v; }
+}
+static __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* __restrict__ in, const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ out, size_t total) {
+    __shared__ uint32_t part[256];
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * (SCAN_TILE / 256);
+    uint32_t v[SCAN_TILE / 256]; uint32_t s = 0;
+    for (int k = 0; k < SCAN_TILE / 256; k++) { size_t i = base + k; v[k] = i < total ? in[i] : 0; s += v[k]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t t = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = tile_base[blockIdx.x] + (threadIdx.x ? part[threadIdx.x - 1] : 0);
+    for (int k = 0; k < SCAN_TILE / 256; k++) { size_t i = base + k; if (i < total) out[i] = run; run += v[k]; }
 }
 
 // sorted[offsets[bucket] + k] = point index | sign << 31
