@@ -5,6 +5,7 @@
 // with (0,0) = infinity (the packed zkey encoding, `/root/reference/co-circom/circom-types/src/traits.rs:107-155`).
 #include "pairing.hpp"
 #include "bench.hpp"
+#include "synth.hpp"
 #include <chrono>
 
 using namespace orc;
@@ -339,6 +340,12 @@ double orc_bench_rep3_party(int curve, int log_m, int threads, uint64_t seed, do
         if (curve == 1) return bench_rep3_party<Bls12_381>(log_m, threads, seed, stage);
         g_err = "bad curve id"; return -1.0;
     } catch (const std::exception& e) { g_err = e.what(); return -2.0; }
+}
+
+// synthetic satisfiable circuit + valid CRS of domain size 2^log_m written as .zkey / .wtns (test tooling)
+int orc_make_synthetic(int curve, int log_m, uint64_t seed, const char* zkey_path, const char* wtns_path, int threads) {
+    DISPATCH(curve, { make_synthetic<C>(log_m, seed, zkey_path, wtns_path, threads); });
+    return 0;
 }
 
 }  // extern "C"

@@ -260,6 +260,11 @@ def bench_rep3_party(curve, log_m, threads, seed=1):
     return t, {"spmv_pointwise_s": stage[0], "ntt_s": stage[1], "msm_g1_s": stage[2], "msm_g2_s": stage[3]}
 
 
+def make_synthetic(curve, log_m, seed, zkey_path, wtns_path, threads=8):
+    """synthetic satisfiable R1CS (m - 2 constraints, 1 public input) with a valid Groth16 CRS, as .zkey + .wtns files"""
+    _chk(lib().orc_make_synthetic(curve, int(log_m), C.c_uint64(seed), zkey_path.encode(), wtns_path.encode(), int(threads)))
+
+
 # ---- snarkjs JSON <-> packed arrays ---------------------------------------------------------------
 def g1_from_json(curve, arr):
     """["x","y","1"] / ["0","1","0"] (traits.rs:186-233)"""
