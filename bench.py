@@ -236,6 +236,12 @@ def main():
         alg_bytes = 96.0 * avg_pts
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         per_step = lambda k: st[k] / args.steps
+        traffic = None          # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes (profiles/)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["dominant_kernel_traffic_bytes_per_launch"] if world == 1 and args.log_m == 22 else None
+        except Exception:
+            traffic = None
         out = {
             "metric": "Groth16 constraints/sec (BN254, 2^22 R1CS), one REP3 party's prove compute",
             "value": value, "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -244,10 +250,10 @@ def main():
             "config": {"workload": f"synthetic R1CS 2^{args.log_m} constraints-domain BN254, REP3 co-groth16 (configs[2])",
                        "num_constraints": w.nc, "domain_size": w.m, "n_vars": w.m, "nnz": w.nnz, "share_components": 2,
                        "msm": "8 G1 + 2 G2 of ~2^%d points" % args.log_m, "ntt": 12, "parallelism": f"msm-range-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<G1> (bucket accumulation, one launch per MSM component)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<G1> (bucket accumulation, one launch per MSM component and table)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": st["msm_acc_g1_calls"], "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound; see DESIGN.md"},
+                         "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound; traffic = FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_traffic.json (each base is re-gathered once per window); see DESIGN.md"},
             "step_hbm": {"algorithmic_bytes_per_step": 2048.0 * w.nc, "achieved_GBs": 2048.0 * w.nc / (elapsed / args.steps) / 1e9},
             "stage_ms_per_step": {"spmv": per_step("spmv_ms"), "pointwise": per_step("vec_ms"), "ntt": per_step("ntt_ms"), "msm_gpu": per_step("msm_ms"),
                                   "msm_sort": per_step("msm_sort_ms"), "msm_acc_g1": per_step("msm_acc_g1_ms"), "msm_acc_g2": per_step("msm_acc_g2_ms"),
