@@ -13,10 +13,12 @@ using namespace cg;
 // launchers living in msm_inst_*.hip / fr_inst_*.hip (explicit instantiations)
 namespace cg {
 struct MsmSortPtrs { const uint32_t* sorted; const uint32_t* offsets; const uint32_t* counts; };
-template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, size_t n, int c, int nwin, char* scratch, MsmSortPtrs* out, hipEvent_t* evs);
-template <class F> int msm_accumulate_reduce(hipStream_t st, const Affine<F>* d_bases, size_t n, int c, int nwin, const uint32_t* sorted, const uint32_t* offsets,
-                                             const uint32_t* counts, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs);
-template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin);
+template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, size_t n, int c, int nwin, int shared, char* scratch, MsmSortPtrs* out, hipEvent_t* evs);
+template <class F> int msm_accumulate_reduce(hipStream_t st, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride, const uint32_t* sorted,
+                                             const uint32_t* offsets, const uint32_t* counts, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs);
+template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared);
+template <class F> int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c);
+constexpr int MSM_SHARED_GROUPS = 16;
 inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) { const size_t nbuckets = (size_t)nwin << (c - 1); return 2 * align_up((size_t)nwin * n * 4) + 3 * align_up(nbuckets * 4) + align_up(((nbuckets + 2047) / 2048) * 4); }
 template <class F> int pack_bases_launch(hipStream_t st, const uint8_t* d_raw, size_t n, size_t stride, long inf_off, Affine<F>* d_dst);
 template <class F> int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi, int log_t, size_t n, Affine<F>* d_out);
@@ -47,6 +49,8 @@ struct EvPair { hipEvent_t a, b; int tag; };
 struct MsmTicket {
     bool live = false;
     int curve = 0, group = 0, k = 0, c = 0, nwin = 0;
+    int nsums = 0;            // partial sums per component delivered by the GPU
+    bool plain_fold = false;  // true: add them (precomputed tables); false: Horner with c doublings (classic)
     void* h_pinned = nullptr; size_t pinned_bytes = 0;   // k * nwin window sums (XYZZ)
     hipEvent_t done = nullptr;
 };
@@ -71,6 +75,8 @@ struct cg_bases {
     int device, curve, group;
     size_t n, pt_bytes;
     void* d_pts;
+    int pre_c = 0, pre_nwin = 0;   // per-window precomputed tables (cg_bases_precompute): d_pre = [pre_nwin][n] points, window 0 = d_pts copy
+    void* d_pre = nullptr;
 };
 
 namespace {
@@ -164,9 +170,17 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
     }
     HIPCHK(hipSetDevice(ctx->device));
     const int curve = bases[0]->curve;
-    const int c = n ? (ctx->msm_window ? ctx->msm_window : auto_window(n)) : 2;
+    const bool shared = bases[0]->pre_c != 0;          // per-window precomputed tables: one bucket set for all windows
+    for (int b = 0; b < nb; b++) {
+        if ((bases[b]->pre_c != 0) != shared || (shared && bases[b]->pre_c != bases[0]->pre_c))
+            return fail(CG_ERR_ARG, "tables of one call must all be precomputed with the same window, or none");
+    }
+    if (shared && n > ((size_t)1 << 24)) return fail(CG_ERR_ARG, "precomputed-table MSM supports at most 2^24 points per call");
+    const int c = shared ? bases[0]->pre_c : (n ? (ctx->msm_window ? ctx->msm_window : auto_window(n)) : 2);
     int nwin = 0;
     { int rc = with_fr(curve, [&](auto tag) -> int { nwin = decltype(tag)::Params::BITS / c + 1; return 0; }); if (rc) return rc; }
+    if (shared && nwin != bases[0]->pre_nwin) return fail(CG_ERR_ARG, "internal: window count mismatch");
+    const int nsums = shared ? ((((size_t)1 << (c - 1)) / std::max<size_t>(1, ((size_t)1 << (c - 1)) / 32768)) >= (size_t)MSM_SHARED_GROUPS ? MSM_SHARED_GROUPS : 1) : nwin;
     // tickets + pinned result buffers
     std::vector<int> slots(nb);
     size_t acc_bytes = 0;
@@ -174,18 +188,18 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
         slots[b] = ticket_slot(ctx);
         MsmTicket& t = ctx->tickets[slots[b]];
         t.live = true;   // reserve before asking for the next slot
-        t.curve = curve; t.group = bases[b]->group; t.k = k; t.c = c; t.nwin = nwin;
+        t.curve = curve; t.group = bases[b]->group; t.k = k; t.c = c; t.nwin = nwin; t.nsums = nsums; t.plain_fold = shared;
         int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
             typedef decltype(ftag) F;
-            const size_t need = (size_t)k * nwin * sizeof(XYZZ<F>);
+            const size_t need = (size_t)k * nsums * sizeof(XYZZ<F>);
             if (t.pinned_bytes < need) {
                 if (t.h_pinned) HIPCHK(hipHostFree(t.h_pinned));
                 t.h_pinned = nullptr; t.pinned_bytes = 0;
                 HIPCHK(hipHostMalloc(&t.h_pinned, need, hipHostMallocDefault));
                 t.pinned_bytes = need;
             }
-            if (n == 0) { XYZZ<F>* h = (XYZZ<F>*)t.h_pinned; for (int i = 0; i < k * nwin; i++) h[i] = XYZZ<F>::infinity(); }
-            else acc_bytes = std::max(acc_bytes, msm_acc_scratch_bytes<F>(n, c, nwin));
+            if (n == 0) { XYZZ<F>* h = (XYZZ<F>*)t.h_pinned; for (int i = 0; i < k * nsums; i++) h[i] = XYZZ<F>::infinity(); }
+            else acc_bytes = std::max(acc_bytes, msm_acc_scratch_bytes<F>(n, c, nwin, shared));
             return 0;
         });
         if (rc) return rc;
@@ -201,7 +215,7 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
             {   // scalar side: once per scalar vector
                 hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
                 if (ctx->stats_on) { const int i0 = ev_open(ctx, TAG_SORT); evs[0] = ctx->ev_live[i0].a; evs[1] = ctx->ev_live[i0].b; pev = evs; }
-                int rc = with_fr(curve, [&](auto tag) -> int { typedef decltype(tag) Fr; return msm_sort_launch<Fr>(ctx->stream, (const Fr*)d_scalars[j], n, c, nwin, sort_scratch, &sp, pev); });
+                int rc = with_fr(curve, [&](auto tag) -> int { typedef decltype(tag) Fr; return msm_sort_launch<Fr>(ctx->stream, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, sort_scratch, &sp, pev); });
                 if (rc) return rc;
             }
             for (int b = 0; b < nb; b++) {   // group side: once per table, reusing the schedule
@@ -213,8 +227,9 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
                 }
                 int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
                     typedef decltype(ftag) F;
-                    const Affine<F>* pts = (const Affine<F>*)bases[b]->d_pts + (offsets ? offsets[b] : 0);
-                    return msm_accumulate_reduce<F>(ctx->stream, pts, n, c, nwin, sp.sorted, sp.offsets, sp.counts, acc_scratch, (XYZZ<F>*)t.h_pinned + (size_t)j * nwin, pev);
+                    const Affine<F>* pts = (const Affine<F>*)(shared ? bases[b]->d_pre : bases[b]->d_pts) + (offsets ? offsets[b] : 0);
+                    return msm_accumulate_reduce<F>(ctx->stream, pts, n, c, nwin, shared ? bases[b]->n : 0, sp.sorted, sp.offsets, sp.counts, acc_scratch,
+                                                    (XYZZ<F>*)t.h_pinned + (size_t)j * nsums, pev);
                 });
                 if (rc) return rc;
             }
@@ -239,7 +254,12 @@ int msm_end_impl(cg_ctx* ctx, int ticket, void* h_out) {
         typedef decltype(ftag) F;
         const XYZZ<F>* h = (const XYZZ<F>*)t.h_pinned;
         Jacobian<F>* out = (Jacobian<F>*)h_out;
-        for (int j = 0; j < t.k; j++) { Jacobian<F> r = msm_fold_windows<F>(h + (size_t)j * t.nwin, t.nwin, t.c); memcpy(out + j, &r, sizeof r); }
+        for (int j = 0; j < t.k; j++) {
+            Jacobian<F> r;
+            if (t.plain_fold) { XYZZ<F> acc = h[(size_t)j * t.nsums]; for (int i = 1; i < t.nsums; i++) acc = xyzz_add(acc, h[(size_t)j * t.nsums + i]); r = xyzz_to_jacobian(acc); }
+            else r = msm_fold_windows<F>(h + (size_t)j * t.nsums, t.nsums, t.c);
+            memcpy(out + j, &r, sizeof r);
+        }
         return 0;
     });
 }
@@ -482,8 +502,29 @@ int32_t cg_bases_release(cg_bases* b) {
     hipSetDevice(b->device);
     hipDeviceSynchronize();
     hipFree(b->d_pts);
+    if (b->d_pre) hipFree(b->d_pre);
     delete b;
     return 0;
+}
+int32_t cg_bases_precompute(cg_ctx* ctx, cg_bases* b, int32_t c) {
+    if (!ctx || !b) return fail(CG_ERR_ARG, "null argument");
+    if (c < 8 || c > 22) return fail(CG_ERR_ARG, "precompute window must be in [8, 22]");
+    if (b->device != ctx->device) return fail(CG_ERR_ARG, "bases live on another device");
+    if (b->n > ((size_t)1 << 24)) return fail(CG_ERR_ARG, "precomputed tables support at most 2^24 points");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (b->d_pre) { HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipFree(b->d_pre)); b->d_pre = nullptr; b->pre_c = b->pre_nwin = 0; }
+    return with_group(b->curve, b->group, [&](auto ftag, auto frtag) -> int {
+        typedef decltype(ftag) F; typedef decltype(frtag) Fr;
+        const int nwin = Fr::Params::BITS / c + 1;
+        const size_t n = std::max<size_t>(b->n, 1);
+        HIPCHK(hipMalloc(&b->d_pre, (size_t)nwin * n * sizeof(Affine<F>)));
+        Affine<F>* tab = (Affine<F>*)b->d_pre;
+        HIPCHK(hipMemcpyAsync(tab, b->d_pts, b->n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, ctx->stream));
+        for (int j = 1; j < nwin; j++) { int rc = precompute_window_launch<F>(ctx->stream, tab + (size_t)(j - 1) * b->n, tab + (size_t)j * b->n, b->n, c); if (rc) return rc; }
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        b->pre_c = c; b->pre_nwin = nwin;
+        return 0;
+    });
 }
 size_t cg_bases_len(const cg_bases* b) { return b ? b->n : 0; }
 

@@ -8,48 +8,58 @@
 namespace cg {
 
 struct MsmGeom {            // derived sizes shared by the host-side planner and the launchers
-    uint32_t nb;            // buckets per window = 2^(c-1)
-    size_t nbuckets;        // nwin * nb
-    uint32_t seg_len, segs; // bucket-reduction segments per window
+    uint32_t nb;            // buckets per bucket set = 2^(c-1)
+    int nsets;              // bucket sets: nwin (classic) or 1 (shared: per-window precomputed tables)
+    size_t nbuckets;        // nsets * nb
+    uint32_t seg_len, segs; // bucket-reduction segments per bucket set
+    int ngroups;            // partial sums handed to the host: nwin window sums (classic) or 16 plain groups (shared)
+    uint32_t group_segs;    // segments summed per group
     uint32_t chunk_len, nchunks;
 };
-inline MsmGeom msm_geom(size_t n, int c, int nwin) {
+constexpr int MSM_SHARED_GROUPS = 16;
+inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared) {
     MsmGeom g;
     g.nb = 1u << (c - 1);
-    g.nbuckets = (size_t)nwin * g.nb;
-    g.seg_len = std::max<uint32_t>(1, g.nb / 2048);      // measured: 8192 segments are slower (per-segment scalar mul dominates)
+    g.nsets = shared ? 1 : nwin;
+    g.nbuckets = (size_t)g.nsets * g.nb;
+    const uint32_t want_segs = shared ? 32768u : 2048u;      // ~32k serial chains in total either way
+    g.seg_len = std::max<uint32_t>(1, g.nb / want_segs);
     g.segs = g.nb / g.seg_len;
+    g.ngroups = shared ? (g.segs >= (uint32_t)MSM_SHARED_GROUPS ? MSM_SHARED_GROUPS : 1) : nwin;
+    g.group_segs = shared ? g.segs / g.ngroups : g.segs;
     const size_t entries = (size_t)nwin * n;
     g.chunk_len = (uint32_t)std::min<size_t>(128, std::max<size_t>(8, entries / (256 * 1024)));
     g.nchunks = (uint32_t)std::max<size_t>(1, (entries + g.chunk_len - 1) / g.chunk_len);
     return g;
 }
 template <class F>
-size_t msm_acc_scratch_bytes(size_t n, int c, int nwin) {
-    const MsmGeom g = msm_geom(n, c, nwin);
+size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared) {
+    const MsmGeom g = msm_geom(n, c, nwin, shared);
     return align_up(g.nbuckets * sizeof(XYZZ<F>)) + align_up((size_t)g.nchunks * sizeof(XYZZ<F>)) + align_up((size_t)g.nchunks * 4) +
-           align_up((size_t)nwin * g.segs * sizeof(XYZZ<F>)) + align_up((size_t)nwin * sizeof(XYZZ<F>));
+           align_up((size_t)g.nsets * g.segs * sizeof(XYZZ<F>)) + align_up((size_t)g.ngroups * sizeof(XYZZ<F>));
 }
 
 // buckets -> window sums for one (bases, sorted schedule) pair; the nwin window sums land in h_out (pinned) via an async copy.
-// evs (optional, 4 events): accumulate [0,1], reduce [2,3]
+// table_stride != 0 selects the shared-bucket-set mode (d_bases = window-0 table of a [nwin][table_stride] precomputed block);
+// the host then receives g.ngroups partial sums to ADD (no doublings).  evs (optional, 4 events): accumulate [0,1], reduce [2,3]
 template <class F>
-int msm_accumulate_reduce(hipStream_t st, const Affine<F>* d_bases, size_t n, int c, int nwin, const uint32_t* sorted, const uint32_t* offsets,
+int msm_accumulate_reduce(hipStream_t st, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride, const uint32_t* sorted, const uint32_t* offsets,
                           const uint32_t* counts, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs) {
-    const MsmGeom g = msm_geom(n, c, nwin);
+    const bool shared = table_stride != 0;
+    const MsmGeom g = msm_geom(n, c, nwin, shared);
     size_t off = 0;
     auto take = [&](size_t bytes) { void* p = scratch + off; off += align_up(bytes); return p; };
     XYZZ<F>* buckets = (XYZZ<F>*)take(g.nbuckets * sizeof(XYZZ<F>));
     XYZZ<F>* cont = (XYZZ<F>*)take((size_t)g.nchunks * sizeof(XYZZ<F>));
     uint32_t* cont_bucket = (uint32_t*)take((size_t)g.nchunks * 4);
-    XYZZ<F>* partials = (XYZZ<F>*)take((size_t)nwin * g.segs * sizeof(XYZZ<F>));
-    XYZZ<F>* wsums = (XYZZ<F>*)take((size_t)nwin * sizeof(XYZZ<F>));
+    XYZZ<F>* partials = (XYZZ<F>*)take((size_t)g.nsets * g.segs * sizeof(XYZZ<F>));
+    XYZZ<F>* wsums = (XYZZ<F>*)take((size_t)g.ngroups * sizeof(XYZZ<F>));
     if (evs) HIPCHK(hipEventRecord(evs[0], st));
     HIPCHK(hipMemsetAsync(buckets, 0, g.nbuckets * sizeof(XYZZ<F>), st));          // all-zero XYZZ = infinity (empty buckets are never written)
     auto launch_acc = [&](auto kern, int T, size_t lds) -> int {
         if (lds > 0) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((g.nchunks + T - 1) / T), dim3(T), lds, st, d_bases, sorted, offsets, counts,
-                           (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, buckets, cont, cont_bucket);
+                           (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, (uint32_t)table_stride, buckets, cont, cont_bucket);
         return 0;
     };
     // accumulator policy per coordinate field:
@@ -64,19 +74,25 @@ int msm_accumulate_reduce(hipStream_t st, const Affine<F>* d_bases, size_t n, in
     if (rc_acc) return rc_acc;
     hipLaunchKernelGGL((k_msm_merge_cont<F>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, buckets, cont, cont_bucket, g.nchunks);
     if (evs) { HIPCHK(hipEventRecord(evs[1], st)); HIPCHK(hipEventRecord(evs[2], st)); }
-    const size_t nseg_threads = (size_t)nwin * g.segs;
-    hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3((unsigned)((nseg_threads + 63) / 64)), dim3(64), 0, st, buckets, g.nb, g.seg_len, nwin, partials);
+    const size_t nseg_threads = (size_t)g.nsets * g.segs;
+    hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3((unsigned)((nseg_threads + 63) / 64)), dim3(64), 0, st, buckets, g.nb, g.seg_len, g.nsets, partials);
     constexpr int WT = sizeof(XYZZ<F>) > 128 ? 128 : 256;
-    hipLaunchKernelGGL((k_msm_window_sum<F, WT>), dim3(nwin), dim3(WT), WT * sizeof(XYZZ<F>), st, partials, g.segs, wsums);
+    hipLaunchKernelGGL((k_msm_window_sum<F, WT>), dim3(g.ngroups), dim3(WT), WT * sizeof(XYZZ<F>), st, partials, g.group_segs, wsums);
     if (evs) HIPCHK(hipEventRecord(evs[3], st));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h_out, wsums, (size_t)nwin * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_out, wsums, (size_t)g.ngroups * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     return 0;
 }
 
 template <class F>
 int pack_bases_launch(hipStream_t st, const uint8_t* d_raw, size_t n, size_t stride, long inf_off, Affine<F>* d_dst) {
     hipLaunchKernelGGL((k_pack_bases<F>), dim3(grid_for(n)), dim3(256), 0, st, d_raw, n, stride, inf_off, d_dst);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class F>
+int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c) {
+    if (n) hipLaunchKernelGGL((k_precompute_window<F>), dim3(grid_for(n)), dim3(256), 0, st, d_src, d_dst, n, c);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -91,8 +107,9 @@ int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi
 
 #define CG_INSTANTIATE_MSM(F, Fr)                                                                                          \
     namespace cg {                                                                                                         \
-    template int msm_accumulate_reduce<F>(hipStream_t, const Affine<F>*, size_t, int, int, const uint32_t*, const uint32_t*, const uint32_t*, char*, XYZZ<F>*, hipEvent_t*); \
-    template size_t msm_acc_scratch_bytes<F>(size_t, int, int);                                                            \
+    template int msm_accumulate_reduce<F>(hipStream_t, const Affine<F>*, size_t, int, int, size_t, const uint32_t*, const uint32_t*, const uint32_t*, char*, XYZZ<F>*, hipEvent_t*); \
+    template size_t msm_acc_scratch_bytes<F>(size_t, int, int, bool);                                                      \
+    template int precompute_window_launch<F>(hipStream_t, const Affine<F>*, Affine<F>*, size_t, int);                      \
     template int pack_bases_launch<F>(hipStream_t, const uint8_t*, size_t, size_t, long, Affine<F>*);                      \
     template int synth_points_launch<F>(hipStream_t, const XYZZ<F>*, const XYZZ<F>*, int, size_t, Affine<F>*);             \
     }

@@ -347,8 +347,9 @@ __device__ __forceinline__ void acc_store(Acc& acc, XYZZ<F>* dst) {
 template <class F, class Acc, int THREADS, int MINW = 1>
 __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                                                            uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks,
+                                                            uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks, uint32_t table_stride,
                                                             XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ cont, uint32_t* __restrict__ cont_bucket) {
+    // table_stride != 0: entries are (window << 24 | index) into per-window precomputed tables laid out [window][table_stride]
     extern __shared__ uint4 acc_lds[];
     const uint32_t q = blockIdx.x * THREADS + threadIdx.x;
     if (q >= nchunks) return;
@@ -372,7 +373,8 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
             bend = offsets[b] + counts[b];
         }
         const uint32_t e = sorted[pos++];
-        Affine<F> p = ld_struct(bases + (e & 0x7fffffffu));
+        const size_t at = table_stride ? (size_t)((e >> 24) & 0x7fu) * table_stride + (e & 0xffffffu) : (size_t)(e & 0x7fffffffu);
+        Affine<F> p = ld_struct(bases + at);
         if (p.is_inf()) continue;
         acc_madd(acc, p.x, p.y, (e >> 31) != 0);
     }
@@ -456,6 +458,16 @@ __global__ void __launch_bounds__(256) k_pack_bases(const uint8_t* __restrict__ 
     }
 }
 
+
+// Per-window precomputed tables: dst[i] = 2^c * src[i] in affine form (one inversion per point; run once per zkey table).
+template <class F>
+__global__ void __launch_bounds__(256) k_precompute_window(const Affine<F>* __restrict__ src, Affine<F>* __restrict__ dst, size_t n, int c) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        XYZZ<F> a = XYZZ<F>::from_affine(ld_struct(src + i));
+        for (int k = 0; k < c; k++) a = xyzz_dbl(a);
+        st_struct(dst + i, xyzz_to_affine(a));
+    }
+}
 
 // Synthetic point tables (bench / test tooling, not on the prover path): out[i] = affine(hi[i >> log_t] + lo[i & (2^log_t-1)]).
 // With lo[j] = (first+j)*P and hi[j] = (j << log_t)*P this yields the consecutive multiples (first+i)*P — valid, pairwise

@@ -9,8 +9,9 @@
 namespace cg {
 
 // digits[w*n + i] = signed digit of scalar i in window w; counts[w*nb + |d|-1]++
+// shared != 0: all windows use ONE bucket set (per-window precomputed base tables, see k_precompute_window)
 template <class Fr>
-__global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scalars, size_t n, int c, int nwin,
+__global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scalars, size_t n, int c, int nwin, int shared,
                                                     int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
     const uint32_t nb = 1u << (c - 1);
     const uint32_t mask = (1u << c) - 1;
@@ -26,7 +27,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scala
             int32_t dig;
             if (d > nb) { dig = (int32_t)d - (int32_t)(1u << c); carry = 1; } else { dig = (int32_t)d; carry = 0; }
             digits[(size_t)w * n + i] = dig;
-            if (dig != 0) atomicAdd(&counts[(size_t)w * nb + (uint32_t)(dig < 0 ? -dig : dig) - 1], 1u);
+            if (dig != 0) atomicAdd(&counts[(shared ? 0 : (size_t)w * nb) + (uint32_t)(dig < 0 ? -dig : dig) - 1], 1u);
         }
     }
 }
@@ -79,7 +80,8 @@ static __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* __res
 }
 
 // sorted[offsets[bucket] + k] = point index | sign << 31
-static __global__ void __launch_bounds__(256) k_msm_scatter(const int32_t* __restrict__ digits, size_t n, int c, int nwin, const uint32_t* __restrict__ offsets,
+// shared != 0: entry = window << 24 | point index (n <= 2^24), sign in bit 31
+static __global__ void __launch_bounds__(256) k_msm_scatter(const int32_t* __restrict__ digits, size_t n, int c, int nwin, int shared, const uint32_t* __restrict__ offsets,
                                                      uint32_t* __restrict__ cursors, uint32_t* __restrict__ sorted) {
     const uint32_t nb = 1u << (c - 1);
     const size_t total = (size_t)nwin * n;
@@ -88,9 +90,9 @@ static __global__ void __launch_bounds__(256) k_msm_scatter(const int32_t* __res
         if (dig == 0) continue;
         const size_t w = idx / n;
         const uint32_t i = (uint32_t)(idx - w * n);
-        const size_t bucket = w * nb + (uint32_t)(dig < 0 ? -dig : dig) - 1;
+        const size_t bucket = (shared ? 0 : w * nb) + (uint32_t)(dig < 0 ? -dig : dig) - 1;
         const uint32_t pos = offsets[bucket] + atomicAdd(&cursors[bucket], 1u);
-        sorted[pos] = i | (dig < 0 ? 0x80000000u : 0u);
+        sorted[pos] = (shared ? ((uint32_t)w << 24) | i : i) | (dig < 0 ? 0x80000000u : 0u);
     }
 }
 

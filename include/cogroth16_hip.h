@@ -66,6 +66,11 @@ int32_t cg_bases_register(cg_ctx* ctx, int32_t curve, int32_t group, const void*
 /* same, source already on the device in packed (x||y, (0,0)=inf) form; the table is copied */
 int32_t cg_bases_register_device(cg_ctx* ctx, int32_t curve, int32_t group, const void* d_points_packed, size_t n, cg_bases** out);
 int32_t cg_bases_release(cg_bases* bases);
+/* Optional, once per table: precompute 2^(c*j) * P_i for every window j (affine, resident: (254/c + 1) x the table size).
+ * MSMs over such a table then use ONE bucket set for all windows: 254/c + 1 mixed additions per point with c up to 22 instead
+ * of 16 at the default c = 16, and no doublings in the final fold.  The zkey queries are fixed for the life of the process
+ * (zkey.rs:48-71), so this is part of registration, not of the proof.  Results are unchanged. */
+int32_t cg_bases_precompute(cg_ctx* ctx, cg_bases* bases, int32_t c);
 size_t  cg_bases_len(const cg_bases* bases);
 
 /* out_jacobian[j] = sum_i scalars[j][i] * bases[offset + i], j < k (k = share components: REP3 2, Shamir/plain 1).

@@ -334,3 +334,42 @@ def test_msm_skewed_scalars(ctx, group):
     same = np.tile(orc.random_field(curve, FR, 1, rng), (n, 1))   # every scalar identical: every window has ONE busy bucket
     msm_check(ctx, curve, group, pts, [small, same])
     msm_check(ctx, curve, group, pts, [same], window=7)
+
+
+@pytest.mark.parametrize("c", [8, 13, 20])
+def test_msm_precomputed_windows(ctx, c):
+    """cg_bases_precompute: per-window tables 2^(c*j) P_i, one bucket set for all windows; results unchanged"""
+    curve, n = BN254, 900
+    rng = np.random.default_rng(50 + c)
+    for group in (G1, G2):
+        pts = make_points(curve, group, n + 2, rng)
+        pts[5] = 0                                           # an infinity base stays infinity in every window table
+        sa, sb = orc.random_field(curve, FR, n, rng), orc.random_field(curve, FR, n, rng)
+        sa[0] = 0; sa[1] = orc.from_dec(curve, FR, 1); sa[2] = orc.from_dec(curve, FR, orc.MODULI[(curve, FR)] - 1)
+        bases = ctx.register_bases(curve, group, pts)
+        ctx.precompute_bases(bases, c)
+        got = ctx.msm_dev(bases, [dev(ctx, sa), dev(ctx, sb)], n, offset=2)
+        for j, sc in enumerate((sa, sb)):
+            np.testing.assert_array_equal(cg.point_to_affine(curve, group, got[j]), orc.msm(curve, group, pts[2:2 + n], sc, threads=8))
+        bases.release()
+
+
+def test_msm_precomputed_multi_and_skew(ctx):
+    curve, n = BN254, 3000
+    rng = np.random.default_rng(61)
+    t1, t2 = make_points(curve, G1, n, rng), make_points(curve, G2, n + 1, rng)
+    b1, b2 = ctx.register_bases(curve, G1, t1), ctx.register_bases(curve, G2, t2)
+    ctx.precompute_bases(b1, 16); ctx.precompute_bases(b2, 16)
+    same = np.tile(orc.random_field(curve, FR, 1, rng), (n, 1))       # every digit of every scalar identical: maximally skewed buckets
+    uni = orc.random_field(curve, FR, n, rng)
+    tickets = ctx.msm_dev_begin_multi([b1, b2], [dev(ctx, same), dev(ctx, uni)], n, offsets=[0, 1])
+    for (g, p, o), t in zip(((G1, t1, 0), (G2, t2, 1)), tickets):
+        got = ctx.msm_end(t)
+        for j, sc in enumerate((same, uni)):
+            np.testing.assert_array_equal(cg.point_to_affine(curve, g, got[j]), orc.msm(curve, g, p[o:o + n], sc, threads=8))
+    # mixing a precomputed and a plain table in one call is rejected
+    b3 = ctx.register_bases(curve, G1, t1)
+    with pytest.raises(cg.BackendError):
+        ctx.msm_dev_begin_multi([b1, b3], [dev(ctx, uni)], n)
+    for b in (b1, b2, b3):
+        b.release()
