@@ -14,8 +14,8 @@ using namespace cg;
 namespace cg {
 struct MsmSortPtrs { const uint32_t* sorted; const uint32_t* offsets; const uint32_t* counts; };
 template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, size_t n, int c, int nwin, int shared, char* scratch, MsmSortPtrs* out, hipEvent_t* evs);
-template <class F> int msm_accumulate_reduce(hipStream_t st, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride, const uint32_t* sorted,
-                                             const uint32_t* offsets, const uint32_t* counts, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs);
+template <class F> int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, const Affine<F>* d_bases, size_t n, int c, int nwin,
+                                             size_t table_stride, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs);
 template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared);
 template <class F> int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c);
 constexpr int MSM_SHARED_GROUPS = 16;
@@ -61,6 +61,11 @@ struct cg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = true;
+    // second stream for the latency-bound bucket reductions, two rotating scratch slots, and the events that order them
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_acc[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};
+    bool slot_busy[2] = {false, false};
+    bool aux_pending = false; int last_slot = 0;
     Arena arena;
     std::map<TwKey, void*> twiddles;
     std::map<CosetKey, CosetTables> cosets;
@@ -83,8 +88,13 @@ namespace {
 
 int ensure_arena(cg_ctx* ctx, size_t bytes) {
     ctx->arena.used = 0;
+    if (ctx->aux_pending) {   // reductions of an earlier MSM may still be reading the arena on the aux stream
+        for (int sl = 0; sl < 2; sl++) if (ctx->slot_busy[sl]) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_red[sl], 0)); ctx->slot_busy[sl] = false; }
+        ctx->aux_pending = false;
+    }
     if (bytes <= ctx->arena.cap) return 0;
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->aux) HIPCHK(hipStreamSynchronize(ctx->aux));
     if (ctx->arena.base) HIPCHK(hipFree(ctx->arena.base));
     ctx->arena.base = nullptr; ctx->arena.cap = 0;
     size_t want = align_up(bytes + bytes / 8, 1 << 20);
@@ -208,8 +218,10 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
     if (n) {
         StatScope ss(ctx, TAG_MSM);
         const size_t sort_bytes = align_up(msm_sort_scratch_bytes(n, c, nwin));
-        { int rc = ensure_arena(ctx, sort_bytes + acc_bytes); if (rc) return rc; }
+        const size_t acc_slot = align_up(acc_bytes);
+        { int rc = ensure_arena(ctx, sort_bytes + 2 * acc_slot); if (rc) return rc; }
         char* sort_scratch = ctx->arena.base; char* acc_scratch = ctx->arena.base + sort_bytes;
+        int iter = 0;
         for (int j = 0; j < k; j++) {
             MsmSortPtrs sp{};
             {   // scalar side: once per scalar vector
@@ -225,17 +237,21 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
                     const int i1 = ev_open(ctx, t.group == CG_G1 ? TAG_ACC_G1 : TAG_ACC_G2), i2 = ev_open(ctx, TAG_REDUCE);
                     evs[0] = ctx->ev_live[i1].a; evs[1] = ctx->ev_live[i1].b; evs[2] = ctx->ev_live[i2].a; evs[3] = ctx->ev_live[i2].b; pev = evs;
                 }
+                const int slot = iter++ & 1;
+                if (ctx->slot_busy[slot]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_red[slot], 0));   // slot's previous reduction must be done
                 int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
                     typedef decltype(ftag) F;
                     const Affine<F>* pts = (const Affine<F>*)(shared ? bases[b]->d_pre : bases[b]->d_pts) + (offsets ? offsets[b] : 0);
-                    return msm_accumulate_reduce<F>(ctx->stream, pts, n, c, nwin, shared ? bases[b]->n : 0, sp.sorted, sp.offsets, sp.counts, acc_scratch,
-                                                    (XYZZ<F>*)t.h_pinned + (size_t)j * nsums, pev);
+                    return msm_accumulate_reduce<F>(ctx->stream, ctx->aux, ctx->ev_acc[slot], ctx->ev_red[slot], pts, n, c, nwin, shared ? bases[b]->n : 0,
+                                                    sp.sorted, sp.offsets, sp.counts, acc_scratch + (size_t)slot * acc_slot, (XYZZ<F>*)t.h_pinned + (size_t)j * nsums, pev);
                 });
                 if (rc) return rc;
+                ctx->slot_busy[slot] = true; ctx->aux_pending = true; ctx->last_slot = slot;
+                if (j == k - 1) HIPCHK(hipEventRecord(t.done, ctx->aux));   // this table's last component: its results are complete on the aux stream
             }
         }
     }
-    for (int b = 0; b < nb; b++) { HIPCHK(hipEventRecord(ctx->tickets[slots[b]].done, ctx->stream)); tickets_out[b] = slots[b]; }
+    for (int b = 0; b < nb; b++) { if (n == 0) HIPCHK(hipEventRecord(ctx->tickets[slots[b]].done, ctx->stream)); tickets_out[b] = slots[b]; }
     return 0;
 }
 
@@ -402,6 +418,8 @@ int32_t cg_ctx_create(int32_t device, cg_ctx** out) {
     cg_ctx* c = new cg_ctx();
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming)); }
     *out = c;
     return 0;
 }
@@ -409,6 +427,9 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     if (!ctx) return 0;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    hipStreamSynchronize(ctx->aux);
+    for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_acc[i]); hipEventDestroy(ctx->ev_red[i]); }
+    hipStreamDestroy(ctx->aux);
     for (auto& kv : ctx->twiddles) hipFree(kv.second);
     for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
     for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.done) hipEventDestroy(t.done); }
@@ -419,11 +440,12 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     delete ctx;
     return 0;
 }
-int32_t cg_ctx_sync(cg_ctx* ctx) { if (!ctx) return fail(CG_ERR_ARG, "null ctx"); HIPCHK(hipStreamSynchronize(ctx->stream)); return 0; }
+int32_t cg_ctx_sync(cg_ctx* ctx) { if (!ctx) return fail(CG_ERR_ARG, "null ctx"); HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->aux)); return 0; }
 void* cg_ctx_stream(cg_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int32_t cg_ctx_set_stream(cg_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(CG_ERR_ARG, "null ctx");
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->aux));
     if (ctx->owns_stream) HIPCHK(hipStreamDestroy(ctx->stream));
     ctx->stream = (hipStream_t)hip_stream;
     ctx->owns_stream = false;
@@ -788,6 +810,7 @@ int32_t cg_stats_enable(cg_ctx* ctx, int32_t on) { if (!ctx) return fail(CG_ERR_
 int32_t cg_stats(cg_ctx* ctx, cg_stage_times* out, int32_t reset) {
     if (!ctx || !out) return fail(CG_ERR_ARG, "null argument");
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->aux));
     double* ms[TAG_COUNT] = {&ctx->stats.msm_ms, &ctx->stats.ntt_ms, &ctx->stats.vec_ms, &ctx->stats.spmv_ms,
                              &ctx->stats.msm_sort_ms, &ctx->stats.msm_acc_g1_ms, &ctx->stats.msm_acc_g2_ms, &ctx->stats.msm_reduce_ms};
     uint64_t* calls[TAG_COUNT] = {&ctx->stats.msm_calls, &ctx->stats.ntt_calls, &ctx->stats.vec_calls, &ctx->stats.spmv_calls,

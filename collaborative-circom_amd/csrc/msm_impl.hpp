@@ -42,9 +42,11 @@ size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared) {
 // buckets -> window sums for one (bases, sorted schedule) pair; the nwin window sums land in h_out (pinned) via an async copy.
 // table_stride != 0 selects the shared-bucket-set mode (d_bases = window-0 table of a [nwin][table_stride] precomputed block);
 // the host then receives g.ngroups partial sums to ADD (no doublings).  evs (optional, 4 events): accumulate [0,1], reduce [2,3]
+// Two streams: the accumulation (which fills the chip) runs on `st`; the latency-bound bucket reduction (a few hundred waves)
+// runs on `st2` behind `ev_acc` and signals `ev_red`, so it overlaps with the NEXT accumulation, which uses another scratch slot.
 template <class F>
-int msm_accumulate_reduce(hipStream_t st, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride, const uint32_t* sorted, const uint32_t* offsets,
-                          const uint32_t* counts, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs) {
+int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride,
+                          const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs) {
     const bool shared = table_stride != 0;
     const MsmGeom g = msm_geom(n, c, nwin, shared);
     size_t off = 0;
@@ -73,14 +75,18 @@ int msm_accumulate_reduce(hipStream_t st, const Affine<F>* d_bases, size_t n, in
     else rc_acc = launch_acc(k_msm_accumulate<F, RegAcc<F>, 256>, 256, 0);
     if (rc_acc) return rc_acc;
     hipLaunchKernelGGL((k_msm_merge_cont<F>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, buckets, cont, cont_bucket, g.nchunks);
-    if (evs) { HIPCHK(hipEventRecord(evs[1], st)); HIPCHK(hipEventRecord(evs[2], st)); }
+    if (evs) HIPCHK(hipEventRecord(evs[1], st));
+    HIPCHK(hipEventRecord(ev_acc, st));
+    HIPCHK(hipStreamWaitEvent(st2, ev_acc, 0));
+    if (evs) HIPCHK(hipEventRecord(evs[2], st2));
     const size_t nseg_threads = (size_t)g.nsets * g.segs;
-    hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3((unsigned)((nseg_threads + 63) / 64)), dim3(64), 0, st, buckets, g.nb, g.seg_len, g.nsets, partials);
+    hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3((unsigned)((nseg_threads + 63) / 64)), dim3(64), 0, st2, buckets, g.nb, g.seg_len, g.nsets, partials);
     constexpr int WT = sizeof(XYZZ<F>) > 128 ? 128 : 256;
-    hipLaunchKernelGGL((k_msm_window_sum<F, WT>), dim3(g.ngroups), dim3(WT), WT * sizeof(XYZZ<F>), st, partials, g.group_segs, wsums);
-    if (evs) HIPCHK(hipEventRecord(evs[3], st));
+    hipLaunchKernelGGL((k_msm_window_sum<F, WT>), dim3(g.ngroups), dim3(WT), WT * sizeof(XYZZ<F>), st2, partials, g.group_segs, wsums);
+    if (evs) HIPCHK(hipEventRecord(evs[3], st2));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h_out, wsums, (size_t)g.ngroups * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_out, wsums, (size_t)g.ngroups * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st2));
+    HIPCHK(hipEventRecord(ev_red, st2));
     return 0;
 }
 
@@ -107,7 +113,7 @@ int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi
 
 #define CG_INSTANTIATE_MSM(F, Fr)                                                                                          \
     namespace cg {                                                                                                         \
-    template int msm_accumulate_reduce<F>(hipStream_t, const Affine<F>*, size_t, int, int, size_t, const uint32_t*, const uint32_t*, const uint32_t*, char*, XYZZ<F>*, hipEvent_t*); \
+    template int msm_accumulate_reduce<F>(hipStream_t, hipStream_t, hipEvent_t, hipEvent_t, const Affine<F>*, size_t, int, int, size_t, const uint32_t*, const uint32_t*, const uint32_t*, char*, XYZZ<F>*, hipEvent_t*); \
     template size_t msm_acc_scratch_bytes<F>(size_t, int, int, bool);                                                      \
     template int precompute_window_launch<F>(hipStream_t, const Affine<F>*, Affine<F>*, size_t, int);                      \
     template int pack_bases_launch<F>(hipStream_t, const uint8_t*, size_t, size_t, long, Affine<F>*);                      \
