@@ -141,9 +141,16 @@ template <class Fn> int with_group(int curve, int group, Fn&& fn) {
 }
 
 // ------------------------------------------------------------------------------------------------ MSM
-int auto_window(size_t n) {
-    int lg = log2_floor(n);
-    return std::max(3, std::min(16, lg - 5));
+// Window size: log2(n) - 5 (measured optimum ~128 entries per bucket), clamped to [3, 16], then nudged so that the TOP window is
+// nearly full.  With bits = c*q + t the top window has only t (+1 carry) bits: all n entries of that window fall into 2^t buckets,
+// which the chunked accumulation balances but whose continuation pieces are merged by few lanes (t = 2 at c = 14 or 18 costs
+// seconds).  Prefer the nearest c with t >= c - 3.
+int auto_window(size_t n, int bits) {
+    const int lg = log2_floor(n);
+    const int c0 = std::max(3, std::min(16, lg - 5));
+    auto ok = [&](int c) { const int t = bits % c; return t != 0 && t >= c - 3; };
+    for (int d : {0, 1, -1, 2, -2, 3, -3}) { const int c = c0 + d; if (c >= 3 && c <= 17 && ok(c)) return c; }
+    return c0;
 }
 
 template <class F>
@@ -186,9 +193,10 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
             return fail(CG_ERR_ARG, "tables of one call must all be precomputed with the same window, or none");
     }
     if (shared && n > ((size_t)1 << 24)) return fail(CG_ERR_ARG, "precomputed-table MSM supports at most 2^24 points per call");
-    const int c = shared ? bases[0]->pre_c : (n ? (ctx->msm_window ? ctx->msm_window : auto_window(n)) : 2);
-    int nwin = 0;
-    { int rc = with_fr(curve, [&](auto tag) -> int { nwin = decltype(tag)::Params::BITS / c + 1; return 0; }); if (rc) return rc; }
+    int bits = 0;
+    { int rc = with_fr(curve, [&](auto tag) -> int { bits = decltype(tag)::Params::BITS; return 0; }); if (rc) return rc; }
+    const int c = shared ? bases[0]->pre_c : (n ? (ctx->msm_window ? ctx->msm_window : auto_window(n, bits)) : 2);
+    const int nwin = bits / c + 1;
     if (shared && nwin != bases[0]->pre_nwin) return fail(CG_ERR_ARG, "internal: window count mismatch");
     const int nsums = shared ? ((((size_t)1 << (c - 1)) / std::max<size_t>(1, ((size_t)1 << (c - 1)) / 32768)) >= (size_t)MSM_SHARED_GROUPS ? MSM_SHARED_GROUPS : 1) : nwin;
     // tickets + pinned result buffers

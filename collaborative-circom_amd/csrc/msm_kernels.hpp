@@ -381,8 +381,26 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
     if (continuation) acc_store(acc, cont + q); else acc_store(acc, buckets + b);
 }
 
-// lane q: if chunk q holds the FIRST continuation piece of its bucket, fold all consecutive continuation pieces of that bucket
-// (chunks q, q+1, ... with the same tag) into buckets[b].  With uniform scalars a bucket spans at most 2-3 chunks.
+// Continuation pieces of one bucket occupy consecutive chunks q0, q0+1, ... (same tag).  Two-level fold so that a bucket spread
+// over thousands of chunks (skewed scalars, small top window) is not summed by a single lane:
+//   level 1: every lane that is a GROUP head (run start, or q a multiple of MERGE_GROUP) sums the pieces up to the next group head;
+//   level 2: the run-start lane adds the group sums of its run into buckets[b].
+// With uniform scalars runs have 1-3 pieces and both levels are a handful of additions.
+constexpr uint32_t MERGE_GROUP = 64;
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_merge_cont_l1(XYZZ<F>* __restrict__ cont, const uint32_t* __restrict__ cont_bucket, uint32_t nchunks) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nchunks) return;
+    const uint32_t b = cont_bucket[q];
+    if (b == 0xffffffffu) return;
+    const bool run_start = q == 0 || cont_bucket[q - 1] != b;
+    if (!run_start && (q % MERGE_GROUP) != 0) return;
+    const uint32_t next_head = (q / MERGE_GROUP + 1) * MERGE_GROUP;           // first aligned position after q
+    if (q + 1 >= nchunks || q + 1 >= next_head || cont_bucket[q + 1] != b) return;   // single piece: nothing to fold
+    XYZZ<F> acc = ld_struct(cont + q);
+    for (uint32_t r = q + 1; r < nchunks && r < next_head && cont_bucket[r] == b; r++) acc = xyzz_add(acc, ld_struct(cont + r));
+    st_struct(cont + q, acc);                                                   // only group heads are written; nobody else reads them in this launch
+}
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_merge_cont(XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ cont, const uint32_t* __restrict__ cont_bucket, uint32_t nchunks) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -390,8 +408,8 @@ __global__ void __launch_bounds__(64) k_msm_merge_cont(XYZZ<F>* __restrict__ buc
     const uint32_t b = cont_bucket[q];
     if (b == 0xffffffffu) return;
     if (q > 0 && cont_bucket[q - 1] == b) return;
-    XYZZ<F> acc = ld_struct(buckets + b);
-    for (uint32_t r = q; r < nchunks && cont_bucket[r] == b; r++) acc = xyzz_add(acc, ld_struct(cont + r));
+    XYZZ<F> acc = xyzz_add(ld_struct(buckets + b), ld_struct(cont + q));
+    for (uint32_t r = (q / MERGE_GROUP + 1) * MERGE_GROUP; r < nchunks && cont_bucket[r] == b; r += MERGE_GROUP) acc = xyzz_add(acc, ld_struct(cont + r));
     st_struct(buckets + b, acc);
 }
 
