@@ -138,7 +138,9 @@ def step(w):
     aux = [w.wa[a0:a1], w.wb[a0:a1]]
     tickets = [ctx.msm_dev_begin(w.h_q, [w.ha[h0:h1], w.hb[h0:h1]], h1 - h0)]
     # l, a, b1 (G1) and b2 (G2) all multiply the aux-witness shares: one digit/sort schedule per share component, four tables
-    tickets += ctx.msm_dev_begin_multi([w.l_q, w.a_q, w.b1_q, w.b2_q], aux, a1 - a0)
+    # (the G2 table goes first: its long bucket reduction then overlaps the following G1 accumulations instead of ending the step)
+    tables = [w.l_q, w.a_q, w.b1_q, w.b2_q] if w.g2_last else [w.b2_q, w.l_q, w.a_q, w.b1_q]
+    tickets += ctx.msm_dev_begin_multi(tables, aux, a1 - a0)
     return [ctx.msm_end(t) for t in tickets]
 
 
@@ -187,6 +189,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-m", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scatter-cap", type=int, default=-1, help="-1 = exact two-pass sort (default), 0 = optimistic one-pass scatter (auto capacity)")
+    ap.add_argument("--g2-last", action="store_true", help="experiment: put the G2 table last in the multi-table MSM")
     ap.add_argument("--precompute", type=int, default=20, help="window size of the per-window precomputed base tables (0 = off)")
     args = ap.parse_args()
 
@@ -208,7 +212,9 @@ def main():
     stream = torch.cuda.Stream(device=device)      # torch is plumbing: one stream shared by its copies/slices and the library's kernels
     ctx.set_stream(stream.cuda_stream)
     torch.cuda.set_stream(stream)
+    ctx.set_scatter_capacity(args.scatter_cap)
     w = Workload(ctx, args.log_m, device, rank, world, precompute=args.precompute)
+    w.g2_last = args.g2_last
     torch.cuda.synchronize()
 
     def barrier():

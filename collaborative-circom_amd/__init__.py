@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "cg_ctx_create", "cg_ctx_destroy", "cg_ctx_sync", "cg_ctx_stream", "cg_ctx_set_stream", "cg_last_error", "cg_version",
     "cg_dev_alloc", "cg_dev_free", "cg_dev_upload", "cg_dev_download", "cg_dev_memset_zero",
     "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute",
-    "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window",
+    "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_scatter_capacity",
     "cg_ntt", "cg_ntt_dev",
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev",
     "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
@@ -258,6 +258,10 @@ class Context:
         out = np.zeros((k, point_words(curve, group, 3)), dtype=np.uint64)
         _chk(load().cg_msm_end(self.h, t, _hp(out)))
         return out
+
+    def set_scatter_capacity(self, cap):
+        """0 = automatic optimistic capacity, > 0 forced (tests), < 0 always the exact two-pass sort"""
+        _chk(load().cg_msm_set_scatter_capacity(self.h, int(cap)))
 
     def set_msm_window(self, c):
         _chk(load().cg_msm_set_window(self.h, int(c)))

@@ -5,6 +5,7 @@
 #include "curve.hpp"
 #include "ntt_kernels.hpp"   // NttVecs, plan constants (no kernels are instantiated in this translation unit)
 
+#include <cmath>
 #include <map>
 #include <vector>
 
@@ -12,10 +13,15 @@ using namespace cg;
 
 // launchers living in msm_inst_*.hip / fr_inst_*.hip (explicit instantiations)
 namespace cg {
-struct MsmSortPtrs { const uint32_t* sorted; const uint32_t* offsets; const uint32_t* counts; };
+struct MsmSortPtrs { const uint32_t* sorted; const uint32_t* offsets; const uint32_t* counts; uint32_t cap; const uint32_t* overflow; };
 template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, size_t n, int c, int nwin, int shared, char* scratch, MsmSortPtrs* out, hipEvent_t* evs);
+template <class Fr> int msm_sort_direct_launch(hipStream_t st, const Fr* d_scalars, size_t n, int c, int nwin, int shared, uint32_t cap, char* scratch, MsmSortPtrs* out, hipEvent_t* evs);
+inline size_t msm_sort_direct_scratch_bytes(size_t n, int c, int nwin, int shared, uint32_t cap) {
+    const size_t nbuckets = (size_t)(shared ? 1 : nwin) << (c - 1);
+    return align_up(nbuckets * cap * 4) + 2 * align_up(nbuckets * 4) + align_up(((nbuckets + 2047) / 2048) * 4) + 256;
+}
 template <class F> int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, const Affine<F>* d_bases, size_t n, int c, int nwin,
-                                             size_t table_stride, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs);
+                                             size_t table_stride, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs);
 template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared);
 template <class F> int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c);
 constexpr int MSM_SHARED_GROUPS = 16;
@@ -49,6 +55,9 @@ struct EvPair { hipEvent_t a, b; int tag; };
 struct MsmTicket {
     bool live = false;
     int curve = 0, group = 0, k = 0, c = 0, nwin = 0;
+    // optimistic one-pass scatter: per-component overflow flags (pinned) + what is needed to redo the MSM exactly if one is set
+    uint32_t* h_flags = nullptr; bool optimistic = false;
+    const cg_bases* bases = nullptr; size_t offset = 0, n = 0; std::vector<const void*> scalars;
     int nsums = 0;            // partial sums per component delivered by the GPU
     bool plain_fold = false;  // true: add them (precomputed tables); false: Horner with c doublings (classic)
     void* h_pinned = nullptr; size_t pinned_bytes = 0;   // k * nwin window sums (XYZZ)
@@ -71,6 +80,7 @@ struct cg_ctx {
     std::map<CosetKey, CosetTables> cosets;
     std::vector<MsmTicket> tickets;
     int msm_window = 0;
+    int scatter_cap = -1;     // < 0 = exact two-pass sort (default: measured equally fast), 0 = optimistic one-pass scatter with automatic capacity, > 0 = forced capacity (tests)
     bool stats_on = false;
     cg_stage_times stats{};
     std::vector<EvPair> ev_live, ev_free;
@@ -175,7 +185,7 @@ template <class Fn> int with_coord_field(int curve, int group, Fn&& fn) {   // g
 
 // One digit/sort schedule per scalar vector, then one accumulate+reduce per base table: `nb` tables (same curve, any groups)
 // multiplied by the SAME k scalar vectors.  tickets_out[b] collects the k results for table b.
-int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, const size_t* offsets, size_t n, const void* const* d_scalars, int k, int* tickets_out) {
+int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, const size_t* offsets, size_t n, const void* const* d_scalars, int k, int* tickets_out, bool force_exact = false) {
     if (!ctx || !bases || !tickets_out || (n && !d_scalars)) return fail(CG_ERR_ARG, "null argument");
     if (nb < 1 || nb > 16) return fail(CG_ERR_ARG, "number of base tables out of range");
     if (k < 1 || k > 8) return fail(CG_ERR_ARG, "k out of range");
@@ -198,6 +208,19 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
     const int c = shared ? bases[0]->pre_c : (n ? (ctx->msm_window ? ctx->msm_window : auto_window(n, bits)) : 2);
     const int nwin = bits / c + 1;
     if (shared && nwin != bases[0]->pre_nwin) return fail(CG_ERR_ARG, "internal: window count mismatch");
+    // optimistic scatter capacity: expected heaviest bucket (regular windows + the narrower top window) + 25 % + 6 sigma
+    uint32_t cap = 0;
+    if (n && !force_exact && ctx->scatter_cap >= 0) {
+        if (ctx->scatter_cap > 0) cap = (uint32_t)ctx->scatter_cap;
+        else {
+            const int t = bits % c;
+            const double nbk = (double)((size_t)1 << (c - 1));
+            const double top = t == 0 ? (double)n : (double)n / (double)((size_t)1 << std::min(c - 1, t));
+            const double avg = shared ? (double)(nwin - 1) * (double)n / nbk + top : std::max((double)n / nbk, top);
+            const double want = 1.25 * avg + 6.0 * std::sqrt(avg) + 16.0;
+            if (want <= 4096.0) { cap = 16; while ((double)cap < want) cap <<= 1; }
+        }
+    }
     const int nsums = shared ? ((((size_t)1 << (c - 1)) / std::max<size_t>(1, ((size_t)1 << (c - 1)) / 32768)) >= (size_t)MSM_SHARED_GROUPS ? MSM_SHARED_GROUPS : 1) : nwin;
     // tickets + pinned result buffers
     std::vector<int> slots(nb);
@@ -207,6 +230,9 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
         MsmTicket& t = ctx->tickets[slots[b]];
         t.live = true;   // reserve before asking for the next slot
         t.curve = curve; t.group = bases[b]->group; t.k = k; t.c = c; t.nwin = nwin; t.nsums = nsums; t.plain_fold = shared;
+        t.optimistic = cap != 0; t.bases = bases[b]; t.offset = offsets ? offsets[b] : 0; t.n = n; t.scalars.assign(d_scalars, d_scalars + (n ? k : 0));
+        if (!t.h_flags) HIPCHK(hipHostMalloc((void**)&t.h_flags, 8 * sizeof(uint32_t), hipHostMallocDefault));
+        for (int i = 0; i < 8; i++) t.h_flags[i] = 0;
         int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
             typedef decltype(ftag) F;
             const size_t need = (size_t)k * nsums * sizeof(XYZZ<F>);
@@ -225,7 +251,7 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
     }
     if (n) {
         StatScope ss(ctx, TAG_MSM);
-        const size_t sort_bytes = align_up(msm_sort_scratch_bytes(n, c, nwin));
+        const size_t sort_bytes = align_up(cap ? msm_sort_direct_scratch_bytes(n, c, nwin, shared ? 1 : 0, cap) : msm_sort_scratch_bytes(n, c, nwin));
         const size_t acc_slot = align_up(acc_bytes);
         { int rc = ensure_arena(ctx, sort_bytes + 2 * acc_slot); if (rc) return rc; }
         char* sort_scratch = ctx->arena.base; char* acc_scratch = ctx->arena.base + sort_bytes;
@@ -235,8 +261,13 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
             {   // scalar side: once per scalar vector
                 hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
                 if (ctx->stats_on) { const int i0 = ev_open(ctx, TAG_SORT); evs[0] = ctx->ev_live[i0].a; evs[1] = ctx->ev_live[i0].b; pev = evs; }
-                int rc = with_fr(curve, [&](auto tag) -> int { typedef decltype(tag) Fr; return msm_sort_launch<Fr>(ctx->stream, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, sort_scratch, &sp, pev); });
+                int rc = with_fr(curve, [&](auto tag) -> int {
+                    typedef decltype(tag) Fr;
+                    return cap ? msm_sort_direct_launch<Fr>(ctx->stream, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, cap, sort_scratch, &sp, pev)
+                               : msm_sort_launch<Fr>(ctx->stream, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, sort_scratch, &sp, pev);
+                });
                 if (rc) return rc;
+                if (cap) for (int b = 0; b < nb; b++) HIPCHK(hipMemcpyAsync(ctx->tickets[slots[b]].h_flags + j, sp.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
             }
             for (int b = 0; b < nb; b++) {   // group side: once per table, reusing the schedule
                 MsmTicket& t = ctx->tickets[slots[b]];
@@ -251,7 +282,7 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
                     typedef decltype(ftag) F;
                     const Affine<F>* pts = (const Affine<F>*)(shared ? bases[b]->d_pre : bases[b]->d_pts) + (offsets ? offsets[b] : 0);
                     return msm_accumulate_reduce<F>(ctx->stream, ctx->aux, ctx->ev_acc[slot], ctx->ev_red[slot], pts, n, c, nwin, shared ? bases[b]->n : 0,
-                                                    sp.sorted, sp.offsets, sp.counts, acc_scratch + (size_t)slot * acc_slot, (XYZZ<F>*)t.h_pinned + (size_t)j * nsums, pev);
+                                                    sp.sorted, sp.offsets, sp.counts, sp.cap, acc_scratch + (size_t)slot * acc_slot, (XYZZ<F>*)t.h_pinned + (size_t)j * nsums, pev);
                 });
                 if (rc) return rc;
                 ctx->slot_busy[slot] = true; ctx->aux_pending = true; ctx->last_slot = slot;
@@ -268,12 +299,25 @@ int msm_begin_impl(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, 
     return msm_begin_multi_impl(ctx, 1, &bases, &offset, n, d_scalars, k, ticket_out);
 }
 
+int msm_end_impl(cg_ctx* ctx, int ticket, void* h_out);
 int msm_end_impl(cg_ctx* ctx, int ticket, void* h_out) {
     if (!ctx || !h_out) return fail(CG_ERR_ARG, "null argument");
     if (ticket < 0 || ticket >= (int)ctx->tickets.size() || !ctx->tickets[ticket].live) return fail(CG_ERR_ARG, "bad MSM ticket");
     MsmTicket& t = ctx->tickets[ticket];
     HIPCHK(hipEventSynchronize(t.done));
     t.live = false;
+    if (t.optimistic) {   // a bucket overflowed its guessed capacity (non-uniform scalars): redo this MSM with the exact schedule
+        bool over = false;
+        for (int j = 0; j < t.k; j++) over = over || t.h_flags[j] != 0;
+        if (over) {
+            const cg_bases* b = t.bases; const size_t off = t.offset, n = t.n; const int k = t.k;
+            std::vector<const void*> sc = t.scalars;
+            int t2 = -1;
+            int rc = msm_begin_multi_impl(ctx, 1, &b, &off, n, sc.data(), k, &t2, true);
+            if (rc) return rc;
+            return msm_end_impl(ctx, t2, h_out);
+        }
+    }
     return with_group(t.curve, t.group, [&](auto ftag, auto) -> int {
         typedef decltype(ftag) F;
         const XYZZ<F>* h = (const XYZZ<F>*)t.h_pinned;
@@ -440,7 +484,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     hipStreamDestroy(ctx->aux);
     for (auto& kv : ctx->twiddles) hipFree(kv.second);
     for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
-    for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.done) hipEventDestroy(t.done); }
+    for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.h_flags) hipHostFree(t.h_flags); if (t.done) hipEventDestroy(t.done); }
     if (ctx->arena.base) hipFree(ctx->arena.base);
     for (auto& p : ctx->ev_live) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
     for (auto& p : ctx->ev_free) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
@@ -598,6 +642,12 @@ int32_t cg_bases_download(cg_ctx* ctx, const cg_bases* bases, size_t offset, siz
     return 0;
 }
 
+int32_t cg_msm_set_scatter_capacity(cg_ctx* ctx, int32_t cap) {
+    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
+    if (cap > 65536) return fail(CG_ERR_ARG, "capacity out of range");
+    ctx->scatter_cap = cap;
+    return 0;
+}
 int32_t cg_msm_set_window(cg_ctx* ctx, int32_t c) {
     if (!ctx) return fail(CG_ERR_ARG, "null ctx");
     if (c != 0 && (c < 2 || c > 20)) return fail(CG_ERR_ARG, "window size must be 0 (auto) or in [2, 20]");

@@ -58,7 +58,7 @@ template <class Fr> int launch_bitrev_scale(hipStream_t st, NttVecs dst, NttVecs
 
 // scalar-dependent half of the MSM: digits, histogram, scan, scatter.  Scratch layout (must match msm_sort_scratch_bytes):
 // digits | sorted | counts | cursors | offsets.   evs (optional, 2 events) bracket the stage.
-struct MsmSortPtrs { const uint32_t* sorted; const uint32_t* offsets; const uint32_t* counts; };
+struct MsmSortPtrs { const uint32_t* sorted; const uint32_t* offsets; const uint32_t* counts; uint32_t cap; const uint32_t* overflow; };   // cap = 0: dense list
 inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) {   // sized for the per-window bucket sets (the shared-set mode needs less)
     const size_t nbuckets = (size_t)nwin << (c - 1);
     return 2 * align_up((size_t)nwin * n * 4) + 3 * align_up(nbuckets * 4) + align_up(((nbuckets + SCAN_TILE - 1) / SCAN_TILE) * 4);
@@ -77,13 +77,40 @@ template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, siz
     if (evs) HIPCHK(hipEventRecord(evs[0], st));
     HIPCHK(hipMemsetAsync(counts, 0, align_up(nbuckets * 4) * 2, st));   // counts + cursors are adjacent
     hipLaunchKernelGGL((k_msm_digits<Fr>), dim3(grid_for(n)), dim3(256), 0, st, d_scalars, n, c, nwin, shared, digits, counts);
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)ntiles), dim3(256), 0, st, counts, tile_sums, nbuckets);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)ntiles), dim3(256), 0, st, counts, tile_sums, nbuckets, 0xffffffffu);
     hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, tile_sums, tile_sums, ntiles);
-    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(256), 0, st, counts, tile_sums, offsets, nbuckets);
+    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(256), 0, st, counts, tile_sums, offsets, nbuckets, 0xffffffffu);
     hipLaunchKernelGGL(k_msm_scatter, dim3(grid_for((size_t)nwin * n)), dim3(256), 0, st, digits, n, c, nwin, shared, offsets, cursors, sorted);
     if (evs) HIPCHK(hipEventRecord(evs[1], st));
     HIPCHK(hipGetLastError());
-    out->sorted = sorted; out->offsets = offsets; out->counts = counts;
+    out->sorted = sorted; out->offsets = offsets; out->counts = counts; out->cap = 0; out->overflow = nullptr;
+    return 0;
+}
+// optimistic one-pass variant: scratch layout  sorted[nbuckets * cap] | counts | offsets | tile sums | overflow flag
+inline size_t msm_sort_direct_scratch_bytes(size_t n, int c, int nwin, int shared, uint32_t cap) {
+    const size_t nbuckets = (size_t)(shared ? 1 : nwin) << (c - 1);
+    return align_up(nbuckets * cap * 4) + 2 * align_up(nbuckets * 4) + align_up(((nbuckets + SCAN_TILE - 1) / SCAN_TILE) * 4) + 256;
+}
+template <class Fr> int msm_sort_direct_launch(hipStream_t st, const Fr* d_scalars, size_t n, int c, int nwin, int shared, uint32_t cap, char* scratch, MsmSortPtrs* out, hipEvent_t* evs) {
+    const size_t nbuckets = (size_t)(shared ? 1 : nwin) << (c - 1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void* p = scratch + off; off += align_up(bytes); return p; };
+    uint32_t* sorted = (uint32_t*)take(nbuckets * cap * 4);
+    uint32_t* counts = (uint32_t*)take(nbuckets * 4);
+    uint32_t* offsets = (uint32_t*)take(nbuckets * 4);
+    const size_t ntiles = (nbuckets + SCAN_TILE - 1) / SCAN_TILE;
+    uint32_t* tile_sums = (uint32_t*)take(ntiles * 4);
+    uint32_t* overflow = (uint32_t*)take(4);
+    if (evs) HIPCHK(hipEventRecord(evs[0], st));
+    HIPCHK(hipMemsetAsync(counts, 0, nbuckets * 4, st));
+    HIPCHK(hipMemsetAsync(overflow, 0, 4, st));
+    hipLaunchKernelGGL((k_msm_scatter_direct<Fr>), dim3(grid_for(n)), dim3(256), 0, st, d_scalars, n, c, nwin, shared, cap, counts, sorted, overflow);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)ntiles), dim3(256), 0, st, counts, tile_sums, nbuckets, cap);
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, tile_sums, tile_sums, ntiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(256), 0, st, counts, tile_sums, offsets, nbuckets, cap);
+    if (evs) HIPCHK(hipEventRecord(evs[1], st));
+    HIPCHK(hipGetLastError());
+    out->sorted = sorted; out->offsets = offsets; out->counts = counts; out->cap = cap; out->overflow = overflow;
     return 0;
 }
 
@@ -99,4 +126,5 @@ template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, siz
     template int launch_ntt_dif_pass<Fr>(hipStream_t, NttVecs, NttVecs, int, size_t, int, int, int, int, const Fr*);                \
     template int launch_bitrev_scale<Fr>(hipStream_t, NttVecs, NttVecs, int, size_t, int, const Fr*, const Fr*, const Fr*, int); \
     template int msm_sort_launch<Fr>(hipStream_t, const Fr*, size_t, int, int, int, char*, MsmSortPtrs*, hipEvent_t*);          \
+    template int msm_sort_direct_launch<Fr>(hipStream_t, const Fr*, size_t, int, int, int, uint32_t, char*, MsmSortPtrs*, hipEvent_t*); \
     }

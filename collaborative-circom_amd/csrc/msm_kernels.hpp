@@ -347,13 +347,16 @@ __device__ __forceinline__ void acc_store(Acc& acc, XYZZ<F>* dst) {
 template <class F, class Acc, int THREADS, int MINW = 1>
 __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                                                            uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks, uint32_t table_stride,
+                                                            uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks, uint32_t table_stride, uint32_t cap,
                                                             XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ cont, uint32_t* __restrict__ cont_bucket) {
     // table_stride != 0: entries are (window << 24 | index) into per-window precomputed tables laid out [window][table_stride]
+    // cap != 0: `sorted` is the padded layout of k_msm_scatter_direct (bucket b owns slots [b*cap, b*cap + min(count, cap)));
+    //           positions (pos, offsets) are still those of the compact list, so the chunking is unchanged
     extern __shared__ uint4 acc_lds[];
     const uint32_t q = blockIdx.x * THREADS + threadIdx.x;
     if (q >= nchunks) return;
-    const uint32_t total = offsets[nbuckets - 1] + counts[nbuckets - 1];
+    const uint32_t capc = cap ? cap : 0xffffffffu;
+    const uint32_t total = offsets[nbuckets - 1] + min(counts[nbuckets - 1], capc);
     uint32_t pos = q * chunk_len;
     if (pos >= total) { cont_bucket[q] = 0xffffffffu; return; }
     const uint32_t end = min(pos + chunk_len, total);
@@ -361,7 +364,8 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
     uint32_t lo = 0, hi = nbuckets - 1;
     while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (offsets[mid] <= pos) lo = mid; else hi = mid - 1; }
     uint32_t b = lo;
-    uint32_t bend = offsets[b] + counts[b];
+    uint32_t bend = offsets[b] + min(counts[b], capc);
+    uint32_t kidx = pos - offsets[b];                       // index inside the bucket
     bool continuation = offsets[b] != pos;
     cont_bucket[q] = continuation ? b : 0xffffffffu;
     Acc acc;
@@ -370,9 +374,11 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
         if (pos == bend) {                                   // finished bucket b inside this chunk
             if (continuation) { acc_store(acc, cont + q); continuation = false; } else acc_store(acc, buckets + b);
             do { b++; } while (counts[b] == 0);
-            bend = offsets[b] + counts[b];
+            bend = offsets[b] + min(counts[b], capc);
+            kidx = 0;
         }
-        const uint32_t e = sorted[pos++];
+        const uint32_t e = sorted[cap ? (size_t)b * cap + kidx : (size_t)pos];
+        pos++; kidx++;
         const size_t at = table_stride ? (size_t)((e >> 24) & 0x7fu) * table_stride + (e & 0xffffffu) : (size_t)(e & 0x7fffffffu);
         Affine<F> p = ld_struct(bases + at);
         if (p.is_inf()) continue;

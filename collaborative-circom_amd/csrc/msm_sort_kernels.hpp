@@ -34,11 +34,11 @@ __global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scala
 
 // exclusive prefix sum of `total` counters in three launches: per-tile sums, scan of the tile sums, per-tile scan + base.
 constexpr int SCAN_TILE = 2048;     // counters per workgroup (256 lanes x 8)
-static __global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t* __restrict__ in, uint32_t* __restrict__ tile_sums, size_t total) {
+static __global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t* __restrict__ in, uint32_t* __restrict__ tile_sums, size_t total, uint32_t cap) {
     __shared__ uint32_t red[256];
     const size_t base = (size_t)blockIdx.x * SCAN_TILE;
     uint32_t s = 0;
-    for (int k = 0; k < SCAN_TILE / 256; k++) { size_t i = base + (size_t)k * 256 + threadIdx.x; if (i < total) s += in[i]; }
+    for (int k = 0; k < SCAN_TILE / 256; k++) { size_t i = base + (size_t)k * 256 + threadIdx.x; if (i < total) s += min(in[i], cap); }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
@@ -62,11 +62,11 @@ static __global__ void __launch_bounds__(1024) k_scan_exclusive(const uint32_t* 
     uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
     for (size_t i = lo; i < hi; i++) { uint32_t v = in[i]; out[i] = run; run += v; }
 }
-static __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* __restrict__ in, const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ out, size_t total) {
+static __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* __restrict__ in, const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ out, size_t total, uint32_t cap) {
     __shared__ uint32_t part[256];
     const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * (SCAN_TILE / 256);
     uint32_t v[SCAN_TILE / 256]; uint32_t s = 0;
-    for (int k = 0; k < SCAN_TILE / 256; k++) { size_t i = base + k; v[k] = i < total ? in[i] : 0; s += v[k]; }
+    for (int k = 0; k < SCAN_TILE / 256; k++) { size_t i = base + k; v[k] = i < total ? min(in[i], cap) : 0; s += v[k]; }
     part[threadIdx.x] = s;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
@@ -93,6 +93,35 @@ static __global__ void __launch_bounds__(256) k_msm_scatter(const int32_t* __res
         const size_t bucket = (shared ? 0 : w * nb) + (uint32_t)(dig < 0 ? -dig : dig) - 1;
         const uint32_t pos = offsets[bucket] + atomicAdd(&cursors[bucket], 1u);
         sorted[pos] = (shared ? ((uint32_t)w << 24) | i : i) | (dig < 0 ? 0x80000000u : 0u);
+    }
+}
+
+// Optimistic one-pass scatter: every bucket owns `cap` slots, so no histogram pass is needed — one atomic per (scalar, window)
+// instead of two, no digit array.  counts[] ends up holding the true per-bucket counts; if any exceeds cap the entry is dropped
+// and *overflow is set: the host then recomputes that MSM with the exact two-pass schedule (cg_msm_end), so results never
+// depend on the guess.  Uniformly random scalars (REP3 shares) stay far below cap (mean + 25 % + 6 sigma).
+template <class Fr>
+__global__ void __launch_bounds__(256) k_msm_scatter_direct(const Fr* __restrict__ scalars, size_t n, int c, int nwin, int shared, uint32_t cap,
+                                                            uint32_t* __restrict__ counts, uint32_t* __restrict__ sorted, uint32_t* __restrict__ overflow) {
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t mask = (1u << c) - 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr s = ld_fp(scalars + i).from_mont();
+        uint32_t carry = 0;
+        for (int w = 0; w < nwin; w++) {
+            uint32_t d = (s.v[0] & mask) + carry;
+            _Pragma("unroll") for (int l = 0; l < Fr::N; l++) {
+                uint64_t two = ((uint64_t)(l + 1 < Fr::N ? s.v[l + 1] : 0u) << 32) | s.v[l];
+                s.v[l] = (uint32_t)(two >> c);
+            }
+            int32_t dig;
+            if (d > nb) { dig = (int32_t)d - (int32_t)(1u << c); carry = 1; } else { dig = (int32_t)d; carry = 0; }
+            if (dig == 0) continue;
+            const size_t bucket = (shared ? 0 : (size_t)w * nb) + (uint32_t)(dig < 0 ? -dig : dig) - 1;
+            const uint32_t pos = atomicAdd(&counts[bucket], 1u);
+            if (pos < cap) sorted[bucket * cap + pos] = (shared ? ((uint32_t)w << 24) | (uint32_t)i : (uint32_t)i) | (dig < 0 ? 0x80000000u : 0u);
+            else *overflow = 1u;
+        }
     }
 }
 

@@ -90,6 +90,12 @@ int32_t cg_msm_dev_begin_multi(cg_ctx* ctx, int32_t n_tables, const cg_bases* co
                                const void* const* d_scalars, int32_t k, int32_t* tickets);
 /* window size override (0 = automatic); tuning knob only, never changes results */
 int32_t cg_msm_set_window(cg_ctx* ctx, int32_t c);
+/* Scalar-side schedule.  Default (cap < 0): exact two-pass counting sort.  cap == 0 selects an optimistic one-pass scatter into
+ * fixed-capacity buckets sized for uniformly random scalars (secret shares); if a bucket overflows, cg_msm_end transparently
+ * recomputes that MSM with the exact sort, so the scalars passed to cg_msm_dev_begin* must then stay valid until the matching
+ * cg_msm_end.  cap > 0 forces a capacity (testing).  Measured equally fast on MI355X (the cost is the scattered stores, not the
+ * atomics), hence opt-in.  Never changes results. */
+int32_t cg_msm_set_scatter_capacity(cg_ctx* ctx, int32_t cap);
 
 /* ---- FFTProvider::{fft,ifft}_in_place  (traits.rs:535-558; rep3.rs:893-921) ------------------------------------
  * k vectors of n = 2^j scalar-field elements, natural order in and out.  `h_group_gen` = domain.group_gen (the caller

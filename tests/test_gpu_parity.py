@@ -373,3 +373,28 @@ def test_msm_precomputed_multi_and_skew(ctx):
         ctx.msm_dev_begin_multi([b1, b3], [dev(ctx, uni)], n)
     for b in (b1, b2, b3):
         b.release()
+
+
+@pytest.mark.parametrize("cap", [-1, 4, 64, 0])
+def test_msm_optimistic_scatter_and_fallback(ctx, cap):
+    """one-pass fixed-capacity scatter: cap=4 overflows everywhere and must fall back to the exact schedule; -1 = always exact"""
+    curve, n = BN254, 2500
+    rng = np.random.default_rng(70)
+    p1, p2 = make_points(curve, G1, n, rng), make_points(curve, G2, n, rng)
+    b1, b2 = ctx.register_bases(curve, G1, p1), ctx.register_bases(curve, G2, p2)
+    uni = orc.random_field(curve, FR, n, rng)
+    skew = np.tile(orc.random_field(curve, FR, 1, rng), (n, 1))
+    ctx.set_scatter_capacity(cap)
+    try:
+        tickets = ctx.msm_dev_begin_multi([b1, b2], [dev(ctx, uni), dev(ctx, skew)], n)
+        for (g, p), t in zip(((G1, p1), (G2, p2)), tickets):
+            got = ctx.msm_end(t)
+            for j, sc in enumerate((uni, skew)):
+                np.testing.assert_array_equal(cg.point_to_affine(curve, g, got[j]), orc.msm(curve, g, p, sc, threads=8))
+        ctx.precompute_bases(b1, 12)
+        got = ctx.msm_dev(b1, [dev(ctx, skew), dev(ctx, uni)], n)
+        for j, sc in enumerate((skew, uni)):
+            np.testing.assert_array_equal(cg.point_to_affine(curve, G1, got[j]), orc.msm(curve, G1, p1, sc, threads=8))
+    finally:
+        ctx.set_scatter_capacity(-1)
+    b1.release(); b2.release()
