@@ -9,9 +9,11 @@ All inputs (CSR matrices, witness shares, masks, the vectors "received" from the
 tables) are resident in HBM before the timed region; the MPC network rounds are excluded on both the GPU and the CPU
 side.  Shares / masks are uniformly random full-width scalars, as REP3 shares always are.
 
-N > 1 (one process per GPU, torch.distributed / RCCL): STRONG scaling of the same proof — every MSM's point range is split
-across the ranks, each rank folds its partial sums locally and one all_gather of 10 Jacobian points per rank exchanges them
-(RCCL has no EC-add reduction).  The witness map (NTT stage, ~10 % of the step) is replicated on every rank in round 1.
+N > 1 (one process per GPU, torch.distributed / RCCL): STRONG scaling of the same proof — the ten MSMs are cut into work units
+(whole zkey tables, range-split only as far as balance needs it: full-size launches are the efficient ones) that plan_units()
+assigns to ranks; every rank holds only its own table slices, and one all_gather of the unit results (a few KB) + host EC
+additions fold the slices (RCCL has no EC-add reduction).  The witness map (NTT stage, ~10 % of the step) is replicated on
+every rank in round 1.
 
 Prints ONE JSON line (rank 0).  `roofline` = dominant kernel (G1 bucket accumulation) against the HBM peak, measured live
 with HIP events on the kernels' own stream; `cpu_baseline` = the oracle's C++ restatement of the same workload on the host.
@@ -77,25 +79,69 @@ class Workload:
         root = lambda k: pow(zt, 1 << (28 - k), r)
         mont = lambda v: np.array([((v << 256) % r >> (64 * j)) & (2**64 - 1) for j in range(4)], dtype=np.uint64)
         self.omega, self.coset_g = mont(root(log_m)), mont(root(log_m + 1))
-        # MSM shards: contiguous point ranges
+        # MSM work units: whole tables / table slices assigned to ranks, see plan_units()
         self.rank, self.world = rank, world
-        self.h_rng = shard_range(m, rank, world)
-        self.aux_rng = shard_range(n_aux, rank, world)
+        self.plan = plan_units(world)
+        self.mine = [(t, i, parts) for (t, i, parts, owner) in self.plan if owner == rank]
         t0 = time.time()
-        sb = lambda group, first, rng: ctx.synth_bases(CURVE, group, first + rng[0], rng[1] - rng[0])
-        self.h_q = sb(cg.G1, 1, self.h_rng); self.l_q = sb(cg.G1, 3, self.aux_rng)
-        self.a_q = sb(cg.G1, 5, self.aux_rng); self.b1_q = sb(cg.G1, 7, self.aux_rng); self.b2_q = sb(cg.G2, 1, self.aux_rng)
+        self.tables = {}                                  # (table, i, parts) -> (bases, lo, hi)
+        for (t, i, parts) in self.mine:
+            n_tab = m if t == "h" else n_aux
+            lo, hi = shard_range(n_tab, i, parts)
+            self.tables[(t, i, parts)] = (ctx.synth_bases(CURVE, TABLE_GROUP[t], TABLE_FIRST[t] + lo, hi - lo), lo, hi)
         self.setup_bases_s = time.time() - t0
         # zkey registration-time work (untimed, like zkey parsing): per-window precomputed tables, resident across proofs
         t0 = time.time()
         self.precompute = precompute
         if precompute:
-            for q in (self.h_q, self.l_q, self.a_q, self.b1_q, self.b2_q):
-                ctx.precompute_bases(q, precompute)
+            for (bases, lo, hi) in self.tables.values():
+                ctx.precompute_bases(bases, precompute)
         self.setup_precompute_s = time.time() - t0
 
     def sl(self, t, rng):
         return t[rng[0]:rng[1]]
+
+
+TABLES = ("h", "l", "a", "b1", "b2")            # zkey queries of create_proof_with_assignment (groth16.rs:248-304)
+TABLE_GROUP = {"h": 0, "l": 0, "a": 0, "b1": 0, "b2": 1}
+TABLE_FIRST = {"h": 1, "l": 3, "a": 5, "b1": 7, "b2": 1}     # synthetic tables: [(first + i) * G]
+G2_COST = 2.3                                    # measured: a G2 accumulate launch costs 2.3 G1 launches
+SORT_COST = 0.45                                 # digit/sort schedule per (scalar set, range), shared by the tables that use it
+
+
+def plan_units(world):
+    """Work units of the MSM stage and their owner ranks.
+    A unit = (table, lo_frac, hi_frac): the MSM of BOTH share components over a contiguous slice of one table.  Whole tables
+    are the preferred unit (full-size launches are the efficient ones: at 1/8 of the points the bucket reduction dominates);
+    a table is range-split only as far as needed to balance the ranks (G2 first: it is the most expensive).  Greedy longest-
+    processing-time assignment; returns [(table, num, den_index, owner)], identical on every rank."""
+    splits = {t: 1 for t in TABLES}
+    def units_of(sp):
+        return [(t, i, sp[t]) for t in TABLES for i in range(sp[t])]
+    def cost(u):
+        t, _, parts = u
+        return (G2_COST if TABLE_GROUP[t] else 1.0) * 2.0 / parts
+    def assign(units):
+        load = [0.0] * world; owner = {}
+        sorts = [set() for _ in range(world)]
+        for u in sorted(units, key=lambda u: -cost(u)):
+            key = lambda r: load[r] + cost(u) + (0.0 if (("h" if u[0] == "h" else "aux"), u[1], u[2]) in sorts[r] else 2 * SORT_COST / u[2])
+            r = min(range(world), key=key)
+            load[r] = key(r); sorts[r].add((("h" if u[0] == "h" else "aux"), u[1], u[2])); owner[u] = r
+        return load, owner
+    best = None
+    for _ in range(8):
+        units = units_of(splits)
+        load, owner = assign(units)
+        if best is None or max(load) < best[0] - 1e-9:
+            best = (max(load), dict(splits), owner)
+        if len(units) >= 4 * world:
+            break
+        # split the table owning the costliest unit further
+        t = max(units, key=cost)[0]
+        splits[t] *= 2
+    _, sp, owner = best
+    return [(t, i, sp[t], owner[(t, i, sp[t])]) for t in TABLES for i in range(sp[t])]
 
 
 def shard_range(n, rank, world):
@@ -133,36 +179,57 @@ def step(w):
     ctx.ntt_dev(C, [w.ca, w.cb], m, w.omega)
     ctx.vec_sub(C, w.ha, w.ha, w.ca, m)
     ctx.vec_sub(C, w.hb, w.hb, w.cb, m)
-    # MSMs (groth16.rs:248-304); scalars sliced to this rank's point range
-    h0, h1 = w.h_rng; a0, a1 = w.aux_rng
-    aux = [w.wa[a0:a1], w.wb[a0:a1]]
-    tickets = [ctx.msm_dev_begin(w.h_q, [w.ha[h0:h1], w.hb[h0:h1]], h1 - h0)]
-    # l, a, b1 (G1) and b2 (G2) all multiply the aux-witness shares: one digit/sort schedule per share component, four tables
-    # (the G2 table goes first: its long bucket reduction then overlaps the following G1 accumulations instead of ending the step)
-    tables = [w.l_q, w.a_q, w.b1_q, w.b2_q] if w.g2_last else [w.b2_q, w.l_q, w.a_q, w.b1_q]
-    tickets += ctx.msm_dev_begin_multi(tables, aux, a1 - a0)
-    return [ctx.msm_end(t) for t in tickets]
+    # MSMs (groth16.rs:248-304) over the units this rank owns.  Units that multiply the same scalar slice share one digit/sort
+    # schedule (l, a, b1, b2 all take the aux-witness shares); G2 goes first so its long bucket reduction overlaps later work.
+    groups = {}
+    for key in w.mine:
+        t, i, parts = key
+        bases, lo, hi = w.tables[key]
+        groups.setdefault(("h" if t == "h" else "aux", lo, hi), []).append((key, bases))
+    pending = []
+    for (kind, lo, hi), members in groups.items():
+        members.sort(key=lambda kb: -TABLE_GROUP[kb[0][0]])
+        sc = [w.ha[lo:hi], w.hb[lo:hi]] if kind == "h" else [w.wa[lo:hi], w.wb[lo:hi]]
+        tk = ctx.msm_dev_begin_multi([b for _, b in members], sc, hi - lo)
+        pending += [(key, t) for (key, _), t in zip(members, tk)]
+    return {key: ctx.msm_end(t) for key, t in pending}
 
 
-def exchange(results, dist, world, device):
-    """all_gather of the 10 partial points per rank (8 x 96 B + 2 x 192 B) and local EC adds"""
-    if world == 1:
-        return results
-    flat = np.concatenate([r.reshape(-1) for r in results]).astype(np.uint64)
-    t = torch.from_numpy(flat.view(np.int64)).to(device)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
-    per_rank = [o.cpu().numpy().view(np.uint64) for o in out]
-    combined, off = [], 0
-    for r in results:
-        k, wlen = r.shape
-        group = cg.G1 if wlen == 12 else cg.G2
-        comp = []
-        for j in range(k):
-            parts = [pr[off + j * wlen: off + (j + 1) * wlen] for pr in per_rank]
-            comp.append(combine_partials(CURVE, group, parts))
-        combined.append(np.stack(comp)); off += k * wlen
-    return combined
+def unit_layout(plan):
+    """flat layout of all unit results (2 components x Jacobian) in plan order: {unit: (offset_words, words_per_component)}"""
+    off, lay = 0, {}
+    for (t, i, parts, owner) in plan:
+        wlen = 12 if TABLE_GROUP[t] == 0 else 24
+        lay[(t, i, parts)] = (off, wlen, owner)
+        off += 2 * wlen
+    return lay, off
+
+
+def exchange(results, plan, rank, dist, world, device):
+    """Each rank contributes the results of its own units (zeros elsewhere); one all_gather of the flat buffer (a few KB), then
+    per table the slices are folded with host EC additions (RCCL has no EC-add reduction).  Returns {table: (2, words)}."""
+    lay, total = unit_layout(plan)
+    flat = np.zeros(total, dtype=np.uint64)
+    for key, r in results.items():
+        off, wlen, _ = lay[key]
+        flat[off:off + 2 * wlen] = r.reshape(-1)
+    if world > 1:
+        t = torch.from_numpy(flat.view(np.int64)).to(device)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        per_rank = [o.cpu().numpy().view(np.uint64) for o in out]
+    else:
+        per_rank = [flat]
+    final = {}
+    for (t, i, parts, owner) in plan:
+        off, wlen, _ = lay[(t, i, parts)]
+        piece = per_rank[owner][off:off + 2 * wlen].reshape(2, wlen)
+        if t not in final:
+            final[t] = piece.copy()
+        else:
+            group = cg.G1 if TABLE_GROUP[t] == 0 else cg.G2
+            final[t] = np.stack([combine_partials(CURVE, group, [final[t][j], piece[j]]) for j in range(2)])
+    return final
 
 
 def cpu_baseline(threads_cap=None):
@@ -223,12 +290,12 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        res = exchange(step(w), dist, world, device)
+        res = exchange(step(w), w.plan, rank, dist, world, device)
     ctx.stats_enable(True); ctx.stats(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = exchange(step(w), dist, world, device)
+        res = exchange(step(w), w.plan, rank, dist, world, device)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -241,12 +308,12 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = w.nc / (elapsed / args.steps)
-        n_h = w.h_rng[1] - w.h_rng[0]; n_x = w.aux_rng[1] - w.aux_rng[0]
+        g1_pts = [hi - lo for (t, i, parts), (b, lo, hi) in w.tables.items() if TABLE_GROUP[t] == 0]
         # dominant kernel: G1 bucket accumulation. Algorithmic bytes per launch: each base read once (64 B)
         # + its scalar read once (32 B) = 96 B per point of the launch's range.
         acc_calls = max(1, st["msm_acc_g1_calls"])
         avg_ms = st["msm_acc_g1_ms"] / acc_calls
-        avg_pts = (2 * n_h + 6 * n_x) / 8.0
+        avg_pts = (sum(g1_pts) / len(g1_pts)) if g1_pts else 0.0
         alg_bytes = 96.0 * avg_pts
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         per_step = lambda k: st[k] / args.steps
@@ -263,7 +330,7 @@ def main():
             "dtype": "u32 limbs (254-bit modular integer arithmetic)", "data": "synthetic",
             "config": {"workload": f"synthetic R1CS 2^{args.log_m} constraints-domain BN254, REP3 co-groth16 (configs[2])",
                        "num_constraints": w.nc, "domain_size": w.m, "n_vars": w.m, "nnz": w.nnz, "share_components": 2,
-                       "msm": "8 G1 + 2 G2 of ~2^%d points" % args.log_m, "msm_window": ("precomputed tables c=%d" % args.precompute) if args.precompute else "c=16, per-window bucket sets", "ntt": 12, "parallelism": f"msm-range-shard x{world}"},
+                       "msm": "8 G1 + 2 G2 of ~2^%d points" % args.log_m, "msm_window": ("precomputed tables c=%d" % args.precompute) if args.precompute else "c=16, per-window bucket sets", "ntt": 12, "parallelism": f"msm units (tables / table slices) over {world} rank(s): " + ",".join(f"{t}{i}/{p}->r{o}" for t, i, p, o in w.plan)},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<G1> (bucket accumulation, one launch per MSM component and table)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": st["msm_acc_g1_calls"], "algorithmic_bytes_per_launch": alg_bytes,

@@ -1,6 +1,7 @@
-"""N > 1 path of bench.py on CPU: world_size-2 gloo. Each rank owns a contiguous point range (shard_range), produces the
-partial MSM results of its shard (here with the oracle standing in for the GPU kernels), and bench.exchange() all_gathers the
-partial Jacobian points and folds them with the product's host EC addition — the result must equal the unsharded MSM."""
+"""N > 1 path of bench.py on CPU: world_size-2 gloo. bench.plan_units() assigns MSM work units (whole tables or contiguous
+table slices) to ranks; each rank produces the results of its units (here the oracle stands in for the GPU kernels) and
+bench.exchange() all_gathers them and folds the slices of every table with the product's host EC addition — the five results
+must equal the unsharded MSMs on every rank."""
 import os
 import socket
 import sys
@@ -29,22 +30,49 @@ def _worker(rank, world, port, n, q):
     curve = orc.BN254
     rng = np.random.default_rng(1234)                     # same inputs on every rank
     ks = orc.random_field(curve, orc.FR, n, rng)
-    results, full = [], []
-    for group, k in ((orc.G1, 2), (orc.G2, 2)):
-        pts = np.stack([orc.generator_mul(curve, group, s) for s in ks])
-        scal = [orc.random_field(curve, orc.FR, n, rng) for _ in range(k)]
-        lo, hi = bench.shard_range(n, rank, world)
-        part = np.stack([cg.point_from_affine(curve, group, orc.msm(curve, group, pts[lo:hi], s[lo:hi])) for s in scal])
-        results.append(part)
-        full.append(np.stack([orc.msm(curve, group, pts, s) for s in scal]))
-    combined = bench.exchange(results, dist, world, torch.device("cpu"))
-    ok = True
-    for r, f, group in zip(combined, full, (orc.G1, orc.G2)):
-        for j in range(r.shape[0]):
-            ok &= bool(np.array_equal(cg.point_to_affine(curve, group, r[j]), f[j]))
-    q.put((rank, ok))
+    plan = bench.plan_units(world)
+    tables, scal, full = {}, {}, {}
+    for t in bench.TABLES:
+        group = orc.G1 if bench.TABLE_GROUP[t] == 0 else orc.G2
+        tables[t] = np.stack([orc.generator_mul(curve, group, s) for s in orc.random_field(curve, orc.FR, n, rng)])
+    scal["h"] = [orc.random_field(curve, orc.FR, n, rng) for _ in range(2)]
+    scal["aux"] = [orc.random_field(curve, orc.FR, n, rng) for _ in range(2)]
+    results = {}
+    for (t, i, parts, owner) in plan:
+        group = orc.G1 if bench.TABLE_GROUP[t] == 0 else orc.G2
+        sc = scal["h" if t == "h" else "aux"]
+        if t not in full:
+            full[t] = np.stack([orc.msm(curve, group, tables[t], s) for s in sc])
+        if owner != rank:
+            continue
+        lo, hi = bench.shard_range(n, i, parts)           # the oracle stands in for the GPU kernels on this unit
+        results[(t, i, parts)] = np.stack([cg.point_from_affine(curve, group, orc.msm(curve, group, tables[t][lo:hi], s[lo:hi])) for s in sc])
+    final = bench.exchange(results, plan, rank, dist, world, torch.device("cpu"))
+    ok = set(final.keys()) == set(bench.TABLES)
+    for t in bench.TABLES:
+        group = orc.G1 if bench.TABLE_GROUP[t] == 0 else orc.G2
+        for j in range(2):
+            ok &= bool(np.array_equal(cg.point_to_affine(curve, group, final[t][j]), full[t][j]))
+    q.put((rank, ok, len(results)))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_plan_units_covers_every_table_once():
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (1, 2, 3, 4, 8):
+        plan = bench.plan_units(world)
+        for t in bench.TABLES:
+            mine = sorted((i, parts) for (tt, i, parts, o) in plan if tt == t)
+            parts = mine[0][1]
+            assert mine == [(i, parts) for i in range(parts)]            # each table: slices 0..parts-1 exactly once
+        owners = [o for (_, _, _, o) in plan]
+        assert set(owners) == set(range(world)) or world > len(plan)      # every rank gets work
+        load = [0.0] * world
+        for (t, i, parts, o) in plan:
+            load[o] += (bench.G2_COST if bench.TABLE_GROUP[t] else 1.0) * 2 / parts
+        assert max(load) <= 1.35 * (sum(load) / world) + 1e-9             # balanced within 35 %
 
 
 def test_shard_range_partitions():
@@ -65,8 +93,9 @@ def test_msm_shard_allgather_combine_world2():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 37, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 23, q)) for r in range(world)]
     for p in procs: p.start()
     got = [q.get(timeout=300) for _ in range(world)]
     for p in procs: p.join(timeout=60)
-    assert sorted(got) == [(0, True), (1, True)]
+    assert sorted((r, ok) for r, ok, _ in got) == [(0, True), (1, True)]
+    assert all(nunits > 0 for _, _, nunits in got)
