@@ -35,8 +35,9 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared) {
 template <class F>
 size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared) {
     const MsmGeom g = msm_geom(n, c, nwin, shared);
-    return align_up(g.nbuckets * sizeof(XYZZ<F>)) + align_up((size_t)g.nchunks * sizeof(XYZZ<F>)) + align_up((size_t)g.nchunks * 4) +
-           align_up((size_t)g.nsets * g.segs * sizeof(XYZZ<F>)) + align_up((size_t)g.ngroups * sizeof(XYZZ<F>));
+    typedef typename BucketOf<F>::type B;
+    return align_up(g.nbuckets * sizeof(B)) + align_up((size_t)g.nchunks * sizeof(B)) + align_up((size_t)g.nchunks * 4) +
+           align_up((size_t)g.nsets * g.segs * sizeof(B)) + align_up((size_t)g.ngroups * sizeof(XYZZ<F>));
 }
 
 // buckets -> window sums for one (bases, sorted schedule) pair; the nwin window sums land in h_out (pinned) via an async copy.
@@ -51,13 +52,14 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     const MsmGeom g = msm_geom(n, c, nwin, shared);
     size_t off = 0;
     auto take = [&](size_t bytes) { void* p = scratch + off; off += align_up(bytes); return p; };
-    XYZZ<F>* buckets = (XYZZ<F>*)take(g.nbuckets * sizeof(XYZZ<F>));
-    XYZZ<F>* cont = (XYZZ<F>*)take((size_t)g.nchunks * sizeof(XYZZ<F>));
+    typedef typename BucketOf<F>::type B;                 // limb-form points for the lazy pipelines, saturated XYZZ otherwise
+    B* buckets = (B*)take(g.nbuckets * sizeof(B));
+    B* cont = (B*)take((size_t)g.nchunks * sizeof(B));
     uint32_t* cont_bucket = (uint32_t*)take((size_t)g.nchunks * 4);
-    XYZZ<F>* partials = (XYZZ<F>*)take((size_t)g.nsets * g.segs * sizeof(XYZZ<F>));
+    B* partials = (B*)take((size_t)g.nsets * g.segs * sizeof(B));
     XYZZ<F>* wsums = (XYZZ<F>*)take((size_t)g.ngroups * sizeof(XYZZ<F>));
     if (evs) HIPCHK(hipEventRecord(evs[0], st));
-    HIPCHK(hipMemsetAsync(buckets, 0, g.nbuckets * sizeof(XYZZ<F>), st));          // all-zero XYZZ = infinity (empty buckets are never written)
+    HIPCHK(hipMemsetAsync(buckets, 0, g.nbuckets * sizeof(B), st));                // all-zero = infinity (empty buckets are never written)
     auto launch_acc = [&](auto kern, int T, size_t lds) -> int {
         if (lds > 0) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((g.nchunks + T - 1) / T), dim3(T), lds, st, d_bases, sorted, offsets, counts,
@@ -74,16 +76,20 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     else if constexpr (sizeof(F) > 64) rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc<F>, 128>, 128, (size_t)128 * sizeof(XYZZ<F>));
     else rc_acc = launch_acc(k_msm_accumulate<F, RegAcc<F>, 256>, 256, 0);
     if (rc_acc) return rc_acc;
-    hipLaunchKernelGGL((k_msm_merge_cont_l1<F>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, cont, cont_bucket, g.nchunks);
-    hipLaunchKernelGGL((k_msm_merge_cont<F>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, buckets, cont, cont_bucket, g.nchunks);
+    hipLaunchKernelGGL((k_msm_merge_cont_l1<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, cont, cont_bucket, g.nchunks);
+    hipLaunchKernelGGL((k_msm_merge_cont<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, buckets, cont, cont_bucket, g.nchunks);
     if (evs) HIPCHK(hipEventRecord(evs[1], st));
     HIPCHK(hipEventRecord(ev_acc, st));
     HIPCHK(hipStreamWaitEvent(st2, ev_acc, 0));
     if (evs) HIPCHK(hipEventRecord(evs[2], st2));
     const size_t nseg_threads = (size_t)g.nsets * g.segs;
-    hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3((unsigned)((nseg_threads + 63) / 64)), dim3(64), 0, st2, buckets, g.nb, g.seg_len, g.nsets, partials);
-    constexpr int WT = sizeof(XYZZ<F>) > 128 ? 128 : 256;
-    hipLaunchKernelGGL((k_msm_window_sum<F, WT>), dim3(g.ngroups), dim3(WT), WT * sizeof(XYZZ<F>), st2, partials, g.group_segs, wsums);
+    hipLaunchKernelGGL((k_msm_reduce_segments<B>), dim3((unsigned)((nseg_threads + 63) / 64)), dim3(64), 0, st2, buckets, g.nb, g.seg_len, g.nsets, partials);
+    constexpr int WT = sizeof(B) > 160 ? 128 : 256;
+    {
+        static bool attr_set = false;
+        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_msm_window_sum<F, B, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WT * sizeof(B)))); attr_set = true; }
+    }
+    hipLaunchKernelGGL((k_msm_window_sum<F, B, WT>), dim3(g.ngroups), dim3(WT), WT * sizeof(B), st2, partials, g.group_segs, wsums);
     if (evs) HIPCHK(hipEventRecord(evs[3], st2));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_out, wsums, (size_t)g.ngroups * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st2));

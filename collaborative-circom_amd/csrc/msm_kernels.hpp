@@ -16,6 +16,7 @@
 //   6. host: Horner fold of the <= 64 window sums (c doublings each) — O(1) work, kept on the host.
 // With uniformly random scalars (REP3 shares always are) every bucket receives n/2^(c-1) +- sqrt points: lanes are balanced.
 #pragma once
+#include <type_traits>
 #include "curve.hpp"
 #include "vec_kernels.hpp"
 #include "msm_sort_kernels.hpp"
@@ -283,6 +284,72 @@ template <class Acc> struct IsLazyAcc { static constexpr bool value = false; };
 template <class F> struct IsLazyAcc<RegAcc29<F>> { static constexpr bool value = true; };
 template <class F> struct IsLazyAcc<LdsAcc29<F>> { static constexpr bool value = true; };
 
+// Buckets, continuation pieces and reduction partials of the lazy pipelines stay in LIMB form (XYZZL: 4 lazy coordinates;
+// all limbs of ZZ zero = infinity, which a finite point can never show because its ZZ is non-zero modulo p), so nothing is
+// converted between the accumulation and the final per-window sums.  Saturated XYZZ<F> is kept for fields without a lazy form.
+template <class F>
+struct alignas(16) XYZZL {
+    typedef typename LazyOf<F>::type L;
+    L c[4];   // X, Y, ZZ, ZZZ
+};
+template <class F> struct BucketOf { typedef XYZZ<F> type; };
+template <class P> struct BucketOf<Fp<P>> { typedef typename std::conditional<Fp<P>::N == 8, XYZZL<Fp<P>>, XYZZ<Fp<P>>>::type type; };
+template <class B> struct BucketOf<Fp2<B>> { typedef typename std::conditional<B::N == 8, XYZZL<Fp2<B>>, XYZZ<Fp2<B>>>::type type; };
+
+template <class F> __device__ __forceinline__ bool bk_is_inf(const XYZZ<F>& p) { return p.is_inf(); }
+template <class F> __device__ __forceinline__ bool bk_is_inf(const XYZZL<F>& p) {
+    const int32_t* w = reinterpret_cast<const int32_t*>(&p.c[2]); int32_t o = 0;
+    _Pragma("unroll") for (int i = 0; i < (int)(sizeof(p.c[2]) / 4); i++) o |= w[i];
+    return o == 0;
+}
+template <class B> __device__ __forceinline__ B bk_inf() { B r; uint32_t* w = reinterpret_cast<uint32_t*>(&r); for (int i = 0; i < (int)(sizeof(B) / 4); i++) w[i] = 0; return r; }
+
+// add-2008-s / dbl-2008-s-1 on lazy limbs (same value classes as the mixed addition: X in (-4.8, 2.8), Y in (-1.9, 1.9),
+// ZZ, ZZZ in (-0.45, 1.45) times p; every product below stays under 72 p^2).  Out of line on purpose (latency-bound kernels).
+template <class F>
+__device__ __attribute__((noinline)) XYZZL<F> bk_dbl(const XYZZL<F>& a) {
+    typedef typename LazyOf<F>::type L;
+    if (bk_is_inf(a) || L::is_zero_mod_p(a.c[1].norm())) return bk_inf<XYZZL<F>>();
+    L U = a.c[1].dbl().norm(), V = L::sqr(U), W = L::mul(U, V), S = L::mul(a.c[0], V);
+    L xx = L::sqr(a.c[0]);
+    L M = (xx.dbl() + xx).norm();
+    L X3 = (L::sqr(M) - S.dbl()).norm();
+    XYZZL<F> r;
+    r.c[0] = X3;
+    r.c[1] = (L::mul(M, S - X3) - L::mul(W, a.c[1])).norm();
+    r.c[2] = L::mul(V, a.c[2]);
+    r.c[3] = L::mul(W, a.c[3]);
+    return r;
+}
+template <class F>
+__device__ __attribute__((noinline)) XYZZL<F> bk_add(const XYZZL<F>& a, const XYZZL<F>& b) {
+    typedef typename LazyOf<F>::type L;
+    if (bk_is_inf(a)) return b;
+    if (bk_is_inf(b)) return a;
+    L U1 = L::mul(a.c[0], b.c[2]), S1 = L::mul(a.c[1], b.c[3]);
+    L P = L::mul(b.c[0], a.c[2]) - U1, R = L::mul(b.c[1], a.c[3]) - S1;
+    if (L::is_zero_mod_p(P.norm())) {
+        if (L::is_zero_mod_p(R.norm())) return bk_dbl(a);
+        return bk_inf<XYZZL<F>>();
+    }
+    L PP = L::sqr(P), PPP = L::mul(P, PP), Q = L::mul(U1, PP);
+    L X3 = (L::sqr(R) - PPP - Q.dbl()).norm();
+    XYZZL<F> r;
+    r.c[0] = X3;
+    r.c[1] = (L::mul(R, Q - X3) - L::mul(S1, PPP)).norm();
+    r.c[2] = L::mul(L::mul(a.c[2], b.c[2]), PP);
+    r.c[3] = L::mul(L::mul(a.c[3], b.c[3]), PPP);
+    return r;
+}
+template <class F> __device__ __forceinline__ XYZZ<F> bk_add(const XYZZ<F>& a, const XYZZ<F>& b) { return xyzz_add(a, b); }
+template <class F> __device__ __forceinline__ XYZZ<F> bk_dbl(const XYZZ<F>& a) { return xyzz_dbl(a); }
+template <class F> __device__ __forceinline__ XYZZ<F> bk_to_xyzz(const XYZZ<F>& a) { return a; }
+template <class F> __device__ __forceinline__ XYZZ<F> bk_to_xyzz(const XYZZL<F>& a) {
+    typedef typename LazyOf<F>::type L;
+    if (bk_is_inf(a)) return XYZZ<F>::infinity();
+    return {L::to_fp(a.c[0]), L::to_fp(a.c[1]), L::to_fp(a.c[2]), L::to_fp(a.c[3])};
+}
+
 // acc += (x2, y2): madd-2008-s on lazy signed limbs (see the bounds above); coordinates 0..3 = X, Y, ZZ, ZZZ
 template <class F, class Acc>
 __device__ __forceinline__ void acc_madd_lazy(Acc& acc, const F& x2f, const F& y2f, bool negate) {
@@ -319,10 +386,9 @@ __device__ __forceinline__ void acc_madd_lazy(Acc& acc, const F& x2f, const F& y
     acc.set(0, X3);
 }
 template <class F, class Acc>
-__device__ __forceinline__ void acc_flush_lazy(Acc& acc, XYZZ<F>* dst) {
-    typedef typename LazyOf<F>::type L;
-    XYZZ<F> r = XYZZ<F>::infinity();
-    if (!acc.inf) { r.x = L::to_fp(acc.get(0)); r.y = L::to_fp(acc.get(1)); r.zz = L::to_fp(acc.get(2)); r.zzz = L::to_fp(acc.get(3)); }
+__device__ __forceinline__ void acc_flush_lazy(Acc& acc, XYZZL<F>* dst) {
+    XYZZL<F> r = bk_inf<XYZZL<F>>();
+    if (!acc.inf) { r.c[0] = acc.get(0); r.c[1] = acc.get(1); r.c[2] = acc.get(2); r.c[3] = acc.get(3); }
     st_struct(dst, r);
     acc.inf = true;
 }
@@ -332,8 +398,8 @@ __device__ __forceinline__ void acc_madd(Acc& acc, const F& x2, const F& y2, boo
     if constexpr (IsLazyAcc<Acc>::value) acc_madd_lazy<F>(acc, x2, y2, negate);
     else acc_madd(acc, x2, negate ? y2.neg() : y2);
 }
-template <class F, class Acc>
-__device__ __forceinline__ void acc_store(Acc& acc, XYZZ<F>* dst) {
+template <class F, class Acc, class B>
+__device__ __forceinline__ void acc_store(Acc& acc, B* dst) {
     if constexpr (IsLazyAcc<Acc>::value) acc_flush_lazy<F>(acc, dst);
     else acc_flush(acc, dst);
 }
@@ -348,7 +414,8 @@ template <class F, class Acc, int THREADS, int MINW = 1>
 __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                             uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks, uint32_t table_stride, uint32_t cap,
-                                                            XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ cont, uint32_t* __restrict__ cont_bucket) {
+                                                            typename BucketOf<F>::type* __restrict__ buckets, typename BucketOf<F>::type* __restrict__ cont,
+                                                            uint32_t* __restrict__ cont_bucket) {
     // table_stride != 0: entries are (window << 24 | index) into per-window precomputed tables laid out [window][table_stride]
     // cap != 0: `sorted` is the padded layout of k_msm_scatter_direct (bucket b owns slots [b*cap, b*cap + min(count, cap)));
     //           positions (pos, offsets) are still those of the compact list, so the chunking is unchanged
@@ -372,7 +439,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
     acc.init(reinterpret_cast<typename Acc::LdsT*>(acc_lds), threadIdx.x, THREADS);
     while (pos < end) {
         if (pos == bend) {                                   // finished bucket b inside this chunk
-            if (continuation) { acc_store(acc, cont + q); continuation = false; } else acc_store(acc, buckets + b);
+            if (continuation) { acc_store<F>(acc, cont + q); continuation = false; } else acc_store<F>(acc, buckets + b);
             do { b++; } while (counts[b] == 0);
             bend = offsets[b] + min(counts[b], capc);
             kidx = 0;
@@ -384,7 +451,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
         if (p.is_inf()) continue;
         acc_madd(acc, p.x, p.y, (e >> 31) != 0);
     }
-    if (continuation) acc_store(acc, cont + q); else acc_store(acc, buckets + b);
+    if (continuation) acc_store<F>(acc, cont + q); else acc_store<F>(acc, buckets + b);
 }
 
 // Continuation pieces of one bucket occupy consecutive chunks q0, q0+1, ... (same tag).  Two-level fold so that a bucket spread
@@ -393,8 +460,8 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
 //   level 2: the run-start lane adds the group sums of its run into buckets[b].
 // With uniform scalars runs have 1-3 pieces and both levels are a handful of additions.
 constexpr uint32_t MERGE_GROUP = 64;
-template <class F>
-__global__ void __launch_bounds__(64) k_msm_merge_cont_l1(XYZZ<F>* __restrict__ cont, const uint32_t* __restrict__ cont_bucket, uint32_t nchunks) {
+template <class B>
+__global__ void __launch_bounds__(64) k_msm_merge_cont_l1(B* __restrict__ cont, const uint32_t* __restrict__ cont_bucket, uint32_t nchunks) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nchunks) return;
     const uint32_t b = cont_bucket[q];
@@ -403,69 +470,68 @@ __global__ void __launch_bounds__(64) k_msm_merge_cont_l1(XYZZ<F>* __restrict__ 
     if (!run_start && (q % MERGE_GROUP) != 0) return;
     const uint32_t next_head = (q / MERGE_GROUP + 1) * MERGE_GROUP;           // first aligned position after q
     if (q + 1 >= nchunks || q + 1 >= next_head || cont_bucket[q + 1] != b) return;   // single piece: nothing to fold
-    XYZZ<F> acc = ld_struct(cont + q);
-    for (uint32_t r = q + 1; r < nchunks && r < next_head && cont_bucket[r] == b; r++) acc = xyzz_add(acc, ld_struct(cont + r));
+    B acc = ld_struct(cont + q);
+    for (uint32_t r = q + 1; r < nchunks && r < next_head && cont_bucket[r] == b; r++) acc = bk_add(acc, ld_struct(cont + r));
     st_struct(cont + q, acc);                                                   // only group heads are written; nobody else reads them in this launch
 }
-template <class F>
-__global__ void __launch_bounds__(64) k_msm_merge_cont(XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ cont, const uint32_t* __restrict__ cont_bucket, uint32_t nchunks) {
+template <class B>
+__global__ void __launch_bounds__(64) k_msm_merge_cont(B* __restrict__ buckets, const B* __restrict__ cont, const uint32_t* __restrict__ cont_bucket, uint32_t nchunks) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nchunks) return;
     const uint32_t b = cont_bucket[q];
     if (b == 0xffffffffu) return;
     if (q > 0 && cont_bucket[q - 1] == b) return;
-    XYZZ<F> acc = xyzz_add(ld_struct(buckets + b), ld_struct(cont + q));
-    for (uint32_t r = (q / MERGE_GROUP + 1) * MERGE_GROUP; r < nchunks && cont_bucket[r] == b; r += MERGE_GROUP) acc = xyzz_add(acc, ld_struct(cont + r));
+    B acc = bk_add(ld_struct(buckets + b), ld_struct(cont + q));
+    for (uint32_t r = (q / MERGE_GROUP + 1) * MERGE_GROUP; r < nchunks && cont_bucket[r] == b; r += MERGE_GROUP) acc = bk_add(acc, ld_struct(cont + r));
     st_struct(buckets + b, acc);
 }
 
-template <class F>
-__device__ __forceinline__ XYZZ<F> xyzz_mul_small(const XYZZ<F>& p, uint32_t k) {
-    XYZZ<F> r = XYZZ<F>::infinity();
+template <class B>
+__device__ __forceinline__ B bk_mul_small(const B& p, uint32_t k) {
+    B r = bk_inf<B>();
     if (k == 0) return r;
     for (int i = 31 - __builtin_clz(k); i >= 0; i--) {
-        r = xyzz_dbl(r);
-        if ((k >> i) & 1u) r = xyzz_add(r, p);
+        r = bk_dbl(r);
+        if ((k >> i) & 1u) r = bk_add(r, p);
     }
     return r;
 }
 
 // lane (w, seg): sum_{b in [lo, lo+L)} (b+1) * B[w][b]  =  sum (b-lo+1) B_b  +  lo * sum B_b
-template <class F>
-__global__ void __launch_bounds__(64) k_msm_reduce_segments(const XYZZ<F>* __restrict__ buckets, uint32_t nb, uint32_t seg_len, int nwin,
-                                                            XYZZ<F>* __restrict__ partials) {
+template <class B>
+__global__ void __launch_bounds__(64) k_msm_reduce_segments(const B* __restrict__ buckets, uint32_t nb, uint32_t seg_len, int nwin, B* __restrict__ partials) {
     const uint32_t segs = nb / seg_len;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)nwin * segs) return;
     const uint32_t w = (uint32_t)(t / segs), seg = (uint32_t)(t % segs);
     const uint32_t lo = seg * seg_len;
-    const XYZZ<F>* B = buckets + (size_t)w * nb;
-    XYZZ<F> run = XYZZ<F>::infinity(), acc = XYZZ<F>::infinity();
+    const B* Bk = buckets + (size_t)w * nb;
+    B run = bk_inf<B>(), acc = bk_inf<B>();
     for (uint32_t b = lo + seg_len; b-- > lo;) {
-        run = xyzz_add(run, ld_struct(B + b));
-        acc = xyzz_add(acc, run);
+        run = bk_add(run, ld_struct(Bk + b));
+        acc = bk_add(acc, run);
     }
-    acc = xyzz_add(acc, xyzz_mul_small(run, lo));
+    acc = bk_add(acc, bk_mul_small(run, lo));
     st_struct(partials + t, acc);
 }
 
-// workgroup w: window_sums[w] = sum of its `segs` partials (strided serial sums, then an LDS tree)
-template <class F, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_msm_window_sum(const XYZZ<F>* __restrict__ partials, uint32_t segs, XYZZ<F>* __restrict__ window_sums) {
+// workgroup g: sums[g] = sum of its `segs` partials (strided serial sums, then an LDS tree), converted to canonical XYZZ for the host
+template <class F, class B, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_msm_window_sum(const B* __restrict__ partials, uint32_t segs, XYZZ<F>* __restrict__ window_sums) {
     extern __shared__ uint4 lds_raw[];
-    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds_raw);
-    const XYZZ<F>* P = partials + (size_t)blockIdx.x * segs;
-    XYZZ<F> acc = XYZZ<F>::infinity();
-    for (uint32_t s = threadIdx.x; s < segs; s += THREADS) acc = xyzz_add(acc, ld_struct(P + s));
+    B* sh = reinterpret_cast<B*>(lds_raw);
+    const B* P = partials + (size_t)blockIdx.x * segs;
+    B acc = bk_inf<B>();
+    for (uint32_t s = threadIdx.x; s < segs; s += THREADS) acc = bk_add(acc, ld_struct(P + s));
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int off = THREADS / 2; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off) { acc = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + off]); }
+        if ((int)threadIdx.x < off) { acc = bk_add(sh[threadIdx.x], sh[threadIdx.x + off]); }
         __syncthreads();
         if ((int)threadIdx.x < off) sh[threadIdx.x] = acc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) st_struct(window_sums + blockIdx.x, sh[0]);
+    if (threadIdx.x == 0) st_struct(window_sums + blockIdx.x, bk_to_xyzz<F>(sh[0]));
 }
 
 // arkworks in-memory affine (x, y, infinity flag at `inf_off`, arbitrary stride) or packed zkey points -> packed device layout
