@@ -25,7 +25,11 @@ template <class F> int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hi
 template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared);
 template <class F> int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c);
 constexpr int MSM_SHARED_GROUPS = 16;
-inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) { const size_t nbuckets = (size_t)nwin << (c - 1); return 2 * align_up((size_t)nwin * n * 4) + 3 * align_up(nbuckets * 4) + align_up(((nbuckets + 2047) / 2048) * 4); }
+inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) {   // must match fr_impl.hpp
+    const size_t nbuckets = (size_t)nwin << (c - 1);
+    const size_t entries = (size_t)nwin * n;
+    return 2 * align_up(entries * 4) + 3 * align_up(nbuckets * 4) + align_up(((nbuckets + 2047) / 2048) * 4) + align_up(entries * 8) + 2 * align_up(4096 * 4) + 256;
+}
 template <class F> int pack_bases_launch(hipStream_t st, const uint8_t* d_raw, size_t n, size_t stride, long inf_off, Affine<F>* d_dst);
 template <class F> int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi, int log_t, size_t n, Affine<F>* d_out);
 template <class Fr> int launch_vec_binary(hipStream_t st, int op, Fr* out, const Fr* a, const Fr* b, size_t n);

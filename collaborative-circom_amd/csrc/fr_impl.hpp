@@ -59,9 +59,16 @@ template <class Fr> int launch_bitrev_scale(hipStream_t st, NttVecs dst, NttVecs
 // scalar-dependent half of the MSM: digits, histogram, scan, scatter.  Scratch layout (must match msm_sort_scratch_bytes):
 // digits | sorted | counts | cursors | offsets.   evs (optional, 2 events) bracket the stage.
 struct MsmSortPtrs { const uint32_t* sorted; const uint32_t* offsets; const uint32_t* counts; uint32_t cap; const uint32_t* overflow; };   // cap = 0: dense list
+inline bool msm_sort_use_partition(size_t n, int c, int nwin, int shared) {
+    const size_t nbuckets = (size_t)(shared ? 1 : nwin) << (c - 1);
+    const size_t nregions = (nbuckets + ((size_t)1 << PART_REGION_LOG) - 1) >> PART_REGION_LOG;
+    return (size_t)nwin * n >= ((size_t)1 << 21) && nregions >= 8 && nregions <= PART_MAX_REGIONS;
+}
 inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) {   // sized for the per-window bucket sets (the shared-set mode needs less)
     const size_t nbuckets = (size_t)nwin << (c - 1);
-    return 2 * align_up((size_t)nwin * n * 4) + 3 * align_up(nbuckets * 4) + align_up(((nbuckets + SCAN_TILE - 1) / SCAN_TILE) * 4);
+    const size_t entries = (size_t)nwin * n, ntiles = (entries + PART_TILE - 1) / PART_TILE;
+    return 2 * align_up(entries * 4) + 3 * align_up(nbuckets * 4) + align_up(((nbuckets + SCAN_TILE - 1) / SCAN_TILE) * 4) +
+           align_up(entries * 8) + 2 * align_up(PART_MAX_REGIONS * 4) + 256;       // partition path: items + region totals/cursors + item count
 }
 template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, size_t n, int c, int nwin, int shared, char* scratch, MsmSortPtrs* out, hipEvent_t* evs) {
     const size_t nbuckets = (size_t)(shared ? 1 : nwin) << (c - 1);
@@ -76,6 +83,29 @@ template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, siz
     uint32_t* tile_sums = (uint32_t*)take(ntiles * 4);
     if (evs) HIPCHK(hipEventRecord(evs[0], st));
     HIPCHK(hipMemsetAsync(counts, 0, align_up(nbuckets * 4) * 2, st));   // counts + cursors are adjacent
+    if (msm_sort_use_partition(n, c, nwin, shared)) {
+        const size_t entries = (size_t)nwin * n, ptiles = (entries + PART_TILE - 1) / PART_TILE;
+        const uint32_t nregions = (uint32_t)((nbuckets + ((size_t)1 << PART_REGION_LOG) - 1) >> PART_REGION_LOG);
+        uint64_t* items = (uint64_t*)take(entries * 8);
+        uint32_t* region_total = (uint32_t*)take(PART_MAX_REGIONS * 4);
+        uint32_t* region_cursor = (uint32_t*)take(PART_MAX_REGIONS * 4);
+        uint32_t* total_items = (uint32_t*)take(4);
+        const unsigned itiles = (unsigned)((entries + ITEM_TILE - 1) / ITEM_TILE);
+        HIPCHK(hipMemsetAsync(region_total, 0, nregions * 4, st));
+        hipLaunchKernelGGL((k_msm_digits_only<Fr>), dim3(grid_for(n)), dim3(256), 0, st, d_scalars, n, c, nwin, digits);
+        hipLaunchKernelGGL(k_part_hist, dim3((unsigned)ptiles), dim3(256), nregions * 4, st, digits, n, c, nwin, shared, nregions, region_total);
+        hipLaunchKernelGGL(k_part_region_scan, dim3(1), dim3(1024), 0, st, region_total, nregions, region_cursor, total_items);
+        hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)ptiles), dim3(256), nregions * 4, st, digits, n, c, nwin, shared, nregions, region_cursor, items);
+        hipLaunchKernelGGL(k_items_hist, dim3(itiles), dim3(256), 0, st, items, total_items, counts);
+        hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)ntiles), dim3(256), 0, st, counts, tile_sums, nbuckets, 0xffffffffu);
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, tile_sums, tile_sums, ntiles);
+        hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(256), 0, st, counts, tile_sums, offsets, nbuckets, 0xffffffffu);
+        hipLaunchKernelGGL(k_items_scatter, dim3(itiles), dim3(256), 0, st, items, total_items, offsets, cursors, sorted);
+        if (evs) HIPCHK(hipEventRecord(evs[1], st));
+        HIPCHK(hipGetLastError());
+        out->sorted = sorted; out->offsets = offsets; out->counts = counts; out->cap = 0; out->overflow = nullptr;
+        return 0;
+    }
     hipLaunchKernelGGL((k_msm_digits<Fr>), dim3(grid_for(n)), dim3(256), 0, st, d_scalars, n, c, nwin, shared, digits, counts);
     hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)ntiles), dim3(256), 0, st, counts, tile_sums, nbuckets, 0xffffffffu);
     hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, tile_sums, tile_sums, ntiles);

@@ -96,6 +96,158 @@ static __global__ void __launch_bounds__(256) k_msm_scatter(const int32_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// MSD partition in front of the counting sort.  A direct counting sort of 54 M (window, scalar) entries into 524 k buckets
+// issues 54 M scattered 4-byte stores (and as many scattered atomics): ~5 ms per schedule, all of it DRAM sector traffic.
+// Partitioning the entries first by REGION (512 consecutive buckets = 2 KB of counters, ~53 k entries = a 212 KB slice of the
+// output) makes the subsequent histogram + scatter L2-local: counters and destination lines stay cache-resident while a region
+// is being processed, and DRAM sees whole lines.  The partition itself writes 8-byte items in runs of ~16 per (tile, region).
+//   k_part_hist     tile histogram of region ids                    (tile = PART_TILE consecutive (window, scalar) entries)
+//   k_part_colscan  per-region totals -> region bases; per-(tile, region) offsets
+//   k_part_scatter  items[(bucket << 32) | payload] grouped by region (rank inside the tile via LDS atomics)
+//   k_items_hist / k_items_scatter   the counting sort proper, reading the region-grouped items
+constexpr int PART_TILE = 16384;
+constexpr int PART_REGION_LOG = 9;      // 512 buckets per region
+constexpr int PART_MAX_REGIONS = 4096;  // LDS histogram limit
+
+__device__ __forceinline__ bool part_decode(int32_t dig, size_t w, uint32_t i, uint32_t nb, int shared, uint32_t* bucket, uint32_t* payload) {
+    if (dig == 0) return false;
+    *bucket = (uint32_t)((shared ? 0 : w * nb) + (uint32_t)(dig < 0 ? -dig : dig) - 1);
+    *payload = (shared ? ((uint32_t)w << 24) | i : i) | (dig < 0 ? 0x80000000u : 0u);
+    return true;
+}
+// digits only (no histogram): the partition passes read them
+template <class Fr>
+__global__ void __launch_bounds__(256) k_msm_digits_only(const Fr* __restrict__ scalars, size_t n, int c, int nwin, int32_t* __restrict__ digits) {
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t mask = (1u << c) - 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr s = ld_fp(scalars + i).from_mont();
+        uint32_t carry = 0;
+        for (int w = 0; w < nwin; w++) {
+            uint32_t d = (s.v[0] & mask) + carry;
+            _Pragma("unroll") for (int l = 0; l < Fr::N; l++) {
+                uint64_t two = ((uint64_t)(l + 1 < Fr::N ? s.v[l + 1] : 0u) << 32) | s.v[l];
+                s.v[l] = (uint32_t)(two >> c);
+            }
+            int32_t dig;
+            if (d > nb) { dig = (int32_t)d - (int32_t)(1u << c); carry = 1; } else { dig = (int32_t)d; carry = 0; }
+            digits[(size_t)w * n + i] = dig;
+        }
+    }
+}
+// per-region totals: tile-local LDS histogram, flushed with one global atomic per (tile, non-empty region)
+static __global__ void __launch_bounds__(256) k_part_hist(const int32_t* __restrict__ digits, size_t n, int c, int nwin, int shared, uint32_t nregions,
+                                                          uint32_t* __restrict__ region_total) {
+    extern __shared__ uint32_t lds_cnt[];
+    for (uint32_t r = threadIdx.x; r < nregions; r += 256) lds_cnt[r] = 0;
+    __syncthreads();
+    const uint32_t nb = 1u << (c - 1);
+    const size_t total = (size_t)nwin * n, base = (size_t)blockIdx.x * PART_TILE;
+    for (int k = 0; k < PART_TILE / 256; k++) {
+        const size_t idx = base + (size_t)k * 256 + threadIdx.x;
+        if (idx >= total) break;
+        const size_t w = idx / n; uint32_t bucket, payload;
+        if (part_decode(digits[idx], w, (uint32_t)(idx - w * n), nb, shared, &bucket, &payload)) atomicAdd(&lds_cnt[bucket >> PART_REGION_LOG], 1u);
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < nregions; r += 256) { const uint32_t v = lds_cnt[r]; if (v) atomicAdd(&region_total[r], v); }
+}
+// exclusive scan of the region totals (<= 4096) -> region_cursor (start of each region's item range); total -> *total_items
+static __global__ void __launch_bounds__(1024) k_part_region_scan(const uint32_t* __restrict__ region_total, uint32_t nregions, uint32_t* __restrict__ region_cursor,
+                                                                  uint32_t* __restrict__ total_items) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nregions + 1023) / 1024;
+    uint32_t v[4] = {0, 0, 0, 0}, mine = 0;
+    for (uint32_t k = 0; k < per; k++) { const uint32_t r = threadIdx.x * per + k; if (r < nregions) { v[k] = region_total[r]; mine += v[k]; } }
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t t = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    if (threadIdx.x == 1023) *total_items = part[1023];
+    for (uint32_t k = 0; k < per; k++) { const uint32_t r = threadIdx.x * per + k; if (r < nregions) { region_cursor[r] = run; run += v[k]; } }
+}
+// tile: count per region (LDS), reserve one contiguous run per region with a global atomic, then write the items into the runs
+static __global__ void __launch_bounds__(256) k_part_scatter(const int32_t* __restrict__ digits, size_t n, int c, int nwin, int shared, uint32_t nregions,
+                                                             uint32_t* __restrict__ region_cursor, uint64_t* __restrict__ items) {
+    extern __shared__ uint32_t lds_cnt[];
+    for (uint32_t r = threadIdx.x; r < nregions; r += 256) lds_cnt[r] = 0;
+    __syncthreads();
+    const uint32_t nb = 1u << (c - 1);
+    const size_t total = (size_t)nwin * n, base = (size_t)blockIdx.x * PART_TILE;
+    for (int k = 0; k < PART_TILE / 256; k++) {
+        const size_t idx = base + (size_t)k * 256 + threadIdx.x;
+        if (idx >= total) break;
+        const size_t w = idx / n; uint32_t bucket, payload;
+        if (part_decode(digits[idx], w, (uint32_t)(idx - w * n), nb, shared, &bucket, &payload)) atomicAdd(&lds_cnt[bucket >> PART_REGION_LOG], 1u);
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < nregions; r += 256) { const uint32_t v = lds_cnt[r]; lds_cnt[r] = v ? atomicAdd(&region_cursor[r], v) : 0u; }
+    __syncthreads();
+    for (int k = 0; k < PART_TILE / 256; k++) {
+        const size_t idx = base + (size_t)k * 256 + threadIdx.x;
+        if (idx >= total) break;
+        const size_t w = idx / n; uint32_t bucket, payload;
+        if (part_decode(digits[idx], w, (uint32_t)(idx - w * n), nb, shared, &bucket, &payload)) {
+            const uint32_t pos = atomicAdd(&lds_cnt[bucket >> PART_REGION_LOG], 1u);
+            items[pos] = ((uint64_t)bucket << 32) | payload;
+        }
+    }
+}
+// Counting sort proper on region-grouped items.  A workgroup takes ITEM_TILE consecutive items; they belong to a few
+// neighbouring regions, so their buckets fall into a window of ITEM_WINDOW consecutive bucket ids that is histogrammed in LDS
+// and flushed / reserved with one global atomic per non-empty bucket (items outside the window take the direct global path).
+constexpr int ITEM_TILE = 16384;
+constexpr uint32_t ITEM_WINDOW = 2048;
+static __global__ void __launch_bounds__(256) k_items_hist(const uint64_t* __restrict__ items, const uint32_t* __restrict__ total_items, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t cnt[ITEM_WINDOW];
+    const size_t total = *total_items, base = (size_t)blockIdx.x * ITEM_TILE;
+    if (base >= total) return;
+    for (uint32_t r = threadIdx.x; r < ITEM_WINDOW; r += 256) cnt[r] = 0;
+    const uint32_t b0 = (uint32_t)(items[base] >> 32) & ~((1u << PART_REGION_LOG) - 1);
+    __syncthreads();
+    for (int k = 0; k < ITEM_TILE / 256; k++) {
+        const size_t e = base + (size_t)k * 256 + threadIdx.x;
+        if (e >= total) break;
+        const uint32_t bucket = (uint32_t)(items[e] >> 32), d = bucket - b0;
+        if (d < ITEM_WINDOW) atomicAdd(&cnt[d], 1u); else atomicAdd(&counts[bucket], 1u);
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < ITEM_WINDOW; r += 256) { const uint32_t v = cnt[r]; if (v) atomicAdd(&counts[b0 + r], v); }
+}
+static __global__ void __launch_bounds__(256) k_items_scatter(const uint64_t* __restrict__ items, const uint32_t* __restrict__ total_items, const uint32_t* __restrict__ offsets,
+                                                              uint32_t* __restrict__ cursors, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t cnt[ITEM_WINDOW];
+    const size_t total = *total_items, base = (size_t)blockIdx.x * ITEM_TILE;
+    if (base >= total) return;
+    for (uint32_t r = threadIdx.x; r < ITEM_WINDOW; r += 256) cnt[r] = 0;
+    const uint32_t b0 = (uint32_t)(items[base] >> 32) & ~((1u << PART_REGION_LOG) - 1);
+    __syncthreads();
+    for (int k = 0; k < ITEM_TILE / 256; k++) {
+        const size_t e = base + (size_t)k * 256 + threadIdx.x;
+        if (e >= total) break;
+        const uint32_t d = (uint32_t)(items[e] >> 32) - b0;
+        if (d < ITEM_WINDOW) atomicAdd(&cnt[d], 1u);
+    }
+    __syncthreads();
+    // reserve this tile's slots in every bucket of the window: cnt[r] becomes the first destination index
+    for (uint32_t r = threadIdx.x; r < ITEM_WINDOW; r += 256) { const uint32_t v = cnt[r]; cnt[r] = v ? offsets[b0 + r] + atomicAdd(&cursors[b0 + r], v) : 0u; }
+    __syncthreads();
+    for (int k = 0; k < ITEM_TILE / 256; k++) {
+        const size_t e = base + (size_t)k * 256 + threadIdx.x;
+        if (e >= total) break;
+        const uint64_t it = items[e];
+        const uint32_t bucket = (uint32_t)(it >> 32), d = bucket - b0;
+        const uint32_t pos = d < ITEM_WINDOW ? atomicAdd(&cnt[d], 1u) : offsets[bucket] + atomicAdd(&cursors[bucket], 1u);
+        sorted[pos] = (uint32_t)it;
+    }
+}
+
 // Optimistic one-pass scatter: every bucket owns `cap` slots, so no histogram pass is needed — one atomic per (scalar, window)
 // instead of two, no digit array.  counts[] ends up holding the true per-bucket counts; if any exceeds cap the entry is dropped
 // and *overflow is set: the host then recomputes that MSM with the exact two-pass schedule (cg_msm_end), so results never
