@@ -176,7 +176,25 @@ struct L29 {
         }
         return any;
     }
-    __device__ __forceinline__ static L29 sqr(const L29& a) { return mul(a, a); }
+    // squaring: the 36 off-diagonal products are taken once, doubled (45 instead of 81 multiplies before the reduction).
+    // Column i is complete before round i uses it: a pair (x, y), x <= y, x + y = i is added in round x <= i/2.
+    __device__ __forceinline__ static L29 sqr(const L29& a) {
+        int64_t T[18];
+        _Pragma("unroll") for (int k = 0; k < 18; k++) T[k] = 0;
+        int32_t a2[9];
+        _Pragma("unroll") for (int k = 0; k < 9; k++) a2[k] = a.l[k] * 2;
+        _Pragma("unroll") for (int i = 0; i < 9; i++) {
+            T[2 * i] += (int64_t)a.l[i] * a.l[i];
+            _Pragma("unroll") for (int j = i + 1; j < 9; j++) T[i + j] += (int64_t)a2[i] * a.l[j];
+            const int32_t m = (int32_t)(((uint32_t)T[i] * (P::INV & MASK)) & MASK);
+            _Pragma("unroll") for (int j = 0; j < 9; j++) T[i + j] += (int64_t)m * pl(j);
+            T[i + 1] += T[i] >> 29;
+        }
+        L29 r;
+        _Pragma("unroll") for (int k = 0; k < 8; k++) { r.l[k] = (int32_t)((uint32_t)T[9 + k] & MASK); T[10 + k] += T[9 + k] >> 29; }
+        r.l[8] = (int32_t)T[17];
+        return r;
+    }
     __device__ __forceinline__ static XYZZ<F> dbl_affine(const F& x, const F& y) { return xyzz_dbl_affine(x, y); }
     // small representative (0.5p .. 1.6p) of 1 in the 2^261 domain: (32 R1) * (32 R1) / 2^261 = 2^261 (mod p), R1 = 2^256 mod p
     __device__ __forceinline__ static L29 one() { const L29 o = unpack<5>(F::one()); return mul(o, o); }
