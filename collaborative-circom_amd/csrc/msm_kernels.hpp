@@ -176,6 +176,22 @@ struct L29 {
         }
         return any;
     }
+    // (a*b - c*d + M p) / 2^261 with ONE reduction: 18 signed products + 9 reduction products per column (< 27 * 2^58 < 2^63)
+    __device__ __forceinline__ static L29 mul_sub(const L29& a, const L29& b, const L29& c, const L29& d) {
+        int64_t T[18];
+        _Pragma("unroll") for (int k = 0; k < 18; k++) T[k] = 0;
+        _Pragma("unroll") for (int i = 0; i < 9; i++) {
+            _Pragma("unroll") for (int j = 0; j < 9; j++) T[i + j] += (int64_t)a.l[i] * b.l[j];
+            _Pragma("unroll") for (int j = 0; j < 9; j++) T[i + j] += (int64_t)(-c.l[i]) * d.l[j];
+            const int32_t m = (int32_t)(((uint32_t)T[i] * (P::INV & MASK)) & MASK);
+            _Pragma("unroll") for (int j = 0; j < 9; j++) T[i + j] += (int64_t)m * pl(j);
+            T[i + 1] += T[i] >> 29;
+        }
+        L29 r;
+        _Pragma("unroll") for (int k = 0; k < 8; k++) { r.l[k] = (int32_t)((uint32_t)T[9 + k] & MASK); T[10 + k] += T[9 + k] >> 29; }
+        r.l[8] = (int32_t)T[17];
+        return r;
+    }
     // squaring: the 36 off-diagonal products are taken once, doubled (45 instead of 81 multiplies before the reduction).
     // Column i is complete before round i uses it: a pair (x, y), x <= y, x + y = i is added in round x <= i/2.
     __device__ __forceinline__ static L29 sqr(const L29& a) {
@@ -261,6 +277,8 @@ struct L29x2 {
         L s = (a.c0 + a.c1).norm(), d = (a.c0 - a.c1).norm();     // limb magnitude back to 2^29 before multiplying
         return {L::mul(s, d), L::mul(a.c0.dbl(), a.c1)};
     }
+    // a*b - c*d: kept as two products here (four signed products per column would not fit 63 bits)
+    __device__ __forceinline__ static L29x2 mul_sub(const L29x2& a, const L29x2& b, const L29x2& c, const L29x2& d) { return (mul(a, b) - mul(c, d)).norm(); }
     __device__ __forceinline__ static bool is_zero_mod_p(const L29x2& x) { return L::is_zero_mod_p(x.c0) && L::is_zero_mod_p(x.c1); }
     __device__ __forceinline__ static L29x2 one() { L z; _Pragma("unroll") for (int k = 0; k < 9; k++) z.l[k] = 0; return {L::one(), z}; }
     __device__ __forceinline__ static F2 to_fp(const L29x2& x) { return {L::to_fp(x.c0), L::to_fp(x.c1)}; }
@@ -334,7 +352,7 @@ __device__ __attribute__((noinline)) XYZZL<F> bk_dbl(const XYZZL<F>& a) {
     L X3 = (L::sqr(M) - S.dbl()).norm();
     XYZZL<F> r;
     r.c[0] = X3;
-    r.c[1] = (L::mul(M, S - X3) - L::mul(W, a.c[1])).norm();
+    r.c[1] = L::mul_sub(M, S - X3, W, a.c[1]);
     r.c[2] = L::mul(V, a.c[2]);
     r.c[3] = L::mul(W, a.c[3]);
     return r;
@@ -354,7 +372,7 @@ __device__ __attribute__((noinline)) XYZZL<F> bk_add(const XYZZL<F>& a, const XY
     L X3 = (L::sqr(R) - PPP - Q.dbl()).norm();
     XYZZL<F> r;
     r.c[0] = X3;
-    r.c[1] = (L::mul(R, Q - X3) - L::mul(S1, PPP)).norm();
+    r.c[1] = L::mul_sub(R, Q - X3, S1, PPP);
     r.c[2] = L::mul(L::mul(a.c[2], b.c[2]), PP);
     r.c[3] = L::mul(L::mul(a.c[3], b.c[3]), PPP);
     return r;
@@ -400,7 +418,7 @@ __device__ __forceinline__ void acc_madd_lazy(Acc& acc, const F& x2f, const F& y
     acc.set(2, L::mul(acc.get(2), PP));
     acc.set(3, L::mul(acc.get(3), PPP));
     L X3 = (L::sqr(R) - PPP - Q.dbl()).norm();
-    acc.set(1, (L::mul(R, Q - X3) - L::mul(acc.get(1), PPP)).norm());
+    acc.set(1, L::mul_sub(R, Q - X3, acc.get(1), PPP));        // one reduction for R*(Q - X3) - Y*PPP (result is normalised)
     acc.set(0, X3);
 }
 template <class F, class Acc>
