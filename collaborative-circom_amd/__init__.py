@@ -38,7 +38,7 @@ def build(bls=True, jobs=8):
 ABI_SYMBOLS = [
     "cg_ctx_create", "cg_ctx_destroy", "cg_ctx_sync", "cg_ctx_stream", "cg_ctx_set_stream", "cg_last_error", "cg_version",
     "cg_dev_alloc", "cg_dev_free", "cg_dev_upload", "cg_dev_download", "cg_dev_memset_zero",
-    "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute",
+    "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute", "cg_bases_check_on_curve",
     "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_scatter_capacity",
     "cg_ntt", "cg_ntt_dev",
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev",
@@ -203,6 +203,12 @@ class Context:
         h = C.c_void_p()
         _chk(load().cg_bases_register_device(self.h, curve, group, _dp(d_points), C.c_size_t(n), C.byref(h)))
         return Bases(self, curve, group, h, n)
+
+    def check_on_curve(self, bases):
+        """(number of non-infinity points off the curve, index of the first one or None) — device-side zkey validation"""
+        nb, fb = C.c_uint64(0), C.c_uint64(0)
+        _chk(load().cg_bases_check_on_curve(self.h, bases.h, C.byref(nb), C.byref(fb)))
+        return nb.value, (None if fb.value == 2**64 - 1 else fb.value)
 
     def precompute_bases(self, bases, c=20):
         """per-window precomputed tables (one-time, (254/c + 1) x memory): fewer mixed additions per point afterwards"""

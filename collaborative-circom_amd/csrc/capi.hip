@@ -24,6 +24,7 @@ template <class F> int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hi
                                              size_t table_stride, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs);
 template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared);
 template <class F> int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c);
+template <class F> int check_on_curve_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, const F& b, unsigned long long* d_counters);
 constexpr int MSM_SHARED_GROUPS = 16;
 inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) {   // must match fr_impl.hpp
     const size_t nbuckets = (size_t)nwin << (c - 1);
@@ -458,6 +459,17 @@ int32_t vec_binary(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_a, con
     });
 }
 
+// curve coefficient b of y^2 = x^3 + b for the group's coordinate field, Montgomery form
+template <class F> struct CurveB;
+template <> struct CurveB<Bn254Fq> { static Bn254Fq get() { Bn254Fq t = Bn254Fq::one(); return t + t + t; } };
+template <> struct CurveB<Fp2<Bn254Fq>> { static Fp2<Bn254Fq> get() {   // 3 / (9 + u)
+    Bn254Fq one = Bn254Fq::one(), three = one + one + one, nine = three + three + three;
+    Fp2<Bn254Fq> xi = {nine, one}; Fp2<Bn254Fq> inv = fp_inverse(xi); return {inv.c0 * three, inv.c1 * three}; } };
+#if CG_WITH_BLS
+template <> struct CurveB<Bls381Fq> { static Bls381Fq get() { Bls381Fq t = Bls381Fq::one(); t = t + t; return t + t; } };
+template <> struct CurveB<Fp2<Bls381Fq>> { static Fp2<Bls381Fq> get() { Bls381Fq f = CurveB<Bls381Fq>::get(); return {f, f}; } };
+#endif
+
 // ==================================================================================================== extern "C"
 extern "C" {
 
@@ -583,6 +595,24 @@ int32_t cg_bases_release(cg_bases* b) {
     if (b->d_pre) hipFree(b->d_pre);
     delete b;
     return 0;
+}
+int32_t cg_bases_check_on_curve(cg_ctx* ctx, const cg_bases* b, uint64_t* n_bad, uint64_t* first_bad) {
+    if (!ctx || !b || !n_bad) return fail(CG_ERR_ARG, "null argument");
+    if (b->device != ctx->device) return fail(CG_ERR_ARG, "bases live on another device");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_group(b->curve, b->group, [&](auto ftag, auto) -> int {
+        typedef decltype(ftag) F;
+        unsigned long long* d = nullptr; unsigned long long h[2] = {0ull, ~0ull};
+        HIPCHK(hipMalloc((void**)&d, 16));
+        HIPCHK(hipMemcpyAsync(d, h, 16, hipMemcpyHostToDevice, ctx->stream));
+        int rc = check_on_curve_launch<F>(ctx->stream, (const Affine<F>*)b->d_pts, b->n, CurveB<F>::get(), d);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(d));
+        *n_bad = h[0]; if (first_bad) *first_bad = h[1];
+        return 0;
+    });
 }
 int32_t cg_bases_precompute(cg_ctx* ctx, cg_bases* b, int32_t c) {
     if (!ctx || !b) return fail(CG_ERR_ARG, "null argument");

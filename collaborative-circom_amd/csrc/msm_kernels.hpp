@@ -585,6 +585,19 @@ __global__ void __launch_bounds__(256) k_pack_bases(const uint8_t* __restrict__ 
 }
 
 
+// zkey fast path: the reference's parser checks every point on the CPU (`circom-types/src/traits.rs:118-123,
+// 148-153`: is_on_curve, then the subgroup check).  On-curve: y^2 == x^3 + b for every non-infinity record, counted on the
+// device.  b is passed in Montgomery form (BN254 G1: 3, G2: 3/(9+u); BLS12-381 G1: 4, G2: 4(1+u)).
+template <class F>
+__global__ void __launch_bounds__(256) k_check_on_curve(const Affine<F>* __restrict__ pts, size_t n, F b, unsigned long long* __restrict__ n_bad, unsigned long long* __restrict__ first_bad) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Affine<F> p = ld_struct(pts + i);
+        if (p.is_inf()) continue;
+        F lhs = p.y.sqr(), rhs = p.x.sqr() * p.x + b;
+        if (lhs != rhs) { atomicAdd(n_bad, 1ull); atomicMin(first_bad, (unsigned long long)i); }
+    }
+}
+
 // Per-window precomputed tables: dst[i] = 2^c * src[i] in affine form (one inversion per point; run once per zkey table).
 template <class F>
 __global__ void __launch_bounds__(256) k_precompute_window(const Affine<F>* __restrict__ src, Affine<F>* __restrict__ dst, size_t n, int c) {

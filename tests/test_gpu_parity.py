@@ -398,3 +398,24 @@ def test_msm_optimistic_scatter_and_fallback(ctx, cap):
     finally:
         ctx.set_scatter_capacity(-1)
     b1.release(); b2.release()
+
+
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_bases_on_curve_check(ctx, curve_name):
+    """device-side point validation (the zkey parser's is_on_curve, circom-types/src/traits.rs:118-123,148-153)"""
+    curve = {"bn254": BN254, "bls12_381": BLS12_381}[curve_name]
+    z = orc.ZKey(curve, os.path.join(GOLDEN, "groth16", curve_name, "poseidon", "circuit.zkey"))
+    for q, group in (("a_query", G1), ("h_query", G1), ("b_g2_query", G2)):
+        pts = z.points(q)                                    # real zkey tables (contain infinity records): all valid
+        bases = ctx.register_bases(curve, group, pts)
+        assert ctx.check_on_curve(bases) == (0, None)
+        bases.release()
+        bad = pts.copy()
+        k = 7 if q != "b_g2_query" else 100
+        while not bad[k].any(): k += 1
+        bad[k][0] ^= np.uint64(1)                            # flip one bit of an x coordinate
+        bases = ctx.register_bases(curve, group, bad)
+        nbad, first = ctx.check_on_curve(bases)
+        assert (nbad, first) == (1, k)
+        assert orc.on_curve(curve, group, pts[k]) and not orc.on_curve(curve, group, bad[k])
+        bases.release()
