@@ -163,6 +163,28 @@ def step(w):
     """one pass of the hot path; returns the 10 (partial) MSM results of this rank"""
     ctx, m, nc = w.ctx, w.m, w.nc
     C = CURVE
+    # MSM work units of this rank (groth16.rs:248-304).  Units that multiply the same scalar slice share one digit/sort schedule
+    # (l, a, b1, b2 all take the aux-witness shares).
+    groups = {}
+    for key in w.mine:
+        t, i, parts = key
+        bases, lo, hi = w.tables[key]
+        groups.setdefault(("h" if t == "h" else "aux", lo, hi), []).append((key, bases))
+    pending = []
+
+    def begin(on, kinds):
+        for (kind, lo, hi), members in groups.items():
+            if kind not in kinds:
+                continue
+            members.sort(key=lambda kb: -TABLE_GROUP[kb[0][0]])
+            sc = [w.ha[lo:hi], w.hb[lo:hi]] if kind == "h" else [w.wa[lo:hi], w.wb[lo:hi]]
+            tk = on.msm_dev_begin_multi([b for _, b in members], sc, hi - lo)
+            pending.extend((on, key, t) for (key, _), t in zip(members, tk))
+
+    # The aux-witness MSMs do not depend on the witness map: they are enqueued first, on a second context (own streams), so that
+    # the HBM/LDS-bound witness map runs underneath their integer-VALU-bound bucket accumulation.
+    if w.ctx_aux is not None:
+        begin(w.ctx_aux, ("aux",))
     # constraint evaluation (groth16.rs:159-171), party 0
     ctx.spmv_csr(C, w.rpA, w.colA, w.coA, nc, w.pub, w.n_inputs, 0, w.wa, w.wb, w.aa, w.ab)
     ctx.spmv_csr(C, w.rpB, w.colB, w.coB, nc, w.pub, w.n_inputs, 0, w.wa, w.wb, w.ba, w.bb)
@@ -179,20 +201,8 @@ def step(w):
     ctx.ntt_dev(C, [w.ca, w.cb], m, w.omega)
     ctx.vec_sub(C, w.ha, w.ha, w.ca, m)
     ctx.vec_sub(C, w.hb, w.hb, w.cb, m)
-    # MSMs (groth16.rs:248-304) over the units this rank owns.  Units that multiply the same scalar slice share one digit/sort
-    # schedule (l, a, b1, b2 all take the aux-witness shares); G2 goes first so its long bucket reduction overlaps later work.
-    groups = {}
-    for key in w.mine:
-        t, i, parts = key
-        bases, lo, hi = w.tables[key]
-        groups.setdefault(("h" if t == "h" else "aux", lo, hi), []).append((key, bases))
-    pending = []
-    for (kind, lo, hi), members in groups.items():
-        members.sort(key=lambda kb: -TABLE_GROUP[kb[0][0]])
-        sc = [w.ha[lo:hi], w.hb[lo:hi]] if kind == "h" else [w.wa[lo:hi], w.wb[lo:hi]]
-        tk = ctx.msm_dev_begin_multi([b for _, b in members], sc, hi - lo)
-        pending += [(key, t) for (key, _), t in zip(members, tk)]
-    return {key: ctx.msm_end(t) for key, t in pending}
+    begin(ctx, ("h",) if w.ctx_aux is not None else ("h", "aux"))
+    return {key: on.msm_end(t) for on, key, t in pending}
 
 
 def unit_layout(plan):
@@ -258,6 +268,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scatter-cap", type=int, default=-1, help="-1 = exact two-pass sort (default), 0 = optimistic one-pass scatter (auto capacity)")
     ap.add_argument("--g2-last", action="store_true", help="experiment: put the G2 table last in the multi-table MSM")
+    ap.add_argument("--one-context", action="store_true", help="run the aux-witness MSMs after the witness map on the same context (no overlap)")
     ap.add_argument("--precompute", type=int, default=20, help="window size of the per-window precomputed base tables (0 = off)")
     args = ap.parse_args()
 
@@ -282,16 +293,24 @@ def main():
     ctx.set_scatter_capacity(args.scatter_cap)
     w = Workload(ctx, args.log_m, device, rank, world, precompute=args.precompute)
     w.g2_last = args.g2_last
+    w.ctx_aux = None
+    if not args.one_context:
+        w.ctx_aux = cg.Context(local_rank)
+        w.ctx_aux.set_scatter_capacity(args.scatter_cap)
     torch.cuda.synchronize()
 
     def barrier():
         torch.cuda.synchronize(); ctx.sync()
+        if w.ctx_aux is not None:
+            w.ctx_aux.sync()
         if dist is not None:
             dist.barrier()
 
     for _ in range(args.warmup):
         res = exchange(step(w), w.plan, rank, dist, world, device)
     ctx.stats_enable(True); ctx.stats(reset=True)
+    if w.ctx_aux is not None:
+        w.ctx_aux.stats_enable(True); w.ctx_aux.stats(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -304,6 +323,10 @@ def main():
         elapsed = float(tt.item())
     st = ctx.stats(reset=True)
     ctx.stats_enable(False)
+    if w.ctx_aux is not None:
+        st2 = w.ctx_aux.stats(reset=True)
+        w.ctx_aux.stats_enable(False)
+        st = {k: st[k] + st2[k] for k in st}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

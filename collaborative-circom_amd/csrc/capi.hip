@@ -80,6 +80,10 @@ struct cg_ctx {
     hipEvent_t ev_acc[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};
     bool slot_busy[2] = {false, false};
     bool aux_pending = false; int last_slot = 0;
+    // third stream for the scalar-side sort (HBM/latency bound): the schedule of component j+1 is built while component j is
+    // accumulated (integer-VALU bound) on the main stream; two rotating schedule slots
+    hipStream_t sortst = nullptr;
+    hipEvent_t ev_in = nullptr, ev_sorted[2] = {nullptr, nullptr}, ev_sched_free[2] = {nullptr, nullptr};
     Arena arena;
     std::map<TwKey, void*> twiddles;
     std::map<CosetKey, CosetTables> cosets;
@@ -110,6 +114,7 @@ int ensure_arena(cg_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->arena.cap) return 0;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->aux) HIPCHK(hipStreamSynchronize(ctx->aux));
+    if (ctx->sortst) HIPCHK(hipStreamSynchronize(ctx->sortst));
     if (ctx->arena.base) HIPCHK(hipFree(ctx->arena.base));
     ctx->arena.base = nullptr; ctx->arena.cap = 0;
     size_t want = align_up(bytes + bytes / 8, 1 << 20);
@@ -258,22 +263,35 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
         StatScope ss(ctx, TAG_MSM);
         const size_t sort_bytes = align_up(cap ? msm_sort_direct_scratch_bytes(n, c, nwin, shared ? 1 : 0, cap) : msm_sort_scratch_bytes(n, c, nwin));
         const size_t acc_slot = align_up(acc_bytes);
-        { int rc = ensure_arena(ctx, sort_bytes + 2 * acc_slot); if (rc) return rc; }
-        char* sort_scratch = ctx->arena.base; char* acc_scratch = ctx->arena.base + sort_bytes;
+        const int nsched = k > 1 ? 2 : 1;                  // two schedule slots so that sort j+1 overlaps accumulate j
+        { int rc = ensure_arena(ctx, nsched * sort_bytes + 2 * acc_slot); if (rc) return rc; }
+        char* acc_scratch = ctx->arena.base + nsched * sort_bytes;
+        HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));   // scalars (and the arena) are ready once the main stream gets here
+        HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_in, 0));
+        std::vector<MsmSortPtrs> sps(k);
+        auto launch_sort = [&](int j) -> int {             // scalar side: once per scalar vector, on the sort stream
+            const int ss_ = j % nsched;
+            if (j >= nsched) HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_sched_free[ss_], 0));   // accumulates of component j-2 have consumed the slot
+            hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
+            if (ctx->stats_on) { const int i0 = ev_open(ctx, TAG_SORT); evs[0] = ctx->ev_live[i0].a; evs[1] = ctx->ev_live[i0].b; pev = evs; }
+            char* sort_scratch = ctx->arena.base + (size_t)ss_ * sort_bytes;
+            int rc = with_fr(curve, [&](auto tag) -> int {
+                typedef decltype(tag) Fr;
+                return cap ? msm_sort_direct_launch<Fr>(ctx->sortst, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, cap, sort_scratch, &sps[j], pev)
+                           : msm_sort_launch<Fr>(ctx->sortst, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, sort_scratch, &sps[j], pev);
+            });
+            if (rc) return rc;
+            if (cap) for (int b = 0; b < nb; b++) HIPCHK(hipMemcpyAsync(ctx->tickets[slots[b]].h_flags + j, sps[j].overflow, 4, hipMemcpyDeviceToHost, ctx->sortst));
+            HIPCHK(hipEventRecord(ctx->ev_sorted[ss_], ctx->sortst));
+            return 0;
+        };
         int iter = 0;
+        { int rc = launch_sort(0); if (rc) return rc; }
         for (int j = 0; j < k; j++) {
-            MsmSortPtrs sp{};
-            {   // scalar side: once per scalar vector
-                hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
-                if (ctx->stats_on) { const int i0 = ev_open(ctx, TAG_SORT); evs[0] = ctx->ev_live[i0].a; evs[1] = ctx->ev_live[i0].b; pev = evs; }
-                int rc = with_fr(curve, [&](auto tag) -> int {
-                    typedef decltype(tag) Fr;
-                    return cap ? msm_sort_direct_launch<Fr>(ctx->stream, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, cap, sort_scratch, &sp, pev)
-                               : msm_sort_launch<Fr>(ctx->stream, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, sort_scratch, &sp, pev);
-                });
-                if (rc) return rc;
-                if (cap) for (int b = 0; b < nb; b++) HIPCHK(hipMemcpyAsync(ctx->tickets[slots[b]].h_flags + j, sp.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
-            }
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[j % nsched], 0));
+            // the next component's schedule is enqueued BEFORE this component's accumulates so that the two streams run side by side
+            if (j + 1 < k && nsched == 2 && j + 1 < nsched) { int rc = launch_sort(j + 1); if (rc) return rc; }
+            const MsmSortPtrs& sp = sps[j];
             for (int b = 0; b < nb; b++) {   // group side: once per table, reusing the schedule
                 MsmTicket& t = ctx->tickets[slots[b]];
                 hipEvent_t evs[4]; hipEvent_t* pev = nullptr;
@@ -293,6 +311,8 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
                 ctx->slot_busy[slot] = true; ctx->aux_pending = true; ctx->last_slot = slot;
                 if (j == k - 1) HIPCHK(hipEventRecord(t.done, ctx->aux));   // this table's last component: its results are complete on the aux stream
             }
+            HIPCHK(hipEventRecord(ctx->ev_sched_free[j % nsched], ctx->stream));
+            if (j + 2 < k && nsched == 2) { int rc = launch_sort(j + 2); if (rc) return rc; }   // needs the slot this component just released
         }
     }
     for (int b = 0; b < nb; b++) { if (n == 0) HIPCHK(hipEventRecord(ctx->tickets[slots[b]].done, ctx->stream)); tickets_out[b] = slots[b]; }
@@ -486,7 +506,14 @@ int32_t cg_ctx_create(int32_t device, cg_ctx** out) {
     cg_ctx* c = new cg_ctx();
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    // the side streams carry short, latency-bound kernels the main stream's next accumulate waits for: let their workgroups
+    // jump the backlog of accumulate workgroups
+    int prio_lo = 0, prio_hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->sortst, hipStreamNonBlocking, prio_hi));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_sched_free[i], hipEventDisableTiming)); }
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming)); }
     *out = c;
     return 0;
@@ -496,8 +523,11 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->aux);
-    for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_acc[i]); hipEventDestroy(ctx->ev_red[i]); }
+    hipStreamSynchronize(ctx->sortst);
+    for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_acc[i]); hipEventDestroy(ctx->ev_red[i]); hipEventDestroy(ctx->ev_sorted[i]); hipEventDestroy(ctx->ev_sched_free[i]); }
+    hipEventDestroy(ctx->ev_in);
     hipStreamDestroy(ctx->aux);
+    hipStreamDestroy(ctx->sortst);
     for (auto& kv : ctx->twiddles) hipFree(kv.second);
     for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
     for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.h_flags) hipHostFree(t.h_flags); if (t.done) hipEventDestroy(t.done); }
@@ -508,10 +538,15 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     delete ctx;
     return 0;
 }
-int32_t cg_ctx_sync(cg_ctx* ctx) { if (!ctx) return fail(CG_ERR_ARG, "null ctx"); HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->aux)); return 0; }
+int32_t cg_ctx_sync(cg_ctx* ctx) {
+    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
+    HIPCHK(hipStreamSynchronize(ctx->sortst)); HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->aux));
+    return 0;
+}
 void* cg_ctx_stream(cg_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int32_t cg_ctx_set_stream(cg_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(CG_ERR_ARG, "null ctx");
+    HIPCHK(hipStreamSynchronize(ctx->sortst));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->aux));
     if (ctx->owns_stream) HIPCHK(hipStreamDestroy(ctx->stream));
@@ -901,6 +936,7 @@ int32_t cg_point_generator(int32_t curve, int32_t group, void* h_out) {
 int32_t cg_stats_enable(cg_ctx* ctx, int32_t on) { if (!ctx) return fail(CG_ERR_ARG, "null ctx"); ctx->stats_on = on != 0; return 0; }
 int32_t cg_stats(cg_ctx* ctx, cg_stage_times* out, int32_t reset) {
     if (!ctx || !out) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipStreamSynchronize(ctx->sortst));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->aux));
     double* ms[TAG_COUNT] = {&ctx->stats.msm_ms, &ctx->stats.ntt_ms, &ctx->stats.vec_ms, &ctx->stats.spmv_ms,
