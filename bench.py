@@ -12,8 +12,11 @@ side.  Shares / masks are uniformly random full-width scalars, 
 N > 1 (one process per GPU, torch.distributed / RCCL): STRONG scaling of the same proof — the ten MSMs are cut into work units
 (whole zkey tables, range-split only as far as balance needs it: full-size launches are the efficient ones) that plan_units()
 assigns to ranks; every rank holds only its own table slices, and one all_gather of the unit results (a few KB) + host EC
-additions fold the slices (RCCL has no EC-add reduction).  The witness map (NTT stage, ~10 % of the step) is replicated on
-every rank in round 1.
+additions fold the slices (RCCL has no EC-add reduction).  The witness map (NTT stage) runs only where its result is needed:
+for N < 4 on the rank that owns the h table; for N >= 4 the six vector pipelines (iNTT, coset shift, NTT of a.a, a.b, b.a, b.b,
+c.a, c.b) are spread over the ranks, the h table is range-split over ALL ranks and one all_to_all hands every rank the slices
+of the six vectors over its own h range (6 * m/N elements; xGMI is point-to-point, so an evenly split all_to_all uses every
+link once), where h = a*b - c and the h-slice MSM are computed.
 
 Prints ONE JSON line (rank 0).  `roofline` = dominant kernel (G1 bucket accumulation) against the HBM peak, measured live
 with HIP events on the kernels' own stream; `cpu_baseline` = the oracle's C++ restatement of the same workload on the host.
@@ -90,6 +93,15 @@ class Workload:
             lo, hi = shard_range(n_tab, i, parts)
             self.tables[(t, i, parts)] = (ctx.synth_bases(CURVE, TABLE_GROUP[t], TABLE_FIRST[t] + lo, hi - lo), lo, hi)
         self.setup_bases_s = time.time() - t0
+        # witness-map roles
+        self.h_units = [(i, parts, owner) + shard_range(m, i, parts) for (t, i, parts, owner) in self.plan if t == "h"]
+        self.owns_h = any(owner == rank for (_, _, owner, _, _) in self.h_units)
+        self.distributed = wm_distributed(world)
+        self.my_vecs = [v for v in range(WM_VECTORS) if wm_vector_owner(v, world) == rank] if self.distributed else []
+        if self.distributed:
+            (self.h_lo, self.h_hi), = [(lo, hi) for (_, _, owner, lo, hi) in self.h_units if owner == rank]
+            hn = self.h_hi - self.h_lo
+            self.hs_a, self.hs_b = (torch.zeros((hn, 4), dtype=torch.int64, device=device) for _ in range(2))
         # zkey registration-time work (untimed, like zkey parsing): per-window precomputed tables, resident across proofs
         t0 = time.time()
         self.precompute = precompute
@@ -107,6 +119,18 @@ TABLE_GROUP = {"h": 0, "l": 0, "a": 0, "b1": 0, "b2": 1}
 TABLE_FIRST = {"h": 1, "l": 3, "a": 5, "b1": 7, "b2": 1}     # synthetic tables: [(first + i) * G]
 G2_COST = 2.3                                    # measured: a G2 accumulate launch costs 2.3 G1 launches
 SORT_COST = 0.45                                 # digit/sort schedule per (scalar set, range), shared by the tables that use it
+WM_COST = 1.0                                    # witness map on the rank that owns h (N < 4), after overlap with its aux MSMs
+WM_DISTRIBUTE_MIN_WORLD = 4                      # from this many ranks on: vector pipelines spread over ranks + all_to_all
+WM_VECTORS = 6                                   # a.a, a.b, b.a, b.b, c.a, c.b
+
+
+def wm_distributed(world):
+    return world >= WM_DISTRIBUTE_MIN_WORLD
+
+
+def wm_vector_owner(v, world):
+    """rank that runs the (iNTT, coset shift, NTT) pipeline of vector v when the witness map is distributed"""
+    return v % world
 
 
 def plan_units(world):
@@ -116,15 +140,23 @@ def plan_units(world):
     a table is range-split only as far as needed to balance the ranks (G2 first: it is the most expensive).  Greedy longest-
     processing-time assignment; returns [(table, num, den_index, owner)], identical on every rank."""
     splits = {t: 1 for t in TABLES}
+    fixed = {}
+    if wm_distributed(world):                     # h is split over all ranks, slice i on rank i (matches the all_to_all)
+        splits["h"] = world
+        fixed = {("h", i, world): i for i in range(world)}
     def units_of(sp):
         return [(t, i, sp[t]) for t in TABLES for i in range(sp[t])]
     def cost(u):
         t, _, parts = u
-        return (G2_COST if TABLE_GROUP[t] else 1.0) * 2.0 / parts
+        return (G2_COST if TABLE_GROUP[t] else 1.0) * 2.0 / parts + (WM_COST if t == "h" and not wm_distributed(world) else 0.0)
     def assign(units):
         load = [0.0] * world; owner = {}
         sorts = [set() for _ in range(world)]
-        for u in sorted(units, key=lambda u: -cost(u)):
+        for u, r in fixed.items():
+            load[r] += cost(u) + 2 * SORT_COST / u[2]; sorts[r].add(("h", u[1], u[2])); owner[u] = r
+            if wm_vector_owner(r, world) == r and r < WM_VECTORS:
+                load[r] += 0.3 * (1 + (1 if r + world < WM_VECTORS else 0))     # its vector pipeline(s)
+        for u in sorted((u for u in units if u not in fixed), key=lambda u: -cost(u)):
             key = lambda r: load[r] + cost(u) + (0.0 if (("h" if u[0] == "h" else "aux"), u[1], u[2]) in sorts[r] else 2 * SORT_COST / u[2])
             r = min(range(world), key=key)
             load[r] = key(r); sorts[r].add((("h" if u[0] == "h" else "aux"), u[1], u[2])); owner[u] = r
@@ -138,7 +170,7 @@ def plan_units(world):
         if len(units) >= 4 * world:
             break
         # split the table owning the costliest unit further
-        t = max(units, key=cost)[0]
+        t = max((u for u in units if u not in fixed and u[0] != "h"), key=cost)[0]      # h: whole (its owner runs the witness map) or fixed
         splits[t] *= 2
     _, sp, owner = best
     return [(t, i, sp[t], owner[(t, i, sp[t])]) for t in TABLES for i in range(sp[t])]
@@ -159,6 +191,120 @@ def combine_partials(curve, group, partials):
     return acc
 
 
+def witness_map_local(w):
+    """whole witness map on this rank (groth16.rs:143-231): h = FFT_coset(a) * FFT_coset(b) - FFT_coset(c)"""
+    ctx, m, nc, C = w.ctx, w.m, w.nc, CURVE
+    # constraint evaluation (groth16.rs:159-171), party 0
+    ctx.spmv_csr(C, w.rpA, w.colA, w.coA, nc, w.pub, w.n_inputs, 0, w.wa, w.wb, w.aa, w.ab)
+    ctx.spmv_csr(C, w.rpB, w.colB, w.coB, nc, w.pub, w.n_inputs, 0, w.wa, w.wb, w.ba, w.bb)
+    w.aa[nc:nc + 2] = w.pub                                       # promote_to_trivial_shares + clone_from_slice (party 0 -> component a)
+    for v in (w.ab, w.ba, w.bb):
+        v[nc:] = 0                                                # rows past the constraints are zero (the buffers are reused in place)
+    # c = mul_vec(a, b): local part on the GPU, the other component arrives from the previous party (resident stand-in)
+    ctx.vec_rep3_mul_local(C, w.ca, w.aa, w.ab, w.ba, w.bb, w.mask1, m)
+    w.cb.copy_(w.recv1)
+    vec4 = [w.aa, w.ab, w.ba, w.bb]
+    ctx.ntt_dev(C, vec4, m, w.omega, inverse=True, coset_gen=w.coset_g)   # ifft + distribute_powers fused
+    ctx.ntt_dev(C, vec4, m, w.omega)
+    ctx.vec_rep3_mul_local(C, w.ha, w.aa, w.ab, w.ba, w.bb, w.mask2, m)
+    w.hb.copy_(w.recv2)
+    ctx.ntt_dev(C, [w.ca, w.cb], m, w.omega, inverse=True, coset_gen=w.coset_g)
+    ctx.ntt_dev(C, [w.ca, w.cb], m, w.omega)
+    ctx.vec_sub(C, w.ha, w.ha, w.ca, m)
+    ctx.vec_sub(C, w.hb, w.hb, w.cb, m)
+
+
+def a2a_splits(world, rank, h_units, m):
+    """all_to_all row counts of the distributed witness map: rank s sends to rank r the slices [lo_r, hi_r) of the vectors s owns.
+    Returns (rows this rank sends to each rank, rows it receives from each rank)."""
+    rng = {owner: (lo, hi) for (_, _, owner, lo, hi) in h_units}
+    nv = lambda r: sum(1 for v in range(WM_VECTORS) if wm_vector_owner(v, world) == r)
+    send = [nv(rank) * (rng[r][1] - rng[r][0]) for r in range(world)]
+    recv = [nv(s) * (rng[rank][1] - rng[rank][0]) for s in range(world)]
+    return send, recv
+
+
+def wm_exchange(comm, vecs, my_vecs, h_units, world, rank, m):
+    """the all_to_all of the distributed witness map: `vecs[v]` (rows x 4 limbs) is valid on the rank that owns v; returns
+    {v: rows [lo, hi) of vector v} for this rank's h range, for all six vectors"""
+    send_rows, recv_rows = a2a_splits(world, rank, h_units, m)
+    rng = {owner: (lo, hi) for (_, _, owner, lo, hi) in h_units}
+    like = vecs[0]
+    pieces = [vecs[v][rng[r][0]:rng[r][1]] for r in range(world) for v in my_vecs]
+    send = torch.cat(pieces) if pieces else torch.empty((0, like.shape[1]), dtype=like.dtype, device=like.device)
+    recv = torch.empty((sum(recv_rows), like.shape[1]), dtype=like.dtype, device=like.device)
+    comm.all_to_all_rows(recv, send, recv_rows, send_rows)
+    hn = rng[rank][1] - rng[rank][0]
+    sl, off = {}, 0
+    for s_rank in range(world):
+        for v in range(WM_VECTORS):
+            if wm_vector_owner(v, world) == s_rank:
+                sl[v] = recv[off:off + hn]; off += hn
+    return sl
+
+
+def witness_map_distributed(w):
+    """world >= 4: this rank runs the pipelines of the vectors it owns, then one all_to_all hands every rank the slices of all six
+    coset-evaluation vectors over its own h range, where h = a*b - c is formed (same arithmetic as witness_map_local)."""
+    ctx, m, nc, C, world, rank = w.ctx, w.m, w.nc, CURVE, w.world, w.rank
+    vecs = [w.aa, w.ab, w.ba, w.bb, w.ca, w.cb]
+    if w.my_vecs:
+        ctx.spmv_csr(C, w.rpA, w.colA, w.coA, nc, w.pub, w.n_inputs, 0, w.wa, w.wb, w.aa, w.ab)
+        ctx.spmv_csr(C, w.rpB, w.colB, w.coB, nc, w.pub, w.n_inputs, 0, w.wa, w.wb, w.ba, w.bb)
+        w.aa[nc:nc + 2] = w.pub
+        for v in (w.ab, w.ba, w.bb):
+            v[nc:] = 0
+        if 4 in w.my_vecs:
+            ctx.vec_rep3_mul_local(C, w.ca, w.aa, w.ab, w.ba, w.bb, w.mask1, m)
+        if 5 in w.my_vecs:
+            w.cb.copy_(w.recv1)
+        mine = [vecs[v] for v in w.my_vecs]
+        ctx.ntt_dev(C, mine, m, w.omega, inverse=True, coset_gen=w.coset_g)
+        ctx.ntt_dev(C, mine, m, w.omega)
+    hn = w.h_hi - w.h_lo
+    sl = wm_exchange(w.comm, vecs, w.my_vecs, w.h_units, world, rank, m)
+    ctx.vec_rep3_mul_local(C, w.hs_a, sl[0], sl[1], sl[2], sl[3], w.mask2[w.h_lo:w.h_hi], hn)
+    w.hs_b.copy_(w.recv2[w.h_lo:w.h_hi])
+    ctx.vec_sub(C, w.hs_a, w.hs_a, sl[4], hn)
+    ctx.vec_sub(C, w.hs_b, w.hs_b, sl[5], hn)
+
+
+class Comm:
+    """torch.distributed plumbing.  nccl (= RCCL): device tensors straight through.  gloo (tests: several ranks sharing one GPU):
+    staged through host memory."""
+
+    def __init__(self, dist, world, device):
+        self.dist, self.world, self.device = dist, world, device
+        self.host = dist is not None and dist.get_backend() == "gloo"
+
+    def all_to_all_rows(self, recv, send, recv_rows, send_rows):
+        if self.dist is None:
+            recv.copy_(send); return
+        if self.host:
+            r = torch.empty(recv.shape, dtype=recv.dtype)
+            self.dist.all_to_all_single(r, send.cpu(), recv_rows, send_rows)
+            recv.copy_(r)
+        else:
+            self.dist.all_to_all_single(recv, send, recv_rows, send_rows)
+
+    def all_gather_flat(self, flat_np):
+        if self.dist is None:
+            return [flat_np]
+        t = torch.from_numpy(flat_np.view(np.int64))
+        if not self.host:
+            t = t.to(self.device)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [o.cpu().numpy().view(np.uint64) for o in out]
+
+    def max_float(self, x):
+        if self.dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=None if self.host else self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
 def step(w):
     """one pass of the hot path; returns the 10 (partial) MSM results of this rank"""
     ctx, m, nc = w.ctx, w.m, w.nc
@@ -177,7 +323,10 @@ def step(w):
             if kind not in kinds:
                 continue
             members.sort(key=lambda kb: -TABLE_GROUP[kb[0][0]])
-            sc = [w.ha[lo:hi], w.hb[lo:hi]] if kind == "h" else [w.wa[lo:hi], w.wb[lo:hi]]
+            if kind == "h":
+                sc = [w.hs_a, w.hs_b] if w.distributed else [w.ha[lo:hi], w.hb[lo:hi]]
+            else:
+                sc = [w.wa[lo:hi], w.wb[lo:hi]]
             tk = on.msm_dev_begin_multi([b for _, b in members], sc, hi - lo)
             pending.extend((on, key, t) for (key, _), t in zip(members, tk))
 
@@ -185,22 +334,10 @@ def step(w):
     # the HBM/LDS-bound witness map runs underneath their integer-VALU-bound bucket accumulation.
     if w.ctx_aux is not None:
         begin(w.ctx_aux, ("aux",))
-    # constraint evaluation (groth16.rs:159-171), party 0
-    ctx.spmv_csr(C, w.rpA, w.colA, w.coA, nc, w.pub, w.n_inputs, 0, w.wa, w.wb, w.aa, w.ab)
-    ctx.spmv_csr(C, w.rpB, w.colB, w.coB, nc, w.pub, w.n_inputs, 0, w.wa, w.wb, w.ba, w.bb)
-    w.aa[nc:nc + 2] = w.pub                                       # promote_to_trivial_shares + clone_from_slice (party 0 -> component a)
-    # c = mul_vec(a, b): local part on the GPU, the other component arrives from the previous party (resident stand-in)
-    ctx.vec_rep3_mul_local(C, w.ca, w.aa, w.ab, w.ba, w.bb, w.mask1, m)
-    w.cb.copy_(w.recv1)
-    vec4 = [w.aa, w.ab, w.ba, w.bb]
-    ctx.ntt_dev(C, vec4, m, w.omega, inverse=True, coset_gen=w.coset_g)   # ifft + distribute_powers fused
-    ctx.ntt_dev(C, vec4, m, w.omega)
-    ctx.vec_rep3_mul_local(C, w.ha, w.aa, w.ab, w.ba, w.bb, w.mask2, m)
-    w.hb.copy_(w.recv2)
-    ctx.ntt_dev(C, [w.ca, w.cb], m, w.omega, inverse=True, coset_gen=w.coset_g)
-    ctx.ntt_dev(C, [w.ca, w.cb], m, w.omega)
-    ctx.vec_sub(C, w.ha, w.ha, w.ca, m)
-    ctx.vec_sub(C, w.hb, w.hb, w.cb, m)
+    if w.distributed:
+        witness_map_distributed(w)
+    elif w.owns_h:
+        witness_map_local(w)
     begin(ctx, ("h",) if w.ctx_aux is not None else ("h", "aux"))
     return {key: on.msm_end(t) for on, key, t in pending}
 
@@ -215,7 +352,7 @@ def unit_layout(plan):
     return lay, off
 
 
-def exchange(results, plan, rank, dist, world, device):
+def exchange(results, plan, comm):
     """Each rank contributes the results of its own units (zeros elsewhere); one all_gather of the flat buffer (a few KB), then
     per table the slices are folded with host EC additions (RCCL has no EC-add reduction).  Returns {table: (2, words)}."""
     lay, total = unit_layout(plan)
@@ -223,13 +360,7 @@ def exchange(results, plan, rank, dist, world, device):
     for key, r in results.items():
         off, wlen, _ = lay[key]
         flat[off:off + 2 * wlen] = r.reshape(-1)
-    if world > 1:
-        t = torch.from_numpy(flat.view(np.int64)).to(device)
-        out = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(out, t)
-        per_rank = [o.cpu().numpy().view(np.uint64) for o in out]
-    else:
-        per_rank = [flat]
+    per_rank = comm.all_gather_flat(flat)
     final = {}
     for (t, i, parts, owner) in plan:
         off, wlen, _ = lay[(t, i, parts)]
@@ -268,6 +399,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scatter-cap", type=int, default=-1, help="-1 = exact two-pass sort (default), 0 = optimistic one-pass scatter (auto capacity)")
     ap.add_argument("--g2-last", action="store_true", help="experiment: put the G2 table last in the multi-table MSM")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (gloo: test mode, exchanges staged through the host)")
+    ap.add_argument("--shared-device", action="store_true", help="test mode: every rank uses GPU 0 (several ranks on one GPU; needs --backend gloo)")
+    ap.add_argument("--dump-result", default=None, help="rank 0 writes the five folded MSM results (affine) of the last step to this .npz")
+    ap.add_argument("--dump-inputs", action="store_true", help="with --dump-result: also store the step's inputs (small --log-m only; tests check the results against the oracle)")
     ap.add_argument("--one-context", action="store_true", help="run the aux-witness MSMs after the witness map on the same context (no overlap)")
     ap.add_argument("--precompute", type=int, default=20, help="window size of the per-window precomputed base tables (0 = off)")
     args = ap.parse_args()
@@ -277,13 +412,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if args.shared_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = Comm(dist, world, device)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     ctx = cg.Context(local_rank)
@@ -293,6 +434,7 @@ def main():
     ctx.set_scatter_capacity(args.scatter_cap)
     w = Workload(ctx, args.log_m, device, rank, world, precompute=args.precompute)
     w.g2_last = args.g2_last
+    w.comm = comm
     w.ctx_aux = None
     if not args.one_context:
         w.ctx_aux = cg.Context(local_rank)
@@ -307,20 +449,17 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        res = exchange(step(w), w.plan, rank, dist, world, device)
+        res = exchange(step(w), w.plan, comm)
     ctx.stats_enable(True); ctx.stats(reset=True)
     if w.ctx_aux is not None:
         w.ctx_aux.stats_enable(True); w.ctx_aux.stats(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = exchange(step(w), w.plan, rank, dist, world, device)
+        res = exchange(step(w), w.plan, comm)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = comm.max_float(elapsed)
     st = ctx.stats(reset=True)
     ctx.stats_enable(False)
     if w.ctx_aux is not None:
@@ -328,6 +467,15 @@ def main():
         w.ctx_aux.stats_enable(False)
         st = {k: st[k] + st2[k] for k in st}
 
+    if rank == 0 and args.dump_result:
+        dump = {t: np.stack([cg.point_to_affine(CURVE, cg.G1 if TABLE_GROUP[t] == 0 else cg.G2, res[t][j]) for j in range(2)]) for t in TABLES}
+        if args.dump_inputs:
+            u64 = lambda t: t.cpu().numpy().view(np.uint64) if t.dtype == torch.int64 else t.cpu().numpy()
+            for name in ("rpA", "colA", "coA", "rpB", "colB", "coB", "pub", "wa", "wb", "mask1", "mask2", "recv1", "recv2"):
+                dump["in_" + name] = u64(getattr(w, name))
+            dump["in_omega"], dump["in_coset_g"] = w.omega, w.coset_g
+            dump["in_shape"] = np.array([w.m, w.nc, w.n_inputs, w.n_aux], dtype=np.int64)
+        np.savez(args.dump_result, **dump)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = w.nc / (elapsed / args.steps)

@@ -1,0 +1,56 @@
+"""bench.py's multi-rank path on real hardware: several ranks share GPU 0 (gloo for the exchanges, staged through the host) and
+must fold to exactly the points the single-rank run produces.  Covers plan_units, table slices, the h-owner-only witness map
+(N = 2), the distributed witness map + all_to_all (N = 4) and the all_gather + host EC-add fold."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(tmp_path, world, extra=(), log_m=14, port=29611):
+    out = str(tmp_path / f"res_{world}_{len(extra)}.npz")
+    common = ["--gpus", str(world), "--steps", "1", "--warmup", "1", "--log-m", str(log_m), "--no-cpu-baseline", "--dump-result", out, *extra]
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *common]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port + world), os.path.join(ROOT, "bench.py"), *common, "--backend", "gloo", "--shared-device"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line), dict(np.load(out))
+
+
+def test_bench_step_matches_oracle(tmp_path):
+    """the step bench.py times computes the right thing: all ten MSM results of a 2^12 step equal the oracle's evaluation of the
+    same inputs (SpMV, REP3 products, coset NTTs, h = ab - c, MSMs)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+    import bench
+    import bench_check
+    assert bench_check.TABLE_FIRST == bench.TABLE_FIRST
+    for extra in ((), ("--precompute", "0")):
+        _, d = run_bench(tmp_path, 1, extra=("--dump-inputs",) + extra, log_m=12)
+        exp = bench_check.expected_results(d)
+        for t in bench.TABLES:
+            np.testing.assert_array_equal(d[t], exp[t], err_msg=f"table {t} {extra}")
+
+
+def test_ranks_fold_to_the_single_rank_result(tmp_path):
+    j1, r1 = run_bench(tmp_path, 1)
+    assert j1["n_gpus"] == 1 and set(r1) == {"h", "l", "a", "b1", "b2"}
+    _, r1b = run_bench(tmp_path, 1, extra=("--one-context",))
+    for t in r1:
+        np.testing.assert_array_equal(r1[t], r1b[t], err_msg=f"one-context vs two-context, table {t}")
+        assert r1[t].any()
+    for world in (2, 4):
+        jw, rw = run_bench(tmp_path, world)
+        assert jw["n_gpus"] == world
+        for t in r1:
+            np.testing.assert_array_equal(r1[t], rw[t], err_msg=f"world {world}, table {t}")

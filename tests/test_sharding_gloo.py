@@ -47,7 +47,7 @@ def _worker(rank, world, port, n, q):
             continue
         lo, hi = bench.shard_range(n, i, parts)           # the oracle stands in for the GPU kernels on this unit
         results[(t, i, parts)] = np.stack([cg.point_from_affine(curve, group, orc.msm(curve, group, tables[t][lo:hi], s[lo:hi])) for s in sc])
-    final = bench.exchange(results, plan, rank, dist, world, torch.device("cpu"))
+    final = bench.exchange(results, plan, bench.Comm(dist, world, torch.device("cpu")))
     ok = set(final.keys()) == set(bench.TABLES)
     for t in bench.TABLES:
         group = orc.G1 if bench.TABLE_GROUP[t] == 0 else orc.G2
@@ -99,3 +99,58 @@ def test_msm_shard_allgather_combine_world2():
     for p in procs: p.join(timeout=60)
     assert sorted((r, ok) for r, ok, _ in got) == [(0, True), (1, True)]
     assert all(nunits > 0 for _, _, nunits in got)
+
+
+def _wm_worker(rank, world, port, m, q):
+    sys.path.insert(0, HERE); sys.path.insert(0, ROOT)
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = bench.Comm(dist, world, torch.device("cpu"))
+    plan = bench.plan_units(world)
+    h_units = [(i, parts, owner) + bench.shard_range(m, i, parts) for (t, i, parts, owner) in plan if t == "h"]
+    my_vecs = [v for v in range(bench.WM_VECTORS) if bench.wm_vector_owner(v, world) == rank]
+    # vector v, row i, limb j = 1000 * i + 10 * v + j on its owner; poison everywhere else (must never be sent)
+    rows = torch.arange(m, dtype=torch.int64).reshape(m, 1) * 1000 + torch.arange(4, dtype=torch.int64).reshape(1, 4)
+    vecs = [(rows + 10 * v) if v in my_vecs else torch.full((m, 4), -1, dtype=torch.int64) for v in range(bench.WM_VECTORS)]
+    sl = bench.wm_exchange(comm, vecs, my_vecs, h_units, world, rank, m)
+    (lo, hi), = [(lo, hi) for (_, _, owner, lo, hi) in h_units if owner == rank]
+    ok = sorted(sl) == list(range(bench.WM_VECTORS))
+    for v in range(bench.WM_VECTORS):
+        ok &= bool(torch.equal(sl[v], rows[lo:hi] + 10 * v))
+    q.put((rank, ok, hi - lo))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,m", [(4, 64), (4, 61), (5, 128)])
+def test_distributed_witness_map_exchange(world, m):
+    """world >= 4: vector pipelines live on different ranks; one all_to_all must hand every rank rows [lo, hi) of all six
+    vectors for its own h slice (bench.wm_exchange), for even and ragged splits"""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_wm_worker, args=(r, world, port, m, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs: p.join(timeout=60)
+    assert sorted(r for r, _, _ in got) == list(range(world))
+    assert all(ok for _, ok, _ in got)
+    assert sum(n for _, _, n in got) == m
+
+
+def test_plan_h_split_matches_all_to_all():
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (4, 5, 8):
+        plan = bench.plan_units(world)
+        hs = [(i, parts, o) for (t, i, parts, o) in plan if t == "h"]
+        assert hs == [(i, world, i) for i in range(world)]                 # slice i of h lives on rank i
+        m = 1 << 12
+        hu = [(i, parts, o) + bench.shard_range(m, i, parts) for (i, parts, o) in hs]
+        sp = [bench.a2a_splits(world, r, hu, m) for r in range(world)]
+        for s in range(world):
+            for r in range(world):
+                assert sp[s][0][r] == sp[r][1][s]                          # what s sends to r is what r expects from s
+    for world in (1, 2, 3):
+        assert sum(1 for (t, _, _, _) in bench.plan_units(world) if t == "h") == 1   # one rank owns h and runs the witness map
