@@ -107,7 +107,7 @@ class Workload:
         self.precompute = precompute
         if precompute:
             for (bases, lo, hi) in self.tables.values():
-                ctx.precompute_bases(bases, precompute)
+                ctx.precompute_bases(bases, precompute if precompute > 0 else 0)      # 0 = library picks by table size
         self.setup_precompute_s = time.time() - t0
 
     def sl(self, t, rng):
@@ -117,9 +117,14 @@ class Workload:
 TABLES = ("h", "l", "a", "b1", "b2")            # zkey queries of create_proof_with_assignment (groth16.rs:248-304)
 TABLE_GROUP = {"h": 0, "l": 0, "a": 0, "b1": 0, "b2": 1}
 TABLE_FIRST = {"h": 1, "l": 3, "a": 5, "b1": 7, "b2": 1}     # synthetic tables: [(first + i) * G]
-G2_COST = 2.3                                    # measured: a G2 accumulate launch costs 2.3 G1 launches
-SORT_COST = 0.45                                 # digit/sort schedule per (scalar set, range), shared by the tables that use it
-WM_COST = 1.0                                    # witness map on the rank that owns h (N < 4), after overlap with its aux MSMs
+# Cost model of the planner (ms on one MI355X; p = points of the unit / 2^20; both share components).  Measured with
+# scripts/sweep_precompute.py and the bench stage split (profiles/): a unit has a fixed cost (bucket reduction, launch tail) that
+# does not shrink with its size, which is why whole tables are preferred over splitting every MSM N ways.
+ACC_COST = {0: [(0.25, 1.65), (0.5, 2.05), (1.0, 3.1), (2.0, 5.3), (4.0, 11.0)],       # group -> [(p, ms)]: accumulate + reduce of a unit,
+            1: [(0.25, 4.6), (0.5, 6.1), (1.0, 9.6), (2.0, 16.6), (4.0, 28.9)]}        # excl. the sort schedule; interpolated
+SORT_COST = (0.3, 1.2)                           # digit/sort schedule per (rank, scalar set, range), shared by the tables that use it
+WM_COST = 4.0                                    # whole witness map on the rank that owns h (N < 4), after overlap with its aux MSMs
+WM_VEC_COST = (0.75, 1.6)                        # distributed witness map: SpMV + products once, then per owned vector pipeline
 WM_DISTRIBUTE_MIN_WORLD = 4                      # from this many ranks on: vector pipelines spread over ranks + all_to_all
 WM_VECTORS = 6                                   # a.a, a.b, b.a, b.b, c.a, c.b
 
@@ -133,47 +138,63 @@ def wm_vector_owner(v, world):
     return v % world
 
 
-def plan_units(world):
+def plan_units(world, log_m=22, with_load=False):
     """Work units of the MSM stage and their owner ranks.
-    A unit = (table, lo_frac, hi_frac): the MSM of BOTH share components over a contiguous slice of one table.  Whole tables
-    are the preferred unit (full-size launches are the efficient ones: at 1/8 of the points the bucket reduction dominates);
-    a table is range-split only as far as needed to balance the ranks (G2 first: it is the most expensive).  Greedy longest-
-    processing-time assignment; returns [(table, num, den_index, owner)], identical on every rank."""
-    splits = {t: 1 for t in TABLES}
-    fixed = {}
-    if wm_distributed(world):                     # h is split over all ranks, slice i on rank i (matches the all_to_all)
-        splits["h"] = world
-        fixed = {("h", i, world): i for i in range(world)}
-    def units_of(sp):
-        return [(t, i, sp[t]) for t in TABLES for i in range(sp[t])]
-    def cost(u):
-        t, _, parts = u
-        return (G2_COST if TABLE_GROUP[t] else 1.0) * 2.0 / parts + (WM_COST if t == "h" and not wm_distributed(world) else 0.0)
-    def assign(units):
-        load = [0.0] * world; owner = {}
-        sorts = [set() for _ in range(world)]
-        for u, r in fixed.items():
-            load[r] += cost(u) + 2 * SORT_COST / u[2]; sorts[r].add(("h", u[1], u[2])); owner[u] = r
-            if wm_vector_owner(r, world) == r and r < WM_VECTORS:
-                load[r] += 0.3 * (1 + (1 if r + world < WM_VECTORS else 0))     # its vector pipeline(s)
-        for u in sorted((u for u in units if u not in fixed), key=lambda u: -cost(u)):
-            key = lambda r: load[r] + cost(u) + (0.0 if (("h" if u[0] == "h" else "aux"), u[1], u[2]) in sorts[r] else 2 * SORT_COST / u[2])
-            r = min(range(world), key=key)
-            load[r] = key(r); sorts[r].add((("h" if u[0] == "h" else "aux"), u[1], u[2])); owner[u] = r
-        return load, owner
+    A unit = (table, i, parts): the MSM of BOTH share components over slice i of `parts` contiguous slices of one table.  Whole
+    tables are the preferred unit; a table is range-split only as far as balance needs it.  Every split choice (the three G1
+    aux tables alike, the G2 table on its own) is tried, units are assigned longest-processing-time first under the measured
+    cost model above, and the plan with the smallest maximum rank load wins (ties: fewer units).  For N >= 4 the h table is
+    split over all ranks, slice i on rank i, which is what the witness map's all_to_all delivers.  Deterministic: identical on
+    every rank.  Returns [(table, i, parts, owner)]."""
+    scale = (1 << log_m) / float(1 << 20)
+    dist_wm = wm_distributed(world)
+
+    def sched(u):
+        return ("h" if u[0] == "h" else "aux", u[1], u[2])
+
+    def acc_cost(u):
+        tab, p = ACC_COST[TABLE_GROUP[u[0]]], scale / u[2]
+        if p <= tab[0][0]:
+            ms = tab[0][1]
+        elif p >= tab[-1][0]:
+            ms = tab[-1][1] * p / tab[-1][0]
+        else:
+            (p0, c0), (p1, c1) = next((lo, hi) for lo, hi in zip(tab, tab[1:]) if lo[0] <= p <= hi[0])
+            ms = c0 + (c1 - c0) * (p - p0) / (p1 - p0)
+        return ms + (WM_COST * scale / 4.0 if u[0] == "h" and not dist_wm else 0.0)
+
+    def sort_cost(u):
+        return SORT_COST[0] + SORT_COST[1] * scale / u[2]
+
+    def assign(splits):
+        units = [(t, i, splits[t]) for t in TABLES for i in range(splits[t])]
+        load = [0.0] * world; owner = {}; scheds = [set() for _ in range(world)]
+        def put(u, r):
+            load[r] += acc_cost(u) + (0.0 if sched(u) in scheds[r] else sort_cost(u))
+            scheds[r].add(sched(u)); owner[u] = r
+        if dist_wm:
+            for r in range(world):
+                nv = sum(1 for v in range(WM_VECTORS) if wm_vector_owner(v, world) == r)
+                load[r] += (WM_VEC_COST[0] + WM_VEC_COST[1] * nv) * scale / 4.0 if nv else 0.0
+                put(("h", r, world), r)
+        rest = [u for u in units if u not in owner]
+        for u in sorted(rest, key=lambda u: (-acc_cost(u), u)):
+            put(u, min(range(world), key=lambda r: (load[r] + acc_cost(u) + (0.0 if sched(u) in scheds[r] else sort_cost(u)), r)))
+        return load, owner, units
+
     best = None
-    for _ in range(8):
-        units = units_of(splits)
-        load, owner = assign(units)
-        if best is None or max(load) < best[0] - 1e-9:
-            best = (max(load), dict(splits), owner)
-        if len(units) >= 4 * world:
-            break
-        # split the table owning the costliest unit further
-        t = max((u for u in units if u not in fixed and u[0] != "h"), key=cost)[0]      # h: whole (its owner runs the witness map) or fixed
-        splits[t] *= 2
-    _, sp, owner = best
-    return [(t, i, sp[t], owner[(t, i, sp[t])]) for t in TABLES for i in range(sp[t])]
+    g1_choices = [c for c in (1, 2, 3, 4, 6, 8) if c <= max(1, world)]
+    g2_choices = [c for c in range(1, 2 * world + 1)]
+    for s1 in g1_choices:
+        for s2 in g2_choices:
+            splits = {"h": world if dist_wm else 1, "l": s1, "a": s1, "b1": s1, "b2": s2}
+            load, owner, units = assign(splits)
+            key = (round(max(load), 6), len(units))
+            if best is None or key < best[0]:
+                best = (key, splits, owner, load)
+    _, sp, owner, load = best
+    plan = [(t, i, sp[t], owner[(t, i, sp[t])]) for t in TABLES for i in range(sp[t])]
+    return (plan, load) if with_load else plan
 
 
 def shard_range(n, rank, world):
@@ -262,7 +283,10 @@ def witness_map_distributed(w):
         ctx.ntt_dev(C, mine, m, w.omega, inverse=True, coset_gen=w.coset_g)
         ctx.ntt_dev(C, mine, m, w.omega)
     hn = w.h_hi - w.h_lo
-    sl = wm_exchange(w.comm, vecs, w.my_vecs, w.h_units, world, rank, m)
+    if w.emulate:       # planner tuning on one GPU: no peers; time the local work only
+        sl = {v: vecs[v][w.h_lo:w.h_hi] for v in range(WM_VECTORS)}
+    else:
+        sl = wm_exchange(w.comm, vecs, w.my_vecs, w.h_units, world, rank, m)
     ctx.vec_rep3_mul_local(C, w.hs_a, sl[0], sl[1], sl[2], sl[3], w.mask2[w.h_lo:w.h_hi], hn)
     w.hs_b.copy_(w.recv2[w.h_lo:w.h_hi])
     ctx.vec_sub(C, w.hs_a, w.hs_a, sl[4], hn)
@@ -403,8 +427,10 @@ def main():
     ap.add_argument("--shared-device", action="store_true", help="test mode: every rank uses GPU 0 (several ranks on one GPU; needs --backend gloo)")
     ap.add_argument("--dump-result", default=None, help="rank 0 writes the five folded MSM results (affine) of the last step to this .npz")
     ap.add_argument("--dump-inputs", action="store_true", help="with --dump-result: also store the step's inputs (small --log-m only; tests check the results against the oracle)")
+    ap.add_argument("--emulate", default=None, metavar="WORLD:RANK", help="planner tuning: time ONLY the work the plan gives RANK of WORLD, on this one GPU, "
+                    "with the exchanges skipped (results are not folded; not a benchmark line)")
     ap.add_argument("--one-context", action="store_true", help="run the aux-witness MSMs after the witness map on the same context (no overlap)")
-    ap.add_argument("--precompute", type=int, default=20, help="window size of the per-window precomputed base tables (0 = off)")
+    ap.add_argument("--precompute", type=int, default=-1, help="window size of the per-window precomputed base tables (-1 = by table size: 20 above ~1.5 M points else 17; 0 = off)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -414,6 +440,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     if args.shared_device:
         local_rank = 0
+    emulate = None
+    if args.emulate:
+        assert world == 1, "--emulate runs as a single process"
+        emulate = tuple(int(x) for x in args.emulate.split(":"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -432,7 +462,8 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     torch.cuda.set_stream(stream)
     ctx.set_scatter_capacity(args.scatter_cap)
-    w = Workload(ctx, args.log_m, device, rank, world, precompute=args.precompute)
+    w = Workload(ctx, args.log_m, device, emulate[1] if emulate else rank, emulate[0] if emulate else world, precompute=args.precompute)
+    w.emulate = emulate is not None
     w.g2_last = args.g2_last
     w.comm = comm
     w.ctx_aux = None
@@ -448,15 +479,16 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    run_step = (lambda: step(w)) if emulate else (lambda: exchange(step(w), w.plan, comm))
     for _ in range(args.warmup):
-        res = exchange(step(w), w.plan, comm)
+        res = run_step()
     ctx.stats_enable(True); ctx.stats(reset=True)
     if w.ctx_aux is not None:
         w.ctx_aux.stats_enable(True); w.ctx_aux.stats(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = exchange(step(w), w.plan, comm)
+        res = run_step()
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = comm.max_float(elapsed)
@@ -476,6 +508,10 @@ def main():
             dump["in_omega"], dump["in_coset_g"] = w.omega, w.coset_g
             dump["in_shape"] = np.array([w.m, w.nc, w.n_inputs, w.n_aux], dtype=np.int64)
         np.savez(args.dump_result, **dump)
+    if emulate:
+        print(json.dumps({"emulated_world": emulate[0], "emulated_rank": emulate[1], "ms_per_step": elapsed / args.steps * 1e3,
+                          "units": [f"{t}{i}/{p}" for (t, i, p) in w.mine], "vectors": w.my_vecs, "stage_ms": {k: v / args.steps for k, v in st.items() if k.endswith("_ms")}}))
+        return
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = w.nc / (elapsed / args.steps)
@@ -501,7 +537,7 @@ def main():
             "dtype": "u32 limbs (254-bit modular integer arithmetic)", "data": "synthetic",
             "config": {"workload": f"synthetic R1CS 2^{args.log_m} constraints-domain BN254, REP3 co-groth16 (configs[2])",
                        "num_constraints": w.nc, "domain_size": w.m, "n_vars": w.m, "nnz": w.nnz, "share_components": 2,
-                       "msm": "8 G1 + 2 G2 of ~2^%d points" % args.log_m, "msm_window": ("precomputed tables c=%d" % args.precompute) if args.precompute else "c=16, per-window bucket sets", "ntt": 12, "parallelism": f"msm units (tables / table slices) over {world} rank(s): " + ",".join(f"{t}{i}/{p}->r{o}" for t, i, p, o in w.plan)},
+                       "msm": "8 G1 + 2 G2 of ~2^%d points" % args.log_m, "msm_window": ("precomputed tables c=%s" % (args.precompute if args.precompute > 0 else "auto (20 above 1.5 M points, else 17)")) if args.precompute else "c=16, per-window bucket sets", "ntt": 12, "parallelism": f"msm units (tables / table slices) over {world} rank(s): " + ",".join(f"{t}{i}/{p}->r{o}" for t, i, p, o in w.plan)},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<G1> (bucket accumulation, one launch per MSM component and table)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": st["msm_acc_g1_calls"], "algorithmic_bytes_per_launch": alg_bytes,

@@ -651,7 +651,9 @@ int32_t cg_bases_check_on_curve(cg_ctx* ctx, const cg_bases* b, uint64_t* n_bad,
 }
 int32_t cg_bases_precompute(cg_ctx* ctx, cg_bases* b, int32_t c) {
     if (!ctx || !b) return fail(CG_ERR_ARG, "null argument");
-    if (c < 8 || c > 22) return fail(CG_ERR_ARG, "precompute window must be in [8, 22]");
+    // c = 0: pick by table size (measured, scripts/sweep_precompute.py): 2^19 buckets only pay for themselves above ~1.5 M points
+    if (c == 0) c = b->n > ((size_t)3 << 19) ? 20 : 17;
+    if (c < 8 || c > 22) return fail(CG_ERR_ARG, "precompute window must be 0 (auto) or in [8, 22]");
     if (b->device != ctx->device) return fail(CG_ERR_ARG, "bases live on another device");
     if (b->n > ((size_t)1 << 24)) return fail(CG_ERR_ARG, "precomputed tables support at most 2^24 points");
     HIPCHK(hipSetDevice(ctx->device));

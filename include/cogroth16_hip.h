@@ -73,7 +73,8 @@ int32_t cg_bases_check_on_curve(cg_ctx* ctx, const cg_bases* bases, uint64_t* n_
 /* Optional, once per table: precompute 2^(c*j) * P_i for every window j (affine, resident: (254/c + 1) x the table size).
  * MSMs over such a table then use ONE bucket set for all windows: 254/c + 1 mixed additions per point with c up to 22 instead
  * of 16 at the default c = 16, and no doublings in the final fold.  The zkey queries are fixed for the life of the process
- * (zkey.rs:48-71), so this is part of registration, not of the proof.  Results are unchanged. */
+ * (zkey.rs:48-71), so this is part of registration, not of the proof.  Results are unchanged.
+ * c = 0 picks the window by table size (20 above ~1.5 M points, else 17); otherwise 8 <= c <= 22. */
 int32_t cg_bases_precompute(cg_ctx* ctx, cg_bases* bases, int32_t c);
 size_t  cg_bases_len(const cg_bases* bases);
 
