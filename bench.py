@@ -499,6 +499,16 @@ def main():
         w.ctx_aux.stats_enable(False)
         st = {k: st[k] + st2[k] for k in st}
 
+    # the dominant kernel on its own: one extra, untimed step with everything on one context (no concurrent witness map / second
+    # MSM stream sharing the CUs), for the roofline's "isolated" figures
+    iso = None
+    if rank == 0 and not emulate and w.ctx_aux is not None and world == 1:
+        keep, w.ctx_aux = w.ctx_aux, None
+        ctx.stats_enable(True); ctx.stats(reset=True)
+        step(w); barrier()
+        iso = ctx.stats(reset=True); ctx.stats_enable(False)
+        w.ctx_aux = keep
+
     if rank == 0 and args.dump_result:
         dump = {t: np.stack([cg.point_to_affine(CURVE, cg.G1 if TABLE_GROUP[t] == 0 else cg.G2, res[t][j]) for j in range(2)]) for t in TABLES}
         if args.dump_inputs:
@@ -541,7 +551,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<G1> (bucket accumulation, one launch per MSM component and table)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": st["msm_acc_g1_calls"], "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound; traffic = FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_traffic.json (each base is re-gathered once per window); see DESIGN.md"},
+                         "isolated_avg_launch_ms": (iso["msm_acc_g1_ms"] / max(1, iso["msm_acc_g1_calls"])) if iso else None,
+                         "isolated_achieved": (alg_bytes / (iso["msm_acc_g1_ms"] / max(1, iso["msm_acc_g1_calls"]) * 1e-3) / 1e9) if iso and iso["msm_acc_g1_ms"] > 0 else None,
+                         "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound; in the timed region the launches share the CUs with the witness map and the "
+                                 "bucket reductions running on other streams (avg_launch_ms), isolated_* = the same kernel in an extra serial step; traffic = "
+                                 "FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_traffic.json (each base is re-gathered once per window); see DESIGN.md"},
             "step_hbm": {"algorithmic_bytes_per_step": 2048.0 * w.nc, "achieved_GBs": 2048.0 * w.nc / (elapsed / args.steps) / 1e9},
             "stage_ms_per_step": {"spmv": per_step("spmv_ms"), "pointwise": per_step("vec_ms"), "ntt": per_step("ntt_ms"), "msm_gpu": per_step("msm_ms"),
                                   "msm_sort": per_step("msm_sort_ms"), "msm_acc_g1": per_step("msm_acc_g1_ms"), "msm_acc_g2": per_step("msm_acc_g2_ms"),
