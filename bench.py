@@ -341,6 +341,10 @@ def step(w):
         bases, lo, hi = w.tables[key]
         groups.setdefault(("h" if t == "h" else "aux", lo, hi), []).append((key, bases))
     pending = []
+    if w.pcie is not None:                       # host -> device: the witness shares first (the aux MSMs start on them) ...
+        for dev_t, host_t in w.pcie["up"][:2]:
+            dev_t.copy_(host_t, non_blocking=True)
+        torch.cuda.current_stream().synchronize()   # the second context must not start on stale shares
 
     def begin(on, kinds):
         for (kind, lo, hi), members in groups.items():
@@ -358,10 +362,16 @@ def step(w):
     # the HBM/LDS-bound witness map runs underneath their integer-VALU-bound bucket accumulation.
     if w.ctx_aux is not None:
         begin(w.ctx_aux, ("aux",))
+    if w.pcie is not None:                       # ... then masks and the vectors received from the previous party, in stream order
+        for dev_t, host_t in w.pcie["up"][2:]:
+            dev_t.copy_(host_t, non_blocking=True)
     if w.distributed:
         witness_map_distributed(w)
     elif w.owns_h:
         witness_map_local(w)
+    if w.pcie is not None and not w.distributed and w.owns_h:   # device -> host: the local products sent to the next party
+        for dev_t, host_t in w.pcie["down"]:
+            host_t.copy_(dev_t, non_blocking=True)
     begin(ctx, ("h",) if w.ctx_aux is not None else ("h", "aux"))
     return {key: on.msm_end(t) for on, key, t in pending}
 
@@ -429,6 +439,8 @@ def main():
     ap.add_argument("--dump-inputs", action="store_true", help="with --dump-result: also store the step's inputs (small --log-m only; tests check the results against the oracle)")
     ap.add_argument("--emulate", default=None, metavar="WORLD:RANK", help="planner tuning: time ONLY the work the plan gives RANK of WORLD, on this one GPU, "
                     "with the exchanges skipped (results are not folded; not a benchmark line)")
+    ap.add_argument("--pcie", action="store_true", help="PCIe-inclusive variant (reported in DESIGN.md, never the headline value): every step also moves what a real "
+                    "REP3 party moves over PCIe - witness shares, the two masks and the two received vectors up, the two local products down")
     ap.add_argument("--one-context", action="store_true", help="run the aux-witness MSMs after the witness map on the same context (no overlap)")
     ap.add_argument("--precompute", type=int, default=-1, help="window size of the per-window precomputed base tables (-1 = by table size: 20 above ~1.5 M points else 17; 0 = off)")
     args = ap.parse_args()
@@ -466,6 +478,11 @@ def main():
     w.emulate = emulate is not None
     w.g2_last = args.g2_last
     w.comm = comm
+    w.pcie = None
+    if args.pcie:
+        pin = lambda t: torch.empty(t.shape, dtype=t.dtype).pin_memory().copy_(t.cpu())
+        w.pcie = {"up": [(getattr(w, k), pin(getattr(w, k))) for k in ("wa", "wb", "mask1", "mask2", "recv1", "recv2")],
+                  "down": [(getattr(w, k), pin(getattr(w, k))) for k in ("ca", "ha")]}
     w.ctx_aux = None
     if not args.one_context:
         w.ctx_aux = cg.Context(local_rank)
@@ -560,6 +577,7 @@ def main():
             "stage_ms_per_step": {"spmv": per_step("spmv_ms"), "pointwise": per_step("vec_ms"), "ntt": per_step("ntt_ms"), "msm_gpu": per_step("msm_ms"),
                                   "msm_sort": per_step("msm_sort_ms"), "msm_acc_g1": per_step("msm_acc_g1_ms"), "msm_acc_g2": per_step("msm_acc_g2_ms"),
                                   "msm_reduce": per_step("msm_reduce_ms")},
+            "pcie_inclusive": bool(args.pcie),
             "setup_s": {"synthetic_bases": w.setup_bases_s, "precompute_tables": w.setup_precompute_s},
         }
         if not args.no_cpu_baseline and world == 1:
