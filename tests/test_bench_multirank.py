@@ -1,6 +1,6 @@
 """bench.py's multi-rank path on real hardware: several ranks share GPU 0 (gloo for the exchanges, staged through the host) and
 must fold to exactly the points the single-rank run produces.  Covers plan_units, table slices, the h-owner-only witness map
-(N = 2), the distributed witness map + all_to_all (N = 4) and the all_gather + host EC-add fold."""
+(N = 2), the distributed witness map + all_to_all (N = 4, 8) and the all_gather + host EC-add fold."""
 import json
 import os
 import subprocess
@@ -49,7 +49,7 @@ def test_ranks_fold_to_the_single_rank_result(tmp_path):
     for t in r1:
         np.testing.assert_array_equal(r1[t], r1b[t], err_msg=f"one-context vs two-context, table {t}")
         assert r1[t].any()
-    for world in (2, 4):
+    for world in (2, 4, 8):
         jw, rw = run_bench(tmp_path, world)
         assert jw["n_gpus"] == world
         for t in r1:
