@@ -38,7 +38,7 @@ def build(bls=True, jobs=8):
 ABI_SYMBOLS = [
     "cg_ctx_create", "cg_ctx_destroy", "cg_ctx_sync", "cg_ctx_stream", "cg_ctx_set_stream", "cg_last_error", "cg_version",
     "cg_dev_alloc", "cg_dev_free", "cg_dev_upload", "cg_dev_download", "cg_dev_memset_zero",
-    "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute", "cg_bases_check_on_curve",
+    "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute", "cg_bases_check_on_curve", "cg_bases_check_subgroup",
     "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_scatter_capacity",
     "cg_ntt", "cg_ntt_dev",
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev",
@@ -208,6 +208,12 @@ class Context:
         """(number of non-infinity points off the curve, index of the first one or None) — device-side zkey validation"""
         nb, fb = C.c_uint64(0), C.c_uint64(0)
         _chk(load().cg_bases_check_on_curve(self.h, bases.h, C.byref(nb), C.byref(fb)))
+        return nb.value, (None if fb.value == 2**64 - 1 else fb.value)
+
+    def check_subgroup(self, bases):
+        """(number of non-infinity points outside the prime-order subgroup, index of the first one or None); assumes on-curve points"""
+        nb, fb = C.c_uint64(0), C.c_uint64(0)
+        _chk(load().cg_bases_check_subgroup(self.h, bases.h, C.byref(nb), C.byref(fb)))
         return nb.value, (None if fb.value == 2**64 - 1 else fb.value)
 
     def precompute_bases(self, bases, c=20):
@@ -396,6 +402,14 @@ def host_zkey_info(curve, path):
     _hchk(load_host().cgh_zkey_info(curve, path.encode(), info))
     keys = ("n_vars", "n_public", "domain_size", "pow", "num_constraints", "nnz_a", "nnz_b")
     return dict(zip(keys, [int(x) for x in info]))
+
+
+def host_zkey_validate(curve, path, device=0):
+    """zkey -> device with the parser's per-point validation on the GPU; raises BackendError naming the first bad point.
+    Returns (host seconds for read + decode, device seconds for upload + validation)."""
+    secs = (C.c_double * 2)()
+    _hchk(load_host().cgh_zkey_validate(int(device), curve, path.encode(), secs))
+    return float(secs[0]), float(secs[1])
 
 
 def host_read_wtns(curve, path):

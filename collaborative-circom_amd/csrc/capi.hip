@@ -25,6 +25,7 @@ template <class F> int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hi
 template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared);
 template <class F> int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c);
 template <class F> int check_on_curve_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, const F& b, unsigned long long* d_counters);
+template <class F, class Fr> int check_subgroup_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, unsigned long long* d_counters);
 constexpr int MSM_SHARED_GROUPS = 16;
 inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) {   // must match fr_impl.hpp
     const size_t nbuckets = (size_t)nwin << (c - 1);
@@ -641,6 +642,26 @@ int32_t cg_bases_check_on_curve(cg_ctx* ctx, const cg_bases* b, uint64_t* n_bad,
         HIPCHK(hipMalloc((void**)&d, 16));
         HIPCHK(hipMemcpyAsync(d, h, 16, hipMemcpyHostToDevice, ctx->stream));
         int rc = check_on_curve_launch<F>(ctx->stream, (const Affine<F>*)b->d_pts, b->n, CurveB<F>::get(), d);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(d));
+        *n_bad = h[0]; if (first_bad) *first_bad = h[1];
+        return 0;
+    });
+}
+int32_t cg_bases_check_subgroup(cg_ctx* ctx, const cg_bases* b, uint64_t* n_bad, uint64_t* first_bad) {
+    if (!ctx || !b || !n_bad) return fail(CG_ERR_ARG, "null argument");
+    if (b->device != ctx->device) return fail(CG_ERR_ARG, "bases live on another device");
+    *n_bad = 0; if (first_bad) *first_bad = ~0ull;
+    if (b->curve == CG_BN254 && b->group == CG_G1) return 0;      // cofactor 1: every curve point is in the group
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_group(b->curve, b->group, [&](auto ftag, auto frtag) -> int {
+        typedef decltype(ftag) F; typedef decltype(frtag) Fr;
+        unsigned long long* d = nullptr; unsigned long long h[2] = {0ull, ~0ull};
+        HIPCHK(hipMalloc((void**)&d, 16));
+        HIPCHK(hipMemcpyAsync(d, h, 16, hipMemcpyHostToDevice, ctx->stream));
+        int rc = check_subgroup_launch<F, Fr>(ctx->stream, (const Affine<F>*)b->d_pts, b->n, d);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -109,6 +109,12 @@ int check_on_curve_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, cons
     HIPCHK(hipGetLastError());
     return 0;
 }
+template <class F, class Fr>
+int check_subgroup_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, unsigned long long* d_counters) {
+    if (n) hipLaunchKernelGGL((k_check_subgroup<F, typename Fr::Params>), dim3((unsigned)std::min<size_t>((n + 127) / 128, 8192)), dim3(128), 0, st, d_pts, n, d_counters, d_counters + 1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 template <class F>
 int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c) {
     if (n) hipLaunchKernelGGL((k_precompute_window<F>), dim3(grid_for(n)), dim3(256), 0, st, d_src, d_dst, n, c);
@@ -130,6 +136,7 @@ int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi
     template size_t msm_acc_scratch_bytes<F>(size_t, int, int, bool);                                                      \
     template int precompute_window_launch<F>(hipStream_t, const Affine<F>*, Affine<F>*, size_t, int);                      \
     template int check_on_curve_launch<F>(hipStream_t, const Affine<F>*, size_t, const F&, unsigned long long*);           \
+    template int check_subgroup_launch<F, Fr>(hipStream_t, const Affine<F>*, size_t, unsigned long long*);                 \
     template int pack_bases_launch<F>(hipStream_t, const uint8_t*, size_t, size_t, long, Affine<F>*);                      \
     template int synth_points_launch<F>(hipStream_t, const XYZZ<F>*, const XYZZ<F>*, int, size_t, Affine<F>*);             \
     }

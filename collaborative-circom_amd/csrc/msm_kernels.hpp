@@ -598,6 +598,24 @@ __global__ void __launch_bounds__(256) k_check_on_curve(const Affine<F>* __restr
     }
 }
 
+// Subgroup check of the same parser step (`is_in_correct_subgroup_assuming_on_curve`): [r]P must be the point at infinity, r = the
+// scalar-field modulus (a plain double-and-add over the 254/255 bits of r; every lane walks the same bits, so no divergence).
+template <class F, class FrP>
+__global__ void __launch_bounds__(128) k_check_subgroup(const Affine<F>* __restrict__ pts, size_t n, unsigned long long* __restrict__ n_bad, unsigned long long* __restrict__ first_bad) {
+    uint32_t k[FrP::N];
+    _Pragma("unroll") for (int j = 0; j < FrP::N; j++) k[j] = FrP::P[j];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const Affine<F> p = ld_struct(pts + i);
+        if (p.is_inf()) continue;
+        XYZZ<F> r = XYZZ<F>::infinity();
+        for (int b = FrP::BITS - 1; b >= 0; b--) {
+            r = xyzz_dbl(r);
+            if ((k[b >> 5] >> (b & 31)) & 1u) r = xyzz_madd(r, p.x, p.y);
+        }
+        if (!r.is_inf()) { atomicAdd(n_bad, 1ull); atomicMin(first_bad, (unsigned long long)i); }
+    }
+}
+
 // Per-window precomputed tables: dst[i] = 2^c * src[i] in affine form (one inversion per point; run once per zkey table).
 template <class F>
 __global__ void __launch_bounds__(256) k_precompute_window(const Affine<F>* __restrict__ src, Affine<F>* __restrict__ dst, size_t n, int c) {

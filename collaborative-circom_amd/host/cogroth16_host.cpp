@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -437,11 +438,32 @@ public:
     }
 };
 
-static DeviceZKey upload_zkey(cg_ctx* ctx, const ZKey& z, const std::vector<Fr>& public_inputs) {
+// The reference's parser validates every point while decoding (circom-types/src/traits.rs:107-155: is_on_curve, then
+// is_in_correct_subgroup_assuming_on_curve; failure = SerializationError::InvalidData).  Here the packed sections go to the device
+// as they are and the same two predicates run there, one pass per table.
+static void validate_bases(cg_ctx* ctx, const cg_bases* b, const char* name) {
+    uint64_t bad = 0, first = 0;
+    CG(cg_bases_check_on_curve(ctx, b, &bad, &first));
+    if (bad) throw std::runtime_error(std::string("invalid data: ") + name + "[" + std::to_string(first) + "] is not on the curve (" + std::to_string(bad) + " bad points)");
+    CG(cg_bases_check_subgroup(ctx, b, &bad, &first));
+    if (bad) throw std::runtime_error(std::string("invalid data: ") + name + "[" + std::to_string(first) + "] is not in the correct subgroup (" + std::to_string(bad) + " bad points)");
+}
+
+static DeviceZKey upload_zkey(cg_ctx* ctx, const ZKey& z, const std::vector<Fr>& public_inputs, bool validate = false) {
     DeviceZKey d; d.z = &z;
     const Curve& c = z.curve;
-    auto reg = [&](const Bytes& pts, int group) { cg_bases* b; CG(cg_bases_register(ctx, c.id, group, pts.data(), pts.size() / c.aff(group), c.aff(group), -1, &b)); return b; };
-    d.a = reg(z.a_query, CG_G1); d.b1 = reg(z.b_g1_query, CG_G1); d.b2 = reg(z.b_g2_query, CG_G2); d.l = reg(z.l_query, CG_G1); d.h = reg(z.h_query, CG_G1);
+    auto reg = [&](const Bytes& pts, int group, const char* name = "") {
+        cg_bases* b; CG(cg_bases_register(ctx, c.id, group, pts.data(), pts.size() / c.aff(group), c.aff(group), -1, &b));
+        if (validate) { try { validate_bases(ctx, b, name); } catch (...) { cg_bases_release(b); throw; } }
+        return b;
+    };
+    if (validate) {   // the O(1) verifying-key points and IC go through the same kernels
+        Bytes g1 = z.alpha_g1; g1.insert(g1.end(), z.beta_g1.begin(), z.beta_g1.end()); g1.insert(g1.end(), z.delta_g1.begin(), z.delta_g1.end()); g1.insert(g1.end(), z.ic.begin(), z.ic.end());
+        Bytes g2 = z.beta_g2; g2.insert(g2.end(), z.gamma_g2.begin(), z.gamma_g2.end()); g2.insert(g2.end(), z.delta_g2.begin(), z.delta_g2.end());
+        cg_bases_release(reg(g1, CG_G1, "vk_g1/ic")); cg_bases_release(reg(g2, CG_G2, "vk_g2"));
+    }
+    d.a = reg(z.a_query, CG_G1, "a_query"); d.b1 = reg(z.b_g1_query, CG_G1, "b_g1_query"); d.b2 = reg(z.b_g2_query, CG_G2, "b_g2_query");
+    d.l = reg(z.l_query, CG_G1, "l_query"); d.h = reg(z.h_query, CG_G1, "h_query");
     auto up = [&](const void* src, size_t bytes) { void* p; CG(cg_dev_alloc(ctx, bytes, &p)); if (bytes) CG(cg_dev_upload(ctx, p, src, bytes)); return p; };
     for (int m = 0; m < 2; m++) {
         d.mat[m].row_ptr = (uint32_t*)up(z.row_ptr[m].data(), z.row_ptr[m].size() * 4);
@@ -475,6 +497,25 @@ int32_t cgh_zkey_info(int32_t curve, const char* path, size_t* info) {
         info[0] = z.n_vars; info[1] = z.n_public; info[2] = z.domain_size; info[3] = z.pow; info[4] = z.num_constraints; info[5] = z.col[0].size(); info[6] = z.col[1].size();
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+// zkey -> device with the parser's point validation done on the GPU (traits.rs:107-155); 0 = every point valid.  seconds[0] = file
+// read + section decode (host), seconds[1] = upload + validation (device)
+int32_t cgh_zkey_validate(int32_t device, int32_t curve, const char* path, double* seconds) {
+    cg_ctx* ctx = nullptr;
+    try {
+        using namespace cgh;
+        auto t0 = std::chrono::steady_clock::now();
+        ZKey z = read_zkey(curve, path);
+        auto t1 = std::chrono::steady_clock::now();
+        if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
+        std::vector<Fr> pub(z.n_public + 1);
+        DeviceZKey dz = upload_zkey(ctx, z, pub, true);
+        release_zkey(ctx, dz);
+        cg_ctx_destroy(ctx);
+        auto t2 = std::chrono::steady_clock::now();
+        if (seconds) { seconds[0] = std::chrono::duration<double>(t1 - t0).count(); seconds[1] = std::chrono::duration<double>(t2 - t1).count(); }
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
 }
 int32_t cgh_read_wtns(int32_t curve, const char* path, uint64_t* out, size_t cap, size_t* n) {
     try {

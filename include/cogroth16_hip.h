@@ -68,8 +68,11 @@ int32_t cg_bases_register_device(cg_ctx* ctx, int32_t curve, int32_t group, cons
 int32_t cg_bases_release(cg_bases* bases);
 /* zkey fast path: the point validation the reference's parser does per point on the CPU (circom-types/src/traits.rs:118-123,
  * 148-153 `is_on_curve`) as one device pass over a registered table.  *n_bad = number of non-infinity records off the curve,
- * *first_bad (optional) = index of the first one (UINT64_MAX if none).  (The prime-order subgroup check of G2 is not included.) */
+ * *first_bad (optional) = index of the first one (UINT64_MAX if none). */
 int32_t cg_bases_check_on_curve(cg_ctx* ctx, const cg_bases* bases, uint64_t* n_bad, uint64_t* first_bad);
+/* second half of that validation (`is_in_correct_subgroup_assuming_on_curve`): counts the non-infinity records P with [r]P != 0,
+ * r = scalar-field modulus.  Assumes the records are on the curve.  BN254 G1 has cofactor 1 and is accepted without work. */
+int32_t cg_bases_check_subgroup(cg_ctx* ctx, const cg_bases* bases, uint64_t* n_bad, uint64_t* first_bad);
 /* Optional, once per table: precompute 2^(c*j) * P_i for every window j (affine, resident: (254/c + 1) x the table size).
  * MSMs over such a table then use ONE bucket set for all windows: 254/c + 1 mixed additions per point with c up to 22 instead
  * of 16 at the default c = 16, and no doublings in the final fold.  The zkey queries are fixed for the life of the process

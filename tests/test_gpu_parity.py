@@ -419,3 +419,83 @@ def test_bases_on_curve_check(ctx, curve_name):
         assert (nbad, first) == (1, k)
         assert orc.on_curve(curve, group, pts[k]) and not orc.on_curve(curve, group, bad[k])
         bases.release()
+
+
+# ---- points on the curve but outside the prime-order subgroup (Python integers; both base fields are = 3 mod 4) --------------------
+_Q = {BN254: 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+      BLS12_381: 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab}
+_R = {BN254: 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+      BLS12_381: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001}
+
+
+def _fp_sqrt(a, p):
+    s = pow(a, (p + 1) // 4, p)
+    return s if s * s % p == a % p else None
+
+
+def _fp2_mul(a, b, p): return ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+
+
+def _fp2_sqrt(a, p):
+    a0, a1 = a
+    if a1 == 0:
+        s = _fp_sqrt(a0, p)
+        if s is not None: return (s, 0)
+        s = _fp_sqrt(-a0 % p, p)
+        return (0, s) if s is not None else None
+    n = _fp_sqrt((a0 * a0 + a1 * a1) % p, p)
+    if n is None: return None
+    inv2 = pow(2, -1, p)
+    for t in ((a0 + n) * inv2 % p, (a0 - n) * inv2 % p):
+        x0 = _fp_sqrt(t, p)
+        if x0:
+            x = (x0, a1 * pow(2 * x0, -1, p) % p)
+            if _fp2_mul(x, x, p) == (a0 % p, a1 % p): return x
+    return None
+
+
+def off_subgroup_point(curve, group):
+    """an affine point satisfying the curve equation, found by incrementing x; lies outside the r-torsion with overwhelming probability"""
+    p = _Q[curve]
+    mont = lambda v: orc.from_dec(curve, FQ, str(v % p))
+    if group == G1:
+        b = 3 if curve == BN254 else 4
+        for x in range(1, 100):
+            y = _fp_sqrt((x * x * x + b) % p, p)
+            if y is not None: return np.concatenate([mont(x), mont(y)])
+    else:
+        if curve == BN254:
+            inv = pow(82, -1, p)                                 # 3 / (9 + u) = 3 (9 - u) / 82
+            b = (27 * inv % p, -3 * inv % p)
+        else:
+            b = (4, 4)
+        for k in range(1, 100):
+            x = (k, 1)
+            x3 = _fp2_mul(_fp2_mul(x, x, p), x, p)
+            y = _fp2_sqrt(((x3[0] + b[0]) % p, (x3[1] + b[1]) % p), p)
+            if y is not None: return np.concatenate([mont(x[0]), mont(x[1]), mont(y[0]), mont(y[1])])
+    raise AssertionError("no point found")
+
+
+@pytest.mark.parametrize("curve_name,group", [("bn254", G2), ("bls12_381", G1), ("bls12_381", G2), ("bn254", G1)])
+def test_bases_subgroup_check(ctx, curve_name, group):
+    """device-side subgroup validation (is_in_correct_subgroup_assuming_on_curve, circom-types/src/traits.rs:121,151)"""
+    curve = {"bn254": BN254, "bls12_381": BLS12_381}[curve_name]
+    z = orc.ZKey(curve, os.path.join(GOLDEN, "groth16", curve_name, "poseidon", "circuit.zkey"))
+    pts = z.points("a_query" if group == G1 else "b_g2_query")
+    bases = ctx.register_bases(curve, group, pts)
+    assert ctx.check_on_curve(bases) == (0, None) and ctx.check_subgroup(bases) == (0, None)      # real zkey tables pass
+    bases.release()
+    if curve == BN254 and group == G1:
+        return                                                   # cofactor 1: there is no off-subgroup curve point
+    bad = off_subgroup_point(curve, group)
+    assert orc.on_curve(curve, group, bad)
+    r_minus_1 = orc.from_dec(curve, FR, str(_R[curve] - 1))
+    rp = orc.point_add(curve, group, orc.points_mul(curve, group, bad[None, :], r_minus_1[None, :])[0], bad)
+    assert rp.any()                                              # oracle: [r]P != infinity, i.e. P is outside the subgroup
+    k = 57
+    tampered = pts.copy(); tampered[k] = bad
+    bases = ctx.register_bases(curve, group, tampered)
+    assert ctx.check_on_curve(bases) == (0, None)                # still on the curve ...
+    assert ctx.check_subgroup(bases) == (1, k)                   # ... but caught by the subgroup pass
+    bases.release()

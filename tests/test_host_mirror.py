@@ -88,3 +88,41 @@ def test_rep3_three_parties_bit_identical_and_verify(curve_name, circuit):
     np.testing.assert_array_equal(proofs, want)               # identical to the oracle's three proofs
     vk = orc.vk_from_json(curve, fx(curve_name, circuit, "verification_key.json"))
     assert orc.verify(curve, vk, w[1:1 + z.n_public], proofs[0])
+
+
+def _zkey_sections(blob):
+    """{section id: (offset, length)} of a zkey container (binfile.rs:52-97)"""
+    assert blob[:4] == b"zkey"
+    ns = int.from_bytes(blob[8:12], "little")
+    off, out = 12, {}
+    for _ in range(ns):
+        sid = int.from_bytes(blob[off:off + 4], "little"); ln = int.from_bytes(blob[off + 4:off + 12], "little")
+        out[sid] = (off + 12, ln); off += 12 + ln
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_zkey_validation_on_device(curve_name, tmp_path):
+    """the parser's per-point checks (circom-types/src/traits.rs:107-155) run on the GPU at upload: the fixtures pass, a corrupted
+    coordinate is reported as off-curve, an on-curve point outside the r-torsion as a subgroup failure — each with table and index"""
+    from oracle_lib import G2
+    from test_gpu_parity import off_subgroup_point
+    ensure_built()
+    curve = CURVES[curve_name]
+    for circuit in ("multiplier2", "poseidon"):
+        cg.host_zkey_validate(curve, fx(curve_name, circuit, "circuit.zkey"))
+    blob = bytearray(open(fx(curve_name, "poseidon", "circuit.zkey"), "rb").read())
+    sec = _zkey_sections(blob)
+    nq = 32 if curve == BN254 else 48
+    # (1) flip one bit of a_query[5].x  -> not on the curve
+    bad = bytearray(blob); bad[sec[5][0] + 5 * 2 * nq + 3] ^= 0x10
+    p1 = tmp_path / "offcurve.zkey"; p1.write_bytes(bad)
+    with pytest.raises(cg.BackendError, match=r"a_query\[5\] is not on the curve"):
+        cg.host_zkey_validate(curve, str(p1))
+    # (2) b_g2_query[9] := a curve point outside the subgroup
+    pt = off_subgroup_point(curve, G2)
+    bad = bytearray(blob); o = sec[7][0] + 9 * 4 * nq; bad[o:o + 4 * nq] = pt.tobytes()
+    p2 = tmp_path / "offsubgroup.zkey"; p2.write_bytes(bad)
+    with pytest.raises(cg.BackendError, match=r"b_g2_query\[9\] is not in the correct subgroup"):
+        cg.host_zkey_validate(curve, str(p2))
