@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev",
     "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
     "cg_point_add", "cg_point_neg", "cg_point_scalar_mul", "cg_point_to_affine", "cg_point_from_affine", "cg_fr_op",
-    "cg_fr_from_canonical", "cg_fr_to_canonical", "cg_point_generator",
+    "cg_fr_from_canonical", "cg_fr_to_canonical", "cg_fq_to_canonical", "cg_fq_from_canonical", "cg_point_generator",
     "cg_bases_synth_multiples", "cg_bases_download",
     "cg_stats_enable", "cg_stats",
 ]
@@ -410,6 +410,28 @@ def host_zkey_validate(curve, path, device=0):
     secs = (C.c_double * 2)()
     _hchk(load_host().cgh_zkey_validate(int(device), curve, path.encode(), secs))
     return float(secs[0]), float(secs[1])
+
+
+def host_proof_to_json(curve, proof):
+    """Groth16Proof JSON text (proof.rs:8-29) of a packed proof A || B || C"""
+    buf = C.create_string_buffer(4096)
+    _hchk(load_host().cgh_proof_to_json(curve, _hp(np.ascontiguousarray(proof, dtype=np.uint64)), buf, C.c_size_t(4096)))
+    return buf.value.decode()
+
+
+def host_proof_from_json(curve, text):
+    nq = 6 if curve == BLS12_381 else 4
+    out = np.zeros(8 * nq, dtype=np.uint64)
+    _hchk(load_host().cgh_proof_from_json(curve, text.encode(), _hp(out)))
+    return out
+
+
+def host_public_to_json(curve, pub):
+    """public.json text (co-circom.rs:620-628) of n public signals in Montgomery form (without the leading constant 1)"""
+    pub = np.ascontiguousarray(pub, dtype=np.uint64).reshape(-1, 4)
+    buf = C.create_string_buffer(96 * max(1, pub.shape[0]) + 16)
+    _hchk(load_host().cgh_public_to_json(curve, _hp(pub), C.c_size_t(pub.shape[0]), buf, C.c_size_t(len(buf))))
+    return buf.value.decode()
 
 
 def host_read_wtns(curve, path):

@@ -149,6 +149,15 @@ template <class Fn> int with_fr(int curve, Fn&& fn) {
 #endif
     return fail(CG_ERR_ARG, "unknown curve id");
 }
+template <class Fn> int with_fq(int curve, Fn&& fn) {
+    if (curve == CG_BN254) return fn(Bn254Fq{});
+#if CG_WITH_BLS
+    if (curve == CG_BLS12_381) return fn(Bls381Fq{});
+#else
+    if (curve == CG_BLS12_381) return fail(CG_ERR_ARG, "library built without BLS12-381 (make BLS=1)");
+#endif
+    return fail(CG_ERR_ARG, "unknown curve id");
+}
 template <class Fn> int with_group(int curve, int group, Fn&& fn) {
     if (curve == CG_BN254 && group == CG_G1) return fn(Bn254Fq{}, Bn254Fr{});
     if (curve == CG_BN254 && group == CG_G2) return fn(Fp2<Bn254Fq>{}, Bn254Fr{});
@@ -943,6 +952,27 @@ int32_t cg_fr_to_canonical(int32_t curve, const void* h_in, void* h_out, size_t 
         typedef decltype(tag) Fr;
         const uint8_t* in = (const uint8_t*)h_in; uint8_t* out = (uint8_t*)h_out;
         for (size_t i = 0; i < n; i++) { Fr a; memcpy(a.v, in + i * sizeof a.v, sizeof a.v); Fr c = a.from_mont(); memcpy(out + i * sizeof a.v, c.v, sizeof c.v); }
+        return 0;
+    });
+}
+// base-field coordinates <-> canonical little-endian (proof / verification-key JSON carries decimal canonical values, traits.rs:186-233)
+int32_t cg_fq_to_canonical(int32_t curve, const void* h_in, void* h_out, size_t n) {
+    return with_fq(curve, [&](auto ftag) -> int {
+        typedef decltype(ftag) Fq;
+        const uint8_t* in = (const uint8_t*)h_in; uint8_t* out = (uint8_t*)h_out;
+        for (size_t i = 0; i < n; i++) { Fq a; memcpy(a.v, in + i * sizeof a.v, sizeof a.v); Fq c = a.from_mont(); memcpy(out + i * sizeof a.v, c.v, sizeof c.v); }
+        return 0;
+    });
+}
+int32_t cg_fq_from_canonical(int32_t curve, const void* h_in, void* h_out, size_t n) {   // input must be < q
+    return with_fq(curve, [&](auto ftag) -> int {
+        typedef decltype(ftag) Fq;
+        const uint8_t* in = (const uint8_t*)h_in; uint8_t* out = (uint8_t*)h_out;
+        for (size_t i = 0; i < n; i++) {
+            Fq a; memcpy(a.v, in + i * sizeof a.v, sizeof a.v);
+            for (int l = Fq::N - 1; l >= 0; l--) { if (a.v[l] < Fq::Params::P[l]) break; if (a.v[l] > Fq::Params::P[l] || l == 0) return fail(CG_ERR_ARG, "coordinate not reduced"); }
+            Fq m = a.to_mont(); memcpy(out + i * sizeof a.v, m.v, sizeof m.v);
+        }
         return 0;
     });
 }

@@ -482,6 +482,84 @@ static void release_zkey(cg_ctx* ctx, DeviceZKey& d) {
 
 static void store_proof(const Proof& p, uint8_t* out) { memcpy(out, p.a.data(), p.a.size()); memcpy(out + p.a.size(), p.b.data(), p.b.size()); memcpy(out + p.a.size() + p.b.size(), p.c.data(), p.c.size()); }
 
+// ---- JSON encodings of proofs and public inputs (circom-types/src/groth16/proof.rs:8-29, traits.rs:186-233, co-circom.rs:540,628) ----
+static std::string limbs_to_dec(const uint64_t* limbs, int n) {          // canonical little-endian -> decimal
+    std::vector<uint32_t> w(2 * n);
+    for (int i = 0; i < n; i++) { w[2 * i] = (uint32_t)limbs[i]; w[2 * i + 1] = (uint32_t)(limbs[i] >> 32); }
+    std::string out;
+    while (true) {
+        uint64_t rem = 0; bool nz = false;
+        for (int i = (int)w.size() - 1; i >= 0; i--) { uint64_t cur = (rem << 32) | w[i]; w[i] = (uint32_t)(cur / 1000000000u); rem = cur % 1000000000u; nz = nz || w[i]; }
+        char buf[16];
+        if (nz) { snprintf(buf, sizeof buf, "%09u", (unsigned)rem); out.insert(0, buf); }
+        else { snprintf(buf, sizeof buf, "%u", (unsigned)rem); out.insert(0, buf); break; }
+    }
+    return out;
+}
+static void dec_to_limbs(const std::string& sdec, uint64_t* limbs, int n) {   // decimal -> canonical little-endian (must fit)
+    std::vector<uint32_t> w(2 * n, 0);
+    if (sdec.empty()) throw std::runtime_error("empty number");
+    for (char ch : sdec) {
+        if (ch < '0' || ch > '9') throw std::runtime_error("invalid decimal digit");
+        uint64_t carry = (uint64_t)(ch - '0');
+        for (size_t i = 0; i < w.size(); i++) { uint64_t cur = (uint64_t)w[i] * 10u + carry; w[i] = (uint32_t)cur; carry = cur >> 32; }
+        if (carry) throw std::runtime_error("number too large for the field");
+    }
+    for (int i = 0; i < n; i++) limbs[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+}
+static std::string fq_dec(const Curve& c, const uint8_t* mont) {
+    uint64_t can[6]; CG(cg_fq_to_canonical(c.id, mont, can, 1));
+    return limbs_to_dec(can, (int)c.fq() / 8);
+}
+static bool all_zero(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
+static const char* curve_name(const Curve& c) { return c.id == CG_BN254 ? "bn128" : "bls12381"; }    // traits.rs:18,31
+static std::string g1_json(const Curve& c, const uint8_t* aff) {
+    if (all_zero(aff, c.aff(CG_G1))) return "[\"0\",\"1\",\"0\"]";                                       // traits.rs:190-192
+    return "[\"" + fq_dec(c, aff) + "\",\"" + fq_dec(c, aff + c.fq()) + "\",\"1\"]";
+}
+static std::string g2_json(const Curve& c, const uint8_t* aff) {
+    if (all_zero(aff, c.aff(CG_G2))) throw std::runtime_error("the point at infinity has no G2 JSON encoding (the reference unwraps xy(), traits.rs:227)");
+    const size_t q = c.fq();
+    return "[[\"" + fq_dec(c, aff) + "\",\"" + fq_dec(c, aff + q) + "\"],[\"" + fq_dec(c, aff + 2 * q) + "\",\"" + fq_dec(c, aff + 3 * q) + "\"],[\"1\",\"0\"]]";
+}
+static std::string proof_to_json(const Curve& c, const uint8_t* packed) {   // packed = A (G1) || B (G2) || C (G1)
+    const uint8_t *a = packed, *b = packed + c.aff(CG_G1), *cc = b + c.aff(CG_G2);
+    return "{\"pi_a\":" + g1_json(c, a) + ",\"pi_b\":" + g2_json(c, b) + ",\"pi_c\":" + g1_json(c, cc) + ",\"protocol\":\"groth16\",\"curve\":\"" + curve_name(c) + "\"}";
+}
+// the decimal strings of a JSON document, in order (the proof schema is fixed: keys pi_a, pi_b, pi_c carry 3 + 6 + 3 numbers)
+static std::vector<std::string> json_numbers_after(const std::string& js, const char* key, size_t count) {
+    size_t pos = js.find(std::string("\"") + key + "\"");
+    if (pos == std::string::npos) throw std::runtime_error(std::string("missing key ") + key);
+    pos = js.find(':', pos);
+    std::vector<std::string> out;
+    while (out.size() < count) {
+        size_t q0 = js.find('"', pos + 1);
+        if (q0 == std::string::npos) throw std::runtime_error("truncated proof JSON");
+        size_t q1 = js.find('"', q0 + 1);
+        if (q1 == std::string::npos) throw std::runtime_error("truncated proof JSON");
+        out.push_back(js.substr(q0 + 1, q1 - q0 - 1));
+        pos = q1;
+    }
+    return out;
+}
+static void proof_from_json(const Curve& c, const std::string& js, uint8_t* packed) {
+    if (js.find(std::string("\"") + curve_name(c) + "\"") == std::string::npos) throw std::runtime_error("proof is for another curve");
+    const int nl = (int)c.fq() / 8;
+    auto put = [&](const std::string& d, uint8_t* dst) { uint64_t can[6] = {0}; dec_to_limbs(d, can, nl); CG(cg_fq_from_canonical(c.id, can, dst, 1)); };
+    auto g1 = [&](const char* key, uint8_t* dst) {
+        auto v = json_numbers_after(js, key, 3);
+        if (v[2] == "0") { memset(dst, 0, c.aff(CG_G1)); return; }          // projective z = 0: infinity
+        if (v[2] != "1") throw std::runtime_error("only z = 1 / z = 0 G1 encodings are produced by circom tools");
+        put(v[0], dst); put(v[1], dst + c.fq());
+    };
+    g1("pi_a", packed);
+    auto v = json_numbers_after(js, "pi_b", 6);
+    if (v[4] != "1" || v[5] != "0") throw std::runtime_error("only z = (1, 0) G2 encodings are produced by circom tools");
+    uint8_t* b = packed + c.aff(CG_G1);
+    for (int i = 0; i < 4; i++) put(v[i], b + i * c.fq());
+    g1("pi_c", b + c.aff(CG_G2));
+}
+
 }  // namespace cgh
 
 // ==================================================================================================== C entry points (tests / tools)
@@ -516,6 +594,31 @@ int32_t cgh_zkey_validate(int32_t device, int32_t curve, const char* path, doubl
         if (seconds) { seconds[0] = std::chrono::duration<double>(t1 - t0).count(); seconds[1] = std::chrono::duration<double>(t2 - t1).count(); }
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
+}
+static int32_t copy_out(const std::string& js, char* out, size_t cap) {
+    if (js.size() + 1 > cap) { g_host_err = "buffer too small"; return 1; }
+    memcpy(out, js.c_str(), js.size() + 1);
+    return 0;
+}
+// Groth16Proof <-> JSON (proof.rs:8-29); proof = A || B || C packed affine Montgomery as returned by cgh_prove_*
+int32_t cgh_proof_to_json(int32_t curve, const uint64_t* proof, char* out, size_t cap) {
+    try { return copy_out(cgh::proof_to_json(cgh::Curve{curve}, (const uint8_t*)proof), out, cap); }
+    catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+int32_t cgh_proof_from_json(int32_t curve, const char* json, uint64_t* out_proof) {
+    try { cgh::proof_from_json(cgh::Curve{curve}, json, (uint8_t*)out_proof); return 0; }
+    catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+// public.json (co-circom.rs:620-628): the public signals without the leading constant 1, as decimal strings; pub = n Montgomery elements
+int32_t cgh_public_to_json(int32_t curve, const uint64_t* pub, size_t n, char* out, size_t cap) {
+    try {
+        std::string js = "[";
+        for (size_t i = 0; i < n; i++) {
+            uint64_t can[4]; if (cg_fr_to_canonical(curve, pub + 4 * i, can, 1)) cgh::die("cg_fr_to_canonical");
+            js += (i ? ",\"" : "\"") + cgh::limbs_to_dec(can, 4) + "\"";
+        }
+        return copy_out(js + "]", out, cap);
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
 int32_t cgh_read_wtns(int32_t curve, const char* path, uint64_t* out, size_t cap, size_t* n) {
     try {

@@ -149,6 +149,10 @@ int32_t cg_fr_op(int32_t curve, int32_t op, const void* h_a, const void* h_b, vo
  * cg_fr_from_canonical reduces mod r first (from_le_bytes_mod_order, traits.rs:50-54). */
 int32_t cg_fr_from_canonical(int32_t curve, const void* h_in, void* h_out, size_t n);
 int32_t cg_fr_to_canonical(int32_t curve, const void* h_in, void* h_out, size_t n);
+/* base-field coordinates (32 B BN254 / 48 B BLS12-381 each), Montgomery <-> canonical little-endian: what the JSON encodings of
+ * proofs and verification keys carry as decimal strings (circom-types/src/traits.rs:186-233).  from_canonical rejects values >= q. */
+int32_t cg_fq_to_canonical(int32_t curve, const void* h_in, void* h_out, size_t n);
+int32_t cg_fq_from_canonical(int32_t curve, const void* h_in, void* h_out, size_t n);
 /* generator of G1/G2 as a Jacobian point (ark-bn254 / ark-bls12-381 constants) */
 int32_t cg_point_generator(int32_t curve, int32_t group, void* h_out);
 

@@ -126,3 +126,29 @@ def test_zkey_validation_on_device(curve_name, tmp_path):
     p2 = tmp_path / "offsubgroup.zkey"; p2.write_bytes(bad)
     with pytest.raises(cg.BackendError, match=r"b_g2_query\[9\] is not in the correct subgroup"):
         cg.host_zkey_validate(curve, str(p2))
+
+
+@pytest.mark.parametrize("curve_name,circuit", FIXTURES)
+def test_proof_and_public_json_match_reference_fixtures(curve_name, circuit):
+    """host JSON codecs against the snarkjs files the reference's tests deserialize (circom-types/src/groth16/proof.rs:43-107,
+    co-groth16/src/lib.rs:56-140): text -> packed proof equals the oracle's parse; packed proof -> text parses back to the same
+    JSON document; public inputs likewise"""
+    ensure_built()
+    curve = CURVES[curve_name]
+    text = open(fx(curve_name, circuit, "circom.proof")).read()
+    packed = cg.host_proof_from_json(curve, text)
+    np.testing.assert_array_equal(packed, orc.proof_from_json(curve, fx(curve_name, circuit, "circom.proof")))
+    assert json.loads(cg.host_proof_to_json(curve, packed)) == json.loads(text)
+    pub = orc.public_from_json(curve, fx(curve_name, circuit, "public.json"))
+    assert json.loads(cg.host_public_to_json(curve, pub)) == json.load(open(fx(curve_name, circuit, "public.json")))
+    with pytest.raises(cg.BackendError):
+        cg.host_proof_from_json(BLS12_381 if curve == BN254 else BN254, text)        # curve tag mismatch
+    # G1 infinity uses the projective encoding ["0","1","0"] (traits.rs:190-192); G2 infinity has none (the reference unwraps)
+    nq = packed.shape[0] // 8
+    inf_a = packed.copy(); inf_a[:2 * nq] = 0
+    doc = json.loads(cg.host_proof_to_json(curve, inf_a))
+    assert doc["pi_a"] == ["0", "1", "0"]
+    np.testing.assert_array_equal(cg.host_proof_from_json(curve, json.dumps(doc)), inf_a)
+    inf_b = packed.copy(); inf_b[2 * nq:6 * nq] = 0
+    with pytest.raises(cg.BackendError):
+        cg.host_proof_to_json(curve, inf_b)
