@@ -6,6 +6,7 @@
 #include "pairing.hpp"
 #include "bench.hpp"
 #include "synth.hpp"
+#include "plonk.hpp"
 #include <chrono>
 
 using namespace orc;
@@ -248,6 +249,46 @@ int orc_wtns_read(int curve, const char* path, uint64_t* out, size_t cap, size_t
         auto w = read_wtns<typename C::Fr>(path);
         *n = w.size();
         if (out) { if (w.size() > cap) { g_err = "buffer too small"; return -3; } memcpy(out, w.data(), w.size() * sizeof(typename C::Fr)); }
+    });
+    return 0;
+}
+
+// ---- co-plonk round 1 (plonk.hpp) ----------------------------------------------------------------------
+// info: n_vars, n_public, domain_size, power, n_additions, n_constraints
+int orc_plonk_zkey_info(int curve, const char* path, size_t* info) {
+    DISPATCH(curve, {
+        auto z = read_plonk_zkey<C>(path);
+        info[0] = z.n_vars; info[1] = z.n_public; info[2] = z.domain_size; info[3] = z.power; info[4] = z.n_additions; info[5] = z.n_constraints;
+    });
+    return 0;
+}
+// maps: 3 x n_constraints u32 (a, b, c); additions: n_additions x (id1, id2) u32 and x (f1, f2) Fr; p_tau: (domain_size + 6) packed G1
+int orc_plonk_zkey_data(int curve, const char* path, uint32_t* maps, uint32_t* add_ids, uint64_t* add_factors, uint64_t* p_tau) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr; typedef typename C::Fq Fq;
+        auto z = read_plonk_zkey<C>(path);
+        for (size_t i = 0; i < z.n_constraints; i++) { maps[i] = z.map_a[i]; maps[z.n_constraints + i] = z.map_b[i]; maps[2 * z.n_constraints + i] = z.map_c[i]; }
+        for (size_t i = 0; i < z.n_additions; i++) {
+            add_ids[2 * i] = z.additions[i].id1; add_ids[2 * i + 1] = z.additions[i].id2;
+            st<Fr>(add_factors + 2 * i * Fr::N, z.additions[i].f1); st<Fr>(add_factors + (2 * i + 1) * Fr::N, z.additions[i].f2);
+        }
+        for (size_t i = 0; i < z.p_tau.size(); i++) st_g1<Fq>(p_tau + i * 2 * Fq::N, z.p_tau[i]);
+    });
+    return 0;
+}
+// full_witness: n_vars - n_additions Montgomery elements (Groth16-style, leading one); blind: 6 Fr; out: 3 packed G1 (a, b, c);
+// polys (optional): 3 x (domain_size + 2) blinded coefficient vectors
+int orc_plonk_round1_plain(int curve, const char* path, const uint64_t* full_witness, const uint64_t* blind, uint64_t* out_commits, uint64_t* polys) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr; typedef typename C::Fq Fq;
+        auto z = read_plonk_zkey<C>(path);
+        const Fr* w = reinterpret_cast<const Fr*>(full_witness);
+        std::vector<Fr> fw(w, w + (z.n_vars - z.n_additions));
+        Fr b[6]; for (int i = 0; i < 6; i++) b[i] = ld<Fr>(blind + i * Fr::N);
+        std::vector<Fr> pl;
+        auto cm = plonk_round1_plain<C>(z, fw, b, polys ? &pl : nullptr);
+        for (int i = 0; i < 3; i++) st_g1<Fq>(out_commits + i * 2 * Fq::N, cm[i]);
+        if (polys) memcpy(polys, pl.data(), pl.size() * sizeof(Fr));
     });
     return 0;
 }

@@ -7,6 +7,7 @@ Sources (values only, no code is copied):
   /root/reference/co-circom/circom-types/src/groth16/zkey.rs:336-719   zkey decode KATs (multiplier2, both curves)
   /root/reference/mpc-core/tests/protocols/rep3.rs:242-350             Fr product KAT (rep3_mul_vec_bn)
   /root/reference/co-circom/circom-types/src/witness.rs:101-134        witness KAT
+  /root/reference/co-circom/co-plonk/src/round1.rs:346-428             Plonk round-1 commitments [a]_1, [b]_1, [c]_1 (blinding b_i = i)
 """
 import json, re, sys, os
 
@@ -65,6 +66,19 @@ for name in ("fq_buf", "g1_buf", "g2_buf"):
     m = re.search(r"fn %s\(\) -> Vec<u8> \{\s*vec!\[(.*?)\]" % name, zsrc, re.S)
     bufs[name] = [int(x) for x in re.findall(r"\d+", m.group(1))]
 out["bn254_one_bytes"] = bufs
+
+# Plonk round 1: exact commitments for the deterministic blinding b_i = i (Round1Challenges::deterministic, round1.rs:99-107)
+src = open(f"{REF}/co-circom/co-plonk/src/round1.rs").read()
+pk = {}
+for t in re.split(r"#\[test\]", src)[1:]:
+    name = re.search(r"fn\s+(\w+)", t).group(1)
+    path = re.search(r'File::open\("([^"]+circuit\.zkey)"\)', t)
+    entry = {"file": path.group(1).replace("../../test_vectors/", "") if path else None}
+    for which in ("commit_a", "commit_b", "commit_c"):
+        m = re.search(r"proof\.%s[^,]*,\s*g1_\w+_from_xy!\(\s*\"(\d+)\",\s*\"(\d+)\"" % which, t, re.S)
+        entry[which] = [m.group(1), m.group(2)]
+    pk[name] = entry
+out["plonk_round1"] = pk
 
 dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")
 json.dump(out, open(dst, "w"), indent=1)

@@ -349,3 +349,31 @@ def random_field(curve, which, n, rng):
         out[todo[~ge]] = x[~ge]
         todo = todo[ge]
     return out
+
+
+# ---- co-plonk round 1 (oracle/plonk.hpp) -----------------------------------------------------------------
+def plonk_zkey_info(curve, path):
+    info = (C.c_size_t * 6)()
+    _chk(lib().orc_plonk_zkey_info(curve, path.encode(), info))
+    return dict(zip(("n_vars", "n_public", "domain_size", "power", "n_additions", "n_constraints"), [int(x) for x in info]))
+
+
+def plonk_zkey_data(curve, path):
+    i = plonk_zkey_info(curve, path)
+    nq = nlimbs(curve, FQ)
+    maps = np.zeros((3, i["n_constraints"]), dtype=np.uint32)
+    add_ids = np.zeros((i["n_additions"], 2), dtype=np.uint32)
+    add_f = np.zeros((i["n_additions"], 2, 4), dtype=np.uint64)
+    p_tau = np.zeros((i["domain_size"] + 6, 2 * nq), dtype=np.uint64)
+    _chk(lib().orc_plonk_zkey_data(curve, path.encode(), _p(maps), _p(add_ids), _p(add_f), _p(p_tau)))
+    return maps, add_ids, add_f, p_tau
+
+
+def plonk_round1_plain(curve, path, full_witness, blind, want_polys=False):
+    i = plonk_zkey_info(curve, path)
+    nq = nlimbs(curve, FQ)
+    out = np.zeros((3, 2 * nq), dtype=np.uint64)
+    polys = np.zeros((3, i["domain_size"] + 2, 4), dtype=np.uint64) if want_polys else None
+    _chk(lib().orc_plonk_round1_plain(curve, path.encode(), _p(np.ascontiguousarray(full_witness, dtype=np.uint64)),
+                                      _p(np.ascontiguousarray(blind, dtype=np.uint64)), _p(out), _p(polys) if want_polys else None))
+    return (out, polys) if want_polys else out
