@@ -434,6 +434,32 @@ def host_public_to_json(curve, pub):
     return buf.value.decode()
 
 
+def host_plonk_zkey_info(curve, path):
+    info = (C.c_size_t * 6)()
+    _hchk(load_host().cgh_plonk_zkey_info(curve, path.encode(), info))
+    return dict(zip(("n_vars", "n_public", "domain_size", "power", "n_additions", "n_constraints"), [int(x) for x in info]))
+
+
+def plonk_round1_plain(curve, zkey_path, full_witness, blind, device=0):
+    """co-plonk round 1 with the plain driver on the GPU: the three wire commitments (3, packed G1)"""
+    nq = 6 if curve == BLS12_381 else 4
+    out = np.zeros((3, 2 * nq), dtype=np.uint64)
+    _hchk(load_host().cgh_plonk_round1_plain(int(device), curve, zkey_path.encode(), _hp(np.ascontiguousarray(full_witness, dtype=np.uint64)),
+                                             _hp(np.ascontiguousarray(blind, dtype=np.uint64)), _hp(out)))
+    return out
+
+
+def plonk_round1_rep3(curve, zkey_path, pub, wit_a, wit_b, blind_a, blind_b, device=0):
+    """three REP3 parties (threads) on one GPU; returns (3 parties, 3 commitments, packed G1)"""
+    nq = 6 if curve == BLS12_381 else 4
+    out = np.zeros((3, 3, 2 * nq), dtype=np.uint64)
+    keep = [[np.ascontiguousarray(x, dtype=np.uint64) for x in lst] for lst in (wit_a, wit_b, blind_a, blind_b)]
+    arr = lambda lst: (C.c_void_p * 3)(*[x.ctypes.data for x in lst])
+    _hchk(load_host().cgh_plonk_round1_rep3(int(device), curve, zkey_path.encode(), _hp(np.ascontiguousarray(pub, dtype=np.uint64)),
+                                            arr(keep[0]), arr(keep[1]), arr(keep[2]), arr(keep[3]), _hp(out)))
+    return out
+
+
 def host_read_wtns(curve, path):
     n = C.c_size_t(0)
     _hchk(load_host().cgh_read_wtns(curve, path.encode(), None, C.c_size_t(0), C.byref(n)))

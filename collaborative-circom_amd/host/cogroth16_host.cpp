@@ -173,7 +173,9 @@ static std::vector<Fr> read_wtns(int curve_id, const std::string& path) {   // w
 
 // co-circom-snarks/src/lib.rs:208-221 + groth16.rs:57-77
 struct Domain { size_t m; int log_m; Fr omega, coset_g; };
-static Domain groth16_domain(const Curve& c, size_t pow, size_t num_constraints, size_t num_inputs) {
+// roots[i] = primitive 2^i-th root of unity derived from the smallest quadratic non-residue (co-circom-snarks/src/lib.rs:208-221)
+struct SnarkjsRoots { Fr q; std::vector<Fr> roots; int two_adicity; };
+static SnarkjsRoots snarkjs_roots(const Curve& c) {
     const uint64_t* r = MOD_R[c.id];
     uint64_t t[4] = {r[0] - 1, r[1], r[2], r[3]};
     int s = 0;
@@ -186,11 +188,14 @@ static Domain groth16_domain(const Curve& c, size_t pow, size_t num_constraints,
     std::vector<Fr> roots(s + 1);
     roots[0] = fr_pow(c, q, t, 4);
     for (int i = 1; i <= s; i++) roots[i] = fr_mul(c, roots[i - 1], roots[i - 1]);
-    std::vector<Fr> rev(roots.rbegin(), roots.rend());
+    return SnarkjsRoots{q, std::vector<Fr>(roots.rbegin(), roots.rend()), s};
+}
+static Domain groth16_domain(const Curve& c, size_t pow, size_t num_constraints, size_t num_inputs) {
+    const SnarkjsRoots rt = snarkjs_roots(c);
     Domain d; d.m = 1; d.log_m = 0;
     while (d.m < num_constraints + num_inputs) { d.m <<= 1; d.log_m++; }
-    d.omega = rev[pow];
-    d.coset_g = s == d.log_m ? fr_mul(c, q, q) : rev[d.log_m + 1];
+    d.omega = rt.roots[pow];
+    d.coset_g = rt.two_adicity == d.log_m ? fr_mul(c, rt.q, rt.q) : rt.roots[d.log_m + 1];
     return d;
 }
 
@@ -482,6 +487,123 @@ static void release_zkey(cg_ctx* ctx, DeviceZKey& d) {
 
 static void store_proof(const Proof& p, uint8_t* out) { memcpy(out, p.a.data(), p.a.size()); memcpy(out + p.a.size(), p.b.data(), p.b.size()); memcpy(out + p.a.size() + p.b.size(), p.c.data(), p.c.size()); }
 
+// ==================================================================================================== co-plonk, round 1
+// First slice of the Plonk prover on the same kernels: [a]_1, [b]_1, [c]_1 = MSM(p_tau, blind(iNTT(wire values))).
+// The reference pins the exact result for the blinding b_i = i (co-plonk/src/round1.rs:346-383).
+struct PlonkZKey {   // circom-types/src/plonk/zkey.rs:18-42 (the fields round 1 reads)
+    Curve curve;
+    size_t n_vars = 0, n_public = 0, domain_size = 0, power = 0, n_additions = 0, n_constraints = 0;
+    struct Addition { uint32_t id1, id2; Fr f1, f2; };
+    std::vector<Addition> additions;
+    std::vector<uint32_t> map[3];
+    Bytes p_tau;        // domain_size + 6 packed G1 points
+};
+static PlonkZKey read_plonk_zkey(int curve_id, const std::string& path) {   // zkey.rs:83-255, header :373-424
+    Curve c{curve_id};
+    Bytes buf = slurp(path);
+    Cursor cur{buf.data(), buf.size()};
+    char magic[5] = {0}; cur.bytes(magic, 4);
+    if (std::string(magic) != "zkey") throw std::runtime_error("not a zkey file");
+    cur.u32();
+    uint32_t ns = cur.u32();
+    std::map<uint32_t, std::pair<size_t, size_t>> sec;
+    for (uint32_t i = 0; i < ns; i++) { uint32_t id = cur.u32(); uint64_t len = cur.u64(); cur.need(len); sec[id] = {cur.off, (size_t)len}; cur.off += len; }
+    auto section = [&](uint32_t id) { auto it = sec.find(id); if (it == sec.end()) throw std::runtime_error("missing zkey section"); return Cursor{buf.data() + it->second.first, it->second.second}; };
+    if (section(1).u32() != 2) throw std::runtime_error("not a plonk zkey");
+    PlonkZKey z; z.curve = c;
+    Cursor h = section(2);
+    if (h.u32() != c.fq()) throw std::runtime_error("unexpected base field byte size");
+    uint64_t q[6] = {0}; h.bytes(q, c.fq());
+    if (memcmp(q, MOD_Q[curve_id], c.fq())) throw std::runtime_error("invalid base prime in header");
+    if (h.u32() != 32) throw std::runtime_error("unexpected scalar field byte size");
+    uint64_t r[4]; h.bytes(r, 32);
+    if (memcmp(r, MOD_R[curve_id], 32)) throw std::runtime_error("invalid scalar prime in header");
+    z.n_vars = h.u32(); z.n_public = h.u32(); z.domain_size = h.u32(); z.n_additions = h.u32(); z.n_constraints = h.u32();
+    if (!z.domain_size || (z.domain_size & (z.domain_size - 1))) throw std::runtime_error("Invalid domain size. Must be power of 2");
+    while (((size_t)1 << z.power) < z.domain_size) z.power++;
+    { Cursor a = section(3); z.additions.resize(z.n_additions); for (auto& e : z.additions) { e.id1 = a.u32(); e.id2 = a.u32(); a.bytes(e.f1.v, 32); a.bytes(e.f2.v, 32); } }
+    for (int k = 0; k < 3; k++) { Cursor m = section(4 + k); z.map[k].resize(z.n_constraints); for (auto& v : z.map[k]) v = m.u32(); }
+    { Cursor t = section(14); z.p_tau.resize((z.domain_size + 6) * c.aff(CG_G1)); t.bytes(z.p_tau.data(), z.p_tau.size()); }
+    return z;
+}
+
+class CoPlonkRound1 {
+public:
+    HipDriver& driver;
+    explicit CoPlonkRound1(HipDriver& d) : driver(d) {}
+
+    // promote_to_trivial_share (rep3/fieldshare.rs:72-78; plain: the value)
+    FieldShare trivial(const Fr& v) const {
+        FieldShare f; const Fr zero = fr_from_u64(driver.curve, 0);
+        f.c[0] = (driver.mode == Mode::Plain || driver.party() == 0) ? v : zero;
+        f.c[1] = (driver.mode == Mode::Rep3 && driver.party() == 1) ? v : zero;
+        return f;
+    }
+    // calculate_additions (round1.rs:208-238): witness || addition witnesses, so that get_witness(i) = ext[i - n_public - 1] (lib.rs:113-137)
+    ShareVec extend_witness(const PlonkZKey& z, const std::vector<Fr>& pub0, const ShareVec& wit) {
+        const Curve& c = driver.curve;
+        const size_t n_priv = z.n_vars - z.n_additions - z.n_public - 1;
+        if (wit.n != n_priv) throw std::runtime_error("witness length does not match the zkey");
+        std::vector<Fr> ext[2];
+        for (int j = 0; j < driver.k(); j++) { ext[j].resize(n_priv + z.n_additions); if (n_priv) CG(cg_dev_download(driver.ctx, ext[j].data(), wit.c[j], n_priv * 32)); }
+        size_t have = n_priv;
+        auto get = [&](size_t idx) -> FieldShare {
+            if (idx <= z.n_public) return trivial(pub0[idx]);
+            if (idx >= z.n_vars || idx - z.n_public - 1 >= have) throw std::runtime_error("Cannot index into witness " + std::to_string(idx));   // PlonkProofError::CorruptedWitness
+            FieldShare f; for (int j = 0; j < driver.k(); j++) f.c[j] = ext[j][idx - z.n_public - 1];
+            return f;
+        };
+        for (const auto& a : z.additions) {
+            FieldShare w1 = get(a.id1), w2 = get(a.id2);
+            for (int j = 0; j < driver.k(); j++) ext[j][have] = fr_add(c, fr_mul(c, a.f1, w1.c[j]), fr_mul(c, a.f2, w2.c[j]));      // mul_with_public, add
+            have++;
+        }
+        return driver.upload_vec(ext[0].data(), driver.k() == 2 ? ext[1].data() : nullptr, ext[0].size());
+    }
+    // round1.rs:118-206 + :260-312.  public_inputs = n_public + 1 values (entry 0 is overwritten by 0, types.rs:107-109);
+    // blind = b_1..b_6 as shares; polys_out (optional) receives the three blinded coefficient vectors (n + 2 each, device)
+    std::vector<Point> round1(const PlonkZKey& z, const cg_bases* p_tau, std::vector<Fr> public_inputs, const ShareVec& private_witness, const FieldShare* blind, ShareVec* polys_out = nullptr) {
+        const Curve& c = driver.curve;
+        cg_ctx* ctx = driver.ctx;
+        const size_t n = z.domain_size, nc = z.n_constraints;
+        if (public_inputs.size() != z.n_public + 1) throw std::runtime_error("public input length does not match the zkey");
+        if (n + 2 > z.domain_size + 6) throw std::runtime_error("polynomial degree too large");
+        public_inputs[0] = fr_from_u64(c, 0);
+        ShareVec ext = z.n_additions ? extend_witness(z, public_inputs, private_witness) : private_witness;
+        void* d_pub = driver.dalloc(public_inputs.size() * 32); CG(cg_dev_upload(ctx, d_pub, public_inputs.data(), public_inputs.size() * 32));
+        // the wire buffers are gathers: one-entry CSR rows with coefficient one reuse the constraint-evaluation kernel, which already
+        // implements get_witness' public/private split with the REP3 party asymmetry
+        std::vector<uint32_t> row_ptr(nc + 1); for (size_t i = 0; i <= nc; i++) row_ptr[i] = (uint32_t)i;
+        std::vector<Fr> ones(nc, fr_from_u64(c, 1));
+        uint32_t* d_rp = (uint32_t*)driver.dalloc((nc + 1) * 4); CG(cg_dev_upload(ctx, d_rp, row_ptr.data(), (nc + 1) * 4));
+        void* d_one = driver.dalloc(std::max<size_t>(nc, 1) * 32); if (nc) CG(cg_dev_upload(ctx, d_one, ones.data(), nc * 32));
+        uint32_t* d_col = (uint32_t*)driver.dalloc(std::max<size_t>(nc, 1) * 4);
+        const Fr omega = snarkjs_roots(c).roots[z.power];                                        // types.rs:70-84
+        std::vector<PointShare> commits;
+        for (int w = 0; w < 3; w++) {
+            if (nc) CG(cg_dev_upload(ctx, d_col, z.map[w].data(), nc * 4));
+            ShareVec poly = driver.alloc_vec(n + 2);                                              // zero-filled: rows >= n_constraints stay 0
+            CG(cg_spmv_csr_dev(ctx, c.id, d_rp, d_col, d_one, nc, d_pub, (uint32_t)(z.n_public + 1), driver.party(), ext.c[0], ext.c[1], poly.c[0], poly.c[1]));
+            CG(cg_ntt_dev(ctx, c.id, poly.c, driver.k(), n, omega.v, 1, nullptr));                // ifft over the first n entries
+            const FieldShare &b_hi = blind[2 * w], &b_lo = blind[2 * w + 1];                      // blind_coefficients, lib.rs:140-158
+            for (int j = 0; j < driver.k(); j++) {
+                Fr head[2]; CG(cg_dev_download(ctx, head, poly.c[j], 64));
+                head[0] = fr_sub(c, head[0], b_lo.c[j]); head[1] = fr_sub(c, head[1], b_hi.c[j]);
+                CG(cg_dev_upload(ctx, poly.c[j], head, 64));
+                Fr tail[2] = {b_lo.c[j], b_hi.c[j]};
+                CG(cg_dev_upload(ctx, (uint8_t*)poly.c[j] + n * 32, tail, 64));
+            }
+            commits.push_back(driver.msm_public_points(p_tau, CG_G1, 0, n + 2, poly));            // round1.rs:276-290
+            if (polys_out) polys_out[w] = poly; else driver.free_vec(poly);
+        }
+        std::vector<Point> opened;                                                                // open_point_many, round1.rs:292
+        for (auto& cm : commits) opened.push_back(driver.open_point(cm));
+        CG(cg_dev_free(ctx, d_pub)); CG(cg_dev_free(ctx, d_rp)); CG(cg_dev_free(ctx, d_one)); CG(cg_dev_free(ctx, d_col));
+        if (z.n_additions) driver.free_vec(ext);
+        return opened;
+    }
+};
+
 // ---- JSON encodings of proofs and public inputs (circom-types/src/groth16/proof.rs:8-29, traits.rs:186-233, co-circom.rs:540,628) ----
 static std::string limbs_to_dec(const uint64_t* limbs, int n) {          // canonical little-endian -> decimal
     std::vector<uint32_t> w(2 * n);
@@ -618,6 +740,73 @@ int32_t cgh_public_to_json(int32_t curve, const uint64_t* pub, size_t n, char* o
             js += (i ? ",\"" : "\"") + cgh::limbs_to_dec(can, 4) + "\"";
         }
         return copy_out(js + "]", out, cap);
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+// info: n_vars, n_public, domain_size, power, n_additions, n_constraints
+int32_t cgh_plonk_zkey_info(int32_t curve, const char* path, size_t* info) {
+    try {
+        cgh::PlonkZKey z = cgh::read_plonk_zkey(curve, path);
+        info[0] = z.n_vars; info[1] = z.n_public; info[2] = z.domain_size; info[3] = z.power; info[4] = z.n_additions; info[5] = z.n_constraints;
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+// PlainHipDriver: full_witness = n_vars - n_additions Montgomery elements (Groth16-style, leading one); blind = 6 Fr; out = 3 packed G1
+int32_t cgh_plonk_round1_plain(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* full_witness, const uint64_t* blind, uint64_t* out_commits) {
+    cg_ctx* ctx = nullptr;
+    try {
+        using namespace cgh;
+        PlonkZKey z = read_plonk_zkey(curve, zkey_path);
+        if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
+        const Curve& c = z.curve;
+        cg_bases* tau = nullptr; CG(cg_bases_register(ctx, c.id, CG_G1, z.p_tau.data(), z.domain_size + 6, c.aff(CG_G1), -1, &tau));
+        const Fr* w = (const Fr*)full_witness;
+        std::vector<Fr> pub(w, w + z.n_public + 1);
+        HipDriver driver(ctx, c, Mode::Plain, nullptr);
+        ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_additions - z.n_public - 1);
+        FieldShare b[6]; for (int i = 0; i < 6; i++) { memcpy(b[i].c[0].v, blind + 4 * i, 32); b[i].c[1] = b[i].c[0]; }
+        CoPlonkRound1 r1(driver);
+        auto cm = r1.round1(z, tau, pub, wit, b);
+        for (int i = 0; i < 3; i++) { Bytes a = pt_to_affine(c, cm[i]); memcpy((uint8_t*)out_commits + i * a.size(), a.data(), a.size()); }
+        driver.free_vec(wit); cg_bases_release(tau); cg_ctx_destroy(ctx);
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
+}
+// Rep3HipProtocol x 3 (three threads, in-process network).  blind_a[i] / blind_b[i] = party i's (a, b) shares of b_1..b_6.
+// out_commits = 3 parties x 3 packed G1 (every party opens the same points)
+int32_t cgh_plonk_round1_rep3(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
+                              const uint64_t* const* blind_a, const uint64_t* const* blind_b, uint64_t* out_commits) {
+    try {
+        using namespace cgh;
+        PlonkZKey z = read_plonk_zkey(curve, zkey_path);
+        const Curve c = z.curve;
+        const size_t n_priv = z.n_vars - z.n_additions - z.n_public - 1;
+        std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
+        cg_ctx* ctx0 = nullptr;
+        if (cg_ctx_create(device, &ctx0)) die("cg_ctx_create");
+        cg_bases* tau = nullptr; CG(cg_bases_register(ctx0, c.id, CG_G1, z.p_tau.data(), z.domain_size + 6, c.aff(CG_G1), -1, &tau));
+        InProcHub hub;
+        std::string errs[3];
+        std::vector<std::thread> th;
+        for (int i = 0; i < 3; i++) th.emplace_back([&, i] {
+            cg_ctx* ctx = nullptr;
+            try {
+                if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
+                InProcNetwork net(&hub, i);
+                HipDriver driver(ctx, c, Mode::Rep3, &net);
+                ShareVec wit = driver.upload_vec((const Fr*)wit_a[i], (const Fr*)wit_b[i], n_priv);
+                FieldShare b[6]; for (int t = 0; t < 6; t++) { memcpy(b[t].c[0].v, blind_a[i] + 4 * t, 32); memcpy(b[t].c[1].v, blind_b[i] + 4 * t, 32); }
+                CoPlonkRound1 r1(driver);
+                auto cm = r1.round1(z, tau, pub, wit, b);
+                for (int t = 0; t < 3; t++) { Bytes a = pt_to_affine(c, cm[t]); memcpy((uint8_t*)out_commits + (i * 3 + t) * a.size(), a.data(), a.size()); }
+                driver.free_vec(wit);
+                cg_ctx_destroy(ctx);
+            } catch (const std::exception& e) { errs[i] = e.what(); if (ctx) cg_ctx_destroy(ctx); }
+        });
+        for (auto& t : th) t.join();
+        cg_bases_release(tau);
+        cg_ctx_destroy(ctx0);
+        for (int i = 0; i < 3; i++) if (!errs[i].empty()) { g_host_err = "party " + std::to_string(i) + ": " + errs[i]; return 1; }
+        return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
 int32_t cgh_read_wtns(int32_t curve, const char* path, uint64_t* out, size_t cap, size_t* n) {

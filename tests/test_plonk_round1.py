@@ -58,3 +58,52 @@ def test_oracle_round1_structure(curve_name):
         np.testing.assert_array_equal(polys1[k, n], b[2 * k + 1]); np.testing.assert_array_equal(polys1[k, n + 1], b[2 * k])
         # commitment recomputed from the coefficient vector with an independent (naive) MSM
         np.testing.assert_array_equal(orc.msm(curve, G1, p_tau[:n + 2], polys1[k], algo="naive"), c1[k])
+
+
+def test_host_plonk_zkey_reader_matches_oracle():
+    ensure_built()
+    for name, curve in CURVES.items():
+        assert cg.host_plonk_zkey_info(curve, fx(name, "circuit.zkey")) == orc.plonk_zkey_info(curve, fx(name, "circuit.zkey"))
+    with pytest.raises(cg.BackendError):
+        cg.host_plonk_zkey_info(BN254, os.path.join(GOLDEN, "groth16", "bn254", "multiplier2", "circuit.zkey"))    # a Groth16 zkey
+
+
+def rep3_share(curve, vals, rng):
+    a = orc.random_field(curve, FR, vals.shape[0], rng); b = orc.random_field(curve, FR, vals.shape[0], rng)
+    c = orc.field_op(curve, FR, "sub", orc.field_op(curve, FR, "sub", vals, a), b)
+    return [a, b, c], [c, a, b]                                  # party i holds (x_i, x_{i-1})
+
+
+@pytest.mark.gpu
+def test_gpu_round1_plain_matches_reference_kat():
+    """the HIP path reproduces the reference's hard-coded commitments bit for bit (round1.rs:346-383)"""
+    ensure_built()
+    w = orc.read_wtns(BN254, fx("bn254", "witness.wtns"))
+    got = cg.plonk_round1_plain(BN254, fx("bn254", "circuit.zkey"), w, deterministic_blinding(BN254))
+    np.testing.assert_array_equal(got, kat_points(BN254, KATS["test_round1_multiplier2"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_gpu_round1_plain_and_rep3_match_oracle(curve_name):
+    ensure_built()
+    curve = CURVES[curve_name]
+    zp = fx(curve_name, "circuit.zkey")
+    info = orc.plonk_zkey_info(curve, zp)
+    w = orc.read_wtns(curve, fx(curve_name, "witness.wtns"))
+    rng = np.random.default_rng(77)
+    blind = orc.random_field(curve, FR, 6, rng)
+    want = orc.plonk_round1_plain(curve, zp, w, blind)
+    np.testing.assert_array_equal(cg.plonk_round1_plain(curve, zp, w, blind), want)
+    # REP3: random sharings of the private witness and of the blinding values; every party must open the same three points
+    npub = info["n_public"]
+    wa, wb = rep3_share(curve, w[npub + 1:], rng)
+    ba, bb = rep3_share(curve, blind, rng)
+    got = cg.plonk_round1_rep3(curve, zp, w[:npub + 1], wa, wb, ba, bb)
+    for party in range(3):
+        np.testing.assert_array_equal(got[party], want, err_msg=f"party {party}")
+    if curve == BN254:   # the reference's deterministic blinding as trivial shares (promote_to_trivial_share: ID0 -> a, ID1 -> b)
+        det = deterministic_blinding(curve); zero = np.zeros_like(det)
+        got = cg.plonk_round1_rep3(curve, zp, w[:npub + 1], wa, wb, [det, zero, zero], [zero, det, zero])
+        for party in range(3):
+            np.testing.assert_array_equal(got[party], kat_points(BN254, KATS["test_round1_multiplier2"]))
