@@ -37,6 +37,7 @@ cg = importlib.import_module("collaborative-circom_amd")
 
 CURVE = cg.BN254
 R_TOP = 0x30644E72E131A029          # top 64-bit limb of the BN254 scalar modulus
+MAD_PEAK_T = 25.6                   # measured v_mad_u64_u32 rate, Tmad/s chip-wide (profiles/microbench_r01.txt)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -441,6 +442,8 @@ def main():
                     "with the exchanges skipped (results are not folded; not a benchmark line)")
     ap.add_argument("--pcie", action="store_true", help="PCIe-inclusive variant (reported in DESIGN.md, never the headline value): every step also moves what a real "
                     "REP3 party moves over PCIe - witness shares, the two masks and the two received vectors up, the two local products down")
+    ap.add_argument("--soak", type=int, default=0, metavar="K", help="after the timed region run K more (untimed) steps and require every one of them to reproduce "
+                    "the folded results of the last timed step bit for bit (the inputs are the same each step: a race between the streams shows up as a mismatch)")
     ap.add_argument("--one-context", action="store_true", help="run the aux-witness MSMs after the witness map on the same context (no overlap)")
     ap.add_argument("--precompute", type=int, default=-1, help="window size of the per-window precomputed base tables (-1 = by table size: 20 above ~1.5 M points else 17; 0 = off)")
     args = ap.parse_args()
@@ -516,6 +519,20 @@ def main():
         w.ctx_aux.stats_enable(False)
         st = {k: st[k] + st2[k] for k in st}
 
+    if args.soak and not emulate:
+        ref = {t: np.array(v, copy=True) for t, v in res.items()}
+        for it in range(args.soak):
+            again = run_step()
+            for t in ref:
+                for j in range(2):
+                    same = np.array_equal(cg.point_to_affine(CURVE, cg.G1 if TABLE_GROUP[t] == 0 else cg.G2, ref[t][j]),
+                                          cg.point_to_affine(CURVE, cg.G1 if TABLE_GROUP[t] == 0 else cg.G2, again[t][j]))
+                    if not same:
+                        raise SystemExit(f"soak: step {it} produced a different result for table {t} component {j} (rank {rank})")
+        barrier()
+        if rank == 0:
+            print(f"soak: {args.soak} extra steps reproduced the results bit for bit", file=sys.stderr)
+
     # the dominant kernel on its own: one extra, untimed step with everything on one context (no concurrent witness map / second
     # MSM stream sharing the CUs), for the roofline's "isolated" figures
     iso = None
@@ -551,6 +568,9 @@ def main():
         alg_bytes = 96.0 * avg_pts
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         per_step = lambda k: st[k] / args.steps
+        iso_ms = (iso["msm_acc_g1_ms"] / max(1, iso["msm_acc_g1_calls"])) if iso else None
+        c_eff = (20 if avg_pts > (3 << 19) else 17) if args.precompute < 0 else (args.precompute or 16)
+        nwin_g1 = 254 // c_eff + 1
         traffic = None          # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes (profiles/)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
@@ -573,6 +593,14 @@ def main():
                          "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound; in the timed region the launches share the CUs with the witness map and the "
                                  "bucket reductions running on other streams (avg_launch_ms), isolated_* = the same kernel in an extra serial step; traffic = "
                                  "FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_traffic.json (each base is re-gathered once per window); see DESIGN.md"},
+            # "MSM is integer-VALU bound; also report achieved 32-bit mul-add rate".  One G1 mixed addition on the lazy 29-bit
+            # core = 1 467 v_mad_u64_u32/v_mad_i64_i32 (6 products x 162 + 2 squarings x 126 + one fused a*b - c*d x 243); a launch adds
+            # every point once per window.  Peak = the chip-wide v_mad_u64_u32 issue rate measured by scripts/microbench.hip.
+            "valu_roofline": {"kernel": "k_msm_accumulate<G1>", "unit": "Tmad/s (32x32+64 multiply-adds)", "mads_per_point_addition": 1467,
+                              "point_additions_per_launch": avg_pts * nwin_g1,
+                              "achieved": (1467.0 * avg_pts * nwin_g1 / (iso_ms * 1e-3) / 1e12) if iso_ms else None,
+                              "peak": MAD_PEAK_T, "frac": (1467.0 * avg_pts * nwin_g1 / (iso_ms * 1e-3) / 1e12 / MAD_PEAK_T) if iso_ms else None,
+                              "launch_ms": iso_ms, "note": "isolated launches (serial extra step); peak from profiles/microbench_r01.txt"},
             "step_hbm": {"algorithmic_bytes_per_step": 2048.0 * w.nc, "achieved_GBs": 2048.0 * w.nc / (elapsed / args.steps) / 1e9},
             "stage_ms_per_step": {"spmv": per_step("spmv_ms"), "pointwise": per_step("vec_ms"), "ntt": per_step("ntt_ms"), "msm_gpu": per_step("msm_ms"),
                                   "msm_sort": per_step("msm_sort_ms"), "msm_acc_g1": per_step("msm_acc_g1_ms"), "msm_acc_g2": per_step("msm_acc_g2_ms"),
