@@ -434,6 +434,19 @@ def host_public_to_json(curve, pub):
     return buf.value.decode()
 
 
+def prove_shamir(curve, zkey_path, n, t, pub, wits, streams, device=0, want_h=False):
+    """n Shamir parties (threads) with threshold t on one GPU; returns (n proofs[, party 0's h shares])"""
+    info = host_zkey_info(curve, zkey_path)
+    nq = 6 if curve == BLS12_381 else 4
+    out = np.zeros((n, 8 * nq), dtype=np.uint64)
+    h = np.zeros((info["domain_size"], 4), dtype=np.uint64) if want_h else None
+    keep = [[np.ascontiguousarray(x, dtype=np.uint64) for x in lst] for lst in (wits, streams)]
+    arr = lambda lst: (C.c_void_p * n)(*[x.ctypes.data for x in lst])
+    _hchk(load_host().cgh_prove_shamir(int(device), curve, zkey_path.encode(), int(n), int(t), _hp(np.ascontiguousarray(pub, dtype=np.uint64)),
+                                       arr(keep[0]), arr(keep[1]), C.c_size_t(keep[1][0].shape[0]), _hp(out), _hp(h) if want_h else None))
+    return (out, h) if want_h else out
+
+
 def host_plonk_zkey_info(curve, path):
     info = (C.c_size_t * 6)()
     _hchk(load_host().cgh_plonk_zkey_info(curve, path.encode(), info))

@@ -228,6 +228,39 @@ struct InProcNetwork : Rep3Network {
     }
 };
 
+// Shamir: any-to-any channels (shamir/network.rs:17-59)
+struct ShamirNet {
+    virtual ~ShamirNet() {}
+    virtual int id() const = 0;
+    virtual int num_parties() const = 0;
+    virtual void send(int to, const void* data, size_t bytes) = 0;
+    virtual void recv(int from, void* data, size_t bytes) = 0;
+};
+struct InProcShamirHub {
+    int n;
+    std::mutex mu; std::condition_variable cv;
+    std::vector<std::deque<Bytes>> q;   // q[from * n + to]
+    explicit InProcShamirHub(int n_) : n(n_), q((size_t)n_ * n_) {}
+};
+struct InProcShamirNet : ShamirNet {
+    InProcShamirHub* hub; int me;
+    InProcShamirNet(InProcShamirHub* h, int i) : hub(h), me(i) {}
+    int id() const override { return me; }
+    int num_parties() const override { return hub->n; }
+    void send(int to, const void* data, size_t bytes) override {
+        { std::lock_guard<std::mutex> l(hub->mu); hub->q[(size_t)me * hub->n + to].emplace_back((const uint8_t*)data, (const uint8_t*)data + bytes); }
+        hub->cv.notify_all();
+    }
+    void recv(int from, void* data, size_t bytes) override {
+        std::unique_lock<std::mutex> l(hub->mu);
+        auto& qq = hub->q[(size_t)from * hub->n + me];
+        hub->cv.wait(l, [&] { return !qq.empty(); });
+        Bytes m = std::move(qq.front()); qq.pop_front();
+        if (m.size() != bytes) throw std::runtime_error("During execution of MPC: Invalid number of elements received");   // shamir.rs:324-329
+        memcpy(data, m.data(), bytes);
+    }
+};
+
 // ---- driver ------------------------------------------------------------------------------------------------------------
 struct ShareVec { void* c[2] = {nullptr, nullptr}; size_t n = 0; };   // device; REP3 uses c[0] = a, c[1] = b; plain only c[0]
 struct FieldShare { Fr c[2]; };
@@ -241,7 +274,7 @@ struct DeviceZKey {   // bases uploaded once and reused by every proof / party (
     void* pub_dev = nullptr;
 };
 
-enum class Mode { Plain, Rep3 };
+enum class Mode { Plain, Rep3, Shamir };
 
 class HipDriver {
 public:
@@ -251,6 +284,178 @@ public:
     int party() const { return mode == Mode::Rep3 ? net->id() : -1; }
 
     HipDriver(cg_ctx* c, Curve cv, Mode m, Rep3Network* n) : ctx(c), curve(cv), mode(m), net(n) {}
+
+    // ---- Shamir state (shamir.rs:196-246): threshold, Lagrange tables, buffered double sharings; randomness = stream rng1
+    ShamirNet* snet = nullptr; int sh_t = 0;
+    std::vector<Fr> open_lagrange_t, mul_lagrange_2t, sh_r_t, sh_r_2t;
+    static constexpr size_t SHAMIR_BATCH = 1024;                                     // ShamirRng::BATCH_SIZE
+    Fr next_rand() { if (cursor >= rng_len) throw std::runtime_error("randomness stream exhausted"); return rng1[cursor++]; }
+    std::vector<Fr> lagrange_from_coeff(const std::vector<size_t>& pts) const {       // shamir_core.rs:56-75
+        std::vector<Fr> res;
+        for (size_t i : pts) {
+            Fr num = fr_from_u64(curve, 1), den = num; const Fr fi = fr_from_u64(curve, i);
+            for (size_t j : pts) if (i != j) { const Fr fj = fr_from_u64(curve, j); num = fr_mul(curve, num, fj); den = fr_mul(curve, den, fr_sub(curve, fj, fi)); }
+            res.push_back(fr_mul(curve, num, fr_inv(curve, den)));
+        }
+        return res;
+    }
+    void shamir_init(ShamirNet* n, int threshold) {                                    // ShamirProtocol::new, shamir.rs:211-246
+        snet = n; sh_t = threshold;
+        const int np = n->num_parties(), id = n->id();
+        if (2 * threshold + 1 > np) throw std::runtime_error("Threshold too large for number of parties");
+        std::vector<size_t> p; for (int i = 0; i <= threshold; i++) p.push_back((size_t)((id + np - i) % np + 1));
+        open_lagrange_t = lagrange_from_coeff(p);
+        p.clear(); for (int i = 1; i <= 2 * threshold + 1; i++) p.push_back((size_t)i);
+        mul_lagrange_2t = lagrange_from_coeff(p);
+    }
+    std::vector<Fr> shamir_share(const Fr& secret, int degree) {                       // shamir_core.rs:8-31
+        const int np = snet->num_parties();
+        std::vector<Fr> coeffs; for (int k = 0; k < degree; k++) coeffs.push_back(next_rand());
+        std::vector<Fr> shares;
+        for (int pidx = 1; pidx <= np; pidx++) {
+            Fr sh = secret; const Fr x = fr_from_u64(curve, (uint64_t)pidx); Fr xp = x;
+            for (const Fr& cf : coeffs) { sh = fr_add(curve, sh, fr_mul(curve, xp, cf)); xp = fr_mul(curve, xp, x); }
+            shares.push_back(sh);
+        }
+        return shares;
+    }
+    void vandermonde_mul(const std::vector<Fr>& in, std::vector<Fr>& out) {            // shamir.rs:904-921 (appends t + 1 values)
+        const int np = snet->num_parties();
+        std::vector<Fr> row(np), cur(np);
+        for (int i = 0; i < np; i++) { row[i] = fr_from_u64(curve, (uint64_t)i + 1); cur[i] = row[i]; }
+        Fr s0 = fr_from_u64(curve, 0); for (const Fr& v : in) s0 = fr_add(curve, s0, v);
+        out.push_back(s0);
+        for (int k = 1; k <= sh_t; k++) {
+            Fr acc = fr_from_u64(curve, 0);
+            for (int i = 0; i < np; i++) { acc = fr_add(curve, acc, fr_mul(curve, cur[i], in[i])); cur[i] = fr_mul(curve, cur[i], row[i]); }
+            out.push_back(acc);
+        }
+    }
+    void buffer_triples(size_t amount) {                                               // shamir.rs:923-1010
+        const int np = snet->num_parties(), me = snet->id();
+        std::vector<Fr> rnd; for (size_t k = 0; k < amount; k++) rnd.push_back(next_rand());
+        std::vector<std::vector<Fr>> send(np);
+        for (const Fr& r : rnd) {
+            auto a = shamir_share(r, sh_t), b = shamir_share(r, 2 * sh_t);
+            for (int to = 0; to < np; to++) { send[to].push_back(a[to]); send[to].push_back(b[to]); }
+        }
+        for (int to = 0; to < np; to++) if (to != me) snet->send(to, send[to].data(), send[to].size() * 32);
+        std::vector<std::vector<Fr>> got(np);
+        for (int from = 0; from < np; from++) { if (from == me) got[from] = send[me]; else { got[from].resize(2 * amount); snet->recv(from, got[from].data(), 2 * amount * 32); } }
+        for (size_t k = 0; k < amount; k++) {
+            std::vector<Fr> in_t(np), in_2t(np);
+            for (int from = 0; from < np; from++) { in_t[from] = got[from][2 * k]; in_2t[from] = got[from][2 * k + 1]; }
+            vandermonde_mul(in_t, sh_r_t); vandermonde_mul(in_2t, sh_r_2t);
+        }
+    }
+    std::pair<Fr, Fr> get_pair() {                                                     // shamir.rs:1012-1025 (LIFO)
+        if (sh_r_t.empty()) buffer_triples(SHAMIR_BATCH);
+        std::pair<Fr, Fr> pr{sh_r_t.back(), sh_r_2t.back()};
+        sh_r_t.pop_back(); sh_r_2t.pop_back();
+        return pr;
+    }
+    // degree_reduce_vec, shamir.rs:302-384.  `local` holds this party's products on the device and is consumed.
+    ShareVec degree_reduce_vec(ShareVec local) {
+        const int np = snet->num_parties(), me = snet->id();
+        const size_t len = local.n;
+        std::vector<Fr> rt(len), r2t(len);
+        for (size_t k = 0; k < len; k++) { auto pr = get_pair(); rt[k] = pr.first; r2t[k] = pr.second; }
+        void* tmp = dalloc(len * 32);
+        CG(cg_dev_upload(ctx, tmp, r2t.data(), len * 32));
+        CG(cg_vec_add_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));          // input += r_2t
+        std::vector<Fr> buf(len);
+        const Fr one = fr_from_u64(curve, 1);
+        if (me == 0) {                                                                 // KING_ID: interpolate at 0 from parties 0..2t, re-share with degree t
+            CG(cg_vec_distribute_powers_dev(ctx, curve.id, local.c[0], len, one.v, mul_lagrange_2t[0].v));   // acc = input * lagrange_0
+            for (int other = 1; other <= 2 * sh_t; other++) {
+                snet->recv(other, buf.data(), len * 32);
+                CG(cg_dev_upload(ctx, tmp, buf.data(), len * 32));
+                CG(cg_vec_distribute_powers_dev(ctx, curve.id, tmp, len, one.v, mul_lagrange_2t[other].v));
+                CG(cg_vec_add_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));
+            }
+            // ShamirCore::share per element: coefficients are drawn element by element (t per element)
+            std::vector<std::vector<Fr>> coeff(sh_t, std::vector<Fr>(len));
+            for (size_t k = 0; k < len; k++) for (int d = 0; d < sh_t; d++) coeff[d][k] = next_rand();
+            std::vector<void*> d_coeff(sh_t);
+            for (int d = 0; d < sh_t; d++) { d_coeff[d] = dalloc(len * 32); CG(cg_dev_upload(ctx, d_coeff[d], coeff[d].data(), len * 32)); }
+            void* share = dalloc(len * 32); void* term = dalloc(len * 32);
+            void* mine = dalloc(len * 32);
+            for (int to = np - 1; to >= 0; to--) {                                     // any order: every share is a function of (acc, coeffs) only
+                const Fr x = fr_from_u64(curve, (uint64_t)to + 1); Fr xp = x;
+                // share = acc + sum_d coeff_d * x^(d+1)
+                bool first = true;
+                for (int d = 0; d < sh_t; d++) {
+                    CG(cg_dev_memset_zero(ctx, term, len * 32));
+                    CG(cg_vec_add_dev(ctx, curve.id, term, term, d_coeff[d], len));
+                    CG(cg_vec_distribute_powers_dev(ctx, curve.id, term, len, one.v, xp.v));
+                    CG(cg_vec_add_dev(ctx, curve.id, share, first ? local.c[0] : share, term, len));
+                    first = false; xp = fr_mul(curve, xp, x);
+                }
+                if (sh_t == 0) { CG(cg_dev_memset_zero(ctx, share, len * 32)); CG(cg_vec_add_dev(ctx, curve.id, share, share, local.c[0], len)); }
+                if (to == 0) { CG(cg_dev_memset_zero(ctx, mine, len * 32)); CG(cg_vec_add_dev(ctx, curve.id, mine, mine, share, len)); }
+                else { CG(cg_dev_download(ctx, buf.data(), share, len * 32)); snet->send(to, buf.data(), len * 32); }
+            }
+            CG(cg_dev_free(ctx, local.c[0])); local.c[0] = mine;
+            for (void* p : d_coeff) CG(cg_dev_free(ctx, p));
+            CG(cg_dev_free(ctx, share)); CG(cg_dev_free(ctx, term));
+        } else {
+            if (me <= 2 * sh_t) { CG(cg_dev_download(ctx, buf.data(), local.c[0], len * 32)); snet->send(0, buf.data(), len * 32); }   // only if my items are required
+            snet->recv(0, buf.data(), len * 32);
+            CG(cg_dev_upload(ctx, local.c[0], buf.data(), len * 32));
+        }
+        CG(cg_dev_upload(ctx, tmp, rt.data(), len * 32));
+        CG(cg_vec_sub_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));          // share - r_t
+        CG(cg_dev_free(ctx, tmp));
+        return local;
+    }
+    Fr degree_reduce(Fr input) {                                                       // shamir.rs:252-300
+        const int np = snet->num_parties(), me = snet->id();
+        auto pr = get_pair();
+        input = fr_add(curve, input, pr.second);
+        Fr my_share;
+        if (me == 0) {
+            Fr acc = fr_mul(curve, input, mul_lagrange_2t[0]);
+            for (int other = 1; other <= 2 * sh_t; other++) { Fr r; snet->recv(other, r.v, 32); acc = fr_add(curve, acc, fr_mul(curve, r, mul_lagrange_2t[other])); }
+            auto shares = shamir_share(acc, sh_t);
+            for (int to = 0; to < np; to++) { if (to == me) my_share = shares[to]; else snet->send(to, shares[to].v, 32); }
+        } else {
+            if (me <= 2 * sh_t) snet->send(0, input.v, 32);
+            snet->recv(0, my_share.v, 32);
+        }
+        return fr_sub(curve, my_share, pr.first);
+    }
+    Point degree_reduce_point(Point input) {                                           // shamir.rs:386-436; C::rand stand-in: G * next_rand()
+        const int np = snet->num_parties(), me = snet->id();
+        const int g = input.group;
+        auto pr = get_pair();
+        const Point gen = pt_generator(curve, g);
+        input = pt_add(curve, input, pt_mul(curve, gen, pr.second));
+        Point my_share = pt_inf(curve, g);
+        const size_t psz = curve.aff(g);
+        if (me == 0) {
+            Point acc = pt_mul(curve, input, mul_lagrange_2t[0]);
+            for (int other = 1; other <= 2 * sh_t; other++) { Bytes a(psz); snet->recv(other, a.data(), psz); acc = pt_add(curve, acc, pt_mul(curve, pt_from_affine(curve, g, a.data()), mul_lagrange_2t[other])); }
+            std::vector<Point> coeffs; for (int d = 0; d < sh_t; d++) coeffs.push_back(pt_mul(curve, gen, next_rand()));
+            for (int to = 0; to < np; to++) {
+                Point sh = acc; const Fr x = fr_from_u64(curve, (uint64_t)to + 1); Fr xp = x;
+                for (const Point& cf : coeffs) { sh = pt_add(curve, sh, pt_mul(curve, cf, xp)); xp = fr_mul(curve, xp, x); }
+                if (to == me) my_share = sh; else { Bytes a = pt_to_affine(curve, sh); snet->send(to, a.data(), a.size()); }
+            }
+        } else {
+            if (me <= 2 * sh_t) { Bytes a = pt_to_affine(curve, input); snet->send(0, a.data(), a.size()); }
+            Bytes a(psz); snet->recv(0, a.data(), psz); my_share = pt_from_affine(curve, g, a.data());
+        }
+        return pt_sub(curve, my_share, pt_mul(curve, gen, pr.first));
+    }
+    // broadcast_next(t + 1) + reconstruct_point (network.rs:233-266, shamir.rs:778-782)
+    Point shamir_open_point(const Point& mine) {
+        const int np = snet->num_parties(), me = snet->id();
+        Bytes a = pt_to_affine(curve, mine);
+        for (int sft = 1; sft <= sh_t; sft++) snet->send((me + sft) % np, a.data(), a.size());
+        Point res = pt_mul(curve, mine, open_lagrange_t[0]);
+        for (int r = 1; r <= sh_t; r++) { Bytes b(a.size()); snet->recv((me + np - r) % np, b.data(), b.size()); res = pt_add(curve, res, pt_mul(curve, pt_from_affine(curve, mine.group, b.data()), open_lagrange_t[r])); }
+        return res;
+    }
 
     void* dalloc(size_t bytes) { void* p; CG(cg_dev_alloc(ctx, bytes, &p)); return p; }
     ShareVec alloc_vec(size_t n) { ShareVec v; v.n = n; for (int j = 0; j < k(); j++) { v.c[j] = dalloc(n * 32); CG(cg_dev_memset_zero(ctx, v.c[j], n * 32)); } return v; }
@@ -271,14 +476,16 @@ public:
     }
     // promote_to_trivial_shares (fieldshare.rs:262-283) + clone_from_slice (rep3.rs:710-725)
     void clone_public_into(ShareVec& dst, size_t dst_off, const std::vector<Fr>& pub) {
-        const int holder = mode == Mode::Plain ? 0 : (party() == 0 ? 0 : party() == 1 ? 1 : -1);   // ID0 -> a, ID1 -> b, ID2 -> nothing
+        const int holder = mode != Mode::Rep3 ? 0 : (party() == 0 ? 0 : party() == 1 ? 1 : -1);   // REP3: ID0 -> a, ID1 -> b, ID2 -> nothing; plain / Shamir: the value itself
         if (holder >= 0) CG(cg_dev_upload(ctx, (uint8_t*)dst.c[holder] + dst_off * 32, pub.data(), pub.size() * 32));
     }
     // mul_vec (traits.rs:164): plain.rs:219-224 ; rep3.rs:650-670 (local product + mask, send to next, receive from prev)
     ShareVec mul_vec(const ShareVec& a, const ShareVec& b) {
         ShareVec out; out.n = a.n;
         out.c[0] = dalloc(a.n * 32);
-        if (mode == Mode::Plain) { CG(cg_vec_mul_dev(ctx, curve.id, out.c[0], a.c[0], b.c[0], a.n)); return out; }
+        if (mode != Mode::Rep3) CG(cg_vec_mul_dev(ctx, curve.id, out.c[0], a.c[0], b.c[0], a.n));
+        if (mode == Mode::Plain) return out;
+        if (mode == Mode::Shamir) return degree_reduce_vec(out);                     // shamir.rs:609-623
         if (cursor + a.n > rng_len) throw std::runtime_error("randomness stream exhausted");
         void* m1 = dalloc(a.n * 32); void* m2 = dalloc(a.n * 32);
         CG(cg_dev_upload(ctx, m1, rng1 + cursor, a.n * 32)); CG(cg_dev_upload(ctx, m2, rng2 + cursor, a.n * 32));
@@ -313,11 +520,15 @@ public:
         return r;
     }
     // rand (rep3.rs:595-598; plain: supplied by the caller)
-    FieldShare rand() { FieldShare f; f.c[0] = draw(rng1); f.c[1] = draw(rng2); cursor++; return f; }
+    FieldShare rand() {
+        if (mode == Mode::Shamir) { FieldShare f; f.c[0] = get_pair().first; f.c[1] = f.c[0]; return f; }   // shamir.rs:570-573
+        FieldShare f; f.c[0] = draw(rng1); f.c[1] = draw(rng2); cursor++; return f;
+    }
     // mul (rep3.rs:503-511 / plain a*b)
     FieldShare mul(const FieldShare& a, const FieldShare& b) {
         FieldShare r;
         if (mode == Mode::Plain) { r.c[0] = fr_mul(curve, a.c[0], b.c[0]); r.c[1] = r.c[0]; return r; }
+        if (mode == Mode::Shamir) { r.c[0] = degree_reduce(fr_mul(curve, a.c[0], b.c[0])); r.c[1] = r.c[0]; return r; }   // shamir.rs:481-488
         Fr local = fr_add(curve, fr_add(curve, fr_mul(curve, a.c[0], b.c[0]), fr_mul(curve, a.c[0], b.c[1])), fr_mul(curve, a.c[1], b.c[0]));
         local = fr_add(curve, local, fr_sub(curve, draw(rng1), draw(rng2))); cursor++;
         net->send_next(local.v, 32);
@@ -331,6 +542,7 @@ public:
     PointShare scalar_mul(const PointShare& a, const FieldShare& b) {           // rep3.rs:835-847, pointshare.rs:117-124
         PointShare r;
         if (mode == Mode::Plain) { r.c[0] = pt_mul(curve, a.c[0], b.c[0]); r.c[1] = pt_inf(curve, a.c[0].group); return r; }
+        if (mode == Mode::Shamir) { r.c[0] = degree_reduce_point(pt_mul(curve, a.c[0], b.c[0])); r.c[1] = pt_inf(curve, a.c[0].group); return r; }   // shamir.rs:769-776
         Point local = pt_add(curve, pt_add(curve, pt_mul(curve, a.c[0], b.c[0]), pt_mul(curve, a.c[1], b.c[0])), pt_mul(curve, a.c[0], b.c[1]));
         const Point gen = pt_generator(curve, a.c[0].group);       // masking_ec_element: G*rand(rng1) - G*rand(rng2)
         local = pt_add(curve, local, pt_sub(curve, pt_mul(curve, gen, draw(rng1)), pt_mul(curve, gen, draw(rng2)))); cursor++;
@@ -343,11 +555,12 @@ public:
     void add_assign_points(PointShare& a, const PointShare& b) { for (int j = 0; j < k(); j++) a.c[j] = pt_add(curve, a.c[j], b.c[j]); }
     void sub_assign_points(PointShare& a, const PointShare& b) { for (int j = 0; j < k(); j++) a.c[j] = pt_sub(curve, a.c[j], b.c[j]); }
     void add_assign_points_public(PointShare& a, const Point& b) {              // rep3.rs:804-818: ID0 -> a, ID1 -> b, ID2 -> nothing
-        if (mode == Mode::Plain || party() == 0) a.c[0] = pt_add(curve, a.c[0], b);
+        if (mode != Mode::Rep3 || party() == 0) a.c[0] = pt_add(curve, a.c[0], b);       // Shamir: every party adds (shamir.rs:733-735)
         else if (party() == 1) a.c[1] = pt_add(curve, a.c[1], b);
     }
     Point open_point(const PointShare& a) {                                      // rep3.rs:849-853
         if (mode == Mode::Plain) return a.c[0];
+        if (mode == Mode::Shamir) return shamir_open_point(a.c[0]);
         Bytes mine = pt_to_affine(curve, a.c[1]);
         net->send_next(mine.data(), mine.size());
         Bytes prev(mine.size()); net->recv_prev(prev.data(), prev.size());
@@ -355,6 +568,7 @@ public:
     }
     std::pair<Point, Point> open_two_points(const PointShare& a, const PointShare& b) {   // rep3.rs:865-877
         if (mode == Mode::Plain) return {a.c[0], b.c[0]};
+        if (mode == Mode::Shamir) { Point p1 = shamir_open_point(a.c[0]); return {p1, shamir_open_point(b.c[0])}; }   // shamir.rs:808-824 (one message per point here)
         Bytes m1 = pt_to_affine(curve, a.c[1]), m2 = pt_to_affine(curve, b.c[1]);
         Bytes msg(m1); msg.insert(msg.end(), m2.begin(), m2.end());
         net->send_next(msg.data(), msg.size());
@@ -740,6 +954,48 @@ int32_t cgh_public_to_json(int32_t curve, const uint64_t* pub, size_t n, char* o
             js += (i ? ",\"" : "\"") + cgh::limbs_to_dec(can, 4) + "\"";
         }
         return copy_out(js + "]", out, cap);
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+// ShamirHipProtocol x n (n threads, in-process any-to-any network), threshold t.  wit[i] = party i's Shamir shares of the private
+// witness; streams[i] = party i's private randomness (consumed in the order the reference draws values).  out_proofs = n proofs.
+int32_t cgh_prove_shamir(int32_t device, int32_t curve, const char* zkey_path, int32_t n, int32_t t, const uint64_t* pub_in, const uint64_t* const* wit,
+                         const uint64_t* const* streams, size_t stream_len, uint64_t* out_proofs, uint64_t* out_h) {
+    try {
+        using namespace cgh;
+        if (n < 3) throw std::runtime_error("Shamir protocol requires at least 3 parties");        // shamir/network.rs:75-77
+        ZKey z = read_zkey(curve, zkey_path);
+        const size_t n_aux = z.n_vars - z.n_public - 1;
+        std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
+        cg_ctx* ctx0 = nullptr;
+        if (cg_ctx_create(device, &ctx0)) die("cg_ctx_create");
+        DeviceZKey dz = upload_zkey(ctx0, z, pub);
+        InProcShamirHub hub(n);
+        const size_t psz = 8 * z.curve.fq();
+        std::vector<std::string> errs(n);
+        std::vector<std::thread> th;
+        for (int i = 0; i < n; i++) th.emplace_back([&, i] {
+            cg_ctx* ctx = nullptr;
+            try {
+                if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
+                InProcShamirNet net(&hub, i);
+                HipDriver driver(ctx, z.curve, Mode::Shamir, nullptr);
+                driver.rng1 = (const Fr*)streams[i]; driver.rng_len = stream_len;
+                driver.shamir_init(&net, t);
+                ShareVec w = driver.upload_vec((const Fr*)wit[i], nullptr, n_aux);
+                CoGroth16 prover(driver);
+                ShareVec h;
+                Proof p = prover.prove(dz, pub, w, nullptr, &h);
+                store_proof(p, (uint8_t*)out_proofs + i * psz);
+                if (out_h && i == 0) CG(cg_dev_download(ctx, out_h, h.c[0], h.n * 32));
+                driver.free_vec(h); driver.free_vec(w);
+                cg_ctx_destroy(ctx);
+            } catch (const std::exception& e) { errs[i] = e.what(); if (ctx) cg_ctx_destroy(ctx); }
+        });
+        for (auto& x : th) x.join();
+        release_zkey(ctx0, dz);
+        cg_ctx_destroy(ctx0);
+        for (int i = 0; i < n; i++) if (!errs[i].empty()) { g_host_err = "party " + std::to_string(i) + ": " + errs[i]; return 1; }
+        return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
 // info: n_vars, n_public, domain_size, power, n_additions, n_constraints

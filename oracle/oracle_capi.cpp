@@ -7,6 +7,7 @@
 #include "bench.hpp"
 #include "synth.hpp"
 #include "plonk.hpp"
+#include "shamir.hpp"
 #include <chrono>
 
 using namespace orc;
@@ -344,6 +345,33 @@ int orc_prove_rep3(void* h, const uint64_t* pub, const uint64_t* const* wit_a, c
         const int psz = 8 * C::Fq::N;
         for (int i = 0; i < 3; i++) st_proof<C>(out_proofs + i * psz, out[i]);
         if (out_h) { memcpy(out_h, hs[0].a.data(), m * sizeof(Fr)); memcpy(out_h + m * 4, hs[0].b.data(), m * sizeof(Fr)); }
+    });
+    return 0;
+}
+// Shamir (n parties, threshold t): wit[i] = party i's shares of the private witness, streams[i] = party i's private randomness.
+// out_proofs = n proofs; out_h (optional) = party 0's h shares
+int orc_prove_shamir(void* h, int n, int t, const uint64_t* pub, const uint64_t* const* wit, const uint64_t* const* streams, size_t stream_len,
+                     int threads, uint64_t* out_proofs, uint64_t* out_h) {
+    ZK(h, {
+        typedef typename C::Fr Fr;
+        const size_t n_aux = z.n_vars - z.n_public - 1;
+        ShamirSim<C> sim(z, n, t);
+        sim.threads = threads;
+        const Fr* p = reinterpret_cast<const Fr*>(pub);
+        sim.pub.assign(p, p + z.n_public + 1);
+        std::vector<std::vector<Fr>> st_(n);
+        for (int i = 0; i < n; i++) {
+            const Fr* a = reinterpret_cast<const Fr*>(wit[i]);
+            sim.wit[i].assign(a, a + n_aux);
+            const Fr* s = reinterpret_cast<const Fr*>(streams[i]);
+            st_[i].assign(s, s + stream_len);
+            sim.stream[i] = &st_[i];
+        }
+        std::vector<std::vector<Fr>> hs;
+        auto out = sim.prove(&hs);
+        const int psz = 8 * C::Fq::N;
+        for (int i = 0; i < n; i++) st_proof<C>(out_proofs + i * psz, out[i]);
+        if (out_h) memcpy(out_h, hs[0].data(), hs[0].size() * sizeof(Fr));
     });
     return 0;
 }

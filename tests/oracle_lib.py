@@ -229,6 +229,32 @@ class ZKey:
         return (out, h) if want_h else out
 
 
+def prove_shamir(self_zkey, n, t, pub, wits, streams, threads=1, want_h=False):
+    """oracle/shamir.hpp: n parties in lock-step; returns (n proofs[, party 0's h shares])"""
+    z = self_zkey
+    nq = nlimbs(z.curve, FQ)
+    keep = [[np.ascontiguousarray(x, dtype=np.uint64) for x in lst] for lst in (wits, streams)]
+    arr = lambda lst: (C.c_void_p * n)(*[x.ctypes.data for x in lst])
+    out = np.zeros((n, 8 * nq), dtype=np.uint64)
+    h = np.zeros((z.domain_size, 4), dtype=np.uint64) if want_h else None
+    _chk(lib().orc_prove_shamir(C.c_void_p(z.h), n, t, _p(np.ascontiguousarray(pub, dtype=np.uint64)), arr(keep[0]), arr(keep[1]),
+                                C.c_size_t(keep[1][0].shape[0]), threads, _p(out), _p(h) if want_h else None))
+    return (out, h) if want_h else out
+
+
+def shamir_share(curve, vals, n, t, rng):
+    """Shamir shares of `vals` for parties 1..n with random degree-t polynomials (shamir_core.rs:8-31)"""
+    coeffs = [random_field(curve, FR, vals.shape[0], rng) for _ in range(t)]
+    shares = []
+    for p in range(1, n + 1):
+        acc = vals.copy(); xp = p
+        for c in coeffs:
+            x = np.broadcast_to(from_dec(curve, FR, str(xp)), c.shape).copy()
+            acc = field_op(curve, FR, "add", acc, field_op(curve, FR, "mul", c, x)); xp *= p
+        shares.append(acc)
+    return shares
+
+
 def read_wtns(curve, path):
     n = C.c_size_t(0)
     _chk(lib().orc_wtns_read(curve, path.encode(), None, C.c_size_t(0), C.byref(n)))
