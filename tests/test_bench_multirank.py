@@ -35,11 +35,24 @@ def test_bench_step_matches_oracle(tmp_path):
     import bench
     import bench_check
     assert bench_check.TABLE_FIRST == bench.TABLE_FIRST
-    for extra in ((), ("--precompute", "0")):
-        _, d = run_bench(tmp_path, 1, extra=("--dump-inputs",) + extra, log_m=12)
+    for extra, log_m in (((), 12), (("--precompute", "0"), 12), ((), 18)):       # 2^18: partition-sort path, window chosen by table size
+        _, d = run_bench(tmp_path, 1, extra=("--dump-inputs",) + extra, log_m=log_m)
         exp = bench_check.expected_results(d)
         for t in bench.TABLES:
-            np.testing.assert_array_equal(d[t], exp[t], err_msg=f"table {t} {extra}")
+            np.testing.assert_array_equal(d[t], exp[t], err_msg=f"table {t} {extra} 2^{log_m}")
+
+
+def test_bench_step_matches_oracle_at_full_size(tmp_path):
+    """BASELINE size (2^22 constraints-domain): the exact workload bench.py times, checked bit for bit against the oracle's evaluation
+    of the same inputs (the synthetic tables [(first + i) G] collapse every MSM to one generator multiplication, so the CPU side
+    stays at a dozen 2^22 NTTs and vectorised field operations)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+    import bench
+    import bench_check
+    _, d = run_bench(tmp_path, 1, extra=("--dump-inputs",), log_m=22)
+    exp = bench_check.expected_results(d)
+    for t in bench.TABLES:
+        np.testing.assert_array_equal(d[t], exp[t], err_msg=f"table {t} at 2^22")
 
 
 def test_ranks_fold_to_the_single_rank_result(tmp_path):
