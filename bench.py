@@ -131,7 +131,7 @@ WM_VECTORS = 6                                   # a.a, a.b, b.a, b.b, c.a, c.b
 
 
 def wm_distributed(world):
-    return world >= WM_DISTRIBUTE_MIN_WORLD
+    return world >= WM_DISTRIBUTE_MIN_WORLD      # (tests lower the threshold to push a single rank through the collective path)
 
 
 def wm_vector_owner(v, world):
@@ -444,6 +444,8 @@ def main():
                     "REP3 party moves over PCIe - witness shares, the two masks and the two received vectors up, the two local products down")
     ap.add_argument("--soak", type=int, default=0, metavar="K", help="after the timed region run K more (untimed) steps and require every one of them to reproduce "
                     "the folded results of the last timed step bit for bit (the inputs are the same each step: a race between the streams shows up as a mismatch)")
+    ap.add_argument("--force-dist", action="store_true", help="test mode: initialise torch.distributed even for one rank and distribute the witness map from "
+                    "one rank on, so that a single GPU drives the RCCL all_to_all / all_gather / all_reduce calls of the N >= 4 path")
     ap.add_argument("--one-context", action="store_true", help="run the aux-witness MSMs after the witness map on the same context (no overlap)")
     ap.add_argument("--precompute", type=int, default=-1, help="window size of the per-window precomputed base tables (-1 = by table size: 20 above ~1.5 M points else 17; 0 = off)")
     args = ap.parse_args()
@@ -462,7 +464,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if args.force_dist:
+        global WM_DISTRIBUTE_MIN_WORLD
+        WM_DISTRIBUTE_MIN_WORLD = 1
+        os.environ.setdefault("MASTER_PORT", "29655"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":

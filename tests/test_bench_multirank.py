@@ -55,6 +55,15 @@ def test_bench_step_matches_oracle_at_full_size(tmp_path):
         np.testing.assert_array_equal(d[t], exp[t], err_msg=f"table {t} at 2^22")
 
 
+def test_single_rank_through_rccl_collectives(tmp_path):
+    """one rank, but with torch.distributed (nccl = RCCL) initialised and the witness map in its distributed form: the all_to_all,
+    all_gather, all_reduce and barrier calls of the N >= 4 path run on real device tensors and must not change the result"""
+    _, ref = run_bench(tmp_path, 1)
+    _, got = run_bench(tmp_path, 1, extra=("--force-dist",))
+    for t in ref:
+        np.testing.assert_array_equal(ref[t], got[t], err_msg=f"table {t}")
+
+
 def test_ranks_fold_to_the_single_rank_result(tmp_path):
     j1, r1 = run_bench(tmp_path, 1)
     assert j1["n_gpus"] == 1 and set(r1) == {"h", "l", "a", "b1", "b2"}
