@@ -37,6 +37,11 @@ template <class F> int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, 
 template <class Fr> int launch_vec_binary(hipStream_t st, int op, Fr* out, const Fr* a, const Fr* b, size_t n);
 template <class Fr> int launch_rep3_mul_local(hipStream_t st, Fr* out, const Fr* aa, const Fr* ab, const Fr* ba, const Fr* bb, const Fr* mask, size_t n);
 template <class Fr> int launch_distribute_powers(hipStream_t st, Fr* v, size_t n, const Fr* lo, const Fr* hi, int log_lo);
+template <class Fr> int launch_vec_fill(hipStream_t st, Fr* v, size_t n, const Fr& value);
+template <class Fr> int launch_vec_affine(hipStream_t st, Fr* out, const Fr* a, size_t n, const Fr& c, const Fr& d);
+template <class Fr> int launch_vec_gather_strided(hipStream_t st, Fr* out, const Fr* in, size_t n, size_t offset, size_t stride);
+template <class Fr> int launch_prefix_prod(hipStream_t st, Fr* out, const Fr* in, size_t n, Fr* scratch);
+template <class Fr> int launch_vec_inverse(hipStream_t st, Fr* out, const Fr* in, size_t n);
 template <class Fr> int launch_spmv_csr(hipStream_t st, const uint32_t* row_ptr, const uint32_t* col, const Fr* coeff, size_t n_rows, const Fr* pub,
                                         uint32_t n_inputs, int party, const Fr* wit_a, const Fr* wit_b, Fr* out_a, Fr* out_b);
 template <class Fr> int launch_build_twiddles(hipStream_t st, Fr* tw, size_t m, int log_m, const Fr* lo, const Fr* hi, int log_lo);
@@ -418,6 +423,11 @@ int get_coset_tables(cg_ctx* ctx, int curve, int log_m, const Fr& g, const Fr& s
     HIPCHK(hipMalloc(&t.hi, hi.size() * sizeof(Fr)));
     HIPCHK(hipMemcpy(t.lo, lo.data(), lo.size() * sizeof(Fr), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(t.hi, hi.data(), hi.size() * sizeof(Fr), hipMemcpyHostToDevice));
+    if (ctx->cosets.size() >= 64) {   // callers that scale by per-proof challenges would otherwise grow the cache without bound
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
+        ctx->cosets.clear();
+    }
     ctx->cosets[key] = t;
     *out = t;
     return 0;
@@ -838,6 +848,56 @@ int32_t cg_vec_distribute_powers_dev(cg_ctx* ctx, int32_t curve, void* d_v, size
         if (rc) return rc;
         StatScope ss(ctx, TAG_VEC);
         return launch_distribute_powers<Fr>(ctx->stream, (Fr*)d_v, n, (const Fr*)t.lo, (const Fr*)t.hi, t.log_lo);
+    });
+}
+int32_t cg_vec_affine_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_a, size_t n, const void* h_c, const void* h_d) {
+    if (!ctx || !d_out || !d_a || !h_c) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        Fr c, d = Fr::zero(); copy_in(c, h_c); if (h_d) copy_in(d, h_d);
+        StatScope ss(ctx, TAG_VEC);
+        return launch_vec_affine<Fr>(ctx->stream, (Fr*)d_out, (const Fr*)d_a, n, c, d);
+    });
+}
+int32_t cg_vec_fill_dev(cg_ctx* ctx, int32_t curve, void* d_v, size_t n, const void* h_value) {
+    if (!ctx || !d_v || !h_value) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        Fr v; copy_in(v, h_value);
+        StatScope ss(ctx, TAG_VEC);
+        return launch_vec_fill<Fr>(ctx->stream, (Fr*)d_v, n, v);
+    });
+}
+int32_t cg_vec_gather_strided_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n, size_t offset, size_t stride) {
+    if (!ctx || !d_out || !d_in) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        StatScope ss(ctx, TAG_VEC);
+        return launch_vec_gather_strided<Fr>(ctx->stream, (Fr*)d_out, (const Fr*)d_in, n, offset, stride);
+    });
+}
+int32_t cg_vec_prefix_prod_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n) {
+    if (!ctx || !d_out || !d_in) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return 0;
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        const size_t ntiles = (n + 2047) / 2048;
+        { int rc = ensure_arena(ctx, align_up(ntiles * sizeof(Fr))); if (rc) return rc; }
+        StatScope ss(ctx, TAG_VEC);
+        return launch_prefix_prod<Fr>(ctx->stream, (Fr*)d_out, (const Fr*)d_in, n, (Fr*)ctx->arena.base);
+    });
+}
+int32_t cg_vec_inverse_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n) {
+    if (!ctx || !d_out || !d_in) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        StatScope ss(ctx, TAG_VEC);
+        return launch_vec_inverse<Fr>(ctx->stream, (Fr*)d_out, (const Fr*)d_in, n);
     });
 }
 int32_t cg_spmv_csr_dev(cg_ctx* ctx, int32_t curve, const uint32_t* d_row_ptr, const uint32_t* d_col, const void* d_coeff, size_t n_rows,

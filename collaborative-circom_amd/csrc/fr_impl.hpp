@@ -27,6 +27,43 @@ template <class Fr> int launch_distribute_powers(hipStream_t st, Fr* v, size_t n
     HIPCHK(hipGetLastError());
     return 0;
 }
+template <class Fr> int launch_vec_affine(hipStream_t st, Fr* out, const Fr* a, size_t n, const Fr& c, const Fr& d) {
+    if (!n) return 0;
+    hipLaunchKernelGGL((k_vec_affine<Fr>), dim3(grid_for(n)), dim3(256), 0, st, out, a, n, c, d);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class Fr> int launch_vec_fill(hipStream_t st, Fr* v, size_t n, const Fr& value) {
+    if (!n) return 0;
+    hipLaunchKernelGGL((k_vec_fill<Fr>), dim3(grid_for(n)), dim3(256), 0, st, v, n, value);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class Fr> int launch_vec_gather_strided(hipStream_t st, Fr* out, const Fr* in, size_t n, size_t offset, size_t stride) {
+    if (!n) return 0;
+    hipLaunchKernelGGL((k_vec_gather_strided<Fr>), dim3(grid_for(n)), dim3(256), 0, st, out, in, n, offset, stride);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// scratch: ceil(n / 2048) elements
+template <class Fr> int launch_prefix_prod(hipStream_t st, Fr* out, const Fr* in, size_t n, Fr* scratch) {
+    if (!n) return 0;
+    const size_t tile = (size_t)256 * SCAN_ITEMS, ntiles = (n + tile - 1) / tile;
+    hipLaunchKernelGGL((k_prefix_prod_tiles<Fr>), dim3((unsigned)ntiles), dim3(256), 0, st, out, in, n, scratch);
+    if (ntiles > 1) {
+        hipLaunchKernelGGL((k_prefix_prod_totals<Fr>), dim3(1), dim3(256), 0, st, scratch, ntiles);
+        hipLaunchKernelGGL((k_prefix_prod_fixup<Fr>), dim3(grid_for(n)), dim3(256), 0, st, out, n, scratch);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class Fr> int launch_vec_inverse(hipStream_t st, Fr* out, const Fr* in, size_t n) {
+    if (!n) return 0;
+    const size_t lanes = (n + INV_ITEMS - 1) / INV_ITEMS;
+    hipLaunchKernelGGL((k_vec_inverse<Fr>), dim3((unsigned)((lanes + 127) / 128)), dim3(128), 0, st, out, in, n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 template <class Fr> int launch_spmv_csr(hipStream_t st, const uint32_t* row_ptr, const uint32_t* col, const Fr* coeff, size_t n_rows, const Fr* pub,
                                         uint32_t n_inputs, int party, const Fr* wit_a, const Fr* wit_b, Fr* out_a, Fr* out_b) {
     if (!n_rows) return 0;
@@ -151,6 +188,11 @@ template <class Fr> int msm_sort_direct_launch(hipStream_t st, const Fr* d_scala
     template int launch_vec_binary<Fr>(hipStream_t, int, Fr*, const Fr*, const Fr*, size_t);                               \
     template int launch_rep3_mul_local<Fr>(hipStream_t, Fr*, const Fr*, const Fr*, const Fr*, const Fr*, const Fr*, size_t); \
     template int launch_distribute_powers<Fr>(hipStream_t, Fr*, size_t, const Fr*, const Fr*, int);                        \
+    template int launch_vec_fill<Fr>(hipStream_t, Fr*, size_t, const Fr&);                                                 \
+    template int launch_vec_affine<Fr>(hipStream_t, Fr*, const Fr*, size_t, const Fr&, const Fr&);                         \
+    template int launch_vec_gather_strided<Fr>(hipStream_t, Fr*, const Fr*, size_t, size_t, size_t);                       \
+    template int launch_prefix_prod<Fr>(hipStream_t, Fr*, const Fr*, size_t, Fr*);                                         \
+    template int launch_vec_inverse<Fr>(hipStream_t, Fr*, const Fr*, size_t);                                              \
     template int launch_spmv_csr<Fr>(hipStream_t, const uint32_t*, const uint32_t*, const Fr*, size_t, const Fr*, uint32_t, int, const Fr*, const Fr*, Fr*, Fr*); \
     template int launch_build_twiddles<Fr>(hipStream_t, Fr*, size_t, int, const Fr*, const Fr*, int);                      \
     template int launch_ntt_dif_pass<Fr>(hipStream_t, NttVecs, NttVecs, int, size_t, int, int, int, int, const Fr*);                \

@@ -2,6 +2,7 @@
 // explicitly instantiated once per (curve, group) in msm_inst_*.hip so that each is its own translation unit.
 // The scalar-dependent half (digits + counting sort) is in fr_impl.hpp and is shared between MSMs over the same scalars.
 #pragma once
+#include <cstdlib>
 #include "common.hpp"
 #include "msm_kernels.hpp"
 
@@ -28,7 +29,8 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared) {
     g.ngroups = shared ? (g.segs >= (uint32_t)MSM_SHARED_GROUPS ? MSM_SHARED_GROUPS : 1) : nwin;
     g.group_segs = shared ? g.segs / g.ngroups : g.segs;
     const size_t entries = (size_t)nwin * n;
-    g.chunk_len = (uint32_t)std::min<size_t>(128, std::max<size_t>(8, entries / (256 * 1024)));
+    static const size_t chunk_max = [] { const char* e = getenv("CG_MSM_CHUNK"); return e ? (size_t)atoi(e) : (size_t)128; }();   // tuning knob
+    g.chunk_len = (uint32_t)std::min<size_t>(chunk_max, std::max<size_t>(8, entries / (256 * 1024)));
     g.nchunks = (uint32_t)std::max<size_t>(1, (entries + g.chunk_len - 1) / g.chunk_len);
     return g;
 }

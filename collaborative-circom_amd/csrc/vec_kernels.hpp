@@ -89,4 +89,97 @@ __global__ void __launch_bounds__(256) k_zero_tail(F* __restrict__ v, size_t fro
     for (size_t i = from + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < to; i += (size_t)gridDim.x * blockDim.x) st_fp(v + i, F::zero());
 }
 
+// ---- co-plonk pointwise helpers (round 2: grand-product polynomial z, co-plonk/src/round2.rs:146-268) ------------------------------
+// out[i] = c * a[i] + d   (mul_with_public / add_with_public of a single-component share vector: plain.rs, shamir.rs:471-506)
+template <class F>
+__global__ void __launch_bounds__(256) k_vec_affine(F* __restrict__ out, const F* __restrict__ a, size_t n, F c, F d) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fp(out + i, c * ld_fp(a + i) + d);
+}
+// v[i] = value
+template <class F>
+__global__ void __launch_bounds__(256) k_vec_fill(F* __restrict__ v, size_t n, F value) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fp(v + i, value);
+}
+// out[i] = in[offset + i * stride]   (e.g. every 4th evaluation of a sigma polynomial, round2.rs:196-206)
+template <class F>
+__global__ void __launch_bounds__(256) k_vec_gather_strided(F* __restrict__ out, const F* __restrict__ in, size_t n, size_t offset, size_t stride) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fp(out + i, ld_fp(in + offset + i * stride));
+}
+
+// Inclusive prefix product out[i] = in[0] * ... * in[i] (what `array_prod_mul` yields for a single-component driver, round2.rs:18-41).
+// Three launches: tiles of 256 x SCAN_ITEMS elements (serial per lane, Hillis-Steele across the workgroup in LDS), a scan of the tile
+// totals by one workgroup, and the fix-up multiply.
+constexpr int SCAN_ITEMS = 8;
+template <class F>
+__device__ __forceinline__ F block_scan_mul(F v, F* sh, F* total) {      // inclusive scan over the 256 lanes; returns the lane's inclusive value
+    const int t = threadIdx.x;
+    sh[t] = v; __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        F x = sh[t];
+        if (t >= off) x = sh[t - off] * x;
+        __syncthreads();
+        sh[t] = x; __syncthreads();
+    }
+    if (total) *total = sh[255];
+    return sh[t];
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_prefix_prod_tiles(F* __restrict__ out, const F* __restrict__ in, size_t n, F* __restrict__ tile_tot) {
+    __shared__ F sh[256];
+    const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_ITEMS;
+    F loc[SCAN_ITEMS]; F run = F::one();
+    _Pragma("unroll") for (int k = 0; k < SCAN_ITEMS; k++) { if (base + k < n) run = run * ld_fp(in + base + k); loc[k] = run; }
+    F tot;
+    F incl = block_scan_mul(run, sh, &tot);
+    __syncthreads();
+    const F excl = threadIdx.x ? sh[threadIdx.x - 1] : F::one();
+    (void)incl;
+    _Pragma("unroll") for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) st_fp(out + base + k, excl * loc[k]);
+    if (threadIdx.x == 0) st_fp(tile_tot + blockIdx.x, tot);
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_prefix_prod_totals(F* __restrict__ tile_tot, size_t ntiles) {   // in place -> EXCLUSIVE prefix of the tile totals
+    __shared__ F sh[256];
+    F carry = F::one();
+    for (size_t b0 = 0; b0 < ntiles; b0 += 256) {
+        const size_t i = b0 + threadIdx.x;
+        F v = i < ntiles ? ld_fp(tile_tot + i) : F::one();
+        F tot;
+        block_scan_mul(v, sh, &tot);
+        __syncthreads();
+        const F excl = carry * (threadIdx.x ? sh[threadIdx.x - 1] : F::one());
+        if (i < ntiles) st_fp(tile_tot + i, excl);
+        carry = carry * tot;
+        __syncthreads();
+    }
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_prefix_prod_fixup(F* __restrict__ out, size_t n, const F* __restrict__ tile_excl) {
+    const size_t tile = (size_t)256 * SCAN_ITEMS;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < tile) continue;
+        st_fp(out + i, ld_fp(tile_excl + i / tile) * ld_fp(out + i));
+    }
+}
+// out[i] = in[i]^-1 (0 -> 0): Montgomery's trick over INV_ITEMS elements per lane, one Fermat inversion per lane (inv_many, plain.rs)
+constexpr int INV_ITEMS = 8;
+template <class F>
+__global__ void __launch_bounds__(128) k_vec_inverse(F* __restrict__ out, const F* __restrict__ in, size_t n) {
+    const size_t base = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * INV_ITEMS;
+    if (base >= n) return;
+    F x[INV_ITEMS], pre[INV_ITEMS]; F run = F::one();
+    _Pragma("unroll") for (int k = 0; k < INV_ITEMS; k++) {
+        x[k] = base + k < n ? ld_fp(in + base + k) : F::one();
+        pre[k] = run;
+        if (!x[k].is_zero()) run = run * x[k];
+    }
+    F inv = fp_inverse(run);
+    _Pragma("unroll") for (int k = INV_ITEMS - 1; k >= 0; k--) {
+        if (base + k >= n) continue;
+        if (x[k].is_zero()) { st_fp(out + base + k, F::zero()); continue; }
+        st_fp(out + base + k, inv * pre[k]);
+        inv = inv * x[k];
+    }
+}
+
 }  // namespace cg

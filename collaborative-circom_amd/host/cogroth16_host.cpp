@@ -364,13 +364,12 @@ public:
         CG(cg_dev_upload(ctx, tmp, r2t.data(), len * 32));
         CG(cg_vec_add_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));          // input += r_2t
         std::vector<Fr> buf(len);
-        const Fr one = fr_from_u64(curve, 1);
         if (me == 0) {                                                                 // KING_ID: interpolate at 0 from parties 0..2t, re-share with degree t
-            CG(cg_vec_distribute_powers_dev(ctx, curve.id, local.c[0], len, one.v, mul_lagrange_2t[0].v));   // acc = input * lagrange_0
+            CG(cg_vec_affine_dev(ctx, curve.id, local.c[0], local.c[0], len, mul_lagrange_2t[0].v, nullptr));   // acc = input * lagrange_0
             for (int other = 1; other <= 2 * sh_t; other++) {
                 snet->recv(other, buf.data(), len * 32);
                 CG(cg_dev_upload(ctx, tmp, buf.data(), len * 32));
-                CG(cg_vec_distribute_powers_dev(ctx, curve.id, tmp, len, one.v, mul_lagrange_2t[other].v));
+                CG(cg_vec_affine_dev(ctx, curve.id, tmp, tmp, len, mul_lagrange_2t[other].v, nullptr));
                 CG(cg_vec_add_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));
             }
             // ShamirCore::share per element: coefficients are drawn element by element (t per element)
@@ -385,9 +384,7 @@ public:
                 // share = acc + sum_d coeff_d * x^(d+1)
                 bool first = true;
                 for (int d = 0; d < sh_t; d++) {
-                    CG(cg_dev_memset_zero(ctx, term, len * 32));
-                    CG(cg_vec_add_dev(ctx, curve.id, term, term, d_coeff[d], len));
-                    CG(cg_vec_distribute_powers_dev(ctx, curve.id, term, len, one.v, xp.v));
+                    CG(cg_vec_affine_dev(ctx, curve.id, term, d_coeff[d], len, xp.v, nullptr));     // term = coeff_d * x^(d+1)
                     CG(cg_vec_add_dev(ctx, curve.id, share, first ? local.c[0] : share, term, len));
                     first = false; xp = fr_mul(curve, xp, x);
                 }

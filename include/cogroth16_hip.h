@@ -125,6 +125,17 @@ int32_t cg_vec_rep3_mul_local_dev(cg_ctx* ctx, int32_t curve, void* d_out, const
                                   const void* d_ba, const void* d_bb, const void* d_mask, size_t n);
 /* distribute_powers_and_mul_by_const (traits.rs:177): v[i] *= c * g^i */
 int32_t cg_vec_distribute_powers_dev(cg_ctx* ctx, int32_t curve, void* d_v, size_t n, const void* h_g, const void* h_c);
+/* Single-component pointwise helpers (plain / Shamir shares, co-plonk round 2):
+ *   affine:  out[i] = c * a[i] + d   (mul_with_public / add_with_public, plain.rs, shamir.rs:471-506; h_d may be NULL = 0)
+ *   fill:    v[i] = value
+ *   gather:  out[i] = in[offset + i * stride]                 (every 4th evaluation of a zkey polynomial, co-plonk round2.rs:196-206)
+ *   prefix:  out[i] = in[0] * ... * in[i]                     (what array_prod_mul yields, round2.rs:18-41); out may equal in
+ *   inverse: out[i] = in[i]^-1, 0 -> 0                        (inv_many; the reference errors on 0, callers check) */
+int32_t cg_vec_affine_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_a, size_t n, const void* h_c, const void* h_d);
+int32_t cg_vec_fill_dev(cg_ctx* ctx, int32_t curve, void* d_v, size_t n, const void* h_value);
+int32_t cg_vec_gather_strided_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n, size_t offset, size_t stride);
+int32_t cg_vec_prefix_prod_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n);
+int32_t cg_vec_inverse_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n);
 /* evaluate_constraint over all rows (traits.rs:180; groth16.rs:159-166): CSR matrix, signal index < n_inputs = public.
  * party: -1 = single component (plain / Shamir), 0..2 = REP3 party id (add_with_public asymmetry, rep3.rs:600-608).
  * d_wit_b / d_out_b may be NULL when party == -1. */

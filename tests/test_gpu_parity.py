@@ -499,3 +499,45 @@ def test_bases_subgroup_check(ctx, curve_name, group):
     assert ctx.check_on_curve(bases) == (0, None)                # still on the curve ...
     assert ctx.check_subgroup(bases) == (1, k)                   # ... but caught by the subgroup pass
     bases.release()
+
+
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
+@pytest.mark.parametrize("n", [1, 7, 2048, 2049, 5000, 1 << 16, (1 << 18) + 3])
+def test_vec_prefix_product_inverse_affine(ctx, curve, n):
+    """single-component helpers behind co-plonk's grand product (round2.rs:18-41,146-268) and mul/add_with_public"""
+    rng = np.random.default_rng(500 + n)
+    x = orc.random_field(curve, FR, n, rng)
+    if n > 4:
+        x[3] = 0                                                      # a zero in the middle: prefix collapses, inverse keeps 0
+    d_x = dev(ctx, x); d_o = ctx.alloc(n * 32)
+    # affine: out = c * x + d
+    c, d = orc.random_field(curve, FR, 2, rng)
+    ctx.vec_affine(curve, d_o, d_x, n, c, d)
+    want = orc.field_op(curve, FR, "add", orc.field_op(curve, FR, "mul", x, np.broadcast_to(c, x.shape).copy()), np.broadcast_to(d, x.shape).copy())
+    np.testing.assert_array_equal(d_o.download((n, 4)), want)
+    # inverse (0 -> 0)
+    ctx.vec_inverse(curve, d_o, d_x, n)
+    inv = d_o.download((n, 4))
+    prod = orc.field_op(curve, FR, "mul", inv, x)
+    one = orc.from_dec(curve, FR, "1")
+    for i in range(n):
+        if x[i].any(): assert np.array_equal(prod[i], one)
+        else: assert not inv[i].any()
+        if i > 64 and i % 97: continue                                 # spot check beyond the first elements
+    if n <= 2049:
+        np.testing.assert_array_equal(inv[5 % n], orc.field_inverse(curve, FR, x[5 % n]) if x[5 % n].any() else np.zeros(4, dtype=np.uint64))
+    # inclusive prefix product, checked through the recurrence out[i] = out[i-1] * x[i] with oracle multiplications
+    ctx.vec_prefix_prod(curve, d_o, d_x, n)
+    got = d_o.download((n, 4))
+    np.testing.assert_array_equal(got[0], x[0])
+    if n > 1:
+        np.testing.assert_array_equal(got[1:], orc.field_op(curve, FR, "mul", got[:-1], x[1:]))
+    # fill + strided gather
+    ctx.vec_fill(curve, d_o, n, c)
+    np.testing.assert_array_equal(d_o.download((n, 4)), np.broadcast_to(c, (n, 4)))
+    m = n // 4
+    if m:
+        d_g = ctx.alloc(m * 32)
+        ctx.vec_gather_strided(curve, d_g, d_x, m, 1 if n > 4 else 0, 4 if 4 * (m - 1) + 1 < n else 1)
+        off, st = (1 if n > 4 else 0), (4 if 4 * (m - 1) + 1 < n else 1)
+        np.testing.assert_array_equal(d_g.download((m, 4)), x[off:off + st * m:st][:m])
