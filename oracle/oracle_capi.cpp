@@ -294,6 +294,33 @@ int orc_plonk_round1_plain(int curve, const char* path, const uint64_t* full_wit
     return 0;
 }
 
+// transcript KAT hook: items = sequence of (kind, payload) with kind 0 = scalar (Fr), 1 = G1 point (packed affine, (0,0) = infinity)
+int orc_plonk_transcript(int curve, const int* kinds, const uint64_t* const* payloads, int n_items, uint64_t* out_challenge) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr; typedef typename C::Fq Fq;
+        PlonkTranscript<C> t;
+        for (int i = 0; i < n_items; i++) { if (kinds[i] == 0) t.add_scalar(ld<Fr>(payloads[i])); else t.add_point(ld_g1<Fq>(payloads[i])); }
+        st<Fr>(out_challenge, t.get_challenge());
+    });
+    return 0;
+}
+// rounds 1 + 2 with the plain driver; blind: 9 Fr (b_1..b_9); out: beta, gamma (Fr), commit_z (packed G1), optional poly_z (domain_size + 3)
+int orc_plonk_round2_plain(int curve, const char* path, const uint64_t* full_witness, const uint64_t* blind, uint64_t* out_beta_gamma, uint64_t* out_commit_z, uint64_t* poly_z) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr; typedef typename C::Fq Fq;
+        auto z = read_plonk_zkey<C>(path);
+        const Fr* w = reinterpret_cast<const Fr*>(full_witness);
+        std::vector<Fr> fw(w, w + (z.n_vars - z.n_additions));
+        Fr b[9]; for (int i = 0; i < 9; i++) b[i] = ld<Fr>(blind + i * Fr::N);
+        auto cm = plonk_round1_plain<C>(z, fw, b);
+        auto r2 = plonk_round2_plain<C>(z, fw, b, cm);
+        st<Fr>(out_beta_gamma, r2.beta); st<Fr>(out_beta_gamma + Fr::N, r2.gamma);
+        st_g1<Fq>(out_commit_z, r2.commit_z);
+        if (poly_z) memcpy(poly_z, r2.poly_z.data(), r2.poly_z.size() * sizeof(Fr));
+    });
+    return 0;
+}
+
 // ---- prover ------------------------------------------------------------------------------------------
 int orc_witness_map_plain(void* h, const uint64_t* full_witness, uint64_t* out_h) {
     ZK(h, {

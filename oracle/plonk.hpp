@@ -14,6 +14,58 @@
 
 namespace orc {
 
+// ---- Keccak-256 (original Keccak padding 0x01, as the `sha3::Keccak256` the reference's transcript uses, co-plonk/src/types.rs:20-25) ----
+struct Keccak256 {
+    uint64_t st[25]; uint8_t buf[136]; size_t fill = 0;
+    Keccak256() { memset(st, 0, sizeof st); }
+    static uint64_t rol(uint64_t x, int s) { return s ? (x << s) | (x >> (64 - s)) : x; }
+    void permute() {
+        static const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull, 0x0000000080000001ull,
+                                        0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+                                        0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull,
+                                        0x000000000000800aull, 0x800000008000000aull, 0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+        static const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+        for (int r = 0; r < 24; r++) {
+            uint64_t C[5], D[5], B[25];
+            for (int x = 0; x < 5; x++) C[x] = st[x] ^ st[x + 5] ^ st[x + 10] ^ st[x + 15] ^ st[x + 20];
+            for (int x = 0; x < 5; x++) D[x] = C[(x + 4) % 5] ^ rol(C[(x + 1) % 5], 1);
+            for (int i = 0; i < 25; i++) st[i] ^= D[i % 5];
+            for (int x = 0; x < 5; x++) for (int y = 0; y < 5; y++) B[y + 5 * ((2 * x + 3 * y) % 5)] = rol(st[x + 5 * y], ROT[x + 5 * y]);
+            for (int y = 0; y < 5; y++) for (int x = 0; x < 5; x++) st[x + 5 * y] = B[x + 5 * y] ^ (~B[(x + 1) % 5 + 5 * y] & B[(x + 2) % 5 + 5 * y]);
+            st[0] ^= RC[r];
+        }
+    }
+    void absorb_block() { for (int i = 0; i < 17; i++) { uint64_t w; memcpy(&w, buf + 8 * i, 8); st[i] ^= w; } permute(); fill = 0; }
+    void update(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) { buf[fill++] = p[i]; if (fill == 136) absorb_block(); } }
+    void finalize(uint8_t out[32]) { memset(buf + fill, 0, 136 - fill); buf[fill] ^= 0x01; buf[135] ^= 0x80; absorb_block(); memcpy(out, st, 32); }
+};
+
+// Keccak256Transcript (co-plonk/src/types.rs:122-176): field elements enter as big-endian canonical bytes; the point at infinity as
+// 2 x byte_len zero bytes; the challenge is the digest read big-endian, reduced mod r
+template <class C>
+struct PlonkTranscript {
+    typedef typename C::Fr Fr; typedef typename C::Fq Fq;
+    Keccak256 h;
+    template <class F> void add_field(const F& v) {
+        uint64_t can[F::N]; v.to_canonical(can);
+        uint8_t be[F::N * 8];
+        for (int i = 0; i < F::N * 8; i++) be[F::N * 8 - 1 - i] = (uint8_t)(can[i / 8] >> (8 * (i % 8)));
+        h.update(be, sizeof be);
+    }
+    void add_scalar(const Fr& s) { add_field(s); }
+    void add_point(const AffineT<Fq>& p) {
+        if (p.inf) { uint8_t z[2 * Fq::N * 8]; memset(z, 0, sizeof z); h.update(z, sizeof z); return; }
+        add_field(p.x); add_field(p.y);
+    }
+    Fr get_challenge() {
+        uint8_t d[32]; h.finalize(d);
+        // from_be_bytes_mod_order: Horner over the 32 bytes
+        Fr acc = Fr::zero(); const Fr b256 = Fr::from_u64(256);
+        for (int i = 0; i < 32; i++) acc = acc * b256 + Fr::from_u64(d[i]);
+        return acc;
+    }
+};
+
 template <class C>
 struct PlonkZKey {
     typedef typename C::Fr Fr; typedef typename C::Fq Fq;
@@ -22,6 +74,9 @@ struct PlonkZKey {
     std::vector<Addition> additions;
     std::vector<uint32_t> map_a, map_b, map_c;
     std::vector<AffineT<Fq>> p_tau;          // domain_size + 6 points (zkey.rs:149-151)
+    Fr k1, k2;                                // verifying key (zkey.rs:328-356)
+    AffineT<Fq> vk_g1[8];                     // qm, ql, qr, qo, qc, s1, s2, s3
+    std::vector<Fr> sigma_eval[3];            // 4 * domain_size evaluations of sigma1..3 on the extended domain (section 12)
 };
 
 template <class C>
@@ -43,6 +98,16 @@ static PlonkZKey<C> read_plonk_zkey(const std::string& path) {
         z.n_vars = h.u32(); z.n_public = h.u32(); z.domain_size = h.u32(); z.n_additions = h.u32(); z.n_constraints = h.u32();
         if (!z.domain_size || (z.domain_size & (z.domain_size - 1))) throw std::runtime_error("invalid domain size");
         while (((size_t)1 << z.power) < z.domain_size) z.power++;
+        z.k1 = read_mont<Fr>(h); z.k2 = read_mont<Fr>(h);
+        for (int i = 0; i < 8; i++) z.vk_g1[i] = read_g1<Fq>(h);
+    }
+    {   // section 12 = sigma1 | sigma2 | sigma3, each domain_size coefficients followed by 4 * domain_size evaluations (zkey.rs:170-180,116-135)
+        Cursor c(sec(12));
+        for (int k = 0; k < 3; k++) {
+            for (size_t i = 0; i < z.domain_size; i++) read_mont<Fr>(c);
+            z.sigma_eval[k].resize(4 * z.domain_size);
+            for (auto& v : z.sigma_eval[k]) v = read_mont<Fr>(c);
+        }
     }
     { Cursor c(sec(3)); z.additions.resize(z.n_additions); for (auto& a : z.additions) { a.id1 = c.u32(); a.id2 = c.u32(); a.f1 = read_mont<Fr>(c); a.f2 = read_mont<Fr>(c); } }
     auto id_map = [&](uint32_t id) { Cursor c(sec(id)); std::vector<uint32_t> m(z.n_constraints); for (auto& v : m) v = c.u32(); return m; };
@@ -78,6 +143,52 @@ static std::vector<AffineT<typename C::Fq>> plonk_round1_plain(const PlonkZKey<C
         if (polys_out) polys_out->insert(polys_out->end(), poly.begin(), poly.end());
     }
     return commits;
+}
+
+// Round 2 (co-plonk/src/round2.rs:146-298) for a single-component driver: challenges beta, gamma from the transcript, the grand
+// product z, its blinded coefficient form and [z]_1.  `round1_commits` = opened [a]_1, [b]_1, [c]_1; blind[6..9) = b_7, b_8, b_9.
+template <class C>
+struct PlonkRound2 { typename C::Fr beta, gamma; AffineT<typename C::Fq> commit_z; std::vector<typename C::Fr> poly_z; };
+template <class C>
+static PlonkRound2<C> plonk_round2_plain(const PlonkZKey<C>& z, const std::vector<typename C::Fr>& full_witness, const typename C::Fr* blind,
+                                         const std::vector<AffineT<typename C::Fq>>& round1_commits) {
+    typedef typename C::Fr Fr; typedef typename C::G1 G1;
+    std::vector<Fr> w(full_witness);
+    w[0] = Fr::zero();
+    auto get = [&](size_t idx) -> Fr { if (idx >= w.size()) throw std::runtime_error("corrupted witness index"); return w[idx]; };
+    for (const auto& a : z.additions) w.push_back(get(a.id1) * a.f1 + get(a.id2) * a.f2);
+    const size_t n = z.domain_size;
+    PlonkRound2<C> out;
+    {   // round2.rs:243-263: vk points, public inputs without the leading entry, the round-1 commitments
+        PlonkTranscript<C> t;
+        for (int i = 0; i < 8; i++) t.add_point(z.vk_g1[i]);
+        for (size_t i = 1; i <= z.n_public; i++) t.add_scalar(w[i]);
+        for (const auto& cm : round1_commits) t.add_point(cm);
+        out.beta = t.get_challenge();
+        PlonkTranscript<C> t2; t2.add_scalar(out.beta);
+        out.gamma = t2.get_challenge();
+    }
+    const Fr omega = roots_of_unity<Fr>().roots[z.power];
+    std::vector<Fr> num(n), den(n);
+    Fr wv = Fr::one();
+    for (size_t i = 0; i < n; i++) {                                                        // :162-210
+        const Fr a = i < z.n_constraints ? get(z.map_a[i]) : Fr::zero(), b = i < z.n_constraints ? get(z.map_b[i]) : Fr::zero(), c = i < z.n_constraints ? get(z.map_c[i]) : Fr::zero();
+        const Fr betaw = out.beta * wv;
+        num[i] = (a + betaw + out.gamma) * (b + z.k1 * betaw + out.gamma) * (c + z.k2 * betaw + out.gamma);
+        den[i] = (a + out.beta * z.sigma_eval[0][4 * i] + out.gamma) * (b + out.beta * z.sigma_eval[1][4 * i] + out.gamma) * (c + out.beta * z.sigma_eval[2][4 * i] + out.gamma);
+        wv = wv * omega;
+    }
+    for (size_t i = 1; i < n; i++) { num[i] = num[i] * num[i - 1]; den[i] = den[i] * den[i - 1]; }   // array_prod_mul (:18-41), single component
+    std::vector<Fr> zb(n);
+    for (size_t i = 0; i < n; i++) zb[(i + 1) % n] = num[i] * den[i].inverse();                         // :229-231 incl. rotate_right(1)
+    ntt_inverse(zb.data(), n, omega);
+    const Fr b6 = blind[6], b7 = blind[7], b8 = blind[8];                                               // coeff_rev = [b6, b7, b8] (lib.rs:140-158)
+    zb[0] = zb[0] - b8; zb[1] = zb[1] - b7; zb[2] = zb[2] - b6;
+    zb.push_back(b8); zb.push_back(b7); zb.push_back(b6);
+    if (zb.size() > z.p_tau.size()) throw std::runtime_error("polynomial degree too large");
+    out.commit_z = msm_naive<G1>(z.p_tau.data(), zb.data(), zb.size()).to_affine();
+    out.poly_z = zb;
+    return out;
 }
 
 }  // namespace orc

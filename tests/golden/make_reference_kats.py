@@ -8,6 +8,8 @@ Sources (values only, no code is copied):
   /root/reference/mpc-core/tests/protocols/rep3.rs:242-350             Fr product KAT (rep3_mul_vec_bn)
   /root/reference/co-circom/circom-types/src/witness.rs:101-134        witness KAT
   /root/reference/co-circom/co-plonk/src/round1.rs:346-428             Plonk round-1 commitments [a]_1, [b]_1, [c]_1 (blinding b_i = i)
+  /root/reference/co-circom/co-plonk/src/round2.rs:326-355             Plonk round-2 commitment [z]_1
+  /root/reference/co-circom/co-plonk/src/types.rs:194-227              Keccak256 transcript challenge
 """
 import json, re, sys, os
 
@@ -79,6 +81,21 @@ for t in re.split(r"#\[test\]", src)[1:]:
         entry[which] = [m.group(1), m.group(2)]
     pk[name] = entry
 out["plonk_round1"] = pk
+
+src = open(f"{REF}/co-circom/co-plonk/src/round2.rs").read()
+m = re.search(r"commit_z,\s*g1_from_xy!\(\s*\"(\d+)\",\s*\"(\d+)\"", src, re.S)
+out["plonk_round2"] = {"test_round2_multiplier2": {"file": "Plonk/bn254/multiplier2/circuit.zkey", "commit_z": [m.group(1), m.group(2)]}}
+
+# transcript KAT: the sequence of add_point / add_scalar calls and the expected challenge (types.rs:194-227)
+src = open(f"{REF}/co-circom/co-plonk/src/types.rs").read()
+body = src[src.index("fn test_keccak_transcript"):]
+items = []
+for mm in re.finditer(r'transcript\.add_point\(to_g1_bn254!\(\s*"(\d+)",\s*"(\d+)"\s*\)\)|transcript\.add_point\(ark_bn254::G1Affine::identity\(\)\)|transcript\.add_scalar\(\s*ark_bn254::Fr::from_str\(\s*"(\d+)"', body, re.S):
+    if mm.group(1): items.append(["point", mm.group(1), mm.group(2)])
+    elif mm.group(3): items.append(["scalar", mm.group(3)])
+    else: items.append(["infinity"])
+exp = re.search(r'assert_eq!\(\s*ark_bn254::Fr::from_str\(\s*"(\d+)"', body, re.S).group(1)
+out["plonk_transcript"] = {"items": items, "challenge": exp}
 
 dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_kats.json")
 json.dump(out, open(dst, "w"), indent=1)

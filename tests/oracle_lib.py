@@ -403,3 +403,25 @@ def plonk_round1_plain(curve, path, full_witness, blind, want_polys=False):
     _chk(lib().orc_plonk_round1_plain(curve, path.encode(), _p(np.ascontiguousarray(full_witness, dtype=np.uint64)),
                                       _p(np.ascontiguousarray(blind, dtype=np.uint64)), _p(out), _p(polys) if want_polys else None))
     return (out, polys) if want_polys else out
+
+
+def plonk_transcript(curve, items):
+    """items: list of ("scalar", limbs) / ("point", packed G1 limbs; zeros = infinity) -> Keccak256 transcript challenge (Fr)"""
+    n = len(items)
+    kinds = (C.c_int * n)(*[0 if k == "scalar" else 1 for k, _ in items])
+    keep = [np.ascontiguousarray(v, dtype=np.uint64) for _, v in items]
+    ptrs = (C.c_void_p * n)(*[v.ctypes.data for v in keep])
+    out = np.zeros(4, dtype=np.uint64)
+    _chk(lib().orc_plonk_transcript(curve, kinds, ptrs, n, _p(out)))
+    return out
+
+
+def plonk_round2_plain(curve, path, full_witness, blind, want_poly=False):
+    """rounds 1 + 2 (plain driver): (beta, gamma, commit_z[, poly_z])"""
+    i = plonk_zkey_info(curve, path)
+    nq = nlimbs(curve, FQ)
+    bg = np.zeros((2, 4), dtype=np.uint64); cz = np.zeros(2 * nq, dtype=np.uint64)
+    poly = np.zeros((i["domain_size"] + 3, 4), dtype=np.uint64) if want_poly else None
+    _chk(lib().orc_plonk_round2_plain(curve, path.encode(), _p(np.ascontiguousarray(full_witness, dtype=np.uint64)),
+                                      _p(np.ascontiguousarray(blind, dtype=np.uint64)), _p(bg), _p(cz), _p(poly) if want_poly else None))
+    return (bg[0], bg[1], cz, poly) if want_poly else (bg[0], bg[1], cz)

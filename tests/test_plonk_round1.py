@@ -12,7 +12,8 @@ from oracle_lib import BN254, BLS12_381, FR, FQ, G1
 from product import cg, ensure_built
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-KATS = json.load(open(os.path.join(GOLDEN, "reference_kats.json")))["plonk_round1"]
+ALL_KATS = json.load(open(os.path.join(GOLDEN, "reference_kats.json")))
+KATS = ALL_KATS["plonk_round1"]
 CURVES = {"bn254": BN254, "bls12_381": BLS12_381}
 
 
@@ -20,8 +21,8 @@ def fx(curve_name, f):
     return os.path.join(GOLDEN, "plonk", curve_name, "multiplier2", f)
 
 
-def deterministic_blinding(curve):
-    return np.stack([orc.from_dec(curve, FR, str(i)) for i in range(6)])        # Round1Challenges::deterministic (round1.rs:99-107)
+def deterministic_blinding(curve, count=6):
+    return np.stack([orc.from_dec(curve, FR, str(i)) for i in range(count)])    # Round1Challenges::deterministic (round1.rs:99-107)
 
 
 def kat_points(curve, kat):
@@ -58,6 +59,26 @@ def test_oracle_round1_structure(curve_name):
         np.testing.assert_array_equal(polys1[k, n], b[2 * k + 1]); np.testing.assert_array_equal(polys1[k, n + 1], b[2 * k])
         # commitment recomputed from the coefficient vector with an independent (naive) MSM
         np.testing.assert_array_equal(orc.msm(curve, G1, p_tau[:n + 2], polys1[k], algo="naive"), c1[k])
+
+
+def test_oracle_transcript_matches_reference_kat():
+    """Keccak256 transcript (co-plonk/src/types.rs:194-227): points, the point at infinity and scalars -> challenge"""
+    kat = ALL_KATS["plonk_transcript"]
+    items = []
+    for it in kat["items"]:
+        if it[0] == "scalar": items.append(("scalar", orc.from_dec(BN254, FR, it[1])))
+        elif it[0] == "point": items.append(("point", np.concatenate([orc.from_dec(BN254, FQ, it[1]), orc.from_dec(BN254, FQ, it[2])])))
+        else: items.append(("point", np.zeros(8, dtype=np.uint64)))
+    np.testing.assert_array_equal(orc.plonk_transcript(BN254, items), orc.from_dec(BN254, FR, kat["challenge"]))
+
+
+def test_oracle_round2_matches_reference_kat():
+    """[z]_1 of the grand-product polynomial with the deterministic blinding (co-plonk/src/round2.rs:326-355)"""
+    kat = ALL_KATS["plonk_round2"]["test_round2_multiplier2"]
+    w = orc.read_wtns(BN254, fx("bn254", "witness.wtns"))
+    beta, gamma, cz = orc.plonk_round2_plain(BN254, fx("bn254", "circuit.zkey"), w, deterministic_blinding(BN254, 9))
+    np.testing.assert_array_equal(cz, np.concatenate([orc.from_dec(BN254, FQ, kat["commit_z"][0]), orc.from_dec(BN254, FQ, kat["commit_z"][1])]))
+    assert beta.any() and gamma.any() and not np.array_equal(beta, gamma)
 
 
 def test_host_plonk_zkey_reader_matches_oracle():
