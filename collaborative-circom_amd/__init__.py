@@ -471,6 +471,28 @@ def plonk_round1_plain(curve, zkey_path, full_witness, blind, device=0):
     return out
 
 
+def plonk_round2_plain(curve, zkey_path, full_witness, blind, device=0, want_poly=False):
+    """co-plonk rounds 1 + 2 with the plain driver on the GPU: (beta, gamma, commit_z[, poly_z])"""
+    info = host_plonk_zkey_info(curve, zkey_path)
+    nq = 6 if curve == BLS12_381 else 4
+    bg = np.zeros((2, 4), dtype=np.uint64); cz = np.zeros(2 * nq, dtype=np.uint64)
+    poly = np.zeros((info["domain_size"] + 3, 4), dtype=np.uint64) if want_poly else None
+    _hchk(load_host().cgh_plonk_round2_plain(int(device), curve, zkey_path.encode(), _hp(np.ascontiguousarray(full_witness, dtype=np.uint64)),
+                                             _hp(np.ascontiguousarray(blind, dtype=np.uint64)), _hp(bg), _hp(cz), _hp(poly) if want_poly else None))
+    return (bg[0], bg[1], cz, poly) if want_poly else (bg[0], bg[1], cz)
+
+
+def host_plonk_transcript(curve, items):
+    """items: list of ("scalar", limbs) / ("point", packed G1 limbs) -> challenge computed by the host mirror's Keccak256 transcript"""
+    n = len(items)
+    kinds = (C.c_int32 * n)(*[0 if k == "scalar" else 1 for k, _ in items])
+    keep = [np.ascontiguousarray(v, dtype=np.uint64) for _, v in items]
+    ptrs = (C.c_void_p * n)(*[v.ctypes.data for v in keep])
+    out = np.zeros(4, dtype=np.uint64)
+    _hchk(load_host().cgh_plonk_transcript(curve, kinds, ptrs, n, _hp(out)))
+    return out
+
+
 def plonk_round1_rep3(curve, zkey_path, pub, wit_a, wit_b, blind_a, blind_b, device=0):
     """three REP3 parties (threads) on one GPU; returns (3 parties, 3 commitments, packed G1)"""
     nq = 6 if curve == BLS12_381 else 4

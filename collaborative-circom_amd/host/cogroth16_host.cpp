@@ -698,6 +698,7 @@ static void release_zkey(cg_ctx* ctx, DeviceZKey& d) {
 
 static void store_proof(const Proof& p, uint8_t* out) { memcpy(out, p.a.data(), p.a.size()); memcpy(out + p.a.size(), p.b.data(), p.b.size()); memcpy(out + p.a.size() + p.b.size(), p.c.data(), p.c.size()); }
 
+static bool all_zero_bytes(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
 // ==================================================================================================== co-plonk, round 1
 // First slice of the Plonk prover on the same kernels: [a]_1, [b]_1, [c]_1 = MSM(p_tau, blind(iNTT(wire values))).
 // The reference pins the exact result for the blinding b_i = i (co-plonk/src/round1.rs:346-383).
@@ -708,6 +709,9 @@ struct PlonkZKey {   // circom-types/src/plonk/zkey.rs:18-42 (the fields round 1
     std::vector<Addition> additions;
     std::vector<uint32_t> map[3];
     Bytes p_tau;        // domain_size + 6 packed G1 points
+    Fr k1, k2;          // verifying key, zkey.rs:328-356
+    Bytes vk_g1;        // qm, ql, qr, qo, qc, s1, s2, s3 (8 packed G1 points)
+    std::vector<Fr> sigma_eval[3];   // 4 * domain_size evaluations of sigma1..3 (section 12, zkey.rs:116-135,170-180)
 };
 static PlonkZKey read_plonk_zkey(int curve_id, const std::string& path) {   // zkey.rs:83-255, header :373-424
     Curve c{curve_id};
@@ -732,11 +736,72 @@ static PlonkZKey read_plonk_zkey(int curve_id, const std::string& path) {   // z
     z.n_vars = h.u32(); z.n_public = h.u32(); z.domain_size = h.u32(); z.n_additions = h.u32(); z.n_constraints = h.u32();
     if (!z.domain_size || (z.domain_size & (z.domain_size - 1))) throw std::runtime_error("Invalid domain size. Must be power of 2");
     while (((size_t)1 << z.power) < z.domain_size) z.power++;
+    h.bytes(z.k1.v, 32); h.bytes(z.k2.v, 32);
+    z.vk_g1.resize(8 * c.aff(CG_G1)); h.bytes(z.vk_g1.data(), z.vk_g1.size());
+    {
+        Cursor sg = section(12);
+        for (int k = 0; k < 3; k++) {
+            sg.need(z.domain_size * 32); sg.off += z.domain_size * 32;                 // coefficient form, not needed by the prover rounds implemented here
+            z.sigma_eval[k].resize(4 * z.domain_size);
+            sg.bytes(z.sigma_eval[k].data(), 4 * z.domain_size * 32);
+        }
+    }
     { Cursor a = section(3); z.additions.resize(z.n_additions); for (auto& e : z.additions) { e.id1 = a.u32(); e.id2 = a.u32(); a.bytes(e.f1.v, 32); a.bytes(e.f2.v, 32); } }
     for (int k = 0; k < 3; k++) { Cursor m = section(4 + k); z.map[k].resize(z.n_constraints); for (auto& v : z.map[k]) v = m.u32(); }
     { Cursor t = section(14); z.p_tau.resize((z.domain_size + 6) * c.aff(CG_G1)); t.bytes(z.p_tau.data(), z.p_tau.size()); }
     return z;
 }
+
+// Keccak-256 (pad 0x01) and the reference's transcript conventions (co-plonk/src/types.rs:122-176): big-endian canonical field
+// bytes, 2 * byte_len zero bytes for the point at infinity, challenge = digest as a big-endian integer mod r
+class Keccak256 {
+    uint64_t a[25]; uint8_t blk[136]; size_t used = 0;
+    static uint64_t rotl(uint64_t v, unsigned s) { return s ? (v << s) | (v >> (64 - s)) : v; }
+    void f1600() {
+        uint64_t lfsr = 1;
+        for (int round = 0; round < 24; round++) {
+            uint64_t col[5];
+            for (int x = 0; x < 5; x++) col[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+            for (int x = 0; x < 5; x++) { const uint64_t d = col[(x + 4) % 5] ^ rotl(col[(x + 1) % 5], 1); for (int y = 0; y < 25; y += 5) a[y + x] ^= d; }
+            // rho + pi along the standard lane walk
+            int x = 1, y = 0; uint64_t cur = a[1];
+            for (int t = 0; t < 24; t++) {
+                const int nx = y, ny = (2 * x + 3 * y) % 5;
+                const uint64_t nxt = a[nx + 5 * ny];
+                a[nx + 5 * ny] = rotl(cur, ((t + 1) * (t + 2) / 2) % 64);
+                cur = nxt; x = nx; y = ny;
+            }
+            for (int yy = 0; yy < 25; yy += 5) { uint64_t r[5]; for (int xx = 0; xx < 5; xx++) r[xx] = a[yy + xx]; for (int xx = 0; xx < 5; xx++) a[yy + xx] = r[xx] ^ (~r[(xx + 1) % 5] & r[(xx + 2) % 5]); }
+            for (int j = 0; j < 7; j++) {                                               // iota via the degree-8 LFSR
+                const bool bit = lfsr & 1; lfsr = (lfsr << 1) ^ ((lfsr >> 7) * 0x71); lfsr &= 0xff;
+                if (bit) a[0] ^= (uint64_t)1 << ((1 << j) - 1);
+            }
+        }
+    }
+    void absorb() { for (int i = 0; i < 17; i++) { uint64_t w; memcpy(&w, blk + 8 * i, 8); a[i] ^= w; } f1600(); used = 0; }
+public:
+    Keccak256() { memset(a, 0, sizeof a); }
+    void update(const uint8_t* p, size_t n) { while (n--) { blk[used++] = *p++; if (used == sizeof blk) absorb(); } }
+    void finish(uint8_t out[32]) { memset(blk + used, 0, sizeof blk - used); blk[used] ^= 0x01; blk[sizeof blk - 1] ^= 0x80; absorb(); memcpy(out, a, 32); }
+};
+class PlonkTranscript {
+    const Curve& c; Keccak256 h;
+    void be_bytes(const uint64_t* canonical, size_t nbytes) { std::vector<uint8_t> be(nbytes); for (size_t i = 0; i < nbytes; i++) be[nbytes - 1 - i] = (uint8_t)(canonical[i / 8] >> (8 * (i % 8))); h.update(be.data(), nbytes); }
+public:
+    explicit PlonkTranscript(const Curve& cv) : c(cv) {}
+    void add_scalar(const Fr& s) { uint64_t can[4]; CG(cg_fr_to_canonical(c.id, s.v, can, 1)); be_bytes(can, 32); }
+    void add_point(const uint8_t* aff) {                                                // packed affine G1, (0,0) = infinity
+        if (all_zero_bytes(aff, c.aff(CG_G1))) { std::vector<uint8_t> z(2 * c.fq(), 0); h.update(z.data(), z.size()); return; }
+        uint64_t can[12]; CG(cg_fq_to_canonical(c.id, aff, can, 2));
+        be_bytes(can, c.fq()); be_bytes(can + c.fq() / 8, c.fq());
+    }
+    Fr get_challenge() {
+        uint8_t d[32]; h.finish(d);
+        Fr acc = fr_from_u64(c, 0); const Fr b = fr_from_u64(c, 256);                  // from_be_bytes_mod_order
+        for (int i = 0; i < 32; i++) acc = fr_add(c, fr_mul(c, acc, b), fr_from_u64(c, d[i]));
+        return acc;
+    }
+};
 
 class CoPlonkRound1 {
 public:
@@ -773,7 +838,8 @@ public:
     }
     // round1.rs:118-206 + :260-312.  public_inputs = n_public + 1 values (entry 0 is overwritten by 0, types.rs:107-109);
     // blind = b_1..b_6 as shares; polys_out (optional) receives the three blinded coefficient vectors (n + 2 each, device)
-    std::vector<Point> round1(const PlonkZKey& z, const cg_bases* p_tau, std::vector<Fr> public_inputs, const ShareVec& private_witness, const FieldShare* blind, ShareVec* polys_out = nullptr) {
+    std::vector<Point> round1(const PlonkZKey& z, const cg_bases* p_tau, std::vector<Fr> public_inputs, const ShareVec& private_witness, const FieldShare* blind,
+                              ShareVec* polys_out = nullptr, ShareVec* buffers_out = nullptr) {
         const Curve& c = driver.curve;
         cg_ctx* ctx = driver.ctx;
         const size_t n = z.domain_size, nc = z.n_constraints;
@@ -795,6 +861,10 @@ public:
             if (nc) CG(cg_dev_upload(ctx, d_col, z.map[w].data(), nc * 4));
             ShareVec poly = driver.alloc_vec(n + 2);                                              // zero-filled: rows >= n_constraints stay 0
             CG(cg_spmv_csr_dev(ctx, c.id, d_rp, d_col, d_one, nc, d_pub, (uint32_t)(z.n_public + 1), driver.party(), ext.c[0], ext.c[1], poly.c[0], poly.c[1]));
+            if (buffers_out) {                                                                    // buffer_a/b/c are read again by round 2 (round2.rs:162-166)
+                buffers_out[w] = driver.alloc_vec(n);
+                for (int j = 0; j < driver.k(); j++) CG(cg_vec_gather_strided_dev(ctx, c.id, buffers_out[w].c[j], poly.c[j], n, 0, 1));
+            }
             CG(cg_ntt_dev(ctx, c.id, poly.c, driver.k(), n, omega.v, 1, nullptr));                // ifft over the first n entries
             const FieldShare &b_hi = blind[2 * w], &b_lo = blind[2 * w + 1];                      // blind_coefficients, lib.rs:140-158
             for (int j = 0; j < driver.k(); j++) {
@@ -812,6 +882,69 @@ public:
         CG(cg_dev_free(ctx, d_pub)); CG(cg_dev_free(ctx, d_rp)); CG(cg_dev_free(ctx, d_one)); CG(cg_dev_free(ctx, d_col));
         if (z.n_additions) driver.free_vec(ext);
         return opened;
+    }
+};
+
+// Round 2 (co-plonk/src/round2.rs:146-298) for the single-component drivers: challenges from the transcript, the grand product z
+// entirely as device vector operations, its blinded coefficients and [z]_1.
+class CoPlonkRound2 {
+public:
+    HipDriver& driver;
+    explicit CoPlonkRound2(HipDriver& d) : driver(d) {}
+    struct Result { Fr beta, gamma; Point commit_z; };
+
+    Result round2(const PlonkZKey& z, const cg_bases* p_tau, const std::vector<Fr>& public_inputs /* n_public values */, const std::vector<Point>& round1_commits,
+                  const ShareVec* buffers, const FieldShare* blind /* b[6..9) used */, ShareVec* poly_z_out = nullptr) {
+        if (driver.mode == Mode::Rep3) throw std::runtime_error("co-plonk round 2 is implemented for the single-component drivers (array_prod_mul / inv_many over REP3 shares: next)");
+        const Curve& c = driver.curve; cg_ctx* ctx = driver.ctx;
+        const size_t n = z.domain_size;
+        Result res;
+        {   // round2.rs:243-263
+            PlonkTranscript t(c);
+            for (int i = 0; i < 8; i++) t.add_point(z.vk_g1.data() + i * c.aff(CG_G1));
+            for (const Fr& v : public_inputs) t.add_scalar(v);
+            for (const Point& cm : round1_commits) { Bytes a = pt_to_affine(c, cm); t.add_point(a.data()); }
+            res.beta = t.get_challenge();
+            PlonkTranscript t2(c); t2.add_scalar(res.beta);
+            res.gamma = t2.get_challenge();
+        }
+        const Fr omega = snarkjs_roots(c).roots[z.power], one = fr_from_u64(c, 1);
+        auto dv = [&]() { return driver.dalloc(n * 32); };
+        void* betaw = dv();                                                                       // beta * omega^i
+        CG(cg_vec_fill_dev(ctx, c.id, betaw, n, res.beta.v));
+        CG(cg_vec_distribute_powers_dev(ctx, c.id, betaw, n, omega.v, one.v));
+        void* num = dv(); void* den = dv(); void* t1 = dv(); void* sig = dv();
+        void* d_sigma = driver.dalloc(4 * n * 32);
+        const Fr k[3] = {one, z.k1, z.k2};
+        for (int w = 0; w < 3; w++) {                                                             // :162-210
+            CG(cg_vec_affine_dev(ctx, c.id, t1, betaw, n, k[w].v, res.gamma.v));                  // k_w * beta * omega^i + gamma
+            CG(cg_vec_add_dev(ctx, c.id, t1, t1, buffers[w].c[0], n));                            // + wire value
+            if (w == 0) CG(cg_vec_gather_strided_dev(ctx, c.id, num, t1, n, 0, 1)); else CG(cg_vec_mul_dev(ctx, c.id, num, num, t1, n));
+            CG(cg_dev_upload(ctx, d_sigma, z.sigma_eval[w].data(), 4 * n * 32));
+            CG(cg_vec_gather_strided_dev(ctx, c.id, sig, d_sigma, n, 0, 4));                      // sigma_w evaluated on the small domain
+            CG(cg_vec_affine_dev(ctx, c.id, t1, sig, n, res.beta.v, res.gamma.v));
+            CG(cg_vec_add_dev(ctx, c.id, t1, t1, buffers[w].c[0], n));
+            if (w == 0) CG(cg_vec_gather_strided_dev(ctx, c.id, den, t1, n, 0, 1)); else CG(cg_vec_mul_dev(ctx, c.id, den, den, t1, n));
+        }
+        CG(cg_vec_prefix_prod_dev(ctx, c.id, num, num, n));                                       // array_prod_mul (:18-41) on one component
+        CG(cg_vec_prefix_prod_dev(ctx, c.id, den, den, n));
+        CG(cg_vec_inverse_dev(ctx, c.id, den, den, n));                                           // inv_many (:228)
+        CG(cg_vec_mul_dev(ctx, c.id, num, num, den, n));
+        ShareVec poly = driver.alloc_vec(n + 3);
+        if (n > 1) CG(cg_vec_gather_strided_dev(ctx, c.id, (uint8_t*)poly.c[0] + 32, num, n - 1, 0, 1));   // rotate_right(1) (:231)
+        CG(cg_vec_gather_strided_dev(ctx, c.id, poly.c[0], num, 1, n - 1, 1));
+        CG(cg_ntt_dev(ctx, c.id, poly.c, 1, n, omega.v, 1, nullptr));                             // :235
+        Fr head[3]; CG(cg_dev_download(ctx, head, poly.c[0], 96));                                // blind_coefficients with b[6..9) (lib.rs:140-158)
+        const Fr b6 = blind[6].c[0], b7 = blind[7].c[0], b8 = blind[8].c[0];
+        head[0] = fr_sub(c, head[0], b8); head[1] = fr_sub(c, head[1], b7); head[2] = fr_sub(c, head[2], b6);
+        CG(cg_dev_upload(ctx, poly.c[0], head, 96));
+        Fr tail[3] = {b8, b7, b6};
+        CG(cg_dev_upload(ctx, (uint8_t*)poly.c[0] + n * 32, tail, 96));
+        if (n + 3 > z.domain_size + 6) throw std::runtime_error("polynomial degree too large");
+        res.commit_z = driver.open_point(driver.msm_public_points(p_tau, CG_G1, 0, n + 3, poly));   // :268-275
+        for (void* p : {betaw, num, den, t1, sig, d_sigma}) CG(cg_dev_free(ctx, p));
+        if (poly_z_out) *poly_z_out = poly; else driver.free_vec(poly);
+        return res;
     }
 };
 
@@ -1023,6 +1156,47 @@ int32_t cgh_plonk_round1_plain(int32_t device, int32_t curve, const char* zkey_p
         driver.free_vec(wit); cg_bases_release(tau); cg_ctx_destroy(ctx);
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
+}
+// rounds 1 + 2 with the plain driver; blind = 9 Fr (b_1..b_9); out: beta, gamma (2 Fr), commit_z (packed G1), optional transcript-free
+// poly_z (domain_size + 3 Fr)
+int32_t cgh_plonk_round2_plain(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* full_witness, const uint64_t* blind,
+                               uint64_t* out_beta_gamma, uint64_t* out_commit_z, uint64_t* out_poly_z) {
+    cg_ctx* ctx = nullptr;
+    try {
+        using namespace cgh;
+        PlonkZKey z = read_plonk_zkey(curve, zkey_path);
+        if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
+        const Curve& c = z.curve;
+        cg_bases* tau = nullptr; CG(cg_bases_register(ctx, c.id, CG_G1, z.p_tau.data(), z.domain_size + 6, c.aff(CG_G1), -1, &tau));
+        const Fr* w = (const Fr*)full_witness;
+        std::vector<Fr> pub(w, w + z.n_public + 1);
+        HipDriver driver(ctx, c, Mode::Plain, nullptr);
+        ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_additions - z.n_public - 1);
+        FieldShare b[9]; for (int i = 0; i < 9; i++) { memcpy(b[i].c[0].v, blind + 4 * i, 32); b[i].c[1] = b[i].c[0]; }
+        CoPlonkRound1 r1(driver);
+        ShareVec buffers[3];
+        auto cm = r1.round1(z, tau, pub, wit, b, nullptr, buffers);
+        CoPlonkRound2 r2(driver);
+        ShareVec poly_z;
+        auto res = r2.round2(z, tau, std::vector<Fr>(pub.begin() + 1, pub.end()), cm, buffers, b, &poly_z);
+        memcpy(out_beta_gamma, res.beta.v, 32); memcpy(out_beta_gamma + 4, res.gamma.v, 32);
+        Bytes a = pt_to_affine(c, res.commit_z); memcpy(out_commit_z, a.data(), a.size());
+        if (out_poly_z) CG(cg_dev_download(ctx, out_poly_z, poly_z.c[0], poly_z.n * 32));
+        driver.free_vec(poly_z); for (auto& bf : buffers) driver.free_vec(bf);
+        driver.free_vec(wit); cg_bases_release(tau); cg_ctx_destroy(ctx);
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
+}
+// Keccak256 transcript hook (tests): kinds[i] 0 = scalar (Fr), 1 = packed G1 point
+int32_t cgh_plonk_transcript(int32_t curve, const int32_t* kinds, const uint64_t* const* payloads, int32_t n_items, uint64_t* out_challenge) {
+    try {
+        using namespace cgh;
+        Curve c{curve};
+        PlonkTranscript t(c);
+        for (int i = 0; i < n_items; i++) { if (kinds[i] == 0) { Fr s; memcpy(s.v, payloads[i], 32); t.add_scalar(s); } else t.add_point((const uint8_t*)payloads[i]); }
+        Fr r = t.get_challenge(); memcpy(out_challenge, r.v, 32);
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
 // Rep3HipProtocol x 3 (three threads, in-process network).  blind_a[i] / blind_b[i] = party i's (a, b) shares of b_1..b_6.
 // out_commits = 3 parties x 3 packed G1 (every party opens the same points)

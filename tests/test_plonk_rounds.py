@@ -72,6 +72,29 @@ def test_oracle_transcript_matches_reference_kat():
     np.testing.assert_array_equal(orc.plonk_transcript(BN254, items), orc.from_dec(BN254, FR, kat["challenge"]))
 
 
+def _transcript_items(curve):
+    kat = ALL_KATS["plonk_transcript"]
+    items = []
+    for it in kat["items"]:
+        if it[0] == "scalar": items.append(("scalar", orc.from_dec(curve, FR, it[1])))
+        elif it[0] == "point": items.append(("point", np.concatenate([orc.from_dec(curve, FQ, it[1]), orc.from_dec(curve, FQ, it[2])])))
+        else: items.append(("point", np.zeros(8, dtype=np.uint64)))
+    return items, orc.from_dec(curve, FR, kat["challenge"])
+
+
+def test_host_transcript_matches_reference_kat():
+    """the host mirror's own Keccak256 transcript (no device needed) against the reference's KAT and, on random input, the oracle's"""
+    ensure_built()
+    items, want = _transcript_items(BN254)
+    np.testing.assert_array_equal(cg.host_plonk_transcript(BN254, items), want)
+    rng = np.random.default_rng(5)
+    for curve in (BN254, BLS12_381):
+        nq = 4 if curve == BN254 else 6
+        more = [("scalar", s) for s in orc.random_field(curve, FR, 40, rng)] + [("point", np.zeros(2 * nq, dtype=np.uint64))]
+        more += [("point", orc.generator_mul(curve, G1, s)) for s in orc.random_field(curve, FR, 3, rng)]
+        np.testing.assert_array_equal(cg.host_plonk_transcript(curve, more), orc.plonk_transcript(curve, more))
+
+
 def test_oracle_round2_matches_reference_kat():
     """[z]_1 of the grand-product polynomial with the deterministic blinding (co-plonk/src/round2.rs:326-355)"""
     kat = ALL_KATS["plonk_round2"]["test_round2_multiplier2"]
@@ -128,3 +151,29 @@ def test_gpu_round1_plain_and_rep3_match_oracle(curve_name):
         got = cg.plonk_round1_rep3(curve, zp, w[:npub + 1], wa, wb, [det, zero, zero], [zero, det, zero])
         for party in range(3):
             np.testing.assert_array_equal(got[party], kat_points(BN254, KATS["test_round1_multiplier2"]))
+
+
+@pytest.mark.gpu
+def test_gpu_round2_plain_matches_reference_kat():
+    """[z]_1 from the HIP path (grand product as device vector kernels, iNTT, MSM) equals the reference's hard-coded point (round2.rs:326-355)"""
+    ensure_built()
+    kat = ALL_KATS["plonk_round2"]["test_round2_multiplier2"]
+    w = orc.read_wtns(BN254, fx("bn254", "witness.wtns"))
+    beta, gamma, cz = cg.plonk_round2_plain(BN254, fx("bn254", "circuit.zkey"), w, deterministic_blinding(BN254, 9))
+    np.testing.assert_array_equal(cz, np.concatenate([orc.from_dec(BN254, FQ, kat["commit_z"][0]), orc.from_dec(BN254, FQ, kat["commit_z"][1])]))
+    ob, og, _ = orc.plonk_round2_plain(BN254, fx("bn254", "circuit.zkey"), w, deterministic_blinding(BN254, 9))
+    np.testing.assert_array_equal(beta, ob); np.testing.assert_array_equal(gamma, og)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_gpu_round2_plain_matches_oracle(curve_name):
+    ensure_built()
+    curve = CURVES[curve_name]
+    zp = fx(curve_name, "circuit.zkey")
+    w = orc.read_wtns(curve, fx(curve_name, "witness.wtns"))
+    blind = orc.random_field(curve, FR, 9, np.random.default_rng(123))
+    want = orc.plonk_round2_plain(curve, zp, w, blind, want_poly=True)
+    got = cg.plonk_round2_plain(curve, zp, w, blind, want_poly=True)
+    for a, b, name in zip(got, want, ("beta", "gamma", "commit_z", "poly_z")):
+        np.testing.assert_array_equal(a, b, err_msg=name)
