@@ -321,6 +321,31 @@ int orc_plonk_round2_plain(int curve, const char* path, const uint64_t* full_wit
     return 0;
 }
 
+// the plain-driver prover up to round `upto` (1..3); blind = 11 Fr.  commits: 7 packed G1 (a, b, c, z, t1, t2, t3; zeros when not reached),
+// challenges: beta, gamma, alpha.  t_polys (optional): t1 (n+1) | t2 (n+1) | t3 (n+6)
+int orc_plonk_prove_plain(int curve, const char* path, const uint64_t* full_witness, const uint64_t* blind, int upto, uint64_t* commits, uint64_t* challenges, uint64_t* t_polys) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr; typedef typename C::Fq Fq;
+        auto z = read_plonk_zkey<C>(path);
+        const Fr* w = reinterpret_cast<const Fr*>(full_witness);
+        std::vector<Fr> fw(w, w + (z.n_vars - z.n_additions));
+        Fr b[11]; for (int i = 0; i < 11; i++) b[i] = ld<Fr>(blind + i * Fr::N);
+        PlonkPlainProver<C> pr(z, fw, b);
+        memset(commits, 0, 7 * 2 * Fq::N * 8); memset(challenges, 0, 3 * Fr::N * 8);
+        pr.round1();
+        for (int k = 0; k < 3; k++) st_g1<Fq>(commits + k * 2 * Fq::N, pr.commit[k]);
+        if (upto >= 2) { pr.round2(); st_g1<Fq>(commits + 3 * 2 * Fq::N, pr.commit_z); st<Fr>(challenges, pr.beta); st<Fr>(challenges + Fr::N, pr.gamma); }
+        if (upto >= 3) {
+            pr.round3();
+            for (int k = 0; k < 3; k++) st_g1<Fq>(commits + (4 + k) * 2 * Fq::N, pr.commit_t[k]);
+            st<Fr>(challenges + 2 * Fr::N, pr.alpha);
+            if (t_polys) { memcpy(t_polys, pr.t1.data(), pr.t1.size() * sizeof(Fr)); memcpy(t_polys + pr.t1.size() * Fr::N, pr.t2.data(), pr.t2.size() * sizeof(Fr));
+                           memcpy(t_polys + (pr.t1.size() + pr.t2.size()) * Fr::N, pr.t3.data(), pr.t3.size() * sizeof(Fr)); }
+        }
+    });
+    return 0;
+}
+
 // ---- prover ------------------------------------------------------------------------------------------
 int orc_witness_map_plain(void* h, const uint64_t* full_witness, uint64_t* out_h) {
     ZK(h, {

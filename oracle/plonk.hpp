@@ -77,6 +77,9 @@ struct PlonkZKey {
     Fr k1, k2;                                // verifying key (zkey.rs:328-356)
     AffineT<Fq> vk_g1[8];                     // qm, ql, qr, qo, qc, s1, s2, s3
     std::vector<Fr> sigma_eval[3];            // 4 * domain_size evaluations of sigma1..3 on the extended domain (section 12)
+    std::vector<Fr> q_eval[5];                // qm, ql, qr, qo, qc on the extended domain (sections 7..11)
+    std::vector<Fr> q_coef[5], sigma_coef[3]; // coefficient forms (round 5)
+    std::vector<std::vector<Fr>> lagrange_eval;   // n_public polynomials, 4 * domain_size evaluations each (section 13)
 };
 
 template <class C>
@@ -104,10 +107,23 @@ static PlonkZKey<C> read_plonk_zkey(const std::string& path) {
     {   // section 12 = sigma1 | sigma2 | sigma3, each domain_size coefficients followed by 4 * domain_size evaluations (zkey.rs:170-180,116-135)
         Cursor c(sec(12));
         for (int k = 0; k < 3; k++) {
-            for (size_t i = 0; i < z.domain_size; i++) read_mont<Fr>(c);
+            z.sigma_coef[k].resize(z.domain_size);
+            for (auto& v : z.sigma_coef[k]) v = read_mont<Fr>(c);
             z.sigma_eval[k].resize(4 * z.domain_size);
             for (auto& v : z.sigma_eval[k]) v = read_mont<Fr>(c);
         }
+    }
+    for (int k = 0; k < 5; k++) {   // zkey.rs:116-135: coefficients then extended evaluations
+        Cursor c(sec(7 + k));
+        z.q_coef[k].resize(z.domain_size);
+        for (auto& v : z.q_coef[k]) v = read_mont<Fr>(c);
+        z.q_eval[k].resize(4 * z.domain_size);
+        for (auto& v : z.q_eval[k]) v = read_mont<Fr>(c);
+    }
+    {
+        Cursor c(sec(13));
+        z.lagrange_eval.resize(z.n_public);
+        for (auto& l : z.lagrange_eval) { for (size_t i = 0; i < z.domain_size; i++) read_mont<Fr>(c); l.resize(4 * z.domain_size); for (auto& v : l) v = read_mont<Fr>(c); }
     }
     { Cursor c(sec(3)); z.additions.resize(z.n_additions); for (auto& a : z.additions) { a.id1 = c.u32(); a.id2 = c.u32(); a.f1 = read_mont<Fr>(c); a.f2 = read_mont<Fr>(c); } }
     auto id_map = [&](uint32_t id) { Cursor c(sec(id)); std::vector<uint32_t> m(z.n_constraints); for (auto& v : m) v = c.u32(); return m; };
@@ -190,5 +206,134 @@ static PlonkRound2<C> plonk_round2_plain(const PlonkZKey<C>& z, const std::vecto
     out.poly_z = zb;
     return out;
 }
+
+// ---- the plain-driver prover, round by round, with the state the reference threads through Round1..Round5 ------------------------------
+template <class C>
+struct PlonkPlainProver {
+    typedef typename C::Fr Fr; typedef typename C::Fq Fq; typedef typename C::G1 G1;
+    const PlonkZKey<C>& z;
+    size_t n;
+    std::vector<Fr> w;                         // witness with the additions appended, w[0] = 0
+    Fr b[11];                                  // Round1Challenges::b
+    Fr omega, omega4;                          // roots[pow], roots[pow + 2] (types.rs:70-97)
+    std::vector<Fr> buf[3], poly[3], eval[3];  // wire values, blinded coefficients (n + 2), evaluations of the UNBLINDED polynomial on 4n points
+    std::vector<Fr> poly_z, eval_z;
+    AffineT<Fq> commit[3], commit_z, commit_t[3];
+    Fr beta, gamma, alpha;
+    std::vector<Fr> t1, t2, t3;
+
+    PlonkPlainProver(const PlonkZKey<C>& zk, const std::vector<Fr>& full_witness, const Fr* blind) : z(zk), n(zk.domain_size), w(full_witness) {
+        if (full_witness.size() + z.n_additions != z.n_vars) throw std::runtime_error("witness length does not match the zkey");
+        for (int i = 0; i < 11; i++) b[i] = blind[i];
+        w[0] = Fr::zero();
+        for (const auto& a : z.additions) w.push_back(w.at(a.id1) * a.f1 + w.at(a.id2) * a.f2);
+        auto rt = roots_of_unity<Fr>();
+        omega = rt.roots[z.power]; omega4 = rt.roots[z.power + 2];
+    }
+    AffineT<Fq> commit_poly(const std::vector<Fr>& p) const {
+        if (p.size() > z.p_tau.size()) throw std::runtime_error("polynomial degree too large");
+        return msm_naive<G1>(z.p_tau.data(), p.data(), p.size()).to_affine();
+    }
+    std::vector<Fr> extended_eval(const std::vector<Fr>& coeffs) const { std::vector<Fr> e(coeffs); e.resize(4 * n, Fr::zero()); ntt_forward(e.data(), 4 * n, omega4); return e; }
+
+    void round1() {                                                                                   // round1.rs:118-312
+        const std::vector<uint32_t>* maps[3] = {&z.map_a, &z.map_b, &z.map_c};
+        for (int k = 0; k < 3; k++) {
+            buf[k].assign(n, Fr::zero());
+            for (size_t i = 0; i < z.n_constraints; i++) buf[k][i] = w.at((*maps[k])[i]);
+            std::vector<Fr> p(buf[k]);
+            ntt_inverse(p.data(), n, omega);
+            eval[k] = extended_eval(p);                                                               // :174-177 (before blinding)
+            p[0] = p[0] - b[2 * k + 1]; p[1] = p[1] - b[2 * k]; p.push_back(b[2 * k + 1]); p.push_back(b[2 * k]);
+            poly[k] = p;
+            commit[k] = commit_poly(p);
+        }
+    }
+    void round2() {                                                                                   // round2.rs:146-298
+        {
+            PlonkTranscript<C> t;
+            for (int i = 0; i < 8; i++) t.add_point(z.vk_g1[i]);
+            for (size_t i = 1; i <= z.n_public; i++) t.add_scalar(w[i]);
+            for (int k = 0; k < 3; k++) t.add_point(commit[k]);
+            beta = t.get_challenge();
+            PlonkTranscript<C> t2; t2.add_scalar(beta); gamma = t2.get_challenge();
+        }
+        std::vector<Fr> num(n), den(n);
+        Fr wv = Fr::one();
+        for (size_t i = 0; i < n; i++) {
+            const Fr bw = beta * wv;
+            num[i] = (buf[0][i] + bw + gamma) * (buf[1][i] + z.k1 * bw + gamma) * (buf[2][i] + z.k2 * bw + gamma);
+            den[i] = (buf[0][i] + beta * z.sigma_eval[0][4 * i] + gamma) * (buf[1][i] + beta * z.sigma_eval[1][4 * i] + gamma) * (buf[2][i] + beta * z.sigma_eval[2][4 * i] + gamma);
+            wv = wv * omega;
+        }
+        for (size_t i = 1; i < n; i++) { num[i] = num[i] * num[i - 1]; den[i] = den[i] * den[i - 1]; }
+        std::vector<Fr> p(n);
+        for (size_t i = 0; i < n; i++) p[(i + 1) % n] = num[i] * den[i].inverse();
+        ntt_inverse(p.data(), n, omega);
+        eval_z = extended_eval(p);                                                                    // :238
+        p[0] = p[0] - b[8]; p[1] = p[1] - b[7]; p[2] = p[2] - b[6]; p.push_back(b[8]); p.push_back(b[7]); p.push_back(b[6]);
+        poly_z = p;
+        commit_z = commit_poly(p);
+    }
+    // round3.rs:234-488, one component.  The quotient is split into its low part (from evaluations of the unblinded polynomials) and the
+    // part produced by the blinding factors (the `...z` vectors), exactly as the reference does, so that the coefficient vectors coincide.
+    void round3() {
+        {
+            PlonkTranscript<C> t; t.add_scalar(beta); t.add_scalar(gamma); t.add_point(commit_z);
+            alpha = t.get_challenge();
+        }
+        const Fr alpha2 = alpha * alpha;
+        const size_t N = 4 * n;
+        const Fr one = Fr::one(), zero = Fr::zero(), two = one + one;
+        const Fr w2r = roots_of_unity<Fr>().roots[2];                                                  // root_of_unity_2
+        const Fr Z1[4] = {zero, zero - one + w2r, zero - two, zero - one - w2r};                      // get_z1..3 (:203-232)
+        const Fr Z2[4] = {zero, (zero - two) * w2r, two * two, zero - (zero - two) * w2r};
+        const Fr Z3[4] = {zero, two + two * w2r, zero - two * two * two, two - two * w2r};
+        std::vector<Fr> tv(N), tzv(N);
+        Fr wv = one;
+        for (size_t i = 0; i < N; i++) {
+            const Fr a = eval[0][i], bb = eval[1][i], c = eval[2][i], zz = eval_z[i], zw = eval_z[(i + 4) % N];
+            const Fr ap = b[1] + b[0] * wv, bp = b[3] + b[2] * wv, cp = b[5] + b[4] * wv;
+            const Fr w2 = wv * wv, zp = b[6] * w2 + b[7] * wv + b[8];
+            const Fr ww = wv * omega, zwp = b[6] * ww * ww + b[7] * ww + b[8];
+            const int mi = (int)(i % 4);
+            const Fr a_b = a * bb, a_bp = a * bp, ap_b = bb * ap, ap_bp = ap * bp;
+            Fr a0 = a_bp + ap_b + Z1[mi] * ap_bp;
+            Fr e1 = z.q_eval[0][i] * a_b + a * z.q_eval[1][i] + bb * z.q_eval[2][i] + c * z.q_eval[3][i];
+            Fr e1z = z.q_eval[0][i] * a0 + ap * z.q_eval[1][i] + bp * z.q_eval[2][i] + cp * z.q_eval[3][i];
+            Fr pi = zero;
+            for (size_t j = 0; j < z.lagrange_eval.size(); j++) pi = pi - z.lagrange_eval[j][i] * buf[0][j];
+            e1 = e1 + pi + z.q_eval[4][i];
+            const Fr bw = beta * wv;
+            auto mul4 = [&](const Fr& A, const Fr& B, const Fr& Cc, const Fr& D, const Fr& Dp, Fr& r, Fr& rz) {   // mul4vec + mul4vec_post (:17-72)
+                const Fr AB = A * B, ABp = A * bp, ApB = ap * B, ApBp = ap * bp, CD = Cc * D, CDp = Cc * Dp, CpD = cp * D, CpDp = cp * Dp;
+                r = AB * CD;
+                const Fr r0 = ApB * CD + ABp * CD + AB * CpD + AB * CDp;
+                const Fr r1 = ApBp * CD + ApB * CpD + ApB * CDp + ABp * CpD + ABp * CDp + AB * CpDp;
+                const Fr r2 = ABp * CpDp + ApB * CpDp + ApBp * CDp + ApBp * CpD;
+                const Fr r3 = ApBp * CpDp;
+                rz = r0 + Z1[mi] * r1 + Z2[mi] * r2 + Z3[mi] * r3;
+            };
+            Fr e2, e2z, e3, e3z;
+            mul4(a + bw + gamma, bb + bw * z.k1 + gamma, c + bw * z.k2 + gamma, zz, zp, e2, e2z);
+            mul4(a + z.sigma_eval[0][i] * beta + gamma, bb + z.sigma_eval[1][i] * beta + gamma, c + z.sigma_eval[2][i] * beta + gamma, zw, zwp, e3, e3z);
+            const Fr l1 = z.lagrange_eval.at(0)[i];
+            const Fr e4 = (zz - one) * l1 * alpha2, e4z = zp * l1 * alpha2;
+            tv[i] = e1 + e2 * alpha - e3 * alpha + e4;
+            tzv[i] = e1z + e2z * alpha - e3z * alpha + e4z;
+            wv = wv * omega4;
+        }
+        ntt_inverse(tv.data(), N, omega4);
+        for (size_t i = 0; i < n; i++) tv[i] = zero - tv[i];                                           // neg_vec_in_place_limit (:443)
+        for (size_t i = n; i < N; i++) tv[i] = tv[i - n] - tv[i];                                      // division by X^n - 1 (:445-450)
+        ntt_inverse(tzv.data(), N, omega4);
+        for (size_t i = 0; i < N; i++) tv[i] = tv[i] + tzv[i];
+        t1.assign(tv.begin(), tv.begin() + n); t2.assign(tv.begin() + n, tv.begin() + 2 * n); t3.assign(tv.begin() + 2 * n, tv.begin() + 3 * n + 6);
+        t1.push_back(b[9]);
+        t2[0] = t2[0] - b[9]; t2.push_back(b[10]);
+        t3[0] = t3[0] - b[10];
+        commit_t[0] = commit_poly(t1); commit_t[1] = commit_poly(t2); commit_t[2] = commit_poly(t3);
+    }
+};
 
 }  // namespace orc

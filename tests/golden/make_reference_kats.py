@@ -9,6 +9,7 @@ Sources (values only, no code is copied):
   /root/reference/co-circom/circom-types/src/witness.rs:101-134        witness KAT
   /root/reference/co-circom/co-plonk/src/round1.rs:346-428             Plonk round-1 commitments [a]_1, [b]_1, [c]_1 (blinding b_i = i)
   /root/reference/co-circom/co-plonk/src/round2.rs:326-355             Plonk round-2 commitment [z]_1
+  /root/reference/co-circom/co-plonk/src/round3.rs:553-596             Plonk round-3 commitments [t1]_1, [t2]_1, [t3]_1
   /root/reference/co-circom/co-plonk/src/types.rs:194-227              Keccak256 transcript challenge
 """
 import json, re, sys, os
@@ -85,6 +86,13 @@ out["plonk_round1"] = pk
 src = open(f"{REF}/co-circom/co-plonk/src/round2.rs").read()
 m = re.search(r"commit_z,\s*g1_from_xy!\(\s*\"(\d+)\",\s*\"(\d+)\"", src, re.S)
 out["plonk_round2"] = {"test_round2_multiplier2": {"file": "Plonk/bn254/multiplier2/circuit.zkey", "commit_z": [m.group(1), m.group(2)]}}
+
+src = open(f"{REF}/co-circom/co-plonk/src/round3.rs").read()
+r3 = {}
+for which in ("commit_t1", "commit_t2", "commit_t3"):
+    m = re.search(r"proof\.%s,\s*g1_from_xy!\(\s*\"(\d+)\",\s*\"(\d+)\"" % which, src, re.S)
+    r3[which] = [m.group(1), m.group(2)]
+out["plonk_round3"] = {"test_round3_multiplier2": dict(file="Plonk/bn254/multiplier2/circuit.zkey", **r3)}
 
 # transcript KAT: the sequence of add_point / add_scalar calls and the expected challenge (types.rs:194-227)
 src = open(f"{REF}/co-circom/co-plonk/src/types.rs").read()

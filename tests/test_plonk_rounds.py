@@ -104,6 +104,21 @@ def test_oracle_round2_matches_reference_kat():
     assert beta.any() and gamma.any() and not np.array_equal(beta, gamma)
 
 
+def _pt(curve, xy):
+    return np.concatenate([orc.from_dec(curve, FQ, xy[0]), orc.from_dec(curve, FQ, xy[1])])
+
+
+def test_oracle_rounds_1_to_3_match_reference_kats():
+    """the round-by-round prover state machine: every commitment the reference hard-codes for rounds 1, 2 and 3 (round1.rs:346-383,
+    round2.rs:326-355, round3.rs:553-596), all from ONE run with the deterministic blinding b_i = i"""
+    w = orc.read_wtns(BN254, fx("bn254", "witness.wtns"))
+    r = orc.plonk_prove_plain(BN254, fx("bn254", "circuit.zkey"), w, deterministic_blinding(BN254, 11), upto=3)
+    k1, k2, k3 = KATS["test_round1_multiplier2"], ALL_KATS["plonk_round2"]["test_round2_multiplier2"], ALL_KATS["plonk_round3"]["test_round3_multiplier2"]
+    for name, kat in (("a", k1["commit_a"]), ("b", k1["commit_b"]), ("c", k1["commit_c"]), ("z", k2["commit_z"]),
+                      ("t1", k3["commit_t1"]), ("t2", k3["commit_t2"]), ("t3", k3["commit_t3"])):
+        np.testing.assert_array_equal(r[name], _pt(BN254, kat), err_msg=name)
+
+
 def test_host_plonk_zkey_reader_matches_oracle():
     ensure_built()
     for name, curve in CURVES.items():
