@@ -482,6 +482,19 @@ def plonk_round2_plain(curve, zkey_path, full_witness, blind, device=0, want_pol
     return (bg[0], bg[1], cz, poly) if want_poly else (bg[0], bg[1], cz)
 
 
+def plonk_prove_plain(curve, zkey_path, full_witness, blind, upto=3, device=0, want_t=False):
+    """co-plonk with the plain driver on the GPU through round `upto` (<= 3): dict(a, b, c, z, t1, t2, t3, beta, gamma, alpha[, t polys])"""
+    info = host_plonk_zkey_info(curve, zkey_path)
+    nq = 6 if curve == BLS12_381 else 4; n = info["domain_size"]
+    commits = np.zeros((7, 2 * nq), dtype=np.uint64); ch = np.zeros((3, 4), dtype=np.uint64)
+    tp = np.zeros((3 * n + 8, 4), dtype=np.uint64) if want_t else None
+    _hchk(load_host().cgh_plonk_prove_plain(int(device), curve, zkey_path.encode(), _hp(np.ascontiguousarray(full_witness, dtype=np.uint64)),
+                                            _hp(np.ascontiguousarray(blind, dtype=np.uint64)), int(upto), _hp(commits), _hp(ch), _hp(tp) if want_t else None))
+    out = dict(zip(("a", "b", "c", "z", "t1", "t2", "t3"), commits)); out.update(beta=ch[0], gamma=ch[1], alpha=ch[2])
+    if want_t: out.update(t1_poly=tp[:n + 1], t2_poly=tp[n + 1:2 * n + 2], t3_poly=tp[2 * n + 2:])
+    return out
+
+
 def host_plonk_transcript(curve, items):
     """items: list of ("scalar", limbs) / ("point", packed G1 limbs) -> challenge computed by the host mirror's Keccak256 transcript"""
     n = len(items)

@@ -712,6 +712,8 @@ struct PlonkZKey {   // circom-types/src/plonk/zkey.rs:18-42 (the fields round 1
     Fr k1, k2;          // verifying key, zkey.rs:328-356
     Bytes vk_g1;        // qm, ql, qr, qo, qc, s1, s2, s3 (8 packed G1 points)
     std::vector<Fr> sigma_eval[3];   // 4 * domain_size evaluations of sigma1..3 (section 12, zkey.rs:116-135,170-180)
+    std::vector<Fr> q_eval[5];       // qm, ql, qr, qo, qc on the extended domain (sections 7..11)
+    std::vector<std::vector<Fr>> lagrange_eval;   // n_public polynomials on the extended domain (section 13)
 };
 static PlonkZKey read_plonk_zkey(int curve_id, const std::string& path) {   // zkey.rs:83-255, header :373-424
     Curve c{curve_id};
@@ -746,6 +748,8 @@ static PlonkZKey read_plonk_zkey(int curve_id, const std::string& path) {   // z
             sg.bytes(z.sigma_eval[k].data(), 4 * z.domain_size * 32);
         }
     }
+    for (int k = 0; k < 5; k++) { Cursor q = section(7 + k); q.need(z.domain_size * 32); q.off += z.domain_size * 32; z.q_eval[k].resize(4 * z.domain_size); q.bytes(z.q_eval[k].data(), 4 * z.domain_size * 32); }
+    { Cursor l = section(13); z.lagrange_eval.resize(z.n_public); for (auto& v : z.lagrange_eval) { l.need(z.domain_size * 32); l.off += z.domain_size * 32; v.resize(4 * z.domain_size); l.bytes(v.data(), 4 * z.domain_size * 32); } }
     { Cursor a = section(3); z.additions.resize(z.n_additions); for (auto& e : z.additions) { e.id1 = a.u32(); e.id2 = a.u32(); a.bytes(e.f1.v, 32); a.bytes(e.f2.v, 32); } }
     for (int k = 0; k < 3; k++) { Cursor m = section(4 + k); z.map[k].resize(z.n_constraints); for (auto& v : z.map[k]) v = m.u32(); }
     { Cursor t = section(14); z.p_tau.resize((z.domain_size + 6) * c.aff(CG_G1)); t.bytes(z.p_tau.data(), z.p_tau.size()); }
@@ -839,7 +843,7 @@ public:
     // round1.rs:118-206 + :260-312.  public_inputs = n_public + 1 values (entry 0 is overwritten by 0, types.rs:107-109);
     // blind = b_1..b_6 as shares; polys_out (optional) receives the three blinded coefficient vectors (n + 2 each, device)
     std::vector<Point> round1(const PlonkZKey& z, const cg_bases* p_tau, std::vector<Fr> public_inputs, const ShareVec& private_witness, const FieldShare* blind,
-                              ShareVec* polys_out = nullptr, ShareVec* buffers_out = nullptr) {
+                              ShareVec* polys_out = nullptr, ShareVec* buffers_out = nullptr, ShareVec* evals_out = nullptr) {
         const Curve& c = driver.curve;
         cg_ctx* ctx = driver.ctx;
         const size_t n = z.domain_size, nc = z.n_constraints;
@@ -866,6 +870,12 @@ public:
                 for (int j = 0; j < driver.k(); j++) CG(cg_vec_gather_strided_dev(ctx, c.id, buffers_out[w].c[j], poly.c[j], n, 0, 1));
             }
             CG(cg_ntt_dev(ctx, c.id, poly.c, driver.k(), n, omega.v, 1, nullptr));                // ifft over the first n entries
+            if (evals_out) {                                                                      // extended evaluations of the unblinded polynomial (round1.rs:174-177)
+                evals_out[w] = driver.alloc_vec(4 * n);
+                const Fr omega4 = snarkjs_roots(c).roots[z.power + 2];
+                for (int j = 0; j < driver.k(); j++) CG(cg_vec_gather_strided_dev(ctx, c.id, evals_out[w].c[j], poly.c[j], n, 0, 1));
+                CG(cg_ntt_dev(ctx, c.id, evals_out[w].c, driver.k(), 4 * n, omega4.v, 0, nullptr));
+            }
             const FieldShare &b_hi = blind[2 * w], &b_lo = blind[2 * w + 1];                      // blind_coefficients, lib.rs:140-158
             for (int j = 0; j < driver.k(); j++) {
                 Fr head[2]; CG(cg_dev_download(ctx, head, poly.c[j], 64));
@@ -894,8 +904,8 @@ public:
     struct Result { Fr beta, gamma; Point commit_z; };
 
     Result round2(const PlonkZKey& z, const cg_bases* p_tau, const std::vector<Fr>& public_inputs /* n_public values */, const std::vector<Point>& round1_commits,
-                  const ShareVec* buffers, const FieldShare* blind /* b[6..9) used */, ShareVec* poly_z_out = nullptr) {
-        if (driver.mode == Mode::Rep3) throw std::runtime_error("co-plonk round 2 is implemented for the single-component drivers (array_prod_mul / inv_many over REP3 shares: next)");
+                  const ShareVec* buffers, const FieldShare* blind /* b[6..9) used */, ShareVec* poly_z_out = nullptr, ShareVec* eval_z_out = nullptr) {
+        if (driver.mode != Mode::Plain) throw std::runtime_error("co-plonk round 2 is implemented for the plain driver (array_prod_mul / inv_many / mul_many over shares: next)");
         const Curve& c = driver.curve; cg_ctx* ctx = driver.ctx;
         const size_t n = z.domain_size;
         Result res;
@@ -934,6 +944,11 @@ public:
         if (n > 1) CG(cg_vec_gather_strided_dev(ctx, c.id, (uint8_t*)poly.c[0] + 32, num, n - 1, 0, 1));   // rotate_right(1) (:231)
         CG(cg_vec_gather_strided_dev(ctx, c.id, poly.c[0], num, 1, n - 1, 1));
         CG(cg_ntt_dev(ctx, c.id, poly.c, 1, n, omega.v, 1, nullptr));                             // :235
+        if (eval_z_out) {                                                                         // :238
+            *eval_z_out = driver.alloc_vec(4 * n);
+            CG(cg_vec_gather_strided_dev(ctx, c.id, eval_z_out->c[0], poly.c[0], n, 0, 1));
+            CG(cg_ntt_dev(ctx, c.id, eval_z_out->c, 1, 4 * n, snarkjs_roots(c).roots[z.power + 2].v, 0, nullptr));
+        }
         Fr head[3]; CG(cg_dev_download(ctx, head, poly.c[0], 96));                                // blind_coefficients with b[6..9) (lib.rs:140-158)
         const Fr b6 = blind[6].c[0], b7 = blind[7].c[0], b8 = blind[8].c[0];
         head[0] = fr_sub(c, head[0], b8); head[1] = fr_sub(c, head[1], b7); head[2] = fr_sub(c, head[2], b6);
@@ -944,6 +959,136 @@ public:
         res.commit_z = driver.open_point(driver.msm_public_points(p_tau, CG_G1, 0, n + 3, poly));   // :268-275
         for (void* p : {betaw, num, den, t1, sig, d_sigma}) CG(cg_dev_free(ctx, p));
         if (poly_z_out) *poly_z_out = poly; else driver.free_vec(poly);
+        return res;
+    }
+};
+
+// Round 3 (co-plonk/src/round3.rs:234-527) for the plain driver: the quotient polynomial on the 4n-point domain as device vector
+// kernels (its blinding-dependent part kept apart exactly as the reference does), two size-4n iNTTs, the division by X^n - 1 as three
+// block subtractions, the split into t1 | t2 | t3 and their commitments.
+class CoPlonkRound3 {
+public:
+    HipDriver& driver;
+    explicit CoPlonkRound3(HipDriver& d) : driver(d) {}
+    struct Result { Fr alpha; Point commit_t[3]; };
+
+    Result round3(const PlonkZKey& z, const cg_bases* p_tau, const Fr& beta, const Fr& gamma, const Point& commit_z, const ShareVec* buffers,
+                  const ShareVec* evals, const ShareVec& eval_z, const FieldShare* blind, ShareVec* t_out = nullptr) {
+        if (driver.mode != Mode::Plain) throw std::runtime_error("co-plonk round 3 is implemented for the plain driver");
+        if (z.lagrange_eval.empty()) throw std::runtime_error("round 3 needs at least one public input (lagrange[0])");
+        const Curve& c = driver.curve; cg_ctx* ctx = driver.ctx;
+        const size_t n = z.domain_size, N = 4 * n;
+        Result res;
+        { PlonkTranscript t(c); t.add_scalar(beta); t.add_scalar(gamma); Bytes a = pt_to_affine(c, commit_z); t.add_point(a.data()); res.alpha = t.get_challenge(); }   // :498-503
+        const Fr alpha = res.alpha, alpha2 = fr_mul(c, alpha, alpha);
+        const SnarkjsRoots rt = snarkjs_roots(c);
+        const Fr omega = rt.roots[z.power], omega4 = rt.roots[z.power + 2], w2r = rt.roots[2];
+        const Fr zero = fr_from_u64(c, 0), one = fr_from_u64(c, 1), two = fr_from_u64(c, 2);
+        auto neg = [&](const Fr& v) { return fr_sub(c, zero, v); };
+        const Fr Z1[4] = {zero, fr_add(c, neg(one), w2r), neg(two), fr_sub(c, neg(one), w2r)};                            // get_z1..3 (:203-232)
+        const Fr m2w = fr_mul(c, neg(two), w2r);
+        const Fr Z2[4] = {zero, m2w, fr_mul(c, two, two), neg(m2w)};
+        const Fr tw = fr_mul(c, two, w2r);
+        const Fr Z3[4] = {zero, fr_add(c, two, tw), neg(fr_mul(c, fr_mul(c, two, two), two)), fr_sub(c, two, tw)};
+        std::vector<void*> live;
+        auto V = [&]() { void* p = driver.dalloc(N * 32); live.push_back(p); return p; };
+        auto mul = [&](void* o, const void* a, const void* b) { CG(cg_vec_mul_dev(ctx, c.id, o, a, b, N)); };
+        auto add = [&](void* o, const void* a, const void* b) { CG(cg_vec_add_dev(ctx, c.id, o, a, b, N)); };
+        auto sub = [&](void* o, const void* a, const void* b) { CG(cg_vec_sub_dev(ctx, c.id, o, a, b, N)); };
+        auto aff = [&](void* o, const void* a, const Fr& k, const Fr& d) { CG(cg_vec_affine_dev(ctx, c.id, o, a, N, k.v, d.v)); };
+        auto upload = [&](const std::vector<Fr>& h) { void* p = V(); CG(cg_dev_upload(ctx, p, h.data(), N * 32)); return p; };
+        auto pattern = [&](const Fr* zz) { std::vector<Fr> h(N); for (size_t i = 0; i < N; i++) h[i] = zz[i & 3]; return upload(h); };
+        const void *a = evals[0].c[0], *b = evals[1].c[0], *cc = evals[2].c[0], *ez = eval_z.c[0];
+        void* z1p = pattern(Z1); void* z2p = pattern(Z2); void* z3p = pattern(Z3);
+        const FieldShare* B = blind;
+        // powers of the 4n-th root and the blinding polynomials evaluated on them (:246-256, :307-322)
+        void* pw = V(); CG(cg_vec_fill_dev(ctx, c.id, pw, N, one.v)); CG(cg_vec_distribute_powers_dev(ctx, c.id, pw, N, omega4.v, one.v));
+        void* ap = V(); aff(ap, pw, B[0].c[0], B[1].c[0]);
+        void* bp = V(); aff(bp, pw, B[2].c[0], B[3].c[0]);
+        void* cp = V(); aff(cp, pw, B[4].c[0], B[5].c[0]);
+        void* t0 = V(); void* t1v = V();
+        void* zp = V(); mul(t0, pw, pw); aff(zp, t0, B[6].c[0], B[8].c[0]); aff(t0, pw, B[7].c[0], zero); add(zp, zp, t0);
+        void* zwp = V(); aff(t1v, pw, omega, zero); mul(t0, t1v, t1v); aff(zwp, t0, B[6].c[0], B[8].c[0]); aff(t0, t1v, B[7].c[0], zero); add(zwp, zwp, t0);
+        void* zw = V();                                                                                                  // z(X omega) = eval_z rotated by 4 (:324-327)
+        CG(cg_vec_gather_strided_dev(ctx, c.id, zw, (const uint8_t*)ez + 4 * 32, N - 4, 0, 1));
+        CG(cg_vec_gather_strided_dev(ctx, c.id, (uint8_t*)zw + (N - 4) * 32, ez, 4, 0, 1));
+        // gate constraint e1 and its blinding part e1z (:333-368)
+        void* a_b = V(); mul(a_b, a, b);
+        void* a_bp = V(); mul(a_bp, a, bp);
+        void* ap_b = V(); mul(ap_b, b, ap);
+        void* ap_bp = V(); mul(ap_bp, ap, bp);
+        void* a0 = V(); add(a0, a_bp, ap_b); mul(t0, z1p, ap_bp); add(a0, a0, t0);
+        void* q[5]; for (int k = 0; k < 5; k++) q[k] = upload(z.q_eval[k]);
+        void* e1 = V(); mul(e1, q[0], a_b); mul(t0, q[1], a); add(e1, e1, t0); mul(t0, q[2], b); add(e1, e1, t0); mul(t0, q[3], cc); add(e1, e1, t0); add(e1, e1, q[4]);
+        void* e1z = V(); mul(e1z, q[0], a0); mul(t0, q[1], ap); add(e1z, e1z, t0); mul(t0, q[2], bp); add(e1z, e1z, t0); mul(t0, q[3], cp); add(e1z, e1z, t0);
+        std::vector<Fr> a_pub(z.lagrange_eval.size());                                                                  // public-input polynomial (:352-358)
+        CG(cg_dev_download(ctx, a_pub.data(), buffers[0].c[0], a_pub.size() * 32));
+        void* l1 = nullptr;
+        for (size_t j = 0; j < z.lagrange_eval.size(); j++) {
+            void* lj = upload(z.lagrange_eval[j]); if (j == 0) l1 = lj;
+            aff(t0, lj, neg(a_pub[j]), zero); add(e1, e1, t0);
+        }
+        // permutation constraints (:370-418): products of four linear factors, each with its blinding companion
+        auto mul4 = [&](const void* A, const void* Bv, const void* Cv, const void* D, const void* Dp, void* r, void* rz) {   // mul4vec + mul4vec_post (:17-72)
+            void* AB = V(); mul(AB, A, Bv);
+            void* S1 = V(); mul(S1, A, bp); mul(t0, ap, Bv); add(S1, S1, t0);                  // ABp + ApB
+            void* CD = V(); mul(CD, Cv, D);
+            void* S2 = V(); mul(S2, Cv, Dp); mul(t0, cp, D); add(S2, S2, t0);                  // CDp + CpD
+            void* CpDp = V(); mul(CpDp, cp, Dp);
+            mul(r, AB, CD);
+            mul(rz, S1, CD); mul(t0, AB, S2); add(rz, rz, t0);                                 // r0
+            void* r1 = V(); mul(r1, ap_bp, CD); mul(t0, S1, S2); add(r1, r1, t0); mul(t0, AB, CpDp); add(r1, r1, t0);
+            mul(t0, z1p, r1); add(rz, rz, t0);
+            mul(r1, S1, CpDp); mul(t0, ap_bp, S2); add(r1, r1, t0);                            // r2 (reusing the buffer)
+            mul(t0, z2p, r1); add(rz, rz, t0);
+            mul(r1, ap_bp, CpDp);                                                              // r3
+            mul(t0, z3p, r1); add(rz, rz, t0);
+        };
+        void *e2 = V(), *e2z = V(), *e3 = V(), *e3z = V();
+        {
+            void *fa = V(), *fb = V(), *fc = V();
+            aff(fa, pw, beta, gamma); add(fa, fa, a);
+            aff(fb, pw, fr_mul(c, beta, z.k1), gamma); add(fb, fb, b);
+            aff(fc, pw, fr_mul(c, beta, z.k2), gamma); add(fc, fc, cc);
+            mul4(fa, fb, fc, ez, zp, e2, e2z);
+            void* sg[3]; for (int k = 0; k < 3; k++) sg[k] = upload(z.sigma_eval[k]);
+            aff(fa, sg[0], beta, gamma); add(fa, fa, a);
+            aff(fb, sg[1], beta, gamma); add(fb, fb, b);
+            aff(fc, sg[2], beta, gamma); add(fc, fc, cc);
+            mul4(fa, fb, fc, zw, zwp, e3, e3z);
+        }
+        // t = e1 + alpha (e2 - e3) + alpha^2 (z - 1) L1 ; tz likewise with the blinding parts (:420-441)
+        ShareVec T; T.n = N; T.c[0] = driver.dalloc(N * 32);
+        sub(t0, e2, e3); aff(t0, t0, alpha, zero); add(T.c[0], e1, t0);
+        aff(t0, ez, alpha2, neg(alpha2)); mul(t0, t0, l1); add(T.c[0], T.c[0], t0);
+        ShareVec TZ; TZ.n = N; TZ.c[0] = driver.dalloc(N * 32);
+        sub(t0, e2z, e3z); aff(t0, t0, alpha, zero); add(TZ.c[0], e1z, t0);
+        aff(t0, zp, alpha2, zero); mul(t0, t0, l1); add(TZ.c[0], TZ.c[0], t0);
+        CG(cg_ntt_dev(ctx, c.id, T.c, 1, N, omega4.v, 1, nullptr));                            // :442
+        uint8_t* tb = (uint8_t*)T.c[0];
+        CG(cg_vec_affine_dev(ctx, c.id, tb, tb, n, neg(one).v, nullptr));                     // neg_vec_in_place_limit (:443)
+        for (int blk = 1; blk < 4; blk++) CG(cg_vec_sub_dev(ctx, c.id, tb + blk * n * 32, tb + (blk - 1) * n * 32, tb + blk * n * 32, n));   // :445-450
+        CG(cg_ntt_dev(ctx, c.id, TZ.c, 1, N, omega4.v, 1, nullptr));
+        add(T.c[0], T.c[0], TZ.c[0]);                                                          // :453
+        // split (:455-470)
+        ShareVec parts[3];
+        const size_t len[3] = {n + 1, n + 1, n + 6};
+        for (int k = 0; k < 3; k++) {
+            parts[k] = driver.alloc_vec(len[k]);
+            CG(cg_vec_gather_strided_dev(ctx, c.id, parts[k].c[0], tb + (size_t)k * n * 32, k == 2 ? n + 6 : n, 0, 1));
+        }
+        const Fr b9 = B[9].c[0], b10 = B[10].c[0];
+        CG(cg_dev_upload(ctx, (uint8_t*)parts[0].c[0] + n * 32, b9.v, 32));
+        Fr h; CG(cg_dev_download(ctx, h.v, parts[1].c[0], 32)); h = fr_sub(c, h, b9); CG(cg_dev_upload(ctx, parts[1].c[0], h.v, 32));
+        CG(cg_dev_upload(ctx, (uint8_t*)parts[1].c[0] + n * 32, b10.v, 32));
+        CG(cg_dev_download(ctx, h.v, parts[2].c[0], 32)); h = fr_sub(c, h, b10); CG(cg_dev_upload(ctx, parts[2].c[0], h.v, 32));
+        for (int k = 0; k < 3; k++) {
+            if (len[k] > z.domain_size + 6) throw std::runtime_error("polynomial degree too large");
+            res.commit_t[k] = driver.open_point(driver.msm_public_points(p_tau, CG_G1, 0, len[k], parts[k]));   // :507-522
+            if (t_out) t_out[k] = parts[k]; else driver.free_vec(parts[k]);
+        }
+        for (void* p : live) CG(cg_dev_free(ctx, p));
+        driver.free_vec(T); driver.free_vec(TZ);
         return res;
     }
 };
@@ -1183,6 +1328,49 @@ int32_t cgh_plonk_round2_plain(int32_t device, int32_t curve, const char* zkey_p
         Bytes a = pt_to_affine(c, res.commit_z); memcpy(out_commit_z, a.data(), a.size());
         if (out_poly_z) CG(cg_dev_download(ctx, out_poly_z, poly_z.c[0], poly_z.n * 32));
         driver.free_vec(poly_z); for (auto& bf : buffers) driver.free_vec(bf);
+        driver.free_vec(wit); cg_bases_release(tau); cg_ctx_destroy(ctx);
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
+}
+// the plain driver through rounds 1..upto (<= 3); blind = 11 Fr; commits = 7 packed G1 (a, b, c, z, t1, t2, t3), challenges = beta, gamma, alpha;
+// t_polys (optional) = t1 (n+1) | t2 (n+1) | t3 (n+6)
+int32_t cgh_plonk_prove_plain(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* full_witness, const uint64_t* blind, int32_t upto,
+                              uint64_t* commits, uint64_t* challenges, uint64_t* t_polys) {
+    cg_ctx* ctx = nullptr;
+    try {
+        using namespace cgh;
+        PlonkZKey z = read_plonk_zkey(curve, zkey_path);
+        if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
+        const Curve& c = z.curve;
+        const size_t psz = c.aff(CG_G1), n = z.domain_size;
+        memset(commits, 0, 7 * psz); memset(challenges, 0, 96);
+        cg_bases* tau = nullptr; CG(cg_bases_register(ctx, c.id, CG_G1, z.p_tau.data(), n + 6, psz, -1, &tau));
+        const Fr* w = (const Fr*)full_witness;
+        std::vector<Fr> pub(w, w + z.n_public + 1);
+        HipDriver driver(ctx, c, Mode::Plain, nullptr);
+        ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_additions - z.n_public - 1);
+        FieldShare b[11]; for (int i = 0; i < 11; i++) { memcpy(b[i].c[0].v, blind + 4 * i, 32); b[i].c[1] = b[i].c[0]; }
+        auto put = [&](int slot, const Point& p) { Bytes a = pt_to_affine(c, p); memcpy((uint8_t*)commits + slot * psz, a.data(), psz); };
+        ShareVec buffers[3], evals[3], eval_z, tparts[3];
+        CoPlonkRound1 r1(driver);
+        auto cm = r1.round1(z, tau, pub, wit, b, nullptr, buffers, evals);
+        for (int k = 0; k < 3; k++) put(k, cm[k]);
+        if (upto >= 2) {
+            CoPlonkRound2 r2(driver);
+            auto res2 = r2.round2(z, tau, std::vector<Fr>(pub.begin() + 1, pub.end()), cm, buffers, b, nullptr, &eval_z);
+            put(3, res2.commit_z); memcpy(challenges, res2.beta.v, 32); memcpy(challenges + 4, res2.gamma.v, 32);
+            if (upto >= 3) {
+                CoPlonkRound3 r3(driver);
+                auto res3 = r3.round3(z, tau, res2.beta, res2.gamma, res2.commit_z, buffers, evals, eval_z, b, tparts);
+                for (int k = 0; k < 3; k++) put(4 + k, res3.commit_t[k]);
+                memcpy(challenges + 8, res3.alpha.v, 32);
+                if (t_polys) { size_t off = 0; for (int k = 0; k < 3; k++) { CG(cg_dev_download(ctx, t_polys + off * 4, tparts[k].c[0], tparts[k].n * 32)); off += tparts[k].n; } }
+                for (auto& t : tparts) driver.free_vec(t);
+            }
+            driver.free_vec(eval_z);
+        }
+        for (auto& v : buffers) driver.free_vec(v);
+        for (auto& v : evals) driver.free_vec(v);
         driver.free_vec(wit); cg_bases_release(tau); cg_ctx_destroy(ctx);
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
