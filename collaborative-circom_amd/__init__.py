@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute", "cg_bases_check_on_curve", "cg_bases_check_subgroup",
     "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_scatter_capacity",
     "cg_ntt", "cg_ntt_dev",
-    "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev", "cg_vec_affine_dev", "cg_vec_fill_dev", "cg_vec_gather_strided_dev", "cg_vec_prefix_prod_dev", "cg_vec_inverse_dev",
+    "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev", "cg_vec_affine_dev", "cg_vec_fill_dev", "cg_vec_gather_strided_dev", "cg_vec_prefix_prod_dev", "cg_vec_prefix_sum_dev", "cg_vec_inverse_dev",
     "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
     "cg_point_add", "cg_point_neg", "cg_point_scalar_mul", "cg_point_to_affine", "cg_point_from_affine", "cg_fr_op",
     "cg_fr_from_canonical", "cg_fr_to_canonical", "cg_fq_to_canonical", "cg_fq_from_canonical", "cg_point_generator",
@@ -315,6 +315,7 @@ class Context:
     def vec_fill(self, curve, v, n, value): _chk(load().cg_vec_fill_dev(self.h, curve, _dp(v), C.c_size_t(n), _hp(np.ascontiguousarray(value, dtype=np.uint64))))
     def vec_gather_strided(self, curve, out, src, n, offset, stride): _chk(load().cg_vec_gather_strided_dev(self.h, curve, _dp(out), _dp(src), C.c_size_t(n), C.c_size_t(offset), C.c_size_t(stride)))
     def vec_prefix_prod(self, curve, out, src, n): _chk(load().cg_vec_prefix_prod_dev(self.h, curve, _dp(out), _dp(src), C.c_size_t(n)))
+    def vec_prefix_sum(self, curve, out, src, n): _chk(load().cg_vec_prefix_sum_dev(self.h, curve, _dp(out), _dp(src), C.c_size_t(n)))
     def vec_inverse(self, curve, out, src, n): _chk(load().cg_vec_inverse_dev(self.h, curve, _dp(out), _dp(src), C.c_size_t(n)))
 
     def spmv_csr(self, curve, row_ptr, col, coeff, n_rows, pub, n_inputs, party, wit_a, wit_b, out_a, out_b):

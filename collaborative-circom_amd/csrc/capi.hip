@@ -40,7 +40,7 @@ template <class Fr> int launch_distribute_powers(hipStream_t st, Fr* v, size_t n
 template <class Fr> int launch_vec_fill(hipStream_t st, Fr* v, size_t n, const Fr& value);
 template <class Fr> int launch_vec_affine(hipStream_t st, Fr* out, const Fr* a, size_t n, const Fr& c, const Fr& d);
 template <class Fr> int launch_vec_gather_strided(hipStream_t st, Fr* out, const Fr* in, size_t n, size_t offset, size_t stride);
-template <class Fr> int launch_prefix_prod(hipStream_t st, Fr* out, const Fr* in, size_t n, Fr* scratch);
+template <class Fr> int launch_prefix_scan(hipStream_t st, int op, Fr* out, const Fr* in, size_t n, Fr* scratch);
 template <class Fr> int launch_vec_inverse(hipStream_t st, Fr* out, const Fr* in, size_t n);
 template <class Fr> int launch_spmv_csr(hipStream_t st, const uint32_t* row_ptr, const uint32_t* col, const Fr* coeff, size_t n_rows, const Fr* pub,
                                         uint32_t n_inputs, int party, const Fr* wit_a, const Fr* wit_b, Fr* out_a, Fr* out_b);
@@ -879,7 +879,7 @@ int32_t cg_vec_gather_strided_dev(cg_ctx* ctx, int32_t curve, void* d_out, const
         return launch_vec_gather_strided<Fr>(ctx->stream, (Fr*)d_out, (const Fr*)d_in, n, offset, stride);
     });
 }
-int32_t cg_vec_prefix_prod_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n) {
+static int32_t prefix_scan_dev(cg_ctx* ctx, int32_t curve, int op, void* d_out, const void* d_in, size_t n) {
     if (!ctx || !d_out || !d_in) return fail(CG_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return 0;
@@ -888,9 +888,11 @@ int32_t cg_vec_prefix_prod_dev(cg_ctx* ctx, int32_t curve, void* d_out, const vo
         const size_t ntiles = (n + 2047) / 2048;
         { int rc = ensure_arena(ctx, align_up(ntiles * sizeof(Fr))); if (rc) return rc; }
         StatScope ss(ctx, TAG_VEC);
-        return launch_prefix_prod<Fr>(ctx->stream, (Fr*)d_out, (const Fr*)d_in, n, (Fr*)ctx->arena.base);
+        return launch_prefix_scan<Fr>(ctx->stream, op, (Fr*)d_out, (const Fr*)d_in, n, (Fr*)ctx->arena.base);
     });
 }
+int32_t cg_vec_prefix_prod_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n) { return prefix_scan_dev(ctx, curve, 0, d_out, d_in, n); }
+int32_t cg_vec_prefix_sum_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n) { return prefix_scan_dev(ctx, curve, 1, d_out, d_in, n); }
 int32_t cg_vec_inverse_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n) {
     if (!ctx || !d_out || !d_in) return fail(CG_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));

@@ -45,17 +45,20 @@ template <class Fr> int launch_vec_gather_strided(hipStream_t st, Fr* out, const
     HIPCHK(hipGetLastError());
     return 0;
 }
-// scratch: ceil(n / 2048) elements
-template <class Fr> int launch_prefix_prod(hipStream_t st, Fr* out, const Fr* in, size_t n, Fr* scratch) {
-    if (!n) return 0;
+// scratch: ceil(n / 2048) elements; op 0 = product, 1 = sum
+template <class Fr, int OP> int launch_prefix_op(hipStream_t st, Fr* out, const Fr* in, size_t n, Fr* scratch) {
     const size_t tile = (size_t)256 * SCAN_ITEMS, ntiles = (n + tile - 1) / tile;
-    hipLaunchKernelGGL((k_prefix_prod_tiles<Fr>), dim3((unsigned)ntiles), dim3(256), 0, st, out, in, n, scratch);
+    hipLaunchKernelGGL((k_prefix_tiles<Fr, OP>), dim3((unsigned)ntiles), dim3(256), 0, st, out, in, n, scratch);
     if (ntiles > 1) {
-        hipLaunchKernelGGL((k_prefix_prod_totals<Fr>), dim3(1), dim3(256), 0, st, scratch, ntiles);
-        hipLaunchKernelGGL((k_prefix_prod_fixup<Fr>), dim3(grid_for(n)), dim3(256), 0, st, out, n, scratch);
+        hipLaunchKernelGGL((k_prefix_totals<Fr, OP>), dim3(1), dim3(256), 0, st, scratch, ntiles);
+        hipLaunchKernelGGL((k_prefix_fixup<Fr, OP>), dim3(grid_for(n)), dim3(256), 0, st, out, n, scratch);
     }
     HIPCHK(hipGetLastError());
     return 0;
+}
+template <class Fr> int launch_prefix_scan(hipStream_t st, int op, Fr* out, const Fr* in, size_t n, Fr* scratch) {
+    if (!n) return 0;
+    return op == 0 ? launch_prefix_op<Fr, 0>(st, out, in, n, scratch) : launch_prefix_op<Fr, 1>(st, out, in, n, scratch);
 }
 template <class Fr> int launch_vec_inverse(hipStream_t st, Fr* out, const Fr* in, size_t n) {
     if (!n) return 0;
@@ -191,7 +194,7 @@ template <class Fr> int msm_sort_direct_launch(hipStream_t st, const Fr* d_scala
     template int launch_vec_fill<Fr>(hipStream_t, Fr*, size_t, const Fr&);                                                 \
     template int launch_vec_affine<Fr>(hipStream_t, Fr*, const Fr*, size_t, const Fr&, const Fr&);                         \
     template int launch_vec_gather_strided<Fr>(hipStream_t, Fr*, const Fr*, size_t, size_t, size_t);                       \
-    template int launch_prefix_prod<Fr>(hipStream_t, Fr*, const Fr*, size_t, Fr*);                                         \
+    template int launch_prefix_scan<Fr>(hipStream_t, int, Fr*, const Fr*, size_t, Fr*);                                    \
     template int launch_vec_inverse<Fr>(hipStream_t, Fr*, const Fr*, size_t);                                              \
     template int launch_spmv_csr<Fr>(hipStream_t, const uint32_t*, const uint32_t*, const Fr*, size_t, const Fr*, uint32_t, int, const Fr*, const Fr*, Fr*, Fr*); \
     template int launch_build_twiddles<Fr>(hipStream_t, Fr*, size_t, int, const Fr*, const Fr*, int);                      \

@@ -106,59 +106,62 @@ __global__ void __launch_bounds__(256) k_vec_gather_strided(F* __restrict__ out,
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fp(out + i, ld_fp(in + offset + i * stride));
 }
 
-// Inclusive prefix product out[i] = in[0] * ... * in[i] (what `array_prod_mul` yields for a single-component driver, round2.rs:18-41).
-// Three launches: tiles of 256 x SCAN_ITEMS elements (serial per lane, Hillis-Steele across the workgroup in LDS), a scan of the tile
-// totals by one workgroup, and the fix-up multiply.
+// Inclusive prefix scan out[i] = in[0] (op) ... (op) in[i], op = field product (what `array_prod_mul` yields for a single-component
+// driver, round2.rs:18-41) or field sum (polynomial evaluation and the synthetic division of round 5).  Three launches: tiles of
+// 256 x SCAN_ITEMS elements (serial per lane, Hillis-Steele across the workgroup in LDS), a scan of the tile totals by one
+// workgroup, and the fix-up pass.
 constexpr int SCAN_ITEMS = 8;
-template <class F>
-__device__ __forceinline__ F block_scan_mul(F v, F* sh, F* total) {      // inclusive scan over the 256 lanes; returns the lane's inclusive value
+template <class F, int OP> struct ScanOp {
+    __device__ __forceinline__ static F id() { return OP == 0 ? F::one() : F::zero(); }
+    __device__ __forceinline__ static F ap(const F& a, const F& b) { return OP == 0 ? a * b : a + b; }
+};
+template <class F, int OP>
+__device__ __forceinline__ void block_scan(F v, F* sh, F* total) {      // inclusive scan over the 256 lanes, left in sh[]
     const int t = threadIdx.x;
     sh[t] = v; __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
         F x = sh[t];
-        if (t >= off) x = sh[t - off] * x;
+        if (t >= off) x = ScanOp<F, OP>::ap(sh[t - off], x);
         __syncthreads();
         sh[t] = x; __syncthreads();
     }
     if (total) *total = sh[255];
-    return sh[t];
 }
-template <class F>
-__global__ void __launch_bounds__(256) k_prefix_prod_tiles(F* __restrict__ out, const F* __restrict__ in, size_t n, F* __restrict__ tile_tot) {
+template <class F, int OP>
+__global__ void __launch_bounds__(256) k_prefix_tiles(F* __restrict__ out, const F* __restrict__ in, size_t n, F* __restrict__ tile_tot) {
     __shared__ F sh[256];
     const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_ITEMS;
-    F loc[SCAN_ITEMS]; F run = F::one();
-    _Pragma("unroll") for (int k = 0; k < SCAN_ITEMS; k++) { if (base + k < n) run = run * ld_fp(in + base + k); loc[k] = run; }
+    F loc[SCAN_ITEMS]; F run = ScanOp<F, OP>::id();
+    _Pragma("unroll") for (int k = 0; k < SCAN_ITEMS; k++) { if (base + k < n) run = ScanOp<F, OP>::ap(run, ld_fp(in + base + k)); loc[k] = run; }
     F tot;
-    F incl = block_scan_mul(run, sh, &tot);
+    block_scan<F, OP>(run, sh, &tot);
     __syncthreads();
-    const F excl = threadIdx.x ? sh[threadIdx.x - 1] : F::one();
-    (void)incl;
-    _Pragma("unroll") for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) st_fp(out + base + k, excl * loc[k]);
+    const F excl = threadIdx.x ? sh[threadIdx.x - 1] : ScanOp<F, OP>::id();
+    _Pragma("unroll") for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) st_fp(out + base + k, ScanOp<F, OP>::ap(excl, loc[k]));
     if (threadIdx.x == 0) st_fp(tile_tot + blockIdx.x, tot);
 }
-template <class F>
-__global__ void __launch_bounds__(256) k_prefix_prod_totals(F* __restrict__ tile_tot, size_t ntiles) {   // in place -> EXCLUSIVE prefix of the tile totals
+template <class F, int OP>
+__global__ void __launch_bounds__(256) k_prefix_totals(F* __restrict__ tile_tot, size_t ntiles) {   // in place -> EXCLUSIVE prefix of the tile totals
     __shared__ F sh[256];
-    F carry = F::one();
+    F carry = ScanOp<F, OP>::id();
     for (size_t b0 = 0; b0 < ntiles; b0 += 256) {
         const size_t i = b0 + threadIdx.x;
-        F v = i < ntiles ? ld_fp(tile_tot + i) : F::one();
+        F v = i < ntiles ? ld_fp(tile_tot + i) : ScanOp<F, OP>::id();
         F tot;
-        block_scan_mul(v, sh, &tot);
+        block_scan<F, OP>(v, sh, &tot);
         __syncthreads();
-        const F excl = carry * (threadIdx.x ? sh[threadIdx.x - 1] : F::one());
+        const F excl = ScanOp<F, OP>::ap(carry, threadIdx.x ? sh[threadIdx.x - 1] : ScanOp<F, OP>::id());
         if (i < ntiles) st_fp(tile_tot + i, excl);
-        carry = carry * tot;
+        carry = ScanOp<F, OP>::ap(carry, tot);
         __syncthreads();
     }
 }
-template <class F>
-__global__ void __launch_bounds__(256) k_prefix_prod_fixup(F* __restrict__ out, size_t n, const F* __restrict__ tile_excl) {
+template <class F, int OP>
+__global__ void __launch_bounds__(256) k_prefix_fixup(F* __restrict__ out, size_t n, const F* __restrict__ tile_excl) {
     const size_t tile = (size_t)256 * SCAN_ITEMS;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         if (i < tile) continue;
-        st_fp(out + i, ld_fp(tile_excl + i / tile) * ld_fp(out + i));
+        st_fp(out + i, ScanOp<F, OP>::ap(ld_fp(tile_excl + i / tile), ld_fp(out + i)));
     }
 }
 // out[i] = in[i]^-1 (0 -> 0): Montgomery's trick over INV_ITEMS elements per lane, one Fermat inversion per lane (inv_many, plain.rs)

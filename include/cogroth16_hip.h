@@ -130,11 +130,13 @@ int32_t cg_vec_distribute_powers_dev(cg_ctx* ctx, int32_t curve, void* d_v, size
  *   fill:    v[i] = value
  *   gather:  out[i] = in[offset + i * stride]                 (every 4th evaluation of a zkey polynomial, co-plonk round2.rs:196-206)
  *   prefix:  out[i] = in[0] * ... * in[i]                     (what array_prod_mul yields, round2.rs:18-41); out may equal in
+ *   prefix sum: out[i] = in[0] + ... + in[i]                  (evaluate_poly_public and div_by_zerofier of co-plonk rounds 4/5 as scans)
  *   inverse: out[i] = in[i]^-1, 0 -> 0                        (inv_many; the reference errors on 0, callers check) */
 int32_t cg_vec_affine_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_a, size_t n, const void* h_c, const void* h_d);
 int32_t cg_vec_fill_dev(cg_ctx* ctx, int32_t curve, void* d_v, size_t n, const void* h_value);
 int32_t cg_vec_gather_strided_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n, size_t offset, size_t stride);
 int32_t cg_vec_prefix_prod_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n);
+int32_t cg_vec_prefix_sum_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n);
 int32_t cg_vec_inverse_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n);
 /* evaluate_constraint over all rows (traits.rs:180; groth16.rs:159-166): CSR matrix, signal index < n_inputs = public.
  * party: -1 = single component (plain / Shamir), 0..2 = REP3 party id (add_with_public asymmetry, rep3.rs:600-608).

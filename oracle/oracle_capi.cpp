@@ -321,9 +321,9 @@ int orc_plonk_round2_plain(int curve, const char* path, const uint64_t* full_wit
     return 0;
 }
 
-// the plain-driver prover up to round `upto` (1..3); blind = 11 Fr.  commits: 7 packed G1 (a, b, c, z, t1, t2, t3; zeros when not reached),
-// challenges: beta, gamma, alpha.  t_polys (optional): t1 (n+1) | t2 (n+1) | t3 (n+6)
-int orc_plonk_prove_plain(int curve, const char* path, const uint64_t* full_witness, const uint64_t* blind, int upto, uint64_t* commits, uint64_t* challenges, uint64_t* t_polys) {
+// the plain-driver prover up to round `upto` (1..5); blind = 11 Fr.  commits: 9 packed G1 (a, b, c, z, t1, t2, t3, wxi, wxiw; zeros when not
+// reached), challenges: beta, gamma, alpha, xi, v; evals: a, b, c, s1, s2, zw.  t_polys (optional): t1 (n+1) | t2 (n+1) | t3 (n+6)
+int orc_plonk_prove_plain(int curve, const char* path, const uint64_t* full_witness, const uint64_t* blind, int upto, uint64_t* commits, uint64_t* challenges, uint64_t* evals, uint64_t* t_polys) {
     DISPATCH(curve, {
         typedef typename C::Fr Fr; typedef typename C::Fq Fq;
         auto z = read_plonk_zkey<C>(path);
@@ -331,7 +331,7 @@ int orc_plonk_prove_plain(int curve, const char* path, const uint64_t* full_witn
         std::vector<Fr> fw(w, w + (z.n_vars - z.n_additions));
         Fr b[11]; for (int i = 0; i < 11; i++) b[i] = ld<Fr>(blind + i * Fr::N);
         PlonkPlainProver<C> pr(z, fw, b);
-        memset(commits, 0, 7 * 2 * Fq::N * 8); memset(challenges, 0, 3 * Fr::N * 8);
+        memset(commits, 0, 9 * 2 * Fq::N * 8); memset(challenges, 0, 5 * Fr::N * 8); memset(evals, 0, 6 * Fr::N * 8);
         pr.round1();
         for (int k = 0; k < 3; k++) st_g1<Fq>(commits + k * 2 * Fq::N, pr.commit[k]);
         if (upto >= 2) { pr.round2(); st_g1<Fq>(commits + 3 * 2 * Fq::N, pr.commit_z); st<Fr>(challenges, pr.beta); st<Fr>(challenges + Fr::N, pr.gamma); }
@@ -341,6 +341,17 @@ int orc_plonk_prove_plain(int curve, const char* path, const uint64_t* full_witn
             st<Fr>(challenges + 2 * Fr::N, pr.alpha);
             if (t_polys) { memcpy(t_polys, pr.t1.data(), pr.t1.size() * sizeof(Fr)); memcpy(t_polys + pr.t1.size() * Fr::N, pr.t2.data(), pr.t2.size() * sizeof(Fr));
                            memcpy(t_polys + (pr.t1.size() + pr.t2.size()) * Fr::N, pr.t3.data(), pr.t3.size() * sizeof(Fr)); }
+        }
+        if (upto >= 4) {
+            pr.round4();
+            st<Fr>(challenges + 3 * Fr::N, pr.xi);
+            const Fr ev[6] = {pr.eval_a, pr.eval_b, pr.eval_c, pr.eval_s1, pr.eval_s2, pr.eval_zw};
+            for (int i = 0; i < 6; i++) st<Fr>(evals + i * Fr::N, ev[i]);
+        }
+        if (upto >= 5) {
+            pr.round5();
+            st<Fr>(challenges + 4 * Fr::N, pr.v[0]);
+            st_g1<Fq>(commits + 7 * 2 * Fq::N, pr.commit_wxi); st_g1<Fq>(commits + 8 * 2 * Fq::N, pr.commit_wxiw);
         }
     });
     return 0;

@@ -219,8 +219,11 @@ struct PlonkPlainProver {
     std::vector<Fr> buf[3], poly[3], eval[3];  // wire values, blinded coefficients (n + 2), evaluations of the UNBLINDED polynomial on 4n points
     std::vector<Fr> poly_z, eval_z;
     AffineT<Fq> commit[3], commit_z, commit_t[3];
-    Fr beta, gamma, alpha;
+    Fr beta, gamma, alpha, xi, v[5];
     std::vector<Fr> t1, t2, t3;
+    Fr eval_a, eval_b, eval_c, eval_zw, eval_s1, eval_s2;
+    std::vector<Fr> wxi, wxiw;
+    AffineT<Fq> commit_wxi, commit_wxiw;
 
     PlonkPlainProver(const PlonkZKey<C>& zk, const std::vector<Fr>& full_witness, const Fr* blind) : z(zk), n(zk.domain_size), w(full_witness) {
         if (full_witness.size() + z.n_additions != z.n_vars) throw std::runtime_error("witness length does not match the zkey");
@@ -333,6 +336,53 @@ struct PlonkPlainProver {
         t2[0] = t2[0] - b[9]; t2.push_back(b[10]);
         t3[0] = t3[0] - b[10];
         commit_t[0] = commit_poly(t1); commit_t[1] = commit_poly(t2); commit_t[2] = commit_poly(t3);
+    }
+    static Fr horner(const std::vector<Fr>& p, const Fr& x) { Fr acc = Fr::zero(); for (size_t i = p.size(); i-- > 0;) acc = acc * x + p[i]; return acc; }   // evaluate_poly_public
+    void round4() {                                                                                   // round4.rs:115-160
+        { PlonkTranscript<C> t; t.add_scalar(alpha); for (int k = 0; k < 3; k++) t.add_point(commit_t[k]); xi = t.get_challenge(); }
+        eval_a = horner(poly[0], xi); eval_b = horner(poly[1], xi); eval_c = horner(poly[2], xi);
+        eval_zw = horner(poly_z, xi * omega);
+        eval_s1 = horner(z.sigma_coef[0], xi); eval_s2 = horner(z.sigma_coef[1], xi);
+    }
+    static void div_by_zerofier1(std::vector<Fr>& p, const Fr& beta_) {                               // round5.rs:97-115 with n = 1
+        const Fr inv = beta_.inverse();
+        p[0] = p[0] * (Fr::zero() - inv);
+        for (size_t i = 1; i < p.size(); i++) p[i] = (p[i - 1] - p[i]) * inv;
+        p.pop_back();
+    }
+    void round5() {                                                                                   // round5.rs:143-365
+        {
+            PlonkTranscript<C> t; t.add_scalar(xi); t.add_scalar(eval_a); t.add_scalar(eval_b); t.add_scalar(eval_c); t.add_scalar(eval_s1); t.add_scalar(eval_s2); t.add_scalar(eval_zw);
+            v[0] = t.get_challenge(); for (int i = 1; i < 5; i++) v[i] = v[i - 1] * v[0];
+        }
+        const Fr one = Fr::one();
+        Fr xin = xi; for (size_t i = 0; i < z.power; i++) xin = xin * xin;                             // lib.rs:160-184
+        const Fr zh = xin - one;
+        std::vector<Fr> l; { Fr wv = one; const Fr nn = Fr::from_u64((uint64_t)n); for (size_t i = 0; i < std::max<size_t>(1, z.n_public); i++) { l.push_back(wv * zh * (nn * (xi - wv)).inverse()); wv = wv * omega; } }
+        Fr eval_pi = Fr::zero(); for (size_t i = 0; i < z.n_public && i < l.size(); i++) eval_pi = eval_pi - l[i] * w[i + 1];   // calculate_pi (:186-195)
+        const Fr coef_ab = eval_a * eval_b, betaxi = beta * xi;
+        const Fr e2 = (eval_a + betaxi + gamma) * (eval_b + betaxi * z.k1 + gamma) * (eval_c + betaxi * z.k2 + gamma) * alpha;
+        const Fr e3 = (eval_a + beta * eval_s1 + gamma) * (eval_b + beta * eval_s2 + gamma) * eval_zw * alpha;
+        const Fr e4 = alpha * alpha * l[0], e24 = e2 + e4;
+        const size_t len = n + 6;
+        std::vector<Fr> r(len, Fr::zero());
+        for (size_t i = 0; i < poly_z.size(); i++) r[i] = e24 * poly_z[i];
+        const Fr me3b = Fr::zero() - e3 * beta;
+        for (size_t i = 0; i < n; i++) r[i] = r[i] + z.q_coef[0][i] * coef_ab + z.q_coef[1][i] * eval_a + z.q_coef[2][i] * eval_b + z.q_coef[3][i] * eval_c + z.q_coef[4][i] + z.sigma_coef[2][i] * me3b;
+        const Fr xin2 = xin * xin;
+        for (size_t i = 0; i < len; i++) {
+            Fr tmp = (i < t3.size() ? t3[i] * xin2 : Fr::zero()) + (i < t2.size() ? t2[i] * xin : Fr::zero()) + (i < t1.size() ? t1[i] : Fr::zero());
+            r[i] = r[i] - tmp * zh;
+        }
+        r[0] = r[0] + (eval_pi - e3 * (eval_c + gamma) - e4);
+        wxi = r;                                                                                       // compute_wxi (:263-311)
+        for (size_t i = 0; i < poly[0].size(); i++) wxi[i] = wxi[i] + v[0] * poly[0][i] + v[1] * poly[1][i] + v[2] * poly[2][i];
+        for (size_t i = 0; i < n; i++) wxi[i] = wxi[i] + v[3] * z.sigma_coef[0][i] + v[4] * z.sigma_coef[1][i];
+        wxi[0] = wxi[0] - v[0] * eval_a - v[1] * eval_b - v[2] * eval_c - v[3] * eval_s1 - v[4] * eval_s2;
+        div_by_zerofier1(wxi, xi);
+        wxiw = poly_z; wxiw[0] = wxiw[0] - eval_zw;                                                    // compute_wxiw (:314-327)
+        div_by_zerofier1(wxiw, xi * omega);
+        commit_wxi = commit_poly(wxi); commit_wxiw = commit_poly(wxiw);
     }
 };
 

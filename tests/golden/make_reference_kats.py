@@ -10,6 +10,8 @@ Sources (values only, no code is copied):
   /root/reference/co-circom/co-plonk/src/round1.rs:346-428             Plonk round-1 commitments [a]_1, [b]_1, [c]_1 (blinding b_i = i)
   /root/reference/co-circom/co-plonk/src/round2.rs:326-355             Plonk round-2 commitment [z]_1
   /root/reference/co-circom/co-plonk/src/round3.rs:553-596             Plonk round-3 commitments [t1]_1, [t2]_1, [t3]_1
+  /root/reference/co-circom/co-plonk/src/round4.rs:169-246             Plonk round-4 evaluations
+  /root/reference/co-circom/co-plonk/src/round5.rs:391-429             Plonk round-5 opening commitments [Wxi]_1, [Wxiw]_1
   /root/reference/co-circom/co-plonk/src/types.rs:194-227              Keccak256 transcript challenge
 """
 import json, re, sys, os
@@ -93,6 +95,19 @@ for which in ("commit_t1", "commit_t2", "commit_t3"):
     m = re.search(r"proof\.%s,\s*g1_from_xy!\(\s*\"(\d+)\",\s*\"(\d+)\"" % which, src, re.S)
     r3[which] = [m.group(1), m.group(2)]
 out["plonk_round3"] = {"test_round3_multiplier2": dict(file="Plonk/bn254/multiplier2/circuit.zkey", **r3)}
+
+src = open(f"{REF}/co-circom/co-plonk/src/round4.rs").read()
+r4 = {}
+for which in ("eval_a", "eval_b", "eval_c", "eval_zw", "eval_s1", "eval_s2"):
+    m = re.search(r"proof\.%s,\s*ark_bn254::Fr::from_str\(\s*\"(\d+)\"" % which, src, re.S)
+    r4[which] = m.group(1)
+out["plonk_round4"] = {"test_round4_multiplier2": dict(file="Plonk/bn254/multiplier2/circuit.zkey", **r4)}
+src = open(f"{REF}/co-circom/co-plonk/src/round5.rs").read()
+r5 = {}
+for which in ("wxi", "wxiw"):
+    m = re.search(r"proof\.%s,\s*g1_from_xy!\(\s*\"(\d+)\",\s*\"(\d+)\"" % which, src, re.S)
+    r5[which] = [m.group(1), m.group(2)]
+out["plonk_round5"] = {"test_round5_multiplier2": dict(file="Plonk/bn254/multiplier2/circuit.zkey", **r5)}
 
 # transcript KAT: the sequence of add_point / add_scalar calls and the expected challenge (types.rs:194-227)
 src = open(f"{REF}/co-circom/co-plonk/src/types.rs").read()

@@ -532,6 +532,11 @@ def test_vec_prefix_product_inverse_affine(ctx, curve, n):
     np.testing.assert_array_equal(got[0], x[0])
     if n > 1:
         np.testing.assert_array_equal(got[1:], orc.field_op(curve, FR, "mul", got[:-1], x[1:]))
+    ctx.vec_prefix_sum(curve, d_o, d_x, n)
+    got = d_o.download((n, 4))
+    np.testing.assert_array_equal(got[0], x[0])
+    if n > 1:
+        np.testing.assert_array_equal(got[1:], orc.field_op(curve, FR, "add", got[:-1], x[1:]))
     # fill + strided gather
     ctx.vec_fill(curve, d_o, n, c)
     np.testing.assert_array_equal(d_o.download((n, 4)), np.broadcast_to(c, (n, 4)))

@@ -108,15 +108,22 @@ def _pt(curve, xy):
     return np.concatenate([orc.from_dec(curve, FQ, xy[0]), orc.from_dec(curve, FQ, xy[1])])
 
 
-def test_oracle_rounds_1_to_3_match_reference_kats():
-    """the round-by-round prover state machine: every commitment the reference hard-codes for rounds 1, 2 and 3 (round1.rs:346-383,
-    round2.rs:326-355, round3.rs:553-596), all from ONE run with the deterministic blinding b_i = i"""
-    w = orc.read_wtns(BN254, fx("bn254", "witness.wtns"))
-    r = orc.plonk_prove_plain(BN254, fx("bn254", "circuit.zkey"), w, deterministic_blinding(BN254, 11), upto=3)
+def check_against_reference_kats(r):
+    """every value the reference hard-codes for the five rounds on Plonk/bn254/multiplier2 with the deterministic blinding b_i = i
+    (round1.rs:346-383, round2.rs:326-355, round3.rs:553-596, round4.rs:169-246, round5.rs:391-429)"""
     k1, k2, k3 = KATS["test_round1_multiplier2"], ALL_KATS["plonk_round2"]["test_round2_multiplier2"], ALL_KATS["plonk_round3"]["test_round3_multiplier2"]
+    k4, k5 = ALL_KATS["plonk_round4"]["test_round4_multiplier2"], ALL_KATS["plonk_round5"]["test_round5_multiplier2"]
     for name, kat in (("a", k1["commit_a"]), ("b", k1["commit_b"]), ("c", k1["commit_c"]), ("z", k2["commit_z"]),
-                      ("t1", k3["commit_t1"]), ("t2", k3["commit_t2"]), ("t3", k3["commit_t3"])):
+                      ("t1", k3["commit_t1"]), ("t2", k3["commit_t2"]), ("t3", k3["commit_t3"]), ("wxi", k5["wxi"]), ("wxiw", k5["wxiw"])):
         np.testing.assert_array_equal(r[name], _pt(BN254, kat), err_msg=name)
+    for name in ("eval_a", "eval_b", "eval_c", "eval_zw", "eval_s1", "eval_s2"):
+        np.testing.assert_array_equal(r[name], orc.from_dec(BN254, FR, k4[name]), err_msg=name)
+
+
+def test_oracle_all_rounds_match_reference_kats():
+    """the round-by-round prover state machine, ONE run through rounds 1-5"""
+    w = orc.read_wtns(BN254, fx("bn254", "witness.wtns"))
+    check_against_reference_kats(orc.plonk_prove_plain(BN254, fx("bn254", "circuit.zkey"), w, deterministic_blinding(BN254, 11), upto=5))
 
 
 def test_host_plonk_zkey_reader_matches_oracle():
