@@ -483,15 +483,21 @@ def plonk_round2_plain(curve, zkey_path, full_witness, blind, device=0, want_pol
     return (bg[0], bg[1], cz, poly) if want_poly else (bg[0], bg[1], cz)
 
 
-def plonk_prove_plain(curve, zkey_path, full_witness, blind, upto=3, device=0, want_t=False):
-    """co-plonk with the plain driver on the GPU through round `upto` (<= 3): dict(a, b, c, z, t1, t2, t3, beta, gamma, alpha[, t polys])"""
+PLONK_COMMITS = ("a", "b", "c", "z", "t1", "t2", "t3", "wxi", "wxiw")
+PLONK_CHALLENGES = ("beta", "gamma", "alpha", "xi", "v")
+PLONK_EVALS = ("eval_a", "eval_b", "eval_c", "eval_s1", "eval_s2", "eval_zw")
+
+
+def plonk_prove_plain(curve, zkey_path, full_witness, blind, upto=5, device=0, want_t=False):
+    """co-plonk with the plain driver on the GPU through round `upto` (<= 5): dict of commitments, challenges, evaluations[, t polys]
+    (the proof of co-plonk/src/plonk.rs = the nine commitments and six evaluations)"""
     info = host_plonk_zkey_info(curve, zkey_path)
     nq = 6 if curve == BLS12_381 else 4; n = info["domain_size"]
-    commits = np.zeros((7, 2 * nq), dtype=np.uint64); ch = np.zeros((3, 4), dtype=np.uint64)
+    commits = np.zeros((9, 2 * nq), dtype=np.uint64); ch = np.zeros((5, 4), dtype=np.uint64); ev = np.zeros((6, 4), dtype=np.uint64)
     tp = np.zeros((3 * n + 8, 4), dtype=np.uint64) if want_t else None
     _hchk(load_host().cgh_plonk_prove_plain(int(device), curve, zkey_path.encode(), _hp(np.ascontiguousarray(full_witness, dtype=np.uint64)),
-                                            _hp(np.ascontiguousarray(blind, dtype=np.uint64)), int(upto), _hp(commits), _hp(ch), _hp(tp) if want_t else None))
-    out = dict(zip(("a", "b", "c", "z", "t1", "t2", "t3"), commits)); out.update(beta=ch[0], gamma=ch[1], alpha=ch[2])
+                                            _hp(np.ascontiguousarray(blind, dtype=np.uint64)), int(upto), _hp(commits), _hp(ch), _hp(ev), _hp(tp) if want_t else None))
+    out = dict(zip(PLONK_COMMITS, commits)); out.update(zip(PLONK_CHALLENGES, ch)); out.update(zip(PLONK_EVALS, ev))
     if want_t: out.update(t1_poly=tp[:n + 1], t2_poly=tp[n + 1:2 * n + 2], t3_poly=tp[2 * n + 2:])
     return out
 

@@ -714,6 +714,7 @@ struct PlonkZKey {   // circom-types/src/plonk/zkey.rs:18-42 (the fields round 1
     std::vector<Fr> sigma_eval[3];   // 4 * domain_size evaluations of sigma1..3 (section 12, zkey.rs:116-135,170-180)
     std::vector<Fr> q_eval[5];       // qm, ql, qr, qo, qc on the extended domain (sections 7..11)
     std::vector<std::vector<Fr>> lagrange_eval;   // n_public polynomials on the extended domain (section 13)
+    std::vector<Fr> q_coef[5], sigma_coef[3];     // coefficient forms (rounds 4 and 5)
 };
 static PlonkZKey read_plonk_zkey(int curve_id, const std::string& path) {   // zkey.rs:83-255, header :373-424
     Curve c{curve_id};
@@ -743,12 +744,12 @@ static PlonkZKey read_plonk_zkey(int curve_id, const std::string& path) {   // z
     {
         Cursor sg = section(12);
         for (int k = 0; k < 3; k++) {
-            sg.need(z.domain_size * 32); sg.off += z.domain_size * 32;                 // coefficient form, not needed by the prover rounds implemented here
+            z.sigma_coef[k].resize(z.domain_size); sg.bytes(z.sigma_coef[k].data(), z.domain_size * 32);
             z.sigma_eval[k].resize(4 * z.domain_size);
             sg.bytes(z.sigma_eval[k].data(), 4 * z.domain_size * 32);
         }
     }
-    for (int k = 0; k < 5; k++) { Cursor q = section(7 + k); q.need(z.domain_size * 32); q.off += z.domain_size * 32; z.q_eval[k].resize(4 * z.domain_size); q.bytes(z.q_eval[k].data(), 4 * z.domain_size * 32); }
+    for (int k = 0; k < 5; k++) { Cursor q = section(7 + k); z.q_coef[k].resize(z.domain_size); q.bytes(z.q_coef[k].data(), z.domain_size * 32); z.q_eval[k].resize(4 * z.domain_size); q.bytes(z.q_eval[k].data(), 4 * z.domain_size * 32); }
     { Cursor l = section(13); z.lagrange_eval.resize(z.n_public); for (auto& v : z.lagrange_eval) { l.need(z.domain_size * 32); l.off += z.domain_size * 32; v.resize(4 * z.domain_size); l.bytes(v.data(), 4 * z.domain_size * 32); } }
     { Cursor a = section(3); z.additions.resize(z.n_additions); for (auto& e : z.additions) { e.id1 = a.u32(); e.id2 = a.u32(); a.bytes(e.f1.v, 32); a.bytes(e.f2.v, 32); } }
     for (int k = 0; k < 3; k++) { Cursor m = section(4 + k); z.map[k].resize(z.n_constraints); for (auto& v : z.map[k]) v = m.u32(); }
@@ -1093,6 +1094,98 @@ public:
     }
 };
 
+// Rounds 4 and 5 (co-plonk/src/round4.rs:115-160, round5.rs:97-365) for the plain driver.  Both rounds are linear in the shared
+// polynomials; the two non-pointwise steps run as scans on the device: evaluation at a point = last entry of prefix_sum(c_i x^i),
+// division by (X - beta) = the recurrence y_i = (y_{i-1} - q_i) / beta, i.e. y_i = p^i * prefix_sum(-p q_j p^-j) with p = 1/beta.
+class CoPlonkRound45 {
+public:
+    HipDriver& driver;
+    explicit CoPlonkRound45(HipDriver& d) : driver(d) {}
+    struct Result { Fr xi, v0, eval_a, eval_b, eval_c, eval_s1, eval_s2, eval_zw; Point commit_wxi, commit_wxiw; };
+
+    Fr eval_poly(const void* d_poly, size_t len, const Fr& x) {                      // evaluate_poly_public (plain.rs) as a scan
+        const Curve& c = driver.curve; cg_ctx* ctx = driver.ctx;
+        const Fr one = fr_from_u64(c, 1);
+        void* t = driver.dalloc(len * 32);
+        CG(cg_vec_gather_strided_dev(ctx, c.id, t, d_poly, len, 0, 1));
+        CG(cg_vec_distribute_powers_dev(ctx, c.id, t, len, x.v, one.v));
+        CG(cg_vec_prefix_sum_dev(ctx, c.id, t, t, len));
+        Fr r; CG(cg_dev_download(ctx, r.v, (const uint8_t*)t + (len - 1) * 32, 32));
+        CG(cg_dev_free(ctx, t));
+        return r;
+    }
+    void div_by_zerofier1(void* d_poly, size_t len, const Fr& beta_) {               // round5.rs:97-115 with n = 1 (the caller drops the last entry)
+        const Curve& c = driver.curve; cg_ctx* ctx = driver.ctx;
+        const Fr one = fr_from_u64(c, 1), zero = fr_from_u64(c, 0), p = fr_inv(c, beta_);
+        CG(cg_vec_affine_dev(ctx, c.id, d_poly, d_poly, len, fr_sub(c, zero, p).v, nullptr));
+        CG(cg_vec_distribute_powers_dev(ctx, c.id, d_poly, len, beta_.v, one.v));
+        CG(cg_vec_prefix_sum_dev(ctx, c.id, d_poly, d_poly, len));
+        CG(cg_vec_distribute_powers_dev(ctx, c.id, d_poly, len, p.v, one.v));
+    }
+    Result run(const PlonkZKey& z, const cg_bases* p_tau, const std::vector<Fr>& public_inputs /* n_public values */, const Fr& beta, const Fr& gamma, const Fr& alpha,
+               const Point* commit_t, const ShareVec* polys /* a, b, c: n + 2 */, const ShareVec& poly_z /* n + 3 */, const ShareVec* t_parts /* n+1, n+1, n+6 */) {
+        if (driver.mode != Mode::Plain) throw std::runtime_error("co-plonk rounds 4/5 are implemented for the plain driver");
+        const Curve& c = driver.curve; cg_ctx* ctx = driver.ctx;
+        const size_t n = z.domain_size, len = n + 6;
+        const Fr zero = fr_from_u64(c, 0), one = fr_from_u64(c, 1);
+        auto neg = [&](const Fr& v) { return fr_sub(c, zero, v); };
+        auto M = [&](const Fr& a, const Fr& b) { return fr_mul(c, a, b); };
+        auto A = [&](const Fr& a, const Fr& b) { return fr_add(c, a, b); };
+        const Fr omega = snarkjs_roots(c).roots[z.power];
+        Result r;
+        { PlonkTranscript t(c); t.add_scalar(alpha); for (int k = 0; k < 3; k++) { Bytes a = pt_to_affine(c, commit_t[k]); t.add_point(a.data()); } r.xi = t.get_challenge(); }   // round4.rs:118-124
+        const Fr xi = r.xi, xiw = M(xi, omega);
+        r.eval_a = eval_poly(polys[0].c[0], n + 2, xi); r.eval_b = eval_poly(polys[1].c[0], n + 2, xi); r.eval_c = eval_poly(polys[2].c[0], n + 2, xi);
+        r.eval_zw = eval_poly(poly_z.c[0], n + 3, xiw);
+        auto up = [&](const std::vector<Fr>& h) { void* p = driver.dalloc(h.size() * 32); CG(cg_dev_upload(ctx, p, h.data(), h.size() * 32)); return p; };
+        void* s_co[3]; for (int k = 0; k < 3; k++) s_co[k] = up(z.sigma_coef[k]);
+        r.eval_s1 = eval_poly(s_co[0], n, xi); r.eval_s2 = eval_poly(s_co[1], n, xi);
+        Fr v[5];
+        { PlonkTranscript t(c); const Fr* items[7] = {&xi, &r.eval_a, &r.eval_b, &r.eval_c, &r.eval_s1, &r.eval_s2, &r.eval_zw}; for (const Fr* e : items) t.add_scalar(*e);   // round5.rs:338-350
+          v[0] = t.get_challenge(); for (int i = 1; i < 5; i++) v[i] = M(v[i - 1], v[0]); }
+        r.v0 = v[0];
+        // compute_r (:143-260)
+        Fr xin = xi; for (size_t i = 0; i < z.power; i++) xin = M(xin, xin);
+        const Fr zh = fr_sub(c, xin, one);
+        std::vector<Fr> l; { Fr wv = one; const Fr nn = fr_from_u64(c, (uint64_t)n); for (size_t i = 0; i < std::max<size_t>(1, z.n_public); i++) { l.push_back(M(M(wv, zh), fr_inv(c, M(nn, fr_sub(c, xi, wv))))); wv = M(wv, omega); } }
+        Fr eval_pi = zero; for (size_t i = 0; i < public_inputs.size() && i < l.size(); i++) eval_pi = fr_sub(c, eval_pi, M(l[i], public_inputs[i]));
+        const Fr betaxi = M(beta, xi);
+        const Fr e2 = M(M(M(A(A(r.eval_a, betaxi), gamma), A(A(r.eval_b, M(betaxi, z.k1)), gamma)), A(A(r.eval_c, M(betaxi, z.k2)), gamma)), alpha);
+        const Fr e3 = M(M(M(A(A(r.eval_a, M(beta, r.eval_s1)), gamma), A(A(r.eval_b, M(beta, r.eval_s2)), gamma)), r.eval_zw), alpha);
+        const Fr e4 = M(M(alpha, alpha), l[0]), e24 = A(e2, e4);
+        void* R = driver.dalloc(len * 32); CG(cg_dev_memset_zero(ctx, R, len * 32));
+        void* tmp = driver.dalloc(len * 32);
+        auto axpy = [&](void* dst, const void* src, size_t cnt, const Fr& k) { CG(cg_vec_affine_dev(ctx, c.id, tmp, src, cnt, k.v, nullptr)); CG(cg_vec_add_dev(ctx, c.id, dst, dst, tmp, cnt)); };   // dst[..cnt] += k * src
+        axpy(R, poly_z.c[0], n + 3, e24);
+        { void* q[5]; for (int k = 0; k < 5; k++) q[k] = up(z.q_coef[k]);
+          axpy(R, q[0], n, M(r.eval_a, r.eval_b)); axpy(R, q[1], n, r.eval_a); axpy(R, q[2], n, r.eval_b); axpy(R, q[3], n, r.eval_c); axpy(R, q[4], n, one);
+          axpy(R, s_co[2], n, neg(M(e3, beta)));
+          for (void* p : q) CG(cg_dev_free(ctx, p)); }
+        axpy(R, t_parts[2].c[0], n + 6, neg(M(zh, M(xin, xin)))); axpy(R, t_parts[1].c[0], n + 1, neg(M(zh, xin))); axpy(R, t_parts[0].c[0], n + 1, neg(zh));
+        const Fr r0 = fr_sub(c, fr_sub(c, eval_pi, M(e3, A(r.eval_c, gamma))), e4);
+        // compute_wxi (:263-311): R + v0 a + v1 b + v2 c + v3 s1 + v4 s2, constant term corrected, divided by (X - xi)
+        for (int k = 0; k < 3; k++) axpy(R, polys[k].c[0], n + 2, v[k]);
+        axpy(R, s_co[0], n, v[3]); axpy(R, s_co[1], n, v[4]);
+        Fr h0; CG(cg_dev_download(ctx, h0.v, R, 32));
+        h0 = A(h0, r0);
+        h0 = fr_sub(c, h0, A(A(A(A(M(v[0], r.eval_a), M(v[1], r.eval_b)), M(v[2], r.eval_c)), M(v[3], r.eval_s1)), M(v[4], r.eval_s2)));
+        CG(cg_dev_upload(ctx, R, h0.v, 32));
+        div_by_zerofier1(R, len, xi);
+        ShareVec wxi; wxi.n = len - 1; wxi.c[0] = R;
+        // compute_wxiw (:314-327)
+        ShareVec wxiw = driver.alloc_vec(n + 3);
+        CG(cg_vec_gather_strided_dev(ctx, c.id, wxiw.c[0], poly_z.c[0], n + 3, 0, 1));
+        CG(cg_dev_download(ctx, h0.v, wxiw.c[0], 32)); h0 = fr_sub(c, h0, r.eval_zw); CG(cg_dev_upload(ctx, wxiw.c[0], h0.v, 32));
+        div_by_zerofier1(wxiw.c[0], n + 3, xiw);
+        wxiw.n = n + 2;
+        r.commit_wxi = driver.open_point(driver.msm_public_points(p_tau, CG_G1, 0, wxi.n, wxi));      // :351-358
+        r.commit_wxiw = driver.open_point(driver.msm_public_points(p_tau, CG_G1, 0, wxiw.n, wxiw));
+        driver.free_vec(wxi); driver.free_vec(wxiw); CG(cg_dev_free(ctx, tmp));
+        for (void* p : s_co) CG(cg_dev_free(ctx, p));
+        return r;
+    }
+};
+
 // ---- JSON encodings of proofs and public inputs (circom-types/src/groth16/proof.rs:8-29, traits.rs:186-233, co-circom.rs:540,628) ----
 static std::string limbs_to_dec(const uint64_t* limbs, int n) {          // canonical little-endian -> decimal
     std::vector<uint32_t> w(2 * n);
@@ -1332,10 +1425,10 @@ int32_t cgh_plonk_round2_plain(int32_t device, int32_t curve, const char* zkey_p
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
 }
-// the plain driver through rounds 1..upto (<= 3); blind = 11 Fr; commits = 7 packed G1 (a, b, c, z, t1, t2, t3), challenges = beta, gamma, alpha;
-// t_polys (optional) = t1 (n+1) | t2 (n+1) | t3 (n+6)
+// the plain driver through rounds 1..upto (<= 5); blind = 11 Fr; commits = 9 packed G1 (a, b, c, z, t1, t2, t3, wxi, wxiw), challenges = beta,
+// gamma, alpha, xi, v; evals = a, b, c, s1, s2, zw; t_polys (optional) = t1 (n+1) | t2 (n+1) | t3 (n+6)
 int32_t cgh_plonk_prove_plain(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* full_witness, const uint64_t* blind, int32_t upto,
-                              uint64_t* commits, uint64_t* challenges, uint64_t* t_polys) {
+                              uint64_t* commits, uint64_t* challenges, uint64_t* evals, uint64_t* t_polys) {
     cg_ctx* ctx = nullptr;
     try {
         using namespace cgh;
@@ -1343,34 +1436,44 @@ int32_t cgh_plonk_prove_plain(int32_t device, int32_t curve, const char* zkey_pa
         if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
         const Curve& c = z.curve;
         const size_t psz = c.aff(CG_G1), n = z.domain_size;
-        memset(commits, 0, 7 * psz); memset(challenges, 0, 96);
+        memset(commits, 0, 9 * psz); memset(challenges, 0, 5 * 32); memset(evals, 0, 6 * 32);
         cg_bases* tau = nullptr; CG(cg_bases_register(ctx, c.id, CG_G1, z.p_tau.data(), n + 6, psz, -1, &tau));
         const Fr* w = (const Fr*)full_witness;
         std::vector<Fr> pub(w, w + z.n_public + 1);
+        const std::vector<Fr> pub_tail(pub.begin() + 1, pub.end());
         HipDriver driver(ctx, c, Mode::Plain, nullptr);
         ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_additions - z.n_public - 1);
         FieldShare b[11]; for (int i = 0; i < 11; i++) { memcpy(b[i].c[0].v, blind + 4 * i, 32); b[i].c[1] = b[i].c[0]; }
         auto put = [&](int slot, const Point& p) { Bytes a = pt_to_affine(c, p); memcpy((uint8_t*)commits + slot * psz, a.data(), psz); };
-        ShareVec buffers[3], evals[3], eval_z, tparts[3];
+        ShareVec polys[3], buffers[3], evl[3], poly_z, eval_z, tparts[3];
         CoPlonkRound1 r1(driver);
-        auto cm = r1.round1(z, tau, pub, wit, b, nullptr, buffers, evals);
+        auto cm = r1.round1(z, tau, pub, wit, b, polys, buffers, evl);
         for (int k = 0; k < 3; k++) put(k, cm[k]);
         if (upto >= 2) {
             CoPlonkRound2 r2(driver);
-            auto res2 = r2.round2(z, tau, std::vector<Fr>(pub.begin() + 1, pub.end()), cm, buffers, b, nullptr, &eval_z);
+            auto res2 = r2.round2(z, tau, pub_tail, cm, buffers, b, &poly_z, &eval_z);
             put(3, res2.commit_z); memcpy(challenges, res2.beta.v, 32); memcpy(challenges + 4, res2.gamma.v, 32);
             if (upto >= 3) {
                 CoPlonkRound3 r3(driver);
-                auto res3 = r3.round3(z, tau, res2.beta, res2.gamma, res2.commit_z, buffers, evals, eval_z, b, tparts);
+                auto res3 = r3.round3(z, tau, res2.beta, res2.gamma, res2.commit_z, buffers, evl, eval_z, b, tparts);
                 for (int k = 0; k < 3; k++) put(4 + k, res3.commit_t[k]);
                 memcpy(challenges + 8, res3.alpha.v, 32);
                 if (t_polys) { size_t off = 0; for (int k = 0; k < 3; k++) { CG(cg_dev_download(ctx, t_polys + off * 4, tparts[k].c[0], tparts[k].n * 32)); off += tparts[k].n; } }
+                if (upto >= 4) {
+                    CoPlonkRound45 r45(driver);
+                    auto res5 = r45.run(z, tau, pub_tail, res2.beta, res2.gamma, res3.alpha, res3.commit_t, polys, poly_z, tparts);
+                    memcpy(challenges + 12, res5.xi.v, 32); memcpy(challenges + 16, res5.v0.v, 32);
+                    const Fr ev[6] = {res5.eval_a, res5.eval_b, res5.eval_c, res5.eval_s1, res5.eval_s2, res5.eval_zw};
+                    memcpy(evals, ev, sizeof ev);
+                    if (upto >= 5) { put(7, res5.commit_wxi); put(8, res5.commit_wxiw); }
+                }
                 for (auto& t : tparts) driver.free_vec(t);
             }
-            driver.free_vec(eval_z);
+            driver.free_vec(poly_z); driver.free_vec(eval_z);
         }
+        for (auto& v : polys) driver.free_vec(v);
         for (auto& v : buffers) driver.free_vec(v);
-        for (auto& v : evals) driver.free_vec(v);
+        for (auto& v : evl) driver.free_vec(v);
         driver.free_vec(wit); cg_bases_release(tau); cg_ctx_destroy(ctx);
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }

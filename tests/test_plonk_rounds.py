@@ -202,27 +202,23 @@ def test_gpu_round2_plain_matches_oracle(curve_name):
 
 
 @pytest.mark.gpu
-def test_gpu_rounds_1_to_3_match_reference_kats():
-    """one run of the HIP plain driver through rounds 1-3 reproduces all seven commitments the reference hard-codes"""
+def test_gpu_all_rounds_match_reference_kats():
+    """one run of the HIP plain driver through rounds 1-5 reproduces every value the reference hard-codes: nine commitments, six evaluations"""
     ensure_built()
     w = orc.read_wtns(BN254, fx("bn254", "witness.wtns"))
-    r = cg.plonk_prove_plain(BN254, fx("bn254", "circuit.zkey"), w, deterministic_blinding(BN254, 11), upto=3)
-    k1, k2, k3 = KATS["test_round1_multiplier2"], ALL_KATS["plonk_round2"]["test_round2_multiplier2"], ALL_KATS["plonk_round3"]["test_round3_multiplier2"]
-    for name, kat in (("a", k1["commit_a"]), ("b", k1["commit_b"]), ("c", k1["commit_c"]), ("z", k2["commit_z"]),
-                      ("t1", k3["commit_t1"]), ("t2", k3["commit_t2"]), ("t3", k3["commit_t3"])):
-        np.testing.assert_array_equal(r[name], _pt(BN254, kat), err_msg=name)
+    check_against_reference_kats(cg.plonk_prove_plain(BN254, fx("bn254", "circuit.zkey"), w, deterministic_blinding(BN254, 11), upto=5))
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
-def test_gpu_rounds_1_to_3_match_oracle(curve_name):
-    """random blinding, both curves (BASELINE configs[4]: BLS12-381 co-plonk): commitments, challenges and the quotient parts"""
+def test_gpu_all_rounds_match_oracle(curve_name):
+    """random blinding, both curves (BASELINE configs[4]: BLS12-381 co-plonk): the whole proof, the challenges and the quotient parts"""
     ensure_built()
     curve = CURVES[curve_name]
     zp = fx(curve_name, "circuit.zkey")
     w = orc.read_wtns(curve, fx(curve_name, "witness.wtns"))
     blind = orc.random_field(curve, FR, 11, np.random.default_rng(321))
-    want = orc.plonk_prove_plain(curve, zp, w, blind, upto=3, want_t=True)
-    got = cg.plonk_prove_plain(curve, zp, w, blind, upto=3, want_t=True)
+    want = orc.plonk_prove_plain(curve, zp, w, blind, upto=5, want_t=True)
+    got = cg.plonk_prove_plain(curve, zp, w, blind, upto=5, want_t=True)
     for key in want:
         np.testing.assert_array_equal(got[key], want[key], err_msg=key)
