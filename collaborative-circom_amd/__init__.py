@@ -463,43 +463,66 @@ def host_plonk_zkey_info(curve, path):
     return dict(zip(("n_vars", "n_public", "domain_size", "power", "n_additions", "n_constraints"), [int(x) for x in info]))
 
 
-def plonk_round1_plain(curve, zkey_path, full_witness, blind, device=0):
-    """co-plonk round 1 with the plain driver on the GPU: the three wire commitments (3, packed G1)"""
-    nq = 6 if curve == BLS12_381 else 4
-    out = np.zeros((3, 2 * nq), dtype=np.uint64)
-    _hchk(load_host().cgh_plonk_round1_plain(int(device), curve, zkey_path.encode(), _hp(np.ascontiguousarray(full_witness, dtype=np.uint64)),
-                                             _hp(np.ascontiguousarray(blind, dtype=np.uint64)), _hp(out)))
-    return out
-
-
-def plonk_round2_plain(curve, zkey_path, full_witness, blind, device=0, want_poly=False):
-    """co-plonk rounds 1 + 2 with the plain driver on the GPU: (beta, gamma, commit_z[, poly_z])"""
-    info = host_plonk_zkey_info(curve, zkey_path)
-    nq = 6 if curve == BLS12_381 else 4
-    bg = np.zeros((2, 4), dtype=np.uint64); cz = np.zeros(2 * nq, dtype=np.uint64)
-    poly = np.zeros((info["domain_size"] + 3, 4), dtype=np.uint64) if want_poly else None
-    _hchk(load_host().cgh_plonk_round2_plain(int(device), curve, zkey_path.encode(), _hp(np.ascontiguousarray(full_witness, dtype=np.uint64)),
-                                             _hp(np.ascontiguousarray(blind, dtype=np.uint64)), _hp(bg), _hp(cz), _hp(poly) if want_poly else None))
-    return (bg[0], bg[1], cz, poly) if want_poly else (bg[0], bg[1], cz)
-
-
 PLONK_COMMITS = ("a", "b", "c", "z", "t1", "t2", "t3", "wxi", "wxiw")
 PLONK_CHALLENGES = ("beta", "gamma", "alpha", "xi", "v")
 PLONK_EVALS = ("eval_a", "eval_b", "eval_c", "eval_s1", "eval_s2", "eval_zw")
 
 
-def plonk_prove_plain(curve, zkey_path, full_witness, blind, upto=5, device=0, want_t=False):
-    """co-plonk with the plain driver on the GPU through round `upto` (<= 5): dict of commitments, challenges, evaluations[, t polys]
+def _pad_blind(blind):
+    blind = np.ascontiguousarray(blind, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((11, 4), dtype=np.uint64); out[:blind.shape[0]] = blind
+    return out
+
+
+def plonk_prove_plain(curve, zkey_path, full_witness, blind, upto=5, device=0, want_t=False, want_poly_z=False):
+    """co-plonk with the plain driver on the GPU through round `upto` (<= 5): dict of commitments, challenges, evaluations[, t polys, poly_z]
     (the proof of co-plonk/src/plonk.rs = the nine commitments and six evaluations)"""
     info = host_plonk_zkey_info(curve, zkey_path)
     nq = 6 if curve == BLS12_381 else 4; n = info["domain_size"]
     commits = np.zeros((9, 2 * nq), dtype=np.uint64); ch = np.zeros((5, 4), dtype=np.uint64); ev = np.zeros((6, 4), dtype=np.uint64)
     tp = np.zeros((3 * n + 8, 4), dtype=np.uint64) if want_t else None
+    pz = np.zeros((n + 3, 4), dtype=np.uint64) if want_poly_z else None
     _hchk(load_host().cgh_plonk_prove_plain(int(device), curve, zkey_path.encode(), _hp(np.ascontiguousarray(full_witness, dtype=np.uint64)),
-                                            _hp(np.ascontiguousarray(blind, dtype=np.uint64)), int(upto), _hp(commits), _hp(ch), _hp(ev), _hp(tp) if want_t else None))
+                                            _hp(_pad_blind(blind)), int(upto), _hp(commits), _hp(ch), _hp(ev), _hp(tp) if want_t else None, _hp(pz) if want_poly_z else None))
     out = dict(zip(PLONK_COMMITS, commits)); out.update(zip(PLONK_CHALLENGES, ch)); out.update(zip(PLONK_EVALS, ev))
     if want_t: out.update(t1_poly=tp[:n + 1], t2_poly=tp[n + 1:2 * n + 2], t3_poly=tp[2 * n + 2:])
+    if want_poly_z: out["poly_z"] = pz
     return out
+
+
+def plonk_round1_plain(curve, zkey_path, full_witness, blind, device=0):
+    """the three wire commitments (3, packed G1)"""
+    r = plonk_prove_plain(curve, zkey_path, full_witness, blind, upto=1, device=device)
+    return np.stack([r["a"], r["b"], r["c"]])
+
+
+def plonk_round2_plain(curve, zkey_path, full_witness, blind, device=0, want_poly=False):
+    """rounds 1 + 2: (beta, gamma, commit_z[, poly_z])"""
+    r = plonk_prove_plain(curve, zkey_path, full_witness, blind, upto=2, device=device, want_poly_z=want_poly)
+    return (r["beta"], r["gamma"], r["z"], r["poly_z"]) if want_poly else (r["beta"], r["gamma"], r["z"])
+
+
+def plonk_prove_rep3(curve, zkey_path, pub, wit_a, wit_b, blind_a, blind_b, streams=None, upto=5, device=0):
+    """three REP3 parties (threads) on one GPU through round `upto`; returns a list of three dicts (one per party) like plonk_prove_plain"""
+    nq = 6 if curve == BLS12_381 else 4
+    commits = np.zeros((3, 9, 2 * nq), dtype=np.uint64); ch = np.zeros((3, 5, 4), dtype=np.uint64); ev = np.zeros((3, 6, 4), dtype=np.uint64)
+    lists = [wit_a, wit_b, [_pad_blind(x) for x in blind_a], [_pad_blind(x) for x in blind_b]] + ([streams] if streams is not None else [])
+    keep = [[np.ascontiguousarray(x, dtype=np.uint64) for x in lst] for lst in lists]
+    arr = lambda lst: (C.c_void_p * 3)(*[x.ctypes.data for x in lst])
+    _hchk(load_host().cgh_plonk_prove_rep3(int(device), curve, zkey_path.encode(), _hp(np.ascontiguousarray(pub, dtype=np.uint64)), arr(keep[0]), arr(keep[1]),
+                                           arr(keep[2]), arr(keep[3]), arr(keep[4]) if streams is not None else None,
+                                           C.c_size_t(keep[4][0].shape[0] if streams is not None else 0), int(upto), _hp(commits), _hp(ev), _hp(ch)))
+    out = []
+    for i in range(3):
+        dct = dict(zip(PLONK_COMMITS, commits[i])); dct.update(zip(PLONK_CHALLENGES, ch[i])); dct.update(zip(PLONK_EVALS, ev[i]))
+        out.append(dct)
+    return out
+
+
+def plonk_round1_rep3(curve, zkey_path, pub, wit_a, wit_b, blind_a, blind_b, device=0):
+    """round 1 only: (3 parties, 3 commitments, packed G1)"""
+    r = plonk_prove_rep3(curve, zkey_path, pub, wit_a, wit_b, blind_a, blind_b, streams=None, upto=1, device=device)
+    return np.stack([np.stack([p["a"], p["b"], p["c"]]) for p in r])
 
 
 def host_plonk_transcript(curve, items):
@@ -510,17 +533,6 @@ def host_plonk_transcript(curve, items):
     ptrs = (C.c_void_p * n)(*[v.ctypes.data for v in keep])
     out = np.zeros(4, dtype=np.uint64)
     _hchk(load_host().cgh_plonk_transcript(curve, kinds, ptrs, n, _hp(out)))
-    return out
-
-
-def plonk_round1_rep3(curve, zkey_path, pub, wit_a, wit_b, blind_a, blind_b, device=0):
-    """three REP3 parties (threads) on one GPU; returns (3 parties, 3 commitments, packed G1)"""
-    nq = 6 if curve == BLS12_381 else 4
-    out = np.zeros((3, 3, 2 * nq), dtype=np.uint64)
-    keep = [[np.ascontiguousarray(x, dtype=np.uint64) for x in lst] for lst in (wit_a, wit_b, blind_a, blind_b)]
-    arr = lambda lst: (C.c_void_p * 3)(*[x.ctypes.data for x in lst])
-    _hchk(load_host().cgh_plonk_round1_rep3(int(device), curve, zkey_path.encode(), _hp(np.ascontiguousarray(pub, dtype=np.uint64)),
-                                            arr(keep[0]), arr(keep[1]), arr(keep[2]), arr(keep[3]), _hp(out)))
     return out
 
 

@@ -205,10 +205,13 @@ struct Rep3Network {   // rep3/network.rs:30-64
     virtual int id() const = 0;
     virtual void send_next(const void* data, size_t bytes) = 0;
     virtual void recv_prev(void* data, size_t bytes) = 0;
+    virtual void send_prev(const void* data, size_t bytes) = 0;   // network.send(id.prev_id(), ..) (rep3.rs:746-753)
+    virtual void recv_next(void* data, size_t bytes) = 0;
 };
 struct InProcHub {
     std::mutex mu; std::condition_variable cv;
-    std::deque<Bytes> q[3];   // q[i] = messages travelling from party i to party i+1
+    std::deque<Bytes> q[3];    // q[i] = messages travelling from party i to party i+1
+    std::deque<Bytes> qb[3];   // qb[i] = messages travelling from party i to party i-1
 };
 struct InProcNetwork : Rep3Network {
     InProcHub* hub; int me;
@@ -224,6 +227,18 @@ struct InProcNetwork : Rep3Network {
         hub->cv.wait(l, [&] { return !hub->q[from].empty(); });
         Bytes m = std::move(hub->q[from].front()); hub->q[from].pop_front();
         if (m.size() != bytes) throw std::runtime_error("During execution of MPC: invalid number of bytes received");   // rep3.rs:663-668
+        memcpy(data, m.data(), bytes);
+    }
+    void send_prev(const void* data, size_t bytes) override {
+        { std::lock_guard<std::mutex> l(hub->mu); hub->qb[me].emplace_back((const uint8_t*)data, (const uint8_t*)data + bytes); }
+        hub->cv.notify_all();
+    }
+    void recv_next(void* data, size_t bytes) override {
+        const int from = (me + 1) % 3;
+        std::unique_lock<std::mutex> l(hub->mu);
+        hub->cv.wait(l, [&] { return !hub->qb[from].empty(); });
+        Bytes m = std::move(hub->qb[from].front()); hub->qb[from].pop_front();
+        if (m.size() != bytes) throw std::runtime_error("During execution of MPC: invalid number of bytes received");
         memcpy(data, m.data(), bytes);
     }
 };
@@ -498,6 +513,45 @@ public:
         CG(cg_dev_free(ctx, m1)); CG(cg_dev_free(ctx, m2));
         return out;
     }
+    // ---- vector forms of rand / mul_open_many / open_many used by co-plonk (rep3.rs:544-558,595-598,620-628,738-757)
+    int public_component() const { return mode != Mode::Rep3 ? 0 : (party() == 0 ? 0 : party() == 1 ? 1 : -1); }   // add_with_public: who holds a public addend
+    ShareVec rand_vec(size_t n) {
+        if (mode != Mode::Rep3) throw std::runtime_error("rand_vec: REP3 only");
+        if (cursor + n > rng_len) throw std::runtime_error("randomness stream exhausted");
+        ShareVec v = upload_vec(rng1 + cursor, rng2 + cursor, n); cursor += n;
+        return v;
+    }
+    // a * b opened: a public device vector (caller frees)
+    void* mul_open_vec(const ShareVec& a, const ShareVec& b) {
+        const size_t n = a.n;
+        void* out = dalloc(n * 32);
+        if (mode == Mode::Plain) { CG(cg_vec_mul_dev(ctx, curve.id, out, a.c[0], b.c[0], n)); return out; }
+        if (mode != Mode::Rep3) throw std::runtime_error("mul_open_vec: plain / REP3 only");
+        if (cursor + n > rng_len) throw std::runtime_error("randomness stream exhausted");
+        void* m1 = dalloc(n * 32); void* m2 = dalloc(n * 32);
+        CG(cg_dev_upload(ctx, m1, rng1 + cursor, n * 32)); CG(cg_dev_upload(ctx, m2, rng2 + cursor, n * 32)); cursor += n;
+        CG(cg_vec_sub_dev(ctx, curve.id, m1, m1, m2, n));
+        CG(cg_vec_rep3_mul_local_dev(ctx, curve.id, out, a.c[0], a.c[1], b.c[0], b.c[1], m1, n));
+        std::vector<Fr> mine(n), p(n), q(n);
+        CG(cg_dev_download(ctx, mine.data(), out, n * 32));
+        net->send_next(mine.data(), n * 32); net->send_prev(mine.data(), n * 32);
+        net->recv_prev(p.data(), n * 32); net->recv_next(q.data(), n * 32);
+        CG(cg_dev_upload(ctx, m1, p.data(), n * 32)); CG(cg_dev_upload(ctx, m2, q.data(), n * 32));
+        CG(cg_vec_add_dev(ctx, curve.id, out, out, m1, n)); CG(cg_vec_add_dev(ctx, curve.id, out, out, m2, n));
+        CG(cg_dev_free(ctx, m1)); CG(cg_dev_free(ctx, m2));
+        return out;
+    }
+    std::vector<Fr> open_many(const std::vector<FieldShare>& a) {
+        std::vector<Fr> out(a.size());
+        if (mode == Mode::Plain) { for (size_t i = 0; i < a.size(); i++) out[i] = a[i].c[0]; return out; }
+        if (mode != Mode::Rep3) throw std::runtime_error("open_many: plain / REP3 only");
+        std::vector<Fr> bs(a.size()), cs(a.size());
+        for (size_t i = 0; i < a.size(); i++) bs[i] = a[i].c[1];
+        net->send_next(bs.data(), bs.size() * 32); net->recv_prev(cs.data(), cs.size() * 32);
+        for (size_t i = 0; i < a.size(); i++) out[i] = fr_add(curve, fr_add(curve, a[i].c[0], a[i].c[1]), cs[i]);
+        return out;
+    }
+
     // FFTProvider (traits.rs:535-558): both share components in one launch
     void fft_in_place(ShareVec& v, const Fr& group_gen) { CG(cg_ntt_dev(ctx, curve.id, v.c, k(), v.n, group_gen.v, 0, nullptr)); }
     void ifft_in_place(ShareVec& v, const Fr& group_gen) { CG(cg_ntt_dev(ctx, curve.id, v.c, k(), v.n, group_gen.v, 1, nullptr)); }
@@ -808,381 +862,344 @@ public:
     }
 };
 
-class CoPlonkRound1 {
+// ==================================================================================================== co-plonk, all rounds, any driver
+// The five rounds (co-plonk/src/round1..5.rs) written once over share-vector operations: per-component kernels for everything
+// linear, the driver's protocols for products of two shared vectors (`mul_vec`), for `array_prod_mul` / `inv_many` (round2.rs:18-41,
+// rep3.rs:544-558) and for openings.  Plain and REP3 run the same code; values that every party reconstructs (commitments,
+// evaluations) are functions of the witness and of the opened blinding values only.
+class CoPlonk {
 public:
-    HipDriver& driver;
-    explicit CoPlonkRound1(HipDriver& d) : driver(d) {}
+    HipDriver& d; const PlonkZKey& z; const cg_bases* tau;
+    const Curve c; cg_ctx* ctx; const size_t n, N; const int k;
+    Fr zero, one, omega, omega4, w2r;
+    FieldShare b[11];
+    std::vector<Fr> pub;                       // n_public + 1 values, entry 0 forced to 0 (types.rs:107-109)
+    ShareVec buf[3], poly[3], evl[3], poly_z, eval_z, tpart[3];
+    Point commit[3], commit_z, commit_t[3], commit_wxi, commit_wxiw;
+    Fr beta, gamma, alpha, xi, v[5], ev_a, ev_b, ev_c, ev_s1, ev_s2, ev_zw;
+    std::vector<ShareVec> tmp_vecs; std::vector<void*> tmp_ptrs;
 
-    // promote_to_trivial_share (rep3/fieldshare.rs:72-78; plain: the value)
-    FieldShare trivial(const Fr& v) const {
-        FieldShare f; const Fr zero = fr_from_u64(driver.curve, 0);
-        f.c[0] = (driver.mode == Mode::Plain || driver.party() == 0) ? v : zero;
-        f.c[1] = (driver.mode == Mode::Rep3 && driver.party() == 1) ? v : zero;
-        return f;
-    }
-    // calculate_additions (round1.rs:208-238): witness || addition witnesses, so that get_witness(i) = ext[i - n_public - 1] (lib.rs:113-137)
-    ShareVec extend_witness(const PlonkZKey& z, const std::vector<Fr>& pub0, const ShareVec& wit) {
-        const Curve& c = driver.curve;
-        const size_t n_priv = z.n_vars - z.n_additions - z.n_public - 1;
-        if (wit.n != n_priv) throw std::runtime_error("witness length does not match the zkey");
-        std::vector<Fr> ext[2];
-        for (int j = 0; j < driver.k(); j++) { ext[j].resize(n_priv + z.n_additions); if (n_priv) CG(cg_dev_download(driver.ctx, ext[j].data(), wit.c[j], n_priv * 32)); }
-        size_t have = n_priv;
-        auto get = [&](size_t idx) -> FieldShare {
-            if (idx <= z.n_public) return trivial(pub0[idx]);
-            if (idx >= z.n_vars || idx - z.n_public - 1 >= have) throw std::runtime_error("Cannot index into witness " + std::to_string(idx));   // PlonkProofError::CorruptedWitness
-            FieldShare f; for (int j = 0; j < driver.k(); j++) f.c[j] = ext[j][idx - z.n_public - 1];
-            return f;
-        };
-        for (const auto& a : z.additions) {
-            FieldShare w1 = get(a.id1), w2 = get(a.id2);
-            for (int j = 0; j < driver.k(); j++) ext[j][have] = fr_add(c, fr_mul(c, a.f1, w1.c[j]), fr_mul(c, a.f2, w2.c[j]));      // mul_with_public, add
-            have++;
-        }
-        return driver.upload_vec(ext[0].data(), driver.k() == 2 ? ext[1].data() : nullptr, ext[0].size());
-    }
-    // round1.rs:118-206 + :260-312.  public_inputs = n_public + 1 values (entry 0 is overwritten by 0, types.rs:107-109);
-    // blind = b_1..b_6 as shares; polys_out (optional) receives the three blinded coefficient vectors (n + 2 each, device)
-    std::vector<Point> round1(const PlonkZKey& z, const cg_bases* p_tau, std::vector<Fr> public_inputs, const ShareVec& private_witness, const FieldShare* blind,
-                              ShareVec* polys_out = nullptr, ShareVec* buffers_out = nullptr, ShareVec* evals_out = nullptr) {
-        const Curve& c = driver.curve;
-        cg_ctx* ctx = driver.ctx;
-        const size_t n = z.domain_size, nc = z.n_constraints;
-        if (public_inputs.size() != z.n_public + 1) throw std::runtime_error("public input length does not match the zkey");
-        if (n + 2 > z.domain_size + 6) throw std::runtime_error("polynomial degree too large");
-        public_inputs[0] = fr_from_u64(c, 0);
-        ShareVec ext = z.n_additions ? extend_witness(z, public_inputs, private_witness) : private_witness;
-        void* d_pub = driver.dalloc(public_inputs.size() * 32); CG(cg_dev_upload(ctx, d_pub, public_inputs.data(), public_inputs.size() * 32));
-        // the wire buffers are gathers: one-entry CSR rows with coefficient one reuse the constraint-evaluation kernel, which already
-        // implements get_witness' public/private split with the REP3 party asymmetry
-        std::vector<uint32_t> row_ptr(nc + 1); for (size_t i = 0; i <= nc; i++) row_ptr[i] = (uint32_t)i;
-        std::vector<Fr> ones(nc, fr_from_u64(c, 1));
-        uint32_t* d_rp = (uint32_t*)driver.dalloc((nc + 1) * 4); CG(cg_dev_upload(ctx, d_rp, row_ptr.data(), (nc + 1) * 4));
-        void* d_one = driver.dalloc(std::max<size_t>(nc, 1) * 32); if (nc) CG(cg_dev_upload(ctx, d_one, ones.data(), nc * 32));
-        uint32_t* d_col = (uint32_t*)driver.dalloc(std::max<size_t>(nc, 1) * 4);
-        const Fr omega = snarkjs_roots(c).roots[z.power];                                        // types.rs:70-84
-        std::vector<PointShare> commits;
-        for (int w = 0; w < 3; w++) {
-            if (nc) CG(cg_dev_upload(ctx, d_col, z.map[w].data(), nc * 4));
-            ShareVec poly = driver.alloc_vec(n + 2);                                              // zero-filled: rows >= n_constraints stay 0
-            CG(cg_spmv_csr_dev(ctx, c.id, d_rp, d_col, d_one, nc, d_pub, (uint32_t)(z.n_public + 1), driver.party(), ext.c[0], ext.c[1], poly.c[0], poly.c[1]));
-            if (buffers_out) {                                                                    // buffer_a/b/c are read again by round 2 (round2.rs:162-166)
-                buffers_out[w] = driver.alloc_vec(n);
-                for (int j = 0; j < driver.k(); j++) CG(cg_vec_gather_strided_dev(ctx, c.id, buffers_out[w].c[j], poly.c[j], n, 0, 1));
-            }
-            CG(cg_ntt_dev(ctx, c.id, poly.c, driver.k(), n, omega.v, 1, nullptr));                // ifft over the first n entries
-            if (evals_out) {                                                                      // extended evaluations of the unblinded polynomial (round1.rs:174-177)
-                evals_out[w] = driver.alloc_vec(4 * n);
-                const Fr omega4 = snarkjs_roots(c).roots[z.power + 2];
-                for (int j = 0; j < driver.k(); j++) CG(cg_vec_gather_strided_dev(ctx, c.id, evals_out[w].c[j], poly.c[j], n, 0, 1));
-                CG(cg_ntt_dev(ctx, c.id, evals_out[w].c, driver.k(), 4 * n, omega4.v, 0, nullptr));
-            }
-            const FieldShare &b_hi = blind[2 * w], &b_lo = blind[2 * w + 1];                      // blind_coefficients, lib.rs:140-158
-            for (int j = 0; j < driver.k(); j++) {
-                Fr head[2]; CG(cg_dev_download(ctx, head, poly.c[j], 64));
-                head[0] = fr_sub(c, head[0], b_lo.c[j]); head[1] = fr_sub(c, head[1], b_hi.c[j]);
-                CG(cg_dev_upload(ctx, poly.c[j], head, 64));
-                Fr tail[2] = {b_lo.c[j], b_hi.c[j]};
-                CG(cg_dev_upload(ctx, (uint8_t*)poly.c[j] + n * 32, tail, 64));
-            }
-            commits.push_back(driver.msm_public_points(p_tau, CG_G1, 0, n + 2, poly));            // round1.rs:276-290
-            if (polys_out) polys_out[w] = poly; else driver.free_vec(poly);
-        }
-        std::vector<Point> opened;                                                                // open_point_many, round1.rs:292
-        for (auto& cm : commits) opened.push_back(driver.open_point(cm));
-        CG(cg_dev_free(ctx, d_pub)); CG(cg_dev_free(ctx, d_rp)); CG(cg_dev_free(ctx, d_one)); CG(cg_dev_free(ctx, d_col));
-        if (z.n_additions) driver.free_vec(ext);
-        return opened;
-    }
-};
-
-// Round 2 (co-plonk/src/round2.rs:146-298) for the single-component drivers: challenges from the transcript, the grand product z
-// entirely as device vector operations, its blinded coefficients and [z]_1.
-class CoPlonkRound2 {
-public:
-    HipDriver& driver;
-    explicit CoPlonkRound2(HipDriver& d) : driver(d) {}
-    struct Result { Fr beta, gamma; Point commit_z; };
-
-    Result round2(const PlonkZKey& z, const cg_bases* p_tau, const std::vector<Fr>& public_inputs /* n_public values */, const std::vector<Point>& round1_commits,
-                  const ShareVec* buffers, const FieldShare* blind /* b[6..9) used */, ShareVec* poly_z_out = nullptr, ShareVec* eval_z_out = nullptr) {
-        if (driver.mode != Mode::Plain) throw std::runtime_error("co-plonk round 2 is implemented for the plain driver (array_prod_mul / inv_many / mul_many over shares: next)");
-        const Curve& c = driver.curve; cg_ctx* ctx = driver.ctx;
-        const size_t n = z.domain_size;
-        Result res;
-        {   // round2.rs:243-263
-            PlonkTranscript t(c);
-            for (int i = 0; i < 8; i++) t.add_point(z.vk_g1.data() + i * c.aff(CG_G1));
-            for (const Fr& v : public_inputs) t.add_scalar(v);
-            for (const Point& cm : round1_commits) { Bytes a = pt_to_affine(c, cm); t.add_point(a.data()); }
-            res.beta = t.get_challenge();
-            PlonkTranscript t2(c); t2.add_scalar(res.beta);
-            res.gamma = t2.get_challenge();
-        }
-        const Fr omega = snarkjs_roots(c).roots[z.power], one = fr_from_u64(c, 1);
-        auto dv = [&]() { return driver.dalloc(n * 32); };
-        void* betaw = dv();                                                                       // beta * omega^i
-        CG(cg_vec_fill_dev(ctx, c.id, betaw, n, res.beta.v));
-        CG(cg_vec_distribute_powers_dev(ctx, c.id, betaw, n, omega.v, one.v));
-        void* num = dv(); void* den = dv(); void* t1 = dv(); void* sig = dv();
-        void* d_sigma = driver.dalloc(4 * n * 32);
-        const Fr k[3] = {one, z.k1, z.k2};
-        for (int w = 0; w < 3; w++) {                                                             // :162-210
-            CG(cg_vec_affine_dev(ctx, c.id, t1, betaw, n, k[w].v, res.gamma.v));                  // k_w * beta * omega^i + gamma
-            CG(cg_vec_add_dev(ctx, c.id, t1, t1, buffers[w].c[0], n));                            // + wire value
-            if (w == 0) CG(cg_vec_gather_strided_dev(ctx, c.id, num, t1, n, 0, 1)); else CG(cg_vec_mul_dev(ctx, c.id, num, num, t1, n));
-            CG(cg_dev_upload(ctx, d_sigma, z.sigma_eval[w].data(), 4 * n * 32));
-            CG(cg_vec_gather_strided_dev(ctx, c.id, sig, d_sigma, n, 0, 4));                      // sigma_w evaluated on the small domain
-            CG(cg_vec_affine_dev(ctx, c.id, t1, sig, n, res.beta.v, res.gamma.v));
-            CG(cg_vec_add_dev(ctx, c.id, t1, t1, buffers[w].c[0], n));
-            if (w == 0) CG(cg_vec_gather_strided_dev(ctx, c.id, den, t1, n, 0, 1)); else CG(cg_vec_mul_dev(ctx, c.id, den, den, t1, n));
-        }
-        CG(cg_vec_prefix_prod_dev(ctx, c.id, num, num, n));                                       // array_prod_mul (:18-41) on one component
-        CG(cg_vec_prefix_prod_dev(ctx, c.id, den, den, n));
-        CG(cg_vec_inverse_dev(ctx, c.id, den, den, n));                                           // inv_many (:228)
-        CG(cg_vec_mul_dev(ctx, c.id, num, num, den, n));
-        ShareVec poly = driver.alloc_vec(n + 3);
-        if (n > 1) CG(cg_vec_gather_strided_dev(ctx, c.id, (uint8_t*)poly.c[0] + 32, num, n - 1, 0, 1));   // rotate_right(1) (:231)
-        CG(cg_vec_gather_strided_dev(ctx, c.id, poly.c[0], num, 1, n - 1, 1));
-        CG(cg_ntt_dev(ctx, c.id, poly.c, 1, n, omega.v, 1, nullptr));                             // :235
-        if (eval_z_out) {                                                                         // :238
-            *eval_z_out = driver.alloc_vec(4 * n);
-            CG(cg_vec_gather_strided_dev(ctx, c.id, eval_z_out->c[0], poly.c[0], n, 0, 1));
-            CG(cg_ntt_dev(ctx, c.id, eval_z_out->c, 1, 4 * n, snarkjs_roots(c).roots[z.power + 2].v, 0, nullptr));
-        }
-        Fr head[3]; CG(cg_dev_download(ctx, head, poly.c[0], 96));                                // blind_coefficients with b[6..9) (lib.rs:140-158)
-        const Fr b6 = blind[6].c[0], b7 = blind[7].c[0], b8 = blind[8].c[0];
-        head[0] = fr_sub(c, head[0], b8); head[1] = fr_sub(c, head[1], b7); head[2] = fr_sub(c, head[2], b6);
-        CG(cg_dev_upload(ctx, poly.c[0], head, 96));
-        Fr tail[3] = {b8, b7, b6};
-        CG(cg_dev_upload(ctx, (uint8_t*)poly.c[0] + n * 32, tail, 96));
-        if (n + 3 > z.domain_size + 6) throw std::runtime_error("polynomial degree too large");
-        res.commit_z = driver.open_point(driver.msm_public_points(p_tau, CG_G1, 0, n + 3, poly));   // :268-275
-        for (void* p : {betaw, num, den, t1, sig, d_sigma}) CG(cg_dev_free(ctx, p));
-        if (poly_z_out) *poly_z_out = poly; else driver.free_vec(poly);
-        return res;
-    }
-};
-
-// Round 3 (co-plonk/src/round3.rs:234-527) for the plain driver: the quotient polynomial on the 4n-point domain as device vector
-// kernels (its blinding-dependent part kept apart exactly as the reference does), two size-4n iNTTs, the division by X^n - 1 as three
-// block subtractions, the split into t1 | t2 | t3 and their commitments.
-class CoPlonkRound3 {
-public:
-    HipDriver& driver;
-    explicit CoPlonkRound3(HipDriver& d) : driver(d) {}
-    struct Result { Fr alpha; Point commit_t[3]; };
-
-    Result round3(const PlonkZKey& z, const cg_bases* p_tau, const Fr& beta, const Fr& gamma, const Point& commit_z, const ShareVec* buffers,
-                  const ShareVec* evals, const ShareVec& eval_z, const FieldShare* blind, ShareVec* t_out = nullptr) {
-        if (driver.mode != Mode::Plain) throw std::runtime_error("co-plonk round 3 is implemented for the plain driver");
-        if (z.lagrange_eval.empty()) throw std::runtime_error("round 3 needs at least one public input (lagrange[0])");
-        const Curve& c = driver.curve; cg_ctx* ctx = driver.ctx;
-        const size_t n = z.domain_size, N = 4 * n;
-        Result res;
-        { PlonkTranscript t(c); t.add_scalar(beta); t.add_scalar(gamma); Bytes a = pt_to_affine(c, commit_z); t.add_point(a.data()); res.alpha = t.get_challenge(); }   // :498-503
-        const Fr alpha = res.alpha, alpha2 = fr_mul(c, alpha, alpha);
+    CoPlonk(HipDriver& drv, const PlonkZKey& zk, const cg_bases* p_tau, const std::vector<Fr>& public_inputs, const FieldShare* blind)
+        : d(drv), z(zk), tau(p_tau), c(drv.curve), ctx(drv.ctx), n(zk.domain_size), N(4 * zk.domain_size), k(drv.k()), pub(public_inputs) {
+        if (d.mode == Mode::Shamir) throw std::runtime_error("co-plonk over Shamir shares is not implemented yet (plain and REP3 are)");
+        if (pub.size() != z.n_public + 1) throw std::runtime_error("public input length does not match the zkey");
+        zero = fr_from_u64(c, 0); one = fr_from_u64(c, 1);
+        pub[0] = zero;
         const SnarkjsRoots rt = snarkjs_roots(c);
-        const Fr omega = rt.roots[z.power], omega4 = rt.roots[z.power + 2], w2r = rt.roots[2];
-        const Fr zero = fr_from_u64(c, 0), one = fr_from_u64(c, 1), two = fr_from_u64(c, 2);
-        auto neg = [&](const Fr& v) { return fr_sub(c, zero, v); };
-        const Fr Z1[4] = {zero, fr_add(c, neg(one), w2r), neg(two), fr_sub(c, neg(one), w2r)};                            // get_z1..3 (:203-232)
-        const Fr m2w = fr_mul(c, neg(two), w2r);
-        const Fr Z2[4] = {zero, m2w, fr_mul(c, two, two), neg(m2w)};
-        const Fr tw = fr_mul(c, two, w2r);
-        const Fr Z3[4] = {zero, fr_add(c, two, tw), neg(fr_mul(c, fr_mul(c, two, two), two)), fr_sub(c, two, tw)};
-        std::vector<void*> live;
-        auto V = [&]() { void* p = driver.dalloc(N * 32); live.push_back(p); return p; };
-        auto mul = [&](void* o, const void* a, const void* b) { CG(cg_vec_mul_dev(ctx, c.id, o, a, b, N)); };
-        auto add = [&](void* o, const void* a, const void* b) { CG(cg_vec_add_dev(ctx, c.id, o, a, b, N)); };
-        auto sub = [&](void* o, const void* a, const void* b) { CG(cg_vec_sub_dev(ctx, c.id, o, a, b, N)); };
-        auto aff = [&](void* o, const void* a, const Fr& k, const Fr& d) { CG(cg_vec_affine_dev(ctx, c.id, o, a, N, k.v, d.v)); };
-        auto upload = [&](const std::vector<Fr>& h) { void* p = V(); CG(cg_dev_upload(ctx, p, h.data(), N * 32)); return p; };
-        auto pattern = [&](const Fr* zz) { std::vector<Fr> h(N); for (size_t i = 0; i < N; i++) h[i] = zz[i & 3]; return upload(h); };
-        const void *a = evals[0].c[0], *b = evals[1].c[0], *cc = evals[2].c[0], *ez = eval_z.c[0];
-        void* z1p = pattern(Z1); void* z2p = pattern(Z2); void* z3p = pattern(Z3);
-        const FieldShare* B = blind;
-        // powers of the 4n-th root and the blinding polynomials evaluated on them (:246-256, :307-322)
-        void* pw = V(); CG(cg_vec_fill_dev(ctx, c.id, pw, N, one.v)); CG(cg_vec_distribute_powers_dev(ctx, c.id, pw, N, omega4.v, one.v));
-        void* ap = V(); aff(ap, pw, B[0].c[0], B[1].c[0]);
-        void* bp = V(); aff(bp, pw, B[2].c[0], B[3].c[0]);
-        void* cp = V(); aff(cp, pw, B[4].c[0], B[5].c[0]);
-        void* t0 = V(); void* t1v = V();
-        void* zp = V(); mul(t0, pw, pw); aff(zp, t0, B[6].c[0], B[8].c[0]); aff(t0, pw, B[7].c[0], zero); add(zp, zp, t0);
-        void* zwp = V(); aff(t1v, pw, omega, zero); mul(t0, t1v, t1v); aff(zwp, t0, B[6].c[0], B[8].c[0]); aff(t0, t1v, B[7].c[0], zero); add(zwp, zwp, t0);
-        void* zw = V();                                                                                                  // z(X omega) = eval_z rotated by 4 (:324-327)
-        CG(cg_vec_gather_strided_dev(ctx, c.id, zw, (const uint8_t*)ez + 4 * 32, N - 4, 0, 1));
-        CG(cg_vec_gather_strided_dev(ctx, c.id, (uint8_t*)zw + (N - 4) * 32, ez, 4, 0, 1));
-        // gate constraint e1 and its blinding part e1z (:333-368)
-        void* a_b = V(); mul(a_b, a, b);
-        void* a_bp = V(); mul(a_bp, a, bp);
-        void* ap_b = V(); mul(ap_b, b, ap);
-        void* ap_bp = V(); mul(ap_bp, ap, bp);
-        void* a0 = V(); add(a0, a_bp, ap_b); mul(t0, z1p, ap_bp); add(a0, a0, t0);
-        void* q[5]; for (int k = 0; k < 5; k++) q[k] = upload(z.q_eval[k]);
-        void* e1 = V(); mul(e1, q[0], a_b); mul(t0, q[1], a); add(e1, e1, t0); mul(t0, q[2], b); add(e1, e1, t0); mul(t0, q[3], cc); add(e1, e1, t0); add(e1, e1, q[4]);
-        void* e1z = V(); mul(e1z, q[0], a0); mul(t0, q[1], ap); add(e1z, e1z, t0); mul(t0, q[2], bp); add(e1z, e1z, t0); mul(t0, q[3], cp); add(e1z, e1z, t0);
-        std::vector<Fr> a_pub(z.lagrange_eval.size());                                                                  // public-input polynomial (:352-358)
-        CG(cg_dev_download(ctx, a_pub.data(), buffers[0].c[0], a_pub.size() * 32));
-        void* l1 = nullptr;
-        for (size_t j = 0; j < z.lagrange_eval.size(); j++) {
-            void* lj = upload(z.lagrange_eval[j]); if (j == 0) l1 = lj;
-            aff(t0, lj, neg(a_pub[j]), zero); add(e1, e1, t0);
-        }
-        // permutation constraints (:370-418): products of four linear factors, each with its blinding companion
-        auto mul4 = [&](const void* A, const void* Bv, const void* Cv, const void* D, const void* Dp, void* r, void* rz) {   // mul4vec + mul4vec_post (:17-72)
-            void* AB = V(); mul(AB, A, Bv);
-            void* S1 = V(); mul(S1, A, bp); mul(t0, ap, Bv); add(S1, S1, t0);                  // ABp + ApB
-            void* CD = V(); mul(CD, Cv, D);
-            void* S2 = V(); mul(S2, Cv, Dp); mul(t0, cp, D); add(S2, S2, t0);                  // CDp + CpD
-            void* CpDp = V(); mul(CpDp, cp, Dp);
-            mul(r, AB, CD);
-            mul(rz, S1, CD); mul(t0, AB, S2); add(rz, rz, t0);                                 // r0
-            void* r1 = V(); mul(r1, ap_bp, CD); mul(t0, S1, S2); add(r1, r1, t0); mul(t0, AB, CpDp); add(r1, r1, t0);
-            mul(t0, z1p, r1); add(rz, rz, t0);
-            mul(r1, S1, CpDp); mul(t0, ap_bp, S2); add(r1, r1, t0);                            // r2 (reusing the buffer)
-            mul(t0, z2p, r1); add(rz, rz, t0);
-            mul(r1, ap_bp, CpDp);                                                              // r3
-            mul(t0, z3p, r1); add(rz, rz, t0);
-        };
-        void *e2 = V(), *e2z = V(), *e3 = V(), *e3z = V();
-        {
-            void *fa = V(), *fb = V(), *fc = V();
-            aff(fa, pw, beta, gamma); add(fa, fa, a);
-            aff(fb, pw, fr_mul(c, beta, z.k1), gamma); add(fb, fb, b);
-            aff(fc, pw, fr_mul(c, beta, z.k2), gamma); add(fc, fc, cc);
-            mul4(fa, fb, fc, ez, zp, e2, e2z);
-            void* sg[3]; for (int k = 0; k < 3; k++) sg[k] = upload(z.sigma_eval[k]);
-            aff(fa, sg[0], beta, gamma); add(fa, fa, a);
-            aff(fb, sg[1], beta, gamma); add(fb, fb, b);
-            aff(fc, sg[2], beta, gamma); add(fc, fc, cc);
-            mul4(fa, fb, fc, zw, zwp, e3, e3z);
-        }
-        // t = e1 + alpha (e2 - e3) + alpha^2 (z - 1) L1 ; tz likewise with the blinding parts (:420-441)
-        ShareVec T; T.n = N; T.c[0] = driver.dalloc(N * 32);
-        sub(t0, e2, e3); aff(t0, t0, alpha, zero); add(T.c[0], e1, t0);
-        aff(t0, ez, alpha2, neg(alpha2)); mul(t0, t0, l1); add(T.c[0], T.c[0], t0);
-        ShareVec TZ; TZ.n = N; TZ.c[0] = driver.dalloc(N * 32);
-        sub(t0, e2z, e3z); aff(t0, t0, alpha, zero); add(TZ.c[0], e1z, t0);
-        aff(t0, zp, alpha2, zero); mul(t0, t0, l1); add(TZ.c[0], TZ.c[0], t0);
-        CG(cg_ntt_dev(ctx, c.id, T.c, 1, N, omega4.v, 1, nullptr));                            // :442
-        uint8_t* tb = (uint8_t*)T.c[0];
-        CG(cg_vec_affine_dev(ctx, c.id, tb, tb, n, neg(one).v, nullptr));                     // neg_vec_in_place_limit (:443)
-        for (int blk = 1; blk < 4; blk++) CG(cg_vec_sub_dev(ctx, c.id, tb + blk * n * 32, tb + (blk - 1) * n * 32, tb + blk * n * 32, n));   // :445-450
-        CG(cg_ntt_dev(ctx, c.id, TZ.c, 1, N, omega4.v, 1, nullptr));
-        add(T.c[0], T.c[0], TZ.c[0]);                                                          // :453
-        // split (:455-470)
-        ShareVec parts[3];
-        const size_t len[3] = {n + 1, n + 1, n + 6};
-        for (int k = 0; k < 3; k++) {
-            parts[k] = driver.alloc_vec(len[k]);
-            CG(cg_vec_gather_strided_dev(ctx, c.id, parts[k].c[0], tb + (size_t)k * n * 32, k == 2 ? n + 6 : n, 0, 1));
-        }
-        const Fr b9 = B[9].c[0], b10 = B[10].c[0];
-        CG(cg_dev_upload(ctx, (uint8_t*)parts[0].c[0] + n * 32, b9.v, 32));
-        Fr h; CG(cg_dev_download(ctx, h.v, parts[1].c[0], 32)); h = fr_sub(c, h, b9); CG(cg_dev_upload(ctx, parts[1].c[0], h.v, 32));
-        CG(cg_dev_upload(ctx, (uint8_t*)parts[1].c[0] + n * 32, b10.v, 32));
-        CG(cg_dev_download(ctx, h.v, parts[2].c[0], 32)); h = fr_sub(c, h, b10); CG(cg_dev_upload(ctx, parts[2].c[0], h.v, 32));
-        for (int k = 0; k < 3; k++) {
-            if (len[k] > z.domain_size + 6) throw std::runtime_error("polynomial degree too large");
-            res.commit_t[k] = driver.open_point(driver.msm_public_points(p_tau, CG_G1, 0, len[k], parts[k]));   // :507-522
-            if (t_out) t_out[k] = parts[k]; else driver.free_vec(parts[k]);
-        }
-        for (void* p : live) CG(cg_dev_free(ctx, p));
-        driver.free_vec(T); driver.free_vec(TZ);
-        return res;
+        omega = rt.roots[z.power]; omega4 = rt.roots[z.power + 2]; w2r = rt.roots[2];
+        for (int i = 0; i < 11; i++) b[i] = blind[i];
     }
-};
-
-// Rounds 4 and 5 (co-plonk/src/round4.rs:115-160, round5.rs:97-365) for the plain driver.  Both rounds are linear in the shared
-// polynomials; the two non-pointwise steps run as scans on the device: evaluation at a point = last entry of prefix_sum(c_i x^i),
-// division by (X - beta) = the recurrence y_i = (y_{i-1} - q_i) / beta, i.e. y_i = p^i * prefix_sum(-p q_j p^-j) with p = 1/beta.
-class CoPlonkRound45 {
-public:
-    HipDriver& driver;
-    explicit CoPlonkRound45(HipDriver& d) : driver(d) {}
-    struct Result { Fr xi, v0, eval_a, eval_b, eval_c, eval_s1, eval_s2, eval_zw; Point commit_wxi, commit_wxiw; };
-
-    Fr eval_poly(const void* d_poly, size_t len, const Fr& x) {                      // evaluate_poly_public (plain.rs) as a scan
-        const Curve& c = driver.curve; cg_ctx* ctx = driver.ctx;
-        const Fr one = fr_from_u64(c, 1);
-        void* t = driver.dalloc(len * 32);
+    ~CoPlonk() {
+        release_tmp();
+        for (ShareVec* sv : {&buf[0], &buf[1], &buf[2], &poly[0], &poly[1], &poly[2], &evl[0], &evl[1], &evl[2], &poly_z, &eval_z, &tpart[0], &tpart[1], &tpart[2]}) d.free_vec(*sv);
+    }
+    // ---- share-vector helpers ------------------------------------------------------------------------------------------------
+    Fr neg(const Fr& v) const { return fr_sub(c, zero, v); }
+    Fr M(const Fr& a, const Fr& x) const { return fr_mul(c, a, x); }
+    Fr A(const Fr& a, const Fr& x) const { return fr_add(c, a, x); }
+    static uint8_t* at(const ShareVec& s, int j, size_t off = 0) { return (uint8_t*)s.c[j] + off * 32; }
+    ShareVec T(size_t len) { ShareVec v = d.alloc_vec(len); tmp_vecs.push_back(v); return v; }          // zeroed temporary, freed by release_tmp
+    ShareVec keep(ShareVec v) { tmp_vecs.push_back(v); return v; }
+    void* Tp(size_t len) { void* p = d.dalloc(len * 32); tmp_ptrs.push_back(p); return p; }
+    void* upload(const std::vector<Fr>& h) { void* p = Tp(h.size()); CG(cg_dev_upload(ctx, p, h.data(), h.size() * 32)); return p; }
+    void release_tmp() { for (auto& v : tmp_vecs) d.free_vec(v); tmp_vecs.clear(); for (void* p : tmp_ptrs) CG(cg_dev_free(ctx, p)); tmp_ptrs.clear(); }
+    static ShareVec view(const ShareVec& s, size_t off, size_t len) { ShareVec v; v.n = len; for (int j = 0; j < 2; j++) v.c[j] = s.c[j] ? (uint8_t*)s.c[j] + off * 32 : nullptr; return v; }
+    void copy(const ShareVec& o, const ShareVec& a, size_t len) { for (int j = 0; j < k; j++) CG(cg_vec_gather_strided_dev(ctx, c.id, o.c[j], a.c[j], len, 0, 1)); }
+    void add(const ShareVec& o, const ShareVec& a, const ShareVec& x, size_t len) { for (int j = 0; j < k; j++) CG(cg_vec_add_dev(ctx, c.id, o.c[j], a.c[j], x.c[j], len)); }
+    void sub(const ShareVec& o, const ShareVec& a, const ShareVec& x, size_t len) { for (int j = 0; j < k; j++) CG(cg_vec_sub_dev(ctx, c.id, o.c[j], a.c[j], x.c[j], len)); }
+    void scale(const ShareVec& o, const ShareVec& a, const Fr& f, size_t len) { for (int j = 0; j < k; j++) CG(cg_vec_affine_dev(ctx, c.id, o.c[j], a.c[j], len, f.v, nullptr)); }   // mul_with_public
+    void mulpub(const ShareVec& o, const ShareVec& a, const void* pv, size_t len) { for (int j = 0; j < k; j++) CG(cg_vec_mul_dev(ctx, c.id, o.c[j], a.c[j], pv, len)); }              // by a public vector
+    void axpy(const ShareVec& o, const ShareVec& a, const Fr& f, size_t len) { ShareVec t = T(len); scale(t, a, f, len); add(o, o, t, len); }                                           // o += f * a
+    void addpub_vec(const ShareVec& o, const ShareVec& a, const void* pv, size_t len) {                                               // add_with_public, element-wise
+        const int pc = d.public_component();
+        for (int j = 0; j < k; j++) { if (j == pc) CG(cg_vec_add_dev(ctx, c.id, o.c[j], a.c[j], pv, len)); else if (o.c[j] != a.c[j]) CG(cg_vec_gather_strided_dev(ctx, c.id, o.c[j], a.c[j], len, 0, 1)); }
+    }
+    void addpub_scalar(const ShareVec& o, const ShareVec& a, const Fr& f, size_t len) {
+        const int pc = d.public_component();
+        for (int j = 0; j < k; j++) { if (j == pc) CG(cg_vec_affine_dev(ctx, c.id, o.c[j], a.c[j], len, one.v, f.v)); else if (o.c[j] != a.c[j]) CG(cg_vec_gather_strided_dev(ctx, c.id, o.c[j], a.c[j], len, 0, 1)); }
+    }
+    void axpy_pub(const ShareVec& o, const void* pv, const Fr& f, size_t len) {                                                       // o += f * (public vector)
+        const int pc = d.public_component(); if (pc < 0) return;
+        void* t = Tp(len); CG(cg_vec_affine_dev(ctx, c.id, t, pv, len, f.v, nullptr)); CG(cg_vec_add_dev(ctx, c.id, o.c[pc], o.c[pc], t, len));
+    }
+    void affine_share(const ShareVec& o, const void* pv, const FieldShare& kk, const FieldShare& dd, size_t len) {                    // o = kk * (public vector) + dd, share-valued kk, dd
+        for (int j = 0; j < k; j++) CG(cg_vec_affine_dev(ctx, c.id, o.c[j], pv, len, kk.c[j].v, dd.c[j].v));
+    }
+    FieldShare get(const ShareVec& s, size_t i) { FieldShare f; f.c[0] = f.c[1] = zero; for (int j = 0; j < k; j++) CG(cg_dev_download(ctx, f.c[j].v, at(s, j, i), 32)); return f; }
+    void set(const ShareVec& s, size_t i, const FieldShare& f) { for (int j = 0; j < k; j++) CG(cg_dev_upload(ctx, at(s, j, i), f.c[j].v, 32)); }
+    FieldShare fs_sub(const FieldShare& a, const FieldShare& x) const { FieldShare r; for (int j = 0; j < 2; j++) r.c[j] = fr_sub(c, a.c[j], x.c[j]); return r; }
+    FieldShare fs_addpub(FieldShare a, const Fr& f) const { const int pc = d.public_component(); if (pc >= 0) a.c[pc] = fr_add(c, a.c[pc], f); return a; }
+    ShareVec mul(const ShareVec& a, const ShareVec& x, size_t len) { ShareVec av = view(a, 0, len), xv = view(x, 0, len); return keep(d.mul_vec(av, xv)); }                // mul_vec / mul_many
+    Point commit_open(const ShareVec& p, size_t len) {
+        if (len > z.domain_size + 6) throw std::runtime_error("polynomial degree too large");
+        return d.open_point(d.msm_public_points(tau, CG_G1, 0, len, p));
+    }
+    void ntt(const ShareVec& s, size_t len, const Fr& g, bool inverse) { void* ptrs[2] = {s.c[0], s.c[1]}; CG(cg_ntt_dev(ctx, c.id, ptrs, k, len, g.v, inverse ? 1 : 0, nullptr)); }
+    // inv_many (rep3.rs:544-558 / plain): element-wise inverse of a shared vector
+    ShareVec inv_many(const ShareVec& a, size_t len) {
+        ShareVec out = T(len);
+        if (d.mode == Mode::Plain) { CG(cg_vec_inverse_dev(ctx, c.id, out.c[0], a.c[0], len)); return out; }
+        ShareVec r = keep(d.rand_vec(len));
+        void* y = d.mul_open_vec(view(a, 0, len), r); tmp_ptrs.push_back(y);
+        CG(cg_vec_inverse_dev(ctx, c.id, y, y, len));                                 // (a zero would make the reference fail with "cannot compute inverse of zero")
+        mulpub(out, r, y, len);
+        return out;
+    }
+    // array_prod_mul (round2.rs:18-41): shared prefix products in a constant number of rounds
+    ShareVec array_prod_mul(const ShareVec& inp, size_t len) {
+        if (d.mode == Mode::Plain) { ShareVec out = T(len); CG(cg_vec_prefix_prod_dev(ctx, c.id, out.c[0], inp.c[0], len)); return out; }
+        ShareVec r = keep(d.rand_vec(len + 1));
+        ShareVec r_inv = inv_many(r, len + 1);
+        ShareVec r_inv0 = T(len);
+        const FieldShare first = get(r_inv, 0);
+        for (int j = 0; j < k; j++) CG(cg_vec_fill_dev(ctx, c.id, r_inv0.c[j], len, first.c[j].v));
+        ShareVec unblind = mul(r_inv0, view(r, 1, len), len);
+        ShareVec m = mul(view(r, 0, len), inp, len);
+        void* open = d.mul_open_vec(m, view(r_inv, 1, len)); tmp_ptrs.push_back(open);
+        CG(cg_vec_prefix_prod_dev(ctx, c.id, open, open, len));
+        mulpub(unblind, unblind, open, len);
+        return unblind;
+    }
+    Fr eval_pub_poly(const void* d_poly, size_t len, const Fr& x) {                    // Horner of a public polynomial as a scan
+        void* t = Tp(len);
         CG(cg_vec_gather_strided_dev(ctx, c.id, t, d_poly, len, 0, 1));
         CG(cg_vec_distribute_powers_dev(ctx, c.id, t, len, x.v, one.v));
         CG(cg_vec_prefix_sum_dev(ctx, c.id, t, t, len));
         Fr r; CG(cg_dev_download(ctx, r.v, (const uint8_t*)t + (len - 1) * 32, 32));
-        CG(cg_dev_free(ctx, t));
         return r;
     }
-    void div_by_zerofier1(void* d_poly, size_t len, const Fr& beta_) {               // round5.rs:97-115 with n = 1 (the caller drops the last entry)
-        const Curve& c = driver.curve; cg_ctx* ctx = driver.ctx;
-        const Fr one = fr_from_u64(c, 1), zero = fr_from_u64(c, 0), p = fr_inv(c, beta_);
-        CG(cg_vec_affine_dev(ctx, c.id, d_poly, d_poly, len, fr_sub(c, zero, p).v, nullptr));
-        CG(cg_vec_distribute_powers_dev(ctx, c.id, d_poly, len, beta_.v, one.v));
-        CG(cg_vec_prefix_sum_dev(ctx, c.id, d_poly, d_poly, len));
-        CG(cg_vec_distribute_powers_dev(ctx, c.id, d_poly, len, p.v, one.v));
+    FieldShare eval_share_poly(const ShareVec& p, size_t len, const Fr& x) {           // evaluate_poly_public (rep3.rs:923-931)
+        FieldShare f; f.c[0] = f.c[1] = zero;
+        for (int j = 0; j < k; j++) f.c[j] = eval_pub_poly(p.c[j], len, x);
+        return f;
     }
-    Result run(const PlonkZKey& z, const cg_bases* p_tau, const std::vector<Fr>& public_inputs /* n_public values */, const Fr& beta, const Fr& gamma, const Fr& alpha,
-               const Point* commit_t, const ShareVec* polys /* a, b, c: n + 2 */, const ShareVec& poly_z /* n + 3 */, const ShareVec* t_parts /* n+1, n+1, n+6 */) {
-        if (driver.mode != Mode::Plain) throw std::runtime_error("co-plonk rounds 4/5 are implemented for the plain driver");
-        const Curve& c = driver.curve; cg_ctx* ctx = driver.ctx;
-        const size_t n = z.domain_size, len = n + 6;
-        const Fr zero = fr_from_u64(c, 0), one = fr_from_u64(c, 1);
-        auto neg = [&](const Fr& v) { return fr_sub(c, zero, v); };
-        auto M = [&](const Fr& a, const Fr& b) { return fr_mul(c, a, b); };
-        auto A = [&](const Fr& a, const Fr& b) { return fr_add(c, a, b); };
-        const Fr omega = snarkjs_roots(c).roots[z.power];
-        Result r;
-        { PlonkTranscript t(c); t.add_scalar(alpha); for (int k = 0; k < 3; k++) { Bytes a = pt_to_affine(c, commit_t[k]); t.add_point(a.data()); } r.xi = t.get_challenge(); }   // round4.rs:118-124
-        const Fr xi = r.xi, xiw = M(xi, omega);
-        r.eval_a = eval_poly(polys[0].c[0], n + 2, xi); r.eval_b = eval_poly(polys[1].c[0], n + 2, xi); r.eval_c = eval_poly(polys[2].c[0], n + 2, xi);
-        r.eval_zw = eval_poly(poly_z.c[0], n + 3, xiw);
-        auto up = [&](const std::vector<Fr>& h) { void* p = driver.dalloc(h.size() * 32); CG(cg_dev_upload(ctx, p, h.data(), h.size() * 32)); return p; };
-        void* s_co[3]; for (int k = 0; k < 3; k++) s_co[k] = up(z.sigma_coef[k]);
-        r.eval_s1 = eval_poly(s_co[0], n, xi); r.eval_s2 = eval_poly(s_co[1], n, xi);
-        Fr v[5];
-        { PlonkTranscript t(c); const Fr* items[7] = {&xi, &r.eval_a, &r.eval_b, &r.eval_c, &r.eval_s1, &r.eval_s2, &r.eval_zw}; for (const Fr* e : items) t.add_scalar(*e);   // round5.rs:338-350
-          v[0] = t.get_challenge(); for (int i = 1; i < 5; i++) v[i] = M(v[i - 1], v[0]); }
-        r.v0 = v[0];
-        // compute_r (:143-260)
-        Fr xin = xi; for (size_t i = 0; i < z.power; i++) xin = M(xin, xin);
+    void div_by_zerofier1(const ShareVec& p, size_t len, const Fr& point) {             // round5.rs:97-115 with n = 1; the caller drops the last entry
+        const Fr pinv = fr_inv(c, point);
+        for (int j = 0; j < k; j++) {
+            CG(cg_vec_affine_dev(ctx, c.id, p.c[j], p.c[j], len, neg(pinv).v, nullptr));
+            CG(cg_vec_distribute_powers_dev(ctx, c.id, p.c[j], len, point.v, one.v));
+            CG(cg_vec_prefix_sum_dev(ctx, c.id, p.c[j], p.c[j], len));
+            CG(cg_vec_distribute_powers_dev(ctx, c.id, p.c[j], len, pinv.v, one.v));
+        }
+    }
+    void transcript_point(PlonkTranscript& t, const Point& p) { Bytes a = pt_to_affine(c, p); t.add_point(a.data()); }
+
+    // ---- round 1 (round1.rs:118-312) ---------------------------------------------------------------------------------------------
+    FieldShare trivial(const Fr& v) const { FieldShare f; f.c[0] = f.c[1] = zero; const int pc = d.public_component(); if (pc >= 0) f.c[pc] = v; return f; }
+    ShareVec extend_witness(const ShareVec& wit) {                                       // calculate_additions (:208-238)
+        const size_t n_priv = z.n_vars - z.n_additions - z.n_public - 1;
+        std::vector<Fr> ext[2];
+        for (int j = 0; j < k; j++) { ext[j].resize(n_priv + z.n_additions); if (n_priv) CG(cg_dev_download(ctx, ext[j].data(), wit.c[j], n_priv * 32)); }
+        size_t have = n_priv;
+        auto getw = [&](size_t idx) -> FieldShare {
+            if (idx <= z.n_public) return trivial(pub[idx]);
+            if (idx >= z.n_vars || idx - z.n_public - 1 >= have) throw std::runtime_error("Cannot index into witness " + std::to_string(idx));
+            FieldShare f; f.c[0] = f.c[1] = zero; for (int j = 0; j < k; j++) f.c[j] = ext[j][idx - z.n_public - 1];
+            return f;
+        };
+        for (const auto& a : z.additions) { FieldShare w1 = getw(a.id1), w2 = getw(a.id2); for (int j = 0; j < k; j++) ext[j][have] = A(M(a.f1, w1.c[j]), M(a.f2, w2.c[j])); have++; }
+        return d.upload_vec(ext[0].data(), k == 2 ? ext[1].data() : nullptr, ext[0].size());
+    }
+    void round1(const ShareVec& private_witness) {
+        const size_t nc = z.n_constraints;
+        if (private_witness.n != z.n_vars - z.n_additions - z.n_public - 1) throw std::runtime_error("witness length does not match the zkey");
+        ShareVec ext = z.n_additions ? keep(extend_witness(private_witness)) : private_witness;
+        void* d_pub = upload(pub);
+        std::vector<uint32_t> row_ptr(nc + 1); for (size_t i = 0; i <= nc; i++) row_ptr[i] = (uint32_t)i;
+        uint32_t* d_rp = (uint32_t*)Tp((nc + 8) / 8 + 1); CG(cg_dev_upload(ctx, d_rp, row_ptr.data(), (nc + 1) * 4));
+        void* d_one = Tp(std::max<size_t>(nc, 1)); CG(cg_vec_fill_dev(ctx, c.id, d_one, std::max<size_t>(nc, 1), one.v));
+        uint32_t* d_col = (uint32_t*)Tp((nc + 8) / 8 + 1);
+        for (int w = 0; w < 3; w++) {
+            if (nc) CG(cg_dev_upload(ctx, d_col, z.map[w].data(), nc * 4));
+            poly[w] = d.alloc_vec(n + 2);
+            // the wire buffers are gathers: one-entry CSR rows with coefficient one reuse the constraint-evaluation kernel (get_witness' public /
+            // private split with the REP3 party asymmetry, lib.rs:113-137)
+            CG(cg_spmv_csr_dev(ctx, c.id, d_rp, d_col, d_one, nc, d_pub, (uint32_t)(z.n_public + 1), d.party(), ext.c[0], ext.c[1], poly[w].c[0], poly[w].c[1]));
+            buf[w] = d.alloc_vec(n); copy(buf[w], poly[w], n);
+            ntt(poly[w], n, omega, true);                                                // :170-172
+            evl[w] = d.alloc_vec(N); copy(evl[w], poly[w], n); ntt(evl[w], N, omega4, false);   // :174-177
+            const FieldShare &b_hi = b[2 * w], &b_lo = b[2 * w + 1];                     // blind_coefficients (lib.rs:140-158)
+            set(poly[w], 0, fs_sub(get(poly[w], 0), b_lo)); set(poly[w], 1, fs_sub(get(poly[w], 1), b_hi));
+            set(poly[w], n, b_lo); set(poly[w], n + 1, b_hi);
+        }
+        PointShare cm[3];
+        for (int w = 0; w < 3; w++) cm[w] = d.msm_public_points(tau, CG_G1, 0, n + 2, poly[w]);   // :276-290
+        for (int w = 0; w < 3; w++) commit[w] = d.open_point(cm[w]);                               // open_point_many (:292)
+        release_tmp();
+    }
+    // ---- round 2 (round2.rs:146-298) ---------------------------------------------------------------------------------------------
+    void round2() {
+        {
+            PlonkTranscript t(c);
+            for (int i = 0; i < 8; i++) t.add_point(z.vk_g1.data() + i * c.aff(CG_G1));
+            for (size_t i = 1; i < pub.size(); i++) t.add_scalar(pub[i]);
+            for (int w = 0; w < 3; w++) transcript_point(t, commit[w]);
+            beta = t.get_challenge();
+            PlonkTranscript t2(c); t2.add_scalar(beta); gamma = t2.get_challenge();
+        }
+        void* betaw = Tp(n); CG(cg_vec_fill_dev(ctx, c.id, betaw, n, beta.v)); CG(cg_vec_distribute_powers_dev(ctx, c.id, betaw, n, omega.v, one.v));
+        void* pv = Tp(n); void* sig = Tp(n);
+        const Fr kk[3] = {one, z.k1, z.k2};
+        ShareVec num, den;
+        for (int w = 0; w < 3; w++) {                                                     // :162-216
+            ShareVec f = T(n);
+            CG(cg_vec_affine_dev(ctx, c.id, pv, betaw, n, kk[w].v, gamma.v));
+            addpub_vec(f, buf[w], pv, n);
+            num = w == 0 ? f : mul(num, f, n);
+            void* d_sigma = upload(z.sigma_eval[w]);
+            CG(cg_vec_gather_strided_dev(ctx, c.id, sig, d_sigma, n, 0, 4));
+            CG(cg_vec_affine_dev(ctx, c.id, pv, sig, n, beta.v, gamma.v));
+            ShareVec g = T(n);
+            addpub_vec(g, buf[w], pv, n);
+            den = w == 0 ? g : mul(den, g, n);
+        }
+        ShareVec num_p = array_prod_mul(num, n), den_p = array_prod_mul(den, n);           // :218-224
+        ShareVec den_i = inv_many(den_p, n);                                               // :228
+        ShareVec zb = mul(num_p, den_i, n);                                                // :229
+        poly_z = d.alloc_vec(n + 3);
+        if (n > 1) copy(view(poly_z, 1, n - 1), zb, n - 1);                                // rotate_right(1) (:230)
+        copy(poly_z, view(zb, n - 1, 1), 1);
+        ntt(poly_z, n, omega, true);                                                       // :235
+        eval_z = d.alloc_vec(N); copy(eval_z, poly_z, n); ntt(eval_z, N, omega4, false);   // :238
+        set(poly_z, 0, fs_sub(get(poly_z, 0), b[8])); set(poly_z, 1, fs_sub(get(poly_z, 1), b[7])); set(poly_z, 2, fs_sub(get(poly_z, 2), b[6]));
+        set(poly_z, n, b[8]); set(poly_z, n + 1, b[7]); set(poly_z, n + 2, b[6]);
+        commit_z = commit_open(poly_z, n + 3);                                             // :268-275
+        release_tmp();
+    }
+    // ---- round 3 (round3.rs:234-527) ---------------------------------------------------------------------------------------------
+    void round3() {
+        if (z.lagrange_eval.empty()) throw std::runtime_error("round 3 needs at least one public input (lagrange[0])");
+        { PlonkTranscript t(c); t.add_scalar(beta); t.add_scalar(gamma); transcript_point(t, commit_z); alpha = t.get_challenge(); }   // :498-503
+        const Fr alpha2 = M(alpha, alpha), two = fr_from_u64(c, 2);
+        const Fr Z1[4] = {zero, A(neg(one), w2r), neg(two), fr_sub(c, neg(one), w2r)};     // get_z1..3 (:203-232)
+        const Fr m2w = M(neg(two), w2r);
+        const Fr Z2[4] = {zero, m2w, M(two, two), neg(m2w)};
+        const Fr tw = M(two, w2r);
+        const Fr Z3[4] = {zero, A(two, tw), neg(M(M(two, two), two)), fr_sub(c, two, tw)};
+        auto pattern = [&](const Fr* zz) { std::vector<Fr> h(N); for (size_t i = 0; i < N; i++) h[i] = zz[i & 3]; return upload(h); };
+        void* z1p = pattern(Z1); void* z2p = pattern(Z2); void* z3p = pattern(Z3);
+        const ShareVec &a = evl[0], &bb = evl[1], &cc = evl[2], &ez = eval_z;
+        const FieldShare fzero = trivial(zero);
+        // the blinding polynomials on the 4n-th roots of unity (:246-256, :307-322)
+        void* pw = Tp(N); CG(cg_vec_fill_dev(ctx, c.id, pw, N, one.v)); CG(cg_vec_distribute_powers_dev(ctx, c.id, pw, N, omega4.v, one.v));
+        void* pw2 = Tp(N); CG(cg_vec_mul_dev(ctx, c.id, pw2, pw, pw, N));
+        void* pww = Tp(N); CG(cg_vec_affine_dev(ctx, c.id, pww, pw, N, omega.v, nullptr));
+        void* pww2 = Tp(N); CG(cg_vec_mul_dev(ctx, c.id, pww2, pww, pww, N));
+        ShareVec ap = T(N), bp = T(N), cp = T(N), zp = T(N), zwp = T(N), t0 = T(N);
+        affine_share(ap, pw, b[0], b[1], N); affine_share(bp, pw, b[2], b[3], N); affine_share(cp, pw, b[4], b[5], N);
+        affine_share(zp, pw2, b[6], b[8], N); affine_share(t0, pw, b[7], fzero, N); add(zp, zp, t0, N);
+        affine_share(zwp, pww2, b[6], b[8], N); affine_share(t0, pww, b[7], fzero, N); add(zwp, zwp, t0, N);
+        ShareVec zw = T(N);                                                                // z(X omega): eval_z rotated by 4 (:324-327)
+        copy(zw, view(ez, 4, N - 4), N - 4); copy(view(zw, N - 4, 4), ez, 4);
+        // gate constraint (:333-368)
+        ShareVec a_b = mul(a, bb, N), a_bp = mul(a, bp, N), ap_b = mul(bb, ap, N), ap_bp = mul(ap, bp, N);
+        ShareVec a0 = T(N); add(a0, a_bp, ap_b, N); mulpub(t0, ap_bp, z1p, N); add(a0, a0, t0, N);
+        void* q[5]; for (int i = 0; i < 5; i++) q[i] = upload(z.q_eval[i]);
+        ShareVec e1 = T(N), e1z = T(N);
+        mulpub(e1, a_b, q[0], N); mulpub(t0, a, q[1], N); add(e1, e1, t0, N); mulpub(t0, bb, q[2], N); add(e1, e1, t0, N); mulpub(t0, cc, q[3], N); add(e1, e1, t0, N);
+        addpub_vec(e1, e1, q[4], N);
+        mulpub(e1z, a0, q[0], N); mulpub(t0, ap, q[1], N); add(e1z, e1z, t0, N); mulpub(t0, bp, q[2], N); add(e1z, e1z, t0, N); mulpub(t0, cp, q[3], N); add(e1z, e1z, t0, N);
+        void* l1 = nullptr;
+        for (size_t j = 0; j < z.lagrange_eval.size(); j++) {                              // public-input polynomial (:352-358): pi -= L_j * buffer_a[j]
+            void* lj = upload(z.lagrange_eval[j]); if (j == 0) l1 = lj;
+            const FieldShare aj = get(buf[0], j);
+            for (int cpn = 0; cpn < k; cpn++) { CG(cg_vec_affine_dev(ctx, c.id, t0.c[cpn], lj, N, neg(aj.c[cpn]).v, nullptr)); }
+            add(e1, e1, t0, N);
+        }
+        // permutation constraints (:370-418)
+        auto mul4 = [&](const ShareVec& Av, const ShareVec& Bv, const ShareVec& Cv, const ShareVec& Dv, const ShareVec& Dp, ShareVec& r, ShareVec& rz) {   // mul4vec + mul4vec_post (:17-72)
+            ShareVec AB = mul(Av, Bv, N);
+            ShareVec S1 = mul(Av, bp, N); add(S1, S1, mul(ap, Bv, N), N);                  // A B' + A' B
+            ShareVec CD = mul(Cv, Dv, N);
+            ShareVec S2 = mul(Cv, Dp, N); add(S2, S2, mul(cp, Dv, N), N);                  // C D' + C' D
+            ShareVec CpDp = mul(cp, Dp, N);
+            r = mul(AB, CD, N);
+            rz = mul(S1, CD, N); add(rz, rz, mul(AB, S2, N), N);
+            ShareVec r1 = mul(ap_bp, CD, N); add(r1, r1, mul(S1, S2, N), N); add(r1, r1, mul(AB, CpDp, N), N);
+            mulpub(t0, r1, z1p, N); add(rz, rz, t0, N);
+            ShareVec r2 = mul(S1, CpDp, N); add(r2, r2, mul(ap_bp, S2, N), N);
+            mulpub(t0, r2, z2p, N); add(rz, rz, t0, N);
+            ShareVec r3 = mul(ap_bp, CpDp, N);
+            mulpub(t0, r3, z3p, N); add(rz, rz, t0, N);
+        };
+        ShareVec e2, e2z, e3, e3z;
+        {
+            void* pvv = Tp(N);
+            ShareVec fa = T(N), fb = T(N), fc = T(N);
+            CG(cg_vec_affine_dev(ctx, c.id, pvv, pw, N, beta.v, gamma.v)); addpub_vec(fa, a, pvv, N);
+            CG(cg_vec_affine_dev(ctx, c.id, pvv, pw, N, M(beta, z.k1).v, gamma.v)); addpub_vec(fb, bb, pvv, N);
+            CG(cg_vec_affine_dev(ctx, c.id, pvv, pw, N, M(beta, z.k2).v, gamma.v)); addpub_vec(fc, cc, pvv, N);
+            mul4(fa, fb, fc, ez, zp, e2, e2z);
+            ShareVec ga = T(N), gb = T(N), gc = T(N);
+            void* sg[3]; for (int i = 0; i < 3; i++) sg[i] = upload(z.sigma_eval[i]);
+            CG(cg_vec_affine_dev(ctx, c.id, pvv, sg[0], N, beta.v, gamma.v)); addpub_vec(ga, a, pvv, N);
+            CG(cg_vec_affine_dev(ctx, c.id, pvv, sg[1], N, beta.v, gamma.v)); addpub_vec(gb, bb, pvv, N);
+            CG(cg_vec_affine_dev(ctx, c.id, pvv, sg[2], N, beta.v, gamma.v)); addpub_vec(gc, cc, pvv, N);
+            mul4(ga, gb, gc, zw, zwp, e3, e3z);
+        }
+        // t = e1 + alpha (e2 - e3) + alpha^2 L1 (z - 1), tz likewise from the blinding parts (:420-441)
+        ShareVec Tv = T(N), TZ = T(N);
+        sub(t0, e2, e3, N); scale(t0, t0, alpha, N); add(Tv, e1, t0, N);
+        addpub_scalar(t0, ez, neg(one), N); mulpub(t0, t0, l1, N); scale(t0, t0, alpha2, N); add(Tv, Tv, t0, N);
+        sub(t0, e2z, e3z, N); scale(t0, t0, alpha, N); add(TZ, e1z, t0, N);
+        mulpub(t0, zp, l1, N); scale(t0, t0, alpha2, N); add(TZ, TZ, t0, N);
+        ntt(Tv, N, omega4, true);                                                          // :442
+        scale(view(Tv, 0, n), view(Tv, 0, n), neg(one), n);                                // neg_vec_in_place_limit (:443)
+        for (int blk = 1; blk < 4; blk++) sub(view(Tv, blk * n, n), view(Tv, (blk - 1) * n, n), view(Tv, blk * n, n), n);   // division by X^n - 1 (:445-450)
+        ntt(TZ, N, omega4, true);
+        add(Tv, Tv, TZ, N);                                                                // :453
+        const size_t len[3] = {n + 1, n + 1, n + 6};                                        // split (:455-470)
+        for (int p = 0; p < 3; p++) { tpart[p] = d.alloc_vec(len[p]); copy(tpart[p], view(Tv, (size_t)p * n, p == 2 ? n + 6 : n), p == 2 ? n + 6 : n); }
+        set(tpart[0], n, b[9]);
+        set(tpart[1], 0, fs_sub(get(tpart[1], 0), b[9])); set(tpart[1], n, b[10]);
+        set(tpart[2], 0, fs_sub(get(tpart[2], 0), b[10]));
+        PointShare cm[3];
+        for (int p = 0; p < 3; p++) { if (len[p] > z.domain_size + 6) throw std::runtime_error("polynomial degree too large"); cm[p] = d.msm_public_points(tau, CG_G1, 0, len[p], tpart[p]); }
+        for (int p = 0; p < 3; p++) commit_t[p] = d.open_point(cm[p]);                     // :507-522
+        release_tmp();
+    }
+    // ---- rounds 4 and 5 (round4.rs:115-160, round5.rs:143-365) --------------------------------------------------------------------
+    void round4() {
+        { PlonkTranscript t(c); t.add_scalar(alpha); for (int p = 0; p < 3; p++) transcript_point(t, commit_t[p]); xi = t.get_challenge(); }
+        const Fr xiw = M(xi, omega);
+        std::vector<FieldShare> sh = {eval_share_poly(poly[0], n + 2, xi), eval_share_poly(poly[1], n + 2, xi), eval_share_poly(poly[2], n + 2, xi), eval_share_poly(poly_z, n + 3, xiw)};
+        const std::vector<Fr> opened = d.open_many(sh);                                    // :131
+        ev_a = opened[0]; ev_b = opened[1]; ev_c = opened[2]; ev_zw = opened[3];
+        ev_s1 = eval_pub_poly(upload(z.sigma_coef[0]), n, xi); ev_s2 = eval_pub_poly(upload(z.sigma_coef[1]), n, xi);
+        release_tmp();
+    }
+    void round5() {
+        { PlonkTranscript t(c); const Fr* items[7] = {&xi, &ev_a, &ev_b, &ev_c, &ev_s1, &ev_s2, &ev_zw}; for (const Fr* e : items) t.add_scalar(*e);
+          v[0] = t.get_challenge(); for (int i = 1; i < 5; i++) v[i] = M(v[i - 1], v[0]); }                                          // :338-350
+        const size_t len = n + 6;
+        Fr xin = xi; for (size_t i = 0; i < z.power; i++) xin = M(xin, xin);               // lib.rs:160-184
         const Fr zh = fr_sub(c, xin, one);
         std::vector<Fr> l; { Fr wv = one; const Fr nn = fr_from_u64(c, (uint64_t)n); for (size_t i = 0; i < std::max<size_t>(1, z.n_public); i++) { l.push_back(M(M(wv, zh), fr_inv(c, M(nn, fr_sub(c, xi, wv))))); wv = M(wv, omega); } }
-        Fr eval_pi = zero; for (size_t i = 0; i < public_inputs.size() && i < l.size(); i++) eval_pi = fr_sub(c, eval_pi, M(l[i], public_inputs[i]));
+        Fr eval_pi = zero; for (size_t i = 1; i < pub.size() && i - 1 < l.size(); i++) eval_pi = fr_sub(c, eval_pi, M(l[i - 1], pub[i]));
         const Fr betaxi = M(beta, xi);
-        const Fr e2 = M(M(M(A(A(r.eval_a, betaxi), gamma), A(A(r.eval_b, M(betaxi, z.k1)), gamma)), A(A(r.eval_c, M(betaxi, z.k2)), gamma)), alpha);
-        const Fr e3 = M(M(M(A(A(r.eval_a, M(beta, r.eval_s1)), gamma), A(A(r.eval_b, M(beta, r.eval_s2)), gamma)), r.eval_zw), alpha);
+        const Fr e2 = M(M(M(A(A(ev_a, betaxi), gamma), A(A(ev_b, M(betaxi, z.k1)), gamma)), A(A(ev_c, M(betaxi, z.k2)), gamma)), alpha);
+        const Fr e3 = M(M(M(A(A(ev_a, M(beta, ev_s1)), gamma), A(A(ev_b, M(beta, ev_s2)), gamma)), ev_zw), alpha);
         const Fr e4 = M(M(alpha, alpha), l[0]), e24 = A(e2, e4);
-        void* R = driver.dalloc(len * 32); CG(cg_dev_memset_zero(ctx, R, len * 32));
-        void* tmp = driver.dalloc(len * 32);
-        auto axpy = [&](void* dst, const void* src, size_t cnt, const Fr& k) { CG(cg_vec_affine_dev(ctx, c.id, tmp, src, cnt, k.v, nullptr)); CG(cg_vec_add_dev(ctx, c.id, dst, dst, tmp, cnt)); };   // dst[..cnt] += k * src
-        axpy(R, poly_z.c[0], n + 3, e24);
-        { void* q[5]; for (int k = 0; k < 5; k++) q[k] = up(z.q_coef[k]);
-          axpy(R, q[0], n, M(r.eval_a, r.eval_b)); axpy(R, q[1], n, r.eval_a); axpy(R, q[2], n, r.eval_b); axpy(R, q[3], n, r.eval_c); axpy(R, q[4], n, one);
-          axpy(R, s_co[2], n, neg(M(e3, beta)));
-          for (void* p : q) CG(cg_dev_free(ctx, p)); }
-        axpy(R, t_parts[2].c[0], n + 6, neg(M(zh, M(xin, xin)))); axpy(R, t_parts[1].c[0], n + 1, neg(M(zh, xin))); axpy(R, t_parts[0].c[0], n + 1, neg(zh));
-        const Fr r0 = fr_sub(c, fr_sub(c, eval_pi, M(e3, A(r.eval_c, gamma))), e4);
-        // compute_wxi (:263-311): R + v0 a + v1 b + v2 c + v3 s1 + v4 s2, constant term corrected, divided by (X - xi)
-        for (int k = 0; k < 3; k++) axpy(R, polys[k].c[0], n + 2, v[k]);
-        axpy(R, s_co[0], n, v[3]); axpy(R, s_co[1], n, v[4]);
-        Fr h0; CG(cg_dev_download(ctx, h0.v, R, 32));
-        h0 = A(h0, r0);
-        h0 = fr_sub(c, h0, A(A(A(A(M(v[0], r.eval_a), M(v[1], r.eval_b)), M(v[2], r.eval_c)), M(v[3], r.eval_s1)), M(v[4], r.eval_s2)));
-        CG(cg_dev_upload(ctx, R, h0.v, 32));
+        ShareVec R = T(len);                                                               // compute_r (:143-260)
+        axpy(R, poly_z, e24, n + 3);
+        void* s_co[3]; for (int i = 0; i < 3; i++) s_co[i] = upload(z.sigma_coef[i]);
+        { const Fr f[5] = {M(ev_a, ev_b), ev_a, ev_b, ev_c, one}; for (int i = 0; i < 5; i++) axpy_pub(R, upload(z.q_coef[i]), f[i], n); }
+        axpy_pub(R, s_co[2], neg(M(e3, beta)), n);
+        axpy(R, tpart[2], neg(M(zh, M(xin, xin))), n + 6); axpy(R, tpart[1], neg(M(zh, xin)), n + 1); axpy(R, tpart[0], neg(zh), n + 1);
+        const Fr r0 = fr_sub(c, fr_sub(c, eval_pi, M(e3, A(ev_c, gamma))), e4);
+        // compute_wxi (:263-311)
+        for (int w = 0; w < 3; w++) axpy(R, poly[w], v[w], n + 2);
+        axpy_pub(R, s_co[0], v[3], n); axpy_pub(R, s_co[1], v[4], n);
+        const Fr corr = fr_sub(c, r0, A(A(A(A(M(v[0], ev_a), M(v[1], ev_b)), M(v[2], ev_c)), M(v[3], ev_s1)), M(v[4], ev_s2)));
+        set(R, 0, fs_addpub(get(R, 0), corr));
         div_by_zerofier1(R, len, xi);
-        ShareVec wxi; wxi.n = len - 1; wxi.c[0] = R;
         // compute_wxiw (:314-327)
-        ShareVec wxiw = driver.alloc_vec(n + 3);
-        CG(cg_vec_gather_strided_dev(ctx, c.id, wxiw.c[0], poly_z.c[0], n + 3, 0, 1));
-        CG(cg_dev_download(ctx, h0.v, wxiw.c[0], 32)); h0 = fr_sub(c, h0, r.eval_zw); CG(cg_dev_upload(ctx, wxiw.c[0], h0.v, 32));
-        div_by_zerofier1(wxiw.c[0], n + 3, xiw);
-        wxiw.n = n + 2;
-        r.commit_wxi = driver.open_point(driver.msm_public_points(p_tau, CG_G1, 0, wxi.n, wxi));      // :351-358
-        r.commit_wxiw = driver.open_point(driver.msm_public_points(p_tau, CG_G1, 0, wxiw.n, wxiw));
-        driver.free_vec(wxi); driver.free_vec(wxiw); CG(cg_dev_free(ctx, tmp));
-        for (void* p : s_co) CG(cg_dev_free(ctx, p));
-        return r;
+        ShareVec W = T(n + 3); copy(W, poly_z, n + 3);
+        set(W, 0, fs_addpub(get(W, 0), neg(ev_zw)));
+        div_by_zerofier1(W, n + 3, M(xi, omega));
+        PointShare c1 = d.msm_public_points(tau, CG_G1, 0, len - 1, R), c2 = d.msm_public_points(tau, CG_G1, 0, n + 2, W);   // :351-358
+        commit_wxi = d.open_point(c1); commit_wxiw = d.open_point(c2);
+        release_tmp();
     }
 };
 
@@ -1374,107 +1391,57 @@ int32_t cgh_plonk_zkey_info(int32_t curve, const char* path, size_t* info) {
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
-// PlainHipDriver: full_witness = n_vars - n_additions Montgomery elements (Groth16-style, leading one); blind = 6 Fr; out = 3 packed G1
-int32_t cgh_plonk_round1_plain(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* full_witness, const uint64_t* blind, uint64_t* out_commits) {
-    cg_ctx* ctx = nullptr;
-    try {
-        using namespace cgh;
-        PlonkZKey z = read_plonk_zkey(curve, zkey_path);
-        if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
-        const Curve& c = z.curve;
-        cg_bases* tau = nullptr; CG(cg_bases_register(ctx, c.id, CG_G1, z.p_tau.data(), z.domain_size + 6, c.aff(CG_G1), -1, &tau));
-        const Fr* w = (const Fr*)full_witness;
-        std::vector<Fr> pub(w, w + z.n_public + 1);
-        HipDriver driver(ctx, c, Mode::Plain, nullptr);
-        ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_additions - z.n_public - 1);
-        FieldShare b[6]; for (int i = 0; i < 6; i++) { memcpy(b[i].c[0].v, blind + 4 * i, 32); b[i].c[1] = b[i].c[0]; }
-        CoPlonkRound1 r1(driver);
-        auto cm = r1.round1(z, tau, pub, wit, b);
-        for (int i = 0; i < 3; i++) { Bytes a = pt_to_affine(c, cm[i]); memcpy((uint8_t*)out_commits + i * a.size(), a.data(), a.size()); }
-        driver.free_vec(wit); cg_bases_release(tau); cg_ctx_destroy(ctx);
-        return 0;
-    } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
+// ---- co-plonk entry points -------------------------------------------------------------------------------------------------------
+namespace {
+struct PlonkOut { uint64_t* commits; uint64_t* challenges; uint64_t* evals; uint64_t* t_polys; uint64_t* poly_z; };
+// runs rounds 1..upto on `driver` and stores what has been computed (slot layout of cgh_plonk_prove_plain)
+void plonk_run(cgh::HipDriver& driver, const cgh::PlonkZKey& z, const cg_bases* tau, const std::vector<cgh::Fr>& pub, const cgh::ShareVec& wit, const cgh::FieldShare* b, int upto, const PlonkOut& o) {
+    using namespace cgh;
+    const Curve& c = z.curve; const size_t psz = c.aff(CG_G1);
+    auto put = [&](int slot, const Point& p) { if (!o.commits) return; Bytes a = pt_to_affine(c, p); memcpy((uint8_t*)o.commits + slot * psz, a.data(), psz); };
+    auto putf = [&](uint64_t* dst, int slot, const Fr& f) { if (dst) memcpy(dst + 4 * slot, f.v, 32); };
+    CoPlonk pk(driver, z, tau, pub, b);
+    pk.round1(wit);
+    for (int k = 0; k < 3; k++) put(k, pk.commit[k]);
+    if (upto >= 2) {
+        pk.round2(); put(3, pk.commit_z); putf(o.challenges, 0, pk.beta); putf(o.challenges, 1, pk.gamma);
+        if (o.poly_z) CG(cg_dev_download(driver.ctx, o.poly_z, pk.poly_z.c[0], pk.poly_z.n * 32));
+    }
+    if (upto >= 3) {
+        pk.round3(); for (int k = 0; k < 3; k++) put(4 + k, pk.commit_t[k]); putf(o.challenges, 2, pk.alpha);
+        if (o.t_polys) { size_t off = 0; for (int k = 0; k < 3; k++) { CG(cg_dev_download(driver.ctx, o.t_polys + off * 4, pk.tpart[k].c[0], pk.tpart[k].n * 32)); off += pk.tpart[k].n; } }
+    }
+    if (upto >= 4) {
+        pk.round4(); putf(o.challenges, 3, pk.xi);
+        const Fr ev[6] = {pk.ev_a, pk.ev_b, pk.ev_c, pk.ev_s1, pk.ev_s2, pk.ev_zw};
+        for (int i = 0; i < 6; i++) putf(o.evals, i, ev[i]);
+    }
+    if (upto >= 5) { pk.round5(); putf(o.challenges, 4, pk.v[0]); put(7, pk.commit_wxi); put(8, pk.commit_wxiw); }
 }
-// rounds 1 + 2 with the plain driver; blind = 9 Fr (b_1..b_9); out: beta, gamma (2 Fr), commit_z (packed G1), optional transcript-free
-// poly_z (domain_size + 3 Fr)
-int32_t cgh_plonk_round2_plain(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* full_witness, const uint64_t* blind,
-                               uint64_t* out_beta_gamma, uint64_t* out_commit_z, uint64_t* out_poly_z) {
-    cg_ctx* ctx = nullptr;
-    try {
-        using namespace cgh;
-        PlonkZKey z = read_plonk_zkey(curve, zkey_path);
-        if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
-        const Curve& c = z.curve;
-        cg_bases* tau = nullptr; CG(cg_bases_register(ctx, c.id, CG_G1, z.p_tau.data(), z.domain_size + 6, c.aff(CG_G1), -1, &tau));
-        const Fr* w = (const Fr*)full_witness;
-        std::vector<Fr> pub(w, w + z.n_public + 1);
-        HipDriver driver(ctx, c, Mode::Plain, nullptr);
-        ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_additions - z.n_public - 1);
-        FieldShare b[9]; for (int i = 0; i < 9; i++) { memcpy(b[i].c[0].v, blind + 4 * i, 32); b[i].c[1] = b[i].c[0]; }
-        CoPlonkRound1 r1(driver);
-        ShareVec buffers[3];
-        auto cm = r1.round1(z, tau, pub, wit, b, nullptr, buffers);
-        CoPlonkRound2 r2(driver);
-        ShareVec poly_z;
-        auto res = r2.round2(z, tau, std::vector<Fr>(pub.begin() + 1, pub.end()), cm, buffers, b, &poly_z);
-        memcpy(out_beta_gamma, res.beta.v, 32); memcpy(out_beta_gamma + 4, res.gamma.v, 32);
-        Bytes a = pt_to_affine(c, res.commit_z); memcpy(out_commit_z, a.data(), a.size());
-        if (out_poly_z) CG(cg_dev_download(ctx, out_poly_z, poly_z.c[0], poly_z.n * 32));
-        driver.free_vec(poly_z); for (auto& bf : buffers) driver.free_vec(bf);
-        driver.free_vec(wit); cg_bases_release(tau); cg_ctx_destroy(ctx);
-        return 0;
-    } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
-}
-// the plain driver through rounds 1..upto (<= 5); blind = 11 Fr; commits = 9 packed G1 (a, b, c, z, t1, t2, t3, wxi, wxiw), challenges = beta,
-// gamma, alpha, xi, v; evals = a, b, c, s1, s2, zw; t_polys (optional) = t1 (n+1) | t2 (n+1) | t3 (n+6)
+}  // namespace
+// PlainHipDriver through rounds 1..upto (<= 5).  full_witness = n_vars - n_additions Montgomery elements (Groth16-style, leading one);
+// blind = 11 Fr; commits = 9 packed G1 (a, b, c, z, t1, t2, t3, wxi, wxiw; zero = not reached), challenges = beta, gamma, alpha, xi, v;
+// evals = a, b, c, s1, s2, zw; optional: t_polys = t1 (n+1) | t2 (n+1) | t3 (n+6), poly_z (n+3)
 int32_t cgh_plonk_prove_plain(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* full_witness, const uint64_t* blind, int32_t upto,
-                              uint64_t* commits, uint64_t* challenges, uint64_t* evals, uint64_t* t_polys) {
+                              uint64_t* commits, uint64_t* challenges, uint64_t* evals, uint64_t* t_polys, uint64_t* poly_z) {
     cg_ctx* ctx = nullptr;
     try {
         using namespace cgh;
         PlonkZKey z = read_plonk_zkey(curve, zkey_path);
         if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
         const Curve& c = z.curve;
-        const size_t psz = c.aff(CG_G1), n = z.domain_size;
-        memset(commits, 0, 9 * psz); memset(challenges, 0, 5 * 32); memset(evals, 0, 6 * 32);
-        cg_bases* tau = nullptr; CG(cg_bases_register(ctx, c.id, CG_G1, z.p_tau.data(), n + 6, psz, -1, &tau));
+        if (commits) memset(commits, 0, 9 * c.aff(CG_G1)); if (challenges) memset(challenges, 0, 5 * 32); if (evals) memset(evals, 0, 6 * 32);
+        cg_bases* tau = nullptr; CG(cg_bases_register(ctx, c.id, CG_G1, z.p_tau.data(), z.domain_size + 6, c.aff(CG_G1), -1, &tau));
         const Fr* w = (const Fr*)full_witness;
         std::vector<Fr> pub(w, w + z.n_public + 1);
-        const std::vector<Fr> pub_tail(pub.begin() + 1, pub.end());
-        HipDriver driver(ctx, c, Mode::Plain, nullptr);
-        ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_additions - z.n_public - 1);
-        FieldShare b[11]; for (int i = 0; i < 11; i++) { memcpy(b[i].c[0].v, blind + 4 * i, 32); b[i].c[1] = b[i].c[0]; }
-        auto put = [&](int slot, const Point& p) { Bytes a = pt_to_affine(c, p); memcpy((uint8_t*)commits + slot * psz, a.data(), psz); };
-        ShareVec polys[3], buffers[3], evl[3], poly_z, eval_z, tparts[3];
-        CoPlonkRound1 r1(driver);
-        auto cm = r1.round1(z, tau, pub, wit, b, polys, buffers, evl);
-        for (int k = 0; k < 3; k++) put(k, cm[k]);
-        if (upto >= 2) {
-            CoPlonkRound2 r2(driver);
-            auto res2 = r2.round2(z, tau, pub_tail, cm, buffers, b, &poly_z, &eval_z);
-            put(3, res2.commit_z); memcpy(challenges, res2.beta.v, 32); memcpy(challenges + 4, res2.gamma.v, 32);
-            if (upto >= 3) {
-                CoPlonkRound3 r3(driver);
-                auto res3 = r3.round3(z, tau, res2.beta, res2.gamma, res2.commit_z, buffers, evl, eval_z, b, tparts);
-                for (int k = 0; k < 3; k++) put(4 + k, res3.commit_t[k]);
-                memcpy(challenges + 8, res3.alpha.v, 32);
-                if (t_polys) { size_t off = 0; for (int k = 0; k < 3; k++) { CG(cg_dev_download(ctx, t_polys + off * 4, tparts[k].c[0], tparts[k].n * 32)); off += tparts[k].n; } }
-                if (upto >= 4) {
-                    CoPlonkRound45 r45(driver);
-                    auto res5 = r45.run(z, tau, pub_tail, res2.beta, res2.gamma, res3.alpha, res3.commit_t, polys, poly_z, tparts);
-                    memcpy(challenges + 12, res5.xi.v, 32); memcpy(challenges + 16, res5.v0.v, 32);
-                    const Fr ev[6] = {res5.eval_a, res5.eval_b, res5.eval_c, res5.eval_s1, res5.eval_s2, res5.eval_zw};
-                    memcpy(evals, ev, sizeof ev);
-                    if (upto >= 5) { put(7, res5.commit_wxi); put(8, res5.commit_wxiw); }
-                }
-                for (auto& t : tparts) driver.free_vec(t);
-            }
-            driver.free_vec(poly_z); driver.free_vec(eval_z);
+        {
+            HipDriver driver(ctx, c, Mode::Plain, nullptr);
+            ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_additions - z.n_public - 1);
+            FieldShare b[11]; for (int i = 0; i < 11; i++) { memcpy(b[i].c[0].v, blind + 4 * i, 32); b[i].c[1] = b[i].c[0]; }
+            plonk_run(driver, z, tau, pub, wit, b, upto, PlonkOut{commits, challenges, evals, t_polys, poly_z});
+            driver.free_vec(wit);
         }
-        for (auto& v : polys) driver.free_vec(v);
-        for (auto& v : buffers) driver.free_vec(v);
-        for (auto& v : evl) driver.free_vec(v);
-        driver.free_vec(wit); cg_bases_release(tau); cg_ctx_destroy(ctx);
+        cg_bases_release(tau); cg_ctx_destroy(ctx);
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
 }
@@ -1489,19 +1456,22 @@ int32_t cgh_plonk_transcript(int32_t curve, const int32_t* kinds, const uint64_t
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
-// Rep3HipProtocol x 3 (three threads, in-process network).  blind_a[i] / blind_b[i] = party i's (a, b) shares of b_1..b_6.
-// out_commits = 3 parties x 3 packed G1 (every party opens the same points)
-int32_t cgh_plonk_round1_rep3(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
-                              const uint64_t* const* blind_a, const uint64_t* const* blind_b, uint64_t* out_commits) {
+// Rep3HipProtocol x 3 (three threads, in-process network) through rounds 1..upto.  blind_a[i] / blind_b[i] = party i's (a, b) shares of
+// b_1..b_11; streams[i] = S_i (party i: rng1 = S_i, rng2 = S_{i-1}; rounds 2 and 3 consume masks and random shares).
+// out_commits = 3 parties x 9 packed G1, out_evals = 3 x 6 Fr, out_challenges = 3 x 5 Fr (every party must report the same values)
+int32_t cgh_plonk_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
+                             const uint64_t* const* blind_a, const uint64_t* const* blind_b, const uint64_t* const* streams, size_t stream_len, int32_t upto,
+                             uint64_t* out_commits, uint64_t* out_evals, uint64_t* out_challenges) {
     try {
         using namespace cgh;
         PlonkZKey z = read_plonk_zkey(curve, zkey_path);
         const Curve c = z.curve;
-        const size_t n_priv = z.n_vars - z.n_additions - z.n_public - 1;
+        const size_t n_priv = z.n_vars - z.n_additions - z.n_public - 1, psz = c.aff(CG_G1);
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
+        memset(out_commits, 0, 3 * 9 * psz); if (out_evals) memset(out_evals, 0, 3 * 6 * 32); if (out_challenges) memset(out_challenges, 0, 3 * 5 * 32);
         cg_ctx* ctx0 = nullptr;
         if (cg_ctx_create(device, &ctx0)) die("cg_ctx_create");
-        cg_bases* tau = nullptr; CG(cg_bases_register(ctx0, c.id, CG_G1, z.p_tau.data(), z.domain_size + 6, c.aff(CG_G1), -1, &tau));
+        cg_bases* tau = nullptr; CG(cg_bases_register(ctx0, c.id, CG_G1, z.p_tau.data(), z.domain_size + 6, psz, -1, &tau));
         InProcHub hub;
         std::string errs[3];
         std::vector<std::thread> th;
@@ -1510,13 +1480,15 @@ int32_t cgh_plonk_round1_rep3(int32_t device, int32_t curve, const char* zkey_pa
             try {
                 if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
                 InProcNetwork net(&hub, i);
-                HipDriver driver(ctx, c, Mode::Rep3, &net);
-                ShareVec wit = driver.upload_vec((const Fr*)wit_a[i], (const Fr*)wit_b[i], n_priv);
-                FieldShare b[6]; for (int t = 0; t < 6; t++) { memcpy(b[t].c[0].v, blind_a[i] + 4 * t, 32); memcpy(b[t].c[1].v, blind_b[i] + 4 * t, 32); }
-                CoPlonkRound1 r1(driver);
-                auto cm = r1.round1(z, tau, pub, wit, b);
-                for (int t = 0; t < 3; t++) { Bytes a = pt_to_affine(c, cm[t]); memcpy((uint8_t*)out_commits + (i * 3 + t) * a.size(), a.data(), a.size()); }
-                driver.free_vec(wit);
+                {
+                    HipDriver driver(ctx, c, Mode::Rep3, &net);
+                    if (streams) { driver.rng1 = (const Fr*)streams[i]; driver.rng2 = (const Fr*)streams[(i + 2) % 3]; driver.rng_len = stream_len; }
+                    ShareVec wit = driver.upload_vec((const Fr*)wit_a[i], (const Fr*)wit_b[i], n_priv);
+                    FieldShare b[11]; for (int t = 0; t < 11; t++) { memcpy(b[t].c[0].v, blind_a[i] + 4 * t, 32); memcpy(b[t].c[1].v, blind_b[i] + 4 * t, 32); }
+                    plonk_run(driver, z, tau, pub, wit, b, upto, PlonkOut{(uint64_t*)((uint8_t*)out_commits + (size_t)i * 9 * psz), out_challenges ? out_challenges + i * 20 : nullptr,
+                                                                          out_evals ? out_evals + i * 24 : nullptr, nullptr, nullptr});
+                    driver.free_vec(wit);
+                }
                 cg_ctx_destroy(ctx);
             } catch (const std::exception& e) { errs[i] = e.what(); if (ctx) cg_ctx_destroy(ctx); }
         });
