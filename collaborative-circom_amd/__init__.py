@@ -519,6 +519,21 @@ def plonk_prove_rep3(curve, zkey_path, pub, wit_a, wit_b, blind_a, blind_b, stre
     return out
 
 
+def plonk_prove_shamir(curve, zkey_path, n, t, pub, wits, blinds, streams, upto=5, device=0):
+    """n Shamir parties (threshold t) on one GPU through round `upto`; returns a list of n dicts like plonk_prove_plain"""
+    nq = 6 if curve == BLS12_381 else 4
+    commits = np.zeros((n, 9, 2 * nq), dtype=np.uint64); ch = np.zeros((n, 5, 4), dtype=np.uint64); ev = np.zeros((n, 6, 4), dtype=np.uint64)
+    keep = [[np.ascontiguousarray(x, dtype=np.uint64) for x in lst] for lst in (wits, [_pad_blind(x) for x in blinds], streams)]
+    arr = lambda lst: (C.c_void_p * n)(*[x.ctypes.data for x in lst])
+    _hchk(load_host().cgh_plonk_prove_shamir(int(device), curve, zkey_path.encode(), int(n), int(t), _hp(np.ascontiguousarray(pub, dtype=np.uint64)),
+                                             arr(keep[0]), arr(keep[1]), arr(keep[2]), C.c_size_t(keep[2][0].shape[0]), int(upto), _hp(commits), _hp(ev), _hp(ch)))
+    out = []
+    for i in range(n):
+        dct = dict(zip(PLONK_COMMITS, commits[i])); dct.update(zip(PLONK_CHALLENGES, ch[i])); dct.update(zip(PLONK_EVALS, ev[i]))
+        out.append(dct)
+    return out
+
+
 def plonk_round1_rep3(curve, zkey_path, pub, wit_a, wit_b, blind_a, blind_b, device=0):
     """round 1 only: (3 parties, 3 commitments, packed G1)"""
     r = plonk_prove_rep3(curve, zkey_path, pub, wit_a, wit_b, blind_a, blind_b, streams=None, upto=1, device=device)

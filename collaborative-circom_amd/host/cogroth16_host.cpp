@@ -302,7 +302,7 @@ public:
 
     // ---- Shamir state (shamir.rs:196-246): threshold, Lagrange tables, buffered double sharings; randomness = stream rng1
     ShamirNet* snet = nullptr; int sh_t = 0;
-    std::vector<Fr> open_lagrange_t, mul_lagrange_2t, sh_r_t, sh_r_2t;
+    std::vector<Fr> open_lagrange_t, open_lagrange_2t, mul_lagrange_2t, sh_r_t, sh_r_2t;
     static constexpr size_t SHAMIR_BATCH = 1024;                                     // ShamirRng::BATCH_SIZE
     Fr next_rand() { if (cursor >= rng_len) throw std::runtime_error("randomness stream exhausted"); return rng1[cursor++]; }
     std::vector<Fr> lagrange_from_coeff(const std::vector<size_t>& pts) const {       // shamir_core.rs:56-75
@@ -320,6 +320,8 @@ public:
         if (2 * threshold + 1 > np) throw std::runtime_error("Threshold too large for number of parties");
         std::vector<size_t> p; for (int i = 0; i <= threshold; i++) p.push_back((size_t)((id + np - i) % np + 1));
         open_lagrange_t = lagrange_from_coeff(p);
+        p.clear(); for (int i = 0; i <= 2 * threshold; i++) p.push_back((size_t)((id + np - i) % np + 1));
+        open_lagrange_2t = lagrange_from_coeff(p);
         p.clear(); for (int i = 1; i <= 2 * threshold + 1; i++) p.push_back((size_t)i);
         mul_lagrange_2t = lagrange_from_coeff(p);
     }
@@ -515,8 +517,19 @@ public:
     }
     // ---- vector forms of rand / mul_open_many / open_many used by co-plonk (rep3.rs:544-558,595-598,620-628,738-757)
     int public_component() const { return mode != Mode::Rep3 ? 0 : (party() == 0 ? 0 : party() == 1 ? 1 : -1); }   // add_with_public: who holds a public addend
+    // broadcast_next(num) of a vector + reconstruction with the given Lagrange table (shamir/network.rs:233-266, shamir.rs:581-601,684-711)
+    std::vector<Fr> shamir_open_vec(const std::vector<Fr>& mine, const std::vector<Fr>& lagrange) {
+        const int np = snet->num_parties(), me = snet->id(), num = (int)lagrange.size();
+        const size_t n = mine.size();
+        for (int sft = 1; sft < num; sft++) snet->send((me + sft) % np, mine.data(), n * 32);
+        std::vector<Fr> out(n), got(n);
+        for (size_t i = 0; i < n; i++) out[i] = fr_mul(curve, mine[i], lagrange[0]);
+        for (int r = 1; r < num; r++) { snet->recv((me + np - r) % np, got.data(), n * 32); for (size_t i = 0; i < n; i++) out[i] = fr_add(curve, out[i], fr_mul(curve, got[i], lagrange[r])); }
+        return out;
+    }
     ShareVec rand_vec(size_t n) {
-        if (mode != Mode::Rep3) throw std::runtime_error("rand_vec: REP3 only");
+        if (mode == Mode::Shamir) { std::vector<Fr> r(n); for (size_t i = 0; i < n; i++) r[i] = get_pair().first; return upload_vec(r.data(), nullptr, n); }   // shamir.rs:570-573
+        if (mode != Mode::Rep3) throw std::runtime_error("rand_vec: REP3 / Shamir only");
         if (cursor + n > rng_len) throw std::runtime_error("randomness stream exhausted");
         ShareVec v = upload_vec(rng1 + cursor, rng2 + cursor, n); cursor += n;
         return v;
@@ -525,8 +538,14 @@ public:
     void* mul_open_vec(const ShareVec& a, const ShareVec& b) {
         const size_t n = a.n;
         void* out = dalloc(n * 32);
-        if (mode == Mode::Plain) { CG(cg_vec_mul_dev(ctx, curve.id, out, a.c[0], b.c[0], n)); return out; }
-        if (mode != Mode::Rep3) throw std::runtime_error("mul_open_vec: plain / REP3 only");
+        if (mode != Mode::Rep3) CG(cg_vec_mul_dev(ctx, curve.id, out, a.c[0], b.c[0], n));
+        if (mode == Mode::Plain) return out;
+        if (mode == Mode::Shamir) {                                                   // degree-2t product opened from 2t + 1 shares (shamir.rs:684-711)
+            std::vector<Fr> mine(n); CG(cg_dev_download(ctx, mine.data(), out, n * 32));
+            const std::vector<Fr> res = shamir_open_vec(mine, open_lagrange_2t);
+            CG(cg_dev_upload(ctx, out, res.data(), n * 32));
+            return out;
+        }
         if (cursor + n > rng_len) throw std::runtime_error("randomness stream exhausted");
         void* m1 = dalloc(n * 32); void* m2 = dalloc(n * 32);
         CG(cg_dev_upload(ctx, m1, rng1 + cursor, n * 32)); CG(cg_dev_upload(ctx, m2, rng2 + cursor, n * 32)); cursor += n;
@@ -544,7 +563,7 @@ public:
     std::vector<Fr> open_many(const std::vector<FieldShare>& a) {
         std::vector<Fr> out(a.size());
         if (mode == Mode::Plain) { for (size_t i = 0; i < a.size(); i++) out[i] = a[i].c[0]; return out; }
-        if (mode != Mode::Rep3) throw std::runtime_error("open_many: plain / REP3 only");
+        if (mode == Mode::Shamir) { std::vector<Fr> mine(a.size()); for (size_t i = 0; i < a.size(); i++) mine[i] = a[i].c[0]; return shamir_open_vec(mine, open_lagrange_t); }   // shamir.rs:581-601
         std::vector<Fr> bs(a.size()), cs(a.size());
         for (size_t i = 0; i < a.size(); i++) bs[i] = a[i].c[1];
         net->send_next(bs.data(), bs.size() * 32); net->recv_prev(cs.data(), cs.size() * 32);
@@ -865,7 +884,7 @@ public:
 // ==================================================================================================== co-plonk, all rounds, any driver
 // The five rounds (co-plonk/src/round1..5.rs) written once over share-vector operations: per-component kernels for everything
 // linear, the driver's protocols for products of two shared vectors (`mul_vec`), for `array_prod_mul` / `inv_many` (round2.rs:18-41,
-// rep3.rs:544-558) and for openings.  Plain and REP3 run the same code; values that every party reconstructs (commitments,
+// rep3.rs:544-558, shamir.rs:521-535) and for openings.  Plain, REP3 and Shamir run the same code; values that every party reconstructs (commitments,
 // evaluations) are functions of the witness and of the opened blinding values only.
 class CoPlonk {
 public:
@@ -881,7 +900,6 @@ public:
 
     CoPlonk(HipDriver& drv, const PlonkZKey& zk, const cg_bases* p_tau, const std::vector<Fr>& public_inputs, const FieldShare* blind)
         : d(drv), z(zk), tau(p_tau), c(drv.curve), ctx(drv.ctx), n(zk.domain_size), N(4 * zk.domain_size), k(drv.k()), pub(public_inputs) {
-        if (d.mode == Mode::Shamir) throw std::runtime_error("co-plonk over Shamir shares is not implemented yet (plain and REP3 are)");
         if (pub.size() != z.n_public + 1) throw std::runtime_error("public input length does not match the zkey");
         zero = fr_from_u64(c, 0); one = fr_from_u64(c, 1);
         pub[0] = zero;
@@ -1453,6 +1471,50 @@ int32_t cgh_plonk_transcript(int32_t curve, const int32_t* kinds, const uint64_t
         PlonkTranscript t(c);
         for (int i = 0; i < n_items; i++) { if (kinds[i] == 0) { Fr s; memcpy(s.v, payloads[i], 32); t.add_scalar(s); } else t.add_point((const uint8_t*)payloads[i]); }
         Fr r = t.get_challenge(); memcpy(out_challenge, r.v, 32);
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+// ShamirHipProtocol x n (threshold t) through rounds 1..upto.  wit[i] / blind[i] = party i's Shamir shares of the private witness and of
+// b_1..b_11; streams[i] = party i's private randomness.  Outputs as for cgh_plonk_prove_rep3, n parties.
+int32_t cgh_plonk_prove_shamir(int32_t device, int32_t curve, const char* zkey_path, int32_t n, int32_t t, const uint64_t* pub_in, const uint64_t* const* wit,
+                               const uint64_t* const* blind, const uint64_t* const* streams, size_t stream_len, int32_t upto,
+                               uint64_t* out_commits, uint64_t* out_evals, uint64_t* out_challenges) {
+    try {
+        using namespace cgh;
+        if (n < 3) throw std::runtime_error("Shamir protocol requires at least 3 parties");
+        PlonkZKey z = read_plonk_zkey(curve, zkey_path);
+        const Curve c = z.curve;
+        const size_t n_priv = z.n_vars - z.n_additions - z.n_public - 1, psz = c.aff(CG_G1);
+        std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
+        memset(out_commits, 0, (size_t)n * 9 * psz); if (out_evals) memset(out_evals, 0, (size_t)n * 6 * 32); if (out_challenges) memset(out_challenges, 0, (size_t)n * 5 * 32);
+        cg_ctx* ctx0 = nullptr;
+        if (cg_ctx_create(device, &ctx0)) die("cg_ctx_create");
+        cg_bases* tau = nullptr; CG(cg_bases_register(ctx0, c.id, CG_G1, z.p_tau.data(), z.domain_size + 6, psz, -1, &tau));
+        InProcShamirHub hub(n);
+        std::vector<std::string> errs(n);
+        std::vector<std::thread> th;
+        for (int i = 0; i < n; i++) th.emplace_back([&, i] {
+            cg_ctx* ctx = nullptr;
+            try {
+                if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
+                InProcShamirNet net(&hub, i);
+                {
+                    HipDriver driver(ctx, c, Mode::Shamir, nullptr);
+                    driver.rng1 = (const Fr*)streams[i]; driver.rng_len = stream_len;
+                    driver.shamir_init(&net, t);
+                    ShareVec w = driver.upload_vec((const Fr*)wit[i], nullptr, n_priv);
+                    FieldShare b[11]; for (int q = 0; q < 11; q++) { memcpy(b[q].c[0].v, blind[i] + 4 * q, 32); b[q].c[1] = b[q].c[0]; }
+                    plonk_run(driver, z, tau, pub, w, b, upto, PlonkOut{(uint64_t*)((uint8_t*)out_commits + (size_t)i * 9 * psz), out_challenges ? out_challenges + i * 20 : nullptr,
+                                                                        out_evals ? out_evals + i * 24 : nullptr, nullptr, nullptr});
+                    driver.free_vec(w);
+                }
+                cg_ctx_destroy(ctx);
+            } catch (const std::exception& e) { errs[i] = e.what(); if (ctx) cg_ctx_destroy(ctx); }
+        });
+        for (auto& x : th) x.join();
+        cg_bases_release(tau);
+        cg_ctx_destroy(ctx0);
+        for (int i = 0; i < n; i++) if (!errs[i].empty()) { g_host_err = "party " + std::to_string(i) + ": " + errs[i]; return 1; }
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }

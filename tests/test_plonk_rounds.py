@@ -252,3 +252,25 @@ def test_gpu_rep3_all_rounds_match_plain_oracle(curve_name):
         got = cg.plonk_prove_rep3(curve, zp, w[:npub + 1], wa, wb, [det, zero, zero], [zero, det, zero], streams, upto=5)
         for party in range(3):
             check_against_reference_kats(got[party])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name,n,t", [("bn254", 3, 1), ("bls12_381", 3, 1), ("bn254", 5, 2)])
+def test_gpu_shamir_all_rounds_match_plain_oracle(curve_name, n, t):
+    """n Shamir parties (threshold t): double-sharing generation, degree reduction after every product, array_prod_mul / inv_many /
+    mul_open_many with 2t + 1 shares, openings "in circles" — every party must report the plain oracle's values for the opened blinding"""
+    ensure_built()
+    curve = CURVES[curve_name]
+    zp = fx(curve_name, "circuit.zkey")
+    npub = orc.plonk_zkey_info(curve, zp)["n_public"]
+    w = orc.read_wtns(curve, fx(curve_name, "witness.wtns"))
+    rng = np.random.default_rng(77 + n)
+    blind = orc.random_field(curve, FR, 11, rng)
+    wits = orc.shamir_share(curve, w[npub + 1:], n, t, rng)
+    blinds = orc.shamir_share(curve, blind, n, t, rng)
+    streams = [orc.random_field(curve, FR, 4 * 1024 * (1 + 3 * t) + 20000, rng) for _ in range(n)]
+    want = orc.plonk_prove_plain(curve, zp, w, blind, upto=5)
+    got = cg.plonk_prove_shamir(curve, zp, n, t, w[:npub + 1], wits, blinds, streams, upto=5)
+    for party in range(n):
+        for key in want:
+            np.testing.assert_array_equal(got[party][key], want[key], err_msg=f"party {party} {key}")
