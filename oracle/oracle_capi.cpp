@@ -357,6 +357,26 @@ int orc_plonk_prove_plain(int curve, const char* path, const uint64_t* full_witn
     return 0;
 }
 
+// Plonk verifier with the verifying key of the zkey: commits = 9 packed G1, evals = 6 Fr, pub = n_pub Fr.  1 = accept, 0 = reject.
+// vk_out (optional): 8 packed G1 (Qm, Ql, Qr, Qo, Qc, S1, S2, S3) | packed G2 X_2 | k1, k2 — to cross-check verification_key.json
+int orc_plonk_verify(int curve, const char* path, const uint64_t* commits, const uint64_t* evals, const uint64_t* pub, size_t n_pub, uint64_t* vk_out) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr; typedef typename C::Fq Fq;
+        auto z = read_plonk_zkey<C>(path);
+        if (vk_out) {
+            for (int i = 0; i < 8; i++) st_g1<Fq>(vk_out + i * 2 * Fq::N, z.vk_g1[i]);
+            st_g2<Fq>(vk_out + 16 * Fq::N, z.x_2);
+            st<Fr>(vk_out + 20 * Fq::N, z.k1); st<Fr>(vk_out + 20 * Fq::N + Fr::N, z.k2);
+        }
+        if (!commits) return 1;
+        AffineT<Fq> cm[9]; for (int i = 0; i < 9; i++) cm[i] = ld_g1<Fq>(commits + i * 2 * Fq::N);
+        Fr ev[6]; for (int i = 0; i < 6; i++) ev[i] = ld<Fr>(evals + i * Fr::N);
+        std::vector<Fr> pv(n_pub); for (size_t i = 0; i < n_pub; i++) pv[i] = ld<Fr>(pub + i * Fr::N);
+        return plonk_verify<C>(z, cm, ev, pv) ? 1 : 0;
+    });
+    return 0;
+}
+
 // ---- prover ------------------------------------------------------------------------------------------
 int orc_witness_map_plain(void* h, const uint64_t* full_witness, uint64_t* out_h) {
     ZK(h, {

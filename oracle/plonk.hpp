@@ -11,6 +11,7 @@
 #pragma once
 #include "formats.hpp"
 #include "ec.hpp"
+#include "pairing.hpp"
 
 namespace orc {
 
@@ -76,6 +77,7 @@ struct PlonkZKey {
     std::vector<AffineT<Fq>> p_tau;          // domain_size + 6 points (zkey.rs:149-151)
     Fr k1, k2;                                // verifying key (zkey.rs:328-356)
     AffineT<Fq> vk_g1[8];                     // qm, ql, qr, qo, qc, s1, s2, s3
+    AffineT<Fp2T<Fq>> x_2;                    // [tau]_2
     std::vector<Fr> sigma_eval[3];            // 4 * domain_size evaluations of sigma1..3 on the extended domain (section 12)
     std::vector<Fr> q_eval[5];                // qm, ql, qr, qo, qc on the extended domain (sections 7..11)
     std::vector<Fr> q_coef[5], sigma_coef[3]; // coefficient forms (round 5)
@@ -103,6 +105,7 @@ static PlonkZKey<C> read_plonk_zkey(const std::string& path) {
         while (((size_t)1 << z.power) < z.domain_size) z.power++;
         z.k1 = read_mont<Fr>(h); z.k2 = read_mont<Fr>(h);
         for (int i = 0; i < 8; i++) z.vk_g1[i] = read_g1<Fq>(h);
+        z.x_2 = read_g2<Fq>(h);
     }
     {   // section 12 = sigma1 | sigma2 | sigma3, each domain_size coefficients followed by 4 * domain_size evaluations (zkey.rs:170-180,116-135)
         Cursor c(sec(12));
@@ -385,5 +388,50 @@ struct PlonkPlainProver {
         commit_wxi = commit_poly(wxi); commit_wxiw = commit_poly(wxiw);
     }
 };
+
+// The verifier (co-plonk/src/plonk.rs:41-131 challenges, :133-271 checks), with the verifying key taken from the zkey header.
+// proof: nine commitments in the order a, b, c, z, t1, t2, t3, wxi, wxiw and the evaluations a, b, c, s1, s2, zw.
+template <class C>
+static bool plonk_verify(const PlonkZKey<C>& z, const AffineT<typename C::Fq>* cm, const typename C::Fr* ev, const std::vector<typename C::Fr>& public_inputs) {
+    typedef typename C::Fr Fr; typedef typename C::G1 G1;
+    if (public_inputs.size() != z.n_public) return false;
+    for (int i = 0; i < 9; i++) if (!cm[i].inf && !G1::on_curve(cm[i])) return false;
+    const Fr eval_a = ev[0], eval_b = ev[1], eval_c = ev[2], eval_s1 = ev[3], eval_s2 = ev[4], eval_zw = ev[5];
+    Fr beta, gamma, alpha, xi, v[5], u;
+    { PlonkTranscript<C> t; for (int i = 0; i < 8; i++) t.add_point(z.vk_g1[i]); for (const Fr& p : public_inputs) t.add_scalar(p); for (int i = 0; i < 3; i++) t.add_point(cm[i]); beta = t.get_challenge(); }
+    { PlonkTranscript<C> t; t.add_scalar(beta); gamma = t.get_challenge(); }
+    { PlonkTranscript<C> t; t.add_scalar(beta); t.add_scalar(gamma); t.add_point(cm[3]); alpha = t.get_challenge(); }
+    { PlonkTranscript<C> t; t.add_scalar(alpha); for (int i = 4; i < 7; i++) t.add_point(cm[i]); xi = t.get_challenge(); }
+    { PlonkTranscript<C> t; t.add_scalar(xi); for (int i = 0; i < 6; i++) t.add_scalar(ev[i]); v[0] = t.get_challenge(); for (int i = 1; i < 5; i++) v[i] = v[i - 1] * v[0]; }
+    { PlonkTranscript<C> t; t.add_point(cm[7]); t.add_point(cm[8]); u = t.get_challenge(); }
+    const Fr one = Fr::one();
+    const Fr omega = roots_of_unity<Fr>().roots[z.power];
+    Fr xin = xi; for (size_t i = 0; i < z.power; i++) xin = xin * xin;
+    const Fr zh = xin - one;
+    std::vector<Fr> l; { Fr wv = one; const Fr nn = Fr::from_u64((uint64_t)z.domain_size); for (size_t i = 0; i < std::max<size_t>(1, z.n_public); i++) { l.push_back(wv * zh * (nn * (xi - wv)).inverse()); wv = wv * omega; } }
+    Fr pi = Fr::zero(); for (size_t i = 0; i < public_inputs.size(); i++) pi = pi - l[i] * public_inputs[i];
+    // calculate_r0_d (:173-224)
+    const Fr e2 = alpha * alpha * l[0];
+    const Fr e3a = eval_a + eval_s1 * beta + gamma, e3b = eval_b + eval_s2 * beta + gamma;
+    const Fr r0 = pi - e2 - e3a * e3b * (eval_c + gamma) * eval_zw * alpha;
+    auto P = [&](int i) { return G1::from_affine(cm[i]); };
+    auto VK = [&](int i) { return G1::from_affine(z.vk_g1[i]); };
+    G1 d1 = scalar_mul(VK(0), eval_a * eval_b).add(scalar_mul(VK(1), eval_a)).add(scalar_mul(VK(2), eval_b)).add(scalar_mul(VK(3), eval_c)).add(VK(4));
+    const Fr betaxi = beta * xi;
+    const Fr d2a = (eval_a + betaxi + gamma) * (eval_b + betaxi * z.k1 + gamma) * (eval_c + betaxi * z.k2 + gamma) * alpha;
+    G1 d2 = scalar_mul(P(3), d2a + e2 + u);
+    G1 d3 = scalar_mul(VK(7), e3a * e3b * (alpha * beta * eval_zw));
+    G1 d4 = scalar_mul(P(4).add(scalar_mul(P(5), xin)).add(scalar_mul(P(6), xin * xin)), zh);
+    G1 d = d1.add(d2).add(d3.neg()).add(d4.neg());
+    const Fr e_s = v[0] * eval_a + v[1] * eval_b + v[2] * eval_c + v[3] * eval_s1 + v[4] * eval_s2 + u * eval_zw - r0;   // calculate_e (:226-239)
+    G1 e = scalar_mul(G1::from_affine(C::g1_generator()), e_s);
+    G1 f = d.add(scalar_mul(P(0), v[0])).add(scalar_mul(P(1), v[1])).add(scalar_mul(P(2), v[2])).add(scalar_mul(VK(5), v[3])).add(scalar_mul(VK(6), v[4]));   // calculate_f
+    // valid_pairing (:254-271): e(Wxi + u Wxiw, X_2) == e(xi Wxi + u xi omega Wxiw - E + F, G2)
+    G1 a1 = P(7).add(scalar_mul(P(8), u));
+    G1 b1 = scalar_mul(P(7), xi).add(scalar_mul(P(8), u * xi * omega)).add(e.neg()).add(f);
+    auto negp = [](typename G1::Affine a) { if (!a.inf) a.y = -a.y; return a; };
+    Fp12T<C> m = miller_tate<C>(a1.to_affine(), z.x_2) * miller_tate<C>(negp(b1.to_affine()), C::g2_generator());
+    return final_exp<C>(m) == Fp12T<C>::one();
+}
 
 }  // namespace orc

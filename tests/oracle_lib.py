@@ -443,3 +443,26 @@ def plonk_prove_plain(curve, path, full_witness, blind, upto=5, want_t=False):
     out = dict(zip(PLONK_COMMITS, commits)); out.update(zip(PLONK_CHALLENGES, ch)); out.update(zip(PLONK_EVALS, ev))
     if want_t: out.update(t1_poly=tp[:n + 1], t2_poly=tp[n + 1:2 * n + 2], t3_poly=tp[2 * n + 2:])
     return out
+
+
+def plonk_verify(curve, zkey_path, proof, pub):
+    """oracle Plonk verifier (co-plonk/src/plonk.rs:133-271), verifying key from the zkey header.  proof: dict with PLONK_COMMITS and PLONK_EVALS"""
+    commits = np.ascontiguousarray(np.stack([proof[k] for k in PLONK_COMMITS]), dtype=np.uint64)
+    evals = np.ascontiguousarray(np.stack([proof[k] for k in PLONK_EVALS]), dtype=np.uint64)
+    pub = np.ascontiguousarray(pub, dtype=np.uint64).reshape(-1, 4)
+    return bool(_chk(lib().orc_plonk_verify(curve, zkey_path.encode(), _p(commits), _p(evals), _p(pub), C.c_size_t(pub.shape[0]), None)))
+
+
+def plonk_zkey_vk(curve, zkey_path):
+    nq = nlimbs(curve, FQ)
+    out = np.zeros(20 * nq + 8, dtype=np.uint64)
+    _chk(lib().orc_plonk_verify(curve, zkey_path.encode(), None, None, None, C.c_size_t(0), _p(out)))
+    g1 = out[:16 * nq].reshape(8, 2 * nq)
+    return dict(zip(("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"), g1), X_2=out[16 * nq:20 * nq], k1=out[20 * nq:20 * nq + 4], k2=out[20 * nq + 4:])
+
+
+def plonk_proof_from_json(curve, path):
+    o = json.load(open(path))
+    d = {k: g1_from_json(curve, o[j]) for k, j in zip(PLONK_COMMITS, ("A", "B", "C", "Z", "T1", "T2", "T3", "Wxi", "Wxiw"))}
+    d.update({k: from_dec(curve, FR, o[k]) for k in PLONK_EVALS})
+    return d

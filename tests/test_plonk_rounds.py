@@ -126,6 +126,40 @@ def test_oracle_all_rounds_match_reference_kats():
     check_against_reference_kats(orc.plonk_prove_plain(BN254, fx("bn254", "circuit.zkey"), w, deterministic_blinding(BN254, 11), upto=5))
 
 
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_oracle_verifier_accepts_snarkjs_proofs(curve_name):
+    """pins the verifier (challenge derivation, linearisation, KZG pairing check) to proofs snarkjs produced: the reference verifies the
+    same files (co-plonk/src/plonk.rs:352-366); tampering with any element must be rejected; the zkey's verifying key equals
+    verification_key.json"""
+    curve = CURVES[curve_name]
+    zp = fx(curve_name, "circuit.zkey")
+    proof = orc.plonk_proof_from_json(curve, fx(curve_name, "circom.proof"))
+    pub = orc.public_from_json(curve, fx(curve_name, "public.json"))
+    assert orc.plonk_verify(curve, zp, proof, pub)
+    vkj = json.load(open(fx(curve_name, "verification_key.json")))
+    vk = orc.plonk_zkey_vk(curve, zp)
+    for key in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"):
+        np.testing.assert_array_equal(vk[key], orc.g1_from_json(curve, vkj[key]), err_msg=key)
+    np.testing.assert_array_equal(vk["X_2"], orc.g2_from_json(curve, vkj["X_2"]))
+    np.testing.assert_array_equal(vk["k1"], orc.from_dec(curve, FR, vkj["k1"])); np.testing.assert_array_equal(vk["k2"], orc.from_dec(curve, FR, vkj["k2"]))
+    for key in ("eval_a", "eval_zw"):
+        bad = dict(proof); bad[key] = orc.field_op(curve, FR, "add", proof[key][None, :], orc.from_dec(curve, FR, "1")[None, :])[0]
+        assert not orc.plonk_verify(curve, zp, bad, pub)
+    bad = dict(proof); bad["wxi"] = proof["wxiw"]
+    assert not orc.plonk_verify(curve, zp, bad, pub)
+    assert not orc.plonk_verify(curve, zp, proof, pub[::-1].copy())
+
+
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_oracle_prover_output_verifies(curve_name):
+    curve = CURVES[curve_name]
+    zp = fx(curve_name, "circuit.zkey")
+    w = orc.read_wtns(curve, fx(curve_name, "witness.wtns"))
+    npub = orc.plonk_zkey_info(curve, zp)["n_public"]
+    proof = orc.plonk_prove_plain(curve, zp, w, orc.random_field(curve, FR, 11, np.random.default_rng(8)), upto=5)
+    assert orc.plonk_verify(curve, zp, proof, w[1:npub + 1])
+
+
 def test_host_plonk_zkey_reader_matches_oracle():
     ensure_built()
     for name, curve in CURVES.items():
@@ -222,6 +256,8 @@ def test_gpu_all_rounds_match_oracle(curve_name):
     got = cg.plonk_prove_plain(curve, zp, w, blind, upto=5, want_t=True)
     for key in want:
         np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+    npub = orc.plonk_zkey_info(curve, zp)["n_public"]
+    assert orc.plonk_verify(curve, zp, got, w[1:npub + 1])                            # the GPU's proof passes the (snarkjs-pinned) verifier
 
 
 @pytest.mark.gpu
