@@ -131,14 +131,16 @@ static ZKey read_zkey(int curve_id, const std::string& path) {
         struct E { uint32_t m, row, sig; Fr v; };
         std::vector<E> es(ncoef);
         uint32_t max_row = 0;
-        const Fr raw_one = {{1, 0, 0, 0}};
-        for (auto& e : es) {
+        std::vector<Fr> disk(ncoef);
+        for (uint32_t i = 0; i < ncoef; i++) {
+            E& e = es[i];
             e.m = s.u32(); e.row = s.u32(); e.sig = s.u32();
-            Fr disk; s.bytes(disk.v, 32);
-            e.v = fr_mul(c, disk, raw_one);
+            s.bytes(disk[i].v, 32);
             if (e.m > 1) throw std::runtime_error("bad matrix id");
             if (e.row > max_row) max_row = e.row;
         }
+        // one Montgomery reduction per value (v R^2 -> v R), batched: Montgomery -> canonical IS that reduction
+        if (ncoef) { std::vector<Fr> dec(ncoef); CG(cg_fr_to_canonical(c.id, disk.data(), dec.data(), ncoef)); for (uint32_t i = 0; i < ncoef; i++) es[i].v = dec[i]; }
         z.num_constraints = (size_t)max_row - z.n_public;
         for (int m = 0; m < 2; m++) {
             z.row_ptr[m].assign(z.num_constraints + 1, 0);
