@@ -176,16 +176,17 @@ template <class Fn> int with_group(int curve, int group, Fn&& fn) {
 }
 
 // ------------------------------------------------------------------------------------------------ MSM
-// Window size: log2(n) - 5 (measured optimum ~128 entries per bucket), clamped to [3, 16], then nudged so that the TOP window is
-// nearly full.  With bits = c*q + t the top window has only t (+1 carry) bits: all n entries of that window fall into 2^t buckets,
-// which the chunked accumulation balances but whose continuation pieces are merged by few lanes (t = 2 at c = 14 or 18 costs
-// seconds).  Prefer the nearest c with t >= c - 3.
+// Window size of the classic path (one bucket set per window), measured on MI355X for both groups (scripts/sweep_classic_window.py):
+// what matters besides the add count is that the TOP window is nearly full — with bits = c*q + t it has only t (+1 carry) bits, all n
+// entries of that window fall into 2^t buckets, and a tiny t (c = 14: t = 2) leaves a few huge buckets whose pieces are merged by
+// few lanes.  c = 8 (t = 6), 13 (t = 7), 15 (t = 14) and 16 (t = 14) are the good choices for 254/255-bit scalars:
+//   n <= 2^12: 8   |   2^13: 13   |   2^14 .. 2^18: 15   |   larger: 16        (2^16 points: 1.75 ms at c = 15 against 5.7 ms at c = 8 or 11)
 int auto_window(size_t n, int bits) {
-    const int lg = log2_floor(n);
-    const int c0 = std::max(3, std::min(16, lg - 5));
-    auto ok = [&](int c) { const int t = bits % c; return t != 0 && t >= c - 3; };
-    for (int d : {0, 1, -1, 2, -2, 3, -3}) { const int c = c0 + d; if (c >= 3 && c <= 17 && ok(c)) return c; }
-    return c0;
+    const int lg = log2_floor(std::max<size_t>(n, 1));
+    int c = lg <= 12 ? 8 : lg == 13 ? 13 : lg <= 18 ? 15 : 16;
+    auto ok = [&](int w) { const int t = bits % w; return t != 0 && t >= w - 3 - (w >= 13 ? 6 : 0); };   // other scalar sizes: nudge to a window with a usable top
+    if (!ok(c)) for (int d : {1, -1, 2, -2, 3, -3}) { if (c + d >= 3 && c + d <= 17 && ok(c + d)) { c += d; break; } }
+    return c;
 }
 
 template <class F>
