@@ -540,6 +540,23 @@ def plonk_round1_rep3(curve, zkey_path, pub, wit_a, wit_b, blind_a, blind_b, dev
     return np.stack([np.stack([p["a"], p["b"], p["c"]]) for p in r])
 
 
+def host_plonk_proof_to_json(curve, proof):
+    """PlonkProof JSON text (circom-types/src/plonk/proof.rs) of a proof dict (PLONK_COMMITS + PLONK_EVALS keys)"""
+    commits = np.ascontiguousarray(np.stack([proof[k] for k in PLONK_COMMITS]), dtype=np.uint64)
+    evals = np.ascontiguousarray(np.stack([proof[k] for k in PLONK_EVALS]), dtype=np.uint64)
+    buf = C.create_string_buffer(8192)
+    _hchk(load_host().cgh_plonk_proof_to_json(curve, _hp(commits), _hp(evals), buf, C.c_size_t(8192)))
+    return buf.value.decode()
+
+
+def host_plonk_proof_from_json(curve, text):
+    nq = 6 if curve == BLS12_381 else 4
+    commits = np.zeros((9, 2 * nq), dtype=np.uint64); evals = np.zeros((6, 4), dtype=np.uint64)
+    _hchk(load_host().cgh_plonk_proof_from_json(curve, text.encode(), _hp(commits), _hp(evals)))
+    out = dict(zip(PLONK_COMMITS, commits)); out.update(zip(PLONK_EVALS, evals))
+    return out
+
+
 def host_plonk_transcript(curve, items):
     """items: list of ("scalar", limbs) / ("point", packed G1 limbs) -> challenge computed by the host mirror's Keccak256 transcript"""
     n = len(items)

@@ -1301,6 +1301,29 @@ static void proof_from_json(const Curve& c, const std::string& js, uint8_t* pack
     g1("pi_c", b + c.aff(CG_G2));
 }
 
+// PlonkProof <-> JSON (circom-types/src/plonk/proof.rs:8-74): nine G1 points A, B, C, Z, T1, T2, T3, Wxi, Wxiw, six evaluations, tags
+static const char* const PLONK_PT_KEYS[9] = {"A", "B", "C", "Z", "T1", "T2", "T3", "Wxi", "Wxiw"};
+static const char* const PLONK_EV_KEYS[6] = {"eval_a", "eval_b", "eval_c", "eval_s1", "eval_s2", "eval_zw"};
+static std::string plonk_proof_to_json(const Curve& c, const uint8_t* commits /* 9 packed G1 */, const Fr* evals /* 6 */) {
+    std::string js = "{";
+    for (int i = 0; i < 9; i++) js += std::string("\"") + PLONK_PT_KEYS[i] + "\":" + g1_json(c, commits + i * c.aff(CG_G1)) + ",";
+    for (int i = 0; i < 6; i++) { uint64_t can[4]; CG(cg_fr_to_canonical(c.id, evals[i].v, can, 1)); js += std::string("\"") + PLONK_EV_KEYS[i] + "\":\"" + limbs_to_dec(can, 4) + "\","; }
+    return js + "\"protocol\":\"plonk\",\"curve\":\"" + curve_name(c) + "\"}";
+}
+static void plonk_proof_from_json(const Curve& c, const std::string& js, uint8_t* commits, Fr* evals) {
+    if (js.find(std::string("\"") + curve_name(c) + "\"") == std::string::npos) throw std::runtime_error("proof is for another curve");
+    if (js.find("\"plonk\"") == std::string::npos) throw std::runtime_error("not a plonk proof");
+    const int nl = (int)c.fq() / 8;
+    for (int i = 0; i < 9; i++) {
+        auto v = json_numbers_after(js, PLONK_PT_KEYS[i], 3);
+        uint8_t* dst = commits + i * c.aff(CG_G1);
+        if (v[2] == "0") { memset(dst, 0, c.aff(CG_G1)); continue; }
+        if (v[2] != "1") throw std::runtime_error("only z = 1 / z = 0 G1 encodings are produced by circom tools");
+        for (int k = 0; k < 2; k++) { uint64_t can[6] = {0}; dec_to_limbs(v[k], can, nl); CG(cg_fq_from_canonical(c.id, can, dst + k * c.fq(), 1)); }
+    }
+    for (int i = 0; i < 6; i++) { auto v = json_numbers_after(js, PLONK_EV_KEYS[i], 1); uint64_t can[4] = {0}; dec_to_limbs(v[0], can, 4); CG(cg_fr_from_canonical(c.id, can, evals[i].v, 1)); }
+}
+
 }  // namespace cgh
 
 // ==================================================================================================== C entry points (tests / tools)
@@ -1348,6 +1371,14 @@ int32_t cgh_proof_to_json(int32_t curve, const uint64_t* proof, char* out, size_
 }
 int32_t cgh_proof_from_json(int32_t curve, const char* json, uint64_t* out_proof) {
     try { cgh::proof_from_json(cgh::Curve{curve}, json, (uint8_t*)out_proof); return 0; }
+    catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+int32_t cgh_plonk_proof_to_json(int32_t curve, const uint64_t* commits, const uint64_t* evals, char* out, size_t cap) {
+    try { return copy_out(cgh::plonk_proof_to_json(cgh::Curve{curve}, (const uint8_t*)commits, (const cgh::Fr*)evals), out, cap); }
+    catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+int32_t cgh_plonk_proof_from_json(int32_t curve, const char* json, uint64_t* out_commits, uint64_t* out_evals) {
+    try { cgh::plonk_proof_from_json(cgh::Curve{curve}, json, (uint8_t*)out_commits, (cgh::Fr*)out_evals); return 0; }
     catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
 // public.json (co-circom.rs:620-628): the public signals without the leading constant 1, as decimal strings; pub = n Montgomery elements

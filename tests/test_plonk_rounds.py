@@ -160,6 +160,21 @@ def test_oracle_prover_output_verifies(curve_name):
     assert orc.plonk_verify(curve, zp, proof, w[1:npub + 1])
 
 
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_host_plonk_proof_json_codec(curve_name):
+    """host mirror's PlonkProof JSON codec against the snarkjs files the reference deserialises (circom-types/src/plonk/proof.rs:84-140)"""
+    ensure_built()
+    curve = CURVES[curve_name]
+    text = open(fx(curve_name, "circom.proof")).read()
+    got = cg.host_plonk_proof_from_json(curve, text)
+    want = orc.plonk_proof_from_json(curve, fx(curve_name, "circom.proof"))
+    for key in want:
+        np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+    assert json.loads(cg.host_plonk_proof_to_json(curve, got)) == json.loads(text)
+    with pytest.raises(cg.BackendError):
+        cg.host_plonk_proof_from_json(BLS12_381 if curve == BN254 else BN254, text)
+
+
 def test_host_plonk_zkey_reader_matches_oracle():
     ensure_built()
     for name, curve in CURVES.items():
