@@ -540,6 +540,22 @@ def plonk_round1_rep3(curve, zkey_path, pub, wit_a, wit_b, blind_a, blind_b, dev
     return np.stack([np.stack([p["a"], p["b"], p["c"]]) for p in r])
 
 
+def host_shared_witness_write(curve, path, pub, a, b=None):
+    """`.shared` witness file (bincode + ark-compressed vectors): REP3 when b is given, Shamir otherwise.  Layout restated from the
+    reference's types; the snapshot holds no .shared fixture to pin it against."""
+    pub = np.ascontiguousarray(pub, dtype=np.uint64).reshape(-1, 4); a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    bb = None if b is None else np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    _hchk(load_host().cgh_shared_witness_write(curve, path.encode(), 0 if b is not None else 1, _hp(pub), C.c_size_t(pub.shape[0]), _hp(a), _hp(bb), C.c_size_t(a.shape[0])))
+
+
+def host_shared_witness_read(curve, path, rep3=True):
+    sizes = (C.c_size_t * 2)()
+    _hchk(load_host().cgh_shared_witness_read(curve, path.encode(), 0 if rep3 else 1, sizes, None, None, None))
+    pub = np.zeros((sizes[0], 4), dtype=np.uint64); a = np.zeros((sizes[1], 4), dtype=np.uint64); b = np.zeros((sizes[1], 4), dtype=np.uint64) if rep3 else None
+    _hchk(load_host().cgh_shared_witness_read(curve, path.encode(), 0 if rep3 else 1, sizes, _hp(pub), _hp(a), _hp(b)))
+    return (pub, a, b) if rep3 else (pub, a)
+
+
 def host_plonk_proof_to_json(curve, proof):
     """PlonkProof JSON text (circom-types/src/plonk/proof.rs) of a proof dict (PLONK_COMMITS + PLONK_EVALS keys)"""
     commits = np.ascontiguousarray(np.stack([proof[k] for k in PLONK_COMMITS]), dtype=np.uint64)

@@ -1301,6 +1301,48 @@ static void proof_from_json(const Curve& c, const std::string& js, uint8_t* pack
     g1("pi_c", b + c.aff(CG_G2));
 }
 
+// `.shared` witness files (co-circom.rs:330,400,449: `bincode::serialize_into(file, &SharedWitness)`).  Layout restated from the
+// types, NOT pinned by a reference fixture (the snapshot ships no .shared file):
+//   SharedWitness { public_inputs, witness } with both fields going through serde_compat::ark_se (co-circom-snarks/src/lib.rs:24-41,
+//   serde_compat.rs:5-13) = serialize_bytes(ark-compressed value) = u64 LE byte length, then the bytes;
+//   ark-compressed Vec<F> = u64 LE element count, then 32-byte canonical little-endian field elements;
+//   Rep3PrimeFieldShareVec { a, b } (rep3/fieldshare.rs:232-236) = Vec a then Vec b; ShamirPrimeFieldShareVec { a } (shamir/fieldshare.rs:152-155) = Vec a.
+static void put_u64(Bytes& o, uint64_t v) { for (int i = 0; i < 8; i++) o.push_back((uint8_t)(v >> (8 * i))); }
+static void put_vec(const Curve& c, Bytes& o, const Fr* v, size_t n) {
+    put_u64(o, n);
+    std::vector<Fr> can(n); if (n) CG(cg_fr_to_canonical(c.id, v, can.data(), n));
+    const uint8_t* p = (const uint8_t*)can.data(); o.insert(o.end(), p, p + n * 32);
+}
+static std::vector<Fr> get_vec(const Curve& c, Cursor& cur) {
+    const uint64_t n = cur.u64(); cur.need(n * 32);
+    std::vector<Fr> raw(n), out(n); cur.bytes(raw.data(), n * 32);
+    for (const Fr& e : raw) { for (int l = 3; l >= 0; l--) { if (e.v[l] < MOD_R[c.id][l]) break; if (e.v[l] > MOD_R[c.id][l] || l == 0) throw std::runtime_error("invalid data: field element not reduced"); } }
+    if (n) CG(cg_fr_from_canonical(c.id, raw.data(), out.data(), n));
+    return out;
+}
+static void write_shared_witness(const Curve& c, const std::string& path, const std::vector<Fr>& pub, const std::vector<Fr>& a, const std::vector<Fr>* b) {
+    Bytes f1, f2, out;
+    put_vec(c, f1, pub.data(), pub.size());
+    put_vec(c, f2, a.data(), a.size()); if (b) put_vec(c, f2, b->data(), b->size());
+    put_u64(out, f1.size()); out.insert(out.end(), f1.begin(), f1.end());
+    put_u64(out, f2.size()); out.insert(out.end(), f2.begin(), f2.end());
+    FILE* f = fopen(path.c_str(), "wb"); if (!f) throw std::runtime_error("cannot open " + path);
+    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size(); fclose(f);
+    if (!ok) throw std::runtime_error("short write " + path);
+}
+static void read_shared_witness(const Curve& c, const std::string& path, bool rep3, std::vector<Fr>& pub, std::vector<Fr>& a, std::vector<Fr>& b) {
+    Bytes buf = slurp(path);
+    Cursor cur{buf.data(), buf.size()};
+    const uint64_t l1 = cur.u64(); cur.need(l1);
+    { Cursor f{buf.data() + cur.off, (size_t)l1}; pub = get_vec(c, f); if (f.off != l1) throw std::runtime_error("trailing bytes in public_inputs"); }
+    cur.off += l1;
+    const uint64_t l2 = cur.u64(); cur.need(l2);
+    { Cursor f{buf.data() + cur.off, (size_t)l2}; a = get_vec(c, f); if (rep3) b = get_vec(c, f); if (f.off != l2) throw std::runtime_error("witness share does not match the protocol (REP3 has two vectors, Shamir one)"); }
+    cur.off += l2;
+    if (cur.off != buf.size()) throw std::runtime_error("trailing bytes after the shared witness");
+    if (rep3 && a.size() != b.size()) throw std::runtime_error("REP3 share components differ in length");
+}
+
 // PlonkProof <-> JSON (circom-types/src/plonk/proof.rs:8-74): nine G1 points A, B, C, Z, T1, T2, T3, Wxi, Wxiw, six evaluations, tags
 static const char* const PLONK_PT_KEYS[9] = {"A", "B", "C", "Z", "T1", "T2", "T3", "Wxi", "Wxiw"};
 static const char* const PLONK_EV_KEYS[6] = {"eval_a", "eval_b", "eval_c", "eval_s1", "eval_s2", "eval_zw"};
@@ -1380,6 +1422,29 @@ int32_t cgh_plonk_proof_to_json(int32_t curve, const uint64_t* commits, const ui
 int32_t cgh_plonk_proof_from_json(int32_t curve, const char* json, uint64_t* out_commits, uint64_t* out_evals) {
     try { cgh::plonk_proof_from_json(cgh::Curve{curve}, json, (uint8_t*)out_commits, (cgh::Fr*)out_evals); return 0; }
     catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+// .shared witness files; protocol: 0 = REP3 (components a, b), 1 = Shamir (a only).  All values Montgomery on this side of the call.
+int32_t cgh_shared_witness_write(int32_t curve, const char* path, int32_t protocol, const uint64_t* pub, size_t n_pub, const uint64_t* a, const uint64_t* b, size_t n) {
+    try {
+        using namespace cgh;
+        std::vector<Fr> p((const Fr*)pub, (const Fr*)pub + n_pub), va((const Fr*)a, (const Fr*)a + n), vb;
+        if (protocol == 0) vb.assign((const Fr*)b, (const Fr*)b + n);
+        write_shared_witness(Curve{curve}, path, p, va, protocol == 0 ? &vb : nullptr);
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+// sizes[0] = n_pub, sizes[1] = n; with out buffers NULL only the sizes are returned
+int32_t cgh_shared_witness_read(int32_t curve, const char* path, int32_t protocol, size_t* sizes, uint64_t* pub, uint64_t* a, uint64_t* b) {
+    try {
+        using namespace cgh;
+        std::vector<Fr> p, va, vb;
+        read_shared_witness(Curve{curve}, path, protocol == 0, p, va, vb);
+        sizes[0] = p.size(); sizes[1] = va.size();
+        if (pub) memcpy(pub, p.data(), p.size() * 32);
+        if (a) memcpy(a, va.data(), va.size() * 32);
+        if (b && protocol == 0) memcpy(b, vb.data(), vb.size() * 32);
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
 // public.json (co-circom.rs:620-628): the public signals without the leading constant 1, as decimal strings; pub = n Montgomery elements
 int32_t cgh_public_to_json(int32_t curve, const uint64_t* pub, size_t n, char* out, size_t cap) {
