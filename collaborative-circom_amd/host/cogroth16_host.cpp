@@ -214,6 +214,8 @@ struct InProcHub {
     std::mutex mu; std::condition_variable cv;
     std::deque<Bytes> q[3];    // q[i] = messages travelling from party i to party i+1
     std::deque<Bytes> qb[3];   // qb[i] = messages travelling from party i to party i-1
+    bool failed = false;       // a party died: wake everybody up instead of waiting for messages that will never come
+    void abort() { { std::lock_guard<std::mutex> l(mu); failed = true; } cv.notify_all(); }
 };
 struct InProcNetwork : Rep3Network {
     InProcHub* hub; int me;
@@ -226,7 +228,8 @@ struct InProcNetwork : Rep3Network {
     void recv_prev(void* data, size_t bytes) override {
         const int from = (me + 2) % 3;
         std::unique_lock<std::mutex> l(hub->mu);
-        hub->cv.wait(l, [&] { return !hub->q[from].empty(); });
+        hub->cv.wait(l, [&] { return !hub->q[from].empty() || hub->failed; });
+        if (hub->q[from].empty()) throw std::runtime_error("another party failed");
         Bytes m = std::move(hub->q[from].front()); hub->q[from].pop_front();
         if (m.size() != bytes) throw std::runtime_error("During execution of MPC: invalid number of bytes received");   // rep3.rs:663-668
         memcpy(data, m.data(), bytes);
@@ -238,7 +241,8 @@ struct InProcNetwork : Rep3Network {
     void recv_next(void* data, size_t bytes) override {
         const int from = (me + 1) % 3;
         std::unique_lock<std::mutex> l(hub->mu);
-        hub->cv.wait(l, [&] { return !hub->qb[from].empty(); });
+        hub->cv.wait(l, [&] { return !hub->qb[from].empty() || hub->failed; });
+        if (hub->qb[from].empty()) throw std::runtime_error("another party failed");
         Bytes m = std::move(hub->qb[from].front()); hub->qb[from].pop_front();
         if (m.size() != bytes) throw std::runtime_error("During execution of MPC: invalid number of bytes received");
         memcpy(data, m.data(), bytes);
@@ -257,7 +261,9 @@ struct InProcShamirHub {
     int n;
     std::mutex mu; std::condition_variable cv;
     std::vector<std::deque<Bytes>> q;   // q[from * n + to]
+    bool failed = false;
     explicit InProcShamirHub(int n_) : n(n_), q((size_t)n_ * n_) {}
+    void abort() { { std::lock_guard<std::mutex> l(mu); failed = true; } cv.notify_all(); }
 };
 struct InProcShamirNet : ShamirNet {
     InProcShamirHub* hub; int me;
@@ -271,7 +277,8 @@ struct InProcShamirNet : ShamirNet {
     void recv(int from, void* data, size_t bytes) override {
         std::unique_lock<std::mutex> l(hub->mu);
         auto& qq = hub->q[(size_t)from * hub->n + me];
-        hub->cv.wait(l, [&] { return !qq.empty(); });
+        hub->cv.wait(l, [&] { return !qq.empty() || hub->failed; });
+        if (qq.empty()) throw std::runtime_error("another party failed");
         Bytes m = std::move(qq.front()); qq.pop_front();
         if (m.size() != bytes) throw std::runtime_error("During execution of MPC: Invalid number of elements received");   // shamir.rs:324-329
         memcpy(data, m.data(), bytes);
@@ -1370,6 +1377,14 @@ static void plonk_proof_from_json(const Curve& c, const std::string& js, uint8_t
 
 // ==================================================================================================== C entry points (tests / tools)
 static thread_local std::string g_host_err;
+// first real failure among the parties (the others only report that somebody else died)
+template <class Errs> static bool report_party_errors(const Errs& errs, int n) {
+    int pick = -1;
+    for (int i = 0; i < n; i++) if (!errs[i].empty() && (pick < 0 || (errs[pick] == "another party failed" && errs[i] != "another party failed"))) pick = i;
+    if (pick < 0) return false;
+    g_host_err = "party " + std::to_string(pick) + ": " + errs[pick];
+    return true;
+}
 extern "C" {
 
 const char* cgh_last_error(void) { return g_host_err.c_str(); }
@@ -1490,12 +1505,12 @@ int32_t cgh_prove_shamir(int32_t device, int32_t curve, const char* zkey_path, i
                 if (out_h && i == 0) CG(cg_dev_download(ctx, out_h, h.c[0], h.n * 32));
                 driver.free_vec(h); driver.free_vec(w);
                 cg_ctx_destroy(ctx);
-            } catch (const std::exception& e) { errs[i] = e.what(); if (ctx) cg_ctx_destroy(ctx); }
+            } catch (const std::exception& e) { errs[i] = e.what(); hub.abort(); if (ctx) cg_ctx_destroy(ctx); }
         });
         for (auto& x : th) x.join();
         release_zkey(ctx0, dz);
         cg_ctx_destroy(ctx0);
-        for (int i = 0; i < n; i++) if (!errs[i].empty()) { g_host_err = "party " + std::to_string(i) + ": " + errs[i]; return 1; }
+        if (report_party_errors(errs, n)) return 1;
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
@@ -1607,12 +1622,12 @@ int32_t cgh_plonk_prove_shamir(int32_t device, int32_t curve, const char* zkey_p
                     driver.free_vec(w);
                 }
                 cg_ctx_destroy(ctx);
-            } catch (const std::exception& e) { errs[i] = e.what(); if (ctx) cg_ctx_destroy(ctx); }
+            } catch (const std::exception& e) { errs[i] = e.what(); hub.abort(); if (ctx) cg_ctx_destroy(ctx); }
         });
         for (auto& x : th) x.join();
         cg_bases_release(tau);
         cg_ctx_destroy(ctx0);
-        for (int i = 0; i < n; i++) if (!errs[i].empty()) { g_host_err = "party " + std::to_string(i) + ": " + errs[i]; return 1; }
+        if (report_party_errors(errs, n)) return 1;
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
@@ -1650,12 +1665,12 @@ int32_t cgh_plonk_prove_rep3(int32_t device, int32_t curve, const char* zkey_pat
                     driver.free_vec(wit);
                 }
                 cg_ctx_destroy(ctx);
-            } catch (const std::exception& e) { errs[i] = e.what(); if (ctx) cg_ctx_destroy(ctx); }
+            } catch (const std::exception& e) { errs[i] = e.what(); hub.abort(); if (ctx) cg_ctx_destroy(ctx); }
         });
         for (auto& t : th) t.join();
         cg_bases_release(tau);
         cg_ctx_destroy(ctx0);
-        for (int i = 0; i < 3; i++) if (!errs[i].empty()) { g_host_err = "party " + std::to_string(i) + ": " + errs[i]; return 1; }
+        if (report_party_errors(errs, 3)) return 1;
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
@@ -1721,12 +1736,12 @@ int32_t cgh_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, con
                 if (out_h && i == 0) { CG(cg_dev_download(ctx, out_h, h.c[0], h.n * 32)); CG(cg_dev_download(ctx, out_h + h.n * 4, h.c[1], h.n * 32)); }
                 driver.free_vec(h); driver.free_vec(wit);
                 cg_ctx_destroy(ctx);
-            } catch (const std::exception& e) { errs[i] = e.what(); if (ctx) cg_ctx_destroy(ctx); }
+            } catch (const std::exception& e) { errs[i] = e.what(); hub.abort(); if (ctx) cg_ctx_destroy(ctx); }
         });
         for (auto& t : th) t.join();
         release_zkey(ctx0, dz);
         cg_ctx_destroy(ctx0);
-        for (int i = 0; i < 3; i++) if (!errs[i].empty()) { g_host_err = "party " + std::to_string(i) + ": " + errs[i]; return 1; }
+        if (report_party_errors(errs, 3)) return 1;
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }

@@ -190,3 +190,17 @@ def test_shared_witness_files_round_trip(curve_name, tmp_path):
     pb.write_bytes(raw + b"\x00")
     with pytest.raises(cg.BackendError):
         cg.host_shared_witness_read(curve, str(pb), rep3=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(120)
+def test_party_failure_is_reported_not_deadlocked():
+    """a party that runs out of randomness mid-protocol must make the whole call fail with ITS error; the peers blocked in recv are woken"""
+    ensure_built()
+    curve = BN254
+    z = orc.ZKey(curve, fx("bn254", "poseidon", "circuit.zkey")); w = orc.read_wtns(curve, fx("bn254", "poseidon", "witness.wtns"))
+    rng = np.random.default_rng(3)
+    wa, wb = rep3_share(curve, w[z.n_public + 1:], rng)
+    streams = [orc.random_field(curve, FR, 300, rng) for _ in range(3)]          # needs 2 * 256 + 4
+    with pytest.raises(cg.BackendError, match="randomness stream exhausted"):
+        cg.prove_rep3(curve, fx("bn254", "poseidon", "circuit.zkey"), w[:z.n_public + 1], wa, wb, streams)
