@@ -26,7 +26,6 @@ template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool 
 template <class F> int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c);
 template <class F> int check_on_curve_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, const F& b, unsigned long long* d_counters);
 template <class F, class Fr> int check_subgroup_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, unsigned long long* d_counters);
-constexpr int MSM_SHARED_GROUPS = 16;
 inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) {   // must match fr_impl.hpp
     const size_t nbuckets = (size_t)nwin << (c - 1);
     const size_t entries = (size_t)nwin * n;
@@ -71,6 +70,7 @@ struct MsmTicket {
     const cg_bases* bases = nullptr; size_t offset = 0, n = 0; std::vector<const void*> scalars;
     int nsums = 0;            // partial sums per component delivered by the GPU
     bool plain_fold = false;  // true: add them (precomputed tables); false: Horner with c doublings (classic)
+    bool bit_fold = false;    // the sums are the per-bit sums T_k of a small shared bucket set: Horner with ONE doubling per step
     void* h_pinned = nullptr; size_t pinned_bytes = 0;   // k * nwin window sums (XYZZ)
     hipEvent_t done = nullptr;
 };
@@ -247,7 +247,8 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
             if (want <= 4096.0) { cap = 16; while ((double)cap < want) cap <<= 1; }
         }
     }
-    const int nsums = shared ? ((((size_t)1 << (c - 1)) / std::max<size_t>(1, ((size_t)1 << (c - 1)) / 32768)) >= (size_t)MSM_SHARED_GROUPS ? MSM_SHARED_GROUPS : 1) : nwin;
+    const MsmGeom geom = msm_geom(std::max<size_t>(n, 1), c, nwin, shared);
+    const int nsums = geom.ngroups;
     // tickets + pinned result buffers
     std::vector<int> slots(nb);
     size_t acc_bytes = 0;
@@ -255,7 +256,7 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
         slots[b] = ticket_slot(ctx);
         MsmTicket& t = ctx->tickets[slots[b]];
         t.live = true;   // reserve before asking for the next slot
-        t.curve = curve; t.group = bases[b]->group; t.k = k; t.c = c; t.nwin = nwin; t.nsums = nsums; t.plain_fold = shared;
+        t.curve = curve; t.group = bases[b]->group; t.k = k; t.c = c; t.nwin = nwin; t.nsums = nsums; t.plain_fold = shared && !geom.bitsum; t.bit_fold = geom.bitsum;
         t.optimistic = cap != 0; t.bases = bases[b]; t.offset = offsets ? offsets[b] : 0; t.n = n; t.scalars.assign(d_scalars, d_scalars + (n ? k : 0));
         if (!t.h_flags) HIPCHK(hipHostMalloc((void**)&t.h_flags, 8 * sizeof(uint32_t), hipHostMallocDefault));
         for (int i = 0; i < 8; i++) t.h_flags[i] = 0;
@@ -365,7 +366,11 @@ int msm_end_impl(cg_ctx* ctx, int ticket, void* h_out) {
         Jacobian<F>* out = (Jacobian<F>*)h_out;
         for (int j = 0; j < t.k; j++) {
             Jacobian<F> r;
-            if (t.plain_fold) { XYZZ<F> acc = h[(size_t)j * t.nsums]; for (int i = 1; i < t.nsums; i++) acc = xyzz_add(acc, h[(size_t)j * t.nsums + i]); r = xyzz_to_jacobian(acc); }
+            if (t.bit_fold) {                                   // sum_k 2^k T_k
+                XYZZ<F> acc = h[(size_t)j * t.nsums + t.nsums - 1];
+                for (int i = t.nsums - 2; i >= 0; i--) acc = xyzz_add(xyzz_dbl(acc), h[(size_t)j * t.nsums + i]);
+                r = xyzz_to_jacobian(acc);
+            } else if (t.plain_fold) { XYZZ<F> acc = h[(size_t)j * t.nsums]; for (int i = 1; i < t.nsums; i++) acc = xyzz_add(acc, h[(size_t)j * t.nsums + i]); r = xyzz_to_jacobian(acc); }
             else r = msm_fold_windows<F>(h + (size_t)j * t.nsums, t.nsums, t.c);
             memcpy(out + j, &r, sizeof r);
         }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include "cogroth16_hip.h"
@@ -22,5 +23,39 @@ constexpr int GRID_CAP = 2048;   // grid-stride kernels: 256 CUs x 8 workgroups
 inline int grid_for(size_t n, int block = 256) { size_t g = (n + block - 1) / block; return (int)std::min<size_t>(std::max<size_t>(g, 1), GRID_CAP); }
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int log2_floor(size_t n) { int l = 0; while (((size_t)2 << l) <= n) l++; return l; }
+
+// ---- MSM launch geometry: shared by the kernel launchers (msm_impl.hpp) and the host-side planner (capi.hip) --------------------------
+constexpr int BITSUM_ITEMS = 8;   // buckets per lane in k_msm_bitsum_partial
+struct MsmGeom {            // derived sizes shared by the host-side planner and the launchers
+    uint32_t nb;            // buckets per bucket set = 2^(c-1)
+    int nsets;              // bucket sets: nwin (classic) or 1 (shared: per-window precomputed tables)
+    size_t nbuckets;        // nsets * nb
+    uint32_t seg_len, segs; // bucket-reduction segments per bucket set
+    int ngroups;            // partial sums handed to the host: nwin window sums (classic) or 16 plain groups (shared)
+    uint32_t group_segs;    // segments summed per group
+    uint32_t chunk_len, nchunks;
+    bool bitsum;            // small shared bucket set: per-bit tree sums instead of the running-sum chain (ngroups = c bit sums)
+    uint32_t bit_groups;    // workgroups per bit in k_msm_bitsum_partial
+};
+constexpr int MSM_SHARED_GROUPS = 16;
+inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared) {
+    MsmGeom g;
+    g.nb = 1u << (c - 1);
+    g.nsets = shared ? 1 : nwin;
+    g.nbuckets = (size_t)g.nsets * g.nb;
+    const uint32_t want_segs = shared ? 32768u : 2048u;      // ~32k serial chains in total either way
+    g.seg_len = std::max<uint32_t>(1, g.nb / want_segs);
+    g.segs = g.nb / g.seg_len;
+    g.ngroups = shared ? (g.segs >= (uint32_t)MSM_SHARED_GROUPS ? MSM_SHARED_GROUPS : 1) : nwin;
+    g.group_segs = shared ? g.segs / g.ngroups : g.segs;
+    g.bitsum = shared && g.nb <= (1u << 16) && g.nb >= 4096;
+    g.bit_groups = std::max<uint32_t>(1, (g.nb / 2 + 256 * BITSUM_ITEMS - 1) / (256 * BITSUM_ITEMS));
+    if (g.bitsum) g.ngroups = c;
+    const size_t entries = (size_t)nwin * n;
+    static const size_t chunk_max = [] { const char* e = getenv("CG_MSM_CHUNK"); return e ? (size_t)atoi(e) : (size_t)128; }();   // tuning knob
+    g.chunk_len = (uint32_t)std::min<size_t>(chunk_max, std::max<size_t>(8, entries / (256 * 1024)));
+    g.nchunks = (uint32_t)std::max<size_t>(1, (entries + g.chunk_len - 1) / g.chunk_len);
+    return g;
+}
 
 }  // namespace cg

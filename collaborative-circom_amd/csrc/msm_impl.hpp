@@ -8,38 +8,12 @@
 
 namespace cg {
 
-struct MsmGeom {            // derived sizes shared by the host-side planner and the launchers
-    uint32_t nb;            // buckets per bucket set = 2^(c-1)
-    int nsets;              // bucket sets: nwin (classic) or 1 (shared: per-window precomputed tables)
-    size_t nbuckets;        // nsets * nb
-    uint32_t seg_len, segs; // bucket-reduction segments per bucket set
-    int ngroups;            // partial sums handed to the host: nwin window sums (classic) or 16 plain groups (shared)
-    uint32_t group_segs;    // segments summed per group
-    uint32_t chunk_len, nchunks;
-};
-constexpr int MSM_SHARED_GROUPS = 16;
-inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared) {
-    MsmGeom g;
-    g.nb = 1u << (c - 1);
-    g.nsets = shared ? 1 : nwin;
-    g.nbuckets = (size_t)g.nsets * g.nb;
-    const uint32_t want_segs = shared ? 32768u : 2048u;      // ~32k serial chains in total either way
-    g.seg_len = std::max<uint32_t>(1, g.nb / want_segs);
-    g.segs = g.nb / g.seg_len;
-    g.ngroups = shared ? (g.segs >= (uint32_t)MSM_SHARED_GROUPS ? MSM_SHARED_GROUPS : 1) : nwin;
-    g.group_segs = shared ? g.segs / g.ngroups : g.segs;
-    const size_t entries = (size_t)nwin * n;
-    static const size_t chunk_max = [] { const char* e = getenv("CG_MSM_CHUNK"); return e ? (size_t)atoi(e) : (size_t)128; }();   // tuning knob
-    g.chunk_len = (uint32_t)std::min<size_t>(chunk_max, std::max<size_t>(8, entries / (256 * 1024)));
-    g.nchunks = (uint32_t)std::max<size_t>(1, (entries + g.chunk_len - 1) / g.chunk_len);
-    return g;
-}
 template <class F>
 size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared) {
     const MsmGeom g = msm_geom(n, c, nwin, shared);
     typedef typename BucketOf<F>::type B;
     return align_up(g.nbuckets * sizeof(B)) + align_up((size_t)g.nchunks * sizeof(B)) + align_up((size_t)g.nchunks * 4) +
-           align_up((size_t)g.nsets * g.segs * sizeof(B)) + align_up((size_t)g.ngroups * sizeof(XYZZ<F>));
+           align_up(std::max((size_t)g.nsets * g.segs, (size_t)64 * g.bit_groups) * sizeof(B)) + align_up((size_t)std::max(g.ngroups, 64) * sizeof(XYZZ<F>));
 }
 
 // buckets -> window sums for one (bases, sorted schedule) pair; the nwin window sums land in h_out (pinned) via an async copy.
@@ -58,8 +32,8 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     B* buckets = (B*)take(g.nbuckets * sizeof(B));
     B* cont = (B*)take((size_t)g.nchunks * sizeof(B));
     uint32_t* cont_bucket = (uint32_t*)take((size_t)g.nchunks * 4);
-    B* partials = (B*)take((size_t)g.nsets * g.segs * sizeof(B));
-    XYZZ<F>* wsums = (XYZZ<F>*)take((size_t)g.ngroups * sizeof(XYZZ<F>));
+    B* partials = (B*)take(std::max((size_t)g.nsets * g.segs, (size_t)64 * g.bit_groups) * sizeof(B));
+    XYZZ<F>* wsums = (XYZZ<F>*)take((size_t)std::max(g.ngroups, 64) * sizeof(XYZZ<F>));
     if (evs) HIPCHK(hipEventRecord(evs[0], st));
     HIPCHK(hipMemsetAsync(buckets, 0, g.nbuckets * sizeof(B), st));                // all-zero = infinity (empty buckets are never written)
     auto launch_acc = [&](auto kern, int T, size_t lds) -> int {
@@ -84,6 +58,21 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     HIPCHK(hipEventRecord(ev_acc, st));
     HIPCHK(hipStreamWaitEvent(st2, ev_acc, 0));
     if (evs) HIPCHK(hipEventRecord(evs[2], st2));
+    if (g.bitsum) {
+        static bool attr_set2 = false;
+        if (!attr_set2) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_msm_bitsum_partial<B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * sizeof(B))));
+            HIPCHK(hipFuncSetAttribute((const void*)k_msm_bitsum_final<F, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * sizeof(B))));
+            attr_set2 = true;
+        }
+        hipLaunchKernelGGL((k_msm_bitsum_partial<B>), dim3((unsigned)(c * g.bit_groups)), dim3(256), 256 * sizeof(B), st2, buckets, g.nb, g.bit_groups, partials);
+        hipLaunchKernelGGL((k_msm_bitsum_final<F, B>), dim3((unsigned)c), dim3(64), 64 * sizeof(B), st2, partials, g.bit_groups, wsums);
+        if (evs) HIPCHK(hipEventRecord(evs[3], st2));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_out, wsums, (size_t)c * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st2));
+        HIPCHK(hipEventRecord(ev_red, st2));
+        return 0;
+    }
     const size_t nseg_threads = (size_t)g.nsets * g.segs;
     hipLaunchKernelGGL((k_msm_reduce_segments<B>), dim3((unsigned)((nseg_threads + 63) / 64)), dim3(64), 0, st2, buckets, g.nb, g.seg_len, g.nsets, partials);
     constexpr int WT = sizeof(B) > 160 ? 128 : 256;

@@ -570,6 +570,53 @@ __global__ void __launch_bounds__(THREADS) k_msm_window_sum(const B* __restrict_
     if (threadIdx.x == 0) st_struct(window_sums + blockIdx.x, bk_to_xyzz<F>(sh[0]));
 }
 
+// Bucket reduction for SMALL bucket sets (shared bucket set with <= 2^16 buckets: shards of a multi-GPU plan, 2^16-constraint
+// circuits), where the running-sum kernels above are a chain of ~45 dependent point additions on a handful of waves and that
+// latency, not the work, is the whole cost of the MSM.  sum_w w B_{w-1} = sum_k 2^k T_k with T_k = sum of the buckets whose
+// weight w has bit k set: c plain sums, each a log-depth tree, ~c/2 additions per bucket in total (nothing at this size).
+//   k_msm_bitsum_partial: workgroup (k, g): 256 lanes x BITSUM_ITEMS buckets with bit k set, serial per lane + LDS tree
+//   k_msm_bitsum_final:   one wave per bit folds the G workgroup results into T_k (canonical XYZZ for the host)
+// The host finishes with one Horner pass over the c sums (one doubling per bit).
+template <class B>
+__global__ void __launch_bounds__(256) k_msm_bitsum_partial(const B* __restrict__ buckets, uint32_t nb, uint32_t groups, B* __restrict__ partials) {
+    extern __shared__ uint4 lds_raw[];
+    B* sh = reinterpret_cast<B*>(lds_raw);
+    const uint32_t k = blockIdx.x / groups, g = blockIdx.x % groups;
+    const uint32_t j0 = (g * 256u + threadIdx.x) * BITSUM_ITEMS;
+    B acc = bk_inf<B>();
+    for (uint32_t i = 0; i < (uint32_t)BITSUM_ITEMS; i++) {
+        const uint32_t j = j0 + i;                                            // j-th weight with bit k set
+        const uint64_t w = (((uint64_t)j >> k) << (k + 1)) | ((uint64_t)1 << k) | (j & (((uint32_t)1 << k) - 1u));
+        if (w >= 1 && w <= nb) acc = bk_add(acc, ld_struct(buckets + (w - 1)));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) acc = bk_add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = acc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st_struct(partials + blockIdx.x, sh[0]);
+}
+template <class F, class B>
+__global__ void __launch_bounds__(64) k_msm_bitsum_final(const B* __restrict__ partials, uint32_t groups, XYZZ<F>* __restrict__ bit_sums) {
+    extern __shared__ uint4 lds_raw[];
+    B* sh = reinterpret_cast<B*>(lds_raw);
+    const B* P = partials + (size_t)blockIdx.x * groups;
+    B acc = bk_inf<B>();
+    for (uint32_t s = threadIdx.x; s < groups; s += 64) acc = bk_add(acc, ld_struct(P + s));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 32; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) acc = bk_add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = acc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st_struct(bit_sums + blockIdx.x, bk_to_xyzz<F>(sh[0]));
+}
+
 // arkworks in-memory affine (x, y, infinity flag at `inf_off`, arbitrary stride) or packed zkey points -> packed device layout
 template <class F>
 __global__ void __launch_bounds__(256) k_pack_bases(const uint8_t* __restrict__ src, size_t n, size_t stride, long inf_off, Affine<F>* __restrict__ dst) {
