@@ -156,6 +156,15 @@ struct L29 {
         r.l[8] = (int32_t)T[17];
         return r;
     }
+    // cheap necessary condition for x = 0 (mod p) on an UNNORMALISED value: carries only travel upwards, so the lowest 29 bits of
+    // limb 0 already are the normalised limb 0 and must equal limb 0 of one of the candidates k*p (a non-zero residue passes with
+    // probability ~10 / 2^29).  Lets the hot loop skip the carry propagation it would otherwise do only for this test.
+    __device__ __forceinline__ static bool maybe_zero_mod_p(const L29& x) {
+        const int32_t lo = x.l[0] & (int32_t)MASK;
+        bool maybe = false;
+        _Pragma("unroll") for (int kk = -3; kk <= 6; kk++) maybe = maybe || (lo == (int32_t)(((int64_t)kk * pl(0)) & MASK));
+        return maybe;
+    }
     // k*p in normalised limbs, k in [-3, 6]: the residues a normalised value in (-4p, 7p) takes when it is 0 mod p
     __device__ __forceinline__ static bool is_zero_mod_p(const L29& x /* normalised */) {
         // cheap filter on the lowest limb (a non-zero residue matches one of the candidates with probability ~10 / 2^29)
@@ -280,6 +289,7 @@ struct L29x2 {
     // a*b - c*d: kept as two products here (four signed products per column would not fit 63 bits)
     __device__ __forceinline__ static L29x2 mul_sub(const L29x2& a, const L29x2& b, const L29x2& c, const L29x2& d) { return (mul(a, b) - mul(c, d)).norm(); }
     __device__ __forceinline__ static bool is_zero_mod_p(const L29x2& x) { return L::is_zero_mod_p(x.c0) && L::is_zero_mod_p(x.c1); }
+    __device__ __forceinline__ static bool maybe_zero_mod_p(const L29x2& x) { return L::maybe_zero_mod_p(x.c0) && L::maybe_zero_mod_p(x.c1); }
     __device__ __forceinline__ static L29x2 one() { L z; _Pragma("unroll") for (int k = 0; k < 9; k++) z.l[k] = 0; return {L::one(), z}; }
     __device__ __forceinline__ static F2 to_fp(const L29x2& x) { return {L::to_fp(x.c0), L::to_fp(x.c1)}; }
     __device__ __forceinline__ static XYZZ<F2> dbl_affine(const F2& x, const F2& y) { return xyzz_dbl_affine(x, y); }
@@ -400,7 +410,7 @@ __device__ __forceinline__ void acc_madd_lazy(Acc& acc, const F& x2f, const F& y
     }
     L P = L::mul(x2, acc.get(2)) - acc.get(0);
     L R = L::mul(y2, acc.get(3)) - acc.get(1);
-    if (L::is_zero_mod_p(P.norm())) {                      // same x: doubling or cancellation (rare)
+    if (L::maybe_zero_mod_p(P) && L::is_zero_mod_p(P.norm())) {   // same x: doubling or cancellation (rare)
         if (L::is_zero_mod_p(R.norm())) {
             XYZZ<F> d = L::dbl_affine(x2f, negate ? y2f.neg() : y2f);
             acc.inf = d.is_inf();
