@@ -32,6 +32,8 @@ inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) {   // must matc
     return 2 * align_up(entries * 4) + 3 * align_up(nbuckets * 4) + align_up(((nbuckets + 2047) / 2048) * 4) + align_up(entries * 8) + 2 * align_up(4096 * 4) + 256;
 }
 template <class F> int pack_bases_launch(hipStream_t st, const uint8_t* d_raw, size_t n, size_t stride, long inf_off, Affine<F>* d_dst);
+template <class F> int gather_points_launch(hipStream_t st, Affine<F>* d_dst, const Affine<F>* d_src, const uint32_t* d_idx, size_t n);
+template <class Fr> int launch_vec_gather_idx(hipStream_t st, Fr* out, const Fr* in, const uint32_t* idx, size_t n, uint32_t base);
 template <class F> int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi, int log_t, size_t n, Affine<F>* d_out);
 template <class Fr> int launch_vec_binary(hipStream_t st, int op, Fr* out, const Fr* a, const Fr* b, size_t n);
 template <class Fr> int launch_rep3_mul_local(hipStream_t st, Fr* out, const Fr* aa, const Fr* ab, const Fr* ba, const Fr* bb, const Fr* mask, size_t n);
@@ -91,6 +93,7 @@ struct cg_ctx {
     hipStream_t sortst = nullptr;
     hipEvent_t ev_in = nullptr, ev_sorted[2] = {nullptr, nullptr}, ev_sched_free[2] = {nullptr, nullptr};
     Arena arena;
+    void* gather_buf = nullptr; size_t gather_cap = 0;   // scalars gathered for compacted tables (see cg_bases::compact)
     std::map<TwKey, void*> twiddles;
     std::map<CosetKey, CosetTables> cosets;
     std::vector<MsmTicket> tickets;
@@ -107,6 +110,11 @@ struct cg_bases {
     void* d_pts;
     int pre_c = 0, pre_nwin = 0;   // per-window precomputed tables (cg_bases_precompute): d_pre = [pre_nwin][n] points, window 0 = d_pts copy
     void* d_pre = nullptr;
+    // Real zkey queries are sparse in points: variables that occur in no B constraint leave the point at infinity in b_g1_query /
+    // b_g2_query (34 % of the poseidon fixture).  When >= 1/8 of a table is infinity the MSMs run over a COMPACTED copy: `compact`
+    // holds the non-infinity records, `h_live` / `d_live` their original indices (ascending), and the scalars are gathered to match.
+    cg_bases* compact = nullptr;
+    std::vector<uint32_t> h_live; uint32_t* d_live = nullptr; uint64_t live_sig = 0;
 };
 
 namespace {
@@ -222,6 +230,62 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
         if (bases[b]->curve != bases[0]->curve) return fail(CG_ERR_ARG, "all tables of one call must be on the same curve");
     }
     HIPCHK(hipSetDevice(ctx->device));
+    {   // tables with a compacted copy: map (offset, n) into the compacted index space, gather the scalars, and run the groups of tables
+        // that ended up with the same scalar set (same infinity pattern and range, e.g. b_g1_query and b_g2_query) as one schedule each
+        bool any = false;
+        for (int b = 0; b < nb; b++) any = any || bases[b]->compact != nullptr;
+        if (any) {
+            struct Grp { uint64_t sig; size_t off, cnt; std::vector<int> members; };
+            std::vector<Grp> groups;
+            std::vector<size_t> off_c(nb), cnt_c(nb);
+            for (int b = 0; b < nb; b++) {
+                const size_t off = offsets ? offsets[b] : 0;
+                uint64_t sig = 0; size_t o = off, cn = n;
+                if (bases[b]->compact) {
+                    const auto& lv = bases[b]->h_live;
+                    o = (size_t)(std::lower_bound(lv.begin(), lv.end(), (uint32_t)off) - lv.begin());
+                    cn = (size_t)(std::lower_bound(lv.begin(), lv.end(), (uint32_t)std::min<size_t>(off + n, 0xffffffffu)) - lv.begin()) - o;
+                    sig = bases[b]->live_sig;
+                }
+                off_c[b] = o; cnt_c[b] = cn;
+                bool placed = false;
+                for (auto& g : groups) if (g.sig == sig && g.cnt == cn && (sig != 0 ? g.off == o : true)) { g.members.push_back(b); placed = true; break; }
+                if (!placed) groups.push_back(Grp{sig, o, cn, {b}});
+            }
+            size_t need = 0;
+            for (auto& g : groups) if (g.sig) need += align_up((size_t)k * g.cnt * 32);
+            if (need > ctx->gather_cap) {
+                HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->sortst));
+                if (ctx->gather_buf) HIPCHK(hipFree(ctx->gather_buf));
+                ctx->gather_buf = nullptr; ctx->gather_cap = 0;
+                HIPCHK(hipMalloc(&ctx->gather_buf, need)); ctx->gather_cap = need;
+            }
+            size_t used = 0;
+            for (auto& g : groups) {
+                std::vector<const cg_bases*> gb; std::vector<size_t> go; std::vector<const void*> gs(k);
+                const int first = g.members[0];
+                for (int m : g.members) { gb.push_back(bases[m]->compact ? bases[m]->compact : bases[m]); go.push_back(bases[m]->compact ? off_c[m] : (offsets ? offsets[m] : 0)); }
+                if (g.sig) {
+                    const size_t off = offsets ? offsets[first] : 0;
+                    for (int j = 0; j < k; j++) {
+                        void* dst = (char*)ctx->gather_buf + used + (size_t)j * g.cnt * 32;
+                        int rc = with_fr(bases[first]->curve, [&](auto tag) -> int {
+                            typedef decltype(tag) Fr;
+                            return launch_vec_gather_idx<Fr>(ctx->stream, (Fr*)dst, (const Fr*)d_scalars[j], bases[first]->d_live + g.off, g.cnt, (uint32_t)off);
+                        });
+                        if (rc) return rc;
+                        gs[j] = dst;
+                    }
+                    used += align_up((size_t)k * g.cnt * 32);
+                } else for (int j = 0; j < k; j++) gs[j] = d_scalars[j];
+                std::vector<int> tk(g.members.size());
+                int rc = msm_begin_multi_impl(ctx, (int)g.members.size(), gb.data(), go.data(), g.cnt, gs.data(), k, tk.data(), true);
+                if (rc) return rc;
+                for (size_t i = 0; i < g.members.size(); i++) tickets_out[g.members[i]] = tk[i];
+            }
+            return 0;
+        }
+    }
     const int curve = bases[0]->curve;
     const bool shared = bases[0]->pre_c != 0;          // per-window precomputed tables: one bucket set for all windows
     for (int b = 0; b < nb; b++) {
@@ -558,6 +622,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
     for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.h_flags) hipHostFree(t.h_flags); if (t.done) hipEventDestroy(t.done); }
     if (ctx->arena.base) hipFree(ctx->arena.base);
+    if (ctx->gather_buf) hipFree(ctx->gather_buf);
     for (auto& p : ctx->ev_live) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
     for (auto& p : ctx->ev_free) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
     if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
@@ -635,6 +700,28 @@ static int32_t bases_register_impl(cg_ctx* ctx, int32_t curve, int32_t group, co
             }
             HIPCHK(hipStreamSynchronize(ctx->stream));
         }
+        static const bool no_compact = getenv("CG_NO_COMPACT") != nullptr;          // measurement knob
+        if (n >= 64 && n < ((size_t)1 << 32) && !no_compact) {   // infinity census on the packed table (registration-time work, like parsing)
+            std::vector<uint8_t> host(n * pt);
+            HIPCHK(hipMemcpy(host.data(), b->d_pts, n * pt, hipMemcpyDeviceToHost));
+            std::vector<uint32_t> live; live.reserve(n);
+            const uint64_t* w = reinterpret_cast<const uint64_t*>(host.data());
+            const size_t words = pt / 8;
+            for (size_t i = 0; i < n; i++) { uint64_t any = 0; for (size_t q = 0; q < words; q++) any |= w[i * words + q]; if (any) live.push_back((uint32_t)i); }
+            if (live.size() * 8 <= n * 7) {
+                cg_bases* cb = new cg_bases{ctx->device, curve, group, live.size(), pt, nullptr};
+                HIPCHK(hipMalloc(&cb->d_pts, std::max<size_t>(live.size() * pt, 16)));
+                HIPCHK(hipMalloc((void**)&b->d_live, std::max<size_t>(live.size() * 4, 16)));
+                if (!live.empty()) {
+                    HIPCHK(hipMemcpy(b->d_live, live.data(), live.size() * 4, hipMemcpyHostToDevice));
+                    int rc = gather_points_launch<F>(ctx->stream, (Affine<F>*)cb->d_pts, (const Affine<F>*)b->d_pts, b->d_live, live.size()); if (rc) return rc;
+                    HIPCHK(hipStreamSynchronize(ctx->stream));
+                }
+                uint64_t h = 1469598103934665603ull ^ (uint64_t)live.size();          // FNV-1a over the index list: equal patterns (b1 / b2) share schedules
+                for (uint32_t v : live) { h ^= v; h *= 1099511628211ull; }
+                b->live_sig = h ? h : 1; b->h_live = std::move(live); b->compact = cb;
+            }
+        }
         *out = b;
         return 0;
     });
@@ -654,6 +741,8 @@ int32_t cg_bases_release(cg_bases* b) {
     hipDeviceSynchronize();
     hipFree(b->d_pts);
     if (b->d_pre) hipFree(b->d_pre);
+    if (b->d_live) hipFree(b->d_live);
+    if (b->compact) { hipFree(b->compact->d_pts); if (b->compact->d_pre) hipFree(b->compact->d_pre); delete b->compact; }
     delete b;
     return 0;
 }
@@ -697,6 +786,7 @@ int32_t cg_bases_check_subgroup(cg_ctx* ctx, const cg_bases* b, uint64_t* n_bad,
 }
 int32_t cg_bases_precompute(cg_ctx* ctx, cg_bases* b, int32_t c) {
     if (!ctx || !b) return fail(CG_ERR_ARG, "null argument");
+    if (b->compact) return cg_bases_precompute(ctx, b->compact, c);      // MSMs only ever read the compacted copy
     // c = 0: pick by table size (measured, scripts/sweep_precompute.py): 2^19 buckets only pay for themselves above ~1.5 M points
     if (c == 0) c = b->n > ((size_t)3 << 19) ? 20 : 17;
     if (c < 8 || c > 22) return fail(CG_ERR_ARG, "precompute window must be 0 (auto) or in [8, 22]");

@@ -33,6 +33,12 @@ template <class Fr> int launch_vec_affine(hipStream_t st, Fr* out, const Fr* a, 
     HIPCHK(hipGetLastError());
     return 0;
 }
+template <class Fr> int launch_vec_gather_idx(hipStream_t st, Fr* out, const Fr* in, const uint32_t* idx, size_t n, uint32_t base) {
+    if (!n) return 0;
+    hipLaunchKernelGGL((k_vec_gather_idx<Fr>), dim3(grid_for(n)), dim3(256), 0, st, out, in, idx, n, base);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 template <class Fr> int launch_vec_fill(hipStream_t st, Fr* v, size_t n, const Fr& value) {
     if (!n) return 0;
     hipLaunchKernelGGL((k_vec_fill<Fr>), dim3(grid_for(n)), dim3(256), 0, st, v, n, value);
@@ -192,6 +198,7 @@ template <class Fr> int msm_sort_direct_launch(hipStream_t st, const Fr* d_scala
     template int launch_rep3_mul_local<Fr>(hipStream_t, Fr*, const Fr*, const Fr*, const Fr*, const Fr*, const Fr*, size_t); \
     template int launch_distribute_powers<Fr>(hipStream_t, Fr*, size_t, const Fr*, const Fr*, int);                        \
     template int launch_vec_fill<Fr>(hipStream_t, Fr*, size_t, const Fr&);                                                 \
+    template int launch_vec_gather_idx<Fr>(hipStream_t, Fr*, const Fr*, const uint32_t*, size_t, uint32_t);                \
     template int launch_vec_affine<Fr>(hipStream_t, Fr*, const Fr*, size_t, const Fr&, const Fr&);                         \
     template int launch_vec_gather_strided<Fr>(hipStream_t, Fr*, const Fr*, size_t, size_t, size_t);                       \
     template int launch_prefix_scan<Fr>(hipStream_t, int, Fr*, const Fr*, size_t, Fr*);                                    \

@@ -95,6 +95,12 @@ int pack_bases_launch(hipStream_t st, const uint8_t* d_raw, size_t n, size_t str
     return 0;
 }
 template <class F>
+int gather_points_launch(hipStream_t st, Affine<F>* d_dst, const Affine<F>* d_src, const uint32_t* d_idx, size_t n) {
+    if (n) hipLaunchKernelGGL((k_gather_points<F>), dim3(grid_for(n)), dim3(256), 0, st, d_dst, d_src, d_idx, n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class F>
 int check_on_curve_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, const F& b, unsigned long long* d_counters) {
     if (n) hipLaunchKernelGGL((k_check_on_curve<F>), dim3(grid_for(n)), dim3(256), 0, st, d_pts, n, b, d_counters, d_counters + 1);
     HIPCHK(hipGetLastError());
@@ -129,5 +135,6 @@ int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi
     template int check_on_curve_launch<F>(hipStream_t, const Affine<F>*, size_t, const F&, unsigned long long*);           \
     template int check_subgroup_launch<F, Fr>(hipStream_t, const Affine<F>*, size_t, unsigned long long*);                 \
     template int pack_bases_launch<F>(hipStream_t, const uint8_t*, size_t, size_t, long, Affine<F>*);                      \
+    template int gather_points_launch<F>(hipStream_t, Affine<F>*, const Affine<F>*, const uint32_t*, size_t);              \
     template int synth_points_launch<F>(hipStream_t, const XYZZ<F>*, const XYZZ<F>*, int, size_t, Affine<F>*);             \
     }

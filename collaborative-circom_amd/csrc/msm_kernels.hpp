@@ -642,6 +642,12 @@ __global__ void __launch_bounds__(256) k_pack_bases(const uint8_t* __restrict__ 
 }
 
 
+// dst[j] = src[idx[j]]   (compaction of a table whose records are partly the point at infinity)
+template <class F>
+__global__ void __launch_bounds__(256) k_gather_points(Affine<F>* __restrict__ dst, const Affine<F>* __restrict__ src, const uint32_t* __restrict__ idx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_struct(dst + i, ld_struct(src + idx[i]));
+}
+
 // zkey fast path: the reference's parser checks every point on the CPU (`circom-types/src/traits.rs:118-123,
 // 148-153`: is_on_curve, then the subgroup check).  On-curve: y^2 == x^3 + b for every non-infinity record, counted on the
 // device.  b is passed in Montgomery form (BN254 G1: 3, G2: 3/(9+u); BLS12-381 G1: 4, G2: 4(1+u)).

@@ -106,6 +106,12 @@ __global__ void __launch_bounds__(256) k_vec_gather_strided(F* __restrict__ out,
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fp(out + i, ld_fp(in + offset + i * stride));
 }
 
+// out[j] = in[idx[j] - base]   (scalars of the non-infinity bases of a compacted table, see cg_bases::compact)
+template <class F>
+__global__ void __launch_bounds__(256) k_vec_gather_idx(F* __restrict__ out, const F* __restrict__ in, const uint32_t* __restrict__ idx, size_t n, uint32_t base) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fp(out + i, ld_fp(in + (idx[i] - base)));
+}
+
 // Inclusive prefix scan out[i] = in[0] (op) ... (op) in[i], op = field product (what `array_prod_mul` yields for a single-component
 // driver, round2.rs:18-41) or field sum (polynomial evaluation and the synthetic division of round 5).  Three launches: tiles of
 // 256 x SCAN_ITEMS elements (serial per lane, Hillis-Steele across the workgroup in LDS), a scan of the tile totals by one

@@ -546,3 +546,42 @@ def test_vec_prefix_product_inverse_affine(ctx, curve, n):
         ctx.vec_gather_strided(curve, d_g, d_x, m, 1 if n > 4 else 0, 4 if 4 * (m - 1) + 1 < n else 1)
         off, st = (1 if n > 4 else 0), (4 if 4 * (m - 1) + 1 < n else 1)
         np.testing.assert_array_equal(d_g.download((m, 4)), x[off:off + st * m:st][:m])
+
+
+@pytest.mark.parametrize("group", [G1, G2])
+def test_msm_table_with_many_infinity_points(ctx, group):
+    """tables that are sparse in points (B queries of real zkeys) are compacted at registration: results must not change — whole table,
+    sub-slices, with and without precomputed window tables, two tables with the same pattern sharing a call, an all-infinity range"""
+    curve = BN254
+    rng = np.random.default_rng(808)
+    n = 3000
+    pts = np.stack([orc.generator_mul(curve, group, s) for s in orc.random_field(curve, FR, 64, rng)])
+    table = pts[rng.integers(0, 64, size=n)]
+    dead = rng.random(n) < 0.45
+    dead[100:400] = True                                            # a long all-infinity stretch
+    table[dead] = 0
+    sc = [orc.random_field(curve, FR, n, rng), orc.random_field(curve, FR, n, rng)]
+    bases = ctx.register_bases(curve, group, table)
+    assert ctx.check_on_curve(bases) == (0, None)
+    np.testing.assert_array_equal(ctx.bases_download(bases, 0, n), table)      # the original indexing stays visible
+    def check(b, lo, cnt):
+        got = ctx.msm(b, [s[lo:lo + cnt] for s in sc], offset=lo, n=cnt)
+        for j in range(2):
+            np.testing.assert_array_equal(cg.point_to_affine(curve, group, got[j]), orc.msm(curve, group, table[lo:lo + cnt], sc[j][lo:lo + cnt]), err_msg=f"range {lo}+{cnt} comp {j}")
+    for lo, cnt in ((0, n), (1, n - 1), (57, 1000), (120, 200), (399, 3), (2990, 10)):
+        check(bases, lo, cnt)
+    ctx.precompute_bases(bases, 12)
+    for lo, cnt in ((0, n), (250, 2000), (120, 200)):
+        check(bases, lo, cnt)
+    # a second table with the SAME infinity pattern and one without infinities in one multi-table call
+    other = table.copy(); other[~dead] = pts[rng.integers(0, 64, size=int((~dead).sum()))]
+    full = pts[rng.integers(0, 64, size=n)]
+    b2 = ctx.register_bases(curve, group, other); b3 = ctx.register_bases(curve, group, full)
+    ctx.precompute_bases(b2, 12); ctx.precompute_bases(b3, 12)
+    d_sc = [dev(ctx, s) for s in sc]
+    tks = ctx.msm_dev_begin_multi([bases, b3, b2], d_sc, n)
+    outs = [ctx.msm_end(t) for t in tks]
+    for tab, out in zip((table, full, other), outs):
+        for j in range(2):
+            np.testing.assert_array_equal(cg.point_to_affine(curve, group, out[j]), orc.msm(curve, group, tab, sc[j]))
+    for b in (bases, b2, b3): b.release()
