@@ -702,10 +702,11 @@ static int32_t bases_register_impl(cg_ctx* ctx, int32_t curve, int32_t group, co
         }
         static const bool no_compact = getenv("CG_NO_COMPACT") != nullptr;          // measurement knob
         if (n >= 64 && n < ((size_t)1 << 32) && !no_compact) {   // infinity census on the packed table (registration-time work, like parsing)
-            std::vector<uint8_t> host(n * pt);
-            HIPCHK(hipMemcpy(host.data(), b->d_pts, n * pt, hipMemcpyDeviceToHost));
+            std::vector<uint8_t> host;
+            const uint64_t* w = nullptr;
+            if (!src_on_device && stride == pt && inf_off < 0) w = reinterpret_cast<const uint64_t*>(src);     // packed host table: scan it where it lies
+            else { host.resize(n * pt); HIPCHK(hipMemcpy(host.data(), b->d_pts, n * pt, hipMemcpyDeviceToHost)); w = reinterpret_cast<const uint64_t*>(host.data()); }
             std::vector<uint32_t> live; live.reserve(n);
-            const uint64_t* w = reinterpret_cast<const uint64_t*>(host.data());
             const size_t words = pt / 8;
             for (size_t i = 0; i < n; i++) { uint64_t any = 0; for (size_t q = 0; q < words; q++) any |= w[i * words + q]; if (any) live.push_back((uint32_t)i); }
             if (live.size() * 8 <= n * 7) {
