@@ -1687,22 +1687,30 @@ int32_t cgh_prove_plain(int32_t device, int32_t curve, const char* zkey_path, co
     cg_ctx* ctx = nullptr;
     try {
         using namespace cgh;
+        const bool timing = getenv("CGH_TIMING") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t0 = now();
         ZKey z = read_zkey(curve, zkey_path);
+        const auto t1 = now();
         if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
         const Fr* w = (const Fr*)full_witness;
         std::vector<Fr> pub(w, w + z.n_public + 1);
         DeviceZKey dz = upload_zkey(ctx, z, pub);
+        const auto t2 = now();
         HipDriver driver(ctx, z.curve, Mode::Plain, nullptr);
         ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_public - 1);
         FieldShare rs[2]; memcpy(rs[0].c[0].v, r, 32); rs[0].c[1] = rs[0].c[0]; memcpy(rs[1].c[0].v, s, 32); rs[1].c[1] = rs[1].c[0];
         CoGroth16 prover(driver);
         ShareVec h;
         Proof p = prover.prove(dz, pub, wit, rs, &h);
+        const auto t3 = now();
         store_proof(p, (uint8_t*)out_proof);
         if (out_h) CG(cg_dev_download(ctx, out_h, h.c[0], h.n * 32));
         driver.free_vec(h); driver.free_vec(wit);
         release_zkey(ctx, dz);
         cg_ctx_destroy(ctx);
+        if (timing) fprintf(stderr, "cgh_prove_plain: read+decode zkey %.1f ms, context + upload %.1f ms, prove %.1f ms, teardown %.1f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
 }
