@@ -19,6 +19,11 @@
 #include <cstring>
 #include <deque>
 #include <chrono>
+#include <fcntl.h>
+#include <memory>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -82,6 +87,27 @@ static Bytes slurp(const std::string& path) {
     fclose(f);
     return b;
 }
+// zkey -> device fast path: the file is mapped, the point sections are handed to cg_bases_register where they lie (one
+// host->device copy, no intermediate buffers); only the small header points and the coefficient section are decoded on the host.
+struct MappedFile {
+    const uint8_t* p = nullptr; size_t n = 0;
+    explicit MappedFile(const std::string& path) {
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + path);
+        struct stat st; if (fstat(fd, &st) != 0) { close(fd); throw std::runtime_error("cannot stat " + path); }
+        n = (size_t)st.st_size;
+        if (n) { void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0); if (m == MAP_FAILED) { close(fd); throw std::runtime_error("cannot map " + path); } p = (const uint8_t*)m; }
+        close(fd);
+    }
+    ~MappedFile() { if (p) munmap((void*)p, n); }
+    MappedFile(const MappedFile&) = delete; MappedFile& operator=(const MappedFile&) = delete;
+};
+struct View {   // a section of the mapped file, with the read-only part of the std::vector interface the prover uses
+    const uint8_t* p = nullptr; size_t n = 0;
+    const uint8_t* data() const { return p; } size_t size() const { return n; }
+    const uint8_t* begin() const { return p; } const uint8_t* end() const { return p + n; }
+};
+
 static const uint64_t MOD_R[2][4] = {{0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull},
                                      {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull}};
 static const uint64_t MOD_Q[2][6] = {{0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull, 0, 0},
@@ -91,14 +117,16 @@ struct ZKey {   // zkey.rs:48-71; points kept in the packed on-disk form (x||y M
     Curve curve;
     size_t n_vars = 0, n_public = 0, domain_size = 0, pow = 0, num_constraints = 0;
     Bytes alpha_g1, beta_g1, delta_g1, beta_g2, gamma_g2, delta_g2;
-    Bytes ic, a_query, b_g1_query, b_g2_query, l_query, h_query;
+    std::shared_ptr<MappedFile> file;                     // keeps the views below alive
+    View ic, a_query, b_g1_query, b_g2_query, l_query, h_query;
     std::vector<uint32_t> row_ptr[2], col[2];
     std::vector<Fr> coeff[2];
 };
 
 static ZKey read_zkey(int curve_id, const std::string& path) {
     Curve c{curve_id};
-    Bytes buf = slurp(path);
+    auto mf = std::make_shared<MappedFile>(path);
+    struct { const uint8_t* p; size_t n; const uint8_t* data() const { return p; } size_t size() const { return n; } } buf{mf->p, mf->n};
     Cursor cur{buf.data(), buf.size()};
     char magic[5] = {0}; cur.bytes(magic, 4);
     if (std::string(magic) != "zkey") throw std::runtime_error("not a zkey file");
@@ -107,7 +135,7 @@ static ZKey read_zkey(int curve_id, const std::string& path) {
     std::map<uint32_t, std::pair<size_t, size_t>> sec;
     for (uint32_t i = 0; i < ns; i++) { uint32_t id = cur.u32(); uint64_t len = cur.u64(); cur.need(len); sec[id] = {cur.off, (size_t)len}; cur.off += len; }
     auto section = [&](uint32_t id) { auto it = sec.find(id); if (it == sec.end()) throw std::runtime_error("missing zkey section"); return Cursor{buf.data() + it->second.first, it->second.second}; };
-    ZKey z; z.curve = c;
+    ZKey z; z.curve = c; z.file = mf;
     {   // header, zkey.rs:258-316
         Cursor h = section(2);
         if (h.u32() != c.fq()) throw std::runtime_error("unexpected base field byte size");
@@ -122,7 +150,7 @@ static ZKey read_zkey(int curve_id, const std::string& path) {
         auto g = [&](int grp) { Bytes b(c.aff(grp)); h.bytes(b.data(), b.size()); return b; };
         z.alpha_g1 = g(CG_G1); z.beta_g1 = g(CG_G1); z.beta_g2 = g(CG_G2); z.gamma_g2 = g(CG_G2); z.delta_g1 = g(CG_G1); z.delta_g2 = g(CG_G2);
     }
-    auto pts = [&](uint32_t id, size_t n, int grp) { Cursor s = section(id); Bytes b(n * c.aff(grp)); s.bytes(b.data(), b.size()); return b; };
+    auto pts = [&](uint32_t id, size_t n, int grp) { Cursor s = section(id); s.need(n * c.aff(grp)); return View{s.p, n * c.aff(grp)}; };
     z.ic = pts(3, z.n_public + 1, CG_G1); z.a_query = pts(5, z.n_vars, CG_G1); z.b_g1_query = pts(6, z.n_vars, CG_G1);
     z.b_g2_query = pts(7, z.n_vars, CG_G2); z.l_query = pts(8, z.n_vars - z.n_public - 1, CG_G1); z.h_query = pts(9, z.domain_size, CG_G1);
     {   // section 4, zkey.rs:184-204: value on disk = v*R^2; one Montgomery reduction gives the Montgomery form of v (traits.rs:65-67)
@@ -688,7 +716,7 @@ public:
     }
 
     // groth16.rs:206-235
-    PointShare calculate_coeff(PointShare initial, const cg_bases* query, const Bytes& query_host, int group, const Bytes& vk_param,
+    PointShare calculate_coeff(PointShare initial, const cg_bases* query, const View& query_host, int group, const Bytes& vk_param,
                                const std::vector<Fr>& input_assignment, const ShareVec& aux_assignment) {
         const Curve& c = driver.curve;
         const size_t pub_len = input_assignment.size(), rec = c.aff(group);
@@ -750,7 +778,7 @@ static void validate_bases(cg_ctx* ctx, const cg_bases* b, const char* name) {
 static DeviceZKey upload_zkey(cg_ctx* ctx, const ZKey& z, const std::vector<Fr>& public_inputs, bool validate = false) {
     DeviceZKey d; d.z = &z;
     const Curve& c = z.curve;
-    auto reg = [&](const Bytes& pts, int group, const char* name = "") {
+    auto reg = [&](const auto& pts, int group, const char* name = "") {
         cg_bases* b; CG(cg_bases_register(ctx, c.id, group, pts.data(), pts.size() / c.aff(group), c.aff(group), -1, &b));
         if (validate) { try { validate_bases(ctx, b, name); } catch (...) { cg_bases_release(b); throw; } }
         return b;
