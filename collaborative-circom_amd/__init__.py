@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute", "cg_bases_check_on_curve", "cg_bases_check_subgroup",
     "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_scatter_capacity",
     "cg_ntt", "cg_ntt_dev",
-    "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev", "cg_vec_affine_dev", "cg_vec_fill_dev", "cg_vec_gather_strided_dev", "cg_vec_prefix_prod_dev", "cg_vec_prefix_sum_dev", "cg_vec_inverse_dev",
+    "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev", "cg_vec_affine_dev", "cg_vec_fill_dev", "cg_vec_gather_strided_dev", "cg_vec_lincomb_dev", "cg_vec_prefix_prod_dev", "cg_vec_prefix_sum_dev", "cg_vec_inverse_dev",
     "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
     "cg_point_add", "cg_point_neg", "cg_point_scalar_mul", "cg_point_to_affine", "cg_point_from_affine", "cg_fr_op",
     "cg_fr_from_canonical", "cg_fr_to_canonical", "cg_fq_to_canonical", "cg_fq_from_canonical", "cg_point_generator",
@@ -314,6 +314,14 @@ class Context:
 
     def vec_fill(self, curve, v, n, value): _chk(load().cg_vec_fill_dev(self.h, curve, _dp(v), C.c_size_t(n), _hp(np.ascontiguousarray(value, dtype=np.uint64))))
     def vec_gather_strided(self, curve, out, src, n, offset, stride): _chk(load().cg_vec_gather_strided_dev(self.h, curve, _dp(out), _dp(src), C.c_size_t(n), C.c_size_t(offset), C.c_size_t(stride)))
+    def vec_lincomb(self, curve, out, out_off, out_stride, n, srcs, src_off, src_stride, coeffs):
+        """out[out_off + i*out_stride] = sum_j coeffs[j] * srcs[j][src_off[j] + i*src_stride[j]] (element units, negative strides allowed)"""
+        k = len(srcs)
+        ptrs = (C.c_void_p * k)(*[_dp(x).value for x in srcs])
+        offs = (C.c_int64 * k)(*[int(x) for x in src_off]); strides = (C.c_int64 * k)(*[int(x) for x in src_stride])
+        _chk(load().cg_vec_lincomb_dev(self.h, curve, _dp(out), C.c_int64(out_off), C.c_int64(out_stride), C.c_size_t(n), k, ptrs, offs, strides,
+                                       _hp(np.ascontiguousarray(coeffs, dtype=np.uint64))))
+
     def vec_prefix_prod(self, curve, out, src, n): _chk(load().cg_vec_prefix_prod_dev(self.h, curve, _dp(out), _dp(src), C.c_size_t(n)))
     def vec_prefix_sum(self, curve, out, src, n): _chk(load().cg_vec_prefix_sum_dev(self.h, curve, _dp(out), _dp(src), C.c_size_t(n)))
     def vec_inverse(self, curve, out, src, n): _chk(load().cg_vec_inverse_dev(self.h, curve, _dp(out), _dp(src), C.c_size_t(n)))
@@ -444,8 +452,9 @@ def host_public_to_json(curve, pub):
     return buf.value.decode()
 
 
-def prove_shamir(curve, zkey_path, n, t, pub, wits, streams, device=0, want_h=False):
-    """n Shamir parties (threads) with threshold t on one GPU; returns (n proofs[, party 0's h shares])"""
+def prove_shamir(curve, zkey_path, n, t, pub, wits, streams, device=0, want_h=False, preprocess=0):
+    """n Shamir parties (threads) with threshold t on one GPU; returns (n proofs[, party 0's h shares]).  preprocess = number of
+    secrets every party double-shares up front on the GPU (ShamirProtocol::preprocess); 0 = the reference's lazy batches of 1024."""
     info = host_zkey_info(curve, zkey_path)
     nq = 6 if curve == BLS12_381 else 4
     out = np.zeros((n, 8 * nq), dtype=np.uint64)
@@ -453,7 +462,7 @@ def prove_shamir(curve, zkey_path, n, t, pub, wits, streams, device=0, want_h=Fa
     keep = [[np.ascontiguousarray(x, dtype=np.uint64) for x in lst] for lst in (wits, streams)]
     arr = lambda lst: (C.c_void_p * n)(*[x.ctypes.data for x in lst])
     _hchk(load_host().cgh_prove_shamir(int(device), curve, zkey_path.encode(), int(n), int(t), _hp(np.ascontiguousarray(pub, dtype=np.uint64)),
-                                       arr(keep[0]), arr(keep[1]), C.c_size_t(keep[1][0].shape[0]), _hp(out), _hp(h) if want_h else None))
+                                       arr(keep[0]), arr(keep[1]), C.c_size_t(keep[1][0].shape[0]), C.c_size_t(int(preprocess)), _hp(out), _hp(h) if want_h else None))
     return (out, h) if want_h else out
 
 

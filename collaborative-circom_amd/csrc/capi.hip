@@ -41,6 +41,7 @@ template <class Fr> int launch_distribute_powers(hipStream_t st, Fr* v, size_t n
 template <class Fr> int launch_vec_fill(hipStream_t st, Fr* v, size_t n, const Fr& value);
 template <class Fr> int launch_vec_affine(hipStream_t st, Fr* out, const Fr* a, size_t n, const Fr& c, const Fr& d);
 template <class Fr> int launch_vec_gather_strided(hipStream_t st, Fr* out, const Fr* in, size_t n, size_t offset, size_t stride);
+template <class Fr> int launch_vec_lincomb(hipStream_t st, Fr* out, long long out_off, long long out_stride, size_t n, const LincombArgs<Fr>& a);
 template <class Fr> int launch_prefix_scan(hipStream_t st, int op, Fr* out, const Fr* in, size_t n, Fr* scratch);
 template <class Fr> int launch_vec_inverse(hipStream_t st, Fr* out, const Fr* in, size_t n);
 template <class Fr> int launch_spmv_csr(hipStream_t st, const uint32_t* row_ptr, const uint32_t* col, const Fr* coeff, size_t n_rows, const Fr* pub,
@@ -974,6 +975,26 @@ int32_t cg_vec_gather_strided_dev(cg_ctx* ctx, int32_t curve, void* d_out, const
         typedef decltype(tag) Fr;
         StatScope ss(ctx, TAG_VEC);
         return launch_vec_gather_strided<Fr>(ctx->stream, (Fr*)d_out, (const Fr*)d_in, n, offset, stride);
+    });
+}
+int32_t cg_vec_lincomb_dev(cg_ctx* ctx, int32_t curve, void* d_out, int64_t out_off, int64_t out_stride, size_t n, int32_t n_terms,
+                           const void* const* d_src, const int64_t* src_off, const int64_t* src_stride, const void* h_coeffs) {
+    if (!ctx || !d_out || !d_src || !src_off || !src_stride || !h_coeffs) return fail(CG_ERR_ARG, "null argument");
+    if (n_terms < 1 || n_terms > LINCOMB_MAX) return fail(CG_ERR_ARG, "cg_vec_lincomb_dev: 1..8 terms");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        LincombArgs<Fr> a; memset(&a, 0, sizeof a);
+        a.n_terms = n_terms;
+        const Fr one = Fr::one();
+        for (int j = 0; j < n_terms; j++) {
+            if (!d_src[j]) return fail(CG_ERR_ARG, "null source vector");
+            a.src[j] = (const Fr*)d_src[j]; a.off[j] = src_off[j]; a.stride[j] = src_stride[j];
+            copy_in(a.coeff[j], (const char*)h_coeffs + (size_t)j * sizeof(Fr));
+            a.unit[j] = memcmp(&a.coeff[j], &one, sizeof(Fr)) == 0;
+        }
+        StatScope ss(ctx, TAG_VEC);
+        return launch_vec_lincomb<Fr>(ctx->stream, (Fr*)d_out, out_off, out_stride, n, a);
     });
 }
 static int32_t prefix_scan_dev(cg_ctx* ctx, int32_t curve, int op, void* d_out, const void* d_in, size_t n) {

@@ -58,4 +58,9 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared) {
     return g;
 }
 
+// arguments of k_vec_lincomb (vec_kernels.hpp), passed by value
+constexpr int LINCOMB_MAX = 8;
+template <class F>
+struct LincombArgs { const F* src[LINCOMB_MAX]; long long off[LINCOMB_MAX]; long long stride[LINCOMB_MAX]; F coeff[LINCOMB_MAX]; int unit[LINCOMB_MAX]; int n_terms; };
+
 }  // namespace cg

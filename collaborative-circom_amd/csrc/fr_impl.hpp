@@ -33,6 +33,12 @@ template <class Fr> int launch_vec_affine(hipStream_t st, Fr* out, const Fr* a, 
     HIPCHK(hipGetLastError());
     return 0;
 }
+template <class Fr> int launch_vec_lincomb(hipStream_t st, Fr* out, long long out_off, long long out_stride, size_t n, const LincombArgs<Fr>& a) {
+    if (!n) return 0;
+    hipLaunchKernelGGL((k_vec_lincomb<Fr>), dim3(grid_for(n)), dim3(256), 0, st, out, out_off, out_stride, n, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 template <class Fr> int launch_vec_gather_idx(hipStream_t st, Fr* out, const Fr* in, const uint32_t* idx, size_t n, uint32_t base) {
     if (!n) return 0;
     hipLaunchKernelGGL((k_vec_gather_idx<Fr>), dim3(grid_for(n)), dim3(256), 0, st, out, in, idx, n, base);
@@ -201,6 +207,7 @@ template <class Fr> int msm_sort_direct_launch(hipStream_t st, const Fr* d_scala
     template int launch_vec_gather_idx<Fr>(hipStream_t, Fr*, const Fr*, const uint32_t*, size_t, uint32_t);                \
     template int launch_vec_affine<Fr>(hipStream_t, Fr*, const Fr*, size_t, const Fr&, const Fr&);                         \
     template int launch_vec_gather_strided<Fr>(hipStream_t, Fr*, const Fr*, size_t, size_t, size_t);                       \
+    template int launch_vec_lincomb<Fr>(hipStream_t, Fr*, long long, long long, size_t, const LincombArgs<Fr>&);           \
     template int launch_prefix_scan<Fr>(hipStream_t, int, Fr*, const Fr*, size_t, Fr*);                                    \
     template int launch_vec_inverse<Fr>(hipStream_t, Fr*, const Fr*, size_t);                                              \
     template int launch_spmv_csr<Fr>(hipStream_t, const uint32_t*, const uint32_t*, const Fr*, size_t, const Fr*, uint32_t, int, const Fr*, const Fr*, Fr*, Fr*); \

@@ -106,6 +106,22 @@ __global__ void __launch_bounds__(256) k_vec_gather_strided(F* __restrict__ out,
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fp(out + i, ld_fp(in + offset + i * stride));
 }
 
+// out[out_off + i * out_stride] = sum_j coeff[j] * src[j][off[j] + i * stride[j]]   (strides in elements, may be negative)
+// The Shamir share algebra as one launch per output: share evaluation (shamir_core.rs:8-31), the Vandermonde step of the
+// double-sharing generation (shamir.rs:904-921), the king's interpolation (shamir.rs:330-345), openings (shamir.rs:581-601)
+// and reading the LIFO pair buffer backwards (shamir.rs:1012-1025).
+template <class F>
+__global__ void __launch_bounds__(256) k_vec_lincomb(F* __restrict__ out, long long out_off, long long out_stride, size_t n, LincombArgs<F> a) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        F acc = F::zero();
+        for (int j = 0; j < a.n_terms; j++) {
+            const F v = ld_fp(a.src[j] + (a.off[j] + (long long)i * a.stride[j]));
+            acc = acc + (a.unit[j] ? v : a.coeff[j] * v);
+        }
+        st_fp(out + (out_off + (long long)i * out_stride), acc);
+    }
+}
+
 // out[j] = in[idx[j] - base]   (scalars of the non-infinity bases of a compacted table, see cg_bases::compact)
 template <class F>
 __global__ void __launch_bounds__(256) k_vec_gather_idx(F* __restrict__ out, const F* __restrict__ in, const uint32_t* __restrict__ idx, size_t n, uint32_t base) {

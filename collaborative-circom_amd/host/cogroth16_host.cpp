@@ -123,7 +123,7 @@ struct ZKey {   // zkey.rs:48-71; points kept in the packed on-disk form (x||y M
     std::vector<Fr> coeff[2];
 };
 
-static ZKey read_zkey(int curve_id, const std::string& path) {
+static ZKey read_zkey(int curve_id, const std::string& path, bool header_only = false) {   // header_only: sizes and counts, no matrix values
     Curve c{curve_id};
     auto mf = std::make_shared<MappedFile>(path);
     struct { const uint8_t* p; size_t n; const uint8_t* data() const { return p; } size_t size() const { return n; } } buf{mf->p, mf->n};
@@ -153,30 +153,40 @@ static ZKey read_zkey(int curve_id, const std::string& path) {
     auto pts = [&](uint32_t id, size_t n, int grp) { Cursor s = section(id); s.need(n * c.aff(grp)); return View{s.p, n * c.aff(grp)}; };
     z.ic = pts(3, z.n_public + 1, CG_G1); z.a_query = pts(5, z.n_vars, CG_G1); z.b_g1_query = pts(6, z.n_vars, CG_G1);
     z.b_g2_query = pts(7, z.n_vars, CG_G2); z.l_query = pts(8, z.n_vars - z.n_public - 1, CG_G1); z.h_query = pts(9, z.domain_size, CG_G1);
-    {   // section 4, zkey.rs:184-204: value on disk = v*R^2; one Montgomery reduction gives the Montgomery form of v (traits.rs:65-67)
+    {   // section 4, zkey.rs:184-204: records (u32 matrix, u32 row, u32 signal, 32 B value); value on disk = v*R^2, one Montgomery
+        // reduction gives the Montgomery form of v (traits.rs:65-67).  Three passes over the mapped records: last row, row counts,
+        // CSR fill with the raw values; then the values are reduced in place, in parallel slices.
         Cursor s = section(4);
-        uint32_t ncoef = s.u32();
-        struct E { uint32_t m, row, sig; Fr v; };
-        std::vector<E> es(ncoef);
+        const uint32_t ncoef = s.u32();
+        s.need((size_t)ncoef * 44);
+        const uint8_t* rec = s.p + s.off;
+        auto word = [&](size_t i, int k) { uint32_t v; memcpy(&v, rec + i * 44 + 4 * k, 4); return v; };
         uint32_t max_row = 0;
-        std::vector<Fr> disk(ncoef);
-        for (uint32_t i = 0; i < ncoef; i++) {
-            E& e = es[i];
-            e.m = s.u32(); e.row = s.u32(); e.sig = s.u32();
-            s.bytes(disk[i].v, 32);
-            if (e.m > 1) throw std::runtime_error("bad matrix id");
-            if (e.row > max_row) max_row = e.row;
-        }
-        // one Montgomery reduction per value (v R^2 -> v R), batched: Montgomery -> canonical IS that reduction
-        if (ncoef) { std::vector<Fr> dec(ncoef); CG(cg_fr_to_canonical(c.id, disk.data(), dec.data(), ncoef)); for (uint32_t i = 0; i < ncoef; i++) es[i].v = dec[i]; }
+        for (size_t i = 0; i < ncoef; i++) { if (word(i, 0) > 1) throw std::runtime_error("bad matrix id"); max_row = std::max(max_row, word(i, 1)); }
         z.num_constraints = (size_t)max_row - z.n_public;
+        for (int m = 0; m < 2; m++) z.row_ptr[m].assign(z.num_constraints + 1, 0);
+        for (size_t i = 0; i < ncoef; i++) { const uint32_t row = word(i, 1); if (row < z.num_constraints) z.row_ptr[word(i, 0)][row + 1]++; }
+        std::vector<uint32_t> fill[2];
         for (int m = 0; m < 2; m++) {
-            z.row_ptr[m].assign(z.num_constraints + 1, 0);
-            for (auto& e : es) if (e.m == (uint32_t)m && e.row < z.num_constraints) z.row_ptr[m][e.row + 1]++;
             for (size_t i = 0; i < z.num_constraints; i++) z.row_ptr[m][i + 1] += z.row_ptr[m][i];
             z.col[m].resize(z.row_ptr[m].back()); z.coeff[m].resize(z.col[m].size());
-            std::vector<uint32_t> fill(z.row_ptr[m].begin(), z.row_ptr[m].end() - 1);
-            for (auto& e : es) if (e.m == (uint32_t)m && e.row < z.num_constraints) { uint32_t k = fill[e.row]++; z.col[m][k] = e.sig; z.coeff[m][k] = e.v; }
+            fill[m].assign(z.row_ptr[m].begin(), z.row_ptr[m].end() - 1);
+        }
+        if (!header_only) {
+            for (size_t i = 0; i < ncoef; i++) {
+                const uint32_t m = word(i, 0), row = word(i, 1);
+                if (row >= z.num_constraints) continue;
+                const uint32_t k = fill[m][row]++;
+                z.col[m][k] = word(i, 2); memcpy(z.coeff[m][k].v, rec + i * 44 + 12, 32);
+            }
+            const int nthreads = (int)std::min<size_t>(8, std::max<size_t>(1, ncoef / 65536));
+            std::vector<std::thread> th; std::vector<int> rc(2 * nthreads, 0);
+            for (int m = 0; m < 2; m++) for (int t = 0; t < nthreads; t++) th.emplace_back([&, m, t] {
+                const size_t n = z.coeff[m].size(), lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
+                if (hi > lo) rc[m * nthreads + t] = cg_fr_to_canonical(c.id, z.coeff[m].data() + lo, z.coeff[m].data() + lo, hi - lo);
+            });
+            for (auto& x : th) x.join();
+            for (int r : rc) if (r) die("cg_fr_to_canonical");
         }
     }
     return z;
@@ -336,10 +346,31 @@ public:
     int party() const { return mode == Mode::Rep3 ? net->id() : -1; }
 
     HipDriver(cg_ctx* c, Curve cv, Mode m, Rep3Network* n) : ctx(c), curve(cv), mode(m), net(n) {}
+    // CGH_TIMING=1: wall-clock marks of the host-side protocol steps (stderr)
+    struct Marks {
+        bool on; const char* what; std::chrono::steady_clock::time_point last; std::string line;
+        Marks(const char* w, bool enabled) : on(enabled && getenv("CGH_TIMING")), what(w), last(std::chrono::steady_clock::now()) {}
+        void mark(const char* name) {
+            if (!on) return;
+            const auto t = std::chrono::steady_clock::now(); char b[96];
+            snprintf(b, sizeof b, " %s %.1f", name, std::chrono::duration<double, std::milli>(t - last).count()); line += b; last = t;
+        }
+        ~Marks() { if (on) fprintf(stderr, "%s [ms]:%s\n", what, line.c_str()); }
+    };
 
     // ---- Shamir state (shamir.rs:196-246): threshold, Lagrange tables, buffered double sharings; randomness = stream rng1
     ShamirNet* snet = nullptr; int sh_t = 0;
     std::vector<Fr> open_lagrange_t, open_lagrange_2t, mul_lagrange_2t, sh_r_t, sh_r_2t;
+    // preprocessed pairs stay on the device: entries [pre_base, pre_base + pre_n) of the two buffers above are held in d_pre_* and
+    // copied to the host only when a scalar pop or the lazy path needs them
+    void* d_pre_rt = nullptr; void* d_pre_r2t = nullptr; size_t pre_base = 0, pre_n = 0; bool pre_on_host = true;
+    void release_pre() { if (d_pre_rt) { cg_dev_free(ctx, d_pre_rt); cg_dev_free(ctx, d_pre_r2t); d_pre_rt = d_pre_r2t = nullptr; } pre_n = 0; pre_on_host = true; }
+    void materialize_pre() {
+        if (pre_on_host) return;
+        const size_t live = std::min(pre_n, sh_r_t.size() > pre_base ? sh_r_t.size() - pre_base : 0);
+        if (live) { CG(cg_dev_download(ctx, sh_r_t.data() + pre_base, d_pre_rt, live * 32)); CG(cg_dev_download(ctx, sh_r_2t.data() + pre_base, d_pre_r2t, live * 32)); }
+        pre_on_host = true;
+    }
     static constexpr size_t SHAMIR_BATCH = 1024;                                     // ShamirRng::BATCH_SIZE
     Fr next_rand() { if (cursor >= rng_len) throw std::runtime_error("randomness stream exhausted"); return rng1[cursor++]; }
     std::vector<Fr> lagrange_from_coeff(const std::vector<size_t>& pts) const {       // shamir_core.rs:56-75
@@ -402,8 +433,75 @@ public:
             vandermonde_mul(in_t, sh_r_t); vandermonde_mul(in_2t, sh_r_2t);
         }
     }
+    // out[off + i*stride] = sum of terms on the device (cg_vec_lincomb_dev, at most 8 terms a launch: longer sums continue on `out`)
+    struct Term { const void* src; int64_t off, stride; Fr coeff; };
+    void lincomb(void* out, int64_t off, int64_t stride, size_t n, const std::vector<Term>& terms) {
+        const Fr one = fr_from_u64(curve, 1);
+        for (size_t at = 0; at < terms.size();) {
+            std::vector<Term> part;
+            if (at) part.push_back({out, off, stride, one});
+            while (at < terms.size() && part.size() < 8) part.push_back(terms[at++]);
+            const void* src[8]; int64_t so[8], ss[8]; Fr cf[8];
+            for (size_t j = 0; j < part.size(); j++) { src[j] = part[j].src; so[j] = part[j].off; ss[j] = part[j].stride; cf[j] = part[j].coeff; }
+            CG(cg_vec_lincomb_dev(ctx, curve.id, out, off, stride, n, (int32_t)part.size(), src, so, ss, cf));
+        }
+    }
+    // ShamirProtocol::preprocess (shamir.rs:248-250) = buffer_triples(amount) (shamir.rs:923-1010) with the share algebra on the
+    // device: the same draws from the stream in the same order (amount secrets, then per secret t + 2t coefficients), the same
+    // values appended to the pair buffers, one message per peer.  The lazily refilled batches of 1024 (get_pair) stay on the host.
+    void preprocess(size_t amount) {
+        if (!amount) return;
+        const int np = snet->num_parties(), me = snet->id(), t = sh_t;
+        const size_t draws = amount * (size_t)(1 + 3 * t);
+        if (cursor + draws > rng_len) throw std::runtime_error("randomness stream exhausted");
+        Marks mk("shamir preprocess", me == 0);
+        void* d_rnd = dalloc(draws * 32);
+        CG(cg_dev_upload(ctx, d_rnd, rng1 + cursor, draws * 32)); cursor += draws;
+        mk.mark("upload draws");
+        const Fr one = fr_from_u64(curve, 1);
+        std::vector<void*> d_got(np);
+        for (int from = 0; from < np; from++) d_got[from] = dalloc(2 * amount * 32);
+        void* d_pairs = dalloc(2 * amount * 32);
+        std::vector<Fr> buf(2 * amount);
+        for (int to = 0; to < np; to++) {                                              // ShamirCore::share for the receiver's point to + 1
+            void* dst = to == me ? d_got[me] : d_pairs;
+            const Fr x = fr_from_u64(curve, (uint64_t)to + 1);
+            std::vector<Term> a{{d_rnd, 0, 1, one}}, b{{d_rnd, 0, 1, one}};
+            Fr xp = x;
+            for (int d = 0; d < 2 * t; d++) {
+                if (d < t) a.push_back({d_rnd, (int64_t)amount + d, 3 * t, xp});
+                b.push_back({d_rnd, (int64_t)amount + t + d, 3 * t, xp});
+                xp = fr_mul(curve, xp, x);
+            }
+            lincomb(dst, 0, 2, amount, a); lincomb(dst, 1, 2, amount, b);
+            if (to != me) { CG(cg_dev_download(ctx, buf.data(), d_pairs, 2 * amount * 32)); snet->send(to, buf.data(), 2 * amount * 32); }
+        }
+        mk.mark("share+send");
+        for (int from = 0; from < np; from++) if (from != me) { snet->recv(from, buf.data(), 2 * amount * 32); CG(cg_dev_upload(ctx, d_got[from], buf.data(), 2 * amount * 32)); }
+        mk.mark("recv+upload");
+        // Vandermonde rows 1, x, .., x^t over the senders' points (shamir.rs:904-921): t + 1 outputs per secret
+        const size_t outn = amount * (size_t)(t + 1);
+        void* d_rt = dalloc(outn * 32); void* d_r2t = dalloc(outn * 32);
+        std::vector<Fr> pw(np, one);
+        for (int kk = 0; kk <= t; kk++) {
+            std::vector<Term> a, b;
+            for (int from = 0; from < np; from++) { a.push_back({d_got[from], 0, 2, pw[from]}); b.push_back({d_got[from], 1, 2, pw[from]}); }
+            lincomb(d_rt, kk, t + 1, amount, a); lincomb(d_r2t, kk, t + 1, amount, b);
+            for (int from = 0; from < np; from++) pw[from] = fr_mul(curve, pw[from], fr_from_u64(curve, (uint64_t)from + 1));
+        }
+        materialize_pre(); release_pre();                                              // an earlier preprocessed block moves to the host
+        pre_base = sh_r_t.size(); pre_n = outn; d_pre_rt = d_rt; d_pre_r2t = d_r2t; pre_on_host = false;
+        sh_r_t.resize(pre_base + outn); sh_r_2t.resize(pre_base + outn);
+        for (void* q : d_got) CG(cg_dev_free(ctx, q));
+        CG(cg_dev_free(ctx, d_rnd)); CG(cg_dev_free(ctx, d_pairs));
+        mk.mark("vandermonde+free");
+    }
     std::pair<Fr, Fr> get_pair() {                                                     // shamir.rs:1012-1025 (LIFO)
-        if (sh_r_t.empty()) buffer_triples(SHAMIR_BATCH);
+        if (sh_r_t.empty()) { release_pre(); buffer_triples(SHAMIR_BATCH); }
+        const size_t idx = sh_r_t.size() - 1;
+        if (!pre_on_host && idx >= pre_base && idx < pre_base + pre_n) {
+            CG(cg_dev_download(ctx, &sh_r_t[idx], (const Fr*)d_pre_rt + (idx - pre_base), 32)); CG(cg_dev_download(ctx, &sh_r_2t[idx], (const Fr*)d_pre_r2t + (idx - pre_base), 32));
+        }
         std::pair<Fr, Fr> pr{sh_r_t.back(), sh_r_2t.back()};
         sh_r_t.pop_back(); sh_r_2t.pop_back();
         return pr;
@@ -412,12 +510,24 @@ public:
     ShareVec degree_reduce_vec(ShareVec local) {
         const int np = snet->num_parties(), me = snet->id();
         const size_t len = local.n;
-        std::vector<Fr> rt(len), r2t(len);
-        for (size_t k = 0; k < len; k++) { auto pr = get_pair(); rt[k] = pr.first; r2t[k] = pr.second; }
+        // the len pairs on top of the LIFO buffers, top first; read straight from the device when the preprocessed block holds them all
+        const size_t top = sh_r_t.size();
+        const bool on_dev = !pre_on_host && top >= len && top - len >= pre_base && top <= pre_base + pre_n;
+        const Fr one = fr_from_u64(curve, 1);
+        std::vector<Fr> rt, r2t;
+        Marks mk(me == 0 ? "degree_reduce_vec king" : "degree_reduce_vec party 1", me <= 1);
         void* tmp = dalloc(len * 32);
-        CG(cg_dev_upload(ctx, tmp, r2t.data(), len * 32));
-        CG(cg_vec_add_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));          // input += r_2t
+        if (on_dev) {
+            lincomb(local.c[0], 0, 1, len, {{local.c[0], 0, 1, one}, {d_pre_r2t, (int64_t)(top - 1 - pre_base), -1, one}});   // input += r_2t
+        } else {
+            materialize_pre();
+            rt.resize(len); r2t.resize(len);
+            for (size_t k = 0; k < len; k++) { auto pr = get_pair(); rt[k] = pr.first; r2t[k] = pr.second; }
+            CG(cg_dev_upload(ctx, tmp, r2t.data(), len * 32));
+            CG(cg_vec_add_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));      // input += r_2t
+        }
         std::vector<Fr> buf(len);
+        mk.mark("add r_2t");
         if (me == 0) {                                                                 // KING_ID: interpolate at 0 from parties 0..2t, re-share with degree t
             CG(cg_vec_affine_dev(ctx, curve.id, local.c[0], local.c[0], len, mul_lagrange_2t[0].v, nullptr));   // acc = input * lagrange_0
             for (int other = 1; other <= 2 * sh_t; other++) {
@@ -426,6 +536,7 @@ public:
                 CG(cg_vec_affine_dev(ctx, curve.id, tmp, tmp, len, mul_lagrange_2t[other].v, nullptr));
                 CG(cg_vec_add_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));
             }
+            mk.mark("recv+interpolate");
             // ShamirCore::share per element: coefficients are drawn element by element (t per element)
             std::vector<std::vector<Fr>> coeff(sh_t, std::vector<Fr>(len));
             for (size_t k = 0; k < len; k++) for (int d = 0; d < sh_t; d++) coeff[d][k] = next_rand();
@@ -449,14 +560,22 @@ public:
             CG(cg_dev_free(ctx, local.c[0])); local.c[0] = mine;
             for (void* p : d_coeff) CG(cg_dev_free(ctx, p));
             CG(cg_dev_free(ctx, share)); CG(cg_dev_free(ctx, term));
+            mk.mark("reshare+send");
         } else {
             if (me <= 2 * sh_t) { CG(cg_dev_download(ctx, buf.data(), local.c[0], len * 32)); snet->send(0, buf.data(), len * 32); }   // only if my items are required
+            mk.mark("download+send");
             snet->recv(0, buf.data(), len * 32);
+            mk.mark("wait for king");
             CG(cg_dev_upload(ctx, local.c[0], buf.data(), len * 32));
+            mk.mark("upload");
         }
-        CG(cg_dev_upload(ctx, tmp, rt.data(), len * 32));
+        if (on_dev) {
+            lincomb(tmp, 0, 1, len, {{d_pre_rt, (int64_t)(top - 1 - pre_base), -1, one}});
+            sh_r_t.resize(top - len); sh_r_2t.resize(top - len);
+        } else CG(cg_dev_upload(ctx, tmp, rt.data(), len * 32));
         CG(cg_vec_sub_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));          // share - r_t
         CG(cg_dev_free(ctx, tmp));
+        mk.mark("sub r_t");
         return local;
     }
     Fr degree_reduce(Fr input) {                                                       // shamir.rs:252-300
@@ -1420,7 +1539,7 @@ const char* cgh_last_error(void) { return g_host_err.c_str(); }
 // info: n_vars, n_public, domain_size, pow, num_constraints, nnzA, nnzB
 int32_t cgh_zkey_info(int32_t curve, const char* path, size_t* info) {
     try {
-        cgh::ZKey z = cgh::read_zkey(curve, path);
+        cgh::ZKey z = cgh::read_zkey(curve, path, true);
         info[0] = z.n_vars; info[1] = z.n_public; info[2] = z.domain_size; info[3] = z.pow; info[4] = z.num_constraints; info[5] = z.col[0].size(); info[6] = z.col[1].size();
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
@@ -1503,7 +1622,7 @@ int32_t cgh_public_to_json(int32_t curve, const uint64_t* pub, size_t n, char* o
 // ShamirHipProtocol x n (n threads, in-process any-to-any network), threshold t.  wit[i] = party i's Shamir shares of the private
 // witness; streams[i] = party i's private randomness (consumed in the order the reference draws values).  out_proofs = n proofs.
 int32_t cgh_prove_shamir(int32_t device, int32_t curve, const char* zkey_path, int32_t n, int32_t t, const uint64_t* pub_in, const uint64_t* const* wit,
-                         const uint64_t* const* streams, size_t stream_len, uint64_t* out_proofs, uint64_t* out_h) {
+                         const uint64_t* const* streams, size_t stream_len, size_t preprocess, uint64_t* out_proofs, uint64_t* out_h) {
     try {
         using namespace cgh;
         if (n < 3) throw std::runtime_error("Shamir protocol requires at least 3 parties");        // shamir/network.rs:75-77
@@ -1525,13 +1644,19 @@ int32_t cgh_prove_shamir(int32_t device, int32_t curve, const char* zkey_path, i
                 HipDriver driver(ctx, z.curve, Mode::Shamir, nullptr);
                 driver.rng1 = (const Fr*)streams[i]; driver.rng_len = stream_len;
                 driver.shamir_init(&net, t);
+                const auto ta = std::chrono::steady_clock::now();
+                driver.preprocess(preprocess);                                            // 0 = the reference's lazy batches of 1024
+                const auto tb = std::chrono::steady_clock::now();
                 ShareVec w = driver.upload_vec((const Fr*)wit[i], nullptr, n_aux);
                 CoGroth16 prover(driver);
                 ShareVec h;
                 Proof p = prover.prove(dz, pub, w, nullptr, &h);
+                if (i == 0 && getenv("CGH_TIMING"))
+                    fprintf(stderr, "cgh_prove_shamir party 0: preprocess %.1f ms, prove %.1f ms\n", std::chrono::duration<double, std::milli>(tb - ta).count(),
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count());
                 store_proof(p, (uint8_t*)out_proofs + i * psz);
                 if (out_h && i == 0) CG(cg_dev_download(ctx, out_h, h.c[0], h.n * 32));
-                driver.free_vec(h); driver.free_vec(w);
+                driver.free_vec(h); driver.free_vec(w); driver.release_pre();
                 cg_ctx_destroy(ctx);
             } catch (const std::exception& e) { errs[i] = e.what(); hub.abort(); if (ctx) cg_ctx_destroy(ctx); }
         });

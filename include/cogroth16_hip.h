@@ -135,6 +135,13 @@ int32_t cg_vec_distribute_powers_dev(cg_ctx* ctx, int32_t curve, void* d_v, size
 int32_t cg_vec_affine_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_a, size_t n, const void* h_c, const void* h_d);
 int32_t cg_vec_fill_dev(cg_ctx* ctx, int32_t curve, void* d_v, size_t n, const void* h_value);
 int32_t cg_vec_gather_strided_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n, size_t offset, size_t stride);
+/* Strided linear combination: out[out_off + i*out_stride] = sum_{j < n_terms} coeff[j] * src[j][src_off[j] + i*src_stride[j]], i < n.
+ * Offsets and strides count elements; strides may be negative (reading a LIFO buffer backwards); 1 <= n_terms <= 8; h_coeffs =
+ * n_terms Montgomery elements on the host.  One launch covers each step of the Shamir share algebra on device-resident vectors:
+ * ShamirCore::share (shamir_core.rs:8-31), the Vandermonde step of buffer_triples (shamir.rs:904-921), the king's interpolation in
+ * degree_reduce_vec (shamir.rs:330-345) and open_many (shamir.rs:581-601).  d_out must not overlap a source it reads differently. */
+int32_t cg_vec_lincomb_dev(cg_ctx* ctx, int32_t curve, void* d_out, int64_t out_off, int64_t out_stride, size_t n, int32_t n_terms,
+                           const void* const* d_src, const int64_t* src_off, const int64_t* src_stride, const void* h_coeffs);
 int32_t cg_vec_prefix_prod_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n);
 int32_t cg_vec_prefix_sum_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n);
 int32_t cg_vec_inverse_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_in, size_t n);

@@ -434,7 +434,7 @@ int orc_prove_rep3(void* h, const uint64_t* pub, const uint64_t* const* wit_a, c
 // Shamir (n parties, threshold t): wit[i] = party i's shares of the private witness, streams[i] = party i's private randomness.
 // out_proofs = n proofs; out_h (optional) = party 0's h shares
 int orc_prove_shamir(void* h, int n, int t, const uint64_t* pub, const uint64_t* const* wit, const uint64_t* const* streams, size_t stream_len,
-                     int threads, uint64_t* out_proofs, uint64_t* out_h) {
+                     size_t preprocess, int threads, uint64_t* out_proofs, uint64_t* out_h) {
     ZK(h, {
         typedef typename C::Fr Fr;
         const size_t n_aux = z.n_vars - z.n_public - 1;
@@ -451,6 +451,7 @@ int orc_prove_shamir(void* h, int n, int t, const uint64_t* pub, const uint64_t*
             sim.stream[i] = &st_[i];
         }
         std::vector<std::vector<Fr>> hs;
+        sim.preprocess(preprocess);
         auto out = sim.prove(&hs);
         const int psz = 8 * C::Fq::N;
         for (int i = 0; i < n; i++) st_proof<C>(out_proofs + i * psz, out[i]);

@@ -82,6 +82,7 @@ struct ShamirSim {
         out.push_back(s0);
         for (int k = 1; k <= t; k++) { Fr acc = Fr::zero(); for (int p = 0; p < n; p++) { acc = acc + curr[p] * in[p]; curr[p] = curr[p] * row[p]; } out.push_back(acc); }
     }
+    void preprocess(size_t amount) { if (amount) buffer_triples(amount); }                        // :248-250
     // one pair per party, taken in lock-step (:1012-1025)
     void get_pairs(std::vector<Fr>& rt, std::vector<Fr>& r2t) {
         if (r_t[0].empty()) buffer_triples(BATCH);

@@ -26,5 +26,17 @@ for log_m in [int(x) for x in sys.argv[1:]] or [16, 18]:
     v1 = z.points("vk_g1"); v2 = z.points("vk_g2")
     vk = {"alpha1": v1[0], "beta2": v2[0], "gamma2": v2[1], "delta2": v2[2], "ic": z.points("ic")}
     ok = orc.verify(BN254, vk, w[1:2], proof) and orc.verify(BN254, vk, w[1:2], proofs[0])
+    t_sh = t_shp = float("nan")
+    if os.environ.get("E2E_SHAMIR", "1") != "0":
+        n, t = 3, 1
+        wits = orc.shamir_share(BN254, w[2:], n, t, rng)
+        need = (2 * m + 4) // (1024 * (t + 1)) + 1
+        amount = (2 * m + 8) // (t + 1) + 1
+        sstreams = [orc.random_field(BN254, FR, (need * 1024 + amount) * (1 + 3 * t) + t * (2 * m + 8), rng) for _ in range(n)]
+        t0 = time.time(); sproofs = cg.prove_shamir(BN254, zp, n, t, w[:2], wits, sstreams); t_sh = time.time() - t0
+        ok = ok and orc.verify(BN254, vk, w[1:2], sproofs[0])
+        t0 = time.time(); sproofs = cg.prove_shamir(BN254, zp, n, t, w[:2], wits, sstreams, preprocess=amount); t_shp = time.time() - t0
+        ok = ok and orc.verify(BN254, vk, w[1:2], sproofs[0])
     print(f"2^{log_m}: zkey {os.path.getsize(zp) / 1e6:.0f} MB (generated in {t_gen:.1f} s); file -> proof: plain {t_plain * 1e3:.0f} ms, "
-          f"3 REP3 parties on one GPU {t_rep3 * 1e3:.0f} ms; verify {'ok' if ok else 'FAILED'}", flush=True)
+          f"3 REP3 parties on one GPU {t_rep3 * 1e3:.0f} ms, "
+          f"3 Shamir parties (t = 1) {t_sh * 1e3:.0f} ms lazy double sharings / {t_shp * 1e3:.0f} ms preprocessed on the GPU; verify {'ok' if ok else 'FAILED'}", flush=True)

@@ -229,7 +229,7 @@ class ZKey:
         return (out, h) if want_h else out
 
 
-def prove_shamir(self_zkey, n, t, pub, wits, streams, threads=1, want_h=False):
+def prove_shamir(self_zkey, n, t, pub, wits, streams, threads=1, want_h=False, preprocess=0):
     """oracle/shamir.hpp: n parties in lock-step; returns (n proofs[, party 0's h shares])"""
     z = self_zkey
     nq = nlimbs(z.curve, FQ)
@@ -238,7 +238,7 @@ def prove_shamir(self_zkey, n, t, pub, wits, streams, threads=1, want_h=False):
     out = np.zeros((n, 8 * nq), dtype=np.uint64)
     h = np.zeros((z.domain_size, 4), dtype=np.uint64) if want_h else None
     _chk(lib().orc_prove_shamir(C.c_void_p(z.h), n, t, _p(np.ascontiguousarray(pub, dtype=np.uint64)), arr(keep[0]), arr(keep[1]),
-                                C.c_size_t(keep[1][0].shape[0]), threads, _p(out), _p(h) if want_h else None))
+                                C.c_size_t(keep[1][0].shape[0]), C.c_size_t(int(preprocess)), threads, _p(out), _p(h) if want_h else None))
     return (out, h) if want_h else out
 
 

@@ -548,6 +548,36 @@ def test_vec_prefix_product_inverse_affine(ctx, curve, n):
         np.testing.assert_array_equal(d_g.download((m, 4)), x[off:off + st * m:st][:m])
 
 
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
+def test_vec_lincomb_strided(ctx, curve):
+    """strided linear combination (the Shamir share algebra in one launch): forward / negative / interleaving strides, unit coefficients"""
+    rng = np.random.default_rng(77)
+    n = 5001
+    xs = [orc.random_field(curve, FR, 3 * n, rng) for _ in range(3)]
+    d_xs = [dev(ctx, x) for x in xs]
+    one = orc.from_dec(curve, FR, "1")
+    cs = orc.random_field(curve, FR, 3, rng); cs[1] = one
+    mulc = lambda c, v: orc.field_op(curve, FR, "mul", v, np.broadcast_to(c, v.shape).copy())
+    add = lambda a, b: orc.field_op(curve, FR, "add", a, b)
+    # out[2i + 1] = c0 * x0[3i + 2] + 1 * x1[3n - 1 - i] + c2 * x2[i]
+    d_o = ctx.alloc(2 * n * 32); ctx.vec_fill(curve, d_o, 2 * n, np.zeros(4, dtype=np.uint64))
+    ctx.vec_lincomb(curve, d_o, 1, 2, n, d_xs, [2, 3 * n - 1, 0], [3, -1, 1], cs)
+    got = d_o.download((2 * n, 4))
+    want = add(add(mulc(cs[0], xs[0][2::3][:n]), xs[1][::-1][:n]), mulc(cs[2], xs[2][:n]))
+    np.testing.assert_array_equal(got[1::2], want)
+    assert not got[0::2].any()
+    # single term, reversed copy with unit coefficient; eight terms
+    ctx.vec_lincomb(curve, d_o, 0, 1, n, [d_xs[0]], [n - 1], [-1], one[None])
+    np.testing.assert_array_equal(d_o.download((2 * n, 4))[:n], xs[0][:n][::-1])
+    c8 = orc.random_field(curve, FR, 8, rng)
+    ctx.vec_lincomb(curve, d_o, 0, 1, n, [d_xs[j % 3] for j in range(8)], [j for j in range(8)], [1] * 8, c8)
+    want = np.zeros((n, 4), dtype=np.uint64)
+    for j in range(8): want = add(want, mulc(c8[j], xs[j % 3][j:j + n]))
+    np.testing.assert_array_equal(d_o.download((2 * n, 4))[:n], want)
+    with pytest.raises(cg.BackendError):
+        ctx.vec_lincomb(curve, d_o, 0, 1, n, [d_xs[0]] * 9, [0] * 9, [1] * 9, orc.random_field(curve, FR, 9, rng))
+
+
 @pytest.mark.parametrize("group", [G1, G2])
 def test_msm_table_with_many_infinity_points(ctx, group):
     """tables that are sparse in points (B queries of real zkeys) are compacted at registration: results must not change — whole table,

@@ -24,15 +24,20 @@ def vk_of(z):
     return {"alpha1": v1[0], "beta2": v2[0], "gamma2": v2[1], "delta2": v2[2], "ic": z.points("ic")}
 
 
-def setup(curve_name, circuit, n, t, seed):
+def setup(curve_name, circuit, n, t, seed, preprocess=0):
     curve = CURVES[curve_name]
     z = orc.ZKey(curve, fx(curve_name, circuit, "circuit.zkey")); w = orc.read_wtns(curve, fx(curve_name, circuit, "witness.wtns"))
     rng = np.random.default_rng(seed)
     wits = orc.shamir_share(curve, w[z.n_public + 1:], n, t, rng)
     # per party: one batch of 1024 double sharings costs 1024 * (1 + 3t) draws; the king adds t per re-shared element
     need = (2 * z.domain_size + 4) // (1024 * (t + 1)) + 1
-    streams = [orc.random_field(curve, FR, need * 1024 * (1 + 3 * t) + t * (2 * z.domain_size + 8), rng) for _ in range(n)]
+    streams = [orc.random_field(curve, FR, (need * 1024 + preprocess) * (1 + 3 * t) + t * (2 * z.domain_size + 8), rng) for _ in range(n)]
     return curve, z, w, wits, streams
+
+
+def full_amount(z, t):
+    """secrets to double-share so that one proof never refills: two mul_vec over the domain + the O(1) scalar pairs"""
+    return (2 * z.domain_size + 8) // (t + 1) + 1
 
 
 @pytest.mark.parametrize("curve_name,circuit", FIXTURES)
@@ -49,6 +54,37 @@ def test_oracle_shamir_proofs_agree_and_verify(curve_name, circuit, n, t):
     curve, z, w, wits2, streams2 = setup(curve_name, circuit, n, t, seed=12)
     other = orc.prove_shamir(z, n, t, w[:z.n_public + 1], wits2, streams2)
     assert not np.array_equal(other[0], proofs[0]) and orc.verify(curve, vk_of(z), w[1:z.n_public + 1], other[0])
+
+
+@pytest.mark.parametrize("n,t,amount", [(3, 1, None), (3, 1, 100), (5, 2, None)])
+def test_oracle_shamir_preprocess(n, t, amount):
+    """ShamirProtocol::preprocess (shamir.rs:248): double sharings made up front, in one batch, instead of lazily by 1024"""
+    curve, z, w, _, _ = setup("bn254", "poseidon", n, t, seed=13)
+    amount = full_amount(z, t) if amount is None else amount
+    curve, z, w, wits, streams = setup("bn254", "poseidon", n, t, seed=13, preprocess=amount)
+    proofs = orc.prove_shamir(z, n, t, w[:z.n_public + 1], wits, streams, preprocess=amount)
+    for p in proofs[1:]:
+        np.testing.assert_array_equal(p, proofs[0])
+    assert orc.verify(curve, vk_of(z), w[1:z.n_public + 1], proofs[0])
+    lazy = orc.prove_shamir(z, n, t, w[:z.n_public + 1], wits, streams)
+    assert not np.array_equal(lazy[0], proofs[0])                       # other pairs -> other r, s -> another valid proof
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name,circuit,n,t,amount", [("bn254", "poseidon", 3, 1, None), ("bn254", "poseidon", 3, 1, 100), ("bls12_381", "poseidon", 5, 2, None),
+                                                           ("bn254", "multiplier2", 9, 4, None), ("bn254", "multiplier2", 9, 4, 3)])
+def test_gpu_shamir_preprocess_matches_oracle(curve_name, circuit, n, t, amount):
+    """double sharings generated on the GPU (one strided linear combination per share / Vandermonde row; 9 parties = more than 8 terms)
+    equal the oracle's buffer_triples(amount); a short amount falls back to the lazy host batches afterwards"""
+    ensure_built()
+    _, z, _, _, _ = setup(curve_name, circuit, n, t, seed=23)
+    amount = full_amount(z, t) if amount is None else amount
+    curve, z, w, wits, streams = setup(curve_name, circuit, n, t, seed=23, preprocess=amount)
+    want, want_h = orc.prove_shamir(z, n, t, w[:z.n_public + 1], wits, streams, want_h=True, preprocess=amount)
+    got, got_h = cg.prove_shamir(curve, fx(curve_name, circuit, "circuit.zkey"), n, t, w[:z.n_public + 1], wits, streams, want_h=True, preprocess=amount)
+    np.testing.assert_array_equal(got_h, want_h)
+    np.testing.assert_array_equal(got, want)
+    assert orc.verify(curve, vk_of(z), w[1:z.n_public + 1], got[0])
 
 
 @pytest.mark.gpu
