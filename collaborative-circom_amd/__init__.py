@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute", "cg_bases_check_on_curve", "cg_bases_check_subgroup",
     "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_scatter_capacity",
     "cg_ntt", "cg_ntt_dev",
+    "cg_host_alloc", "cg_host_free", "cg_dev_download_begin", "cg_dev_upload_begin", "cg_copy_wait", "cg_copy_fence",
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev", "cg_vec_affine_dev", "cg_vec_fill_dev", "cg_vec_gather_strided_dev", "cg_vec_lincomb_dev", "cg_vec_prefix_prod_dev", "cg_vec_prefix_sum_dev", "cg_vec_inverse_dev",
     "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
     "cg_point_add", "cg_point_neg", "cg_point_scalar_mul", "cg_point_to_affine", "cg_point_from_affine", "cg_fr_op",
@@ -188,6 +189,30 @@ class Context:
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)
         return DevBuf(self, max(arr.nbytes, 16)).upload(arr)
+
+    # ---- page-locked staging + asynchronous copies (exchange chunks move under the compute)
+    def host_alloc(self, shape, dtype=np.uint64):
+        """page-locked numpy array (free with host_free)"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        _chk(load().cg_host_alloc(C.c_size_t(n), C.byref(p)))
+        arr = np.ctypeslib.as_array((C.c_uint8 * max(n, 1)).from_address(p.value))[:n].view(dtype).reshape(shape)
+        return arr
+
+    def host_free(self, arr): _chk(load().cg_host_free(C.c_void_p(arr.ctypes.data)))
+
+    def download_begin(self, h_dst, d_src, nbytes=None, offset=0):
+        t = C.c_int32(-1)
+        _chk(load().cg_dev_download_begin(self.h, _hp(h_dst), C.c_void_p(_dp(d_src).value + offset), C.c_size_t(h_dst.nbytes if nbytes is None else nbytes), C.byref(t)))
+        return t.value
+
+    def upload_begin(self, d_dst, h_src, after_stream=True, nbytes=None, offset=0):
+        t = C.c_int32(-1)
+        _chk(load().cg_dev_upload_begin(self.h, C.c_void_p(_dp(d_dst).value + offset), _hp(h_src), C.c_size_t(h_src.nbytes if nbytes is None else nbytes), int(bool(after_stream)), C.byref(t)))
+        return t.value
+
+    def copy_wait(self, ticket): _chk(load().cg_copy_wait(self.h, int(ticket)))
+    def copy_fence(self, ticket): _chk(load().cg_copy_fence(self.h, int(ticket)))
 
     # ---- MSM
     def register_bases(self, curve, group, points, stride=None, infinity_offset=-1):

@@ -93,6 +93,10 @@ struct cg_ctx {
     // accumulated (integer-VALU bound) on the main stream; two rotating schedule slots
     hipStream_t sortst = nullptr;
     hipEvent_t ev_in = nullptr, ev_sorted[2] = {nullptr, nullptr}, ev_sched_free[2] = {nullptr, nullptr};
+    // copy streams of the asynchronous host <-> device transfers (cg_dev_*_begin): MPC exchanges move under the compute
+    static constexpr int COPY_TICKETS = 256;
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    hipEvent_t copy_ev[COPY_TICKETS] = {}; hipEvent_t ev_copy_order = nullptr; uint32_t copy_next = 0;
     Arena arena;
     void* gather_buf = nullptr; size_t gather_cap = 0;   // scalars gathered for compacted tables (see cg_bases::compact)
     std::map<TwKey, void*> twiddles;
@@ -617,6 +621,12 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     hipStreamSynchronize(ctx->sortst);
     for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_acc[i]); hipEventDestroy(ctx->ev_red[i]); hipEventDestroy(ctx->ev_sorted[i]); hipEventDestroy(ctx->ev_sched_free[i]); }
     hipEventDestroy(ctx->ev_in);
+    if (ctx->h2d) {
+        hipStreamSynchronize(ctx->h2d); hipStreamSynchronize(ctx->d2h);
+        for (hipEvent_t e : ctx->copy_ev) if (e) hipEventDestroy(e);
+        hipEventDestroy(ctx->ev_copy_order);
+        hipStreamDestroy(ctx->h2d); hipStreamDestroy(ctx->d2h);
+    }
     hipStreamDestroy(ctx->aux);
     hipStreamDestroy(ctx->sortst);
     for (auto& kv : ctx->twiddles) hipFree(kv.second);
@@ -633,6 +643,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
 int32_t cg_ctx_sync(cg_ctx* ctx) {
     if (!ctx) return fail(CG_ERR_ARG, "null ctx");
     HIPCHK(hipStreamSynchronize(ctx->sortst)); HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->aux));
+    if (ctx->h2d) { HIPCHK(hipStreamSynchronize(ctx->h2d)); HIPCHK(hipStreamSynchronize(ctx->d2h)); }
     return 0;
 }
 void* cg_ctx_stream(cg_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -669,6 +680,51 @@ int32_t cg_dev_download(cg_ctx* ctx, void* h_dst, const void* d_src, size_t byte
     if (!ctx) return fail(CG_ERR_ARG, "null ctx");
     HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+// ---- page-locked staging and asynchronous copies (the mul_vec / degree_reduce exchanges move in chunks under the compute)
+int32_t cg_host_alloc(size_t bytes, void** h_ptr) {
+    if (!h_ptr) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipHostMalloc(h_ptr, std::max<size_t>(bytes, 16), hipHostMallocDefault));
+    return 0;
+}
+int32_t cg_host_free(void* h_ptr) {
+    if (h_ptr) HIPCHK(hipHostFree(h_ptr));
+    return 0;
+}
+static int32_t copy_begin(cg_ctx* ctx, bool up, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, bool after_stream, int32_t* ticket) {
+    if (!ctx || !ticket || ((!dst || !src) && bytes)) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->h2d) {                                        // the copy streams exist from the first asynchronous copy on
+        HIPCHK(hipStreamCreateWithFlags(&ctx->h2d, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&ctx->d2h, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_copy_order, hipEventDisableTiming));
+    }
+    hipStream_t st = up ? ctx->h2d : ctx->d2h;
+    if (after_stream) {                                     // everything enqueued on the context's stream so far comes first
+        HIPCHK(hipEventRecord(ctx->ev_copy_order, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_copy_order, 0));
+    }
+    if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, kind, st));
+    const uint32_t slot = ctx->copy_next++ % cg_ctx::COPY_TICKETS;
+    if (!ctx->copy_ev[slot]) HIPCHK(hipEventCreateWithFlags(&ctx->copy_ev[slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ctx->copy_ev[slot], st));
+    *ticket = (int32_t)slot;
+    return 0;
+}
+int32_t cg_dev_download_begin(cg_ctx* ctx, void* h_dst_pinned, const void* d_src, size_t bytes, int32_t* ticket) {
+    return copy_begin(ctx, false, h_dst_pinned, d_src, bytes, hipMemcpyDeviceToHost, true, ticket);
+}
+int32_t cg_dev_upload_begin(cg_ctx* ctx, void* d_dst, const void* h_src_pinned, size_t bytes, int32_t after_stream, int32_t* ticket) {
+    return copy_begin(ctx, true, d_dst, h_src_pinned, bytes, hipMemcpyHostToDevice, after_stream != 0, ticket);
+}
+int32_t cg_copy_wait(cg_ctx* ctx, int32_t ticket) {
+    if (!ctx || ticket < 0 || ticket >= cg_ctx::COPY_TICKETS || !ctx->copy_ev[ticket]) return fail(CG_ERR_ARG, "bad copy ticket");
+    HIPCHK(hipEventSynchronize(ctx->copy_ev[ticket]));
+    return 0;
+}
+int32_t cg_copy_fence(cg_ctx* ctx, int32_t ticket) {
+    if (!ctx || ticket < 0 || ticket >= cg_ctx::COPY_TICKETS || !ctx->copy_ev[ticket]) return fail(CG_ERR_ARG, "bad copy ticket");
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->copy_ev[ticket], 0));
     return 0;
 }
 int32_t cg_dev_memset_zero(cg_ctx* ctx, void* d_dst, size_t bytes) {

@@ -650,27 +650,115 @@ public:
         if (holder >= 0) CG(cg_dev_upload(ctx, (uint8_t*)dst.c[holder] + dst_off * 32, pub.data(), pub.size() * 32));
     }
     // mul_vec (traits.rs:164): plain.rs:219-224 ; rep3.rs:650-670 (local product + mask, send to next, receive from prev)
-    ShareVec mul_vec(const ShareVec& a, const ShareVec& b) {
-        ShareVec out; out.n = a.n;
+    // ---- page-locked staging rings for the asynchronous exchanges: chunks of XCHG_CHUNK elements travel over the
+    // context's copy streams while the compute stream keeps running; a slot is reused once the copy that used it has completed
+    static constexpr size_t XCHG_CHUNK_MAX = (size_t)1 << 17;                           // 4 MiB of field elements
+    static constexpr int XCHG_SLOTS = 8;
+    // chunk length for a vector of n elements: about n / 8, a power of two in [4096, 2^17] (page-locking memory is slow: small proofs get small rings)
+    static size_t xchg_chunk(size_t n) { size_t c = 4096; while (c < XCHG_CHUNK_MAX && c * XCHG_SLOTS < n) c <<= 1; return c; }
+    struct PinRing { uint8_t* base = nullptr; size_t chunk = 0; int32_t busy[XCHG_SLOTS]; int next = 0; int last = 0; };
+    PinRing ring_out, ring_in;
+    uint8_t* ring_slot(PinRing& r, size_t chunk) {
+        if (r.chunk < chunk) {                                                          // first use, or a longer vector than before
+            if (r.base) { CG(cg_ctx_sync(ctx)); CG(cg_host_free(r.base)); }
+            void* p; CG(cg_host_alloc(XCHG_SLOTS * chunk * 32, &p)); r.base = (uint8_t*)p; r.chunk = chunk; for (int32_t& b : r.busy) b = -1;
+        }
+        r.last = r.next++ % XCHG_SLOTS;
+        if (r.busy[r.last] >= 0) { CG(cg_copy_wait(ctx, r.busy[r.last])); r.busy[r.last] = -1; }
+        return r.base + (size_t)r.last * r.chunk * 32;
+    }
+    void release_rings() { for (PinRing* r : {&ring_out, &ring_in}) if (r->base) { cg_ctx_sync(ctx); cg_host_free(r->base); r->base = nullptr; r->chunk = 0; } }
+    std::vector<void*> deferred;                                                        // device buffers freed at the next quiet point
+    void defer_free(void* p) { if (p) deferred.push_back(p); }
+    void free_deferred() { for (void* p : deferred) CG(cg_dev_free(ctx, p)); deferred.clear(); }
+    // host (pageable) -> device through the ring, asynchronous; returns the ticket of the last chunk
+    int32_t upload_staged(void* d_dst, const Fr* src, size_t n) {
+        int32_t tk = -1;
+        const size_t ch = xchg_chunk(n);
+        for (size_t off = 0; off < n; off += ch) {
+            const size_t len = std::min(ch, n - off);
+            uint8_t* slot = ring_slot(ring_in, ch);
+            memcpy(slot, src + off, len * 32);
+            CG(cg_dev_upload_begin(ctx, (uint8_t*)d_dst + off * 32, slot, len * 32, 0, &tk));
+            ring_in.busy[ring_in.last] = tk;
+        }
+        return tk;
+    }
+    // mul_vec (rep3.rs:650-670) in two halves, so that the caller can enqueue independent work between the local product and the
+    // exchange: `begin` masks and multiplies on the device and starts streaming the local product to the host; `finish` sends it to
+    // the next party chunk by chunk while receiving the previous party's chunks, which go straight back up.  Plain / Shamir: `begin`
+    // is the whole operation.
+    // shorter vectors: one synchronous message (setting up rings and copy streams costs more than it hides); CGH_XCHG_ASYNC_MIN overrides (A/B runs)
+    const size_t XCHG_ASYNC_MIN = getenv("CGH_XCHG_ASYNC_MIN") ? (size_t)atoll(getenv("CGH_XCHG_ASYNC_MIN")) : (size_t)1 << 19;
+    struct PendingMul { ShareVec out; bool exchange = false; };
+    PendingMul mul_vec_begin(const ShareVec& a, const ShareVec& b) {
+        PendingMul pm; ShareVec& out = pm.out; out.n = a.n;
         out.c[0] = dalloc(a.n * 32);
         if (mode != Mode::Rep3) CG(cg_vec_mul_dev(ctx, curve.id, out.c[0], a.c[0], b.c[0], a.n));
-        if (mode == Mode::Plain) return out;
-        if (mode == Mode::Shamir) return degree_reduce_vec(out);                     // shamir.rs:609-623
+        if (mode == Mode::Plain) return pm;
+        if (mode == Mode::Shamir) { out = degree_reduce_vec(out); return pm; }         // shamir.rs:609-623
         if (cursor + a.n > rng_len) throw std::runtime_error("randomness stream exhausted");
         void* m1 = dalloc(a.n * 32); void* m2 = dalloc(a.n * 32);
-        CG(cg_dev_upload(ctx, m1, rng1 + cursor, a.n * 32)); CG(cg_dev_upload(ctx, m2, rng2 + cursor, a.n * 32));
+        if (a.n < XCHG_ASYNC_MIN) { CG(cg_dev_upload(ctx, m1, rng1 + cursor, a.n * 32)); CG(cg_dev_upload(ctx, m2, rng2 + cursor, a.n * 32)); }
+        else {
+            upload_staged(m1, rng1 + cursor, a.n);
+            const int32_t tk = upload_staged(m2, rng2 + cursor, a.n);
+            if (tk >= 0) CG(cg_copy_fence(ctx, tk));                                   // uploads complete in order: the last ticket covers both masks
+        }
         cursor += a.n;
-        CG(cg_vec_sub_dev(ctx, curve.id, m1, m1, m2, a.n));                         // masking_field_element = rand(rng1) - rand(rng2)
+        CG(cg_vec_sub_dev(ctx, curve.id, m1, m1, m2, a.n));                           // masking_field_element = rand(rng1) - rand(rng2)
         CG(cg_vec_rep3_mul_local_dev(ctx, curve.id, out.c[0], a.c[0], a.c[1], b.c[0], b.c[1], m1, a.n));
-        std::vector<Fr> local(a.n), recv(a.n);
-        CG(cg_dev_download(ctx, local.data(), out.c[0], a.n * 32));
-        net->send_next(local.data(), a.n * 32);
-        net->recv_prev(recv.data(), a.n * 32);
+        defer_free(m1); defer_free(m2);
         out.c[1] = dalloc(a.n * 32);
-        CG(cg_dev_upload(ctx, out.c[1], recv.data(), a.n * 32));
-        CG(cg_dev_free(ctx, m1)); CG(cg_dev_free(ctx, m2));
+        pm.exchange = true;
+        return pm;
+    }
+    ShareVec mul_vec_finish(PendingMul& pm) {
+        if (!pm.exchange) return pm.out;
+        ShareVec& out = pm.out;
+        pm.exchange = false;
+        if (out.n < XCHG_ASYNC_MIN) {                                                  // rep3.rs:661-669 as one message
+            std::vector<Fr> local(out.n), recv(out.n);
+            CG(cg_dev_download(ctx, local.data(), out.c[0], out.n * 32));
+            net->send_next(local.data(), out.n * 32);
+            net->recv_prev(recv.data(), out.n * 32);
+            CG(cg_dev_upload(ctx, out.c[1], recv.data(), out.n * 32));
+            return out;
+        }
+        const size_t n = out.n, XCHG_CHUNK = xchg_chunk(n), nch = (n + XCHG_CHUNK - 1) / XCHG_CHUNK;
+        struct Down { uint8_t* slot; int32_t tk; };
+        std::deque<Down> down;
+        size_t issued = 0;
+        int32_t up = -1;
+        for (size_t c = 0; c < nch; c++) {
+            while (issued < nch && issued < c + XCHG_SLOTS - 1) {                      // keep the download stream ahead of the sender
+                const size_t off = issued * XCHG_CHUNK, len = std::min(XCHG_CHUNK, n - off);
+                Down d; d.slot = ring_slot(ring_out, XCHG_CHUNK);
+                CG(cg_dev_download_begin(ctx, d.slot, (const uint8_t*)out.c[0] + off * 32, len * 32, &d.tk));
+                ring_out.busy[ring_out.last] = d.tk;
+                down.push_back(d); issued++;
+            }
+            const size_t off = c * XCHG_CHUNK, len = std::min(XCHG_CHUNK, n - off);
+            CG(cg_copy_wait(ctx, down.front().tk));
+            net->send_next(down.front().slot, len * 32);                               // chunked send_next_many
+            down.pop_front();
+            uint8_t* slot = ring_slot(ring_in, XCHG_CHUNK);
+            net->recv_prev(slot, len * 32);
+            CG(cg_dev_upload_begin(ctx, (uint8_t*)out.c[1] + off * 32, slot, len * 32, 0, &up));
+            ring_in.busy[ring_in.last] = up;
+        }
+        if (up >= 0) CG(cg_copy_fence(ctx, up));                                       // later launches see the received component
+        pm.exchange = false;
         return out;
     }
+    ShareVec mul_vec(const ShareVec& a, const ShareVec& b) { PendingMul pm = mul_vec_begin(a, b); ShareVec r = mul_vec_finish(pm); free_deferred(); return r; }
+    // before the context goes away (idempotent; also run by the destructor when a party dies with an exception)
+    void shutdown() {
+        for (void* p : deferred) cg_dev_free(ctx, p);
+        deferred.clear();
+        release_rings(); release_pre();
+    }
+    ~HipDriver() { shutdown(); }
     // ---- vector forms of rand / mul_open_many / open_many used by co-plonk (rep3.rs:544-558,595-598,620-628,738-757)
     int public_component() const { return mode != Mode::Rep3 ? 0 : (party() == 0 ? 0 : party() == 1 ? 1 : -1); }   // add_with_public: who holds a public addend
     // broadcast_next(num) of a vector + reconstruction with the given Lagrange table (shamir/network.rs:233-266, shamir.rs:581-601,684-711)
@@ -821,16 +909,28 @@ public:
         ShareVec a = driver.evaluate_constraints(dz.mat[0], dz.pub_dev, (uint32_t)num_inputs, private_witness, dom.m);   // :156-166
         ShareVec b = driver.evaluate_constraints(dz.mat[1], dz.pub_dev, (uint32_t)num_inputs, private_witness, dom.m);
         driver.clone_public_into(a, num_constraints, public_inputs);                                   // :168-171
-        ShareVec c = driver.mul_vec(a, b);                                                             // :174
+        // The two mul_vec exchanges (:174, :190) run under the transforms that do not depend on them: the local product is started,
+        // the independent NTTs are enqueued, then the party-to-party exchange proceeds while the GPU works (values as in the reference).
+        HipDriver::Marks mk("witness_map party 0", driver.party() <= 0);
+        mk.mark("spmv enqueue");
+        auto c_pending = driver.mul_vec_begin(a, b);                                                   // :174
+        mk.mark("mul_vec_begin");
         driver.ifft_coset_in_place(a, dom.omega, dom.coset_g);                                         // :175,177-181
         driver.ifft_coset_in_place(b, dom.omega, dom.coset_g);                                         // :176,182-186
         driver.fft_in_place(a, dom.omega); driver.fft_in_place(b, dom.omega);                          // :187-188
-        ShareVec ab = driver.mul_vec(a, b);                                                            // :190
-        driver.free_vec(a); driver.free_vec(b);
+        mk.mark("ntt enqueue");
+        ShareVec c = driver.mul_vec_finish(c_pending);
+        mk.mark("mul_vec_finish");
+        auto ab_pending = driver.mul_vec_begin(a, b);                                                  // :190
+        mk.mark("mul_vec_begin");
         driver.ifft_coset_in_place(c, dom.omega, dom.coset_g);                                         // :194-199
         driver.fft_in_place(c, dom.omega);                                                             // :200
+        mk.mark("ntt enqueue");
+        ShareVec ab = driver.mul_vec_finish(ab_pending);
+        mk.mark("mul_vec_finish");
         driver.sub_assign_vec(ab, c);                                                                  // :202
-        driver.free_vec(c);
+        driver.free_vec(a); driver.free_vec(b); driver.free_vec(c); driver.free_deferred();
+        mk.mark("free (sync)");
         return ab;
     }
 
@@ -853,12 +953,15 @@ public:
     // groth16.rs:113-139 + :237-326
     Proof prove(const DeviceZKey& dz, const std::vector<Fr>& public_inputs, const ShareVec& private_witness, const FieldShare* rs_plain, ShareVec* h_out = nullptr) {
         const ZKey& z = *dz.z; const Curve& c = driver.curve;
+        HipDriver::Marks mk("prove party 0", driver.party() <= 0);
         ShareVec h = witness_map_from_matrices(dz, public_inputs, private_witness);
+        mk.mark("witness map");
         FieldShare r = rs_plain ? rs_plain[0] : driver.rand();                                         // :134-135
         FieldShare s = rs_plain ? rs_plain[1] : driver.rand();
         std::vector<Fr> input_assignment(public_inputs.begin() + 1, public_inputs.end());
         PointShare h_acc = driver.msm_public_points(dz.h, CG_G1, 0, h.n, h);                           // :248
         PointShare l_aux_acc = driver.msm_public_points(dz.l, CG_G1, 0, private_witness.n, private_witness);   // :251
+        mk.mark("msm h + l");
         const Point delta_g1 = pt_from_affine(c, CG_G1, z.delta_g1.data());
         FieldShare rs = driver.mul(r, s);                                                              // :258
         PointShare r_s_delta_g1 = driver.scalar_mul_public_point(delta_g1, rs);                        // :259
@@ -877,7 +980,9 @@ public:
         driver.sub_assign_points(g_c, r_s_delta_g1);
         driver.add_assign_points(g_c, l_aux_acc);
         driver.add_assign_points(g_c, h_acc);
+        mk.mark("msm a, b1, b2 + scalar steps");
         auto opened = driver.open_two_points(g_c, g2_b);                                               // :316
+        mk.mark("open");
         if (h_out) *h_out = h; else driver.free_vec(h);
         return Proof{pt_to_affine(c, g_a_opened), pt_to_affine(c, opened.second), pt_to_affine(c, opened.first)};   // :319-325
     }
@@ -1656,7 +1761,7 @@ int32_t cgh_prove_shamir(int32_t device, int32_t curve, const char* zkey_path, i
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count());
                 store_proof(p, (uint8_t*)out_proofs + i * psz);
                 if (out_h && i == 0) CG(cg_dev_download(ctx, out_h, h.c[0], h.n * 32));
-                driver.free_vec(h); driver.free_vec(w); driver.release_pre();
+                driver.free_vec(h); driver.free_vec(w); driver.shutdown();
                 cg_ctx_destroy(ctx);
             } catch (const std::exception& e) { errs[i] = e.what(); hub.abort(); if (ctx) cg_ctx_destroy(ctx); }
         });
@@ -1860,7 +1965,7 @@ int32_t cgh_prove_plain(int32_t device, int32_t curve, const char* zkey_path, co
         const auto t3 = now();
         store_proof(p, (uint8_t*)out_proof);
         if (out_h) CG(cg_dev_download(ctx, out_h, h.c[0], h.n * 32));
-        driver.free_vec(h); driver.free_vec(wit);
+        driver.free_vec(h); driver.free_vec(wit); driver.shutdown();
         release_zkey(ctx, dz);
         cg_ctx_destroy(ctx);
         if (timing) fprintf(stderr, "cgh_prove_plain: read+decode zkey %.1f ms, context + upload %.1f ms, prove %.1f ms, teardown %.1f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
@@ -1895,7 +2000,7 @@ int32_t cgh_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, con
                 Proof p = prover.prove(dz, pub, wit, nullptr, &h);
                 store_proof(p, (uint8_t*)out_proofs + i * psz);
                 if (out_h && i == 0) { CG(cg_dev_download(ctx, out_h, h.c[0], h.n * 32)); CG(cg_dev_download(ctx, out_h + h.n * 4, h.c[1], h.n * 32)); }
-                driver.free_vec(h); driver.free_vec(wit);
+                driver.free_vec(h); driver.free_vec(wit); driver.shutdown();
                 cg_ctx_destroy(ctx);
             } catch (const std::exception& e) { errs[i] = e.what(); hub.abort(); if (ctx) cg_ctx_destroy(ctx); }
         });

@@ -57,6 +57,19 @@ int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr);
 int32_t cg_dev_upload(cg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);     /* synchronous */
 int32_t cg_dev_download(cg_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* synchronous */
 int32_t cg_dev_memset_zero(cg_ctx* ctx, void* d_dst, size_t bytes);
+/* Page-locked staging buffers and asynchronous copies on the context's two copy streams, so that the MPC exchanges of mul_vec
+ * (rep3.rs:650-670) and degree_reduce_vec (shamir.rs:302-384) can move in chunks under the compute.
+ *   download_begin: the copy is ordered after everything enqueued on the context's stream so far.
+ *   upload_begin:   after_stream != 0 orders it the same way (d_dst still in use by enqueued work); 0 = d_dst is not in use.
+ *   A ticket names the copy until 256 further copies were begun on the context.  cg_copy_wait blocks the host until the copy is done;
+ *   cg_copy_fence makes later launches on the context's stream wait for it without blocking the host.  Copies of one direction
+ *   complete in the order they were begun.  Host buffers must come from cg_host_alloc and stay valid until the copy is done. */
+int32_t cg_host_alloc(size_t bytes, void** h_ptr);
+int32_t cg_host_free(void* h_ptr);
+int32_t cg_dev_download_begin(cg_ctx* ctx, void* h_dst_pinned, const void* d_src, size_t bytes, int32_t* ticket);
+int32_t cg_dev_upload_begin(cg_ctx* ctx, void* d_dst, const void* h_src_pinned, size_t bytes, int32_t after_stream, int32_t* ticket);
+int32_t cg_copy_wait(cg_ctx* ctx, int32_t ticket);
+int32_t cg_copy_fence(cg_ctx* ctx, int32_t ticket);
 
 /* ---- MSMProvider::msm_public_points  (traits.rs:561-568; rep3.rs:934-947, shamir.rs:1027-1039, plain.rs:408-416) */
 /* Upload a point table once (zkey a/b1/b2/l/h query, zkey.rs:48-71); it is reused by every proof.

@@ -548,6 +548,43 @@ def test_vec_prefix_product_inverse_affine(ctx, curve, n):
         np.testing.assert_array_equal(d_g.download((m, 4)), x[off:off + st * m:st][:m])
 
 
+def test_async_copies_through_pinned_staging(ctx):
+    """cg_host_alloc + cg_dev_upload_begin / cg_copy_fence / cg_dev_download_begin / cg_copy_wait: chunks uploaded on the copy stream,
+    consumed by a kernel on the context's stream, and streamed back while further work is enqueued"""
+    curve = BN254
+    rng = np.random.default_rng(99)
+    n, ch = 40000, 4096
+    a, b = orc.random_field(curve, FR, n, rng), orc.random_field(curve, FR, n, rng)
+    pin_a, pin_b, pin_o = ctx.host_alloc((n, 4)), ctx.host_alloc((n, 4)), ctx.host_alloc((n, 4))
+    pin_a[:] = a; pin_b[:] = b
+    d_a, d_b, d_o = ctx.alloc(n * 32), ctx.alloc(n * 32), ctx.alloc(n * 32)
+    tk = None
+    for off in range(0, n, ch):
+        m = min(ch, n - off)
+        ctx.upload_begin(d_a, pin_a[off:off + m], after_stream=False, offset=off * 32)
+        tk = ctx.upload_begin(d_b, pin_b[off:off + m], after_stream=False, offset=off * 32)
+    ctx.copy_fence(tk)                                            # copies of one direction complete in order
+    ctx.vec_mul(curve, d_o, d_a, d_b, n)
+    tks = [(off, ctx.download_begin(pin_o[off:off + min(ch, n - off)], d_o, offset=off * 32)) for off in range(0, n, ch)]
+    ctx.vec_add(curve, d_a, d_a, d_b, n)                           # enqueued behind the product; the downloads were ordered before it
+    for off, t in tks:
+        ctx.copy_wait(t)
+        np.testing.assert_array_equal(pin_o[off:off + min(ch, n - off)], orc.field_op(curve, FR, "mul", a[off:off + ch], b[off:off + ch]))
+    np.testing.assert_array_equal(d_a.download((n, 4)), orc.field_op(curve, FR, "add", a, b))
+    # an upload that must wait for enqueued readers of its destination
+    pin_a[:] = b
+    ctx.vec_add(curve, d_o, d_a, d_b, n)                           # reads d_a (= a + b)
+    t = ctx.upload_begin(d_a, pin_a, after_stream=True)
+    ctx.copy_fence(t)
+    ctx.vec_add(curve, d_b, d_a, d_a, n)                           # sees the uploaded b
+    np.testing.assert_array_equal(d_o.download((n, 4)), orc.field_op(curve, FR, "add", orc.field_op(curve, FR, "add", a, b), b))
+    np.testing.assert_array_equal(d_b.download((n, 4)), orc.field_op(curve, FR, "add", b, b))
+    with pytest.raises(cg.BackendError):
+        ctx.copy_wait(255)                                         # a ticket that was never issued
+    ctx.sync()
+    for p in (pin_a, pin_b, pin_o): ctx.host_free(p)
+
+
 @pytest.mark.parametrize("curve", [BN254, BLS12_381])
 def test_vec_lincomb_strided(ctx, curve):
     """strided linear combination (the Shamir share algebra in one launch): forward / negative / interleaving strides, unit coefficients"""
