@@ -757,7 +757,9 @@ public:
         for (void* p : deferred) cg_dev_free(ctx, p);
         deferred.clear();
         release_rings(); release_pre();
+        if (aux) { cg_ctx_destroy(aux); aux = nullptr; }
     }
+    void use_second_context(cg_ctx* second) { aux = second; }                           // owned from here on (shutdown destroys it)
     ~HipDriver() { shutdown(); }
     // ---- vector forms of rand / mul_open_many / open_many used by co-plonk (rep3.rs:544-558,595-598,620-628,738-757)
     int public_component() const { return mode != Mode::Rep3 ? 0 : (party() == 0 ? 0 : party() == 1 ? 1 : -1); }   // add_with_public: who holds a public addend
@@ -828,6 +830,27 @@ public:
         Bytes out(curve.jac(group) * k());
         const void* sc[2] = {s.c[0], s.c[1]};
         CG(cg_msm_dev(ctx, bases, off, n, sc, k(), out.data()));
+        PointShare r;
+        for (int j = 0; j < k(); j++) r.c[j] = Point{Bytes(out.begin() + j * curve.jac(group), out.begin() + (j + 1) * curve.jac(group)), group};
+        if (k() == 1) r.c[1] = pt_inf(curve, group);
+        return r;
+    }
+    // The same MSMs started early and collected later (cg_msm_dev_begin_multi / cg_msm_end): the four queries over the private witness
+    // (groth16.rs:251,267,284,298) share one scalar decomposition and run on a second context (`aux`, own streams) while the witness
+    // map and its exchanges occupy the first.  MSMs involve no network, so the party-to-party message order is the reference's.
+    cg_ctx* aux = nullptr;
+    struct PendingMsm { cg_ctx* on = nullptr; std::vector<int32_t> tickets; std::vector<int> groups; };
+    PendingMsm msm_begin_multi(const std::vector<const cg_bases*>& tables, const std::vector<size_t>& offsets, const std::vector<int>& groups, size_t n, const ShareVec& s, bool on_aux) {
+        PendingMsm p; p.on = on_aux && aux ? aux : ctx; p.groups = groups; p.tickets.resize(tables.size());
+        const void* sc[2] = {s.c[0], s.c[1]};
+        if (p.on != ctx) CG(cg_ctx_sync(ctx));                                          // the scalars were produced on this driver's stream
+        CG(cg_msm_dev_begin_multi(p.on, (int32_t)tables.size(), tables.data(), offsets.data(), n, sc, k(), p.tickets.data()));
+        return p;
+    }
+    PointShare msm_finish(PendingMsm& p, size_t i) {
+        const int group = p.groups[i];
+        Bytes out(curve.jac(group) * k());
+        CG(cg_msm_end(p.on, p.tickets[i], out.data()));
         PointShare r;
         for (int j = 0; j < k(); j++) r.c[j] = Point{Bytes(out.begin() + j * curve.jac(group), out.begin() + (j + 1) * curve.jac(group)), group};
         if (k() == 1) r.c[1] = pt_inf(curve, group);
@@ -935,13 +958,13 @@ public:
     }
 
     // groth16.rs:206-235
-    PointShare calculate_coeff(PointShare initial, const cg_bases* query, const View& query_host, int group, const Bytes& vk_param,
-                               const std::vector<Fr>& input_assignment, const ShareVec& aux_assignment) {
+    // priv_acc = msm_public_points(&query[1 + pub_len..], aux_assignment) (:221), started before the witness map (see prove)
+    PointShare calculate_coeff(PointShare initial, const View& query_host, int group, const Bytes& vk_param,
+                               const std::vector<Fr>& input_assignment, const PointShare& priv_acc) {
         const Curve& c = driver.curve;
         const size_t pub_len = input_assignment.size(), rec = c.aff(group);
         Point pub_acc = pt_inf(c, group);                                                              // :220 (tiny, plain scalars)
         for (size_t i = 0; i < pub_len; i++) pub_acc = pt_add(c, pub_acc, pt_mul(c, pt_from_affine(c, group, query_host.data() + (1 + i) * rec), input_assignment[i]));
-        PointShare priv_acc = driver.msm_public_points(query, group, 1 + pub_len, aux_assignment.n, aux_assignment);   // :221
         PointShare res = initial;
         driver.add_assign_points_public(res, pt_from_affine(c, group, query_host.data()));             // :227
         driver.add_assign_points_public(res, pt_from_affine(c, group, vk_param.data()));               // :228
@@ -954,27 +977,31 @@ public:
     Proof prove(const DeviceZKey& dz, const std::vector<Fr>& public_inputs, const ShareVec& private_witness, const FieldShare* rs_plain, ShareVec* h_out = nullptr) {
         const ZKey& z = *dz.z; const Curve& c = driver.curve;
         HipDriver::Marks mk("prove party 0", driver.party() <= 0);
+        std::vector<Fr> input_assignment(public_inputs.begin() + 1, public_inputs.end());
+        const size_t first_aux = 1 + input_assignment.size();
+        // l (:251), a (:267 -> :221), b1 (:284), b2 (:298): one call, one scalar schedule, on the second context
+        auto aux_msm = driver.msm_begin_multi({dz.l, dz.a, dz.b1, dz.b2}, {0, first_aux, first_aux, first_aux}, {CG_G1, CG_G1, CG_G1, CG_G2}, private_witness.n, private_witness, true);
         ShareVec h = witness_map_from_matrices(dz, public_inputs, private_witness);
         mk.mark("witness map");
+        auto h_msm = driver.msm_begin_multi({dz.h}, {0}, {CG_G1}, h.n, h, false);                      // :248
         FieldShare r = rs_plain ? rs_plain[0] : driver.rand();                                         // :134-135
         FieldShare s = rs_plain ? rs_plain[1] : driver.rand();
-        std::vector<Fr> input_assignment(public_inputs.begin() + 1, public_inputs.end());
-        PointShare h_acc = driver.msm_public_points(dz.h, CG_G1, 0, h.n, h);                           // :248
-        PointShare l_aux_acc = driver.msm_public_points(dz.l, CG_G1, 0, private_witness.n, private_witness);   // :251
+        PointShare h_acc = driver.msm_finish(h_msm, 0);
+        PointShare l_aux_acc = driver.msm_finish(aux_msm, 0);
         mk.mark("msm h + l");
         const Point delta_g1 = pt_from_affine(c, CG_G1, z.delta_g1.data());
         FieldShare rs = driver.mul(r, s);                                                              // :258
         PointShare r_s_delta_g1 = driver.scalar_mul_public_point(delta_g1, rs);                        // :259
         PointShare r_g1 = driver.scalar_mul_public_point(delta_g1, r);                                 // :265
-        PointShare g_a = calculate_coeff(r_g1, dz.a, z.a_query, CG_G1, z.alpha_g1, input_assignment, private_witness);   // :267
+        PointShare g_a = calculate_coeff(r_g1, z.a_query, CG_G1, z.alpha_g1, input_assignment, driver.msm_finish(aux_msm, 1));   // :267
         Point g_a_opened = driver.open_point(g_a);                                                     // :276
         PointShare s_g_a = driver.scalar_mul_public_point(g_a_opened, s);                              // :277
         PointShare s_g1 = driver.scalar_mul_public_point(delta_g1, s);                                 // :283
-        PointShare g1_b = calculate_coeff(s_g1, dz.b1, z.b_g1_query, CG_G1, z.beta_g1, input_assignment, private_witness);   // :284
+        PointShare g1_b = calculate_coeff(s_g1, z.b_g1_query, CG_G1, z.beta_g1, input_assignment, driver.msm_finish(aux_msm, 2));   // :284
         PointShare r_g1_b = driver.scalar_mul(g1_b, r);                                                // :291
         const Point delta_g2 = pt_from_affine(c, CG_G2, z.delta_g2.data());
         PointShare s_g2 = driver.scalar_mul_public_point(delta_g2, s);                                 // :297
-        PointShare g2_b = calculate_coeff(s_g2, dz.b2, z.b_g2_query, CG_G2, z.beta_g2, input_assignment, private_witness);   // :298
+        PointShare g2_b = calculate_coeff(s_g2, z.b_g2_query, CG_G2, z.beta_g2, input_assignment, driver.msm_finish(aux_msm, 3));   // :298
         PointShare g_c = s_g_a;                                                                        // :308-312
         driver.add_assign_points(g_c, r_g1_b);
         driver.sub_assign_points(g_c, r_s_delta_g1);
@@ -1029,6 +1056,20 @@ static void release_zkey(cg_ctx* ctx, DeviceZKey& d) {
     for (int m = 0; m < 2; m++) { cg_dev_free(ctx, d.mat[m].row_ptr); cg_dev_free(ctx, d.mat[m].col); cg_dev_free(ctx, d.mat[m].coeff); }
     cg_dev_free(ctx, d.pub_dev);
 }
+
+// Second contexts for the witness-independent MSMs (HipDriver::aux).  Creating a context costs 15-25 ms (its streams), so they are
+// made on a helper thread while the zkey is read and uploaded, and only for zkeys large enough (>= ~2^19 constraints) to gain.
+struct SecondContexts {
+    std::vector<cg_ctx*> made; std::thread worker;
+    SecondContexts(int device, const char* zkey_path, int count) : made(count, nullptr) {
+        struct stat st{};
+        if (getenv("CGH_ONE_CONTEXT") || stat(zkey_path, &st) != 0 || st.st_size < (off_t)200 << 20) return;
+        worker = std::thread([this, device] { for (auto& c : made) if (cg_ctx_create(device, &c) != 0) c = nullptr; });
+    }
+    void ready() { if (worker.joinable()) worker.join(); }
+    cg_ctx* take(int i) { ready(); cg_ctx* c = made[i]; made[i] = nullptr; return c; }
+    ~SecondContexts() { ready(); for (cg_ctx* c : made) if (c) cg_ctx_destroy(c); }
+};
 
 static void store_proof(const Proof& p, uint8_t* out) { memcpy(out, p.a.data(), p.a.size()); memcpy(out + p.a.size(), p.b.data(), p.b.size()); memcpy(out + p.a.size() + p.b.size(), p.c.data(), p.c.size()); }
 
@@ -1731,12 +1772,14 @@ int32_t cgh_prove_shamir(int32_t device, int32_t curve, const char* zkey_path, i
     try {
         using namespace cgh;
         if (n < 3) throw std::runtime_error("Shamir protocol requires at least 3 parties");        // shamir/network.rs:75-77
+        SecondContexts second(device, zkey_path, n);
         ZKey z = read_zkey(curve, zkey_path);
         const size_t n_aux = z.n_vars - z.n_public - 1;
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
         cg_ctx* ctx0 = nullptr;
         if (cg_ctx_create(device, &ctx0)) die("cg_ctx_create");
         DeviceZKey dz = upload_zkey(ctx0, z, pub);
+        second.ready();
         InProcShamirHub hub(n);
         const size_t psz = 8 * z.curve.fq();
         std::vector<std::string> errs(n);
@@ -1747,6 +1790,7 @@ int32_t cgh_prove_shamir(int32_t device, int32_t curve, const char* zkey_path, i
                 if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
                 InProcShamirNet net(&hub, i);
                 HipDriver driver(ctx, z.curve, Mode::Shamir, nullptr);
+                driver.use_second_context(second.take(i));
                 driver.rng1 = (const Fr*)streams[i]; driver.rng_len = stream_len;
                 driver.shamir_init(&net, t);
                 const auto ta = std::chrono::steady_clock::now();
@@ -1949,6 +1993,7 @@ int32_t cgh_prove_plain(int32_t device, int32_t curve, const char* zkey_path, co
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         const auto t0 = now();
+        SecondContexts second(device, zkey_path, 1);
         ZKey z = read_zkey(curve, zkey_path);
         const auto t1 = now();
         if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
@@ -1957,6 +2002,7 @@ int32_t cgh_prove_plain(int32_t device, int32_t curve, const char* zkey_path, co
         DeviceZKey dz = upload_zkey(ctx, z, pub);
         const auto t2 = now();
         HipDriver driver(ctx, z.curve, Mode::Plain, nullptr);
+        driver.use_second_context(second.take(0));
         ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_public - 1);
         FieldShare rs[2]; memcpy(rs[0].c[0].v, r, 32); rs[0].c[1] = rs[0].c[0]; memcpy(rs[1].c[0].v, s, 32); rs[1].c[1] = rs[1].c[0];
         CoGroth16 prover(driver);
@@ -1977,12 +2023,14 @@ int32_t cgh_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, con
                        const uint64_t* const* streams, size_t stream_len, uint64_t* out_proofs, uint64_t* out_h) {
     try {
         using namespace cgh;
+        SecondContexts second(device, zkey_path, 3);
         ZKey z = read_zkey(curve, zkey_path);
         const size_t n_aux = z.n_vars - z.n_public - 1;
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
         cg_ctx* ctx0 = nullptr;
         if (cg_ctx_create(device, &ctx0)) die("cg_ctx_create");
         DeviceZKey dz = upload_zkey(ctx0, z, pub);            // one device-resident zkey shared by the three co-located parties
+        second.ready();
         InProcHub hub;
         const size_t psz = 8 * z.curve.fq();
         std::string errs[3];
@@ -1993,6 +2041,7 @@ int32_t cgh_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, con
                 if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
                 InProcNetwork net(&hub, i);
                 HipDriver driver(ctx, z.curve, Mode::Rep3, &net);
+                driver.use_second_context(second.take(i));
                 driver.rng1 = (const Fr*)streams[i]; driver.rng2 = (const Fr*)streams[(i + 2) % 3]; driver.rng_len = stream_len;
                 ShareVec wit = driver.upload_vec((const Fr*)wit_a[i], (const Fr*)wit_b[i], n_aux);
                 CoGroth16 prover(driver);
