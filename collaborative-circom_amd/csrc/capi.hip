@@ -303,6 +303,8 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
     const int c = shared ? bases[0]->pre_c : (n ? (ctx->msm_window ? ctx->msm_window : auto_window(n, bits)) : 2);
     const int nwin = bits / c + 1;
     if (shared && nwin != bases[0]->pre_nwin) return fail(CG_ERR_ARG, "internal: window count mismatch");
+    if ((uint64_t)nwin * n >= ((uint64_t)1 << 32))        // schedule positions are 32-bit
+        return fail(CG_ERR_ARG, "MSM of more than 2^32 / windows points in one call (about 2^27): pass the table in slices and add the partial sums");
     // optimistic scatter capacity: expected heaviest bucket (regular windows + the narrower top window) + 25 % + 6 sigma
     uint32_t cap = 0;
     if (n && !force_exact && ctx->scatter_cap >= 0) {

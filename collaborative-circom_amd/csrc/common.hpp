@@ -48,7 +48,8 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared) {
     g.segs = g.nb / g.seg_len;
     g.ngroups = shared ? (g.segs >= (uint32_t)MSM_SHARED_GROUPS ? MSM_SHARED_GROUPS : 1) : nwin;
     g.group_segs = shared ? g.segs / g.ngroups : g.segs;
-    g.bitsum = shared && g.nb <= (1u << 16) && g.nb >= 4096;
+    static const bool no_bitsum = getenv("CG_NO_BITSUM") != nullptr;                     // tuning knob
+    g.bitsum = shared && g.nb <= (1u << 16) && g.nb >= 4096 && !no_bitsum;
     g.bit_groups = std::max<uint32_t>(1, (g.nb / 2 + 256 * BITSUM_ITEMS - 1) / (256 * BITSUM_ITEMS));
     if (g.bitsum) g.ngroups = c;
     const size_t entries = (size_t)nwin * n;

@@ -52,6 +52,8 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     else if constexpr (sizeof(F) > 64) rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc<F>, 128>, 128, (size_t)128 * sizeof(XYZZ<F>));
     else rc_acc = launch_acc(k_msm_accumulate<F, RegAcc<F>, 256>, 256, 0);
     if (rc_acc) return rc_acc;
+    hipLaunchKernelGGL((k_msm_merge_direct<B>), dim3((unsigned)((g.nbuckets + 63) / 64)), dim3(64), 0, st, buckets, cont, cont_bucket, offsets, counts,
+                       (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, cap);
     hipLaunchKernelGGL((k_msm_merge_cont_l1<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, cont, cont_bucket, g.nchunks);
     hipLaunchKernelGGL((k_msm_merge_cont<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, buckets, cont, cont_bucket, g.nchunks);
     if (evs) HIPCHK(hipEventRecord(evs[1], st));

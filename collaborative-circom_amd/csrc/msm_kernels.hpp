@@ -505,6 +505,26 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
 //   level 1: every lane that is a GROUP head (run start, or q a multiple of MERGE_GROUP) sums the pieces up to the next group head;
 //   level 2: the run-start lane adds the group sums of its run into buckets[b].
 // With uniform scalars runs have 1-3 pieces and both levels are a handful of additions.
+// Level 0, bucket-major: with a small shared bucket set (table slices of a multi-GPU plan: 2^16 buckets, ~230 entries each, chunks
+// of ~57) nearly every chunk ends in a continuation piece and each bucket owns 3-5 of them; summing them chunk-major leaves three
+// lanes in four idle.  Here lane b adds the pieces of bucket b, whose chunk range follows from offsets / counts alone, and retires
+// them (tag -> none).  Buckets spread over more than MERGE_DIRECT_MAX chunks (skewed scalars) are left to the two levels below.
+constexpr uint32_t MERGE_DIRECT_MAX = 12;
+template <class B>
+__global__ void __launch_bounds__(64) k_msm_merge_direct(B* __restrict__ buckets, const B* __restrict__ cont, uint32_t* __restrict__ cont_bucket,
+                                                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                         uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks, uint32_t cap) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    const uint32_t cnt = cap ? min(counts[b], cap) : counts[b];
+    if (cnt == 0) return;
+    const uint32_t first = offsets[b], last = first + cnt - 1;           // positions of the bucket's entries in the compact list
+    const uint32_t q0 = first / chunk_len + 1, q1 = last / chunk_len;     // chunks that continue it
+    if (q0 > q1 || q1 - q0 >= MERGE_DIRECT_MAX || q1 >= nchunks) return;
+    B acc = ld_struct(buckets + b);
+    for (uint32_t q = q0; q <= q1; q++) { acc = bk_add(acc, ld_struct(cont + q)); cont_bucket[q] = 0xffffffffu; }
+    st_struct(buckets + b, acc);
+}
 constexpr uint32_t MERGE_GROUP = 64;
 template <class B>
 __global__ void __launch_bounds__(64) k_msm_merge_cont_l1(B* __restrict__ cont, const uint32_t* __restrict__ cont_bucket, uint32_t nchunks) {
