@@ -447,7 +447,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="test mode: initialise torch.distributed even for one rank and distribute the witness map from "
                     "one rank on, so that a single GPU drives the RCCL all_to_all / all_gather / all_reduce calls of the N >= 4 path")
     ap.add_argument("--one-context", action="store_true", help="run the aux-witness MSMs after the witness map on the same context (no overlap)")
-    ap.add_argument("--precompute", type=int, default=-1, help="window size of the per-window precomputed base tables (-1 = by table size: 20 above ~1.5 M points else 17; 0 = off)")
+    ap.add_argument("--precompute", type=int, default=-1, help="window size of the per-window precomputed base tables (-1 = by table size: 20 above ~3 M G1 / ~1.5 M G2 points else 17; 0 = off)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -575,7 +575,7 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         per_step = lambda k: st[k] / args.steps
         iso_ms = (iso["msm_acc_g1_ms"] / max(1, iso["msm_acc_g1_calls"])) if iso else None
-        c_eff = (20 if avg_pts > (3 << 19) else 17) if args.precompute < 0 else (args.precompute or 16)
+        c_eff = (20 if avg_pts > (3 << 20) else 17) if args.precompute < 0 else (args.precompute or 16)
         nwin_g1 = 254 // c_eff + 1
         traffic = None          # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes (profiles/)
         try:
@@ -590,7 +590,7 @@ def main():
             "dtype": "u32 limbs (254-bit modular integer arithmetic)", "data": "synthetic",
             "config": {"workload": f"synthetic R1CS 2^{args.log_m} constraints-domain BN254, REP3 co-groth16 (configs[2])",
                        "num_constraints": w.nc, "domain_size": w.m, "n_vars": w.m, "nnz": w.nnz, "share_components": 2,
-                       "msm": "8 G1 + 2 G2 of ~2^%d points" % args.log_m, "msm_window": ("precomputed tables c=%s" % (args.precompute if args.precompute > 0 else "auto (20 above 1.5 M points, else 17)")) if args.precompute else "c=16, per-window bucket sets", "ntt": 12, "parallelism": f"msm units (tables / table slices) over {world} rank(s): " + ",".join(f"{t}{i}/{p}->r{o}" for t, i, p, o in w.plan)},
+                       "msm": "8 G1 + 2 G2 of ~2^%d points" % args.log_m, "msm_window": ("precomputed tables c=%s" % (args.precompute if args.precompute > 0 else "auto (20 above 3 M G1 / 1.5 M G2 points, else 17)")) if args.precompute else "c=16, per-window bucket sets", "ntt": 12, "parallelism": f"msm units (tables / table slices) over {world} rank(s): " + ",".join(f"{t}{i}/{p}->r{o}" for t, i, p, o in w.plan)},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<G1> (bucket accumulation, one launch per MSM component and table)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": st["msm_acc_g1_calls"], "algorithmic_bytes_per_launch": alg_bytes,
