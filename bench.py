@@ -575,7 +575,7 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         per_step = lambda k: st[k] / args.steps
         iso_ms = (iso["msm_acc_g1_ms"] / max(1, iso["msm_acc_g1_calls"])) if iso else None
-        c_eff = (20 if avg_pts > (3 << 20) else 17) if args.precompute < 0 else (args.precompute or 16)
+        c_eff = (20 if avg_pts > (3 << 20) else 16 if avg_pts <= (1 << 18) else 17) if args.precompute < 0 else (args.precompute or 16)
         nwin_g1 = 254 // c_eff + 1
         traffic = None          # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes (profiles/)
         try:

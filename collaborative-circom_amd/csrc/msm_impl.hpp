@@ -8,10 +8,15 @@
 
 namespace cg {
 
+// buckets per lane of k_msm_bitsum_partial and the resulting workgroups per bit
+template <class B> constexpr int bitsum_items() { return BITSUM_ITEMS; }   // 2 for G2 measured slower (four times the LDS trees): 2^18 step 8.5 -> 10.1 ms
+template <class B> uint32_t bitsum_groups(uint32_t nb) { return std::max<uint32_t>(1, (nb / 2 + 256 * bitsum_items<B>() - 1) / (256 * bitsum_items<B>())); }
+
 template <class F>
 size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared) {
-    const MsmGeom g = msm_geom(n, c, nwin, shared);
+    MsmGeom g = msm_geom(n, c, nwin, shared);
     typedef typename BucketOf<F>::type B;
+    g.bit_groups = bitsum_groups<B>(g.nb);
     return align_up(g.nbuckets * sizeof(B)) + align_up((size_t)g.nchunks * sizeof(B)) + align_up((size_t)g.nchunks * 4) +
            align_up(std::max((size_t)g.nsets * g.segs, (size_t)64 * g.bit_groups) * sizeof(B)) + align_up((size_t)std::max(g.ngroups, 64) * sizeof(XYZZ<F>));
 }
@@ -25,10 +30,11 @@ template <class F>
 int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride,
                           const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs) {
     const bool shared = table_stride != 0;
-    const MsmGeom g = msm_geom(n, c, nwin, shared);
+    MsmGeom g = msm_geom(n, c, nwin, shared);
     size_t off = 0;
     auto take = [&](size_t bytes) { void* p = scratch + off; off += align_up(bytes); return p; };
     typedef typename BucketOf<F>::type B;                 // limb-form points for the lazy pipelines, saturated XYZZ otherwise
+    g.bit_groups = bitsum_groups<B>(g.nb);
     B* buckets = (B*)take(g.nbuckets * sizeof(B));
     B* cont = (B*)take((size_t)g.nchunks * sizeof(B));
     uint32_t* cont_bucket = (uint32_t*)take((size_t)g.nchunks * 4);
@@ -63,11 +69,11 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     if (g.bitsum) {
         static bool attr_set2 = false;
         if (!attr_set2) {
-            HIPCHK(hipFuncSetAttribute((const void*)k_msm_bitsum_partial<B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * sizeof(B))));
+            HIPCHK(hipFuncSetAttribute((const void*)k_msm_bitsum_partial<B, bitsum_items<B>()>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * sizeof(B))));
             HIPCHK(hipFuncSetAttribute((const void*)k_msm_bitsum_final<F, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * sizeof(B))));
             attr_set2 = true;
         }
-        hipLaunchKernelGGL((k_msm_bitsum_partial<B>), dim3((unsigned)(c * g.bit_groups)), dim3(256), 256 * sizeof(B), st2, buckets, g.nb, g.bit_groups, partials);
+        hipLaunchKernelGGL((k_msm_bitsum_partial<B, bitsum_items<B>()>), dim3((unsigned)(c * g.bit_groups)), dim3(256), 256 * sizeof(B), st2, buckets, g.nb, g.bit_groups, partials);
         hipLaunchKernelGGL((k_msm_bitsum_final<F, B>), dim3((unsigned)c), dim3(64), 64 * sizeof(B), st2, partials, g.bit_groups, wsums);
         if (evs) HIPCHK(hipEventRecord(evs[3], st2));
         HIPCHK(hipGetLastError());

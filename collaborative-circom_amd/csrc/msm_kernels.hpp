@@ -604,17 +604,17 @@ __global__ void __launch_bounds__(THREADS) k_msm_window_sum(const B* __restrict_
 // circuits), where the running-sum kernels above are a chain of ~45 dependent point additions on a handful of waves and that
 // latency, not the work, is the whole cost of the MSM.  sum_w w B_{w-1} = sum_k 2^k T_k with T_k = sum of the buckets whose
 // weight w has bit k set: c plain sums, each a log-depth tree, ~c/2 additions per bucket in total (nothing at this size).
-//   k_msm_bitsum_partial: workgroup (k, g): 256 lanes x BITSUM_ITEMS buckets with bit k set, serial per lane + LDS tree
+//   k_msm_bitsum_partial: workgroup (k, g): 256 lanes x ITEMS buckets with bit k set, serial per lane + LDS tree
 //   k_msm_bitsum_final:   one wave per bit folds the G workgroup results into T_k (canonical XYZZ for the host)
 // The host finishes with one Horner pass over the c sums (one doubling per bit).
-template <class B>
+template <class B, int ITEMS>
 __global__ void __launch_bounds__(256) k_msm_bitsum_partial(const B* __restrict__ buckets, uint32_t nb, uint32_t groups, B* __restrict__ partials) {
     extern __shared__ uint4 lds_raw[];
     B* sh = reinterpret_cast<B*>(lds_raw);
     const uint32_t k = blockIdx.x / groups, g = blockIdx.x % groups;
-    const uint32_t j0 = (g * 256u + threadIdx.x) * BITSUM_ITEMS;
+    const uint32_t j0 = (g * 256u + threadIdx.x) * ITEMS;
     B acc = bk_inf<B>();
-    for (uint32_t i = 0; i < (uint32_t)BITSUM_ITEMS; i++) {
+    for (uint32_t i = 0; i < (uint32_t)ITEMS; i++) {
         const uint32_t j = j0 + i;                                            // j-th weight with bit k set
         const uint64_t w = (((uint64_t)j >> k) << (k + 1)) | ((uint64_t)1 << k) | (j & (((uint32_t)1 << k) - 1u));
         if (w >= 1 && w <= nb) acc = bk_add(acc, ld_struct(buckets + (w - 1)));
