@@ -787,9 +787,19 @@ public:
         if (mode != Mode::Rep3) CG(cg_vec_mul_dev(ctx, curve.id, out, a.c[0], b.c[0], n));
         if (mode == Mode::Plain) return out;
         if (mode == Mode::Shamir) {                                                   // degree-2t product opened from 2t + 1 shares (shamir.rs:684-711)
-            std::vector<Fr> mine(n); CG(cg_dev_download(ctx, mine.data(), out, n * 32));
-            const std::vector<Fr> res = shamir_open_vec(mine, open_lagrange_2t);
-            CG(cg_dev_upload(ctx, out, res.data(), n * 32));
+            // broadcast_next(2t) + reconstruction (shamir/network.rs:233-266): the Lagrange combination runs on the device
+            const int np = snet->num_parties(), me = snet->id(), num = (int)open_lagrange_2t.size();
+            std::vector<Fr> buf(n); CG(cg_dev_download(ctx, buf.data(), out, n * 32));
+            for (int sft = 1; sft < num; sft++) snet->send((me + sft) % np, buf.data(), n * 32);
+            std::vector<Term> terms{{out, 0, 1, open_lagrange_2t[0]}};
+            std::vector<void*> got;
+            for (int r = 1; r < num; r++) {
+                snet->recv((me + np - r) % np, buf.data(), n * 32);
+                void* d = dalloc(n * 32); CG(cg_dev_upload(ctx, d, buf.data(), n * 32));
+                got.push_back(d); terms.push_back({d, 0, 1, open_lagrange_2t[r]});
+            }
+            lincomb(out, 0, 1, n, terms);
+            for (void* d : got) CG(cg_dev_free(ctx, d));
             return out;
         }
         if (cursor + n > rng_len) throw std::runtime_error("randomness stream exhausted");
