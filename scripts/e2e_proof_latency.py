@@ -1,11 +1,12 @@
 """End-to-end proof latency through the host mirror (C++ drivers over the C ABI): zkey file -> proof, plain driver and three REP3
-parties sharing one GPU, on a synthetic satisfiable circuit.  usage: python scripts/e2e_proof_latency.py [log_m ...]"""
+parties sharing one GPU, on a synthetic satisfiable circuit.  usage: [E2E_CURVE=bls12_381] [E2E_SHAMIR=0] python scripts/e2e_proof_latency.py [log_m ...]"""
 import importlib, os, sys, time, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 cg = importlib.import_module("collaborative-circom_amd")
 import oracle_lib as orc
-from oracle_lib import BN254, FR
+from oracle_lib import BN254, BLS12_381, FR
+if os.environ.get("E2E_CURVE", "bn254") == "bls12_381": BN254 = BLS12_381     # same script on the second curve
 
 for log_m in [int(x) for x in sys.argv[1:]] or [16, 18]:
     d = tempfile.mkdtemp()
