@@ -129,9 +129,11 @@ def test_ntt_matches_oracle(ctx, curve, lg):
     np.testing.assert_array_equal(cx, orc.distribute_powers(curve, orc.ntt(curve, x, w, inverse=True), g, orc.from_dec(curve, FR, 1)))
 
 
-def test_ntt_large_roundtrip_and_linearity(ctx):
-    """size-independent properties at a BASELINE-scale length (2^20): iNTT(NTT(x)) == x and NTT(x+y) == NTT(x)+NTT(y)"""
-    curve, lg = BN254, 20
+@pytest.mark.parametrize("lg", [20, 24])
+def test_ntt_large_roundtrip_and_linearity(ctx, lg):
+    """size-independent properties at BASELINE-scale lengths (2^20; 2^24 = configs[3]): iNTT(NTT(x)) == x, NTT(x+y) == NTT(x)+NTT(y),
+    and 64 outputs against the definition"""
+    curve = BN254
     n = 1 << lg
     rng = np.random.default_rng(7)
     _, roots, _ = orc.roots_of_unity(curve)
@@ -281,6 +283,37 @@ def test_msm_medium_and_linearity(ctx):
     for r in range(1, reps):
         folded = orc.field_op(curve, FR, "add", folded, a.reshape(reps, n, 4)[r])
     np.testing.assert_array_equal(cg.point_to_affine(curve, G1, ra), orc.msm(curve, G1, pts, folded, threads=8))
+    bases.release()
+
+
+@pytest.mark.parametrize("group,lg", [(G1, 24), (G2, 22)])
+def test_msm_at_maximum_table_size(ctx, group, lg):
+    """BASELINE configs[3] table size (2^24 points; G2 at the 2^22 of configs[2]): synthetic table [(1 + i) G], so the exact answer is
+    one generator multiplication by sum_i s_i (1 + i), evaluated with oracle field arithmetic.  Precomputed tables (window 20, 13
+    windows, 2^24-point index range fully used) and the plain per-window path on a sub-slice; linearity across the two components."""
+    import bench_check as bc
+    curve = BN254
+    n = 1 << lg
+    rng = np.random.default_rng(2400 + lg)
+    a = orc.random_field(curve, FR, n, rng); b = orc.random_field(curve, FR, n, rng)
+    idx = np.zeros((n, 4), dtype=np.uint64); idx[:, 0] = np.arange(n, dtype=np.uint64) + np.uint64(1)
+    wts = bc.to_mont(idx)
+    want = [orc.generator_mul(curve, group, bc.field_sum(bc.mul(s, wts))) for s in (a, b)]
+    bases = ctx.synth_bases(curve, group, 1, n)
+    da, db = dev(ctx, a), dev(ctx, b)
+    # per-window bucket sets on the last quarter of the table (offset + length as a caller slices a zkey query)
+    off, m = 3 * n // 4, n // 4
+    got = ctx.msm_dev(bases, [da.ptr + off * 32, db.ptr + off * 32], m, offset=off)
+    part = [orc.generator_mul(curve, group, bc.field_sum(bc.mul(s[off:], wts[off:]))) for s in (a, b)]
+    for j in range(2):
+        np.testing.assert_array_equal(cg.point_to_affine(curve, group, got[j]), part[j])
+    ctx.precompute_bases(bases, 0)
+    got = ctx.msm_dev(bases, [da, db], n)
+    for j in range(2):
+        np.testing.assert_array_equal(cg.point_to_affine(curve, group, got[j]), want[j])
+    ds = ctx.alloc(n * 32); ctx.vec_add(curve, ds, da, db, n)
+    rs, = ctx.msm_dev(bases, [ds], n)
+    np.testing.assert_array_equal(cg.point_to_affine(curve, group, rs), cg.point_to_affine(curve, group, cg.point_add(curve, group, got[0], got[1])))
     bases.release()
 
 
