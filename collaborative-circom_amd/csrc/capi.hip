@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <vector>
 
 using namespace cg;
@@ -593,6 +594,32 @@ extern "C" {
 const char* cg_last_error(void) { return g_err.c_str(); }
 const char* cg_version(void) { return "cogroth16-hip 0.1 (gfx950)"; }
 
+// Creating a HIP stream costs 4-10 ms on this platform (measured), a context has three to five of them: streams of destroyed
+// contexts are parked per (device, priority class) and handed to the next context of the process (a prover that serves many proofs,
+// the test-suite) instead of being destroyed.  A parked stream is idle: cg_ctx_destroy synchronises it first.
+namespace {
+std::mutex g_stream_pool_mu;
+std::map<std::pair<int, int>, std::vector<hipStream_t>> g_stream_pool;      // (device, high priority?) -> idle streams
+int pooled_stream(int device, bool high, hipStream_t* out) {
+    {
+        std::lock_guard<std::mutex> l(g_stream_pool_mu);
+        auto& v = g_stream_pool[{device, high ? 1 : 0}];
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return 0; }
+    }
+    if (!high) { HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking)); return 0; }
+    int prio_lo = 0, prio_hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_hi));
+    return 0;
+}
+void park_stream(int device, bool high, hipStream_t st) {
+    if (!st) return;
+    std::lock_guard<std::mutex> l(g_stream_pool_mu);
+    auto& v = g_stream_pool[{device, high ? 1 : 0}];
+    if (v.size() < 32) v.push_back(st); else hipStreamDestroy(st);
+}
+}  // namespace
+
 int32_t cg_ctx_create(int32_t device, cg_ctx** out) {
     if (!out) return fail(CG_ERR_ARG, "null out");
     int count = 0;
@@ -602,13 +629,11 @@ int32_t cg_ctx_create(int32_t device, cg_ctx** out) {
     HIPCHK(hipSetDevice(device));
     cg_ctx* c = new cg_ctx();
     c->device = device;
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    { int rc = pooled_stream(device, false, &c->stream); if (rc) return rc; }
     // the side streams carry short, latency-bound kernels the main stream's next accumulate waits for: let their workgroups
     // jump the backlog of accumulate workgroups
-    int prio_lo = 0, prio_hi = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    HIPCHK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_hi));
-    HIPCHK(hipStreamCreateWithPriority(&c->sortst, hipStreamNonBlocking, prio_hi));
+    { int rc = pooled_stream(device, true, &c->aux); if (rc) return rc; }
+    { int rc = pooled_stream(device, true, &c->sortst); if (rc) return rc; }
     HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_sched_free[i], hipEventDisableTiming)); }
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming)); }
@@ -627,10 +652,10 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
         hipStreamSynchronize(ctx->h2d); hipStreamSynchronize(ctx->d2h);
         for (hipEvent_t e : ctx->copy_ev) if (e) hipEventDestroy(e);
         hipEventDestroy(ctx->ev_copy_order);
-        hipStreamDestroy(ctx->h2d); hipStreamDestroy(ctx->d2h);
+        park_stream(ctx->device, false, ctx->h2d); park_stream(ctx->device, false, ctx->d2h);
     }
-    hipStreamDestroy(ctx->aux);
-    hipStreamDestroy(ctx->sortst);
+    park_stream(ctx->device, true, ctx->aux);
+    park_stream(ctx->device, true, ctx->sortst);
     for (auto& kv : ctx->twiddles) hipFree(kv.second);
     for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
     for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.h_flags) hipHostFree(t.h_flags); if (t.done) hipEventDestroy(t.done); }
@@ -638,7 +663,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     if (ctx->gather_buf) hipFree(ctx->gather_buf);
     for (auto& p : ctx->ev_live) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
     for (auto& p : ctx->ev_free) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
-    if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
+    if (ctx->owns_stream) park_stream(ctx->device, false, ctx->stream);
     delete ctx;
     return 0;
 }
@@ -654,7 +679,7 @@ int32_t cg_ctx_set_stream(cg_ctx* ctx, void* hip_stream) {
     HIPCHK(hipStreamSynchronize(ctx->sortst));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->aux));
-    if (ctx->owns_stream) HIPCHK(hipStreamDestroy(ctx->stream));
+    if (ctx->owns_stream) park_stream(ctx->device, false, ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->owns_stream = false;
     return 0;
@@ -698,7 +723,8 @@ static int32_t copy_begin(cg_ctx* ctx, bool up, void* dst, const void* src, size
     if (!ctx || !ticket || ((!dst || !src) && bytes)) return fail(CG_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->h2d) {                                        // the copy streams exist from the first asynchronous copy on
-        HIPCHK(hipStreamCreateWithFlags(&ctx->h2d, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&ctx->d2h, hipStreamNonBlocking));
+        { int rc = pooled_stream(ctx->device, false, &ctx->h2d); if (rc) return rc; }
+        { int rc = pooled_stream(ctx->device, false, &ctx->d2h); if (rc) return rc; }
         HIPCHK(hipEventCreateWithFlags(&ctx->ev_copy_order, hipEventDisableTiming));
     }
     hipStream_t st = up ? ctx->h2d : ctx->d2h;
