@@ -461,11 +461,45 @@ void host_pow_tables(const Fr& w, const Fr& first, int log_lo, size_t hi_n, std:
     for (size_t j = 0; j < hi_n; j++) { hi[j] = h; h = h * step; }
 }
 
+// Twiddle tables depend only on (device, curve, size, generator): contexts of one process share them (three co-located parties, a
+// prover serving many proofs).  A table is complete before it is published (the builder synchronises its stream); unused tables
+// stay cached up to 1 GiB per process, least recently used first out.
+struct SharedTwiddles { void* p; size_t bytes; int refs; uint64_t stamp; };
+std::mutex g_tw_mu;
+std::map<std::pair<int, TwKey>, SharedTwiddles> g_tw;
+uint64_t g_tw_clock = 0;
+void* shared_twiddles_acquire(int device, const TwKey& key) {
+    std::lock_guard<std::mutex> l(g_tw_mu);
+    auto it = g_tw.find({device, key});
+    if (it == g_tw.end()) return nullptr;
+    it->second.refs++; it->second.stamp = ++g_tw_clock;
+    return it->second.p;
+}
+void* shared_twiddles_publish(int device, const TwKey& key, void* p, size_t bytes) {
+    std::lock_guard<std::mutex> l(g_tw_mu);
+    auto it = g_tw.find({device, key});
+    if (it != g_tw.end()) { hipFree(p); it->second.refs++; it->second.stamp = ++g_tw_clock; return it->second.p; }   // another context was faster
+    g_tw[{device, key}] = SharedTwiddles{p, bytes, 1, ++g_tw_clock};
+    return p;
+}
+void shared_twiddles_release(int device, const TwKey& key) {
+    std::lock_guard<std::mutex> l(g_tw_mu);
+    auto it = g_tw.find({device, key});
+    if (it != g_tw.end() && it->second.refs > 0) it->second.refs--;
+    for (;;) {                                            // trim the idle tables
+        size_t idle = 0; auto victim = g_tw.end();
+        for (auto j = g_tw.begin(); j != g_tw.end(); ++j) if (j->second.refs == 0) { idle += j->second.bytes; if (victim == g_tw.end() || j->second.stamp < victim->second.stamp) victim = j; }
+        if (idle <= ((size_t)1 << 30) || victim == g_tw.end()) break;
+        hipFree(victim->second.p); g_tw.erase(victim);
+    }
+}
+
 template <class Fr>
 int get_twiddles(cg_ctx* ctx, int curve, int log_m, const Fr& w, const Fr** out) {
     TwKey key; key.curve = curve; key.log_m = log_m; memcpy(key.gen, w.v, sizeof key.gen);
     auto it = ctx->twiddles.find(key);
     if (it != ctx->twiddles.end()) { *out = (const Fr*)it->second; return 0; }
+    if (void* shared = shared_twiddles_acquire(ctx->device, key)) { ctx->twiddles[key] = shared; *out = (const Fr*)shared; return 0; }
     const size_t m = (size_t)1 << log_m;
     const int log_lo = std::min(11, std::max(0, log_m - 1));
     const size_t hi_n = std::max<size_t>(1, (m / 2) >> log_lo);
@@ -480,6 +514,7 @@ int get_twiddles(cg_ctx* ctx, int curve, int log_m, const Fr& w, const Fr** out)
     { int rc = launch_build_twiddles<Fr>(ctx->stream, d_tw, m, log_m, d_lo, d_hi, log_lo); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(ctx->stream));   // lo/hi host vectors and temporaries die here
     HIPCHK(hipFree(d_lo)); HIPCHK(hipFree(d_hi));
+    d_tw = (Fr*)shared_twiddles_publish(ctx->device, key, d_tw, std::max<size_t>(m - 1, 1) * sizeof(Fr));
     ctx->twiddles[key] = d_tw;
     *out = d_tw;
     return 0;
@@ -656,7 +691,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     }
     park_stream(ctx->device, true, ctx->aux);
     park_stream(ctx->device, true, ctx->sortst);
-    for (auto& kv : ctx->twiddles) hipFree(kv.second);
+    for (auto& kv : ctx->twiddles) shared_twiddles_release(ctx->device, kv.first);
     for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
     for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.h_flags) hipHostFree(t.h_flags); if (t.done) hipEventDestroy(t.done); }
     if (ctx->arena.base) hipFree(ctx->arena.base);
