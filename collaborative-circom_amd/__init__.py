@@ -491,6 +491,37 @@ def prove_shamir(curve, zkey_path, n, t, pub, wits, streams, device=0, want_h=Fa
     return (out, h) if want_h else out
 
 
+class ProvingSession:
+    """zkey read, uploaded and (optionally) given per-window precomputed tables once; proofs then cost what co-circom.rs:503-506 times"""
+
+    def __init__(self, curve, zkey_path, precompute=True, device=0):
+        self.curve, self.info = curve, host_zkey_info(curve, zkey_path)
+        h = C.c_void_p()
+        _hchk(load_host().cgh_session_open(int(device), curve, zkey_path.encode(), -1 if precompute is True else int(precompute), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h: load_host().cgh_session_close(self.h); self.h = None
+
+    def prove_plain(self, witness, r, s):
+        """returns (proof, seconds)"""
+        nq = 6 if self.curve == BLS12_381 else 4
+        out = np.zeros(8 * nq, dtype=np.uint64); sec = (C.c_double * 1)()
+        _hchk(load_host().cgh_session_prove_plain(self.h, _hp(np.ascontiguousarray(witness, dtype=np.uint64)), _hp(np.ascontiguousarray(r, dtype=np.uint64)),
+                                                  _hp(np.ascontiguousarray(s, dtype=np.uint64)), _hp(out), sec))
+        return out, sec[0]
+
+    def prove_rep3(self, pub, wit_a, wit_b, streams, solo=True):
+        """three co-located parties; returns (3 proofs, seconds of the three together, seconds of party 0 replayed alone on the GPU)"""
+        nq = 6 if self.curve == BLS12_381 else 4
+        out = np.zeros((3, 8 * nq), dtype=np.uint64); sec = (C.c_double * 2)()
+        keep = [[np.ascontiguousarray(x, dtype=np.uint64) for x in lst] for lst in (wit_a, wit_b, streams)]
+        arr = lambda lst: (C.c_void_p * 3)(*[x.ctypes.data for x in lst])
+        _hchk(load_host().cgh_session_prove_rep3(self.h, _hp(np.ascontiguousarray(pub, dtype=np.uint64)), arr(keep[0]), arr(keep[1]), arr(keep[2]),
+                                                 C.c_size_t(keep[2][0].shape[0]), _hp(out), sec if solo else None))
+        return out, sec[0], sec[1]
+
+
 def host_plonk_zkey_info(curve, path):
     info = (C.c_size_t * 6)()
     _hchk(load_host().cgh_plonk_zkey_info(curve, path.encode(), info))

@@ -292,12 +292,26 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
             return 0;
         }
     }
+    {   // a schedule depends on the window: tables precomputed with different windows (the automatic choice differs between G1 and
+        // G2 for 1.5-3 M points), or a mix of precomputed and plain tables, run as one sub-call per window
+        bool mixed = false;
+        for (int b = 1; b < nb; b++) mixed = mixed || bases[b]->pre_c != bases[0]->pre_c;
+        if (mixed) {
+            std::vector<char> done(nb, 0);
+            for (int b = 0; b < nb; b++) {
+                if (done[b]) continue;
+                std::vector<const cg_bases*> gb; std::vector<size_t> go; std::vector<int> idx;
+                for (int m = b; m < nb; m++) if (!done[m] && bases[m]->pre_c == bases[b]->pre_c) { gb.push_back(bases[m]); go.push_back(offsets ? offsets[m] : 0); idx.push_back(m); done[m] = 1; }
+                std::vector<int> tk(idx.size());
+                int rc = msm_begin_multi_impl(ctx, (int)idx.size(), gb.data(), go.data(), n, d_scalars, k, tk.data(), force_exact);
+                if (rc) return rc;
+                for (size_t i = 0; i < idx.size(); i++) tickets_out[idx[i]] = tk[i];
+            }
+            return 0;
+        }
+    }
     const int curve = bases[0]->curve;
     const bool shared = bases[0]->pre_c != 0;          // per-window precomputed tables: one bucket set for all windows
-    for (int b = 0; b < nb; b++) {
-        if ((bases[b]->pre_c != 0) != shared || (shared && bases[b]->pre_c != bases[0]->pre_c))
-            return fail(CG_ERR_ARG, "tables of one call must all be precomputed with the same window, or none");
-    }
     if (shared && n > ((size_t)1 << 24)) return fail(CG_ERR_ARG, "precomputed-table MSM supports at most 2^24 points per call");
     int bits = 0;
     { int rc = with_fr(curve, [&](auto tag) -> int { bits = decltype(tag)::Params::BITS; return 0; }); if (rc) return rc; }

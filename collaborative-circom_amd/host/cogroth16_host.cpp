@@ -287,6 +287,32 @@ struct InProcNetwork : Rep3Network {
     }
 };
 
+// A party's incoming traffic recorded during a three-party run and replayed to the same party running alone: its messages depend
+// only on the inputs and the randomness streams, so the solo run repeats the recorded one bit for bit.  Used to time ONE party with
+// the GPU to itself, as in a deployment (each party on its own machine), without a second and third GPU.
+struct RecordingNetwork : Rep3Network {
+    Rep3Network* inner; std::deque<Bytes>* from_prev; std::deque<Bytes>* from_next;
+    RecordingNetwork(Rep3Network* n, std::deque<Bytes>* p, std::deque<Bytes>* q) : inner(n), from_prev(p), from_next(q) {}
+    int id() const override { return inner->id(); }
+    void send_next(const void* d, size_t b) override { inner->send_next(d, b); }
+    void send_prev(const void* d, size_t b) override { inner->send_prev(d, b); }
+    void recv_prev(void* d, size_t b) override { inner->recv_prev(d, b); from_prev->emplace_back((const uint8_t*)d, (const uint8_t*)d + b); }
+    void recv_next(void* d, size_t b) override { inner->recv_next(d, b); from_next->emplace_back((const uint8_t*)d, (const uint8_t*)d + b); }
+};
+struct ReplayNetwork : Rep3Network {
+    int me; std::deque<Bytes>* from_prev; std::deque<Bytes>* from_next;
+    ReplayNetwork(int i, std::deque<Bytes>* p, std::deque<Bytes>* q) : me(i), from_prev(p), from_next(q) {}
+    int id() const override { return me; }
+    void send_next(const void*, size_t) override {}
+    void send_prev(const void*, size_t) override {}
+    static void pop(std::deque<Bytes>* q, void* d, size_t b) {
+        if (q->empty() || q->front().size() != b) throw std::runtime_error("replay: message sequence differs from the recorded run");
+        memcpy(d, q->front().data(), b); q->pop_front();
+    }
+    void recv_prev(void* d, size_t b) override { pop(from_prev, d, b); }
+    void recv_next(void* d, size_t b) override { pop(from_next, d, b); }
+};
+
 // Shamir: any-to-any channels (shamir/network.rs:17-59)
 struct ShamirNet {
     virtual ~ShamirNet() {}
@@ -690,7 +716,19 @@ public:
     // is the whole operation.
     // shorter vectors: one synchronous message (setting up rings and copy streams costs more than it hides); CGH_XCHG_ASYNC_MIN overrides (A/B runs)
     const size_t XCHG_ASYNC_MIN = getenv("CGH_XCHG_ASYNC_MIN") ? (size_t)atoll(getenv("CGH_XCHG_ASYNC_MIN")) : (size_t)1 << 19;
-    struct PendingMul { ShareVec out; bool exchange = false; };
+    struct Down { uint8_t* slot; int32_t tk; };
+    struct PendingMul { ShareVec out; bool exchange = false; std::deque<Down> down; size_t issued = 0; };
+    // start streaming chunks of the local product to the host, as many as the ring has room for
+    void issue_downloads(PendingMul& pm, size_t upto) {
+        const size_t n = pm.out.n, ch = xchg_chunk(n), nch = (n + ch - 1) / ch;
+        while (pm.issued < nch && pm.issued < upto) {
+            const size_t off = pm.issued * ch, len = std::min(ch, n - off);
+            Down d; d.slot = ring_slot(ring_out, ch);
+            CG(cg_dev_download_begin(ctx, d.slot, (const uint8_t*)pm.out.c[0] + off * 32, len * 32, &d.tk));
+            ring_out.busy[ring_out.last] = d.tk;
+            pm.down.push_back(d); pm.issued++;
+        }
+    }
     PendingMul mul_vec_begin(const ShareVec& a, const ShareVec& b) {
         PendingMul pm; ShareVec& out = pm.out; out.n = a.n;
         out.c[0] = dalloc(a.n * 32);
@@ -711,6 +749,7 @@ public:
         defer_free(m1); defer_free(m2);
         out.c[1] = dalloc(a.n * 32);
         pm.exchange = true;
+        if (a.n >= XCHG_ASYNC_MIN) issue_downloads(pm, XCHG_SLOTS - 1);                // ordered right behind the product, ahead of whatever the caller enqueues next
         return pm;
     }
     ShareVec mul_vec_finish(PendingMul& pm) {
@@ -726,18 +765,10 @@ public:
             return out;
         }
         const size_t n = out.n, XCHG_CHUNK = xchg_chunk(n), nch = (n + XCHG_CHUNK - 1) / XCHG_CHUNK;
-        struct Down { uint8_t* slot; int32_t tk; };
-        std::deque<Down> down;
-        size_t issued = 0;
+        std::deque<Down>& down = pm.down;
         int32_t up = -1;
         for (size_t c = 0; c < nch; c++) {
-            while (issued < nch && issued < c + XCHG_SLOTS - 1) {                      // keep the download stream ahead of the sender
-                const size_t off = issued * XCHG_CHUNK, len = std::min(XCHG_CHUNK, n - off);
-                Down d; d.slot = ring_slot(ring_out, XCHG_CHUNK);
-                CG(cg_dev_download_begin(ctx, d.slot, (const uint8_t*)out.c[0] + off * 32, len * 32, &d.tk));
-                ring_out.busy[ring_out.last] = d.tk;
-                down.push_back(d); issued++;
-            }
+            issue_downloads(pm, c + XCHG_SLOTS - 1);                                   // keep the download stream ahead of the sender
             const size_t off = c * XCHG_CHUNK, len = std::min(XCHG_CHUNK, n - off);
             CG(cg_copy_wait(ctx, down.front().tk));
             net->send_next(down.front().slot, len * 32);                               // chunked send_next_many
@@ -2067,6 +2098,111 @@ int32_t cgh_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, con
         release_zkey(ctx0, dz);
         cg_ctx_destroy(ctx0);
         if (report_party_errors(errs, 3)) return 1;
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+
+// ---- proving sessions: the zkey is read, uploaded (and optionally given per-window precomputed tables) ONCE; proofs then cost
+// what co-circom.rs:503-506 times.  A zkey is fixed for the life of a prover process (zkey.rs:48-71).
+struct cgh_session { cgh::ZKey z; cg_ctx* ctx0 = nullptr; cgh::DeviceZKey dz; int device = 0; bool second_context = false; };
+int32_t cgh_session_open(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, void** out) {
+    cgh_session* s = nullptr;
+    try {
+        using namespace cgh;
+        s = new cgh_session(); s->device = device;
+        s->z = read_zkey(curve, zkey_path);
+        if (cg_ctx_create(device, &s->ctx0)) die("cg_ctx_create");
+        std::vector<Fr> pub(s->z.n_public + 1);
+        s->dz = upload_zkey(s->ctx0, s->z, pub);
+        if (precompute) for (cg_bases* b : {s->dz.a, s->dz.b1, s->dz.b2, s->dz.l, s->dz.h}) CG(cg_bases_precompute(s->ctx0, b, precompute > 0 ? precompute : 0));
+        CG(cg_ctx_sync(s->ctx0));
+        s->second_context = s->z.n_vars >= ((size_t)1 << 19) && !getenv("CGH_ONE_CONTEXT");
+        *out = s;
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); if (s) { if (s->ctx0) cg_ctx_destroy(s->ctx0); delete s; } return 1; }
+}
+int32_t cgh_session_close(void* h) {
+    cgh_session* s = (cgh_session*)h;
+    if (!s) return 0;
+    cgh::release_zkey(s->ctx0, s->dz); cg_ctx_destroy(s->ctx0); delete s;
+    return 0;
+}
+static void session_set_public(cgh_session* s, const std::vector<cgh::Fr>& pub) { using namespace cgh; CG(cg_dev_upload(s->ctx0, s->dz.pub_dev, pub.data(), pub.size() * 32)); }
+// plain driver on an open session; seconds[0] (optional) = wall time of the prove
+int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uint64_t* r, const uint64_t* sc, uint64_t* out_proof, double* seconds) {
+    cgh_session* s = (cgh_session*)h; cg_ctx* ctx = nullptr;
+    try {
+        using namespace cgh;
+        const ZKey& z = s->z;
+        const Fr* w = (const Fr*)full_witness;
+        std::vector<Fr> pub(w, w + z.n_public + 1);
+        session_set_public(s, pub);
+        if (cg_ctx_create(s->device, &ctx)) die("cg_ctx_create");
+        cg_ctx* second = nullptr; if (s->second_context && cg_ctx_create(s->device, &second)) die("cg_ctx_create");
+        const auto t0 = std::chrono::steady_clock::now();
+        HipDriver driver(ctx, z.curve, Mode::Plain, nullptr);
+        driver.use_second_context(second);
+        ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_public - 1);
+        FieldShare rs[2]; memcpy(rs[0].c[0].v, r, 32); rs[0].c[1] = rs[0].c[0]; memcpy(rs[1].c[0].v, sc, 32); rs[1].c[1] = rs[1].c[0];
+        CoGroth16 prover(driver);
+        Proof p = prover.prove(s->dz, pub, wit, rs, nullptr);
+        if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        store_proof(p, (uint8_t*)out_proof);
+        driver.free_vec(wit); driver.shutdown();
+        cg_ctx_destroy(ctx);
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
+}
+// three REP3 parties on an open session (threads, in-process network).  seconds (optional, 2 values): [0] = wall time of the three
+// co-located parties; [1] = party 0 ALONE on the GPU, replaying the messages it received in the first run (its proof must repeat).
+int32_t cgh_session_prove_rep3(void* h, const uint64_t* pub_in, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
+                               const uint64_t* const* streams, size_t stream_len, uint64_t* out_proofs, double* seconds) {
+    cgh_session* s = (cgh_session*)h;
+    try {
+        using namespace cgh;
+        const ZKey& z = s->z;
+        const size_t n_aux = z.n_vars - z.n_public - 1, psz = 8 * z.curve.fq();
+        std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
+        session_set_public(s, pub);
+        std::deque<Bytes> rec_prev, rec_next;
+        auto party = [&](int i, Rep3Network* net, uint8_t* out) {
+            cg_ctx* ctx = nullptr;
+            try {
+                if (cg_ctx_create(s->device, &ctx)) die("cg_ctx_create");
+                cg_ctx* second = nullptr; if (s->second_context && cg_ctx_create(s->device, &second)) die("cg_ctx_create");
+                HipDriver driver(ctx, z.curve, Mode::Rep3, net);
+                driver.use_second_context(second);
+                driver.rng1 = (const Fr*)streams[i]; driver.rng2 = (const Fr*)streams[(i + 2) % 3]; driver.rng_len = stream_len;
+                ShareVec wit = driver.upload_vec((const Fr*)wit_a[i], (const Fr*)wit_b[i], n_aux);
+                CoGroth16 prover(driver);
+                Proof p = prover.prove(s->dz, pub, wit, nullptr, nullptr);
+                store_proof(p, out);
+                driver.free_vec(wit); driver.shutdown();
+                cg_ctx_destroy(ctx);
+            } catch (...) { if (ctx) cg_ctx_destroy(ctx); throw; }
+        };
+        InProcHub hub;
+        std::string errs[3];
+        std::vector<std::thread> th;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 3; i++) th.emplace_back([&, i] {
+            try {
+                InProcNetwork net(&hub, i);
+                RecordingNetwork rec(&net, &rec_prev, &rec_next);
+                party(i, i == 0 && seconds ? (Rep3Network*)&rec : (Rep3Network*)&net, (uint8_t*)out_proofs + i * psz);
+            } catch (const std::exception& e) { errs[i] = e.what(); hub.abort(); }
+        });
+        for (auto& t : th) t.join();
+        if (report_party_errors(errs, 3)) return 1;
+        if (seconds) {
+            seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            Bytes solo(psz);
+            ReplayNetwork replay(0, &rec_prev, &rec_next);
+            const auto t1 = std::chrono::steady_clock::now();
+            party(0, &replay, solo.data());
+            seconds[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+            if (memcmp(solo.data(), out_proofs, psz)) throw std::runtime_error("replayed party produced a different proof");
+        }
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }

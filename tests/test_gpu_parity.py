@@ -400,11 +400,15 @@ def test_msm_precomputed_multi_and_skew(ctx):
         got = ctx.msm_end(t)
         for j, sc in enumerate((same, uni)):
             np.testing.assert_array_equal(cg.point_to_affine(curve, g, got[j]), orc.msm(curve, g, p[o:o + n], sc, threads=8))
-    # mixing a precomputed and a plain table in one call is rejected
+    # tables with different windows (the automatic choice differs by group and size) or without precomputed tables may share a call:
+    # one schedule per window, tickets in the caller's order
     b3 = ctx.register_bases(curve, G1, t1)
-    with pytest.raises(cg.BackendError):
-        ctx.msm_dev_begin_multi([b1, b3], [dev(ctx, uni)], n)
-    for b in (b1, b2, b3):
+    b4 = ctx.register_bases(curve, G2, t2); ctx.precompute_bases(b4, 13)
+    tickets = ctx.msm_dev_begin_multi([b3, b1, b4, b2], [dev(ctx, uni)], n, offsets=[0, 0, 1, 1])
+    for (g, p, o), t in zip(((G1, t1, 0), (G1, t1, 0), (G2, t2, 1), (G2, t2, 1)), tickets):
+        got = ctx.msm_end(t)
+        np.testing.assert_array_equal(cg.point_to_affine(curve, g, got[0]), orc.msm(curve, g, p[o:o + n], uni, threads=8))
+    for b in (b1, b2, b3, b4):
         b.release()
 
 
