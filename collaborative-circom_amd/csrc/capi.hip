@@ -48,6 +48,9 @@ template <class Fr> int launch_vec_inverse(hipStream_t st, Fr* out, const Fr* in
 template <class Fr> int launch_spmv_csr(hipStream_t st, const uint32_t* row_ptr, const uint32_t* col, const Fr* coeff, size_t n_rows, const Fr* pub,
                                         uint32_t n_inputs, int party, const Fr* wit_a, const Fr* wit_b, Fr* out_a, Fr* out_b);
 template <class Fr> int launch_build_twiddles(hipStream_t st, Fr* tw, size_t m, int log_m, const Fr* lo, const Fr* hi, int log_lo);
+template <class Fr> int launch_build_twiddles_lazy(hipStream_t st, void* tw, size_t m, int log_m, const Fr* lo, const Fr* hi, int log_lo, const Fr& c32);
+template <class Fr> int launch_ntt_ct_pass(hipStream_t st, bool first, NttVecs src, NttVecs dst, int nvec, size_t n, int log_m, int s0, int k, int t, const void* tw);
+template <class Fr> int launch_bitrev_finish_lazy(hipStream_t st, NttVecs dst, NttVecs src, int nvec, size_t n, int log_m, const Fr* scale, const Fr* c_lo, const Fr* c_hi, int log_lo);
 template <class Fr> int launch_ntt_dif_pass(hipStream_t st, NttVecs src, NttVecs dst, int nvec, size_t n, int log_m, int s0, int k, int t, const Fr* tw);
 template <class Fr> int launch_bitrev_scale(hipStream_t st, NttVecs dst, NttVecs src, int nvec, size_t n, int log_m, const Fr* scale, const Fr* c_lo, const Fr* c_hi, int log_lo);
 }  // namespace cg
@@ -59,7 +62,8 @@ struct Arena {
     void* take(size_t bytes) { void* p = base + used; used += align_up(bytes); return p; }
 };
 
-struct TwKey { int curve; int log_m; uint32_t gen[8]; bool operator<(const TwKey& o) const { if (curve != o.curve) return curve < o.curve; if (log_m != o.log_m) return log_m < o.log_m; return memcmp(gen, o.gen, sizeof gen) < 0; } };
+struct TwKey { int curve; int log_m; uint32_t gen[8]; int kind = 0;   // kind 0: stage-major packed tables (DIF passes), 1: bit-reversed limb-form table (lazy passes)
+    bool operator<(const TwKey& o) const { if (curve != o.curve) return curve < o.curve; if (log_m != o.log_m) return log_m < o.log_m; if (kind != o.kind) return kind < o.kind; return memcmp(gen, o.gen, sizeof gen) < 0; } };
 struct CosetKey { TwKey k; uint32_t scale[8]; bool operator<(const CosetKey& o) const { if (k < o.k) return true; if (o.k < k) return false; return memcmp(scale, o.scale, sizeof scale) < 0; } };
 struct CosetTables { void* lo; void* hi; int log_lo; };
 
@@ -534,6 +538,35 @@ int get_twiddles(cg_ctx* ctx, int curve, int log_m, const Fr& w, const Fr** out)
     return 0;
 }
 
+// limb-form table of the lazy passes: tw[i] = 32 * w^bitrev(i), i < m/2 (ntt_kernels.hpp)
+template <class Fr>
+int get_twiddles_lazy(cg_ctx* ctx, int curve, int log_m, const Fr& w, const void** out) {
+    TwKey key; key.curve = curve; key.log_m = log_m; key.kind = 1; memcpy(key.gen, w.v, sizeof key.gen);
+    auto it = ctx->twiddles.find(key);
+    if (it != ctx->twiddles.end()) { *out = it->second; return 0; }
+    if (void* shared = shared_twiddles_acquire(ctx->device, key)) { ctx->twiddles[key] = shared; *out = shared; return 0; }
+    const size_t m = (size_t)1 << log_m;
+    const int log_lo = std::min(11, std::max(0, log_m - 1));
+    const size_t hi_n = std::max<size_t>(1, (m / 2) >> log_lo);
+    std::vector<Fr> lo, hi;
+    host_pow_tables(w, Fr::one(), log_lo, hi_n, lo, hi);
+    Fr c32 = Fr::one(); for (int i = 0; i < 5; i++) c32 = c32 + c32;
+    Fr *d_lo = nullptr, *d_hi = nullptr; void* d_tw = nullptr;
+    const size_t bytes = lazy29_bytes(std::max<size_t>(m / 2, 1));
+    HIPCHK(hipMalloc((void**)&d_lo, lo.size() * sizeof(Fr)));
+    HIPCHK(hipMalloc((void**)&d_hi, hi.size() * sizeof(Fr)));
+    HIPCHK(hipMalloc(&d_tw, bytes));
+    HIPCHK(hipMemcpyAsync(d_lo, lo.data(), lo.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_hi, hi.data(), hi.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    { int rc = launch_build_twiddles_lazy<Fr>(ctx->stream, d_tw, m, log_m, d_lo, d_hi, log_lo, c32); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(d_lo)); HIPCHK(hipFree(d_hi));
+    d_tw = shared_twiddles_publish(ctx->device, key, d_tw, bytes);
+    ctx->twiddles[key] = d_tw;
+    *out = d_tw;
+    return 0;
+}
+
 // tables with lo[j] = scale * g^j, hi[j] = g^(j << log_lo), covering exponents < 2^log_m
 template <class Fr>
 int get_coset_tables(cg_ctx* ctx, int curve, int log_m, const Fr& g, const Fr& scale, CosetTables* out) {
@@ -561,16 +594,16 @@ int get_coset_tables(cg_ctx* ctx, int curve, int log_m, const Fr& g, const Fr& s
 }
 
 struct NttPass { int s0, k, t; };
-std::vector<NttPass> ntt_plan(int log_m) {
+std::vector<NttPass> ntt_plan(int log_m, int tile_log = NTT_TILE_LOG) {
     std::vector<NttPass> plan;
-    const int k_last = std::min(log_m, NTT_TILE_LOG);
+    const int k_last = std::min(log_m, tile_log);
     const int rest = log_m - k_last;
     int s0 = 0;
     if (rest > 0) {
         const int np = (rest + 6) / 7;
         for (int i = 0; i < np; i++) {
             int k = rest / np + (i < rest % np ? 1 : 0);
-            plan.push_back({s0, k, NTT_TILE_LOG - k});   // lo_bits >= 11 here, so t = 11 - k fits
+            plan.push_back({s0, k, tile_log - k});       // lo_bits >= tile_log here, so t = tile_log - k fits
             s0 += k;
         }
     }
@@ -585,6 +618,32 @@ int ntt_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_t n, const 
     if (k < 1 || k > NTT_MAX_VECS) return fail(CG_ERR_ARG, "k out of range");
     if (n == 1) return 0;
     const Fr w = inverse ? fp_inverse(gen) : gen;
+    static const bool legacy = getenv("CG_NTT_DIF") != nullptr;                 // A/B knob: the canonical DIF passes
+    if (!legacy) {
+        // lazy Cooley-Tukey passes (ntt_kernels.hpp): packed vectors -> limb-form scratch -> ... -> permutation back into the vectors,
+        // which multiplies by 32 * (1/m) * coset power (32: the lazy core divides by 2^261, the ABI's R is 2^256)
+        if (!inverse && coset) return fail(CG_ERR_ARG, "coset_gen is only supported with inverse != 0");
+        const void* twl = nullptr;
+        int rc = get_twiddles_lazy<Fr>(ctx, curve, log_m, w, &twl);
+        if (rc) return rc;
+        NttVecs data{}, tmp{};
+        for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->arena.base + arena_off + (size_t)j * lazy29_bytes(n); }
+        hipStream_t st = ctx->stream;
+        bool first = true;
+        static const int lazy_tile = [] { const char* e = getenv("CG_NTT_TILE"); const int v = e ? atoi(e) : NTT_TILE_LOG_LAZY; return std::min(NTT_TILE_LOG, std::max(8, v)); }();   // tuning knob
+        for (const NttPass& p : ntt_plan(log_m, lazy_tile)) { rc = launch_ntt_ct_pass<Fr>(st, first, first ? data : tmp, tmp, k, n, log_m, p.s0, p.k, p.t, twl); if (rc) return rc; first = false; }
+        Fr scale32 = Fr::one(); for (int i = 0; i < 5; i++) scale32 = scale32 + scale32;
+        if (inverse) {
+            uint32_t e[Fr::N] = {0}; e[log_m / 32] = 1u << (log_m % 32);
+            Fr nn; for (int i = 0; i < Fr::N; i++) nn.v[i] = e[i];
+            scale32 = scale32 * fp_inverse(nn.to_mont());
+        }
+        CosetTables t;
+        const Fr* d_scale = nullptr; const Fr* c_lo = nullptr; const Fr* c_hi = nullptr; int log_lo = 0;
+        if (coset) { rc = get_coset_tables<Fr>(ctx, curve, log_m, *coset, scale32, &t); if (rc) return rc; c_lo = (const Fr*)t.lo; c_hi = (const Fr*)t.hi; log_lo = t.log_lo; }
+        else { rc = get_coset_tables<Fr>(ctx, curve, 0, Fr::one(), scale32, &t); if (rc) return rc; d_scale = (const Fr*)t.lo; }
+        return launch_bitrev_finish_lazy<Fr>(st, data, tmp, k, n, log_m, d_scale, c_lo, c_hi, log_lo);
+    }
     const Fr* tw = nullptr;
     int rc = get_twiddles<Fr>(ctx, curve, log_m, w, &tw);
     if (rc) return rc;
@@ -1036,7 +1095,7 @@ int32_t cg_ntt_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, int32_t k, s
         typedef decltype(tag) Fr;
         Fr gen, cos; copy_in(gen, h_group_gen);
         if (h_coset_gen) copy_in(cos, h_coset_gen);
-        if (n > 1) { int rc = ensure_arena(ctx, (size_t)k * n * sizeof(Fr)); if (rc) return rc; }
+        if (n > 1) { int rc = ensure_arena(ctx, (size_t)k * lazy29_bytes(n)); if (rc) return rc; }
         StatScope ss(ctx, TAG_NTT);
         return ntt_run<Fr>(ctx, curve, d_vecs, k, n, gen, inverse != 0, h_coset_gen ? &cos : nullptr, 0);
     });

@@ -99,6 +99,32 @@ template <class Fr> int launch_ntt_dif_pass(hipStream_t st, NttVecs src, NttVecs
     HIPCHK(hipGetLastError());
     return 0;
 }
+template <class Fr> int launch_build_twiddles_lazy(hipStream_t st, void* tw, size_t m, int log_m, const Fr* lo, const Fr* hi, int log_lo, const Fr& c32) {
+    if (m > 1) hipLaunchKernelGGL((k_build_twiddles_lazy<Fr>), dim3(grid_for(m / 2)), dim3(256), 0, st, tw, m / 2, log_m, lo, hi, log_lo, c32);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class Fr> int launch_ntt_ct_pass(hipStream_t st, bool first, NttVecs src, NttVecs dst, int nvec, size_t n, int log_m, int s0, int k, int t, const void* tw) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_ntt_ct_pass<Fr, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 36 << NTT_TILE_LOG));
+        HIPCHK(hipFuncSetAttribute((const void*)k_ntt_ct_pass<Fr, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 36 << NTT_TILE_LOG));
+        attr_set = true;
+    }
+    const int E = 1 << (k + t);
+    if (first) hipLaunchKernelGGL((k_ntt_ct_pass<Fr, true>), dim3((unsigned)(n / E), nvec), dim3(NTT_THREADS), (size_t)E * 36, st, src, dst, log_m, s0, k, t, tw);
+    else hipLaunchKernelGGL((k_ntt_ct_pass<Fr, false>), dim3((unsigned)(n / E), nvec), dim3(NTT_THREADS), (size_t)E * 36, st, src, dst, log_m, s0, k, t, tw);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class Fr> int launch_bitrev_finish_lazy(hipStream_t st, NttVecs dst, NttVecs src, int nvec, size_t n, int log_m, const Fr* scale, const Fr* c_lo, const Fr* c_hi, int log_lo) {
+    if (log_m >= 2 * BITREV_B_LAZY)
+        hipLaunchKernelGGL((k_bitrev_finish_lazy<Fr>), dim3((unsigned)(n >> (2 * BITREV_B_LAZY)), nvec), dim3(256), 0, st, dst, src, log_m, scale, c_lo, c_hi, log_lo);
+    else
+        hipLaunchKernelGGL((k_bitrev_finish_lazy_small<Fr>), dim3(grid_for(n), nvec), dim3(256), 0, st, dst, src, log_m, scale, c_lo, c_hi, log_lo);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 template <class Fr> int launch_bitrev_scale(hipStream_t st, NttVecs dst, NttVecs src, int nvec, size_t n, int log_m, const Fr* scale, const Fr* c_lo, const Fr* c_hi, int log_lo) {
     if (log_m >= 2 * BITREV_B)
         hipLaunchKernelGGL((k_bitrev_scale<Fr>), dim3((unsigned)(n >> (2 * BITREV_B)), nvec), dim3(256), 0, st, dst, src, log_m, scale, c_lo, c_hi, log_lo);
@@ -213,6 +239,9 @@ template <class Fr> int msm_sort_direct_launch(hipStream_t st, const Fr* d_scala
     template int launch_spmv_csr<Fr>(hipStream_t, const uint32_t*, const uint32_t*, const Fr*, size_t, const Fr*, uint32_t, int, const Fr*, const Fr*, Fr*, Fr*); \
     template int launch_build_twiddles<Fr>(hipStream_t, Fr*, size_t, int, const Fr*, const Fr*, int);                      \
     template int launch_ntt_dif_pass<Fr>(hipStream_t, NttVecs, NttVecs, int, size_t, int, int, int, int, const Fr*);                \
+    template int launch_build_twiddles_lazy<Fr>(hipStream_t, void*, size_t, int, const Fr*, const Fr*, int, const Fr&);             \
+    template int launch_ntt_ct_pass<Fr>(hipStream_t, bool, NttVecs, NttVecs, int, size_t, int, int, int, int, const void*);         \
+    template int launch_bitrev_finish_lazy<Fr>(hipStream_t, NttVecs, NttVecs, int, size_t, int, const Fr*, const Fr*, const Fr*, int); \
     template int launch_bitrev_scale<Fr>(hipStream_t, NttVecs, NttVecs, int, size_t, int, const Fr*, const Fr*, const Fr*, int); \
     template int msm_sort_launch<Fr>(hipStream_t, const Fr*, size_t, int, int, int, char*, MsmSortPtrs*, hipEvent_t*);          \
     template int msm_sort_direct_launch<Fr>(hipStream_t, const Fr*, size_t, int, int, int, uint32_t, char*, MsmSortPtrs*, hipEvent_t*); \

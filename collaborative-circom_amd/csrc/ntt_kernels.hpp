@@ -10,6 +10,7 @@
 // natural order and fuses the 1/m scaling and the coset shift g^i (rep3.rs:681-688) into the same HBM round trip.
 #pragma once
 #include "field.hpp"
+#include "lazy29.hpp"
 #include "vec_kernels.hpp"
 
 namespace cg {
@@ -19,6 +20,8 @@ struct NttVecs { void* p[NTT_MAX_VECS]; };
 
 constexpr int NTT_TILE_LOG = 11;                       // 2048 elements x 32 B = 64 KiB of LDS per workgroup
 constexpr int NTT_THREADS = 256;
+constexpr int NTT_TILE_LOG_LAZY = 10;                  // lazy passes: 1024 elements x 36 B = 36 KiB, four workgroups per CU
+constexpr int BITREV_B_LAZY = 5;
 
 __host__ __device__ inline size_t tw_stage_offset(size_t m, int s) { return m - (m >> s); }
 
@@ -88,6 +91,146 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_dif_pass(NttVecs src_vecs, 
         const size_t g = base + ((size_t)(idx >> t) << lo_bits) + (idx & tmask);
         uint4* q = reinterpret_cast<uint4*>(dst + g);
         q[0] = pl0[idx]; q[1] = pl1[idx];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Lazy passes.  The DIF pass above is bound by VALU issue, not by HBM or LDS (521 instructions per butterfly, 162 of them
+// multiplies: canonical add, canonical subtract, and a product that unpacks 8 x 32 -> 9 x 29 bits, reduces, and packs again).
+// The passes below keep the elements as SIGNED LAZY 29-bit limbs (lazy29.hpp) from the first load to the final permutation:
+//   * Cooley-Tukey butterflies on natural-order input, (u, v) -> (u + w v, u - w v): only v meets a multiplier, u just
+//     accumulates (|value| grows by ~p per stage: 25 p after 24 stages, the limbs hold 169 p), so there is no reduction
+//     and no conditional subtraction anywhere; the pairs (and therefore tiles, passes and the bit-reversed result) are those of
+//     the DIF passes, the twiddle of a butterfly is w^bitrev(block index): ONE table of m/2 entries, contiguous per tile;
+//   * twiddles are stored unpacked and pre-multiplied by 2^5 (the lazy core divides by 2^261, the ABI's Montgomery R is 2^256);
+//   * between passes the elements stay in limb form (36 B each, three planes) in scratch; the final permutation multiplies by
+//     32 * scale * coset power — which also brings the value back under 2p — and packs.
+// ~350 instructions per butterfly.
+struct Lazy29Planes { uint4* p0; uint4* p1; uint32_t* p2; };
+__host__ __device__ inline size_t lazy29_bytes(size_t n) { return ((n * 36 + 255) / 256) * 256; }
+__device__ __forceinline__ Lazy29Planes lazy29_planes(void* base, size_t n) {
+    char* b = reinterpret_cast<char*>(base);
+    return {reinterpret_cast<uint4*>(b), reinterpret_cast<uint4*>(b + n * 16), reinterpret_cast<uint32_t*>(b + n * 32)};
+}
+template <class L> __device__ __forceinline__ L lazy29_load(const uint4* p0, const uint4* p1, const uint32_t* p2, size_t i) {
+    const uint4 x = p0[i], y = p1[i]; L r;
+    r.l[0] = (int32_t)x.x; r.l[1] = (int32_t)x.y; r.l[2] = (int32_t)x.z; r.l[3] = (int32_t)x.w;
+    r.l[4] = (int32_t)y.x; r.l[5] = (int32_t)y.y; r.l[6] = (int32_t)y.z; r.l[7] = (int32_t)y.w; r.l[8] = (int32_t)p2[i];
+    return r;
+}
+template <class L> __device__ __forceinline__ void lazy29_store(uint4* p0, uint4* p1, uint32_t* p2, size_t i, const L& v) {
+    p0[i] = make_uint4((uint32_t)v.l[0], (uint32_t)v.l[1], (uint32_t)v.l[2], (uint32_t)v.l[3]);
+    p1[i] = make_uint4((uint32_t)v.l[4], (uint32_t)v.l[5], (uint32_t)v.l[6], (uint32_t)v.l[7]);
+    p2[i] = (uint32_t)v.l[8];
+}
+
+// tw[i] = unpack(32 * w^bitrev(i)), i < m/2, bitrev over log_m - 1 bits; c32 = Montgomery form of 32
+template <class F>
+__global__ void __launch_bounds__(256) k_build_twiddles_lazy(void* tw_base, size_t half, int log_m, const F* __restrict__ lo, const F* __restrict__ hi, int log_lo, F c32) {
+    typedef L29<F> L;
+    const Lazy29Planes tw = lazy29_planes(tw_base, half);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = log_m > 1 ? (size_t)(__brevll((unsigned long long)i) >> (64 - (log_m - 1))) : 0;
+        const F w = ld_fp(lo + (e & (((size_t)1 << log_lo) - 1))) * ld_fp(hi + (e >> log_lo)) * c32;
+        lazy29_store<L>(tw.p0, tw.p1, tw.p2, i, L::template unpack<0>(w));
+    }
+}
+
+// One Cooley-Tukey pass over stages [s0, s0+k): same tiles as k_ntt_dif_pass.  FIRST: src = the caller's packed vectors;
+// otherwise src = dst = limb-form scratch (in place).
+template <class F, bool FIRST>
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_ct_pass(NttVecs src_vecs, NttVecs dst_vecs, int log_m, int s0, int k, int t, const void* tw_base) {
+    static_assert(F::N == 8, "NTT is specialised for 256-bit scalar fields");
+    typedef L29<F> L;
+    extern __shared__ uint4 lds[];
+    const int E = 1 << (k + t);
+    uint4* pl0 = lds;
+    uint4* pl1 = lds + E;
+    uint32_t* pl2 = reinterpret_cast<uint32_t*>(lds + 2 * E);
+    const size_t m = (size_t)1 << log_m;
+    const Lazy29Planes tw = lazy29_planes(const_cast<void*>(tw_base), m / 2);
+    const Lazy29Planes dst = lazy29_planes(dst_vecs.p[blockIdx.y], m);
+    const int lo_bits = log_m - s0 - k;
+    const size_t tiles_per_hi = (size_t)1 << (lo_bits - t);
+    const size_t hi = blockIdx.x / tiles_per_hi;
+    const size_t lo0 = (blockIdx.x % tiles_per_hi) << t;
+    const size_t base = (hi << (log_m - s0)) + lo0;
+    const int tmask = (1 << t) - 1;
+
+    for (int idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+        const size_t g = base + ((size_t)(idx >> t) << lo_bits) + (idx & tmask);
+        L v;
+        if constexpr (FIRST) v = L::template unpack<0>(ld_fp(reinterpret_cast<const F*>(src_vecs.p[blockIdx.y]) + g));
+        else v = lazy29_load<L>(dst.p0, dst.p1, dst.p2, g);
+        lazy29_store<L>(pl0, pl1, pl2, idx, v);
+    }
+    __syncthreads();
+    for (int q = 0; q < k; q++) {
+        const int pb = k - 1 - q;
+        for (int u = threadIdx.x; u < E / 2; u += NTT_THREADS) {
+            const int lo_local = u & tmask;
+            const int mu = u >> t;
+            const int mid0 = ((mu >> pb) << (pb + 1)) | (mu & ((1 << pb) - 1));
+            const int i0 = (mid0 << t) | lo_local;
+            const int i1 = i0 + (1 << (pb + t));
+            const size_t blk = (hi << q) | (size_t)(mid0 >> (k - q));       // index of the butterfly's block at stage s0 + q
+            const L a = lazy29_load<L>(pl0, pl1, pl2, i0), b = lazy29_load<L>(pl0, pl1, pl2, i1);
+            const L w = lazy29_load<L>(tw.p0, tw.p1, tw.p2, blk);
+            const L v = L::mul(b, w);
+            lazy29_store<L>(pl0, pl1, pl2, i0, (a + v).norm());
+            lazy29_store<L>(pl0, pl1, pl2, i1, (a - v).norm());
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+        const size_t g = base + ((size_t)(idx >> t) << lo_bits) + (idx & tmask);
+        lazy29_store<L>(dst.p0, dst.p1, dst.p2, g, lazy29_load<L>(pl0, pl1, pl2, idx));
+    }
+}
+
+// dst[bitrev(i)] = pack(src[i] * c(bitrev(i))), src in limb form: c = *scale (a constant that already contains the factor 32) or
+// the product of the two coset tables (whose `lo` half contains 32 * scale).  Same LDS-tiled permutation as k_bitrev_scale.
+template <class F>
+__global__ void __launch_bounds__(256) k_bitrev_finish_lazy(NttVecs dst, NttVecs src, int log_m, const F* __restrict__ scale,
+                                                            const F* __restrict__ cos_lo, const F* __restrict__ cos_hi, int log_lo) {
+    typedef L29<F> L;
+    constexpr int B = BITREV_B_LAZY, S = 1 << B;
+    __shared__ uint4 tile0[S * (S + 1)];
+    __shared__ uint4 tile1[S * (S + 1)];
+    __shared__ uint32_t tile2[S * (S + 1)];
+    const size_t m = (size_t)1 << log_m;
+    const Lazy29Planes in = lazy29_planes(src.p[blockIdx.y], m);
+    F* out = reinterpret_cast<F*>(dst.p[blockIdx.y]);
+    const int mid_bits = log_m - 2 * B;
+    const size_t mid = blockIdx.x;
+    const size_t rmid = mid_bits > 0 ? (__brevll((unsigned long long)mid) >> (64 - mid_bits)) : 0;
+    for (int e = threadIdx.x; e < S * S; e += 256) {
+        const int h = e >> B, l = e & (S - 1);
+        const size_t i = ((size_t)h << (log_m - B)) | (mid << B) | (size_t)l;
+        tile0[h * (S + 1) + l] = in.p0[i]; tile1[h * (S + 1) + l] = in.p1[i]; tile2[h * (S + 1) + l] = in.p2[i];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < S * S; e += 256) {
+        const int rl = e >> B, rh = e & (S - 1);
+        const int l = __brev((unsigned)rl) >> (32 - B), h = __brev((unsigned)rh) >> (32 - B);
+        const size_t o = ((size_t)rl << (log_m - B)) | (rmid << B) | (size_t)rh;
+        const L v = lazy29_load<L>(tile0, tile1, tile2, (size_t)(h * (S + 1) + l));
+        const F c = cos_lo ? ld_fp(cos_lo + (o & (((size_t)1 << log_lo) - 1))) * ld_fp(cos_hi + (o >> log_lo)) : ld_fp(scale);
+        st_fp(out + o, L::pack_reduced(L::mul(v, L::template unpack<0>(c))));
+    }
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_bitrev_finish_lazy_small(NttVecs dst, NttVecs src, int log_m, const F* __restrict__ scale,
+                                                                  const F* __restrict__ cos_lo, const F* __restrict__ cos_hi, int log_lo) {
+    typedef L29<F> L;
+    const size_t m = (size_t)1 << log_m;
+    const Lazy29Planes in = lazy29_planes(src.p[blockIdx.y], m);
+    F* out = reinterpret_cast<F*>(dst.p[blockIdx.y]);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = log_m ? (__brevll((unsigned long long)i) >> (64 - log_m)) : 0;
+        const L v = lazy29_load<L>(in.p0, in.p1, in.p2, i);
+        const F c = cos_lo ? ld_fp(cos_lo + (o & (((size_t)1 << log_lo) - 1))) * ld_fp(cos_hi + (o >> log_lo)) : ld_fp(scale);
+        st_fp(out + o, L::pack_reduced(L::mul(v, L::template unpack<0>(c))));
     }
 }
 
