@@ -68,10 +68,9 @@ struct L29 {
     // limb 0 already are the normalised limb 0 and must equal limb 0 of one of the candidates k*p (a non-zero residue passes with
     // probability ~10 / 2^29).  Lets the hot loop skip the carry propagation it would otherwise do only for this test.
     __device__ __forceinline__ static bool maybe_zero_mod_p(const L29& x) {
-        const int32_t lo = x.l[0] & (int32_t)MASK;
-        bool maybe = false;
-        _Pragma("unroll") for (int kk = -3; kk <= 6; kk++) maybe = maybe || (lo == (int32_t)(((int64_t)kk * pl(0)) & MASK));
-        return maybe;
+        // x = k p with -3 <= k <= 6  =>  k = x p^-1 (mod 2^29) lies in that range; p^-1 = -INV (mod 2^29)
+        const uint32_t k = ((uint32_t)x.l[0] * (0u - P::INV)) & MASK;
+        return ((k + 3u) & MASK) < 10u;
     }
     // k*p in normalised limbs, k in [-3, 6]: the residues a normalised value in (-4p, 7p) takes when it is 0 mod p
     __device__ __forceinline__ static bool is_zero_mod_p(const L29& x /* normalised */) {
