@@ -22,7 +22,7 @@ inline size_t msm_sort_direct_scratch_bytes(size_t n, int c, int nwin, int share
     return align_up(nbuckets * cap * 4) + 2 * align_up(nbuckets * 4) + align_up(((nbuckets + 2047) / 2048) * 4) + 256;
 }
 template <class F> int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, const Affine<F>* d_bases, size_t n, int c, int nwin,
-                                             size_t table_stride, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs);
+                                             size_t table_stride, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs, bool may_have_inf);
 template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared);
 template <class F> int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c);
 template <class F> int check_on_curve_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, const F& b, unsigned long long* d_counters);
@@ -125,6 +125,7 @@ struct cg_bases {
     // holds the non-infinity records, `h_live` / `d_live` their original indices (ascending), and the scalars are gathered to match.
     cg_bases* compact = nullptr;
     std::vector<uint32_t> h_live; uint32_t* d_live = nullptr; uint64_t live_sig = 0;
+    bool no_inf = false;          // registration census found no point at infinity: the accumulate kernel skips its per-point test
 };
 
 namespace {
@@ -412,7 +413,7 @@ int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, cons
                     typedef decltype(ftag) F;
                     const Affine<F>* pts = (const Affine<F>*)(shared ? bases[b]->d_pre : bases[b]->d_pts) + (offsets ? offsets[b] : 0);
                     return msm_accumulate_reduce<F>(ctx->stream, ctx->aux, ctx->ev_acc[slot], ctx->ev_red[slot], pts, n, c, nwin, shared ? bases[b]->n : 0,
-                                                    sp.sorted, sp.offsets, sp.counts, sp.cap, acc_scratch + (size_t)slot * acc_slot, (XYZZ<F>*)t.h_pinned + (size_t)j * nsums, pev);
+                                                    sp.sorted, sp.offsets, sp.counts, sp.cap, acc_scratch + (size_t)slot * acc_slot, (XYZZ<F>*)t.h_pinned + (size_t)j * nsums, pev, !bases[b]->no_inf);
                 });
                 if (rc) return rc;
                 ctx->slot_busy[slot] = true; ctx->aux_pending = true; ctx->last_slot = slot;
@@ -902,8 +903,10 @@ static int32_t bases_register_impl(cg_ctx* ctx, int32_t curve, int32_t group, co
             std::vector<uint32_t> live; live.reserve(n);
             const size_t words = pt / 8;
             for (size_t i = 0; i < n; i++) { uint64_t any = 0; for (size_t q = 0; q < words; q++) any |= w[i * words + q]; if (any) live.push_back((uint32_t)i); }
+            b->no_inf = live.size() == n;
             if (live.size() * 8 <= n * 7) {
                 cg_bases* cb = new cg_bases{ctx->device, curve, group, live.size(), pt, nullptr};
+                cb->no_inf = true;
                 HIPCHK(hipMalloc(&cb->d_pts, std::max<size_t>(live.size() * pt, 16)));
                 HIPCHK(hipMalloc((void**)&b->d_live, std::max<size_t>(live.size() * 4, 16)));
                 if (!live.empty()) {
@@ -1028,6 +1031,7 @@ int32_t cg_bases_synth_multiples(cg_ctx* ctx, int32_t curve, int32_t group, uint
         HIPCHK(hipMemcpy(d_lo, lo.data(), T * sizeof(XYZZ<F>), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d_hi, hi.data(), H * sizeof(XYZZ<F>), hipMemcpyHostToDevice));
         cg_bases* b = new cg_bases{ctx->device, curve, group, n, sizeof(Affine<F>), nullptr};
+        b->no_inf = first >= 1 && first + n > first;             // (first + i) G with 1 <= first + i < 2^64 < r is never the point at infinity
         HIPCHK(hipMalloc(&b->d_pts, std::max<size_t>(n * sizeof(Affine<F>), 16)));
         int rc = synth_points_launch<F>(ctx->stream, d_lo, d_hi, log_t, n, (Affine<F>*)b->d_pts);
         if (rc) return rc;

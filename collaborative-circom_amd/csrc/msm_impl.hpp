@@ -28,7 +28,7 @@ size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared) {
 // runs on `st2` behind `ev_acc` and signals `ev_red`, so it overlaps with the NEXT accumulation, which uses another scratch slot.
 template <class F>
 int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride,
-                          const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs) {
+                          const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs, bool may_have_inf) {
     const bool shared = table_stride != 0;
     MsmGeom g = msm_geom(n, c, nwin, shared);
     size_t off = 0;
@@ -45,7 +45,7 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     auto launch_acc = [&](auto kern, int T, size_t lds) -> int {
         if (lds > 0) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((g.nchunks + T - 1) / T), dim3(T), lds, st, d_bases, sorted, offsets, counts,
-                           (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, (uint32_t)table_stride, cap, buckets, cont, cont_bucket);
+                           (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, (uint32_t)table_stride, cap, buckets, cont, cont_bucket, may_have_inf ? 1u : 0u);
         return 0;
     };
     // accumulator policy per coordinate field:
@@ -137,7 +137,7 @@ int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi
 
 #define CG_INSTANTIATE_MSM(F, Fr)                                                                                          \
     namespace cg {                                                                                                         \
-    template int msm_accumulate_reduce<F>(hipStream_t, hipStream_t, hipEvent_t, hipEvent_t, const Affine<F>*, size_t, int, int, size_t, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, char*, XYZZ<F>*, hipEvent_t*); \
+    template int msm_accumulate_reduce<F>(hipStream_t, hipStream_t, hipEvent_t, hipEvent_t, const Affine<F>*, size_t, int, int, size_t, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, char*, XYZZ<F>*, hipEvent_t*, bool); \
     template size_t msm_acc_scratch_bytes<F>(size_t, int, int, bool);                                                      \
     template int precompute_window_launch<F>(hipStream_t, const Affine<F>*, Affine<F>*, size_t, int);                      \
     template int check_on_curve_launch<F>(hipStream_t, const Affine<F>*, size_t, const F&, unsigned long long*);           \

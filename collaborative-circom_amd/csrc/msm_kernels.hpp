@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
                                                             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                             uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks, uint32_t table_stride, uint32_t cap,
                                                             typename BucketOf<F>::type* __restrict__ buckets, typename BucketOf<F>::type* __restrict__ cont,
-                                                            uint32_t* __restrict__ cont_bucket) {
+                                                            uint32_t* __restrict__ cont_bucket, uint32_t may_have_inf) {
     // table_stride != 0: entries are (window << 24 | index) into per-window precomputed tables laid out [window][table_stride]
     // cap != 0: `sorted` is the padded layout of k_msm_scatter_direct (bucket b owns slots [b*cap, b*cap + min(count, cap)));
     //           positions (pos, offsets) are still those of the compact list, so the chunking is unchanged
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
         pos++; kidx++;
         const size_t at = table_stride ? (size_t)((e >> 24) & 0x7fu) * table_stride + (e & 0xffffffu) : (size_t)(e & 0x7fffffffu);
         Affine<F> p = ld_struct(bases + at);
-        if (p.is_inf()) continue;
+        if (may_have_inf && p.is_inf()) continue;               // tables without a point at infinity (registration census) skip the test
         acc_madd(acc, p.x, p.y, (e >> 31) != 0);
     }
     if (continuation) acc_store<F>(acc, cont + q); else acc_store<F>(acc, buckets + b);
