@@ -103,6 +103,7 @@ struct cg_ctx {
     hipStream_t h2d = nullptr, d2h = nullptr;
     hipEvent_t copy_ev[COPY_TICKETS] = {}; hipEvent_t ev_copy_order = nullptr; uint32_t copy_next = 0;
     Arena arena;
+    std::vector<void*> retired;                        // outgrown arena blocks that enqueued kernels may still use
     void* gather_buf = nullptr; size_t gather_cap = 0;   // scalars gathered for compacted tables (see cg_bases::compact)
     std::map<TwKey, void*> twiddles;
     std::map<CosetKey, CosetTables> cosets;
@@ -137,10 +138,12 @@ int ensure_arena(cg_ctx* ctx, size_t bytes) {
         ctx->aux_pending = false;
     }
     if (bytes <= ctx->arena.cap) return 0;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (ctx->aux) HIPCHK(hipStreamSynchronize(ctx->aux));
-    if (ctx->sortst) HIPCHK(hipStreamSynchronize(ctx->sortst));
-    if (ctx->arena.base) HIPCHK(hipFree(ctx->arena.base));
+    // grow WITHOUT draining the streams (a host that blocks here stalls the exchange pipeline of the drivers): kernels already
+    // enqueued keep their pointers into the old block, which is retired and freed once the streams are idle
+    const bool idle = hipStreamQuery(ctx->stream) == hipSuccess && (!ctx->aux || hipStreamQuery(ctx->aux) == hipSuccess) && (!ctx->sortst || hipStreamQuery(ctx->sortst) == hipSuccess);
+    (void)hipGetLastError();                                // hipErrorNotReady from the queries is not an error
+    if (idle) { for (void* p : ctx->retired) HIPCHK(hipFree(p)); ctx->retired.clear(); }
+    if (ctx->arena.base) { if (idle) HIPCHK(hipFree(ctx->arena.base)); else ctx->retired.push_back(ctx->arena.base); }
     ctx->arena.base = nullptr; ctx->arena.cap = 0;
     size_t want = align_up(bytes + bytes / 8, 1 << 20);
     HIPCHK(hipMalloc((void**)&ctx->arena.base, want));
@@ -769,6 +772,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
     for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.h_flags) hipHostFree(t.h_flags); if (t.done) hipEventDestroy(t.done); }
     if (ctx->arena.base) hipFree(ctx->arena.base);
+    for (void* p : ctx->retired) hipFree(p);
     if (ctx->gather_buf) hipFree(ctx->gather_buf);
     for (auto& p : ctx->ev_live) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
     for (auto& p : ctx->ev_free) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
@@ -827,6 +831,12 @@ int32_t cg_host_alloc(size_t bytes, void** h_ptr) {
 int32_t cg_host_free(void* h_ptr) {
     if (h_ptr) HIPCHK(hipHostFree(h_ptr));
     return 0;
+}
+int32_t cg_host_is_pinned(const void* h_ptr) {
+    if (!h_ptr) return 0;
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, h_ptr) != hipSuccess) { (void)hipGetLastError(); return 0; }   // ordinary pageable memory is unknown to the runtime
+    return a.type == hipMemoryTypeHost ? 1 : 0;
 }
 static int32_t copy_begin(cg_ctx* ctx, bool up, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, bool after_stream, int32_t* ticket) {
     if (!ctx || !ticket || ((!dst || !src) && bytes)) return fail(CG_ERR_ARG, "null argument");

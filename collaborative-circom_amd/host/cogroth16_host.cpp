@@ -658,6 +658,14 @@ public:
     void free_vec(ShareVec& v) { for (int j = 0; j < 2; j++) if (v.c[j]) { CG(cg_dev_free(ctx, v.c[j])); v.c[j] = nullptr; } }
     ShareVec upload_vec(const Fr* a, const Fr* b, size_t n) {
         ShareVec v; v.n = n;
+        if (n >= XCHG_ASYNC_MIN && cg_host_is_pinned(a) && (!b || k() < 2 || cg_host_is_pinned(b))) {   // page-locked shares: asynchronous DMA, the stream waits
+            v.c[0] = dalloc(n * 32);
+            int32_t tk = upload_staged(v.c[0], a, n);
+            if (b && k() == 2) { v.c[1] = dalloc(n * 32); tk = upload_staged(v.c[1], b, n); }
+            if (tk >= 0) CG(cg_copy_fence(ctx, tk));
+            if (aux) CG(cg_copy_wait(ctx, tk));                                        // the second context reads the shares too
+            return v;
+        }
         v.c[0] = dalloc(n * 32); CG(cg_dev_upload(ctx, v.c[0], a, n * 32));
         if (k() == 2) { v.c[1] = dalloc(n * 32); CG(cg_dev_upload(ctx, v.c[1], b, n * 32)); }
         return v;
@@ -700,6 +708,10 @@ public:
     // host (pageable) -> device through the ring, asynchronous; returns the ticket of the last chunk
     int32_t upload_staged(void* d_dst, const Fr* src, size_t n) {
         int32_t tk = -1;
+        if (n && cg_host_is_pinned(src)) {                                             // the caller keeps this vector page-locked: DMA straight from it
+            CG(cg_dev_upload_begin(ctx, d_dst, src, n * 32, 0, &tk));
+            return tk;
+        }
         const size_t ch = xchg_chunk(n);
         for (size_t off = 0; off < n; off += ch) {
             const size_t len = std::min(ch, n - off);
@@ -716,6 +728,21 @@ public:
     // is the whole operation.
     // shorter vectors: one synchronous message (setting up rings and copy streams costs more than it hides); CGH_XCHG_ASYNC_MIN overrides (A/B runs)
     const size_t XCHG_ASYNC_MIN = getenv("CGH_XCHG_ASYNC_MIN") ? (size_t)atoll(getenv("CGH_XCHG_ASYNC_MIN")) : (size_t)1 << 19;
+    // masks of the coming mul_vec calls, uploaded ahead of time (only from page-locked randomness streams, where the copy is a plain
+    // asynchronous DMA): the product kernel then never waits for PCIe
+    struct MaskSet { void* m1; void* m2; int32_t tk; size_t n, at; };
+    std::deque<MaskSet> prefetched;
+    void prefetch_masks(int count, size_t n) {
+        if (mode != Mode::Rep3 || n < XCHG_ASYNC_MIN || !rng1 || !rng2) return;
+        size_t at = cursor;
+        for (int i = 0; i < count && at + n <= rng_len; i++, at += n) {
+            if (!cg_host_is_pinned(rng1 + at) || !cg_host_is_pinned(rng2 + at)) return;
+            MaskSet ms{dalloc(n * 32), dalloc(n * 32), -1, n, at};
+            upload_staged(ms.m1, rng1 + at, n);
+            ms.tk = upload_staged(ms.m2, rng2 + at, n);
+            prefetched.push_back(ms);
+        }
+    }
     struct Down { uint8_t* slot; int32_t tk; };
     struct PendingMul { ShareVec out; bool exchange = false; std::deque<Down> down; size_t issued = 0; };
     // start streaming chunks of the local product to the host, as many as the ring has room for
@@ -736,12 +763,19 @@ public:
         if (mode == Mode::Plain) return pm;
         if (mode == Mode::Shamir) { out = degree_reduce_vec(out); return pm; }         // shamir.rs:609-623
         if (cursor + a.n > rng_len) throw std::runtime_error("randomness stream exhausted");
-        void* m1 = dalloc(a.n * 32); void* m2 = dalloc(a.n * 32);
+        void* m1 = nullptr; void* m2 = nullptr;
+        if (!prefetched.empty() && prefetched.front().at == cursor && prefetched.front().n == a.n) {
+            const MaskSet ms = prefetched.front(); prefetched.pop_front();
+            m1 = ms.m1; m2 = ms.m2;
+            if (ms.tk >= 0) CG(cg_copy_fence(ctx, ms.tk));
+        } else {
+            m1 = dalloc(a.n * 32); m2 = dalloc(a.n * 32);
         if (a.n < XCHG_ASYNC_MIN) { CG(cg_dev_upload(ctx, m1, rng1 + cursor, a.n * 32)); CG(cg_dev_upload(ctx, m2, rng2 + cursor, a.n * 32)); }
         else {
             upload_staged(m1, rng1 + cursor, a.n);
             const int32_t tk = upload_staged(m2, rng2 + cursor, a.n);
             if (tk >= 0) CG(cg_copy_fence(ctx, tk));                                   // uploads complete in order: the last ticket covers both masks
+        }
         }
         cursor += a.n;
         CG(cg_vec_sub_dev(ctx, curve.id, m1, m1, m2, a.n));                           // masking_field_element = rand(rng1) - rand(rng2)
@@ -787,8 +821,10 @@ public:
     void shutdown() {
         for (void* p : deferred) cg_dev_free(ctx, p);
         deferred.clear();
+        for (auto& ms : prefetched) { cg_dev_free(ctx, ms.m1); cg_dev_free(ctx, ms.m2); }
+        prefetched.clear();
         release_rings(); release_pre();
-        if (aux) { cg_ctx_destroy(aux); aux = nullptr; }
+        if (aux) { if (owns_aux) cg_ctx_destroy(aux); aux = nullptr; }
     }
     void use_second_context(cg_ctx* second) { aux = second; }                           // owned from here on (shutdown destroys it)
     ~HipDriver() { shutdown(); }
@@ -879,7 +915,7 @@ public:
     // The same MSMs started early and collected later (cg_msm_dev_begin_multi / cg_msm_end): the four queries over the private witness
     // (groth16.rs:251,267,284,298) share one scalar decomposition and run on a second context (`aux`, own streams) while the witness
     // map and its exchanges occupy the first.  MSMs involve no network, so the party-to-party message order is the reference's.
-    cg_ctx* aux = nullptr;
+    cg_ctx* aux = nullptr; bool owns_aux = true;       // a session lends its contexts (owns_aux = false)
     struct PendingMsm { cg_ctx* on = nullptr; std::vector<int32_t> tickets; std::vector<int> groups; };
     PendingMsm msm_begin_multi(const std::vector<const cg_bases*>& tables, const std::vector<size_t>& offsets, const std::vector<int>& groups, size_t n, const ShareVec& s, bool on_aux) {
         PendingMsm p; p.on = on_aux && aux ? aux : ctx; p.groups = groups; p.tickets.resize(tables.size());
@@ -976,6 +1012,7 @@ public:
         // The two mul_vec exchanges (:174, :190) run under the transforms that do not depend on them: the local product is started,
         // the independent NTTs are enqueued, then the party-to-party exchange proceeds while the GPU works (values as in the reference).
         HipDriver::Marks mk("witness_map party 0", driver.party() <= 0);
+        driver.prefetch_masks(2, dom.m);                                                               // :174 and :190 draw next to each other
         mk.mark("spmv enqueue");
         auto c_pending = driver.mul_vec_begin(a, b);                                                   // :174
         mk.mark("mul_vec_begin");
@@ -2104,7 +2141,16 @@ int32_t cgh_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, con
 
 // ---- proving sessions: the zkey is read, uploaded (and optionally given per-window precomputed tables) ONCE; proofs then cost
 // what co-circom.rs:503-506 times.  A zkey is fixed for the life of a prover process (zkey.rs:48-71).
-struct cgh_session { cgh::ZKey z; cg_ctx* ctx0 = nullptr; cgh::DeviceZKey dz; int device = 0; bool second_context = false; };
+struct cgh_session {
+    cgh::ZKey z; cg_ctx* ctx0 = nullptr; cgh::DeviceZKey dz; int device = 0; bool second_context = false;
+    // contexts are kept between proofs: their scratch arenas (GBs at 2^22) are allocated once
+    std::mutex mu; std::vector<cg_ctx*> idle;
+    cg_ctx* take() {
+        { std::lock_guard<std::mutex> l(mu); if (!idle.empty()) { cg_ctx* c = idle.back(); idle.pop_back(); return c; } }
+        cg_ctx* c = nullptr; if (cg_ctx_create(device, &c)) cgh::die("cg_ctx_create"); return c;
+    }
+    void give(cg_ctx* c) { if (!c) return; cg_ctx_sync(c); std::lock_guard<std::mutex> l(mu); idle.push_back(c); }
+};
 int32_t cgh_session_open(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, void** out) {
     cgh_session* s = nullptr;
     try {
@@ -2124,6 +2170,7 @@ int32_t cgh_session_open(int32_t device, int32_t curve, const char* zkey_path, i
 int32_t cgh_session_close(void* h) {
     cgh_session* s = (cgh_session*)h;
     if (!s) return 0;
+    for (cg_ctx* c : s->idle) cg_ctx_destroy(c);
     cgh::release_zkey(s->ctx0, s->dz); cg_ctx_destroy(s->ctx0); delete s;
     return 0;
 }
@@ -2137,11 +2184,11 @@ int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uin
         const Fr* w = (const Fr*)full_witness;
         std::vector<Fr> pub(w, w + z.n_public + 1);
         session_set_public(s, pub);
-        if (cg_ctx_create(s->device, &ctx)) die("cg_ctx_create");
-        cg_ctx* second = nullptr; if (s->second_context && cg_ctx_create(s->device, &second)) die("cg_ctx_create");
+        ctx = s->take();
+        cg_ctx* second = s->second_context ? s->take() : nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         HipDriver driver(ctx, z.curve, Mode::Plain, nullptr);
-        driver.use_second_context(second);
+        driver.aux = second; driver.owns_aux = false;
         ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_public - 1);
         FieldShare rs[2]; memcpy(rs[0].c[0].v, r, 32); rs[0].c[1] = rs[0].c[0]; memcpy(rs[1].c[0].v, sc, 32); rs[1].c[1] = rs[1].c[0];
         CoGroth16 prover(driver);
@@ -2149,7 +2196,7 @@ int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uin
         if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         store_proof(p, (uint8_t*)out_proof);
         driver.free_vec(wit); driver.shutdown();
-        cg_ctx_destroy(ctx);
+        s->give(second); s->give(ctx);
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
 }
@@ -2168,17 +2215,17 @@ int32_t cgh_session_prove_rep3(void* h, const uint64_t* pub_in, const uint64_t* 
         auto party = [&](int i, Rep3Network* net, uint8_t* out) {
             cg_ctx* ctx = nullptr;
             try {
-                if (cg_ctx_create(s->device, &ctx)) die("cg_ctx_create");
-                cg_ctx* second = nullptr; if (s->second_context && cg_ctx_create(s->device, &second)) die("cg_ctx_create");
+                ctx = s->take();
+                cg_ctx* second = s->second_context ? s->take() : nullptr;
                 HipDriver driver(ctx, z.curve, Mode::Rep3, net);
-                driver.use_second_context(second);
+                driver.aux = second; driver.owns_aux = false;
                 driver.rng1 = (const Fr*)streams[i]; driver.rng2 = (const Fr*)streams[(i + 2) % 3]; driver.rng_len = stream_len;
                 ShareVec wit = driver.upload_vec((const Fr*)wit_a[i], (const Fr*)wit_b[i], n_aux);
                 CoGroth16 prover(driver);
                 Proof p = prover.prove(s->dz, pub, wit, nullptr, nullptr);
                 store_proof(p, out);
                 driver.free_vec(wit); driver.shutdown();
-                cg_ctx_destroy(ctx);
+                s->give(second); s->give(ctx);
             } catch (...) { if (ctx) cg_ctx_destroy(ctx); throw; }
         };
         InProcHub hub;

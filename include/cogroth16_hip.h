@@ -66,6 +66,9 @@ int32_t cg_dev_memset_zero(cg_ctx* ctx, void* d_dst, size_t bytes);
  *   complete in the order they were begun.  Host buffers must come from cg_host_alloc and stay valid until the copy is done. */
 int32_t cg_host_alloc(size_t bytes, void** h_ptr);
 int32_t cg_host_free(void* h_ptr);
+/* 1 if h_ptr lies in page-locked memory known to the runtime (cg_host_alloc or registered by the caller): such buffers can be the
+ * source / destination of the asynchronous copies directly, without staging */
+int32_t cg_host_is_pinned(const void* h_ptr);
 int32_t cg_dev_download_begin(cg_ctx* ctx, void* h_dst_pinned, const void* d_src, size_t bytes, int32_t* ticket);
 int32_t cg_dev_upload_begin(cg_ctx* ctx, void* d_dst, const void* h_src_pinned, size_t bytes, int32_t after_stream, int32_t* ticket);
 int32_t cg_copy_wait(cg_ctx* ctx, int32_t ticket);
