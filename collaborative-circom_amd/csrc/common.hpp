@@ -38,7 +38,11 @@ struct MsmGeom {            // derived sizes shared by the host-side planner and
     uint32_t bit_groups;    // workgroups per bit in k_msm_bitsum_partial
 };
 constexpr int MSM_SHARED_GROUPS = 16;
-inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared) {
+// resident_lanes: lanes of the accumulation kernel the chip holds at once (0 = unknown).  Its workgroups do equal work and finish
+// in lock step, so a launch of 2.16 residency rounds takes as long as 2.33 (the last 0.16 round runs one wave per SIMD, three
+// times as fast, on a sixth of the chip): when the list is long enough the chunk length is chosen so that the chunks fill a whole
+// number of rounds (2^22 points, 13 windows: 139 entries per lane, 2 rounds, instead of 128; measured 4.70 -> 4.51 ms per launch).
+inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_lanes = 0) {
     MsmGeom g;
     g.nb = 1u << (c - 1);
     g.nsets = shared ? 1 : nwin;
@@ -56,6 +60,11 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared) {
     static const size_t chunk_max = [] { const char* e = getenv("CG_MSM_CHUNK"); return e ? (size_t)atoi(e) : (size_t)128; }();   // tuning knob
     static const size_t chunk_min = [] { const char* e = getenv("CG_MSM_CHUNK_MIN"); return e ? (size_t)atoi(e) : (size_t)16; }();  // tuning knob (8 -> 16: 2^17-constraint step 7.3 -> 5.8 ms: half the continuation pieces)
     g.chunk_len = (uint32_t)std::min<size_t>(chunk_max, std::max<size_t>(chunk_min, entries / (256 * 1024)));
+    static const bool no_rounds = getenv("CG_MSM_NO_ROUNDS") != nullptr;                  // tuning knob
+    if (resident_lanes && !no_rounds && entries >= resident_lanes * chunk_max) {
+        const size_t rounds = std::max<size_t>(1, (entries + resident_lanes * chunk_max / 2) / (resident_lanes * chunk_max));
+        g.chunk_len = (uint32_t)((entries + rounds * resident_lanes - 1) / (rounds * resident_lanes));
+    }
     g.nchunks = (uint32_t)std::max<size_t>(1, (entries + g.chunk_len - 1) / g.chunk_len);
     return g;
 }

@@ -39,6 +39,26 @@ struct L29 {
         if (SHIFT) r.l[8] = (int32_t)(a.v[7] >> (29 * 8 - SHIFT - 32 * 7));   // top limb keeps all remaining bits
         return r;
     }
+    // floor(2^285 / p) (slightly under): quotient estimator of unpack_small.  p's top 64 bits give it to a relative 2^-62.
+    static constexpr uint32_t quot_c() {
+        unsigned __int128 top = ((unsigned __int128)P::P[F::N - 1] << 32) | P::P[F::N - 2];      // p >> (32 N - 64)
+        return (uint32_t)((((unsigned __int128)1) << (285 - (32 * F::N - 64))) / (top + 1));
+    }
+    // The representative of 32*a (mod p) in [-p, p), normalised: a small accumulator coordinate straight from a table record
+    // (a < p in the ABI's 2^256 Montgomery form), without a multiplication.  32a = x8 2^232 + low < 32p; k = floor(x8 c / 2^53)
+    // with c = floor(2^285 / p) underestimates floor(32a / p) by at most one, so 32a - (k + 1) p lies in [-p, p).
+    __device__ __forceinline__ static L29 unpack_small(const F& a) {
+        static_assert(F::N == 8, "");
+        const L29 x = unpack<5>(a);
+        const int32_t k1 = (int32_t)(__umulhi((uint32_t)x.l[8], quot_c()) >> 21) + 1;           // <= 33
+        L29 r; int64_t c = 0;
+        _Pragma("unroll") for (int j = 0; j < 9; j++) {
+            const int64_t t = (int64_t)x.l[j] - (int64_t)k1 * pl(j) + c;
+            r.l[j] = j < 8 ? (int32_t)((uint32_t)t & MASK) : (int32_t)t;
+            c = t >> 29;
+        }
+        return r;
+    }
     __device__ __forceinline__ L29 operator+(const L29& b) const { L29 r; _Pragma("unroll") for (int k = 0; k < 9; k++) r.l[k] = l[k] + b.l[k]; return r; }
     __device__ __forceinline__ L29 operator-(const L29& b) const { L29 r; _Pragma("unroll") for (int k = 0; k < 9; k++) r.l[k] = l[k] - b.l[k]; return r; }
     __device__ __forceinline__ L29 neg() const { L29 r; _Pragma("unroll") for (int k = 0; k < 9; k++) r.l[k] = -l[k]; return r; }
@@ -130,6 +150,14 @@ struct L29 {
     __device__ __forceinline__ static XYZZ<F> dbl_affine(const F& x, const F& y) { return xyzz_dbl_affine(x, y); }
     // small representative (0.5p .. 1.6p) of 1 in the 2^261 domain: (32 R1) * (32 R1) / 2^261 = 2^261 (mod p), R1 = 2^256 mod p
     __device__ __forceinline__ static L29 one() { const L29 o = unpack<5>(F::one()); return mul(o, o); }
+    // the same residue in [0, p) without a product (constant-folded: F::one() is a compile-time constant)
+    __device__ __forceinline__ static L29 one_small() {
+        L29 o = unpack_small(F::one());
+        L29 pp; _Pragma("unroll") for (int k = 0; k < 9; k++) pp.l[k] = pl(k);
+        const L29 t = (o + pp).norm();
+        if (o.l[8] < 0) o = t;
+        return o;
+    }
     // back to a canonical field element in the ABI's 2^256 Montgomery domain; |value| < 8p
     __device__ __forceinline__ static F to_fp(const L29& x) {
         L29 c; _Pragma("unroll") for (int k = 0; k < 9; k++) c.l[k] = 0;

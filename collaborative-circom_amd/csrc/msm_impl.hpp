@@ -12,9 +12,13 @@ namespace cg {
 template <class B> constexpr int bitsum_items() { return BITSUM_ITEMS; }   // 2 for G2 measured slower (four times the LDS trees): 2^18 step 8.5 -> 10.1 ms
 template <class B> uint32_t bitsum_groups(uint32_t nb) { return std::max<uint32_t>(1, (nb / 2 + 256 * bitsum_items<B>() - 1) / (256 * bitsum_items<B>())); }
 
+// lanes of the accumulation kernel resident at once on a 256-CU gfx950: G1 (32-byte coordinates, 167 VGPRs) runs 3 workgroups of 256
+// per CU in lock step; the G2 workgroups (2 waves per SIMD, one of them favoured by the arbiter) do not, so no rounding there (0)
+template <class F> constexpr size_t acc_resident_lanes() { return sizeof(F) == 32 ? (size_t)256 * 3 * 256 : 0; }
+
 template <class F>
 size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared) {
-    MsmGeom g = msm_geom(n, c, nwin, shared);
+    MsmGeom g = msm_geom(n, c, nwin, shared, acc_resident_lanes<F>());
     typedef typename BucketOf<F>::type B;
     g.bit_groups = bitsum_groups<B>(g.nb);
     return align_up(g.nbuckets * sizeof(B)) + align_up((size_t)g.nchunks * sizeof(B)) + align_up((size_t)g.nchunks * 4) +
@@ -30,7 +34,7 @@ template <class F>
 int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride,
                           const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs, bool may_have_inf) {
     const bool shared = table_stride != 0;
-    MsmGeom g = msm_geom(n, c, nwin, shared);
+    MsmGeom g = msm_geom(n, c, nwin, shared, acc_resident_lanes<F>());
     size_t off = 0;
     auto take = [&](size_t bytes) { void* p = scratch + off; off += align_up(bytes); return p; };
     typedef typename BucketOf<F>::type B;                 // limb-form points for the lazy pipelines, saturated XYZZ otherwise
@@ -53,6 +57,40 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     //   64 B  (BN254 Fq2)       lazy 29-bit limbs, accumulator in LDS (72 dwords per lane), 128-lane workgroups
     //   48 B  (BLS12-381 Fq)    saturated limbs in VGPRs          96 B (BLS12-381 Fq2)  saturated limbs, accumulator in LDS
     int rc_acc;
+    // Compact lists (cap == 0) of the lazy-limb fields run the software-pipelined kernel.  CG_ACC_VARIANT (tuning knob, read per
+    // call; scripts/acc_variants.py): 0 = k_msm_accumulate, 1 = pipelined + L2 warm-up of the next record, 2 = pipelined + next
+    // record in registers (one wave per SIMD less), 3 / unset = pipelined index and boundary reads only (the default: the record
+    // prefetches measured no faster, the launch is bound by vector issue and not by the latency of the gather)
+    const char* var_s = getenv("CG_ACC_VARIANT");
+    const int variant = var_s ? atoi(var_s) : 3;
+    auto launch_pf = [&](auto kern, int T, size_t lds) -> int {
+        if (lds > 0) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((g.nchunks + T - 1) / T), dim3(T), lds, st, d_bases, sorted, offsets, counts,
+                           (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, (uint32_t)table_stride, buckets, cont, cont_bucket, may_have_inf ? 1u : 0u);
+        return 0;
+    };
+    if (variant && cap == 0 && sizeof(F) == 32) {
+        if constexpr (sizeof(F) == 32) {
+            if (variant == 1) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 1>, 256, 256 * 4);
+            else if (variant == 2) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 2, 2>, 256, 0);
+#ifdef CG_ACC_DEBUG_VARIANTS   // timing experiments with wrong results (scripts/acc_variants.py): where the launch spends its time
+            else if (variant == 4) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0, 1>, 256, 0);
+            else if (variant == 5) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0, 2>, 256, 0);
+            else if (variant == 6) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0, 3>, 256, 0);
+            else if (variant == 7) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0, 7>, 256, 0);
+            else if (variant == 8) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0, 4>, 256, 0);
+            else if (variant == 9) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0, 8>, 256, 0);
+#endif
+            else rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0>, 256, 0);
+        }
+    } else if (variant && cap == 0 && sizeof(F) == 64) {
+        if constexpr (sizeof(F) == 64) {
+            const size_t lds = (size_t)128 * 4 * sizeof(typename LazyOf<F>::type);
+            if (variant == 1) rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 1>, 128, lds + 128 * 4);
+            else if (variant == 2) rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 2>, 128, lds);
+            else rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 0>, 128, lds);
+        }
+    } else
     if constexpr (sizeof(F) == 32) rc_acc = launch_acc(k_msm_accumulate<F, RegAcc29<F>, 256>, 256, 0);
     else if constexpr (sizeof(F) == 64) rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc29<F>, 128>, 128, (size_t)128 * 4 * sizeof(typename LazyOf<F>::type));
     else if constexpr (sizeof(F) > 64) rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc<F>, 128>, 128, (size_t)128 * sizeof(XYZZ<F>));

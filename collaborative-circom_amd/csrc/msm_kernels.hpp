@@ -58,6 +58,7 @@ template <class F>
 struct LdsAcc {
     typedef uint4 LdsT;
     static constexpr bool USES_LDS = true;
+    static constexpr size_t LDS_BYTES_PER_LANE = sizeof(XYZZ<F>);
     static constexpr int Q = sizeof(F) / 16;          // 16-byte quads per coordinate
     uint4* base; int stride;                           // quad e of this lane at base[e * stride]
     bool inf;
@@ -113,6 +114,8 @@ struct L29x2 {
     typedef L29<F> L;
     L c0, c1;
     template <int SHIFT> __device__ __forceinline__ static L29x2 unpack(const F2& a) { return {L::template unpack<SHIFT>(a.c0), L::template unpack<SHIFT>(a.c1)}; }
+    __device__ __forceinline__ static L29x2 unpack_small(const F2& a) { return {L::unpack_small(a.c0), L::unpack_small(a.c1)}; }
+    __device__ __forceinline__ static L29x2 one_small() { L z; _Pragma("unroll") for (int k = 0; k < 9; k++) z.l[k] = 0; return {L::one_small(), z}; }
     __device__ __forceinline__ L29x2 operator+(const L29x2& b) const { return {c0 + b.c0, c1 + b.c1}; }
     __device__ __forceinline__ L29x2 operator-(const L29x2& b) const { return {c0 - b.c0, c1 - b.c1}; }
     __device__ __forceinline__ L29x2 neg() const { return {c0.neg(), c1.neg()}; }
@@ -160,6 +163,7 @@ template <class F>
 struct RegAcc29 {
     typedef uint32_t LdsT;
     typedef typename LazyOf<F>::type L;
+    static constexpr bool USES_LDS = false;
     L c[4];
     bool inf;
     __device__ __forceinline__ void init(uint32_t*, int, int) { inf = true; }
@@ -170,6 +174,8 @@ template <class F>
 struct LdsAcc29 {
     typedef uint32_t LdsT;
     typedef typename LazyOf<F>::type L;
+    static constexpr bool USES_LDS = true;
+    static constexpr size_t LDS_BYTES_PER_LANE = 4 * sizeof(L);
     static constexpr int W = sizeof(L) / 4;               // dwords per coordinate
     uint32_t* base; int stride; bool inf;
     __device__ __forceinline__ void init(uint32_t* lds, int tid, int nthreads) { base = lds + tid; stride = nthreads; inf = true; }
@@ -260,9 +266,12 @@ __device__ __forceinline__ void acc_madd_lazy(Acc& acc, const F& x2f, const F& y
     L x2 = L::template unpack<5>(x2f), y2 = L::template unpack<5>(y2f);     // 32*x2, 32*y2: the 2^261 domain
     if (negate) y2 = y2.neg();
     if (acc.inf) {
-        // bring the coordinates into the small range first: (32 a) * one / 2^261 = 32 a (mod p), magnitude < 1.5p
-        const L one = L::one();
-        acc.set(0, L::mul(x2, one)); acc.set(1, L::mul(y2, one)); acc.set(2, one); acc.set(3, one); acc.inf = false;
+        // First point of a bucket: some lane of a wave is here on nearly every second iteration (64 lanes, ~100 entries per
+        // bucket), and the whole wave waits for it, so this path must be short: the coordinates are brought into the small range
+        // [-p, p) by subtracting a multiple of p (quotient estimated from the top limb) instead of multiplying by one.
+        const L one = L::one_small();
+        const L ys = L::unpack_small(y2f);
+        acc.set(0, L::unpack_small(x2f)); acc.set(1, negate ? ys.neg().norm() : ys); acc.set(2, one); acc.set(3, one); acc.inf = false;
         return;
     }
     L P = L::mul(x2, acc.get(2)) - acc.get(0);
@@ -353,6 +362,84 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
         Affine<F> p = ld_struct(bases + at);
         if (may_have_inf && p.is_inf()) continue;               // tables without a point at infinity (registration census) skip the test
         acc_madd(acc, p.x, p.y, (e >> 31) != 0);
+    }
+    if (continuation) acc_store<F>(acc, cont + q); else acc_store<F>(acc, buckets + b);
+}
+
+// Software-pipelined form of the same kernel for the compact list (cap == 0), written around where a wave of the kernel above
+// spends the cycles it does not issue in (SQ_WAIT_ANY 19 % of wave time at 3 waves per SIMD): three dependent memory round trips
+// per entry — sorted[pos] (L2), then the 64/128-byte gather bases[...] (HBM, random), and on nearly every second iteration of a
+// WAVE (some lane of 64 crosses a bucket boundary) counts[b] / offsets[b] of the next bucket.  Here
+//   * the sorted entries are read two iterations ahead (e0 current, e1 next, e2 in flight),
+//   * the end of the NEXT bucket (offsets[b + 2]) is read when a bucket is entered, so a boundary costs no round trip,
+//   * PF == 1: the record of the next entry is pulled into L2 while the current addition runs: one global_load_lds_dword per
+//     64 bytes into a junk LDS slot (no VGPR destination, nothing to wait for), issued after the current record has arrived;
+//   * PF == 2: the next record itself is loaded into registers before the current addition (for a 2-wave-per-SIMD build).
+template <class Acc, int THREADS> __host__ __device__ constexpr size_t acc_lds_bytes() {
+    if constexpr (Acc::USES_LDS) return (size_t)THREADS * Acc::LDS_BYTES_PER_LANE; else return 0;
+}
+template <class F, class Acc, int THREADS, int MINW, int PF, int DBG = 0>
+__global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate_pf(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                                     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                                     uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks, uint32_t table_stride,
+                                                                     typename BucketOf<F>::type* __restrict__ buckets, typename BucketOf<F>::type* __restrict__ cont,
+                                                                     uint32_t* __restrict__ cont_bucket, uint32_t may_have_inf) {
+    extern __shared__ uint4 acc_lds[];        // [accumulators (LDS policies)] [PF == 1: THREADS junk dwords, see PF_JUNK_OFFSET]
+    const uint32_t q = blockIdx.x * THREADS + threadIdx.x;
+    if (q >= nchunks) return;
+    const uint32_t total = offsets[nbuckets - 1] + counts[nbuckets - 1];
+    uint32_t pos = q * chunk_len;
+    if (pos >= total) { cont_bucket[q] = 0xffffffffu; return; }
+    const uint32_t end = min(pos + chunk_len, total);
+    uint32_t lo = 0, hi = nbuckets - 1;
+    while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (offsets[mid] <= pos) lo = mid; else hi = mid - 1; }
+    uint32_t b = lo;
+    auto end_of = [&](uint32_t bb) -> uint32_t { return bb + 1 < nbuckets ? offsets[bb + 1] : total; };   // exclusive scan: end of bucket bb
+    uint32_t bend = end_of(b), bend_next = end_of(b + 1);
+    bool continuation = offsets[b] != pos;
+    cont_bucket[q] = continuation ? b : 0xffffffffu;
+    Acc acc;
+    acc.init(reinterpret_cast<typename Acc::LdsT*>(acc_lds), threadIdx.x, THREADS);
+    // DBG (timing experiments only, results are wrong): 1 = cache-resident gather addresses, 2 = bucket boundaries ignored
+    auto at_of = [&](uint32_t e) -> size_t {
+        if constexpr (DBG & 1) return (size_t)(threadIdx.x + 256u * (e & 63u));
+        if constexpr (DBG & 8) return (size_t)((e * 2654435761u) >> 12);                   // random over 2^20 records (64 MB: few pages, no cache reuse)
+        return table_stride ? (size_t)((e >> 24) & 0x7fu) * table_stride + (e & 0xffffffu) : (size_t)(e & 0x7fffffffu);
+    };
+    auto entry = [&](uint32_t at) -> uint32_t { if constexpr (DBG & 4) return at * 2654435761u; else return sorted[at]; };   // DBG 4: no index loads
+    uint32_t e0 = entry(pos);
+    uint32_t e1 = pos + 1 < end ? entry(pos + 1) : e0;
+    Affine<F> pn;
+    Affine<F> psyn;                                                                  // DBG 4: operands from registers, no gather
+    if constexpr (DBG & 4) { uint32_t* w = reinterpret_cast<uint32_t*>(&psyn); for (int i = 0; i < (int)(sizeof(psyn) / 4); i++) w[i] = (threadIdx.x * 2654435761u + i * 40503u) & 0x0fffffffu; }
+    if constexpr (PF == 2) pn = ld_struct(bases + at_of(e0));
+    while (pos < end) {
+        if (!(DBG & 2) && pos == bend) {                     // finished bucket b inside this chunk
+            if (continuation) { acc_store<F>(acc, cont + q); continuation = false; } else acc_store<F>(acc, buckets + b);
+            b++; bend = bend_next; bend_next = end_of(b + 1);
+            while (bend == pos) { b++; bend = bend_next; bend_next = end_of(b + 1); }      // empty buckets (rare)
+        }
+        // load order matters: vmcnt counts in issue order, so the index read two iterations ahead is issued AFTER the record
+        // loads — the wait for the current record then leaves it (and, PF == 2, the next record) in flight
+        Affine<F> p;
+        if constexpr (DBG & 4) { uint32_t* w = reinterpret_cast<uint32_t*>(&psyn); w[0] += 0x9e3779b9u; w[9] ^= w[0]; p = psyn; }
+        else if constexpr (PF == 2) { p = pn; pn = ld_struct(bases + at_of(e1)); }
+        else p = ld_struct(bases + at_of(e0));
+        const uint32_t e2 = pos + 2 < end ? entry(pos + 2) : e1;
+        if constexpr (PF == 1) {
+            // after the last quad of p has arrived (the empty asm makes the address depend on it), so that the wait for p is not
+            // extended to this load
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(&p);
+            uintptr_t a = reinterpret_cast<uintptr_t>(bases + at_of(e1));
+            asm volatile("" : "+v"(a) : "v"(w[0]), "v"(w[sizeof(Affine<F>) / 4 - 1]), "v"(w[sizeof(Affine<F>) / 8]), "v"(w[sizeof(Affine<F>) / 8 - 1]));
+            _Pragma("unroll") for (int k = 0; k < (int)(sizeof(Affine<F>) / 32); k++)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(a) + 8 * k,
+                                                 (__attribute__((address_space(3))) uint32_t*)(reinterpret_cast<char*>(acc_lds) + acc_lds_bytes<Acc, THREADS>()), 4, 0, 0);
+        }
+        const bool neg = (e0 >> 31) != 0;
+        pos++; e0 = e1; e1 = e2;
+        if (may_have_inf && p.is_inf()) continue;
+        acc_madd(acc, p.x, p.y, neg);
     }
     if (continuation) acc_store<F>(acc, cont + q); else acc_store<F>(acc, buckets + b);
 }
