@@ -35,6 +35,40 @@ __global__ void __launch_bounds__(256, 3) k_l29_chain(uint32_t* out, uint32_t se
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// the same product, product scanning with hand-placed multiply-adds: the carry of column k-1 is the addend of the first
+// multiply-add of column k (the compiler re-associates the sum and spends a 64-bit addition on it)
+__device__ __forceinline__ int64_t madv(int32_t a, int32_t b, int64_t c) { int64_t d; uint64_t cy; asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ int64_t mads(int32_t a, int32_t b, int64_t c) { int64_t d; uint64_t cy; asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "s"(b), "v"(c)); return d; }
+template <class F>
+__device__ __forceinline__ L29<F> mul_cols(const L29<F>& a, const L29<F>& b) {
+    typedef L29<F> L; typedef typename F::Params P;
+    int32_t m[9];
+    int64_t T = 0;
+    _Pragma("unroll") for (int k = 0; k < 9; k++) {
+        _Pragma("unroll") for (int i = 0; i <= k; i++) T = madv(a.l[i], b.l[k - i], T);
+        _Pragma("unroll") for (int i = 0; i < k; i++) T = mads(m[i], L::pl(k - i), T);
+        m[k] = (int32_t)(((uint32_t)T * (P::INV & L::MASK)) & L::MASK);
+        T = mads(m[k], L::pl(0), T);
+        T >>= 29;
+    }
+    L r;
+    _Pragma("unroll") for (int k = 9; k < 17; k++) {
+        _Pragma("unroll") for (int i = k - 8; i < 9; i++) { T = madv(a.l[i], b.l[k - i], T); T = mads(m[i], L::pl(k - i), T); }
+        r.l[k - 9] = (int32_t)((uint32_t)T & L::MASK);
+        T >>= 29;
+    }
+    r.l[8] = (int32_t)T;
+    return r;
+}
+__global__ void __launch_bounds__(256, 3) k_l29_chain_cols(uint32_t* out, uint32_t seed, int iters) {
+    typedef L29<Bn254Fq> L;
+    L a, m;
+    for (int k = 0; k < 9; k++) { a.l[k] = (int32_t)((threadIdx.x * 2654435761u + k * 40503u + seed) & 0x0fffffffu); m.l[k] = (int32_t)((seed * 7 + k * 977u) & 0x0fffffffu); }
+    for (int it = 0; it < iters; it++) a = mul_cols(a, m);
+    uint32_t s = 0; for (int k = 0; k < 9; k++) s ^= (uint32_t)a.l[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // 52-bit-limb floating-point product, instruction mix of one Montgomery multiplication: 25 limb pairs for a*b and 25 for q*p,
 // each pair = hi = fma_rz(x, y, 2^104); lo = fma_rz(x, y, (2^104 + 2^52) - hi); two 64-bit integer additions of the raw bit
 // patterns into column accumulators; per round one q = low 52 bits of (column * p') (2 fma + 1 add + bit fiddling) and one carry.
@@ -114,15 +148,16 @@ int main() {
         }
     }
     printf("== Montgomery product chains, 2048 workgroups x 256 lanes, 3 waves per SIMD\n");
-    for (int which = 0; which < 2; which++) {
+    for (int which = 0; which < 3; which++) {
         const int iters = 4096;
         for (int rep = 0; rep < 2; rep++) {
             CHK(hipEventRecord(e0));
             if (which == 0) hipLaunchKernelGGL(k_l29_chain, dim3(2048), dim3(256), 0, 0, d, 11u, iters);
+            else if (which == 2) hipLaunchKernelGGL(k_l29_chain_cols, dim3(2048), dim3(256), 0, 0, d, 11u, iters);
             else hipLaunchKernelGGL(k_dfma_chain, dim3(2048), dim3(256), 0, 0, d, 11u, iters);
             CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
             float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
-            printf("%-34s rep %d: %8.3f ms  %7.1f G products/s\n", which == 0 ? "lazy 29-bit integer (9x9 limbs)" : "52-bit floating point (5x5 limbs)", rep, ms, 2048.0 * 256 * iters / (ms * 1e-3) / 1e9);
+            printf("%-34s rep %d: %8.3f ms  %7.1f G products/s\n", which == 0 ? "lazy 29-bit integer (9x9 limbs)" : which == 2 ? "lazy 29-bit, product scanning (asm)" : "52-bit floating point (5x5 limbs)", rep, ms, 2048.0 * 256 * iters / (ms * 1e-3) / 1e9);
         }
     }
     printf("== mixed additions on lazy limbs, operands in registers (compute floor of k_msm_accumulate)\n");
