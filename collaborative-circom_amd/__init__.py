@@ -251,6 +251,12 @@ class Context:
         _chk(load().cg_bases_synth_multiples(self.h, curve, group, C.c_uint64(first), C.c_size_t(n), C.byref(h)))
         return Bases(self, curve, group, h, n)
 
+    def bases_from_scalars(self, curve, group, d_scalars, n):
+        """device-side table [s_i * G] for n device-resident Montgomery scalars (setup tooling: synthetic CRS)"""
+        h = C.c_void_p()
+        _chk(load().cg_bases_from_scalars(self.h, curve, group, _dp(d_scalars), C.c_size_t(n), C.byref(h)))
+        return Bases(self, curve, group, h, n)
+
     def bases_download(self, bases, offset, n):
         out = np.zeros((n, point_words(bases.curve, bases.group, 2)), dtype=np.uint64)
         _chk(load().cg_bases_download(self.h, bases.h, C.c_size_t(offset), C.c_size_t(n), _hp(out)))
@@ -491,13 +497,25 @@ def prove_shamir(curve, zkey_path, n, t, pub, wits, streams, device=0, want_h=Fa
     return (out, h) if want_h else out
 
 
+def host_synth_circuit(curve, log_m, seed, zkey_path, wtns_path, device=0):
+    """synthetic satisfiable circuit of 2^log_m - 2 constraints with a valid Groth16 CRS (toxic waste from `seed`, point tables by
+    fixed-base batch multiplication on the GPU), written as snarkjs-format .zkey + .wtns files (bench / test tooling)"""
+    _hchk(load_host().cgh_synth_circuit(int(device), curve, int(log_m), C.c_uint64(seed), zkey_path.encode(), wtns_path.encode()))
+
+
+def host_set_zkey_validation(on):
+    """the prove entry points and session_open validate every zkey point on the GPU by default (the reference's parser does);
+    callers that validated the file before can switch it off"""
+    _hchk(load_host().cgh_set_zkey_validation(int(bool(on))))
+
+
 class ProvingSession:
     """zkey read, uploaded and (optionally) given per-window precomputed tables once; proofs then cost what co-circom.rs:503-506 times"""
 
-    def __init__(self, curve, zkey_path, precompute=True, device=0):
+    def __init__(self, curve, zkey_path, precompute=True, device=0, validate=True):
         self.curve, self.info = curve, host_zkey_info(curve, zkey_path)
         h = C.c_void_p()
-        _hchk(load_host().cgh_session_open(int(device), curve, zkey_path.encode(), -1 if precompute is True else int(precompute), C.byref(h)))
+        _hchk(load_host().cgh_session_open_ex(int(device), curve, zkey_path.encode(), -1 if precompute is True else int(precompute), C.c_uint32(0 if validate else 1), C.byref(h)))
         self.h = h
 
     def close(self):

@@ -36,6 +36,7 @@ template <class F> int pack_bases_launch(hipStream_t st, const uint8_t* d_raw, s
 template <class F> int gather_points_launch(hipStream_t st, Affine<F>* d_dst, const Affine<F>* d_src, const uint32_t* d_idx, size_t n);
 template <class Fr> int launch_vec_gather_idx(hipStream_t st, Fr* out, const Fr* in, const uint32_t* idx, size_t n, uint32_t base);
 template <class F> int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi, int log_t, size_t n, Affine<F>* d_out);
+template <class F, class Fr> int fixed_base_mul_launch(hipStream_t st, const Affine<F>& g, const Fr* d_scalars, size_t n, Affine<F>* d_tab, Affine<F>* d_out);
 template <class Fr> int launch_vec_binary(hipStream_t st, int op, Fr* out, const Fr* a, const Fr* b, size_t n);
 template <class Fr> int launch_rep3_mul_local(hipStream_t st, Fr* out, const Fr* aa, const Fr* ab, const Fr* ba, const Fr* bb, const Fr* mask, size_t n);
 template <class Fr> int launch_distribute_powers(hipStream_t st, Fr* v, size_t n, const Fr* lo, const Fr* hi, int log_lo);
@@ -1047,6 +1048,27 @@ int32_t cg_bases_synth_multiples(cg_ctx* ctx, int32_t curve, int32_t group, uint
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipFree(d_lo)); HIPCHK(hipFree(d_hi));
+        *out = b;
+        return 0;
+    });
+}
+int32_t cg_bases_from_scalars(cg_ctx* ctx, int32_t curve, int32_t group, const void* d_scalars, size_t n, cg_bases** out) {
+    if (!ctx || !out || (!d_scalars && n)) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_group(curve, group, [&](auto ftag, auto frtag) -> int {
+        typedef decltype(ftag) F; typedef decltype(frtag) Fr;
+        const uint32_t* src = curve == CG_BN254 ? (group == CG_G1 ? Bn254G1_GEN : Bn254G2_GEN) : (group == CG_G1 ? Bls381G1_GEN : Bls381G2_GEN);
+        Affine<F> ga; memcpy(&ga, src, sizeof ga);
+        const int nwin = (Fr::Params::BITS + 7) / 8;
+        Affine<F>* d_tab = nullptr;
+        HIPCHK(hipMalloc((void**)&d_tab, (size_t)nwin * 255 * sizeof(Affine<F>)));
+        cg_bases* b = new cg_bases{ctx->device, curve, group, n, sizeof(Affine<F>), nullptr};
+        hipError_t e = hipMalloc(&b->d_pts, std::max<size_t>(n * sizeof(Affine<F>), 16));
+        if (e != hipSuccess) { hipFree(d_tab); delete b; return fail(CG_ERR_OOM, "cg_bases_from_scalars: out of device memory"); }
+        int rc = fixed_base_mul_launch<F, Fr>(ctx->stream, ga, (const Fr*)d_scalars, n, d_tab, (Affine<F>*)b->d_pts);
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        hipFree(d_tab);
+        if (rc || e2 != hipSuccess) { hipFree(b->d_pts); delete b; return rc ? rc : fail(CG_ERR_HIP, std::string("cg_bases_from_scalars: ") + hipGetErrorString(e2)); }
         *out = b;
         return 0;
     });

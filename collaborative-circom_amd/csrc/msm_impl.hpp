@@ -171,6 +171,15 @@ int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi
     return 0;
 }
 
+template <class F, class Fr>
+int fixed_base_mul_launch(hipStream_t st, const Affine<F>& g, const Fr* d_scalars, size_t n, Affine<F>* d_tab, Affine<F>* d_out) {
+    const int nwin = (Fr::Params::BITS + 7) / 8;
+    hipLaunchKernelGGL((k_fixed_base_table<F>), dim3((nwin * 255 + 255) / 256), dim3(256), 0, st, g, nwin, d_tab);
+    if (n) hipLaunchKernelGGL((k_fixed_base_mul<F, Fr>), dim3((unsigned)std::min<size_t>((n + 127) / 128, 16384)), dim3(128), 0, st, d_scalars, n, nwin, d_tab, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace cg
 
 #define CG_INSTANTIATE_MSM(F, Fr)                                                                                          \
@@ -183,4 +192,5 @@ int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi
     template int pack_bases_launch<F>(hipStream_t, const uint8_t*, size_t, size_t, long, Affine<F>*);                      \
     template int gather_points_launch<F>(hipStream_t, Affine<F>*, const Affine<F>*, const uint32_t*, size_t);              \
     template int synth_points_launch<F>(hipStream_t, const XYZZ<F>*, const XYZZ<F>*, int, size_t, Affine<F>*);             \
+    template int fixed_base_mul_launch<F, Fr>(hipStream_t, const Affine<F>&, const Fr*, size_t, Affine<F>*, Affine<F>*);   \
     }

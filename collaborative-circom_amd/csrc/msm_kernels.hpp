@@ -666,4 +666,29 @@ __global__ void __launch_bounds__(256) k_synth_points(const XYZZ<F>* __restrict_
     }
 }
 
+// Fixed-base batch multiplication (setup tooling, not on the prover path): out[i] = s_i * G for Montgomery scalars s_i, by 8-bit
+// windows over the table tab[w][d - 1] = d * 2^(8w) * G (affine; 32 x 255 records, cache resident).  Used to build a synthetic but
+// VALID Groth16 CRS on the device (the [u_i(tau)]_1, [v_i(tau)]_2, ... queries of a zkey are scalar multiples of the generators).
+template <class F>
+__global__ void __launch_bounds__(256) k_fixed_base_table(Affine<F> g, int nwin, Affine<F>* __restrict__ tab) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nwin * 255) return;
+    const int w = t / 255, d = t % 255 + 1;
+    uint32_t k[9]; for (int i = 0; i < 9; i++) k[i] = 0;
+    k[w / 4] = (uint32_t)d << (8 * (w % 4));                     // d * 2^(8w)
+    st_struct(tab + t, xyzz_to_affine(xyzz_scalar_mul(XYZZ<F>::from_affine(g), k, 9)));
+}
+template <class F, class Fr>
+__global__ void __launch_bounds__(128) k_fixed_base_mul(const Fr* __restrict__ scalars, size_t n, int nwin, const Affine<F>* __restrict__ tab, Affine<F>* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const Fr s = ld_fp(scalars + i).from_mont();
+        XYZZ<F> acc = XYZZ<F>::infinity();
+        for (int w = 0; w < nwin; w++) {
+            const uint32_t d = (s.v[w / 4] >> (8 * (w % 4))) & 0xffu;
+            if (d) { const Affine<F> p = ld_struct(tab + (size_t)w * 255 + (d - 1)); acc = xyzz_madd(acc, p.x, p.y); }
+        }
+        st_struct(out + i, xyzz_to_affine(acc));
+    }
+}
+
 }  // namespace cg

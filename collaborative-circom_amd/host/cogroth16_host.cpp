@@ -20,10 +20,12 @@
 #include <deque>
 #include <chrono>
 #include <fcntl.h>
+#include <functional>
 #include <memory>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -73,7 +75,7 @@ static Point pt_generator(const Curve& c, int g) { Point p{Bytes(c.jac(g)), g}; 
 // ---- file formats ----------------------------------------------------------------------------------------------------
 struct Cursor {
     const uint8_t* p; size_t n, off = 0;
-    void need(size_t k) const { if (off + k > n) throw std::runtime_error("unexpected end of section"); }
+    void need(size_t k) const { if (off > n || k > n - off) throw std::runtime_error("unexpected end of section"); }   // no wrap-around for a 64-bit length read from the file
     uint32_t u32() { need(4); uint32_t x; memcpy(&x, p + off, 4); off += 4; return x; }
     uint64_t u64() { need(8); uint64_t x; memcpy(&x, p + off, 8); off += 8; return x; }
     void bytes(void* d, size_t k) { need(k); memcpy(d, p + off, k); off += k; }
@@ -146,6 +148,7 @@ static ZKey read_zkey(int curve_id, const std::string& path, bool header_only = 
         if (memcmp(r, MOD_R[curve_id], 32)) throw std::runtime_error("invalid scalar prime in header");
         z.n_vars = h.u32(); z.n_public = h.u32(); z.domain_size = h.u32();
         if (!z.domain_size || (z.domain_size & (z.domain_size - 1))) throw std::runtime_error("domain size must be a power of two");
+        if (z.n_vars <= z.n_public) throw std::runtime_error("invalid data: n_vars must exceed n_public");
         while (((size_t)1 << z.pow) < z.domain_size) z.pow++;
         auto g = [&](int grp) { Bytes b(c.aff(grp)); h.bytes(b.data(), b.size()); return b; };
         z.alpha_g1 = g(CG_G1); z.beta_g1 = g(CG_G1); z.beta_g2 = g(CG_G2); z.gamma_g2 = g(CG_G2); z.delta_g1 = g(CG_G1); z.delta_g2 = g(CG_G2);
@@ -163,6 +166,7 @@ static ZKey read_zkey(int curve_id, const std::string& path, bool header_only = 
         auto word = [&](size_t i, int k) { uint32_t v; memcpy(&v, rec + i * 44 + 4 * k, 4); return v; };
         uint32_t max_row = 0;
         for (size_t i = 0; i < ncoef; i++) { if (word(i, 0) > 1) throw std::runtime_error("bad matrix id"); max_row = std::max(max_row, word(i, 1)); }
+        if (ncoef == 0 || max_row < z.n_public) throw std::runtime_error("invalid data: coefficient section has no rows beyond the public inputs");
         z.num_constraints = (size_t)max_row - z.n_public;
         for (int m = 0; m < 2; m++) z.row_ptr[m].assign(z.num_constraints + 1, 0);
         for (size_t i = 0; i < ncoef; i++) { const uint32_t row = word(i, 1); if (row < z.num_constraints) z.row_ptr[word(i, 0)][row + 1]++; }
@@ -177,6 +181,7 @@ static ZKey read_zkey(int curve_id, const std::string& path, bool header_only = 
                 const uint32_t m = word(i, 0), row = word(i, 1);
                 if (row >= z.num_constraints) continue;
                 const uint32_t k = fill[m][row]++;
+                if (word(i, 2) >= z.n_vars) throw std::runtime_error("invalid data: matrix column index beyond n_vars");   // the device mat-vec indexes the witness with it
                 z.col[m][k] = word(i, 2); memcpy(z.coeff[m][k].v, rec + i * 44 + 12, 32);
             }
             const int nthreads = (int)std::min<size_t>(8, std::max<size_t>(1, ncoef / 65536));
@@ -358,8 +363,9 @@ struct DeviceMatrix { uint32_t* row_ptr; uint32_t* col; void* coeff; size_t rows
 struct DeviceZKey {   // bases uploaded once and reused by every proof / party (ownership of host buffers stays with ZKey)
     const ZKey* z;
     cg_bases *a = nullptr, *b1 = nullptr, *b2 = nullptr, *l = nullptr, *h = nullptr;
-    DeviceMatrix mat[2];
+    DeviceMatrix mat[2] = {{nullptr, nullptr, nullptr, 0}, {nullptr, nullptr, nullptr, 0}};
     void* pub_dev = nullptr;
+    cg_ctx* owner = nullptr;
 };
 
 enum class Mode { Plain, Rep3, Shamir };
@@ -994,6 +1000,13 @@ public:
 };
 
 // ---- prover --------------------------------------------------------------------------------------------------------------
+struct VecGuard {   // device share vector released when the entry point leaves, however it leaves
+    HipDriver& d; ShareVec v;
+    explicit VecGuard(HipDriver& drv) : d(drv) {}
+    VecGuard(HipDriver& drv, ShareVec x) : d(drv), v(x) {}
+    ~VecGuard() { try { d.free_vec(v); } catch (...) {} }
+    VecGuard(const VecGuard&) = delete; VecGuard& operator=(const VecGuard&) = delete;
+};
 struct Proof { Bytes a, b, c; };   // packed affine, (0,0) = infinity  (Groth16Proof, groth16/proof.rs:8-29)
 
 class CoGroth16 {
@@ -1104,8 +1117,21 @@ static void validate_bases(cg_ctx* ctx, const cg_bases* b, const char* name) {
     if (bad) throw std::runtime_error(std::string("invalid data: ") + name + "[" + std::to_string(first) + "] is not in the correct subgroup (" + std::to_string(bad) + " bad points)");
 }
 
-static DeviceZKey upload_zkey(cg_ctx* ctx, const ZKey& z, const std::vector<Fr>& public_inputs, bool validate = false) {
-    DeviceZKey d; d.z = &z;
+// The reference validates every zkey point while parsing (traits.rs:116-123, 147-153), so the prove entry points and
+// cgh_session_open do too, by default.  Opt-out for callers that validated the file before (cgh_zkey_validate): the environment
+// variable CGH_SKIP_ZKEY_VALIDATION or cgh_set_zkey_validation(0).
+static std::atomic<int> g_validate_zkey{-1};
+static bool validate_by_default() {
+    int v = g_validate_zkey.load();
+    if (v < 0) { v = getenv("CGH_SKIP_ZKEY_VALIDATION") ? 0 : 1; g_validate_zkey.store(v); }
+    return v != 0;
+}
+struct DeviceZKeyGuard;
+static void release_zkey(cg_ctx* ctx, DeviceZKey& d);
+static DeviceZKey upload_zkey(cg_ctx* ctx, const ZKey& z, const std::vector<Fr>& public_inputs, int validate_flag = -1) {
+    const bool validate = validate_flag < 0 ? validate_by_default() : validate_flag != 0;
+    DeviceZKey d; d.z = &z; d.owner = ctx;
+    struct Undo { cg_ctx* c; DeviceZKey* d; bool armed = true; ~Undo() { if (armed) release_zkey(c, *d); } } undo{ctx, &d};   // a failing table must not leak the ones before it
     const Curve& c = z.curve;
     auto reg = [&](const auto& pts, int group, const char* name = "") {
         cg_bases* b; CG(cg_bases_register(ctx, c.id, group, pts.data(), pts.size() / c.aff(group), c.aff(group), -1, &b));
@@ -1127,13 +1153,32 @@ static DeviceZKey upload_zkey(cg_ctx* ctx, const ZKey& z, const std::vector<Fr>&
         d.mat[m].rows = z.num_constraints;
     }
     d.pub_dev = up(public_inputs.data(), public_inputs.size() * 32);
+    undo.armed = false;
     return d;
 }
 static void release_zkey(cg_ctx* ctx, DeviceZKey& d) {
-    for (cg_bases* b : {d.a, d.b1, d.b2, d.l, d.h}) cg_bases_release(b);
-    for (int m = 0; m < 2; m++) { cg_dev_free(ctx, d.mat[m].row_ptr); cg_dev_free(ctx, d.mat[m].col); cg_dev_free(ctx, d.mat[m].coeff); }
-    cg_dev_free(ctx, d.pub_dev);
+    for (cg_bases** b : {&d.a, &d.b1, &d.b2, &d.l, &d.h}) { if (*b) cg_bases_release(*b); *b = nullptr; }
+    for (int m = 0; m < 2; m++) {
+        if (d.mat[m].row_ptr) cg_dev_free(ctx, d.mat[m].row_ptr); if (d.mat[m].col) cg_dev_free(ctx, d.mat[m].col); if (d.mat[m].coeff) cg_dev_free(ctx, d.mat[m].coeff);
+        d.mat[m] = DeviceMatrix{nullptr, nullptr, nullptr, 0};
+    }
+    if (d.pub_dev) cg_dev_free(ctx, d.pub_dev);
+    d.pub_dev = nullptr;
 }
+// scope guards of the C entry points: whatever a failing proof leaves behind on the device is released (a long-lived prover that
+// hits "randomness stream exhausted" a few times must not run out of HBM)
+struct DeviceZKeyGuard {
+    cg_ctx* ctx; DeviceZKey dz; bool live = true;
+    DeviceZKeyGuard(cg_ctx* c, DeviceZKey d) : ctx(c), dz(d) {}
+    ~DeviceZKeyGuard() { if (live) release_zkey(ctx, dz); }
+    DeviceZKeyGuard(const DeviceZKeyGuard&) = delete; DeviceZKeyGuard& operator=(const DeviceZKeyGuard&) = delete;
+};
+struct CtxGuard {
+    cg_ctx* ctx = nullptr;
+    ~CtxGuard() { if (ctx) cg_ctx_destroy(ctx); }
+    cg_ctx* release() { cg_ctx* c = ctx; ctx = nullptr; return c; }
+};
+struct DevBufGuard { cg_ctx* ctx; void* p; ~DevBufGuard() { if (p) cg_dev_free(ctx, p); } };
 
 // Second contexts for the witness-independent MSMs (HipDriver::aux).  Creating a context costs 15-25 ms (its streams), so they are
 // made on a helper thread while the zkey is read and uploaded, and only for zkeys large enough (>= ~2^19 constraints) to gain.
@@ -1744,6 +1789,151 @@ static void plonk_proof_from_json(const Curve& c, const std::string& js, uint8_t
     for (int i = 0; i < 6; i++) { auto v = json_numbers_after(js, PLONK_EV_KEYS[i], 1); uint64_t can[4] = {0}; dec_to_limbs(v[0], can, 4); CG(cg_fr_from_canonical(c.id, can, evals[i].v, 1)); }
 }
 
+// ---- synthetic satisfiable circuit + valid Groth16 CRS (bench / test tooling; SURVEY.md §8d "synthetic R1CS generator") --------------
+// Writes a snarkjs-format .zkey (sections 1-9, the layout read_zkey above parses: circom-types/src/groth16/zkey.rs:139-316) and a
+// .wtns (witness.rs:51-91), so that sessions and file -> proof runs have a real file of any size to work on: the shipped fixtures stop
+// at 213 constraints.  n_public = 1, num_constraints = m - 2, n_vars = m = domain size; constraint j:
+//     (ca_j * w[j+1]) * (cb_j * w[sb_j]) = w[j+2],   sb_j = 1 + (7 j + 3) mod (j + 1)  (<= j + 1: the witness is computed forward).
+// CRS from seeded toxic waste (tau, alpha, beta, gamma, delta): polynomial evaluations on the host (field arithmetic through the
+// ABI's cg_fr_op, on a few threads), the five point tables by fixed-base batch multiplication on the GPU (cg_bases_from_scalars).
+// Conventions the prover relies on (groth16.rs:141-204): section 4 carries the rows A[nc + i] = w_i for i <= n_public, and
+//     h_query[i] = [ (tau^2m - 1) g w^i / (2 m delta (tau - g w^i)) ]_1,   g = w_2m:
+// H = (AB - C)/Z is interpolated on the odd coset gH, where Z = g^m - 1 = -2, so the prover's h_i = (AB - C)(g w^i) needs no division.
+static void parallel_for(size_t n, const std::function<void(size_t, size_t)>& fn) {
+    const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::thread::hardware_concurrency(), n / 4096 + 1}));
+    if (T == 1) { fn(0, n); return; }
+    std::vector<std::thread> th; std::vector<std::string> err(T);
+    for (size_t t = 0; t < T; t++) th.emplace_back([&, t] { try { fn(n * t / T, n * (t + 1) / T); } catch (const std::exception& e) { err[t] = e.what(); } });
+    for (auto& x : th) x.join();
+    for (auto& e : err) if (!e.empty()) throw std::runtime_error(e);
+}
+static void batch_inverse(const Curve& c, std::vector<Fr>& v) {           // Montgomery's trick per slice; no zero elements
+    parallel_for(v.size(), [&](size_t lo, size_t hi) {
+        if (hi <= lo) return;
+        std::vector<Fr> pre(hi - lo);
+        Fr acc = fr_from_u64(c, 1);
+        for (size_t i = lo; i < hi; i++) { pre[i - lo] = acc; acc = fr_mul(c, acc, v[i]); }
+        Fr inv = fr_inv(c, acc);
+        for (size_t i = hi; i-- > lo;) { const Fr t = fr_mul(c, inv, pre[i - lo]); inv = fr_mul(c, inv, v[i]); v[i] = t; }
+    });
+}
+struct SplitMix { uint64_t s; uint64_t next() { uint64_t z = (s += 0x9e3779b97f4a7c15ull); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); } };
+static Fr random_nonzero_fr(const Curve& c, SplitMix& g) {
+    for (;;) {
+        Fr raw; for (int i = 0; i < 4; i++) raw.v[i] = g.next();
+        raw.v[3] &= c.id == CG_BN254 ? 0x3fffffffffffffffull : 0x7fffffffffffffffull;
+        bool lt = false, gt = false;
+        for (int i = 3; i >= 0 && !lt && !gt; i--) { if (raw.v[i] < MOD_R[c.id][i]) lt = true; else if (raw.v[i] > MOD_R[c.id][i]) gt = true; }
+        if (!lt || !(raw.v[0] | raw.v[1] | raw.v[2] | raw.v[3])) continue;
+        Fr m; CG(cg_fr_from_canonical(c.id, raw.v, m.v, 1));
+        return m;
+    }
+}
+struct SectionWriter {     // sections are streamed: a 2^22-constraint zkey is 2 GB
+    FILE* f;
+    SectionWriter(const std::string& path, const char* magic, uint32_t version, uint32_t nsec) {
+        f = fopen(path.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot write " + path);
+        put(magic, 4); u32(version); u32(nsec);
+    }
+    ~SectionWriter() { if (f) fclose(f); }
+    void put(const void* p, size_t n) { if (n && fwrite(p, 1, n, f) != n) throw std::runtime_error("short write"); }
+    void u32(uint32_t x) { put(&x, 4); }
+    void u64(uint64_t x) { put(&x, 8); }
+    void begin(uint32_t id, uint64_t bytes) { u32(id); u64(bytes); }
+    void close() { if (f && fclose(f) != 0) { f = nullptr; throw std::runtime_error("close failed"); } f = nullptr; }
+};
+static void synth_circuit(int device, int curve_id, int log_m, uint64_t seed, const std::string& zkey_path, const std::string& wtns_path) {
+    if (log_m < 2 || log_m > 26) throw std::runtime_error("log_m out of range");
+    const Curve c{curve_id};
+    const size_t m = (size_t)1 << log_m, nc = m - 2, n_pub = 1, n_vars = m, n_inp = n_pub + 1;
+    SplitMix rng{seed * 0x2545f4914f6cdd1dull + 0x1234567};
+    // circuit + witness (a serial chain by construction)
+    std::vector<Fr> ca(nc), cb(nc), w(n_vars);
+    std::vector<uint32_t> sb(nc);
+    for (size_t j = 0; j < nc; j++) { ca[j] = random_nonzero_fr(c, rng); cb[j] = random_nonzero_fr(c, rng); sb[j] = (uint32_t)(1 + (7 * j + 3) % (j + 1)); }
+    w[0] = fr_from_u64(c, 1); w[1] = random_nonzero_fr(c, rng);
+    for (size_t j = 0; j < nc; j++) w[j + 2] = fr_mul(c, fr_mul(c, ca[j], w[j + 1]), fr_mul(c, cb[j], w[sb[j]]));
+    // toxic waste, Lagrange values of the domain at tau
+    const Fr tau = random_nonzero_fr(c, rng), alpha = random_nonzero_fr(c, rng), beta = random_nonzero_fr(c, rng), gamma = random_nonzero_fr(c, rng), delta = random_nonzero_fr(c, rng);
+    const Domain dom = groth16_domain(c, (size_t)log_m, nc, n_inp);
+    const Fr one = fr_from_u64(c, 1);
+    Fr tau_m = tau; for (int i = 0; i < log_m; i++) tau_m = fr_mul(c, tau_m, tau_m);
+    std::vector<Fr> wpow(m), lag(m), hexp(m);
+    {   // w^j by slices: each slice starts from w^lo (square-and-multiply) and runs a product chain
+        parallel_for(m, [&](size_t lo, size_t hi) {
+            if (hi <= lo) return;
+            uint64_t e[1] = {lo};
+            Fr acc = fr_pow(c, dom.omega, e, 1);
+            for (size_t j = lo; j < hi; j++) { wpow[j] = acc; acc = fr_mul(c, acc, dom.omega); }
+        });
+    }
+    parallel_for(m, [&](size_t lo, size_t hi) { for (size_t j = lo; j < hi; j++) { lag[j] = fr_sub(c, tau, wpow[j]); hexp[j] = fr_sub(c, tau, fr_mul(c, dom.coset_g, wpow[j])); } });
+    batch_inverse(c, lag); batch_inverse(c, hexp);
+    const Fr zt_over_m = fr_mul(c, fr_sub(c, tau_m, one), fr_inv(c, fr_from_u64(c, (uint64_t)m)));
+    const Fr hfac = fr_mul(c, fr_mul(c, fr_sub(c, fr_mul(c, tau_m, tau_m), one), fr_inv(c, fr_mul(c, fr_from_u64(c, 2 * (uint64_t)m), delta))), dom.coset_g);
+    parallel_for(m, [&](size_t lo, size_t hi) { for (size_t j = lo; j < hi; j++) { lag[j] = fr_mul(c, fr_mul(c, zt_over_m, wpow[j]), lag[j]); hexp[j] = fr_mul(c, fr_mul(c, hfac, wpow[j]), hexp[j]); } });
+    { std::vector<Fr>().swap(wpow); }
+    // u_i = sum_j A[j][i] L_j(tau), v_i, and the C column (C[j][j+2] = 1)
+    const Fr zero = fr_sub(c, one, one);
+    std::vector<Fr> u(n_vars, zero), v(n_vars, zero), lic(n_vars);
+    parallel_for(nc, [&](size_t lo, size_t hi) { for (size_t j = lo; j < hi; j++) u[j + 1] = fr_mul(c, ca[j], lag[j]); });
+    for (size_t j = 0; j < nc; j++) v[sb[j]] = fr_add(c, v[sb[j]], fr_mul(c, cb[j], lag[j]));     // colliding targets: serial
+    for (size_t i = 0; i < n_inp; i++) u[i] = fr_add(c, u[i], lag[nc + i]);
+    const Fr ginv = fr_inv(c, gamma), dinv = fr_inv(c, delta);
+    parallel_for(n_vars, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            Fr t = fr_add(c, fr_mul(c, beta, u[i]), fr_mul(c, alpha, v[i]));
+            if (i >= 2) t = fr_add(c, t, lag[i - 2]);                                         // C column: w_i = L_(i-2) for i >= 2
+            lic[i] = fr_mul(c, t, i <= n_pub ? ginv : dinv);
+        }
+    });
+    // group elements on the GPU
+    CtxGuard cg; if (cg_ctx_create(device, &cg.ctx)) die("cg_ctx_create");
+    cg_ctx* ctx = cg.ctx;
+    auto table = [&](const std::vector<Fr>& sc, int group) {
+        DevBufGuard d{ctx, nullptr};
+        CG(cg_dev_alloc(ctx, sc.size() * 32, &d.p));
+        CG(cg_dev_upload(ctx, d.p, sc.data(), sc.size() * 32));
+        cg_bases* b = nullptr; CG(cg_bases_from_scalars(ctx, c.id, group, d.p, sc.size(), &b));
+        Bytes out(sc.size() * c.aff(group));
+        const int rc = cg_bases_download(ctx, b, 0, sc.size(), out.data());
+        cg_bases_release(b);
+        if (rc) die("cg_bases_download");
+        return out;
+    };
+    auto g1 = [&](const Fr& k) { return pt_to_affine(c, pt_mul(c, pt_generator(c, CG_G1), k)); };
+    auto g2 = [&](const Fr& k) { return pt_to_affine(c, pt_mul(c, pt_generator(c, CG_G2), k)); };
+    const uint32_t ncoef = (uint32_t)(2 * nc + n_inp);
+    SectionWriter zk(zkey_path, "zkey", 1, 9);
+    zk.begin(1, 4); zk.u32(1);                                                               // protocol: groth16
+    zk.begin(2, 4 + c.fq() + 4 + 32 + 12 + 3 * c.aff(CG_G1) + 3 * c.aff(CG_G2));
+    zk.u32((uint32_t)c.fq()); zk.put(MOD_Q[c.id], c.fq()); zk.u32(32); zk.put(MOD_R[c.id], 32);
+    zk.u32((uint32_t)n_vars); zk.u32((uint32_t)n_pub); zk.u32((uint32_t)m);
+    { Bytes a1 = g1(alpha), b1 = g1(beta), b2 = g2(beta), c2 = g2(gamma), d1 = g1(delta), d2 = g2(delta);
+      zk.put(a1.data(), a1.size()); zk.put(b1.data(), b1.size()); zk.put(b2.data(), b2.size()); zk.put(c2.data(), c2.size()); zk.put(d1.data(), d1.size()); zk.put(d2.data(), d2.size()); }
+    Bytes l_all = table(lic, CG_G1);
+    { std::vector<Fr>().swap(lic); }
+    zk.begin(3, n_inp * c.aff(CG_G1)); zk.put(l_all.data(), n_inp * c.aff(CG_G1));
+    zk.begin(4, 4 + (uint64_t)ncoef * 44); zk.u32(ncoef);
+    {   // value on disk = v * R^2: the Montgomery form of the Montgomery form (traits.rs:57-67 reduces once)
+        auto rec = [&](uint32_t mat, uint32_t row, uint32_t sig, const Fr& val) { Fr d; CG(cg_fr_from_canonical(c.id, val.v, d.v, 1)); zk.u32(mat); zk.u32(row); zk.u32(sig); zk.put(d.v, 32); };
+        for (size_t j = 0; j < nc; j++) { rec(0, (uint32_t)j, (uint32_t)(j + 1), ca[j]); rec(1, (uint32_t)j, sb[j], cb[j]); }
+        for (size_t i = 0; i < n_inp; i++) rec(0, (uint32_t)(nc + i), (uint32_t)i, one);
+    }
+    { Bytes t = table(u, CG_G1); zk.begin(5, t.size()); zk.put(t.data(), t.size()); }
+    { Bytes t = table(v, CG_G1); zk.begin(6, t.size()); zk.put(t.data(), t.size()); }
+    { Bytes t = table(v, CG_G2); zk.begin(7, t.size()); zk.put(t.data(), t.size()); }
+    zk.begin(8, (n_vars - n_inp) * c.aff(CG_G1)); zk.put(l_all.data() + n_inp * c.aff(CG_G1), (n_vars - n_inp) * c.aff(CG_G1));
+    { Bytes t = table(hexp, CG_G1); zk.begin(9, t.size()); zk.put(t.data(), t.size()); }
+    zk.close();
+    SectionWriter wt(wtns_path, "wtns", 2, 2);
+    wt.begin(1, 4 + 32 + 4); wt.u32(32); wt.put(MOD_R[c.id], 32); wt.u32((uint32_t)n_vars);
+    wt.begin(2, (uint64_t)n_vars * 32);
+    { std::vector<Fr> can(n_vars); CG(cg_fr_to_canonical(c.id, w.data(), can.data(), n_vars)); wt.put(can.data(), n_vars * 32); }
+    wt.close();
+}
+
 }  // namespace cgh
 
 // ==================================================================================================== C entry points (tests / tools)
@@ -1779,7 +1969,7 @@ int32_t cgh_zkey_validate(int32_t device, int32_t curve, const char* path, doubl
         auto t1 = std::chrono::steady_clock::now();
         if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
         std::vector<Fr> pub(z.n_public + 1);
-        DeviceZKey dz = upload_zkey(ctx, z, pub, true);
+        DeviceZKey dz = upload_zkey(ctx, z, pub, 1);
         release_zkey(ctx, dz);
         cg_ctx_destroy(ctx);
         auto t2 = std::chrono::steady_clock::now();
@@ -1943,6 +2133,7 @@ int32_t cgh_plonk_prove_plain(int32_t device, int32_t curve, const char* zkey_pa
         const Curve& c = z.curve;
         if (commits) memset(commits, 0, 9 * c.aff(CG_G1)); if (challenges) memset(challenges, 0, 5 * 32); if (evals) memset(evals, 0, 6 * 32);
         cg_bases* tau = nullptr; CG(cg_bases_register(ctx, c.id, CG_G1, z.p_tau.data(), z.domain_size + 6, c.aff(CG_G1), -1, &tau));
+        if (validate_by_default()) { try { validate_bases(ctx, tau, "p_tau"); } catch (...) { cg_bases_release(tau); throw; } }   // the zkey parser's per-point checks
         const Fr* w = (const Fr*)full_witness;
         std::vector<Fr> pub(w, w + z.n_public + 1);
         {
@@ -1983,6 +2174,7 @@ int32_t cgh_plonk_prove_shamir(int32_t device, int32_t curve, const char* zkey_p
         cg_ctx* ctx0 = nullptr;
         if (cg_ctx_create(device, &ctx0)) die("cg_ctx_create");
         cg_bases* tau = nullptr; CG(cg_bases_register(ctx0, c.id, CG_G1, z.p_tau.data(), z.domain_size + 6, psz, -1, &tau));
+        if (validate_by_default()) { try { validate_bases(ctx0, tau, "p_tau"); } catch (...) { cg_bases_release(tau); throw; } }   // the zkey parser's per-point checks
         InProcShamirHub hub(n);
         std::vector<std::string> errs(n);
         std::vector<std::thread> th;
@@ -2027,6 +2219,7 @@ int32_t cgh_plonk_prove_rep3(int32_t device, int32_t curve, const char* zkey_pat
         cg_ctx* ctx0 = nullptr;
         if (cg_ctx_create(device, &ctx0)) die("cg_ctx_create");
         cg_bases* tau = nullptr; CG(cg_bases_register(ctx0, c.id, CG_G1, z.p_tau.data(), z.domain_size + 6, psz, -1, &tau));
+        if (validate_by_default()) { try { validate_bases(ctx0, tau, "p_tau"); } catch (...) { cg_bases_release(tau); throw; } }   // the zkey parser's per-point checks
         InProcHub hub;
         std::string errs[3];
         std::vector<std::thread> th;
@@ -2064,7 +2257,6 @@ int32_t cgh_read_wtns(int32_t curve, const char* path, uint64_t* out, size_t cap
 }
 // PlainHipDriver: full_witness = n_vars Montgomery elements; proof = A || B || C packed affine
 int32_t cgh_prove_plain(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* full_witness, const uint64_t* r, const uint64_t* s, uint64_t* out_proof, uint64_t* out_h) {
-    cg_ctx* ctx = nullptr;
     try {
         using namespace cgh;
         const bool timing = getenv("CGH_TIMING") != nullptr;
@@ -2074,27 +2266,29 @@ int32_t cgh_prove_plain(int32_t device, int32_t curve, const char* zkey_path, co
         SecondContexts second(device, zkey_path, 1);
         ZKey z = read_zkey(curve, zkey_path);
         const auto t1 = now();
-        if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
+        CtxGuard cg;                                           // destroyed last: everything below lives on it
+        if (cg_ctx_create(device, &cg.ctx)) die("cg_ctx_create");
+        cg_ctx* ctx = cg.ctx;
         const Fr* w = (const Fr*)full_witness;
         std::vector<Fr> pub(w, w + z.n_public + 1);
-        DeviceZKey dz = upload_zkey(ctx, z, pub);
+        DeviceZKeyGuard dzg(ctx, upload_zkey(ctx, z, pub));
         const auto t2 = now();
-        HipDriver driver(ctx, z.curve, Mode::Plain, nullptr);
-        driver.use_second_context(second.take(0));
-        ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_public - 1);
-        FieldShare rs[2]; memcpy(rs[0].c[0].v, r, 32); rs[0].c[1] = rs[0].c[0]; memcpy(rs[1].c[0].v, s, 32); rs[1].c[1] = rs[1].c[0];
-        CoGroth16 prover(driver);
-        ShareVec h;
-        Proof p = prover.prove(dz, pub, wit, rs, &h);
-        const auto t3 = now();
-        store_proof(p, (uint8_t*)out_proof);
-        if (out_h) CG(cg_dev_download(ctx, out_h, h.c[0], h.n * 32));
-        driver.free_vec(h); driver.free_vec(wit); driver.shutdown();
-        release_zkey(ctx, dz);
-        cg_ctx_destroy(ctx);
-        if (timing) fprintf(stderr, "cgh_prove_plain: read+decode zkey %.1f ms, context + upload %.1f ms, prove %.1f ms, teardown %.1f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
+        std::chrono::steady_clock::time_point t3;
+        {
+            HipDriver driver(ctx, z.curve, Mode::Plain, nullptr);
+            driver.use_second_context(second.take(0));
+            VecGuard wit(driver, driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_public - 1)), h(driver);
+            FieldShare rs[2]; memcpy(rs[0].c[0].v, r, 32); rs[0].c[1] = rs[0].c[0]; memcpy(rs[1].c[0].v, s, 32); rs[1].c[1] = rs[1].c[0];
+            CoGroth16 prover(driver);
+            Proof p = prover.prove(dzg.dz, pub, wit.v, rs, &h.v);
+            t3 = now();
+            store_proof(p, (uint8_t*)out_proof);
+            if (out_h) CG(cg_dev_download(ctx, out_h, h.v.c[0], h.v.n * 32));
+        }
+        if (timing) fprintf(stderr, "cgh_prove_plain: read+decode zkey %.1f ms, context + upload%s %.1f ms, prove %.1f ms, teardown %.1f ms\n", ms(t0, t1),
+                            validate_by_default() ? " + point validation" : "", ms(t1, t2), ms(t2, t3), ms(t3, now()));
         return 0;
-    } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
 // Rep3HipProtocol x 3 on three threads over the in-process network; streams[i] = S_i (party i: rng1 = S_i, rng2 = S_{i-1})
 int32_t cgh_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
@@ -2105,35 +2299,31 @@ int32_t cgh_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, con
         ZKey z = read_zkey(curve, zkey_path);
         const size_t n_aux = z.n_vars - z.n_public - 1;
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
-        cg_ctx* ctx0 = nullptr;
-        if (cg_ctx_create(device, &ctx0)) die("cg_ctx_create");
-        DeviceZKey dz = upload_zkey(ctx0, z, pub);            // one device-resident zkey shared by the three co-located parties
+        CtxGuard cg0;
+        if (cg_ctx_create(device, &cg0.ctx)) die("cg_ctx_create");
+        DeviceZKeyGuard dzg(cg0.ctx, upload_zkey(cg0.ctx, z, pub));   // one device-resident zkey shared by the three co-located parties
+        const DeviceZKey& dz = dzg.dz;
         second.ready();
         InProcHub hub;
         const size_t psz = 8 * z.curve.fq();
         std::string errs[3];
         std::vector<std::thread> th;
         for (int i = 0; i < 3; i++) th.emplace_back([&, i] {
-            cg_ctx* ctx = nullptr;
             try {
-                if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
+                CtxGuard cg;
+                if (cg_ctx_create(device, &cg.ctx)) die("cg_ctx_create");
                 InProcNetwork net(&hub, i);
-                HipDriver driver(ctx, z.curve, Mode::Rep3, &net);
+                HipDriver driver(cg.ctx, z.curve, Mode::Rep3, &net);
                 driver.use_second_context(second.take(i));
                 driver.rng1 = (const Fr*)streams[i]; driver.rng2 = (const Fr*)streams[(i + 2) % 3]; driver.rng_len = stream_len;
-                ShareVec wit = driver.upload_vec((const Fr*)wit_a[i], (const Fr*)wit_b[i], n_aux);
+                VecGuard wit(driver, driver.upload_vec((const Fr*)wit_a[i], (const Fr*)wit_b[i], n_aux)), h(driver);
                 CoGroth16 prover(driver);
-                ShareVec h;
-                Proof p = prover.prove(dz, pub, wit, nullptr, &h);
+                Proof p = prover.prove(dz, pub, wit.v, nullptr, &h.v);
                 store_proof(p, (uint8_t*)out_proofs + i * psz);
-                if (out_h && i == 0) { CG(cg_dev_download(ctx, out_h, h.c[0], h.n * 32)); CG(cg_dev_download(ctx, out_h + h.n * 4, h.c[1], h.n * 32)); }
-                driver.free_vec(h); driver.free_vec(wit); driver.shutdown();
-                cg_ctx_destroy(ctx);
-            } catch (const std::exception& e) { errs[i] = e.what(); hub.abort(); if (ctx) cg_ctx_destroy(ctx); }
+                if (out_h && i == 0) { CG(cg_dev_download(cg.ctx, out_h, h.v.c[0], h.v.n * 32)); CG(cg_dev_download(cg.ctx, out_h + h.v.n * 4, h.v.c[1], h.v.n * 32)); }
+            } catch (const std::exception& e) { errs[i] = e.what(); hub.abort(); }
         });
         for (auto& t : th) t.join();
-        release_zkey(ctx0, dz);
-        cg_ctx_destroy(ctx0);
         if (report_party_errors(errs, 3)) return 1;
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
@@ -2151,7 +2341,30 @@ struct cgh_session {
     }
     void give(cg_ctx* c) { if (!c) return; cg_ctx_sync(c); std::lock_guard<std::mutex> l(mu); idle.push_back(c); }
 };
-int32_t cgh_session_open(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, void** out) {
+namespace {
+// a context borrowed from the session: returned to the pool on success, destroyed when the proof failed (its streams may hold
+// half-finished work)
+struct Borrowed {
+    cgh_session* s; cg_ctx* c = nullptr; bool ok = false;
+    Borrowed(cgh_session* ses, bool wanted = true) : s(ses) { if (wanted) c = ses->take(); }
+    ~Borrowed() { if (!c) return; if (ok) s->give(c); else cg_ctx_destroy(c); }
+    Borrowed(const Borrowed&) = delete; Borrowed& operator=(const Borrowed&) = delete;
+};
+// the zkey tables of the session with this proof's own public-input buffer (several proofs may run on one session at a time)
+struct ProofZKey {
+    cg_ctx* ctx; cgh::DeviceZKey dz;
+    ProofZKey(cgh_session* s, cg_ctx* on, const std::vector<cgh::Fr>& pub) : ctx(on), dz(s->dz) {
+        using namespace cgh;
+        dz.pub_dev = nullptr;
+        CG(cg_dev_alloc(ctx, pub.size() * 32, &dz.pub_dev));
+        CG(cg_dev_upload(ctx, dz.pub_dev, pub.data(), pub.size() * 32));
+    }
+    ~ProofZKey() { if (dz.pub_dev) cg_dev_free(ctx, dz.pub_dev); }
+    ProofZKey(const ProofZKey&) = delete; ProofZKey& operator=(const ProofZKey&) = delete;
+};
+}
+// flags: bit 0 = skip the point validation (the file was validated before, cgh_zkey_validate)
+int32_t cgh_session_open_ex(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, uint32_t flags, void** out) {
     cgh_session* s = nullptr;
     try {
         using namespace cgh;
@@ -2159,13 +2372,16 @@ int32_t cgh_session_open(int32_t device, int32_t curve, const char* zkey_path, i
         s->z = read_zkey(curve, zkey_path);
         if (cg_ctx_create(device, &s->ctx0)) die("cg_ctx_create");
         std::vector<Fr> pub(s->z.n_public + 1);
-        s->dz = upload_zkey(s->ctx0, s->z, pub);
+        s->dz = upload_zkey(s->ctx0, s->z, pub, (flags & 1u) ? 0 : -1);
         if (precompute) for (cg_bases* b : {s->dz.a, s->dz.b1, s->dz.b2, s->dz.l, s->dz.h}) CG(cg_bases_precompute(s->ctx0, b, precompute > 0 ? precompute : 0));
         CG(cg_ctx_sync(s->ctx0));
         s->second_context = s->z.n_vars >= ((size_t)1 << 19) && !getenv("CGH_ONE_CONTEXT");
         *out = s;
         return 0;
-    } catch (const std::exception& e) { g_host_err = e.what(); if (s) { if (s->ctx0) cg_ctx_destroy(s->ctx0); delete s; } return 1; }
+    } catch (const std::exception& e) { g_host_err = e.what(); if (s) { if (s->ctx0) { cgh::release_zkey(s->ctx0, s->dz); cg_ctx_destroy(s->ctx0); } delete s; } return 1; }
+}
+int32_t cgh_session_open(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, void** out) {
+    return cgh_session_open_ex(device, curve, zkey_path, precompute, 0, out);
 }
 int32_t cgh_session_close(void* h) {
     cgh_session* s = (cgh_session*)h;
@@ -2174,31 +2390,30 @@ int32_t cgh_session_close(void* h) {
     cgh::release_zkey(s->ctx0, s->dz); cg_ctx_destroy(s->ctx0); delete s;
     return 0;
 }
-static void session_set_public(cgh_session* s, const std::vector<cgh::Fr>& pub) { using namespace cgh; CG(cg_dev_upload(s->ctx0, s->dz.pub_dev, pub.data(), pub.size() * 32)); }
 // plain driver on an open session; seconds[0] (optional) = wall time of the prove
 int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uint64_t* r, const uint64_t* sc, uint64_t* out_proof, double* seconds) {
-    cgh_session* s = (cgh_session*)h; cg_ctx* ctx = nullptr;
+    cgh_session* s = (cgh_session*)h;
     try {
         using namespace cgh;
         const ZKey& z = s->z;
         const Fr* w = (const Fr*)full_witness;
         std::vector<Fr> pub(w, w + z.n_public + 1);
-        session_set_public(s, pub);
-        ctx = s->take();
-        cg_ctx* second = s->second_context ? s->take() : nullptr;
+        Borrowed ctx(s), second(s, s->second_context);
+        ProofZKey pz(s, ctx.c, pub);
         const auto t0 = std::chrono::steady_clock::now();
-        HipDriver driver(ctx, z.curve, Mode::Plain, nullptr);
-        driver.aux = second; driver.owns_aux = false;
-        ShareVec wit = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_public - 1);
-        FieldShare rs[2]; memcpy(rs[0].c[0].v, r, 32); rs[0].c[1] = rs[0].c[0]; memcpy(rs[1].c[0].v, sc, 32); rs[1].c[1] = rs[1].c[0];
-        CoGroth16 prover(driver);
-        Proof p = prover.prove(s->dz, pub, wit, rs, nullptr);
-        if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        store_proof(p, (uint8_t*)out_proof);
-        driver.free_vec(wit); driver.shutdown();
-        s->give(second); s->give(ctx);
+        {
+            HipDriver driver(ctx.c, z.curve, Mode::Plain, nullptr);
+            driver.aux = second.c; driver.owns_aux = false;
+            VecGuard wit(driver, driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_public - 1));
+            FieldShare rs[2]; memcpy(rs[0].c[0].v, r, 32); rs[0].c[1] = rs[0].c[0]; memcpy(rs[1].c[0].v, sc, 32); rs[1].c[1] = rs[1].c[0];
+            CoGroth16 prover(driver);
+            Proof p = prover.prove(pz.dz, pub, wit.v, rs, nullptr);
+            if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            store_proof(p, (uint8_t*)out_proof);
+        }
+        ctx.ok = second.ok = true;
         return 0;
-    } catch (const std::exception& e) { g_host_err = e.what(); if (ctx) cg_ctx_destroy(ctx); return 1; }
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
 // three REP3 parties on an open session (threads, in-process network).  seconds (optional, 2 values): [0] = wall time of the three
 // co-located parties; [1] = party 0 ALONE on the GPU, replaying the messages it received in the first run (its proof must repeat).
@@ -2210,23 +2425,20 @@ int32_t cgh_session_prove_rep3(void* h, const uint64_t* pub_in, const uint64_t* 
         const ZKey& z = s->z;
         const size_t n_aux = z.n_vars - z.n_public - 1, psz = 8 * z.curve.fq();
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
-        session_set_public(s, pub);
         std::deque<Bytes> rec_prev, rec_next;
         auto party = [&](int i, Rep3Network* net, uint8_t* out) {
-            cg_ctx* ctx = nullptr;
-            try {
-                ctx = s->take();
-                cg_ctx* second = s->second_context ? s->take() : nullptr;
-                HipDriver driver(ctx, z.curve, Mode::Rep3, net);
-                driver.aux = second; driver.owns_aux = false;
+            Borrowed ctx(s), second(s, s->second_context);
+            ProofZKey pz(s, ctx.c, pub);
+            {
+                HipDriver driver(ctx.c, z.curve, Mode::Rep3, net);
+                driver.aux = second.c; driver.owns_aux = false;
                 driver.rng1 = (const Fr*)streams[i]; driver.rng2 = (const Fr*)streams[(i + 2) % 3]; driver.rng_len = stream_len;
-                ShareVec wit = driver.upload_vec((const Fr*)wit_a[i], (const Fr*)wit_b[i], n_aux);
+                VecGuard wit(driver, driver.upload_vec((const Fr*)wit_a[i], (const Fr*)wit_b[i], n_aux));
                 CoGroth16 prover(driver);
-                Proof p = prover.prove(s->dz, pub, wit, nullptr, nullptr);
+                Proof p = prover.prove(pz.dz, pub, wit.v, nullptr, nullptr);
                 store_proof(p, out);
-                driver.free_vec(wit); driver.shutdown();
-                s->give(second); s->give(ctx);
-            } catch (...) { if (ctx) cg_ctx_destroy(ctx); throw; }
+            }
+            ctx.ok = second.ok = true;
         };
         InProcHub hub;
         std::string errs[3];
@@ -2252,6 +2464,12 @@ int32_t cgh_session_prove_rep3(void* h, const uint64_t* pub_in, const uint64_t* 
         }
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+int32_t cgh_set_zkey_validation(int32_t on) { cgh::g_validate_zkey.store(on ? 1 : 0); return 0; }
+// synthetic satisfiable circuit of 2^log_m - 2 constraints with a valid CRS, written as .zkey + .wtns (bench / test tooling)
+int32_t cgh_synth_circuit(int32_t device, int32_t curve, int32_t log_m, uint64_t seed, const char* zkey_path, const char* wtns_path) {
+    try { cgh::synth_circuit(device, curve, log_m, seed, zkey_path, wtns_path); return 0; }
+    catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
 
 }  // extern "C"

@@ -196,6 +196,11 @@ int32_t cg_point_generator(int32_t curve, int32_t group, void* h_out);
 /* Builds, on the device, the table [(first + i) * G]_{i<n} of consecutive multiples of the group generator: valid,
  * pairwise distinct points with known discrete logs, used as synthetic zkey-sized bases. */
 int32_t cg_bases_synth_multiples(cg_ctx* ctx, int32_t curve, int32_t group, uint64_t first, size_t n, cg_bases** out);
+/* Fixed-base batch multiplication on the device: table[i] = s_i * G for n device-resident Montgomery scalars (G = the group
+ * generator of cg_point_generator).  A zero scalar gives the point at infinity.  Builds the queries of a synthetic but VALID
+ * Groth16 CRS from toxic-waste polynomial evaluations (SURVEY.md §8d "synthetic R1CS generator"; the reference has no setup
+ * code — snarkjs produces its zkeys — so this replaces nothing on the prover path). */
+int32_t cg_bases_from_scalars(cg_ctx* ctx, int32_t curve, int32_t group, const void* d_scalars, size_t n, cg_bases** out);
 /* copies n packed affine points of a table back to the host */
 int32_t cg_bases_download(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, void* h_out_packed);
 

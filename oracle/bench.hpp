@@ -8,48 +8,103 @@
 // (at most ceil(254/c) useful threads) and data-parallel FFT stages / pointwise loops.  Network rounds are excluded on both sides.
 #pragma once
 #include "groth16.hpp"
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <functional>
 
 namespace orc {
 
-static inline void parallel_for(size_t n, int threads, const std::function<void(size_t, size_t)>& fn) {
-    if (threads <= 1 || n < 1024) { fn(0, n); return; }
-    std::vector<std::thread> pool;
-    size_t chunk = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; t++) {
-        size_t lo = (size_t)t * chunk, hi = std::min(n, lo + chunk);
-        if (lo >= hi) break;
-        pool.emplace_back([=, &fn] { fn(lo, hi); });
+// Persistent worker pool (rayon's role in the reference binary): the workers sleep on a condition variable between jobs, a job is
+// a range cut into slices that the workers claim with an atomic counter.  (Spawning threads per butterfly stage, as the first
+// version of this file did, cost more than the stage.)
+class Pool {
+    std::vector<std::thread> workers; std::mutex mu; std::condition_variable cv_job, cv_done;
+    const std::function<void(size_t, size_t)>* fn = nullptr; size_t n = 0, slice = 1; std::atomic<size_t> next{0};
+    size_t generation = 0; int busy = 0; bool stop = false;
+    void work() { for (;;) { const size_t lo = next.fetch_add(slice); if (lo >= n) return; (*fn)(lo, std::min(n, lo + slice)); } }
+public:
+    explicit Pool(int threads) {
+        for (int t = 1; t < threads; t++) workers.emplace_back([this] {
+            size_t seen = 0;
+            for (;;) {
+                { std::unique_lock<std::mutex> l(mu); cv_job.wait(l, [&] { return stop || generation != seen; }); if (stop) return; seen = generation; }
+                work();
+                { std::lock_guard<std::mutex> l(mu); if (--busy == 0) cv_done.notify_one(); }
+            }
+        });
     }
-    for (auto& th : pool) th.join();
+    ~Pool() { { std::lock_guard<std::mutex> l(mu); stop = true; } cv_job.notify_all(); for (auto& w : workers) w.join(); }
+    int size() const { return (int)workers.size() + 1; }
+    void run(size_t count, size_t min_slice, const std::function<void(size_t, size_t)>& f) {
+        if (count == 0) return;
+        if (workers.empty() || count <= min_slice) { f(0, count); return; }
+        { std::lock_guard<std::mutex> l(mu); fn = &f; n = count; slice = std::max(min_slice, (count + 8 * (size_t)size() - 1) / (8 * (size_t)size())); next = 0; busy = (int)workers.size(); generation++; }
+        cv_job.notify_all();
+        work();
+        std::unique_lock<std::mutex> l(mu); cv_done.wait(l, [&] { return busy == 0; });
+    }
+};
+static inline void parallel_for(size_t n, int threads, const std::function<void(size_t, size_t)>& fn) {      // one-off jobs (setup code)
+    if (threads <= 1 || n < 1024) { fn(0, n); return; }
+    Pool p(threads); p.run(n, 256, fn);
 }
 
-// same transforms as poly.hpp, butterflies of each stage split across threads
+// Cache-blocked radix-2 transforms, same arithmetic and results as poly.hpp.  The 2^BLK-point sub-transforms (1 MiB of field
+// elements) are independent once the long-range stages are done (forward: decimation in frequency, long strides first; inverse:
+// decimation in time, short strides first), so each is run through all of its stages by one worker while it sits in that core's L2;
+// only the log2(n) - BLK long-range stages sweep the whole array.  The bit reversal is split over the workers as well.
+constexpr int NTT_BLK = 15;
 template <class F>
-static void ntt_forward_mt(F* a, size_t n, const std::vector<F>& tw, int threads) {
-    for (size_t half = n / 2, step = 1; half >= 1; half >>= 1, step <<= 1)
-        parallel_for(n / 2, threads, [&](size_t lo, size_t hi) {
-            for (size_t u = lo; u < hi; u++) {
-                size_t blk = (u / half) * 2 * half, j = u % half;
-                F x = a[blk + j], y = a[blk + j + half];
-                a[blk + j] = x + y; a[blk + j + half] = (x - y) * tw[j * step];
-            }
-        });
-    bitrev_permute(a, n);
+static void bitrev_permute_mt(F* a, size_t n, Pool& pool) {
+    const int lg = log2_exact(n);
+    pool.run(n, 4096, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) { const size_t j = bitrev(i, lg); if (i < j) std::swap(a[i], a[j]); } });
 }
 template <class F>
-static void ntt_inverse_mt(F* a, size_t n, const std::vector<F>& twi, const F& ninv, int threads) {
-    bitrev_permute(a, n);
-    for (size_t half = 1, step = n / 2; half < n; half <<= 1, step >>= 1)
-        parallel_for(n / 2, threads, [&](size_t lo, size_t hi) {
+static void ntt_forward_mt(F* a, size_t n, const std::vector<F>& tw, Pool& pool) {
+    const size_t blk = std::min<size_t>(n, (size_t)1 << NTT_BLK);
+    size_t half = n / 2, step = 1;
+    for (; 2 * half > blk; half >>= 1, step <<= 1)
+        pool.run(n / 2, 4096, [&](size_t lo, size_t hi) {
             for (size_t u = lo; u < hi; u++) {
-                size_t blk = (u / half) * 2 * half, j = u % half;
-                F x = a[blk + j], y = a[blk + j + half] * twi[j * step];
-                a[blk + j] = x + y; a[blk + j + half] = x - y;
+                const size_t b = (u / half) * 2 * half, j = u % half;
+                const F x = a[b + j], y = a[b + j + half];
+                a[b + j] = x + y; a[b + j + half] = (x - y) * tw[j * step];
             }
         });
-    parallel_for(n, threads, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) a[i] = a[i] * ninv; });
+    pool.run(n / blk, 1, [&](size_t lo, size_t hi) {
+        for (size_t q = lo; q < hi; q++) {
+            F* s = a + q * blk;
+            for (size_t h = half, st = step; h >= 1; h >>= 1, st <<= 1)
+                for (size_t b = 0; b < blk; b += 2 * h)
+                    for (size_t j = 0; j < h; j++) { const F x = s[b + j], y = s[b + j + h]; s[b + j] = x + y; s[b + j + h] = (x - y) * tw[j * st]; }
+        }
+    });
+    bitrev_permute_mt(a, n, pool);
+}
+template <class F>
+static void ntt_inverse_mt(F* a, size_t n, const std::vector<F>& twi, const F& ninv, Pool& pool) {
+    bitrev_permute_mt(a, n, pool);
+    const size_t blk = std::min<size_t>(n, (size_t)1 << NTT_BLK);
+    pool.run(n / blk, 1, [&](size_t lo, size_t hi) {
+        for (size_t q = lo; q < hi; q++) {
+            F* s = a + q * blk;
+            for (size_t h = 1, st = n / 2; 2 * h <= blk; h <<= 1, st >>= 1)
+                for (size_t b = 0; b < blk; b += 2 * h)
+                    for (size_t j = 0; j < h; j++) { const F x = s[b + j], y = s[b + j + h] * twi[j * st]; s[b + j] = x + y; s[b + j + h] = x - y; }
+        }
+    });
+    for (size_t half = blk, step = n / (2 * blk); half < n; half <<= 1, step >>= 1)
+        pool.run(n / 2, 4096, [&](size_t lo, size_t hi) {
+            for (size_t u = lo; u < hi; u++) {
+                const size_t b = (u / half) * 2 * half, j = u % half;
+                const F x = a[b + j], y = a[b + j + half] * twi[j * step];
+                a[b + j] = x + y; a[b + j + half] = x - y;
+            }
+        });
+    pool.run(n, 4096, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) a[i] = a[i] * ninv; });
 }
 
 struct XorShift { uint64_t s; uint64_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; } };
@@ -59,34 +114,34 @@ template <class F> static F rand_fp(XorShift& r) {
     return x;
 }
 
-// returns wall seconds of one party-0 prove compute at domain size m = 2^log_m; stage[0..3] = spmv+pointwise, ntt, msm_g1, msm_g2
+// One party-0 prove compute at domain size m = 2^log_m.  Returns wall seconds with `threads` workers; stage[0..3] = spmv + pointwise,
+// ntt, msm_g1, msm_g2.  threads_b > 0: the timed region is run a second time with threads_b workers (stage_b, *total_b) on the same
+// inputs; the MSM stages are window-parallel (at most `windows` workers are ever busy, ark-ec msm_bigint), so when both settings
+// have at least that many workers the second run re-times only the other stages and takes the MSM times over (*msm_shared = 1).
 template <class C>
-static double bench_rep3_party(int log_m, int threads, uint64_t seed, double* stage) {
+static double bench_rep3_party(int log_m, int threads, uint64_t seed, double* stage, int threads_b = 0, double* stage_b = nullptr, double* total_b = nullptr, int* msm_shared = nullptr) {
     typedef typename C::Fr Fr; typedef typename C::G1 G1; typedef typename C::G2 G2;
     C::init();
     const size_t m = (size_t)1 << log_m, nc = m - 2, n_aux = m - 2, n_inputs = 2;
     XorShift rng{seed | 1};
-    // ---- untimed setup: bases = consecutive multiples of the generators, CSR matrices, shares
-    auto make_g1 = [&](size_t n, uint64_t first) {
-        std::vector<typename G1::Affine> out(n);
-        uint64_t k[1] = {first};
-        G1 acc = G1::from_affine(C::g1_generator()).mul(k, 1);
-        std::vector<G1> jac(n);
-        for (size_t i = 0; i < n; i++) { jac[i] = acc; acc = acc.add_affine(C::g1_generator()); }
-        std::vector<typename C::Fq> zs(n);
-        for (size_t i = 0; i < n; i++) zs[i] = jac[i].z;
-        batch_inverse(zs.data(), n);
-        parallel_for(n, threads, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) { auto zi2 = zs[i].sqr(); out[i] = {jac[i].x * zi2, jac[i].y * zi2 * zs[i], false}; } });
+    // ---- untimed setup: bases = consecutive multiples of the generators (slices in parallel), CSR matrices, shares
+    const int setup_threads = std::max(threads, threads_b);
+    auto make_table = [&](auto gen_affine, auto jac_tag, size_t n, uint64_t first) {
+        typedef decltype(jac_tag) J;
+        std::vector<typename J::Affine> out(n);
+        parallel_for(n, setup_threads, [&](size_t lo, size_t hi) {
+            if (hi <= lo) return;
+            uint64_t k[1] = {first + lo};
+            J acc = J::from_affine(gen_affine).mul(k, 1);
+            std::vector<J> jac(hi - lo);
+            for (size_t i = lo; i < hi; i++) { jac[i - lo] = acc; acc = acc.add_affine(gen_affine); }
+            for (size_t i = lo; i < hi; i++) out[i] = jac[i - lo].to_affine();
+        });
         return out;
     };
-    auto h_q = make_g1(m, 1), l_q = make_g1(n_aux, 3), a_q = make_g1(n_aux, 5), b1_q = make_g1(n_aux, 7);
-    std::vector<typename G2::Affine> b2_q(n_aux);
-    {
-        G2 acc = G2::from_affine(C::g2_generator());
-        std::vector<G2> jac(n_aux);
-        for (size_t i = 0; i < n_aux; i++) { jac[i] = acc; acc = acc.add_affine(C::g2_generator()); }
-        parallel_for(n_aux, threads, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) b2_q[i] = jac[i].to_affine(); });
-    }
+    auto h_q = make_table(C::g1_generator(), G1::infinity(), m, 1), l_q = make_table(C::g1_generator(), G1::infinity(), n_aux, 3);
+    auto a_q = make_table(C::g1_generator(), G1::infinity(), n_aux, 5), b1_q = make_table(C::g1_generator(), G1::infinity(), n_aux, 7);
+    auto b2_q = make_table(C::g2_generator(), G2::infinity(), n_aux, 1);
     std::vector<uint32_t> rpA(nc + 1), colA(2 * nc), rpB(nc + 1), colB(nc);
     std::vector<Fr> coA(2 * nc), coB(nc);
     for (size_t i = 0; i < nc; i++) {
@@ -99,57 +154,73 @@ static double bench_rep3_party(int log_m, int threads, uint64_t seed, double* st
     std::vector<Fr> pub = {Fr::one(), rand_fp<Fr>(rng)}, wa(n_aux), wb(n_aux), mask1(m), mask2(m), recv1(m), recv2(m);
     for (auto* v : {&wa, &wb, &mask1, &mask2, &recv1, &recv2}) for (auto& x : *v) x = rand_fp<Fr>(rng);
     auto dom = groth16_domain<Fr>((size_t)log_m, nc, n_inputs);
-    std::vector<Fr> tw(m / 2), twi(m / 2), gp(m);
+    std::vector<Fr> tw(m / 2), twi(m / 2);
     { Fr wi = dom.omega.inverse(); tw[0] = twi[0] = Fr::one(); for (size_t i = 1; i < m / 2; i++) { tw[i] = tw[i - 1] * dom.omega; twi[i] = twi[i - 1] * wi; } }
     Fr ninv = Fr::from_u64((uint64_t)m).inverse();
+    const int windows = (Fr::K.bits + ark_window_size(m) - 1) / ark_window_size(m);
 
-    // ---- timed region
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
-    auto t0 = now();
-    std::vector<Fr> aa(m, Fr::zero()), ab(m, Fr::zero()), ba(m, Fr::zero()), bb(m, Fr::zero()), ca(m), cb, ha(m), hb;
-    auto spmv = [&](const std::vector<uint32_t>& rp, const std::vector<uint32_t>& col, const std::vector<Fr>& co, std::vector<Fr>& oa, std::vector<Fr>& ob) {
-        parallel_for(nc, threads, [&](size_t lo, size_t hi) {
-            for (size_t r = lo; r < hi; r++) {
-                Fr xa = Fr::zero(), xb = Fr::zero();
-                for (uint32_t k = rp[r]; k < rp[r + 1]; k++) {
-                    size_t idx = col[k];
-                    if (idx < n_inputs) xa = xa + co[k] * pub[idx];                       // party 0: add_with_public -> component a
-                    else { xa = xa + co[k] * wa[idx - n_inputs]; xb = xb + co[k] * wb[idx - n_inputs]; }
+    auto run = [&](int nthreads, bool with_msm, double* st) {
+        Pool pool(nthreads);
+        auto t0 = now();
+        std::vector<Fr> aa(m, Fr::zero()), ab(m, Fr::zero()), ba(m, Fr::zero()), bb(m, Fr::zero()), ca(m), cb, ha(m), hb;
+        auto spmv = [&](const std::vector<uint32_t>& rp, const std::vector<uint32_t>& col, const std::vector<Fr>& co, std::vector<Fr>& oa, std::vector<Fr>& ob) {
+            pool.run(nc, 1024, [&](size_t lo, size_t hi) {
+                for (size_t r = lo; r < hi; r++) {
+                    Fr xa = Fr::zero(), xb = Fr::zero();
+                    for (uint32_t k = rp[r]; k < rp[r + 1]; k++) {
+                        size_t idx = col[k];
+                        if (idx < n_inputs) xa = xa + co[k] * pub[idx];                       // party 0: add_with_public -> component a
+                        else { xa = xa + co[k] * wa[idx - n_inputs]; xb = xb + co[k] * wb[idx - n_inputs]; }
+                    }
+                    oa[r] = xa; ob[r] = xb;
                 }
-                oa[r] = xa; ob[r] = xb;
-            }
-        });
+            });
+        };
+        spmv(rpA, colA, coA, aa, ab); spmv(rpB, colB, coB, ba, bb);
+        for (size_t i = 0; i < n_inputs; i++) aa[nc + i] = pub[i];
+        auto mul_local = [&](std::vector<Fr>& out, const std::vector<Fr>& mask) {
+            pool.run(m, 1024, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) out[i] = aa[i] * ba[i] + aa[i] * bb[i] + ab[i] * ba[i] + mask[i]; });
+        };
+        mul_local(ca, mask1); cb = recv1;
+        auto t1 = now();
+        auto pipeline = [&](std::vector<Fr>& v) {
+            ntt_inverse_mt(v.data(), m, twi, ninv, pool);
+            Fr pw = Fr::one(); for (auto& x : v) { x = x * pw; pw = pw * dom.coset_g; }        // serial running power, as rep3.rs:681-688
+            ntt_forward_mt(v.data(), m, tw, pool);
+        };
+        pipeline(aa); pipeline(ab); pipeline(ba); pipeline(bb);
+        auto t2 = now();
+        mul_local(ha, mask2); hb = recv2;
+        auto t3 = now();
+        pipeline(ca); pipeline(cb);
+        auto t4 = now();
+        pool.run(m, 1024, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) { ha[i] = ha[i] - ca[i]; hb[i] = hb[i] - cb[i]; } });
+        auto t5 = now();
+        st[0] = secs(t0, t1) + secs(t2, t3) + secs(t4, t5); st[1] = secs(t1, t2) + secs(t3, t4);
+        if (!with_msm) return;
+        G1 acc1 = G1::infinity();
+        auto m1 = [&](const std::vector<typename G1::Affine>& q, const std::vector<Fr>& s, size_t n) { acc1 = acc1.add(msm_pippenger<G1, Fr>(q.data(), s.data(), n, nthreads)); };
+        m1(h_q, ha, m); m1(h_q, hb, m); m1(l_q, wa, n_aux); m1(l_q, wb, n_aux); m1(a_q, wa, n_aux); m1(a_q, wb, n_aux); m1(b1_q, wa, n_aux); m1(b1_q, wb, n_aux);
+        auto t6 = now();
+        G2 acc2 = msm_pippenger<G2, Fr>(b2_q.data(), wa.data(), n_aux, nthreads).add(msm_pippenger<G2, Fr>(b2_q.data(), wb.data(), n_aux, nthreads));
+        auto t7 = now();
+        volatile bool sink = acc1.is_inf() || acc2.is_inf(); (void)sink;
+        st[2] = secs(t5, t6); st[3] = secs(t6, t7);
     };
-    spmv(rpA, colA, coA, aa, ab); spmv(rpB, colB, coB, ba, bb);
-    for (size_t i = 0; i < n_inputs; i++) aa[nc + i] = pub[i];
-    auto mul_local = [&](std::vector<Fr>& out, const std::vector<Fr>& mask) {
-        parallel_for(m, threads, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) out[i] = aa[i] * ba[i] + aa[i] * bb[i] + ab[i] * ba[i] + mask[i]; });
-    };
-    mul_local(ca, mask1); cb = recv1;
-    auto t1 = now();
-    auto pipeline = [&](std::vector<Fr>& v) {
-        ntt_inverse_mt(v.data(), m, twi, ninv, threads);
-        Fr pw = Fr::one(); for (auto& x : v) { x = x * pw; pw = pw * dom.coset_g; }        // serial running power, as rep3.rs:681-688
-        ntt_forward_mt(v.data(), m, tw, threads);
-    };
-    pipeline(aa); pipeline(ab); pipeline(ba); pipeline(bb);
-    auto t2 = now();
-    mul_local(ha, mask2); hb = recv2;
-    auto t3 = now();
-    pipeline(ca); pipeline(cb);
-    auto t4 = now();
-    parallel_for(m, threads, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) { ha[i] = ha[i] - ca[i]; hb[i] = hb[i] - cb[i]; } });
-    auto t5 = now();
-    G1 acc1 = G1::infinity();
-    auto m1 = [&](const std::vector<typename G1::Affine>& q, const std::vector<Fr>& s, size_t n) { acc1 = acc1.add(msm_pippenger<G1, Fr>(q.data(), s.data(), n, threads)); };
-    m1(h_q, ha, m); m1(h_q, hb, m); m1(l_q, wa, n_aux); m1(l_q, wb, n_aux); m1(a_q, wa, n_aux); m1(a_q, wb, n_aux); m1(b1_q, wa, n_aux); m1(b1_q, wb, n_aux);
-    auto t6 = now();
-    G2 acc2 = msm_pippenger<G2, Fr>(b2_q.data(), wa.data(), n_aux, threads).add(msm_pippenger<G2, Fr>(b2_q.data(), wb.data(), n_aux, threads));
-    auto t7 = now();
-    volatile bool sink = acc1.is_inf() || acc2.is_inf(); (void)sink;
-    if (stage) { stage[0] = secs(t0, t1) + secs(t2, t3) + secs(t4, t5); stage[1] = secs(t1, t2) + secs(t3, t4); stage[2] = secs(t5, t6); stage[3] = secs(t6, t7); }
-    return secs(t0, t7);
+    double sa[4] = {0, 0, 0, 0};
+    run(threads, true, sa);
+    if (stage) for (int i = 0; i < 4; i++) stage[i] = sa[i];
+    if (threads_b > 0 && stage_b && total_b) {
+        const bool shared = threads >= windows && threads_b >= windows;
+        double sb2[4] = {0, 0, sa[2], sa[3]};
+        run(threads_b, !shared, sb2);
+        for (int i = 0; i < 4; i++) stage_b[i] = sb2[i];
+        *total_b = sb2[0] + sb2[1] + sb2[2] + sb2[3];
+        if (msm_shared) *msm_shared = shared ? 1 : 0;
+    }
+    return sa[0] + sa[1] + sa[2] + sa[3];
 }
 
 }  // namespace orc

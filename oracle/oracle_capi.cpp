@@ -495,6 +495,35 @@ double orc_bench_rep3_party(int curve, int log_m, int threads, uint64_t seed, do
     } catch (const std::exception& e) { g_err = e.what(); return -2.0; }
 }
 
+// the cache-blocked multi-threaded transforms of the CPU baseline against the plain ones of poly.hpp (1 = identical results)
+int orc_bench_ntt_selfcheck(int curve, int log_n, int threads) {
+    DISPATCH(curve, {
+        typedef typename C::Fr Fr;
+        const size_t n = (size_t)1 << log_n;
+        auto dom = groth16_domain<Fr>((size_t)log_n, n - 2, 2);
+        XorShift rng{77};
+        std::vector<Fr> a(n); for (auto& x : a) x = rand_fp<Fr>(rng);
+        std::vector<Fr> f1 = a, f2 = a, i1 = a, i2 = a;
+        std::vector<Fr> tw(n / 2 ? n / 2 : 1), twi(n / 2 ? n / 2 : 1);
+        Fr wi = dom.omega.inverse(); tw[0] = twi[0] = Fr::one(); for (size_t i = 1; i < n / 2; i++) { tw[i] = tw[i - 1] * dom.omega; twi[i] = twi[i - 1] * wi; }
+        Pool pool(threads);
+        ntt_forward(f1.data(), n, dom.omega); ntt_forward_mt(f2.data(), n, tw, pool);
+        ntt_inverse(i1.data(), n, dom.omega); ntt_inverse_mt(i2.data(), n, twi, Fr::from_u64((uint64_t)n).inverse(), pool);
+        for (size_t i = 0; i < n; i++) if (!(f1[i] == f2[i]) || !(i1[i] == i2[i])) return 0;
+        return 1;
+    });
+    return 1;
+}
+
+// the same with a second thread setting on the same inputs (out: stage_b[4], total_b, msm_shared; see bench.hpp)
+double orc_bench_rep3_party2(int curve, int log_m, int threads, int threads_b, uint64_t seed, double* stage, double* stage_b, double* total_b, int* msm_shared) {
+    try {
+        if (curve == 0) return bench_rep3_party<Bn254>(log_m, threads, seed, stage, threads_b, stage_b, total_b, msm_shared);
+        if (curve == 1) return bench_rep3_party<Bls12_381>(log_m, threads, seed, stage, threads_b, stage_b, total_b, msm_shared);
+        g_err = "bad curve id"; return -1.0;
+    } catch (const std::exception& e) { g_err = e.what(); return -2.0; }
+}
+
 // synthetic satisfiable circuit + valid CRS of domain size 2^log_m written as .zkey / .wtns (test tooling)
 int orc_make_synthetic(int curve, int log_m, uint64_t seed, const char* zkey_path, const char* wtns_path, int threads) {
     DISPATCH(curve, { make_synthetic<C>(log_m, seed, zkey_path, wtns_path, threads); });

@@ -286,6 +286,18 @@ def bench_rep3_party(curve, log_m, threads, seed=1):
     return t, {"spmv_pointwise_s": stage[0], "ntt_s": stage[1], "msm_g1_s": stage[2], "msm_g2_s": stage[3]}
 
 
+def bench_rep3_party2(curve, log_m, threads, threads_b, seed=1):
+    """the same workload timed with two thread settings on the same inputs: (seconds, stages), (seconds_b, stages_b), msm_shared —
+    msm_shared: both settings cover every MSM window, the second run re-timed only the non-MSM stages (oracle/bench.hpp)"""
+    lib().orc_bench_rep3_party2.restype = C.c_double
+    sa, sb, tb, shared = (C.c_double * 4)(), (C.c_double * 4)(), C.c_double(0), C.c_int(0)
+    t = lib().orc_bench_rep3_party2(curve, int(log_m), int(threads), int(threads_b), C.c_uint64(seed), sa, sb, C.byref(tb), C.byref(shared))
+    if t < 0:
+        raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+    names = ("spmv_pointwise_s", "ntt_s", "msm_g1_s", "msm_g2_s")
+    return (t, dict(zip(names, sa))), (tb.value, dict(zip(names, sb))), bool(shared.value)
+
+
 def make_synthetic(curve, log_m, seed, zkey_path, wtns_path, threads=8):
     """synthetic satisfiable R1CS (m - 2 constraints, 1 public input) with a valid Groth16 CRS, as .zkey + .wtns files"""
     _chk(lib().orc_make_synthetic(curve, int(log_m), C.c_uint64(seed), zkey_path.encode(), wtns_path.encode(), int(threads)))

@@ -237,3 +237,11 @@ def test_rep3_prove_three_parties_agree_and_verify(curve_name, circuit):
     r = add(add(streams[0][2 * m], streams[1][2 * m]), streams[2][2 * m])
     s = add(add(streams[0][2 * m + 1], streams[1][2 * m + 1]), streams[2][2 * m + 1])
     np.testing.assert_array_equal(z.prove_plain(w, r, s), proofs[0])
+
+
+@pytest.mark.parametrize("log_n", [1, 4, 14, 15, 16, 18])
+def test_cpu_baseline_transforms_equal_the_plain_ones(log_n):
+    """bench.py's cpu_baseline leg times cache-blocked, multi-threaded transforms (oracle/bench.hpp); they must produce what the
+    plain radix-2 transforms of oracle/poly.hpp produce, below, at and above the block size"""
+    for curve in (orc.BN254, orc.BLS12_381):
+        assert orc.lib().orc_bench_ntt_selfcheck(curve, log_n, 4) == 1
