@@ -46,7 +46,8 @@ ABI_SYMBOLS = [
     "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
     "cg_point_add", "cg_point_neg", "cg_point_scalar_mul", "cg_point_to_affine", "cg_point_from_affine", "cg_fr_op",
     "cg_fr_from_canonical", "cg_fr_to_canonical", "cg_fq_to_canonical", "cg_fq_from_canonical", "cg_point_generator",
-    "cg_bases_synth_multiples", "cg_bases_download",
+    "cg_bases_synth_multiples", "cg_bases_download", "cg_bases_from_scalars",
+    "cg_dev_copy_peer", "cg_ctx_device", "cg_device_count",
     "cg_stats_enable", "cg_stats",
 ]
 
@@ -512,10 +513,14 @@ def host_set_zkey_validation(on):
 class ProvingSession:
     """zkey read, uploaded and (optionally) given per-window precomputed tables once; proofs then cost what co-circom.rs:503-506 times"""
 
-    def __init__(self, curve, zkey_path, precompute=True, device=0, validate=True):
+    def __init__(self, curve, zkey_path, precompute=True, device=0, validate=True, devices=None):
+        """devices: several GPUs of one node for this party (cgh_session_open_multi): devices[0] runs the witness map and slice 0 of
+        every MSM, devices[i] slice i"""
         self.curve, self.info = curve, host_zkey_info(curve, zkey_path)
         h = C.c_void_p()
-        _hchk(load_host().cgh_session_open_ex(int(device), curve, zkey_path.encode(), -1 if precompute is True else int(precompute), C.c_uint32(0 if validate else 1), C.byref(h)))
+        devs = [int(device)] if devices is None else [int(d) for d in devices]
+        arr = (C.c_int32 * len(devs))(*devs)
+        _hchk(load_host().cgh_session_open_multi(arr, len(devs), curve, zkey_path.encode(), -1 if precompute is True else int(precompute), C.c_uint32(0 if validate else 1), C.byref(h)))
         self.h = h
 
     def close(self):

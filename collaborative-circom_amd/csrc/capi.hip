@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <map>
+#include <set>
 #include <mutex>
 #include <vector>
 
@@ -102,7 +103,10 @@ struct cg_ctx {
     // copy streams of the asynchronous host <-> device transfers (cg_dev_*_begin): MPC exchanges move under the compute
     static constexpr int COPY_TICKETS = 256;
     hipStream_t h2d = nullptr, d2h = nullptr;
-    hipEvent_t copy_ev[COPY_TICKETS] = {}; hipEvent_t ev_copy_order = nullptr; uint32_t copy_next = 0;
+    // ticket = running copy number (31 bits); slot = ticket % COPY_TICKETS holds its event.  A slot is recycled only after its
+    // previous copy has completed (copy_begin waits for it), so a ticket older than the slot's current owner names a finished copy.
+    hipEvent_t copy_ev[COPY_TICKETS] = {}; uint32_t copy_id[COPY_TICKETS] = {}; hipEvent_t ev_copy_order = nullptr; uint32_t copy_next = 0;
+    hipEvent_t ev_peer = nullptr;                         // cg_dev_copy_peer: "source stream reached this point"
     Arena arena;
     std::vector<void*> retired;                        // outgrown arena blocks that enqueued kernels may still use
     void* gather_buf = nullptr; size_t gather_cap = 0;   // scalars gathered for compacted tables (see cg_bases::compact)
@@ -764,6 +768,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     if (ctx->h2d) {
         hipStreamSynchronize(ctx->h2d); hipStreamSynchronize(ctx->d2h);
         for (hipEvent_t e : ctx->copy_ev) if (e) hipEventDestroy(e);
+        if (ctx->ev_peer) hipEventDestroy(ctx->ev_peer);
         hipEventDestroy(ctx->ev_copy_order);
         park_stream(ctx->device, false, ctx->h2d); park_stream(ctx->device, false, ctx->d2h);
     }
@@ -853,10 +858,12 @@ static int32_t copy_begin(cg_ctx* ctx, bool up, void* dst, const void* src, size
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_copy_order, 0));
     }
     if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, kind, st));
-    const uint32_t slot = ctx->copy_next++ % cg_ctx::COPY_TICKETS;
+    const uint32_t id = ctx->copy_next++ & 0x7fffffffu, slot = id % cg_ctx::COPY_TICKETS;
     if (!ctx->copy_ev[slot]) HIPCHK(hipEventCreateWithFlags(&ctx->copy_ev[slot], hipEventDisableTiming));
+    else HIPCHK(hipEventSynchronize(ctx->copy_ev[slot]));     // the copy that owned the slot 256 copies ago (long finished in practice)
     HIPCHK(hipEventRecord(ctx->copy_ev[slot], st));
-    *ticket = (int32_t)slot;
+    ctx->copy_id[slot] = id;
+    *ticket = (int32_t)id;
     return 0;
 }
 int32_t cg_dev_download_begin(cg_ctx* ctx, void* h_dst_pinned, const void* d_src, size_t bytes, int32_t* ticket) {
@@ -866,15 +873,44 @@ int32_t cg_dev_upload_begin(cg_ctx* ctx, void* d_dst, const void* h_src_pinned, 
     return copy_begin(ctx, true, d_dst, h_src_pinned, bytes, hipMemcpyHostToDevice, after_stream != 0, ticket);
 }
 int32_t cg_copy_wait(cg_ctx* ctx, int32_t ticket) {
-    if (!ctx || ticket < 0 || ticket >= cg_ctx::COPY_TICKETS || !ctx->copy_ev[ticket]) return fail(CG_ERR_ARG, "bad copy ticket");
-    HIPCHK(hipEventSynchronize(ctx->copy_ev[ticket]));
+    if (!ctx || ticket < 0 || !ctx->copy_ev[ticket % cg_ctx::COPY_TICKETS]) return fail(CG_ERR_ARG, "bad copy ticket");
+    const int slot = ticket % cg_ctx::COPY_TICKETS;
+    if (ctx->copy_id[slot] != (uint32_t)ticket) return 0;       // recycled since: that copy completed before the slot was reused
+    HIPCHK(hipEventSynchronize(ctx->copy_ev[slot]));
     return 0;
 }
 int32_t cg_copy_fence(cg_ctx* ctx, int32_t ticket) {
-    if (!ctx || ticket < 0 || ticket >= cg_ctx::COPY_TICKETS || !ctx->copy_ev[ticket]) return fail(CG_ERR_ARG, "bad copy ticket");
-    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->copy_ev[ticket], 0));
+    if (!ctx || ticket < 0 || !ctx->copy_ev[ticket % cg_ctx::COPY_TICKETS]) return fail(CG_ERR_ARG, "bad copy ticket");
+    const int slot = ticket % cg_ctx::COPY_TICKETS;
+    if (ctx->copy_id[slot] != (uint32_t)ticket) return 0;       // recycled since: that copy completed before the slot was reused
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->copy_ev[slot], 0));
     return 0;
 }
+// device -> device between two contexts (same or different GPUs): enqueued on the destination context's stream behind everything the
+// source context's stream holds so far.  Different devices: peer access is switched on at first use (xGMI), hipMemcpyPeerAsync.
+int32_t cg_dev_copy_peer(cg_ctx* dst, void* d_dst, cg_ctx* src, const void* d_src, size_t bytes) {
+    if (!dst || !src || ((!d_dst || !d_src) && bytes)) return fail(CG_ERR_ARG, "null argument");
+    if (!src->ev_peer) { HIPCHK(hipSetDevice(src->device)); HIPCHK(hipEventCreateWithFlags(&src->ev_peer, hipEventDisableTiming)); }
+    HIPCHK(hipSetDevice(src->device));
+    HIPCHK(hipEventRecord(src->ev_peer, src->stream));
+    HIPCHK(hipSetDevice(dst->device));
+    HIPCHK(hipStreamWaitEvent(dst->stream, src->ev_peer, 0));
+    if (!bytes) return 0;
+    if (dst->device == src->device) { HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, dst->stream)); return 0; }
+    {
+        static std::mutex mu; static std::set<std::pair<int, int>> enabled;
+        std::lock_guard<std::mutex> l(mu);
+        if (!enabled.count({dst->device, src->device})) {
+            int can = 0; HIPCHK(hipDeviceCanAccessPeer(&can, dst->device, src->device));
+            if (can) { hipError_t e = hipDeviceEnablePeerAccess(src->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCHK(e); (void)hipGetLastError(); }
+            enabled.insert({dst->device, src->device});      // without peer access the runtime stages the copy through the host
+        }
+    }
+    HIPCHK(hipMemcpyPeerAsync(d_dst, dst->device, d_src, src->device, bytes, dst->stream));
+    return 0;
+}
+int32_t cg_ctx_device(const cg_ctx* ctx) { return ctx ? ctx->device : -1; }
+int32_t cg_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 int32_t cg_dev_memset_zero(cg_ctx* ctx, void* d_dst, size_t bytes) {
     if (!ctx) return fail(CG_ERR_ARG, "null ctx");
     HIPCHK(hipMemsetAsync(d_dst, 0, bytes, ctx->stream));

@@ -366,7 +366,12 @@ struct DeviceZKey {   // bases uploaded once and reused by every proof / party (
     DeviceMatrix mat[2] = {{nullptr, nullptr, nullptr, 0}, {nullptr, nullptr, nullptr, 0}};
     void* pub_dev = nullptr;
     cg_ctx* owner = nullptr;
+    // several GPUs: this device holds the records [aux_lo, aux_lo + aux_n) of the four private-witness queries (counted
+    // from the first private variable) and [h_lo, h_lo + h_n) of h_query, registered as tables of their own (offset 0)
+    bool sliced = false; size_t aux_lo = 0, aux_n = 0, h_lo = 0, h_n = 0;
 };
+struct WorkerDevice { cg_ctx* ctx = nullptr; const DeviceZKey* dz = nullptr; };     // one further GPU of a party: a context on it + its table slices
+struct MultiDevice { std::vector<WorkerDevice> workers; };
 
 enum class Mode { Plain, Rep3, Shamir };
 
@@ -922,7 +927,45 @@ public:
     // (groth16.rs:251,267,284,298) share one scalar decomposition and run on a second context (`aux`, own streams) while the witness
     // map and its exchanges occupy the first.  MSMs involve no network, so the party-to-party message order is the reference's.
     cg_ctx* aux = nullptr; bool owns_aux = true;       // a session lends its contexts (owns_aux = false)
-    struct PendingMsm { cg_ctx* on = nullptr; std::vector<int32_t> tickets; std::vector<int> groups; };
+    struct PendingMsm {
+        cg_ctx* on = nullptr; std::vector<int32_t> tickets; std::vector<int> groups;
+        struct Part { cg_ctx* on; std::vector<int32_t> tickets; void* sc[2]; };     // the same MSMs over the slices held by further GPUs
+        std::vector<Part> parts;
+    };
+    // Several GPUs: every MSM range is cut into one contiguous slice per device (the primary context's device holds slice 0); the scalar
+    // slices travel device to device (cg_dev_copy_peer, xGMI), each device runs the bucket method on its slice, and the partial sums
+    // — one Jacobian point per table, component and device — are added on the host (RCCL has no EC-add reduction, and a few hundred
+    // bytes per proof need no collective).  MSMProvider::msm_public_points (rep3.rs:934-947) is linear in the (scalar, point) pairs.
+    const MultiDevice* md = nullptr;
+    PendingMsm msm_begin_sharded(const DeviceZKey& dz, bool aux_tables, const ShareVec& s) {
+        const size_t lo = aux_tables ? dz.aux_lo : dz.h_lo, n = aux_tables ? dz.aux_n : dz.h_n;
+        ShareVec mine; mine.n = n; for (int j = 0; j < k(); j++) mine.c[j] = (char*)s.c[j] + lo * 32;
+        PendingMsm p = aux_tables ? msm_begin_multi({dz.l, dz.a, dz.b1, dz.b2}, {0, 0, 0, 0}, {CG_G1, CG_G1, CG_G1, CG_G2}, n, mine, true)
+                                  : msm_begin_multi({dz.h}, {0}, {CG_G1}, n, mine, false);
+        if (!md) return p;
+        static const bool primary_only = getenv("CGH_EMULATE_PRIMARY_ONLY") != nullptr;    // planning knob: time the primary device's share of an
+        if (primary_only) return p;                                                       // N-device proof on one GPU (the proof is then wrong)
+        for (const WorkerDevice& w : md->workers) {
+            const DeviceZKey& wz = *w.dz;
+            const size_t wlo = aux_tables ? wz.aux_lo : wz.h_lo, wn = aux_tables ? wz.aux_n : wz.h_n;
+            PendingMsm::Part part{w.ctx, {}, {nullptr, nullptr}};
+            for (int j = 0; j < k(); j++) {
+                CG(cg_dev_alloc(w.ctx, std::max<size_t>(wn * 32, 32), &part.sc[j]));
+                CG(cg_dev_copy_peer(w.ctx, part.sc[j], ctx, (const char*)s.c[j] + wlo * 32, wn * 32));
+            }
+            std::vector<const cg_bases*> tabs = aux_tables ? std::vector<const cg_bases*>{wz.l, wz.a, wz.b1, wz.b2} : std::vector<const cg_bases*>{wz.h};
+            std::vector<size_t> offs(tabs.size(), 0);
+            part.tickets.resize(tabs.size());
+            const void* sc[2] = {part.sc[0], part.sc[1]};
+            CG(cg_msm_dev_begin_multi(w.ctx, (int32_t)tabs.size(), tabs.data(), offs.data(), wn, sc, k(), part.tickets.data()));
+            p.parts.push_back(part);
+        }
+        return p;
+    }
+    void msm_release(PendingMsm& p) {      // after the last msm_finish: the slices' scalar copies
+        for (auto& part : p.parts) for (int j = 0; j < 2; j++) if (part.sc[j]) { cg_dev_free(part.on, part.sc[j]); part.sc[j] = nullptr; }
+        p.parts.clear();
+    }
     PendingMsm msm_begin_multi(const std::vector<const cg_bases*>& tables, const std::vector<size_t>& offsets, const std::vector<int>& groups, size_t n, const ShareVec& s, bool on_aux) {
         PendingMsm p; p.on = on_aux && aux ? aux : ctx; p.groups = groups; p.tickets.resize(tables.size());
         const void* sc[2] = {s.c[0], s.c[1]};
@@ -936,6 +979,10 @@ public:
         CG(cg_msm_end(p.on, p.tickets[i], out.data()));
         PointShare r;
         for (int j = 0; j < k(); j++) r.c[j] = Point{Bytes(out.begin() + j * curve.jac(group), out.begin() + (j + 1) * curve.jac(group)), group};
+        for (auto& part : p.parts) {                                                    // slices on further GPUs: fold the partial sums
+            CG(cg_msm_end(part.on, part.tickets[i], out.data()));
+            for (int j = 0; j < k(); j++) r.c[j] = pt_add(curve, r.c[j], Point{Bytes(out.begin() + j * curve.jac(group), out.begin() + (j + 1) * curve.jac(group)), group});
+        }
         if (k() == 1) r.c[1] = pt_inf(curve, group);
         return r;
     }
@@ -1071,10 +1118,11 @@ public:
         std::vector<Fr> input_assignment(public_inputs.begin() + 1, public_inputs.end());
         const size_t first_aux = 1 + input_assignment.size();
         // l (:251), a (:267 -> :221), b1 (:284), b2 (:298): one call, one scalar schedule, on the second context
-        auto aux_msm = driver.msm_begin_multi({dz.l, dz.a, dz.b1, dz.b2}, {0, first_aux, first_aux, first_aux}, {CG_G1, CG_G1, CG_G1, CG_G2}, private_witness.n, private_witness, true);
+        auto aux_msm = dz.sliced ? driver.msm_begin_sharded(dz, true, private_witness)
+                                 : driver.msm_begin_multi({dz.l, dz.a, dz.b1, dz.b2}, {0, first_aux, first_aux, first_aux}, {CG_G1, CG_G1, CG_G1, CG_G2}, private_witness.n, private_witness, true);
         ShareVec h = witness_map_from_matrices(dz, public_inputs, private_witness);
         mk.mark("witness map");
-        auto h_msm = driver.msm_begin_multi({dz.h}, {0}, {CG_G1}, h.n, h, false);                      // :248
+        auto h_msm = dz.sliced ? driver.msm_begin_sharded(dz, false, h) : driver.msm_begin_multi({dz.h}, {0}, {CG_G1}, h.n, h, false);   // :248
         FieldShare r = rs_plain ? rs_plain[0] : driver.rand();                                         // :134-135
         FieldShare s = rs_plain ? rs_plain[1] : driver.rand();
         PointShare h_acc = driver.msm_finish(h_msm, 0);
@@ -1101,6 +1149,7 @@ public:
         mk.mark("msm a, b1, b2 + scalar steps");
         auto opened = driver.open_two_points(g_c, g2_b);                                               // :316
         mk.mark("open");
+        driver.msm_release(aux_msm); driver.msm_release(h_msm);
         if (h_out) *h_out = h; else driver.free_vec(h);
         return Proof{pt_to_affine(c, g_a_opened), pt_to_affine(c, opened.second), pt_to_affine(c, opened.first)};   // :319-325
     }
@@ -1128,7 +1177,14 @@ static bool validate_by_default() {
 }
 struct DeviceZKeyGuard;
 static void release_zkey(cg_ctx* ctx, DeviceZKey& d);
-static DeviceZKey upload_zkey(cg_ctx* ctx, const ZKey& z, const std::vector<Fr>& public_inputs, int validate_flag = -1) {
+// slice `rank` of `world` of a range of n items (sizes differ by at most one)
+static std::pair<size_t, size_t> slice_of(size_t n, int rank, int world) {
+    const size_t base = n / world, rem = n % world, lo = (size_t)rank * base + std::min<size_t>((size_t)rank, rem);
+    return {lo, lo + base + ((size_t)rank < rem ? 1 : 0)};
+}
+// rank/world: this device's share of a party's GPUs (world == 1: the whole zkey).  Rank 0 also holds the constraint matrices (the
+// witness map runs there); every rank holds slice `rank` of the five queries.
+static DeviceZKey upload_zkey(cg_ctx* ctx, const ZKey& z, const std::vector<Fr>& public_inputs, int validate_flag = -1, int rank = 0, int world = 1) {
     const bool validate = validate_flag < 0 ? validate_by_default() : validate_flag != 0;
     DeviceZKey d; d.z = &z; d.owner = ctx;
     struct Undo { cg_ctx* c; DeviceZKey* d; bool armed = true; ~Undo() { if (armed) release_zkey(c, *d); } } undo{ctx, &d};   // a failing table must not leak the ones before it
@@ -1138,14 +1194,29 @@ static DeviceZKey upload_zkey(cg_ctx* ctx, const ZKey& z, const std::vector<Fr>&
         if (validate) { try { validate_bases(ctx, b, name); } catch (...) { cg_bases_release(b); throw; } }
         return b;
     };
-    if (validate) {   // the O(1) verifying-key points and IC go through the same kernels
+    if (validate && rank == 0) {   // the O(1) verifying-key points and IC go through the same kernels
         Bytes g1 = z.alpha_g1; g1.insert(g1.end(), z.beta_g1.begin(), z.beta_g1.end()); g1.insert(g1.end(), z.delta_g1.begin(), z.delta_g1.end()); g1.insert(g1.end(), z.ic.begin(), z.ic.end());
         Bytes g2 = z.beta_g2; g2.insert(g2.end(), z.gamma_g2.begin(), z.gamma_g2.end()); g2.insert(g2.end(), z.delta_g2.begin(), z.delta_g2.end());
         cg_bases_release(reg(g1, CG_G1, "vk_g1/ic")); cg_bases_release(reg(g2, CG_G2, "vk_g2"));
     }
-    d.a = reg(z.a_query, CG_G1, "a_query"); d.b1 = reg(z.b_g1_query, CG_G1, "b_g1_query"); d.b2 = reg(z.b_g2_query, CG_G2, "b_g2_query");
-    d.l = reg(z.l_query, CG_G1, "l_query"); d.h = reg(z.h_query, CG_G1, "h_query");
     auto up = [&](const void* src, size_t bytes) { void* p; CG(cg_dev_alloc(ctx, bytes, &p)); if (bytes) CG(cg_dev_upload(ctx, p, src, bytes)); return p; };
+    if (world > 1) {
+        const size_t first_aux = z.n_public + 1, n_aux = z.n_vars - first_aux;
+        const auto ar = slice_of(n_aux, rank, world), hr = slice_of(z.domain_size, rank, world);
+        d.sliced = true; d.aux_lo = ar.first; d.aux_n = ar.second - ar.first; d.h_lo = hr.first; d.h_n = hr.second - hr.first;
+        auto cut = [&](const View& v, int group, size_t first, size_t count) { return View{v.data() + first * c.aff(group), count * c.aff(group)}; };
+        if (validate && rank == 0) {   // the public-input records of a, b1, b2 stay on the host (calculate_coeff): checked here once
+            cg_bases_release(reg(cut(z.a_query, CG_G1, 0, first_aux), CG_G1, "a_query")); cg_bases_release(reg(cut(z.b_g1_query, CG_G1, 0, first_aux), CG_G1, "b_g1_query"));
+            cg_bases_release(reg(cut(z.b_g2_query, CG_G2, 0, first_aux), CG_G2, "b_g2_query"));
+        }
+        d.a = reg(cut(z.a_query, CG_G1, first_aux + d.aux_lo, d.aux_n), CG_G1, "a_query"); d.b1 = reg(cut(z.b_g1_query, CG_G1, first_aux + d.aux_lo, d.aux_n), CG_G1, "b_g1_query");
+        d.b2 = reg(cut(z.b_g2_query, CG_G2, first_aux + d.aux_lo, d.aux_n), CG_G2, "b_g2_query");
+        d.l = reg(cut(z.l_query, CG_G1, d.aux_lo, d.aux_n), CG_G1, "l_query"); d.h = reg(cut(z.h_query, CG_G1, d.h_lo, d.h_n), CG_G1, "h_query");
+        if (rank != 0) { undo.armed = false; return d; }
+    } else {
+        d.a = reg(z.a_query, CG_G1, "a_query"); d.b1 = reg(z.b_g1_query, CG_G1, "b_g1_query"); d.b2 = reg(z.b_g2_query, CG_G2, "b_g2_query");
+        d.l = reg(z.l_query, CG_G1, "l_query"); d.h = reg(z.h_query, CG_G1, "h_query");
+    }
     for (int m = 0; m < 2; m++) {
         d.mat[m].row_ptr = (uint32_t*)up(z.row_ptr[m].data(), z.row_ptr[m].size() * 4);
         d.mat[m].col = (uint32_t*)up(z.col[m].data(), z.col[m].size() * 4);
@@ -2332,28 +2403,31 @@ int32_t cgh_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, con
 // ---- proving sessions: the zkey is read, uploaded (and optionally given per-window precomputed tables) ONCE; proofs then cost
 // what co-circom.rs:503-506 times.  A zkey is fixed for the life of a prover process (zkey.rs:48-71).
 struct cgh_session {
-    cgh::ZKey z; cg_ctx* ctx0 = nullptr; cgh::DeviceZKey dz; int device = 0; bool second_context = false;
-    // contexts are kept between proofs: their scratch arenas (GBs at 2^22) are allocated once
-    std::mutex mu; std::vector<cg_ctx*> idle;
-    cg_ctx* take() {
-        { std::lock_guard<std::mutex> l(mu); if (!idle.empty()) { cg_ctx* c = idle.back(); idle.pop_back(); return c; } }
-        cg_ctx* c = nullptr; if (cg_ctx_create(device, &c)) cgh::die("cg_ctx_create"); return c;
+    cgh::ZKey z; int device = 0; bool second_context = false;
+    // one entry per GPU of the party (a plain session has one): the context the tables were registered with and the tables / table
+    // slices it holds.  Contexts for proofs are kept between proofs, per device: their scratch arenas (GBs at 2^22) are allocated once
+    std::vector<int> devices; std::vector<cg_ctx*> ctx0; std::vector<cgh::DeviceZKey> dzs;
+    cg_ctx*& ctx0_ref() { return ctx0[0]; }
+    std::mutex mu; std::vector<std::vector<cg_ctx*>> idle;
+    cg_ctx* take(int slot = 0) {
+        { std::lock_guard<std::mutex> l(mu); if (!idle[slot].empty()) { cg_ctx* c = idle[slot].back(); idle[slot].pop_back(); return c; } }
+        cg_ctx* c = nullptr; if (cg_ctx_create(devices[slot], &c)) cgh::die("cg_ctx_create"); return c;
     }
-    void give(cg_ctx* c) { if (!c) return; cg_ctx_sync(c); std::lock_guard<std::mutex> l(mu); idle.push_back(c); }
+    void give(cg_ctx* c, int slot = 0) { if (!c) return; cg_ctx_sync(c); std::lock_guard<std::mutex> l(mu); idle[slot].push_back(c); }
 };
 namespace {
 // a context borrowed from the session: returned to the pool on success, destroyed when the proof failed (its streams may hold
 // half-finished work)
 struct Borrowed {
-    cgh_session* s; cg_ctx* c = nullptr; bool ok = false;
-    Borrowed(cgh_session* ses, bool wanted = true) : s(ses) { if (wanted) c = ses->take(); }
-    ~Borrowed() { if (!c) return; if (ok) s->give(c); else cg_ctx_destroy(c); }
+    cgh_session* s; cg_ctx* c = nullptr; bool ok = false; int slot;
+    Borrowed(cgh_session* ses, bool wanted = true, int device_slot = 0) : s(ses), slot(device_slot) { if (wanted) c = ses->take(slot); }
+    ~Borrowed() { if (!c) return; if (ok) s->give(c, slot); else cg_ctx_destroy(c); }
     Borrowed(const Borrowed&) = delete; Borrowed& operator=(const Borrowed&) = delete;
 };
 // the zkey tables of the session with this proof's own public-input buffer (several proofs may run on one session at a time)
 struct ProofZKey {
     cg_ctx* ctx; cgh::DeviceZKey dz;
-    ProofZKey(cgh_session* s, cg_ctx* on, const std::vector<cgh::Fr>& pub) : ctx(on), dz(s->dz) {
+    ProofZKey(cgh_session* s, cg_ctx* on, const std::vector<cgh::Fr>& pub) : ctx(on), dz(s->dzs[0]) {
         using namespace cgh;
         dz.pub_dev = nullptr;
         CG(cg_dev_alloc(ctx, pub.size() * 32, &dz.pub_dev));
@@ -2362,34 +2436,58 @@ struct ProofZKey {
     ~ProofZKey() { if (dz.pub_dev) cg_dev_free(ctx, dz.pub_dev); }
     ProofZKey(const ProofZKey&) = delete; ProofZKey& operator=(const ProofZKey&) = delete;
 };
+// the further GPUs of a multi-device session for one proof: a borrowed context per device, bound to that device's table slices
+struct ProofWorkers {
+    std::vector<std::unique_ptr<Borrowed>> ctxs; cgh::MultiDevice md;
+    explicit ProofWorkers(cgh_session* s) {
+        for (size_t d = 1; d < s->devices.size(); d++) {
+            ctxs.emplace_back(new Borrowed(s, true, (int)d));
+            md.workers.push_back(cgh::WorkerDevice{ctxs.back()->c, &s->dzs[d]});
+        }
+    }
+    const cgh::MultiDevice* get() const { return md.workers.empty() ? nullptr : &md; }
+    void ok() { for (auto& b : ctxs) b->ok = true; }
+};
+void session_destroy(cgh_session* s) {
+    if (!s) return;
+    for (auto& pool : s->idle) for (cg_ctx* c : pool) cg_ctx_destroy(c);
+    for (size_t d = 0; d < s->ctx0.size(); d++) if (s->ctx0[d]) { cgh::release_zkey(s->ctx0[d], s->dzs[d]); cg_ctx_destroy(s->ctx0[d]); }
+    delete s;
 }
-// flags: bit 0 = skip the point validation (the file was validated before, cgh_zkey_validate)
-int32_t cgh_session_open_ex(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, uint32_t flags, void** out) {
+}
+// Several GPUs of one node for one party: devices[0] runs the witness map and slice 0 of every MSM, devices[i]
+// slice i (table slices registered, validated and given their window tables on their own device); partial sums are folded on the
+// host.  The prove calls below work on either kind of session.  The same device may be listed more than once (tests).
+int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t curve, const char* zkey_path, int32_t precompute, uint32_t flags, void** out) {
     cgh_session* s = nullptr;
     try {
         using namespace cgh;
-        s = new cgh_session(); s->device = device;
+        if (!devices || n_dev < 1 || n_dev > 64) throw std::runtime_error("cgh_session_open_multi: bad device list");
+        s = new cgh_session(); s->device = devices[0];
+        s->devices.assign(devices, devices + n_dev); s->ctx0.assign(n_dev, nullptr); s->dzs.resize(n_dev); s->idle.resize(n_dev);
         s->z = read_zkey(curve, zkey_path);
-        if (cg_ctx_create(device, &s->ctx0)) die("cg_ctx_create");
         std::vector<Fr> pub(s->z.n_public + 1);
-        s->dz = upload_zkey(s->ctx0, s->z, pub, (flags & 1u) ? 0 : -1);
-        if (precompute) for (cg_bases* b : {s->dz.a, s->dz.b1, s->dz.b2, s->dz.l, s->dz.h}) CG(cg_bases_precompute(s->ctx0, b, precompute > 0 ? precompute : 0));
-        CG(cg_ctx_sync(s->ctx0));
+        for (int d = 0; d < n_dev; d++) {
+            if (cg_ctx_create(devices[d], &s->ctx0[d])) die("cg_ctx_create");
+            s->dzs[d] = upload_zkey(s->ctx0[d], s->z, pub, (flags & 1u) ? 0 : -1, d, n_dev);
+            s->dzs[d].z = &s->z;
+        }
+        if (precompute) for (int d = 0; d < n_dev; d++) for (cg_bases* b : {s->dzs[d].a, s->dzs[d].b1, s->dzs[d].b2, s->dzs[d].l, s->dzs[d].h})
+            if (cg_bases_len(b)) CG(cg_bases_precompute(s->ctx0[d], b, precompute > 0 ? precompute : 0));
+        for (int d = 0; d < n_dev; d++) CG(cg_ctx_sync(s->ctx0[d]));
         s->second_context = s->z.n_vars >= ((size_t)1 << 19) && !getenv("CGH_ONE_CONTEXT");
         *out = s;
         return 0;
-    } catch (const std::exception& e) { g_host_err = e.what(); if (s) { if (s->ctx0) { cgh::release_zkey(s->ctx0, s->dz); cg_ctx_destroy(s->ctx0); } delete s; } return 1; }
+    } catch (const std::exception& e) { g_host_err = e.what(); session_destroy(s); return 1; }
+}
+// flags: bit 0 = skip the point validation (the file was validated before, cgh_zkey_validate)
+int32_t cgh_session_open_ex(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, uint32_t flags, void** out) {
+    return cgh_session_open_multi(&device, 1, curve, zkey_path, precompute, flags, out);
 }
 int32_t cgh_session_open(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, void** out) {
     return cgh_session_open_ex(device, curve, zkey_path, precompute, 0, out);
 }
-int32_t cgh_session_close(void* h) {
-    cgh_session* s = (cgh_session*)h;
-    if (!s) return 0;
-    for (cg_ctx* c : s->idle) cg_ctx_destroy(c);
-    cgh::release_zkey(s->ctx0, s->dz); cg_ctx_destroy(s->ctx0); delete s;
-    return 0;
-}
+int32_t cgh_session_close(void* h) { session_destroy((cgh_session*)h); return 0; }
 // plain driver on an open session; seconds[0] (optional) = wall time of the prove
 int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uint64_t* r, const uint64_t* sc, uint64_t* out_proof, double* seconds) {
     cgh_session* s = (cgh_session*)h;
@@ -2399,11 +2497,12 @@ int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uin
         const Fr* w = (const Fr*)full_witness;
         std::vector<Fr> pub(w, w + z.n_public + 1);
         Borrowed ctx(s), second(s, s->second_context);
+        ProofWorkers workers(s);
         ProofZKey pz(s, ctx.c, pub);
         const auto t0 = std::chrono::steady_clock::now();
         {
             HipDriver driver(ctx.c, z.curve, Mode::Plain, nullptr);
-            driver.aux = second.c; driver.owns_aux = false;
+            driver.aux = second.c; driver.owns_aux = false; driver.md = workers.get();
             VecGuard wit(driver, driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_public - 1));
             FieldShare rs[2]; memcpy(rs[0].c[0].v, r, 32); rs[0].c[1] = rs[0].c[0]; memcpy(rs[1].c[0].v, sc, 32); rs[1].c[1] = rs[1].c[0];
             CoGroth16 prover(driver);
@@ -2411,7 +2510,7 @@ int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uin
             if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             store_proof(p, (uint8_t*)out_proof);
         }
-        ctx.ok = second.ok = true;
+        ctx.ok = second.ok = true; workers.ok();
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
@@ -2428,17 +2527,18 @@ int32_t cgh_session_prove_rep3(void* h, const uint64_t* pub_in, const uint64_t* 
         std::deque<Bytes> rec_prev, rec_next;
         auto party = [&](int i, Rep3Network* net, uint8_t* out) {
             Borrowed ctx(s), second(s, s->second_context);
+            ProofWorkers workers(s);
             ProofZKey pz(s, ctx.c, pub);
             {
                 HipDriver driver(ctx.c, z.curve, Mode::Rep3, net);
-                driver.aux = second.c; driver.owns_aux = false;
+                driver.aux = second.c; driver.owns_aux = false; driver.md = workers.get();
                 driver.rng1 = (const Fr*)streams[i]; driver.rng2 = (const Fr*)streams[(i + 2) % 3]; driver.rng_len = stream_len;
                 VecGuard wit(driver, driver.upload_vec((const Fr*)wit_a[i], (const Fr*)wit_b[i], n_aux));
                 CoGroth16 prover(driver);
                 Proof p = prover.prove(pz.dz, pub, wit.v, nullptr, nullptr);
                 store_proof(p, out);
             }
-            ctx.ok = second.ok = true;
+            ctx.ok = second.ok = true; workers.ok();
         };
         InProcHub hub;
         std::string errs[3];

@@ -57,6 +57,12 @@ int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr);
 int32_t cg_dev_upload(cg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);     /* synchronous */
 int32_t cg_dev_download(cg_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* synchronous */
 int32_t cg_dev_memset_zero(cg_ctx* ctx, void* d_dst, size_t bytes);
+/* Several GPUs of one node: one context per device; a party's prover splits each MSM range over its contexts and
+ * moves scalar slices with this copy — device to device between two contexts, enqueued on the DESTINATION context's stream behind
+ * everything the source context's stream holds so far (xGMI peer copy between different devices).  cg_device_count() = visible GPUs. */
+int32_t cg_dev_copy_peer(cg_ctx* dst, void* d_dst, cg_ctx* src, const void* d_src, size_t bytes);
+int32_t cg_ctx_device(const cg_ctx* ctx);
+int32_t cg_device_count(void);
 /* Page-locked staging buffers and asynchronous copies on the context's two copy streams, so that the MPC exchanges of mul_vec
  * (rep3.rs:650-670) and degree_reduce_vec (shamir.rs:302-384) can move in chunks under the compute.
  *   download_begin: the copy is ordered after everything enqueued on the context's stream so far.

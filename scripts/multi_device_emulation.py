@@ -1,0 +1,34 @@
+"""Critical path of the PRIMARY device of an N-GPU proving session, timed on one GPU (no multi-GPU box here): the session is opened
+over N contexts on GPU 0 and CGH_EMULATE_PRIMARY_ONLY makes the further devices' MSM slices no-ops, so that the timed proof is what
+device 0 of N does — witness map, its table slices, folding — while the others would work beside it (their share is never larger).
+usage: CGH_EMULATE_PRIMARY_ONLY=1 python scripts/multi_device_emulation.py [log_m=22] [worlds=1,2,4,8]"""
+import importlib, os, sys, tempfile, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+cg = importlib.import_module("collaborative-circom_amd")
+import bench
+log_m = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+worlds = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,2,4,8").split(",")]
+assert os.environ.get("CGH_EMULATE_PRIMARY_ONLY") or worlds == [1], "set CGH_EMULATE_PRIMARY_ONLY=1 (otherwise all slices run on the one GPU)"
+dev = torch.device("cuda", 0); ctx = cg.Context(0)
+d = tempfile.mkdtemp(); zp, wp = os.path.join(d, "s.zkey"), os.path.join(d, "s.wtns")
+cg.host_synth_circuit(cg.BN254, log_m, 5, zp, wp)
+w = cg.host_read_wtns(cg.BN254, wp); m = 1 << log_m; n_aux = m - 2
+g = torch.Generator(device=dev); g.manual_seed(1)
+host = lambda t: t.cpu().numpy().view(np.uint64)
+r, s = host(bench.rand_fr(2, dev, g))
+da, db = bench.rand_fr(n_aux, dev, g), bench.rand_fr(n_aux, dev, g)
+dw = torch.from_numpy(np.ascontiguousarray(w[2:]).view(np.int64)).to(dev); dc = torch.empty_like(dw)
+ctx.vec_sub(cg.BN254, dc, dw, da, n_aux); ctx.vec_sub(cg.BN254, dc, dc, db, n_aux); ctx.sync()
+pin = lambda x: (lambda p: (p.__setitem__(slice(None), x), p)[1])(ctx.host_alloc(x.shape))
+a, b, c = pin(host(da)), pin(host(db)), pin(host(dc))
+streams = [pin(host(bench.rand_fr(2 * m + 4, dev, g))) for _ in range(3)]
+del da, db, dc, dw
+for world in worlds:
+    ses = cg.ProvingSession(cg.BN254, zp, precompute=True, devices=[0] * world, validate=False)
+    ses.prove_plain(w, r, s)
+    tp = min(ses.prove_plain(w, r, s)[1] for _ in range(3))
+    ses.prove_rep3(w[:2], [a, b, c], [c, a, b], streams, solo=False)
+    t1 = min(ses.prove_rep3(w[:2], [a, b, c], [c, a, b], streams)[2] for _ in range(2))
+    ses.close()
+    print(f"2^{log_m}, {world} device(s), primary device only: plain {tp * 1e3:.1f} ms, one REP3 party alone {t1 * 1e3:.1f} ms", flush=True)
