@@ -13,6 +13,7 @@
 // Everything O(n) runs on the GPU through the ABI; this file only sequences calls, moves the two `mul_vec` messages and the
 // O(1) points between parties, and does O(1) scalar/point algebra through the ABI's host helpers.  No CPU fallback exists.
 #include "cogroth16_hip.h"
+#include "cogroth16_host.h"
 
 #include <condition_variable>
 #include <cstdio>

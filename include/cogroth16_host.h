@@ -1,0 +1,114 @@
+/* cogroth16_host.h — C ABI of the host mirror (libcogroth16_host.so): the co-circom prover entry points on top of cogroth16_hip.h.
+ *
+ * The reference is Rust and cannot be built in this image (no cargo), so the host side above the kernel ABI is C++
+ * (collaborative-circom_amd/host/cogroth16_host.cpp): drivers PlainHipDriver / Rep3HipProtocol / ShamirHipProtocol with the method names of
+ * the reference's traits (mpc-core/src/traits.rs:43-223, 535-568), CoGroth16::prove (co-groth16/src/groth16.rs:113-326) and CoPlonk
+ * rounds 1-5 (co-plonk/src/round{1..5}.rs) with the reference's call sequence, in-process REP3 / Shamir networks in the role of
+ * tests/src/rep3_network.rs, and the readers / writers of the file formats (circom-types).  These entry points are what the CLI's
+ * proving commands do once their arguments are parsed — co-circom/co-circom/src/bin/co-circom.rs:455-543 (generate-proof: read
+ * zkey :482, read shares :487-495, construct the driver :497-499, prove :503-506, write proof :512-532) — with buffers instead of
+ * files where the CLI reads them into memory first.  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions: every function returns 0 on success; on failure a non-zero value, message from cgh_last_error() (thread local).
+ * Field elements are 4 x u64 (6 for the BLS12-381 base field) little-endian Montgomery limbs, exactly arkworks' in-memory form
+ * (circom-types/src/traits.rs:57-67).  Proofs are packed affine points A (G1) || B (G2) || C (G1), (0, 0) = infinity
+ * (groth16/proof.rs:8-29).  curve: CG_BN254 / CG_BLS12_381 of cogroth16_hip.h.  No function here has a CPU fallback.
+ */
+#ifndef COGROTH16_HOST_H
+#define COGROTH16_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* cgh_last_error(void);
+
+/* ---- zkey / witness files (circom-types/src/groth16/zkey.rs:139-316, witness.rs:51-91, plonk/zkey.rs:83-255) -------------------- */
+/* info[7]: n_vars, n_public, domain_size, log2(domain_size), num_constraints, nnz(A), nnz(B) */
+int32_t cgh_zkey_info(int32_t curve, const char* path, size_t* info);
+/* the parser's per-point checks (traits.rs:107-155: on the curve, in the prime-order subgroup) for every point of the file, on the GPU;
+ * seconds[2] (optional): host read + decode, upload + validation.  0 = every point valid. */
+int32_t cgh_zkey_validate(int32_t device, int32_t curve, const char* path, double* seconds);
+/* The prove entry points and cgh_session_open run that validation themselves, as the reference's parser does.  Callers that validated
+ * the file before can switch it off process-wide (or set the environment variable CGH_SKIP_ZKEY_VALIDATION). */
+int32_t cgh_set_zkey_validation(int32_t on);
+/* witness.rs:51-91: n values in Montgomery form; out == NULL: only *n */
+int32_t cgh_read_wtns(int32_t curve, const char* path, uint64_t* out, size_t cap, size_t* n);
+/* info[6]: n_vars, n_public, domain_size, power, n_additions, n_constraints */
+int32_t cgh_plonk_zkey_info(int32_t curve, const char* path, size_t* info);
+
+/* ---- proof / public-input JSON (groth16/proof.rs:8-29, traits.rs:186-233; plonk/proof.rs) ------------------------------------------ */
+int32_t cgh_proof_to_json(int32_t curve, const uint64_t* proof, char* out, size_t cap);
+int32_t cgh_proof_from_json(int32_t curve, const char* json, uint64_t* out_proof);
+int32_t cgh_public_to_json(int32_t curve, const uint64_t* pub, size_t n, char* out, size_t cap);
+int32_t cgh_plonk_proof_to_json(int32_t curve, const uint64_t* commits, const uint64_t* evals, char* out, size_t cap);
+int32_t cgh_plonk_proof_from_json(int32_t curve, const char* json, uint64_t* out_commits, uint64_t* out_evals);
+
+/* ---- secret-shared witness container (co-circom-snarks/src/lib.rs:24-41; rep3/fieldshare.rs:233-236).  PARITY UNPINNED: the layout is
+ * restated from the reference's types (bincode u64 length || ark-serialize compressed vectors); the snapshot ships no `.shared`
+ * file to check it against.  protocol: 0 = REP3 (two vectors a, b), 1 = Shamir (one vector). ------------------------------------- */
+int32_t cgh_shared_witness_write(int32_t curve, const char* path, int32_t protocol, const uint64_t* pub, size_t n_pub, const uint64_t* a, const uint64_t* b, size_t n);
+/* sizes[0] = n_pub, sizes[1] = n; with the output buffers NULL only the sizes are returned */
+int32_t cgh_shared_witness_read(int32_t curve, const char* path, int32_t protocol, size_t* sizes, uint64_t* pub, uint64_t* a, uint64_t* b);
+
+/* ---- one-shot Groth16 proofs: zkey file -> proof (co-circom.rs:482-506; groth16.rs:113-139) ---------------------------------------- */
+/* PlainHipDriver (plain.rs).  full_witness = n_vars elements (leading one, public inputs, private part); r, s: the two blinding
+ * scalars the reference draws at groth16.rs:134-135.  out_h (optional): the m quotient evaluations of witness_map_from_matrices. */
+int32_t cgh_prove_plain(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* full_witness, const uint64_t* r, const uint64_t* s, uint64_t* out_proof, uint64_t* out_h);
+/* Rep3HipProtocol x 3 (three threads, in-process network like tests/src/rep3_network.rs).  pub_in = n_public + 1 values;
+ * wit_a[i] / wit_b[i] = party i's replicated shares of the private witness (rep3/fieldshare.rs:233-236); streams[i] = the field
+ * elements party i's rng1 produces (party i: rng1 = S_i, rng2 = S_(i-1), rngs.rs:25-46), stream_len each.  out_proofs = 3 proofs
+ * (all equal when the run is correct); out_h (optional) = party 0's share of h (a then b). */
+int32_t cgh_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
+                       const uint64_t* const* streams, size_t stream_len, uint64_t* out_proofs, uint64_t* out_h);
+/* ShamirHipProtocol x n, threshold t (shamir.rs:196-246).  wit[i] = party i's Shamir shares; streams[i] = its private randomness in
+ * the order the reference draws values; preprocess > 0: that many double sharings are generated on the GPU first (shamir.rs:248-300). */
+int32_t cgh_prove_shamir(int32_t device, int32_t curve, const char* zkey_path, int32_t n, int32_t t, const uint64_t* pub_in, const uint64_t* const* wit,
+                         const uint64_t* const* streams, size_t stream_len, size_t preprocess, uint64_t* out_proofs, uint64_t* out_h);
+
+/* ---- proving sessions: the zkey is read, uploaded, validated (and given per-window precomputed tables) once; a proof then costs what
+ * co-circom.rs:503-506 times.  A zkey is fixed for the life of a prover process (zkey.rs:48-71). ------------------------------------- */
+/* precompute: 0 = none, -1 = window chosen per table size, > 0 = that window */
+int32_t cgh_session_open(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, void** out_session);
+/* flags: bit 0 = skip the point validation */
+int32_t cgh_session_open_ex(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, uint32_t flags, void** out_session);
+/* Several GPUs of one node for one party: devices[0] runs the witness map and slice 0 of every MSM
+ * (mpc-core/src/protocols/rep3.rs:934-947 is linear in the (scalar, point) pairs), devices[i] slice i; scalar slices move device to
+ * device (cg_dev_copy_peer), partial sums are folded on the host.  The prove calls below accept either kind of session. */
+int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_devices, int32_t curve, const char* zkey_path, int32_t precompute, uint32_t flags, void** out_session);
+int32_t cgh_session_close(void* session);
+/* seconds[1] (optional): wall time of the prove */
+int32_t cgh_session_prove_plain(void* session, const uint64_t* full_witness, const uint64_t* r, const uint64_t* s, uint64_t* out_proof, double* seconds);
+/* three REP3 parties sharing the session's GPU(s).  seconds[2] (optional): [0] the three parties together; [1] party 0 ALONE on the GPU,
+ * replaying the messages it received in the first run (its proof must repeat bit for bit): one party's cost with its peers elsewhere. */
+int32_t cgh_session_prove_rep3(void* session, const uint64_t* pub_in, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
+                               const uint64_t* const* streams, size_t stream_len, uint64_t* out_proofs, double* seconds);
+
+/* ---- co-plonk (co-plonk/src/plonk.rs:133-271 drives round1..round5) ------------------------------------------------------------------ */
+/* PlainHipDriver through rounds 1..upto (<= 5).  full_witness = n_vars - n_additions elements; blind = the 11 blinding scalars b_1..b_11
+ * (round1.rs:346-383 fixes them to 1..11 in its test); commits = 9 packed G1 (a, b, c, z, t1, t2, t3, wxi, wxiw; zero = not reached),
+ * challenges = beta, gamma, alpha, xi, v; evals = a, b, c, s1, s2, zw; optional: t_polys = t1 (n+1) | t2 (n+1) | t3 (n+6), poly_z (n+3). */
+int32_t cgh_plonk_prove_plain(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* full_witness, const uint64_t* blind, int32_t upto,
+                              uint64_t* commits, uint64_t* challenges, uint64_t* evals, uint64_t* t_polys, uint64_t* poly_z);
+/* Rep3HipProtocol x 3 through rounds 1..upto.  blind_a[i] / blind_b[i] = party i's shares of b_1..b_11.  out_commits = 3 x 9 packed G1,
+ * out_evals = 3 x 6, out_challenges = 3 x 5 (every party must report the same values). */
+int32_t cgh_plonk_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
+                             const uint64_t* const* blind_a, const uint64_t* const* blind_b, const uint64_t* const* streams, size_t stream_len, int32_t upto,
+                             uint64_t* out_commits, uint64_t* out_evals, uint64_t* out_challenges);
+/* ShamirHipProtocol x n (threshold t) through rounds 1..upto; outputs as for cgh_plonk_prove_rep3, n parties. */
+int32_t cgh_plonk_prove_shamir(int32_t device, int32_t curve, const char* zkey_path, int32_t n, int32_t t, const uint64_t* pub_in, const uint64_t* const* wit,
+                               const uint64_t* const* blind, const uint64_t* const* streams, size_t stream_len, int32_t upto,
+                               uint64_t* out_commits, uint64_t* out_evals, uint64_t* out_challenges);
+/* Keccak256 transcript (co-plonk/src/types.rs:102-227): kinds[i] 0 = scalar, 1 = packed G1 point; out = the challenge */
+int32_t cgh_plonk_transcript(int32_t curve, const int32_t* kinds, const uint64_t* const* payloads, int32_t n_items, uint64_t* out_challenge);
+
+/* ---- tooling (bench / tests; not on the prover path) ---------------------------------------------------------------------------------- */
+/* synthetic satisfiable circuit of 2^log_m - 2 constraints (n_public = 1, n_vars = domain size = 2^log_m) with a VALID Groth16 CRS from
+ * seeded toxic waste, written as snarkjs-format .zkey + .wtns; the point tables are built on the GPU */
+int32_t cgh_synth_circuit(int32_t device, int32_t curve, int32_t log_m, uint64_t seed, const char* zkey_path, const char* wtns_path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,201 @@
+//! The GPU side shared by the three drivers: one `cg_ctx` per party thread (mirrors `&mut self` of the trait methods), the table cache
+//! that maps the `&[C::Affine]` slices the provers pass to `msm_public_points` onto device-resident tables, and the layout checks
+//! that make it sound to hand arkworks' in-memory values to the C ABI without conversion.
+use crate::ffi::*;
+use ark_ec::short_weierstrass::{Affine, Projective, SWCurveConfig};
+use ark_ff::{Field, PrimeField};
+use std::{collections::HashMap, marker::PhantomData, mem::{offset_of, size_of}, os::raw::c_void, ptr};
+
+/// Compile-time (post-monomorphisation) proof that `Affine<P>` / `Projective<P>` have the layout the ABI reads and writes:
+/// x at offset 0, y right behind it (the packed `x || y` the kernels load), the infinity flag somewhere after (its offset and the
+/// stride are passed to `cg_bases_register`), and (X, Y, Z) contiguous for the Jacobian results.  `repr(Rust)` gives no ordering
+/// guarantee, so a toolchain that reorders these fields fails to BUILD instead of proving garbage.
+pub struct Layout<P: SWCurveConfig>(PhantomData<P>);
+impl<P: SWCurveConfig> Layout<P> {
+    pub const COORD: usize = size_of::<P::BaseField>();
+    pub const STRIDE: usize = size_of::<Affine<P>>();
+    pub const INFINITY_OFFSET: usize = offset_of!(Affine<P>, infinity);
+    pub const CHECK: () = {
+        assert!(offset_of!(Affine<P>, x) == 0, "Affine.x is not the first field");
+        assert!(offset_of!(Affine<P>, y) == size_of::<P::BaseField>(), "Affine.y does not follow x");
+        assert!(offset_of!(Affine<P>, infinity) >= 2 * size_of::<P::BaseField>(), "Affine.infinity overlaps the coordinates");
+        assert!(offset_of!(Projective<P>, x) == 0 && offset_of!(Projective<P>, y) == size_of::<P::BaseField>()
+                    && offset_of!(Projective<P>, z) == 2 * size_of::<P::BaseField>(), "Projective is not (X, Y, Z)");
+        assert!(size_of::<Projective<P>>() == 3 * size_of::<P::BaseField>(), "Projective has padding");
+        // Fp<MontBackend<_, N>, N> is #[repr(transparent)]-like over BigInt<N>([u64; N]): N limbs, nothing else
+        assert!(size_of::<P::ScalarField>() % 8 == 0 && size_of::<P::BaseField>() % 8 == 0);
+    };
+}
+
+/// BN254 or BLS12-381, decided by the scalar modulus (the ABI's `curve` argument)
+pub fn curve_id<F: PrimeField>() -> i32 {
+    let m = F::MODULUS;
+    if m.as_ref() == <ark_bn254::Fr as PrimeField>::MODULUS.as_ref() {
+        CG_BN254
+    } else if m.as_ref() == <ark_bls12_381::Fr as PrimeField>::MODULUS.as_ref() {
+        CG_BLS12_381
+    } else {
+        panic!("cogroth16_hip supports the BN254 and BLS12-381 scalar fields only")
+    }
+}
+/// G1 (coordinates in the prime field) or G2 (coordinates in its quadratic extension)
+pub fn group_id<P: SWCurveConfig>() -> i32 {
+    if <P::BaseField as Field>::extension_degree() == 1 { CG_G1 } else { CG_G2 }
+}
+
+pub(crate) fn check(rc: i32, what: &str) {
+    if rc != 0 {
+        // the trait methods that reach the GPU are infallible in the reference (traits.rs:535-568)
+        panic!("cogroth16_hip: {what}: {}", last_error());
+    }
+}
+
+struct Table {
+    bases: *mut cg_bases,
+    /// address range of the host slice this table was registered from
+    host_lo: usize,
+    host_hi: usize,
+    stride: usize,
+}
+
+pub struct Gpu {
+    pub(crate) ctx: *mut cg_ctx,
+    tables: Vec<Table>,
+    by_start: HashMap<usize, usize>,
+    /// window of `cg_bases_precompute` for tables registered from here on (0 = none, -1 = by table size)
+    pub precompute: i32,
+}
+// a context is used by one thread at a time; moving the driver to another thread between calls is fine (no thread-local HIP state)
+unsafe impl Send for Gpu {}
+
+impl Gpu {
+    pub fn new(device: i32) -> eyre::Result<Self> {
+        let mut ctx = ptr::null_mut();
+        let rc = unsafe { cg_ctx_create(device, &mut ctx) };
+        if rc != 0 {
+            eyre::bail!("cg_ctx_create({device}): {}", last_error());
+        }
+        Ok(Self { ctx, tables: Vec::new(), by_start: HashMap::new(), precompute: 0 })
+    }
+
+    /// Registers a whole zkey query (`ZKey::a_query` … `h_query`, circom-types/src/groth16/zkey.rs:48-71) once.  The vectors live for the
+    /// process and are reused across proofs; later `msm_public_points` calls on any sub-slice of them resolve to (table, offset).
+    pub fn register<P: SWCurveConfig>(&mut self, points: &[Affine<P>]) -> usize {
+        #[allow(clippy::let_unit_value)]
+        let _ = Layout::<P>::CHECK;
+        let lo = points.as_ptr() as usize;
+        if let Some(&i) = self.by_start.get(&lo) {
+            if self.tables[i].host_hi >= lo + points.len() * Layout::<P>::STRIDE {
+                return i;
+            }
+        }
+        let mut bases = ptr::null_mut();
+        check(
+            unsafe {
+                cg_bases_register(self.ctx, curve_id::<P::ScalarField>(), group_id::<P>(), points.as_ptr() as *const c_void, points.len(),
+                                  Layout::<P>::STRIDE, Layout::<P>::INFINITY_OFFSET as i64, &mut bases)
+            },
+            "cg_bases_register",
+        );
+        if self.precompute != 0 && points.len() >= (1 << 14) {
+            check(unsafe { cg_bases_precompute(self.ctx, bases, if self.precompute < 0 { 0 } else { self.precompute }) }, "cg_bases_precompute");
+        }
+        self.tables.push(Table { bases, host_lo: lo, host_hi: lo + points.len() * Layout::<P>::STRIDE, stride: Layout::<P>::STRIDE });
+        self.by_start.insert(lo, self.tables.len() - 1);
+        self.tables.len() - 1
+    }
+
+    /// The parser's per-point checks (circom-types/src/traits.rs:107-155) on the device, for zkeys parsed with `Validate::No`
+    pub fn validate(&mut self, table: usize) -> Result<(), String> {
+        let (mut bad, mut first) = (0u64, 0u64);
+        check(unsafe { cg_bases_check_on_curve(self.ctx, self.tables[table].bases, &mut bad, &mut first) }, "cg_bases_check_on_curve");
+        if bad != 0 {
+            return Err(format!("point {first} is not on the curve ({bad} bad points)"));
+        }
+        check(unsafe { cg_bases_check_subgroup(self.ctx, self.tables[table].bases, &mut bad, &mut first) }, "cg_bases_check_subgroup");
+        if bad != 0 {
+            return Err(format!("point {first} is not in the correct subgroup ({bad} bad points)"));
+        }
+        Ok(())
+    }
+
+    /// (table, offset in points) for a slice: a registered parent allocation that contains it, else the slice becomes a table of its
+    /// own.  The provers pass sub-slices such as `&query[1 + pub_len..]` (groth16.rs:221) and `&p_tau[..len]` (co-plonk round1.rs:276-290).
+    fn bases_for<P: SWCurveConfig>(&mut self, points: &[Affine<P>]) -> (*const cg_bases, usize) {
+        let lo = points.as_ptr() as usize;
+        let hi = lo + points.len() * Layout::<P>::STRIDE;
+        for t in &self.tables {
+            if t.host_lo <= lo && hi <= t.host_hi && t.stride == Layout::<P>::STRIDE && (lo - t.host_lo) % t.stride == 0 {
+                return (t.bases, (lo - t.host_lo) / t.stride);
+            }
+        }
+        let i = self.register(points);
+        (self.tables[i].bases, 0)
+    }
+
+    /// `k` MSMs over the same points (one per share component, the loop of rep3.rs:942-943 in one call: the points are gathered once
+    /// per component from the same resident table and the components' digit schedules overlap with each other's accumulation)
+    pub fn msm<P: SWCurveConfig>(&mut self, points: &[Affine<P>], scalars: &[&[P::ScalarField]]) -> Vec<Projective<P>> {
+        for s in scalars {
+            assert_eq!(s.len(), points.len(), "msm_public_points: length mismatch");
+        }
+        let (bases, offset) = self.bases_for(points);
+        let ptrs: Vec<*const c_void> = scalars.iter().map(|s| s.as_ptr() as *const c_void).collect();
+        let mut out = vec![Projective::<P>::default(); scalars.len()];
+        check(
+            unsafe { cg_msm(self.ctx, bases, offset, points.len(), ptrs.as_ptr(), ptrs.len() as i32, out.as_mut_ptr() as *mut c_void) },
+            "cg_msm",
+        );
+        out
+    }
+
+    /// in-place transforms of `k` vectors with the domain's own generator (the callers overwrite `group_gen`, groth16.rs:63-70,
+    /// co-plonk/src/types.rs:83-90, so nothing about the root of unity is assumed here)
+    pub fn ntt<F: PrimeField>(&mut self, vecs: &mut [&mut [F]], group_gen: F, inverse: bool, coset_gen: Option<F>) {
+        let n = vecs[0].len();
+        assert!(vecs.iter().all(|v| v.len() == n) && n.is_power_of_two(), "fft: vectors must have the domain's (power of two) size");
+        let ptrs: Vec<*mut c_void> = vecs.iter_mut().map(|v| v.as_mut_ptr() as *mut c_void).collect();
+        let g = coset_gen.as_ref().map_or(ptr::null(), |g| g as *const F as *const c_void);
+        check(
+            unsafe { cg_ntt(self.ctx, curve_id::<F>(), ptrs.as_ptr(), ptrs.len() as i32, n, &group_gen as *const F as *const c_void, inverse as i32, g) },
+            "cg_ntt",
+        );
+    }
+
+    pub fn mul<F: PrimeField>(&mut self, a: &[F], b: &[F]) -> Vec<F> {
+        assert_eq!(a.len(), b.len());
+        let mut out = vec![F::zero(); a.len()];
+        check(
+            unsafe { cg_vec_mul(self.ctx, curve_id::<F>(), out.as_mut_ptr() as *mut c_void, a.as_ptr() as *const c_void, b.as_ptr() as *const c_void, a.len()) },
+            "cg_vec_mul",
+        );
+        out
+    }
+
+    /// aa*ba + aa*bb + ab*ba + mask, the local part of REP3 `mul_vec` (rep3.rs:656-660)
+    pub fn rep3_mul_local<F: PrimeField>(&mut self, aa: &[F], ab: &[F], ba: &[F], bb: &[F], mask: &[F]) -> Vec<F> {
+        let n = aa.len();
+        assert!(ab.len() == n && ba.len() == n && bb.len() == n && mask.len() == n);
+        let mut out = vec![F::zero(); n];
+        check(
+            unsafe {
+                cg_vec_rep3_mul_local(self.ctx, curve_id::<F>(), out.as_mut_ptr() as *mut c_void, aa.as_ptr() as *const c_void,
+                                      ab.as_ptr() as *const c_void, ba.as_ptr() as *const c_void, bb.as_ptr() as *const c_void,
+                                      mask.as_ptr() as *const c_void, n)
+            },
+            "cg_vec_rep3_mul_local",
+        );
+        out
+    }
+}
+
+impl Drop for Gpu {
+    fn drop(&mut self) {
+        unsafe {
+            for t in &self.tables {
+                cg_bases_release(t.bases);
+            }
+            cg_ctx_destroy(self.ctx);
+        }
+    }
+}

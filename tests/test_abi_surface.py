@@ -25,6 +25,22 @@ def test_header_symbols_exported():
     assert b"gfx950" in cg.load().cg_version()
 
 
+def test_host_mirror_header_matches_the_library():
+    """include/cogroth16_host.h declares exactly the cgh_* entry points libcogroth16_host.so exports (the host mirror is compiled against
+    the header, so the signatures agree as well)"""
+    import subprocess
+    ensure_built()
+    hdr = open(os.path.join(ROOT, "include", "cogroth16_host.h")).read()
+    declared = sorted(set(re.findall(r"\b(cgh_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(cg.HOST_LIB_PATH)
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, f"declared in cogroth16_host.h but not exported: {missing}"
+    nm = subprocess.run(["nm", "-D", "--defined-only", cg.HOST_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r"\bT (cgh_[a-z0-9_]+)$", nm, flags=re.M)))
+    assert exported == declared, f"exported but not declared: {sorted(set(exported) - set(declared))}"
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     ensure_built()
