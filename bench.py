@@ -37,7 +37,8 @@ cg = importlib.import_module("collaborative-circom_amd")
 
 CURVE = cg.BN254
 R_TOP = 0x30644E72E131A029          # top 64-bit limb of the BN254 scalar modulus
-MAD_PEAK_T = 25.6                   # measured v_mad_u64_u32 rate, Tmad/s chip-wide (profiles/microbench_r01.txt)
+MAD_PEAK_T = 30.0                   # sustained v_mad_u64_u32 rate, Tmad/s chip-wide at the 2.3 GHz the chip holds on that loop
+                                    # (scripts/microbench_clock.hip, profiles/r02_microbench_clock.txt; a 0.3 ms burst gives 26.4)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -599,15 +600,34 @@ def main():
         if rank == 0:
             print(f"soak: {args.soak} extra steps reproduced the results bit for bit", file=sys.stderr)
 
-    # the dominant kernel on its own: one extra, untimed step with everything on one context (no concurrent witness map / second
-    # MSM stream sharing the CUs), for the roofline's "isolated" figures
+    # The kernels on their own (rank 0, untimed): one share component at a time on one context, so that the digit/sort schedule, the
+    # accumulation and the bucket reduction run one after the other and nothing shares the CUs — the per-launch figures rocprofv3
+    # lists for a serial run (profiles/r02_serial_kernel_stats.csv).  HIP events of the library on the kernels' own streams.
     iso = None
-    if rank == 0 and not emulate and w.ctx_aux is not None and world == 1:
-        keep, w.ctx_aux = w.ctx_aux, None
-        ctx.stats_enable(True); ctx.stats(reset=True)
-        step(w); barrier()
-        iso = ctx.stats(reset=True); ctx.stats_enable(False)
-        w.ctx_aux = keep
+    if rank == 0 and not emulate and world == 1:
+        def alone(fn, reps=3):
+            fn(); barrier()
+            ctx.stats_enable(True); ctx.stats(reset=True)
+            for _ in range(reps):
+                fn()
+            barrier()
+            st_ = ctx.stats(reset=True); ctx.stats_enable(False)
+            return st_
+        iso = {}
+        g1_key = next((k for k in w.tables if TABLE_GROUP[k[0]] == 0), None)
+        g2_key = next((k for k in w.tables if TABLE_GROUP[k[0]] == 1), None)
+        for name, key in (("g1", g1_key), ("g2", g2_key)):
+            if key is None:
+                continue
+            bases, lo, hi = w.tables[key]
+            sc = [(w.ha if key[0] == "h" else w.wa)[lo:hi]]
+            st_ = alone(lambda: ctx.msm_end(ctx.msm_dev_begin_multi([bases], sc, hi - lo)[0]))
+            iso["acc_%s_ms" % name] = st_["msm_acc_%s_ms" % name] / max(1, st_["msm_acc_%s_calls" % name])
+            iso["sort_ms"] = st_["msm_sort_ms"] / 3
+            iso["reduce_%s_ms" % name] = st_["msm_reduce_ms"] / 3
+            iso["points_%s" % name] = hi - lo
+        st_ = alone(lambda: ctx.ntt_dev(CURVE, [w.ca], w.m, w.omega))
+        iso["ntt_ms"] = st_["ntt_ms"] / 3
 
     if rank == 0 and args.dump_result:
         dump = {t: np.stack([cg.point_to_affine(CURVE, cg.G1 if TABLE_GROUP[t] == 0 else cg.G2, res[t][j]) for j in range(2)]) for t in TABLES}
@@ -634,15 +654,21 @@ def main():
         alg_bytes = 96.0 * avg_pts
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         per_step = lambda k: st[k] / args.steps
-        iso_ms = (iso["msm_acc_g1_ms"] / max(1, iso["msm_acc_g1_calls"])) if iso else None
+        iso_ms = iso.get("acc_g1_ms") if iso else None
+        iso_pts = iso.get("points_g1", avg_pts) if iso else avg_pts
         c_eff = (20 if avg_pts > (3 << 20) else 16 if avg_pts <= (1 << 18) else 17) if args.precompute < 0 else (args.precompute or 16)
         nwin_g1 = 254 // c_eff + 1
         traffic = None          # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes (profiles/)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["dominant_kernel_traffic_bytes_per_launch"] if world == 1 and args.log_m == 22 else None
-        except Exception:
-            traffic = None
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    traffic = json.load(f)["dominant_kernel_traffic_bytes_per_launch"] if world == 1 and args.log_m == 22 else None
+                break
+            except Exception:
+                traffic = None
+        free_b, total_b = torch.cuda.mem_get_info(device)
+        roof = lambda bytes_, ms: {"achieved": bytes_ / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "launch_ms": ms, "algorithmic_bytes_per_launch": bytes_} if ms else None
         out = {
             "metric": "Groth16 constraints/sec (BN254, 2^22 R1CS), one REP3 party's prove compute",
             "value": value, "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -651,22 +677,32 @@ def main():
             "config": {"workload": f"synthetic R1CS 2^{args.log_m} constraints-domain BN254, REP3 co-groth16 (configs[2])",
                        "num_constraints": w.nc, "domain_size": w.m, "n_vars": w.m, "nnz": w.nnz, "share_components": 2,
                        "msm": "8 G1 + 2 G2 of ~2^%d points" % args.log_m, "msm_window": ("precomputed tables c=%s" % (args.precompute if args.precompute > 0 else "auto (20 above 3 M G1 / 1.5 M G2 points, else 17)")) if args.precompute else "c=16, per-window bucket sets", "ntt": 12, "parallelism": f"msm units (tables / table slices) over {world} rank(s): " + ",".join(f"{t}{i}/{p}->r{o}" for t, i, p, o in w.plan)},
-            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<G1> (bucket accumulation, one launch per MSM component and table)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "launches": st["msm_acc_g1_calls"], "algorithmic_bytes_per_launch": alg_bytes,
-                         "isolated_avg_launch_ms": (iso["msm_acc_g1_ms"] / max(1, iso["msm_acc_g1_calls"])) if iso else None,
-                         "isolated_achieved": (alg_bytes / (iso["msm_acc_g1_ms"] / max(1, iso["msm_acc_g1_calls"]) * 1e-3) / 1e9) if iso and iso["msm_acc_g1_ms"] > 0 else None,
-                         "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound; in the timed region the launches share the CUs with the witness map and the "
-                                 "bucket reductions running on other streams (avg_launch_ms), isolated_* = the same kernel in an extra serial step; traffic = "
-                                 "FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_traffic.json (each base is re-gathered once per window); see DESIGN.md"},
+            # frac is computed from the kernel ALONE (isolated launch, what a serial rocprofv3 trace shows); avg_launch_ms is the same kernel
+            # inside the timed region, where four streams share the CUs
+            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate_pf<G1> (bucket accumulation, one launch per MSM component and table)",
+                         "achieved": (96.0 * iso_pts / (iso_ms * 1e-3) / 1e9) if iso_ms else achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ((96.0 * iso_pts / (iso_ms * 1e-3) / 1e9) if iso_ms else achieved) / HBM_PEAK_GBS, "traffic": traffic,
+                         "launch_ms": iso_ms, "algorithmic_bytes_per_launch": 96.0 * iso_pts,
+                         "overlapped_avg_launch_ms": avg_ms, "overlapped_launches": st["msm_acc_g1_calls"],
+                         "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound, and clocked by the chip's power management: the launch holds ~1.9 GHz "
+                                 "(GRBM_GUI_ACTIVE / duration, scripts/clock_by_kernel.py) where the same additions with operands in registers hold 2.35 GHz; "
+                                 "traffic = FETCH_SIZE + WRITE_SIZE per launch (each base is gathered once per window); see DESIGN.md"},
+            "roofline_g2": roof(160.0 * iso["points_g2"], iso.get("acc_g2_ms")) if iso and "acc_g2_ms" in iso else None,
+            "roofline_ntt": dict(roof(64.0 * w.m, iso["ntt_ms"]), kernel="k_ntt_ct_pass x2-3 + k_bitrev_finish_lazy, one 2^%d transform (32 B read + 32 B written per element, single-pass ideal)" % args.log_m) if iso else None,
+            "roofline_sort": dict(roof((32.0 + 16.0 * nwin_g1) * iso["points_g1"], iso["sort_ms"]), kernel="digit + MSD partition sort schedule of one scalar vector (32 B per scalar + 16 B per (point, window) entry)") if iso else None,
             # "MSM is integer-VALU bound; also report achieved 32-bit mul-add rate".  One G1 mixed addition on the lazy 29-bit
             # core = 1 467 v_mad_u64_u32/v_mad_i64_i32 (6 products x 162 + 2 squarings x 126 + one fused a*b - c*d x 243); a launch adds
-            # every point once per window.  Peak = the chip-wide v_mad_u64_u32 issue rate measured by scripts/microbench.hip.
-            "valu_roofline": {"kernel": "k_msm_accumulate<G1>", "unit": "Tmad/s (32x32+64 multiply-adds)", "mads_per_point_addition": 1467,
-                              "point_additions_per_launch": avg_pts * nwin_g1,
-                              "achieved": (1467.0 * avg_pts * nwin_g1 / (iso_ms * 1e-3) / 1e12) if iso_ms else None,
-                              "peak": MAD_PEAK_T, "frac": (1467.0 * avg_pts * nwin_g1 / (iso_ms * 1e-3) / 1e12 / MAD_PEAK_T) if iso_ms else None,
-                              "launch_ms": iso_ms, "note": "isolated launches (serial extra step); peak from profiles/microbench_r01.txt"},
+            # every point once per window.  Peak = the chip-wide sustained v_mad_u64_u32 issue rate (scripts/microbench_clock.hip).
+            "valu_roofline": {"kernel": "k_msm_accumulate_pf<G1>", "unit": "Tmad/s (32x32+64 multiply-adds)", "mads_per_point_addition": 1467,
+                              "point_additions_per_launch": iso_pts * nwin_g1,
+                              "achieved": (1467.0 * iso_pts * nwin_g1 / (iso_ms * 1e-3) / 1e12) if iso_ms else None,
+                              "peak": MAD_PEAK_T, "frac": (1467.0 * iso_pts * nwin_g1 / (iso_ms * 1e-3) / 1e12 / MAD_PEAK_T) if iso_ms else None,
+                              "launch_ms": iso_ms, "note": "isolated launches; peak = sustained rate of a pure v_mad_u64_u32 loop at the 2.3 GHz it holds; the launch itself "
+                                                             "holds ~1.9 GHz and issues 1 467 multiply-adds + ~750 other vector instructions per addition"},
+            "isolated_ms": iso,
+            "hbm_footprint": {"device_bytes_in_use": int(total_b - free_b), "device_bytes_total": int(total_b),
+                              "note": "resident while the step runs: five zkey-sized tables with their per-window precomputed copies (13 windows: 21 GB at 2^22), "
+                                      "share vectors, twiddles, sort / bucket scratch of two contexts"},
             "step_hbm": {"algorithmic_bytes_per_step": 2048.0 * w.nc, "achieved_GBs": 2048.0 * w.nc / (elapsed / args.steps) / 1e9},
             "stage_ms_per_step": {"spmv": per_step("spmv_ms"), "pointwise": per_step("vec_ms"), "ntt": per_step("ntt_ms"), "msm_gpu": per_step("msm_ms"),
                                   "msm_sort": per_step("msm_sort_ms"), "msm_acc_g1": per_step("msm_acc_g1_ms"), "msm_acc_g2": per_step("msm_acc_g2_ms"),

@@ -44,8 +44,8 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     uint32_t* cont_bucket = (uint32_t*)take((size_t)g.nchunks * 4);
     B* partials = (B*)take(std::max((size_t)g.nsets * g.segs, (size_t)64 * g.bit_groups) * sizeof(B));
     XYZZ<F>* wsums = (XYZZ<F>*)take((size_t)std::max(g.ngroups, 64) * sizeof(XYZZ<F>));
-    if (evs) HIPCHK(hipEventRecord(evs[0], st));
     HIPCHK(hipMemsetAsync(buckets, 0, g.nbuckets * sizeof(B), st));                // all-zero = infinity (empty buckets are never written)
+    if (evs) HIPCHK(hipEventRecord(evs[0], st));                                     // [0, 1] bracket the accumulation KERNEL alone (what rocprofv3 lists per launch)
     auto launch_acc = [&](auto kern, int T, size_t lds) -> int {
         if (lds > 0) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((g.nchunks + T - 1) / T), dim3(T), lds, st, d_bases, sorted, offsets, counts,
@@ -96,11 +96,11 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     else if constexpr (sizeof(F) > 64) rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc<F>, 128>, 128, (size_t)128 * sizeof(XYZZ<F>));
     else rc_acc = launch_acc(k_msm_accumulate<F, RegAcc<F>, 256>, 256, 0);
     if (rc_acc) return rc_acc;
+    if (evs) HIPCHK(hipEventRecord(evs[1], st));
     hipLaunchKernelGGL((k_msm_merge_direct<B>), dim3((unsigned)((g.nbuckets + 63) / 64)), dim3(64), 0, st, buckets, cont, cont_bucket, offsets, counts,
                        (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, cap);
     hipLaunchKernelGGL((k_msm_merge_cont_l1<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, cont, cont_bucket, g.nchunks);
     hipLaunchKernelGGL((k_msm_merge_cont<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, buckets, cont, cont_bucket, g.nchunks);
-    if (evs) HIPCHK(hipEventRecord(evs[1], st));
     HIPCHK(hipEventRecord(ev_acc, st));
     HIPCHK(hipStreamWaitEvent(st2, ev_acc, 0));
     if (evs) HIPCHK(hipEventRecord(evs[2], st2));
