@@ -15,14 +15,14 @@ pytestmark = pytest.mark.gpu
 
 def run_bench(tmp_path, world, extra=(), log_m=14, port=29611):
     out = str(tmp_path / f"res_{world}_{len(extra)}.npz")
-    common = ["--gpus", str(world), "--steps", "1", "--warmup", "1", "--log-m", str(log_m), "--no-cpu-baseline", "--dump-result", out, *extra]
+    common = ["--gpus", str(world), "--steps", "1", "--warmup", "1", "--log-m", str(log_m), "--no-cpu-baseline", "--no-session", "--dump-result", out, *extra]
     if world == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *common]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", str(port + world), os.path.join(ROOT, "bench.py"), *common, "--backend", "gloo", "--shared-device"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     return json.loads(line), dict(np.load(out))
@@ -53,6 +53,30 @@ def test_bench_step_matches_oracle_at_full_size(tmp_path):
     exp = bench_check.expected_results(d)
     for t in bench.TABLES:
         np.testing.assert_array_equal(d[t], exp[t], err_msg=f"table {t} at 2^22")
+
+
+def test_bench_step_matches_oracle_at_2_24(tmp_path):
+    """BASELINE configs[3] size on one GPU: the 2^24 step (2^24-point tables with their precomputed window copies, 2^24 transforms),
+    all ten MSM results bit for bit against the oracle's evaluation of the same inputs.  What stays unexercised of configs[3] is RCCL
+    between different devices."""
+    if os.environ.get("CG_SKIP_2_24"):
+        pytest.skip("CG_SKIP_2_24 set")
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+    import bench
+    import bench_check
+    _, d = run_bench(tmp_path, 1, extra=("--dump-inputs",), log_m=24)
+    exp = bench_check.expected_results(d)
+    for t in bench.TABLES:
+        np.testing.assert_array_equal(d[t], exp[t], err_msg=f"table {t} at 2^24")
+
+
+def test_eight_ranks_fold_at_2_20(tmp_path):
+    """the 8-rank plan (table slices, distributed witness map, all_to_all, all_gather + fold) at 2^20, eight ranks sharing GPU 0"""
+    _, r1 = run_bench(tmp_path, 1, log_m=20)
+    _, r8 = run_bench(tmp_path, 8, log_m=20)
+    for t in r1:
+        assert r1[t].any()
+        np.testing.assert_array_equal(r1[t], r8[t], err_msg=f"world 8 at 2^20, table {t}")
 
 
 def test_single_rank_through_rccl_collectives(tmp_path):
