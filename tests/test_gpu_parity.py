@@ -317,6 +317,32 @@ def test_msm_at_maximum_table_size(ctx, group, lg):
     bases.release()
 
 
+@pytest.mark.parametrize("group", [G1, G2])
+def test_msm_witness_like_scalars_at_scale(ctx, group):
+    """what the plain driver multiplies on a real circuit: half the scalars 0, a third 1, some bytes, the rest full width, 2^20 of
+    them — one bucket (digit 1 of the lowest window) holds a third of all entries.  Exact value through the synthetic table
+    [(1 + i) G]; classic per-window bucket sets and precomputed window tables (one shared bucket set)."""
+    import bench_check as bc
+    curve, n = BN254, 1 << 20
+    rng = np.random.default_rng(77)
+    sc = orc.random_field(curve, FR, n, rng)
+    sel = rng.random(n)
+    small = np.stack([orc.from_dec(curve, FR, v) for v in range(256)])
+    sc[sel < 0.5] = 0
+    sc[(sel >= 0.5) & (sel < 0.83)] = small[1]
+    m = (sel >= 0.83) & (sel < 0.93); sc[m] = small[rng.integers(2, 256, size=int(m.sum()))]
+    idx = np.zeros((n, 4), dtype=np.uint64); idx[:, 0] = np.arange(n, dtype=np.uint64) + np.uint64(1)
+    want = orc.generator_mul(curve, group, bc.field_sum(bc.mul(sc, bc.to_mont(idx))))
+    bases = ctx.synth_bases(curve, group, 1, n)
+    d = dev(ctx, sc)
+    got, = ctx.msm_dev(bases, [d], n)
+    np.testing.assert_array_equal(cg.point_to_affine(curve, group, got), want)
+    ctx.precompute_bases(bases, 0)
+    got, = ctx.msm_dev(bases, [d], n)
+    np.testing.assert_array_equal(cg.point_to_affine(curve, group, got), want)
+    bases.release()
+
+
 def test_msm_async_tickets(ctx):
     curve = BN254
     rng = np.random.default_rng(4)
