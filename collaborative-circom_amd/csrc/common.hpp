@@ -61,8 +61,8 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_
     static const size_t chunk_min = [] { const char* e = getenv("CG_MSM_CHUNK_MIN"); return e ? (size_t)atoi(e) : (size_t)16; }();  // tuning knob (8 -> 16: 2^17-constraint step 7.3 -> 5.8 ms: half the continuation pieces)
     g.chunk_len = (uint32_t)std::min<size_t>(chunk_max, std::max<size_t>(chunk_min, entries / (256 * 1024)));
     static const bool no_rounds = getenv("CG_MSM_NO_ROUNDS") != nullptr;                  // tuning knob
-    if (resident_lanes && !no_rounds && entries >= resident_lanes * chunk_max) {
-        const size_t rounds = std::max<size_t>(1, (entries + resident_lanes * chunk_max / 2) / (resident_lanes * chunk_max));
+    if (resident_lanes && !no_rounds && entries >= resident_lanes * 2 * chunk_min) {      // from 32 entries per lane on (table slices of a multi-GPU plan:
+        const size_t rounds = std::max<size_t>(1, (entries + resident_lanes * chunk_max / 2) / (resident_lanes * chunk_max));   // 2^20 points x 15 windows = one round of 80)
         g.chunk_len = (uint32_t)((entries + rounds * resident_lanes - 1) / (rounds * resident_lanes));
     }
     g.nchunks = (uint32_t)std::max<size_t>(1, (entries + g.chunk_len - 1) / g.chunk_len);

@@ -15,6 +15,9 @@ template <class B> uint32_t bitsum_groups(uint32_t nb) { return std::max<uint32_
 // lanes of the accumulation kernel resident at once on a 256-CU gfx950: G1 (32-byte coordinates, 167 VGPRs) runs 3 workgroups of 256
 // per CU in lock step; the G2 workgroups (2 waves per SIMD, one of them favoured by the arbiter) do not, so no rounding there (0)
 template <class F> constexpr size_t acc_resident_lanes() { return sizeof(F) == 32 ? (size_t)256 * 3 * 256 : 0; }
+// coordinates in the base field (G1: VGPR accumulator) or its quadratic extension (G2: LDS accumulator)
+template <class F> struct IsFp2 { static constexpr bool value = false; };
+template <class B> struct IsFp2<Fp2<B>> { static constexpr bool value = true; };
 
 template <class F>
 size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared) {
@@ -52,10 +55,9 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
                            (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, (uint32_t)table_stride, cap, buckets, cont, cont_bucket, may_have_inf ? 1u : 0u);
         return 0;
     };
-    // accumulator policy per coordinate field:
-    //   32 B  (BN254 Fq)        lazy 29-bit limbs in VGPRs
-    //   64 B  (BN254 Fq2)       lazy 29-bit limbs, accumulator in LDS (72 dwords per lane), 128-lane workgroups
-    //   48 B  (BLS12-381 Fq)    saturated limbs in VGPRs          96 B (BLS12-381 Fq2)  saturated limbs, accumulator in LDS
+    // accumulator policy per coordinate field (lazy limbs everywhere: 9 x 29 bits for BN254, 14 x 28 bits for BLS12-381 Fq):
+    //   G1 (Fq)    accumulator in VGPRs, 256-lane workgroups
+    //   G2 (Fq2)   accumulator in LDS (72 / 112 dwords per lane), 128-lane workgroups
     int rc_acc;
     // Compact lists (cap == 0) of the lazy-limb fields run the software-pipelined kernel.  CG_ACC_VARIANT (tuning knob, read per
     // call; scripts/acc_variants.py): 0 = k_msm_accumulate, 1 = pipelined + L2 warm-up of the next record, 2 = pipelined + next
@@ -69,32 +71,29 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
                            (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, (uint32_t)table_stride, buckets, cont, cont_bucket, may_have_inf ? 1u : 0u);
         return 0;
     };
-    if (variant && cap == 0 && sizeof(F) == 32) {
-        if constexpr (sizeof(F) == 32) {
-            if (variant == 1) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 1>, 256, 256 * 4);
-            else if (variant == 2) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 2, 2>, 256, 0);
+    constexpr bool g2 = IsFp2<F>::value;
+    constexpr int MINW1 = sizeof(F) == 32 ? 3 : 2;            // G1 waves per SIMD the register budget is set for (BN254: 167 VGPRs; BLS12-381: 14-limb values)
+    const size_t lds2 = g2 ? (size_t)128 * 4 * sizeof(typename LazyOf<F>::type) : 0;
+    if (variant && cap == 0) {
+        if constexpr (!g2) {
+            if (variant == 1) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 1>, 256, 256 * 4);
+            else if (variant == 2) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1 - 1, 2>, 256, 0);
 #ifdef CG_ACC_DEBUG_VARIANTS   // timing experiments with wrong results (scripts/acc_variants.py): where the launch spends its time
-            else if (variant == 4) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0, 1>, 256, 0);
-            else if (variant == 5) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0, 2>, 256, 0);
-            else if (variant == 6) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0, 3>, 256, 0);
-            else if (variant == 7) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0, 7>, 256, 0);
-            else if (variant == 8) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0, 4>, 256, 0);
-            else if (variant == 9) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0, 8>, 256, 0);
+            else if (variant == 4) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 0, 1>, 256, 0);
+            else if (variant == 5) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 0, 2>, 256, 0);
+            else if (variant == 6) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 0, 3>, 256, 0);
+            else if (variant == 7) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 0, 7>, 256, 0);
+            else if (variant == 8) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 0, 4>, 256, 0);
+            else if (variant == 9) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 0, 8>, 256, 0);
 #endif
-            else rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, 3, 0>, 256, 0);
+            else rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 0>, 256, 0);
+        } else {
+            if (variant == 1) rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 1>, 128, lds2 + 128 * 4);
+            else if (variant == 2) rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 2>, 128, lds2);
+            else rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 0>, 128, lds2);
         }
-    } else if (variant && cap == 0 && sizeof(F) == 64) {
-        if constexpr (sizeof(F) == 64) {
-            const size_t lds = (size_t)128 * 4 * sizeof(typename LazyOf<F>::type);
-            if (variant == 1) rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 1>, 128, lds + 128 * 4);
-            else if (variant == 2) rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 2>, 128, lds);
-            else rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 0>, 128, lds);
-        }
-    } else
-    if constexpr (sizeof(F) == 32) rc_acc = launch_acc(k_msm_accumulate<F, RegAcc29<F>, 256>, 256, 0);
-    else if constexpr (sizeof(F) == 64) rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc29<F>, 128>, 128, (size_t)128 * 4 * sizeof(typename LazyOf<F>::type));
-    else if constexpr (sizeof(F) > 64) rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc<F>, 128>, 128, (size_t)128 * sizeof(XYZZ<F>));
-    else rc_acc = launch_acc(k_msm_accumulate<F, RegAcc<F>, 256>, 256, 0);
+    } else if constexpr (!g2) rc_acc = launch_acc(k_msm_accumulate<F, RegAcc29<F>, 256>, 256, 0);
+    else rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc29<F>, 128>, 128, lds2);
     if (rc_acc) return rc_acc;
     if (evs) HIPCHK(hipEventRecord(evs[1], st));
     hipLaunchKernelGGL((k_msm_merge_direct<B>), dim3((unsigned)((g.nbuckets + 63) / 64)), dim3(64), 0, st, buckets, cont, cont_bucket, offsets, counts,

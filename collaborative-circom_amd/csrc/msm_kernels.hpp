@@ -115,7 +115,7 @@ struct L29x2 {
     L c0, c1;
     template <int SHIFT> __device__ __forceinline__ static L29x2 unpack(const F2& a) { return {L::template unpack<SHIFT>(a.c0), L::template unpack<SHIFT>(a.c1)}; }
     __device__ __forceinline__ static L29x2 unpack_small(const F2& a) { return {L::unpack_small(a.c0), L::unpack_small(a.c1)}; }
-    __device__ __forceinline__ static L29x2 one_small() { L z; _Pragma("unroll") for (int k = 0; k < 9; k++) z.l[k] = 0; return {L::one_small(), z}; }
+    __device__ __forceinline__ static L29x2 one_small() { L z; _Pragma("unroll") for (int k = 0; k < L::NL; k++) z.l[k] = 0; return {L::one_small(), z}; }
     __device__ __forceinline__ L29x2 operator+(const L29x2& b) const { return {c0 + b.c0, c1 + b.c1}; }
     __device__ __forceinline__ L29x2 operator-(const L29x2& b) const { return {c0 - b.c0, c1 - b.c1}; }
     __device__ __forceinline__ L29x2 neg() const { return {c0.neg(), c1.neg()}; }
@@ -124,20 +124,15 @@ struct L29x2 {
     // r = (a*b + s*c*d + M p) / 2^261, s = +1 or -1: the fused two-product Montgomery step
     template <int SIGN>
     __device__ __forceinline__ static L mul2(const L& a, const L& b, const L& c, const L& d) {
-        typedef typename F::Params P;
-        int64_t T[18];
-        _Pragma("unroll") for (int k = 0; k < 18; k++) T[k] = 0;
-        _Pragma("unroll") for (int i = 0; i < 9; i++) {
-            _Pragma("unroll") for (int j = 0; j < 9; j++) T[i + j] += (int64_t)a.l[i] * b.l[j];
-            _Pragma("unroll") for (int j = 0; j < 9; j++) T[i + j] += (int64_t)(SIGN > 0 ? c.l[i] : -c.l[i]) * d.l[j];
-            const int32_t m = (int32_t)(((uint32_t)T[i] * (P::INV & L::MASK)) & L::MASK);
-            _Pragma("unroll") for (int j = 0; j < 9; j++) T[i + j] += (int64_t)m * L::pl(j);
-            T[i + 1] += T[i] >> 29;
+        constexpr int NL = L::NL;
+        int64_t T[2 * NL];
+        _Pragma("unroll") for (int k = 0; k < 2 * NL; k++) T[k] = 0;
+        _Pragma("unroll") for (int i = 0; i < NL; i++) {
+            _Pragma("unroll") for (int j = 0; j < NL; j++) T[i + j] += (int64_t)a.l[i] * b.l[j];
+            _Pragma("unroll") for (int j = 0; j < NL; j++) T[i + j] += (int64_t)(SIGN > 0 ? c.l[i] : -c.l[i]) * d.l[j];
+            L::reduce_round(T, i);
         }
-        L r;
-        _Pragma("unroll") for (int k = 0; k < 8; k++) { r.l[k] = (int32_t)((uint32_t)T[9 + k] & L::MASK); T[10 + k] += T[9 + k] >> 29; }
-        r.l[8] = (int32_t)T[17];
-        return r;
+        return L::upper_half(T);
     }
     static __device__ CG_L29X2_INLINE L29x2 mul(const L29x2& a, const L29x2& b) {
         return {mul2<-1>(a.c0, b.c0, a.c1, b.c1), mul2<+1>(a.c0, b.c1, a.c1, b.c0)};
@@ -150,13 +145,15 @@ struct L29x2 {
     __device__ __forceinline__ static L29x2 mul_sub(const L29x2& a, const L29x2& b, const L29x2& c, const L29x2& d) { return (mul(a, b) - mul(c, d)).norm(); }
     __device__ __forceinline__ static bool is_zero_mod_p(const L29x2& x) { return L::is_zero_mod_p(x.c0) && L::is_zero_mod_p(x.c1); }
     __device__ __forceinline__ static bool maybe_zero_mod_p(const L29x2& x) { return L::maybe_zero_mod_p(x.c0) && L::maybe_zero_mod_p(x.c1); }
-    __device__ __forceinline__ static L29x2 one() { L z; _Pragma("unroll") for (int k = 0; k < 9; k++) z.l[k] = 0; return {L::one(), z}; }
+    __device__ __forceinline__ static L29x2 one() { L z; _Pragma("unroll") for (int k = 0; k < L::NL; k++) z.l[k] = 0; return {L::one(), z}; }
     __device__ __forceinline__ static F2 to_fp(const L29x2& x) { return {L::to_fp(x.c0), L::to_fp(x.c1)}; }
     __device__ __forceinline__ static XYZZ<F2> dbl_affine(const F2& x, const F2& y) { return xyzz_dbl_affine(x, y); }
 };
 
 template <class F> struct LazyOf { typedef L29<F> type; };
 template <class B> struct LazyOf<Fp2<B>> { typedef L29x2<Fp2<B>> type; };
+template <class L> struct LazyShift { static constexpr int value = L::SH; };                 // bits between the ABI's and the lazy Montgomery domain
+template <class F2> struct LazyShift<L29x2<F2>> { static constexpr int value = L29x2<F2>::L::SH; };
 
 // lazy accumulator in VGPRs (G1) or LDS (G2: 72 dwords per lane)
 template <class F>
@@ -202,8 +199,8 @@ struct alignas(16) XYZZL {
     L c[4];   // X, Y, ZZ, ZZZ
 };
 template <class F> struct BucketOf { typedef XYZZ<F> type; };
-template <class P> struct BucketOf<Fp<P>> { typedef typename std::conditional<Fp<P>::N == 8, XYZZL<Fp<P>>, XYZZ<Fp<P>>>::type type; };
-template <class B> struct BucketOf<Fp2<B>> { typedef typename std::conditional<B::N == 8, XYZZL<Fp2<B>>, XYZZ<Fp2<B>>>::type type; };
+template <class P> struct BucketOf<Fp<P>> { typedef XYZZL<Fp<P>> type; };                  // every field has a lazy form (9 x 29 or 14 x 28 limbs)
+template <class B> struct BucketOf<Fp2<B>> { typedef XYZZL<Fp2<B>> type; };
 
 template <class F> __device__ __forceinline__ bool bk_is_inf(const XYZZ<F>& p) { return p.is_inf(); }
 template <class F> __device__ __forceinline__ bool bk_is_inf(const XYZZL<F>& p) {
@@ -263,7 +260,7 @@ template <class F> __device__ __forceinline__ XYZZ<F> bk_to_xyzz(const XYZZL<F>&
 template <class F, class Acc>
 __device__ __forceinline__ void acc_madd_lazy(Acc& acc, const F& x2f, const F& y2f, bool negate) {
     typedef typename LazyOf<F>::type L;
-    L x2 = L::template unpack<5>(x2f), y2 = L::template unpack<5>(y2f);     // 32*x2, 32*y2: the 2^261 domain
+    L x2 = L::template unpack<LazyShift<L>::value>(x2f), y2 = L::template unpack<LazyShift<L>::value>(y2f);     // 2^SH * x2, 2^SH * y2: the 2^(NL W) domain
     if (negate) y2 = y2.neg();
     if (acc.inf) {
         // First point of a bucket: some lane of a wave is here on nearly every second iteration (64 lanes, ~100 entries per
@@ -282,8 +279,9 @@ __device__ __forceinline__ void acc_madd_lazy(Acc& acc, const F& x2f, const F& y
             acc.inf = d.is_inf();
             if (!acc.inf) {
                 const L one = L::one();
-                acc.set(0, L::mul(L::template unpack<5>(d.x), one)); acc.set(1, L::mul(L::template unpack<5>(d.y), one));
-                acc.set(2, L::mul(L::template unpack<5>(d.zz), one)); acc.set(3, L::mul(L::template unpack<5>(d.zzz), one));
+                constexpr int SH = LazyShift<L>::value;
+                acc.set(0, L::mul(L::template unpack<SH>(d.x), one)); acc.set(1, L::mul(L::template unpack<SH>(d.y), one));
+                acc.set(2, L::mul(L::template unpack<SH>(d.zz), one)); acc.set(3, L::mul(L::template unpack<SH>(d.zzz), one));
             }
         } else acc.inf = true;
         return;
