@@ -61,8 +61,9 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     int rc_acc;
     // Compact lists (cap == 0) of the lazy-limb fields run the software-pipelined kernel.  CG_ACC_VARIANT (tuning knob, read per
     // call; scripts/acc_variants.py): 0 = k_msm_accumulate, 1 = pipelined + L2 warm-up of the next record, 2 = pipelined + next
-    // record in registers (one wave per SIMD less), 3 / unset = pipelined index and boundary reads only (the default: the record
-    // prefetches measured no faster, the launch is bound by vector issue and not by the latency of the gather)
+    // record in registers (one wave per SIMD less), 3 / unset = pipelined boundary reads + index list read 16 bytes at a time (the default:
+    // the record prefetches measured no faster, the launch is bound by vector issue and not by the latency of the gather),
+    // 10 = 4-byte index reads two iterations ahead
     const char* var_s = getenv("CG_ACC_VARIANT");
     const int variant = var_s ? atoi(var_s) : 3;
     auto launch_pf = [&](auto kern, int T, size_t lds) -> int {
@@ -78,6 +79,7 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
         if constexpr (!g2) {
             if (variant == 1) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 1>, 256, 256 * 4);
             else if (variant == 2) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1 - 1, 2>, 256, 0);
+            else if (variant == 10) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 0>, 256, 0);
 #ifdef CG_ACC_DEBUG_VARIANTS   // timing experiments with wrong results (scripts/acc_variants.py): where the launch spends its time
             else if (variant == 4) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 0, 1>, 256, 0);
             else if (variant == 5) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 0, 2>, 256, 0);
@@ -86,11 +88,12 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
             else if (variant == 8) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 0, 4>, 256, 0);
             else if (variant == 9) rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 0, 8>, 256, 0);
 #endif
-            else rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 0>, 256, 0);
+            else rc_acc = launch_pf(k_msm_accumulate_pf<F, RegAcc29<F>, 256, MINW1, 3>, 256, 0);
         } else {
             if (variant == 1) rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 1>, 128, lds2 + 128 * 4);
             else if (variant == 2) rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 2>, 128, lds2);
-            else rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 0>, 128, lds2);
+            else if (variant == 10) rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 0>, 128, lds2);
+            else rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 3>, 128, lds2);
         }
     } else if constexpr (!g2) rc_acc = launch_acc(k_msm_accumulate<F, RegAcc29<F>, 256>, 256, 0);
     else rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc29<F>, 128>, 128, lds2);

@@ -405,8 +405,19 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate_pf(const Affin
         return table_stride ? (size_t)((e >> 24) & 0x7fu) * table_stride + (e & 0xffffffu) : (size_t)(e & 0x7fffffffu);
     };
     auto entry = [&](uint32_t at) -> uint32_t { if constexpr (DBG & 4) return at * 2654435761u; else return sorted[at]; };   // DBG 4: no index loads
-    uint32_t e0 = entry(pos);
-    uint32_t e1 = pos + 1 < end ? entry(pos + 1) : e0;
+    uint32_t e0 = 0, e1 = 0;
+    // PF == 3: the index list is read 16 bytes per lane every fourth iteration instead of 4 bytes every iteration:
+    // a lane's entries are consecutive, but 64 lanes x 4 bytes touch 64 cache lines per load and each line comes back from L2 — or,
+    // evicted by the gathers streaming through, from HBM — 32 times (1 GB of the 4.8 GB a 2^22 launch reads, r02_pmc_traffic.json)
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    auto quad = [&](uint32_t at4) -> uint4 { return *reinterpret_cast<const uint4*>(sorted + at4); };    // reads past `end` stay inside the arena and are never used
+    if constexpr (PF == 3) {
+        cur = quad(pos & ~3u);
+        for (uint32_t k = 0; k < (pos & 3u); k++) { cur.x = cur.y; cur.y = cur.z; cur.z = cur.w; }
+    } else {
+        e0 = entry(pos);
+        e1 = pos + 1 < end ? entry(pos + 1) : e0;
+    }
     Affine<F> pn;
     Affine<F> psyn;                                                                  // DBG 4: operands from registers, no gather
     if constexpr (DBG & 4) { uint32_t* w = reinterpret_cast<uint32_t*>(&psyn); for (int i = 0; i < (int)(sizeof(psyn) / 4); i++) w[i] = (threadIdx.x * 2654435761u + i * 40503u) & 0x0fffffffu; }
@@ -422,8 +433,12 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate_pf(const Affin
         Affine<F> p;
         if constexpr (DBG & 4) { uint32_t* w = reinterpret_cast<uint32_t*>(&psyn); w[0] += 0x9e3779b9u; w[9] ^= w[0]; p = psyn; }
         else if constexpr (PF == 2) { p = pn; pn = ld_struct(bases + at_of(e1)); }
-        else p = ld_struct(bases + at_of(e0));
-        const uint32_t e2 = pos + 2 < end ? entry(pos + 2) : e1;
+        else { if constexpr (PF == 3) e0 = cur.x; p = ld_struct(bases + at_of(e0)); }
+        uint32_t e2 = 0;
+        if constexpr (PF == 3) {
+            cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
+            if (((pos + 1) & 3u) == 0 && pos + 1 < end) cur = quad(pos + 1);   // issued behind the record loads: it arrives during this addition
+        } else e2 = pos + 2 < end ? entry(pos + 2) : e1;
         if constexpr (PF == 1) {
             // after the last quad of p has arrived (the empty asm makes the address depend on it), so that the wait for p is not
             // extended to this load
@@ -435,7 +450,8 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate_pf(const Affin
                                                  (__attribute__((address_space(3))) uint32_t*)(reinterpret_cast<char*>(acc_lds) + acc_lds_bytes<Acc, THREADS>()), 4, 0, 0);
         }
         const bool neg = (e0 >> 31) != 0;
-        pos++; e0 = e1; e1 = e2;
+        pos++;
+        if constexpr (PF != 3) { e0 = e1; e1 = e2; }
         if (may_have_inf && p.is_inf()) continue;
         acc_madd(acc, p.x, p.y, neg);
     }
