@@ -106,6 +106,7 @@ struct cg_ctx {
     // ticket = running copy number (31 bits); slot = ticket % COPY_TICKETS holds its event.  A slot is recycled only after its
     // previous copy has completed (copy_begin waits for it), so a ticket older than the slot's current owner names a finished copy.
     hipEvent_t copy_ev[COPY_TICKETS] = {}; uint32_t copy_id[COPY_TICKETS] = {}; hipEvent_t ev_copy_order = nullptr; uint32_t copy_next = 0;
+    bool main_high = false;
     hipEvent_t ev_peer = nullptr;                         // cg_dev_copy_peer: "source stream reached this point"
     Arena arena;
     std::vector<void*> retired;                        // outgrown arena blocks that enqueued kernels may still use
@@ -737,7 +738,10 @@ void park_stream(int device, bool high, hipStream_t st) {
 }
 }  // namespace
 
-int32_t cg_ctx_create(int32_t device, cg_ctx** out) {
+int32_t cg_ctx_create(int32_t device, cg_ctx** out) { return cg_ctx_create_ex(device, 0, out); }
+// flags bit 0: the context's main stream gets high priority — for the context that carries a dependency chain (witness map with its
+// party-to-party exchanges) while another context of the same party keeps the chip full with independent bucket accumulations
+int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     if (!out) return fail(CG_ERR_ARG, "null out");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
@@ -746,7 +750,8 @@ int32_t cg_ctx_create(int32_t device, cg_ctx** out) {
     HIPCHK(hipSetDevice(device));
     cg_ctx* c = new cg_ctx();
     c->device = device;
-    { int rc = pooled_stream(device, false, &c->stream); if (rc) return rc; }
+    c->main_high = (flags & 1u) != 0;
+    { int rc = pooled_stream(device, c->main_high, &c->stream); if (rc) return rc; }
     // the side streams carry short, latency-bound kernels the main stream's next accumulate waits for: let their workgroups
     // jump the backlog of accumulate workgroups
     { int rc = pooled_stream(device, true, &c->aux); if (rc) return rc; }
@@ -782,7 +787,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     if (ctx->gather_buf) hipFree(ctx->gather_buf);
     for (auto& p : ctx->ev_live) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
     for (auto& p : ctx->ev_free) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
-    if (ctx->owns_stream) park_stream(ctx->device, false, ctx->stream);
+    if (ctx->owns_stream) park_stream(ctx->device, ctx->main_high, ctx->stream);
     delete ctx;
     return 0;
 }
@@ -798,7 +803,7 @@ int32_t cg_ctx_set_stream(cg_ctx* ctx, void* hip_stream) {
     HIPCHK(hipStreamSynchronize(ctx->sortst));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->aux));
-    if (ctx->owns_stream) park_stream(ctx->device, false, ctx->stream);
+    if (ctx->owns_stream) park_stream(ctx->device, ctx->main_high, ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->owns_stream = false;
     return 0;

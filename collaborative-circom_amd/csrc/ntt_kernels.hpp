@@ -165,7 +165,35 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_ct_pass(NttVecs src_vecs, N
         lazy29_store<L>(pl0, pl1, pl2, idx, v);
     }
     __syncthreads();
-    for (int q = 0; q < k; q++) {
+    int q = 0;
+    // Two stages per trip through LDS (radix-4 step in registers): a lane takes the four elements that differ in bits pb, pb - 1 of the
+    // tile index, runs the two butterflies of stage q (one twiddle, the pairs differ in bit pb) and the two of stage q + 1 (two
+    // twiddles: blocks 2 blk and 2 blk + 1, the pairs differ in bit pb - 1).  Half the LDS traffic and barriers, 3 instead of 4
+    // twiddle loads per four butterflies, and the two values that are only added to in stage q + 1 skip their carry normalisation.
+    for (; q + 1 < k; q += 2) {
+        const int pb = k - 1 - q;
+        for (int u = threadIdx.x; u < E / 4; u += NTT_THREADS) {
+            const int lo_local = u & tmask;
+            const int mu = u >> t;
+            const int mid0 = ((mu >> (pb - 1)) << (pb + 1)) | (mu & ((1 << (pb - 1)) - 1));
+            const int i00 = (mid0 << t) | lo_local, d0 = 1 << (pb + t), d1 = 1 << (pb - 1 + t);
+            const size_t blk = (hi << q) | (size_t)(mid0 >> (k - q));
+            L a0 = lazy29_load<L>(pl0, pl1, pl2, i00), a1 = lazy29_load<L>(pl0, pl1, pl2, i00 + d1);
+            const L a2 = lazy29_load<L>(pl0, pl1, pl2, i00 + d0), a3 = lazy29_load<L>(pl0, pl1, pl2, i00 + d0 + d1);
+            const L w = lazy29_load<L>(tw.p0, tw.p1, tw.p2, blk);
+            const L v2 = L::mul(a2, w), v3 = L::mul(a3, w);
+            const L b0 = a0 + v2, b2 = (a0 - v2).norm();            // b0 is only added to below: its limbs may stay unnormalised
+            const L b1 = (a1 + v3).norm(), b3 = (a1 - v3).norm();
+            const L w0 = lazy29_load<L>(tw.p0, tw.p1, tw.p2, 2 * blk), w1 = lazy29_load<L>(tw.p0, tw.p1, tw.p2, 2 * blk + 1);
+            const L y1 = L::mul(b1, w0), y3 = L::mul(b3, w1);
+            lazy29_store<L>(pl0, pl1, pl2, i00, (b0 + y1).norm());
+            lazy29_store<L>(pl0, pl1, pl2, i00 + d1, (b0 - y1).norm());
+            lazy29_store<L>(pl0, pl1, pl2, i00 + d0, (b2 + y3).norm());
+            lazy29_store<L>(pl0, pl1, pl2, i00 + d0 + d1, (b2 - y3).norm());
+        }
+        __syncthreads();
+    }
+    for (; q < k; q++) {
         const int pb = k - 1 - q;
         for (int u = threadIdx.x; u < E / 2; u += NTT_THREADS) {
             const int lo_local = u & tmask;

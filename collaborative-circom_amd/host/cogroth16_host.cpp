@@ -2409,20 +2409,23 @@ struct cgh_session {
     // slices it holds.  Contexts for proofs are kept between proofs, per device: their scratch arenas (GBs at 2^22) are allocated once
     std::vector<int> devices; std::vector<cg_ctx*> ctx0; std::vector<cgh::DeviceZKey> dzs;
     cg_ctx*& ctx0_ref() { return ctx0[0]; }
-    std::mutex mu; std::vector<std::vector<cg_ctx*>> idle;
-    cg_ctx* take(int slot = 0) {
-        { std::lock_guard<std::mutex> l(mu); if (!idle[slot].empty()) { cg_ctx* c = idle[slot].back(); idle[slot].pop_back(); return c; } }
-        cg_ctx* c = nullptr; if (cg_ctx_create(devices[slot], &c)) cgh::die("cg_ctx_create"); return c;
+    // `chain` contexts have a high-priority main stream: they carry the witness map and its exchanges (a dependency chain) while the
+    // party's second context fills the chip with the witness-independent MSMs
+    std::mutex mu; std::vector<std::vector<cg_ctx*>> idle, idle_chain;
+    cg_ctx* take(int slot = 0, bool chain = false) {
+        auto& pool = chain ? idle_chain : idle;
+        { std::lock_guard<std::mutex> l(mu); if (!pool[slot].empty()) { cg_ctx* c = pool[slot].back(); pool[slot].pop_back(); return c; } }
+        cg_ctx* c = nullptr; if (cg_ctx_create_ex(devices[slot], chain ? 1u : 0u, &c)) cgh::die("cg_ctx_create"); return c;
     }
-    void give(cg_ctx* c, int slot = 0) { if (!c) return; cg_ctx_sync(c); std::lock_guard<std::mutex> l(mu); idle[slot].push_back(c); }
+    void give(cg_ctx* c, int slot = 0, bool chain = false) { if (!c) return; cg_ctx_sync(c); std::lock_guard<std::mutex> l(mu); (chain ? idle_chain : idle)[slot].push_back(c); }
 };
 namespace {
 // a context borrowed from the session: returned to the pool on success, destroyed when the proof failed (its streams may hold
 // half-finished work)
 struct Borrowed {
-    cgh_session* s; cg_ctx* c = nullptr; bool ok = false; int slot;
-    Borrowed(cgh_session* ses, bool wanted = true, int device_slot = 0) : s(ses), slot(device_slot) { if (wanted) c = ses->take(slot); }
-    ~Borrowed() { if (!c) return; if (ok) s->give(c, slot); else cg_ctx_destroy(c); }
+    cgh_session* s; cg_ctx* c = nullptr; bool ok = false; int slot; bool chain;
+    Borrowed(cgh_session* ses, bool wanted = true, int device_slot = 0, bool chain_ctx = false) : s(ses), slot(device_slot), chain(chain_ctx) { if (wanted) c = ses->take(slot, chain); }
+    ~Borrowed() { if (!c) return; if (ok) s->give(c, slot, chain); else cg_ctx_destroy(c); }
     Borrowed(const Borrowed&) = delete; Borrowed& operator=(const Borrowed&) = delete;
 };
 // the zkey tables of the session with this proof's own public-input buffer (several proofs may run on one session at a time)
@@ -2452,6 +2455,7 @@ struct ProofWorkers {
 void session_destroy(cgh_session* s) {
     if (!s) return;
     for (auto& pool : s->idle) for (cg_ctx* c : pool) cg_ctx_destroy(c);
+    for (auto& pool : s->idle_chain) for (cg_ctx* c : pool) cg_ctx_destroy(c);
     for (size_t d = 0; d < s->ctx0.size(); d++) if (s->ctx0[d]) { cgh::release_zkey(s->ctx0[d], s->dzs[d]); cg_ctx_destroy(s->ctx0[d]); }
     delete s;
 }
@@ -2465,7 +2469,7 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
         using namespace cgh;
         if (!devices || n_dev < 1 || n_dev > 64) throw std::runtime_error("cgh_session_open_multi: bad device list");
         s = new cgh_session(); s->device = devices[0];
-        s->devices.assign(devices, devices + n_dev); s->ctx0.assign(n_dev, nullptr); s->dzs.resize(n_dev); s->idle.resize(n_dev);
+        s->devices.assign(devices, devices + n_dev); s->ctx0.assign(n_dev, nullptr); s->dzs.resize(n_dev); s->idle.resize(n_dev); s->idle_chain.resize(n_dev);
         s->z = read_zkey(curve, zkey_path);
         std::vector<Fr> pub(s->z.n_public + 1);
         for (int d = 0; d < n_dev; d++) {
@@ -2497,7 +2501,8 @@ int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uin
         const ZKey& z = s->z;
         const Fr* w = (const Fr*)full_witness;
         std::vector<Fr> pub(w, w + z.n_public + 1);
-        Borrowed ctx(s), second(s, s->second_context);
+        static const bool no_prio = getenv("CGH_NO_CHAIN_PRIORITY") != nullptr;          // tuning knob
+        Borrowed ctx(s, true, 0, s->second_context && !no_prio), second(s, s->second_context);
         ProofWorkers workers(s);
         ProofZKey pz(s, ctx.c, pub);
         const auto t0 = std::chrono::steady_clock::now();
@@ -2527,7 +2532,8 @@ int32_t cgh_session_prove_rep3(void* h, const uint64_t* pub_in, const uint64_t* 
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
         std::deque<Bytes> rec_prev, rec_next;
         auto party = [&](int i, Rep3Network* net, uint8_t* out) {
-            Borrowed ctx(s), second(s, s->second_context);
+            static const bool no_prio = getenv("CGH_NO_CHAIN_PRIORITY") != nullptr;      // tuning knob
+            Borrowed ctx(s, true, 0, s->second_context && !no_prio), second(s, s->second_context);
             ProofWorkers workers(s);
             ProofZKey pz(s, ctx.c, pub);
             {

@@ -42,6 +42,9 @@ enum { CG_OK = 0, CG_ERR_ARG = 1, CG_ERR_HIP = 2, CG_ERR_NODEVICE = 3, CG_ERR_OO
 
 /* ---- context ------------------------------------------------------------------------------------------------- */
 int32_t cg_ctx_create(int32_t device, cg_ctx** out);
+/* flags bit 0: high-priority main stream — for the context that carries a dependency chain (the witness map with its party-to-party
+ * exchanges, groth16.rs:141-204) while another context of the same party keeps the chip full with independent MSMs */
+int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out);
 int32_t cg_ctx_destroy(cg_ctx* ctx);
 int32_t cg_ctx_sync(cg_ctx* ctx);
 void*   cg_ctx_stream(cg_ctx* ctx);                 /* the hipStream_t every launch of this context goes to */
