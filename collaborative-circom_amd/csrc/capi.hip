@@ -107,6 +107,7 @@ struct cg_ctx {
     // previous copy has completed (copy_begin waits for it), so a ticket older than the slot's current owner names a finished copy.
     hipEvent_t copy_ev[COPY_TICKETS] = {}; uint32_t copy_id[COPY_TICKETS] = {}; hipEvent_t ev_copy_order = nullptr; uint32_t copy_next = 0;
     bool main_high = false;
+    uint32_t msm_chunk = 0;                               // cg_msm_set_chunk
     hipEvent_t ev_peer = nullptr;                         // cg_dev_copy_peer: "source stream reached this point"
     Arena arena;
     std::vector<void*> retired;                        // outgrown arena blocks that enqueued kernels may still use
@@ -239,7 +240,12 @@ template <class Fn> int with_coord_field(int curve, int group, Fn&& fn) {   // g
 
 // One digit/sort schedule per scalar vector, then one accumulate+reduce per base table: `nb` tables (same curve, any groups)
 // multiplied by the SAME k scalar vectors.  tickets_out[b] collects the k results for table b.
+int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, const size_t* offsets, size_t n, const void* const* d_scalars, int k, int* tickets_out, bool force_exact);
 int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, const size_t* offsets, size_t n, const void* const* d_scalars, int k, int* tickets_out, bool force_exact = false) {
+    struct Scope { uint32_t prev; Scope(uint32_t v) : prev(g_chunk_request) { g_chunk_request = v; } ~Scope() { g_chunk_request = prev; } } scope(ctx ? ctx->msm_chunk : 0);   // geometry of this context's launches
+    return msm_begin_multi_impl_(ctx, nb, bases, offsets, n, d_scalars, k, tickets_out, force_exact);
+}
+int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, const size_t* offsets, size_t n, const void* const* d_scalars, int k, int* tickets_out, bool force_exact) {
     if (!ctx || !bases || !tickets_out || (n && !d_scalars)) return fail(CG_ERR_ARG, "null argument");
     if (nb < 1 || nb > 16) return fail(CG_ERR_ARG, "number of base tables out of range");
     if (k < 1 || k > 8) return fail(CG_ERR_ARG, "k out of range");
@@ -1126,6 +1132,12 @@ int32_t cg_msm_set_scatter_capacity(cg_ctx* ctx, int32_t cap) {
     if (!ctx) return fail(CG_ERR_ARG, "null ctx");
     if (cap > 65536) return fail(CG_ERR_ARG, "capacity out of range");
     ctx->scatter_cap = cap;
+    return 0;
+}
+int32_t cg_msm_set_chunk(cg_ctx* ctx, int32_t entries_per_lane) {
+    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
+    if (entries_per_lane < 0 || entries_per_lane > 4096) return fail(CG_ERR_ARG, "chunk length out of range");
+    ctx->msm_chunk = (uint32_t)entries_per_lane;
     return 0;
 }
 int32_t cg_msm_set_window(cg_ctx* ctx, int32_t c) {

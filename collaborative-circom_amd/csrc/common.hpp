@@ -42,6 +42,10 @@ constexpr int MSM_SHARED_GROUPS = 16;
 // in lock step, so a launch of 2.16 residency rounds takes as long as 2.33 (the last 0.16 round runs one wave per SIMD, three
 // times as fast, on a sixth of the chip): when the list is long enough the chunk length is chosen so that the chunks fill a whole
 // number of rounds (2^22 points, 13 windows: 139 entries per lane, 2 rounds, instead of 128; measured 4.70 -> 4.51 ms per launch).
+// entries per lane requested by the calling context for this thread's launches (cg_msm_set_chunk; 0 = automatic): a context whose
+// accumulations run BESIDE a latency-critical chain on another context uses shorter chunks — a workgroup then lives ~1 ms instead of
+// ~2 and the chain's kernels, which can only start as workgroups retire, get onto the chip sooner
+inline thread_local uint32_t g_chunk_request = 0;
 inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_lanes = 0) {
     MsmGeom g;
     g.nb = 1u << (c - 1);
@@ -61,7 +65,8 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_
     static const size_t chunk_min = [] { const char* e = getenv("CG_MSM_CHUNK_MIN"); return e ? (size_t)atoi(e) : (size_t)16; }();  // tuning knob (8 -> 16: 2^17-constraint step 7.3 -> 5.8 ms: half the continuation pieces)
     g.chunk_len = (uint32_t)std::min<size_t>(chunk_max, std::max<size_t>(chunk_min, entries / (256 * 1024)));
     static const bool no_rounds = getenv("CG_MSM_NO_ROUNDS") != nullptr;                  // tuning knob
-    if (resident_lanes && !no_rounds && entries >= resident_lanes * 2 * chunk_min) {      // from 32 entries per lane on (table slices of a multi-GPU plan:
+    if (g_chunk_request) g.chunk_len = (uint32_t)std::min<size_t>(g.chunk_len, std::max<size_t>(chunk_min, g_chunk_request));
+    else if (resident_lanes && !no_rounds && entries >= resident_lanes * 2 * chunk_min) {      // from 32 entries per lane on (table slices of a multi-GPU plan:
         const size_t rounds = std::max<size_t>(1, (entries + resident_lanes * chunk_max / 2) / (resident_lanes * chunk_max));   // 2^20 points x 15 windows = one round of 80)
         g.chunk_len = (uint32_t)((entries + rounds * resident_lanes - 1) / (rounds * resident_lanes));
     }

@@ -253,6 +253,9 @@ struct Rep3Network {   // rep3/network.rs:30-64
     virtual void recv_prev(void* data, size_t bytes) = 0;
     virtual void send_prev(const void* data, size_t bytes) = 0;   // network.send(id.prev_id(), ..) (rep3.rs:746-753)
     virtual void recv_next(void* data, size_t bytes) = 0;
+    // Optional zero-copy receive: the next message from the previous party, already in page-locked memory that stays valid until the
+    // network object goes away (a transport that receives into registered buffers); nullptr = not available, use recv_prev.
+    virtual const void* recv_prev_pinned(size_t bytes) { (void)bytes; return nullptr; }
 };
 struct InProcHub {
     std::mutex mu; std::condition_variable cv;
@@ -296,27 +299,48 @@ struct InProcNetwork : Rep3Network {
 // A party's incoming traffic recorded during a three-party run and replayed to the same party running alone: its messages depend
 // only on the inputs and the randomness streams, so the solo run repeats the recorded one bit for bit.  Used to time ONE party with
 // the GPU to itself, as in a deployment (each party on its own machine), without a second and third GPU.
+// Large messages (the 4 MiB chunks of a mul_vec exchange) are recorded into page-locked memory, so that the replay can hand them to the
+// driver where they lie (recv_prev_pinned) — a peer whose data is already in registered buffers, i.e. the network itself is excluded
+// from the solo timing, as SURVEY §8d asks; small messages are copied as before.
+struct RecordedMsg { Bytes small; void* pinned = nullptr; size_t n = 0; };
+struct RecordedQueue {
+    std::deque<RecordedMsg> q; std::vector<void*> owned;
+    ~RecordedQueue() { for (void* p : owned) cg_host_free(p); }
+    void add(const void* d, size_t b) {
+        RecordedMsg m; m.n = b;
+        if (b >= ((size_t)1 << 20) && cg_host_alloc(b, &m.pinned) == 0) { memcpy(m.pinned, d, b); owned.push_back(m.pinned); }
+        else { m.pinned = nullptr; m.small.assign((const uint8_t*)d, (const uint8_t*)d + b); }
+        q.push_back(std::move(m));
+    }
+};
 struct RecordingNetwork : Rep3Network {
-    Rep3Network* inner; std::deque<Bytes>* from_prev; std::deque<Bytes>* from_next;
-    RecordingNetwork(Rep3Network* n, std::deque<Bytes>* p, std::deque<Bytes>* q) : inner(n), from_prev(p), from_next(q) {}
+    Rep3Network* inner; RecordedQueue* from_prev; RecordedQueue* from_next;
+    RecordingNetwork(Rep3Network* n, RecordedQueue* p, RecordedQueue* q) : inner(n), from_prev(p), from_next(q) {}
     int id() const override { return inner->id(); }
     void send_next(const void* d, size_t b) override { inner->send_next(d, b); }
     void send_prev(const void* d, size_t b) override { inner->send_prev(d, b); }
-    void recv_prev(void* d, size_t b) override { inner->recv_prev(d, b); from_prev->emplace_back((const uint8_t*)d, (const uint8_t*)d + b); }
-    void recv_next(void* d, size_t b) override { inner->recv_next(d, b); from_next->emplace_back((const uint8_t*)d, (const uint8_t*)d + b); }
+    void recv_prev(void* d, size_t b) override { inner->recv_prev(d, b); from_prev->add(d, b); }
+    void recv_next(void* d, size_t b) override { inner->recv_next(d, b); from_next->add(d, b); }
 };
 struct ReplayNetwork : Rep3Network {
-    int me; std::deque<Bytes>* from_prev; std::deque<Bytes>* from_next;
-    ReplayNetwork(int i, std::deque<Bytes>* p, std::deque<Bytes>* q) : me(i), from_prev(p), from_next(q) {}
+    int me; RecordedQueue* from_prev; RecordedQueue* from_next;
+    ReplayNetwork(int i, RecordedQueue* p, RecordedQueue* q) : me(i), from_prev(p), from_next(q) {}
     int id() const override { return me; }
     void send_next(const void*, size_t) override {}
     void send_prev(const void*, size_t) override {}
-    static void pop(std::deque<Bytes>* q, void* d, size_t b) {
-        if (q->empty() || q->front().size() != b) throw std::runtime_error("replay: message sequence differs from the recorded run");
-        memcpy(d, q->front().data(), b); q->pop_front();
+    static void pop(RecordedQueue* q, void* d, size_t b) {
+        if (q->q.empty() || q->q.front().n != b) throw std::runtime_error("replay: message sequence differs from the recorded run");
+        const RecordedMsg& m = q->q.front();
+        memcpy(d, m.pinned ? m.pinned : (const void*)m.small.data(), b); q->q.pop_front();
     }
     void recv_prev(void* d, size_t b) override { pop(from_prev, d, b); }
     void recv_next(void* d, size_t b) override { pop(from_next, d, b); }
+    const void* recv_prev_pinned(size_t b) override {
+        if (from_prev->q.empty() || from_prev->q.front().n != b) throw std::runtime_error("replay: message sequence differs from the recorded run");
+        const void* p = from_prev->q.front().pinned;
+        if (p) from_prev->q.pop_front();                 // the memory itself stays with the queue's owner list
+        return p;
+    }
 };
 
 // Shamir: any-to-any channels (shamir/network.rs:17-59)
@@ -819,10 +843,14 @@ public:
             CG(cg_copy_wait(ctx, down.front().tk));
             net->send_next(down.front().slot, len * 32);                               // chunked send_next_many
             down.pop_front();
-            uint8_t* slot = ring_slot(ring_in, XCHG_CHUNK);
-            net->recv_prev(slot, len * 32);
-            CG(cg_dev_upload_begin(ctx, (uint8_t*)out.c[1] + off * 32, slot, len * 32, 0, &up));
-            ring_in.busy[ring_in.last] = up;
+            if (const void* direct = net->recv_prev_pinned(len * 32)) {                    // the transport holds it in page-locked memory already
+                CG(cg_dev_upload_begin(ctx, (uint8_t*)out.c[1] + off * 32, direct, len * 32, 0, &up));
+            } else {
+                uint8_t* slot = ring_slot(ring_in, XCHG_CHUNK);
+                net->recv_prev(slot, len * 32);
+                CG(cg_dev_upload_begin(ctx, (uint8_t*)out.c[1] + off * 32, slot, len * 32, 0, &up));
+                ring_in.busy[ring_in.last] = up;
+            }
         }
         if (up >= 0) CG(cg_copy_fence(ctx, up));                                       // later launches see the received component
         pm.exchange = false;
@@ -969,6 +997,10 @@ public:
     }
     PendingMsm msm_begin_multi(const std::vector<const cg_bases*>& tables, const std::vector<size_t>& offsets, const std::vector<int>& groups, size_t n, const ShareVec& s, bool on_aux) {
         PendingMsm p; p.on = on_aux && aux ? aux : ctx; p.groups = groups; p.tickets.resize(tables.size());
+        // REP3 at sizes where the exchanges are asynchronous: these MSMs run beside the witness map's dependency chain (product -> down ->
+        // peer -> up, twice) on the other context; shorter-lived workgroups let the chain's kernels onto the chip sooner (2^22: one party
+        // alone 107 -> 97 ms)
+        if (p.on != ctx) CG(cg_msm_set_chunk(p.on, mode == Mode::Rep3 && n >= XCHG_ASYNC_MIN ? 64 : 0));
         const void* sc[2] = {s.c[0], s.c[1]};
         if (p.on != ctx) CG(cg_ctx_sync(ctx));                                          // the scalars were produced on this driver's stream
         CG(cg_msm_dev_begin_multi(p.on, (int32_t)tables.size(), tables.data(), offsets.data(), n, sc, k(), p.tickets.data()));
@@ -2530,7 +2562,7 @@ int32_t cgh_session_prove_rep3(void* h, const uint64_t* pub_in, const uint64_t* 
         const ZKey& z = s->z;
         const size_t n_aux = z.n_vars - z.n_public - 1, psz = 8 * z.curve.fq();
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
-        std::deque<Bytes> rec_prev, rec_next;
+        RecordedQueue rec_prev, rec_next;
         auto party = [&](int i, Rep3Network* net, uint8_t* out) {
             static const bool no_prio = getenv("CGH_NO_CHAIN_PRIORITY") != nullptr;      // tuning knob
             Borrowed ctx(s, true, 0, s->second_context && !no_prio), second(s, s->second_context);

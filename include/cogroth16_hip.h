@@ -122,6 +122,9 @@ int32_t cg_msm_end(cg_ctx* ctx, int32_t ticket, void* h_out_jacobian);
 int32_t cg_msm_dev_begin_multi(cg_ctx* ctx, int32_t n_tables, const cg_bases* const* tables, const size_t* offsets, size_t n,
                                const void* const* d_scalars, int32_t k, int32_t* tickets);
 /* window size override (0 = automatic); tuning knob only, never changes results */
+/* entries of the sorted list one lane folds in the bucket accumulation of THIS context's MSMs (0 = automatic: ~128, whole residency
+ * rounds).  Shorter chunks = shorter-lived workgroups: for a context whose MSMs run beside a dependency chain on another context. */
+int32_t cg_msm_set_chunk(cg_ctx* ctx, int32_t entries_per_lane);
 int32_t cg_msm_set_window(cg_ctx* ctx, int32_t c);
 /* Scalar-side schedule.  Default (cap < 0): exact two-pass counting sort.  cap == 0 selects an optimistic one-pass scatter into
  * fixed-capacity buckets sized for uniformly random scalars (secret shares); if a bucket overflows, cg_msm_end transparently
