@@ -106,7 +106,8 @@ struct cg_ctx {
     // ticket = running copy number (31 bits); slot = ticket % COPY_TICKETS holds its event.  A slot is recycled only after its
     // previous copy has completed (copy_begin waits for it), so a ticket older than the slot's current owner names a finished copy.
     hipEvent_t copy_ev[COPY_TICKETS] = {}; uint32_t copy_id[COPY_TICKETS] = {}; hipEvent_t ev_copy_order = nullptr; uint32_t copy_next = 0;
-    bool main_high = false;
+    // priority class of each stream: +1 high, 0 normal, -1 low (pooled_stream)
+    int prio_main = 0, prio_side = 1, prio_copy = 0;
     uint32_t msm_chunk = 0;                               // cg_msm_set_chunk
     hipEvent_t ev_peer = nullptr;                         // cg_dev_copy_peer: "source stream reached this point"
     Arena arena;
@@ -723,30 +724,41 @@ const char* cg_version(void) { return "cogroth16-hip 0.1 (gfx950)"; }
 // the test-suite) instead of being destroyed.  A parked stream is idle: cg_ctx_destroy synchronises it first.
 namespace {
 std::mutex g_stream_pool_mu;
-std::map<std::pair<int, int>, std::vector<hipStream_t>> g_stream_pool;      // (device, high priority?) -> idle streams
-int pooled_stream(int device, bool high, hipStream_t* out) {
+std::map<std::pair<int, int>, std::vector<hipStream_t>> g_stream_pool;      // (device, priority class) -> idle streams
+// cls: +1 high, 0 normal, -1 low.  The runtime keeps one set of hardware queues per priority and hands a new stream the least used
+// queue of its set: streams of one class that are created one after the other land on different queues (while the set lasts).
+int pooled_stream(int device, int cls, hipStream_t* out) {
     {
         std::lock_guard<std::mutex> l(g_stream_pool_mu);
-        auto& v = g_stream_pool[{device, high ? 1 : 0}];
+        auto& v = g_stream_pool[{device, cls}];
         if (!v.empty()) { *out = v.back(); v.pop_back(); return 0; }
     }
-    if (!high) { HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking)); return 0; }
-    int prio_lo = 0, prio_hi = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio_hi));
+    if (cls == 0) { HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking)); return 0; }
+    int prio_least = 0, prio_greatest = 0;                                   // numerically: least >= greatest
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, cls > 0 ? prio_greatest : prio_least));
     return 0;
 }
-void park_stream(int device, bool high, hipStream_t st) {
+void park_stream(int device, int cls, hipStream_t st) {
     if (!st) return;
     std::lock_guard<std::mutex> l(g_stream_pool_mu);
-    auto& v = g_stream_pool[{device, high ? 1 : 0}];
+    auto& v = g_stream_pool[{device, cls}];
     if (v.size() < 32) v.push_back(st); else hipStreamDestroy(st);
+}
+int make_copy_streams(cg_ctx* c) {
+    { int rc = pooled_stream(c->device, c->prio_copy, &c->h2d); if (rc) return rc; }
+    { int rc = pooled_stream(c->device, c->prio_copy, &c->d2h); if (rc) return rc; }
+    HIPCHK(hipEventCreateWithFlags(&c->ev_copy_order, hipEventDisableTiming));
+    return 0;
 }
 }  // namespace
 
 int32_t cg_ctx_create(int32_t device, cg_ctx** out) { return cg_ctx_create_ex(device, 0, out); }
-// flags bit 0: the context's main stream gets high priority — for the context that carries a dependency chain (witness map with its
-// party-to-party exchanges) while another context of the same party keeps the chip full with independent bucket accumulations
+// flags bit 0 ("chain"): for the context that carries a dependency chain (witness map with its party-to-party exchanges) while another
+// context of the same party keeps the chip full with independent bucket accumulations — main stream and copy streams (created here,
+// one after the other: three different hardware queues) get high priority, the side streams normal priority.
+// flags bit 1 ("bulk"): the context next to a chain context — main stream low priority, side streams normal: its kernels fill what
+// the chain leaves free and share no hardware queue with it.
 int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     if (!out) return fail(CG_ERR_ARG, "null out");
     int count = 0;
@@ -756,12 +768,14 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     HIPCHK(hipSetDevice(device));
     cg_ctx* c = new cg_ctx();
     c->device = device;
-    c->main_high = (flags & 1u) != 0;
-    { int rc = pooled_stream(device, c->main_high, &c->stream); if (rc) return rc; }
+    if (flags & 1u) { c->prio_main = 1; c->prio_copy = 1; c->prio_side = 0; }
+    else if (flags & 2u) { static const int bulk_cls = getenv("CG_BULK_CLASS") ? atoi(getenv("CG_BULK_CLASS")) : -1; c->prio_main = bulk_cls; c->prio_side = 0; }   // CG_BULK_CLASS: tuning knob
+    { int rc = pooled_stream(device, c->prio_main, &c->stream); if (rc) return rc; }
+    if (flags & 1u) { int rc = make_copy_streams(c); if (rc) return rc; }
     // the side streams carry short, latency-bound kernels the main stream's next accumulate waits for: let their workgroups
-    // jump the backlog of accumulate workgroups
-    { int rc = pooled_stream(device, true, &c->aux); if (rc) return rc; }
-    { int rc = pooled_stream(device, true, &c->sortst); if (rc) return rc; }
+    // jump the backlog of accumulate workgroups (one priority class above the main stream's, except next to a chain)
+    { int rc = pooled_stream(device, c->prio_side, &c->aux); if (rc) return rc; }
+    { int rc = pooled_stream(device, c->prio_side, &c->sortst); if (rc) return rc; }
     HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_sched_free[i], hipEventDisableTiming)); }
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming)); }
@@ -781,10 +795,10 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
         for (hipEvent_t e : ctx->copy_ev) if (e) hipEventDestroy(e);
         if (ctx->ev_peer) hipEventDestroy(ctx->ev_peer);
         hipEventDestroy(ctx->ev_copy_order);
-        park_stream(ctx->device, false, ctx->h2d); park_stream(ctx->device, false, ctx->d2h);
+        park_stream(ctx->device, ctx->prio_copy, ctx->h2d); park_stream(ctx->device, ctx->prio_copy, ctx->d2h);
     }
-    park_stream(ctx->device, true, ctx->aux);
-    park_stream(ctx->device, true, ctx->sortst);
+    park_stream(ctx->device, ctx->prio_side, ctx->aux);
+    park_stream(ctx->device, ctx->prio_side, ctx->sortst);
     for (auto& kv : ctx->twiddles) shared_twiddles_release(ctx->device, kv.first);
     for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
     for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.h_flags) hipHostFree(t.h_flags); if (t.done) hipEventDestroy(t.done); }
@@ -793,7 +807,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     if (ctx->gather_buf) hipFree(ctx->gather_buf);
     for (auto& p : ctx->ev_live) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
     for (auto& p : ctx->ev_free) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
-    if (ctx->owns_stream) park_stream(ctx->device, ctx->main_high, ctx->stream);
+    if (ctx->owns_stream) park_stream(ctx->device, ctx->prio_main, ctx->stream);
     delete ctx;
     return 0;
 }
@@ -809,22 +823,79 @@ int32_t cg_ctx_set_stream(cg_ctx* ctx, void* hip_stream) {
     HIPCHK(hipStreamSynchronize(ctx->sortst));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->aux));
-    if (ctx->owns_stream) park_stream(ctx->device, ctx->main_high, ctx->stream);
+    if (ctx->owns_stream) park_stream(ctx->device, ctx->prio_main, ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->owns_stream = false;
     return 0;
 }
 
+// ---- device blocks.  hipFree waits for every stream of the device (measured: a prover freeing its witness-map vectors stalled for
+// 25 ms behind another context's MSM), so blocks released with cg_dev_free are parked per device with an event recorded behind the
+// work of the releasing context's streams and handed out again, to any context of the device, once that event has completed — from
+// then on nothing enqueued before the release can touch the block.  CG_DEV_CACHE_MB bounds the parked bytes per device (default 32768,
+// 0 = release at once); when an allocation fails the parked blocks are released and it is tried again.
+namespace {
+struct ParkedBlock { void* p; hipEvent_t ev; };
+struct DevCache {
+    std::mutex mu;
+    std::multimap<size_t, ParkedBlock> parked; size_t parked_bytes = 0;
+    std::map<void*, size_t> live;                        // blocks handed out by cg_dev_alloc -> rounded size
+    std::vector<hipEvent_t> spare;
+};
+DevCache& dev_cache(int device) {
+    static std::mutex mu; static std::map<int, DevCache*> m;
+    std::lock_guard<std::mutex> l(mu);
+    DevCache*& c = m[device]; if (!c) c = new DevCache(); return *c;
+}
+size_t dev_cache_cap() { static const size_t cap = [] { const char* e = getenv("CG_DEV_CACHE_MB"); return (e ? (size_t)atoll(e) : (size_t)32768) << 20; }(); return cap; }
+size_t dev_round(size_t bytes) { const size_t q = bytes >= (64u << 10) ? 4096 : 256; return (std::max<size_t>(bytes, 16) + q - 1) / q * q; }
+void dev_cache_flush(DevCache& dc) {                     // caller holds dc.mu
+    for (auto& kv : dc.parked) { (void)hipFree(kv.second.p); dc.spare.push_back(kv.second.ev); }
+    dc.parked.clear(); dc.parked_bytes = 0;
+}
+}  // namespace
 int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr) {
     if (!ctx || !d_ptr) return fail(CG_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMalloc(d_ptr, std::max<size_t>(bytes, 16)));
+    const size_t rb = dev_round(bytes);
+    DevCache& dc = dev_cache(ctx->device);
+    std::lock_guard<std::mutex> l(dc.mu);
+    auto range = dc.parked.equal_range(rb);
+    for (auto it = range.first; it != range.second; ++it) {
+        if (hipEventQuery(it->second.ev) != hipSuccess) { (void)hipGetLastError(); continue; }
+        *d_ptr = it->second.p; dc.spare.push_back(it->second.ev); dc.parked.erase(it); dc.parked_bytes -= rb; dc.live[*d_ptr] = rb;
+        return 0;
+    }
+    hipError_t e = hipMalloc(d_ptr, rb);
+    if (e == hipErrorOutOfMemory && !dc.parked.empty()) { (void)hipGetLastError(); dev_cache_flush(dc); e = hipMalloc(d_ptr, rb); }
+    HIPCHK(e);
+    dc.live[*d_ptr] = rb;
     return 0;
 }
 int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr) {
     if (!ctx) return fail(CG_ERR_ARG, "null ctx");
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (d_ptr) HIPCHK(hipFree(d_ptr));
+    if (!d_ptr) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    DevCache& dc = dev_cache(ctx->device);
+    std::unique_lock<std::mutex> l(dc.mu);
+    auto it = dc.live.find(d_ptr);
+    const size_t rb = it == dc.live.end() ? 0 : it->second;
+    if (it != dc.live.end()) dc.live.erase(it);
+    if (!rb || dc.parked_bytes + rb > dev_cache_cap()) {  // not one of ours, or no room to park it: the synchronising release
+        l.unlock();
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(d_ptr));
+        return 0;
+    }
+    hipEvent_t ev = nullptr;
+    if (!dc.spare.empty()) { ev = dc.spare.back(); dc.spare.pop_back(); } else HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    // the block's last users may sit on any of the context's streams: the main stream collects them, the event follows
+    for (hipStream_t side : {ctx->aux, ctx->sortst, ctx->h2d, ctx->d2h}) if (side) {
+        HIPCHK(hipEventRecord(ev, side));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ev, 0));
+    }
+    HIPCHK(hipEventRecord(ev, ctx->stream));
+    dc.parked.insert({rb, ParkedBlock{d_ptr, ev}}); dc.parked_bytes += rb;
     return 0;
 }
 int32_t cg_dev_upload(cg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
@@ -840,13 +911,48 @@ int32_t cg_dev_download(cg_ctx* ctx, void* h_dst, const void* d_src, size_t byte
     return 0;
 }
 // ---- page-locked staging and asynchronous copies (the mul_vec / degree_reduce exchanges move in chunks under the compute)
+// Page-locking and releasing host memory is slow (measured: hipHostMalloc of a 32 MB exchange ring 8 ms, hipHostFree 11-14 ms, each
+// proof of a session used to pay both twice): released blocks are parked by size and handed out again.  CG_HOST_CACHE_MB bounds the
+// parked bytes (default 2048, 0 = release at once).  The caller releases a block only when no copy uses it any more, as before.
+namespace {
+struct HostCache { std::mutex mu; std::multimap<size_t, void*> parked; size_t parked_bytes = 0; std::map<void*, size_t> live; };
+HostCache& host_cache() { static HostCache* c = new HostCache(); return *c; }
+size_t host_cache_cap() { static const size_t cap = [] { const char* e = getenv("CG_HOST_CACHE_MB"); return (e ? (size_t)atoll(e) : (size_t)2048) << 20; }(); return cap; }
+}  // namespace
 int32_t cg_host_alloc(size_t bytes, void** h_ptr) {
     if (!h_ptr) return fail(CG_ERR_ARG, "null argument");
-    HIPCHK(hipHostMalloc(h_ptr, std::max<size_t>(bytes, 16), hipHostMallocDefault));
+    const size_t rb = (std::max<size_t>(bytes, 16) + 4095) / 4096 * 4096;
+    HostCache& hc = host_cache();
+    {
+        std::lock_guard<std::mutex> l(hc.mu);
+        auto it = hc.parked.find(rb);
+        if (it != hc.parked.end()) { *h_ptr = it->second; hc.parked.erase(it); hc.parked_bytes -= rb; hc.live[*h_ptr] = rb; return 0; }
+    }
+    hipError_t e = hipHostMalloc(h_ptr, rb, hipHostMallocDefault);
+    if (e != hipSuccess) {                                  // make room and try once more
+        (void)hipGetLastError();
+        std::vector<void*> drop;
+        { std::lock_guard<std::mutex> l(hc.mu); for (auto& kv : hc.parked) drop.push_back(kv.second); hc.parked.clear(); hc.parked_bytes = 0; }
+        for (void* p : drop) (void)hipHostFree(p);
+        e = hipHostMalloc(h_ptr, rb, hipHostMallocDefault);
+    }
+    HIPCHK(e);
+    std::lock_guard<std::mutex> l(hc.mu);
+    hc.live[*h_ptr] = rb;
     return 0;
 }
 int32_t cg_host_free(void* h_ptr) {
-    if (h_ptr) HIPCHK(hipHostFree(h_ptr));
+    if (!h_ptr) return 0;
+    HostCache& hc = host_cache();
+    {
+        std::lock_guard<std::mutex> l(hc.mu);
+        auto it = hc.live.find(h_ptr);
+        if (it != hc.live.end()) {
+            const size_t rb = it->second; hc.live.erase(it);
+            if (hc.parked_bytes + rb <= host_cache_cap()) { hc.parked.insert({rb, h_ptr}); hc.parked_bytes += rb; return 0; }
+        }
+    }
+    HIPCHK(hipHostFree(h_ptr));
     return 0;
 }
 int32_t cg_host_is_pinned(const void* h_ptr) {
@@ -858,11 +964,7 @@ int32_t cg_host_is_pinned(const void* h_ptr) {
 static int32_t copy_begin(cg_ctx* ctx, bool up, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, bool after_stream, int32_t* ticket) {
     if (!ctx || !ticket || ((!dst || !src) && bytes)) return fail(CG_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
-    if (!ctx->h2d) {                                        // the copy streams exist from the first asynchronous copy on
-        { int rc = pooled_stream(ctx->device, false, &ctx->h2d); if (rc) return rc; }
-        { int rc = pooled_stream(ctx->device, false, &ctx->d2h); if (rc) return rc; }
-        HIPCHK(hipEventCreateWithFlags(&ctx->ev_copy_order, hipEventDisableTiming));
-    }
+    if (!ctx->h2d) { int rc = make_copy_streams(ctx); if (rc) return rc; }   // the copy streams exist from the first asynchronous copy on
     hipStream_t st = up ? ctx->h2d : ctx->d2h;
     if (after_stream) {                                     // everything enqueued on the context's stream so far comes first
         HIPCHK(hipEventRecord(ctx->ev_copy_order, ctx->stream));

@@ -66,10 +66,18 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     // 10 = 4-byte index reads two iterations ahead
     const char* var_s = getenv("CG_ACC_VARIANT");
     const int variant = var_s ? atoi(var_s) : 3;
+    // A context that runs next to a latency chain (cg_msm_set_chunk) launches the G2 accumulation one chip-load of workgroups at a
+    // time: its workgroups hold 147 of the CU's 160 KB of LDS, so nothing that needs LDS (an NTT pass: 72 KB) can start while the
+    // launch lasts — measured: a high-priority NTT pass waited 11 ms, the whole launch.  Between the slices the chip drains and the
+    // waiting kernels go first.
     auto launch_pf = [&](auto kern, int T, size_t lds) -> int {
         if (lds > 0) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((g.nchunks + T - 1) / T), dim3(T), lds, st, d_bases, sorted, offsets, counts,
-                           (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, (uint32_t)table_stride, buckets, cont, cont_bucket, may_have_inf ? 1u : 0u);
+        const uint32_t groups = (g.nchunks + T - 1) / T;
+        static const bool no_slice = getenv("CG_G2_NO_SLICE") != nullptr;       // tuning knob
+        const uint32_t slice = lds > 0 && g_chunk_request && !no_slice ? 256u * (uint32_t)std::max<size_t>(1, ((size_t)160 << 10) / lds) : groups;
+        for (uint32_t first = 0; first < groups; first += slice)
+            hipLaunchKernelGGL(kern, dim3(std::min(slice, groups - first)), dim3(T), lds, st, d_bases, sorted, offsets, counts,
+                               (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, (uint32_t)table_stride, buckets, cont, cont_bucket, may_have_inf ? 1u : 0u, first * (uint32_t)T);
         return 0;
     };
     constexpr bool g2 = IsFp2<F>::value;

@@ -381,9 +381,9 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate_pf(const Affin
                                                                      const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                                      uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks, uint32_t table_stride,
                                                                      typename BucketOf<F>::type* __restrict__ buckets, typename BucketOf<F>::type* __restrict__ cont,
-                                                                     uint32_t* __restrict__ cont_bucket, uint32_t may_have_inf) {
+                                                                     uint32_t* __restrict__ cont_bucket, uint32_t may_have_inf, uint32_t first_chunk) {
     extern __shared__ uint4 acc_lds[];        // [accumulators (LDS policies)] [PF == 1: THREADS junk dwords, see PF_JUNK_OFFSET]
-    const uint32_t q = blockIdx.x * THREADS + threadIdx.x;
+    const uint32_t q = first_chunk + blockIdx.x * THREADS + threadIdx.x;   // first_chunk: a launch may cover a slice of the chunks (msm_accumulate_reduce)
     if (q >= nchunks) return;
     const uint32_t total = offsets[nbuckets - 1] + counts[nbuckets - 1];
     uint32_t pos = q * chunk_len;

@@ -715,9 +715,12 @@ public:
         return out;
     }
     // promote_to_trivial_shares (fieldshare.rs:262-283) + clone_from_slice (rep3.rs:710-725)
-    void clone_public_into(ShareVec& dst, size_t dst_off, const std::vector<Fr>& pub) {
+    // d_pub (optional): the same values already on the device — the copy is then enqueued like a kernel, the host does not wait
+    void clone_public_into(ShareVec& dst, size_t dst_off, const std::vector<Fr>& pub, const void* d_pub = nullptr) {
         const int holder = mode != Mode::Rep3 ? 0 : (party() == 0 ? 0 : party() == 1 ? 1 : -1);   // REP3: ID0 -> a, ID1 -> b, ID2 -> nothing; plain / Shamir: the value itself
-        if (holder >= 0) CG(cg_dev_upload(ctx, (uint8_t*)dst.c[holder] + dst_off * 32, pub.data(), pub.size() * 32));
+        if (holder < 0) return;
+        if (d_pub) CG(cg_dev_copy_peer(ctx, (uint8_t*)dst.c[holder] + dst_off * 32, ctx, d_pub, pub.size() * 32));
+        else CG(cg_dev_upload(ctx, (uint8_t*)dst.c[holder] + dst_off * 32, pub.data(), pub.size() * 32));
     }
     // mul_vec (traits.rs:164): plain.rs:219-224 ; rep3.rs:650-670 (local product + mask, send to next, receive from prev)
     // ---- page-locked staging rings for the asynchronous exchanges: chunks of XCHG_CHUNK elements travel over the
@@ -1099,13 +1102,13 @@ public:
         const ZKey& z = *dz.z;
         const size_t num_inputs = z.n_public + 1, num_constraints = z.num_constraints;
         const Domain dom = groth16_domain(driver.curve, z.pow, num_constraints, num_inputs);          // :150-153
+        HipDriver::Marks mk("witness_map party 0", driver.party() <= 0);
         ShareVec a = driver.evaluate_constraints(dz.mat[0], dz.pub_dev, (uint32_t)num_inputs, private_witness, dom.m);   // :156-166
         ShareVec b = driver.evaluate_constraints(dz.mat[1], dz.pub_dev, (uint32_t)num_inputs, private_witness, dom.m);
-        driver.clone_public_into(a, num_constraints, public_inputs);                                   // :168-171
+        driver.clone_public_into(a, num_constraints, public_inputs, dz.pub_dev);                       // :168-171
         // The two mul_vec exchanges (:174, :190) run under the transforms that do not depend on them: the local product is started,
         // the independent NTTs are enqueued, then the party-to-party exchange proceeds while the GPU works (values as in the reference).
-        HipDriver::Marks mk("witness_map party 0", driver.party() <= 0);
-        driver.prefetch_masks(2, dom.m);                                                               // :174 and :190 draw next to each other
+        if (driver.prefetched.empty()) driver.prefetch_masks(2, dom.m);                                // :174 and :190 draw next to each other
         mk.mark("spmv enqueue");
         auto c_pending = driver.mul_vec_begin(a, b);                                                   // :174
         mk.mark("mul_vec_begin");
@@ -1153,6 +1156,11 @@ public:
         // l (:251), a (:267 -> :221), b1 (:284), b2 (:298): one call, one scalar schedule, on the second context
         auto aux_msm = dz.sliced ? driver.msm_begin_sharded(dz, true, private_witness)
                                  : driver.msm_begin_multi({dz.l, dz.a, dz.b1, dz.b2}, {0, first_aux, first_aux, first_aux}, {CG_G1, CG_G1, CG_G1, CG_G2}, private_witness.n, private_witness, true);
+        mk.mark("aux msm enqueued");
+        // the masks of the witness map's two mul_vec calls (:174, :190) start their way to the device now: behind the witness shares and the
+        // few small synchronous uploads of the MSM set-up (the copy engine serves its requests in order), ahead of everything else
+        driver.prefetch_masks(2, groth16_domain(c, z.pow, z.num_constraints, public_inputs.size()).m);
+        mk.mark("mask uploads enqueued");
         ShareVec h = witness_map_from_matrices(dz, public_inputs, private_witness);
         mk.mark("witness map");
         auto h_msm = dz.sliced ? driver.msm_begin_sharded(dz, false, h) : driver.msm_begin_multi({dz.h}, {0}, {CG_G1}, h.n, h, false);   // :248
@@ -2444,10 +2452,11 @@ struct cgh_session {
     // `chain` contexts have a high-priority main stream: they carry the witness map and its exchanges (a dependency chain) while the
     // party's second context fills the chip with the witness-independent MSMs
     std::mutex mu; std::vector<std::vector<cg_ctx*>> idle, idle_chain;
+    bool bulk_second = false;                                                            // the non-chain contexts run next to a chain context
     cg_ctx* take(int slot = 0, bool chain = false) {
         auto& pool = chain ? idle_chain : idle;
         { std::lock_guard<std::mutex> l(mu); if (!pool[slot].empty()) { cg_ctx* c = pool[slot].back(); pool[slot].pop_back(); return c; } }
-        cg_ctx* c = nullptr; if (cg_ctx_create_ex(devices[slot], chain ? 1u : 0u, &c)) cgh::die("cg_ctx_create"); return c;
+        cg_ctx* c = nullptr; if (cg_ctx_create_ex(devices[slot], chain ? 1u : (bulk_second && slot == 0 ? 2u : 0u), &c)) cgh::die("cg_ctx_create"); return c;
     }
     void give(cg_ctx* c, int slot = 0, bool chain = false) { if (!c) return; cg_ctx_sync(c); std::lock_guard<std::mutex> l(mu); (chain ? idle_chain : idle)[slot].push_back(c); }
 };
@@ -2513,6 +2522,7 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
             if (cg_bases_len(b)) CG(cg_bases_precompute(s->ctx0[d], b, precompute > 0 ? precompute : 0));
         for (int d = 0; d < n_dev; d++) CG(cg_ctx_sync(s->ctx0[d]));
         s->second_context = s->z.n_vars >= ((size_t)1 << 19) && !getenv("CGH_ONE_CONTEXT");
+        s->bulk_second = s->second_context && !getenv("CGH_NO_CHAIN_PRIORITY");
         *out = s;
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); session_destroy(s); return 1; }

@@ -42,8 +42,9 @@ enum { CG_OK = 0, CG_ERR_ARG = 1, CG_ERR_HIP = 2, CG_ERR_NODEVICE = 3, CG_ERR_OO
 
 /* ---- context ------------------------------------------------------------------------------------------------- */
 int32_t cg_ctx_create(int32_t device, cg_ctx** out);
-/* flags bit 0: high-priority main stream — for the context that carries a dependency chain (the witness map with its party-to-party
- * exchanges, groth16.rs:141-204) while another context of the same party keeps the chip full with independent MSMs */
+/* flags bit 0 ("chain"): for the context that carries a dependency chain (the witness map with its party-to-party exchanges,
+ * groth16.rs:141-204) while another context of the same party keeps the chip full with independent MSMs — high-priority main and copy
+ * streams on hardware queues of their own.  flags bit 1 ("bulk"): the context next to it — low-priority main stream. */
 int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out);
 int32_t cg_ctx_destroy(cg_ctx* ctx);
 int32_t cg_ctx_sync(cg_ctx* ctx);
@@ -55,6 +56,9 @@ const char* cg_last_error(void);
 const char* cg_version(void);
 
 /* ---- device memory (thin wrappers so non-HIP hosts can keep vectors resident between calls) ------------------- */
+/* cg_dev_free does not wait: the block is parked behind the work the context's streams hold at that moment and handed out again by a
+ * later cg_dev_alloc (any context of the device) once that work has completed.  Work on OTHER contexts that uses the block must have
+ * completed before the call.  CG_DEV_CACHE_MB bounds the parked bytes per device (0: release at once, which waits for the device). */
 int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr);
 int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr);
 int32_t cg_dev_upload(cg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);     /* synchronous */
