@@ -262,7 +262,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         bool any = false;
         for (int b = 0; b < nb; b++) any = any || bases[b]->compact != nullptr;
         if (any) {
-            struct Grp { uint64_t sig; size_t off, cnt; std::vector<int> members; };
+            struct Grp { uint64_t sig; size_t off, cnt, caller_off; std::vector<int> members; };
             std::vector<Grp> groups;
             std::vector<size_t> off_c(nb), cnt_c(nb);
             for (int b = 0; b < nb; b++) {
@@ -276,8 +276,18 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
                 }
                 off_c[b] = o; cnt_c[b] = cn;
                 bool placed = false;
-                for (auto& g : groups) if (g.sig == sig && g.cnt == cn && (sig != 0 ? g.off == o : true)) { g.members.push_back(b); placed = true; break; }
-                if (!placed) groups.push_back(Grp{sig, o, cn, {b}});
+                // one gather serves a group: same caller offset (the gather's index base), same compacted range, and the same live
+                // indices inside it — compared element by element, the 64-bit signature only short-cuts the mismatch
+                for (auto& g : groups) {
+                    if (g.sig != sig || g.cnt != cn) continue;
+                    if (sig != 0) {
+                        if (g.off != o || g.caller_off != off) continue;
+                        const auto& la = bases[g.members[0]]->h_live; const auto& lb = bases[b]->h_live;
+                        if (memcmp(la.data() + o, lb.data() + o, cn * sizeof(uint32_t)) != 0) continue;
+                    }
+                    g.members.push_back(b); placed = true; break;
+                }
+                if (!placed) groups.push_back(Grp{sig, o, cn, off, {b}});
             }
             size_t need = 0;
             for (auto& g : groups) if (g.sig) need += align_up((size_t)k * g.cnt * 32);

@@ -689,6 +689,7 @@ def test_msm_table_with_many_infinity_points(ctx, group):
     table = pts[rng.integers(0, 64, size=n)]
     dead = rng.random(n) < 0.45
     dead[100:400] = True                                            # a long all-infinity stretch
+    dead[2100:2102] = True                                          # (the two-offset case below ends on these)
     table[dead] = 0
     sc = [orc.random_field(curve, FR, n, rng), orc.random_field(curve, FR, n, rng)]
     bases = ctx.register_bases(curve, group, table)
@@ -714,6 +715,15 @@ def test_msm_table_with_many_infinity_points(ctx, group):
     for tab, out in zip((table, full, other), outs):
         for j in range(2):
             np.testing.assert_array_equal(cg.point_to_affine(curve, group, out[j]), orc.msm(curve, group, tab, sc[j]))
+    # same pattern, DIFFERENT caller offsets that land on the same compacted range (the offsets differ only across infinity entries):
+    # each table must still pair point i with scalar i - its own offset
+    m = 2000
+    assert dead[100] and dead[101] and dead[102 + m - 1] and dead[102 + m - 2]
+    tks = ctx.msm_dev_begin_multi([bases, b2], d_sc, m, offsets=[100, 102])
+    outs = [ctx.msm_end(t) for t in tks]
+    for tab, off, out in zip((table, other), (100, 102), outs):
+        for j in range(2):
+            np.testing.assert_array_equal(cg.point_to_affine(curve, group, out[j]), orc.msm(curve, group, tab[off:off + m], sc[j][:m]), err_msg=f"offset {off} comp {j}")
     for b in (bases, b2, b3): b.release()
 
 
