@@ -22,7 +22,7 @@ inline size_t msm_sort_direct_scratch_bytes(size_t n, int c, int nwin, int share
     const size_t nbuckets = (size_t)(shared ? 1 : nwin) << (c - 1);
     return align_up(nbuckets * cap * 4) + 2 * align_up(nbuckets * 4) + align_up(((nbuckets + 2047) / 2048) * 4) + 256;
 }
-template <class F> int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, const Affine<F>* d_bases, size_t n, int c, int nwin,
+template <class F> int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, hipEvent_t ev_merged, const Affine<F>* d_bases, size_t n, int c, int nwin,
                                              size_t table_stride, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs, bool may_have_inf);
 template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared);
 template <class F> int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c);
@@ -100,6 +100,8 @@ struct cg_ctx {
     // accumulated (integer-VALU bound) on the main stream; two rotating schedule slots
     hipStream_t sortst = nullptr;
     hipEvent_t ev_in = nullptr, ev_sorted[2] = {nullptr, nullptr}, ev_sched_free[2] = {nullptr, nullptr};
+    // the merge kernels on the aux stream are the last readers of a schedule: [slot] = the most recent one per schedule slot
+    hipEvent_t ev_merged[2] = {nullptr, nullptr}; bool merged_pending[2] = {false, false};
     // copy streams of the asynchronous host <-> device transfers (cg_dev_*_begin): MPC exchanges move under the compute
     static constexpr int COPY_TICKETS = 256;
     hipStream_t h2d = nullptr, d2h = nullptr;
@@ -402,10 +404,14 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         char* acc_scratch = ctx->arena.base + nsched * sort_bytes;
         HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));   // scalars (and the arena) are ready once the main stream gets here
         HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_in, 0));
+        for (int i = 0; i < 2; i++) if (ctx->merged_pending[i]) HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_merged[i], 0));   // ... and the previous call's merges have read the old schedules
         std::vector<MsmSortPtrs> sps(k);
         auto launch_sort = [&](int j) -> int {             // scalar side: once per scalar vector, on the sort stream
             const int ss_ = j % nsched;
-            if (j >= nsched) HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_sched_free[ss_], 0));   // accumulates of component j-2 have consumed the slot
+            if (j >= nsched) {                                   // accumulates and merges of component j-2 have consumed the slot
+                HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_sched_free[ss_], 0));
+                HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_merged[ss_], 0));
+            }
             hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
             if (ctx->stats_on) { const int i0 = ev_open(ctx, TAG_SORT); evs[0] = ctx->ev_live[i0].a; evs[1] = ctx->ev_live[i0].b; pev = evs; }
             char* sort_scratch = ctx->arena.base + (size_t)ss_ * sort_bytes;
@@ -438,11 +444,11 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
                 int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
                     typedef decltype(ftag) F;
                     const Affine<F>* pts = (const Affine<F>*)(shared ? bases[b]->d_pre : bases[b]->d_pts) + (offsets ? offsets[b] : 0);
-                    return msm_accumulate_reduce<F>(ctx->stream, ctx->aux, ctx->ev_acc[slot], ctx->ev_red[slot], pts, n, c, nwin, shared ? bases[b]->n : 0,
+                    return msm_accumulate_reduce<F>(ctx->stream, ctx->aux, ctx->ev_acc[slot], ctx->ev_red[slot], ctx->ev_merged[j % nsched], pts, n, c, nwin, shared ? bases[b]->n : 0,
                                                     sp.sorted, sp.offsets, sp.counts, sp.cap, acc_scratch + (size_t)slot * acc_slot, (XYZZ<F>*)t.h_pinned + (size_t)j * nsums, pev, !bases[b]->no_inf);
                 });
                 if (rc) return rc;
-                ctx->slot_busy[slot] = true; ctx->aux_pending = true; ctx->last_slot = slot;
+                ctx->slot_busy[slot] = true; ctx->aux_pending = true; ctx->last_slot = slot; ctx->merged_pending[j % nsched] = true;
                 if (j == k - 1) HIPCHK(hipEventRecord(t.done, ctx->aux));   // this table's last component: its results are complete on the aux stream
             }
             HIPCHK(hipEventRecord(ctx->ev_sched_free[j % nsched], ctx->stream));
@@ -787,7 +793,7 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     { int rc = pooled_stream(device, c->prio_side, &c->aux); if (rc) return rc; }
     { int rc = pooled_stream(device, c->prio_side, &c->sortst); if (rc) return rc; }
     HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-    for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_sched_free[i], hipEventDisableTiming)); }
+    for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_sched_free[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_merged[i], hipEventDisableTiming)); }
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming)); }
     *out = c;
     return 0;
@@ -798,7 +804,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->aux);
     hipStreamSynchronize(ctx->sortst);
-    for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_acc[i]); hipEventDestroy(ctx->ev_red[i]); hipEventDestroy(ctx->ev_sorted[i]); hipEventDestroy(ctx->ev_sched_free[i]); }
+    for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_acc[i]); hipEventDestroy(ctx->ev_red[i]); hipEventDestroy(ctx->ev_sorted[i]); hipEventDestroy(ctx->ev_sched_free[i]); hipEventDestroy(ctx->ev_merged[i]); }
     hipEventDestroy(ctx->ev_in);
     if (ctx->h2d) {
         hipStreamSynchronize(ctx->h2d); hipStreamSynchronize(ctx->d2h);

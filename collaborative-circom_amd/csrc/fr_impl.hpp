@@ -168,7 +168,7 @@ template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, siz
         uint32_t* region_total = (uint32_t*)take(PART_MAX_REGIONS * 4);
         uint32_t* region_cursor = (uint32_t*)take(PART_MAX_REGIONS * 4);
         uint32_t* total_items = (uint32_t*)take(4);
-        const unsigned itiles = (unsigned)((entries + ITEM_TILE - 1) / ITEM_TILE);
+        const unsigned itiles = (unsigned)(((entries + ITEM_TILE - 1) / ITEM_TILE + 7) / 8 * 8);   // a multiple of 8: xcd_tile() deals the tiles to the XCDs
         HIPCHK(hipMemsetAsync(region_total, 0, nregions * 4, st));
         hipLaunchKernelGGL((k_msm_digits_only<Fr>), dim3(grid_for(n)), dim3(256), 0, st, d_scalars, n, c, nwin, digits);
         hipLaunchKernelGGL(k_part_hist, dim3((unsigned)ptiles), dim3(256), nregions * 4, st, digits, n, c, nwin, shared, nregions, region_total);

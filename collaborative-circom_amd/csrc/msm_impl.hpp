@@ -31,10 +31,10 @@ size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared) {
 // buckets -> window sums for one (bases, sorted schedule) pair; the nwin window sums land in h_out (pinned) via an async copy.
 // table_stride != 0 selects the shared-bucket-set mode (d_bases = window-0 table of a [nwin][table_stride] precomputed block);
 // the host then receives g.ngroups partial sums to ADD (no doublings).  evs (optional, 4 events): accumulate [0,1], reduce [2,3]
-// Two streams: the accumulation (which fills the chip) runs on `st`; the latency-bound bucket reduction (a few hundred waves)
-// runs on `st2` behind `ev_acc` and signals `ev_red`, so it overlaps with the NEXT accumulation, which uses another scratch slot.
+// Two streams: the accumulation (which fills the chip) runs on `st`; the merge of chunk-boundary pieces (signals `ev_merged`: the
+// schedule is no longer needed) and the latency-bound bucket reduction (a few hundred waves) run on `st2` behind `ev_acc` and signal `ev_red`, so it overlaps with the NEXT accumulation, which uses another scratch slot.
 template <class F>
-int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride,
+int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, hipEvent_t ev_merged, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride,
                           const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs, bool may_have_inf) {
     const bool shared = table_stride != 0;
     MsmGeom g = msm_geom(n, c, nwin, shared, acc_resident_lanes<F>());
@@ -107,13 +107,17 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     else rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc29<F>, 128>, 128, lds2);
     if (rc_acc) return rc_acc;
     if (evs) HIPCHK(hipEventRecord(evs[1], st));
-    hipLaunchKernelGGL((k_msm_merge_direct<B>), dim3((unsigned)((g.nbuckets + 63) / 64)), dim3(64), 0, st, buckets, cont, cont_bucket, offsets, counts,
-                       (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, cap);
-    hipLaunchKernelGGL((k_msm_merge_cont_l1<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, cont, cont_bucket, g.nchunks);
-    hipLaunchKernelGGL((k_msm_merge_cont<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st, buckets, cont, cont_bucket, g.nchunks);
+    // The merge of the chunk-boundary pieces belongs to the reduction side: a few hundred waves that would leave the chip idle for
+    // 0.3 (G1) to 1.5 ms (G2) per MSM in front of the next accumulation (measured in the 2^22 step: ~5 ms per step with no accumulation
+    // running), while the next accumulation works on the other scratch slot and needs nothing from them.
     HIPCHK(hipEventRecord(ev_acc, st));
     HIPCHK(hipStreamWaitEvent(st2, ev_acc, 0));
     if (evs) HIPCHK(hipEventRecord(evs[2], st2));
+    hipLaunchKernelGGL((k_msm_merge_direct<B>), dim3((unsigned)((g.nbuckets + 63) / 64)), dim3(64), 0, st2, buckets, cont, cont_bucket, offsets, counts,
+                       (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, cap);
+    hipLaunchKernelGGL((k_msm_merge_cont_l1<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st2, cont, cont_bucket, g.nchunks);
+    hipLaunchKernelGGL((k_msm_merge_cont<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st2, buckets, cont, cont_bucket, g.nchunks);
+    HIPCHK(hipEventRecord(ev_merged, st2));                                          // the last reader of the sorted schedule (offsets / counts)
     if (g.bitsum) {
         static bool attr_set2 = false;
         if (!attr_set2) {
@@ -194,7 +198,7 @@ int fixed_base_mul_launch(hipStream_t st, const Affine<F>& g, const Fr* d_scalar
 
 #define CG_INSTANTIATE_MSM(F, Fr)                                                                                          \
     namespace cg {                                                                                                         \
-    template int msm_accumulate_reduce<F>(hipStream_t, hipStream_t, hipEvent_t, hipEvent_t, const Affine<F>*, size_t, int, int, size_t, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, char*, XYZZ<F>*, hipEvent_t*, bool); \
+    template int msm_accumulate_reduce<F>(hipStream_t, hipStream_t, hipEvent_t, hipEvent_t, hipEvent_t, const Affine<F>*, size_t, int, int, size_t, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, char*, XYZZ<F>*, hipEvent_t*, bool); \
     template size_t msm_acc_scratch_bytes<F>(size_t, int, int, bool);                                                      \
     template int precompute_window_launch<F>(hipStream_t, const Affine<F>*, Affine<F>*, size_t, int);                      \
     template int check_on_curve_launch<F>(hipStream_t, const Affine<F>*, size_t, const F&, unsigned long long*);           \

@@ -204,9 +204,17 @@ static __global__ void __launch_bounds__(256) k_part_scatter(const int32_t* __re
 // and flushed / reserved with one global atomic per non-empty bucket (items outside the window take the direct global path).
 constexpr int ITEM_TILE = 16384;
 constexpr uint32_t ITEM_WINDOW = 2048;
+// Workgroup i of a launch runs on XCD i % 8 and every XCD has its own L2.  Consecutive item tiles belong to the same region, i.e. they
+// write into the same 212 KB slice of the output and bump the same 512 counters: XCD x takes the x-th eighth of the tiles, so that the
+// tiles that share lines and counters share an L2 and the lines reach HBM whole (measured before: 1.41 GB written per launch for
+// 218 MB of output, the 4-byte stores of one line coming from several XCDs).
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t block, uint32_t nblocks) {
+    const uint32_t per = (nblocks + 7) / 8;
+    return (block & 7u) * per + (block >> 3);           // may be >= nblocks for the last XCD: the caller returns
+}
 static __global__ void __launch_bounds__(256) k_items_hist(const uint64_t* __restrict__ items, const uint32_t* __restrict__ total_items, uint32_t* __restrict__ counts) {
     __shared__ uint32_t cnt[ITEM_WINDOW];
-    const size_t total = *total_items, base = (size_t)blockIdx.x * ITEM_TILE;
+    const size_t total = *total_items, base = (size_t)xcd_tile(blockIdx.x, gridDim.x) * ITEM_TILE;
     if (base >= total) return;
     for (uint32_t r = threadIdx.x; r < ITEM_WINDOW; r += 256) cnt[r] = 0;
     const uint32_t b0 = (uint32_t)(items[base] >> 32) & ~((1u << PART_REGION_LOG) - 1);
@@ -223,7 +231,7 @@ static __global__ void __launch_bounds__(256) k_items_hist(const uint64_t* __res
 static __global__ void __launch_bounds__(256) k_items_scatter(const uint64_t* __restrict__ items, const uint32_t* __restrict__ total_items, const uint32_t* __restrict__ offsets,
                                                               uint32_t* __restrict__ cursors, uint32_t* __restrict__ sorted) {
     __shared__ uint32_t cnt[ITEM_WINDOW];
-    const size_t total = *total_items, base = (size_t)blockIdx.x * ITEM_TILE;
+    const size_t total = *total_items, base = (size_t)xcd_tile(blockIdx.x, gridDim.x) * ITEM_TILE;
     if (base >= total) return;
     for (uint32_t r = threadIdx.x; r < ITEM_WINDOW; r += 256) cnt[r] = 0;
     const uint32_t b0 = (uint32_t)(items[base] >> 32) & ~((1u << PART_REGION_LOG) - 1);
