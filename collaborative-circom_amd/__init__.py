@@ -155,11 +155,17 @@ class Bases:
 class Context:
     """One per MPC party thread (mirrors `&mut self` of the reference drivers)."""
 
-    def __init__(self, device=0):
+    CHAIN, BULK = 1, 2          # cg_ctx_create_ex flags: the context of a dependency chain / the context that fills the chip next to it
+
+    def __init__(self, device=0, flags=0):
         h = C.c_void_p()
-        _chk(load().cg_ctx_create(int(device), C.byref(h)))
+        _chk(load().cg_ctx_create_ex(int(device), C.c_uint32(int(flags)), C.byref(h)))
         self.h = h
         self.device = device
+
+    def msm_set_chunk(self, entries):
+        """entries per accumulation lane for this context's MSMs (0 = automatic): short-lived workgroups next to a latency chain"""
+        _chk(load().cg_msm_set_chunk(self.h, C.c_uint32(int(entries))))
 
     def close(self):
         if self.h:

@@ -1,0 +1,111 @@
+"""Context classes (cg_ctx_create_ex: chain / bulk), parked device and page-locked blocks (cg_dev_alloc / cg_dev_free,
+cg_host_alloc / cg_host_free), and the sliced G2 accumulation of a context that runs next to a latency chain (cg_msm_set_chunk).
+None of this may change a result: every check is bit-exact against the oracle or against the default context."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from oracle_lib import BN254, FR, G1, G2
+from product import cg, ensure_built
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def built():
+    ensure_built()
+
+
+def test_chain_and_bulk_contexts_compute_the_same(built):
+    """the three context classes differ in stream priorities and hardware queues only"""
+    rng = np.random.default_rng(77)
+    n = 5000
+    a, b = orc.random_field(BN254, FR, n, rng), orc.random_field(BN254, FR, n, rng)
+    pts = np.stack([orc.generator_mul(BN254, G1, s) for s in orc.random_field(BN254, FR, 32, rng)])[rng.integers(0, 32, size=n)]
+    want_mul = orc.field_op(BN254, FR, "mul", a, b)
+    want_msm = orc.msm(BN254, G1, pts, a)
+    for flags in (0, cg.Context.CHAIN, cg.Context.BULK):
+        c = cg.Context(0, flags)
+        da, db = c.to_device(a), c.to_device(b)
+        out = c.alloc(n * 32)
+        c.vec_mul(BN254, out, da, db, n)
+        np.testing.assert_array_equal(out.download((n, 4)), want_mul)
+        # asynchronous copies: the chain context has its copy streams from the start, the others create them here
+        h = c.host_alloc((n, 4)); h[:] = b
+        t = c.upload_begin(out, h, after_stream=True); c.copy_wait(t)
+        np.testing.assert_array_equal(out.download((n, 4)), b)
+        c.host_free(h)
+        bases = c.register_bases(BN254, G1, pts)
+        got = c.msm(bases, [a])
+        np.testing.assert_array_equal(cg.point_to_affine(BN254, G1, got[0]), want_msm)
+        bases.release(); c.close()
+
+
+def test_released_blocks_are_handed_out_again_and_hold_no_stale_work(built):
+    """cg_dev_free parks a block behind the work enqueued so far; the next allocation of that size gets it back only once that work is done"""
+    c = cg.Context(0)
+    rng = np.random.default_rng(5)
+    n = 1 << 16
+    a, b = orc.random_field(BN254, FR, n, rng), orc.random_field(BN254, FR, n, rng)
+    da, db = c.to_device(a), c.to_device(b)
+    want = orc.field_op(BN254, FR, "mul", a, b)
+    seen = set()
+    for rep in range(6):
+        out = c.alloc(n * 32)
+        seen.add(out.ptr)
+        for _ in range(20): c.vec_mul(BN254, out, da, db, n)       # the stream is still busy with these when the block is released
+        got_before_free = out.download((n, 4))
+        np.testing.assert_array_equal(got_before_free, want)
+        c.vec_mul(BN254, out, db, da, n)                            # enqueued, not waited for
+        out.free()
+        other = c.alloc(n * 32); other.zero()                       # same size: may be the parked block — never while the product above is pending
+        np.testing.assert_array_equal(other.download((n, 4)), np.zeros((n, 4), dtype=np.uint64))
+        other.free()
+    assert len(seen) <= 3, "released blocks were not reused"
+    # a size nobody released: a fresh block; zero-size and odd sizes round up
+    for nbytes in (1, 17, 4097, (1 << 16) + 8):
+        blk = c.alloc(nbytes); blk.zero(); blk.free()
+    c.close()
+
+
+def test_pinned_blocks_are_parked(built):
+    c = cg.Context(0)
+    h1 = c.host_alloc((1 << 18, 4)); h1[:] = 7
+    p1 = h1.ctypes.data
+    assert cg.load().cg_host_is_pinned(cg.C.c_void_p(p1)) == 1
+    c.host_free(h1)
+    h2 = c.host_alloc((1 << 18, 4))
+    assert h2.ctypes.data == p1, "a released page-locked block of the same size should be handed out again"
+    assert cg.load().cg_host_is_pinned(cg.C.c_void_p(h2.ctypes.data)) == 1
+    d = c.alloc(h2.nbytes)
+    h2[:] = 9
+    c.copy_wait(c.upload_begin(d, h2, after_stream=False))
+    assert (d.download((1 << 18, 4)) == 9).all()
+    c.host_free(h2); c.close()
+
+
+@pytest.mark.parametrize("group", [G1, G2])
+def test_msm_next_to_a_chain_equals_the_default(built, group):
+    """a bulk context with a chunk request (short-lived workgroups; G2: the accumulation launched one chip-load at a time, several
+    launches at this size) returns the same points as the default context"""
+    log_n = 20
+    n = 1 << log_n
+    rng = np.random.default_rng(41)
+    base_scalars, sc = orc.random_field(BN254, FR, n, rng), orc.random_field(BN254, FR, n, rng)
+    outs = []
+    for flags, chunk in ((0, 0), (cg.Context.BULK, 64), (cg.Context.BULK, 16)):
+        c = cg.Context(0, flags)
+        if chunk: c.msm_set_chunk(chunk)
+        d_base, d_sc = c.to_device(base_scalars), c.to_device(sc)
+        bases = c.bases_from_scalars(BN254, group, d_base, n)
+        c.precompute_bases(bases, 0)
+        out = c.msm_end(c.msm_dev_begin_multi([bases], [d_sc], n)[0])
+        outs.append(cg.point_to_affine(BN254, group, out[0]))
+        bases.release(); c.close()
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], outs[2])
+    # and the value itself: sum_i s_i * (b_i * G) = (sum_i s_i b_i) * G
+    acc = orc.field_op(BN254, FR, "mul", base_scalars, sc)
+    while acc.shape[0] > 1:
+        acc = orc.field_op(BN254, FR, "add", acc[: acc.shape[0] // 2], acc[acc.shape[0] // 2:])
+    np.testing.assert_array_equal(outs[0], orc.generator_mul(BN254, group, acc[0]))
