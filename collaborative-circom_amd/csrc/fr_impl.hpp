@@ -173,12 +173,23 @@ template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, siz
         hipLaunchKernelGGL((k_msm_digits_only<Fr>), dim3(grid_for(n)), dim3(256), 0, st, d_scalars, n, c, nwin, digits);
         hipLaunchKernelGGL(k_part_hist, dim3((unsigned)ptiles), dim3(256), nregions * 4, st, digits, n, c, nwin, shared, nregions, region_total);
         hipLaunchKernelGGL(k_part_region_scan, dim3(1), dim3(1024), 0, st, region_total, nregions, region_cursor, total_items);
+        static const bool staged = getenv("CG_SORT_NO_STAGING") == nullptr;        // measurement knob
+        if (staged && nregions <= STAGE_MAX_REGIONS) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                HIPCHK(hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_staged_lds(STAGE_MAX_REGIONS)));
+                HIPCHK(hipFuncSetAttribute((const void*)k_items_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ITEMS_STAGED_LDS));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_part_scatter_staged, dim3((unsigned)ptiles), dim3(STAGE_THREADS), part_staged_lds(nregions), st, digits, n, c, nwin, shared, nregions, region_cursor, items);
+        } else
         hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)ptiles), dim3(256), nregions * 4, st, digits, n, c, nwin, shared, nregions, region_cursor, items);
         hipLaunchKernelGGL(k_items_hist, dim3(itiles), dim3(256), 0, st, items, total_items, counts);
         hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)ntiles), dim3(256), 0, st, counts, tile_sums, nbuckets, 0xffffffffu);
         hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, tile_sums, tile_sums, ntiles);
         hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(256), 0, st, counts, tile_sums, offsets, nbuckets, 0xffffffffu);
-        hipLaunchKernelGGL(k_items_scatter, dim3(itiles), dim3(256), 0, st, items, total_items, offsets, cursors, sorted);
+        if (staged && nregions <= STAGE_MAX_REGIONS) hipLaunchKernelGGL(k_items_scatter_staged, dim3(itiles), dim3(STAGE_THREADS), ITEMS_STAGED_LDS, st, items, total_items, offsets, cursors, sorted);
+        else hipLaunchKernelGGL(k_items_scatter, dim3(itiles), dim3(256), 0, st, items, total_items, offsets, cursors, sorted);
         if (evs) HIPCHK(hipEventRecord(evs[1], st));
         HIPCHK(hipGetLastError());
         out->sorted = sorted; out->offsets = offsets; out->counts = counts; out->cap = 0; out->overflow = nullptr;

@@ -256,6 +256,129 @@ static __global__ void __launch_bounds__(256) k_items_scatter(const uint64_t* __
     }
 }
 
+// ---- staged variants: the tile is ranked in LDS, laid out there in destination order, and written out run by run.
+// The kernels above store each entry where its LDS rank says — 64 lanes, 64 different lines per instruction, 4 or 8 bytes each, and
+// the counters say what that costs: 1.56 GB written for 436 MB of items, 1.41 GB for 218 MB of indices (r02_pmc_traffic.json).  Here a
+// wave writes consecutive entries of the same run (~16 items = 128 B per (tile, region), ~32 indices = 128 B per (tile, bucket)), and the
+// tile's 16 entries per lane are loaded up front (16 independent loads in flight instead of one per loop trip).
+constexpr int STAGE_THREADS = 1024;
+constexpr int STAGE_PER_LANE = PART_TILE / STAGE_THREADS;       // 16
+constexpr uint32_t STAGE_MAX_REGIONS = 2048;                     // cnt + delta + 128 KB of staged items must fit 160 KB of LDS
+inline size_t part_staged_lds(uint32_t nregions) { return (size_t)(2 * nregions + 32) * 4 + (size_t)PART_TILE * 8; }
+constexpr size_t ITEMS_STAGED_LDS = (size_t)(2 * ITEM_WINDOW + 32) * 4 + (size_t)ITEM_TILE * 6;
+// exclusive prefix over the workgroup of one value per lane (1024 lanes); scratch: 16 dwords of LDS; ends with a barrier
+__device__ __forceinline__ uint32_t stage_block_scan(uint32_t v, uint32_t* scratch, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+    _Pragma("unroll") for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < STAGE_THREADS / 64 ? scratch[lane] : 0, winc = w;
+        _Pragma("unroll") for (int off = 1; off < STAGE_THREADS / 64; off <<= 1) { const uint32_t t = __shfl_up(winc, off, 64); if (lane >= off) winc += t; }
+        if (lane < STAGE_THREADS / 64) scratch[lane] = winc - w;
+        if (lane == STAGE_THREADS / 64 - 1) scratch[STAGE_THREADS / 64] = winc;
+    }
+    __syncthreads();
+    const uint32_t r = scratch[wave] + inc - v;
+    *total = scratch[STAGE_THREADS / 64];
+    __syncthreads();
+    return r;
+}
+// LDS: cnt[nregions] | delta[nregions] | 17 dwords | staged items (PART_TILE x 8 B)
+static __global__ void __launch_bounds__(STAGE_THREADS) k_part_scatter_staged(const int32_t* __restrict__ digits, size_t n, int c, int nwin, int shared, uint32_t nregions,
+                                                                            uint32_t* __restrict__ region_cursor, uint64_t* __restrict__ items) {
+    extern __shared__ uint32_t lds_u32[];
+    uint32_t* cnt = lds_u32;
+    uint32_t* delta = cnt + nregions;
+    uint32_t* scratch = delta + nregions;
+    uint64_t* stage = reinterpret_cast<uint64_t*>(scratch + 32);
+    for (uint32_t r = threadIdx.x; r < nregions; r += STAGE_THREADS) cnt[r] = 0;
+    const uint32_t nb = 1u << (c - 1);
+    const size_t total = (size_t)nwin * n, base = (size_t)blockIdx.x * PART_TILE;
+    int32_t dig[STAGE_PER_LANE];
+    _Pragma("unroll") for (int k = 0; k < STAGE_PER_LANE; k++) {
+        const size_t idx = base + (size_t)k * STAGE_THREADS + threadIdx.x;
+        dig[k] = idx < total ? digits[idx] : 0;
+    }
+    __syncthreads();
+    uint32_t bucket[STAGE_PER_LANE], payload[STAGE_PER_LANE], rank[STAGE_PER_LANE];
+    _Pragma("unroll") for (int k = 0; k < STAGE_PER_LANE; k++) {
+        const size_t idx = base + (size_t)k * STAGE_THREADS + threadIdx.x;
+        const size_t w = idx / n;
+        bucket[k] = 0xffffffffu; payload[k] = 0; rank[k] = 0;
+        if (part_decode(dig[k], w, (uint32_t)(idx - w * n), nb, shared, &bucket[k], &payload[k])) rank[k] = atomicAdd(&cnt[bucket[k] >> PART_REGION_LOG], 1u);
+        else bucket[k] = 0xffffffffu;
+    }
+    __syncthreads();
+    // tile offsets (exclusive scan over the regions) and one global reservation per non-empty region
+    const uint32_t per = (nregions + STAGE_THREADS - 1) / STAGE_THREADS;          // 1 or 2
+    uint32_t v[2] = {0, 0}, mine = 0;
+    for (uint32_t j = 0; j < per; j++) { const uint32_t r = threadIdx.x * per + j; if (r < nregions) { v[j] = cnt[r]; mine += v[j]; } }
+    uint32_t tile_items;
+    uint32_t run = stage_block_scan(mine, scratch, &tile_items);
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t r = threadIdx.x * per + j;
+        if (r < nregions) { cnt[r] = run; delta[r] = (v[j] ? atomicAdd(&region_cursor[r], v[j]) : 0u) - run; run += v[j]; }
+    }
+    __syncthreads();
+    _Pragma("unroll") for (int k = 0; k < STAGE_PER_LANE; k++)
+        if (bucket[k] != 0xffffffffu) stage[cnt[bucket[k] >> PART_REGION_LOG] + rank[k]] = ((uint64_t)bucket[k] << 32) | payload[k];
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < tile_items; s += STAGE_THREADS) {
+        const uint64_t it = stage[s];
+        items[delta[(uint32_t)(it >> 32) >> PART_REGION_LOG] + s] = it;
+    }
+}
+// LDS: cnt[ITEM_WINDOW] | delta[ITEM_WINDOW] | 32 dwords | staged indices (ITEM_TILE x 4 B) | their window slots (ITEM_TILE x 2 B)
+static __global__ void __launch_bounds__(STAGE_THREADS) k_items_scatter_staged(const uint64_t* __restrict__ items, const uint32_t* __restrict__ total_items,
+                                                                             const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors, uint32_t* __restrict__ sorted) {
+    extern __shared__ uint32_t lds_u32[];
+    uint32_t* cnt = lds_u32;
+    uint32_t* delta = cnt + ITEM_WINDOW;
+    uint32_t* scratch = delta + ITEM_WINDOW;
+    uint32_t* stage = scratch + 32;
+    uint16_t* slot = reinterpret_cast<uint16_t*>(stage + ITEM_TILE);
+    const size_t total = *total_items, base = (size_t)xcd_tile(blockIdx.x, gridDim.x) * ITEM_TILE;
+    if (base >= total) return;
+    for (uint32_t r = threadIdx.x; r < ITEM_WINDOW; r += STAGE_THREADS) cnt[r] = 0;
+    uint64_t it[STAGE_PER_LANE];
+    _Pragma("unroll") for (int k = 0; k < STAGE_PER_LANE; k++) {
+        const size_t e = base + (size_t)k * STAGE_THREADS + threadIdx.x;
+        it[k] = e < total ? items[e] : ~(uint64_t)0;
+    }
+    const uint32_t b0 = (uint32_t)(items[base] >> 32) & ~((1u << PART_REGION_LOG) - 1);
+    __syncthreads();
+    uint32_t rank[STAGE_PER_LANE];
+    _Pragma("unroll") for (int k = 0; k < STAGE_PER_LANE; k++) {
+        rank[k] = 0;
+        if (it[k] == ~(uint64_t)0) continue;
+        const uint32_t bucket = (uint32_t)(it[k] >> 32), d = bucket - b0;
+        if (d < ITEM_WINDOW) rank[k] = atomicAdd(&cnt[d], 1u);
+        else { sorted[offsets[bucket] + atomicAdd(&cursors[bucket], 1u)] = (uint32_t)it[k]; it[k] = ~(uint64_t)0; }   // outside the window (tiny regions): direct
+    }
+    __syncthreads();
+    constexpr uint32_t per = ITEM_WINDOW / STAGE_THREADS;                          // 2
+    uint32_t v[per], mine = 0;
+    _Pragma("unroll") for (uint32_t j = 0; j < per; j++) { v[j] = cnt[threadIdx.x * per + j]; mine += v[j]; }
+    uint32_t tile_items;
+    uint32_t run = stage_block_scan(mine, scratch, &tile_items);
+    _Pragma("unroll") for (uint32_t j = 0; j < per; j++) {
+        const uint32_t r = threadIdx.x * per + j;
+        cnt[r] = run;
+        delta[r] = (v[j] ? offsets[b0 + r] + atomicAdd(&cursors[b0 + r], v[j]) : 0u) - run;
+        run += v[j];
+    }
+    __syncthreads();
+    _Pragma("unroll") for (int k = 0; k < STAGE_PER_LANE; k++) {
+        if (it[k] == ~(uint64_t)0) continue;
+        const uint32_t d = (uint32_t)(it[k] >> 32) - b0, at = cnt[d] + rank[k];
+        stage[at] = (uint32_t)it[k]; slot[at] = (uint16_t)d;
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < tile_items; s += STAGE_THREADS) sorted[delta[slot[s]] + s] = stage[s];
+}
+
 // Optimistic one-pass scatter: every bucket owns `cap` slots, so no histogram pass is needed — one atomic per (scalar, window)
 // instead of two, no digit array.  counts[] ends up holding the true per-bucket counts; if any exceeds cap the entry is dropped
 // and *overflow is set: the host then recomputes that MSM with the exact two-pass schedule (cg_msm_end), so results never
