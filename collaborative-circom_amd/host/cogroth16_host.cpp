@@ -1003,7 +1003,9 @@ public:
         // REP3 at sizes where the exchanges are asynchronous: these MSMs run beside the witness map's dependency chain (product -> down ->
         // peer -> up, twice) on the other context; shorter-lived workgroups let the chain's kernels onto the chip sooner (2^22: one party
         // alone 107 -> 97 ms)
-        if (p.on != ctx) CG(cg_msm_set_chunk(p.on, mode == Mode::Rep3 && n >= XCHG_ASYNC_MIN ? 64 : 0));
+        static const uint32_t bulk_chunk = getenv("CGH_BULK_CHUNK") ? (uint32_t)atoi(getenv("CGH_BULK_CHUNK")) : 64u;   // tuning knob
+        static const uint32_t plain_chunk = getenv("CGH_PLAIN_CHUNK") ? (uint32_t)atoi(getenv("CGH_PLAIN_CHUNK")) : 0u;  // tuning knob
+        if (p.on != ctx) CG(cg_msm_set_chunk(p.on, mode == Mode::Rep3 && n >= XCHG_ASYNC_MIN ? bulk_chunk : plain_chunk));
         const void* sc[2] = {s.c[0], s.c[1]};
         if (p.on != ctx) CG(cg_ctx_sync(ctx));                                          // the scalars were produced on this driver's stream
         CG(cg_msm_dev_begin_multi(p.on, (int32_t)tables.size(), tables.data(), offsets.data(), n, sc, k(), p.tickets.data()));
