@@ -21,6 +21,12 @@ inline int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 constexpr int GRID_CAP = 2048;   // grid-stride kernels: 256 CUs x 8 workgroups
 inline int grid_for(size_t n, int block = 256) { size_t g = (n + block - 1) / block; return (int)std::min<size_t>(std::max<size_t>(g, 1), GRID_CAP); }
+// Launch attributes (the dynamic-LDS ceiling) belong to the (function, device) pair: call sites set them the first time they run on each
+// device of the process (a multi-device session launches the same kernels on every GPU).  A repeated set is harmless.
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool first() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true; if (done[d]) return false; done[d] = true; return true; }
+};
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int log2_floor(size_t n) { int l = 0; while (((size_t)2 << l) <= n) l++; return l; }
 

@@ -92,8 +92,8 @@ template <class Fr> int launch_build_twiddles(hipStream_t st, Fr* tw, size_t m, 
     return 0;
 }
 template <class Fr> int launch_ntt_dif_pass(hipStream_t st, NttVecs src, NttVecs dst, int nvec, size_t n, int log_m, int s0, int k, int t, const Fr* tw) {
-    static bool attr_set = false;
-    if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_ntt_dif_pass<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_set = true; }
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) { HIPCHK(hipFuncSetAttribute((const void*)k_ntt_dif_pass<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); }
     const int E = 1 << (k + t);
     hipLaunchKernelGGL((k_ntt_dif_pass<Fr>), dim3((unsigned)(n / E), nvec), dim3(NTT_THREADS), (size_t)E * 32, st, src, dst, log_m, s0, k, t, tw);
     HIPCHK(hipGetLastError());
@@ -105,11 +105,10 @@ template <class Fr> int launch_build_twiddles_lazy(hipStream_t st, void* tw, siz
     return 0;
 }
 template <class Fr> int launch_ntt_ct_pass(hipStream_t st, bool first, NttVecs src, NttVecs dst, int nvec, size_t n, int log_m, int s0, int k, int t, const void* tw) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         HIPCHK(hipFuncSetAttribute((const void*)k_ntt_ct_pass<Fr, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 36 << NTT_TILE_LOG));
         HIPCHK(hipFuncSetAttribute((const void*)k_ntt_ct_pass<Fr, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 36 << NTT_TILE_LOG));
-        attr_set = true;
     }
     const int E = 1 << (k + t);
     if (first) hipLaunchKernelGGL((k_ntt_ct_pass<Fr, true>), dim3((unsigned)(n / E), nvec), dim3(NTT_THREADS), (size_t)E * 36, st, src, dst, log_m, s0, k, t, tw);
@@ -175,11 +174,10 @@ template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, siz
         hipLaunchKernelGGL(k_part_region_scan, dim3(1), dim3(1024), 0, st, region_total, nregions, region_cursor, total_items);
         static const bool staged = getenv("CG_SORT_NO_STAGING") == nullptr;        // measurement knob
         if (staged && nregions <= STAGE_MAX_REGIONS) {
-            static bool attr_set = false;
-            if (!attr_set) {
+            static PerDeviceOnce attr_set;
+            if (attr_set.first()) {
                 HIPCHK(hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_staged_lds(STAGE_MAX_REGIONS)));
                 HIPCHK(hipFuncSetAttribute((const void*)k_items_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ITEMS_STAGED_LDS));
-                attr_set = true;
             }
             hipLaunchKernelGGL(k_part_scatter_staged, dim3((unsigned)ptiles), dim3(STAGE_THREADS), part_staged_lds(nregions), st, digits, n, c, nwin, shared, nregions, region_cursor, items);
         } else
