@@ -109,3 +109,66 @@ def test_msm_next_to_a_chain_equals_the_default(built, group):
     while acc.shape[0] > 1:
         acc = orc.field_op(BN254, FR, "add", acc[: acc.shape[0] // 2], acc[acc.shape[0] // 2:])
     np.testing.assert_array_equal(outs[0], orc.generator_mul(BN254, group, acc[0]))
+
+
+def _closed_form(base_scalars, sc, group):
+    acc = orc.field_op(BN254, FR, "mul", base_scalars, sc)
+    while acc.shape[0] > 1:
+        acc = orc.field_op(BN254, FR, "add", acc[: acc.shape[0] // 2], acc[acc.shape[0] // 2:])
+    return orc.generator_mul(BN254, group, acc[0])
+
+
+def test_sort_schedule_variants_agree(built):
+    """the scalar-side schedule has three shapes at this size: staged scatters (default), the record-per-lane scatters they replaced
+    (kept for key spaces of more than 2 048 regions: here a classic MSM with window 18, 15 bucket sets = 3 840 regions) and the
+    one-pass counting sort of small inputs; all give sum_i s_i (b_i G) = (sum_i s_i b_i) G"""
+    n = 1 << 18
+    rng = np.random.default_rng(4242)
+    base_scalars, sc = orc.random_field(BN254, FR, n, rng), orc.random_field(BN254, FR, n, rng)
+    want = _closed_form(base_scalars, sc, G1)
+    c = cg.Context(0)
+    d_base, d_sc = c.to_device(base_scalars), c.to_device(sc)
+    bases = c.bases_from_scalars(BN254, G1, d_base, n)
+    for window in (0, 18, 16, 13):                          # automatic, 3 840 regions (legacy scatters), 1 024 regions (staged), 80 regions
+        c.set_msm_window(window)
+        out = c.msm_end(c.msm_dev_begin_multi([bases], [d_sc], n)[0])
+        np.testing.assert_array_equal(cg.point_to_affine(BN254, G1, out[0]), want, err_msg=f"window {window}")
+    c.set_msm_window(0)
+    c.precompute_bases(bases, 0)                            # shared bucket set
+    out = c.msm_end(c.msm_dev_begin_multi([bases], [d_sc], n)[0])
+    np.testing.assert_array_equal(cg.point_to_affine(BN254, G1, out[0]), want)
+    bases.release(); c.close()
+
+
+def test_legacy_scatters_and_release_at_once_in_a_fresh_process(built):
+    """CG_SORT_NO_STAGING (the former scatter kernels on the default shape) and CG_DEV_CACHE_MB=0 / CG_HOST_CACHE_MB=0 (blocks released at
+    once) are read when the library is loaded: a child process runs an MSM and a REP3 product against the closed forms under them"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+import oracle_lib as orc
+from oracle_lib import BN254, FR, G1
+from product import cg, ensure_built
+ensure_built()
+n = 1 << 18
+rng = np.random.default_rng(99)
+b, s = orc.random_field(BN254, FR, n, rng), orc.random_field(BN254, FR, n, rng)
+acc = orc.field_op(BN254, FR, "mul", b, s)
+while acc.shape[0] > 1: acc = orc.field_op(BN254, FR, "add", acc[: acc.shape[0] // 2], acc[acc.shape[0] // 2:])
+want = orc.generator_mul(BN254, G1, acc[0])
+c = cg.Context(0)
+for rep in range(3):
+    db, ds = c.to_device(b), c.to_device(s)
+    bases = c.bases_from_scalars(BN254, G1, db, n); c.precompute_bases(bases, 0)
+    out = c.msm_end(c.msm_dev_begin_multi([bases], [ds], n)[0])
+    assert (cg.point_to_affine(BN254, G1, out[0]) == want).all()
+    h = c.host_alloc((n, 4)); h[:] = s; c.copy_wait(c.upload_begin(ds, h, after_stream=False)); c.host_free(h)
+    bases.release(); db.free(); ds.free()
+c.close()
+print("child ok")
+'''
+    env = dict(os.environ, CG_SORT_NO_STAGING="1", CG_DEV_CACHE_MB="0", CG_HOST_CACHE_MB="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
