@@ -93,8 +93,9 @@ struct cg_ctx {
     bool owns_stream = true;
     // second stream for the latency-bound bucket reductions, two rotating scratch slots, and the events that order them
     hipStream_t aux = nullptr;
-    hipEvent_t ev_acc[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};
-    bool slot_busy[2] = {false, false};
+    static constexpr int ACC_SLOTS_MAX = 8;                // rotating scratch slots of the accumulate / reduce pipeline (4 in use, see msm_begin_multi_impl)
+    hipEvent_t ev_acc[ACC_SLOTS_MAX] = {}, ev_red[ACC_SLOTS_MAX] = {};
+    bool slot_busy[ACC_SLOTS_MAX] = {};
     bool aux_pending = false; int last_slot = 0;
     // third stream for the scalar-side sort (HBM/latency bound): the schedule of component j+1 is built while component j is
     // accumulated (integer-VALU bound) on the main stream; two rotating schedule slots
@@ -144,7 +145,7 @@ namespace {
 int ensure_arena(cg_ctx* ctx, size_t bytes) {
     ctx->arena.used = 0;
     if (ctx->aux_pending) {   // reductions of an earlier MSM may still be reading the arena on the aux stream
-        for (int sl = 0; sl < 2; sl++) if (ctx->slot_busy[sl]) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_red[sl], 0)); ctx->slot_busy[sl] = false; }
+        for (int sl = 0; sl < cg_ctx::ACC_SLOTS_MAX; sl++) if (ctx->slot_busy[sl]) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_red[sl], 0)); ctx->slot_busy[sl] = false; }
         ctx->aux_pending = false;
     }
     if (bytes <= ctx->arena.cap) return 0;
@@ -400,7 +401,11 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         const size_t sort_bytes = align_up(cap ? msm_sort_direct_scratch_bytes(n, c, nwin, shared ? 1 : 0, cap) : msm_sort_scratch_bytes(n, c, nwin));
         const size_t acc_slot = align_up(acc_bytes);
         const int nsched = k > 1 ? 2 : 1;                  // two schedule slots so that sort j+1 overlaps accumulate j
-        { int rc = ensure_arena(ctx, nsched * sort_bytes + 2 * acc_slot); if (rc) return rc; }
+        // Four rotating scratch slots: an accumulation waits for the bucket reduction that used its slot, and beside the accumulations the
+        // reduction chain of one MSM (merge, segment sums, window sums; 1 ms alone) takes 3-8 ms — with two slots the main stream stalled
+        // on it (2^22 step: 71.0 -> 69.95 ms with four, no further gain with six or eight; CG_ACC_SLOTS = 2 .. 8 for A/B runs)
+        static const int acc_slots = [] { const char* e = getenv("CG_ACC_SLOTS"); const int v = e ? atoi(e) : 4; return std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(2, v)); }();
+        { int rc = ensure_arena(ctx, nsched * sort_bytes + (size_t)acc_slots * acc_slot); if (rc) return rc; }
         char* acc_scratch = ctx->arena.base + nsched * sort_bytes;
         HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));   // scalars (and the arena) are ready once the main stream gets here
         HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_in, 0));
@@ -439,7 +444,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
                     const int i1 = ev_open(ctx, t.group == CG_G1 ? TAG_ACC_G1 : TAG_ACC_G2), i2 = ev_open(ctx, TAG_REDUCE);
                     evs[0] = ctx->ev_live[i1].a; evs[1] = ctx->ev_live[i1].b; evs[2] = ctx->ev_live[i2].a; evs[3] = ctx->ev_live[i2].b; pev = evs;
                 }
-                const int slot = iter++ & 1;
+                const int slot = iter++ % acc_slots;
                 if (ctx->slot_busy[slot]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_red[slot], 0));   // slot's previous reduction must be done
                 int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
                     typedef decltype(ftag) F;
@@ -794,7 +799,7 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     { int rc = pooled_stream(device, c->prio_side, &c->sortst); if (rc) return rc; }
     HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_sched_free[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_merged[i], hipEventDisableTiming)); }
-    for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming)); }
+    for (int i = 0; i < cg_ctx::ACC_SLOTS_MAX; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming)); }
     *out = c;
     return 0;
 }
@@ -804,7 +809,8 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->aux);
     hipStreamSynchronize(ctx->sortst);
-    for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_acc[i]); hipEventDestroy(ctx->ev_red[i]); hipEventDestroy(ctx->ev_sorted[i]); hipEventDestroy(ctx->ev_sched_free[i]); hipEventDestroy(ctx->ev_merged[i]); }
+    for (int i = 0; i < cg_ctx::ACC_SLOTS_MAX; i++) { hipEventDestroy(ctx->ev_acc[i]); hipEventDestroy(ctx->ev_red[i]); }
+    for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_sorted[i]); hipEventDestroy(ctx->ev_sched_free[i]); hipEventDestroy(ctx->ev_merged[i]); }
     hipEventDestroy(ctx->ev_in);
     if (ctx->h2d) {
         hipStreamSynchronize(ctx->h2d); hipStreamSynchronize(ctx->d2h);
