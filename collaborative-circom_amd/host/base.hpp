@@ -1,0 +1,79 @@
+// Host-side mirror of the reference's prover interface for the co-groth16 path, written ONLY against the C ABI
+// (include/cogroth16_hip.h) — i.e. it does what a Rust driver crate bound to that ABI would do:
+//
+//   HipDriver  (modes Plain / Rep3)  ~  PlainDriver `mpc-core/src/protocols/plain.rs`, Rep3Protocol `mpc-core/src/protocols/rep3.rs`
+//       method names, argument meaning and party-id asymmetries follow the traits of `mpc-core/src/traits.rs`
+//       (PrimeFieldMpcProtocol :43, EcMpcProtocol :472, PairingEcMpcProtocol :525, FFTProvider :535, MSMProvider :561);
+//       vectors are DEVICE-resident share vectors (SoA, like Rep3PrimeFieldShareVec `rep3/fieldshare.rs:233-236`).
+//   CoGroth16::prove                 ~  `co-circom/co-groth16/src/groth16.rs:113-326` (same call sequence, line refs inline)
+//   Rep3Network / InProcNetwork      ~  `mpc-core/src/protocols/rep3/network.rs:30-64` and the in-process test network
+//                                       `tests/src/rep3_network.rs` (three parties on three threads, one queue per edge)
+//   read_zkey / read_wtns            ~  `circom-types/src/groth16/zkey.rs:139-316`, `binfile.rs:52-97`, `witness.rs:51-91`
+//
+// Everything O(n) runs on the GPU through the ABI; this file only sequences calls, moves the two `mul_vec` messages and the
+// O(1) points between parties, and does O(1) scalar/point algebra through the ABI's host helpers.  No CPU fallback exists.
+#pragma once
+#include "cogroth16_hip.h"
+#include "cogroth16_host.h"
+
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <chrono>
+#include <fcntl.h>
+#include <functional>
+#include <memory>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace cgh {
+
+
+typedef std::vector<uint8_t> Bytes;
+struct Fr { uint64_t v[4]; };
+
+[[noreturn]] static void die(const std::string& what) { throw std::runtime_error(what + ": " + cg_last_error()); }
+#define CG(call) do { if ((call) != 0) die(#call); } while (0)
+
+struct Curve {
+    int id;
+    size_t fq() const { return id == CG_BLS12_381 ? 48 : 32; }
+    size_t aff(int g) const { return fq() * (g == CG_G1 ? 2 : 4); }
+    size_t jac(int g) const { return fq() * (g == CG_G1 ? 3 : 6); }
+};
+
+// ---- O(1) algebra through the ABI's host helpers ----------------------------------------------------------------
+static Fr fr_op(const Curve& c, int op, const Fr& a, const Fr* b = nullptr) { Fr r; CG(cg_fr_op(c.id, op, a.v, b ? b->v : nullptr, r.v)); return r; }
+static Fr fr_add(const Curve& c, const Fr& a, const Fr& b) { return fr_op(c, 0, a, &b); }
+static Fr fr_sub(const Curve& c, const Fr& a, const Fr& b) { return fr_op(c, 1, a, &b); }
+static Fr fr_mul(const Curve& c, const Fr& a, const Fr& b) { return fr_op(c, 2, a, &b); }
+static Fr fr_inv(const Curve& c, const Fr& a) { return fr_op(c, 3, a); }
+static Fr fr_from_u64(const Curve& c, uint64_t x) { Fr raw = {{x, 0, 0, 0}}, r; CG(cg_fr_from_canonical(c.id, raw.v, r.v, 1)); return r; }
+static bool fr_eq(const Fr& a, const Fr& b) { return memcmp(a.v, b.v, 32) == 0; }
+static Fr fr_pow(const Curve& c, Fr base, const uint64_t* e, int nlimbs) {
+    Fr r = fr_from_u64(c, 1);
+    for (int i = nlimbs * 64 - 1; i >= 0; i--) { r = fr_mul(c, r, r); if ((e[i / 64] >> (i % 64)) & 1) r = fr_mul(c, r, base); }
+    return r;
+}
+
+struct Point { Bytes b; int group; };   // Jacobian, Montgomery
+static Point pt_from_affine(const Curve& c, int g, const uint8_t* aff) { Point p{Bytes(c.jac(g)), g}; CG(cg_point_from_affine(c.id, g, aff, p.b.data())); return p; }
+static Point pt_inf(const Curve& c, int g) { Bytes z(c.aff(g), 0); return pt_from_affine(c, g, z.data()); }
+static Point pt_add(const Curve& c, const Point& a, const Point& b) { Point r{Bytes(a.b.size()), a.group}; CG(cg_point_add(c.id, a.group, a.b.data(), b.b.data(), r.b.data())); return r; }
+static Point pt_neg(const Curve& c, const Point& a) { Point r{Bytes(a.b.size()), a.group}; CG(cg_point_neg(c.id, a.group, a.b.data(), r.b.data())); return r; }
+static Point pt_sub(const Curve& c, const Point& a, const Point& b) { return pt_add(c, a, pt_neg(c, b)); }
+static Point pt_mul(const Curve& c, const Point& a, const Fr& k) { Point r{Bytes(a.b.size()), a.group}; CG(cg_point_scalar_mul(c.id, a.group, a.b.data(), k.v, r.b.data())); return r; }
+static Bytes pt_to_affine(const Curve& c, const Point& a) { Bytes r(c.aff(a.group)); CG(cg_point_to_affine(c.id, a.group, a.b.data(), r.data())); return r; }
+static Point pt_generator(const Curve& c, int g) { Point p{Bytes(c.jac(g)), g}; CG(cg_point_generator(c.id, g, p.b.data())); return p; }
+
+
+}  // namespace cgh

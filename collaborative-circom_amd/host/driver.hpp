@@ -1,0 +1,713 @@
+// HipDriver: the MPC driver (modes Plain / Rep3 / Shamir) with the method names of mpc-core/src/traits.rs, every O(n) step on the GPU through the C ABI
+#pragma once
+#include "formats.hpp"
+#include "network.hpp"
+
+namespace cgh {
+
+// ---- driver ------------------------------------------------------------------------------------------------------------
+struct ShareVec { void* c[2] = {nullptr, nullptr}; size_t n = 0; };   // device; REP3 uses c[0] = a, c[1] = b; plain only c[0]
+struct FieldShare { Fr c[2]; };
+struct PointShare { Point c[2]; };
+struct DeviceMatrix { uint32_t* row_ptr; uint32_t* col; void* coeff; size_t rows; };
+
+struct DeviceZKey {   // bases uploaded once and reused by every proof / party (ownership of host buffers stays with ZKey)
+    const ZKey* z;
+    cg_bases *a = nullptr, *b1 = nullptr, *b2 = nullptr, *l = nullptr, *h = nullptr;
+    DeviceMatrix mat[2] = {{nullptr, nullptr, nullptr, 0}, {nullptr, nullptr, nullptr, 0}};
+    void* pub_dev = nullptr;
+    cg_ctx* owner = nullptr;
+    // several GPUs: this device holds the records [aux_lo, aux_lo + aux_n) of the four private-witness queries (counted
+    // from the first private variable) and [h_lo, h_lo + h_n) of h_query, registered as tables of their own (offset 0)
+    bool sliced = false; size_t aux_lo = 0, aux_n = 0, h_lo = 0, h_n = 0;
+};
+struct WorkerDevice { cg_ctx* ctx = nullptr; const DeviceZKey* dz = nullptr; };     // one further GPU of a party: a context on it + its table slices
+struct MultiDevice { std::vector<WorkerDevice> workers; };
+
+enum class Mode { Plain, Rep3, Shamir };
+
+class HipDriver {
+public:
+    cg_ctx* ctx; Curve curve; Mode mode; Rep3Network* net;
+    const Fr* rng1 = nullptr; const Fr* rng2 = nullptr; size_t rng_len = 0, cursor = 0;   // rngs.rs:25-46 streams (inputs)
+    int k() const { return mode == Mode::Rep3 ? 2 : 1; }
+    int party() const { return mode == Mode::Rep3 ? net->id() : -1; }
+
+    HipDriver(cg_ctx* c, Curve cv, Mode m, Rep3Network* n) : ctx(c), curve(cv), mode(m), net(n) {}
+    // CGH_TIMING=1: wall-clock marks of the host-side protocol steps (stderr)
+    struct Marks {
+        bool on; const char* what; std::chrono::steady_clock::time_point last; std::string line;
+        Marks(const char* w, bool enabled) : on(enabled && getenv("CGH_TIMING")), what(w), last(std::chrono::steady_clock::now()) {}
+        void mark(const char* name) {
+            if (!on) return;
+            const auto t = std::chrono::steady_clock::now(); char b[96];
+            snprintf(b, sizeof b, " %s %.1f", name, std::chrono::duration<double, std::milli>(t - last).count()); line += b; last = t;
+        }
+        ~Marks() { if (on) fprintf(stderr, "%s [ms]:%s\n", what, line.c_str()); }
+    };
+
+    // ---- Shamir state (shamir.rs:196-246): threshold, Lagrange tables, buffered double sharings; randomness = stream rng1
+    ShamirNet* snet = nullptr; int sh_t = 0;
+    std::vector<Fr> open_lagrange_t, open_lagrange_2t, mul_lagrange_2t, sh_r_t, sh_r_2t;
+    // preprocessed pairs stay on the device: entries [pre_base, pre_base + pre_n) of the two buffers above are held in d_pre_* and
+    // copied to the host only when a scalar pop or the lazy path needs them
+    void* d_pre_rt = nullptr; void* d_pre_r2t = nullptr; size_t pre_base = 0, pre_n = 0; bool pre_on_host = true;
+    void release_pre() { if (d_pre_rt) { cg_dev_free(ctx, d_pre_rt); cg_dev_free(ctx, d_pre_r2t); d_pre_rt = d_pre_r2t = nullptr; } pre_n = 0; pre_on_host = true; }
+    void materialize_pre() {
+        if (pre_on_host) return;
+        const size_t live = std::min(pre_n, sh_r_t.size() > pre_base ? sh_r_t.size() - pre_base : 0);
+        if (live) { CG(cg_dev_download(ctx, sh_r_t.data() + pre_base, d_pre_rt, live * 32)); CG(cg_dev_download(ctx, sh_r_2t.data() + pre_base, d_pre_r2t, live * 32)); }
+        pre_on_host = true;
+    }
+    static constexpr size_t SHAMIR_BATCH = 1024;                                     // ShamirRng::BATCH_SIZE
+    Fr next_rand() { if (cursor >= rng_len) throw std::runtime_error("randomness stream exhausted"); return rng1[cursor++]; }
+    std::vector<Fr> lagrange_from_coeff(const std::vector<size_t>& pts) const {       // shamir_core.rs:56-75
+        std::vector<Fr> res;
+        for (size_t i : pts) {
+            Fr num = fr_from_u64(curve, 1), den = num; const Fr fi = fr_from_u64(curve, i);
+            for (size_t j : pts) if (i != j) { const Fr fj = fr_from_u64(curve, j); num = fr_mul(curve, num, fj); den = fr_mul(curve, den, fr_sub(curve, fj, fi)); }
+            res.push_back(fr_mul(curve, num, fr_inv(curve, den)));
+        }
+        return res;
+    }
+    void shamir_init(ShamirNet* n, int threshold) {                                    // ShamirProtocol::new, shamir.rs:211-246
+        snet = n; sh_t = threshold;
+        const int np = n->num_parties(), id = n->id();
+        if (2 * threshold + 1 > np) throw std::runtime_error("Threshold too large for number of parties");
+        std::vector<size_t> p; for (int i = 0; i <= threshold; i++) p.push_back((size_t)((id + np - i) % np + 1));
+        open_lagrange_t = lagrange_from_coeff(p);
+        p.clear(); for (int i = 0; i <= 2 * threshold; i++) p.push_back((size_t)((id + np - i) % np + 1));
+        open_lagrange_2t = lagrange_from_coeff(p);
+        p.clear(); for (int i = 1; i <= 2 * threshold + 1; i++) p.push_back((size_t)i);
+        mul_lagrange_2t = lagrange_from_coeff(p);
+    }
+    std::vector<Fr> shamir_share(const Fr& secret, int degree) {                       // shamir_core.rs:8-31
+        const int np = snet->num_parties();
+        std::vector<Fr> coeffs; for (int k = 0; k < degree; k++) coeffs.push_back(next_rand());
+        std::vector<Fr> shares;
+        for (int pidx = 1; pidx <= np; pidx++) {
+            Fr sh = secret; const Fr x = fr_from_u64(curve, (uint64_t)pidx); Fr xp = x;
+            for (const Fr& cf : coeffs) { sh = fr_add(curve, sh, fr_mul(curve, xp, cf)); xp = fr_mul(curve, xp, x); }
+            shares.push_back(sh);
+        }
+        return shares;
+    }
+    void vandermonde_mul(const std::vector<Fr>& in, std::vector<Fr>& out) {            // shamir.rs:904-921 (appends t + 1 values)
+        const int np = snet->num_parties();
+        std::vector<Fr> row(np), cur(np);
+        for (int i = 0; i < np; i++) { row[i] = fr_from_u64(curve, (uint64_t)i + 1); cur[i] = row[i]; }
+        Fr s0 = fr_from_u64(curve, 0); for (const Fr& v : in) s0 = fr_add(curve, s0, v);
+        out.push_back(s0);
+        for (int k = 1; k <= sh_t; k++) {
+            Fr acc = fr_from_u64(curve, 0);
+            for (int i = 0; i < np; i++) { acc = fr_add(curve, acc, fr_mul(curve, cur[i], in[i])); cur[i] = fr_mul(curve, cur[i], row[i]); }
+            out.push_back(acc);
+        }
+    }
+    void buffer_triples(size_t amount) {                                               // shamir.rs:923-1010
+        const int np = snet->num_parties(), me = snet->id();
+        std::vector<Fr> rnd; for (size_t k = 0; k < amount; k++) rnd.push_back(next_rand());
+        std::vector<std::vector<Fr>> send(np);
+        for (const Fr& r : rnd) {
+            auto a = shamir_share(r, sh_t), b = shamir_share(r, 2 * sh_t);
+            for (int to = 0; to < np; to++) { send[to].push_back(a[to]); send[to].push_back(b[to]); }
+        }
+        for (int to = 0; to < np; to++) if (to != me) snet->send(to, send[to].data(), send[to].size() * 32);
+        std::vector<std::vector<Fr>> got(np);
+        for (int from = 0; from < np; from++) { if (from == me) got[from] = send[me]; else { got[from].resize(2 * amount); snet->recv(from, got[from].data(), 2 * amount * 32); } }
+        for (size_t k = 0; k < amount; k++) {
+            std::vector<Fr> in_t(np), in_2t(np);
+            for (int from = 0; from < np; from++) { in_t[from] = got[from][2 * k]; in_2t[from] = got[from][2 * k + 1]; }
+            vandermonde_mul(in_t, sh_r_t); vandermonde_mul(in_2t, sh_r_2t);
+        }
+    }
+    // out[off + i*stride] = sum of terms on the device (cg_vec_lincomb_dev, at most 8 terms a launch: longer sums continue on `out`)
+    struct Term { const void* src; int64_t off, stride; Fr coeff; };
+    void lincomb(void* out, int64_t off, int64_t stride, size_t n, const std::vector<Term>& terms) {
+        const Fr one = fr_from_u64(curve, 1);
+        for (size_t at = 0; at < terms.size();) {
+            std::vector<Term> part;
+            if (at) part.push_back({out, off, stride, one});
+            while (at < terms.size() && part.size() < 8) part.push_back(terms[at++]);
+            const void* src[8]; int64_t so[8], ss[8]; Fr cf[8];
+            for (size_t j = 0; j < part.size(); j++) { src[j] = part[j].src; so[j] = part[j].off; ss[j] = part[j].stride; cf[j] = part[j].coeff; }
+            CG(cg_vec_lincomb_dev(ctx, curve.id, out, off, stride, n, (int32_t)part.size(), src, so, ss, cf));
+        }
+    }
+    // ShamirProtocol::preprocess (shamir.rs:248-250) = buffer_triples(amount) (shamir.rs:923-1010) with the share algebra on the
+    // device: the same draws from the stream in the same order (amount secrets, then per secret t + 2t coefficients), the same
+    // values appended to the pair buffers, one message per peer.  The lazily refilled batches of 1024 (get_pair) stay on the host.
+    void preprocess(size_t amount) {
+        if (!amount) return;
+        const int np = snet->num_parties(), me = snet->id(), t = sh_t;
+        const size_t draws = amount * (size_t)(1 + 3 * t);
+        if (cursor + draws > rng_len) throw std::runtime_error("randomness stream exhausted");
+        Marks mk("shamir preprocess", me == 0);
+        void* d_rnd = dalloc(draws * 32);
+        CG(cg_dev_upload(ctx, d_rnd, rng1 + cursor, draws * 32)); cursor += draws;
+        mk.mark("upload draws");
+        const Fr one = fr_from_u64(curve, 1);
+        std::vector<void*> d_got(np);
+        for (int from = 0; from < np; from++) d_got[from] = dalloc(2 * amount * 32);
+        void* d_pairs = dalloc(2 * amount * 32);
+        std::vector<Fr> buf(2 * amount);
+        for (int to = 0; to < np; to++) {                                              // ShamirCore::share for the receiver's point to + 1
+            void* dst = to == me ? d_got[me] : d_pairs;
+            const Fr x = fr_from_u64(curve, (uint64_t)to + 1);
+            std::vector<Term> a{{d_rnd, 0, 1, one}}, b{{d_rnd, 0, 1, one}};
+            Fr xp = x;
+            for (int d = 0; d < 2 * t; d++) {
+                if (d < t) a.push_back({d_rnd, (int64_t)amount + d, 3 * t, xp});
+                b.push_back({d_rnd, (int64_t)amount + t + d, 3 * t, xp});
+                xp = fr_mul(curve, xp, x);
+            }
+            lincomb(dst, 0, 2, amount, a); lincomb(dst, 1, 2, amount, b);
+            if (to != me) { CG(cg_dev_download(ctx, buf.data(), d_pairs, 2 * amount * 32)); snet->send(to, buf.data(), 2 * amount * 32); }
+        }
+        mk.mark("share+send");
+        for (int from = 0; from < np; from++) if (from != me) { snet->recv(from, buf.data(), 2 * amount * 32); CG(cg_dev_upload(ctx, d_got[from], buf.data(), 2 * amount * 32)); }
+        mk.mark("recv+upload");
+        // Vandermonde rows 1, x, .., x^t over the senders' points (shamir.rs:904-921): t + 1 outputs per secret
+        const size_t outn = amount * (size_t)(t + 1);
+        void* d_rt = dalloc(outn * 32); void* d_r2t = dalloc(outn * 32);
+        std::vector<Fr> pw(np, one);
+        for (int kk = 0; kk <= t; kk++) {
+            std::vector<Term> a, b;
+            for (int from = 0; from < np; from++) { a.push_back({d_got[from], 0, 2, pw[from]}); b.push_back({d_got[from], 1, 2, pw[from]}); }
+            lincomb(d_rt, kk, t + 1, amount, a); lincomb(d_r2t, kk, t + 1, amount, b);
+            for (int from = 0; from < np; from++) pw[from] = fr_mul(curve, pw[from], fr_from_u64(curve, (uint64_t)from + 1));
+        }
+        materialize_pre(); release_pre();                                              // an earlier preprocessed block moves to the host
+        pre_base = sh_r_t.size(); pre_n = outn; d_pre_rt = d_rt; d_pre_r2t = d_r2t; pre_on_host = false;
+        sh_r_t.resize(pre_base + outn); sh_r_2t.resize(pre_base + outn);
+        for (void* q : d_got) CG(cg_dev_free(ctx, q));
+        CG(cg_dev_free(ctx, d_rnd)); CG(cg_dev_free(ctx, d_pairs));
+        mk.mark("vandermonde+free");
+    }
+    std::pair<Fr, Fr> get_pair() {                                                     // shamir.rs:1012-1025 (LIFO)
+        if (sh_r_t.empty()) { release_pre(); buffer_triples(SHAMIR_BATCH); }
+        const size_t idx = sh_r_t.size() - 1;
+        if (!pre_on_host && idx >= pre_base && idx < pre_base + pre_n) {
+            CG(cg_dev_download(ctx, &sh_r_t[idx], (const Fr*)d_pre_rt + (idx - pre_base), 32)); CG(cg_dev_download(ctx, &sh_r_2t[idx], (const Fr*)d_pre_r2t + (idx - pre_base), 32));
+        }
+        std::pair<Fr, Fr> pr{sh_r_t.back(), sh_r_2t.back()};
+        sh_r_t.pop_back(); sh_r_2t.pop_back();
+        return pr;
+    }
+    // degree_reduce_vec, shamir.rs:302-384.  `local` holds this party's products on the device and is consumed.
+    ShareVec degree_reduce_vec(ShareVec local) {
+        const int np = snet->num_parties(), me = snet->id();
+        const size_t len = local.n;
+        // the len pairs on top of the LIFO buffers, top first; read straight from the device when the preprocessed block holds them all
+        const size_t top = sh_r_t.size();
+        const bool on_dev = !pre_on_host && top >= len && top - len >= pre_base && top <= pre_base + pre_n;
+        const Fr one = fr_from_u64(curve, 1);
+        std::vector<Fr> rt, r2t;
+        Marks mk(me == 0 ? "degree_reduce_vec king" : "degree_reduce_vec party 1", me <= 1);
+        void* tmp = dalloc(len * 32);
+        if (on_dev) {
+            lincomb(local.c[0], 0, 1, len, {{local.c[0], 0, 1, one}, {d_pre_r2t, (int64_t)(top - 1 - pre_base), -1, one}});   // input += r_2t
+        } else {
+            materialize_pre();
+            rt.resize(len); r2t.resize(len);
+            for (size_t k = 0; k < len; k++) { auto pr = get_pair(); rt[k] = pr.first; r2t[k] = pr.second; }
+            CG(cg_dev_upload(ctx, tmp, r2t.data(), len * 32));
+            CG(cg_vec_add_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));      // input += r_2t
+        }
+        std::vector<Fr> buf(len);
+        mk.mark("add r_2t");
+        if (me == 0) {                                                                 // KING_ID: interpolate at 0 from parties 0..2t, re-share with degree t
+            CG(cg_vec_affine_dev(ctx, curve.id, local.c[0], local.c[0], len, mul_lagrange_2t[0].v, nullptr));   // acc = input * lagrange_0
+            for (int other = 1; other <= 2 * sh_t; other++) {
+                snet->recv(other, buf.data(), len * 32);
+                CG(cg_dev_upload(ctx, tmp, buf.data(), len * 32));
+                CG(cg_vec_affine_dev(ctx, curve.id, tmp, tmp, len, mul_lagrange_2t[other].v, nullptr));
+                CG(cg_vec_add_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));
+            }
+            mk.mark("recv+interpolate");
+            // ShamirCore::share per element: coefficients are drawn element by element (t per element)
+            std::vector<std::vector<Fr>> coeff(sh_t, std::vector<Fr>(len));
+            for (size_t k = 0; k < len; k++) for (int d = 0; d < sh_t; d++) coeff[d][k] = next_rand();
+            std::vector<void*> d_coeff(sh_t);
+            for (int d = 0; d < sh_t; d++) { d_coeff[d] = dalloc(len * 32); CG(cg_dev_upload(ctx, d_coeff[d], coeff[d].data(), len * 32)); }
+            void* share = dalloc(len * 32); void* term = dalloc(len * 32);
+            void* mine = dalloc(len * 32);
+            for (int to = np - 1; to >= 0; to--) {                                     // any order: every share is a function of (acc, coeffs) only
+                const Fr x = fr_from_u64(curve, (uint64_t)to + 1); Fr xp = x;
+                // share = acc + sum_d coeff_d * x^(d+1)
+                bool first = true;
+                for (int d = 0; d < sh_t; d++) {
+                    CG(cg_vec_affine_dev(ctx, curve.id, term, d_coeff[d], len, xp.v, nullptr));     // term = coeff_d * x^(d+1)
+                    CG(cg_vec_add_dev(ctx, curve.id, share, first ? local.c[0] : share, term, len));
+                    first = false; xp = fr_mul(curve, xp, x);
+                }
+                if (sh_t == 0) { CG(cg_dev_memset_zero(ctx, share, len * 32)); CG(cg_vec_add_dev(ctx, curve.id, share, share, local.c[0], len)); }
+                if (to == 0) { CG(cg_dev_memset_zero(ctx, mine, len * 32)); CG(cg_vec_add_dev(ctx, curve.id, mine, mine, share, len)); }
+                else { CG(cg_dev_download(ctx, buf.data(), share, len * 32)); snet->send(to, buf.data(), len * 32); }
+            }
+            CG(cg_dev_free(ctx, local.c[0])); local.c[0] = mine;
+            for (void* p : d_coeff) CG(cg_dev_free(ctx, p));
+            CG(cg_dev_free(ctx, share)); CG(cg_dev_free(ctx, term));
+            mk.mark("reshare+send");
+        } else {
+            if (me <= 2 * sh_t) { CG(cg_dev_download(ctx, buf.data(), local.c[0], len * 32)); snet->send(0, buf.data(), len * 32); }   // only if my items are required
+            mk.mark("download+send");
+            snet->recv(0, buf.data(), len * 32);
+            mk.mark("wait for king");
+            CG(cg_dev_upload(ctx, local.c[0], buf.data(), len * 32));
+            mk.mark("upload");
+        }
+        if (on_dev) {
+            lincomb(tmp, 0, 1, len, {{d_pre_rt, (int64_t)(top - 1 - pre_base), -1, one}});
+            sh_r_t.resize(top - len); sh_r_2t.resize(top - len);
+        } else CG(cg_dev_upload(ctx, tmp, rt.data(), len * 32));
+        CG(cg_vec_sub_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));          // share - r_t
+        CG(cg_dev_free(ctx, tmp));
+        mk.mark("sub r_t");
+        return local;
+    }
+    Fr degree_reduce(Fr input) {                                                       // shamir.rs:252-300
+        const int np = snet->num_parties(), me = snet->id();
+        auto pr = get_pair();
+        input = fr_add(curve, input, pr.second);
+        Fr my_share;
+        if (me == 0) {
+            Fr acc = fr_mul(curve, input, mul_lagrange_2t[0]);
+            for (int other = 1; other <= 2 * sh_t; other++) { Fr r; snet->recv(other, r.v, 32); acc = fr_add(curve, acc, fr_mul(curve, r, mul_lagrange_2t[other])); }
+            auto shares = shamir_share(acc, sh_t);
+            for (int to = 0; to < np; to++) { if (to == me) my_share = shares[to]; else snet->send(to, shares[to].v, 32); }
+        } else {
+            if (me <= 2 * sh_t) snet->send(0, input.v, 32);
+            snet->recv(0, my_share.v, 32);
+        }
+        return fr_sub(curve, my_share, pr.first);
+    }
+    Point degree_reduce_point(Point input) {                                           // shamir.rs:386-436; C::rand stand-in: G * next_rand()
+        const int np = snet->num_parties(), me = snet->id();
+        const int g = input.group;
+        auto pr = get_pair();
+        const Point gen = pt_generator(curve, g);
+        input = pt_add(curve, input, pt_mul(curve, gen, pr.second));
+        Point my_share = pt_inf(curve, g);
+        const size_t psz = curve.aff(g);
+        if (me == 0) {
+            Point acc = pt_mul(curve, input, mul_lagrange_2t[0]);
+            for (int other = 1; other <= 2 * sh_t; other++) { Bytes a(psz); snet->recv(other, a.data(), psz); acc = pt_add(curve, acc, pt_mul(curve, pt_from_affine(curve, g, a.data()), mul_lagrange_2t[other])); }
+            std::vector<Point> coeffs; for (int d = 0; d < sh_t; d++) coeffs.push_back(pt_mul(curve, gen, next_rand()));
+            for (int to = 0; to < np; to++) {
+                Point sh = acc; const Fr x = fr_from_u64(curve, (uint64_t)to + 1); Fr xp = x;
+                for (const Point& cf : coeffs) { sh = pt_add(curve, sh, pt_mul(curve, cf, xp)); xp = fr_mul(curve, xp, x); }
+                if (to == me) my_share = sh; else { Bytes a = pt_to_affine(curve, sh); snet->send(to, a.data(), a.size()); }
+            }
+        } else {
+            if (me <= 2 * sh_t) { Bytes a = pt_to_affine(curve, input); snet->send(0, a.data(), a.size()); }
+            Bytes a(psz); snet->recv(0, a.data(), psz); my_share = pt_from_affine(curve, g, a.data());
+        }
+        return pt_sub(curve, my_share, pt_mul(curve, gen, pr.first));
+    }
+    // broadcast_next(t + 1) + reconstruct_point (network.rs:233-266, shamir.rs:778-782)
+    Point shamir_open_point(const Point& mine) {
+        const int np = snet->num_parties(), me = snet->id();
+        Bytes a = pt_to_affine(curve, mine);
+        for (int sft = 1; sft <= sh_t; sft++) snet->send((me + sft) % np, a.data(), a.size());
+        Point res = pt_mul(curve, mine, open_lagrange_t[0]);
+        for (int r = 1; r <= sh_t; r++) { Bytes b(a.size()); snet->recv((me + np - r) % np, b.data(), b.size()); res = pt_add(curve, res, pt_mul(curve, pt_from_affine(curve, mine.group, b.data()), open_lagrange_t[r])); }
+        return res;
+    }
+
+    void* dalloc(size_t bytes) { void* p; CG(cg_dev_alloc(ctx, bytes, &p)); return p; }
+    ShareVec alloc_vec(size_t n) { ShareVec v; v.n = n; for (int j = 0; j < k(); j++) { v.c[j] = dalloc(n * 32); CG(cg_dev_memset_zero(ctx, v.c[j], n * 32)); } return v; }
+    void free_vec(ShareVec& v) { for (int j = 0; j < 2; j++) if (v.c[j]) { CG(cg_dev_free(ctx, v.c[j])); v.c[j] = nullptr; } }
+    ShareVec upload_vec(const Fr* a, const Fr* b, size_t n) {
+        ShareVec v; v.n = n;
+        if (n >= XCHG_ASYNC_MIN && cg_host_is_pinned(a) && (!b || k() < 2 || cg_host_is_pinned(b))) {   // page-locked shares: asynchronous DMA, the stream waits
+            v.c[0] = dalloc(n * 32);
+            int32_t tk = upload_staged(v.c[0], a, n);
+            if (b && k() == 2) { v.c[1] = dalloc(n * 32); tk = upload_staged(v.c[1], b, n); }
+            if (tk >= 0) CG(cg_copy_fence(ctx, tk));
+            if (aux) CG(cg_copy_wait(ctx, tk));                                        // the second context reads the shares too
+            return v;
+        }
+        v.c[0] = dalloc(n * 32); CG(cg_dev_upload(ctx, v.c[0], a, n * 32));
+        if (k() == 2) { v.c[1] = dalloc(n * 32); CG(cg_dev_upload(ctx, v.c[1], b, n * 32)); }
+        return v;
+    }
+    Fr draw(const Fr* s) const { if (cursor >= rng_len) throw std::runtime_error("randomness stream exhausted"); return s[cursor]; }
+
+    // evaluate_constraint for every row (traits.rs:180; plain.rs:243-258, rep3.rs:690-708) into a zero-padded length-m vector
+    ShareVec evaluate_constraints(const DeviceMatrix& mt, const void* d_pub, uint32_t n_inputs, const ShareVec& wit, size_t m) {
+        ShareVec out = alloc_vec(m);
+        CG(cg_spmv_csr_dev(ctx, curve.id, mt.row_ptr, mt.col, mt.coeff, mt.rows, d_pub, n_inputs, party(), wit.c[0], wit.c[1], out.c[0], out.c[1]));
+        return out;
+    }
+    // promote_to_trivial_shares (fieldshare.rs:262-283) + clone_from_slice (rep3.rs:710-725)
+    // d_pub (optional): the same values already on the device — the copy is then enqueued like a kernel, the host does not wait
+    void clone_public_into(ShareVec& dst, size_t dst_off, const std::vector<Fr>& pub, const void* d_pub = nullptr) {
+        const int holder = mode != Mode::Rep3 ? 0 : (party() == 0 ? 0 : party() == 1 ? 1 : -1);   // REP3: ID0 -> a, ID1 -> b, ID2 -> nothing; plain / Shamir: the value itself
+        if (holder < 0) return;
+        if (d_pub) CG(cg_dev_copy_peer(ctx, (uint8_t*)dst.c[holder] + dst_off * 32, ctx, d_pub, pub.size() * 32));
+        else CG(cg_dev_upload(ctx, (uint8_t*)dst.c[holder] + dst_off * 32, pub.data(), pub.size() * 32));
+    }
+    // mul_vec (traits.rs:164): plain.rs:219-224 ; rep3.rs:650-670 (local product + mask, send to next, receive from prev)
+    // ---- page-locked staging rings for the asynchronous exchanges: chunks of XCHG_CHUNK elements travel over the
+    // context's copy streams while the compute stream keeps running; a slot is reused once the copy that used it has completed
+    static constexpr size_t XCHG_CHUNK_MAX = (size_t)1 << 17;                           // 4 MiB of field elements
+    static constexpr int XCHG_SLOTS = 8;
+    // chunk length for a vector of n elements: about n / 8, a power of two in [4096, 2^17] (page-locking memory is slow: small proofs get small rings)
+    static size_t xchg_chunk(size_t n) { size_t c = 4096; while (c < XCHG_CHUNK_MAX && c * XCHG_SLOTS < n) c <<= 1; return c; }
+    struct PinRing { uint8_t* base = nullptr; size_t chunk = 0; int32_t busy[XCHG_SLOTS]; int next = 0; int last = 0; };
+    PinRing ring_out, ring_in;
+    uint8_t* ring_slot(PinRing& r, size_t chunk) {
+        if (r.chunk < chunk) {                                                          // first use, or a longer vector than before
+            if (r.base) { CG(cg_ctx_sync(ctx)); CG(cg_host_free(r.base)); }
+            void* p; CG(cg_host_alloc(XCHG_SLOTS * chunk * 32, &p)); r.base = (uint8_t*)p; r.chunk = chunk; for (int32_t& b : r.busy) b = -1;
+        }
+        r.last = r.next++ % XCHG_SLOTS;
+        if (r.busy[r.last] >= 0) { CG(cg_copy_wait(ctx, r.busy[r.last])); r.busy[r.last] = -1; }
+        return r.base + (size_t)r.last * r.chunk * 32;
+    }
+    void release_rings() { for (PinRing* r : {&ring_out, &ring_in}) if (r->base) { cg_ctx_sync(ctx); cg_host_free(r->base); r->base = nullptr; r->chunk = 0; } }
+    std::vector<void*> deferred;                                                        // device buffers freed at the next quiet point
+    void defer_free(void* p) { if (p) deferred.push_back(p); }
+    void free_deferred() { for (void* p : deferred) CG(cg_dev_free(ctx, p)); deferred.clear(); }
+    // host (pageable) -> device through the ring, asynchronous; returns the ticket of the last chunk
+    int32_t upload_staged(void* d_dst, const Fr* src, size_t n) {
+        int32_t tk = -1;
+        if (n && cg_host_is_pinned(src)) {                                             // the caller keeps this vector page-locked: DMA straight from it
+            CG(cg_dev_upload_begin(ctx, d_dst, src, n * 32, 0, &tk));
+            return tk;
+        }
+        const size_t ch = xchg_chunk(n);
+        for (size_t off = 0; off < n; off += ch) {
+            const size_t len = std::min(ch, n - off);
+            uint8_t* slot = ring_slot(ring_in, ch);
+            memcpy(slot, src + off, len * 32);
+            CG(cg_dev_upload_begin(ctx, (uint8_t*)d_dst + off * 32, slot, len * 32, 0, &tk));
+            ring_in.busy[ring_in.last] = tk;
+        }
+        return tk;
+    }
+    // mul_vec (rep3.rs:650-670) in two halves, so that the caller can enqueue independent work between the local product and the
+    // exchange: `begin` masks and multiplies on the device and starts streaming the local product to the host; `finish` sends it to
+    // the next party chunk by chunk while receiving the previous party's chunks, which go straight back up.  Plain / Shamir: `begin`
+    // is the whole operation.
+    // shorter vectors: one synchronous message (setting up rings and copy streams costs more than it hides); CGH_XCHG_ASYNC_MIN overrides (A/B runs)
+    const size_t XCHG_ASYNC_MIN = getenv("CGH_XCHG_ASYNC_MIN") ? (size_t)atoll(getenv("CGH_XCHG_ASYNC_MIN")) : (size_t)1 << 19;
+    // masks of the coming mul_vec calls, uploaded ahead of time (only from page-locked randomness streams, where the copy is a plain
+    // asynchronous DMA): the product kernel then never waits for PCIe
+    struct MaskSet { void* m1; void* m2; int32_t tk; size_t n, at; };
+    std::deque<MaskSet> prefetched;
+    void prefetch_masks(int count, size_t n) {
+        if (mode != Mode::Rep3 || n < XCHG_ASYNC_MIN || !rng1 || !rng2) return;
+        size_t at = cursor;
+        for (int i = 0; i < count && at + n <= rng_len; i++, at += n) {
+            if (!cg_host_is_pinned(rng1 + at) || !cg_host_is_pinned(rng2 + at)) return;
+            MaskSet ms{dalloc(n * 32), dalloc(n * 32), -1, n, at};
+            upload_staged(ms.m1, rng1 + at, n);
+            ms.tk = upload_staged(ms.m2, rng2 + at, n);
+            prefetched.push_back(ms);
+        }
+    }
+    struct Down { uint8_t* slot; int32_t tk; };
+    struct PendingMul { ShareVec out; bool exchange = false; std::deque<Down> down; size_t issued = 0; };
+    // start streaming chunks of the local product to the host, as many as the ring has room for
+    void issue_downloads(PendingMul& pm, size_t upto) {
+        const size_t n = pm.out.n, ch = xchg_chunk(n), nch = (n + ch - 1) / ch;
+        while (pm.issued < nch && pm.issued < upto) {
+            const size_t off = pm.issued * ch, len = std::min(ch, n - off);
+            Down d; d.slot = ring_slot(ring_out, ch);
+            CG(cg_dev_download_begin(ctx, d.slot, (const uint8_t*)pm.out.c[0] + off * 32, len * 32, &d.tk));
+            ring_out.busy[ring_out.last] = d.tk;
+            pm.down.push_back(d); pm.issued++;
+        }
+    }
+    PendingMul mul_vec_begin(const ShareVec& a, const ShareVec& b) {
+        PendingMul pm; ShareVec& out = pm.out; out.n = a.n;
+        out.c[0] = dalloc(a.n * 32);
+        if (mode != Mode::Rep3) CG(cg_vec_mul_dev(ctx, curve.id, out.c[0], a.c[0], b.c[0], a.n));
+        if (mode == Mode::Plain) return pm;
+        if (mode == Mode::Shamir) { out = degree_reduce_vec(out); return pm; }         // shamir.rs:609-623
+        if (cursor + a.n > rng_len) throw std::runtime_error("randomness stream exhausted");
+        void* m1 = nullptr; void* m2 = nullptr;
+        if (!prefetched.empty() && prefetched.front().at == cursor && prefetched.front().n == a.n) {
+            const MaskSet ms = prefetched.front(); prefetched.pop_front();
+            m1 = ms.m1; m2 = ms.m2;
+            if (ms.tk >= 0) CG(cg_copy_fence(ctx, ms.tk));
+        } else {
+            m1 = dalloc(a.n * 32); m2 = dalloc(a.n * 32);
+        if (a.n < XCHG_ASYNC_MIN) { CG(cg_dev_upload(ctx, m1, rng1 + cursor, a.n * 32)); CG(cg_dev_upload(ctx, m2, rng2 + cursor, a.n * 32)); }
+        else {
+            upload_staged(m1, rng1 + cursor, a.n);
+            const int32_t tk = upload_staged(m2, rng2 + cursor, a.n);
+            if (tk >= 0) CG(cg_copy_fence(ctx, tk));                                   // uploads complete in order: the last ticket covers both masks
+        }
+        }
+        cursor += a.n;
+        CG(cg_vec_sub_dev(ctx, curve.id, m1, m1, m2, a.n));                           // masking_field_element = rand(rng1) - rand(rng2)
+        CG(cg_vec_rep3_mul_local_dev(ctx, curve.id, out.c[0], a.c[0], a.c[1], b.c[0], b.c[1], m1, a.n));
+        defer_free(m1); defer_free(m2);
+        out.c[1] = dalloc(a.n * 32);
+        pm.exchange = true;
+        if (a.n >= XCHG_ASYNC_MIN) issue_downloads(pm, XCHG_SLOTS - 1);                // ordered right behind the product, ahead of whatever the caller enqueues next
+        return pm;
+    }
+    ShareVec mul_vec_finish(PendingMul& pm) {
+        if (!pm.exchange) return pm.out;
+        ShareVec& out = pm.out;
+        pm.exchange = false;
+        if (out.n < XCHG_ASYNC_MIN) {                                                  // rep3.rs:661-669 as one message
+            std::vector<Fr> local(out.n), recv(out.n);
+            CG(cg_dev_download(ctx, local.data(), out.c[0], out.n * 32));
+            net->send_next(local.data(), out.n * 32);
+            net->recv_prev(recv.data(), out.n * 32);
+            CG(cg_dev_upload(ctx, out.c[1], recv.data(), out.n * 32));
+            return out;
+        }
+        const size_t n = out.n, XCHG_CHUNK = xchg_chunk(n), nch = (n + XCHG_CHUNK - 1) / XCHG_CHUNK;
+        std::deque<Down>& down = pm.down;
+        int32_t up = -1;
+        for (size_t c = 0; c < nch; c++) {
+            issue_downloads(pm, c + XCHG_SLOTS - 1);                                   // keep the download stream ahead of the sender
+            const size_t off = c * XCHG_CHUNK, len = std::min(XCHG_CHUNK, n - off);
+            CG(cg_copy_wait(ctx, down.front().tk));
+            net->send_next(down.front().slot, len * 32);                               // chunked send_next_many
+            down.pop_front();
+            if (const void* direct = net->recv_prev_pinned(len * 32)) {                    // the transport holds it in page-locked memory already
+                CG(cg_dev_upload_begin(ctx, (uint8_t*)out.c[1] + off * 32, direct, len * 32, 0, &up));
+            } else {
+                uint8_t* slot = ring_slot(ring_in, XCHG_CHUNK);
+                net->recv_prev(slot, len * 32);
+                CG(cg_dev_upload_begin(ctx, (uint8_t*)out.c[1] + off * 32, slot, len * 32, 0, &up));
+                ring_in.busy[ring_in.last] = up;
+            }
+        }
+        if (up >= 0) CG(cg_copy_fence(ctx, up));                                       // later launches see the received component
+        pm.exchange = false;
+        return out;
+    }
+    ShareVec mul_vec(const ShareVec& a, const ShareVec& b) { PendingMul pm = mul_vec_begin(a, b); ShareVec r = mul_vec_finish(pm); free_deferred(); return r; }
+    // before the context goes away (idempotent; also run by the destructor when a party dies with an exception)
+    void shutdown() {
+        for (void* p : deferred) cg_dev_free(ctx, p);
+        deferred.clear();
+        for (auto& ms : prefetched) { cg_dev_free(ctx, ms.m1); cg_dev_free(ctx, ms.m2); }
+        prefetched.clear();
+        release_rings(); release_pre();
+        if (aux) { if (owns_aux) cg_ctx_destroy(aux); aux = nullptr; }
+    }
+    void use_second_context(cg_ctx* second) { aux = second; }                           // owned from here on (shutdown destroys it)
+    ~HipDriver() { shutdown(); }
+    // ---- vector forms of rand / mul_open_many / open_many used by co-plonk (rep3.rs:544-558,595-598,620-628,738-757)
+    int public_component() const { return mode != Mode::Rep3 ? 0 : (party() == 0 ? 0 : party() == 1 ? 1 : -1); }   // add_with_public: who holds a public addend
+    // broadcast_next(num) of a vector + reconstruction with the given Lagrange table (shamir/network.rs:233-266, shamir.rs:581-601,684-711)
+    std::vector<Fr> shamir_open_vec(const std::vector<Fr>& mine, const std::vector<Fr>& lagrange) {
+        const int np = snet->num_parties(), me = snet->id(), num = (int)lagrange.size();
+        const size_t n = mine.size();
+        for (int sft = 1; sft < num; sft++) snet->send((me + sft) % np, mine.data(), n * 32);
+        std::vector<Fr> out(n), got(n);
+        for (size_t i = 0; i < n; i++) out[i] = fr_mul(curve, mine[i], lagrange[0]);
+        for (int r = 1; r < num; r++) { snet->recv((me + np - r) % np, got.data(), n * 32); for (size_t i = 0; i < n; i++) out[i] = fr_add(curve, out[i], fr_mul(curve, got[i], lagrange[r])); }
+        return out;
+    }
+    ShareVec rand_vec(size_t n) {
+        if (mode == Mode::Shamir) { std::vector<Fr> r(n); for (size_t i = 0; i < n; i++) r[i] = get_pair().first; return upload_vec(r.data(), nullptr, n); }   // shamir.rs:570-573
+        if (mode != Mode::Rep3) throw std::runtime_error("rand_vec: REP3 / Shamir only");
+        if (cursor + n > rng_len) throw std::runtime_error("randomness stream exhausted");
+        ShareVec v = upload_vec(rng1 + cursor, rng2 + cursor, n); cursor += n;
+        return v;
+    }
+    // a * b opened: a public device vector (caller frees)
+    void* mul_open_vec(const ShareVec& a, const ShareVec& b) {
+        const size_t n = a.n;
+        void* out = dalloc(n * 32);
+        if (mode != Mode::Rep3) CG(cg_vec_mul_dev(ctx, curve.id, out, a.c[0], b.c[0], n));
+        if (mode == Mode::Plain) return out;
+        if (mode == Mode::Shamir) {                                                   // degree-2t product opened from 2t + 1 shares (shamir.rs:684-711)
+            // broadcast_next(2t) + reconstruction (shamir/network.rs:233-266): the Lagrange combination runs on the device
+            const int np = snet->num_parties(), me = snet->id(), num = (int)open_lagrange_2t.size();
+            std::vector<Fr> buf(n); CG(cg_dev_download(ctx, buf.data(), out, n * 32));
+            for (int sft = 1; sft < num; sft++) snet->send((me + sft) % np, buf.data(), n * 32);
+            std::vector<Term> terms{{out, 0, 1, open_lagrange_2t[0]}};
+            std::vector<void*> got;
+            for (int r = 1; r < num; r++) {
+                snet->recv((me + np - r) % np, buf.data(), n * 32);
+                void* d = dalloc(n * 32); CG(cg_dev_upload(ctx, d, buf.data(), n * 32));
+                got.push_back(d); terms.push_back({d, 0, 1, open_lagrange_2t[r]});
+            }
+            lincomb(out, 0, 1, n, terms);
+            for (void* d : got) CG(cg_dev_free(ctx, d));
+            return out;
+        }
+        if (cursor + n > rng_len) throw std::runtime_error("randomness stream exhausted");
+        void* m1 = dalloc(n * 32); void* m2 = dalloc(n * 32);
+        CG(cg_dev_upload(ctx, m1, rng1 + cursor, n * 32)); CG(cg_dev_upload(ctx, m2, rng2 + cursor, n * 32)); cursor += n;
+        CG(cg_vec_sub_dev(ctx, curve.id, m1, m1, m2, n));
+        CG(cg_vec_rep3_mul_local_dev(ctx, curve.id, out, a.c[0], a.c[1], b.c[0], b.c[1], m1, n));
+        std::vector<Fr> mine(n), p(n), q(n);
+        CG(cg_dev_download(ctx, mine.data(), out, n * 32));
+        net->send_next(mine.data(), n * 32); net->send_prev(mine.data(), n * 32);
+        net->recv_prev(p.data(), n * 32); net->recv_next(q.data(), n * 32);
+        CG(cg_dev_upload(ctx, m1, p.data(), n * 32)); CG(cg_dev_upload(ctx, m2, q.data(), n * 32));
+        CG(cg_vec_add_dev(ctx, curve.id, out, out, m1, n)); CG(cg_vec_add_dev(ctx, curve.id, out, out, m2, n));
+        CG(cg_dev_free(ctx, m1)); CG(cg_dev_free(ctx, m2));
+        return out;
+    }
+    std::vector<Fr> open_many(const std::vector<FieldShare>& a) {
+        std::vector<Fr> out(a.size());
+        if (mode == Mode::Plain) { for (size_t i = 0; i < a.size(); i++) out[i] = a[i].c[0]; return out; }
+        if (mode == Mode::Shamir) { std::vector<Fr> mine(a.size()); for (size_t i = 0; i < a.size(); i++) mine[i] = a[i].c[0]; return shamir_open_vec(mine, open_lagrange_t); }   // shamir.rs:581-601
+        std::vector<Fr> bs(a.size()), cs(a.size());
+        for (size_t i = 0; i < a.size(); i++) bs[i] = a[i].c[1];
+        net->send_next(bs.data(), bs.size() * 32); net->recv_prev(cs.data(), cs.size() * 32);
+        for (size_t i = 0; i < a.size(); i++) out[i] = fr_add(curve, fr_add(curve, a[i].c[0], a[i].c[1]), cs[i]);
+        return out;
+    }
+
+    // FFTProvider (traits.rs:535-558): both share components in one launch
+    void fft_in_place(ShareVec& v, const Fr& group_gen) { CG(cg_ntt_dev(ctx, curve.id, v.c, k(), v.n, group_gen.v, 0, nullptr)); }
+    void ifft_in_place(ShareVec& v, const Fr& group_gen) { CG(cg_ntt_dev(ctx, curve.id, v.c, k(), v.n, group_gen.v, 1, nullptr)); }
+    void distribute_powers_and_mul_by_const(ShareVec& v, const Fr& g, const Fr& c) { for (int j = 0; j < k(); j++) CG(cg_vec_distribute_powers_dev(ctx, curve.id, v.c[j], v.n, g.v, c.v)); }
+    // fused ifft_in_place + distribute_powers_and_mul_by_const(g, 1): one HBM round trip less per vector
+    void ifft_coset_in_place(ShareVec& v, const Fr& group_gen, const Fr& g) { CG(cg_ntt_dev(ctx, curve.id, v.c, k(), v.n, group_gen.v, 1, g.v)); }
+    void sub_assign_vec(ShareVec& a, const ShareVec& b) { for (int j = 0; j < k(); j++) CG(cg_vec_sub_dev(ctx, curve.id, a.c[j], a.c[j], b.c[j], a.n)); }
+
+    // MSMProvider::msm_public_points (traits.rs:561-568) on a sub-slice of a registered table
+    PointShare msm_public_points(const cg_bases* bases, int group, size_t off, size_t n, const ShareVec& s) {
+        Bytes out(curve.jac(group) * k());
+        const void* sc[2] = {s.c[0], s.c[1]};
+        CG(cg_msm_dev(ctx, bases, off, n, sc, k(), out.data()));
+        PointShare r;
+        for (int j = 0; j < k(); j++) r.c[j] = Point{Bytes(out.begin() + j * curve.jac(group), out.begin() + (j + 1) * curve.jac(group)), group};
+        if (k() == 1) r.c[1] = pt_inf(curve, group);
+        return r;
+    }
+    // The same MSMs started early and collected later (cg_msm_dev_begin_multi / cg_msm_end): the four queries over the private witness
+    // (groth16.rs:251,267,284,298) share one scalar decomposition and run on a second context (`aux`, own streams) while the witness
+    // map and its exchanges occupy the first.  MSMs involve no network, so the party-to-party message order is the reference's.
+    cg_ctx* aux = nullptr; bool owns_aux = true;       // a session lends its contexts (owns_aux = false)
+    struct PendingMsm {
+        cg_ctx* on = nullptr; std::vector<int32_t> tickets; std::vector<int> groups;
+        struct Part { cg_ctx* on; std::vector<int32_t> tickets; void* sc[2]; };     // the same MSMs over the slices held by further GPUs
+        std::vector<Part> parts;
+    };
+    // Several GPUs: every MSM range is cut into one contiguous slice per device (the primary context's device holds slice 0); the scalar
+    // slices travel device to device (cg_dev_copy_peer, xGMI), each device runs the bucket method on its slice, and the partial sums
+    // — one Jacobian point per table, component and device — are added on the host (RCCL has no EC-add reduction, and a few hundred
+    // bytes per proof need no collective).  MSMProvider::msm_public_points (rep3.rs:934-947) is linear in the (scalar, point) pairs.
+    const MultiDevice* md = nullptr;
+    PendingMsm msm_begin_sharded(const DeviceZKey& dz, bool aux_tables, const ShareVec& s) {
+        const size_t lo = aux_tables ? dz.aux_lo : dz.h_lo, n = aux_tables ? dz.aux_n : dz.h_n;
+        ShareVec mine; mine.n = n; for (int j = 0; j < k(); j++) mine.c[j] = (char*)s.c[j] + lo * 32;
+        PendingMsm p = aux_tables ? msm_begin_multi({dz.l, dz.a, dz.b1, dz.b2}, {0, 0, 0, 0}, {CG_G1, CG_G1, CG_G1, CG_G2}, n, mine, true)
+                                  : msm_begin_multi({dz.h}, {0}, {CG_G1}, n, mine, false);
+        if (!md) return p;
+        static const bool primary_only = getenv("CGH_EMULATE_PRIMARY_ONLY") != nullptr;    // planning knob: time the primary device's share of an
+        if (primary_only) return p;                                                       // N-device proof on one GPU (the proof is then wrong)
+        for (const WorkerDevice& w : md->workers) {
+            const DeviceZKey& wz = *w.dz;
+            const size_t wlo = aux_tables ? wz.aux_lo : wz.h_lo, wn = aux_tables ? wz.aux_n : wz.h_n;
+            PendingMsm::Part part{w.ctx, {}, {nullptr, nullptr}};
+            for (int j = 0; j < k(); j++) {
+                CG(cg_dev_alloc(w.ctx, std::max<size_t>(wn * 32, 32), &part.sc[j]));
+                CG(cg_dev_copy_peer(w.ctx, part.sc[j], ctx, (const char*)s.c[j] + wlo * 32, wn * 32));
+            }
+            std::vector<const cg_bases*> tabs = aux_tables ? std::vector<const cg_bases*>{wz.l, wz.a, wz.b1, wz.b2} : std::vector<const cg_bases*>{wz.h};
+            std::vector<size_t> offs(tabs.size(), 0);
+            part.tickets.resize(tabs.size());
+            const void* sc[2] = {part.sc[0], part.sc[1]};
+            CG(cg_msm_dev_begin_multi(w.ctx, (int32_t)tabs.size(), tabs.data(), offs.data(), wn, sc, k(), part.tickets.data()));
+            p.parts.push_back(part);
+        }
+        return p;
+    }
+    void msm_release(PendingMsm& p) {      // after the last msm_finish: the slices' scalar copies
+        for (auto& part : p.parts) for (int j = 0; j < 2; j++) if (part.sc[j]) { cg_dev_free(part.on, part.sc[j]); part.sc[j] = nullptr; }
+        p.parts.clear();
+    }
+    PendingMsm msm_begin_multi(const std::vector<const cg_bases*>& tables, const std::vector<size_t>& offsets, const std::vector<int>& groups, size_t n, const ShareVec& s, bool on_aux) {
+        PendingMsm p; p.on = on_aux && aux ? aux : ctx; p.groups = groups; p.tickets.resize(tables.size());
+        // REP3 at sizes where the exchanges are asynchronous: these MSMs run beside the witness map's dependency chain (product -> down ->
+        // peer -> up, twice) on the other context; shorter-lived workgroups let the chain's kernels onto the chip sooner (2^22: one party
+        // alone 107 -> 97 ms)
+        static const uint32_t bulk_chunk = getenv("CGH_BULK_CHUNK") ? (uint32_t)atoi(getenv("CGH_BULK_CHUNK")) : 64u;   // tuning knob
+        static const uint32_t plain_chunk = getenv("CGH_PLAIN_CHUNK") ? (uint32_t)atoi(getenv("CGH_PLAIN_CHUNK")) : 0u;  // tuning knob
+        if (p.on != ctx) CG(cg_msm_set_chunk(p.on, mode == Mode::Rep3 && n >= XCHG_ASYNC_MIN ? bulk_chunk : plain_chunk));
+        const void* sc[2] = {s.c[0], s.c[1]};
+        if (p.on != ctx) CG(cg_ctx_sync(ctx));                                          // the scalars were produced on this driver's stream
+        CG(cg_msm_dev_begin_multi(p.on, (int32_t)tables.size(), tables.data(), offsets.data(), n, sc, k(), p.tickets.data()));
+        return p;
+    }
+    PointShare msm_finish(PendingMsm& p, size_t i) {
+        const int group = p.groups[i];
+        Bytes out(curve.jac(group) * k());
+        CG(cg_msm_end(p.on, p.tickets[i], out.data()));
+        PointShare r;
+        for (int j = 0; j < k(); j++) r.c[j] = Point{Bytes(out.begin() + j * curve.jac(group), out.begin() + (j + 1) * curve.jac(group)), group};
+        for (auto& part : p.parts) {                                                    // slices on further GPUs: fold the partial sums
+            CG(cg_msm_end(part.on, part.tickets[i], out.data()));
+            for (int j = 0; j < k(); j++) r.c[j] = pt_add(curve, r.c[j], Point{Bytes(out.begin() + j * curve.jac(group), out.begin() + (j + 1) * curve.jac(group)), group});
+        }
+        if (k() == 1) r.c[1] = pt_inf(curve, group);
+        return r;
+    }
+    // rand (rep3.rs:595-598; plain: supplied by the caller)
+    FieldShare rand() {
+        if (mode == Mode::Shamir) { FieldShare f; f.c[0] = get_pair().first; f.c[1] = f.c[0]; return f; }   // shamir.rs:570-573
+        FieldShare f; f.c[0] = draw(rng1); f.c[1] = draw(rng2); cursor++; return f;
+    }
+    // mul (rep3.rs:503-511 / plain a*b)
+    FieldShare mul(const FieldShare& a, const FieldShare& b) {
+        FieldShare r;
+        if (mode == Mode::Plain) { r.c[0] = fr_mul(curve, a.c[0], b.c[0]); r.c[1] = r.c[0]; return r; }
+        if (mode == Mode::Shamir) { r.c[0] = degree_reduce(fr_mul(curve, a.c[0], b.c[0])); r.c[1] = r.c[0]; return r; }   // shamir.rs:481-488
+        Fr local = fr_add(curve, fr_add(curve, fr_mul(curve, a.c[0], b.c[0]), fr_mul(curve, a.c[0], b.c[1])), fr_mul(curve, a.c[1], b.c[0]));
+        local = fr_add(curve, local, fr_sub(curve, draw(rng1), draw(rng2))); cursor++;
+        net->send_next(local.v, 32);
+        Fr prev; net->recv_prev(prev.v, 32);
+        r.c[0] = local; r.c[1] = prev;
+        return r;
+    }
+    PointShare scalar_mul_public_point(const Point& p, const FieldShare& s) {   // rep3.rs:820-825
+        PointShare r; for (int j = 0; j < 2; j++) r.c[j] = j < k() ? pt_mul(curve, p, s.c[j]) : pt_inf(curve, p.group); return r;
+    }
+    PointShare scalar_mul(const PointShare& a, const FieldShare& b) {           // rep3.rs:835-847, pointshare.rs:117-124
+        PointShare r;
+        if (mode == Mode::Plain) { r.c[0] = pt_mul(curve, a.c[0], b.c[0]); r.c[1] = pt_inf(curve, a.c[0].group); return r; }
+        if (mode == Mode::Shamir) { r.c[0] = degree_reduce_point(pt_mul(curve, a.c[0], b.c[0])); r.c[1] = pt_inf(curve, a.c[0].group); return r; }   // shamir.rs:769-776
+        Point local = pt_add(curve, pt_add(curve, pt_mul(curve, a.c[0], b.c[0]), pt_mul(curve, a.c[1], b.c[0])), pt_mul(curve, a.c[0], b.c[1]));
+        const Point gen = pt_generator(curve, a.c[0].group);       // masking_ec_element: G*rand(rng1) - G*rand(rng2)
+        local = pt_add(curve, local, pt_sub(curve, pt_mul(curve, gen, draw(rng1)), pt_mul(curve, gen, draw(rng2)))); cursor++;
+        Bytes aff = pt_to_affine(curve, local);                    // points cross the wire in affine form (ark-serialize)
+        net->send_next(aff.data(), aff.size());
+        Bytes prev(aff.size()); net->recv_prev(prev.data(), prev.size());
+        r.c[0] = local; r.c[1] = pt_from_affine(curve, local.group, prev.data());
+        return r;
+    }
+    void add_assign_points(PointShare& a, const PointShare& b) { for (int j = 0; j < k(); j++) a.c[j] = pt_add(curve, a.c[j], b.c[j]); }
+    void sub_assign_points(PointShare& a, const PointShare& b) { for (int j = 0; j < k(); j++) a.c[j] = pt_sub(curve, a.c[j], b.c[j]); }
+    void add_assign_points_public(PointShare& a, const Point& b) {              // rep3.rs:804-818: ID0 -> a, ID1 -> b, ID2 -> nothing
+        if (mode != Mode::Rep3 || party() == 0) a.c[0] = pt_add(curve, a.c[0], b);       // Shamir: every party adds (shamir.rs:733-735)
+        else if (party() == 1) a.c[1] = pt_add(curve, a.c[1], b);
+    }
+    Point open_point(const PointShare& a) {                                      // rep3.rs:849-853
+        if (mode == Mode::Plain) return a.c[0];
+        if (mode == Mode::Shamir) return shamir_open_point(a.c[0]);
+        Bytes mine = pt_to_affine(curve, a.c[1]);
+        net->send_next(mine.data(), mine.size());
+        Bytes prev(mine.size()); net->recv_prev(prev.data(), prev.size());
+        return pt_add(curve, pt_add(curve, a.c[0], a.c[1]), pt_from_affine(curve, a.c[0].group, prev.data()));
+    }
+    std::pair<Point, Point> open_two_points(const PointShare& a, const PointShare& b) {   // rep3.rs:865-877
+        if (mode == Mode::Plain) return {a.c[0], b.c[0]};
+        if (mode == Mode::Shamir) { Point p1 = shamir_open_point(a.c[0]); return {p1, shamir_open_point(b.c[0])}; }   // shamir.rs:808-824 (one message per point here)
+        Bytes m1 = pt_to_affine(curve, a.c[1]), m2 = pt_to_affine(curve, b.c[1]);
+        Bytes msg(m1); msg.insert(msg.end(), m2.begin(), m2.end());
+        net->send_next(msg.data(), msg.size());
+        Bytes prev(msg.size()); net->recv_prev(prev.data(), prev.size());
+        Point r1 = pt_add(curve, pt_from_affine(curve, CG_G1, prev.data()), pt_add(curve, a.c[0], a.c[1]));
+        Point r2 = pt_add(curve, pt_from_affine(curve, CG_G2, prev.data() + m1.size()), pt_add(curve, b.c[0], b.c[1]));
+        return {r1, r2};
+    }
+};
+
+}  // namespace cgh

@@ -1,0 +1,235 @@
+// CoGroth16::prove (co-circom/co-groth16/src/groth16.rs:113-326) over HipDriver, zkey -> device tables, scope guards of the entry points
+#pragma once
+#include "driver.hpp"
+
+namespace cgh {
+
+// ---- prover --------------------------------------------------------------------------------------------------------------
+struct VecGuard {   // device share vector released when the entry point leaves, however it leaves
+    HipDriver& d; ShareVec v;
+    explicit VecGuard(HipDriver& drv) : d(drv) {}
+    VecGuard(HipDriver& drv, ShareVec x) : d(drv), v(x) {}
+    ~VecGuard() { try { d.free_vec(v); } catch (...) {} }
+    VecGuard(const VecGuard&) = delete; VecGuard& operator=(const VecGuard&) = delete;
+};
+struct Proof { Bytes a, b, c; };   // packed affine, (0,0) = infinity  (Groth16Proof, groth16/proof.rs:8-29)
+
+class CoGroth16 {
+public:
+    HipDriver& driver;
+    explicit CoGroth16(HipDriver& d) : driver(d) {}
+
+    // groth16.rs:141-204
+    ShareVec witness_map_from_matrices(const DeviceZKey& dz, const std::vector<Fr>& public_inputs, const ShareVec& private_witness) {
+        const ZKey& z = *dz.z;
+        const size_t num_inputs = z.n_public + 1, num_constraints = z.num_constraints;
+        const Domain dom = groth16_domain(driver.curve, z.pow, num_constraints, num_inputs);          // :150-153
+        HipDriver::Marks mk("witness_map party 0", driver.party() <= 0);
+        ShareVec a = driver.evaluate_constraints(dz.mat[0], dz.pub_dev, (uint32_t)num_inputs, private_witness, dom.m);   // :156-166
+        ShareVec b = driver.evaluate_constraints(dz.mat[1], dz.pub_dev, (uint32_t)num_inputs, private_witness, dom.m);
+        driver.clone_public_into(a, num_constraints, public_inputs, dz.pub_dev);                       // :168-171
+        // The two mul_vec exchanges (:174, :190) run under the transforms that do not depend on them: the local product is started,
+        // the independent NTTs are enqueued, then the party-to-party exchange proceeds while the GPU works (values as in the reference).
+        if (driver.prefetched.empty()) driver.prefetch_masks(2, dom.m);                                // :174 and :190 draw next to each other
+        mk.mark("spmv enqueue");
+        auto c_pending = driver.mul_vec_begin(a, b);                                                   // :174
+        mk.mark("mul_vec_begin");
+        driver.ifft_coset_in_place(a, dom.omega, dom.coset_g);                                         // :175,177-181
+        driver.ifft_coset_in_place(b, dom.omega, dom.coset_g);                                         // :176,182-186
+        driver.fft_in_place(a, dom.omega); driver.fft_in_place(b, dom.omega);                          // :187-188
+        mk.mark("ntt enqueue");
+        ShareVec c = driver.mul_vec_finish(c_pending);
+        mk.mark("mul_vec_finish");
+        auto ab_pending = driver.mul_vec_begin(a, b);                                                  // :190
+        mk.mark("mul_vec_begin");
+        driver.ifft_coset_in_place(c, dom.omega, dom.coset_g);                                         // :194-199
+        driver.fft_in_place(c, dom.omega);                                                             // :200
+        mk.mark("ntt enqueue");
+        ShareVec ab = driver.mul_vec_finish(ab_pending);
+        mk.mark("mul_vec_finish");
+        driver.sub_assign_vec(ab, c);                                                                  // :202
+        driver.free_vec(a); driver.free_vec(b); driver.free_vec(c); driver.free_deferred();
+        mk.mark("free (sync)");
+        return ab;
+    }
+
+    // groth16.rs:206-235
+    // priv_acc = msm_public_points(&query[1 + pub_len..], aux_assignment) (:221), started before the witness map (see prove)
+    PointShare calculate_coeff(PointShare initial, const View& query_host, int group, const Bytes& vk_param,
+                               const std::vector<Fr>& input_assignment, const PointShare& priv_acc) {
+        const Curve& c = driver.curve;
+        const size_t pub_len = input_assignment.size(), rec = c.aff(group);
+        Point pub_acc = pt_inf(c, group);                                                              // :220 (tiny, plain scalars)
+        for (size_t i = 0; i < pub_len; i++) pub_acc = pt_add(c, pub_acc, pt_mul(c, pt_from_affine(c, group, query_host.data() + (1 + i) * rec), input_assignment[i]));
+        PointShare res = initial;
+        driver.add_assign_points_public(res, pt_from_affine(c, group, query_host.data()));             // :227
+        driver.add_assign_points_public(res, pt_from_affine(c, group, vk_param.data()));               // :228
+        driver.add_assign_points_public(res, pub_acc);                                                 // :229
+        driver.add_assign_points(res, priv_acc);                                                       // :230
+        return res;
+    }
+
+    // groth16.rs:113-139 + :237-326
+    Proof prove(const DeviceZKey& dz, const std::vector<Fr>& public_inputs, const ShareVec& private_witness, const FieldShare* rs_plain, ShareVec* h_out = nullptr) {
+        const ZKey& z = *dz.z; const Curve& c = driver.curve;
+        HipDriver::Marks mk("prove party 0", driver.party() <= 0);
+        std::vector<Fr> input_assignment(public_inputs.begin() + 1, public_inputs.end());
+        const size_t first_aux = 1 + input_assignment.size();
+        // l (:251), a (:267 -> :221), b1 (:284), b2 (:298): one call, one scalar schedule, on the second context
+        auto aux_msm = dz.sliced ? driver.msm_begin_sharded(dz, true, private_witness)
+                                 : driver.msm_begin_multi({dz.l, dz.a, dz.b1, dz.b2}, {0, first_aux, first_aux, first_aux}, {CG_G1, CG_G1, CG_G1, CG_G2}, private_witness.n, private_witness, true);
+        mk.mark("aux msm enqueued");
+        // the masks of the witness map's two mul_vec calls (:174, :190) start their way to the device now: behind the witness shares and the
+        // few small synchronous uploads of the MSM set-up (the copy engine serves its requests in order), ahead of everything else
+        driver.prefetch_masks(2, groth16_domain(c, z.pow, z.num_constraints, public_inputs.size()).m);
+        mk.mark("mask uploads enqueued");
+        ShareVec h = witness_map_from_matrices(dz, public_inputs, private_witness);
+        mk.mark("witness map");
+        auto h_msm = dz.sliced ? driver.msm_begin_sharded(dz, false, h) : driver.msm_begin_multi({dz.h}, {0}, {CG_G1}, h.n, h, false);   // :248
+        FieldShare r = rs_plain ? rs_plain[0] : driver.rand();                                         // :134-135
+        FieldShare s = rs_plain ? rs_plain[1] : driver.rand();
+        PointShare h_acc = driver.msm_finish(h_msm, 0);
+        PointShare l_aux_acc = driver.msm_finish(aux_msm, 0);
+        mk.mark("msm h + l");
+        const Point delta_g1 = pt_from_affine(c, CG_G1, z.delta_g1.data());
+        FieldShare rs = driver.mul(r, s);                                                              // :258
+        PointShare r_s_delta_g1 = driver.scalar_mul_public_point(delta_g1, rs);                        // :259
+        PointShare r_g1 = driver.scalar_mul_public_point(delta_g1, r);                                 // :265
+        PointShare g_a = calculate_coeff(r_g1, z.a_query, CG_G1, z.alpha_g1, input_assignment, driver.msm_finish(aux_msm, 1));   // :267
+        Point g_a_opened = driver.open_point(g_a);                                                     // :276
+        PointShare s_g_a = driver.scalar_mul_public_point(g_a_opened, s);                              // :277
+        PointShare s_g1 = driver.scalar_mul_public_point(delta_g1, s);                                 // :283
+        PointShare g1_b = calculate_coeff(s_g1, z.b_g1_query, CG_G1, z.beta_g1, input_assignment, driver.msm_finish(aux_msm, 2));   // :284
+        PointShare r_g1_b = driver.scalar_mul(g1_b, r);                                                // :291
+        const Point delta_g2 = pt_from_affine(c, CG_G2, z.delta_g2.data());
+        PointShare s_g2 = driver.scalar_mul_public_point(delta_g2, s);                                 // :297
+        PointShare g2_b = calculate_coeff(s_g2, z.b_g2_query, CG_G2, z.beta_g2, input_assignment, driver.msm_finish(aux_msm, 3));   // :298
+        PointShare g_c = s_g_a;                                                                        // :308-312
+        driver.add_assign_points(g_c, r_g1_b);
+        driver.sub_assign_points(g_c, r_s_delta_g1);
+        driver.add_assign_points(g_c, l_aux_acc);
+        driver.add_assign_points(g_c, h_acc);
+        mk.mark("msm a, b1, b2 + scalar steps");
+        auto opened = driver.open_two_points(g_c, g2_b);                                               // :316
+        mk.mark("open");
+        driver.msm_release(aux_msm); driver.msm_release(h_msm);
+        if (h_out) *h_out = h; else driver.free_vec(h);
+        return Proof{pt_to_affine(c, g_a_opened), pt_to_affine(c, opened.second), pt_to_affine(c, opened.first)};   // :319-325
+    }
+};
+
+// The reference's parser validates every point while decoding (circom-types/src/traits.rs:107-155: is_on_curve, then
+// is_in_correct_subgroup_assuming_on_curve; failure = SerializationError::InvalidData).  Here the packed sections go to the device
+// as they are and the same two predicates run there, one pass per table.
+static void validate_bases(cg_ctx* ctx, const cg_bases* b, const char* name) {
+    uint64_t bad = 0, first = 0;
+    CG(cg_bases_check_on_curve(ctx, b, &bad, &first));
+    if (bad) throw std::runtime_error(std::string("invalid data: ") + name + "[" + std::to_string(first) + "] is not on the curve (" + std::to_string(bad) + " bad points)");
+    CG(cg_bases_check_subgroup(ctx, b, &bad, &first));
+    if (bad) throw std::runtime_error(std::string("invalid data: ") + name + "[" + std::to_string(first) + "] is not in the correct subgroup (" + std::to_string(bad) + " bad points)");
+}
+
+// The reference validates every zkey point while parsing (traits.rs:116-123, 147-153), so the prove entry points and
+// cgh_session_open do too, by default.  Opt-out for callers that validated the file before (cgh_zkey_validate): the environment
+// variable CGH_SKIP_ZKEY_VALIDATION or cgh_set_zkey_validation(0).
+inline std::atomic<int> g_validate_zkey{-1};
+static bool validate_by_default() {
+    int v = g_validate_zkey.load();
+    if (v < 0) { v = getenv("CGH_SKIP_ZKEY_VALIDATION") ? 0 : 1; g_validate_zkey.store(v); }
+    return v != 0;
+}
+struct DeviceZKeyGuard;
+static void release_zkey(cg_ctx* ctx, DeviceZKey& d);
+// slice `rank` of `world` of a range of n items (sizes differ by at most one)
+static std::pair<size_t, size_t> slice_of(size_t n, int rank, int world) {
+    const size_t base = n / world, rem = n % world, lo = (size_t)rank * base + std::min<size_t>((size_t)rank, rem);
+    return {lo, lo + base + ((size_t)rank < rem ? 1 : 0)};
+}
+// rank/world: this device's share of a party's GPUs (world == 1: the whole zkey).  Rank 0 also holds the constraint matrices (the
+// witness map runs there); every rank holds slice `rank` of the five queries.
+static DeviceZKey upload_zkey(cg_ctx* ctx, const ZKey& z, const std::vector<Fr>& public_inputs, int validate_flag = -1, int rank = 0, int world = 1) {
+    const bool validate = validate_flag < 0 ? validate_by_default() : validate_flag != 0;
+    DeviceZKey d; d.z = &z; d.owner = ctx;
+    struct Undo { cg_ctx* c; DeviceZKey* d; bool armed = true; ~Undo() { if (armed) release_zkey(c, *d); } } undo{ctx, &d};   // a failing table must not leak the ones before it
+    const Curve& c = z.curve;
+    auto reg = [&](const auto& pts, int group, const char* name = "") {
+        cg_bases* b; CG(cg_bases_register(ctx, c.id, group, pts.data(), pts.size() / c.aff(group), c.aff(group), -1, &b));
+        if (validate) { try { validate_bases(ctx, b, name); } catch (...) { cg_bases_release(b); throw; } }
+        return b;
+    };
+    if (validate && rank == 0) {   // the O(1) verifying-key points and IC go through the same kernels
+        Bytes g1 = z.alpha_g1; g1.insert(g1.end(), z.beta_g1.begin(), z.beta_g1.end()); g1.insert(g1.end(), z.delta_g1.begin(), z.delta_g1.end()); g1.insert(g1.end(), z.ic.begin(), z.ic.end());
+        Bytes g2 = z.beta_g2; g2.insert(g2.end(), z.gamma_g2.begin(), z.gamma_g2.end()); g2.insert(g2.end(), z.delta_g2.begin(), z.delta_g2.end());
+        cg_bases_release(reg(g1, CG_G1, "vk_g1/ic")); cg_bases_release(reg(g2, CG_G2, "vk_g2"));
+    }
+    auto up = [&](const void* src, size_t bytes) { void* p; CG(cg_dev_alloc(ctx, bytes, &p)); if (bytes) CG(cg_dev_upload(ctx, p, src, bytes)); return p; };
+    if (world > 1) {
+        const size_t first_aux = z.n_public + 1, n_aux = z.n_vars - first_aux;
+        const auto ar = slice_of(n_aux, rank, world), hr = slice_of(z.domain_size, rank, world);
+        d.sliced = true; d.aux_lo = ar.first; d.aux_n = ar.second - ar.first; d.h_lo = hr.first; d.h_n = hr.second - hr.first;
+        auto cut = [&](const View& v, int group, size_t first, size_t count) { return View{v.data() + first * c.aff(group), count * c.aff(group)}; };
+        if (validate && rank == 0) {   // the public-input records of a, b1, b2 stay on the host (calculate_coeff): checked here once
+            cg_bases_release(reg(cut(z.a_query, CG_G1, 0, first_aux), CG_G1, "a_query")); cg_bases_release(reg(cut(z.b_g1_query, CG_G1, 0, first_aux), CG_G1, "b_g1_query"));
+            cg_bases_release(reg(cut(z.b_g2_query, CG_G2, 0, first_aux), CG_G2, "b_g2_query"));
+        }
+        d.a = reg(cut(z.a_query, CG_G1, first_aux + d.aux_lo, d.aux_n), CG_G1, "a_query"); d.b1 = reg(cut(z.b_g1_query, CG_G1, first_aux + d.aux_lo, d.aux_n), CG_G1, "b_g1_query");
+        d.b2 = reg(cut(z.b_g2_query, CG_G2, first_aux + d.aux_lo, d.aux_n), CG_G2, "b_g2_query");
+        d.l = reg(cut(z.l_query, CG_G1, d.aux_lo, d.aux_n), CG_G1, "l_query"); d.h = reg(cut(z.h_query, CG_G1, d.h_lo, d.h_n), CG_G1, "h_query");
+        if (rank != 0) { undo.armed = false; return d; }
+    } else {
+        d.a = reg(z.a_query, CG_G1, "a_query"); d.b1 = reg(z.b_g1_query, CG_G1, "b_g1_query"); d.b2 = reg(z.b_g2_query, CG_G2, "b_g2_query");
+        d.l = reg(z.l_query, CG_G1, "l_query"); d.h = reg(z.h_query, CG_G1, "h_query");
+    }
+    for (int m = 0; m < 2; m++) {
+        d.mat[m].row_ptr = (uint32_t*)up(z.row_ptr[m].data(), z.row_ptr[m].size() * 4);
+        d.mat[m].col = (uint32_t*)up(z.col[m].data(), z.col[m].size() * 4);
+        d.mat[m].coeff = up(z.coeff[m].data(), z.coeff[m].size() * 32);
+        d.mat[m].rows = z.num_constraints;
+    }
+    d.pub_dev = up(public_inputs.data(), public_inputs.size() * 32);
+    undo.armed = false;
+    return d;
+}
+static void release_zkey(cg_ctx* ctx, DeviceZKey& d) {
+    for (cg_bases** b : {&d.a, &d.b1, &d.b2, &d.l, &d.h}) { if (*b) cg_bases_release(*b); *b = nullptr; }
+    for (int m = 0; m < 2; m++) {
+        if (d.mat[m].row_ptr) cg_dev_free(ctx, d.mat[m].row_ptr); if (d.mat[m].col) cg_dev_free(ctx, d.mat[m].col); if (d.mat[m].coeff) cg_dev_free(ctx, d.mat[m].coeff);
+        d.mat[m] = DeviceMatrix{nullptr, nullptr, nullptr, 0};
+    }
+    if (d.pub_dev) cg_dev_free(ctx, d.pub_dev);
+    d.pub_dev = nullptr;
+}
+// scope guards of the C entry points: whatever a failing proof leaves behind on the device is released (a long-lived prover that
+// hits "randomness stream exhausted" a few times must not run out of HBM)
+struct DeviceZKeyGuard {
+    cg_ctx* ctx; DeviceZKey dz; bool live = true;
+    DeviceZKeyGuard(cg_ctx* c, DeviceZKey d) : ctx(c), dz(d) {}
+    ~DeviceZKeyGuard() { if (live) release_zkey(ctx, dz); }
+    DeviceZKeyGuard(const DeviceZKeyGuard&) = delete; DeviceZKeyGuard& operator=(const DeviceZKeyGuard&) = delete;
+};
+struct CtxGuard {
+    cg_ctx* ctx = nullptr;
+    ~CtxGuard() { if (ctx) cg_ctx_destroy(ctx); }
+    cg_ctx* release() { cg_ctx* c = ctx; ctx = nullptr; return c; }
+};
+struct DevBufGuard { cg_ctx* ctx; void* p; ~DevBufGuard() { if (p) cg_dev_free(ctx, p); } };
+
+// Second contexts for the witness-independent MSMs (HipDriver::aux).  Creating a context costs 15-25 ms (its streams), so they are
+// made on a helper thread while the zkey is read and uploaded, and only for zkeys large enough (>= ~2^19 constraints) to gain.
+struct SecondContexts {
+    std::vector<cg_ctx*> made; std::thread worker;
+    SecondContexts(int device, const char* zkey_path, int count) : made(count, nullptr) {
+        struct stat st{};
+        if (getenv("CGH_ONE_CONTEXT") || stat(zkey_path, &st) != 0 || st.st_size < (off_t)200 << 20) return;
+        worker = std::thread([this, device] { for (auto& c : made) if (cg_ctx_create(device, &c) != 0) c = nullptr; });
+    }
+    void ready() { if (worker.joinable()) worker.join(); }
+    cg_ctx* take(int i) { ready(); cg_ctx* c = made[i]; made[i] = nullptr; return c; }
+    ~SecondContexts() { ready(); for (cg_ctx* c : made) if (c) cg_ctx_destroy(c); }
+};
+
+static void store_proof(const Proof& p, uint8_t* out) { memcpy(out, p.a.data(), p.a.size()); memcpy(out + p.a.size(), p.b.data(), p.b.size()); memcpy(out + p.a.size() + p.b.size(), p.c.data(), p.c.size()); }
+
+static bool all_zero_bytes(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i]) return false; return true; }
+
+}  // namespace cgh

@@ -1,0 +1,141 @@
+// party-to-party channels of the drivers: Rep3Network (mpc-core/src/protocols/rep3/network.rs:13-64) and the Shamir any-to-any net (shamir/network.rs:17-59); in-process, recording / replaying and C-callback transports
+#pragma once
+#include "base.hpp"
+
+namespace cgh {
+
+// ---- network -----------------------------------------------------------------------------------------------------------
+struct Rep3Network {   // rep3/network.rs:30-64
+    virtual ~Rep3Network() {}
+    virtual int id() const = 0;
+    virtual void send_next(const void* data, size_t bytes) = 0;
+    virtual void recv_prev(void* data, size_t bytes) = 0;
+    virtual void send_prev(const void* data, size_t bytes) = 0;   // network.send(id.prev_id(), ..) (rep3.rs:746-753)
+    virtual void recv_next(void* data, size_t bytes) = 0;
+    // Optional zero-copy receive: the next message from the previous party, already in page-locked memory that stays valid until the
+    // network object goes away (a transport that receives into registered buffers); nullptr = not available, use recv_prev.
+    virtual const void* recv_prev_pinned(size_t bytes) { (void)bytes; return nullptr; }
+};
+struct InProcHub {
+    std::mutex mu; std::condition_variable cv;
+    std::deque<Bytes> q[3];    // q[i] = messages travelling from party i to party i+1
+    std::deque<Bytes> qb[3];   // qb[i] = messages travelling from party i to party i-1
+    bool failed = false;       // a party died: wake everybody up instead of waiting for messages that will never come
+    void abort() { { std::lock_guard<std::mutex> l(mu); failed = true; } cv.notify_all(); }
+};
+struct InProcNetwork : Rep3Network {
+    InProcHub* hub; int me;
+    InProcNetwork(InProcHub* h, int i) : hub(h), me(i) {}
+    int id() const override { return me; }
+    void send_next(const void* data, size_t bytes) override {
+        { std::lock_guard<std::mutex> l(hub->mu); hub->q[me].emplace_back((const uint8_t*)data, (const uint8_t*)data + bytes); }
+        hub->cv.notify_all();
+    }
+    void recv_prev(void* data, size_t bytes) override {
+        const int from = (me + 2) % 3;
+        std::unique_lock<std::mutex> l(hub->mu);
+        hub->cv.wait(l, [&] { return !hub->q[from].empty() || hub->failed; });
+        if (hub->q[from].empty()) throw std::runtime_error("another party failed");
+        Bytes m = std::move(hub->q[from].front()); hub->q[from].pop_front();
+        if (m.size() != bytes) throw std::runtime_error("During execution of MPC: invalid number of bytes received");   // rep3.rs:663-668
+        memcpy(data, m.data(), bytes);
+    }
+    void send_prev(const void* data, size_t bytes) override {
+        { std::lock_guard<std::mutex> l(hub->mu); hub->qb[me].emplace_back((const uint8_t*)data, (const uint8_t*)data + bytes); }
+        hub->cv.notify_all();
+    }
+    void recv_next(void* data, size_t bytes) override {
+        const int from = (me + 1) % 3;
+        std::unique_lock<std::mutex> l(hub->mu);
+        hub->cv.wait(l, [&] { return !hub->qb[from].empty() || hub->failed; });
+        if (hub->qb[from].empty()) throw std::runtime_error("another party failed");
+        Bytes m = std::move(hub->qb[from].front()); hub->qb[from].pop_front();
+        if (m.size() != bytes) throw std::runtime_error("During execution of MPC: invalid number of bytes received");
+        memcpy(data, m.data(), bytes);
+    }
+};
+
+// A party's incoming traffic recorded during a three-party run and replayed to the same party running alone: its messages depend
+// only on the inputs and the randomness streams, so the solo run repeats the recorded one bit for bit.  Used to time ONE party with
+// the GPU to itself, as in a deployment (each party on its own machine), without a second and third GPU.
+// Large messages (the 4 MiB chunks of a mul_vec exchange) are recorded into page-locked memory, so that the replay can hand them to the
+// driver where they lie (recv_prev_pinned) — a peer whose data is already in registered buffers, i.e. the network itself is excluded
+// from the solo timing, as SURVEY §8d asks; small messages are copied as before.
+struct RecordedMsg { Bytes small; void* pinned = nullptr; size_t n = 0; };
+struct RecordedQueue {
+    std::deque<RecordedMsg> q; std::vector<void*> owned;
+    ~RecordedQueue() { for (void* p : owned) cg_host_free(p); }
+    void add(const void* d, size_t b) {
+        RecordedMsg m; m.n = b;
+        if (b >= ((size_t)1 << 20) && cg_host_alloc(b, &m.pinned) == 0) { memcpy(m.pinned, d, b); owned.push_back(m.pinned); }
+        else { m.pinned = nullptr; m.small.assign((const uint8_t*)d, (const uint8_t*)d + b); }
+        q.push_back(std::move(m));
+    }
+};
+struct RecordingNetwork : Rep3Network {
+    Rep3Network* inner; RecordedQueue* from_prev; RecordedQueue* from_next;
+    RecordingNetwork(Rep3Network* n, RecordedQueue* p, RecordedQueue* q) : inner(n), from_prev(p), from_next(q) {}
+    int id() const override { return inner->id(); }
+    void send_next(const void* d, size_t b) override { inner->send_next(d, b); }
+    void send_prev(const void* d, size_t b) override { inner->send_prev(d, b); }
+    void recv_prev(void* d, size_t b) override { inner->recv_prev(d, b); from_prev->add(d, b); }
+    void recv_next(void* d, size_t b) override { inner->recv_next(d, b); from_next->add(d, b); }
+};
+struct ReplayNetwork : Rep3Network {
+    int me; RecordedQueue* from_prev; RecordedQueue* from_next;
+    ReplayNetwork(int i, RecordedQueue* p, RecordedQueue* q) : me(i), from_prev(p), from_next(q) {}
+    int id() const override { return me; }
+    void send_next(const void*, size_t) override {}
+    void send_prev(const void*, size_t) override {}
+    static void pop(RecordedQueue* q, void* d, size_t b) {
+        if (q->q.empty() || q->q.front().n != b) throw std::runtime_error("replay: message sequence differs from the recorded run");
+        const RecordedMsg& m = q->q.front();
+        memcpy(d, m.pinned ? m.pinned : (const void*)m.small.data(), b); q->q.pop_front();
+    }
+    void recv_prev(void* d, size_t b) override { pop(from_prev, d, b); }
+    void recv_next(void* d, size_t b) override { pop(from_next, d, b); }
+    const void* recv_prev_pinned(size_t b) override {
+        if (from_prev->q.empty() || from_prev->q.front().n != b) throw std::runtime_error("replay: message sequence differs from the recorded run");
+        const void* p = from_prev->q.front().pinned;
+        if (p) from_prev->q.pop_front();                 // the memory itself stays with the queue's owner list
+        return p;
+    }
+};
+
+// Shamir: any-to-any channels (shamir/network.rs:17-59)
+struct ShamirNet {
+    virtual ~ShamirNet() {}
+    virtual int id() const = 0;
+    virtual int num_parties() const = 0;
+    virtual void send(int to, const void* data, size_t bytes) = 0;
+    virtual void recv(int from, void* data, size_t bytes) = 0;
+};
+struct InProcShamirHub {
+    int n;
+    std::mutex mu; std::condition_variable cv;
+    std::vector<std::deque<Bytes>> q;   // q[from * n + to]
+    bool failed = false;
+    explicit InProcShamirHub(int n_) : n(n_), q((size_t)n_ * n_) {}
+    void abort() { { std::lock_guard<std::mutex> l(mu); failed = true; } cv.notify_all(); }
+};
+struct InProcShamirNet : ShamirNet {
+    InProcShamirHub* hub; int me;
+    InProcShamirNet(InProcShamirHub* h, int i) : hub(h), me(i) {}
+    int id() const override { return me; }
+    int num_parties() const override { return hub->n; }
+    void send(int to, const void* data, size_t bytes) override {
+        { std::lock_guard<std::mutex> l(hub->mu); hub->q[(size_t)me * hub->n + to].emplace_back((const uint8_t*)data, (const uint8_t*)data + bytes); }
+        hub->cv.notify_all();
+    }
+    void recv(int from, void* data, size_t bytes) override {
+        std::unique_lock<std::mutex> l(hub->mu);
+        auto& qq = hub->q[(size_t)from * hub->n + me];
+        hub->cv.wait(l, [&] { return !qq.empty() || hub->failed; });
+        if (qq.empty()) throw std::runtime_error("another party failed");
+        Bytes m = std::move(qq.front()); qq.pop_front();
+        if (m.size() != bytes) throw std::runtime_error("During execution of MPC: Invalid number of elements received");   // shamir.rs:324-329
+        memcpy(data, m.data(), bytes);
+    }
+};
+
+}  // namespace cgh

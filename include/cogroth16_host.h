@@ -1,7 +1,7 @@
 /* cogroth16_host.h — C ABI of the host mirror (libcogroth16_host.so): the co-circom prover entry points on top of cogroth16_hip.h.
  *
  * The reference is Rust and cannot be built in this image (no cargo), so the host side above the kernel ABI is C++
- * (collaborative-circom_amd/host/cogroth16_host.cpp): drivers PlainHipDriver / Rep3HipProtocol / ShamirHipProtocol with the method names of
+ * (collaborative-circom_amd/host/ (headers per layer: formats, network, driver, groth16, plonk, codecs, synth; entry points in capi_*.cpp)): drivers PlainHipDriver / Rep3HipProtocol / ShamirHipProtocol with the method names of
  * the reference's traits (mpc-core/src/traits.rs:43-223, 535-568), CoGroth16::prove (co-groth16/src/groth16.rs:113-326) and CoPlonk
  * rounds 1-5 (co-plonk/src/round{1..5}.rs) with the reference's call sequence, in-process REP3 / Shamir networks in the role of
  * tests/src/rep3_network.rs, and the readers / writers of the file formats (circom-types).  These entry points are what the CLI's

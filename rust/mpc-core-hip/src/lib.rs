@@ -13,7 +13,7 @@
 //! ```
 //!
 //! SOURCE ONLY here: the image this repository is built in has no Rust toolchain.  The C++ host mirror
-//! (`collaborative-circom_amd/host/cogroth16_host.cpp`) runs the same call sequence against the same library and is what the tests
+//! (`collaborative-circom_amd/host/ (headers per layer: formats, network, driver, groth16, plonk, codecs, synth; entry points in capi_*.cpp)`) runs the same call sequence against the same library and is what the tests
 //! exercise; `include/cogroth16_host.h` is its ABI.
 pub mod ffi;
 pub mod gpu;

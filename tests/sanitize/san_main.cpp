@@ -1,5 +1,5 @@
 // Sanitizer run (AddressSanitizer + UndefinedBehaviorSanitizer) of the two pieces of host C++ that parse untrusted files and juggle raw
-// buffers: the CPU oracle (oracle/oracle_capi.cpp, test infrastructure) and the host mirror (collaborative-circom_amd/host/cogroth16_host.cpp).
+// buffers: the CPU oracle (oracle/oracle_capi.cpp, test infrastructure) and the host mirror (collaborative-circom_amd/host/*.hpp and capi_*.cpp).
 // Both are compiled INTO this binary with -fsanitize=address,undefined (tests/sanitize/Makefile); no GPU is touched: the host
 // mirror's readers, JSON codecs and the secret-shared witness container run on the CPU, everything else is the oracle.
 //   usage: san_main <golden dir> <scratch dir>
