@@ -415,6 +415,12 @@ def point_scalar_mul(curve, group, a, k):
     return out
 
 
+def point_generator(curve, group):
+    out = np.zeros(point_words(curve, group, 3), dtype=np.uint64)
+    _chk(load().cg_point_generator(curve, group, _hp(out)))
+    return out
+
+
 def point_to_affine(curve, group, a):
     out = np.zeros(point_words(curve, group, 2), dtype=np.uint64)
     _chk(load().cg_point_to_affine(curve, group, _hp(np.ascontiguousarray(a)), _hp(out)))
@@ -549,6 +555,67 @@ class ProvingSession:
         _hchk(load_host().cgh_session_prove_rep3(self.h, _hp(np.ascontiguousarray(pub, dtype=np.uint64)), arr(keep[0]), arr(keep[1]), arr(keep[2]),
                                                  C.c_size_t(keep[2][0].shape[0]), _hp(out), sec if solo else None))
         return out, sec[0], sec[1]
+
+
+# ---- one REP3 party with the caller's network and randomness (cgh_session_prove_rep3_party) ------------------------------------
+_SEND = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t)
+_RECV = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t)
+_RECV_PINNED = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class Rep3NetTable(C.Structure):
+    """cgh_rep3_net (include/cogroth16_host.h): the party's channels to its two peers"""
+    _fields_ = [("user", C.c_void_p), ("party_id", C.c_int32), ("send_next", _SEND), ("recv_prev", _RECV), ("send_prev", _SEND), ("recv_next", _RECV),
+                ("recv_prev_pinned", _RECV_PINNED)]
+
+
+_MASKS = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p))
+_FES = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
+_EC = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p)
+
+
+class Rep3RandTable(C.Structure):
+    """cgh_rep3_rand: the party's correlated randomness (Rep3Rand, rep3/rngs.rs:25-62)"""
+    _fields_ = [("user", C.c_void_p), ("masking_field_elements", _MASKS), ("random_fes", _FES), ("masking_ec_element", _EC)]
+
+
+class LoopbackHub:
+    """three parties of one process joined by in-memory queues (cgh_loopback_*); net(i) is party i's callback table"""
+
+    def __init__(self):
+        self.h = C.c_void_p(); _hchk(load_host().cgh_loopback_create(C.byref(self.h)))
+
+    def net(self, party, record=False):
+        t = Rep3NetTable(); _hchk(load_host().cgh_loopback_net(self.h, int(party), int(bool(record)), C.byref(t))); return t
+
+    def replay_net(self, party):
+        t = Rep3NetTable(); _hchk(load_host().cgh_loopback_replay_net(self.h, int(party), C.byref(t))); return t
+
+    def abort(self): load_host().cgh_loopback_abort(self.h)
+
+    def close(self):
+        if self.h: load_host().cgh_loopback_destroy(self.h); self.h = None
+
+
+class StreamRand:
+    """Rep3Rand over two pre-generated streams of field elements (cgh_stream_rand_create); .table is the callback table"""
+
+    def __init__(self, curve, rng1, rng2):
+        self.keep = (np.ascontiguousarray(rng1, dtype=np.uint64), np.ascontiguousarray(rng2, dtype=np.uint64))
+        self.h = C.c_void_p(); self.table = Rep3RandTable()
+        _hchk(load_host().cgh_stream_rand_create(curve, _hp(self.keep[0]), _hp(self.keep[1]), C.c_size_t(self.keep[0].shape[0]), C.byref(self.h), C.byref(self.table)))
+
+    def close(self):
+        if self.h: load_host().cgh_stream_rand_destroy(self.h); self.h = None
+
+
+def host_prove_rep3_party(session, pub, wit_a, wit_b, net_table, rand_table):
+    """ONE REP3 party on an open ProvingSession through the callback ABI; returns (proof, seconds).  Call it from one thread per party."""
+    nq = 6 if session.curve == BLS12_381 else 4
+    out = np.zeros(8 * nq, dtype=np.uint64); sec = (C.c_double * 1)()
+    keep = [np.ascontiguousarray(x, dtype=np.uint64) for x in (pub, wit_a, wit_b)]
+    _hchk(load_host().cgh_session_prove_rep3_party(session.h, _hp(keep[0]), _hp(keep[1]), _hp(keep[2]), C.byref(net_table), C.byref(rand_table), _hp(out), sec))
+    return out, sec[0]
 
 
 def host_plonk_zkey_info(curve, path):

@@ -76,4 +76,14 @@ static Bytes pt_to_affine(const Curve& c, const Point& a) { Bytes r(c.aff(a.grou
 static Point pt_generator(const Curve& c, int g) { Point p{Bytes(c.jac(g)), g}; CG(cg_point_generator(c.id, g, p.b.data())); return p; }
 
 
+// fn(lo, hi) over slices of [0, n) on a few threads; the first exception of a slice is re-thrown
+static void parallel_for(size_t n, const std::function<void(size_t, size_t)>& fn) {
+    const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::thread::hardware_concurrency(), n / 4096 + 1}));
+    if (T == 1) { fn(0, n); return; }
+    std::vector<std::thread> th; std::vector<std::string> err(T);
+    for (size_t t = 0; t < T; t++) th.emplace_back([&, t] { try { fn(n * t / T, n * (t + 1) / T); } catch (const std::exception& e) { err[t] = e.what(); } });
+    for (auto& x : th) x.join();
+    for (auto& e : err) if (!e.empty()) throw std::runtime_error(e);
+}
+
 }  // namespace cgh

@@ -125,57 +125,186 @@ int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uin
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
-// three REP3 parties on an open session (threads, in-process network).  seconds (optional, 2 values): [0] = wall time of the three
-// co-located parties; [1] = party 0 ALONE on the GPU, replaying the messages it received in the first run (its proof must repeat).
-int32_t cgh_session_prove_rep3(void* h, const uint64_t* pub_in, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
-                               const uint64_t* const* streams, size_t stream_len, uint64_t* out_proofs, double* seconds) {
+// ---- ONE REP3 party with the caller's network and randomness (include/cogroth16_host.h; co-circom.rs:484-506) ----------------------------
+int32_t cgh_session_prove_rep3_party(void* h, const uint64_t* pub_in, const uint64_t* wit_a, const uint64_t* wit_b,
+                                     const cgh_rep3_net* net_cb, const cgh_rep3_rand* rnd_cb, uint64_t* out_proof, double* seconds) {
     cgh_session* s = (cgh_session*)h;
     try {
         using namespace cgh;
+        if (!s || !pub_in || !wit_a || !wit_b || !net_cb || !rnd_cb || !out_proof) throw std::runtime_error("cgh_session_prove_rep3_party: null argument");
         const ZKey& z = s->z;
-        const size_t n_aux = z.n_vars - z.n_public - 1, psz = 8 * z.curve.fq();
+        const size_t n_aux = z.n_vars - z.n_public - 1;
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
-        RecordedQueue rec_prev, rec_next;
-        auto party = [&](int i, Rep3Network* net, uint8_t* out) {
-            static const bool no_prio = getenv("CGH_NO_CHAIN_PRIORITY") != nullptr;      // tuning knob
-            Borrowed ctx(s, true, 0, s->second_context && !no_prio), second(s, s->second_context);
-            ProofWorkers workers(s);
-            ProofZKey pz(s, ctx.c, pub);
-            {
-                HipDriver driver(ctx.c, z.curve, Mode::Rep3, net);
-                driver.aux = second.c; driver.owns_aux = false; driver.md = workers.get();
-                driver.rng1 = (const Fr*)streams[i]; driver.rng2 = (const Fr*)streams[(i + 2) % 3]; driver.rng_len = stream_len;
-                VecGuard wit(driver, driver.upload_vec((const Fr*)wit_a[i], (const Fr*)wit_b[i], n_aux));
-                CoGroth16 prover(driver);
-                Proof p = prover.prove(pz.dz, pub, wit.v, nullptr, nullptr);
-                store_proof(p, out);
+        CallbackNetwork net(*net_cb);
+        CallbackRand rnd(*rnd_cb);
+        static const bool no_prio = getenv("CGH_NO_CHAIN_PRIORITY") != nullptr;          // tuning knob
+        Borrowed ctx(s, true, 0, s->second_context && !no_prio), second(s, s->second_context);
+        ProofWorkers workers(s);
+        ProofZKey pz(s, ctx.c, pub);
+        const auto t0 = std::chrono::steady_clock::now();
+        {
+            HipDriver driver(ctx.c, z.curve, Mode::Rep3, &net);
+            driver.aux = second.c; driver.owns_aux = false; driver.md = workers.get();
+            driver.rsrc = &rnd;
+            VecGuard wit(driver, driver.upload_vec((const Fr*)wit_a, (const Fr*)wit_b, n_aux));
+            CoGroth16 prover(driver);
+            Proof p = prover.prove(pz.dz, pub, wit.v, nullptr, nullptr);                 // groth16.rs:113-139
+            if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            store_proof(p, (uint8_t*)out_proof);
+        }
+        ctx.ok = second.ok = true; workers.ok();
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+
+// ---- in-process transport behind the callback table (tests / bench / three parties on one box) ------------------------------------------
+namespace {
+struct Loopback {
+    cgh::InProcHub hub;
+    cgh::RecordedQueue rec[3][2];                                     // [party][0 = from prev, 1 = from next]
+    std::vector<std::unique_ptr<cgh::Rep3Network>> nets;              // what the callback tables point at
+    std::mutex mu;
+};
+#define NET_CALL(stmt) try { stmt; return 0; } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+int32_t lb_send_next(void* u, const void* d, size_t b) { NET_CALL(((cgh::Rep3Network*)u)->send_next(d, b)) }
+int32_t lb_recv_prev(void* u, void* d, size_t b) { NET_CALL(((cgh::Rep3Network*)u)->recv_prev(d, b)) }
+int32_t lb_send_prev(void* u, const void* d, size_t b) { NET_CALL(((cgh::Rep3Network*)u)->send_prev(d, b)) }
+int32_t lb_recv_next(void* u, void* d, size_t b) { NET_CALL(((cgh::Rep3Network*)u)->recv_next(d, b)) }
+#undef NET_CALL
+const void* lb_recv_prev_pinned(void* u, size_t b) { try { return ((cgh::Rep3Network*)u)->recv_prev_pinned(b); } catch (const std::exception& e) { g_host_err = e.what(); return nullptr; } }
+void fill_table(cgh_rep3_net* out, cgh::Rep3Network* n, bool pinned) {
+    out->user = n; out->party_id = n->id();
+    out->send_next = lb_send_next; out->recv_prev = lb_recv_prev; out->send_prev = lb_send_prev; out->recv_next = lb_recv_next;
+    out->recv_prev_pinned = pinned ? lb_recv_prev_pinned : nullptr;
+}
+// owns an inner network next to the recorder that wraps it
+struct OwningRecorder : cgh::RecordingNetwork {
+    std::unique_ptr<cgh::Rep3Network> held;
+    OwningRecorder(std::unique_ptr<cgh::Rep3Network> in, cgh::RecordedQueue* p, cgh::RecordedQueue* q) : cgh::RecordingNetwork(in.get(), p, q), held(std::move(in)) {}
+};
+}
+int32_t cgh_loopback_create(void** out) { try { *out = new Loopback(); return 0; } catch (const std::exception& e) { g_host_err = e.what(); return 1; } }
+int32_t cgh_loopback_net(void* hub, int32_t party, int32_t record, cgh_rep3_net* out) {
+    Loopback* lb = (Loopback*)hub;
+    try {
+        if (!lb || !out || party < 0 || party > 2) throw std::runtime_error("cgh_loopback_net: bad argument");
+        std::unique_ptr<cgh::Rep3Network> n(new cgh::InProcNetwork(&lb->hub, party));
+        if (record) n.reset(new OwningRecorder(std::move(n), &lb->rec[party][0], &lb->rec[party][1]));
+        std::lock_guard<std::mutex> l(lb->mu);
+        fill_table(out, n.get(), false);
+        lb->nets.push_back(std::move(n));
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+int32_t cgh_loopback_replay_net(void* hub, int32_t party, cgh_rep3_net* out) {
+    Loopback* lb = (Loopback*)hub;
+    try {
+        if (!lb || !out || party < 0 || party > 2) throw std::runtime_error("cgh_loopback_replay_net: bad argument");
+        std::unique_ptr<cgh::Rep3Network> n(new cgh::ReplayNetwork(party, &lb->rec[party][0], &lb->rec[party][1]));
+        std::lock_guard<std::mutex> l(lb->mu);
+        fill_table(out, n.get(), true);
+        lb->nets.push_back(std::move(n));
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+/* a party died: wake the others out of their receives (they fail with "another party failed") */
+int32_t cgh_loopback_abort(void* hub) { if (hub) ((Loopback*)hub)->hub.abort(); return 0; }
+int32_t cgh_loopback_destroy(void* hub) { delete (Loopback*)hub; return 0; }
+
+// ---- Rep3Rand over two pre-generated streams (rngs.rs:25-62 with the ChaCha draws done by the caller) -------------------------------------
+namespace {
+struct StreamRand {
+    cgh::Curve curve; const cgh::Fr* rng1; const cgh::Fr* rng2; size_t len, cursor = 0;
+    cgh::Fr* diff = nullptr; bool pinned = false;                      // rng1[k] - rng2[k]; page-locked when a device is present
+    ~StreamRand() { if (diff) { if (pinned) cg_host_free(diff); else free(diff); } }
+};
+int32_t sr_masks(void* u, size_t n, uint64_t*, const uint64_t** out) {
+    StreamRand* r = (StreamRand*)u;
+    if (r->cursor + n > r->len) { g_host_err = "randomness stream exhausted"; return 1; }
+    *out = r->diff[r->cursor].v; r->cursor += n;
+    return 0;
+}
+int32_t sr_random_fes(void* u, uint64_t* a, uint64_t* b) {
+    StreamRand* r = (StreamRand*)u;
+    if (r->cursor >= r->len) { g_host_err = "randomness stream exhausted"; return 1; }
+    memcpy(a, r->rng1[r->cursor].v, 32); memcpy(b, r->rng2[r->cursor].v, 32); r->cursor++;
+    return 0;
+}
+int32_t sr_masking_ec(void* u, int32_t group, uint64_t* out) {
+    StreamRand* r = (StreamRand*)u;
+    try {
+        using namespace cgh;
+        if (r->cursor >= r->len) throw std::runtime_error("randomness stream exhausted");
+        const Point gen = pt_generator(r->curve, group);
+        const Point m = pt_sub(r->curve, pt_mul(r->curve, gen, r->rng1[r->cursor]), pt_mul(r->curve, gen, r->rng2[r->cursor])); r->cursor++;
+        memcpy(out, m.b.data(), m.b.size());
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+}
+int32_t cgh_stream_rand_create(int32_t curve, const uint64_t* rng1, const uint64_t* rng2, size_t len, void** out_handle, cgh_rep3_rand* out) {
+    StreamRand* r = nullptr;
+    try {
+        using namespace cgh;
+        if (!rng1 || !rng2 || !out_handle || !out || (curve != CG_BN254 && curve != CG_BLS12_381)) throw std::runtime_error("cgh_stream_rand_create: bad argument");
+        r = new StreamRand{Curve{curve}, (const Fr*)rng1, (const Fr*)rng2, len};
+        void* p = nullptr;
+        if (cg_host_alloc(std::max<size_t>(len, 1) * 32, &p) == 0) r->pinned = true;   // a source made where no device is visible (host-only tooling) keeps pageable memory
+        else if (!(p = malloc(std::max<size_t>(len, 1) * 32))) throw std::runtime_error("cgh_stream_rand_create: out of memory");
+        r->diff = (Fr*)p;
+        const uint64_t* mod = MOD_R[curve];
+        parallel_for(len, [&](size_t lo, size_t hi) {                 // a - b mod r on 4 x 64-bit limbs (Montgomery form subtracts like the canonical one)
+            for (size_t i = lo; i < hi; i++) {
+                const uint64_t* a = r->rng1[i].v; const uint64_t* b = r->rng2[i].v; uint64_t* d = r->diff[i].v;
+                unsigned __int128 br = 0;
+                for (int k = 0; k < 4; k++) { const unsigned __int128 t = (unsigned __int128)a[k] - b[k] - (uint64_t)br; d[k] = (uint64_t)t; br = (t >> 64) & 1; }
+                if (br) { unsigned __int128 c = 0; for (int k = 0; k < 4; k++) { c += (unsigned __int128)d[k] + mod[k]; d[k] = (uint64_t)c; c >>= 64; } }
             }
-            ctx.ok = second.ok = true; workers.ok();
-        };
-        InProcHub hub;
+        });
+        out->user = r; out->masking_field_elements = sr_masks; out->random_fes = sr_random_fes; out->masking_ec_element = sr_masking_ec;
+        *out_handle = r;
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); delete r; return 1; }
+}
+int32_t cgh_stream_rand_destroy(void* handle) { delete (StreamRand*)handle; return 0; }
+
+// three REP3 parties on an open session: three threads, each calling the one-party entry above with a loopback transport and a stream
+// randomness source (party i: rng1 = S_i, rng2 = S_(i-1)).  seconds (optional, 2 values): [0] = wall time of the three co-located
+// parties; [1] = party 0 ALONE on the GPU, served the messages it received in the first run (its proof must repeat).
+int32_t cgh_session_prove_rep3(void* h, const uint64_t* pub_in, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
+                               const uint64_t* const* streams, size_t stream_len, uint64_t* out_proofs, double* seconds) {
+    cgh_session* s = (cgh_session*)h;
+    void* hub = nullptr; void* rh[4] = {nullptr, nullptr, nullptr, nullptr};
+    auto cleanup = [&] { for (void* r : rh) if (r) cgh_stream_rand_destroy(r); if (hub) cgh_loopback_destroy(hub); };
+    try {
+        using namespace cgh;
+        const size_t psz = 8 * s->z.curve.fq();
+        cgh_rep3_net nets[3]; cgh_rep3_rand rnd[4];
+        if (cgh_loopback_create(&hub)) throw std::runtime_error(g_host_err);
+        for (int i = 0; i < 3; i++) {
+            if (cgh_loopback_net(hub, i, i == 0 && seconds, &nets[i])) throw std::runtime_error(g_host_err);
+            if (cgh_stream_rand_create(s->z.curve.id, streams[i], streams[(i + 2) % 3], stream_len, &rh[i], &rnd[i])) throw std::runtime_error(g_host_err);
+        }
+        if (seconds && cgh_stream_rand_create(s->z.curve.id, streams[0], streams[2], stream_len, &rh[3], &rnd[3])) throw std::runtime_error(g_host_err);
         std::string errs[3];
         std::vector<std::thread> th;
         const auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < 3; i++) th.emplace_back([&, i] {
-            try {
-                InProcNetwork net(&hub, i);
-                RecordingNetwork rec(&net, &rec_prev, &rec_next);
-                party(i, i == 0 && seconds ? (Rep3Network*)&rec : (Rep3Network*)&net, (uint8_t*)out_proofs + i * psz);
-            } catch (const std::exception& e) { errs[i] = e.what(); hub.abort(); }
+            if (cgh_session_prove_rep3_party(h, pub_in, wit_a[i], wit_b[i], &nets[i], &rnd[i], (uint64_t*)((uint8_t*)out_proofs + i * psz), nullptr)) { errs[i] = g_host_err; cgh_loopback_abort(hub); }
         });
         for (auto& t : th) t.join();
-        if (report_party_errors(errs, 3)) return 1;
+        if (report_party_errors(errs, 3)) { cleanup(); return 1; }
         if (seconds) {
             seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             Bytes solo(psz);
-            ReplayNetwork replay(0, &rec_prev, &rec_next);
-            const auto t1 = std::chrono::steady_clock::now();
-            party(0, &replay, solo.data());
-            seconds[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+            cgh_rep3_net replay;
+            if (cgh_loopback_replay_net(hub, 0, &replay)) throw std::runtime_error(g_host_err);
+            if (cgh_session_prove_rep3_party(h, pub_in, wit_a[0], wit_b[0], &replay, &rnd[3], (uint64_t*)solo.data(), &seconds[1])) throw std::runtime_error(g_host_err);
             if (memcmp(solo.data(), out_proofs, psz)) throw std::runtime_error("replayed party produced a different proof");
         }
+        cleanup();
         return 0;
-    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+    } catch (const std::exception& e) { const std::string m = e.what(); cleanup(); g_host_err = m; return 1; }
 }
 
 }  // extern "C"

@@ -30,6 +30,10 @@ class HipDriver {
 public:
     cg_ctx* ctx; Curve curve; Mode mode; Rep3Network* net;
     const Fr* rng1 = nullptr; const Fr* rng2 = nullptr; size_t rng_len = 0, cursor = 0;   // rngs.rs:25-46 streams (inputs)
+    // REP3 with the caller's own Rep3Rand (cgh_session_prove_rep3_party): every draw goes through it instead of the two arrays above
+    Rep3RandSource* rsrc = nullptr;
+    std::vector<void*> mask_bufs;                                                          // page-locked scratch lent to rsrc, released at shutdown
+    Fr* mask_scratch(size_t n) { void* p; CG(cg_host_alloc(n * 32, &p)); mask_bufs.push_back(p); return (Fr*)p; }
     int k() const { return mode == Mode::Rep3 ? 2 : 1; }
     int party() const { return mode == Mode::Rep3 ? net->id() : -1; }
 
@@ -398,7 +402,17 @@ public:
     struct MaskSet { void* m1; void* m2; int32_t tk; size_t n, at; };
     std::deque<MaskSet> prefetched;
     void prefetch_masks(int count, size_t n) {
-        if (mode != Mode::Rep3 || n < XCHG_ASYNC_MIN || !rng1 || !rng2) return;
+        if (mode != Mode::Rep3 || n < XCHG_ASYNC_MIN) return;
+        if (rsrc) {                                                                     // drawn now, in the reference's order (both mul_vec calls precede every other draw)
+            for (int i = 0; i < count; i++) {
+                const Fr* m = rsrc->masking_field_elements(n, mask_scratch(n));
+                MaskSet ms{dalloc(n * 32), nullptr, -1, n, 0};
+                ms.tk = upload_staged(ms.m1, m, n);
+                prefetched.push_back(ms);
+            }
+            return;
+        }
+        if (!rng1 || !rng2) return;
         size_t at = cursor;
         for (int i = 0; i < count && at + n <= rng_len; i++, at += n) {
             if (!cg_host_is_pinned(rng1 + at) || !cg_host_is_pinned(rng2 + at)) return;
@@ -427,8 +441,19 @@ public:
         if (mode != Mode::Rep3) CG(cg_vec_mul_dev(ctx, curve.id, out.c[0], a.c[0], b.c[0], a.n));
         if (mode == Mode::Plain) return pm;
         if (mode == Mode::Shamir) { out = degree_reduce_vec(out); return pm; }         // shamir.rs:609-623
-        if (cursor + a.n > rng_len) throw std::runtime_error("randomness stream exhausted");
         void* m1 = nullptr; void* m2 = nullptr;
+        if (rsrc) {
+            if (!prefetched.empty() && prefetched.front().n == a.n) {
+                const MaskSet ms = prefetched.front(); prefetched.pop_front();
+                m1 = ms.m1;
+                if (ms.tk >= 0) CG(cg_copy_fence(ctx, ms.tk));
+            } else {
+                m1 = dalloc(a.n * 32);
+                if (a.n < XCHG_ASYNC_MIN) { std::vector<Fr> buf(a.n); CG(cg_dev_upload(ctx, m1, rsrc->masking_field_elements(a.n, buf.data()), a.n * 32)); }
+                else { const int32_t tk = upload_staged(m1, rsrc->masking_field_elements(a.n, mask_scratch(a.n)), a.n); if (tk >= 0) CG(cg_copy_fence(ctx, tk)); }
+            }
+        } else {
+        if (cursor + a.n > rng_len) throw std::runtime_error("randomness stream exhausted");
         if (!prefetched.empty() && prefetched.front().at == cursor && prefetched.front().n == a.n) {
             const MaskSet ms = prefetched.front(); prefetched.pop_front();
             m1 = ms.m1; m2 = ms.m2;
@@ -444,6 +469,7 @@ public:
         }
         cursor += a.n;
         CG(cg_vec_sub_dev(ctx, curve.id, m1, m1, m2, a.n));                           // masking_field_element = rand(rng1) - rand(rng2)
+        }
         CG(cg_vec_rep3_mul_local_dev(ctx, curve.id, out.c[0], a.c[0], a.c[1], b.c[0], b.c[1], m1, a.n));
         defer_free(m1); defer_free(m2);
         out.c[1] = dalloc(a.n * 32);
@@ -490,8 +516,9 @@ public:
     void shutdown() {
         for (void* p : deferred) cg_dev_free(ctx, p);
         deferred.clear();
-        for (auto& ms : prefetched) { cg_dev_free(ctx, ms.m1); cg_dev_free(ctx, ms.m2); }
+        for (auto& ms : prefetched) { cg_dev_free(ctx, ms.m1); if (ms.m2) cg_dev_free(ctx, ms.m2); }
         prefetched.clear();
+        if (!mask_bufs.empty()) { cg_ctx_sync(ctx); for (void* p : mask_bufs) cg_host_free(p); mask_bufs.clear(); }   // uploads from them may still be in flight
         release_rings(); release_pre();
         if (aux) { if (owns_aux) cg_ctx_destroy(aux); aux = nullptr; }
     }
@@ -512,6 +539,7 @@ public:
     ShareVec rand_vec(size_t n) {
         if (mode == Mode::Shamir) { std::vector<Fr> r(n); for (size_t i = 0; i < n; i++) r[i] = get_pair().first; return upload_vec(r.data(), nullptr, n); }   // shamir.rs:570-573
         if (mode != Mode::Rep3) throw std::runtime_error("rand_vec: REP3 / Shamir only");
+        if (rsrc) { std::vector<Fr> a(n), b(n); for (size_t i = 0; i < n; i++) rsrc->random_fes(a[i], b[i]); return upload_vec(a.data(), b.data(), n); }
         if (cursor + n > rng_len) throw std::runtime_error("randomness stream exhausted");
         ShareVec v = upload_vec(rng1 + cursor, rng2 + cursor, n); cursor += n;
         return v;
@@ -538,10 +566,13 @@ public:
             for (void* d : got) CG(cg_dev_free(ctx, d));
             return out;
         }
-        if (cursor + n > rng_len) throw std::runtime_error("randomness stream exhausted");
         void* m1 = dalloc(n * 32); void* m2 = dalloc(n * 32);
-        CG(cg_dev_upload(ctx, m1, rng1 + cursor, n * 32)); CG(cg_dev_upload(ctx, m2, rng2 + cursor, n * 32)); cursor += n;
-        CG(cg_vec_sub_dev(ctx, curve.id, m1, m1, m2, n));
+        if (rsrc) { std::vector<Fr> buf(n); CG(cg_dev_upload(ctx, m1, rsrc->masking_field_elements(n, buf.data()), n * 32)); }
+        else {
+            if (cursor + n > rng_len) throw std::runtime_error("randomness stream exhausted");
+            CG(cg_dev_upload(ctx, m1, rng1 + cursor, n * 32)); CG(cg_dev_upload(ctx, m2, rng2 + cursor, n * 32)); cursor += n;
+            CG(cg_vec_sub_dev(ctx, curve.id, m1, m1, m2, n));
+        }
         CG(cg_vec_rep3_mul_local_dev(ctx, curve.id, out, a.c[0], a.c[1], b.c[0], b.c[1], m1, n));
         std::vector<Fr> mine(n), p(n), q(n);
         CG(cg_dev_download(ctx, mine.data(), out, n * 32));
@@ -653,7 +684,9 @@ public:
     // rand (rep3.rs:595-598; plain: supplied by the caller)
     FieldShare rand() {
         if (mode == Mode::Shamir) { FieldShare f; f.c[0] = get_pair().first; f.c[1] = f.c[0]; return f; }   // shamir.rs:570-573
-        FieldShare f; f.c[0] = draw(rng1); f.c[1] = draw(rng2); cursor++; return f;
+        FieldShare f;
+        if (rsrc) { rsrc->random_fes(f.c[0], f.c[1]); return f; }
+        f.c[0] = draw(rng1); f.c[1] = draw(rng2); cursor++; return f;
     }
     // mul (rep3.rs:503-511 / plain a*b)
     FieldShare mul(const FieldShare& a, const FieldShare& b) {
@@ -661,7 +694,8 @@ public:
         if (mode == Mode::Plain) { r.c[0] = fr_mul(curve, a.c[0], b.c[0]); r.c[1] = r.c[0]; return r; }
         if (mode == Mode::Shamir) { r.c[0] = degree_reduce(fr_mul(curve, a.c[0], b.c[0])); r.c[1] = r.c[0]; return r; }   // shamir.rs:481-488
         Fr local = fr_add(curve, fr_add(curve, fr_mul(curve, a.c[0], b.c[0]), fr_mul(curve, a.c[0], b.c[1])), fr_mul(curve, a.c[1], b.c[0]));
-        local = fr_add(curve, local, fr_sub(curve, draw(rng1), draw(rng2))); cursor++;
+        if (rsrc) { Fr buf; local = fr_add(curve, local, *rsrc->masking_field_elements(1, &buf)); }
+        else { local = fr_add(curve, local, fr_sub(curve, draw(rng1), draw(rng2))); cursor++; }
         net->send_next(local.v, 32);
         Fr prev; net->recv_prev(prev.v, 32);
         r.c[0] = local; r.c[1] = prev;
@@ -675,8 +709,11 @@ public:
         if (mode == Mode::Plain) { r.c[0] = pt_mul(curve, a.c[0], b.c[0]); r.c[1] = pt_inf(curve, a.c[0].group); return r; }
         if (mode == Mode::Shamir) { r.c[0] = degree_reduce_point(pt_mul(curve, a.c[0], b.c[0])); r.c[1] = pt_inf(curve, a.c[0].group); return r; }   // shamir.rs:769-776
         Point local = pt_add(curve, pt_add(curve, pt_mul(curve, a.c[0], b.c[0]), pt_mul(curve, a.c[1], b.c[0])), pt_mul(curve, a.c[0], b.c[1]));
-        const Point gen = pt_generator(curve, a.c[0].group);       // masking_ec_element: G*rand(rng1) - G*rand(rng2)
-        local = pt_add(curve, local, pt_sub(curve, pt_mul(curve, gen, draw(rng1)), pt_mul(curve, gen, draw(rng2)))); cursor++;
+        if (rsrc) { Point m{Bytes(curve.jac(a.c[0].group)), a.c[0].group}; rsrc->masking_ec_element(m.group, m.b.data()); local = pt_add(curve, local, m); }   // rngs.rs:48-51
+        else {
+            const Point gen = pt_generator(curve, a.c[0].group);   // masking_ec_element: G*rand(rng1) - G*rand(rng2)
+            local = pt_add(curve, local, pt_sub(curve, pt_mul(curve, gen, draw(rng1)), pt_mul(curve, gen, draw(rng2)))); cursor++;
+        }
         Bytes aff = pt_to_affine(curve, local);                    // points cross the wire in affine form (ark-serialize)
         net->send_next(aff.data(), aff.size());
         Bytes prev(aff.size()); net->recv_prev(prev.data(), prev.size());

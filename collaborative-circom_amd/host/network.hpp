@@ -102,6 +102,49 @@ struct ReplayNetwork : Rep3Network {
     }
 };
 
+// The caller's own transport behind the C callback table of cgh_session_prove_rep3_party (include/cogroth16_host.h): in the Rust binding the
+// callbacks are closures over Rep3MpcNet::{send_bytes, recv_bytes} (rep3/network.rs:137-176).  A failing callback ends the proof with
+// std::io::Error's role: an exception that names the call and the code.
+struct CallbackNetwork : Rep3Network {
+    cgh_rep3_net cb;
+    explicit CallbackNetwork(const cgh_rep3_net& c) : cb(c) {
+        if (cb.party_id < 0 || cb.party_id > 2) throw std::runtime_error("REP3 party id must be 0, 1 or 2");     // id.rs: PartyID::try_from
+        if (!cb.send_next || !cb.recv_prev) throw std::runtime_error("cgh_rep3_net: send_next and recv_prev are required");
+    }
+    static void check(int32_t rc, const char* what) { if (rc) throw std::runtime_error(std::string("network: ") + what + " failed with code " + std::to_string(rc)); }
+    int id() const override { return cb.party_id; }
+    void send_next(const void* d, size_t b) override { check(cb.send_next(cb.user, d, b), "send_next"); }
+    void recv_prev(void* d, size_t b) override { check(cb.recv_prev(cb.user, d, b), "recv_prev"); }
+    void send_prev(const void* d, size_t b) override { if (!cb.send_prev) throw std::runtime_error("cgh_rep3_net: send_prev is not provided"); check(cb.send_prev(cb.user, d, b), "send_prev"); }
+    void recv_next(void* d, size_t b) override { if (!cb.recv_next) throw std::runtime_error("cgh_rep3_net: recv_next is not provided"); check(cb.recv_next(cb.user, d, b), "recv_next"); }
+    const void* recv_prev_pinned(size_t b) override { return cb.recv_prev_pinned ? cb.recv_prev_pinned(cb.user, b) : nullptr; }
+};
+
+// Rep3Rand (rep3/rngs.rs:25-62) as the driver sees it: masking vectors, replicated random shares, masking points.  The draws themselves
+// belong to the caller (ChaCha12 streams agreed with the peers, rep3.rs:385-398).
+struct Rep3RandSource {
+    virtual ~Rep3RandSource() {}
+    // n masking field elements; `buf` (page-locked, n elements) may be used for them or ignored; the result stays valid until the proof ends
+    virtual const Fr* masking_field_elements(size_t n, Fr* buf) = 0;
+    virtual void random_fes(Fr& a, Fr& b) = 0;
+    virtual void masking_ec_element(int group, uint8_t* out_jacobian) = 0;
+};
+struct CallbackRand : Rep3RandSource {
+    cgh_rep3_rand cb;
+    explicit CallbackRand(const cgh_rep3_rand& c) : cb(c) {
+        if (!cb.masking_field_elements || !cb.random_fes || !cb.masking_ec_element) throw std::runtime_error("cgh_rep3_rand: all three callbacks are required");
+    }
+    static void check(int32_t rc, const char* what) { if (rc) throw std::runtime_error(std::string("randomness source: ") + what + " failed with code " + std::to_string(rc)); }
+    const Fr* masking_field_elements(size_t n, Fr* buf) override {
+        const uint64_t* out = nullptr;
+        check(cb.masking_field_elements(cb.user, n, (uint64_t*)buf, &out), "masking_field_elements");
+        if (!out) throw std::runtime_error("randomness source: masking_field_elements returned no data");
+        return (const Fr*)out;
+    }
+    void random_fes(Fr& a, Fr& b) override { check(cb.random_fes(cb.user, a.v, b.v), "random_fes"); }
+    void masking_ec_element(int group, uint8_t* out) override { check(cb.masking_ec_element(cb.user, group, (uint64_t*)out), "masking_ec_element"); }
+};
+
 // Shamir: any-to-any channels (shamir/network.rs:17-59)
 struct ShamirNet {
     virtual ~ShamirNet() {}

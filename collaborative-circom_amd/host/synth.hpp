@@ -14,14 +14,6 @@ namespace cgh {
 // Conventions the prover relies on (groth16.rs:141-204): section 4 carries the rows A[nc + i] = w_i for i <= n_public, and
 //     h_query[i] = [ (tau^2m - 1) g w^i / (2 m delta (tau - g w^i)) ]_1,   g = w_2m:
 // H = (AB - C)/Z is interpolated on the odd coset gH, where Z = g^m - 1 = -2, so the prover's h_i = (AB - C)(g w^i) needs no division.
-static void parallel_for(size_t n, const std::function<void(size_t, size_t)>& fn) {
-    const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::thread::hardware_concurrency(), n / 4096 + 1}));
-    if (T == 1) { fn(0, n); return; }
-    std::vector<std::thread> th; std::vector<std::string> err(T);
-    for (size_t t = 0; t < T; t++) th.emplace_back([&, t] { try { fn(n * t / T, n * (t + 1) / T); } catch (const std::exception& e) { err[t] = e.what(); } });
-    for (auto& x : th) x.join();
-    for (auto& e : err) if (!e.empty()) throw std::runtime_error(e);
-}
 static void batch_inverse(const Curve& c, std::vector<Fr>& v) {           // Montgomery's trick per slice; no zero elements
     parallel_for(v.size(), [&](size_t lo, size_t hi) {
         if (hi <= lo) return;

@@ -85,6 +85,64 @@ int32_t cgh_session_prove_plain(void* session, const uint64_t* full_witness, con
 int32_t cgh_session_prove_rep3(void* session, const uint64_t* pub_in, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
                                const uint64_t* const* streams, size_t stream_len, uint64_t* out_proofs, double* seconds);
 
+/* ---- ONE party of a REP3 proof, with the caller's network and the caller's correlated randomness ------------------------------------
+ * This is what `co-circom generate-proof --protocol REP3` runs per process (co-circom.rs:484-506): the party's own shares, a network
+ * to its two peers (Rep3MpcNet, mpc-core/src/protocols/rep3/network.rs:13-64) and the randomness it agreed on with them
+ * (Rep3CorrelatedRng, rep3/rngs.rs:25-62, set up by Rep3Protocol::new, rep3.rs:385-398).  The network rounds and every random draw stay
+ * with the caller — the callbacks below are closures over `Rep3MpcNet::{send_bytes, recv_bytes}` and `Rep3Rand` in the Rust binding
+ * (rust/mpc-core-hip/src/session.rs) — and the prove itself runs on the session's resident tables exactly as cgh_session_prove_rep3
+ * does for three co-located parties.
+ *
+ * Messages are opaque byte strings between parties that run THIS backend: field vectors travel as 32-byte Montgomery limbs, points
+ * as packed affine coordinates; one send_* call is one message and must be delivered whole, in order, to the matching recv_* call of
+ * the peer (which asks for the same number of bytes).  The two `mul_vec` exchanges (rep3.rs:650-670) are sent in chunks of at most
+ * 4 MiB so that the transfer overlaps the GPU work; the number and order of messages is a function of the circuit size only.
+ * All callbacks are called from the thread that called the prove, return 0 on success and anything else on an I/O failure (the
+ * prove then fails with that code in its message). */
+typedef struct cgh_rep3_net {
+    void* user;
+    int32_t party_id;                                                      /* get_id(): 0, 1 or 2 (network.rs:15) */
+    int32_t (*send_next)(void* user, const void* data, size_t bytes);      /* to party id + 1 (network.rs:30-37) */
+    int32_t (*recv_prev)(void* user, void* data, size_t bytes);            /* from party id - 1 (network.rs:57-64) */
+    int32_t (*send_prev)(void* user, const void* data, size_t bytes);      /* send(id.prev_id(), ..) (rep3.rs:746-753; co-plonk openings) */
+    int32_t (*recv_next)(void* user, void* data, size_t bytes);
+    /* optional (may be NULL): the next message from the previous party where the transport already holds it, in page-locked memory that
+     * stays valid until the prove returns; NULL result = not available, recv_prev is used */
+    const void* (*recv_prev_pinned)(void* user, size_t bytes);
+} cgh_rep3_net;
+typedef struct cgh_rep3_rand {
+    void* user;
+    /* n x Rep3Rand::masking_field_element (rngs.rs:37-40: rand(rng1) - rand(rng2)), Montgomery.  `buf` is page-locked scratch of n
+     * elements owned by the library; the callee either fills it and stores buf in *out, or stores a pointer to n elements of its own
+     * (valid until the prove returns; page-locked memory from cg_host_alloc is uploaded without a staging copy). */
+    int32_t (*masking_field_elements)(void* user, size_t n, uint64_t* buf, const uint64_t** out);
+    /* Rep3Rand::random_fes (rngs.rs:42-46): a = rand(rng1), b = rand(rng2) — one replicated random share (Rep3Protocol::rand, rep3.rs:595-598) */
+    int32_t (*random_fes)(void* user, uint64_t* a, uint64_t* b);
+    /* Rep3Rand::masking_ec_element::<C> (rngs.rs:48-51), Jacobian Montgomery (X, Y, Z); group: CG_G1 / CG_G2 */
+    int32_t (*masking_ec_element)(void* user, int32_t group, uint64_t* out_jacobian);
+} cgh_rep3_rand;
+/* Groth16 proof of one REP3 party on an open session.  pub_in = n_public + 1 values, wit_a / wit_b = this party's replicated shares of
+ * the private witness (page-locked buffers are read by DMA where they lie).  seconds[1] (optional) = wall time of the prove. */
+int32_t cgh_session_prove_rep3_party(void* session, const uint64_t* pub_in, const uint64_t* wit_a, const uint64_t* wit_b,
+                                     const cgh_rep3_net* net, const cgh_rep3_rand* rnd, uint64_t* out_proof, double* seconds);
+
+/* Transports and randomness sources for tests, benches and single-box deployments; each fills a callback table for the entry above.
+ * cgh_loopback_*: three parties of one process joined by in-memory queues (the role of tests/src/rep3_network.rs).  record != 0 keeps
+ * a copy of everything that party receives (large messages in page-locked memory); cgh_loopback_replay_net then serves that traffic
+ * back to the same party running ALONE — one party's cost with its peers on other machines, network time excluded. */
+int32_t cgh_loopback_create(void** out_hub);
+int32_t cgh_loopback_net(void* hub, int32_t party, int32_t record, cgh_rep3_net* out);
+int32_t cgh_loopback_replay_net(void* hub, int32_t party, cgh_rep3_net* out);
+/* a party failed: the others' pending and later receives fail instead of waiting for messages that will never come */
+int32_t cgh_loopback_abort(void* hub);
+int32_t cgh_loopback_destroy(void* hub);
+/* Rep3Rand over two pre-generated streams of field elements (rng1[k], rng2[k] = the k-th F::rand of each ChaCha stream): masks are
+ * rng1[k] - rng2[k] (computed here, once, into page-locked memory), random_fes returns (rng1[k], rng2[k]), masking_ec_element is
+ * G * rng1[k] - G * rng2[k] (a stand-in for C::rand, which no caller can reproduce without arkworks; the proof does not depend on it).
+ * Every draw advances k by one, a masking vector of n elements by n. */
+int32_t cgh_stream_rand_create(int32_t curve, const uint64_t* rng1, const uint64_t* rng2, size_t len, void** out_handle, cgh_rep3_rand* out);
+int32_t cgh_stream_rand_destroy(void* handle);
+
 /* ---- co-plonk (co-plonk/src/plonk.rs:133-271 drives round1..round5) ------------------------------------------------------------------ */
 /* PlainHipDriver through rounds 1..upto (<= 5).  full_witness = n_vars - n_additions elements; blind = the 11 blinding scalars b_1..b_11
  * (round1.rs:346-383 fixes them to 1..11 in its test); commits = 9 packed G1 (a, b, c, z, t1, t2, t3, wxi, wxiw; zero = not reached),

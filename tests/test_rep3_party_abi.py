@@ -1,0 +1,312 @@
+"""ONE REP3 party behind the C callback ABI (cgh_session_prove_rep3_party, include/cogroth16_host.h): what `co-circom generate-proof
+--protocol REP3` runs per process (co-circom/co-circom/src/bin/co-circom.rs:484-506) — the party's own shares, the caller's network
+(Rep3Network, mpc-core/src/protocols/rep3/network.rs:13-64) and the caller's correlated randomness (Rep3Rand, rep3/rngs.rs:25-62).
+CPU part: the transports and randomness sources that fill the callback tables.  GPU part (-m gpu): three parties on three threads,
+each through the callback ABI over real sockets (length-delimited frames like mpc-net), give the oracle's proofs bit for bit."""
+import ctypes as C
+import os
+import queue
+import socket
+import struct
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from oracle_lib import BN254, BLS12_381, FR
+from product import cg, ensure_built
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fx(curve_name, circuit, f):
+    return os.path.join(GOLDEN, "groth16", curve_name, circuit, f)
+
+
+def rep3_share(curve, vals, rng):
+    a = orc.random_field(curve, FR, vals.shape[0], rng); b = orc.random_field(curve, FR, vals.shape[0], rng)
+    c = orc.field_op(curve, FR, "sub", orc.field_op(curve, FR, "sub", vals, a), b)
+    return [a, b, c], [c, a, b]
+
+
+# ---- a transport over stream sockets: u64 length prefix + payload per message (mpc-net's LengthDelimitedCodec framing); a reader
+# thread per incoming connection queues the frames, so that three parties sending 4 MiB chunks at once cannot block each other
+class SocketEnd:
+    def __init__(self, party, to_next, from_prev, to_prev, from_next):
+        self.party = party
+        self.out = {"next": to_next, "prev": to_prev}
+        self.inq = {"prev": queue.Queue(), "next": queue.Queue()}
+        self.sent = {"next": 0, "prev": 0}
+        self.fail_send_next_at = None
+        self.readers = [threading.Thread(target=self._reader, args=(from_prev, self.inq["prev"]), daemon=True),
+                        threading.Thread(target=self._reader, args=(from_next, self.inq["next"]), daemon=True)]
+        for t in self.readers: t.start()
+        self._cbs = (cg._SEND(lambda u, d, n: self._send("next", d, n)), cg._RECV(lambda u, d, n: self._recv("prev", d, n)),
+                     cg._SEND(lambda u, d, n: self._send("prev", d, n)), cg._RECV(lambda u, d, n: self._recv("next", d, n)))
+        self.table = cg.Rep3NetTable(None, party, self._cbs[0], self._cbs[1], self._cbs[2], self._cbs[3], cg._RECV_PINNED())
+
+    @staticmethod
+    def _reader(sock, q):
+        try:
+            while True:
+                hdr = b""
+                while len(hdr) < 8:
+                    part = sock.recv(8 - len(hdr))
+                    if not part: q.put(None); return
+                    hdr += part
+                n, = struct.unpack("<Q", hdr)
+                buf = bytearray(n); view = memoryview(buf); got = 0
+                while got < n:
+                    k = sock.recv_into(view[got:], n - got)
+                    if k == 0: q.put(None); return
+                    got += k
+                q.put(bytes(buf))
+        except OSError:
+            q.put(None)
+
+    def _send(self, where, data, n):
+        try:
+            if where == "next" and self.fail_send_next_at is not None and self.sent["next"] == self.fail_send_next_at:
+                return 32                                                          # EPIPE: the peer went away
+            self.out[where].sendall(struct.pack("<Q", n) + C.string_at(data, n))
+            self.sent[where] += 1
+            return 0
+        except OSError as e:
+            return e.errno or 5
+
+    def _recv(self, where, data, n):
+        try: msg = self.inq[where].get(timeout=120)
+        except queue.Empty: return 110                                             # ETIMEDOUT
+        if msg is None: return 104                                                 # ECONNRESET
+        if len(msg) != n: return 74                                                # EBADMSG: rep3.rs:663-668 "invalid number of elements received"
+        C.memmove(data, msg, n)
+        return 0
+
+    def close(self):
+        for s in self.out.values():
+            try: s.shutdown(socket.SHUT_RDWR)
+            except OSError: pass
+            s.close()
+
+
+def socket_ring():
+    """three SocketEnds joined pairwise by socketpairs: i -> i+1 (next direction) and i -> i-1 (prev direction)"""
+    fwd = [socket.socketpair() for _ in range(3)]          # fwd[i]: party i writes [0], party i+1 reads [1]
+    bwd = [socket.socketpair() for _ in range(3)]          # bwd[i]: party i writes [0], party i-1 reads [1]
+    return [SocketEnd(i, fwd[i][0], fwd[(i + 2) % 3][1], bwd[i][0], bwd[(i + 1) % 3][1]) for i in range(3)]
+
+
+class PyRand:
+    """Rep3Rand written in Python over two streams: fills the library's buffer (the other way of answering masking_field_elements),
+    G * a - G * b as masking point (the oracle's stand-in for C::rand, oracle/groth16.hpp)"""
+
+    def __init__(self, curve, rng1, rng2):
+        self.curve, self.r1, self.r2, self.k = curve, rng1, rng2, 0
+        self.diff = orc.field_op(curve, FR, "sub", rng1, rng2)
+        self._cbs = (cg._MASKS(self._masks), cg._FES(self._fes), cg._EC(self._ec))
+        self.table = cg.Rep3RandTable(None, *self._cbs)
+
+    def _masks(self, u, n, buf, out):
+        if self.k + n > self.diff.shape[0]: return 1
+        C.memmove(buf, self.diff[self.k:self.k + n].ctypes.data, 32 * n); out[0] = buf; self.k += n
+        return 0
+
+    def _fes(self, u, a, b):
+        C.memmove(a, self.r1[self.k].ctypes.data, 32); C.memmove(b, self.r2[self.k].ctypes.data, 32); self.k += 1
+        return 0
+
+    def _ec(self, u, group, out):
+        g = cg.point_generator(self.curve, group)
+        m = cg.point_add(self.curve, group, cg.point_scalar_mul(self.curve, group, g, self.r1[self.k]),
+                         cg.point_neg(self.curve, group, cg.point_scalar_mul(self.curve, group, g, self.r2[self.k])))
+        self.k += 1
+        m = np.ascontiguousarray(m, dtype=np.uint64); C.memmove(out, m.ctypes.data, m.nbytes)
+        return 0
+
+
+def run_three_parties(ses, pub, wa, wb, nets, rands):
+    out, errs = [None] * 3, [None] * 3
+
+    def party(i):
+        try: out[i], _ = cg.host_prove_rep3_party(ses, pub, wa[i], wb[i], nets[i], rands[i])
+        except Exception as e: errs[i] = e
+    th = [threading.Thread(target=party, args=(i,)) for i in range(3)]
+    for t in th: t.start()
+    for t in th: t.join(300)
+    return out, errs
+
+
+# ---------------------------------------------------------------------------------------------------------------- CPU
+def test_loopback_tables_move_messages_between_threads():
+    ensure_built()
+    hub = cg.LoopbackHub()
+    try:
+        nets = [hub.net(i, record=(i == 1)) for i in range(3)]
+        assert [n.party_id for n in nets] == [0, 1, 2]
+        msg = np.arange(1000, dtype=np.uint64)
+        got = np.zeros_like(msg); back = np.zeros(4, dtype=np.uint64)
+        assert nets[0].send_next(nets[0].user, msg.ctypes.data, msg.nbytes) == 0          # 0 -> 1
+        assert nets[2].send_prev(nets[2].user, msg[:4].ctypes.data, 32) == 0              # 2 -> 1 (prev direction)
+        t = threading.Thread(target=lambda: (nets[1].recv_prev(nets[1].user, got.ctypes.data, got.nbytes), nets[1].recv_next(nets[1].user, back.ctypes.data, 32)))
+        t.start(); t.join(30)
+        np.testing.assert_array_equal(got, msg); np.testing.assert_array_equal(back, msg[:4])
+        # a message of the wrong size is an error (rep3.rs:663-668), not a truncated read
+        assert nets[1].send_next(nets[1].user, msg.ctypes.data, 64) == 0
+        assert nets[2].recv_prev(nets[2].user, got.ctypes.data, 32) != 0
+        assert b"invalid number of bytes" in cg.load_host().cgh_last_error()
+        # party 1's traffic was recorded: the replay table serves it again, sends are dropped
+        rp = hub.replay_net(1)
+        got[:] = 0; back[:] = 0
+        assert rp.send_next(rp.user, msg.ctypes.data, 8) == 0
+        assert rp.recv_prev(rp.user, got.ctypes.data, got.nbytes) == 0 and rp.recv_next(rp.user, back.ctypes.data, 32) == 0
+        np.testing.assert_array_equal(got, msg); np.testing.assert_array_equal(back, msg[:4])
+        assert rp.recv_prev(rp.user, got.ctypes.data, 8) != 0                             # nothing left
+        # abort wakes a waiting receiver
+        res = []
+        t = threading.Thread(target=lambda: res.append(nets[0].recv_prev(nets[0].user, got.ctypes.data, 8)))
+        t.start(); hub.abort(); t.join(30)
+        assert res and res[0] != 0
+    finally:
+        hub.close()
+
+
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
+def test_stream_rand_follows_rep3rand(curve):
+    """rngs.rs:37-46: masking element = rand(rng1) - rand(rng2), random_fes = the pair; every draw advances both streams by one"""
+    ensure_built()
+    rng = np.random.default_rng(4)
+    n = 5000
+    r1 = orc.random_field(curve, FR, n, rng); r2 = orc.random_field(curve, FR, n, rng)
+    r2[7] = r1[7]; r1[8] = 0; r2[9] = 0                                                  # difference 0, minuend 0, subtrahend 0
+    src = cg.StreamRand(curve, r1, r2)
+    try:
+        t = src.table
+        out = C.c_void_p()
+        assert t.masking_field_elements(t.user, 4000, None, C.byref(out)) == 0
+        got = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(4000, 4))
+        np.testing.assert_array_equal(got, orc.field_op(curve, FR, "sub", r1[:4000], r2[:4000]))
+        a = np.zeros(4, dtype=np.uint64); b = np.zeros(4, dtype=np.uint64)
+        assert t.random_fes(t.user, a.ctypes.data, b.ctypes.data) == 0
+        np.testing.assert_array_equal(a, r1[4000]); np.testing.assert_array_equal(b, r2[4000])
+        assert t.masking_field_elements(t.user, 999, None, C.byref(out)) == 0
+        got = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint64)), shape=(999, 4))
+        np.testing.assert_array_equal(got, orc.field_op(curve, FR, "sub", r1[4001:5000], r2[4001:5000]))
+        assert t.random_fes(t.user, a.ctypes.data, b.ctypes.data) != 0                    # exhausted
+        assert b"exhausted" in cg.load_host().cgh_last_error()
+    finally:
+        src.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_three_parties_over_sockets_give_the_oracle_proof(curve_name):
+    """tests/tests/circom/e2e_tests/mod.rs:33-82, one thread per party, each through the callback ABI over sockets (poseidon fixture)"""
+    ensure_built()
+    curve = {"bn254": BN254, "bls12_381": BLS12_381}[curve_name]
+    zpath = fx(curve_name, "poseidon", "circuit.zkey")
+    z = orc.ZKey(curve, zpath); w = orc.read_wtns(curve, fx(curve_name, "poseidon", "witness.wtns"))
+    rng = np.random.default_rng(15)
+    pub = w[:z.n_public + 1]
+    wa, wb = rep3_share(curve, w[z.n_public + 1:], rng)
+    streams = [orc.random_field(curve, FR, 2 * z.domain_size + 4, rng) for _ in range(3)]
+    want = z.prove_rep3(pub, wa, wb, streams)
+    ses = cg.ProvingSession(curve, zpath, precompute=False)
+    ends = socket_ring()
+    rands = [PyRand(curve, streams[0], streams[2]), cg.StreamRand(curve, streams[1], streams[0]), cg.StreamRand(curve, streams[2], streams[1])]
+    try:
+        out, errs = run_three_parties(ses, pub, wa, wb, [e.table for e in ends], [r.table for r in rands])
+        assert errs == [None, None, None], errs
+        np.testing.assert_array_equal(np.stack(out), want)
+        vk = orc.vk_from_json(curve, fx(curve_name, "poseidon", "verification_key.json"))
+        assert orc.verify(curve, vk, w[1:1 + z.n_public], out[0])
+        assert all(e.sent["next"] > 0 for e in ends)                                      # the proofs really crossed the sockets
+    finally:
+        for e in ends: e.close()
+        for r in rands[1:]: r.close()
+        ses.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunked", [False, True])
+def test_three_parties_over_sockets_at_2_16(chunked, tmp_path, monkeypatch):
+    """BASELINE configs[1] scale.  chunked: the two mul_vec exchanges travel as asynchronous 128 KiB chunks (the path a 2^22 proof
+    takes with 4 MiB chunks), forced here by lowering the threshold"""
+    ensure_built()
+    if chunked: monkeypatch.setenv("CGH_XCHG_ASYNC_MIN", "4096")
+    curve, log_m = BN254, 16
+    threads = min(32, os.cpu_count() or 8)
+    zp, wp = str(tmp_path / "s.zkey"), str(tmp_path / "s.wtns")
+    orc.make_synthetic(curve, log_m, 31, zp, wp, threads=threads)
+    z = orc.ZKey(curve, zp); w = orc.read_wtns(curve, wp)
+    rng = np.random.default_rng(19)
+    wa, wb = rep3_share(curve, w[2:], rng)
+    streams = [orc.random_field(curve, FR, 2 * z.domain_size + 4, rng) for _ in range(3)]
+    want = z.prove_rep3(w[:2], wa, wb, streams, threads=threads)
+    ses = cg.ProvingSession(curve, zp, precompute=True)
+    ends = socket_ring()
+    rands = [cg.StreamRand(curve, streams[i], streams[(i + 2) % 3]) for i in range(3)]
+    try:
+        out, errs = run_three_parties(ses, w[:2], wa, wb, [e.table for e in ends], [r.table for r in rands])
+        assert errs == [None, None, None], errs
+        np.testing.assert_array_equal(np.stack(out), want)
+        if chunked: assert ends[0].sent["next"] > 2 * 4                                   # 2 exchanges in several chunks + the O(1) rounds
+        # the same session through the loopback transport, then party 0 alone on its recorded traffic
+        hub = cg.LoopbackHub()
+        r2 = [cg.StreamRand(curve, streams[i], streams[(i + 2) % 3]) for i in range(3)] + [cg.StreamRand(curve, streams[0], streams[2])]
+        try:
+            out2, errs = run_three_parties(ses, w[:2], wa, wb, [hub.net(i, record=(i == 0)) for i in range(3)], [r.table for r in r2[:3]])
+            assert errs == [None, None, None], errs
+            np.testing.assert_array_equal(np.stack(out2), want)
+            solo, sec = cg.host_prove_rep3_party(ses, w[:2], wa[0], wb[0], hub.replay_net(0), r2[3].table)
+            np.testing.assert_array_equal(solo, want[0]); assert sec > 0
+        finally:
+            for r in r2: r.close()
+            hub.close()
+    finally:
+        for e in ends: e.close()
+        for r in rands: r.close()
+        ses.close()
+
+
+@pytest.mark.gpu
+def test_a_failing_network_callback_fails_the_proof():
+    """std::io::Error from the network ends the prove (rep3.rs:661-669 `?`): the code reaches the caller, nothing hangs, the session
+    stays usable"""
+    ensure_built()
+    curve = BN254
+    zpath = fx("bn254", "poseidon", "circuit.zkey")
+    z = orc.ZKey(curve, zpath); w = orc.read_wtns(curve, fx("bn254", "poseidon", "witness.wtns"))
+    rng = np.random.default_rng(23)
+    pub = w[:z.n_public + 1]
+    wa, wb = rep3_share(curve, w[z.n_public + 1:], rng)
+    streams = [orc.random_field(curve, FR, 2 * z.domain_size + 4, rng) for _ in range(3)]
+    ses = cg.ProvingSession(curve, zpath, precompute=False)
+    try:
+        ends = socket_ring()
+        ends[1].fail_send_next_at = 1                                                     # party 1's second message never leaves
+        rands = [cg.StreamRand(curve, streams[i], streams[(i + 2) % 3]) for i in range(3)]
+        out, errs = [None] * 3, [None] * 3
+
+        def party(i):
+            try: out[i], _ = cg.host_prove_rep3_party(ses, pub, wa[i], wb[i], ends[i].table, rands[i].table)
+            except Exception as e: errs[i] = e
+            finally: ends[i].close()                                                      # a dying process closes its connections
+        th = [threading.Thread(target=party, args=(i,)) for i in range(3)]
+        for t in th: t.start()
+        for t in th: t.join(120)
+        assert not any(t.is_alive() for t in th)
+        assert errs[1] is not None and "send_next failed with code 32" in str(errs[1])
+        assert errs[2] is not None and "recv_prev failed" in str(errs[2])
+        for r in rands: r.close()
+        # the session still proves
+        ends = socket_ring()
+        rands = [cg.StreamRand(curve, streams[i], streams[(i + 2) % 3]) for i in range(3)]
+        out, errs = run_three_parties(ses, pub, wa, wb, [e.table for e in ends], [r.table for r in rands])
+        assert errs == [None, None, None], errs
+        np.testing.assert_array_equal(np.stack(out), z.prove_rep3(pub, wa, wb, streams))
+        for e in ends: e.close()
+        for r in rands: r.close()
+    finally:
+        ses.close()
