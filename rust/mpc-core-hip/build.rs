@@ -12,6 +12,7 @@ fn main() {
     }
     println!("cargo:rustc-link-search=native={}", dir.display());
     println!("cargo:rustc-link-lib=dylib=cogroth16_hip");
+    println!("cargo:rustc-link-lib=dylib=cogroth16_host");   // session.rs (the host mirror's prove entry points; `make -C collaborative-circom_amd/host`)
     println!("cargo:rustc-link-arg=-Wl,-rpath,{}", dir.display());
     println!("cargo:rerun-if-env-changed=COGROTH16_HIP_LIB_DIR");
     println!("cargo:rerun-if-changed=../../include/cogroth16_hip.h");

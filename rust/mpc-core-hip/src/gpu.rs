@@ -1,5 +1,5 @@
-//! The GPU side shared by the three drivers: one `cg_ctx` per party thread (mirrors `&mut self` of the trait methods), the table cache
-//! that maps the `&[C::Affine]` slices the provers pass to `msm_public_points` onto device-resident tables, and the layout checks
+//! The GPU side shared by the three drivers: one `cg_ctx` per party thread (mirrors `&mut self` of the trait methods), the table registry
+//! that maps sub-slices of EXPLICITLY registered zkey vectors onto device-resident tables (anything else is uploaded per call), and the layout checks
 //! that make it sound to hand arkworks' in-memory values to the C ABI without conversion.
 use crate::ffi::*;
 use ark_ec::short_weierstrass::{Affine, Projective, SWCurveConfig};
@@ -85,7 +85,8 @@ impl Gpu {
         let _ = Layout::<P>::CHECK;
         let lo = points.as_ptr() as usize;
         if let Some(&i) = self.by_start.get(&lo) {
-            if self.tables[i].host_hi >= lo + points.len() * Layout::<P>::STRIDE {
+            // the same vector registered twice (same start, same length): the caller's promise about its lifetime covers both
+            if self.tables[i].host_hi == lo + points.len() * Layout::<P>::STRIDE {
                 return i;
             }
         }
@@ -119,33 +120,64 @@ impl Gpu {
         Ok(())
     }
 
-    /// (table, offset in points) for a slice: a registered parent allocation that contains it, else the slice becomes a table of its
-    /// own.  The provers pass sub-slices such as `&query[1 + pub_len..]` (groth16.rs:221) and `&p_tau[..len]` (co-plonk round1.rs:276-290).
-    fn bases_for<P: SWCurveConfig>(&mut self, points: &[Affine<P>]) -> (*const cg_bases, usize) {
+    /// Forgets a table registered with `register` (its host vector is about to be dropped or rewritten) and frees its device copy.
+    /// Indices of other tables stay valid.
+    pub fn unregister(&mut self, table: usize) {
+        let t = &mut self.tables[table];
+        if !t.bases.is_null() {
+            unsafe { cg_bases_release(t.bases) };
+            t.bases = ptr::null_mut();
+            self.by_start.remove(&t.host_lo);
+            t.host_lo = 0;
+            t.host_hi = 0;
+        }
+    }
+
+    /// (table, offset in points) for a slice that lies inside a vector registered EXPLICITLY with `register` — the provers pass
+    /// sub-slices such as `&query[1 + pub_len..]` (groth16.rs:221) and `&p_tau[..len]` (co-plonk round1.rs:276-290).  Only explicit
+    /// registrations are matched: the caller vouches that those vectors live, unchanged, as long as the table does (zkey vectors do,
+    /// zkey.rs:48-71).  An address range says nothing about the contents of any other slice, so nothing else is ever cached.
+    fn registered<P: SWCurveConfig>(&self, points: &[Affine<P>]) -> Option<(*const cg_bases, usize)> {
         let lo = points.as_ptr() as usize;
         let hi = lo + points.len() * Layout::<P>::STRIDE;
-        for t in &self.tables {
-            if t.host_lo <= lo && hi <= t.host_hi && t.stride == Layout::<P>::STRIDE && (lo - t.host_lo) % t.stride == 0 {
-                return (t.bases, (lo - t.host_lo) / t.stride);
-            }
-        }
-        let i = self.register(points);
-        (self.tables[i].bases, 0)
+        self.tables
+            .iter()
+            .find(|t| !t.bases.is_null() && t.host_lo <= lo && hi <= t.host_hi && t.stride == Layout::<P>::STRIDE && (lo - t.host_lo) % t.stride == 0)
+            .map(|t| (t.bases as *const cg_bases, (lo - t.host_lo) / t.stride))
     }
 
     /// `k` MSMs over the same points (one per share component, the loop of rep3.rs:942-943 in one call: the points are gathered once
-    /// per component from the same resident table and the components' digit schedules overlap with each other's accumulation)
+    /// per component from the same resident table and the components' digit schedules overlap with each other's accumulation).
+    /// Points that are not part of a registered vector are uploaded as a temporary table that is released before the call returns.
     pub fn msm<P: SWCurveConfig>(&mut self, points: &[Affine<P>], scalars: &[&[P::ScalarField]]) -> Vec<Projective<P>> {
+        #[allow(clippy::let_unit_value)]
+        let _ = Layout::<P>::CHECK;
         for s in scalars {
             assert_eq!(s.len(), points.len(), "msm_public_points: length mismatch");
         }
-        let (bases, offset) = self.bases_for(points);
+        let mut temporary = ptr::null_mut();
+        let (bases, offset) = match self.registered(points) {
+            Some(hit) => hit,
+            None => {
+                check(
+                    unsafe {
+                        cg_bases_register(self.ctx, curve_id::<P::ScalarField>(), group_id::<P>(), points.as_ptr() as *const c_void, points.len(),
+                                          Layout::<P>::STRIDE, Layout::<P>::INFINITY_OFFSET as i64, &mut temporary)
+                    },
+                    "cg_bases_register",
+                );
+                (temporary as *const cg_bases, 0)
+            }
+        };
         let ptrs: Vec<*const c_void> = scalars.iter().map(|s| s.as_ptr() as *const c_void).collect();
         let mut out = vec![Projective::<P>::default(); scalars.len()];
-        check(
-            unsafe { cg_msm(self.ctx, bases, offset, points.len(), ptrs.as_ptr(), ptrs.len() as i32, out.as_mut_ptr() as *mut c_void) },
-            "cg_msm",
-        );
+        tracing::trace!("> MSM public points for {} elements", points.len()); // the reference's enter / exit events (rep3.rs:940-944)
+        let rc = unsafe { cg_msm(self.ctx, bases, offset, points.len(), ptrs.as_ptr(), ptrs.len() as i32, out.as_mut_ptr() as *mut c_void) };
+        if !temporary.is_null() {
+            unsafe { cg_bases_release(temporary) };
+        }
+        check(rc, "cg_msm");
+        tracing::trace!("< MSM public points for {} elements", points.len());
         out
     }
 
@@ -156,10 +188,13 @@ impl Gpu {
         assert!(vecs.iter().all(|v| v.len() == n) && n.is_power_of_two(), "fft: vectors must have the domain's (power of two) size");
         let ptrs: Vec<*mut c_void> = vecs.iter_mut().map(|v| v.as_mut_ptr() as *mut c_void).collect();
         let g = coset_gen.as_ref().map_or(ptr::null(), |g| g as *const F as *const c_void);
+        let what = if inverse { "IFFT" } else { "FFT" }; // the reference's enter / exit events (rep3.rs:886-897,905-920)
+        tracing::trace!("> {what} (in place) for {n} elements");
         check(
             unsafe { cg_ntt(self.ctx, curve_id::<F>(), ptrs.as_ptr(), ptrs.len() as i32, n, &group_gen as *const F as *const c_void, inverse as i32, g) },
             "cg_ntt",
         );
+        tracing::trace!("< {what} (in place) for {n} elements");
     }
 
     pub fn mul<F: PrimeField>(&mut self, a: &[F], b: &[F]) -> Vec<F> {
@@ -193,7 +228,9 @@ impl Drop for Gpu {
     fn drop(&mut self) {
         unsafe {
             for t in &self.tables {
-                cg_bases_release(t.bases);
+                if !t.bases.is_null() {
+                    cg_bases_release(t.bases);
+                }
             }
             cg_ctx_destroy(self.ctx);
         }

@@ -12,6 +12,10 @@
 //! let mut prover = CoGroth16::<_, P>::new(protocol);
 //! ```
 //!
+//! The per-call drivers above move the caller's `Vec`s over PCIe on every trait call.  The fast path for Groth16 is `Groth16Session`
+//! (session.rs): the zkey stays resident on the GPU(s) and one call proves for this party, with the network and the randomness of the
+//! stock `Rep3Protocol` behind C callbacks (`rust/co-circom-hip-backend.patch` wires it to `co-circom generate-proof --backend hip`).
+//!
 //! SOURCE ONLY here: the image this repository is built in has no Rust toolchain.  The C++ host mirror
 //! (`collaborative-circom_amd/host/ (headers per layer: formats, network, driver, groth16, plonk, codecs, synth; entry points in capi_*.cpp)`) runs the same call sequence against the same library and is what the tests
 //! exercise; `include/cogroth16_host.h` is its ABI.
@@ -19,9 +23,11 @@ pub mod ffi;
 pub mod gpu;
 pub mod plain;
 pub mod rep3;
+pub mod session;
 pub mod shamir;
 
 pub use gpu::{curve_id, group_id, Gpu, Layout};
 pub use plain::PlainHipDriver;
 pub use rep3::Rep3HipProtocol;
+pub use session::Groth16Session;
 pub use shamir::ShamirHipProtocol;

@@ -1,0 +1,222 @@
+//! The fast path behind `co-circom generate-proof --protocol REP3`: ONE party of a co-groth16 proof on a proving session
+//! (`cgh_session_open` keeps the zkey's tables resident, validated and precomputed on the GPU), with the party's own network and its own
+//! correlated randomness handed to the library as C callbacks (`cgh_session_prove_rep3_party`, include/cogroth16_host.h).
+//!
+//! What stays in Rust, unchanged: `Rep3MpcNet` (every message of the proof goes through `send_bytes` / `recv_bytes`,
+//! mpc-core/src/protocols/rep3/network.rs:137-176), `Rep3Protocol::new` (the PRF set-up, rep3.rs:385-398) and every random draw
+//! (`Rep3Rand`, rep3/rngs.rs:25-62).  What moves: the whole of `CoGroth16::prove` (co-groth16/src/groth16.rs:113-326) between the
+//! draws and the messages — witness map, the two `mul_vec` local products, the five MSMs and the O(1) point algebra — runs inside the
+//! library on device-resident vectors, so the 2 x 128 MiB share vectors cross PCIe once instead of once per trait call (the per-call
+//! drivers of rep3.rs / plain.rs / shamir.rs in this crate remain the drop-in for co-plonk and for mixed deployments).
+//!
+//! Wire format: the messages are byte strings between parties that all run this backend (field vectors as 32-byte Montgomery limbs in
+//! chunks of at most 4 MiB, points as packed affine coordinates); a party running the stock CPU prover cannot be mixed into such a run.
+//!
+//! SOURCE ONLY (no Rust toolchain in the image this repository is built in).  The same entry point is exercised by
+//! tests/test_rep3_party_abi.py: three threads, each through the callback ABI over sockets, bit-identical to the oracle's proofs.
+use crate::gpu::curve_id;
+use ark_ec::{pairing::Pairing, short_weierstrass::{Affine, Projective, SWCurveConfig}, AffineRepr, CurveGroup};
+use ark_ff::PrimeField;
+use bytes::Bytes;
+use mpc_core::protocols::rep3::{id::PartyID, network::{Rep3MpcNet, Rep3Network}, Rep3Protocol};
+use std::{ffi::{c_void, CStr, CString}, io, mem::size_of, os::raw::c_char, path::Path, ptr, slice};
+
+// ---- include/cogroth16_host.h ------------------------------------------------------------------------------------------------------------
+#[repr(C)]
+pub struct cgh_rep3_net {
+    pub user: *mut c_void,
+    pub party_id: i32,
+    pub send_next: Option<unsafe extern "C" fn(*mut c_void, *const c_void, usize) -> i32>,
+    pub recv_prev: Option<unsafe extern "C" fn(*mut c_void, *mut c_void, usize) -> i32>,
+    pub send_prev: Option<unsafe extern "C" fn(*mut c_void, *const c_void, usize) -> i32>,
+    pub recv_next: Option<unsafe extern "C" fn(*mut c_void, *mut c_void, usize) -> i32>,
+    pub recv_prev_pinned: Option<unsafe extern "C" fn(*mut c_void, usize) -> *const c_void>,
+}
+#[repr(C)]
+pub struct cgh_rep3_rand {
+    pub user: *mut c_void,
+    pub masking_field_elements: Option<unsafe extern "C" fn(*mut c_void, usize, *mut u64, *mut *const u64) -> i32>,
+    pub random_fes: Option<unsafe extern "C" fn(*mut c_void, *mut u64, *mut u64) -> i32>,
+    pub masking_ec_element: Option<unsafe extern "C" fn(*mut c_void, i32, *mut u64) -> i32>,
+}
+#[link(name = "cogroth16_host")]
+extern "C" {
+    fn cgh_last_error() -> *const c_char;
+    fn cgh_session_open_multi(devices: *const i32, n_devices: i32, curve: i32, zkey_path: *const c_char, precompute: i32, flags: u32, out: *mut *mut c_void) -> i32;
+    fn cgh_session_close(session: *mut c_void) -> i32;
+    fn cgh_session_prove_rep3_party(session: *mut c_void, pub_in: *const u64, wit_a: *const u64, wit_b: *const u64, net: *const cgh_rep3_net,
+                                    rnd: *const cgh_rep3_rand, out_proof: *mut u64, seconds: *mut f64) -> i32;
+}
+fn host_error() -> String {
+    unsafe {
+        let p = cgh_last_error();
+        if p.is_null() { String::new() } else { CStr::from_ptr(p).to_string_lossy().into_owned() }
+    }
+}
+
+/// A zkey resident on one or several GPUs of this machine (one session per prover process; `ZKey` is fixed for its life, zkey.rs:48-71).
+/// Opening reads the file (mapped, the point sections go to the device where they lie), runs the parser's per-point checks
+/// (circom-types/src/traits.rs:107-155) on the GPU and builds the per-window tables — the work `co-circom.rs:482` does before its timer
+/// starts at `:503`.
+pub struct Groth16Session {
+    handle: *mut c_void,
+}
+unsafe impl Send for Groth16Session {}
+
+impl Groth16Session {
+    /// `devices`: the party's GPUs (devices[0] runs the witness map; every device holds a slice of the five queries).
+    /// `validate = false` skips the point checks for a file that was validated before.
+    pub fn open<F: PrimeField>(devices: &[i32], zkey: &Path, validate: bool) -> eyre::Result<Self> {
+        let path = CString::new(zkey.to_string_lossy().as_bytes())?;
+        let mut handle = ptr::null_mut();
+        let rc = unsafe { cgh_session_open_multi(devices.as_ptr(), devices.len() as i32, curve_id::<F>(), path.as_ptr(), -1, if validate { 0 } else { 1 }, &mut handle) };
+        if rc != 0 {
+            eyre::bail!("cgh_session_open_multi: {}", host_error());
+        }
+        Ok(Self { handle })
+    }
+
+    /// `CoGroth16::<Rep3Protocol<_, Rep3MpcNet>, P>::prove` (groth16.rs:113-139) for this party.  `public_inputs` includes the leading one
+    /// (`SharedWitness::public_inputs`, co-circom-snarks/src/lib.rs:32-34); `(wit_a, wit_b)` = `SharedWitness::witness.get_ab()`
+    /// (rep3/fieldshare.rs:245-247).  Returns (pi_a, pi_b, pi_c) — the fields of `Groth16Proof` (circom-types/src/groth16/proof.rs:8-29).
+    pub fn prove_rep3<P: Pairing>(
+        &self,
+        protocol: &mut Rep3Protocol<P::ScalarField, Rep3MpcNet>,
+        public_inputs: &[P::ScalarField],
+        wit_a: &[P::ScalarField],
+        wit_b: &[P::ScalarField],
+    ) -> io::Result<(P::G1Affine, P::G2Affine, P::G1Affine)>
+    where
+        P::G1: PackedAffine,
+        P::G2: PackedAffine,
+    {
+        assert_eq!(wit_a.len(), wit_b.len());
+        let span = tracing::trace_span!("cogroth16_hip::prove_rep3", n = wit_a.len());
+        let _enter = span.enter();
+        let mut state = Callbacks::<P> { protocol, error: None };
+        let id: usize = state.protocol.network_mut().get_id().into();
+        let net = cgh_rep3_net {
+            user: &mut state as *mut _ as *mut c_void,
+            party_id: id as i32,
+            send_next: Some(send_next::<P>),
+            recv_prev: Some(recv_prev::<P>),
+            send_prev: Some(send_prev::<P>),
+            recv_next: Some(recv_next::<P>),
+            recv_prev_pinned: None, // BytesMut frames live in pageable memory
+        };
+        let rnd = cgh_rep3_rand {
+            user: &mut state as *mut _ as *mut c_void,
+            masking_field_elements: Some(masking_field_elements::<P>),
+            random_fes: Some(random_fes::<P>),
+            masking_ec_element: Some(masking_ec_element::<P>),
+        };
+        let fq = size_of::<<P::G1 as CurveGroup>::BaseField>() / 8;
+        let mut proof = vec![0u64; 8 * fq];
+        let rc = unsafe {
+            cgh_session_prove_rep3_party(self.handle, public_inputs.as_ptr() as *const u64, wit_a.as_ptr() as *const u64, wit_b.as_ptr() as *const u64,
+                                         &net, &rnd, proof.as_mut_ptr(), ptr::null_mut())
+        };
+        if rc != 0 {
+            // the io::Error a callback met (rep3.rs:661-669 would have returned it with `?`), else the library's message
+            return Err(state.error.take().unwrap_or_else(|| io::Error::new(io::ErrorKind::Other, host_error())));
+        }
+        let (a, rest) = proof.split_at(2 * fq);
+        let (b, c) = rest.split_at(4 * fq);
+        Ok((<P::G1 as PackedAffine>::from_packed(a), <P::G2 as PackedAffine>::from_packed(b), <P::G1 as PackedAffine>::from_packed(c)))
+    }
+}
+impl Drop for Groth16Session {
+    fn drop(&mut self) {
+        unsafe { cgh_session_close(self.handle) };
+    }
+}
+
+/// packed affine `x || y` in Montgomery limbs, all zero = the point at infinity (the zkey's own encoding, circom-types/src/traits.rs:107-155)
+pub trait PackedAffine: CurveGroup {
+    fn from_packed(limbs: &[u64]) -> Self::Affine;
+}
+impl<Q: SWCurveConfig> PackedAffine for Projective<Q> {
+    fn from_packed(limbs: &[u64]) -> Affine<Q> {
+        if limbs.iter().all(|&w| w == 0) {
+            return Affine::<Q>::zero();
+        }
+        let n = size_of::<Q::BaseField>();
+        // Fp<MontBackend, N> / QuadExtField are plain limb arrays in memory (layout asserted in gpu.rs::Layout::CHECK)
+        unsafe {
+            let x = ptr::read_unaligned(limbs.as_ptr() as *const Q::BaseField);
+            let y = ptr::read_unaligned((limbs.as_ptr() as *const u8).add(n) as *const Q::BaseField);
+            Affine::<Q>::new_unchecked(x, y)
+        }
+    }
+}
+
+// ---- the callbacks: closures over the stock protocol object ------------------------------------------------------------------------------------
+struct Callbacks<'a, P: Pairing> {
+    protocol: &'a mut Rep3Protocol<P::ScalarField, Rep3MpcNet>,
+    error: Option<io::Error>,
+}
+fn fail<P: Pairing>(s: &mut Callbacks<P>, e: io::Error) -> i32 {
+    let code = e.raw_os_error().unwrap_or(5);
+    s.error.get_or_insert(e);
+    if code == 0 { 5 } else { code }
+}
+unsafe fn send<P: Pairing>(user: *mut c_void, to_next: bool, data: *const c_void, bytes: usize) -> i32 {
+    let s = &mut *(user as *mut Callbacks<P>);
+    let net = s.protocol.network_mut();
+    let id = net.get_id();
+    let target: PartyID = if to_next { id.next_id() } else { id.prev_id() };
+    tracing::trace!("> send {bytes} bytes to {target:?}");
+    match net.send_bytes(target, Bytes::copy_from_slice(slice::from_raw_parts(data as *const u8, bytes))) {
+        Ok(()) => 0,
+        Err(e) => fail(s, e),
+    }
+}
+unsafe fn recv<P: Pairing>(user: *mut c_void, from_prev: bool, data: *mut c_void, bytes: usize) -> i32 {
+    let s = &mut *(user as *mut Callbacks<P>);
+    let net = s.protocol.network_mut();
+    let id = net.get_id();
+    let from: PartyID = if from_prev { id.prev_id() } else { id.next_id() };
+    match net.recv_bytes(from) {
+        Ok(frame) if frame.len() == bytes => {
+            ptr::copy_nonoverlapping(frame.as_ptr(), data as *mut u8, bytes);
+            tracing::trace!("< received {bytes} bytes from {from:?}");
+            0
+        }
+        Ok(_) => fail(s, io::Error::new(io::ErrorKind::InvalidData, "During execution of mul_vec in MPC: Invalid number of elements received")), // rep3.rs:663-668
+        Err(e) => fail(s, e),
+    }
+}
+unsafe extern "C" fn send_next<P: Pairing>(u: *mut c_void, d: *const c_void, n: usize) -> i32 { send::<P>(u, true, d, n) }
+unsafe extern "C" fn send_prev<P: Pairing>(u: *mut c_void, d: *const c_void, n: usize) -> i32 { send::<P>(u, false, d, n) }
+unsafe extern "C" fn recv_prev<P: Pairing>(u: *mut c_void, d: *mut c_void, n: usize) -> i32 { recv::<P>(u, true, d, n) }
+unsafe extern "C" fn recv_next<P: Pairing>(u: *mut c_void, d: *mut c_void, n: usize) -> i32 { recv::<P>(u, false, d, n) }
+
+/// `n` draws of `Rep3Rand::masking_field_element` (rngs.rs:37-40) written into the library's page-locked buffer: the upload to the GPU
+/// starts from there without another copy.  The draws are the reference's, in the reference's order (both `mul_vec` calls of
+/// groth16.rs:174,190 precede every other draw of the proof), so the peers' `rng2` streams stay in step.
+unsafe extern "C" fn masking_field_elements<P: Pairing>(u: *mut c_void, n: usize, buf: *mut u64, out: *mut *const u64) -> i32 {
+    let s = &mut *(u as *mut Callbacks<P>);
+    let dst = slice::from_raw_parts_mut(buf as *mut P::ScalarField, n);
+    for d in dst.iter_mut() {
+        *d = s.protocol.masking_field_element();
+    }
+    *out = buf;
+    0
+}
+unsafe extern "C" fn random_fes<P: Pairing>(u: *mut c_void, a: *mut u64, b: *mut u64) -> i32 {
+    let s = &mut *(u as *mut Callbacks<P>);
+    let (x, y) = s.protocol.random_fes();
+    ptr::write_unaligned(a as *mut P::ScalarField, x);
+    ptr::write_unaligned(b as *mut P::ScalarField, y);
+    0
+}
+unsafe extern "C" fn masking_ec_element<P: Pairing>(u: *mut c_void, group: i32, out: *mut u64) -> i32 {
+    let s = &mut *(u as *mut Callbacks<P>);
+    // Projective{x, y, z} is the ABI's Jacobian layout (gpu.rs::Layout::CHECK)
+    if group == crate::ffi::CG_G1 {
+        ptr::write_unaligned(out as *mut P::G1, s.protocol.masking_ec_element::<P::G1>());
+    } else {
+        ptr::write_unaligned(out as *mut P::G2, s.protocol.masking_ec_element::<P::G2>());
+    }
+    0
+}
