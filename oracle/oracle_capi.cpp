@@ -486,6 +486,22 @@ int orc_pairing_selfcheck(int curve, const uint64_t* scalar) {
     return 0;
 }
 
+// e(P, Q) as snarkjs / arkworks define it (pairing.hpp::optimal_ate_pairing), in the JSON layout of `vk_alphabeta_12`
+// (circom-types/src/groth16/verification_key.rs:46-49): out[i][j][k] = coefficient c_i.c_j.c_k of Fq12 = Fq6[w]/(w^2 - v),
+// Fq6 = Fq2[v]/(v^3 - xi), 12 base-field elements in Montgomery form
+int orc_pairing(int curve, const uint64_t* g1_affine, const uint64_t* g2_affine, uint64_t* out) {
+    DISPATCH(curve, {
+        typedef typename C::Fq Fq;
+        auto e = optimal_ate_pairing<C>(ld_g1<Fq>(g1_affine), ld_g2<Fq>(g2_affine));
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) {           // coefficient of w^(2j + i)
+            st<Fq>(out + ((i * 3 + j) * 2 + 0) * Fq::N, e.c[2 * j + i].c0);
+            st<Fq>(out + ((i * 3 + j) * 2 + 1) * Fq::N, e.c[2 * j + i].c1);
+        }
+        return 0;
+    });
+    return 0;
+}
+
 // bench.py cpu_baseline leg: seconds for one REP3 party's prove compute at m = 2^log_m (stage = 4 doubles, optional)
 double orc_bench_rep3_party(int curve, int log_m, int threads, uint64_t seed, double* stage) {
     try {

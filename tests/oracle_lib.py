@@ -272,6 +272,15 @@ def verify(curve, vk, pub, proof):
                                       _p(ic), C.c_size_t(pub.shape[0]), _p(pub), _p(np.ascontiguousarray(proof, dtype=np.uint64)))))
 
 
+def pairing(curve, g1_affine, g2_affine):
+    """e(P, Q) with snarkjs' / arkworks' value convention (oracle/pairing.hpp::optimal_ate_pairing) as (2, 3, 2, limbs): the JSON layout
+    of `vk_alphabeta_12`, Montgomery form"""
+    nq = 6 if curve == BLS12_381 else 4
+    out = np.zeros((2, 3, 2, nq), dtype=np.uint64)
+    _chk(lib().orc_pairing(curve, _p(np.ascontiguousarray(g1_affine, dtype=np.uint64)), _p(np.ascontiguousarray(g2_affine, dtype=np.uint64)), _p(out)))
+    return out
+
+
 def pairing_selfcheck(curve, scalar):
     return bool(_chk(lib().orc_pairing_selfcheck(curve, _p(np.ascontiguousarray(scalar, dtype=np.uint64)))))
 

@@ -245,3 +245,24 @@ def test_cpu_baseline_transforms_equal_the_plain_ones(log_n):
     plain radix-2 transforms of oracle/poly.hpp produce, below, at and above the block size"""
     for curve in (orc.BN254, orc.BLS12_381):
         assert orc.lib().orc_bench_ntt_selfcheck(curve, log_n, 4) == 1
+
+
+@pytest.mark.parametrize("curve_name,circuit", [(c, k) for c in ("bn254", "bls12_381") for k in ("multiplier2", "poseidon")])
+def test_vk_alphabeta_12_pairing_kat(curve_name, circuit):
+    """`vk_alphabeta_12` of verification_key.json (circom-types/src/groth16/verification_key.rs:46-49) is e(vk_alpha_1, vk_beta_2), twelve
+    base-field values written by snarkjs and parsed by the reference into `P::TargetField`: an exact-value KAT for the optimal ate
+    pairing (Miller loop, Frobenius twist constants, final exponentiation with the libraries' exponent multiple, tower layout)."""
+    curve = {"bn254": BN254, "bls12_381": BLS12_381}[curve_name]
+    path = os.path.join(GOLDEN, "groth16", curve_name, circuit, "verification_key.json")
+    vk = orc.vk_from_json(curve, path)
+    want = json.load(open(path))["vk_alphabeta_12"]
+    got = orc.pairing(curve, vk["alpha1"], vk["beta2"])
+    for i in range(2):
+        for j in range(3):
+            for k in range(2):
+                np.testing.assert_array_equal(got[i, j, k], orc.from_dec(curve, orc.FQ, want[i][j][k]), err_msg=f"c{i}.c{j}.c{k}")
+    # and it is bilinear: e(P, Q) with P = alpha, Q = beta differs from e(2 alpha, beta) by a square (checked through e(alpha, 2 beta))
+    two = orc.from_dec(curve, orc.FR, 2)
+    a2 = orc.points_mul(curve, G1, vk["alpha1"][None], two[None])[0]
+    b2 = orc.points_mul(curve, G2, vk["beta2"][None], two[None])[0]
+    np.testing.assert_array_equal(orc.pairing(curve, a2, vk["beta2"]), orc.pairing(curve, vk["alpha1"], b2))
