@@ -57,6 +57,11 @@ template <class Fr> int launch_ntt_dif_pass(hipStream_t st, NttVecs src, NttVecs
 template <class Fr> int launch_bitrev_scale(hipStream_t st, NttVecs dst, NttVecs src, int nvec, size_t n, int log_m, const Fr* scale, const Fr* c_lo, const Fr* c_hi, int log_lo);
 }  // namespace cg
 
+// every device allocation of the library outside cg_dev_alloc: hipMalloc that, when the device is out of memory, gives back the blocks
+// parked by cg_dev_free on the current device (up to CG_DEV_CACHE_MB of them) and tries once more
+hipError_t hip_malloc_flush(void** p, size_t bytes);
+template <class T> hipError_t hip_malloc_flush(T** p, size_t bytes) { return hip_malloc_flush((void**)p, bytes); }
+
 namespace {
 
 struct Arena {
@@ -157,7 +162,7 @@ int ensure_arena(cg_ctx* ctx, size_t bytes) {
     if (ctx->arena.base) { if (idle) HIPCHK(hipFree(ctx->arena.base)); else ctx->retired.push_back(ctx->arena.base); }
     ctx->arena.base = nullptr; ctx->arena.cap = 0;
     size_t want = align_up(bytes + bytes / 8, 1 << 20);
-    HIPCHK(hipMalloc((void**)&ctx->arena.base, want));
+    HIPCHK(hip_malloc_flush((void**)&ctx->arena.base, want));
     ctx->arena.cap = want;
     return 0;
 }
@@ -298,7 +303,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
                 HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->sortst));
                 if (ctx->gather_buf) HIPCHK(hipFree(ctx->gather_buf));
                 ctx->gather_buf = nullptr; ctx->gather_cap = 0;
-                HIPCHK(hipMalloc(&ctx->gather_buf, need)); ctx->gather_cap = need;
+                HIPCHK(hip_malloc_flush(&ctx->gather_buf, need)); ctx->gather_cap = need;
             }
             size_t used = 0;
             for (auto& g : groups) {
@@ -562,9 +567,9 @@ int get_twiddles(cg_ctx* ctx, int curve, int log_m, const Fr& w, const Fr** out)
     std::vector<Fr> lo, hi;
     host_pow_tables(w, Fr::one(), log_lo, hi_n, lo, hi);
     Fr *d_lo = nullptr, *d_hi = nullptr, *d_tw = nullptr;
-    HIPCHK(hipMalloc((void**)&d_lo, lo.size() * sizeof(Fr)));
-    HIPCHK(hipMalloc((void**)&d_hi, hi.size() * sizeof(Fr)));
-    HIPCHK(hipMalloc((void**)&d_tw, std::max<size_t>(m - 1, 1) * sizeof(Fr)));
+    HIPCHK(hip_malloc_flush((void**)&d_lo, lo.size() * sizeof(Fr)));
+    HIPCHK(hip_malloc_flush((void**)&d_hi, hi.size() * sizeof(Fr)));
+    HIPCHK(hip_malloc_flush((void**)&d_tw, std::max<size_t>(m - 1, 1) * sizeof(Fr)));
     HIPCHK(hipMemcpyAsync(d_lo, lo.data(), lo.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_hi, hi.data(), hi.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     { int rc = launch_build_twiddles<Fr>(ctx->stream, d_tw, m, log_m, d_lo, d_hi, log_lo); if (rc) return rc; }
@@ -591,9 +596,9 @@ int get_twiddles_lazy(cg_ctx* ctx, int curve, int log_m, const Fr& w, const void
     Fr c32 = Fr::one(); for (int i = 0; i < 5; i++) c32 = c32 + c32;
     Fr *d_lo = nullptr, *d_hi = nullptr; void* d_tw = nullptr;
     const size_t bytes = lazy29_bytes(std::max<size_t>(m / 2, 1));
-    HIPCHK(hipMalloc((void**)&d_lo, lo.size() * sizeof(Fr)));
-    HIPCHK(hipMalloc((void**)&d_hi, hi.size() * sizeof(Fr)));
-    HIPCHK(hipMalloc(&d_tw, bytes));
+    HIPCHK(hip_malloc_flush((void**)&d_lo, lo.size() * sizeof(Fr)));
+    HIPCHK(hip_malloc_flush((void**)&d_hi, hi.size() * sizeof(Fr)));
+    HIPCHK(hip_malloc_flush(&d_tw, bytes));
     HIPCHK(hipMemcpyAsync(d_lo, lo.data(), lo.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_hi, hi.data(), hi.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
     { int rc = launch_build_twiddles_lazy<Fr>(ctx->stream, d_tw, m, log_m, d_lo, d_hi, log_lo, c32); if (rc) return rc; }
@@ -617,8 +622,8 @@ int get_coset_tables(cg_ctx* ctx, int curve, int log_m, const Fr& g, const Fr& s
     std::vector<Fr> lo, hi;
     host_pow_tables(g, scale, log_lo, hi_n, lo, hi);
     CosetTables t; t.log_lo = log_lo;
-    HIPCHK(hipMalloc(&t.lo, lo.size() * sizeof(Fr)));
-    HIPCHK(hipMalloc(&t.hi, hi.size() * sizeof(Fr)));
+    HIPCHK(hip_malloc_flush(&t.lo, lo.size() * sizeof(Fr)));
+    HIPCHK(hip_malloc_flush(&t.hi, hi.size() * sizeof(Fr)));
     HIPCHK(hipMemcpy(t.lo, lo.data(), lo.size() * sizeof(Fr), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(t.hi, hi.data(), hi.size() * sizeof(Fr), hipMemcpyHostToDevice));
     if (ctx->cosets.size() >= 64) {   // callers that scale by per-proof challenges would otherwise grow the cache without bound
@@ -876,6 +881,18 @@ void dev_cache_flush(DevCache& dc) {                     // caller holds dc.mu
     dc.parked.clear(); dc.parked_bytes = 0;
 }
 }  // namespace
+extern "C++" hipError_t hip_malloc_flush(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipErrorOutOfMemory) return e;
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return e;
+    DevCache& dc = dev_cache(d);
+    std::lock_guard<std::mutex> l(dc.mu);
+    if (dc.parked.empty()) return e;
+    (void)hipGetLastError();
+    dev_cache_flush(dc);
+    return hipMalloc(p, bytes);
+}
 int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr) {
     if (!ctx || !d_ptr) return fail(CG_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1062,13 +1079,13 @@ static int32_t bases_register_impl(cg_ctx* ctx, int32_t curve, int32_t group, co
         if (stride < pt) return fail(CG_ERR_ARG, "stride smaller than a point record");
         if (inf_off >= 0 && (size_t)inf_off >= stride) return fail(CG_ERR_ARG, "infinity_offset outside the record");
         cg_bases* b = new cg_bases{ctx->device, curve, group, n, pt, nullptr};
-        HIPCHK(hipMalloc(&b->d_pts, std::max<size_t>(n * pt, 16)));
+        HIPCHK(hip_malloc_flush(&b->d_pts, std::max<size_t>(n * pt, 16)));
         if (n) {
             if (src_on_device) HIPCHK(hipMemcpyAsync(b->d_pts, src, n * pt, hipMemcpyDeviceToDevice, ctx->stream));
             else if (stride == pt && inf_off < 0) HIPCHK(hipMemcpyAsync(b->d_pts, src, n * pt, hipMemcpyHostToDevice, ctx->stream));
             else {
                 void* d_raw = nullptr;
-                HIPCHK(hipMalloc(&d_raw, n * stride));
+                HIPCHK(hip_malloc_flush(&d_raw, n * stride));
                 HIPCHK(hipMemcpyAsync(d_raw, src, n * stride, hipMemcpyHostToDevice, ctx->stream));
                 { int rc = pack_bases_launch<F>(ctx->stream, (const uint8_t*)d_raw, n, stride, (long)inf_off, (Affine<F>*)b->d_pts); if (rc) return rc; }
                 HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1089,8 +1106,8 @@ static int32_t bases_register_impl(cg_ctx* ctx, int32_t curve, int32_t group, co
             if (live.size() * 8 <= n * 7) {
                 cg_bases* cb = new cg_bases{ctx->device, curve, group, live.size(), pt, nullptr};
                 cb->no_inf = true;
-                HIPCHK(hipMalloc(&cb->d_pts, std::max<size_t>(live.size() * pt, 16)));
-                HIPCHK(hipMalloc((void**)&b->d_live, std::max<size_t>(live.size() * 4, 16)));
+                HIPCHK(hip_malloc_flush(&cb->d_pts, std::max<size_t>(live.size() * pt, 16)));
+                HIPCHK(hip_malloc_flush((void**)&b->d_live, std::max<size_t>(live.size() * 4, 16)));
                 if (!live.empty()) {
                     HIPCHK(hipMemcpy(b->d_live, live.data(), live.size() * 4, hipMemcpyHostToDevice));
                     int rc = gather_points_launch<F>(ctx->stream, (Affine<F>*)cb->d_pts, (const Affine<F>*)b->d_pts, b->d_live, live.size()); if (rc) return rc;
@@ -1132,7 +1149,7 @@ int32_t cg_bases_check_on_curve(cg_ctx* ctx, const cg_bases* b, uint64_t* n_bad,
     return with_group(b->curve, b->group, [&](auto ftag, auto) -> int {
         typedef decltype(ftag) F;
         unsigned long long* d = nullptr; unsigned long long h[2] = {0ull, ~0ull};
-        HIPCHK(hipMalloc((void**)&d, 16));
+        HIPCHK(hip_malloc_flush((void**)&d, 16));
         HIPCHK(hipMemcpyAsync(d, h, 16, hipMemcpyHostToDevice, ctx->stream));
         int rc = check_on_curve_launch<F>(ctx->stream, (const Affine<F>*)b->d_pts, b->n, CurveB<F>::get(), d);
         if (rc) return rc;
@@ -1152,7 +1169,7 @@ int32_t cg_bases_check_subgroup(cg_ctx* ctx, const cg_bases* b, uint64_t* n_bad,
     return with_group(b->curve, b->group, [&](auto ftag, auto frtag) -> int {
         typedef decltype(ftag) F; typedef decltype(frtag) Fr;
         unsigned long long* d = nullptr; unsigned long long h[2] = {0ull, ~0ull};
-        HIPCHK(hipMalloc((void**)&d, 16));
+        HIPCHK(hip_malloc_flush((void**)&d, 16));
         HIPCHK(hipMemcpyAsync(d, h, 16, hipMemcpyHostToDevice, ctx->stream));
         int rc = check_subgroup_launch<F, Fr>(ctx->stream, (const Affine<F>*)b->d_pts, b->n, d);
         if (rc) return rc;
@@ -1169,6 +1186,7 @@ int32_t cg_bases_precompute(cg_ctx* ctx, cg_bases* b, int32_t c) {
     // c = 0: pick by table size (measured per extra table of a shared-schedule call): 2^19 buckets only pay for themselves above
     // ~3 M points in G1 (2 M points: 5.4 ms at c = 17, 5.9 at c = 20) and above ~1.5 M in G2, whose additions cost three times as much
     // (small tables: 2^15 buckets, a shorter bit-sum reduction: 2^16-constraint step 5.25 -> 4.7 ms, 2^18 9.0 -> 8.5 ms)
+    const bool auto_window = c == 0;
     if (c == 0) c = b->n > ((size_t)3 << (b->group == CG_G1 ? 20 : 19)) ? 20 : (b->n <= ((size_t)1 << 18) ? 16 : 17);
     if (c < 8 || c > 22) return fail(CG_ERR_ARG, "precompute window must be 0 (auto) or in [8, 22]");
     if (b->device != ctx->device) return fail(CG_ERR_ARG, "bases live on another device");
@@ -1179,7 +1197,12 @@ int32_t cg_bases_precompute(cg_ctx* ctx, cg_bases* b, int32_t c) {
         typedef decltype(ftag) F; typedef decltype(frtag) Fr;
         const int nwin = Fr::Params::BITS / c + 1;
         const size_t n = std::max<size_t>(b->n, 1);
-        HIPCHK(hipMalloc(&b->d_pre, (size_t)nwin * n * sizeof(Affine<F>)));
+        const hipError_t e_pre = hip_malloc_flush(&b->d_pre, (size_t)nwin * n * sizeof(Affine<F>));
+        if (e_pre == hipErrorOutOfMemory && auto_window) {     // the tables are an optimisation: a table that does not fit keeps the per-window bucket sets
+            (void)hipGetLastError(); b->d_pre = nullptr;
+            return 0;
+        }
+        HIPCHK(e_pre);
         Affine<F>* tab = (Affine<F>*)b->d_pre;
         HIPCHK(hipMemcpyAsync(tab, b->d_pts, b->n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, ctx->stream));
         for (int j = 1; j < nwin; j++) { int rc = precompute_window_launch<F>(ctx->stream, tab + (size_t)(j - 1) * b->n, tab + (size_t)j * b->n, b->n, c); if (rc) return rc; }
@@ -1209,12 +1232,12 @@ int32_t cg_bases_synth_multiples(cg_ctx* ctx, int32_t curve, int32_t group, uint
         acc = XYZZ<F>::infinity();
         for (size_t j = 0; j < H; j++) { hi[j] = acc; acc = xyzz_add(acc, step); }
         XYZZ<F>*d_lo = nullptr, *d_hi = nullptr;
-        HIPCHK(hipMalloc((void**)&d_lo, T * sizeof(XYZZ<F>))); HIPCHK(hipMalloc((void**)&d_hi, H * sizeof(XYZZ<F>)));
+        HIPCHK(hip_malloc_flush((void**)&d_lo, T * sizeof(XYZZ<F>))); HIPCHK(hip_malloc_flush((void**)&d_hi, H * sizeof(XYZZ<F>)));
         HIPCHK(hipMemcpy(d_lo, lo.data(), T * sizeof(XYZZ<F>), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d_hi, hi.data(), H * sizeof(XYZZ<F>), hipMemcpyHostToDevice));
         cg_bases* b = new cg_bases{ctx->device, curve, group, n, sizeof(Affine<F>), nullptr};
         b->no_inf = first >= 1 && first + n > first;             // (first + i) G with 1 <= first + i < 2^64 < r is never the point at infinity
-        HIPCHK(hipMalloc(&b->d_pts, std::max<size_t>(n * sizeof(Affine<F>), 16)));
+        HIPCHK(hip_malloc_flush(&b->d_pts, std::max<size_t>(n * sizeof(Affine<F>), 16)));
         int rc = synth_points_launch<F>(ctx->stream, d_lo, d_hi, log_t, n, (Affine<F>*)b->d_pts);
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1232,9 +1255,9 @@ int32_t cg_bases_from_scalars(cg_ctx* ctx, int32_t curve, int32_t group, const v
         Affine<F> ga; memcpy(&ga, src, sizeof ga);
         const int nwin = (Fr::Params::BITS + 7) / 8;
         Affine<F>* d_tab = nullptr;
-        HIPCHK(hipMalloc((void**)&d_tab, (size_t)nwin * 255 * sizeof(Affine<F>)));
+        HIPCHK(hip_malloc_flush((void**)&d_tab, (size_t)nwin * 255 * sizeof(Affine<F>)));
         cg_bases* b = new cg_bases{ctx->device, curve, group, n, sizeof(Affine<F>), nullptr};
-        hipError_t e = hipMalloc(&b->d_pts, std::max<size_t>(n * sizeof(Affine<F>), 16));
+        hipError_t e = hip_malloc_flush(&b->d_pts, std::max<size_t>(n * sizeof(Affine<F>), 16));
         if (e != hipSuccess) { hipFree(d_tab); delete b; return fail(CG_ERR_OOM, "cg_bases_from_scalars: out of device memory"); }
         int rc = fixed_base_mul_launch<F, Fr>(ctx->stream, ga, (const Fr*)d_scalars, n, d_tab, (Affine<F>*)b->d_pts);
         hipError_t e2 = hipStreamSynchronize(ctx->stream);
@@ -1291,7 +1314,7 @@ int32_t cg_msm(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, cons
     std::vector<void*> d(k, nullptr);
     const size_t bytes = std::max<size_t>(n * 32, 16);
     for (int j = 0; j < k; j++) {
-        HIPCHK(hipMalloc(&d[j], bytes));
+        HIPCHK(hip_malloc_flush(&d[j], bytes));
         if (n) HIPCHK(hipMemcpyAsync(d[j], h_scalars[j], n * 32, hipMemcpyHostToDevice, ctx->stream));
     }
     int rc = cg_msm_dev(ctx, bases, offset, n, (const void* const*)d.data(), k, h_out);
@@ -1318,7 +1341,7 @@ int32_t cg_ntt(cg_ctx* ctx, int32_t curve, void* const* h_vecs, int32_t k, size_
     if (k < 1 || k > NTT_MAX_VECS) return fail(CG_ERR_ARG, "k out of range");
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<void*> d(k, nullptr);
-    for (int j = 0; j < k; j++) { HIPCHK(hipMalloc(&d[j], std::max<size_t>(n * 32, 16))); HIPCHK(hipMemcpyAsync(d[j], h_vecs[j], n * 32, hipMemcpyHostToDevice, ctx->stream)); }
+    for (int j = 0; j < k; j++) { HIPCHK(hip_malloc_flush(&d[j], std::max<size_t>(n * 32, 16))); HIPCHK(hipMemcpyAsync(d[j], h_vecs[j], n * 32, hipMemcpyHostToDevice, ctx->stream)); }
     int rc = cg_ntt_dev(ctx, curve, d.data(), k, n, h_group_gen, inverse, h_coset_gen);
     if (!rc) for (int j = 0; j < k; j++) { hipError_t e = hipMemcpyAsync(h_vecs[j], d[j], n * 32, hipMemcpyDeviceToHost, ctx->stream); if (e != hipSuccess) rc = fail(CG_ERR_HIP, hipGetErrorString(e)); }
     hipStreamSynchronize(ctx->stream);
@@ -1446,7 +1469,7 @@ static int32_t host_vec_call(cg_ctx* ctx, size_t n, int n_in, const void* const*
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<void*> d(n_in + 1, nullptr);
     const size_t bytes = std::max<size_t>(n * 32, 16);
-    for (int j = 0; j <= n_in; j++) HIPCHK(hipMalloc(&d[j], bytes));
+    for (int j = 0; j <= n_in; j++) HIPCHK(hip_malloc_flush(&d[j], bytes));
     for (int j = 0; j < n_in; j++) if (h_in[j]) HIPCHK(hipMemcpyAsync(d[j], h_in[j], n * 32, hipMemcpyHostToDevice, ctx->stream));
     std::vector<void*> args(d.begin(), d.begin() + n_in);
     for (int j = 0; j < n_in; j++) if (!h_in[j]) args[j] = nullptr;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -22,10 +23,15 @@ inline int fail(int code, const std::string& msg) { g_err = msg; return code; }
 constexpr int GRID_CAP = 2048;   // grid-stride kernels: 256 CUs x 8 workgroups
 inline int grid_for(size_t n, int block = 256) { size_t g = (n + block - 1) / block; return (int)std::min<size_t>(std::max<size_t>(g, 1), GRID_CAP); }
 // Launch attributes (the dynamic-LDS ceiling) belong to the (function, device) pair: call sites set them the first time they run on each
-// device of the process (a multi-device session launches the same kernels on every GPU).  A repeated set is harmless.
+// device of the process (a multi-device session launches the same kernels on every GPU).  Several party threads reach the same call
+// site at once (cgh_prove_rep3): a thread may launch only after the attribute calls have SUCCEEDED on its device, so the flag is set
+// after them (`mark`), never before; two threads that both find it unset both set the attribute, which is harmless, and a failed
+// set leaves the flag clear for the next call.
 struct PerDeviceOnce {
-    bool done[64] = {};
-    bool first() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true; if (done[d]) return false; done[d] = true; return true; }
+    std::atomic<bool> done[64] = {};
+    static int dev() { int d = 0; return hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64 ? d : -1; }
+    bool pending() const { const int d = dev(); return d < 0 || !done[d].load(std::memory_order_acquire); }
+    void mark() { const int d = dev(); if (d >= 0) done[d].store(true, std::memory_order_release); }
 };
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int log2_floor(size_t n) { int l = 0; while (((size_t)2 << l) <= n) l++; return l; }

@@ -93,7 +93,7 @@ template <class Fr> int launch_build_twiddles(hipStream_t st, Fr* tw, size_t m, 
 }
 template <class Fr> int launch_ntt_dif_pass(hipStream_t st, NttVecs src, NttVecs dst, int nvec, size_t n, int log_m, int s0, int k, int t, const Fr* tw) {
     static PerDeviceOnce attr_set;
-    if (attr_set.first()) { HIPCHK(hipFuncSetAttribute((const void*)k_ntt_dif_pass<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); }
+    if (attr_set.pending()) { HIPCHK(hipFuncSetAttribute((const void*)k_ntt_dif_pass<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_set.mark(); }
     const int E = 1 << (k + t);
     hipLaunchKernelGGL((k_ntt_dif_pass<Fr>), dim3((unsigned)(n / E), nvec), dim3(NTT_THREADS), (size_t)E * 32, st, src, dst, log_m, s0, k, t, tw);
     HIPCHK(hipGetLastError());
@@ -106,9 +106,10 @@ template <class Fr> int launch_build_twiddles_lazy(hipStream_t st, void* tw, siz
 }
 template <class Fr> int launch_ntt_ct_pass(hipStream_t st, bool first, NttVecs src, NttVecs dst, int nvec, size_t n, int log_m, int s0, int k, int t, const void* tw) {
     static PerDeviceOnce attr_set;
-    if (attr_set.first()) {
+    if (attr_set.pending()) {
         HIPCHK(hipFuncSetAttribute((const void*)k_ntt_ct_pass<Fr, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 36 << NTT_TILE_LOG));
         HIPCHK(hipFuncSetAttribute((const void*)k_ntt_ct_pass<Fr, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 36 << NTT_TILE_LOG));
+        attr_set.mark();
     }
     const int E = 1 << (k + t);
     if (first) hipLaunchKernelGGL((k_ntt_ct_pass<Fr, true>), dim3((unsigned)(n / E), nvec), dim3(NTT_THREADS), (size_t)E * 36, st, src, dst, log_m, s0, k, t, tw);
@@ -175,9 +176,10 @@ template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, siz
         static const bool staged = getenv("CG_SORT_NO_STAGING") == nullptr;        // measurement knob
         if (staged && nregions <= STAGE_MAX_REGIONS) {
             static PerDeviceOnce attr_set;
-            if (attr_set.first()) {
+            if (attr_set.pending()) {
                 HIPCHK(hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_staged_lds(STAGE_MAX_REGIONS)));
                 HIPCHK(hipFuncSetAttribute((const void*)k_items_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ITEMS_STAGED_LDS));
+                attr_set.mark();
             }
             hipLaunchKernelGGL(k_part_scatter_staged, dim3((unsigned)ptiles), dim3(STAGE_THREADS), part_staged_lds(nregions), st, digits, n, c, nwin, shared, nregions, region_cursor, items);
         } else

@@ -120,9 +120,10 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     HIPCHK(hipEventRecord(ev_merged, st2));                                          // the last reader of the sorted schedule (offsets / counts)
     if (g.bitsum) {
         static PerDeviceOnce attr_set2;
-        if (attr_set2.first()) {
+        if (attr_set2.pending()) {
             HIPCHK(hipFuncSetAttribute((const void*)k_msm_bitsum_partial<B, bitsum_items<B>()>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * sizeof(B))));
             HIPCHK(hipFuncSetAttribute((const void*)k_msm_bitsum_final<F, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * sizeof(B))));
+            attr_set2.mark();
         }
         hipLaunchKernelGGL((k_msm_bitsum_partial<B, bitsum_items<B>()>), dim3((unsigned)(c * g.bit_groups)), dim3(256), 256 * sizeof(B), st2, buckets, g.nb, g.bit_groups, partials);
         hipLaunchKernelGGL((k_msm_bitsum_final<F, B>), dim3((unsigned)c), dim3(64), 64 * sizeof(B), st2, partials, g.bit_groups, wsums);
@@ -137,7 +138,7 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     constexpr int WT = sizeof(B) > 160 ? 128 : 256;
     {
         static PerDeviceOnce attr_set;
-        if (attr_set.first()) { HIPCHK(hipFuncSetAttribute((const void*)k_msm_window_sum<F, B, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WT * sizeof(B)))); }
+        if (attr_set.pending()) { HIPCHK(hipFuncSetAttribute((const void*)k_msm_window_sum<F, B, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WT * sizeof(B)))); attr_set.mark(); }
     }
     hipLaunchKernelGGL((k_msm_window_sum<F, B, WT>), dim3(g.ngroups), dim3(WT), WT * sizeof(B), st2, partials, g.group_segs, wsums);
     if (evs) HIPCHK(hipEventRecord(evs[3], st2));

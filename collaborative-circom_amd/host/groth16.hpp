@@ -88,28 +88,34 @@ public:
         auto h_msm = dz.sliced ? driver.msm_begin_sharded(dz, false, h) : driver.msm_begin_multi({dz.h}, {0}, {CG_G1}, h.n, h, false);   // :248
         FieldShare r = rs_plain ? rs_plain[0] : driver.rand();                                         // :134-135
         FieldShare s = rs_plain ? rs_plain[1] : driver.rand();
-        PointShare h_acc = driver.msm_finish(h_msm, 0);
-        PointShare l_aux_acc = driver.msm_finish(aux_msm, 0);
-        mk.mark("msm h + l");
+        // The GPU is busy with the MSMs for tens of milliseconds from here on.  Everything of :258-297 that does not read an MSM result
+        // — the product r*s (one network round) and the five multiplications of public points by r, s, r*s (254-bit scalar
+        // multiplications on the host) — is done while it works, and the MSM results are then collected in the order the aux context
+        // completes them (a, b1, b2, l) with h, which starts last, at the end.  Messages between the parties keep the reference's order:
+        // mul (:258), open_point (:276), scalar_mul (:291), open_two_points (:316); MSMs involve no network.
         const Point delta_g1 = pt_from_affine(c, CG_G1, z.delta_g1.data());
+        const Point delta_g2 = pt_from_affine(c, CG_G2, z.delta_g2.data());
         FieldShare rs = driver.mul(r, s);                                                              // :258
         PointShare r_s_delta_g1 = driver.scalar_mul_public_point(delta_g1, rs);                        // :259
         PointShare r_g1 = driver.scalar_mul_public_point(delta_g1, r);                                 // :265
+        PointShare s_g1 = driver.scalar_mul_public_point(delta_g1, s);                                 // :283
+        PointShare s_g2 = driver.scalar_mul_public_point(delta_g2, s);                                 // :297
+        mk.mark("scalar steps under the msms");
         PointShare g_a = calculate_coeff(r_g1, z.a_query, CG_G1, z.alpha_g1, input_assignment, driver.msm_finish(aux_msm, 1));   // :267
         Point g_a_opened = driver.open_point(g_a);                                                     // :276
         PointShare s_g_a = driver.scalar_mul_public_point(g_a_opened, s);                              // :277
-        PointShare s_g1 = driver.scalar_mul_public_point(delta_g1, s);                                 // :283
         PointShare g1_b = calculate_coeff(s_g1, z.b_g1_query, CG_G1, z.beta_g1, input_assignment, driver.msm_finish(aux_msm, 2));   // :284
         PointShare r_g1_b = driver.scalar_mul(g1_b, r);                                                // :291
-        const Point delta_g2 = pt_from_affine(c, CG_G2, z.delta_g2.data());
-        PointShare s_g2 = driver.scalar_mul_public_point(delta_g2, s);                                 // :297
         PointShare g2_b = calculate_coeff(s_g2, z.b_g2_query, CG_G2, z.beta_g2, input_assignment, driver.msm_finish(aux_msm, 3));   // :298
+        mk.mark("msm a, b1, b2 + their scalar steps");
+        PointShare l_aux_acc = driver.msm_finish(aux_msm, 0);                                          // :251
+        PointShare h_acc = driver.msm_finish(h_msm, 0);                                                // :248
+        mk.mark("msm l + h");
         PointShare g_c = s_g_a;                                                                        // :308-312
         driver.add_assign_points(g_c, r_g1_b);
         driver.sub_assign_points(g_c, r_s_delta_g1);
         driver.add_assign_points(g_c, l_aux_acc);
         driver.add_assign_points(g_c, h_acc);
-        mk.mark("msm a, b1, b2 + scalar steps");
         auto opened = driver.open_two_points(g_c, g2_b);                                               // :316
         mk.mark("open");
         driver.msm_release(aux_msm); driver.msm_release(h_msm);

@@ -106,7 +106,9 @@ int32_t cg_bases_check_subgroup(cg_ctx* ctx, const cg_bases* bases, uint64_t* n_
  * MSMs over such a table then use ONE bucket set for all windows: 254/c + 1 mixed additions per point with c up to 22 instead
  * of 16 at the default c = 16, and no doublings in the final fold.  The zkey queries are fixed for the life of the process
  * (zkey.rs:48-71), so this is part of registration, not of the proof.  Results are unchanged.
- * c = 0 picks the window by table size (20 above ~3 M points in G1 / ~1.5 M in G2, 16 up to 2^18 points, else 17); otherwise 8 <= c <= 22. */
+ * c = 0 picks the window by table size (20 above ~3 M points in G1 / ~1.5 M in G2, 16 up to 2^18 points, else 17); otherwise 8 <= c <= 22.
+ * With c = 0 a table whose window copies do not fit in device memory simply stays without them (the call succeeds, MSMs over it use the
+ * per-window bucket sets); an explicit c that does not fit fails with CG_ERR_OOM. */
 int32_t cg_bases_precompute(cg_ctx* ctx, cg_bases* bases, int32_t c);
 size_t  cg_bases_len(const cg_bases* bases);
 
