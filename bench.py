@@ -436,6 +436,9 @@ def cpu_baseline(log_m_target=22, threads_cap=None, budget_s=45.0):
                            "note": "same inputs; " + ("both settings cover all 15 MSM windows, so the MSM stage times are shared and only the other stages were re-timed" if shared else "full second run")}}
 
 
+SESSION_PROOFS = 5
+
+
 def session_leg(ctx, log_m, device):
     """The product's real entry point under the driver's clock (co-circom.rs:503-506 times exactly this): a proving session on a
     zkey FILE (product-side synthetic circuit with a valid CRS, cgh_synth_circuit), one plain proof and one REP3 party proved
@@ -466,19 +469,54 @@ def session_leg(ctx, log_m, device):
         a, b, c = pin(host(da)), pin(host(db)), pin(host(dc))
         streams = [pin(host(rand_fr(2 * m + 4, device, g))) for _ in range(3)]
         del da, db, dc, dw
-        ses.prove_rep3(w[:2], [a, b, c], [c, a, b], streams, solo=False)             # warm-up
-        runs = [ses.prove_rep3(w[:2], [a, b, c], [c, a, b], streams) for _ in range(2)]
-        proofs = runs[-1][0]
+        # Three parties, one thread each, every one through the ONE-PARTY entry point (cgh_session_prove_rep3_party: the caller's network
+        # and randomness behind C callback tables, what `co-circom generate-proof --backend hip` binds); the transport is the in-process
+        # loopback, party 0's incoming traffic is recorded.  Then party 0 ALONE on the GPU, as in a deployment (one party per machine),
+        # served its recorded traffic from page-locked memory: network time excluded, every byte of shares, masks and exchanged vectors
+        # crossing PCIe inside the timed call.
+        import threading
+        wa, wb = [a, b, c], [c, a, b]
+
+        def three_parties(record):
+            hub = cg.LoopbackHub()
+            rands = [cg.StreamRand(CURVE, streams[i], streams[(i + 2) % 3]) for i in range(3)]
+            nets = [hub.net(i, record=(record and i == 0)) for i in range(3)]
+            out, errs = [None] * 3, [None] * 3
+
+            def party(i):
+                try: out[i], _ = cg.host_prove_rep3_party(ses, w[:2], wa[i], wb[i], nets[i], rands[i].table)
+                except Exception as e: errs[i] = e; hub.abort()
+            th = [threading.Thread(target=party, args=(i,)) for i in range(3)]
+            t0 = time.perf_counter()
+            for t in th: t.start()
+            for t in th: t.join()
+            dt = time.perf_counter() - t0
+            for r_ in rands: r_.close()
+            if any(errs): raise RuntimeError(f"REP3 parties failed: {errs}")
+            return hub, np.stack(out), dt
+        hub, _, _ = three_parties(False); hub.close()                                   # warm-up
+        t_three = []
+        for _ in range(2):
+            hub, proofs, dt = three_parties(True); t_three.append(dt)
+            if _ == 0: hub.close()
         agree = bool((proofs[0] == proofs[1]).all() and (proofs[1] == proofs[2]).all())
+        solo = []
+        for _ in range(max(3, SESSION_PROOFS)):
+            rnd = cg.StreamRand(CURVE, streams[0], streams[2])
+            got, sec = cg.host_prove_rep3_party(ses, w[:2], wa[0], wb[0], hub.replay_net(0), rnd.table)
+            rnd.close()
+            if not (got == proofs[0]).all(): raise RuntimeError("the party served its recorded traffic produced a different proof")
+            solo.append(sec)
+        hub.close()
         ses.close()
         for x in [a, b, c] + streams:
             ctx.host_free(x)
         nc = m - 2
-        t_plain, t_party, t_three = min(plain), min(x[2] for x in runs), min(x[1] for x in runs)
-        return {"entry_points": "cgh_session_prove_plain / cgh_session_prove_rep3 (host buffers in, proof out)", "pcie_inclusive": True,
-                "plain_ms": t_plain * 1e3, "plain_constraints_per_s": nc / t_plain,
-                "rep3_party_ms": t_party * 1e3, "rep3_party_constraints_per_s": nc / t_party,
-                "rep3_three_parties_one_gpu_ms": t_three * 1e3, "three_parties_agree": agree,
+        t_plain, t_party, t_party_mean = min(plain), min(solo), sum(solo) / len(solo)
+        return {"entry_points": "cgh_session_prove_plain / cgh_session_prove_rep3_party (host buffers in, proof out; network and randomness through the callback tables)",
+                "pcie_inclusive": True, "plain_ms": t_plain * 1e3, "plain_constraints_per_s": nc / t_plain,
+                "rep3_party_ms": t_party_mean * 1e3, "rep3_party_ms_min": t_party * 1e3, "rep3_party_proofs": len(solo), "rep3_party_constraints_per_s": nc / t_party_mean,
+                "rep3_three_parties_one_gpu_ms": min(t_three) * 1e3, "three_parties_agree": agree,
                 "zkey": {"generate_s": t_gen, "session_open_s": t_open, "file_bytes": os.path.getsize(zp),
                          "note": "session_open = map + decode the file, upload, validate every point on the GPU (on-curve + subgroup), precompute the window tables"}}
     finally:
@@ -711,7 +749,14 @@ def main():
             "setup_s": {"synthetic_bases": w.setup_bases_s, "precompute_tables": w.setup_precompute_s},
         }
         if not args.no_session and world == 1 and args.log_m <= 22:
-            out["session"] = session_leg(ctx, args.log_m, device)
+            out["session"] = ses_ = session_leg(ctx, args.log_m, device)
+            # What co-circom.rs:503-506 times, through the entry point the CLI binds: ONE REP3 party, host buffers in, proof out, every share,
+            # mask and exchanged vector crossing PCIe inside the call (mean over `proofs` calls).  `value` above stays the inputs-resident
+            # step the bench contract defines (a PCIe-inclusive rate is never `value`); this is the figure a deployment sees.
+            out["product_entry"] = {"entry": "cgh_session_prove_rep3_party", "value": ses_["rep3_party_constraints_per_s"], "unit": "constraints/s",
+                                    "ms_per_proof": ses_["rep3_party_ms"], "ms_per_proof_min": ses_["rep3_party_ms_min"], "proofs": ses_["rep3_party_proofs"],
+                                    "pcie_inclusive": True, "network": "loopback replay from page-locked memory (excluded, SURVEY.md 8d)",
+                                    "randomness": "masks pre-drawn by the caller (ChaCha12 draws excluded, as in cpu_baseline)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.log_m)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

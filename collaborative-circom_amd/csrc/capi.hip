@@ -114,6 +114,8 @@ struct cg_ctx {
     // ticket = running copy number (31 bits); slot = ticket % COPY_TICKETS holds its event.  A slot is recycled only after its
     // previous copy has completed (copy_begin waits for it), so a ticket older than the slot's current owner names a finished copy.
     hipEvent_t copy_ev[COPY_TICKETS] = {}; uint32_t copy_id[COPY_TICKETS] = {}; hipEvent_t ev_copy_order = nullptr; uint32_t copy_next = 0;
+    // cg_msm_scalars_after: the scalar-side schedule of component j of the NEXT begin call waits for this event (an upload still in flight)
+    hipEvent_t comp_after[4] = {};
     // priority class of each stream: +1 high, 0 normal, -1 low (pooled_stream)
     int prio_main = 0, prio_side = 1, prio_copy = 0;
     uint32_t msm_chunk = 0;                               // cg_msm_set_chunk
@@ -418,6 +420,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         std::vector<MsmSortPtrs> sps(k);
         auto launch_sort = [&](int j) -> int {             // scalar side: once per scalar vector, on the sort stream
             const int ss_ = j % nsched;
+            if (j < 4 && ctx->comp_after[j]) HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->comp_after[j], 0));   // this component's scalars are still on their way up
             if (j >= nsched) {                                   // accumulates and merges of component j-2 have consumed the slot
                 HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_sched_free[ss_], 0));
                 HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_merged[ss_], 0));
@@ -1293,12 +1296,23 @@ int32_t cg_msm_set_window(cg_ctx* ctx, int32_t c) {
     ctx->msm_window = c;
     return 0;
 }
+int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int32_t copy_ticket) {
+    if (!ctx || !owner || component < 0 || component >= 4) return fail(CG_ERR_ARG, "bad argument");
+    if (copy_ticket < 0 || !owner->copy_ev[copy_ticket % cg_ctx::COPY_TICKETS]) return fail(CG_ERR_ARG, "bad copy ticket");
+    const int slot = copy_ticket % cg_ctx::COPY_TICKETS;
+    ctx->comp_after[component] = owner->copy_id[slot] == (uint32_t)copy_ticket ? owner->copy_ev[slot] : nullptr;   // recycled: completed long ago
+    return 0;
+}
 int32_t cg_msm_dev_begin(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* d_scalars, int32_t k, int32_t* ticket) {
-    return msm_begin_impl(ctx, bases, offset, n, d_scalars, k, ticket);
+    const int rc = msm_begin_impl(ctx, bases, offset, n, d_scalars, k, ticket);
+    if (ctx) for (hipEvent_t& e : ctx->comp_after) e = nullptr;
+    return rc;
 }
 int32_t cg_msm_dev_begin_multi(cg_ctx* ctx, int32_t n_tables, const cg_bases* const* bases, const size_t* offsets, size_t n,
                                const void* const* d_scalars, int32_t k, int32_t* tickets) {
-    return msm_begin_multi_impl(ctx, n_tables, bases, offsets, n, d_scalars, k, tickets);
+    const int rc = msm_begin_multi_impl(ctx, n_tables, bases, offsets, n, d_scalars, k, tickets);
+    if (ctx) for (hipEvent_t& e : ctx->comp_after) e = nullptr;
+    return rc;
 }
 int32_t cg_msm_end(cg_ctx* ctx, int32_t ticket, void* h_out_jacobian) { return msm_end_impl(ctx, ticket, h_out_jacobian); }
 int32_t cg_msm_dev(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* d_scalars, int32_t k, void* h_out) {

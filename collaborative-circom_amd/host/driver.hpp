@@ -6,7 +6,10 @@
 namespace cgh {
 
 // ---- driver ------------------------------------------------------------------------------------------------------------
-struct ShareVec { void* c[2] = {nullptr, nullptr}; size_t n = 0; };   // device; REP3 uses c[0] = a, c[1] = b; plain only c[0]
+struct ShareVec {   // device; REP3 uses c[0] = a, c[1] = b; plain only c[0]
+    void* c[2] = {nullptr, nullptr}; size_t n = 0;
+    int32_t up[2] = {-1, -1}; cg_ctx* up_ctx = nullptr;   // asynchronous uploads still filling the components (copy tickets of up_ctx)
+};
 struct FieldShare { Fr c[2]; };
 struct PointShare { Point c[2]; };
 struct DeviceMatrix { uint32_t* row_ptr; uint32_t* col; void* coeff; size_t rows; };
@@ -326,11 +329,11 @@ public:
         ShareVec v; v.n = n;
         if (n >= XCHG_ASYNC_MIN && cg_host_is_pinned(a) && (!b || k() < 2 || cg_host_is_pinned(b))) {   // page-locked shares: asynchronous DMA, the stream waits
             v.c[0] = dalloc(n * 32);
-            int32_t tk = upload_staged(v.c[0], a, n);
-            if (b && k() == 2) { v.c[1] = dalloc(n * 32); tk = upload_staged(v.c[1], b, n); }
-            if (tk >= 0) CG(cg_copy_fence(ctx, tk));
-            if (aux) CG(cg_copy_wait(ctx, tk));                                        // the second context reads the shares too
-            return v;
+            int32_t tk = v.up[0] = upload_staged(v.c[0], a, n);
+            if (b && k() == 2) { v.c[1] = dalloc(n * 32); tk = v.up[1] = upload_staged(v.c[1], b, n); }
+            v.up_ctx = ctx;
+            if (tk >= 0) CG(cg_copy_fence(ctx, tk));                                   // this context's stream: behind the last copy (they complete in order)
+            return v;                                                                   // other readers: msm_begin_multi (per component, on the device)
         }
         v.c[0] = dalloc(n * 32); CG(cg_dev_upload(ctx, v.c[0], a, n * 32));
         if (k() == 2) { v.c[1] = dalloc(n * 32); CG(cg_dev_upload(ctx, v.c[1], b, n * 32)); }
@@ -664,7 +667,11 @@ public:
         static const uint32_t plain_chunk = getenv("CGH_PLAIN_CHUNK") ? (uint32_t)atoi(getenv("CGH_PLAIN_CHUNK")) : 0u;  // tuning knob
         if (p.on != ctx) CG(cg_msm_set_chunk(p.on, mode == Mode::Rep3 && n >= XCHG_ASYNC_MIN ? bulk_chunk : plain_chunk));
         const void* sc[2] = {s.c[0], s.c[1]};
-        if (p.on != ctx) CG(cg_ctx_sync(ctx));                                          // the scalars were produced on this driver's stream
+        if (p.on != ctx) {
+            if (s.up_ctx) {                                                             // fresh uploads: component j's schedule waits for ITS copy on the device,
+                for (int j = 0; j < k(); j++) if (s.up[j] >= 0) CG(cg_msm_scalars_after(p.on, j, s.up_ctx, s.up[j]));   // a is accumulated while b is still crossing PCIe
+            } else CG(cg_ctx_sync(ctx));                                                // the scalars were produced on this driver's stream
+        }
         CG(cg_msm_dev_begin_multi(p.on, (int32_t)tables.size(), tables.data(), offsets.data(), n, sc, k(), p.tickets.data()));
         return p;
     }

@@ -81,23 +81,21 @@ struct RecordingNetwork : Rep3Network {
     void recv_prev(void* d, size_t b) override { inner->recv_prev(d, b); from_prev->add(d, b); }
     void recv_next(void* d, size_t b) override { inner->recv_next(d, b); from_next->add(d, b); }
 };
-struct ReplayNetwork : Rep3Network {
-    int me; RecordedQueue* from_prev; RecordedQueue* from_next;
+struct ReplayNetwork : Rep3Network {      // reads the recorded queues without consuming them: every replay object starts at the first message
+    int me; RecordedQueue* from_prev; RecordedQueue* from_next; size_t at_prev = 0, at_next = 0;
     ReplayNetwork(int i, RecordedQueue* p, RecordedQueue* q) : me(i), from_prev(p), from_next(q) {}
     int id() const override { return me; }
     void send_next(const void*, size_t) override {}
     void send_prev(const void*, size_t) override {}
-    static void pop(RecordedQueue* q, void* d, size_t b) {
-        if (q->q.empty() || q->q.front().n != b) throw std::runtime_error("replay: message sequence differs from the recorded run");
-        const RecordedMsg& m = q->q.front();
-        memcpy(d, m.pinned ? m.pinned : (const void*)m.small.data(), b); q->q.pop_front();
+    static const RecordedMsg& peek(RecordedQueue* q, size_t at, size_t b) {
+        if (at >= q->q.size() || q->q[at].n != b) throw std::runtime_error("replay: message sequence differs from the recorded run");
+        return q->q[at];
     }
-    void recv_prev(void* d, size_t b) override { pop(from_prev, d, b); }
-    void recv_next(void* d, size_t b) override { pop(from_next, d, b); }
+    void recv_prev(void* d, size_t b) override { const RecordedMsg& m = peek(from_prev, at_prev, b); memcpy(d, m.pinned ? m.pinned : (const void*)m.small.data(), b); at_prev++; }
+    void recv_next(void* d, size_t b) override { const RecordedMsg& m = peek(from_next, at_next, b); memcpy(d, m.pinned ? m.pinned : (const void*)m.small.data(), b); at_next++; }
     const void* recv_prev_pinned(size_t b) override {
-        if (from_prev->q.empty() || from_prev->q.front().n != b) throw std::runtime_error("replay: message sequence differs from the recorded run");
-        const void* p = from_prev->q.front().pinned;
-        if (p) from_prev->q.pop_front();                 // the memory itself stays with the queue's owner list
+        const void* p = peek(from_prev, at_prev, b).pinned;
+        if (p) at_prev++;                                // the memory itself stays with the queue's owner list
         return p;
     }
 };
