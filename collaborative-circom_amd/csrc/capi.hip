@@ -86,6 +86,7 @@ struct MsmTicket {
     int nsums = 0;            // partial sums per component delivered by the GPU
     bool plain_fold = false;  // true: add them (precomputed tables); false: Horner with c doublings (classic)
     bool bit_fold = false;    // the sums are the per-bit sums T_k of a small shared bucket set: Horner with ONE doubling per step
+    bool grid_fold = false; int log_l = 0, log_h = 0; uint32_t gc = 1, gr = 1;   // row / column bit sums of a large shared bucket set (k_msm_grid_*)
     void* h_pinned = nullptr; size_t pinned_bytes = 0;   // k * nwin window sums (XYZZ)
     hipEvent_t done = nullptr;
 };
@@ -383,7 +384,8 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         slots[b] = ticket_slot(ctx);
         MsmTicket& t = ctx->tickets[slots[b]];
         t.live = true;   // reserve before asking for the next slot
-        t.curve = curve; t.group = bases[b]->group; t.k = k; t.c = c; t.nwin = nwin; t.nsums = nsums; t.plain_fold = shared && !geom.bitsum; t.bit_fold = geom.bitsum;
+        t.curve = curve; t.group = bases[b]->group; t.k = k; t.c = c; t.nwin = nwin; t.nsums = nsums; t.plain_fold = shared && !geom.bitsum && !geom.grid; t.bit_fold = geom.bitsum;
+        t.grid_fold = geom.grid; t.log_l = geom.log_l; t.log_h = geom.log_h; t.gc = geom.gc; t.gr = geom.gr;
         t.optimistic = cap != 0; t.bases = bases[b]; t.offset = offsets ? offsets[b] : 0; t.n = n; t.scalars.assign(d_scalars, d_scalars + (n ? k : 0));
         if (!t.h_flags) HIPCHK(hipHostMalloc((void**)&t.h_flags, 8 * sizeof(uint32_t), hipHostMallocDefault));
         for (int i = 0; i < 8; i++) t.h_flags[i] = 0;
@@ -502,7 +504,18 @@ int msm_end_impl(cg_ctx* ctx, int ticket, void* h_out) {
         Jacobian<F>* out = (Jacobian<F>*)h_out;
         for (int j = 0; j < t.k; j++) {
             Jacobian<F> r;
-            if (t.bit_fold) {                                   // sum_k 2^k T_k
+            if (t.grid_fold) {
+                // sum_b (b + 1) B_b = sum_k 2^k TC_k + 2^log_l sum_k 2^k TR_k: bit sums of the column side (k <= log_l, gc partial sums each)
+                // then of the row side (k < log_h, gr each), merged into one sequence U_k and folded with one doubling per bit
+                const XYZZ<F>* hs = h + (size_t)j * t.nsums;
+                std::vector<XYZZ<F>> U((size_t)t.log_l + t.log_h + 1, XYZZ<F>::infinity());
+                size_t at = 0;
+                for (int kk = 0; kk <= t.log_l; kk++) for (uint32_t g = 0; g < t.gc; g++) U[kk] = xyzz_add(U[kk], hs[at++]);
+                for (int kk = 0; kk < t.log_h; kk++) for (uint32_t g = 0; g < t.gr; g++) U[t.log_l + kk] = xyzz_add(U[t.log_l + kk], hs[at++]);
+                XYZZ<F> acc = U.back();
+                for (size_t i = U.size() - 1; i-- > 0;) acc = xyzz_add(xyzz_dbl(acc), U[i]);
+                r = xyzz_to_jacobian(acc);
+            } else if (t.bit_fold) {                            // sum_k 2^k T_k
                 XYZZ<F> acc = h[(size_t)j * t.nsums + t.nsums - 1];
                 for (int i = t.nsums - 2; i >= 0; i--) acc = xyzz_add(xyzz_dbl(acc), h[(size_t)j * t.nsums + i]);
                 r = xyzz_to_jacobian(acc);

@@ -48,6 +48,9 @@ struct MsmGeom {            // derived sizes shared by the host-side planner and
     uint32_t chunk_len, nchunks;
     bool bitsum;            // small shared bucket set: per-bit tree sums instead of the running-sum chain (ngroups = c bit sums)
     uint32_t bit_groups;    // workgroups per bit in k_msm_bitsum_partial
+    // large shared bucket set: row / column sums + per-bit sums (k_msm_grid_partial / k_msm_grid_bitsum); ngroups = (log_l + 1) gc + log_h gr
+    bool grid; int log_l, log_h; uint32_t gc, gr;
+    size_t grid_partials() const { return grid ? ((size_t)1 << log_h) / 32 * ((size_t)1 << log_l) + ((size_t)1 << log_h) * (((size_t)1 << log_l) / 64) : 0; }
 };
 constexpr int MSM_SHARED_GROUPS = 16;
 // resident_lanes: lanes of the accumulation kernel the chip holds at once (0 = unknown).  Its workgroups do equal work and finish
@@ -72,6 +75,14 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_
     g.bitsum = shared && g.nb <= (1u << 16) && g.nb >= 4096 && !no_bitsum;
     g.bit_groups = std::max<uint32_t>(1, (g.nb / 2 + 256 * BITSUM_ITEMS - 1) / (256 * BITSUM_ITEMS));
     if (g.bitsum) g.ngroups = c;
+    static const bool no_grid = getenv("CG_NO_GRID_REDUCE") != nullptr;                  // tuning knob (A/B against the running-sum chain)
+    g.grid = shared && g.nb > (1u << 16) && !no_grid; g.log_l = 10; g.log_h = c - 1 - 10; g.gc = g.gr = 1;
+    if (g.grid) {
+        const size_t H = (size_t)1 << g.log_h, L = (size_t)1 << g.log_l, per_group = 256 * BITSUM_ITEMS;
+        g.gc = (uint32_t)std::max<size_t>(1, (H / 32 * (L / 2) + per_group - 1) / per_group);
+        g.gr = (uint32_t)std::max<size_t>(1, (H / 2 * (L / 64) + per_group - 1) / per_group);
+        g.ngroups = (int)((g.log_l + 1) * g.gc + g.log_h * g.gr);
+    }
     const size_t entries = (size_t)nwin * n;
     static const size_t chunk_max = [] { const char* e = getenv("CG_MSM_CHUNK"); return e ? (size_t)atoi(e) : (size_t)128; }();   // tuning knob
     static const size_t chunk_min = [] { const char* e = getenv("CG_MSM_CHUNK_MIN"); return e ? (size_t)atoi(e) : (size_t)16; }();  // tuning knob (8 -> 16: 2^17-constraint step 7.3 -> 5.8 ms: half the continuation pieces)

@@ -25,7 +25,7 @@ size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared) {
     typedef typename BucketOf<F>::type B;
     g.bit_groups = bitsum_groups<B>(g.nb);
     return align_up(g.nbuckets * sizeof(B)) + align_up((size_t)g.nchunks * sizeof(B)) + align_up((size_t)g.nchunks * 4) +
-           align_up(std::max((size_t)g.nsets * g.segs, (size_t)64 * g.bit_groups) * sizeof(B)) + align_up((size_t)std::max(g.ngroups, 64) * sizeof(XYZZ<F>));
+           align_up(std::max({(size_t)g.nsets * g.segs, (size_t)64 * g.bit_groups, g.grid_partials()}) * sizeof(B)) + align_up((size_t)std::max(g.ngroups, 64) * sizeof(XYZZ<F>));
 }
 
 // buckets -> window sums for one (bases, sorted schedule) pair; the nwin window sums land in h_out (pinned) via an async copy.
@@ -45,7 +45,7 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     B* buckets = (B*)take(g.nbuckets * sizeof(B));
     B* cont = (B*)take((size_t)g.nchunks * sizeof(B));
     uint32_t* cont_bucket = (uint32_t*)take((size_t)g.nchunks * 4);
-    B* partials = (B*)take(std::max((size_t)g.nsets * g.segs, (size_t)64 * g.bit_groups) * sizeof(B));
+    B* partials = (B*)take(std::max({(size_t)g.nsets * g.segs, (size_t)64 * g.bit_groups, g.grid_partials()}) * sizeof(B));
     XYZZ<F>* wsums = (XYZZ<F>*)take((size_t)std::max(g.ngroups, 64) * sizeof(XYZZ<F>));
     HIPCHK(hipMemsetAsync(buckets, 0, g.nbuckets * sizeof(B), st));                // all-zero = infinity (empty buckets are never written)
     if (evs) HIPCHK(hipEventRecord(evs[0], st));                                     // [0, 1] bracket the accumulation KERNEL alone (what rocprofv3 lists per launch)
@@ -130,6 +130,23 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
         if (evs) HIPCHK(hipEventRecord(evs[3], st2));
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_out, wsums, (size_t)c * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st2));
+        HIPCHK(hipEventRecord(ev_red, st2));
+        return 0;
+    }
+    if (g.grid) {
+        static PerDeviceOnce attr_set3;
+        if (attr_set3.pending()) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_msm_grid_partial<B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * sizeof(B))));
+            HIPCHK(hipFuncSetAttribute((const void*)k_msm_grid_bitsum<F, B, BITSUM_ITEMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * sizeof(B))));
+            attr_set3.mark();
+        }
+        const uint32_t H = 1u << g.log_h, L = 1u << g.log_l;
+        B* colpart = partials; B* rowpart = partials + (size_t)(H / GRID_TR) * L;
+        hipLaunchKernelGGL((k_msm_grid_partial<B>), dim3((H / GRID_TR) * (L / GRID_TC)), dim3(256), 256 * sizeof(B), st2, buckets, (uint32_t)g.log_l, g.nb, colpart, rowpart);
+        hipLaunchKernelGGL((k_msm_grid_bitsum<F, B, BITSUM_ITEMS>), dim3((unsigned)g.ngroups), dim3(256), 256 * sizeof(B), st2, colpart, rowpart, (uint32_t)g.log_l, (uint32_t)g.log_h, g.gc, g.gr, wsums);
+        if (evs) HIPCHK(hipEventRecord(evs[3], st2));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_out, wsums, (size_t)g.ngroups * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st2));
         HIPCHK(hipEventRecord(ev_red, st2));
         return 0;
     }

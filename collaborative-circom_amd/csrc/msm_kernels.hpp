@@ -605,6 +605,93 @@ __global__ void __launch_bounds__(64) k_msm_bitsum_final(const B* __restrict__ p
     if (threadIdx.x == 0) st_struct(bit_sums + blockIdx.x, bk_to_xyzz<F>(sh[0]));
 }
 
+// Bucket reduction for LARGE shared bucket sets (per-window precomputed tables: 2^19 buckets at c = 20), two launches instead of a
+// chain of ~90 dependent additions on half a wave per SIMD (k_msm_reduce_segments + k_msm_window_sum: 2.2 additions per bucket, 0.77 ms
+// alone for G1, 1.97 ms for G2).  The bucket index is split b = hi * L + lo (L = 2^10 columns, H = nb / L rows), weight w = b + 1:
+//     sum_b w B_b = L * sum_hi hi * R_hi + sum_lo (lo + 1) * C_lo,     R_hi = row sums, C_lo = column sums      (2 additions per bucket)
+// and the two small weighted sums are done by bits, sum_w w X_w = sum_k 2^k T_k with T_k = the sum of the X_w whose weight has bit k
+// set (plain log-depth tree sums), the host finishing with one Horner pass as for k_msm_bitsum_*.
+//   k_msm_grid_partial: workgroup = 32 rows x 64 columns: 8 serial additions per lane in each direction + short LDS trees ->
+//       colpart[H / 32][L] and rowpart[H][L / 64]                                   (2^19 buckets: 256 workgroups, 65 536 lanes)
+//   k_msm_grid_bitsum:  workgroup (side, bit k, group g): 256 lanes x ITEMS partials whose weight has bit k set + LDS tree -> one
+//       canonical XYZZ sum per workgroup for the host (62 of them at 2^19 buckets)
+constexpr int GRID_LOG_L = 10, GRID_TR = 32, GRID_TC = 64;
+template <class B>
+__global__ void __launch_bounds__(256) k_msm_grid_partial(const B* __restrict__ buckets, uint32_t log_l, uint32_t nb, B* __restrict__ colpart, B* __restrict__ rowpart) {
+    extern __shared__ uint4 lds_raw[];
+    B* sh = reinterpret_cast<B*>(lds_raw);
+    const uint32_t L = 1u << log_l, ncb = L / GRID_TC;
+    const uint32_t cb = blockIdx.x % ncb, rb = blockIdx.x / ncb, t = threadIdx.x;
+    const B* tile = buckets + (size_t)rb * GRID_TR * L + (size_t)cb * GRID_TC;
+    {   // columns: lane = (row quarter, column); 8 rows each, then 4 -> 1 through LDS
+        const uint32_t col = t & 63u, rq = t >> 6;
+        B acc = ld_struct(tile + (size_t)(rq * 8) * L + col);
+        for (uint32_t i = 1; i < 8; i++) acc = bk_add(acc, ld_struct(tile + (size_t)(rq * 8 + i) * L + col));
+        sh[t] = acc;
+        __syncthreads();
+        for (int off = 128; off >= 64; off >>= 1) {
+            if ((int)t < off) acc = bk_add(sh[t], sh[t + off]);
+            __syncthreads();
+            if ((int)t < off) sh[t] = acc;
+            __syncthreads();
+        }
+        if (t < 64) st_struct(colpart + (size_t)rb * L + (size_t)cb * GRID_TC + t, acc);
+        __syncthreads();
+    }
+    {   // rows: lane = (row, segment of 8 columns); 8 -> 1 through LDS
+        const uint32_t row = t >> 3, seg = t & 7u;
+        const B* src = tile + (size_t)row * L + seg * 8;
+        B acc = ld_struct(src);
+        for (uint32_t i = 1; i < 8; i++) acc = bk_add(acc, ld_struct(src + i));
+        sh[t] = acc;
+        __syncthreads();
+        for (uint32_t off = 4; off >= 1; off >>= 1) {
+            if (seg < off) acc = bk_add(sh[t], sh[t + off]);
+            __syncthreads();
+            if (seg < off) sh[t] = acc;
+            __syncthreads();
+        }
+        if (seg == 0) st_struct(rowpart + (size_t)(rb * GRID_TR + row) * ncb + cb, acc);
+    }
+}
+// j-th integer (j >= 0) whose bit k is set
+__device__ __forceinline__ uint32_t nth_with_bit(uint32_t j, uint32_t k) { return ((j >> k) << (k + 1)) | (1u << k) | (j & ((1u << k) - 1u)); }
+template <class F, class B, int ITEMS>
+__global__ void __launch_bounds__(256) k_msm_grid_bitsum(const B* __restrict__ colpart, const B* __restrict__ rowpart, uint32_t log_l, uint32_t log_h,
+                                                         uint32_t gc, uint32_t gr, XYZZ<F>* __restrict__ sums) {
+    extern __shared__ uint4 lds_raw[];
+    B* sh = reinterpret_cast<B*>(lds_raw);
+    const uint32_t L = 1u << log_l, H = 1u << log_h, nrb = H / GRID_TR, ncb = L / GRID_TC, t = threadIdx.x;
+    const uint32_t njc = (log_l + 1) * gc;
+    B acc = bk_inf<B>();
+    if (blockIdx.x < njc) {                                   // column side: element (rb, j), weight = column + 1 = j-th value with bit k, <= L
+        const uint32_t k = blockIdx.x / gc, g = blockIdx.x % gc, half = L / 2;
+        for (uint32_t i = 0; i < (uint32_t)ITEMS; i++) {
+            const uint32_t e = (g * 256u + t) * ITEMS + i;
+            if (e >= nrb * half) break;
+            const uint32_t w = nth_with_bit(e % half, k);
+            if (w <= L) acc = bk_add(acc, ld_struct(colpart + (size_t)(e / half) * L + (w - 1)));
+        }
+    } else {                                                  // row side: element (j, cb), weight = row = j-th value with bit k, < H
+        const uint32_t idx = blockIdx.x - njc, k = idx / gr, g = idx % gr;
+        for (uint32_t i = 0; i < (uint32_t)ITEMS; i++) {
+            const uint32_t e = (g * 256u + t) * ITEMS + i;
+            if (e >= (H / 2) * ncb) break;
+            const uint32_t w = nth_with_bit(e / ncb, k);
+            if (w < H) acc = bk_add(acc, ld_struct(rowpart + (size_t)w * ncb + (e % ncb)));
+        }
+    }
+    sh[t] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)t < off) acc = bk_add(sh[t], sh[t + off]);
+        __syncthreads();
+        if ((int)t < off) sh[t] = acc;
+        __syncthreads();
+    }
+    if (t == 0) st_struct(sums + blockIdx.x, bk_to_xyzz<F>(sh[0]));
+}
+
 // arkworks in-memory affine (x, y, infinity flag at `inf_off`, arbitrary stride) or packed zkey points -> packed device layout
 template <class F>
 __global__ void __launch_bounds__(256) k_pack_bases(const uint8_t* __restrict__ src, size_t n, size_t stride, long inf_off, Affine<F>* __restrict__ dst) {

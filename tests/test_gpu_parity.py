@@ -395,10 +395,11 @@ def test_msm_skewed_scalars(ctx, group):
     msm_check(ctx, curve, group, pts, [same], window=7)
 
 
-@pytest.mark.parametrize("c", [8, 13, 20])
-def test_msm_precomputed_windows(ctx, c):
-    """cg_bases_precompute: per-window tables 2^(c*j) P_i, one bucket set for all windows; results unchanged"""
-    curve, n = BN254, 900
+@pytest.mark.parametrize("curve,c", [(BN254, 8), (BN254, 13), (BN254, 17), (BN254, 18), (BN254, 19), (BN254, 20), (BN254, 21), (BN254, 22), (BLS12_381, 18), (BLS12_381, 20)])
+def test_msm_precomputed_windows(ctx, curve, c):
+    """cg_bases_precompute: per-window tables 2^(c*j) P_i, one bucket set for all windows; results unchanged.  c <= 17: per-bit sums of the
+    shared bucket set (k_msm_bitsum_*); c >= 18: row / column sums + per-bit sums (k_msm_grid_*) over 2^17 .. 2^21 mostly empty buckets"""
+    n = 900
     rng = np.random.default_rng(50 + c)
     for group in (G1, G2):
         pts = make_points(curve, group, n + 2, rng)
@@ -411,6 +412,24 @@ def test_msm_precomputed_windows(ctx, c):
         for j, sc in enumerate((sa, sb)):
             np.testing.assert_array_equal(cg.point_to_affine(curve, group, got[j]), orc.msm(curve, group, pts[2:2 + n], sc, threads=8))
         bases.release()
+
+
+@pytest.mark.parametrize("group", [G1, G2])
+def test_msm_grid_reduction_dense_buckets(ctx, group):
+    """the row / column reduction with every bucket populated: 2^18 points of the synthetic table [(1 + i) G] against per-window tables
+    with c = 18 (2^17 buckets, ~30 entries each); exact value = one generator multiplication by sum s_i (1 + i)"""
+    import bench_check as bc
+    curve, n = BN254, 1 << 18
+    rng = np.random.default_rng(77)
+    bases = ctx.synth_bases(curve, group, 1, n)
+    ctx.precompute_bases(bases, 18)
+    sa, sb = orc.random_field(curve, FR, n, rng), orc.random_field(curve, FR, n, rng)
+    idx = np.zeros((n, 4), dtype=np.uint64); idx[:, 0] = np.arange(n, dtype=np.uint64) + np.uint64(1)
+    wts = bc.to_mont(idx)
+    got = ctx.msm_dev(bases, [dev(ctx, sa), dev(ctx, sb)], n)
+    for j, sc in enumerate((sa, sb)):
+        np.testing.assert_array_equal(cg.point_to_affine(curve, group, got[j]), orc.generator_mul(curve, group, bc.field_sum(bc.mul(sc, wts))))
+    bases.release()
 
 
 def test_msm_precomputed_multi_and_skew(ctx):
