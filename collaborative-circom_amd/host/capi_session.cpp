@@ -50,7 +50,10 @@ struct ProofWorkers {
     explicit ProofWorkers(cgh_session* s) {
         for (size_t d = 1; d < s->devices.size(); d++) {
             ctxs.emplace_back(new Borrowed(s, true, (int)d));
-            md.workers.push_back(cgh::WorkerDevice{ctxs.back()->c, &s->dzs[d]});
+            cgh::WorkerDevice w; w.ctx = ctxs.back()->c; w.dz = &s->dzs[d];
+            ctxs.emplace_back(new Borrowed(s, true, (int)d, true));                   // its share of the witness map: a chain context of its own
+            w.chain = ctxs.back()->c;
+            md.workers.push_back(w);
         }
     }
     const cgh::MultiDevice* get() const { return md.workers.empty() ? nullptr : &md; }

@@ -24,7 +24,9 @@ struct DeviceZKey {   // bases uploaded once and reused by every proof / party (
     // from the first private variable) and [h_lo, h_lo + h_n) of h_query, registered as tables of their own (offset 0)
     bool sliced = false; size_t aux_lo = 0, aux_n = 0, h_lo = 0, h_n = 0;
 };
-struct WorkerDevice { cg_ctx* ctx = nullptr; const DeviceZKey* dz = nullptr; };     // one further GPU of a party: a context on it + its table slices
+struct WorkerDevice {     // one further GPU of a party: a context on it (its MSM slices) + its table slices; `chain`: a second, high-priority
+    cg_ctx* ctx = nullptr; const DeviceZKey* dz = nullptr; cg_ctx* chain = nullptr;   // context for its share of the witness map (multidev.hpp)
+};
 struct MultiDevice { std::vector<WorkerDevice> workers; };
 
 enum class Mode { Plain, Rep3, Shamir };

@@ -1,6 +1,7 @@
 // CoGroth16::prove (co-circom/co-groth16/src/groth16.rs:113-326) over HipDriver, zkey -> device tables, scope guards of the entry points
 #pragma once
 #include "driver.hpp"
+#include "multidev.hpp"
 
 namespace cgh {
 
@@ -79,13 +80,39 @@ public:
         auto aux_msm = dz.sliced ? driver.msm_begin_sharded(dz, true, private_witness)
                                  : driver.msm_begin_multi({dz.l, dz.a, dz.b1, dz.b2}, {0, first_aux, first_aux, first_aux}, {CG_G1, CG_G1, CG_G1, CG_G2}, private_witness.n, private_witness, true);
         mk.mark("aux msm enqueued");
+        // Several GPUs: the witness map itself is spread over them (multidev.hpp) and every device multiplies its own rows of h
+        const bool distributed = DistributedWitnessMap::usable(driver, dz);
+        std::unique_ptr<DistributedWitnessMap> dmap;
+        DistributedH dh;
+        ShareVec h;
+        HipDriver::PendingMsm h_msm;
+        if (distributed) {
+            if (h_out) throw std::runtime_error("the quotient vector of a multi-device proof stays distributed (h_out is a single-device option)");
+            dmap.reset(new DistributedWitnessMap(driver, dz, *driver.md));
+            dh = dmap->run(dz, public_inputs, private_witness);
+            mk.mark("witness map (distributed)");
+            h_msm.on = driver.ctx; h_msm.groups = {CG_G1}; h_msm.tickets.resize(1);
+            for (size_t d = 0; d < dh.parts.size(); d++) {                                             // :248, rows of device d against its slice of h_query
+                const DistributedH::Part& part = dh.parts[d];
+                if (d && dmap->primary_only) break;
+                const cg_bases* tab = dmap->devs[d].dz->h; const size_t off0 = 0;
+                const void* sc[2] = {part.h.c[0], part.h.c[1]};
+                if (d == 0) CG(cg_msm_dev_begin_multi(part.ctx, 1, &tab, &off0, part.h.n, sc, driver.k(), h_msm.tickets.data()));
+                else {
+                    HipDriver::PendingMsm::Part p{part.ctx, std::vector<int32_t>(1), {nullptr, nullptr}};
+                    CG(cg_msm_dev_begin_multi(part.ctx, 1, &tab, &off0, part.h.n, sc, driver.k(), p.tickets.data()));
+                    h_msm.parts.push_back(p);
+                }
+            }
+        } else {
         // the masks of the witness map's two mul_vec calls (:174, :190) start their way to the device now: behind the witness shares and the
         // few small synchronous uploads of the MSM set-up (the copy engine serves its requests in order), ahead of everything else
         driver.prefetch_masks(2, groth16_domain(c, z.pow, z.num_constraints, public_inputs.size()).m);
         mk.mark("mask uploads enqueued");
-        ShareVec h = witness_map_from_matrices(dz, public_inputs, private_witness);
+        h = witness_map_from_matrices(dz, public_inputs, private_witness);
         mk.mark("witness map");
-        auto h_msm = dz.sliced ? driver.msm_begin_sharded(dz, false, h) : driver.msm_begin_multi({dz.h}, {0}, {CG_G1}, h.n, h, false);   // :248
+        h_msm = dz.sliced ? driver.msm_begin_sharded(dz, false, h) : driver.msm_begin_multi({dz.h}, {0}, {CG_G1}, h.n, h, false);   // :248
+        }
         FieldShare r = rs_plain ? rs_plain[0] : driver.rand();                                         // :134-135
         FieldShare s = rs_plain ? rs_plain[1] : driver.rand();
         // The GPU is busy with the MSMs for tens of milliseconds from here on.  Everything of :258-297 that does not read an MSM result
@@ -119,6 +146,8 @@ public:
         auto opened = driver.open_two_points(g_c, g2_b);                                               // :316
         mk.mark("open");
         driver.msm_release(aux_msm); driver.msm_release(h_msm);
+        for (auto& part : dh.parts) for (int j = 0; j < 2; j++) if (part.h.c[j]) CG(cg_dev_free(part.ctx, part.h.c[j]));
+        dmap.reset();
         if (h_out) *h_out = h; else driver.free_vec(h);
         return Proof{pt_to_affine(c, g_a_opened), pt_to_affine(c, opened.second), pt_to_affine(c, opened.first)};   // :319-325
     }
