@@ -697,7 +697,7 @@ def main():
         c_eff = (20 if avg_pts > (3 << 20) else 16 if avg_pts <= (1 << 18) else 17) if args.precompute < 0 else (args.precompute or 16)
         nwin_g1 = 254 // c_eff + 1
         traffic = None          # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes (profiles/)
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = json.load(f)["dominant_kernel_traffic_bytes_per_launch"] if world == 1 and args.log_m == 22 else None
