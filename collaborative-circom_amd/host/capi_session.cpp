@@ -19,7 +19,9 @@ struct cgh_session {
     cg_ctx* take(int slot = 0, bool chain = false) {
         auto& pool = chain ? idle_chain : idle;
         { std::lock_guard<std::mutex> l(mu); if (!pool[slot].empty()) { cg_ctx* c = pool[slot].back(); pool[slot].pop_back(); return c; } }
-        cg_ctx* c = nullptr; if (cg_ctx_create_ex(devices[slot], chain ? 1u : (bulk_second && slot == 0 ? 2u : 0u), &c)) cgh::die("cg_ctx_create"); return c;
+        static const uint32_t chain_flag = getenv("CGH_CHAIN_FLAG") ? (uint32_t)atoi(getenv("CGH_CHAIN_FLAG")) : 1u;     // tuning knobs (scripts/party_knobs_ab.sh)
+        static const uint32_t bulk_flag = getenv("CGH_BULK_FLAG") ? (uint32_t)atoi(getenv("CGH_BULK_FLAG")) : 2u;
+        cg_ctx* c = nullptr; if (cg_ctx_create_ex(devices[slot], chain ? chain_flag : (bulk_second && slot == 0 ? bulk_flag : 0u), &c)) cgh::die("cg_ctx_create"); return c;
     }
     void give(cg_ctx* c, int slot = 0, bool chain = false) { if (!c) return; cg_ctx_sync(c); std::lock_guard<std::mutex> l(mu); (chain ? idle_chain : idle)[slot].push_back(c); }
 };
