@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "cg_dev_alloc", "cg_dev_free", "cg_dev_upload", "cg_dev_download", "cg_dev_memset_zero",
     "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute", "cg_bases_check_on_curve", "cg_bases_check_subgroup",
     "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_chunk", "cg_msm_scalars_after", "cg_msm_set_scatter_capacity",
-    "cg_ntt", "cg_ntt_dev",
+    "cg_ntt", "cg_ntt_dev", "cg_ntt_coset_pair_dev",
     "cg_host_alloc", "cg_host_free", "cg_host_is_pinned", "cg_dev_download_begin", "cg_dev_upload_begin", "cg_copy_wait", "cg_copy_fence",
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev", "cg_vec_affine_dev", "cg_vec_fill_dev", "cg_vec_gather_strided_dev", "cg_vec_lincomb_dev", "cg_vec_prefix_prod_dev", "cg_vec_prefix_sum_dev", "cg_vec_inverse_dev",
     "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
@@ -334,6 +334,12 @@ class Context:
         gg = np.ascontiguousarray(group_gen, dtype=np.uint64)
         cg = None if coset_gen is None else np.ascontiguousarray(coset_gen, dtype=np.uint64)
         _chk(load().cg_ntt_dev(self.h, curve, ptrs, k, C.c_size_t(n), _hp(gg), int(inverse), _hp(cg)))
+
+    def ntt_coset_pair_dev(self, curve, d_vecs, n, group_gen, coset_gen):
+        """v <- NTT(g^i * iNTT(v)_i) in one call (groth16.rs:175-188), natural order in and out"""
+        k = len(d_vecs)
+        ptrs = (C.c_void_p * k)(*[_dp(v).value for v in d_vecs])
+        _chk(load().cg_ntt_coset_pair_dev(self.h, curve, ptrs, k, C.c_size_t(n), _hp(np.ascontiguousarray(group_gen, dtype=np.uint64)), _hp(np.ascontiguousarray(coset_gen, dtype=np.uint64))))
 
     # ---- vector ops (device operands)
     def vec_add(self, curve, out, a, b, n): _chk(load().cg_vec_add_dev(self.h, curve, _dp(out), _dp(a), _dp(b), C.c_size_t(n)))

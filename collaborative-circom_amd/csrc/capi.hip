@@ -52,6 +52,9 @@ template <class Fr> int launch_spmv_csr(hipStream_t st, const uint32_t* row_ptr,
 template <class Fr> int launch_build_twiddles(hipStream_t st, Fr* tw, size_t m, int log_m, const Fr* lo, const Fr* hi, int log_lo);
 template <class Fr> int launch_build_twiddles_lazy(hipStream_t st, void* tw, size_t m, int log_m, const Fr* lo, const Fr* hi, int log_lo, const Fr& c32);
 template <class Fr> int launch_ntt_ct_pass(hipStream_t st, bool first, NttVecs src, NttVecs dst, int nvec, size_t n, int log_m, int s0, int k, int t, const void* tw);
+template <class Fr> int launch_build_twiddles_lazy_natural(hipStream_t st, void* tw, size_t m, const Fr* lo, const Fr* hi, int log_lo, const Fr& c32);
+template <class Fr> int launch_ntt_dit_pass(hipStream_t st, bool first, bool last, NttVecs out, NttVecs tmp, int nvec, size_t n, int log_m, int s0, int k, int t, const void* tw,
+                                            const Fr* c_lo, const Fr* c_hi, int log_lo, const Fr& c32);
 template <class Fr> int launch_bitrev_finish_lazy(hipStream_t st, NttVecs dst, NttVecs src, int nvec, size_t n, int log_m, const Fr* scale, const Fr* c_lo, const Fr* c_hi, int log_lo);
 template <class Fr> int launch_ntt_dif_pass(hipStream_t st, NttVecs src, NttVecs dst, int nvec, size_t n, int log_m, int s0, int k, int t, const Fr* tw);
 template <class Fr> int launch_bitrev_scale(hipStream_t st, NttVecs dst, NttVecs src, int nvec, size_t n, int log_m, const Fr* scale, const Fr* c_lo, const Fr* c_hi, int log_lo);
@@ -626,6 +629,35 @@ int get_twiddles_lazy(cg_ctx* ctx, int curve, int log_m, const Fr& w, const void
     return 0;
 }
 
+// natural-order limb-form table of the decimation-in-time passes: tw[e] = 32 * w^e, e < m/2 (ntt_kernels.hpp, k_ntt_dit_pass)
+template <class Fr>
+int get_twiddles_lazy_natural(cg_ctx* ctx, int curve, int log_m, const Fr& w, const void** out) {
+    TwKey key; key.curve = curve; key.log_m = log_m; key.kind = 2; memcpy(key.gen, w.v, sizeof key.gen);
+    auto it = ctx->twiddles.find(key);
+    if (it != ctx->twiddles.end()) { *out = it->second; return 0; }
+    if (void* shared = shared_twiddles_acquire(ctx->device, key)) { ctx->twiddles[key] = shared; *out = shared; return 0; }
+    const size_t m = (size_t)1 << log_m;
+    const int log_lo = std::min(11, std::max(0, log_m - 1));
+    const size_t hi_n = std::max<size_t>(1, (m / 2) >> log_lo);
+    std::vector<Fr> lo, hi;
+    host_pow_tables(w, Fr::one(), log_lo, hi_n, lo, hi);
+    Fr c32 = Fr::one(); for (int i = 0; i < 5; i++) c32 = c32 + c32;
+    Fr *d_lo = nullptr, *d_hi = nullptr; void* d_tw = nullptr;
+    const size_t bytes = lazy29_bytes(std::max<size_t>(m / 2, 1));
+    HIPCHK(hip_malloc_flush((void**)&d_lo, lo.size() * sizeof(Fr)));
+    HIPCHK(hip_malloc_flush((void**)&d_hi, hi.size() * sizeof(Fr)));
+    HIPCHK(hip_malloc_flush(&d_tw, bytes));
+    HIPCHK(hipMemcpyAsync(d_lo, lo.data(), lo.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_hi, hi.data(), hi.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    { int rc = launch_build_twiddles_lazy_natural<Fr>(ctx->stream, d_tw, m, d_lo, d_hi, log_lo, c32); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(d_lo)); HIPCHK(hipFree(d_hi));
+    d_tw = shared_twiddles_publish(ctx->device, key, d_tw, bytes);
+    ctx->twiddles[key] = d_tw;
+    *out = d_tw;
+    return 0;
+}
+
 // tables with lo[j] = scale * g^j, hi[j] = g^(j << log_lo), covering exponents < 2^log_m
 template <class Fr>
 int get_coset_tables(cg_ctx* ctx, int curve, int log_m, const Fr& g, const Fr& scale, CosetTables* out) {
@@ -727,6 +759,37 @@ int ntt_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_t n, const 
     } else if (coset) return fail(CG_ERR_ARG, "coset_gen is only supported with inverse != 0");
     // the permutation brings the result back: tmp -> data (natural order), fused with 1/m and the coset powers
     return launch_bitrev_scale<Fr>(st, data, tmp, k, n, log_m, d_scale, c_lo, c_hi, log_lo);
+}
+
+// v <- NTT_w( g^i * (iNTT_w v)_i ): the inverse transform's passes leave the coefficients bit-reversed in limb-form scratch, the
+// decimation-in-time passes take them from there (scaling by (1/m) g^i on the way in) and write the natural-order result
+template <class Fr>
+int ntt_coset_pair_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_t n, const Fr& gen, const Fr& coset, size_t arena_off) {
+    const int log_m = log2_floor(n);
+    if (((size_t)1 << log_m) != n) return fail(CG_ERR_ARG, "NTT length must be a power of two");
+    if (k < 1 || k > NTT_MAX_VECS) return fail(CG_ERR_ARG, "k out of range");
+    if (n == 1) return 0;                                                       // both transforms and g^0 are the identity
+    const void* tw_inv = nullptr; const void* tw_fwd = nullptr;
+    int rc = get_twiddles_lazy<Fr>(ctx, curve, log_m, fp_inverse(gen), &tw_inv); if (rc) return rc;
+    rc = get_twiddles_lazy_natural<Fr>(ctx, curve, log_m, gen, &tw_fwd); if (rc) return rc;
+    Fr c32 = Fr::one(); for (int i = 0; i < 5; i++) c32 = c32 + c32;
+    uint32_t e[Fr::N] = {0}; e[log_m / 32] = 1u << (log_m % 32);
+    Fr nn; for (int i = 0; i < Fr::N; i++) nn.v[i] = e[i];
+    CosetTables ct;
+    rc = get_coset_tables<Fr>(ctx, curve, log_m, coset, c32 * fp_inverse(nn.to_mont()), &ct); if (rc) return rc;
+    NttVecs data{}, tmp{};
+    for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->arena.base + arena_off + (size_t)j * lazy29_bytes(n); }
+    hipStream_t st = ctx->stream;
+    static const int lazy_tile = [] { const char* e_ = getenv("CG_NTT_TILE"); const int v = e_ ? atoi(e_) : NTT_TILE_LOG_LAZY; return std::min(NTT_TILE_LOG, std::max(8, v)); }();
+    const std::vector<NttPass> plan = ntt_plan(log_m, lazy_tile);
+    bool first = true;
+    for (const NttPass& p : plan) { rc = launch_ntt_ct_pass<Fr>(st, first, first ? data : tmp, tmp, k, n, log_m, p.s0, p.k, p.t, tw_inv); if (rc) return rc; first = false; }
+    for (size_t i = plan.size(); i-- > 0;) {
+        const NttPass& p = plan[i];
+        rc = launch_ntt_dit_pass<Fr>(st, i + 1 == plan.size(), i == 0, data, tmp, k, n, log_m, p.s0, p.k, p.t, tw_fwd, (const Fr*)ct.lo, (const Fr*)ct.hi, ct.log_lo, c32);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 template <class F> void copy_in(F& dst, const void* src) { memcpy(dst.v, src, sizeof dst.v); }
@@ -1361,6 +1424,19 @@ int32_t cg_ntt_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, int32_t k, s
         if (n > 1) { int rc = ensure_arena(ctx, (size_t)k * lazy29_bytes(n)); if (rc) return rc; }
         StatScope ss(ctx, TAG_NTT);
         return ntt_run<Fr>(ctx, curve, d_vecs, k, n, gen, inverse != 0, h_coset_gen ? &cos : nullptr, 0);
+    });
+}
+int32_t cg_ntt_coset_pair_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, int32_t k, size_t n, const void* h_group_gen, const void* h_coset_gen) {
+    if (!ctx || !d_vecs || !h_group_gen || !h_coset_gen) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    static const bool two_calls = getenv("CG_NTT_NO_PAIR") != nullptr;         // A/B knob: the two separate transforms
+    if (two_calls) { int rc = cg_ntt_dev(ctx, curve, d_vecs, k, n, h_group_gen, 1, h_coset_gen); return rc ? rc : cg_ntt_dev(ctx, curve, d_vecs, k, n, h_group_gen, 0, nullptr); }
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        Fr gen, cos; copy_in(gen, h_group_gen); copy_in(cos, h_coset_gen);
+        if (n > 1) { int rc = ensure_arena(ctx, (size_t)k * lazy29_bytes(n)); if (rc) return rc; }
+        StatScope ss(ctx, TAG_NTT);
+        return ntt_coset_pair_run<Fr>(ctx, curve, d_vecs, k, n, gen, cos, 0);
     });
 }
 int32_t cg_ntt(cg_ctx* ctx, int32_t curve, void* const* h_vecs, int32_t k, size_t n, const void* h_group_gen, int32_t inverse, const void* h_coset_gen) {

@@ -117,6 +117,30 @@ template <class Fr> int launch_ntt_ct_pass(hipStream_t st, bool first, NttVecs s
     HIPCHK(hipGetLastError());
     return 0;
 }
+template <class Fr> int launch_build_twiddles_lazy_natural(hipStream_t st, void* tw, size_t m, const Fr* lo, const Fr* hi, int log_lo, const Fr& c32) {
+    if (m > 1) hipLaunchKernelGGL((k_build_twiddles_lazy_natural<Fr>), dim3(grid_for(m / 2)), dim3(256), 0, st, tw, m / 2, lo, hi, log_lo, c32);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class Fr> int launch_ntt_dit_pass(hipStream_t st, bool first, bool last, NttVecs out, NttVecs tmp, int nvec, size_t n, int log_m, int s0, int k, int t, const void* tw,
+                                            const Fr* c_lo, const Fr* c_hi, int log_lo, const Fr& c32) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.pending()) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_ntt_dit_pass<Fr, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 36 << NTT_TILE_LOG));
+        HIPCHK(hipFuncSetAttribute((const void*)k_ntt_dit_pass<Fr, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 36 << NTT_TILE_LOG));
+        HIPCHK(hipFuncSetAttribute((const void*)k_ntt_dit_pass<Fr, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 36 << NTT_TILE_LOG));
+        HIPCHK(hipFuncSetAttribute((const void*)k_ntt_dit_pass<Fr, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 36 << NTT_TILE_LOG));
+        attr_set.mark();
+    }
+    const int E = 1 << (k + t);
+    const dim3 grid((unsigned)(n / E), nvec); const size_t lds = (size_t)E * 36;
+    if (first && last) hipLaunchKernelGGL((k_ntt_dit_pass<Fr, true, true>), grid, dim3(NTT_THREADS), lds, st, out, tmp, log_m, s0, k, t, tw, c_lo, c_hi, log_lo, c32);
+    else if (first) hipLaunchKernelGGL((k_ntt_dit_pass<Fr, true, false>), grid, dim3(NTT_THREADS), lds, st, out, tmp, log_m, s0, k, t, tw, c_lo, c_hi, log_lo, c32);
+    else if (last) hipLaunchKernelGGL((k_ntt_dit_pass<Fr, false, true>), grid, dim3(NTT_THREADS), lds, st, out, tmp, log_m, s0, k, t, tw, c_lo, c_hi, log_lo, c32);
+    else hipLaunchKernelGGL((k_ntt_dit_pass<Fr, false, false>), grid, dim3(NTT_THREADS), lds, st, out, tmp, log_m, s0, k, t, tw, c_lo, c_hi, log_lo, c32);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 template <class Fr> int launch_bitrev_finish_lazy(hipStream_t st, NttVecs dst, NttVecs src, int nvec, size_t n, int log_m, const Fr* scale, const Fr* c_lo, const Fr* c_hi, int log_lo) {
     if (log_m >= 2 * BITREV_B_LAZY)
         hipLaunchKernelGGL((k_bitrev_finish_lazy<Fr>), dim3((unsigned)(n >> (2 * BITREV_B_LAZY)), nvec), dim3(256), 0, st, dst, src, log_m, scale, c_lo, c_hi, log_lo);
@@ -252,6 +276,8 @@ template <class Fr> int msm_sort_direct_launch(hipStream_t st, const Fr* d_scala
     template int launch_ntt_dif_pass<Fr>(hipStream_t, NttVecs, NttVecs, int, size_t, int, int, int, int, const Fr*);                \
     template int launch_build_twiddles_lazy<Fr>(hipStream_t, void*, size_t, int, const Fr*, const Fr*, int, const Fr&);             \
     template int launch_ntt_ct_pass<Fr>(hipStream_t, bool, NttVecs, NttVecs, int, size_t, int, int, int, int, const void*);         \
+    template int launch_build_twiddles_lazy_natural<Fr>(hipStream_t, void*, size_t, const Fr*, const Fr*, int, const Fr&);          \
+    template int launch_ntt_dit_pass<Fr>(hipStream_t, bool, bool, NttVecs, NttVecs, int, size_t, int, int, int, int, const void*, const Fr*, const Fr*, int, const Fr&); \
     template int launch_bitrev_finish_lazy<Fr>(hipStream_t, NttVecs, NttVecs, int, size_t, int, const Fr*, const Fr*, const Fr*, int); \
     template int launch_bitrev_scale<Fr>(hipStream_t, NttVecs, NttVecs, int, size_t, int, const Fr*, const Fr*, const Fr*, int); \
     template int msm_sort_launch<Fr>(hipStream_t, const Fr*, size_t, int, int, int, char*, MsmSortPtrs*, hipEvent_t*);          \

@@ -216,6 +216,105 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_ct_pass(NttVecs src_vecs, N
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The other half of the pair: BIT-REVERSED input -> natural output, for `ifft_in_place; distribute_powers_and_mul_by_const(g, 1);
+// fft_in_place` (groth16.rs:175-188, rep3.rs:893-921, :681-688) without the two permutation passes in the middle: the inverse transform
+// runs the passes above (natural -> bit-reversed, limb-form scratch), the forward transform runs these.  Decimation in time: stage s
+// (s = 0 first) pairs the elements whose indices differ in bit s, (u, v) -> (u + w v, u - w v) with w = omega^(j m / 2^(s+1)),
+// j = index mod 2^s — the same lazy butterfly, so the value bounds of the passes above hold; twiddles come from ONE natural-order
+// limb-form table tw[e] = 32 omega^e, e < m/2, read at e = j << (log_m - 1 - s).  Tiles are those of k_ntt_ct_pass taken in the opposite
+// order (first the contiguous tile: stages 0 .. k_last - 1, then the strided ones), inside a tile the stages go from the low row bit up.
+//   FIRST: the element at position g holds coefficient bitrev(g) of the inverse transform; it is multiplied by 32 (1/m) g^bitrev(g)
+//          (the two coset tables of the permutation kernel), which also reduces it;
+//   LAST:  the results are multiplied by 32 (-> the ABI's Montgomery form, reduced) and packed into the caller's vectors, natural order.
+template <class F>
+__global__ void __launch_bounds__(256) k_build_twiddles_lazy_natural(void* tw_base, size_t half, const F* __restrict__ lo, const F* __restrict__ hi, int log_lo, F c32) {
+    typedef L29<F> L;
+    const Lazy29Planes tw = lazy29_planes(tw_base, half);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < half; e += (size_t)gridDim.x * blockDim.x) {
+        const F w = ld_fp(lo + (e & (((size_t)1 << log_lo) - 1))) * ld_fp(hi + (e >> log_lo)) * c32;
+        lazy29_store<L>(tw.p0, tw.p1, tw.p2, e, L::template unpack<0>(w));
+    }
+}
+template <class F, bool FIRST, bool LAST>
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_dit_pass(NttVecs out_vecs, NttVecs tmp_vecs, int log_m, int s0, int k, int t, const void* tw_base,
+                                                             const F* __restrict__ cos_lo, const F* __restrict__ cos_hi, int log_lo, F c32) {
+    static_assert(F::N == 8, "NTT is specialised for 256-bit scalar fields");
+    typedef L29<F> L;
+    extern __shared__ uint4 lds[];
+    const int E = 1 << (k + t);
+    uint4* pl0 = lds;
+    uint4* pl1 = lds + E;
+    uint32_t* pl2 = reinterpret_cast<uint32_t*>(lds + 2 * E);
+    const size_t m = (size_t)1 << log_m;
+    const Lazy29Planes tw = lazy29_planes(const_cast<void*>(tw_base), m / 2);
+    const Lazy29Planes buf = lazy29_planes(tmp_vecs.p[blockIdx.y], m);
+    const int lo_bits = log_m - s0 - k;                        // = first stage of this pass
+    const size_t tiles_per_hi = (size_t)1 << (lo_bits - t);
+    const size_t hi = blockIdx.x / tiles_per_hi;
+    const size_t lo0 = (blockIdx.x % tiles_per_hi) << t;
+    const size_t base = (hi << (log_m - s0)) + lo0;
+    const int tmask = (1 << t) - 1;
+
+    for (int idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+        const size_t g = base + ((size_t)(idx >> t) << lo_bits) + (idx & tmask);
+        L v = lazy29_load<L>(buf.p0, buf.p1, buf.p2, g);
+        if constexpr (FIRST) {
+            const size_t i = (size_t)(__brevll((unsigned long long)g) >> (64 - log_m));
+            const F c = ld_fp(cos_lo + (i & (((size_t)1 << log_lo) - 1))) * ld_fp(cos_hi + (i >> log_lo));
+            v = L::mul(v, L::template unpack<0>(c));
+        }
+        lazy29_store<L>(pl0, pl1, pl2, idx, v);
+    }
+    __syncthreads();
+    int q = 0;
+    for (; q + 1 < k; q += 2) {                                 // two stages per trip through LDS
+        const int s = lo_bits + q;
+        for (int u = threadIdx.x; u < E / 4; u += NTT_THREADS) {
+            const int lo_local = u & tmask;
+            const int mu = u >> t;
+            const int mid0 = ((mu >> q) << (q + 2)) | (mu & ((1 << q) - 1));
+            const int i00 = (mid0 << t) | lo_local, d = 1 << (q + t);
+            const size_t j = ((size_t)(mid0 & ((1 << q) - 1)) << lo_bits) + lo0 + lo_local;
+            const size_t e0 = j << (log_m - 1 - s), e1 = j << (log_m - 2 - s);
+            const L a00 = lazy29_load<L>(pl0, pl1, pl2, i00), a01 = lazy29_load<L>(pl0, pl1, pl2, i00 + d);
+            const L a10 = lazy29_load<L>(pl0, pl1, pl2, i00 + 2 * d), a11 = lazy29_load<L>(pl0, pl1, pl2, i00 + 3 * d);
+            const L w0 = lazy29_load<L>(tw.p0, tw.p1, tw.p2, e0);
+            const L v1 = L::mul(a01, w0), v3 = L::mul(a11, w0);
+            const L b00 = a00 + v1, b01 = a00 - v1;                  // only added to below: no carry normalisation
+            const L b10 = (a10 + v3).norm(), b11 = (a10 - v3).norm();
+            const L w1a = lazy29_load<L>(tw.p0, tw.p1, tw.p2, e1), w1b = lazy29_load<L>(tw.p0, tw.p1, tw.p2, e1 + (m >> 2));
+            const L y2 = L::mul(b10, w1a), y3 = L::mul(b11, w1b);
+            lazy29_store<L>(pl0, pl1, pl2, i00, (b00 + y2).norm());
+            lazy29_store<L>(pl0, pl1, pl2, i00 + 2 * d, (b00 - y2).norm());
+            lazy29_store<L>(pl0, pl1, pl2, i00 + d, (b01 + y3).norm());
+            lazy29_store<L>(pl0, pl1, pl2, i00 + 3 * d, (b01 - y3).norm());
+        }
+        __syncthreads();
+    }
+    for (; q < k; q++) {
+        const int s = lo_bits + q;
+        for (int u = threadIdx.x; u < E / 2; u += NTT_THREADS) {
+            const int lo_local = u & tmask;
+            const int mu = u >> t;
+            const int mid0 = ((mu >> q) << (q + 1)) | (mu & ((1 << q) - 1));
+            const int i0 = (mid0 << t) | lo_local, i1 = i0 + (1 << (q + t));
+            const size_t j = ((size_t)(mid0 & ((1 << q) - 1)) << lo_bits) + lo0 + lo_local;
+            const L a = lazy29_load<L>(pl0, pl1, pl2, i0), b = lazy29_load<L>(pl0, pl1, pl2, i1);
+            const L v = L::mul(b, lazy29_load<L>(tw.p0, tw.p1, tw.p2, j << (log_m - 1 - s)));
+            lazy29_store<L>(pl0, pl1, pl2, i0, (a + v).norm());
+            lazy29_store<L>(pl0, pl1, pl2, i1, (a - v).norm());
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
+        const size_t g = base + ((size_t)(idx >> t) << lo_bits) + (idx & tmask);
+        const L v = lazy29_load<L>(pl0, pl1, pl2, idx);
+        if constexpr (LAST) st_fp(reinterpret_cast<F*>(out_vecs.p[blockIdx.y]) + g, L::pack_reduced(L::mul(v, L::template unpack<0>(c32))));
+        else lazy29_store<L>(buf.p0, buf.p1, buf.p2, g, v);
+    }
+}
+
 // dst[bitrev(i)] = pack(src[i] * c(bitrev(i))), src in limb form: c = *scale (a constant that already contains the factor 32) or
 // the product of the two coset tables (whose `lo` half contains 32 * scale).  Same LDS-tiled permutation as k_bitrev_scale.
 template <class F>

@@ -605,6 +605,8 @@ public:
     void distribute_powers_and_mul_by_const(ShareVec& v, const Fr& g, const Fr& c) { for (int j = 0; j < k(); j++) CG(cg_vec_distribute_powers_dev(ctx, curve.id, v.c[j], v.n, g.v, c.v)); }
     // fused ifft_in_place + distribute_powers_and_mul_by_const(g, 1): one HBM round trip less per vector
     void ifft_coset_in_place(ShareVec& v, const Fr& group_gen, const Fr& g) { CG(cg_ntt_dev(ctx, curve.id, v.c, k(), v.n, group_gen.v, 1, g.v)); }
+    // ifft_in_place; distribute_powers_and_mul_by_const(g, 1); fft_in_place (groth16.rs:175-188) as one call: no permutation passes in between
+    void ifft_coset_fft_in_place(ShareVec& v, const Fr& group_gen, const Fr& g) { CG(cg_ntt_coset_pair_dev(ctx, curve.id, v.c, k(), v.n, group_gen.v, g.v)); }
     void sub_assign_vec(ShareVec& a, const ShareVec& b) { for (int j = 0; j < k(); j++) CG(cg_vec_sub_dev(ctx, curve.id, a.c[j], a.c[j], b.c[j], a.n)); }
 
     // MSMProvider::msm_public_points (traits.rs:561-568) on a sub-slice of a registered table

@@ -35,16 +35,14 @@ public:
         mk.mark("spmv enqueue");
         auto c_pending = driver.mul_vec_begin(a, b);                                                   // :174
         mk.mark("mul_vec_begin");
-        driver.ifft_coset_in_place(a, dom.omega, dom.coset_g);                                         // :175,177-181
-        driver.ifft_coset_in_place(b, dom.omega, dom.coset_g);                                         // :176,182-186
-        driver.fft_in_place(a, dom.omega); driver.fft_in_place(b, dom.omega);                          // :187-188
+        driver.ifft_coset_fft_in_place(a, dom.omega, dom.coset_g);                                     // :175,177-181,187
+        driver.ifft_coset_fft_in_place(b, dom.omega, dom.coset_g);                                     // :176,182-186,188
         mk.mark("ntt enqueue");
         ShareVec c = driver.mul_vec_finish(c_pending);
         mk.mark("mul_vec_finish");
         auto ab_pending = driver.mul_vec_begin(a, b);                                                  // :190
         mk.mark("mul_vec_begin");
-        driver.ifft_coset_in_place(c, dom.omega, dom.coset_g);                                         // :194-199
-        driver.fft_in_place(c, dom.omega);                                                             // :200
+        driver.ifft_coset_fft_in_place(c, dom.omega, dom.coset_g);                                     // :194-200
         mk.mark("ntt enqueue");
         ShareVec ab = driver.mul_vec_finish(ab_pending);
         mk.mark("mul_vec_finish");

@@ -235,8 +235,7 @@ public:
             const size_t o = owner(v);
             if (skip(o)) continue;
             void* p[1] = {vec[v]};
-            CG(cg_ntt_dev(devs[o].ctx, curve.id, p, 1, dom.m, dom.omega.v, 1, dom.coset_g.v));
-            CG(cg_ntt_dev(devs[o].ctx, curve.id, p, 1, dom.m, dom.omega.v, 0, nullptr));
+            CG(cg_ntt_coset_pair_dev(devs[o].ctx, curve.id, p, 1, dom.m, dom.omega.v, dom.coset_g.v));
         }
     }
 };

@@ -153,6 +153,11 @@ int32_t cg_ntt(cg_ctx* ctx, int32_t curve, void* const* h_vecs, int32_t k, size_
                const void* h_group_gen, int32_t inverse, const void* h_coset_gen);
 int32_t cg_ntt_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, int32_t k, size_t n,
                    const void* h_group_gen, int32_t inverse, const void* h_coset_gen);
+/* The provers' sequence `ifft_in_place; distribute_powers_and_mul_by_const(g, 1); fft_in_place` (groth16.rs:175-188, rep3.rs:893-921,
+ * :681-688) as ONE call: v <- NTT( g^i * iNTT(v)_i ), natural order in and out, same values as the two cg_ntt_dev calls.  The inverse
+ * transform leaves its coefficients bit-reversed in the context's scratch and the forward transform (decimation in time) takes them from
+ * there, so the two permutation passes in the middle — and their trips through HBM — do not happen. */
+int32_t cg_ntt_coset_pair_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, int32_t k, size_t n, const void* h_group_gen, const void* h_coset_gen);
 
 /* ---- PrimeFieldMpcProtocol vector methods (device-resident operands) ------------------------------------------ */
 /* add_vec traits.rs:161 / sub_assign_vec :67 / plain+Shamir local mul_vec :164 (plain.rs:219-224, shamir.rs:618-621) */

@@ -12,7 +12,7 @@ def short(name):
     if not m: return name[:60]
     k, t = m.group(1), m.group(2) or ""
     tag = ""
-    if any(w in k for w in ("accumulate", "reduce", "window_sum", "merge", "precompute", "synth", "pack_bases", "check_on_curve")):
+    if any(w in k for w in ("accumulate", "reduce", "window_sum", "merge", "grid", "bitsum", "precompute", "synth", "pack_bases", "check_on_curve")):
         tag = "<G2" if "Fp2" in t else "<G1"
         for a in ("RegAcc29", "LdsAcc29", "RegAcc", "LdsAcc"):
             if a in t: tag += "," + a; break

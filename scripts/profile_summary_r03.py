@@ -13,7 +13,7 @@ def short(name):
         return name[:60]
     k, t = m.group(1), m.group(2) or ""
     tag = ""
-    if any(w in k for w in ("accumulate", "reduce", "window_sum", "merge", "precompute", "synth", "pack_bases", "check_on_curve", "bitsum")):
+    if any(w in k for w in ("accumulate", "reduce", "window_sum", "merge", "grid", "bitsum", "precompute", "synth", "pack_bases", "check_on_curve", "bitsum")):
         tag = "<G2>" if "Fp2" in t else "<G1>"
     return k + tag
 

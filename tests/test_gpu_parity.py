@@ -343,6 +343,43 @@ def test_msm_witness_like_scalars_at_scale(ctx, group):
     bases.release()
 
 
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
+def test_ntt_coset_pair_matches_the_three_reference_steps(ctx, curve):
+    """cg_ntt_coset_pair_dev = ifft_in_place; distribute_powers_and_mul_by_const(g, 1); fft_in_place (groth16.rs:175-188) without the
+    permutation passes in the middle (inverse passes natural -> bit-reversed, decimation-in-time passes bit-reversed -> natural): exact
+    against the oracle for every size 2^0 .. 2^16 (one to three passes per direction, odd and even stage counts), one and two vectors"""
+    rng = np.random.default_rng(61)
+    _, roots, _ = orc.roots_of_unity(curve)
+    one = orc.from_dec(curve, FR, 1)
+    for lg in range(0, 17):
+        n = 1 << lg
+        x, y = orc.random_field(curve, FR, n, rng), orc.random_field(curve, FR, n, rng)
+        if n >= 4: x[1] = 0; x[2] = orc.from_dec(curve, FR, orc.MODULI[(curve, FR)] - 1)
+        w, g = roots[lg], roots[lg + 1]
+        want = [orc.ntt(curve, orc.distribute_powers(curve, orc.ntt(curve, v, w, inverse=True), g, one), w) for v in (x, y)]
+        dx, dy = dev(ctx, x), dev(ctx, y)
+        ctx.ntt_coset_pair_dev(curve, [dx, dy], n, w, g)
+        np.testing.assert_array_equal(dx.download((n, 4)), want[0], err_msg=f"2^{lg}")
+        np.testing.assert_array_equal(dy.download((n, 4)), want[1], err_msg=f"2^{lg}")
+        dz = dev(ctx, y)
+        ctx.ntt_coset_pair_dev(curve, [dz], n, w, g)
+        np.testing.assert_array_equal(dz.download((n, 4)), want[1], err_msg=f"2^{lg} single")
+
+
+@pytest.mark.parametrize("lg", [20, 24])
+def test_ntt_coset_pair_at_scale_equals_the_two_transforms(ctx, lg):
+    """2^20 / 2^24 (BASELINE configs[3] size): the pair equals the inverse-with-coset transform followed by the forward transform, which
+    the round-trip / linearity / decimated-DFT tests above pin"""
+    curve, n = BN254, 1 << lg
+    rng = np.random.default_rng(lg)
+    _, roots, _ = orc.roots_of_unity(curve)
+    x = orc.random_field(curve, FR, n, rng)
+    a, b = dev(ctx, x), dev(ctx, x)
+    ctx.ntt_dev(curve, [a], n, roots[lg], inverse=True, coset_gen=roots[lg + 1]); ctx.ntt_dev(curve, [a], n, roots[lg])
+    ctx.ntt_coset_pair_dev(curve, [b], n, roots[lg], roots[lg + 1])
+    np.testing.assert_array_equal(b.download((n, 4)), a.download((n, 4)))
+
+
 def test_msm_async_tickets(ctx):
     curve = BN254
     rng = np.random.default_rng(4)
