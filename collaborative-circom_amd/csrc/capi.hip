@@ -120,6 +120,7 @@ struct cg_ctx {
     hipEvent_t copy_ev[COPY_TICKETS] = {}; uint32_t copy_id[COPY_TICKETS] = {}; hipEvent_t ev_copy_order = nullptr; uint32_t copy_next = 0;
     // cg_msm_scalars_after: the scalar-side schedule of component j of the NEXT begin call waits for this event (an upload still in flight)
     hipEvent_t comp_after[4] = {};
+    hipStream_t joinst = nullptr; hipEvent_t park_ev[5] = {};   // cg_dev_free: a work-free stream that joins the context's streams behind a released block
     // priority class of each stream: +1 high, 0 normal, -1 low (pooled_stream)
     int prio_main = 0, prio_side = 1, prio_copy = 0;
     uint32_t msm_chunk = 0;                               // cg_msm_set_chunk
@@ -905,6 +906,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     }
     park_stream(ctx->device, ctx->prio_side, ctx->aux);
     park_stream(ctx->device, ctx->prio_side, ctx->sortst);
+    if (ctx->joinst) { hipStreamSynchronize(ctx->joinst); for (hipEvent_t e : ctx->park_ev) if (e) hipEventDestroy(e); park_stream(ctx->device, -1, ctx->joinst); }
     for (auto& kv : ctx->twiddles) shared_twiddles_release(ctx->device, kv.first);
     for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
     for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.h_flags) hipHostFree(t.h_flags); if (t.done) hipEventDestroy(t.done); }
@@ -1005,14 +1007,18 @@ int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr) {
         HIPCHK(hipFree(d_ptr));
         return 0;
     }
+    // The block's last users may sit on any of the context's streams.  None of them is made to wait for another (a chain context's main
+    // stream must not queue behind its pending copies): a stream of the context that carries no work (`joinst`, low priority) waits for
+    // the five, and ONE event behind it marks the block as free (an event per stream and block ran the runtime out of signals).
+    if (!ctx->joinst) {
+        { int rc = pooled_stream(ctx->device, -1, &ctx->joinst); if (rc) return rc; }
+        for (hipEvent_t& e : ctx->park_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    int i = 0;
+    for (hipStream_t st : {ctx->stream, ctx->aux, ctx->sortst, ctx->h2d, ctx->d2h}) { if (st) { HIPCHK(hipEventRecord(ctx->park_ev[i], st)); HIPCHK(hipStreamWaitEvent(ctx->joinst, ctx->park_ev[i], 0)); } i++; }
     hipEvent_t ev = nullptr;
     if (!dc.spare.empty()) { ev = dc.spare.back(); dc.spare.pop_back(); } else HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    // the block's last users may sit on any of the context's streams: the main stream collects them, the event follows
-    for (hipStream_t side : {ctx->aux, ctx->sortst, ctx->h2d, ctx->d2h}) if (side) {
-        HIPCHK(hipEventRecord(ev, side));
-        HIPCHK(hipStreamWaitEvent(ctx->stream, ev, 0));
-    }
-    HIPCHK(hipEventRecord(ev, ctx->stream));
+    HIPCHK(hipEventRecord(ev, ctx->joinst));
     dc.parked.insert({rb, ParkedBlock{d_ptr, ev}}); dc.parked_bytes += rb;
     return 0;
 }

@@ -45,7 +45,8 @@ public:
         return !off && d.md && !d.md->workers.empty() && dz0.sliced && (d.mode == Mode::Plain || d.mode == Mode::Rep3);
     }
     ~DistributedWitnessMap() {
-        for (Dev& d : devs) { if (!d.owned.empty()) cg_ctx_sync(d.ctx); for (void* p : d.owned) cg_dev_free(d.ctx, p); }
+        for (Dev& d : devs) cg_ctx_sync(d.ctx);                                    // blocks of one device are read by the others' peer copies: all quiet first
+        for (Dev& d : devs) for (void* p : d.owned) cg_dev_free(d.ctx, p);
         for (void* p : pinned) cg_host_free(p);
     }
     bool skip(size_t d) const { return primary_only && d != 0; }
