@@ -653,7 +653,7 @@ public:
             std::vector<size_t> offs(tabs.size(), 0);
             part.tickets.resize(tabs.size());
             const void* sc[2] = {part.sc[0], part.sc[1]};
-            CG(cg_msm_dev_begin_multi(w.ctx, (int32_t)tabs.size(), tabs.data(), offs.data(), wn, sc, k(), part.tickets.data()));
+            begin_multi_ordered(w.ctx, tabs, offs, aux_tables ? std::vector<int>{CG_G1, CG_G1, CG_G1, CG_G2} : std::vector<int>{CG_G1}, wn, sc, part.tickets);
             p.parts.push_back(part);
         }
         return p;
@@ -661,6 +661,22 @@ public:
     void msm_release(PendingMsm& p) {      // after the last msm_finish: the slices' scalar copies
         for (auto& part : p.parts) for (int j = 0; j < 2; j++) if (part.sc[j]) { cg_dev_free(part.on, part.sc[j]); part.sc[j] = nullptr; }
         p.parts.clear();
+    }
+    // One cg_msm_dev_begin_multi call with the G2 tables FIRST in every share component's run of accumulations (tickets come back in the
+    // caller's table order).  The G2 accumulation of a context that runs beside a chain is launched one chip-load at a time, which costs
+    // ~2 ms per launch when nothing else wants the chip: with the G2 table last, the last MSM to finish — alone on the GPU, after the chain
+    // has long completed — was exactly that one (timeline of a 2^22 party: 14 ms for the final G2 accumulation against 11.8 unsliced).
+    void begin_multi_ordered(cg_ctx* on, const std::vector<const cg_bases*>& tables, const std::vector<size_t>& offsets, const std::vector<int>& groups, size_t n,
+                             const void* const* sc, std::vector<int32_t>& tickets) {
+        static const bool g2_first = getenv("CGH_G2_LAST") == nullptr;                  // A/B knob: the round-2 order
+        std::vector<size_t> ord;
+        for (size_t i = 0; i < tables.size(); i++) if (g2_first && groups[i] == CG_G2) ord.push_back(i);
+        for (size_t i = 0; i < tables.size(); i++) if (!(g2_first && groups[i] == CG_G2)) ord.push_back(i);
+        std::vector<const cg_bases*> t(tables.size()); std::vector<size_t> o(tables.size()); std::vector<int32_t> tk(tables.size());
+        for (size_t j = 0; j < ord.size(); j++) { t[j] = tables[ord[j]]; o[j] = offsets[ord[j]]; }
+        CG(cg_msm_dev_begin_multi(on, (int32_t)t.size(), t.data(), o.data(), n, sc, k(), tk.data()));
+        tickets.resize(tables.size());
+        for (size_t j = 0; j < ord.size(); j++) tickets[ord[j]] = tk[j];
     }
     PendingMsm msm_begin_multi(const std::vector<const cg_bases*>& tables, const std::vector<size_t>& offsets, const std::vector<int>& groups, size_t n, const ShareVec& s, bool on_aux) {
         PendingMsm p; p.on = on_aux && aux ? aux : ctx; p.groups = groups; p.tickets.resize(tables.size());
@@ -676,7 +692,7 @@ public:
                 for (int j = 0; j < k(); j++) if (s.up[j] >= 0) CG(cg_msm_scalars_after(p.on, j, s.up_ctx, s.up[j]));   // a is accumulated while b is still crossing PCIe
             } else CG(cg_ctx_sync(ctx));                                                // the scalars were produced on this driver's stream
         }
-        CG(cg_msm_dev_begin_multi(p.on, (int32_t)tables.size(), tables.data(), offsets.data(), n, sc, k(), p.tickets.data()));
+        begin_multi_ordered(p.on, tables, offsets, groups, n, sc, p.tickets);
         return p;
     }
     PointShare msm_finish(PendingMsm& p, size_t i) {
