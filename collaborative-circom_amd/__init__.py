@@ -615,6 +615,31 @@ class StreamRand:
         if self.h: load_host().cgh_stream_rand_destroy(self.h); self.h = None
 
 
+_SH_SEND = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t)
+_SH_RECV = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t)
+_SH_RAND = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class ShamirNetTable(C.Structure):
+    """cgh_shamir_net: any-to-any channels of one of n parties (shamir/network.rs:17-59)"""
+    _fields_ = [("user", C.c_void_p), ("party_id", C.c_int32), ("num_parties", C.c_int32), ("send", _SH_SEND), ("recv", _SH_RECV)]
+
+
+class ShamirRandTable(C.Structure):
+    """cgh_shamir_rand: the party's private RNG (F::rand draws in the reference's order)"""
+    _fields_ = [("user", C.c_void_p), ("random_field_elements", _SH_RAND)]
+
+
+def host_prove_shamir_party(session, threshold, pub, wit, net_table, rand_table, preprocess=0):
+    """ONE Shamir party on an open ProvingSession through the callback ABI; returns (proof, seconds).  Call it from one thread per party."""
+    nq = 6 if session.curve == BLS12_381 else 4
+    out = np.zeros(8 * nq, dtype=np.uint64); sec = (C.c_double * 1)()
+    keep = [np.ascontiguousarray(x, dtype=np.uint64) for x in (pub, wit)]
+    _hchk(load_host().cgh_session_prove_shamir_party(session.h, int(threshold), _hp(keep[0]), _hp(keep[1]), C.byref(net_table), C.byref(rand_table),
+                                                     C.c_size_t(int(preprocess)), _hp(out), sec))
+    return out, sec[0]
+
+
 def host_prove_rep3_party(session, pub, wit_a, wit_b, net_table, rand_table):
     """ONE REP3 party on an open ProvingSession through the callback ABI; returns (proof, seconds).  Call it from one thread per party."""
     nq = 6 if session.curve == BLS12_381 else 4

@@ -23,8 +23,8 @@ inline size_t msm_sort_direct_scratch_bytes(size_t n, int c, int nwin, int share
     return align_up(nbuckets * cap * 4) + 2 * align_up(nbuckets * 4) + align_up(((nbuckets + 2047) / 2048) * 4) + 256;
 }
 template <class F> int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, hipEvent_t ev_merged, const Affine<F>* d_bases, size_t n, int c, int nwin,
-                                             size_t table_stride, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs, bool may_have_inf);
-template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared);
+                                             size_t table_stride, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs, bool may_have_inf, uint32_t chunk_request);
+template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared, uint32_t chunk_request);
 template <class F> int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c);
 template <class F> int check_on_curve_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, const F& b, unsigned long long* d_counters);
 template <class F, class Fr> int check_subgroup_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, unsigned long long* d_counters);
@@ -258,10 +258,10 @@ template <class Fn> int with_coord_field(int curve, int group, Fn&& fn) {   // g
 // multiplied by the SAME k scalar vectors.  tickets_out[b] collects the k results for table b.
 int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, const size_t* offsets, size_t n, const void* const* d_scalars, int k, int* tickets_out, bool force_exact);
 int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, const size_t* offsets, size_t n, const void* const* d_scalars, int k, int* tickets_out, bool force_exact = false) {
-    struct Scope { uint32_t prev; Scope(uint32_t v) : prev(g_chunk_request) { g_chunk_request = v; } ~Scope() { g_chunk_request = prev; } } scope(ctx ? ctx->msm_chunk : 0);   // geometry of this context's launches
     return msm_begin_multi_impl_(ctx, nb, bases, offsets, n, d_scalars, k, tickets_out, force_exact);
 }
 int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, const size_t* offsets, size_t n, const void* const* d_scalars, int k, int* tickets_out, bool force_exact) {
+    const uint32_t chunk_request = ctx ? ctx->msm_chunk : 0;   // cg_msm_set_chunk: handed to every geometry computation of this call
     if (!ctx || !bases || !tickets_out || (n && !d_scalars)) return fail(CG_ERR_ARG, "null argument");
     if (nb < 1 || nb > 16) return fail(CG_ERR_ARG, "number of base tables out of range");
     if (k < 1 || k > 8) return fail(CG_ERR_ARG, "k out of range");
@@ -379,7 +379,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
             if (want <= 4096.0) { cap = 16; while ((double)cap < want) cap <<= 1; }
         }
     }
-    const MsmGeom geom = msm_geom(std::max<size_t>(n, 1), c, nwin, shared);
+    const MsmGeom geom = msm_geom(std::max<size_t>(n, 1), c, nwin, shared, 0, chunk_request);   // what is read here (sums per component, reduction kind) does not depend on the chunking
     const int nsums = geom.ngroups;
     // tickets + pinned result buffers
     std::vector<int> slots(nb);
@@ -403,7 +403,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
                 t.pinned_bytes = need;
             }
             if (n == 0) { XYZZ<F>* h = (XYZZ<F>*)t.h_pinned; for (int i = 0; i < k * nsums; i++) h[i] = XYZZ<F>::infinity(); }
-            else acc_bytes = std::max(acc_bytes, msm_acc_scratch_bytes<F>(n, c, nwin, shared));
+            else acc_bytes = std::max(acc_bytes, msm_acc_scratch_bytes<F>(n, c, nwin, shared, chunk_request));
             return 0;
         });
         if (rc) return rc;
@@ -464,7 +464,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
                     typedef decltype(ftag) F;
                     const Affine<F>* pts = (const Affine<F>*)(shared ? bases[b]->d_pre : bases[b]->d_pts) + (offsets ? offsets[b] : 0);
                     return msm_accumulate_reduce<F>(ctx->stream, ctx->aux, ctx->ev_acc[slot], ctx->ev_red[slot], ctx->ev_merged[j % nsched], pts, n, c, nwin, shared ? bases[b]->n : 0,
-                                                    sp.sorted, sp.offsets, sp.counts, sp.cap, acc_scratch + (size_t)slot * acc_slot, (XYZZ<F>*)t.h_pinned + (size_t)j * nsums, pev, !bases[b]->no_inf);
+                                                    sp.sorted, sp.offsets, sp.counts, sp.cap, acc_scratch + (size_t)slot * acc_slot, (XYZZ<F>*)t.h_pinned + (size_t)j * nsums, pev, !bases[b]->no_inf, chunk_request);
                 });
                 if (rc) return rc;
                 ctx->slot_busy[slot] = true; ctx->aux_pending = true; ctx->last_slot = slot; ctx->merged_pending[j % nsched] = true;

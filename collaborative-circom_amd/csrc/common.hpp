@@ -57,11 +57,12 @@ constexpr int MSM_SHARED_GROUPS = 16;
 // in lock step, so a launch of 2.16 residency rounds takes as long as 2.33 (the last 0.16 round runs one wave per SIMD, three
 // times as fast, on a sixth of the chip): when the list is long enough the chunk length is chosen so that the chunks fill a whole
 // number of rounds (2^22 points, 13 windows: 139 entries per lane, 2 rounds, instead of 128; measured 4.70 -> 4.51 ms per launch).
-// entries per lane requested by the calling context for this thread's launches (cg_msm_set_chunk; 0 = automatic): a context whose
-// accumulations run BESIDE a latency-critical chain on another context uses shorter chunks — a workgroup then lives ~1 ms instead of
-// ~2 and the chain's kernels, which can only start as workgroups retire, get onto the chip sooner
-inline thread_local uint32_t g_chunk_request = 0;
-inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_lanes = 0) {
+// chunk_request: entries per lane requested by the calling context (cg_msm_set_chunk; 0 = automatic): a context whose accumulations run
+// BESIDE a latency-critical chain on another context uses shorter chunks — a workgroup then lives ~1 ms instead of ~2 and the chain's
+// kernels, which can only start as workgroups retire, get onto the chip sooner.  Passed explicitly by every caller that sizes scratch
+// or launches from the geometry (the planner in capi.hip, msm_acc_scratch_bytes, msm_accumulate_reduce): all three must agree on nchunks.
+// g2: coordinates in the quadratic extension (LDS accumulators, no lock-stepped residency): chunks capped at CG_G2_CHUNK.
+inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_lanes = 0, uint32_t chunk_request = 0, bool g2 = false) {
     MsmGeom g;
     g.nb = 1u << (c - 1);
     g.nsets = shared ? 1 : nwin;
@@ -91,12 +92,12 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_
     // hardware's workgroup scheduler even out what the waves do not — 2^22 points: 12.4 -> 11.7 ms per launch alone, the step 71.5 -> 70.7 ms
     // (48: no better, the merge of twice as many boundary pieces takes it back).  CG_G2_CHUNK overrides (0 = no cap).
     static const size_t g2_chunk = [] { const char* e = getenv("CG_G2_CHUNK"); return e ? (size_t)atoi(e) : (size_t)64; }();
-    if (!resident_lanes && g2_chunk) g.chunk_len = (uint32_t)std::min<size_t>(g.chunk_len, std::max<size_t>(chunk_min, g2_chunk));
+    if (g2 && g2_chunk) g.chunk_len = (uint32_t)std::min<size_t>(g.chunk_len, std::max<size_t>(chunk_min, g2_chunk));
     static const bool no_rounds = getenv("CG_MSM_NO_ROUNDS") != nullptr;                  // tuning knob
-    if (g_chunk_request) g.chunk_len = (uint32_t)std::min<size_t>(g.chunk_len, std::max<size_t>(chunk_min, g_chunk_request));
+    if (chunk_request) g.chunk_len = (uint32_t)std::min<size_t>(g.chunk_len, std::max<size_t>(chunk_min, chunk_request));
     else if (resident_lanes && !no_rounds && entries >= resident_lanes * 2 * chunk_min) {      // from 32 entries per lane on (table slices of a multi-GPU plan:
         const size_t rounds = std::max<size_t>(1, (entries + resident_lanes * chunk_max / 2) / (resident_lanes * chunk_max));   // 2^20 points x 15 windows = one round of 80)
-        g.chunk_len = (uint32_t)((entries + rounds * resident_lanes - 1) / (rounds * resident_lanes));
+        g.chunk_len = (uint32_t)((entries + rounds * resident_lanes - 1) / (rounds * resident_lanes));   // between 2/3 and 3/2 of chunk_max (up to 192 entries): whole rounds matter more than the cap
     }
     g.nchunks = (uint32_t)std::max<size_t>(1, (entries + g.chunk_len - 1) / g.chunk_len);
     return g;

@@ -20,8 +20,8 @@ template <class F> struct IsFp2 { static constexpr bool value = false; };
 template <class B> struct IsFp2<Fp2<B>> { static constexpr bool value = true; };
 
 template <class F>
-size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared) {
-    MsmGeom g = msm_geom(n, c, nwin, shared, acc_resident_lanes<F>());
+size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared, uint32_t chunk_request) {
+    MsmGeom g = msm_geom(n, c, nwin, shared, acc_resident_lanes<F>(), chunk_request, IsFp2<F>::value);
     typedef typename BucketOf<F>::type B;
     g.bit_groups = bitsum_groups<B>(g.nb);
     return align_up(g.nbuckets * sizeof(B)) + align_up((size_t)g.nchunks * sizeof(B)) + align_up((size_t)g.nchunks * 4) +
@@ -35,9 +35,9 @@ size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared) {
 // schedule is no longer needed) and the latency-bound bucket reduction (a few hundred waves) run on `st2` behind `ev_acc` and signal `ev_red`, so it overlaps with the NEXT accumulation, which uses another scratch slot.
 template <class F>
 int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, hipEvent_t ev_merged, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride,
-                          const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs, bool may_have_inf) {
+                          const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs, bool may_have_inf, uint32_t chunk_request) {
     const bool shared = table_stride != 0;
-    MsmGeom g = msm_geom(n, c, nwin, shared, acc_resident_lanes<F>());
+    MsmGeom g = msm_geom(n, c, nwin, shared, acc_resident_lanes<F>(), chunk_request, IsFp2<F>::value);
     size_t off = 0;
     auto take = [&](size_t bytes) { void* p = scratch + off; off += align_up(bytes); return p; };
     typedef typename BucketOf<F>::type B;                 // limb-form points for the lazy pipelines, saturated XYZZ otherwise
@@ -74,7 +74,7 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
         if (lds > 0) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const uint32_t groups = (g.nchunks + T - 1) / T;
         static const bool no_slice = getenv("CG_G2_NO_SLICE") != nullptr;       // tuning knob
-        const uint32_t slice = lds > 0 && g_chunk_request && !no_slice ? 256u * (uint32_t)std::max<size_t>(1, ((size_t)160 << 10) / lds) : groups;
+        const uint32_t slice = lds > 0 && chunk_request && !no_slice ? 256u * (uint32_t)std::max<size_t>(1, ((size_t)160 << 10) / lds) : groups;
         for (uint32_t first = 0; first < groups; first += slice)
             hipLaunchKernelGGL(kern, dim3(std::min(slice, groups - first)), dim3(T), lds, st, d_bases, sorted, offsets, counts,
                                (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, (uint32_t)table_stride, buckets, cont, cont_bucket, may_have_inf ? 1u : 0u, first * (uint32_t)T);
@@ -215,8 +215,8 @@ int fixed_base_mul_launch(hipStream_t st, const Affine<F>& g, const Fr* d_scalar
 
 #define CG_INSTANTIATE_MSM(F, Fr)                                                                                          \
     namespace cg {                                                                                                         \
-    template int msm_accumulate_reduce<F>(hipStream_t, hipStream_t, hipEvent_t, hipEvent_t, hipEvent_t, const Affine<F>*, size_t, int, int, size_t, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, char*, XYZZ<F>*, hipEvent_t*, bool); \
-    template size_t msm_acc_scratch_bytes<F>(size_t, int, int, bool);                                                      \
+    template int msm_accumulate_reduce<F>(hipStream_t, hipStream_t, hipEvent_t, hipEvent_t, hipEvent_t, const Affine<F>*, size_t, int, int, size_t, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, char*, XYZZ<F>*, hipEvent_t*, bool, uint32_t); \
+    template size_t msm_acc_scratch_bytes<F>(size_t, int, int, bool, uint32_t);                                                      \
     template int precompute_window_launch<F>(hipStream_t, const Affine<F>*, Affine<F>*, size_t, int);                      \
     template int check_on_curve_launch<F>(hipStream_t, const Affine<F>*, size_t, const F&, unsigned long long*);           \
     template int check_subgroup_launch<F, Fr>(hipStream_t, const Affine<F>*, size_t, unsigned long long*);                 \

@@ -162,6 +162,39 @@ int32_t cgh_session_prove_rep3_party(void* h, const uint64_t* pub_in, const uint
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
 
+// ---- ONE Shamir party with the caller's network and randomness (co-circom.rs:507-527) -----------------------------------------------------
+int32_t cgh_session_prove_shamir_party(void* h, int32_t threshold, const uint64_t* pub_in, const uint64_t* wit_in, const cgh_shamir_net* net_cb,
+                                       const cgh_shamir_rand* rnd_cb, size_t preprocess, uint64_t* out_proof, double* seconds) {
+    cgh_session* s = (cgh_session*)h;
+    try {
+        using namespace cgh;
+        if (!s || !pub_in || !wit_in || !net_cb || !rnd_cb || !out_proof) throw std::runtime_error("cgh_session_prove_shamir_party: null argument");
+        if (!rnd_cb->random_field_elements) throw std::runtime_error("cgh_shamir_rand: random_field_elements is required");
+        const ZKey& z = s->z;
+        const size_t n_aux = z.n_vars - z.n_public - 1;
+        std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
+        CallbackShamirNet net(*net_cb);
+        Borrowed ctx(s, true, 0, false), second(s, s->second_context);
+        ProofWorkers workers(s);
+        ProofZKey pz(s, ctx.c, pub);
+        const auto t0 = std::chrono::steady_clock::now();
+        {
+            HipDriver driver(ctx.c, z.curve, Mode::Shamir, nullptr);
+            driver.aux = second.c; driver.owns_aux = false; driver.md = workers.get();
+            driver.sh_rand = rnd_cb;
+            driver.shamir_init(&net, threshold);                                        // ShamirProtocol::new, shamir.rs:211-246
+            driver.preprocess(preprocess);
+            VecGuard wit(driver, driver.upload_vec((const Fr*)wit_in, nullptr, n_aux));
+            CoGroth16 prover(driver);
+            Proof p = prover.prove(pz.dz, pub, wit.v, nullptr, nullptr);
+            if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            store_proof(p, (uint8_t*)out_proof);
+        }
+        ctx.ok = second.ok = true; workers.ok();
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+
 // ---- in-process transport behind the callback table (tests / bench / three parties on one box) ------------------------------------------
 namespace {
 struct Loopback {

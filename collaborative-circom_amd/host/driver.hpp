@@ -69,7 +69,14 @@ public:
         pre_on_host = true;
     }
     static constexpr size_t SHAMIR_BATCH = 1024;                                     // ShamirRng::BATCH_SIZE
-    Fr next_rand() { if (cursor >= rng_len) throw std::runtime_error("randomness stream exhausted"); return rng1[cursor++]; }
+    // Shamir with the caller's own RNG (cgh_session_prove_shamir_party): every draw goes through the callback instead of the stream rng1
+    const cgh_shamir_rand* sh_rand = nullptr;
+    void shamir_draw(size_t n, Fr* out) {
+        if (sh_rand) { if (const int32_t rc = sh_rand->random_field_elements(sh_rand->user, n, (uint64_t*)out)) throw std::runtime_error("randomness source: random_field_elements failed with code " + std::to_string(rc)); return; }
+        if (cursor + n > rng_len) throw std::runtime_error("randomness stream exhausted");
+        memcpy(out, rng1 + cursor, n * 32); cursor += n;
+    }
+    Fr next_rand() { Fr x; shamir_draw(1, &x); return x; }
     std::vector<Fr> lagrange_from_coeff(const std::vector<size_t>& pts) const {       // shamir_core.rs:56-75
         std::vector<Fr> res;
         for (size_t i : pts) {
@@ -150,10 +157,11 @@ public:
         if (!amount) return;
         const int np = snet->num_parties(), me = snet->id(), t = sh_t;
         const size_t draws = amount * (size_t)(1 + 3 * t);
-        if (cursor + draws > rng_len) throw std::runtime_error("randomness stream exhausted");
+        if (!sh_rand && cursor + draws > rng_len) throw std::runtime_error("randomness stream exhausted");
         Marks mk("shamir preprocess", me == 0);
         void* d_rnd = dalloc(draws * 32);
-        CG(cg_dev_upload(ctx, d_rnd, rng1 + cursor, draws * 32)); cursor += draws;
+        if (sh_rand) { std::vector<Fr> tmp(draws); shamir_draw(draws, tmp.data()); CG(cg_dev_upload(ctx, d_rnd, tmp.data(), draws * 32)); }
+        else { CG(cg_dev_upload(ctx, d_rnd, rng1 + cursor, draws * 32)); cursor += draws; }
         mk.mark("upload draws");
         const Fr one = fr_from_u64(curve, 1);
         std::vector<void*> d_got(np);

@@ -179,4 +179,18 @@ struct InProcShamirNet : ShamirNet {
     }
 };
 
+// the caller's any-to-any transport behind cgh_shamir_net (cgh_session_prove_shamir_party): closures over ShamirMpcNet in the Rust binding
+struct CallbackShamirNet : ShamirNet {
+    cgh_shamir_net cb;
+    explicit CallbackShamirNet(const cgh_shamir_net& c) : cb(c) {
+        if (cb.num_parties < 3) throw std::runtime_error("Shamir protocol requires at least 3 parties");                       // shamir/network.rs:75-77
+        if (cb.party_id < 0 || cb.party_id >= cb.num_parties) throw std::runtime_error("Shamir party id out of range");
+        if (!cb.send || !cb.recv) throw std::runtime_error("cgh_shamir_net: send and recv are required");
+    }
+    int id() const override { return cb.party_id; }
+    int num_parties() const override { return cb.num_parties; }
+    void send(int to, const void* d, size_t b) override { if (const int32_t rc = cb.send(cb.user, to, d, b)) throw std::runtime_error("network: send failed with code " + std::to_string(rc)); }
+    void recv(int from, void* d, size_t b) override { if (const int32_t rc = cb.recv(cb.user, from, d, b)) throw std::runtime_error("network: recv failed with code " + std::to_string(rc)); }
+};
+
 }  // namespace cgh

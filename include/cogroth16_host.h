@@ -126,6 +126,24 @@ typedef struct cgh_rep3_rand {
 int32_t cgh_session_prove_rep3_party(void* session, const uint64_t* pub_in, const uint64_t* wit_a, const uint64_t* wit_b,
                                      const cgh_rep3_net* net, const cgh_rep3_rand* rnd, uint64_t* out_proof, double* seconds);
 
+/* The Shamir twin (co-circom.rs:507-527: `ShamirMpcNet::new`, `ShamirProtocol::new(t, net)`, `prover.prove`): ONE of n parties, threshold t,
+ * with the caller's any-to-any network (shamir/network.rs:17-59: one message = one send / recv pair between two parties) and the caller's
+ * PRIVATE randomness (ShamirProtocol's own RNG: the coefficients of ShamirCore::share, shamir/shamir_core.rs:8-31, the secrets of
+ * buffer_triples, shamir.rs:923-1010 — F::rand draws in the order the reference makes them).  preprocess > 0: that many double sharings are
+ * generated up front on the GPU (ShamirProtocol::preprocess, shamir.rs:248-250); 0 = the reference's lazy batches of 1024. */
+typedef struct cgh_shamir_net {
+    void* user;
+    int32_t party_id, num_parties;                                              /* get_id(), get_num_parties() */
+    int32_t (*send)(void* user, int32_t to, const void* data, size_t bytes);
+    int32_t (*recv)(void* user, int32_t from, void* data, size_t bytes);
+} cgh_shamir_net;
+typedef struct cgh_shamir_rand {
+    void* user;
+    int32_t (*random_field_elements)(void* user, size_t n, uint64_t* out);      /* n x F::rand(&mut self.rng), Montgomery */
+} cgh_shamir_rand;
+int32_t cgh_session_prove_shamir_party(void* session, int32_t threshold, const uint64_t* pub_in, const uint64_t* wit, const cgh_shamir_net* net,
+                                       const cgh_shamir_rand* rnd, size_t preprocess, uint64_t* out_proof, double* seconds);
+
 /* Transports and randomness sources for tests, benches and single-box deployments; each fills a callback table for the entry above.
  * cgh_loopback_*: three parties of one process joined by in-memory queues (the role of tests/src/rep3_network.rs).  record != 0 keeps
  * a copy of everything that party receives (large messages in page-locked memory); cgh_loopback_replay_net then serves that traffic

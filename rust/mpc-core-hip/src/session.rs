@@ -220,3 +220,91 @@ unsafe extern "C" fn masking_ec_element<P: Pairing>(u: *mut c_void, group: i32, 
     }
     0
 }
+
+// ---- the Shamir twin (co-circom.rs:507-527) ----------------------------------------------------------------------------------------------------
+// ONE of n Shamir parties: the any-to-any network stays the caller's `ShamirMpcNet` (send_bytes / recv_bytes, shamir/network.rs:134-160) and
+// the party's PRIVATE randomness its own `rand::Rng` — `ShamirProtocol` keeps both in private fields (`network`, `rng_buffer.rng`,
+// shamir.rs:197-205, 873-880), so this entry takes them directly instead of through the protocol object: construct the net as the CLI
+// does (`ShamirMpcNet::new(config.network)`), seed an `RngType` as `ShamirProtocol::new` does (`RngType::from_entropy()`), and call this
+// instead of `ShamirProtocol::new(t, net)` + `CoGroth16::prove`.
+#[repr(C)]
+pub struct cgh_shamir_net {
+    pub user: *mut c_void,
+    pub party_id: i32,
+    pub num_parties: i32,
+    pub send: Option<unsafe extern "C" fn(*mut c_void, i32, *const c_void, usize) -> i32>,
+    pub recv: Option<unsafe extern "C" fn(*mut c_void, i32, *mut c_void, usize) -> i32>,
+}
+#[repr(C)]
+pub struct cgh_shamir_rand {
+    pub user: *mut c_void,
+    pub random_field_elements: Option<unsafe extern "C" fn(*mut c_void, usize, *mut u64) -> i32>,
+}
+extern "C" {
+    fn cgh_session_prove_shamir_party(session: *mut c_void, threshold: i32, pub_in: *const u64, wit: *const u64, net: *const cgh_shamir_net,
+                                      rnd: *const cgh_shamir_rand, preprocess: usize, out_proof: *mut u64, seconds: *mut f64) -> i32;
+}
+struct ShamirCallbacks<'a, F: PrimeField, R: rand::Rng> {
+    net: &'a mut mpc_core::protocols::shamir::network::ShamirMpcNet,
+    rng: &'a mut R,
+    error: Option<io::Error>,
+    _f: std::marker::PhantomData<F>,
+}
+unsafe extern "C" fn sh_send<F: PrimeField, R: rand::Rng>(u: *mut c_void, to: i32, d: *const c_void, n: usize) -> i32 {
+    let s = &mut *(u as *mut ShamirCallbacks<F, R>);
+    match s.net.send_bytes(to as usize, Bytes::copy_from_slice(slice::from_raw_parts(d as *const u8, n))) {
+        Ok(()) => 0,
+        Err(e) => { let c = e.raw_os_error().unwrap_or(5); s.error.get_or_insert(e); if c == 0 { 5 } else { c } }
+    }
+}
+unsafe extern "C" fn sh_recv<F: PrimeField, R: rand::Rng>(u: *mut c_void, from: i32, d: *mut c_void, n: usize) -> i32 {
+    let s = &mut *(u as *mut ShamirCallbacks<F, R>);
+    match s.net.recv_bytes(from as usize) {
+        Ok(frame) if frame.len() == n => { ptr::copy_nonoverlapping(frame.as_ptr(), d as *mut u8, n); 0 }
+        Ok(_) => { s.error.get_or_insert(io::Error::new(io::ErrorKind::InvalidData, "During execution of degree_reduce_vec in MPC: Invalid number of elements received")); 74 } // shamir.rs:324-329
+        Err(e) => { let c = e.raw_os_error().unwrap_or(5); s.error.get_or_insert(e); if c == 0 { 5 } else { c } }
+    }
+}
+unsafe extern "C" fn sh_rand<F: PrimeField, R: rand::Rng>(u: *mut c_void, n: usize, out: *mut u64) -> i32 {
+    let s = &mut *(u as *mut ShamirCallbacks<F, R>);
+    for d in slice::from_raw_parts_mut(out as *mut F, n).iter_mut() {
+        *d = F::rand(s.rng); // the draws of ShamirCore::share / buffer_triples, in the reference's order
+    }
+    0
+}
+impl Groth16Session {
+    /// `CoGroth16::<ShamirProtocol<_, ShamirMpcNet>, P>::prove` for this party.  `witness` = `SharedWitness::witness` as plain field elements
+    /// (`ShamirPrimeFieldShareVec`, shamir/fieldshare.rs:152-155); `preprocess` > 0 generates that many double sharings on the GPU up front.
+    pub fn prove_shamir<P: Pairing, R: rand::Rng>(
+        &self,
+        net: &mut mpc_core::protocols::shamir::network::ShamirMpcNet,
+        rng: &mut R,
+        threshold: usize,
+        public_inputs: &[P::ScalarField],
+        witness: &[P::ScalarField],
+        preprocess: usize,
+    ) -> io::Result<(P::G1Affine, P::G2Affine, P::G1Affine)>
+    where
+        P::G1: PackedAffine,
+        P::G2: PackedAffine,
+    {
+        use mpc_core::protocols::shamir::network::ShamirNetwork;
+        let (id, n) = (net.get_id(), net.get_num_parties());
+        let mut state = ShamirCallbacks::<P::ScalarField, R> { net, rng, error: None, _f: std::marker::PhantomData };
+        let user = &mut state as *mut _ as *mut c_void;
+        let net_cb = cgh_shamir_net { user, party_id: id as i32, num_parties: n as i32, send: Some(sh_send::<P::ScalarField, R>), recv: Some(sh_recv::<P::ScalarField, R>) };
+        let rnd_cb = cgh_shamir_rand { user, random_field_elements: Some(sh_rand::<P::ScalarField, R>) };
+        let fq = size_of::<<P::G1 as CurveGroup>::BaseField>() / 8;
+        let mut proof = vec![0u64; 8 * fq];
+        let rc = unsafe {
+            cgh_session_prove_shamir_party(self.handle, threshold as i32, public_inputs.as_ptr() as *const u64, witness.as_ptr() as *const u64, &net_cb, &rnd_cb,
+                                           preprocess, proof.as_mut_ptr(), ptr::null_mut())
+        };
+        if rc != 0 {
+            return Err(state.error.take().unwrap_or_else(|| io::Error::new(io::ErrorKind::Other, host_error())));
+        }
+        let (a, rest) = proof.split_at(2 * fq);
+        let (b, c) = rest.split_at(4 * fq);
+        Ok((<P::G1 as PackedAffine>::from_packed(a), <P::G2 as PackedAffine>::from_packed(b), <P::G1 as PackedAffine>::from_packed(c)))
+    }
+}

@@ -310,3 +310,75 @@ def test_a_failing_network_callback_fails_the_proof():
         for r in rands: r.close()
     finally:
         ses.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- Shamir twin
+class ShamirMeshEnd:
+    """party `me` of n: one socket per directed pair, framed messages, a reader thread per incoming socket (as SocketEnd)"""
+
+    def __init__(self, me, n, outs, ins, stream):
+        self.me, self.n, self.out = me, n, outs
+        self.inq = {p: queue.Queue() for p in ins}
+        self.readers = [threading.Thread(target=SocketEnd._reader, args=(sock, self.inq[p]), daemon=True) for p, sock in ins.items()]
+        for r in self.readers: r.start()
+        self.stream, self.k, self.sent = stream, 0, 0
+        self._cbs = (cg._SH_SEND(self._send), cg._SH_RECV(self._recv), cg._SH_RAND(self._rand))
+        self.net = cg.ShamirNetTable(None, me, n, self._cbs[0], self._cbs[1])
+        self.rand = cg.ShamirRandTable(None, self._cbs[2])
+
+    def _send(self, u, to, data, nbytes):
+        try: self.out[to].sendall(struct.pack("<Q", nbytes) + C.string_at(data, nbytes)); self.sent += 1; return 0
+        except OSError as e: return e.errno or 5
+
+    def _recv(self, u, frm, data, nbytes):
+        try: msg = self.inq[frm].get(timeout=120)
+        except queue.Empty: return 110
+        if msg is None: return 104
+        if len(msg) != nbytes: return 74
+        C.memmove(data, msg, nbytes)
+        return 0
+
+    def _rand(self, u, n, out):
+        if self.k + n > self.stream.shape[0]: return 1
+        C.memmove(out, self.stream[self.k:self.k + n].ctypes.data, 32 * n); self.k += n
+        return 0
+
+    def close(self):
+        for s in self.out.values():
+            try: s.shutdown(socket.SHUT_RDWR)
+            except OSError: pass
+            s.close()
+
+
+def shamir_mesh(n, streams):
+    pairs = {(a, b): socket.socketpair() for a in range(n) for b in range(n) if a != b}      # (a, b): a writes [0], b reads [1]
+    return [ShamirMeshEnd(i, n, {b: pairs[(i, b)][0] for b in range(n) if b != i}, {a: pairs[(a, i)][1] for a in range(n) if a != i}, streams[i]) for i in range(n)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name,n,t,preprocess", [("bn254", 3, 1, 0), ("bn254", 5, 2, 600), ("bls12_381", 3, 1, 0)])
+def test_shamir_parties_over_sockets_give_the_oracle_proof(curve_name, n, t, preprocess):
+    """cgh_session_prove_shamir_party: n threads, each ONE party through the C callback ABI (any-to-any sockets, the party's private
+    randomness served by a callback), poseidon fixture; lazy double sharings (batches of 1024) and preprocess(amount) on the GPU"""
+    from test_shamir import setup
+    ensure_built()
+    curve, z, w, wits, streams = setup(curve_name, "poseidon", n, t, seed=41, preprocess=preprocess)
+    pub = w[:z.n_public + 1]
+    want = orc.prove_shamir(z, n, t, pub, wits, streams, preprocess=preprocess)
+    ses = cg.ProvingSession(curve, fx(curve_name, "poseidon", "circuit.zkey"), precompute=False)
+    ends = shamir_mesh(n, streams)
+    out, errs = [None] * n, [None] * n
+
+    def party(i):
+        try: out[i], _ = cg.host_prove_shamir_party(ses, t, pub, wits[i], ends[i].net, ends[i].rand, preprocess=preprocess)
+        except Exception as e: errs[i] = e
+    try:
+        th = [threading.Thread(target=party, args=(i,)) for i in range(n)]
+        for x in th: x.start()
+        for x in th: x.join(300)
+        assert errs == [None] * n, errs
+        np.testing.assert_array_equal(np.stack(out), want)
+        assert all(e.sent > 0 for e in ends)
+    finally:
+        for e in ends: e.close()
+        ses.close()
