@@ -644,7 +644,7 @@ public:
     PendingMsm msm_begin_sharded(const DeviceZKey& dz, bool aux_tables, const ShareVec& s) {
         const size_t lo = aux_tables ? dz.aux_lo : dz.h_lo, n = aux_tables ? dz.aux_n : dz.h_n;
         ShareVec mine; mine.n = n; for (int j = 0; j < k(); j++) mine.c[j] = (char*)s.c[j] + lo * 32;
-        PendingMsm p = aux_tables ? msm_begin_multi({dz.l, dz.a, dz.b1, dz.b2}, {0, 0, 0, 0}, {CG_G1, CG_G1, CG_G1, CG_G2}, n, mine, true)
+        PendingMsm p = aux_tables ? msm_begin_multi({dz.a, dz.b1, dz.b2, dz.l}, {0, 0, 0, 0}, {CG_G1, CG_G1, CG_G2, CG_G1}, n, mine, true)   // table order = CoGroth16::prove's AUX_* indices
                                   : msm_begin_multi({dz.h}, {0}, {CG_G1}, n, mine, false);
         if (!md) return p;
         static const bool primary_only = getenv("CGH_EMULATE_PRIMARY_ONLY") != nullptr;    // planning knob: time the primary device's share of an
@@ -657,11 +657,11 @@ public:
                 CG(cg_dev_alloc(w.ctx, std::max<size_t>(wn * 32, 32), &part.sc[j]));
                 CG(cg_dev_copy_peer(w.ctx, part.sc[j], ctx, (const char*)s.c[j] + wlo * 32, wn * 32));
             }
-            std::vector<const cg_bases*> tabs = aux_tables ? std::vector<const cg_bases*>{wz.l, wz.a, wz.b1, wz.b2} : std::vector<const cg_bases*>{wz.h};
+            std::vector<const cg_bases*> tabs = aux_tables ? std::vector<const cg_bases*>{wz.a, wz.b1, wz.b2, wz.l} : std::vector<const cg_bases*>{wz.h};
             std::vector<size_t> offs(tabs.size(), 0);
             part.tickets.resize(tabs.size());
             const void* sc[2] = {part.sc[0], part.sc[1]};
-            begin_multi_ordered(w.ctx, tabs, offs, aux_tables ? std::vector<int>{CG_G1, CG_G1, CG_G1, CG_G2} : std::vector<int>{CG_G1}, wn, sc, part.tickets);
+            begin_multi_ordered(w.ctx, tabs, offs, aux_tables ? std::vector<int>{CG_G1, CG_G1, CG_G2, CG_G1} : std::vector<int>{CG_G1}, wn, sc, part.tickets);
             p.parts.push_back(part);
         }
         return p;

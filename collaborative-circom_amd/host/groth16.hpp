@@ -74,9 +74,12 @@ public:
         HipDriver::Marks mk("prove party 0", driver.party() <= 0);
         std::vector<Fr> input_assignment(public_inputs.begin() + 1, public_inputs.end());
         const size_t first_aux = 1 + input_assignment.size();
-        // l (:251), a (:267 -> :221), b1 (:284), b2 (:298): one call, one scalar schedule, on the second context
+        // a (:267 -> :221), b1 (:284), b2 (:298), l (:251): one call, one scalar schedule, on the second context.  Launch order within a
+        // share component: b2 (G2 first, HipDriver::begin_multi_ordered), a, b1, l — the order in which the results are consumed below, so
+        // that the host's work on a result (public-input terms, openings, scalar multiplications) runs under the accumulation of the next
+        enum { AUX_A = 0, AUX_B1 = 1, AUX_B2 = 2, AUX_L = 3 };
         auto aux_msm = dz.sliced ? driver.msm_begin_sharded(dz, true, private_witness)
-                                 : driver.msm_begin_multi({dz.l, dz.a, dz.b1, dz.b2}, {0, first_aux, first_aux, first_aux}, {CG_G1, CG_G1, CG_G1, CG_G2}, private_witness.n, private_witness, true);
+                                 : driver.msm_begin_multi({dz.a, dz.b1, dz.b2, dz.l}, {first_aux, first_aux, first_aux, 0}, {CG_G1, CG_G1, CG_G2, CG_G1}, private_witness.n, private_witness, true);
         mk.mark("aux msm enqueued");
         // Several GPUs: the witness map itself is spread over them (multidev.hpp) and every device multiplies its own rows of h
         const bool distributed = DistributedWitnessMap::usable(driver, dz);
@@ -126,14 +129,14 @@ public:
         PointShare s_g1 = driver.scalar_mul_public_point(delta_g1, s);                                 // :283
         PointShare s_g2 = driver.scalar_mul_public_point(delta_g2, s);                                 // :297
         mk.mark("scalar steps under the msms");
-        PointShare g_a = calculate_coeff(r_g1, z.a_query, CG_G1, z.alpha_g1, input_assignment, driver.msm_finish(aux_msm, 1));   // :267
+        PointShare g_a = calculate_coeff(r_g1, z.a_query, CG_G1, z.alpha_g1, input_assignment, driver.msm_finish(aux_msm, AUX_A));   // :267
         Point g_a_opened = driver.open_point(g_a);                                                     // :276
         PointShare s_g_a = driver.scalar_mul_public_point(g_a_opened, s);                              // :277
-        PointShare g1_b = calculate_coeff(s_g1, z.b_g1_query, CG_G1, z.beta_g1, input_assignment, driver.msm_finish(aux_msm, 2));   // :284
+        PointShare g1_b = calculate_coeff(s_g1, z.b_g1_query, CG_G1, z.beta_g1, input_assignment, driver.msm_finish(aux_msm, AUX_B1));   // :284
         PointShare r_g1_b = driver.scalar_mul(g1_b, r);                                                // :291
-        PointShare g2_b = calculate_coeff(s_g2, z.b_g2_query, CG_G2, z.beta_g2, input_assignment, driver.msm_finish(aux_msm, 3));   // :298
+        PointShare g2_b = calculate_coeff(s_g2, z.b_g2_query, CG_G2, z.beta_g2, input_assignment, driver.msm_finish(aux_msm, AUX_B2));   // :298
         mk.mark("msm a, b1, b2 + their scalar steps");
-        PointShare l_aux_acc = driver.msm_finish(aux_msm, 0);                                          // :251
+        PointShare l_aux_acc = driver.msm_finish(aux_msm, AUX_L);                                          // :251
         PointShare h_acc = driver.msm_finish(h_msm, 0);                                                // :248
         mk.mark("msm l + h");
         PointShare g_c = s_g_a;                                                                        // :308-312
