@@ -48,6 +48,7 @@ public:
         for (Dev& d : devs) cg_ctx_sync(d.ctx);                                    // blocks of one device are read by the others' peer copies: all quiet first
         for (Dev& d : devs) for (void* p : d.owned) cg_dev_free(d.ctx, p);
         for (void* p : pinned) cg_host_free(p);
+        for (void* p : host_tmp) free(p);
     }
     bool skip(size_t d) const { return primary_only && d != 0; }
     void* dalloc(Dev& d, size_t bytes) { void* p; CG(cg_dev_alloc(d.ctx, std::max<size_t>(bytes, 32), &p)); d.owned.push_back(p); return p; }
@@ -226,8 +227,6 @@ public:
             release(D, h.c[0]); if (h.c[1]) release(D, h.c[1]);                                // handed to the caller
             out.parts.push_back({D.ctx, h});
         }
-        for (void* p : host_tmp) free(p);
-        host_tmp.clear();
         return out;
     }
     // iNTT -> coset shift -> NTT of vectors [v0, v1) on their owners' streams
