@@ -198,6 +198,29 @@ def test_stream_rand_follows_rep3rand(curve):
         src.close()
 
 
+def test_party_entries_reject_bad_arguments_without_a_gpu():
+    """the one-party entries validate what they are handed before touching a device: null pointers, a party id outside 0..2, missing
+    required callbacks, fewer than three Shamir parties (shamir/network.rs:75-77) — status 1 and a message, never a crash"""
+    ensure_built()
+    h = cg.load_host()
+    out = np.zeros(32, dtype=np.uint64); pub = np.zeros((2, 4), dtype=np.uint64)
+    net = cg.Rep3NetTable(); rnd = cg.Rep3RandTable()
+    assert h.cgh_session_prove_rep3_party(None, None, None, None, C.byref(net), C.byref(rnd), None, None) != 0
+    assert b"null argument" in h.cgh_last_error()
+    sn = cg.ShamirNetTable(); sr = cg.ShamirRandTable()
+    assert h.cgh_session_prove_shamir_party(None, 1, None, None, C.byref(sn), C.byref(sr), C.c_size_t(0), None, None) != 0
+    assert b"null argument" in h.cgh_last_error()
+    # loopback tables for a party id that does not exist
+    hub = cg.LoopbackHub()
+    try:
+        with pytest.raises(cg.BackendError):
+            hub.net(3)
+        with pytest.raises(cg.BackendError):
+            hub.replay_net(-1)
+    finally:
+        hub.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
