@@ -1,0 +1,15 @@
+"""The product's session entry points (cgh_session_prove_plain / cgh_session_prove_rep3_party: host buffers in, proof out, PCIe inside the
+timed call) at several circuit sizes, with bench.py's own session leg.  usage: python scripts/product_entry_sizes.py [log_m ...]"""
+import importlib, json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+cg = importlib.import_module("collaborative-circom_amd")
+import bench
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+ctx = cg.Context(0)
+for log_m in [int(x) for x in sys.argv[1:]] or [20, 22]:
+    s = bench.session_leg(ctx, log_m, dev)
+    nc = (1 << log_m) - 2
+    print(f"2^{log_m}: plain {s['plain_ms']:.1f} ms ({nc / s['plain_ms'] / 1e3:.1f} M constraints/s); one REP3 party {s['rep3_party_ms']:.1f} ms mean / {s['rep3_party_ms_min']:.1f} min "
+          f"({nc / s['rep3_party_ms'] / 1e3:.1f} M constraints/s); three parties on one GPU {s['rep3_three_parties_one_gpu_ms']:.1f} ms; zkey {s['zkey']['file_bytes'] / 1e9:.2f} GB generated in "
+          f"{s['zkey']['generate_s']:.1f} s, session open {s['zkey']['session_open_s']:.1f} s; proofs agree: {s['three_parties_agree']}", flush=True)
