@@ -84,13 +84,15 @@ public:
         // Several GPUs: the witness map itself is spread over them (multidev.hpp) and every device multiplies its own rows of h
         const bool distributed = DistributedWitnessMap::usable(driver, dz);
         std::unique_ptr<DistributedWitnessMap> dmap;
-        DistributedH dh;
+        struct HParts : DistributedH {     // the rows of h on their devices: released when prove leaves, however it leaves (after the map's own buffers)
+            ~HParts() { for (auto& part : parts) for (int j = 0; j < 2; j++) if (part.h.c[j]) cg_dev_free(part.ctx, part.h.c[j]); }
+        } dh;
         ShareVec h;
         HipDriver::PendingMsm h_msm;
         if (distributed) {
             if (h_out) throw std::runtime_error("the quotient vector of a multi-device proof stays distributed (h_out is a single-device option)");
             dmap.reset(new DistributedWitnessMap(driver, dz, *driver.md));
-            dh = dmap->run(dz, public_inputs, private_witness);
+            static_cast<DistributedH&>(dh) = dmap->run(dz, public_inputs, private_witness);
             mk.mark("witness map (distributed)");
             h_msm.on = driver.ctx; h_msm.groups = {CG_G1}; h_msm.tickets.resize(1);
             for (size_t d = 0; d < dh.parts.size(); d++) {                                             // :248, rows of device d against its slice of h_query
@@ -147,7 +149,6 @@ public:
         auto opened = driver.open_two_points(g_c, g2_b);                                               // :316
         mk.mark("open");
         driver.msm_release(aux_msm); driver.msm_release(h_msm);
-        for (auto& part : dh.parts) for (int j = 0; j < 2; j++) if (part.h.c[j]) CG(cg_dev_free(part.ctx, part.h.c[j]));
         dmap.reset();
         if (h_out) *h_out = h; else driver.free_vec(h);
         return Proof{pt_to_affine(c, g_a_opened), pt_to_affine(c, opened.second), pt_to_affine(c, opened.first)};   // :319-325

@@ -130,7 +130,8 @@ int32_t cg_msm_dev_begin_multi(cg_ctx* ctx, int32_t n_tables, const cg_bases* co
 /* Scalars still crossing PCIe: the NEXT cg_msm_dev_begin / _begin_multi on `ctx` lets the digit / sort schedule of share component
  * `component` (0 <= component < 4) wait on the device for the asynchronous upload `copy_ticket` of context `owner` (cg_dev_upload_begin)
  * instead of the host waiting for it — component a is scheduled and accumulated while component b is still on its way up
- * (`Rep3PrimeFieldShareVec{a, b}`, rep3/fieldshare.rs:233-236, arrives as two vectors).  Consumed by that one call. */
+ * (`Rep3PrimeFieldShareVec{a, b}`, rep3/fieldshare.rs:233-236, arrives as two vectors).  Consumed by that one call; `owner` must stay alive
+ * until that call has returned (the library keeps a reference to the copy's completion event, not to the context). */
 int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int32_t copy_ticket);
 /* window size override (0 = automatic); tuning knob only, never changes results */
 /* entries of the sorted list one lane folds in the bucket accumulation of THIS context's MSMs (0 = automatic: ~128, whole residency
