@@ -113,11 +113,22 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     HIPCHK(hipEventRecord(ev_acc, st));
     HIPCHK(hipStreamWaitEvent(st2, ev_acc, 0));
     if (evs) HIPCHK(hipEventRecord(evs[2], st2));
+    // measurement only (results are WRONG): what the merges (1: skipped too) and the bucket reduction (2: only it) cost the step beside the accumulations
+    static const int skip_reduce = getenv("CG_DEBUG_NO_REDUCE") ? atoi(getenv("CG_DEBUG_NO_REDUCE")) : 0;
+    auto fake_reduce = [&]() -> int {
+        if (evs) HIPCHK(hipEventRecord(evs[3], st2));
+        HIPCHK(hipMemsetAsync(wsums, 0, (size_t)g.ngroups * sizeof(XYZZ<F>), st2));
+        HIPCHK(hipMemcpyAsync(h_out, wsums, (size_t)g.ngroups * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st2));
+        HIPCHK(hipEventRecord(ev_red, st2));
+        return 0;
+    };
+    if (skip_reduce == 1) { HIPCHK(hipEventRecord(ev_merged, st2)); return fake_reduce(); }
     hipLaunchKernelGGL((k_msm_merge_direct<B>), dim3((unsigned)((g.nbuckets + 63) / 64)), dim3(64), 0, st2, buckets, cont, cont_bucket, offsets, counts,
                        (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, cap);
     hipLaunchKernelGGL((k_msm_merge_cont_l1<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st2, cont, cont_bucket, g.nchunks);
     hipLaunchKernelGGL((k_msm_merge_cont<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st2, buckets, cont, cont_bucket, g.nchunks);
     HIPCHK(hipEventRecord(ev_merged, st2));                                          // the last reader of the sorted schedule (offsets / counts)
+    if (skip_reduce == 2) return fake_reduce();
     if (g.bitsum) {
         static PerDeviceOnce attr_set2;
         if (attr_set2.pending()) {
