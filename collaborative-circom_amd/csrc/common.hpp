@@ -38,6 +38,10 @@ inline int log2_floor(size_t n) { int l = 0; while (((size_t)2 << l) <= n) l++; 
 
 // ---- MSM launch geometry: shared by the kernel launchers (msm_impl.hpp) and the host-side planner (capi.hip) --------------------------
 constexpr int BITSUM_ITEMS = 8;   // buckets per lane in k_msm_bitsum_partial
+#ifndef CG_GRID_TR
+#define CG_GRID_TR 32
+#endif
+constexpr int GRID_LOG_L = 10, GRID_TR = CG_GRID_TR, GRID_TC = 64;   // k_msm_grid_partial: columns of the bucket grid, tile rows / columns per workgroup
 struct MsmGeom {            // derived sizes shared by the host-side planner and the launchers
     uint32_t nb;            // buckets per bucket set = 2^(c-1)
     int nsets;              // bucket sets: nwin (classic) or 1 (shared: per-window precomputed tables)
@@ -50,7 +54,7 @@ struct MsmGeom {            // derived sizes shared by the host-side planner and
     uint32_t bit_groups;    // workgroups per bit in k_msm_bitsum_partial
     // large shared bucket set: row / column sums + per-bit sums (k_msm_grid_partial / k_msm_grid_bitsum); ngroups = (log_l + 1) gc + log_h gr
     bool grid; int log_l, log_h; uint32_t gc, gr;
-    size_t grid_partials() const { return grid ? ((size_t)1 << log_h) / 32 * ((size_t)1 << log_l) + ((size_t)1 << log_h) * (((size_t)1 << log_l) / 64) : 0; }
+    size_t grid_partials() const { return grid ? ((size_t)1 << log_h) / GRID_TR * ((size_t)1 << log_l) + ((size_t)1 << log_h) * (((size_t)1 << log_l) / GRID_TC) : 0; }
 };
 constexpr int MSM_SHARED_GROUPS = 16;
 // resident_lanes: lanes of the accumulation kernel the chip holds at once (0 = unknown).  Its workgroups do equal work and finish
@@ -80,8 +84,8 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_
     g.grid = shared && g.nb > (1u << 16) && !no_grid; g.log_l = 10; g.log_h = c - 1 - 10; g.gc = g.gr = 1;
     if (g.grid) {
         const size_t H = (size_t)1 << g.log_h, L = (size_t)1 << g.log_l, per_group = 256 * BITSUM_ITEMS;
-        g.gc = (uint32_t)std::max<size_t>(1, (H / 32 * (L / 2) + per_group - 1) / per_group);
-        g.gr = (uint32_t)std::max<size_t>(1, (H / 2 * (L / 64) + per_group - 1) / per_group);
+        g.gc = (uint32_t)std::max<size_t>(1, (H / GRID_TR * (L / 2) + per_group - 1) / per_group);
+        g.gr = (uint32_t)std::max<size_t>(1, (H / 2 * (L / GRID_TC) + per_group - 1) / per_group);
         g.ngroups = (int)((g.log_l + 1) * g.gc + g.log_h * g.gr);
     }
     const size_t entries = (size_t)nwin * n;

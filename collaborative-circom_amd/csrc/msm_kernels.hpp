@@ -17,6 +17,7 @@
 // With uniformly random scalars (REP3 shares always are) every bucket receives n/2^(c-1) +- sqrt points: lanes are balanced.
 #pragma once
 #include <type_traits>
+#include "common.hpp"
 #include "curve.hpp"
 #include "lazy29.hpp"
 #include "vec_kernels.hpp"
@@ -615,7 +616,6 @@ __global__ void __launch_bounds__(64) k_msm_bitsum_final(const B* __restrict__ p
 //       colpart[H / 32][L] and rowpart[H][L / 64]                                   (2^19 buckets: 256 workgroups, 65 536 lanes)
 //   k_msm_grid_bitsum:  workgroup (side, bit k, group g): 256 lanes x ITEMS partials whose weight has bit k set + LDS tree -> one
 //       canonical XYZZ sum per workgroup for the host (62 of them at 2^19 buckets)
-constexpr int GRID_LOG_L = 10, GRID_TR = 32, GRID_TC = 64;
 template <class B>
 __global__ void __launch_bounds__(256) k_msm_grid_partial(const B* __restrict__ buckets, uint32_t log_l, uint32_t nb, B* __restrict__ colpart, B* __restrict__ rowpart) {
     extern __shared__ uint4 lds_raw[];
@@ -623,10 +623,12 @@ __global__ void __launch_bounds__(256) k_msm_grid_partial(const B* __restrict__ 
     const uint32_t L = 1u << log_l, ncb = L / GRID_TC;
     const uint32_t cb = blockIdx.x % ncb, rb = blockIdx.x / ncb, t = threadIdx.x;
     const B* tile = buckets + (size_t)rb * GRID_TR * L + (size_t)cb * GRID_TC;
-    {   // columns: lane = (row quarter, column); 8 rows each, then 4 -> 1 through LDS
+    constexpr uint32_t RPQ = GRID_TR / 4;                    // rows per lane in the column phase (four lanes share a column)
+    constexpr uint32_t SEGS = 256 / GRID_TR, CPS = GRID_TC / SEGS;   // row phase: SEGS lanes share a row, CPS columns each
+    {   // columns: lane = (row quarter, column); RPQ rows each, then 4 -> 1 through LDS
         const uint32_t col = t & 63u, rq = t >> 6;
-        B acc = ld_struct(tile + (size_t)(rq * 8) * L + col);
-        for (uint32_t i = 1; i < 8; i++) acc = bk_add(acc, ld_struct(tile + (size_t)(rq * 8 + i) * L + col));
+        B acc = ld_struct(tile + (size_t)(rq * RPQ) * L + col);
+        for (uint32_t i = 1; i < RPQ; i++) acc = bk_add(acc, ld_struct(tile + (size_t)(rq * RPQ + i) * L + col));
         sh[t] = acc;
         __syncthreads();
         for (int off = 128; off >= 64; off >>= 1) {
@@ -638,14 +640,14 @@ __global__ void __launch_bounds__(256) k_msm_grid_partial(const B* __restrict__ 
         if (t < 64) st_struct(colpart + (size_t)rb * L + (size_t)cb * GRID_TC + t, acc);
         __syncthreads();
     }
-    {   // rows: lane = (row, segment of 8 columns); 8 -> 1 through LDS
-        const uint32_t row = t >> 3, seg = t & 7u;
-        const B* src = tile + (size_t)row * L + seg * 8;
+    {   // rows: lane = (row, segment of CPS columns); SEGS -> 1 through LDS
+        const uint32_t row = t / SEGS, seg = t % SEGS;
+        const B* src = tile + (size_t)row * L + seg * CPS;
         B acc = ld_struct(src);
-        for (uint32_t i = 1; i < 8; i++) acc = bk_add(acc, ld_struct(src + i));
+        for (uint32_t i = 1; i < CPS; i++) acc = bk_add(acc, ld_struct(src + i));
         sh[t] = acc;
         __syncthreads();
-        for (uint32_t off = 4; off >= 1; off >>= 1) {
+        for (uint32_t off = SEGS / 2; off >= 1; off >>= 1) {
             if (seg < off) acc = bk_add(sh[t], sh[t + off]);
             __syncthreads();
             if (seg < off) sh[t] = acc;
