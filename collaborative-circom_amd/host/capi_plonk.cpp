@@ -168,4 +168,46 @@ int32_t cgh_plonk_prove_rep3(int32_t device, int32_t curve, const char* zkey_pat
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
 
+
+// ONE REP3 party of co-plonk with the caller's network and correlated randomness (co-circom.rs:560-600 builds a Rep3Protocol and hands it to
+// CoPlonk::prove; the tables are those of cgh_session_prove_rep3_party).  blind_a / blind_b = this party's shares of b_1..b_11, or both NULL to
+// draw them with rand() in the reference's order (round1.rs:93-99) before anything else.  Outputs: 9 packed G1, 6 evaluations, 5 challenges.
+int32_t cgh_plonk_prove_rep3_party(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* wit_a, const uint64_t* wit_b,
+                                   const uint64_t* blind_a, const uint64_t* blind_b, const cgh_rep3_net* net_cb, const cgh_rep3_rand* rnd_cb, int32_t upto,
+                                   uint64_t* out_commits, uint64_t* out_evals, uint64_t* out_challenges) {
+    cg_ctx* ctx = nullptr; cg_bases* tau = nullptr;
+    try {
+        using namespace cgh;
+        if (!zkey_path || !pub_in || !wit_a || !wit_b || !net_cb || !rnd_cb || !out_commits) throw std::runtime_error("cgh_plonk_prove_rep3_party: null argument");
+        if ((blind_a == nullptr) != (blind_b == nullptr)) throw std::runtime_error("cgh_plonk_prove_rep3_party: blind_a and blind_b go together");
+        if (upto < 1 || upto > 5) throw std::runtime_error("cgh_plonk_prove_rep3_party: upto must be 1..5");
+        PlonkZKey z = read_plonk_zkey(curve, zkey_path);
+        const Curve c = z.curve;
+        const size_t n_priv = z.n_vars - z.n_additions - z.n_public - 1, psz = c.aff(CG_G1);
+        std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
+        memset(out_commits, 0, 9 * psz); if (out_evals) memset(out_evals, 0, 6 * 32); if (out_challenges) memset(out_challenges, 0, 5 * 32);
+        if (cg_ctx_create(device, &ctx)) die("cg_ctx_create");
+        CG(cg_bases_register(ctx, c.id, CG_G1, z.p_tau.data(), z.domain_size + 6, psz, -1, &tau));
+        if (validate_by_default()) validate_bases(ctx, tau, "p_tau");
+        CallbackNetwork net(*net_cb);
+        CallbackRand rnd(*rnd_cb);
+        {
+            HipDriver driver(ctx, c, Mode::Rep3, &net);
+            driver.rsrc = &rnd;
+            FieldShare b[11];
+            for (int t = 0; t < 11; t++) {
+                if (blind_a) { memcpy(b[t].c[0].v, blind_a + 4 * t, 32); memcpy(b[t].c[1].v, blind_b + 4 * t, 32); }
+                else b[t] = driver.rand();
+            }
+            ShareVec wit = driver.upload_vec((const Fr*)wit_a, (const Fr*)wit_b, n_priv);
+            try { plonk_run(driver, z, tau, pub, wit, b, upto, PlonkOut{out_commits, out_challenges, out_evals, nullptr, nullptr}); }
+            catch (...) { driver.free_vec(wit); throw; }
+            driver.free_vec(wit);
+        }
+        cg_bases_release(tau);
+        cg_ctx_destroy(ctx);
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); if (tau) cg_bases_release(tau); if (ctx) cg_ctx_destroy(ctx); return 1; }
+}
+
 }  // extern "C"

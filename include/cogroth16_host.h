@@ -172,6 +172,12 @@ int32_t cgh_plonk_prove_plain(int32_t device, int32_t curve, const char* zkey_pa
 int32_t cgh_plonk_prove_rep3(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* const* wit_a, const uint64_t* const* wit_b,
                              const uint64_t* const* blind_a, const uint64_t* const* blind_b, const uint64_t* const* streams, size_t stream_len, int32_t upto,
                              uint64_t* out_commits, uint64_t* out_evals, uint64_t* out_challenges);
+/* ONE REP3 party of co-plonk over the caller's network and randomness tables (co-circom.rs:560-600: the CLI's plonk branch hands its
+ * Rep3Protocol to CoPlonk::prove).  blind_a / blind_b: this party's shares of b_1..b_11, or both NULL to draw them with rand() first
+ * (round1.rs:93-99).  out_commits = 9 packed G1, out_evals = 6, out_challenges = 5 (both optional). */
+int32_t cgh_plonk_prove_rep3_party(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* wit_a, const uint64_t* wit_b,
+                                   const uint64_t* blind_a, const uint64_t* blind_b, const cgh_rep3_net* net, const cgh_rep3_rand* rand, int32_t upto,
+                                   uint64_t* out_commits, uint64_t* out_evals, uint64_t* out_challenges);
 /* ShamirHipProtocol x n (threshold t) through rounds 1..upto; outputs as for cgh_plonk_prove_rep3, n parties. */
 int32_t cgh_plonk_prove_shamir(int32_t device, int32_t curve, const char* zkey_path, int32_t n, int32_t t, const uint64_t* pub_in, const uint64_t* const* wit,
                                const uint64_t* const* blind, const uint64_t* const* streams, size_t stream_len, int32_t upto,

@@ -29,5 +29,5 @@ pub mod shamir;
 pub use gpu::{curve_id, group_id, Gpu, Layout};
 pub use plain::PlainHipDriver;
 pub use rep3::Rep3HipProtocol;
-pub use session::Groth16Session;
+pub use session::{plonk_prove_rep3, Groth16Session};
 pub use shamir::ShamirHipProtocol;

@@ -13,10 +13,11 @@
 //! chunks of at most 4 MiB, points as packed affine coordinates); a party running the stock CPU prover cannot be mixed into such a run.
 //!
 //! SOURCE ONLY (no Rust toolchain in the image this repository is built in).  The same entry point is exercised by
-//! tests/test_rep3_party_abi.py: three threads, each through the callback ABI over sockets, bit-identical to the oracle's proofs.
+//! tests/test_rep3_party_abi.py: three threads, each through the callback ABI over sockets, bit-identical to the oracle's proofs
+//! (`plonk_prove_rep3`, the co-plonk twin over the same tables: tests/test_plonk_rounds.py).
 use crate::gpu::curve_id;
 use ark_ec::{pairing::Pairing, short_weierstrass::{Affine, Projective, SWCurveConfig}, AffineRepr, CurveGroup};
-use ark_ff::PrimeField;
+use ark_ff::{PrimeField, Zero};
 use bytes::Bytes;
 use mpc_core::protocols::rep3::{id::PartyID, network::{Rep3MpcNet, Rep3Network}, Rep3Protocol};
 use std::{ffi::{c_void, CStr, CString}, io, mem::size_of, os::raw::c_char, path::Path, ptr, slice};
@@ -44,6 +45,9 @@ extern "C" {
     fn cgh_last_error() -> *const c_char;
     fn cgh_session_open_multi(devices: *const i32, n_devices: i32, curve: i32, zkey_path: *const c_char, precompute: i32, flags: u32, out: *mut *mut c_void) -> i32;
     fn cgh_session_close(session: *mut c_void) -> i32;
+    fn cgh_plonk_prove_rep3_party(device: i32, curve: i32, zkey_path: *const c_char, pub_in: *const u64, wit_a: *const u64, wit_b: *const u64,
+                                  blind_a: *const u64, blind_b: *const u64, net: *const cgh_rep3_net, rnd: *const cgh_rep3_rand, upto: i32,
+                                  out_commits: *mut u64, out_evals: *mut u64, out_challenges: *mut u64) -> i32;
     fn cgh_session_prove_rep3_party(session: *mut c_void, pub_in: *const u64, wit_a: *const u64, wit_b: *const u64, net: *const cgh_rep3_net,
                                     rnd: *const cgh_rep3_rand, out_proof: *mut u64, seconds: *mut f64) -> i32;
 }
@@ -129,6 +133,57 @@ impl Drop for Groth16Session {
     fn drop(&mut self) {
         unsafe { cgh_session_close(self.handle) };
     }
+}
+
+/// `CoPlonk::<Rep3Protocol<_, Rep3MpcNet>, P>::prove` (co-plonk/src/plonk.rs:133-271) for this party on GPU `device`, through the same callback
+/// tables as `Groth16Session::prove_rep3` (`cgh_plonk_prove_rep3_party`; the CLI's plonk branch is co-circom.rs:560-600).  The eleven blinding
+/// shares are drawn with `protocol.rand()` inside the library, first, as `Round1Challenges::random` does (round1.rs:93-99).
+/// Returns the nine commitments (a, b, c, z, t1, t2, t3, wxi, wxiw) and six evaluations (a, b, c, s1, s2, zw) of `PlonkProof`
+/// (circom-types/src/plonk/proof.rs).
+pub fn plonk_prove_rep3<P: Pairing>(
+    device: i32,
+    zkey: &Path,
+    protocol: &mut Rep3Protocol<P::ScalarField, Rep3MpcNet>,
+    public_inputs: &[P::ScalarField],
+    wit_a: &[P::ScalarField],
+    wit_b: &[P::ScalarField],
+) -> io::Result<(Vec<P::G1Affine>, Vec<P::ScalarField>)>
+where
+    P::G1: PackedAffine,
+{
+    assert_eq!(wit_a.len(), wit_b.len());
+    let span = tracing::trace_span!("cogroth16_hip::plonk_prove_rep3", n = wit_a.len());
+    let _enter = span.enter();
+    let path = CString::new(zkey.to_string_lossy().as_bytes()).map_err(|e| io::Error::new(io::ErrorKind::InvalidInput, e))?;
+    let mut state = Callbacks::<P> { protocol, error: None };
+    let id: usize = state.protocol.network_mut().get_id().into();
+    let net = cgh_rep3_net {
+        user: &mut state as *mut _ as *mut c_void,
+        party_id: id as i32,
+        send_next: Some(send_next::<P>),
+        recv_prev: Some(recv_prev::<P>),
+        send_prev: Some(send_prev::<P>),
+        recv_next: Some(recv_next::<P>),
+        recv_prev_pinned: None,
+    };
+    let rnd = cgh_rep3_rand {
+        user: &mut state as *mut _ as *mut c_void,
+        masking_field_elements: Some(masking_field_elements::<P>),
+        random_fes: Some(random_fes::<P>),
+        masking_ec_element: Some(masking_ec_element::<P>),
+    };
+    let fq = size_of::<<P::G1 as CurveGroup>::BaseField>() / 8;
+    let mut commits = vec![0u64; 9 * 2 * fq];
+    let mut evals = vec![P::ScalarField::zero(); 6];
+    let rc = unsafe {
+        cgh_plonk_prove_rep3_party(device, curve_id::<P::ScalarField>(), path.as_ptr(), public_inputs.as_ptr() as *const u64, wit_a.as_ptr() as *const u64,
+                                   wit_b.as_ptr() as *const u64, ptr::null(), ptr::null(), &net, &rnd, 5, commits.as_mut_ptr(), evals.as_mut_ptr() as *mut u64,
+                                   ptr::null_mut())
+    };
+    if rc != 0 {
+        return Err(state.error.take().unwrap_or_else(|| io::Error::new(io::ErrorKind::Other, host_error())));
+    }
+    Ok((commits.chunks(2 * fq).map(<P::G1 as PackedAffine>::from_packed).collect(), evals))
 }
 
 /// packed affine `x || y` in Montgomery limbs, all zero = the point at infinity (the zkey's own encoding, circom-types/src/traits.rs:107-155)

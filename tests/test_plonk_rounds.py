@@ -325,3 +325,83 @@ def test_gpu_shamir_all_rounds_match_plain_oracle(curve_name, n, t):
     for party in range(n):
         for key in want:
             np.testing.assert_array_equal(got[party][key], want[key], err_msg=f"party {party} {key}")
+
+
+# ---- ONE REP3 party of co-plonk behind the callback ABI (cgh_plonk_prove_rep3_party; co-circom.rs:560-600) -------------------------------
+def test_plonk_party_entry_rejects_bad_arguments_without_a_gpu():
+    """null tables / pointers, blinding shares given by halves, a round outside 1..5: status 1 and a message before any device is touched"""
+    import ctypes as C
+    ensure_built()
+    h = cg.load_host()
+    net = cg.Rep3NetTable(); rnd = cg.Rep3RandTable()
+    out = np.zeros((9, 8), dtype=np.uint64); buf = np.zeros((16, 4), dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    zp = fx("bn254", "circuit.zkey").encode()
+    assert h.cgh_plonk_prove_rep3_party(0, BN254, zp, p(buf), p(buf), p(buf), None, None, None, C.byref(rnd), 5, p(out), None, None) != 0
+    assert b"null argument" in h.cgh_last_error()
+    assert h.cgh_plonk_prove_rep3_party(0, BN254, zp, p(buf), p(buf), p(buf), p(buf), None, C.byref(net), C.byref(rnd), 5, p(out), None, None) != 0
+    assert b"go together" in h.cgh_last_error()
+    assert h.cgh_plonk_prove_rep3_party(0, BN254, zp, p(buf), p(buf), p(buf), None, None, C.byref(net), C.byref(rnd), 6, p(out), None, None) != 0
+    assert b"upto" in h.cgh_last_error()
+
+
+def _three_plonk_parties(curve, zp, pub, wa, wb, streams, blind=None, upto=5):
+    """three threads, each ONE party through the callback ABI: loopback transport, randomness = the streams (party i: S_i, S_{i-1})"""
+    import threading
+    hub = cg.LoopbackHub()
+    rnds = [cg.StreamRand(curve, streams[i], streams[(i + 2) % 3]) for i in range(3)]
+    got, errs = [None] * 3, [None] * 3
+
+    def run(i):
+        try:
+            ba, bb = (None, None) if blind is None else (blind[0][i], blind[1][i])
+            got[i] = cg.plonk_prove_rep3_party(curve, zp, pub, wa[i], wb[i], hub.net(i), rnds[i].table, ba, bb, upto=upto)
+        except Exception as e:                                                          # noqa: BLE001 (reported below, peers released)
+            errs[i] = e; hub.abort()
+    th = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for r in rnds: r.close()
+    hub.close()
+    assert errs == [None] * 3, errs
+    return got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_gpu_plonk_party_entry_matches_plain_oracle(curve_name):
+    """every party, alone behind the callback tables, reports the plain oracle's proof for the opened blinding — with the blinding
+    shares handed in, and with the blinding drawn by rand() (round1.rs:93-99: eleven draws before anything else, so that
+    b_t = S_0[t] + S_1[t] + S_2[t]); on BN254 the reference's deterministic blinding gives its hard-coded values again"""
+    ensure_built()
+    curve = CURVES[curve_name]
+    zp = fx(curve_name, "circuit.zkey")
+    npub = orc.plonk_zkey_info(curve, zp)["n_public"]
+    w = orc.read_wtns(curve, fx(curve_name, "witness.wtns"))
+    rng = np.random.default_rng(4242)
+    blind = orc.random_field(curve, FR, 11, rng)
+    wa, wb = rep3_share(curve, w[npub + 1:], rng)
+    ba, bb = rep3_share(curve, blind, rng)
+    streams = [orc.random_field(curve, FR, 40000, rng) for _ in range(3)]
+    want = orc.plonk_prove_plain(curve, zp, w, blind, upto=5)
+    got = _three_plonk_parties(curve, zp, w[:npub + 1], wa, wb, streams, (ba, bb))
+    for party in range(3):
+        for key in want:
+            np.testing.assert_array_equal(got[party][key], want[key], err_msg=f"party {party} {key}")
+    # the same values as the three-party in-process entry on the same streams
+    ref3 = cg.plonk_prove_rep3(curve, zp, w[:npub + 1], wa, wb, ba, bb, streams, upto=5)
+    for key in want:
+        np.testing.assert_array_equal(got[0][key], ref3[0][key], err_msg=key)
+    # blinding drawn through the randomness table
+    drawn = orc.field_op(curve, FR, "add", orc.field_op(curve, FR, "add", streams[0][:11], streams[1][:11]), streams[2][:11])
+    want = orc.plonk_prove_plain(curve, zp, w, drawn, upto=5)
+    got = _three_plonk_parties(curve, zp, w[:npub + 1], wa, wb, streams, None)
+    for party in range(3):
+        for key in want:
+            np.testing.assert_array_equal(got[party][key], want[key], err_msg=f"drawn blinding, party {party} {key}")
+    assert orc.plonk_verify(curve, zp, got[0], w[1:npub + 1])
+    if curve == BN254:
+        det = deterministic_blinding(curve, 11); zero = np.zeros_like(det)
+        got = _three_plonk_parties(curve, zp, w[:npub + 1], wa, wb, streams, ([det, zero, zero], [zero, det, zero]))
+        for party in range(3):
+            check_against_reference_kats(got[party])
