@@ -531,14 +531,15 @@ def host_set_zkey_validation(on):
 class ProvingSession:
     """zkey read, uploaded and (optionally) given per-window precomputed tables once; proofs then cost what co-circom.rs:503-506 times"""
 
-    def __init__(self, curve, zkey_path, precompute=True, device=0, validate=True, devices=None):
+    def __init__(self, curve, zkey_path, precompute=True, device=0, validate=True, devices=None, additive_h=False):
         """devices: several GPUs of one node for this party (cgh_session_open_multi): devices[0] runs the witness map and slice 0 of
-        every MSM, devices[i] slice i"""
+        every MSM, devices[i] slice i.  additive_h: REP3 proofs run the additive-quotient variant (CGH_SESSION_ADDITIVE_H, opt-in: not the
+        reference's message sequence, same proof)"""
         self.curve, self.info = curve, host_zkey_info(curve, zkey_path)
         h = C.c_void_p()
         devs = [int(device)] if devices is None else [int(d) for d in devices]
         arr = (C.c_int32 * len(devs))(*devs)
-        _hchk(load_host().cgh_session_open_multi(arr, len(devs), curve, zkey_path.encode(), -1 if precompute is True else int(precompute), C.c_uint32(0 if validate else 1), C.byref(h)))
+        _hchk(load_host().cgh_session_open_multi(arr, len(devs), curve, zkey_path.encode(), -1 if precompute is True else int(precompute), C.c_uint32((0 if validate else 1) | (2 if additive_h else 0)), C.byref(h)))
         self.h = h
 
     def close(self):

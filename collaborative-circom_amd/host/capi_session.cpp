@@ -16,6 +16,7 @@ struct cgh_session {
     // party's second context fills the chip with the witness-independent MSMs
     std::mutex mu; std::vector<std::vector<cg_ctx*>> idle, idle_chain;
     bool bulk_second = false;                                                            // the non-chain contexts run next to a chain context
+    bool additive_h = false;                                                             // open flag bit 1: REP3 additive-quotient variant
     cg_ctx* take(int slot = 0, bool chain = false) {
         auto& pool = chain ? idle_chain : idle;
         { std::lock_guard<std::mutex> l(mu); if (!pool[slot].empty()) { cg_ctx* c = pool[slot].back(); pool[slot].pop_back(); return c; } }
@@ -91,11 +92,13 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
         for (int d = 0; d < n_dev; d++) CG(cg_ctx_sync(s->ctx0[d]));
         s->second_context = s->z.n_vars >= ((size_t)1 << 19) && !getenv("CGH_ONE_CONTEXT");
         s->bulk_second = s->second_context && !getenv("CGH_NO_CHAIN_PRIORITY");
+        s->additive_h = (flags & 2u) != 0;
         *out = s;
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); session_destroy(s); return 1; }
 }
-// flags: bit 0 = skip the point validation (the file was validated before, cgh_zkey_validate)
+// flags: bit 0 = skip the point validation (the file was validated before, cgh_zkey_validate); bit 1 = REP3 proofs of this session run the
+// additive-quotient variant (CoGroth16::prove: no vector exchange, MSMs on the own component, one five-point re-sharing round)
 int32_t cgh_session_open_ex(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, uint32_t flags, void** out) {
     return cgh_session_open_multi(&device, 1, curve, zkey_path, precompute, flags, out);
 }
@@ -150,7 +153,7 @@ int32_t cgh_session_prove_rep3_party(void* h, const uint64_t* pub_in, const uint
         {
             HipDriver driver(ctx.c, z.curve, Mode::Rep3, &net);
             driver.aux = second.c; driver.owns_aux = false; driver.md = workers.get();
-            driver.rsrc = &rnd;
+            driver.rsrc = &rnd; driver.additive_h = s->additive_h;
             VecGuard wit(driver, driver.upload_vec((const Fr*)wit_a, (const Fr*)wit_b, n_aux));
             CoGroth16 prover(driver);
             Proof p = prover.prove(pz.dz, pub, wit.v, nullptr, nullptr);                 // groth16.rs:113-139
@@ -181,7 +184,7 @@ int32_t cgh_session_prove_shamir_party(void* h, int32_t threshold, const uint64_
         {
             HipDriver driver(ctx.c, z.curve, Mode::Shamir, nullptr);
             driver.aux = second.c; driver.owns_aux = false; driver.md = workers.get();
-            driver.sh_rand = rnd_cb;
+            driver.sh_rand = rnd_cb; driver.additive_h = s->additive_h;
             driver.shamir_init(&net, threshold);                                        // ShamirProtocol::new, shamir.rs:211-246
             driver.preprocess(preprocess);
             VecGuard wit(driver, driver.upload_vec((const Fr*)wit_in, nullptr, n_aux));

@@ -39,7 +39,10 @@ public:
     Rep3RandSource* rsrc = nullptr;
     std::vector<void*> mask_bufs;                                                          // page-locked scratch lent to rsrc, released at shutdown
     Fr* mask_scratch(size_t n) { void* p; CG(cg_host_alloc(n * 32, &p)); mask_bufs.push_back(p); return (Fr*)p; }
-    int k() const { return mode == Mode::Rep3 ? 2 : 1; }
+    int k() const { return k_override ? k_override : (mode == Mode::Rep3 ? 2 : 1); }
+    // REP3 "additive quotient" variant (opt-in, NOT the reference's message sequence; see CoGroth16::prove): vector work on the own component only
+    int k_override = 0; bool additive_h = false;
+    struct Components { HipDriver& d; int old; Components(HipDriver& drv, int kk) : d(drv), old(drv.k_override) { d.k_override = kk; } ~Components() { d.k_override = old; } };
     int party() const { return mode == Mode::Rep3 ? net->id() : -1; }
 
     HipDriver(cg_ctx* c, Curve cv, Mode m, Rep3Network* n) : ctx(c), curve(cv), mode(m), net(n) {}
@@ -448,12 +451,12 @@ public:
             pm.down.push_back(d); pm.issued++;
         }
     }
-    PendingMul mul_vec_begin(const ShareVec& a, const ShareVec& b) {
+    PendingMul mul_vec_begin(const ShareVec& a, const ShareVec& b, bool exchange = true) {   // exchange = false: the masked local product only (additive share)
         PendingMul pm; ShareVec& out = pm.out; out.n = a.n;
         out.c[0] = dalloc(a.n * 32);
         if (mode != Mode::Rep3) CG(cg_vec_mul_dev(ctx, curve.id, out.c[0], a.c[0], b.c[0], a.n));
         if (mode == Mode::Plain) return pm;
-        if (mode == Mode::Shamir) { out = degree_reduce_vec(out); return pm; }         // shamir.rs:609-623
+        if (mode == Mode::Shamir) { if (exchange) out = degree_reduce_vec(out); return pm; }   // shamir.rs:609-623 (exchange = false: the degree-2t products)
         void* m1 = nullptr; void* m2 = nullptr;
         if (rsrc) {
             if (!prefetched.empty() && prefetched.front().n == a.n) {
@@ -485,6 +488,7 @@ public:
         }
         CG(cg_vec_rep3_mul_local_dev(ctx, curve.id, out.c[0], a.c[0], a.c[1], b.c[0], b.c[1], m1, a.n));
         defer_free(m1); defer_free(m2);
+        if (!exchange) return pm;
         out.c[1] = dalloc(a.n * 32);
         pm.exchange = true;
         if (a.n >= XCHG_ASYNC_MIN) issue_downloads(pm, XCHG_SLOTS - 1);                // ordered right behind the product, ahead of whatever the caller enqueues next
@@ -632,7 +636,7 @@ public:
     // map and its exchanges occupy the first.  MSMs involve no network, so the party-to-party message order is the reference's.
     cg_ctx* aux = nullptr; bool owns_aux = true;       // a session lends its contexts (owns_aux = false)
     struct PendingMsm {
-        cg_ctx* on = nullptr; std::vector<int32_t> tickets; std::vector<int> groups;
+        cg_ctx* on = nullptr; std::vector<int32_t> tickets; std::vector<int> groups; int k = 0;     // k: share components multiplied (0 = the driver's)
         struct Part { cg_ctx* on; std::vector<int32_t> tickets; void* sc[2]; };     // the same MSMs over the slices held by further GPUs
         std::vector<Part> parts;
     };
@@ -687,7 +691,7 @@ public:
         for (size_t j = 0; j < ord.size(); j++) tickets[ord[j]] = tk[j];
     }
     PendingMsm msm_begin_multi(const std::vector<const cg_bases*>& tables, const std::vector<size_t>& offsets, const std::vector<int>& groups, size_t n, const ShareVec& s, bool on_aux) {
-        PendingMsm p; p.on = on_aux && aux ? aux : ctx; p.groups = groups; p.tickets.resize(tables.size());
+        PendingMsm p; p.on = on_aux && aux ? aux : ctx; p.groups = groups; p.tickets.resize(tables.size()); p.k = k();
         // REP3 at sizes where the exchanges are asynchronous: these MSMs run beside the witness map's dependency chain (product -> down ->
         // peer -> up, twice) on the other context; shorter-lived workgroups let the chain's kernels onto the chip sooner (2^22: one party
         // alone 107 -> 97 ms)
@@ -704,17 +708,28 @@ public:
         return p;
     }
     PointShare msm_finish(PendingMsm& p, size_t i) {
-        const int group = p.groups[i];
-        Bytes out(curve.jac(group) * k());
+        const int group = p.groups[i], kk = p.k ? p.k : k();
+        Bytes out(curve.jac(group) * kk);
         CG(cg_msm_end(p.on, p.tickets[i], out.data()));
         PointShare r;
-        for (int j = 0; j < k(); j++) r.c[j] = Point{Bytes(out.begin() + j * curve.jac(group), out.begin() + (j + 1) * curve.jac(group)), group};
+        for (int j = 0; j < kk; j++) r.c[j] = Point{Bytes(out.begin() + j * curve.jac(group), out.begin() + (j + 1) * curve.jac(group)), group};
         for (auto& part : p.parts) {                                                    // slices on further GPUs: fold the partial sums
             CG(cg_msm_end(part.on, part.tickets[i], out.data()));
-            for (int j = 0; j < k(); j++) r.c[j] = pt_add(curve, r.c[j], Point{Bytes(out.begin() + j * curve.jac(group), out.begin() + (j + 1) * curve.jac(group)), group});
+            for (int j = 0; j < kk; j++) r.c[j] = pt_add(curve, r.c[j], Point{Bytes(out.begin() + j * curve.jac(group), out.begin() + (j + 1) * curve.jac(group)), group});
         }
-        if (k() == 1) r.c[1] = pt_inf(curve, group);
+        if (kk == 1) r.c[1] = pt_inf(curve, group);
         return r;
+    }
+    // additive -> replicated for a handful of points in ONE round: every party sends its own component to the next party and takes the
+    // previous party's as its second component (the pair (x_i, x_{i-1}) of rep3/pointshare.rs:14-17).  Used by the additive-quotient variant.
+    void reshare_points(const std::vector<PointShare*>& pts) {
+        if (mode != Mode::Rep3) return;
+        Bytes msg;
+        for (PointShare* ps : pts) { Bytes aff = pt_to_affine(curve, ps->c[0]); msg.insert(msg.end(), aff.begin(), aff.end()); }
+        net->send_next(msg.data(), msg.size());
+        Bytes got(msg.size()); net->recv_prev(got.data(), got.size());
+        size_t at = 0;
+        for (PointShare* ps : pts) { const int g = ps->c[0].group; ps->c[1] = pt_from_affine(curve, g, got.data() + at); at += curve.aff(g); }
     }
     // rand (rep3.rs:595-598; plain: supplied by the caller)
     FieldShare rand() {

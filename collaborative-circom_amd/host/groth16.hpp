@@ -19,6 +19,7 @@ class CoGroth16 {
 public:
     HipDriver& driver;
     explicit CoGroth16(HipDriver& d) : driver(d) {}
+    bool additive() const { return driver.additive_h && driver.mode != Mode::Plain; }
 
     // groth16.rs:141-204
     ShareVec witness_map_from_matrices(const DeviceZKey& dz, const std::vector<Fr>& public_inputs, const ShareVec& private_witness) {
@@ -33,6 +34,24 @@ public:
         // the independent NTTs are enqueued, then the party-to-party exchange proceeds while the GPU works (values as in the reference).
         if (driver.prefetched.empty()) driver.prefetch_masks(2, dom.m);                                // :174 and :190 draw next to each other
         mk.mark("spmv enqueue");
+        if (additive()) {
+            // Shamir: the same with degree-2t sharings — products of degree-t shares, linear transforms, a difference — reduced to degree t
+            // as ONE point after the MSM (degree_reduce_point, shamir.rs:386-436) instead of 2 x m field elements before it.
+            // Additive-quotient variant: neither product is re-shared.  The masked local products (rep3.rs:655-660, same masks in the same
+            // order) are additive shares of a*b; the transforms are linear; so h_i = ab_i - c_i sums to the reference's h, and the only reader
+            // of h is the MSM against h_query.  The 2 x 32 B x m exchange of :174 and :190 and the second component of c and h disappear.
+            auto c_local = driver.mul_vec_begin(a, b, false);
+            driver.ifft_coset_fft_in_place(a, dom.omega, dom.coset_g);
+            driver.ifft_coset_fft_in_place(b, dom.omega, dom.coset_g);
+            ShareVec c = c_local.out;
+            { HipDriver::Components own(driver, 1); driver.ifft_coset_fft_in_place(c, dom.omega, dom.coset_g); }
+            ShareVec ab = driver.mul_vec_begin(a, b, false).out;
+            { HipDriver::Components own(driver, 1); driver.sub_assign_vec(ab, c); }
+            mk.mark("products + ntt enqueue (additive)");
+            driver.free_vec(a); driver.free_vec(b); driver.free_vec(c); driver.free_deferred();
+            mk.mark("free (sync)");
+            return ab;
+        }
         auto c_pending = driver.mul_vec_begin(a, b);                                                   // :174
         mk.mark("mul_vec_begin");
         driver.ifft_coset_fft_in_place(a, dom.omega, dom.coset_g);                                     // :175,177-181,187
@@ -78,11 +97,19 @@ public:
         // share component: b2 (G2 first, HipDriver::begin_multi_ordered), a, b1, l — the order in which the results are consumed below, so
         // that the host's work on a result (public-input terms, openings, scalar multiplications) runs under the accumulation of the next
         enum { AUX_A = 0, AUX_B1 = 1, AUX_B2 = 2, AUX_L = 3 };
+        // Additive-quotient variant (HipDriver::additive_h, REP3, opt-in): every MSM multiplies the party's OWN component only — the second
+        // component of an MSM result is by definition the previous party's first (rep3.rs:934-947 on the pair (x_i, x_{i-1})) — and the five
+        // results become replicated shares again in ONE round of five points (reshare_points).  From there on every value and every message
+        // is the reference's, and so is the proof.  What changes on the wire: the two vector exchanges of the witness map are gone, one
+        // 384-byte (BN254) message is added; all three parties must run the variant.
+        const bool add_h = additive();
+        std::unique_ptr<HipDriver::Components> own(add_h ? new HipDriver::Components(driver, 1) : nullptr);   // (Shamir has one component anyway)
         auto aux_msm = dz.sliced ? driver.msm_begin_sharded(dz, true, private_witness)
                                  : driver.msm_begin_multi({dz.a, dz.b1, dz.b2, dz.l}, {first_aux, first_aux, first_aux, 0}, {CG_G1, CG_G1, CG_G2, CG_G1}, private_witness.n, private_witness, true);
+        own.reset();
         mk.mark("aux msm enqueued");
         // Several GPUs: the witness map itself is spread over them (multidev.hpp) and every device multiplies its own rows of h
-        const bool distributed = DistributedWitnessMap::usable(driver, dz);
+        const bool distributed = !add_h && DistributedWitnessMap::usable(driver, dz);              // (the variant keeps the map on the primary device)
         std::unique_ptr<DistributedWitnessMap> dmap;
         struct HParts : DistributedH {     // the rows of h on their devices: released when prove leaves, however it leaves (after the map's own buffers)
             ~HParts() { for (auto& part : parts) for (int j = 0; j < 2; j++) if (part.h.c[j]) cg_dev_free(part.ctx, part.h.c[j]); }
@@ -114,7 +141,9 @@ public:
         mk.mark("mask uploads enqueued");
         h = witness_map_from_matrices(dz, public_inputs, private_witness);
         mk.mark("witness map");
+        if (add_h) own.reset(new HipDriver::Components(driver, 1));
         h_msm = dz.sliced ? driver.msm_begin_sharded(dz, false, h) : driver.msm_begin_multi({dz.h}, {0}, {CG_G1}, h.n, h, false);   // :248
+        own.reset();
         }
         FieldShare r = rs_plain ? rs_plain[0] : driver.rand();                                         // :134-135
         FieldShare s = rs_plain ? rs_plain[1] : driver.rand();
@@ -131,15 +160,25 @@ public:
         PointShare s_g1 = driver.scalar_mul_public_point(delta_g1, s);                                 // :283
         PointShare s_g2 = driver.scalar_mul_public_point(delta_g2, s);                                 // :297
         mk.mark("scalar steps under the msms");
-        PointShare g_a = calculate_coeff(r_g1, z.a_query, CG_G1, z.alpha_g1, input_assignment, driver.msm_finish(aux_msm, AUX_A));   // :267
+        PointShare early[5]; bool have_early = false;
+        if (add_h) {                                                                                   // all five results, then the one re-sharing round
+            for (int i : {AUX_A, AUX_B1, AUX_B2, AUX_L}) early[i] = driver.msm_finish(aux_msm, i);
+            early[4] = driver.msm_finish(h_msm, 0);
+            if (driver.mode == Mode::Rep3) driver.reshare_points({&early[0], &early[1], &early[2], &early[3], &early[4]});
+            else early[4].c[0] = driver.degree_reduce_point(early[4].c[0]);                            // Shamir: h was a degree-2t sharing
+            have_early = true;
+            mk.mark("msms + reshare (additive)");
+        }
+        auto aux_result = [&](int i) { return have_early ? early[i] : driver.msm_finish(aux_msm, i); };
+        PointShare g_a = calculate_coeff(r_g1, z.a_query, CG_G1, z.alpha_g1, input_assignment, aux_result(AUX_A));   // :267
         Point g_a_opened = driver.open_point(g_a);                                                     // :276
         PointShare s_g_a = driver.scalar_mul_public_point(g_a_opened, s);                              // :277
-        PointShare g1_b = calculate_coeff(s_g1, z.b_g1_query, CG_G1, z.beta_g1, input_assignment, driver.msm_finish(aux_msm, AUX_B1));   // :284
+        PointShare g1_b = calculate_coeff(s_g1, z.b_g1_query, CG_G1, z.beta_g1, input_assignment, aux_result(AUX_B1));   // :284
         PointShare r_g1_b = driver.scalar_mul(g1_b, r);                                                // :291
-        PointShare g2_b = calculate_coeff(s_g2, z.b_g2_query, CG_G2, z.beta_g2, input_assignment, driver.msm_finish(aux_msm, AUX_B2));   // :298
+        PointShare g2_b = calculate_coeff(s_g2, z.b_g2_query, CG_G2, z.beta_g2, input_assignment, aux_result(AUX_B2));   // :298
         mk.mark("msm a, b1, b2 + their scalar steps");
-        PointShare l_aux_acc = driver.msm_finish(aux_msm, AUX_L);                                          // :251
-        PointShare h_acc = driver.msm_finish(h_msm, 0);                                                // :248
+        PointShare l_aux_acc = aux_result(AUX_L);                                          // :251
+        PointShare h_acc = have_early ? early[4] : driver.msm_finish(h_msm, 0);                                               // :248
         mk.mark("msm l + h");
         PointShare g_c = s_g_a;                                                                        // :308-312
         driver.add_assign_points(g_c, r_g1_b);

@@ -71,7 +71,14 @@ int32_t cgh_prove_shamir(int32_t device, int32_t curve, const char* zkey_path, i
  * co-circom.rs:503-506 times.  A zkey is fixed for the life of a prover process (zkey.rs:48-71). ------------------------------------- */
 /* precompute: 0 = none, -1 = window chosen per table size, > 0 = that window */
 int32_t cgh_session_open(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, void** out_session);
-/* flags: bit 0 = skip the point validation */
+/* flags: bit 0 = skip the point validation.
+ * bit 1 (CGH_SESSION_ADDITIVE_H) = REP3 proofs of the session run the ADDITIVE-QUOTIENT variant — an opt-in protocol variant, not the
+ * reference's message sequence: the two mul_vec calls of the witness map (groth16.rs:174,190) keep their masked local products and are not
+ * re-shared (no 2 x 32 B x m exchange), every MSM multiplies the party's own share component, and the five MSM results become replicated
+ * shares again in one round of five points; from there on every value and message is the reference's and the proof is bit-identical.
+ * Randomness is drawn exactly as in the reference.  All three parties must open their sessions with the same flag. */
+#define CGH_SESSION_SKIP_VALIDATION 1u
+#define CGH_SESSION_ADDITIVE_H 2u
 int32_t cgh_session_open_ex(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, uint32_t flags, void** out_session);
 /* Several GPUs of one node for one party: devices[0] runs the witness map and slice 0 of every MSM
  * (mpc-core/src/protocols/rep3.rs:934-947 is linear in the (scalar, point) pairs), devices[i] slice i; scalar slices move device to

@@ -71,9 +71,17 @@ impl Groth16Session {
     /// `devices`: the party's GPUs (devices[0] runs the witness map; every device holds a slice of the five queries).
     /// `validate = false` skips the point checks for a file that was validated before.
     pub fn open<F: PrimeField>(devices: &[i32], zkey: &Path, validate: bool) -> eyre::Result<Self> {
+        Self::open_with::<F>(devices, zkey, validate, false)
+    }
+
+    /// `additive_h = true` (`CGH_SESSION_ADDITIVE_H`): the opt-in REP3 / Shamir variant in which the witness map's two products are not
+    /// re-shared (no 2 x 32 B x m exchange), every MSM multiplies the party's own share component and the five results are re-shared as
+    /// points in one round.  NOT the message sequence of `CoGroth16::prove`; the proof is the same.  All parties must agree on it.
+    pub fn open_with<F: PrimeField>(devices: &[i32], zkey: &Path, validate: bool, additive_h: bool) -> eyre::Result<Self> {
         let path = CString::new(zkey.to_string_lossy().as_bytes())?;
         let mut handle = ptr::null_mut();
-        let rc = unsafe { cgh_session_open_multi(devices.as_ptr(), devices.len() as i32, curve_id::<F>(), path.as_ptr(), -1, if validate { 0 } else { 1 }, &mut handle) };
+        let flags = (if validate { 0 } else { 1 }) | (if additive_h { 2 } else { 0 });
+        let rc = unsafe { cgh_session_open_multi(devices.as_ptr(), devices.len() as i32, curve_id::<F>(), path.as_ptr(), -1, flags, &mut handle) };
         if rc != 0 {
             eyre::bail!("cgh_session_open_multi: {}", host_error());
         }

@@ -38,6 +38,7 @@ class SocketEnd:
         self.out = {"next": to_next, "prev": to_prev}
         self.inq = {"prev": queue.Queue(), "next": queue.Queue()}
         self.sent = {"next": 0, "prev": 0}
+        self.sent_bytes = 0
         self.fail_send_next_at = None
         self.readers = [threading.Thread(target=self._reader, args=(from_prev, self.inq["prev"]), daemon=True),
                         threading.Thread(target=self._reader, args=(from_next, self.inq["next"]), daemon=True)]
@@ -70,7 +71,7 @@ class SocketEnd:
             if where == "next" and self.fail_send_next_at is not None and self.sent["next"] == self.fail_send_next_at:
                 return 32                                                          # EPIPE: the peer went away
             self.out[where].sendall(struct.pack("<Q", n) + C.string_at(data, n))
-            self.sent[where] += 1
+            self.sent[where] += 1; self.sent_bytes += n
             return 0
         except OSError as e:
             return e.errno or 5
@@ -405,3 +406,97 @@ def test_shamir_parties_over_sockets_give_the_oracle_proof(curve_name, n, t, pre
     finally:
         for e in ends: e.close()
         ses.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name,circuit", [("bn254", "poseidon"), ("bls12_381", "multiplier2")])
+def test_additive_quotient_variant_gives_the_same_proofs(curve_name, circuit):
+    """CGH_SESSION_ADDITIVE_H (opt-in, not the reference's message sequence): the witness map's products stay masked local products, MSMs run
+    on the own component, five points are re-shared in one round — the three proofs are the ORACLE's (reference protocol) bit for bit on
+    the same shares and randomness, and the parties exchange O(1) bytes instead of 2 x 32 B x domain_size"""
+    ensure_built()
+    curve = {"bn254": BN254, "bls12_381": BLS12_381}[curve_name]
+    zpath = fx(curve_name, circuit, "circuit.zkey")
+    z = orc.ZKey(curve, zpath); w = orc.read_wtns(curve, fx(curve_name, circuit, "witness.wtns"))
+    rng = np.random.default_rng(615)
+    pub = w[:z.n_public + 1]
+    wa, wb = rep3_share(curve, w[z.n_public + 1:], rng)
+    streams = [orc.random_field(curve, FR, 2 * z.domain_size + 4, rng) for _ in range(3)]
+    want = z.prove_rep3(pub, wa, wb, streams)
+    sent = {}
+    for additive in (False, True):
+        ses = cg.ProvingSession(curve, zpath, precompute=False, additive_h=additive)
+        ends = socket_ring()
+        rands = [cg.StreamRand(curve, streams[i], streams[(i + 2) % 3]) for i in range(3)]
+        try:
+            out, errs = run_three_parties(ses, pub, wa, wb, [e.table for e in ends], [r.table for r in rands])
+            assert errs == [None, None, None], errs
+            np.testing.assert_array_equal(np.stack(out), want)
+            sent[additive] = ends[0].sent_bytes
+        finally:
+            for e in ends: e.close()
+            for r in rands: r.close()
+            ses.close()
+    nq = 48 if curve == BLS12_381 else 32
+    assert sent[False] - sent[True] == 2 * 32 * z.domain_size - (4 * 2 * nq + 4 * nq)    # two vector messages fewer, one message of 4 G1 + 1 G2 more
+
+
+@pytest.mark.gpu
+def test_additive_quotient_variant_at_2_16(tmp_path):
+    """the variant on the chunked-exchange sizes (precomputed tables, second context, prefetched masks) and on a two-device session"""
+    ensure_built()
+    curve, log_m = BN254, 16
+    threads = min(32, os.cpu_count() or 8)
+    zp, wp = str(tmp_path / "s.zkey"), str(tmp_path / "s.wtns")
+    orc.make_synthetic(curve, log_m, 33, zp, wp, threads=threads)
+    z = orc.ZKey(curve, zp); w = orc.read_wtns(curve, wp)
+    rng = np.random.default_rng(29)
+    wa, wb = rep3_share(curve, w[2:], rng)
+    streams = [orc.random_field(curve, FR, 2 * z.domain_size + 4, rng) for _ in range(3)]
+    want = z.prove_rep3(w[:2], wa, wb, streams, threads=threads)
+    for devices in (None, [0, 0]):
+        ses = cg.ProvingSession(curve, zp, precompute=True, additive_h=True, devices=devices)
+        hub = cg.LoopbackHub()
+        rands = [cg.StreamRand(curve, streams[i], streams[(i + 2) % 3]) for i in range(3)]
+        try:
+            out, errs = run_three_parties(ses, w[:2], wa, wb, [hub.net(i) for i in range(3)], [r.table for r in rands])
+            assert errs == [None, None, None], errs
+            np.testing.assert_array_equal(np.stack(out), want)
+        finally:
+            for r in rands: r.close()
+            hub.close(); ses.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name,n,t", [("bn254", 3, 1), ("bn254", 5, 2), ("bls12_381", 3, 1)])
+def test_shamir_degree_2t_quotient_variant(curve_name, n, t):
+    """CGH_SESSION_ADDITIVE_H with Shamir parties: the witness map's products stay degree-2t sharings (no vector degree reduction, so a
+    handful of double sharings instead of 2 x domain_size), h is reduced as one point after its MSM.  The blinding r, s are then other
+    pairs of the same randomness than in the reference's order, so the proof is not the oracle's bit for bit: every party must hold
+    the SAME proof, and it must pass the snarkjs-pinned verifier for the circuit's public inputs"""
+    from test_shamir import setup
+    ensure_built()
+    curve, z, w, wits, streams = setup(curve_name, "poseidon", n, t, seed=43, preprocess=0)
+    pub = w[:z.n_public + 1]
+    vk = orc.vk_from_json(curve, fx(curve_name, "poseidon", "verification_key.json"))
+    sent = {}
+    for additive in (False, True):
+        ses = cg.ProvingSession(curve, fx(curve_name, "poseidon", "circuit.zkey"), precompute=False, additive_h=additive)
+        ends = shamir_mesh(n, streams)
+        out, errs = [None] * n, [None] * n
+
+        def party(i):
+            try: out[i], _ = cg.host_prove_shamir_party(ses, t, pub, wits[i], ends[i].net, ends[i].rand, preprocess=0)
+            except Exception as e: errs[i] = e
+        try:
+            th = [threading.Thread(target=party, args=(i,)) for i in range(n)]
+            for x in th: x.start()
+            for x in th: x.join(300)
+            assert errs == [None] * n, errs
+            for i in range(1, n): np.testing.assert_array_equal(out[i], out[0])
+            assert orc.verify(curve, vk, w[1:1 + z.n_public], out[0])
+            sent[additive] = sum(e.sent for e in ends)
+        finally:
+            for e in ends: e.close()
+            ses.close()
+    assert sent[True] < sent[False]
