@@ -13,3 +13,8 @@ for log_m in [int(x) for x in sys.argv[1:]] or [20, 22]:
     print(f"2^{log_m}: plain {s['plain_ms']:.1f} ms ({nc / s['plain_ms'] / 1e3:.1f} M constraints/s); one REP3 party {s['rep3_party_ms']:.1f} ms mean / {s['rep3_party_ms_min']:.1f} min "
           f"({nc / s['rep3_party_ms'] / 1e3:.1f} M constraints/s); three parties on one GPU {s['rep3_three_parties_one_gpu_ms']:.1f} ms; zkey {s['zkey']['file_bytes'] / 1e9:.2f} GB generated in "
           f"{s['zkey']['generate_s']:.1f} s, session open {s['zkey']['session_open_s']:.1f} s; proofs agree: {s['three_parties_agree']}", flush=True)
+    v = s.get("additive_h_variant") or {}
+    if "rep3_party_ms" in v:
+        print(f"    opt-in additive-quotient variant: one REP3 party {v['rep3_party_ms']:.1f} ms mean / {v['rep3_party_ms_min']:.1f} min; three parties on one GPU "
+              f"{v['rep3_three_parties_one_gpu_ms']:.1f} ms; same proofs as the reference protocol: {v['same_proofs_as_reference_protocol']}", flush=True)
+    elif v: print("    variant failed:", v, flush=True)
