@@ -1,7 +1,8 @@
 """Critical path of the PRIMARY device of an N-GPU proving session, timed on one GPU (no multi-GPU box here): the session is opened
 over N contexts on GPU 0 and CGH_EMULATE_PRIMARY_ONLY makes the further devices' MSM slices no-ops, so that the timed proof is what
 device 0 of N does — witness map, its table slices, folding — while the others would work beside it (their share is never larger).
-usage: CGH_EMULATE_PRIMARY_ONLY=1 python scripts/multi_device_emulation.py [log_m=22] [worlds=1,2,4,8]"""
+usage: CGH_EMULATE_PRIMARY_ONLY=1 python scripts/multi_device_emulation.py [log_m=22] [worlds=1,2,4,8] [additive]
+(additive: sessions opened with CGH_SESSION_ADDITIVE_H, the opt-in protocol variant)"""
 import importlib, os, sys, tempfile, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -9,6 +10,7 @@ cg = importlib.import_module("collaborative-circom_amd")
 import bench
 log_m = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 worlds = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,2,4,8").split(",")]
+additive = len(sys.argv) > 3 and sys.argv[3] == "additive"
 assert os.environ.get("CGH_EMULATE_PRIMARY_ONLY") or worlds == [1], "set CGH_EMULATE_PRIMARY_ONLY=1 (otherwise all slices run on the one GPU)"
 dev = torch.device("cuda", 0); ctx = cg.Context(0)
 d = tempfile.mkdtemp(); zp, wp = os.path.join(d, "s.zkey"), os.path.join(d, "s.wtns")
@@ -24,11 +26,12 @@ pin = lambda x: (lambda p: (p.__setitem__(slice(None), x), p)[1])(ctx.host_alloc
 a, b, c = pin(host(da)), pin(host(db)), pin(host(dc))
 streams = [pin(host(bench.rand_fr(2 * m + 4, dev, g))) for _ in range(3)]
 del da, db, dc, dw
+tag = ", additive-quotient variant" if additive else ""
 for world in worlds:
-    ses = cg.ProvingSession(cg.BN254, zp, precompute=True, devices=[0] * world, validate=False)
+    ses = cg.ProvingSession(cg.BN254, zp, precompute=True, devices=[0] * world, validate=False, additive_h=additive)
     ses.prove_plain(w, r, s)
     tp = min(ses.prove_plain(w, r, s)[1] for _ in range(3))
     ses.prove_rep3(w[:2], [a, b, c], [c, a, b], streams, solo=False)
     t1 = min(ses.prove_rep3(w[:2], [a, b, c], [c, a, b], streams)[2] for _ in range(2))
     ses.close()
-    print(f"2^{log_m}, {world} device(s), primary device only: plain {tp * 1e3:.1f} ms, one REP3 party alone {t1 * 1e3:.1f} ms", flush=True)
+    print(f"2^{log_m}, {world} device(s), primary device only{tag}: plain {tp * 1e3:.1f} ms, one REP3 party alone {t1 * 1e3:.1f} ms", flush=True)
