@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "cg_host_alloc", "cg_host_free", "cg_host_is_pinned", "cg_dev_download_begin", "cg_dev_upload_begin", "cg_copy_wait", "cg_copy_fence",
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev", "cg_vec_affine_dev", "cg_vec_fill_dev", "cg_vec_gather_strided_dev", "cg_vec_lincomb_dev", "cg_vec_prefix_prod_dev", "cg_vec_prefix_sum_dev", "cg_vec_inverse_dev",
     "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
-    "cg_point_add", "cg_point_neg", "cg_point_scalar_mul", "cg_point_to_affine", "cg_point_from_affine", "cg_fr_op",
+    "cg_point_add", "cg_point_neg", "cg_point_scalar_mul", "cg_point_to_affine", "cg_point_from_affine", "cg_point_validate", "cg_fr_is_canonical", "cg_fr_op",
     "cg_fr_from_canonical", "cg_fr_to_canonical", "cg_fq_to_canonical", "cg_fq_from_canonical", "cg_point_generator",
     "cg_bases_synth_multiples", "cg_bases_download", "cg_bases_from_scalars",
     "cg_dev_copy_peer", "cg_ctx_device", "cg_device_count",
@@ -425,6 +425,20 @@ def point_generator(curve, group):
     out = np.zeros(point_words(curve, group, 3), dtype=np.uint64)
     _chk(load().cg_point_generator(curve, group, _hp(out)))
     return out
+
+
+def point_validate(curve, group, affine):
+    """the reference's checks on a deserialised point (coordinates below the modulus, on the curve, in the subgroup); host arithmetic"""
+    ok = C.c_int32(0)
+    _chk(load().cg_point_validate(curve, group, _hp(np.ascontiguousarray(affine, dtype=np.uint64)), C.byref(ok)))
+    return bool(ok.value)
+
+
+def fr_is_canonical(curve, elements):
+    e = np.ascontiguousarray(elements, dtype=np.uint64).reshape(-1, 4)
+    ok = C.c_int32(0)
+    _chk(load().cg_fr_is_canonical(curve, _hp(e), C.c_size_t(e.shape[0]), C.byref(ok)))
+    return bool(ok.value)
 
 
 def point_to_affine(curve, group, a):

@@ -1637,6 +1637,46 @@ int32_t cg_point_from_affine(int32_t curve, int32_t group, const void* h_affine,
         memcpy(h_out, &r, sizeof r); return 0;
     });
 }
+// the checks a deserialised point gets in the reference (ark-serialize with Validate::Yes, as mpc-net's receivers use it): coordinates
+// below the modulus, on the curve, in the prime-order subgroup.  Host arithmetic: for the handful of points a proof receives from its peers.
+extern "C++" {
+namespace {
+template <class P> bool limbs_below_modulus(const cg::Fp<P>& a) {
+    for (int i = P::N - 1; i >= 0; i--) { if (a.v[i] < P::P[i]) return true; if (a.v[i] > P::P[i]) return false; }
+    return false;
+}
+template <class B> bool limbs_below_modulus(const cg::Fp2<B>& a) { return limbs_below_modulus(a.c0) && limbs_below_modulus(a.c1); }
+}
+}  // extern "C++"
+int32_t cg_point_validate(int32_t curve, int32_t group, const void* h_affine, int32_t* ok) {
+    if (!h_affine || !ok) return fail(CG_ERR_ARG, "null argument");
+    return with_group(curve, group, [&](auto ftag, auto frtag) -> int {
+        typedef decltype(ftag) F; typedef decltype(frtag) Fr;
+        Affine<F> a; memcpy(&a, h_affine, sizeof a);
+        *ok = 0;
+        if (!limbs_below_modulus(a.x) || !limbs_below_modulus(a.y)) return 0;
+        if (a.is_inf()) { *ok = 1; return 0; }
+        if (a.y.sqr() != a.x.sqr() * a.x + CurveB<F>::get()) return 0;
+        if (!(curve == CG_BN254 && group == CG_G1)) {                                    // cofactor 1 there
+            XYZZ<F> r = XYZZ<F>::infinity();
+            for (int b = Fr::Params::BITS - 1; b >= 0; b--) {
+                r = xyzz_dbl(r);
+                if ((Fr::Params::P[b >> 5] >> (b & 31)) & 1u) r = xyzz_madd(r, a.x, a.y);
+            }
+            if (!r.is_inf()) return 0;
+        }
+        *ok = 1; return 0;
+    });
+}
+int32_t cg_fr_is_canonical(int32_t curve, const void* h_in, size_t n, int32_t* ok) {
+    if (!h_in || !ok) return fail(CG_ERR_ARG, "null argument");
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        *ok = 1;
+        for (size_t i = 0; i < n && *ok; i++) { Fr a; memcpy(a.v, (const uint8_t*)h_in + i * sizeof a.v, sizeof a.v); if (!limbs_below_modulus(a)) *ok = 0; }
+        return 0;
+    });
+}
 int32_t cg_fr_op(int32_t curve, int32_t op, const void* h_a, const void* h_b, void* h_out) {
     return with_fr(curve, [&](auto tag) -> int {
         typedef decltype(tag) Fr;

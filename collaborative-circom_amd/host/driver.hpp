@@ -43,6 +43,18 @@ public:
     // REP3 "additive quotient" variant (opt-in, NOT the reference's message sequence; see CoGroth16::prove): vector work on the own component only
     int k_override = 0; bool additive_h = false;
     struct Components { HipDriver& d; int old; Components(HipDriver& drv, int kk) : d(drv), old(drv.k_override) { d.k_override = kk; } ~Components() { d.k_override = old; } };
+    // What arrives from a peer is checked the way the reference's deserialisation checks it (ark-serialize Validate::Yes behind
+    // mpc-net's recv, rep3/network.rs:137-176 / shamir/network.rs:159-213): points on the curve and in the subgroup, field elements
+    // below the modulus; failure = InvalidData.  (The 2 x m-element exchanges of mul_vec go to the device unchecked: DESIGN.md §4.)
+    Point received_point(int group, const uint8_t* aff) const {
+        int32_t ok = 0; CG(cg_point_validate(curve.id, group, aff, &ok));
+        if (!ok) throw std::runtime_error("invalid data: a point received from a peer is not a valid curve point");
+        return pt_from_affine(curve, group, aff);
+    }
+    void check_received(const void* elements, size_t n) const {
+        int32_t ok = 0; CG(cg_fr_is_canonical(curve.id, elements, n, &ok));
+        if (!ok) throw std::runtime_error("invalid data: a field element received from a peer is not below the modulus");
+    }
     int party() const { return mode == Mode::Rep3 ? net->id() : -1; }
 
     HipDriver(cg_ctx* c, Curve cv, Mode m, Rep3Network* n) : ctx(c), curve(cv), mode(m), net(n) {}
@@ -293,12 +305,12 @@ public:
         Fr my_share;
         if (me == 0) {
             Fr acc = fr_mul(curve, input, mul_lagrange_2t[0]);
-            for (int other = 1; other <= 2 * sh_t; other++) { Fr r; snet->recv(other, r.v, 32); acc = fr_add(curve, acc, fr_mul(curve, r, mul_lagrange_2t[other])); }
+            for (int other = 1; other <= 2 * sh_t; other++) { Fr r; snet->recv(other, r.v, 32); check_received(r.v, 1); acc = fr_add(curve, acc, fr_mul(curve, r, mul_lagrange_2t[other])); }
             auto shares = shamir_share(acc, sh_t);
             for (int to = 0; to < np; to++) { if (to == me) my_share = shares[to]; else snet->send(to, shares[to].v, 32); }
         } else {
             if (me <= 2 * sh_t) snet->send(0, input.v, 32);
-            snet->recv(0, my_share.v, 32);
+            snet->recv(0, my_share.v, 32); check_received(my_share.v, 1);
         }
         return fr_sub(curve, my_share, pr.first);
     }
@@ -312,7 +324,7 @@ public:
         const size_t psz = curve.aff(g);
         if (me == 0) {
             Point acc = pt_mul(curve, input, mul_lagrange_2t[0]);
-            for (int other = 1; other <= 2 * sh_t; other++) { Bytes a(psz); snet->recv(other, a.data(), psz); acc = pt_add(curve, acc, pt_mul(curve, pt_from_affine(curve, g, a.data()), mul_lagrange_2t[other])); }
+            for (int other = 1; other <= 2 * sh_t; other++) { Bytes a(psz); snet->recv(other, a.data(), psz); acc = pt_add(curve, acc, pt_mul(curve, received_point(g, a.data()), mul_lagrange_2t[other])); }
             std::vector<Point> coeffs; for (int d = 0; d < sh_t; d++) coeffs.push_back(pt_mul(curve, gen, next_rand()));
             for (int to = 0; to < np; to++) {
                 Point sh = acc; const Fr x = fr_from_u64(curve, (uint64_t)to + 1); Fr xp = x;
@@ -321,7 +333,7 @@ public:
             }
         } else {
             if (me <= 2 * sh_t) { Bytes a = pt_to_affine(curve, input); snet->send(0, a.data(), a.size()); }
-            Bytes a(psz); snet->recv(0, a.data(), psz); my_share = pt_from_affine(curve, g, a.data());
+            Bytes a(psz); snet->recv(0, a.data(), psz); my_share = received_point(g, a.data());
         }
         return pt_sub(curve, my_share, pt_mul(curve, gen, pr.first));
     }
@@ -331,7 +343,7 @@ public:
         Bytes a = pt_to_affine(curve, mine);
         for (int sft = 1; sft <= sh_t; sft++) snet->send((me + sft) % np, a.data(), a.size());
         Point res = pt_mul(curve, mine, open_lagrange_t[0]);
-        for (int r = 1; r <= sh_t; r++) { Bytes b(a.size()); snet->recv((me + np - r) % np, b.data(), b.size()); res = pt_add(curve, res, pt_mul(curve, pt_from_affine(curve, mine.group, b.data()), open_lagrange_t[r])); }
+        for (int r = 1; r <= sh_t; r++) { Bytes b(a.size()); snet->recv((me + np - r) % np, b.data(), b.size()); res = pt_add(curve, res, pt_mul(curve, received_point(mine.group, b.data()), open_lagrange_t[r])); }
         return res;
     }
 
@@ -502,7 +514,7 @@ public:
             std::vector<Fr> local(out.n), recv(out.n);
             CG(cg_dev_download(ctx, local.data(), out.c[0], out.n * 32));
             net->send_next(local.data(), out.n * 32);
-            net->recv_prev(recv.data(), out.n * 32);
+            net->recv_prev(recv.data(), out.n * 32); check_received(recv.data(), out.n);
             CG(cg_dev_upload(ctx, out.c[1], recv.data(), out.n * 32));
             return out;
         }
@@ -550,7 +562,7 @@ public:
         for (int sft = 1; sft < num; sft++) snet->send((me + sft) % np, mine.data(), n * 32);
         std::vector<Fr> out(n), got(n);
         for (size_t i = 0; i < n; i++) out[i] = fr_mul(curve, mine[i], lagrange[0]);
-        for (int r = 1; r < num; r++) { snet->recv((me + np - r) % np, got.data(), n * 32); for (size_t i = 0; i < n; i++) out[i] = fr_add(curve, out[i], fr_mul(curve, got[i], lagrange[r])); }
+        for (int r = 1; r < num; r++) { snet->recv((me + np - r) % np, got.data(), n * 32); check_received(got.data(), n); for (size_t i = 0; i < n; i++) out[i] = fr_add(curve, out[i], fr_mul(curve, got[i], lagrange[r])); }
         return out;
     }
     ShareVec rand_vec(size_t n) {
@@ -575,7 +587,7 @@ public:
             std::vector<Term> terms{{out, 0, 1, open_lagrange_2t[0]}};
             std::vector<void*> got;
             for (int r = 1; r < num; r++) {
-                snet->recv((me + np - r) % np, buf.data(), n * 32);
+                snet->recv((me + np - r) % np, buf.data(), n * 32); check_received(buf.data(), n);
                 void* d = dalloc(n * 32); CG(cg_dev_upload(ctx, d, buf.data(), n * 32));
                 got.push_back(d); terms.push_back({d, 0, 1, open_lagrange_2t[r]});
             }
@@ -594,7 +606,7 @@ public:
         std::vector<Fr> mine(n), p(n), q(n);
         CG(cg_dev_download(ctx, mine.data(), out, n * 32));
         net->send_next(mine.data(), n * 32); net->send_prev(mine.data(), n * 32);
-        net->recv_prev(p.data(), n * 32); net->recv_next(q.data(), n * 32);
+        net->recv_prev(p.data(), n * 32); net->recv_next(q.data(), n * 32); check_received(p.data(), n); check_received(q.data(), n);
         CG(cg_dev_upload(ctx, m1, p.data(), n * 32)); CG(cg_dev_upload(ctx, m2, q.data(), n * 32));
         CG(cg_vec_add_dev(ctx, curve.id, out, out, m1, n)); CG(cg_vec_add_dev(ctx, curve.id, out, out, m2, n));
         CG(cg_dev_free(ctx, m1)); CG(cg_dev_free(ctx, m2));
@@ -606,7 +618,7 @@ public:
         if (mode == Mode::Shamir) { std::vector<Fr> mine(a.size()); for (size_t i = 0; i < a.size(); i++) mine[i] = a[i].c[0]; return shamir_open_vec(mine, open_lagrange_t); }   // shamir.rs:581-601
         std::vector<Fr> bs(a.size()), cs(a.size());
         for (size_t i = 0; i < a.size(); i++) bs[i] = a[i].c[1];
-        net->send_next(bs.data(), bs.size() * 32); net->recv_prev(cs.data(), cs.size() * 32);
+        net->send_next(bs.data(), bs.size() * 32); net->recv_prev(cs.data(), cs.size() * 32); check_received(cs.data(), cs.size());
         for (size_t i = 0; i < a.size(); i++) out[i] = fr_add(curve, fr_add(curve, a[i].c[0], a[i].c[1]), cs[i]);
         return out;
     }
@@ -729,7 +741,7 @@ public:
         net->send_next(msg.data(), msg.size());
         Bytes got(msg.size()); net->recv_prev(got.data(), got.size());
         size_t at = 0;
-        for (PointShare* ps : pts) { const int g = ps->c[0].group; ps->c[1] = pt_from_affine(curve, g, got.data() + at); at += curve.aff(g); }
+        for (PointShare* ps : pts) { const int g = ps->c[0].group; ps->c[1] = received_point(g, got.data() + at); at += curve.aff(g); }
     }
     // rand (rep3.rs:595-598; plain: supplied by the caller)
     FieldShare rand() {
@@ -747,7 +759,7 @@ public:
         if (rsrc) { Fr buf; local = fr_add(curve, local, *rsrc->masking_field_elements(1, &buf)); }
         else { local = fr_add(curve, local, fr_sub(curve, draw(rng1), draw(rng2))); cursor++; }
         net->send_next(local.v, 32);
-        Fr prev; net->recv_prev(prev.v, 32);
+        Fr prev; net->recv_prev(prev.v, 32); check_received(prev.v, 1);
         r.c[0] = local; r.c[1] = prev;
         return r;
     }
@@ -767,7 +779,7 @@ public:
         Bytes aff = pt_to_affine(curve, local);                    // points cross the wire in affine form (ark-serialize)
         net->send_next(aff.data(), aff.size());
         Bytes prev(aff.size()); net->recv_prev(prev.data(), prev.size());
-        r.c[0] = local; r.c[1] = pt_from_affine(curve, local.group, prev.data());
+        r.c[0] = local; r.c[1] = received_point(local.group, prev.data());
         return r;
     }
     void add_assign_points(PointShare& a, const PointShare& b) { for (int j = 0; j < k(); j++) a.c[j] = pt_add(curve, a.c[j], b.c[j]); }
@@ -782,7 +794,7 @@ public:
         Bytes mine = pt_to_affine(curve, a.c[1]);
         net->send_next(mine.data(), mine.size());
         Bytes prev(mine.size()); net->recv_prev(prev.data(), prev.size());
-        return pt_add(curve, pt_add(curve, a.c[0], a.c[1]), pt_from_affine(curve, a.c[0].group, prev.data()));
+        return pt_add(curve, pt_add(curve, a.c[0], a.c[1]), received_point(a.c[0].group, prev.data()));
     }
     std::pair<Point, Point> open_two_points(const PointShare& a, const PointShare& b) {   // rep3.rs:865-877
         if (mode == Mode::Plain) return {a.c[0], b.c[0]};
@@ -791,8 +803,8 @@ public:
         Bytes msg(m1); msg.insert(msg.end(), m2.begin(), m2.end());
         net->send_next(msg.data(), msg.size());
         Bytes prev(msg.size()); net->recv_prev(prev.data(), prev.size());
-        Point r1 = pt_add(curve, pt_from_affine(curve, CG_G1, prev.data()), pt_add(curve, a.c[0], a.c[1]));
-        Point r2 = pt_add(curve, pt_from_affine(curve, CG_G2, prev.data() + m1.size()), pt_add(curve, b.c[0], b.c[1]));
+        Point r1 = pt_add(curve, received_point(CG_G1, prev.data()), pt_add(curve, a.c[0], a.c[1]));
+        Point r2 = pt_add(curve, received_point(CG_G2, prev.data() + m1.size()), pt_add(curve, b.c[0], b.c[1]));
         return {r1, r2};
     }
 };

@@ -208,6 +208,11 @@ int32_t cg_point_neg(int32_t curve, int32_t group, const void* h_a, void* h_out)
 int32_t cg_point_scalar_mul(int32_t curve, int32_t group, const void* h_a, const void* h_k, void* h_out);
 int32_t cg_point_to_affine(int32_t curve, int32_t group, const void* h_a, void* h_out_affine);
 int32_t cg_point_from_affine(int32_t curve, int32_t group, const void* h_affine, void* h_out);
+/* What the reference checks when it deserialises a point or field elements received from a peer (ark-serialize, Validate::Yes: mpc-net's
+ * recv paths, rep3/network.rs:137-176): coordinates below the modulus, on the curve, in the prime-order subgroup; limbs below the scalar
+ * modulus.  Host arithmetic, for the O(1) values of a proof.  *ok = 1 / 0. */
+int32_t cg_point_validate(int32_t curve, int32_t group, const void* h_affine, int32_t* ok);
+int32_t cg_fr_is_canonical(int32_t curve, const void* h_elements, size_t n, int32_t* ok);
 /* O(1) scalar-field helpers used by the host drivers (Montgomery in/out): op 0 add, 1 sub, 2 mul, 3 inverse(a) */
 int32_t cg_fr_op(int32_t curve, int32_t op, const void* h_a, const void* h_b, void* h_out);
 /* canonical little-endian integers (wtns values, circom-types/src/witness.rs:51-91) <-> Montgomery form; n elements, host.

@@ -240,3 +240,29 @@ def test_party_failure_is_reported_not_deadlocked():
     streams = [orc.random_field(curve, FR, 300, rng) for _ in range(3)]          # needs 2 * 256 + 4
     with pytest.raises(cg.BackendError, match="randomness stream exhausted"):
         cg.prove_rep3(curve, fx("bn254", "poseidon", "circuit.zkey"), w[:z.n_public + 1], wa, wb, streams)
+
+
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_received_points_and_scalars_are_validated_like_a_deserialiser(curve_name):
+    """what a party receives from its peers is checked as ark-serialize (Validate::Yes) checks it behind mpc-net's recv: coordinates
+    below the modulus, on the curve, in the prime-order subgroup; field elements below the modulus (host arithmetic, no GPU)"""
+    from test_gpu_parity import off_subgroup_point
+    from oracle_lib import G1, G2
+    ensure_built()
+    curve = BN254 if curve_name == "bn254" else BLS12_381
+    for group in (G1, G2):
+        g = cg.point_to_affine(curve, group, cg.point_generator(curve, group))
+        assert cg.point_validate(curve, group, g)
+        assert cg.point_validate(curve, group, np.zeros_like(g))                         # the point at infinity
+        k = orc.random_field(curve, FR, 1, np.random.default_rng(3))[0]
+        assert cg.point_validate(curve, group, cg.point_to_affine(curve, group, cg.point_scalar_mul(curve, group, cg.point_generator(curve, group), k)))
+        bad = g.copy(); bad[0] ^= np.uint64(1)
+        assert not cg.point_validate(curve, group, bad)                                  # off the curve
+        big = g.copy(); big[:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        assert not cg.point_validate(curve, group, big)                                  # limbs above the modulus
+        off = off_subgroup_point(curve, group)
+        assert cg.point_validate(curve, group, off) == (curve == BN254 and group == G1)  # BN254 G1 has cofactor 1
+    ok = orc.random_field(curve, FR, 5, np.random.default_rng(4))
+    assert cg.fr_is_canonical(curve, ok)
+    ok[3] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert not cg.fr_is_canonical(curve, ok)

@@ -40,6 +40,7 @@ class SocketEnd:
         self.sent = {"next": 0, "prev": 0}
         self.sent_bytes = 0
         self.fail_send_next_at = None
+        self.corrupt_send_next_at = None
         self.readers = [threading.Thread(target=self._reader, args=(from_prev, self.inq["prev"]), daemon=True),
                         threading.Thread(target=self._reader, args=(from_next, self.inq["next"]), daemon=True)]
         for t in self.readers: t.start()
@@ -70,7 +71,10 @@ class SocketEnd:
         try:
             if where == "next" and self.fail_send_next_at is not None and self.sent["next"] == self.fail_send_next_at:
                 return 32                                                          # EPIPE: the peer went away
-            self.out[where].sendall(struct.pack("<Q", n) + C.string_at(data, n))
+            payload = C.string_at(data, n)
+            if where == "next" and self.corrupt_send_next_at is not None and self.sent["next"] == self.corrupt_send_next_at:
+                payload = bytes([payload[0] ^ 1]) + payload[1:]                    # a bit flipped on the wire
+            self.out[where].sendall(struct.pack("<Q", n) + payload)
             self.sent[where] += 1; self.sent_bytes += n
             return 0
         except OSError as e:
@@ -500,3 +504,37 @@ def test_shamir_degree_2t_quotient_variant(curve_name, n, t):
             for e in ends: e.close()
             ses.close()
     assert sent[True] < sent[False]
+
+
+@pytest.mark.gpu
+def test_a_corrupted_point_from_a_peer_is_invalid_data():
+    """the reference deserialises what it receives with validation (ark-serialize behind mpc-net's recv): a point that is not on the curve
+    ends the prove with InvalidData.  Party 1's open_point message (its fourth to the next party: two mul_vec vectors, r*s, the point)
+    gets one bit flipped; party 2 must refuse it"""
+    ensure_built()
+    curve = BN254
+    zpath = fx("bn254", "poseidon", "circuit.zkey")
+    z = orc.ZKey(curve, zpath); w = orc.read_wtns(curve, fx("bn254", "poseidon", "witness.wtns"))
+    rng = np.random.default_rng(31)
+    pub = w[:z.n_public + 1]
+    wa, wb = rep3_share(curve, w[z.n_public + 1:], rng)
+    streams = [orc.random_field(curve, FR, 2 * z.domain_size + 4, rng) for _ in range(3)]
+    ses = cg.ProvingSession(curve, zpath, precompute=False)
+    try:
+        ends = socket_ring()
+        ends[1].corrupt_send_next_at = 3
+        rands = [cg.StreamRand(curve, streams[i], streams[(i + 2) % 3]) for i in range(3)]
+        out, errs = [None] * 3, [None] * 3
+
+        def party(i):
+            try: out[i], _ = cg.host_prove_rep3_party(ses, pub, wa[i], wb[i], ends[i].table, rands[i].table)
+            except Exception as e: errs[i] = e
+            finally: ends[i].close()
+        th = [threading.Thread(target=party, args=(i,)) for i in range(3)]
+        for t in th: t.start()
+        for t in th: t.join(120)
+        assert not any(t.is_alive() for t in th)
+        assert errs[2] is not None and "invalid data" in str(errs[2]), errs
+        for r in rands: r.close()
+    finally:
+        ses.close()
