@@ -41,6 +41,7 @@ template <class F, class Fr> int fixed_base_mul_launch(hipStream_t st, const Aff
 template <class Fr> int launch_vec_binary(hipStream_t st, int op, Fr* out, const Fr* a, const Fr* b, size_t n);
 template <class Fr> int launch_rep3_mul_local(hipStream_t st, Fr* out, const Fr* aa, const Fr* ab, const Fr* ba, const Fr* bb, const Fr* mask, size_t n);
 template <class Fr> int launch_distribute_powers(hipStream_t st, Fr* v, size_t n, const Fr* lo, const Fr* hi, int log_lo);
+template <class Fr> int launch_vec_count_noncanonical(hipStream_t st, const Fr* v, size_t n, unsigned long long* n_bad);
 template <class Fr> int launch_vec_fill(hipStream_t st, Fr* v, size_t n, const Fr& value);
 template <class Fr> int launch_vec_affine(hipStream_t st, Fr* out, const Fr* a, size_t n, const Fr& c, const Fr& d);
 template <class Fr> int launch_vec_gather_strided(hipStream_t st, Fr* out, const Fr* in, size_t n, size_t offset, size_t stride);
@@ -1470,6 +1471,15 @@ int32_t cg_vec_rep3_mul_local_dev(cg_ctx* ctx, int32_t curve, void* d_out, const
         typedef decltype(tag) Fr;
         StatScope ss(ctx, TAG_VEC);
         return launch_rep3_mul_local<Fr>(ctx->stream, (Fr*)d_out, (const Fr*)d_aa, (const Fr*)d_ab, (const Fr*)d_ba, (const Fr*)d_bb, (const Fr*)d_mask, n);
+    });
+}
+int32_t cg_vec_check_canonical_dev(cg_ctx* ctx, int32_t curve, const void* d_vec, size_t n, void* d_count) {
+    if (!ctx || !d_vec || !d_count) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        StatScope ss(ctx, TAG_VEC);
+        return launch_vec_count_noncanonical<Fr>(ctx->stream, (const Fr*)d_vec, n, (unsigned long long*)d_count);
     });
 }
 int32_t cg_vec_distribute_powers_dev(cg_ctx* ctx, int32_t curve, void* d_v, size_t n, const void* h_g, const void* h_c) {

@@ -21,6 +21,12 @@ template <class Fr> int launch_rep3_mul_local(hipStream_t st, Fr* out, const Fr*
     HIPCHK(hipGetLastError());
     return 0;
 }
+template <class Fr> int launch_vec_count_noncanonical(hipStream_t st, const Fr* v, size_t n, unsigned long long* n_bad) {
+    if (!n) return 0;
+    hipLaunchKernelGGL((k_vec_count_noncanonical<Fr>), dim3(grid_for(n)), dim3(256), 0, st, v, n, n_bad);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 template <class Fr> int launch_distribute_powers(hipStream_t st, Fr* v, size_t n, const Fr* lo, const Fr* hi, int log_lo) {
     if (!n) return 0;
     hipLaunchKernelGGL((k_distribute_powers<Fr>), dim3(grid_for(n)), dim3(256), 0, st, v, n, lo, hi, log_lo);
@@ -264,6 +270,7 @@ template <class Fr> int msm_sort_direct_launch(hipStream_t st, const Fr* d_scala
     template int launch_vec_binary<Fr>(hipStream_t, int, Fr*, const Fr*, const Fr*, size_t);                               \
     template int launch_rep3_mul_local<Fr>(hipStream_t, Fr*, const Fr*, const Fr*, const Fr*, const Fr*, const Fr*, size_t); \
     template int launch_distribute_powers<Fr>(hipStream_t, Fr*, size_t, const Fr*, const Fr*, int);                        \
+    template int launch_vec_count_noncanonical<Fr>(hipStream_t, const Fr*, size_t, unsigned long long*);                   \
     template int launch_vec_fill<Fr>(hipStream_t, Fr*, size_t, const Fr&);                                                 \
     template int launch_vec_gather_idx<Fr>(hipStream_t, Fr*, const Fr*, const uint32_t*, size_t, uint32_t);                \
     template int launch_vec_affine<Fr>(hipStream_t, Fr*, const Fr*, size_t, const Fr&, const Fr&);                         \

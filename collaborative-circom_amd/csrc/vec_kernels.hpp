@@ -44,6 +44,19 @@ __global__ void __launch_bounds__(256) k_rep3_mul_local(F* __restrict__ out, con
     }
 }
 
+// elements whose limbs are not below the modulus (what a deserialiser rejects): counted into *n_bad.  32 B read per element.
+template <class F>
+__global__ void __launch_bounds__(256) k_vec_count_noncanonical(const F* __restrict__ v, size_t n, unsigned long long* __restrict__ n_bad) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const F a = ld_fp(v + i);
+        bool below = false, decided = false;
+        _Pragma("unroll") for (int j = F::N - 1; j >= 0; j--) {
+            if (!decided && a.v[j] != F::Params::P[j]) { below = a.v[j] < F::Params::P[j]; decided = true; }
+        }
+        if (!below) atomicAdd(n_bad, 1ull);
+    }
+}
+
 // v[i] *= c * g^i  (rep3.rs:681-688 / plain.rs:226-234).  g^i = hi[i >> LOG_LO] * lo[i & (2^LOG_LO - 1)] from two small
 // tables (lo[j] = c*g^j, hi[j] = g^(j << LOG_LO)) that stay in L2: no per-element power chain, no m-entry table in HBM.
 template <class F>

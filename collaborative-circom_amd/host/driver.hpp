@@ -51,6 +51,18 @@ public:
         if (!ok) throw std::runtime_error("invalid data: a point received from a peer is not a valid curve point");
         return pt_from_affine(curve, group, aff);
     }
+    // the m-element vectors a peer sends go from the transport's buffer to the device; the same range check runs there, behind the
+    // upload, into a device counter that is read where the witness map synchronises anyway (verify_received_vectors)
+    void* d_bad = nullptr;
+    void check_received_dev(const void* d_vec, size_t n) {
+        if (!d_bad) { CG(cg_dev_alloc(ctx, 32, &d_bad)); CG(cg_dev_memset_zero(ctx, d_bad, 32)); }
+        CG(cg_vec_check_canonical_dev(ctx, curve.id, d_vec, n, d_bad));
+    }
+    void verify_received_vectors() {
+        if (!d_bad) return;
+        uint64_t bad = 0; CG(cg_dev_download(ctx, &bad, d_bad, 8));
+        if (bad) { CG(cg_dev_memset_zero(ctx, d_bad, 32)); throw std::runtime_error("invalid data: " + std::to_string(bad) + " field element(s) of a vector received from a peer are not below the modulus"); }
+    }
     void check_received(const void* elements, size_t n) const {
         int32_t ok = 0; CG(cg_fr_is_canonical(curve.id, elements, n, &ok));
         if (!ok) throw std::runtime_error("invalid data: a field element received from a peer is not below the modulus");
@@ -537,6 +549,7 @@ public:
             }
         }
         if (up >= 0) CG(cg_copy_fence(ctx, up));                                       // later launches see the received component
+        check_received_dev(out.c[1], n);
         pm.exchange = false;
         return out;
     }
@@ -545,6 +558,7 @@ public:
     void shutdown() {
         for (void* p : deferred) cg_dev_free(ctx, p);
         deferred.clear();
+        if (d_bad) { cg_dev_free(ctx, d_bad); d_bad = nullptr; }
         for (auto& ms : prefetched) { cg_dev_free(ctx, ms.m1); if (ms.m2) cg_dev_free(ctx, ms.m2); }
         prefetched.clear();
         if (!mask_bufs.empty()) { cg_ctx_sync(ctx); for (void* p : mask_bufs) cg_host_free(p); mask_bufs.clear(); }   // uploads from them may still be in flight

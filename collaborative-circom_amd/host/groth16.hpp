@@ -180,6 +180,8 @@ public:
         PointShare l_aux_acc = aux_result(AUX_L);                                          // :251
         PointShare h_acc = have_early ? early[4] : driver.msm_finish(h_msm, 0);                                               // :248
         mk.mark("msm l + h");
+        if (dmap) dmap->verify_received();
+        driver.verify_received_vectors();      // rep3.rs:663-669: what deserialising the two mul_vec messages would have refused (counted on the device, read here where the stream is idle)
         PointShare g_c = s_g_a;                                                                        // :308-312
         driver.add_assign_points(g_c, r_g1_b);
         driver.sub_assign_points(g_c, r_s_delta_g1);

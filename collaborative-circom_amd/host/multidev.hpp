@@ -29,6 +29,7 @@ public:
         void* av[2] = {nullptr, nullptr}; void* bv[2] = {nullptr, nullptr};      // rows of a and b (components)
         void* prod = nullptr; void* recv = nullptr;                                // mul_vec result rows: local component, received component
         int32_t up_tk = -1;                                                        // last upload into this device
+        void* bad = nullptr;                                                       // device counter: received elements that are not below the modulus
         std::vector<void*> owned;                                                  // device allocations to release at the end
     };
     std::vector<Dev> devs;
@@ -152,8 +153,19 @@ public:
             });
         }
         for (size_t d = 0; d < devs.size(); d++) if (!skip(d) && devs[d].up_tk >= 0) CG(cg_copy_fence(devs[d].ctx, devs[d].up_tk));   // later launches see the received rows
+        for (size_t d = 0; d < devs.size(); d++) if (!skip(d) && devs[d].recv && devs[d].n) {                                         // the receiver's range check (HipDriver::check_received_dev)
+            Dev& D = devs[d];
+            if (!D.bad) { D.bad = dalloc(D, 32); CG(cg_dev_memset_zero(D.ctx, D.bad, 32)); }
+            CG(cg_vec_check_canonical_dev(D.ctx, curve.id, D.recv, D.n, D.bad));
+        }
     }
 
+    // read where the proof's streams are idle (CoGroth16::prove, before the last opening)
+    void verify_received() {
+        uint64_t total = 0;
+        for (Dev& D : devs) if (D.bad) { uint64_t bad = 0; CG(cg_dev_download(D.ctx, &bad, D.bad, 8)); total += bad; }
+        if (total) throw std::runtime_error("invalid data: " + std::to_string(total) + " field element(s) of a vector received from a peer are not below the modulus");
+    }
     // rows [D.lo, D.lo + D.n) of whole vectors `src[j]` (on device `from`) into D's row buffers dst[j]
     void rows_to(Dev& D, void* const* dst, Dev& from, void* const* src) {
         for (int j = 0; j < k; j++) CG(cg_dev_copy_peer(D.ctx, dst[j], from.ctx, (const uint8_t*)src[j] + D.lo * 32, D.n * 32));

@@ -213,6 +213,9 @@ int32_t cg_point_from_affine(int32_t curve, int32_t group, const void* h_affine,
  * modulus.  Host arithmetic, for the O(1) values of a proof.  *ok = 1 / 0. */
 int32_t cg_point_validate(int32_t curve, int32_t group, const void* h_affine, int32_t* ok);
 int32_t cg_fr_is_canonical(int32_t curve, const void* h_elements, size_t n, int32_t* ok);
+/* The same check for a vector on the device (the m-element messages of mul_vec): adds the number of elements that are not below the
+ * modulus to the uint64 at d_count (device memory, zeroed by the caller); enqueued on the context's stream, 32 B read per element. */
+int32_t cg_vec_check_canonical_dev(cg_ctx* ctx, int32_t curve, const void* d_vec, size_t n, void* d_count);
 /* O(1) scalar-field helpers used by the host drivers (Montgomery in/out): op 0 add, 1 sub, 2 mul, 3 inverse(a) */
 int32_t cg_fr_op(int32_t curve, int32_t op, const void* h_a, const void* h_b, void* h_out);
 /* canonical little-endian integers (wtns values, circom-types/src/witness.rs:51-91) <-> Montgomery form; n elements, host.

@@ -41,6 +41,7 @@ class SocketEnd:
         self.sent_bytes = 0
         self.fail_send_next_at = None
         self.corrupt_send_next_at = None
+        self.corrupt_top_byte_at = None
         self.readers = [threading.Thread(target=self._reader, args=(from_prev, self.inq["prev"]), daemon=True),
                         threading.Thread(target=self._reader, args=(from_next, self.inq["next"]), daemon=True)]
         for t in self.readers: t.start()
@@ -74,6 +75,8 @@ class SocketEnd:
             payload = C.string_at(data, n)
             if where == "next" and self.corrupt_send_next_at is not None and self.sent["next"] == self.corrupt_send_next_at:
                 payload = bytes([payload[0] ^ 1]) + payload[1:]                    # a bit flipped on the wire
+            if where == "next" and self.corrupt_top_byte_at is not None and self.sent["next"] == self.corrupt_top_byte_at:
+                payload = payload[:31] + b"\xff" + payload[32:]                   # first element: top limb above the modulus
             self.out[where].sendall(struct.pack("<Q", n) + payload)
             self.sent[where] += 1; self.sent_bytes += n
             return 0
@@ -535,6 +538,41 @@ def test_a_corrupted_point_from_a_peer_is_invalid_data():
         for t in th: t.join(120)
         assert not any(t.is_alive() for t in th)
         assert errs[2] is not None and "invalid data" in str(errs[2]), errs
+        for r in rands: r.close()
+    finally:
+        ses.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunked", [False, True])
+def test_a_non_canonical_element_in_a_mul_vec_message_is_invalid_data(chunked, tmp_path, monkeypatch):
+    """the m-element messages of mul_vec are range-checked too — on the host when they travel as one message, on the device (behind the
+    upload, read at the end of the prove) when they travel in chunks: an element whose limbs are not below the modulus = InvalidData"""
+    ensure_built()
+    if chunked: monkeypatch.setenv("CGH_XCHG_ASYNC_MIN", "4096")
+    curve, log_m = BN254, 14
+    zp, wp = str(tmp_path / "s.zkey"), str(tmp_path / "s.wtns")
+    orc.make_synthetic(curve, log_m, 35, zp, wp, threads=min(32, os.cpu_count() or 8))
+    z = orc.ZKey(curve, zp); w = orc.read_wtns(curve, wp)
+    rng = np.random.default_rng(37)
+    wa, wb = rep3_share(curve, w[2:], rng)
+    streams = [orc.random_field(curve, FR, 2 * z.domain_size + 4, rng) for _ in range(3)]
+    ses = cg.ProvingSession(curve, zp, precompute=False)
+    try:
+        ends = socket_ring()
+        ends[0].corrupt_top_byte_at = 0                                                   # party 0's first mul_vec message (or its first chunk)
+        rands = [cg.StreamRand(curve, streams[i], streams[(i + 2) % 3]) for i in range(3)]
+        out, errs = [None] * 3, [None] * 3
+
+        def party(i):
+            try: out[i], _ = cg.host_prove_rep3_party(ses, w[:2], wa[i], wb[i], ends[i].table, rands[i].table)
+            except Exception as e: errs[i] = e
+            finally: ends[i].close()
+        th = [threading.Thread(target=party, args=(i,)) for i in range(3)]
+        for t in th: t.start()
+        for t in th: t.join(120)
+        assert not any(t.is_alive() for t in th)
+        assert errs[1] is not None and "invalid data" in str(errs[1]), errs
         for r in rands: r.close()
     finally:
         ses.close()
