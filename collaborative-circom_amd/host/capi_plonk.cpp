@@ -38,6 +38,7 @@ void plonk_run(cgh::HipDriver& driver, const cgh::PlonkZKey& z, const cg_bases* 
         for (int i = 0; i < 6; i++) putf(o.evals, i, ev[i]);
     }
     if (upto >= 5) { pk.round5(); putf(o.challenges, 4, pk.v[0]); put(7, pk.commit_wxi); put(8, pk.commit_wxiw); }
+    driver.verify_received_vectors();                                              // range check of the vectors received from peers (counted on the device)
 }
 }  // namespace
 // PlainHipDriver through rounds 1..upto (<= 5).  full_witness = n_vars - n_additions Montgomery elements (Groth16-style, leading one);

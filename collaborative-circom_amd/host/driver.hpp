@@ -52,7 +52,7 @@ public:
         return pt_from_affine(curve, group, aff);
     }
     // the m-element vectors a peer sends go from the transport's buffer to the device; the same range check runs there, behind the
-    // upload, into a device counter that is read where the witness map synchronises anyway (verify_received_vectors)
+    // upload, into a device counter that the provers read before their last opening (verify_received_vectors)
     void* d_bad = nullptr;
     void check_received_dev(const void* d_vec, size_t n) {
         if (!d_bad) { CG(cg_dev_alloc(ctx, 32, &d_bad)); CG(cg_dev_memset_zero(ctx, d_bad, 32)); }
@@ -157,7 +157,7 @@ public:
         }
         for (int to = 0; to < np; to++) if (to != me) snet->send(to, send[to].data(), send[to].size() * 32);
         std::vector<std::vector<Fr>> got(np);
-        for (int from = 0; from < np; from++) { if (from == me) got[from] = send[me]; else { got[from].resize(2 * amount); snet->recv(from, got[from].data(), 2 * amount * 32); } }
+        for (int from = 0; from < np; from++) { if (from == me) got[from] = send[me]; else { got[from].resize(2 * amount); snet->recv(from, got[from].data(), 2 * amount * 32); check_received(got[from].data(), 2 * amount); } }
         for (size_t k = 0; k < amount; k++) {
             std::vector<Fr> in_t(np), in_2t(np);
             for (int from = 0; from < np; from++) { in_t[from] = got[from][2 * k]; in_2t[from] = got[from][2 * k + 1]; }
@@ -209,7 +209,7 @@ public:
             if (to != me) { CG(cg_dev_download(ctx, buf.data(), d_pairs, 2 * amount * 32)); snet->send(to, buf.data(), 2 * amount * 32); }
         }
         mk.mark("share+send");
-        for (int from = 0; from < np; from++) if (from != me) { snet->recv(from, buf.data(), 2 * amount * 32); CG(cg_dev_upload(ctx, d_got[from], buf.data(), 2 * amount * 32)); }
+        for (int from = 0; from < np; from++) if (from != me) { snet->recv(from, buf.data(), 2 * amount * 32); CG(cg_dev_upload(ctx, d_got[from], buf.data(), 2 * amount * 32)); check_received_dev(d_got[from], 2 * amount); }
         mk.mark("recv+upload");
         // Vandermonde rows 1, x, .., x^t over the senders' points (shamir.rs:904-921): t + 1 outputs per secret
         const size_t outn = amount * (size_t)(t + 1);
@@ -264,7 +264,7 @@ public:
             CG(cg_vec_affine_dev(ctx, curve.id, local.c[0], local.c[0], len, mul_lagrange_2t[0].v, nullptr));   // acc = input * lagrange_0
             for (int other = 1; other <= 2 * sh_t; other++) {
                 snet->recv(other, buf.data(), len * 32);
-                CG(cg_dev_upload(ctx, tmp, buf.data(), len * 32));
+                CG(cg_dev_upload(ctx, tmp, buf.data(), len * 32)); check_received_dev(tmp, len);
                 CG(cg_vec_affine_dev(ctx, curve.id, tmp, tmp, len, mul_lagrange_2t[other].v, nullptr));
                 CG(cg_vec_add_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));
             }
@@ -298,7 +298,7 @@ public:
             mk.mark("download+send");
             snet->recv(0, buf.data(), len * 32);
             mk.mark("wait for king");
-            CG(cg_dev_upload(ctx, local.c[0], buf.data(), len * 32));
+            CG(cg_dev_upload(ctx, local.c[0], buf.data(), len * 32)); check_received_dev(local.c[0], len);
             mk.mark("upload");
         }
         if (on_dev) {
