@@ -727,6 +727,21 @@ def main():
                 break
             except Exception:
                 traffic = None
+        # "state the measured stream-copy ceiling beside" the 8 TB/s peak: one 1 GiB device-to-device copy (read + write),
+        # best of 5, timed with events on the stream the copy runs on (torch's current stream)
+        copy_gbs = None
+        try:
+            src = torch.empty(1 << 30, dtype=torch.uint8, device=device); dst = torch.empty_like(src)
+            dst.copy_(src); torch.cuda.synchronize(device)
+            best = None
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); dst.copy_(src); e1.record(); torch.cuda.synchronize(device)
+                t = e0.elapsed_time(e1); best = t if best is None else min(best, t)
+            copy_gbs = 2.0 * (1 << 30) / (best * 1e-3) / 1e9
+            del src, dst
+        except Exception:                                                                # noqa: BLE001 (a side figure)
+            copy_gbs = None
         free_b, total_b = torch.cuda.mem_get_info(device)
         roof = lambda bytes_, ms: {"achieved": bytes_ / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "launch_ms": ms, "algorithmic_bytes_per_launch": bytes_} if ms else None
@@ -743,7 +758,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate_pf<G1> (bucket accumulation, one launch per MSM component and table)",
                          "achieved": (96.0 * iso_pts / (iso_ms * 1e-3) / 1e9) if iso_ms else achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ((96.0 * iso_pts / (iso_ms * 1e-3) / 1e9) if iso_ms else achieved) / HBM_PEAK_GBS, "traffic": traffic,
-                         "launch_ms": iso_ms, "algorithmic_bytes_per_launch": 96.0 * iso_pts,
+                         "launch_ms": iso_ms, "algorithmic_bytes_per_launch": 96.0 * iso_pts, "measured_copy_ceiling_GBs": copy_gbs,
                          "overlapped_avg_launch_ms": avg_ms, "overlapped_launches": st["msm_acc_g1_calls"],
                          "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound, and clocked by the chip's power management: the launch holds ~1.9 GHz "
                                  "(GRBM_GUI_ACTIVE / duration, scripts/clock_by_kernel.py) where the same additions with operands in registers hold 2.35 GHz; "
