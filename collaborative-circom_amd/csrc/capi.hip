@@ -3,6 +3,7 @@
 // There is deliberately no CPU fallback here: without a HIP device cg_ctx_create fails.
 #include "common.hpp"
 #include "curve.hpp"
+#include "subgroup.hpp"
 #include "ntt_kernels.hpp"   // NttVecs, plan constants (no kernels are instantiated in this translation unit)
 
 #include <cmath>
@@ -28,6 +29,7 @@ template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool 
 template <class F> int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c);
 template <class F> int check_on_curve_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, const F& b, unsigned long long* d_counters);
 template <class F, class Fr> int check_subgroup_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, unsigned long long* d_counters);
+template <class F> int check_subgroup_fast_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, const FastSubgroup<F>& c, unsigned long long* d_counters);
 inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) {   // must match fr_impl.hpp
     const size_t nbuckets = (size_t)nwin << (c - 1);
     const size_t entries = (size_t)nwin * n;
@@ -820,6 +822,67 @@ template <> struct CurveB<Bls381Fq> { static Bls381Fq get() { Bls381Fq t = Bls38
 template <> struct CurveB<Fp2<Bls381Fq>> { static Fp2<Bls381Fq> get() { Bls381Fq f = CurveB<Bls381Fq>::get(); return {f, f}; } };
 #endif
 
+// ---- constants of the endomorphism-based subgroup tests (subgroup.hpp), computed once per process on the host
+namespace {
+// (p - 1) / d for the coordinate field's modulus, little-endian 32-bit limbs (d = 2 or 3 divides p - 1 for both curves)
+template <class B> void modulus_minus_one_over(uint32_t d, uint32_t (&out)[B::N]) {
+    uint32_t t[B::N]; for (int i = 0; i < B::N; i++) t[i] = B::Params::P[i];
+    t[0] -= 1;                                                                       // p is odd: no borrow
+    uint64_t rem = 0;
+    for (int i = B::N - 1; i >= 0; i--) { const uint64_t cur = (rem << 32) | t[i]; out[i] = (uint32_t)(cur / d); rem = cur % d; }
+}
+template <class F> Affine<F> group_generator();
+template <> Affine<Fp2<Bn254Fq>> group_generator() { Affine<Fp2<Bn254Fq>> a; memcpy(&a, Bn254G2_GEN, sizeof a); return a; }
+#if CG_WITH_BLS
+template <> Affine<Fp2<Bls381Fq>> group_generator() { Affine<Fp2<Bls381Fq>> a; memcpy(&a, Bls381G2_GEN, sizeof a); return a; }
+template <> Affine<Bls381Fq> group_generator() { Affine<Bls381Fq> a; memcpy(&a, Bls381G1_GEN, sizeof a); return a; }
+#endif
+// psi constants: xi^((p-1)/3), xi^((p-1)/2) for a D-type twist, their inverses for an M-type twist; the generator decides
+template <class B> FastSubgroup<Fp2<B>> make_psi_subgroup(const Fp2<B>& xi) {
+    uint32_t e3[B::N], e2[B::N];
+    modulus_minus_one_over<B>(3, e3); modulus_minus_one_over<B>(2, e2);
+    const Fp2<B> gx = fp_pow(xi, e3, B::N), gy = fp_pow(xi, e2, B::N);
+    const Affine<Fp2<B>> gen = group_generator<Fp2<B>>();
+    FastSubgroup<Fp2<B>> c;
+    c.psi = PsiMap<B>{gx, gy};
+    if (c.contains(gen)) return c;
+    c.psi = PsiMap<B>{fp_inverse(gx), fp_inverse(gy)};
+    if (c.contains(gen)) return c;
+    throw std::runtime_error("subgroup test constants: the generator fails both twist conventions");
+}
+template <class F> struct FastSubgroupFactory { static FastSubgroup<F> make() { return FastSubgroup<F>(); } };
+template <> struct FastSubgroupFactory<Fp2<Bn254Fq>> { static FastSubgroup<Fp2<Bn254Fq>> make() {
+    Bn254Fq one = Bn254Fq::one(), three = one + one + one, nine = three + three + three;
+    return make_psi_subgroup<Bn254Fq>(Fp2<Bn254Fq>{nine, one}); } };                 // xi = 9 + u
+#if CG_WITH_BLS
+template <> struct FastSubgroupFactory<Fp2<Bls381Fq>> { static FastSubgroup<Fp2<Bls381Fq>> make() {
+    return make_psi_subgroup<Bls381Fq>(Fp2<Bls381Fq>{Bls381Fq::one(), Bls381Fq::one()}); } };   // xi = 1 + u
+template <> struct FastSubgroupFactory<Bls381Fq> { static FastSubgroup<Bls381Fq> make() {
+    uint32_t e3[Bls381Fq::N]; modulus_minus_one_over<Bls381Fq>(3, e3);
+    const Affine<Bls381Fq> gen = group_generator<Bls381Fq>();
+    Bls381Fq g = Bls381Fq::one();
+    for (int tries = 0; tries < 64; tries++) {                                        // g^((p-1)/3) is a primitive cube root of unity unless g is a cube
+        g = g + Bls381Fq::one();
+        const Bls381Fq w = fp_pow(g, e3, Bls381Fq::N);
+        if (w == Bls381Fq::one()) continue;
+        FastSubgroup<Bls381Fq> c; c.beta = w;
+        if (c.contains(gen)) return c;
+        c.beta = w.sqr();
+        if (c.contains(gen)) return c;
+        break;
+    }
+    throw std::runtime_error("subgroup test constants: no cube root of unity makes the generator pass"); } };
+#endif
+// nullptr (and the [r]P path) when the group has no fast test, when CG_SUBGROUP_FULL is set, or when the constants could not be made
+template <class F> const FastSubgroup<F>* fast_subgroup() {
+    if (!FastSubgroup<F>::available || getenv("CG_SUBGROUP_FULL")) return nullptr;
+    static const std::pair<bool, FastSubgroup<F>> made = [] {
+        try { return std::make_pair(true, FastSubgroupFactory<F>::make()); } catch (const std::exception&) { return std::make_pair(false, FastSubgroup<F>()); }
+    }();
+    return made.first ? &made.second : nullptr;
+}
+}  // namespace
+
 // ==================================================================================================== extern "C"
 extern "C" {
 
@@ -1257,7 +1320,9 @@ int32_t cg_bases_check_subgroup(cg_ctx* ctx, const cg_bases* b, uint64_t* n_bad,
         unsigned long long* d = nullptr; unsigned long long h[2] = {0ull, ~0ull};
         HIPCHK(hip_malloc_flush((void**)&d, 16));
         HIPCHK(hipMemcpyAsync(d, h, 16, hipMemcpyHostToDevice, ctx->stream));
-        int rc = check_subgroup_launch<F, Fr>(ctx->stream, (const Affine<F>*)b->d_pts, b->n, d);
+        const FastSubgroup<F>* fast = fast_subgroup<F>();
+        int rc = fast ? check_subgroup_fast_launch<F>(ctx->stream, (const Affine<F>*)b->d_pts, b->n, *fast, d)
+                      : check_subgroup_launch<F, Fr>(ctx->stream, (const Affine<F>*)b->d_pts, b->n, d);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1667,6 +1732,7 @@ int32_t cg_point_validate(int32_t curve, int32_t group, const void* h_affine, in
         if (!limbs_below_modulus(a.x) || !limbs_below_modulus(a.y)) return 0;
         if (a.is_inf()) { *ok = 1; return 0; }
         if (a.y.sqr() != a.x.sqr() * a.x + CurveB<F>::get()) return 0;
+        if (const FastSubgroup<F>* fast = fast_subgroup<F>()) { *ok = fast->contains(a) ? 1 : 0; return 0; }
         if (!(curve == CG_BN254 && group == CG_G1)) {                                    // cofactor 1 there
             XYZZ<F> r = XYZZ<F>::infinity();
             for (int b = Fr::Params::BITS - 1; b >= 0; b--) {

@@ -201,6 +201,12 @@ int check_subgroup_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, unsi
     return 0;
 }
 template <class F>
+int check_subgroup_fast_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, const FastSubgroup<F>& c, unsigned long long* d_counters) {
+    if (n) hipLaunchKernelGGL((k_check_subgroup_fast<F>), dim3((unsigned)std::min<size_t>((n + 127) / 128, 8192)), dim3(128), 0, st, d_pts, n, c, d_counters, d_counters + 1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+template <class F>
 int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c) {
     if (n) hipLaunchKernelGGL((k_precompute_window<F>), dim3(grid_for(n)), dim3(256), 0, st, d_src, d_dst, n, c);
     HIPCHK(hipGetLastError());
@@ -231,6 +237,7 @@ int fixed_base_mul_launch(hipStream_t st, const Affine<F>& g, const Fr* d_scalar
     template int precompute_window_launch<F>(hipStream_t, const Affine<F>*, Affine<F>*, size_t, int);                      \
     template int check_on_curve_launch<F>(hipStream_t, const Affine<F>*, size_t, const F&, unsigned long long*);           \
     template int check_subgroup_launch<F, Fr>(hipStream_t, const Affine<F>*, size_t, unsigned long long*);                 \
+    template int check_subgroup_fast_launch<F>(hipStream_t, const Affine<F>*, size_t, const FastSubgroup<F>&, unsigned long long*); \
     template int pack_bases_launch<F>(hipStream_t, const uint8_t*, size_t, size_t, long, Affine<F>*);                      \
     template int gather_points_launch<F>(hipStream_t, Affine<F>*, const Affine<F>*, const uint32_t*, size_t);              \
     template int synth_points_launch<F>(hipStream_t, const XYZZ<F>*, const XYZZ<F>*, int, size_t, Affine<F>*);             \

@@ -18,6 +18,7 @@
 #pragma once
 #include <type_traits>
 #include "common.hpp"
+#include "subgroup.hpp"
 #include "curve.hpp"
 #include "lazy29.hpp"
 #include "vec_kernels.hpp"
@@ -725,6 +726,15 @@ __global__ void __launch_bounds__(256) k_check_on_curve(const Affine<F>* __restr
         if (p.is_inf()) continue;
         F lhs = p.y.sqr(), rhs = p.x.sqr() * p.x + b;
         if (lhs != rhs) { atomicAdd(n_bad, 1ull); atomicMin(first_bad, (unsigned long long)i); }
+    }
+}
+
+// The same predicate through the curve's endomorphisms (subgroup.hpp): 4 to 16 times fewer group operations than [r]P.
+template <class F>
+__global__ void __launch_bounds__(128) k_check_subgroup_fast(const Affine<F>* __restrict__ pts, size_t n, FastSubgroup<F> c, unsigned long long* __restrict__ n_bad, unsigned long long* __restrict__ first_bad) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const Affine<F> p = ld_struct(pts + i);
+        if (!c.contains(p)) { atomicAdd(n_bad, 1ull); atomicMin(first_bad, (unsigned long long)i); }
     }
 }
 

@@ -573,32 +573,40 @@ def _fp2_sqrt(a, p):
     return None
 
 
-def off_subgroup_point(curve, group):
-    """an affine point satisfying the curve equation, found by incrementing x; lies outside the r-torsion with overwhelming probability"""
+def off_subgroup_point(curve, group, skip=0):
+    """an affine point satisfying the curve equation, found by incrementing x (the skip-th one found); lies outside the r-torsion with
+    overwhelming probability"""
     p = _Q[curve]
     mont = lambda v: orc.from_dec(curve, FQ, str(v % p))
     if group == G1:
         b = 3 if curve == BN254 else 4
-        for x in range(1, 100):
+        for x in range(1, 100 + 4 * skip):
             y = _fp_sqrt((x * x * x + b) % p, p)
-            if y is not None: return np.concatenate([mont(x), mont(y)])
+            if y is not None:
+                if skip: skip -= 1; continue
+                return np.concatenate([mont(x), mont(y)])
     else:
         if curve == BN254:
             inv = pow(82, -1, p)                                 # 3 / (9 + u) = 3 (9 - u) / 82
             b = (27 * inv % p, -3 * inv % p)
         else:
             b = (4, 4)
-        for k in range(1, 100):
+        for k in range(1, 100 + 4 * skip):
             x = (k, 1)
             x3 = _fp2_mul(_fp2_mul(x, x, p), x, p)
             y = _fp2_sqrt(((x3[0] + b[0]) % p, (x3[1] + b[1]) % p), p)
-            if y is not None: return np.concatenate([mont(x[0]), mont(x[1]), mont(y[0]), mont(y[1])])
+            if y is not None:
+                if skip: skip -= 1; continue
+                return np.concatenate([mont(x[0]), mont(x[1]), mont(y[0]), mont(y[1])])
     raise AssertionError("no point found")
 
 
 @pytest.mark.parametrize("curve_name,group", [("bn254", G2), ("bls12_381", G1), ("bls12_381", G2), ("bn254", G1)])
-def test_bases_subgroup_check(ctx, curve_name, group):
-    """device-side subgroup validation (is_in_correct_subgroup_assuming_on_curve, circom-types/src/traits.rs:121,151)"""
+@pytest.mark.parametrize("full", [False, True])
+def test_bases_subgroup_check(ctx, curve_name, group, full, monkeypatch):
+    """device-side subgroup validation (is_in_correct_subgroup_assuming_on_curve, circom-types/src/traits.rs:121,151): through the
+    curve's endomorphisms (csrc/subgroup.hpp, the default) and as [r]P (CG_SUBGROUP_FULL=1)"""
+    if full: monkeypatch.setenv("CG_SUBGROUP_FULL", "1")
     curve = {"bn254": BN254, "bls12_381": BLS12_381}[curve_name]
     z = orc.ZKey(curve, os.path.join(GOLDEN, "groth16", curve_name, "poseidon", "circuit.zkey"))
     pts = z.points("a_query" if group == G1 else "b_g2_query")
@@ -617,6 +625,12 @@ def test_bases_subgroup_check(ctx, curve_name, group):
     bases = ctx.register_bases(curve, group, tampered)
     assert ctx.check_on_curve(bases) == (0, None)                # still on the curve ...
     assert ctx.check_subgroup(bases) == (1, k)                   # ... but caught by the subgroup pass
+    bases.release()
+    # a table of nothing but points outside the subgroup, with two valid ones among them: every bad one is counted
+    many = np.stack([off_subgroup_point(curve, group, skip=i) for i in range(24)])
+    many[5] = pts[3]; many[17] = pts[9]
+    bases = ctx.register_bases(curve, group, many)
+    assert ctx.check_on_curve(bases) == (0, None) and ctx.check_subgroup(bases) == (22, 0)
     bases.release()
 
 

@@ -266,3 +266,77 @@ def test_received_points_and_scalars_are_validated_like_a_deserialiser(curve_nam
     assert cg.fr_is_canonical(curve, ok)
     ok[3] = np.uint64(0xFFFFFFFFFFFFFFFF)
     assert not cg.fr_is_canonical(curve, ok)
+
+
+def test_endomorphism_subgroup_tests_are_sufficient_for_these_curves():
+    """csrc/subgroup.hpp: a curve point P with f(psi)P = 0 is killed by Res(f, X^2 - tX + p) because psi satisfies X^2 - tX + p on the
+    whole curve; the test is sufficient when that integer is a multiple of r and coprime to the cofactor.  Recomputed here with plain
+    integers for the three tests (BN254 G2 four-term relation, BLS12-381 G2 psi = [x], BLS12-381 G1 sigma = [-x^2])."""
+    from fractions import Fraction
+    from math import gcd
+
+    def det(m):
+        m = [[Fraction(v) for v in row] for row in m]; d = Fraction(1)
+        for i in range(len(m)):
+            piv = next((j for j in range(i, len(m)) if m[j][i] != 0), None)
+            if piv is None: return 0
+            if piv != i: m[i], m[piv] = m[piv], m[i]; d = -d
+            d *= m[i][i]
+            for j in range(i + 1, len(m)):
+                f = m[j][i] / m[i][i]
+                for k in range(i, len(m)): m[j][k] -= f * m[i][k]
+        assert d.denominator == 1
+        return int(d)
+
+    def resultant(f, g):                                     # coefficients, highest degree first (Sylvester matrix)
+        mf, mg = len(f) - 1, len(g) - 1
+        return det([[0] * i + f + [0] * (mg - 1 - i) for i in range(mg)] + [[0] * i + g + [0] * (mf - 1 - i) for i in range(mf)])
+    # BN254: p, r, t from the family's polynomials; #E'(Fp2) = r (p - 1 + t)
+    x = 4965661367192848881
+    p = 36 * x**4 + 36 * x**3 + 24 * x**2 + 6 * x + 1; r = 36 * x**4 + 36 * x**3 + 18 * x**2 + 6 * x + 1; t = 6 * x * x + 1
+    assert p == 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    assert r == 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    h2 = p - 1 + t
+    res = resultant([-2 * x, x, x, x + 1], [1, -t, p])       # (x + 1) + x psi + x psi^2 - 2x psi^3
+    assert res % r == 0 and gcd(abs(res), h2) == 1 and h2 % r != 0
+    # BLS12-381
+    x = -0xd201000000010000
+    r = x**4 - x**2 + 1; p = (x - 1)**2 * r // 3 + x; t = x + 1
+    assert p == 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    assert r == 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    num = x**8 - 4 * x**7 + 5 * x**6 - 4 * x**4 + 6 * x**3 - 4 * x**2 - 4 * x + 13
+    assert num % 9 == 0
+    h2 = num // 9                                            # cofactor of G2 in E'(Fp2)
+    res = resultant([1, -x], [1, -t, p])                     # psi - x
+    assert res % r == 0 and gcd(abs(res), h2) == 1 and h2 % r != 0
+    h1 = (x - 1)**2 // 3
+    assert (p + 1 - t) == h1 * r
+    res = resultant([1, x * x], [1, 1, 1])                   # sigma + x^2, sigma^2 + sigma + 1 = 0
+    assert abs(res) == r                                     # [r]P = 0 outright
+
+
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_endomorphism_subgroup_tests_agree_with_r_times_p(curve_name, monkeypatch):
+    """the fast membership tests and [r]P give the same verdict on multiples of the generator, on curve points outside the subgroup, and on
+    sums of both (host code, the same functions the device kernel runs)"""
+    from test_gpu_parity import off_subgroup_point
+    from oracle_lib import G1, G2
+    ensure_built()
+    curve = BN254 if curve_name == "bn254" else BLS12_381
+    rng = np.random.default_rng(77)
+    for group in (G1, G2):
+        gen = cg.point_generator(curve, group)
+        cases = []
+        for k in orc.random_field(curve, FR, 6, rng):
+            cases.append((cg.point_to_affine(curve, group, cg.point_scalar_mul(curve, group, gen, k)), True))
+        if not (curve == BN254 and group == G1):
+            for i in range(10):
+                off = off_subgroup_point(curve, group, skip=i)
+                cases.append((off, False))
+                mixed = cg.point_add(curve, group, cg.point_from_affine(curve, group, off), cg.point_scalar_mul(curve, group, gen, orc.random_field(curve, FR, 1, rng)[0]))
+                cases.append((cg.point_to_affine(curve, group, mixed), False))
+        for full in (False, True):
+            if full: monkeypatch.setenv("CG_SUBGROUP_FULL", "1")
+            else: monkeypatch.delenv("CG_SUBGROUP_FULL", raising=False)
+            for pt, want in cases:
+                assert cg.point_validate(curve, group, pt) == want
