@@ -545,5 +545,9 @@ int orc_make_synthetic(int curve, int log_m, uint64_t seed, const char* zkey_pat
     DISPATCH(curve, { make_synthetic<C>(log_m, seed, zkey_path, wtns_path, threads); });
     return 0;
 }
+int orc_make_synthetic_pub(int curve, int log_m, uint64_t seed, const char* zkey_path, const char* wtns_path, int threads, uint64_t n_public) {
+    DISPATCH(curve, { make_synthetic<C>(log_m, seed, zkey_path, wtns_path, threads, (size_t)n_public); });
+    return 0;
+}
 
 }  // extern "C"

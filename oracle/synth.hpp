@@ -3,7 +3,7 @@
 // Synthetic satisfiable R1CS + Groth16 CRS generator (SURVEY.md §8d "synthetic R1CS generator"): writes a snarkjs-format
 // `.zkey` (sections 1-9, `/root/reference/co-circom/circom-types/src/groth16/zkey.rs:139-316`) and `.wtns`
 // (`witness.rs:51-91`) so that the format readers, the witness map and all five MSMs are exercised at sizes the shipped
-// fixtures (<= 213 constraints) do not reach.  Circuit: n_public = 1, num_constraints = m - 2, n_vars = m (domain size exactly m);
+// fixtures (<= 213 constraints) do not reach.  Circuit: n_public = 1 by default (any number on request), num_constraints = m - n_public - 1, n_vars = m (domain size exactly m);
 // constraint j:  (a_j * w[j+1]) * (b_j * w[sb_j]) = w[j+2]   with sb_j <= j+1, so the witness is computed forward.
 // CRS from seeded toxic waste (tau, alpha, beta, gamma, delta), in the snarkjs conventions the reference consumes:
 //   * section 4 carries the extra rows  A[nc+i] = w_i (i <= n_public)  that the prover mirrors at groth16.rs:168-171
@@ -59,21 +59,21 @@ static inline void write_sections(const std::string& path, const char* magic, ui
 }
 
 template <class C>
-static void make_synthetic(int log_m, uint64_t seed, const std::string& zkey_path, const std::string& wtns_path, int threads) {
+static void make_synthetic(int log_m, uint64_t seed, const std::string& zkey_path, const std::string& wtns_path, int threads, size_t n_pub = 1) {
     typedef typename C::Fr Fr; typedef typename C::Fq Fq; typedef typename C::G1 G1; typedef typename C::G2 G2;
     C::init();
-    const size_t m = (size_t)1 << log_m, nc = m - 2, n_pub = 1, n_vars = m, n_inp = n_pub + 1;
-    if (log_m < 2) throw std::runtime_error("log_m must be >= 2");
+    const size_t m = (size_t)1 << log_m, n_inp = n_pub + 1, nc = m - n_inp, n_vars = m;      // n_pub public inputs (default 1): still domain size exactly m
+    if (log_m < 2 || n_pub < 1 || n_inp + 1 > m) throw std::runtime_error("log_m must be >= 2 and 1 <= n_public <= m - 2");
     XorShift rng{seed * 2654435761ull + 12345};
     auto rnd = [&] { Fr x; do { x = rand_fp<Fr>(rng); } while (x.is_zero()); return x; };
     // ---- circuit + witness
     std::vector<Fr> ca(nc), cb(nc), w(n_vars);
     std::vector<uint32_t> sb(nc);
-    w[0] = Fr::one(); w[1] = rnd();
-    for (size_t j = 0; j < nc; j++) {
+    w[0] = Fr::one(); for (size_t i = 1; i <= n_pub; i++) w[i] = rnd();
+    for (size_t j = 0; j < nc; j++) {                                        // constraint j defines w[n_pub + 1 + j] from its predecessor and an earlier signal
         ca[j] = rnd(); cb[j] = rnd();
-        sb[j] = (uint32_t)(1 + (j * 2654435761ull + 7) % (j + 1));          // in [1, j+1]
-        w[j + 2] = (ca[j] * w[j + 1]) * (cb[j] * w[sb[j]]);
+        sb[j] = (uint32_t)(1 + (j * 2654435761ull + 7) % (j + n_pub));      // in [1, j + n_pub]
+        w[j + n_pub + 1] = (ca[j] * w[j + n_pub]) * (cb[j] * w[sb[j]]);
     }
     // ---- toxic waste and Lagrange values on H
     Fr tau = rnd(), alpha = rnd(), beta = rnd(), gamma = rnd(), delta = rnd();
@@ -88,7 +88,7 @@ static void make_synthetic(int log_m, uint64_t seed, const std::string& zkey_pat
     for (size_t j = 0; j < m; j++) lag[j] = zt * minv * wpow[j] * den[j];
     // u_i = sum_j A[j][i] L_j, v_i, w_i (C matrix: C[j][j+2] = 1)
     std::vector<Fr> u(n_vars, Fr::zero()), v(n_vars, Fr::zero()), wc(n_vars, Fr::zero());
-    for (size_t j = 0; j < nc; j++) { u[j + 1] += ca[j] * lag[j]; v[sb[j]] += cb[j] * lag[j]; wc[j + 2] += lag[j]; }
+    for (size_t j = 0; j < nc; j++) { u[j + n_pub] += ca[j] * lag[j]; v[sb[j]] += cb[j] * lag[j]; wc[j + n_pub + 1] += lag[j]; }
     for (size_t i = 0; i < n_inp; i++) u[i] += lag[nc + i];
     // h exponents on the odd coset
     std::vector<Fr> hden(m), hexp(m);
@@ -125,7 +125,7 @@ static void make_synthetic(int log_m, uint64_t seed, const std::string& zkey_pat
         put32(s, (uint32_t)(2 * nc + n_inp));
         Fr r2 = Fr::from_mont_limbs(Fr::K.r2);
         auto coef = [&](uint32_t mat, uint32_t row, uint32_t sig, const Fr& val) { put32(s, mat); put32(s, row); put32(s, sig); put_mont(s, val * r2); };   // value * R^2 on disk
-        for (size_t j = 0; j < nc; j++) { coef(0, (uint32_t)j, (uint32_t)(j + 1), ca[j]); coef(1, (uint32_t)j, sb[j], cb[j]); }
+        for (size_t j = 0; j < nc; j++) { coef(0, (uint32_t)j, (uint32_t)(j + n_pub), ca[j]); coef(1, (uint32_t)j, sb[j], cb[j]); }
         for (size_t i = 0; i < n_inp; i++) coef(0, (uint32_t)(nc + i), (uint32_t)i, Fr::one());
         secs.push_back({4, s});
     }

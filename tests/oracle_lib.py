@@ -307,9 +307,12 @@ def bench_rep3_party2(curve, log_m, threads, threads_b, seed=1):
     return (t, dict(zip(names, sa))), (tb.value, dict(zip(names, sb))), bool(shared.value)
 
 
-def make_synthetic(curve, log_m, seed, zkey_path, wtns_path, threads=8):
-    """synthetic satisfiable R1CS (m - 2 constraints, 1 public input) with a valid Groth16 CRS, as .zkey + .wtns files"""
-    _chk(lib().orc_make_synthetic(curve, int(log_m), C.c_uint64(seed), zkey_path.encode(), wtns_path.encode(), int(threads)))
+def make_synthetic(curve, log_m, seed, zkey_path, wtns_path, threads=8, n_public=1):
+    """synthetic satisfiable R1CS (m - n_public - 1 constraints, n_public public inputs) with a valid Groth16 CRS, as .zkey + .wtns files"""
+    if n_public == 1:
+        _chk(lib().orc_make_synthetic(curve, int(log_m), C.c_uint64(seed), zkey_path.encode(), wtns_path.encode(), int(threads)))
+    else:
+        _chk(lib().orc_make_synthetic_pub(curve, int(log_m), C.c_uint64(seed), zkey_path.encode(), wtns_path.encode(), int(threads), C.c_uint64(int(n_public))))
 
 
 # ---- snarkjs JSON <-> packed arrays ---------------------------------------------------------------
