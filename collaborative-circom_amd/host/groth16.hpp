@@ -109,7 +109,7 @@ public:
         own.reset();
         mk.mark("aux msm enqueued");
         // Several GPUs: the witness map itself is spread over them (multidev.hpp) and every device multiplies its own rows of h
-        const bool distributed = !add_h && DistributedWitnessMap::usable(driver, dz);              // (the variant keeps the map on the primary device)
+        const bool distributed = DistributedWitnessMap::usable(driver, dz);
         std::unique_ptr<DistributedWitnessMap> dmap;
         struct HParts : DistributedH {     // the rows of h on their devices: released when prove leaves, however it leaves (after the map's own buffers)
             ~HParts() { for (auto& part : parts) for (int j = 0; j < 2; j++) if (part.h.c[j]) cg_dev_free(part.ctx, part.h.c[j]); }
@@ -121,16 +121,17 @@ public:
             dmap.reset(new DistributedWitnessMap(driver, dz, *driver.md));
             static_cast<DistributedH&>(dh) = dmap->run(dz, public_inputs, private_witness);
             mk.mark("witness map (distributed)");
-            h_msm.on = driver.ctx; h_msm.groups = {CG_G1}; h_msm.tickets.resize(1);
+            const int hk = add_h ? 1 : driver.k();                                                     // the variant's h has one component
+            h_msm.on = driver.ctx; h_msm.groups = {CG_G1}; h_msm.tickets.resize(1); h_msm.k = hk;
             for (size_t d = 0; d < dh.parts.size(); d++) {                                             // :248, rows of device d against its slice of h_query
                 const DistributedH::Part& part = dh.parts[d];
                 if (d && dmap->primary_only) break;
                 const cg_bases* tab = dmap->devs[d].dz->h; const size_t off0 = 0;
                 const void* sc[2] = {part.h.c[0], part.h.c[1]};
-                if (d == 0) CG(cg_msm_dev_begin_multi(part.ctx, 1, &tab, &off0, part.h.n, sc, driver.k(), h_msm.tickets.data()));
+                if (d == 0) CG(cg_msm_dev_begin_multi(part.ctx, 1, &tab, &off0, part.h.n, sc, hk, h_msm.tickets.data()));
                 else {
                     HipDriver::PendingMsm::Part p{part.ctx, std::vector<int32_t>(1), {nullptr, nullptr}};
-                    CG(cg_msm_dev_begin_multi(part.ctx, 1, &tab, &off0, part.h.n, sc, driver.k(), p.tickets.data()));
+                    CG(cg_msm_dev_begin_multi(part.ctx, 1, &tab, &off0, part.h.n, sc, hk, p.tickets.data()));
                     h_msm.parts.push_back(p);
                 }
             }

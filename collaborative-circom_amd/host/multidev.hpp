@@ -24,6 +24,8 @@ struct DistributedH {                          // the quotient evaluations, rows
 class DistributedWitnessMap {
 public:
     HipDriver& drv; const Curve curve; const int k;
+    const bool additive;                       // REP3 additive-quotient variant: products are not exchanged, c and h have one component
+    const int kc;                              // components of c and h
     struct Dev {
         cg_ctx* ctx = nullptr; const DeviceZKey* dz = nullptr; size_t lo = 0, n = 0;
         void* av[2] = {nullptr, nullptr}; void* bv[2] = {nullptr, nullptr};      // rows of a and b (components)
@@ -37,7 +39,7 @@ public:
     std::vector<void*> pinned;                 // page-locked staging released at the end
 
     DistributedWitnessMap(HipDriver& d, const DeviceZKey& dz0, const MultiDevice& md)
-        : drv(d), curve(d.curve), k(d.k()), primary_only(getenv("CGH_EMULATE_PRIMARY_ONLY") != nullptr) {
+        : drv(d), curve(d.curve), k(d.k()), additive(d.additive_h && d.mode == Mode::Rep3), kc(additive ? 1 : d.k()), primary_only(getenv("CGH_EMULATE_PRIMARY_ONLY") != nullptr) {
         Dev p; p.ctx = d.ctx; p.dz = &dz0; p.lo = dz0.h_lo; p.n = dz0.h_n; devs.push_back(p);
         for (const WorkerDevice& w : md.workers) { Dev x; x.ctx = w.chain ? w.chain : w.ctx; x.dz = w.dz; x.lo = w.dz->h_lo; x.n = w.dz->h_n; devs.push_back(x); }
     }
@@ -98,13 +100,13 @@ public:
         upload_masks(mask, m);
         for (size_t d = 0; d < devs.size(); d++) {
             Dev& D = devs[d];
-            D.prod = dalloc(D, D.n * 32); D.recv = k == 2 ? dalloc(D, D.n * 32) : nullptr;
+            D.prod = dalloc(D, D.n * 32); D.recv = kc == 2 ? dalloc(D, D.n * 32) : nullptr;
             if (skip(d) || !D.n) continue;
             if (drv.mode == Mode::Plain) { CG(cg_vec_mul_dev(D.ctx, curve.id, D.prod, D.av[0], D.bv[0], D.n)); continue; }
             if (D.up_tk >= 0) CG(cg_copy_fence(D.ctx, D.up_tk));
             CG(cg_vec_rep3_mul_local_dev(D.ctx, curve.id, D.prod, D.av[0], D.av[1], D.bv[0], D.bv[1], mask[d], D.n));
         }
-        if (drv.mode != Mode::Rep3) return;
+        if (drv.mode != Mode::Rep3 || additive) return;                            // (variant: the masked local products are the result)
         const bool async = m >= drv.XCHG_ASYNC_MIN;
         const size_t ch = async ? HipDriver::xchg_chunk(m) : m, nch = (m + ch - 1) / ch;
         const int S = async ? HipDriver::XCHG_SLOTS : 1, P = async ? S - 1 : 1;
@@ -183,7 +185,7 @@ public:
         for (int j = 0; j < k; j++) { P0.owned.push_back(a.c[j]); P0.owned.push_back(b.c[j]); }
         drv.clone_public_into(a, num_constraints, public_inputs, dz.pub_dev);
         // whole vectors to their owners (vector index: a components 0..k-1, b components k..2k-1, c components 2k..3k-1)
-        std::vector<void*> vec((size_t)3 * k, nullptr);
+        std::vector<void*> vec((size_t)2 * k + kc, nullptr);
         for (int j = 0; j < k; j++) { vec[j] = a.c[j]; vec[k + j] = b.c[j]; }
         for (int v = 0; v < 2 * k; v++) {
             const size_t o = owner(v);
@@ -207,7 +209,7 @@ public:
         // c: rows to the owners of its components, pipelines there (:194-200)
         std::vector<void*> crow_a(nd), crow_b(nd);
         for (size_t d = 0; d < nd; d++) { crow_a[d] = devs[d].prod; crow_b[d] = devs[d].recv; }
-        for (int j = 0; j < k; j++) {
+        for (int j = 0; j < kc; j++) {
             Dev& O = devs[owner(2 * k + j)];
             vec[2 * k + j] = dalloc(O, m * 32);
             for (size_t d = 0; d < nd; d++) {
@@ -215,7 +217,7 @@ public:
                 if (D.n) CG(cg_dev_copy_peer(O.ctx, (uint8_t*)vec[2 * k + j] + D.lo * 32, D.ctx, j == 0 ? crow_a[d] : crow_b[d], D.n * 32));
             }
         }
-        mul_rows_begin_pipelines(vec, 2 * k, 3 * k, dom);
+        mul_rows_begin_pipelines(vec, 2 * k, 2 * k + kc, dom);
         // rows of the transformed a and b for the second product (:190)
         for (size_t d = 0; d < nd; d++) {
             Dev& D = devs[d];
@@ -230,8 +232,8 @@ public:
         DistributedH out;
         for (size_t d = 0; d < nd; d++) {
             Dev& D = devs[d];
-            ShareVec h; h.n = D.n; h.c[0] = D.prod; h.c[1] = k == 2 ? D.recv : nullptr;
-            for (int j = 0; j < k; j++) {
+            ShareVec h; h.n = D.n; h.c[0] = D.prod; h.c[1] = kc == 2 ? D.recv : nullptr;
+            for (int j = 0; j < kc; j++) {
                 void* crow = dalloc(D, D.n * 32);
                 CG(cg_dev_copy_peer(D.ctx, crow, devs[owner(2 * k + j)].ctx, (const uint8_t*)vec[2 * k + j] + D.lo * 32, D.n * 32));
                 if (!skip(d) && D.n) CG(cg_vec_sub_dev(D.ctx, curve.id, h.c[j], h.c[j], crow, D.n));
