@@ -805,3 +805,31 @@ def test_msm_randomised_against_oracle():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_msm.py"), "20", "11"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "agree with the oracle" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("curve_name,group", [("bn254", G2), ("bls12_381", G1), ("bls12_381", G2)])
+def test_subgroup_check_fast_and_full_agree_on_mixed_tables(ctx, curve_name, group, monkeypatch):
+    """a table of 384 curve points — multiples of the generator, points outside the subgroup, and sums of both — gets the same verdict
+    from the endomorphism-based kernel and from [r]P, and the verdict is the expected one (count and first index)"""
+    curve = {"bn254": BN254, "bls12_381": BLS12_381}[curve_name]
+    rng = np.random.default_rng(5150)
+    gen = cg.point_generator(curve, group)
+    offs = [cg.point_from_affine(curve, group, off_subgroup_point(curve, group, skip=i)) for i in range(8)]
+    pts, bad = [], []
+    for i, k in enumerate(orc.random_field(curve, FR, 384, rng)):
+        p = cg.point_scalar_mul(curve, group, gen, k)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:                                                            # valid + a point outside the subgroup: outside
+            p = cg.point_add(curve, group, p, offs[i % 8]); bad.append(i)
+        elif kind == 1 and i % 3 == 0:                                          # a small multiple of a point outside the subgroup: outside
+            p = cg.point_scalar_mul(curve, group, offs[i % 8], orc.from_dec(curve, FR, str(2 + i % 5))); bad.append(i)
+        pts.append(cg.point_to_affine(curve, group, p))
+    pts = np.stack(pts)
+    want = (len(bad), bad[0])
+    for full in (False, True):
+        if full: monkeypatch.setenv("CG_SUBGROUP_FULL", "1")
+        else: monkeypatch.delenv("CG_SUBGROUP_FULL", raising=False)
+        bases = ctx.register_bases(curve, group, pts)
+        assert ctx.check_on_curve(bases) == (0, None)
+        assert ctx.check_subgroup(bases) == want
+        bases.release()
