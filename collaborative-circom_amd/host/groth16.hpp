@@ -114,7 +114,8 @@ public:
         struct HParts : DistributedH {     // the rows of h on their devices: released when prove leaves, however it leaves (after the map's own buffers)
             ~HParts() { for (auto& part : parts) for (int j = 0; j < 2; j++) if (part.h.c[j]) cg_dev_free(part.ctx, part.h.c[j]); }
         } dh;
-        ShareVec h;
+        VecGuard hg(driver);               // the quotient vector is released when prove leaves, however it leaves (a failing network round, invalid data)
+        ShareVec& h = hg.v;
         HipDriver::PendingMsm h_msm;
         if (distributed) {
             if (h_out) throw std::runtime_error("the quotient vector of a multi-device proof stays distributed (h_out is a single-device option)");
@@ -192,7 +193,7 @@ public:
         mk.mark("open");
         driver.msm_release(aux_msm); driver.msm_release(h_msm);
         dmap.reset();
-        if (h_out) *h_out = h; else driver.free_vec(h);
+        if (h_out) { *h_out = h; h = ShareVec(); }                                                      // handed to the caller
         return Proof{pt_to_affine(c, g_a_opened), pt_to_affine(c, opened.second), pt_to_affine(c, opened.first)};   // :319-325
     }
 };
