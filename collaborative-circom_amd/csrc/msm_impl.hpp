@@ -208,7 +208,8 @@ int check_subgroup_fast_launch(hipStream_t st, const Affine<F>* d_pts, size_t n,
 }
 template <class F>
 int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c) {
-    if (n) hipLaunchKernelGGL((k_precompute_window<F>), dim3(grid_for(n)), dim3(256), 0, st, d_src, d_dst, n, c);
+    constexpr int K = sizeof(F) >= 64 ? 2 : 4;                     // points per lane sharing one inversion (G2 coordinates are twice as wide)
+    if (n) hipLaunchKernelGGL((k_precompute_window<F, K>), dim3((unsigned)std::min<size_t>(((n + K - 1) / K + 255) / 256, 65535)), dim3(256), 0, st, d_src, d_dst, n, c);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -757,12 +757,32 @@ __global__ void __launch_bounds__(128) k_check_subgroup(const Affine<F>* __restr
 }
 
 // Per-window precomputed tables: dst[i] = 2^c * src[i] in affine form (one inversion per point; run once per zkey table).
-template <class F>
+// The conversion back to affine costs one field inversion (~380 products by Fermat, twice the c doublings): a lane takes K points a grid
+// stride apart and inverts the product of their zzz once (Montgomery's trick: 3 products per point + one inversion per K points).
+template <class F, int K>
 __global__ void __launch_bounds__(256) k_precompute_window(const Affine<F>* __restrict__ src, Affine<F>* __restrict__ dst, size_t n, int c) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        XYZZ<F> a = XYZZ<F>::from_affine(ld_struct(src + i));
-        for (int k = 0; k < c; k++) a = xyzz_dbl(a);
-        st_struct(dst + i, xyzz_to_affine(a));
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += (size_t)K * stride) {
+        XYZZ<F> a[K]; F pre[K];
+        F run = F::one();
+        _Pragma("unroll") for (int j = 0; j < K; j++) {
+            const size_t i = i0 + (size_t)j * stride;
+            a[j] = i < n ? XYZZ<F>::from_affine(ld_struct(src + i)) : XYZZ<F>::infinity();
+            for (int k = 0; k < c; k++) a[j] = xyzz_dbl(a[j]);
+            pre[j] = run;
+            if (!a[j].is_inf()) run = run * a[j].zzz;
+        }
+        F inv = fp_inverse(run);                                   // 1 / (product of the finite points' zzz)
+        _Pragma("unroll") for (int j = K - 1; j >= 0; j--) {
+            const size_t i = i0 + (size_t)j * stride;
+            if (i >= n) continue;
+            if (a[j].is_inf()) { st_struct(dst + i, Affine<F>::infinity()); continue; }
+            const F izzz = inv * pre[j];                           // 1 / zzz_j
+            inv = inv * a[j].zzz;
+            const F iz = izzz * a[j].zz;                           // zz / zzz = 1 / z
+            const F izz = iz.sqr();
+            st_struct(dst + i, Affine<F>{a[j].x * izz, a[j].y * izzz});
+        }
     }
 }
 
