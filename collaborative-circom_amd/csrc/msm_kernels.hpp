@@ -229,6 +229,30 @@ __device__ __attribute__((noinline)) XYZZL<F> bk_dbl(const XYZZL<F>& a) {
     r.c[3] = L::mul(W, a.c[3]);
     return r;
 }
+// bk_add_inl: the same addition inlined into its caller.  Out of line, both operands and the result travel through scratch memory
+// (3 x 144 / 288 bytes per call and lane): in the reduction kernels, whose lanes run short serial chains of additions at one wave
+// per SIMD, those round trips are on the critical path.
+template <class F>
+__device__ __forceinline__ XYZZL<F> bk_add_inl(const XYZZL<F>& a, const XYZZL<F>& b) {
+    typedef typename LazyOf<F>::type L;
+    if (bk_is_inf(a)) return b;
+    if (bk_is_inf(b)) return a;
+    L U1 = L::mul(a.c[0], b.c[2]), S1 = L::mul(a.c[1], b.c[3]);
+    L P = L::mul(b.c[0], a.c[2]) - U1, R = L::mul(b.c[1], a.c[3]) - S1;
+    if (L::is_zero_mod_p(P.norm())) {
+        if (L::is_zero_mod_p(R.norm())) return bk_dbl(a);
+        return bk_inf<XYZZL<F>>();
+    }
+    L PP = L::sqr(P), PPP = L::mul(P, PP), Q = L::mul(U1, PP);
+    L X3 = (L::sqr(R) - PPP - Q.dbl()).norm();
+    XYZZL<F> r;
+    r.c[0] = X3;
+    r.c[1] = L::mul_sub(R, Q - X3, S1, PPP);
+    r.c[2] = L::mul(L::mul(a.c[2], b.c[2]), PP);
+    r.c[3] = L::mul(L::mul(a.c[3], b.c[3]), PPP);
+    return r;
+}
+template <class F> __device__ __forceinline__ XYZZ<F> bk_add_inl(const XYZZ<F>& a, const XYZZ<F>& b) { return xyzz_add(a, b); }
 template <class F>
 __device__ __attribute__((noinline)) XYZZL<F> bk_add(const XYZZL<F>& a, const XYZZL<F>& b) {
     typedef typename LazyOf<F>::type L;
@@ -482,7 +506,7 @@ __global__ void __launch_bounds__(64) k_msm_merge_direct(B* __restrict__ buckets
     const uint32_t q0 = first / chunk_len + 1, q1 = last / chunk_len;     // chunks that continue it
     if (q0 > q1 || q1 - q0 >= MERGE_DIRECT_MAX || q1 >= nchunks) return;
     B acc = ld_struct(buckets + b);
-    for (uint32_t q = q0; q <= q1; q++) { acc = bk_add(acc, ld_struct(cont + q)); cont_bucket[q] = 0xffffffffu; }
+    for (uint32_t q = q0; q <= q1; q++) { acc = bk_add_inl(acc, ld_struct(cont + q)); cont_bucket[q] = 0xffffffffu; }
     st_struct(buckets + b, acc);
 }
 constexpr uint32_t MERGE_GROUP = 64;
@@ -629,11 +653,11 @@ __global__ void __launch_bounds__(256) k_msm_grid_partial(const B* __restrict__ 
     {   // columns: lane = (row quarter, column); RPQ rows each, then 4 -> 1 through LDS
         const uint32_t col = t & 63u, rq = t >> 6;
         B acc = ld_struct(tile + (size_t)(rq * RPQ) * L + col);
-        for (uint32_t i = 1; i < RPQ; i++) acc = bk_add(acc, ld_struct(tile + (size_t)(rq * RPQ + i) * L + col));
+        for (uint32_t i = 1; i < RPQ; i++) acc = bk_add_inl(acc, ld_struct(tile + (size_t)(rq * RPQ + i) * L + col));
         sh[t] = acc;
         __syncthreads();
         for (int off = 128; off >= 64; off >>= 1) {
-            if ((int)t < off) acc = bk_add(sh[t], sh[t + off]);
+            if ((int)t < off) acc = bk_add_inl(sh[t], sh[t + off]);
             __syncthreads();
             if ((int)t < off) sh[t] = acc;
             __syncthreads();
@@ -645,11 +669,11 @@ __global__ void __launch_bounds__(256) k_msm_grid_partial(const B* __restrict__ 
         const uint32_t row = t / SEGS, seg = t % SEGS;
         const B* src = tile + (size_t)row * L + seg * CPS;
         B acc = ld_struct(src);
-        for (uint32_t i = 1; i < CPS; i++) acc = bk_add(acc, ld_struct(src + i));
+        for (uint32_t i = 1; i < CPS; i++) acc = bk_add_inl(acc, ld_struct(src + i));
         sh[t] = acc;
         __syncthreads();
         for (uint32_t off = SEGS / 2; off >= 1; off >>= 1) {
-            if (seg < off) acc = bk_add(sh[t], sh[t + off]);
+            if (seg < off) acc = bk_add_inl(sh[t], sh[t + off]);
             __syncthreads();
             if (seg < off) sh[t] = acc;
             __syncthreads();
@@ -673,7 +697,7 @@ __global__ void __launch_bounds__(256) k_msm_grid_bitsum(const B* __restrict__ c
             const uint32_t e = (g * 256u + t) * ITEMS + i;
             if (e >= nrb * half) break;
             const uint32_t w = nth_with_bit(e % half, k);
-            if (w <= L) acc = bk_add(acc, ld_struct(colpart + (size_t)(e / half) * L + (w - 1)));
+            if (w <= L) acc = bk_add_inl(acc, ld_struct(colpart + (size_t)(e / half) * L + (w - 1)));
         }
     } else {                                                  // row side: element (j, cb), weight = row = j-th value with bit k, < H
         const uint32_t idx = blockIdx.x - njc, k = idx / gr, g = idx % gr;
@@ -681,13 +705,13 @@ __global__ void __launch_bounds__(256) k_msm_grid_bitsum(const B* __restrict__ c
             const uint32_t e = (g * 256u + t) * ITEMS + i;
             if (e >= (H / 2) * ncb) break;
             const uint32_t w = nth_with_bit(e / ncb, k);
-            if (w < H) acc = bk_add(acc, ld_struct(rowpart + (size_t)w * ncb + (e % ncb)));
+            if (w < H) acc = bk_add_inl(acc, ld_struct(rowpart + (size_t)w * ncb + (e % ncb)));
         }
     }
     sh[t] = acc;
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
-        if ((int)t < off) acc = bk_add(sh[t], sh[t + off]);
+        if ((int)t < off) acc = bk_add_inl(sh[t], sh[t + off]);
         __syncthreads();
         if ((int)t < off) sh[t] = acc;
         __syncthreads();
