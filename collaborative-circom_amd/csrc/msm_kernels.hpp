@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(64) k_msm_merge_cont_l1(B* __restrict__ cont, 
     const uint32_t next_head = (q / MERGE_GROUP + 1) * MERGE_GROUP;           // first aligned position after q
     if (q + 1 >= nchunks || q + 1 >= next_head || cont_bucket[q + 1] != b) return;   // single piece: nothing to fold
     B acc = ld_struct(cont + q);
-    for (uint32_t r = q + 1; r < nchunks && r < next_head && cont_bucket[r] == b; r++) acc = bk_add(acc, ld_struct(cont + r));
+    for (uint32_t r = q + 1; r < nchunks && r < next_head && cont_bucket[r] == b; r++) acc = bk_add_inl(acc, ld_struct(cont + r));
     st_struct(cont + q, acc);                                                   // only group heads are written; nobody else reads them in this launch
 }
 template <class B>
@@ -531,8 +531,8 @@ __global__ void __launch_bounds__(64) k_msm_merge_cont(B* __restrict__ buckets, 
     const uint32_t b = cont_bucket[q];
     if (b == 0xffffffffu) return;
     if (q > 0 && cont_bucket[q - 1] == b) return;
-    B acc = bk_add(ld_struct(buckets + b), ld_struct(cont + q));
-    for (uint32_t r = (q / MERGE_GROUP + 1) * MERGE_GROUP; r < nchunks && cont_bucket[r] == b; r += MERGE_GROUP) acc = bk_add(acc, ld_struct(cont + r));
+    B acc = bk_add_inl(ld_struct(buckets + b), ld_struct(cont + q));
+    for (uint32_t r = (q / MERGE_GROUP + 1) * MERGE_GROUP; r < nchunks && cont_bucket[r] == b; r += MERGE_GROUP) acc = bk_add_inl(acc, ld_struct(cont + r));
     st_struct(buckets + b, acc);
 }
 
@@ -558,8 +558,8 @@ __global__ void __launch_bounds__(64) k_msm_reduce_segments(const B* __restrict_
     const B* Bk = buckets + (size_t)w * nb;
     B run = bk_inf<B>(), acc = bk_inf<B>();
     for (uint32_t b = lo + seg_len; b-- > lo;) {
-        run = bk_add(run, ld_struct(Bk + b));
-        acc = bk_add(acc, run);
+        run = bk_add_inl(run, ld_struct(Bk + b));
+        acc = bk_add_inl(acc, run);
     }
     acc = bk_add(acc, bk_mul_small(run, lo));
     st_struct(partials + t, acc);
@@ -572,11 +572,11 @@ __global__ void __launch_bounds__(THREADS) k_msm_window_sum(const B* __restrict_
     B* sh = reinterpret_cast<B*>(lds_raw);
     const B* P = partials + (size_t)blockIdx.x * segs;
     B acc = bk_inf<B>();
-    for (uint32_t s = threadIdx.x; s < segs; s += THREADS) acc = bk_add(acc, ld_struct(P + s));
+    for (uint32_t s = threadIdx.x; s < segs; s += THREADS) acc = bk_add_inl(acc, ld_struct(P + s));
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int off = THREADS / 2; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off) { acc = bk_add(sh[threadIdx.x], sh[threadIdx.x + off]); }
+        if ((int)threadIdx.x < off) { acc = bk_add_inl(sh[threadIdx.x], sh[threadIdx.x + off]); }
         __syncthreads();
         if ((int)threadIdx.x < off) sh[threadIdx.x] = acc;
         __syncthreads();
@@ -601,12 +601,12 @@ __global__ void __launch_bounds__(256) k_msm_bitsum_partial(const B* __restrict_
     for (uint32_t i = 0; i < (uint32_t)ITEMS; i++) {
         const uint32_t j = j0 + i;                                            // j-th weight with bit k set
         const uint64_t w = (((uint64_t)j >> k) << (k + 1)) | ((uint64_t)1 << k) | (j & (((uint32_t)1 << k) - 1u));
-        if (w >= 1 && w <= nb) acc = bk_add(acc, ld_struct(buckets + (w - 1)));
+        if (w >= 1 && w <= nb) acc = bk_add_inl(acc, ld_struct(buckets + (w - 1)));
     }
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off) acc = bk_add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        if ((int)threadIdx.x < off) acc = bk_add_inl(sh[threadIdx.x], sh[threadIdx.x + off]);
         __syncthreads();
         if ((int)threadIdx.x < off) sh[threadIdx.x] = acc;
         __syncthreads();
@@ -619,11 +619,11 @@ __global__ void __launch_bounds__(64) k_msm_bitsum_final(const B* __restrict__ p
     B* sh = reinterpret_cast<B*>(lds_raw);
     const B* P = partials + (size_t)blockIdx.x * groups;
     B acc = bk_inf<B>();
-    for (uint32_t s = threadIdx.x; s < groups; s += 64) acc = bk_add(acc, ld_struct(P + s));
+    for (uint32_t s = threadIdx.x; s < groups; s += 64) acc = bk_add_inl(acc, ld_struct(P + s));
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int off = 32; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off) acc = bk_add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        if ((int)threadIdx.x < off) acc = bk_add_inl(sh[threadIdx.x], sh[threadIdx.x + off]);
         __syncthreads();
         if ((int)threadIdx.x < off) sh[threadIdx.x] = acc;
         __syncthreads();
