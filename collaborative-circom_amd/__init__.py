@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "cg_dev_alloc", "cg_dev_free", "cg_dev_upload", "cg_dev_download", "cg_dev_memset_zero",
     "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute", "cg_bases_check_on_curve", "cg_bases_check_subgroup",
     "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_chunk", "cg_msm_scalars_after", "cg_msm_set_scatter_capacity",
-    "cg_ntt", "cg_ntt_dev", "cg_ntt_coset_pair_dev",
+    "cg_ntt", "cg_ntt_dev", "cg_ntt_coset_pair_dev", "cg_chacha12_fr_rand_dev",
     "cg_host_alloc", "cg_host_free", "cg_host_is_pinned", "cg_dev_download_begin", "cg_dev_upload_begin", "cg_copy_wait", "cg_copy_fence",
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev", "cg_vec_affine_dev", "cg_vec_fill_dev", "cg_vec_gather_strided_dev", "cg_vec_lincomb_dev", "cg_vec_prefix_prod_dev", "cg_vec_prefix_sum_dev", "cg_vec_inverse_dev",
     "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
@@ -196,6 +196,13 @@ class Context:
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)
         return DevBuf(self, max(arr.nbytes, 16)).upload(arr)
+
+    # ---- Rep3Rand's O(n) draws on the device (cg_chacha12_fr_rand_dev)
+    def chacha12_fr_rand(self, curve, seed, word_pos, n):
+        """n x F::rand over ChaCha12Rng::from_seed(seed) positioned at word_pos: (DevBuf of n x 32 B, word position afterwards)"""
+        buf = self.alloc(max(n * 32, 16)); after = C.c_uint64(0)
+        _chk(load().cg_chacha12_fr_rand_dev(self.h, curve, bytes(seed), C.c_uint64(word_pos), C.c_size_t(n), C.c_void_p(buf.ptr), C.byref(after)))
+        return buf, after.value
 
     # ---- page-locked staging + asynchronous copies (exchange chunks move under the compute)
     def host_alloc(self, shape, dtype=np.uint64):
@@ -630,6 +637,38 @@ class StreamRand:
         if self.h: load_host().cgh_stream_rand_destroy(self.h); self.h = None
 
 
+_CH_STATE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64))
+_CH_SETPOS = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64)
+
+
+class Rep3ChaChaTable(C.Structure):
+    """cgh_rep3_chacha: seeds and word positions of Rep3Rand's two ChaCha12 generators, so that the masking vectors are drawn on the GPU"""
+    _fields_ = [("user", C.c_void_p), ("get_state", _CH_STATE), ("set_word_pos", _CH_SETPOS)]
+
+
+class ChaChaRand:
+    """Rep3Rand over two ChaCha12 generators (cgh_chacha_rand_create): .table = the O(1) / host callbacks, .streams = the generator description"""
+
+    def __init__(self, curve, seed1, seed2):
+        self.h = C.c_void_p(); self.table = Rep3RandTable(); self.streams = Rep3ChaChaTable()
+        _hchk(load_host().cgh_chacha_rand_create(curve, bytes(seed1), bytes(seed2), C.byref(self.h), C.byref(self.table), C.byref(self.streams)))
+
+    def positions(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _hchk(load_host().cgh_chacha_rand_positions(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self.h: load_host().cgh_chacha_rand_destroy(self.h); self.h = None
+
+
+def chacha12_fr_rand_host(curve, seed, word_pos, n):
+    """n x F::rand over ChaCha12Rng::from_seed(seed) at word_pos, on the host (one thread): (n x 4 limbs, word position afterwards)"""
+    out = np.zeros((n, 4), dtype=np.uint64); after = C.c_uint64(0)
+    _hchk(load_host().cgh_chacha12_fr_rand_host(curve, bytes(seed), C.c_uint64(word_pos), C.c_size_t(n), _hp(out), C.byref(after)))
+    return out, after.value
+
+
 _SH_SEND = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t)
 _SH_RECV = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t)
 _SH_RAND = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -655,12 +694,14 @@ def host_prove_shamir_party(session, threshold, pub, wit, net_table, rand_table,
     return out, sec[0]
 
 
-def host_prove_rep3_party(session, pub, wit_a, wit_b, net_table, rand_table):
-    """ONE REP3 party on an open ProvingSession through the callback ABI; returns (proof, seconds).  Call it from one thread per party."""
+def host_prove_rep3_party(session, pub, wit_a, wit_b, net_table, rand_table, streams_table=None):
+    """ONE REP3 party on an open ProvingSession through the callback ABI; returns (proof, seconds).  Call it from one thread per party.
+    streams_table (Rep3ChaChaTable): the masking vectors are drawn on the GPU from the described ChaCha12 generators."""
     nq = 6 if session.curve == BLS12_381 else 4
     out = np.zeros(8 * nq, dtype=np.uint64); sec = (C.c_double * 1)()
     keep = [np.ascontiguousarray(x, dtype=np.uint64) for x in (pub, wit_a, wit_b)]
-    _hchk(load_host().cgh_session_prove_rep3_party(session.h, _hp(keep[0]), _hp(keep[1]), _hp(keep[2]), C.byref(net_table), C.byref(rand_table), _hp(out), sec))
+    _hchk(load_host().cgh_session_prove_rep3_party_ex(session.h, _hp(keep[0]), _hp(keep[1]), _hp(keep[2]), C.byref(net_table), C.byref(rand_table),
+                                                      C.byref(streams_table) if streams_table is not None else None, _hp(out), sec))
     return out, sec[0]
 
 

@@ -41,6 +41,8 @@ template <class Fr> int launch_vec_gather_idx(hipStream_t st, Fr* out, const Fr*
 template <class F> int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi, int log_t, size_t n, Affine<F>* d_out);
 template <class F, class Fr> int fixed_base_mul_launch(hipStream_t st, const Affine<F>& g, const Fr* d_scalars, size_t n, Affine<F>* d_tab, Affine<F>* d_out);
 template <class Fr> int launch_vec_binary(hipStream_t st, int op, Fr* out, const Fr* a, const Fr* b, size_t n);
+int chacha12_fr_rand_launch(hipStream_t st, const uint32_t* key8, const uint32_t* mod8, int modulus_bits, uint64_t word_pos, uint64_t n_pairs, uint64_t n,
+                            void* d_cand, uint32_t* d_tiles, unsigned long long* d_result, void* d_out);   // chacha_rand.hip
 template <class Fr> int launch_rep3_mul_local(hipStream_t st, Fr* out, const Fr* aa, const Fr* ab, const Fr* ba, const Fr* bb, const Fr* mask, size_t n);
 template <class Fr> int launch_distribute_powers(hipStream_t st, Fr* v, size_t n, const Fr* lo, const Fr* hi, int log_lo);
 template <class Fr> int launch_vec_count_noncanonical(hipStream_t st, const Fr* v, size_t n, unsigned long long* n_bad);
@@ -1536,6 +1538,40 @@ int32_t cg_vec_rep3_mul_local_dev(cg_ctx* ctx, int32_t curve, void* d_out, const
         typedef decltype(tag) Fr;
         StatScope ss(ctx, TAG_VEC);
         return launch_rep3_mul_local<Fr>(ctx->stream, (Fr*)d_out, (const Fr*)d_aa, (const Fr*)d_ab, (const Fr*)d_ba, (const Fr*)d_bb, (const Fr*)d_mask, n);
+    });
+}
+int32_t cg_chacha12_fr_rand_dev(cg_ctx* ctx, int32_t curve, const uint8_t* seed32, uint64_t word_pos, size_t n, void* d_out, uint64_t* word_pos_after) {
+    if (!ctx || !seed32 || (n && !d_out)) return fail(CG_ERR_ARG, "null argument");
+    if (n >= ((size_t)1 << 31) || word_pos > (~0ull >> 1)) return fail(CG_ERR_ARG, "cg_chacha12_fr_rand_dev: size or position out of range");
+    if (n == 0) { if (word_pos_after) *word_pos_after = word_pos; return 0; }
+    HIPCHK(hipSetDevice(ctx->device));
+    return with_fr(curve, [&](auto tag) -> int {
+        typedef decltype(tag) Fr;
+        typedef typename Fr::Params P;
+        StatScope ss(ctx, TAG_VEC);
+        uint32_t key[8];
+        for (int i = 0; i < 8; i++) key[i] = (uint32_t)seed32[4 * i] | (uint32_t)seed32[4 * i + 1] << 8 | (uint32_t)seed32[4 * i + 2] << 16 | (uint32_t)seed32[4 * i + 3] << 24;
+        // acceptance rate = modulus / 2^BITS (BN254 Fr 0.756, BLS12-381 Fr 0.906); candidates for n draws + 8 standard deviations + a floor
+        const double accept = (double)P::P[7] / (double)(1ull << (P::BITS - 224));
+        double margin = 8.0 * std::sqrt((double)n) + 64.0;
+        for (int attempt = 0; attempt < 4; attempt++, margin *= 4.0) {
+            const uint64_t n_cand = (uint64_t)(((double)n + margin) / accept) + 2;
+            const uint64_t n_pairs = n_cand / 2 + 2;
+            const uint64_t tiles = (n_pairs + 255) / 256;
+            void* d_cand = nullptr; void* d_small = nullptr;
+            if (int rc = cg_dev_alloc(ctx, n_pairs * 64, &d_cand)) return rc;
+            if (int rc = cg_dev_alloc(ctx, tiles * 4 + 16, &d_small)) { cg_dev_free(ctx, d_cand); return rc; }
+            unsigned long long* d_result = (unsigned long long*)d_small;
+            unsigned long long h_result[2] = {0, 0};
+            int rc = chacha12_fr_rand_launch(ctx->stream, key, P::P, P::BITS, word_pos, n_pairs, n, d_cand, (uint32_t*)((char*)d_small + 16), d_result, d_out);
+            hipError_t e = rc ? hipSuccess : hipMemcpyAsync(h_result, d_result, sizeof h_result, hipMemcpyDeviceToHost, ctx->stream);
+            if (!rc && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            cg_dev_free(ctx, d_cand); cg_dev_free(ctx, d_small);
+            if (rc) return rc;
+            HIPCHK(e);
+            if (h_result[0] >= n) { if (word_pos_after) *word_pos_after = word_pos + 8 * ((uint64_t)h_result[1] + 1); return 0; }
+        }
+        return fail(CG_ERR_HIP, "cg_chacha12_fr_rand_dev: too few accepted candidates");
     });
 }
 int32_t cg_vec_check_canonical_dev(cg_ctx* ctx, int32_t curve, const void* d_vec, size_t n, void* d_count) {

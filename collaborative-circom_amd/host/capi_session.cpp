@@ -1,6 +1,7 @@
 // C entry points: proving sessions (zkey resident on the device, one proof = what co-circom.rs:503-506 times)
 #include "groth16.hpp"
 #include "capi_common.hpp"
+#include "chacha.hpp"
 
 extern "C" {
 
@@ -136,6 +137,11 @@ int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uin
 // ---- ONE REP3 party with the caller's network and randomness (include/cogroth16_host.h; co-circom.rs:484-506) ----------------------------
 int32_t cgh_session_prove_rep3_party(void* h, const uint64_t* pub_in, const uint64_t* wit_a, const uint64_t* wit_b,
                                      const cgh_rep3_net* net_cb, const cgh_rep3_rand* rnd_cb, uint64_t* out_proof, double* seconds) {
+    return cgh_session_prove_rep3_party_ex(h, pub_in, wit_a, wit_b, net_cb, rnd_cb, nullptr, out_proof, seconds);
+}
+// streams_cb != NULL: rng1 / rng2 are ChaCha12 generators the caller can position; the masking vectors of both mul_vec calls are drawn on the GPU
+int32_t cgh_session_prove_rep3_party_ex(void* h, const uint64_t* pub_in, const uint64_t* wit_a, const uint64_t* wit_b, const cgh_rep3_net* net_cb,
+                                        const cgh_rep3_rand* rnd_cb, const cgh_rep3_chacha* streams_cb, uint64_t* out_proof, double* seconds) {
     cgh_session* s = (cgh_session*)h;
     try {
         using namespace cgh;
@@ -145,6 +151,7 @@ int32_t cgh_session_prove_rep3_party(void* h, const uint64_t* pub_in, const uint
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
         CallbackNetwork net(*net_cb);
         CallbackRand rnd(*rnd_cb);
+        rnd.describe_streams(streams_cb);
         static const bool no_prio = getenv("CGH_NO_CHAIN_PRIORITY") != nullptr;          // tuning knob
         Borrowed ctx(s, true, 0, s->second_context && !no_prio), second(s, s->second_context);
         ProofWorkers workers(s);
@@ -308,6 +315,73 @@ int32_t cgh_stream_rand_create(int32_t curve, const uint64_t* rng1, const uint64
     } catch (const std::exception& e) { g_host_err = e.what(); delete r; return 1; }
 }
 int32_t cgh_stream_rand_destroy(void* handle) { delete (StreamRand*)handle; return 0; }
+
+// ---- Rep3Rand over two ChaCha12 generators (rngs.rs:25-46), host side: chacha.hpp ---------------------------------------------------------
+namespace {
+struct ChaChaRand {
+    cgh::Curve curve; cgh::ChaCha12 rng1, rng2; uint8_t seed1[32], seed2[32];
+    const uint64_t* mod() const { return cgh::MOD_R[curve.id]; }
+    int bits() const { return curve.id == CG_BN254 ? 254 : 255; }
+};
+int32_t cr_masks(void* u, size_t n, uint64_t* buf, const uint64_t** out) {
+    ChaChaRand* r = (ChaChaRand*)u;
+    const uint64_t* mod = r->mod(); const int bits = r->bits();
+    for (size_t i = 0; i < n; i++) {                                   // masking_field_element: rand(rng1) - rand(rng2) (rngs.rs:37-46), one host thread like the reference
+        uint64_t a[4], b[4]; uint64_t* d = buf + 4 * i;
+        r->rng1.fr_rand(mod, bits, a); r->rng2.fr_rand(mod, bits, b);
+        unsigned __int128 br = 0;
+        for (int k = 0; k < 4; k++) { const unsigned __int128 t = (unsigned __int128)a[k] - b[k] - (uint64_t)br; d[k] = (uint64_t)t; br = (t >> 64) & 1; }
+        if (br) { unsigned __int128 c = 0; for (int k = 0; k < 4; k++) { c += (unsigned __int128)d[k] + mod[k]; d[k] = (uint64_t)c; c >>= 64; } }
+    }
+    *out = buf;
+    return 0;
+}
+int32_t cr_random_fes(void* u, uint64_t* a, uint64_t* b) {
+    ChaChaRand* r = (ChaChaRand*)u;
+    r->rng1.fr_rand(r->mod(), r->bits(), a); r->rng2.fr_rand(r->mod(), r->bits(), b);
+    return 0;
+}
+int32_t cr_masking_ec(void* u, int32_t group, uint64_t* out) {
+    ChaChaRand* r = (ChaChaRand*)u;
+    try {
+        using namespace cgh;
+        Fr a, b;
+        r->rng1.fr_rand(r->mod(), r->bits(), a.v); r->rng2.fr_rand(r->mod(), r->bits(), b.v);
+        const Point gen = pt_generator(r->curve, group);
+        const Point m = pt_sub(r->curve, pt_mul(r->curve, gen, a), pt_mul(r->curve, gen, b));
+        memcpy(out, m.b.data(), m.b.size());
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+int32_t cr_get_state(void* u, uint8_t* s1, uint64_t* p1, uint8_t* s2, uint64_t* p2) {
+    ChaChaRand* r = (ChaChaRand*)u;
+    memcpy(s1, r->seed1, 32); memcpy(s2, r->seed2, 32); *p1 = r->rng1.word_pos; *p2 = r->rng2.word_pos;
+    return 0;
+}
+int32_t cr_set_word_pos(void* u, uint64_t p1, uint64_t p2) { ChaChaRand* r = (ChaChaRand*)u; r->rng1.word_pos = p1; r->rng2.word_pos = p2; return 0; }
+}
+int32_t cgh_chacha_rand_create(int32_t curve, const uint8_t* seed1, const uint8_t* seed2, void** out_handle, cgh_rep3_rand* out, cgh_rep3_chacha* out_streams) {
+    if (!seed1 || !seed2 || !out_handle || !out || (curve != CG_BN254 && curve != CG_BLS12_381)) { g_host_err = "cgh_chacha_rand_create: bad argument"; return 1; }
+    ChaChaRand* r = new ChaChaRand{cgh::Curve{curve}, cgh::ChaCha12(seed1), cgh::ChaCha12(seed2), {}, {}};
+    memcpy(r->seed1, seed1, 32); memcpy(r->seed2, seed2, 32);
+    out->user = r; out->masking_field_elements = cr_masks; out->random_fes = cr_random_fes; out->masking_ec_element = cr_masking_ec;
+    if (out_streams) { out_streams->user = r; out_streams->get_state = cr_get_state; out_streams->set_word_pos = cr_set_word_pos; }
+    *out_handle = r;
+    return 0;
+}
+int32_t cgh_chacha_rand_positions(void* handle, uint64_t* p1, uint64_t* p2) {
+    if (!handle || !p1 || !p2) { g_host_err = "cgh_chacha_rand_positions: null argument"; return 1; }
+    *p1 = ((ChaChaRand*)handle)->rng1.word_pos; *p2 = ((ChaChaRand*)handle)->rng2.word_pos;
+    return 0;
+}
+int32_t cgh_chacha_rand_destroy(void* handle) { delete (ChaChaRand*)handle; return 0; }
+int32_t cgh_chacha12_fr_rand_host(int32_t curve, const uint8_t* seed32, uint64_t word_pos, size_t n, uint64_t* out, uint64_t* word_pos_after) {
+    if (!seed32 || (n && !out) || (curve != CG_BN254 && curve != CG_BLS12_381)) { g_host_err = "cgh_chacha12_fr_rand_host: bad argument"; return 1; }
+    cgh::ChaCha12 rng(seed32, word_pos);
+    for (size_t i = 0; i < n; i++) rng.fr_rand(cgh::MOD_R[curve], curve == CG_BN254 ? 254 : 255, out + 4 * i);
+    if (word_pos_after) *word_pos_after = rng.word_pos;
+    return 0;
+}
 
 // three REP3 parties on an open session: three threads, each calling the one-party entry above with a loopback transport and a stream
 // randomness source (party i: rng1 = S_i, rng2 = S_(i-1)).  seconds (optional, 2 values): [0] = wall time of the three co-located

@@ -440,14 +440,23 @@ public:
     // masks of the coming mul_vec calls, uploaded ahead of time (only from page-locked randomness streams, where the copy is a plain
     // asynchronous DMA): the product kernel then never waits for PCIe
     struct MaskSet { void* m1; void* m2; int32_t tk; size_t n, at; };
+    // a randomness source that describes its ChaCha12 generators has its masks drawn by the backend (no host draws, no upload); short vectors
+    // are not worth three launches and a stream synchronisation
+    const size_t DEVICE_MASKS_MIN = (size_t)1 << 14;
+    bool masks_on_device(void* d_m, size_t n) {
+        if (!rsrc || n < DEVICE_MASKS_MIN) return false;
+        void* tmp = dalloc(n * 32);
+        const bool done = rsrc->masks_on_device(ctx, curve.id, n, d_m, tmp);
+        defer_free(tmp);
+        return done;
+    }
     std::deque<MaskSet> prefetched;
     void prefetch_masks(int count, size_t n) {
         if (mode != Mode::Rep3 || n < XCHG_ASYNC_MIN) return;
         if (rsrc) {                                                                     // drawn now, in the reference's order (both mul_vec calls precede every other draw)
             for (int i = 0; i < count; i++) {
-                const Fr* m = rsrc->masking_field_elements(n, mask_scratch(n));
                 MaskSet ms{dalloc(n * 32), nullptr, -1, n, 0};
-                ms.tk = upload_staged(ms.m1, m, n);
+                if (!masks_on_device(ms.m1, n)) ms.tk = upload_staged(ms.m1, rsrc->masking_field_elements(n, mask_scratch(n)), n);
                 prefetched.push_back(ms);
             }
             return;
@@ -489,7 +498,8 @@ public:
                 if (ms.tk >= 0) CG(cg_copy_fence(ctx, ms.tk));
             } else {
                 m1 = dalloc(a.n * 32);
-                if (a.n < XCHG_ASYNC_MIN) { std::vector<Fr> buf(a.n); CG(cg_dev_upload(ctx, m1, rsrc->masking_field_elements(a.n, buf.data()), a.n * 32)); }
+                if (masks_on_device(m1, a.n)) {}
+                else if (a.n < XCHG_ASYNC_MIN) { std::vector<Fr> buf(a.n); CG(cg_dev_upload(ctx, m1, rsrc->masking_field_elements(a.n, buf.data()), a.n * 32)); }
                 else { const int32_t tk = upload_staged(m1, rsrc->masking_field_elements(a.n, mask_scratch(a.n)), a.n); if (tk >= 0) CG(cg_copy_fence(ctx, tk)); }
             }
         } else {

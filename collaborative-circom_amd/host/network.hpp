@@ -126,6 +126,8 @@ struct Rep3RandSource {
     virtual const Fr* masking_field_elements(size_t n, Fr* buf) = 0;
     virtual void random_fes(Fr& a, Fr& b) = 0;
     virtual void masking_ec_element(int group, uint8_t* out_jacobian) = 0;
+    // optional: the n masks drawn ON THE DEVICE into d_out (d_tmp: n elements of scratch), both generators advanced; false = not offered
+    virtual bool masks_on_device(cg_ctx*, int /*curve*/, size_t /*n*/, void* /*d_out*/, void* /*d_tmp*/) { return false; }
 };
 struct CallbackRand : Rep3RandSource {
     cgh_rep3_rand cb;
@@ -141,6 +143,23 @@ struct CallbackRand : Rep3RandSource {
     }
     void random_fes(Fr& a, Fr& b) override { check(cb.random_fes(cb.user, a.v, b.v), "random_fes"); }
     void masking_ec_element(int group, uint8_t* out) override { check(cb.masking_ec_element(cb.user, group, (uint64_t*)out), "masking_ec_element"); }
+    // cgh_rep3_chacha: rng1 / rng2 are ChaCha12 streams the caller can position — the backend draws F::rand(rng1) - F::rand(rng2) itself
+    cgh_rep3_chacha streams{}; bool has_streams = false;
+    void describe_streams(const cgh_rep3_chacha* st) {
+        if (!st) return;
+        if (!st->get_state || !st->set_word_pos) throw std::runtime_error("cgh_rep3_chacha: both callbacks are required");
+        streams = *st; has_streams = true;
+    }
+    bool masks_on_device(cg_ctx* ctx, int curve, size_t n, void* d_out, void* d_tmp) override {
+        if (!has_streams) return false;
+        uint8_t s1[32], s2[32]; uint64_t p1 = 0, p2 = 0, a1 = 0, a2 = 0;
+        check(streams.get_state(streams.user, s1, &p1, s2, &p2), "get_state");
+        if (cg_chacha12_fr_rand_dev(ctx, curve, s1, p1, n, d_out, &a1) || cg_chacha12_fr_rand_dev(ctx, curve, s2, p2, n, d_tmp, &a2) ||
+            cg_vec_sub_dev(ctx, curve, d_out, d_out, d_tmp, n))
+            throw std::runtime_error(std::string("masks on the device: ") + cg_last_error());
+        check(streams.set_word_pos(streams.user, a1, a2), "set_word_pos");
+        return true;
+    }
 };
 
 // Shamir: any-to-any channels (shamir/network.rs:17-59)

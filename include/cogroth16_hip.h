@@ -168,6 +168,13 @@ int32_t cg_vec_mul_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_a,
 /* REP3 mul_vec local part (rep3.rs:656-660): out = aa*ba + aa*bb + ab*ba + mask ; d_mask may be NULL */
 int32_t cg_vec_rep3_mul_local_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_aa, const void* d_ab,
                                   const void* d_ba, const void* d_bb, const void* d_mask, size_t n);
+/* The O(n) draws behind Rep3Rand::masking_field_element (rep3/rngs.rs:37-46; mul_vec draws n of them, rep3.rs:656-660) on the device:
+ * n x `F::rand(&mut rng)` for rng = rand_chacha::ChaCha12Rng (mpc-core/src/lib.rs:10) with the given 32-byte seed (stream id 0), starting at
+ * the 32-bit word position word_pos (ChaCha12Rng::get_word_pos; below 2^64) — ark-ff's rejection sampling (8 stream words per attempt, the
+ * top 256 - MODULUS_BIT_SIZE bits cleared, accepted when below the modulus; the accepted bits are the Montgomery representation).
+ * d_out receives the n elements in draw order; *word_pos_after is what the caller hands to ChaCha12Rng::set_word_pos so that its
+ * next draw continues behind the last one taken here.  Synchronises the context's stream (the position is known only after the draws). */
+int32_t cg_chacha12_fr_rand_dev(cg_ctx* ctx, int32_t curve, const uint8_t* seed32, uint64_t word_pos, size_t n, void* d_out, uint64_t* word_pos_after);
 /* distribute_powers_and_mul_by_const (traits.rs:177): v[i] *= c * g^i */
 int32_t cg_vec_distribute_powers_dev(cg_ctx* ctx, int32_t curve, void* d_v, size_t n, const void* h_g, const void* h_c);
 /* Single-component pointwise helpers (plain / Shamir shares, co-plonk round 2):

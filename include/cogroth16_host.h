@@ -133,6 +133,23 @@ typedef struct cgh_rep3_rand {
 int32_t cgh_session_prove_rep3_party(void* session, const uint64_t* pub_in, const uint64_t* wit_a, const uint64_t* wit_b,
                                      const cgh_rep3_net* net, const cgh_rep3_rand* rnd, uint64_t* out_proof, double* seconds);
 
+/* Optional description of Rep3Rand's two generators, for the O(n) draws.  Rep3Rand::masking_field_element (rngs.rs:37-46) is
+ * `F::rand(&mut rng1) - F::rand(&mut rng2)` with `RngType = rand_chacha::ChaCha12Rng` (mpc-core/src/lib.rs:10): 2 n rejection-sampled draws
+ * per mul_vec on one host thread in the reference (4 x 2^22 per 2^22-constraint proof — several times the GPU's whole prove).  A ChaCha
+ * stream is addressable by position, so with this table the library makes those draws on the GPU (cg_chacha12_fr_rand_dev: every candidate
+ * in parallel, accepted ones compacted in order) and never moves a mask over PCIe: get_state reports seed and word position of rng1 / rng2
+ * (ChaCha12Rng::get_seed, get_word_pos) right before a vector of masks is due, set_word_pos (ChaCha12Rng::set_word_pos) puts both
+ * generators behind the draws taken, so the caller's next draw — random_fes, masking_ec_element, the next proof — is the one the reference
+ * would make.  The O(1) draws stay with cgh_rep3_rand.  Vectors shorter than 2^14 elements still come through masking_field_elements. */
+typedef struct cgh_rep3_chacha {
+    void* user;
+    int32_t (*get_state)(void* user, uint8_t* seed1_32, uint64_t* word_pos1, uint8_t* seed2_32, uint64_t* word_pos2);
+    int32_t (*set_word_pos)(void* user, uint64_t word_pos1, uint64_t word_pos2);
+} cgh_rep3_chacha;
+/* cgh_session_prove_rep3_party with the generators described (streams may be NULL: the entry above) */
+int32_t cgh_session_prove_rep3_party_ex(void* session, const uint64_t* pub_in, const uint64_t* wit_a, const uint64_t* wit_b, const cgh_rep3_net* net,
+                                        const cgh_rep3_rand* rnd, const cgh_rep3_chacha* streams, uint64_t* out_proof, double* seconds);
+
 /* The Shamir twin (co-circom.rs:507-527: `ShamirMpcNet::new`, `ShamirProtocol::new(t, net)`, `prover.prove`): ONE of n parties, threshold t,
  * with the caller's any-to-any network (shamir/network.rs:17-59: one message = one send / recv pair between two parties) and the caller's
  * PRIVATE randomness (ShamirProtocol's own RNG: the coefficients of ShamirCore::share, shamir/shamir_core.rs:8-31, the secrets of
@@ -167,6 +184,15 @@ int32_t cgh_loopback_destroy(void* hub);
  * Every draw advances k by one, a masking vector of n elements by n. */
 int32_t cgh_stream_rand_create(int32_t curve, const uint64_t* rng1, const uint64_t* rng2, size_t len, void** out_handle, cgh_rep3_rand* out);
 int32_t cgh_stream_rand_destroy(void* handle);
+/* Rep3Rand over two ChaCha12 generators, as the reference holds it (rngs.rs:25-35: `RngType::from_seed(seed1)`, `from_seed(seed2)`): the
+ * host side of the draws (rand_chacha's block function and ark-ff's F::rand restated in this library), for tests, benches and single-box
+ * deployments — a Rust caller passes its own Rep3Rand instead (rust/mpc-core-hip/src/session.rs).  out = the three O(1) / host callbacks,
+ * out_streams (optional) = the table above.  masking_ec_element is the stand-in of cgh_stream_rand_create (G * rand(rng1) - G * rand(rng2)).
+ * cgh_chacha12_fr_rand_host: n x F::rand on the host from a seed and word position, single thread — what the reference's party does. */
+int32_t cgh_chacha_rand_create(int32_t curve, const uint8_t* seed1_32, const uint8_t* seed2_32, void** out_handle, cgh_rep3_rand* out, cgh_rep3_chacha* out_streams);
+int32_t cgh_chacha_rand_positions(void* handle, uint64_t* word_pos1, uint64_t* word_pos2);
+int32_t cgh_chacha_rand_destroy(void* handle);
+int32_t cgh_chacha12_fr_rand_host(int32_t curve, const uint8_t* seed32, uint64_t word_pos, size_t n, uint64_t* out, uint64_t* word_pos_after);
 
 /* ---- co-plonk (co-plonk/src/plonk.rs:133-271 drives round1..round5) ------------------------------------------------------------------ */
 /* PlainHipDriver through rounds 1..upto (<= 5).  full_witness = n_vars - n_additions elements; blind = the 11 blinding scalars b_1..b_11

@@ -8,6 +8,7 @@
 #include "synth.hpp"
 #include "plonk.hpp"
 #include "shamir.hpp"
+#include "rngs.hpp"
 #include <chrono>
 
 using namespace orc;
@@ -547,6 +548,31 @@ int orc_make_synthetic(int curve, int log_m, uint64_t seed, const char* zkey_pat
 }
 int orc_make_synthetic_pub(int curve, int log_m, uint64_t seed, const char* zkey_path, const char* wtns_path, int threads, uint64_t n_public) {
     DISPATCH(curve, { make_synthetic<C>(log_m, seed, zkey_path, wtns_path, threads, (size_t)n_public); });
+    return 0;
+}
+
+// ---- randomness streams (rngs.hpp): rand_chacha ChaCha12Rng + ark-ff Fp::rand, restated ------------------------------------------------------
+int orc_chacha_block(int rounds, const uint32_t* key8, uint64_t counter, uint64_t stream, uint32_t* out16) { chacha_block(rounds, key8, counter, stream, out16); return 0; }
+// n x Fr::rand from ChaCha12Rng::from_seed(seed) positioned at word_pos; *word_pos_after = get_word_pos() after the last draw
+int orc_chacha12_fr_rand(int curve, const uint8_t* seed32, uint64_t word_pos, size_t n, uint64_t* out, uint64_t* word_pos_after) {
+    DISPATCH(curve, {
+        ChaCha12Stream rng(seed32, word_pos);
+        for (size_t i = 0; i < n; i++) fr_rand(rng, C::Fr::K.p, C::Fr::K.bits, out + 4 * i);
+        if (word_pos_after) *word_pos_after = rng.word_pos;
+    });
+    return 0;
+}
+// Rep3Rand::masking_field_element x n (rngs.rs:37-46): rand(rng1) - rand(rng2), each stream advanced by its own rejections
+int orc_rep3_masks_chacha12(int curve, const uint8_t* seed1, uint64_t* pos1, const uint8_t* seed2, uint64_t* pos2, size_t n, uint64_t* out) {
+    DISPATCH(curve, {
+        ChaCha12Stream r1(seed1, *pos1), r2(seed2, *pos2);
+        for (size_t i = 0; i < n; i++) {
+            uint64_t a[4], b[4];
+            fr_rand(r1, C::Fr::K.p, C::Fr::K.bits, a); fr_rand(r2, C::Fr::K.p, C::Fr::K.bits, b);
+            st(out + 4 * i, ld<typename C::Fr>(a) - ld<typename C::Fr>(b));
+        }
+        *pos1 = r1.word_pos; *pos2 = r2.word_pos;
+    });
     return 0;
 }
 

@@ -40,9 +40,19 @@ pub struct cgh_rep3_rand {
     pub random_fes: Option<unsafe extern "C" fn(*mut c_void, *mut u64, *mut u64) -> i32>,
     pub masking_ec_element: Option<unsafe extern "C" fn(*mut c_void, i32, *mut u64) -> i32>,
 }
+/// Rep3Rand's two ChaCha12 generators described by seed and word position: the library then draws the masking vectors of `mul_vec` on the
+/// GPU (`cg_chacha12_fr_rand_dev`) instead of asking for them element by element.
+#[repr(C)]
+pub struct cgh_rep3_chacha {
+    pub user: *mut c_void,
+    pub get_state: Option<unsafe extern "C" fn(*mut c_void, *mut u8, *mut u64, *mut u8, *mut u64) -> i32>,
+    pub set_word_pos: Option<unsafe extern "C" fn(*mut c_void, u64, u64) -> i32>,
+}
 #[link(name = "cogroth16_host")]
 extern "C" {
     fn cgh_last_error() -> *const c_char;
+    fn cgh_session_prove_rep3_party_ex(session: *mut c_void, pub_in: *const u64, wit_a: *const u64, wit_b: *const u64, net: *const cgh_rep3_net,
+                                       rnd: *const cgh_rep3_rand, streams: *const cgh_rep3_chacha, out_proof: *mut u64, seconds: *mut f64) -> i32;
     fn cgh_session_open_multi(devices: *const i32, n_devices: i32, curve: i32, zkey_path: *const c_char, precompute: i32, flags: u32, out: *mut *mut c_void) -> i32;
     fn cgh_session_close(session: *mut c_void) -> i32;
     fn cgh_plonk_prove_rep3_party(device: i32, curve: i32, zkey_path: *const c_char, pub_in: *const u64, wit_a: *const u64, wit_b: *const u64,
@@ -122,11 +132,18 @@ impl Groth16Session {
             random_fes: Some(random_fes::<P>),
             masking_ec_element: Some(masking_ec_element::<P>),
         };
+        // the O(n) draws (2 x m per mul_vec, rngs.rs:37-46) happen on the GPU from the generators' seeds and positions; the O(1) draws
+        // (random_fes, masking_ec_element) stay with `rnd` above and continue behind them
+        let streams = cgh_rep3_chacha {
+            user: &mut state as *mut _ as *mut c_void,
+            get_state: Some(chacha_get_state::<P>),
+            set_word_pos: Some(chacha_set_word_pos::<P>),
+        };
         let fq = size_of::<<P::G1 as CurveGroup>::BaseField>() / 8;
         let mut proof = vec![0u64; 8 * fq];
         let rc = unsafe {
-            cgh_session_prove_rep3_party(self.handle, public_inputs.as_ptr() as *const u64, wit_a.as_ptr() as *const u64, wit_b.as_ptr() as *const u64,
-                                         &net, &rnd, proof.as_mut_ptr(), ptr::null_mut())
+            cgh_session_prove_rep3_party_ex(self.handle, public_inputs.as_ptr() as *const u64, wit_a.as_ptr() as *const u64, wit_b.as_ptr() as *const u64,
+                                            &net, &rnd, &streams, proof.as_mut_ptr(), ptr::null_mut())
         };
         if rc != 0 {
             // the io::Error a callback met (rep3.rs:661-669 would have returned it with `?`), else the library's message
@@ -264,6 +281,27 @@ unsafe extern "C" fn masking_field_elements<P: Pairing>(u: *mut c_void, n: usize
         *d = s.protocol.masking_field_element();
     }
     *out = buf;
+    0
+}
+/// `ChaCha12Rng::get_seed` / `get_word_pos` of Rep3Rand's rng1 and rng2 (accessor added by mpc-core-accessors.patch).  A position beyond
+/// 2^64 words (2^66 bytes drawn from one generator) is refused rather than truncated.
+unsafe extern "C" fn chacha_get_state<P: Pairing>(u: *mut c_void, seed1: *mut u8, pos1: *mut u64, seed2: *mut u8, pos2: *mut u64) -> i32 {
+    let s = &mut *(u as *mut Callbacks<P>);
+    let (s1, p1, s2, p2) = s.protocol.rand_stream_state();
+    if p1 > u64::MAX as u128 >> 1 || p2 > u64::MAX as u128 >> 1 {
+        return fail(s, io::Error::new(io::ErrorKind::Other, "ChaCha12 word position out of the backend's range"));
+    }
+    ptr::copy_nonoverlapping(s1.as_ptr(), seed1, 32);
+    ptr::copy_nonoverlapping(s2.as_ptr(), seed2, 32);
+    *pos1 = p1 as u64;
+    *pos2 = p2 as u64;
+    0
+}
+/// `ChaCha12Rng::set_word_pos` on both generators: the next draw made in Rust is the one behind the GPU's last.
+unsafe extern "C" fn chacha_set_word_pos<P: Pairing>(u: *mut c_void, pos1: u64, pos2: u64) -> i32 {
+    let s = &mut *(u as *mut Callbacks<P>);
+    s.protocol.set_rand_stream_positions(pos1 as u128, pos2 as u128);
+    tracing::trace!("rng1 / rng2 moved to words {pos1} / {pos2} behind the device's draws");
     0
 }
 unsafe extern "C" fn random_fes<P: Pairing>(u: *mut c_void, a: *mut u64, b: *mut u64) -> i32 {

@@ -490,3 +490,29 @@ def plonk_proof_from_json(curve, path):
     d = {k: g1_from_json(curve, o[j]) for k, j in zip(PLONK_COMMITS, ("A", "B", "C", "Z", "T1", "T2", "T3", "Wxi", "Wxiw"))}
     d.update({k: from_dec(curve, FR, o[k]) for k in PLONK_EVALS})
     return d
+
+
+# ---- randomness streams (oracle/rngs.hpp) ----------------------------------------------------------------------------
+def chacha_block(rounds, key_words, counter, stream=0):
+    key = np.ascontiguousarray(key_words, dtype=np.uint32)
+    out = np.zeros(16, dtype=np.uint32)
+    lib().orc_chacha_block(rounds, _p(key), C.c_uint64(counter), C.c_uint64(stream), _p(out))
+    return out
+
+
+def chacha12_fr_rand(curve, seed, word_pos, n):
+    """n x Fr::rand over ChaCha12Rng::from_seed(seed) at word_pos -> (n x 4 limbs, word position afterwards)"""
+    seed = np.frombuffer(bytes(seed), dtype=np.uint8).copy()
+    out = np.zeros((n, 4), dtype=np.uint64)
+    after = C.c_uint64(0)
+    _chk(lib().orc_chacha12_fr_rand(curve, _p(seed), C.c_uint64(word_pos), C.c_size_t(n), _p(out), C.byref(after)))
+    return out, after.value
+
+
+def rep3_masks_chacha12(curve, seed1, pos1, seed2, pos2, n):
+    """n x Rep3Rand::masking_field_element -> (masks, pos1 after, pos2 after)"""
+    s1 = np.frombuffer(bytes(seed1), dtype=np.uint8).copy(); s2 = np.frombuffer(bytes(seed2), dtype=np.uint8).copy()
+    out = np.zeros((n, 4), dtype=np.uint64)
+    p1, p2 = C.c_uint64(pos1), C.c_uint64(pos2)
+    _chk(lib().orc_rep3_masks_chacha12(curve, _p(s1), C.byref(p1), _p(s2), C.byref(p2), C.c_size_t(n), _p(out)))
+    return out, p1.value, p2.value

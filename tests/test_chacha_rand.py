@@ -1,0 +1,190 @@
+"""Rep3Rand's draws (mpc-core/src/protocols/rep3/rngs.rs:25-46: `F::rand(&mut rng1) - F::rand(&mut rng2)`, RngType = ChaCha12Rng,
+mpc-core/src/lib.rs:10) in three places that must agree: the oracle's restatement (oracle/rngs.hpp), the host library's
+(collaborative-circom_amd/host/chacha.hpp, the O(1) draws and short vectors) and the device kernels (csrc/chacha_rand.hip, the m-element
+masking vectors of mul_vec, rep3.rs:656-660).  The block function is pinned to the published ChaCha known-answer vectors; the draw order
+(rand_chacha's word stream + ark-ff's rejection sampling) is restated from the crates' published algorithms — no reference test holds a
+drawn value (PARITY UNPINNED for that part, see oracle/rngs.hpp)."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from oracle_lib import BN254, BLS12_381, FR
+from product import cg, ensure_built
+
+MOD = {BN254: 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+       BLS12_381: 52435875175126190479447740508185965837690552500527637822603658699938581184513}
+
+
+def to_int(limbs):
+    return sum(int(x) << (64 * i) for i, x in enumerate(limbs))
+
+
+# ---------------------------------------------------------------------------------------------------------------- CPU
+def test_chacha_block_known_answers():
+    zero = np.zeros(8, dtype=np.uint32)
+    # ChaCha20, all-zero key and nonce, block 0 (the classic vector; RFC 7539 A.1 #1)
+    assert orc.chacha_block(20, zero, 0).tobytes().hex() == (
+        "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+    # RFC 7539 2.3.2: key 00..1f, counter 1, nonce 00:00:00:09 00:00:00:4a 00:00:00:00 (state words 13, 14 here: counter high / stream low)
+    key = np.frombuffer(bytes(range(32)), dtype=np.uint32)
+    assert orc.chacha_block(20, key, 1 | (0x09000000 << 32), 0x4a000000).tobytes().hex() == (
+        "10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4ed2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+    # ChaCha12 (the round count of rand_chacha::ChaCha12Rng), all-zero key and nonce, block 0 (draft-strombergson-chacha-test-vectors TC1)
+    assert orc.chacha_block(12, zero, 0).tobytes().hex() == (
+        "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f0564f879d27ae3c02ce82834acfa8c793a629f2ca0de6919610be82f411326be")
+
+
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
+def test_oracle_draws_follow_fp_rand(curve):
+    """ark-ff 0.4.2 `Distribution<Fp> for Standard`: four next_u64 per attempt (8 stream words), top bits cleared, below the modulus;
+    a stream continued from the reported position repeats the tail of a longer draw"""
+    seed = bytes((7 * i + 3) & 255 for i in range(32))
+    bits = 254 if curve == BN254 else 255
+    r, after = orc.chacha12_fr_rand(curve, seed, 0, 4000)
+    assert all(to_int(x) < MOD[curve] for x in r)
+    assert after % 8 == 0 and after >= 8 * 4000
+    # re-derive the accepted values from the raw blocks: word stream = successive 12-round blocks, little-endian words
+    key = np.frombuffer(seed, dtype=np.uint32)
+    words = np.concatenate([orc.chacha_block(12, key, b) for b in range(after // 16 + 1)])[:after]
+    cands = words.reshape(-1, 8)
+    vals = [sum(int(w) << (32 * i) for i, w in enumerate(c)) & ((1 << bits) - 1) for c in cands]
+    acc = [v for v in vals if v < MOD[curve]]
+    assert len(acc) == 4000 and vals[-1] < MOD[curve]
+    assert acc == [to_int(x) for x in r]
+    assert abs(len(acc) / len(vals) - MOD[curve] / 2.0 ** bits) < 0.03
+    head, mid = orc.chacha12_fr_rand(curve, seed, 0, 1500)
+    tail, end = orc.chacha12_fr_rand(curve, seed, mid, 2500)
+    np.testing.assert_array_equal(np.concatenate([head, tail]), r); assert end == after
+    # unaligned positions (a 32-bit draw in between, e.g. the bool of C::rand) address the same word stream
+    r3, a3 = orc.chacha12_fr_rand(curve, seed, 13, 50)
+    words = np.concatenate([orc.chacha_block(12, key, b) for b in range(a3 // 16 + 2)])
+    vals = [sum(int(w) << (32 * i) for i, w in enumerate(words[13 + 8 * k:21 + 8 * k])) & ((1 << bits) - 1) for k in range((a3 - 13) // 8)]
+    assert [v for v in vals if v < MOD[curve]] == [to_int(x) for x in r3]
+
+
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
+def test_host_library_draws_equal_the_oracle(curve):
+    ensure_built()
+    rng = np.random.default_rng(21 + curve)
+    for pos in (0, 8, 5, 63, 64, 2**32 - 8, 2**36 + 3):
+        seed = rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
+        want, wa = orc.chacha12_fr_rand(curve, seed, pos, 777)
+        got, ga = cg.chacha12_fr_rand_host(curve, seed, pos, 777)
+        np.testing.assert_array_equal(got, want); assert ga == wa
+
+
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
+def test_chacha_source_follows_rep3rand(curve):
+    """cgh_chacha_rand_create: masking elements = rand(rng1) - rand(rng2) (rngs.rs:37-46), random_fes the pair (:42-46); the generator
+    description reports and moves both positions"""
+    import ctypes as C
+    ensure_built()
+    s1, s2 = bytes(range(32)), bytes(range(100, 132))
+    src = cg.ChaChaRand(curve, s1, s2)
+    try:
+        t = src.table
+        buf = np.zeros((1000, 4), dtype=np.uint64); out = C.c_void_p()
+        assert t.masking_field_elements(t.user, 1000, buf.ctypes.data, C.byref(out)) == 0
+        want, p1, p2 = orc.rep3_masks_chacha12(curve, s1, 0, s2, 0, 1000)
+        np.testing.assert_array_equal(buf, want); assert src.positions() == (p1, p2)
+        a = np.zeros(4, dtype=np.uint64); b = np.zeros(4, dtype=np.uint64)
+        assert t.random_fes(t.user, a.ctypes.data, b.ctypes.data) == 0
+        wa, q1 = orc.chacha12_fr_rand(curve, s1, p1, 1); wb, q2 = orc.chacha12_fr_rand(curve, s2, p2, 1)
+        np.testing.assert_array_equal(a, wa[0]); np.testing.assert_array_equal(b, wb[0]); assert src.positions() == (q1, q2)
+        st = src.streams
+        g1 = (C.c_uint8 * 32)(); g2 = (C.c_uint8 * 32)(); w1 = C.c_uint64(); w2 = C.c_uint64()
+        assert st.get_state(st.user, g1, C.byref(w1), g2, C.byref(w2)) == 0
+        assert bytes(g1) == s1 and bytes(g2) == s2 and (w1.value, w2.value) == (q1, q2)
+        assert st.set_word_pos(st.user, 160, 320) == 0 and src.positions() == (160, 320)
+    finally:
+        src.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
+def test_device_draws_equal_the_oracle(curve):
+    ensure_built()
+    ctx = cg.Context()
+    rng = np.random.default_rng(5 + curve)
+    try:
+        for n, pos in ((1, 0), (2, 8), (255, 3), (1000, 13), (4097, 63), (70001, 64), (30000, 2**32 - 8), (12345, 2**36 + 5), (513, 2**40 + 15)):
+            seed = rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
+            want, wa = orc.chacha12_fr_rand(curve, seed, pos, n)
+            buf, ga = ctx.chacha12_fr_rand(curve, seed, pos, n)
+            got = buf.download((n, 4)); buf.free()
+            np.testing.assert_array_equal(got, want); assert ga == wa, (n, pos)
+        # nothing to draw: the position stays
+        buf, ga = ctx.chacha12_fr_rand(curve, bytes(32), 40, 0); buf.free()
+        assert ga == 40
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_draws_at_full_size():
+    """2^22 draws (one masking vector of the headline circuit) against the host library's single-thread draws"""
+    import time
+    ensure_built()
+    ctx = cg.Context()
+    try:
+        seed = bytes(range(7, 39)); n = 1 << 22
+        t0 = time.time(); want, wa = cg.chacha12_fr_rand_host(BN254, seed, 0, n); t_host = time.time() - t0
+        buf, ga = ctx.chacha12_fr_rand(BN254, seed, 0, n); buf.free()          # warm-up (allocations)
+        t0 = time.time(); buf, ga = ctx.chacha12_fr_rand(BN254, seed, 0, n); t_dev = time.time() - t0
+        got = buf.download((n, 4)); buf.free()
+        np.testing.assert_array_equal(got, want); assert ga == wa
+        print(f"2^22 F::rand draws: host (one thread) {t_host * 1e3:.1f} ms, device {t_dev * 1e3:.2f} ms")
+    finally:
+        ctx.close()
+
+
+def rep3_share(curve, vals, rng):
+    a = orc.random_field(curve, FR, vals.shape[0], rng); b = orc.random_field(curve, FR, vals.shape[0], rng)
+    c = orc.field_op(curve, FR, "sub", orc.field_op(curve, FR, "sub", vals, a), b)
+    return [a, b, c], [c, a, b]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve,log_m", [(BN254, 15), (BLS12_381, 14)])
+def test_parties_with_device_drawn_masks_give_the_oracle_proof(curve, log_m, tmp_path):
+    """three parties through the callback ABI, each holding Rep3Rand as two ChaCha12 seeds (rngs.rs:30-35; party i's rng2 is party
+    i-1's rng1, rep3.rs:343-349): masks drawn on the GPU (generators described) and on the host (not described) give the same proofs,
+    and both equal the oracle's, whose streams are the oracle's own draws from the same seeds; the generators end at the same positions"""
+    ensure_built()
+    threads = min(32, os.cpu_count() or 8)
+    zp, wp = str(tmp_path / "s.zkey"), str(tmp_path / "s.wtns")
+    orc.make_synthetic(curve, log_m, 41, zp, wp, threads=threads)
+    z = orc.ZKey(curve, zp); w = orc.read_wtns(curve, wp)
+    rng = np.random.default_rng(19)
+    wa, wb = rep3_share(curve, w[2:], rng)
+    seeds = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(3)]
+    streams = [orc.chacha12_fr_rand(curve, s, 0, 2 * z.domain_size + 4)[0] for s in seeds]
+    want = z.prove_rep3(w[:2], wa, wb, streams, threads=threads)
+    ses = cg.ProvingSession(curve, zp, precompute=False)
+    try:
+        results = {}
+        for on_device in (True, False):
+            hub = cg.LoopbackHub()
+            rands = [cg.ChaChaRand(curve, seeds[i], seeds[(i + 2) % 3]) for i in range(3)]
+            out, errs = [None] * 3, [None] * 3
+
+            def party(i):
+                try: out[i], _ = cg.host_prove_rep3_party(ses, w[:2], wa[i], wb[i], hub.net(i), rands[i].table, rands[i].streams if on_device else None)
+                except Exception as e: errs[i] = e; hub.abort()
+            th = [threading.Thread(target=party, args=(i,)) for i in range(3)]
+            for t in th: t.start()
+            for t in th: t.join(300)
+            assert errs == [None, None, None], errs
+            results[on_device] = (np.stack(out), [r.positions() for r in rands])
+            for r in rands: r.close()
+            hub.close()
+        np.testing.assert_array_equal(results[True][0], want)
+        np.testing.assert_array_equal(results[False][0], want)
+        assert results[True][1] == results[False][1]
+        assert all(p1 >= 8 * 2 * z.domain_size for p1, _ in results[True][1])
+    finally:
+        ses.close()
