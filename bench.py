@@ -841,7 +841,7 @@ def main():
                                     "randomness": "masks pre-drawn by the caller (ChaCha12 draws excluded, as in cpu_baseline)"}
             ch_ = ses_.get("chacha12_randomness") or {}
             if "rep3_party_ms_device_draws" in ch_:                       # the same entry with the party's ChaCha12 draws inside the timed call
-                out["product_entry"]["with_randomness"] = {"ms_per_proof": ch_["rep3_party_ms_device_draws"], "value": (m - 2) / (ch_["rep3_party_ms_device_draws"] * 1e-3),
+                out["product_entry"]["with_randomness"] = {"ms_per_proof": ch_["rep3_party_ms_device_draws"], "value": ((1 << args.log_m) - 2) / (ch_["rep3_party_ms_device_draws"] * 1e-3),
                                                            "unit": "constraints/s", "draws": "on the GPU (cg_chacha12_fr_rand_dev)",
                                                            "ms_per_proof_host_draws": ch_["rep3_party_ms_host_draws"]}
         if not args.no_cpu_baseline and world == 1:
