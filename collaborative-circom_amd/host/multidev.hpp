@@ -63,6 +63,20 @@ public:
         if (drv.mode != Mode::Rep3) return;
         const bool async = m >= drv.XCHG_ASYNC_MIN;
         const Fr* whole = nullptr; const Fr* s1 = nullptr; const Fr* s2 = nullptr;
+        // generators described (cgh_rep3_chacha): the whole vector is drawn on the primary device — a row's stream position depends on the
+        // rejections before it — and every device takes its rows over its link to the primary
+        if (drv.rsrc && m >= drv.DEVICE_MASKS_MIN && !primary_only) {
+            Dev& P = devs[0];
+            void* all = dalloc(P, m * 32); void* tmp = dalloc(P, m * 32);
+            if (drv.rsrc->masks_on_device(P.ctx, curve.id, m, all, tmp)) {
+                for (size_t d = 0; d < devs.size(); d++) {
+                    Dev& D = devs[d];
+                    mask[d] = dalloc(D, D.n * 32);
+                    if (D.n) CG(cg_dev_copy_peer(D.ctx, mask[d], P.ctx, (const uint8_t*)all + D.lo * 32, D.n * 32));
+                }
+                return;
+            }
+        }
         if (drv.rsrc) {
             Fr* buf = nullptr;
             if (async) { void* p; CG(cg_host_alloc(m * 32, &p)); pinned.push_back(p); buf = (Fr*)p; }

@@ -164,16 +164,17 @@ def test_parties_with_device_drawn_masks_give_the_oracle_proof(curve, log_m, tmp
     seeds = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(3)]
     streams = [orc.chacha12_fr_rand(curve, s, 0, 2 * z.domain_size + 4)[0] for s in seeds]
     want = z.prove_rep3(w[:2], wa, wb, streams, threads=threads)
-    ses = cg.ProvingSession(curve, zp, precompute=False)
+    sessions = {"one": cg.ProvingSession(curve, zp, precompute=False)}
+    if curve == BN254: sessions["three contexts as devices"] = cg.ProvingSession(curve, zp, precompute=False, devices=[0, 0, 0])   # host/multidev.hpp: drawn on the primary, rows peer-copied
     try:
         results = {}
-        for on_device in (True, False):
+        for on_device, ses in ((True, sessions["one"]), (False, sessions["one"])) + (((None, sessions["three contexts as devices"]),) if len(sessions) > 1 else ()):
             hub = cg.LoopbackHub()
             rands = [cg.ChaChaRand(curve, seeds[i], seeds[(i + 2) % 3]) for i in range(3)]
             out, errs = [None] * 3, [None] * 3
 
             def party(i):
-                try: out[i], _ = cg.host_prove_rep3_party(ses, w[:2], wa[i], wb[i], hub.net(i), rands[i].table, rands[i].streams if on_device else None)
+                try: out[i], _ = cg.host_prove_rep3_party(ses, w[:2], wa[i], wb[i], hub.net(i), rands[i].table, rands[i].streams if on_device is not False else None)
                 except Exception as e: errs[i] = e; hub.abort()
             th = [threading.Thread(target=party, args=(i,)) for i in range(3)]
             for t in th: t.start()
@@ -186,5 +187,7 @@ def test_parties_with_device_drawn_masks_give_the_oracle_proof(curve, log_m, tmp
         np.testing.assert_array_equal(results[False][0], want)
         assert results[True][1] == results[False][1]
         assert all(p1 >= 8 * 2 * z.domain_size for p1, _ in results[True][1])
+        if None in results:
+            np.testing.assert_array_equal(results[None][0], want); assert results[None][1] == results[True][1]
     finally:
-        ses.close()
+        for ses in sessions.values(): ses.close()
