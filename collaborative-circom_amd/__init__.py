@@ -694,6 +694,16 @@ def host_prove_shamir_party(session, threshold, pub, wit, net_table, rand_table,
     return out, sec[0]
 
 
+def host_prove_shamir_party_seeded(session, threshold, pub, wit, net_table, seed, preprocess=0):
+    """ONE Shamir party whose private randomness is a ChaCha12 generator run by the library from `seed` (32 bytes); returns (proof, seconds)"""
+    nq = 6 if session.curve == BLS12_381 else 4
+    out = np.zeros(8 * nq, dtype=np.uint64); sec = (C.c_double * 1)()
+    keep = [np.ascontiguousarray(x, dtype=np.uint64) for x in (pub, wit)]
+    _hchk(load_host().cgh_session_prove_shamir_party_seeded(session.h, int(threshold), _hp(keep[0]), _hp(keep[1]), C.byref(net_table), bytes(seed),
+                                                            C.c_size_t(int(preprocess)), _hp(out), sec))
+    return out, sec[0]
+
+
 def host_prove_rep3_party(session, pub, wit_a, wit_b, net_table, rand_table, streams_table=None):
     """ONE REP3 party on an open ProvingSession through the callback ABI; returns (proof, seconds).  Call it from one thread per party.
     streams_table (Rep3ChaChaTable): the masking vectors are drawn on the GPU from the described ChaCha12 generators."""

@@ -173,13 +173,25 @@ int32_t cgh_session_prove_rep3_party_ex(void* h, const uint64_t* pub_in, const u
 }
 
 // ---- ONE Shamir party with the caller's network and randomness (co-circom.rs:507-527) -----------------------------------------------------
+static int32_t shamir_party_impl(void* h, int32_t threshold, const uint64_t* pub_in, const uint64_t* wit_in, const cgh_shamir_net* net_cb,
+                                 const cgh_shamir_rand* rnd_cb, const uint8_t* seed32, size_t preprocess, uint64_t* out_proof, double* seconds);
 int32_t cgh_session_prove_shamir_party(void* h, int32_t threshold, const uint64_t* pub_in, const uint64_t* wit_in, const cgh_shamir_net* net_cb,
                                        const cgh_shamir_rand* rnd_cb, size_t preprocess, uint64_t* out_proof, double* seconds) {
+    if (!rnd_cb) { g_host_err = "cgh_session_prove_shamir_party: null argument"; return 1; }
+    return shamir_party_impl(h, threshold, pub_in, wit_in, net_cb, rnd_cb, nullptr, preprocess, out_proof, seconds);
+}
+int32_t cgh_session_prove_shamir_party_seeded(void* h, int32_t threshold, const uint64_t* pub_in, const uint64_t* wit_in, const cgh_shamir_net* net_cb,
+                                              const uint8_t* seed32, size_t preprocess, uint64_t* out_proof, double* seconds) {
+    if (!seed32) { g_host_err = "cgh_session_prove_shamir_party_seeded: null argument"; return 1; }
+    return shamir_party_impl(h, threshold, pub_in, wit_in, net_cb, nullptr, seed32, preprocess, out_proof, seconds);
+}
+static int32_t shamir_party_impl(void* h, int32_t threshold, const uint64_t* pub_in, const uint64_t* wit_in, const cgh_shamir_net* net_cb,
+                                 const cgh_shamir_rand* rnd_cb, const uint8_t* seed32, size_t preprocess, uint64_t* out_proof, double* seconds) {
     cgh_session* s = (cgh_session*)h;
     try {
         using namespace cgh;
-        if (!s || !pub_in || !wit_in || !net_cb || !rnd_cb || !out_proof) throw std::runtime_error("cgh_session_prove_shamir_party: null argument");
-        if (!rnd_cb->random_field_elements) throw std::runtime_error("cgh_shamir_rand: random_field_elements is required");
+        if (!s || !pub_in || !wit_in || !net_cb || (!rnd_cb && !seed32) || !out_proof) throw std::runtime_error("cgh_session_prove_shamir_party: null argument");
+        if (rnd_cb && !rnd_cb->random_field_elements) throw std::runtime_error("cgh_shamir_rand: random_field_elements is required");
         const ZKey& z = s->z;
         const size_t n_aux = z.n_vars - z.n_public - 1;
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
@@ -192,6 +204,7 @@ int32_t cgh_session_prove_shamir_party(void* h, int32_t threshold, const uint64_
             HipDriver driver(ctx.c, z.curve, Mode::Shamir, nullptr);
             driver.aux = second.c; driver.owns_aux = false; driver.md = workers.get();
             driver.sh_rand = rnd_cb; driver.additive_h = s->additive_h;
+            if (seed32) { driver.sh_gen = ChaCha12(seed32); driver.sh_gen_on = true; }
             driver.shamir_init(&net, threshold);                                        // ShamirProtocol::new, shamir.rs:211-246
             driver.preprocess(preprocess);
             VecGuard wit(driver, driver.upload_vec((const Fr*)wit_in, nullptr, n_aux));

@@ -2,6 +2,7 @@
 #pragma once
 #include "formats.hpp"
 #include "network.hpp"
+#include "chacha.hpp"
 
 namespace cgh {
 
@@ -98,7 +99,12 @@ public:
     static constexpr size_t SHAMIR_BATCH = 1024;                                     // ShamirRng::BATCH_SIZE
     // Shamir with the caller's own RNG (cgh_session_prove_shamir_party): every draw goes through the callback instead of the stream rng1
     const cgh_shamir_rand* sh_rand = nullptr;
+    // ... or from a ChaCha12 generator seeded by the caller for this proof (cgh_session_prove_shamir_party_seeded).  ShamirProtocol's RNG is
+    // PRIVATE (`RngType::from_entropy()`, shamir.rs:211-246: no peer reproduces its draws), so a generator the library positions itself is
+    // as good as the caller's: the amount * (1 + 3t) draws of `preprocess` are then made on the device, the short ones here, one stream.
+    ChaCha12 sh_gen; bool sh_gen_on = false;
     void shamir_draw(size_t n, Fr* out) {
+        if (sh_gen_on) { for (size_t i = 0; i < n; i++) sh_gen.fr_rand(MOD_R[curve.id], curve.id == CG_BN254 ? 254 : 255, out[i].v); return; }
         if (sh_rand) { if (const int32_t rc = sh_rand->random_field_elements(sh_rand->user, n, (uint64_t*)out)) throw std::runtime_error("randomness source: random_field_elements failed with code " + std::to_string(rc)); return; }
         if (cursor + n > rng_len) throw std::runtime_error("randomness stream exhausted");
         memcpy(out, rng1 + cursor, n * 32); cursor += n;
@@ -184,10 +190,14 @@ public:
         if (!amount) return;
         const int np = snet->num_parties(), me = snet->id(), t = sh_t;
         const size_t draws = amount * (size_t)(1 + 3 * t);
-        if (!sh_rand && cursor + draws > rng_len) throw std::runtime_error("randomness stream exhausted");
+        if (!sh_rand && !sh_gen_on && cursor + draws > rng_len) throw std::runtime_error("randomness stream exhausted");
         Marks mk("shamir preprocess", me == 0);
         void* d_rnd = dalloc(draws * 32);
-        if (sh_rand) { std::vector<Fr> tmp(draws); shamir_draw(draws, tmp.data()); CG(cg_dev_upload(ctx, d_rnd, tmp.data(), draws * 32)); }
+        if (sh_gen_on && draws >= DEVICE_MASKS_MIN) {                                  // the same stream, drawn where it is needed
+            uint64_t after = 0;
+            CG(cg_chacha12_fr_rand_dev(ctx, curve.id, (const uint8_t*)sh_gen.key, sh_gen.word_pos, draws, d_rnd, &after));
+            sh_gen.word_pos = after;
+        } else if (sh_rand || sh_gen_on) { std::vector<Fr> tmp(draws); shamir_draw(draws, tmp.data()); CG(cg_dev_upload(ctx, d_rnd, tmp.data(), draws * 32)); }
         else { CG(cg_dev_upload(ctx, d_rnd, rng1 + cursor, draws * 32)); cursor += draws; }
         mk.mark("upload draws");
         const Fr one = fr_from_u64(curve, 1);

@@ -167,6 +167,12 @@ typedef struct cgh_shamir_rand {
 } cgh_shamir_rand;
 int32_t cgh_session_prove_shamir_party(void* session, int32_t threshold, const uint64_t* pub_in, const uint64_t* wit, const cgh_shamir_net* net,
                                        const cgh_shamir_rand* rnd, size_t preprocess, uint64_t* out_proof, double* seconds);
+/* The same party with its private randomness as ONE 32-byte seed (what the caller's rng yields with `rng.gen::<[u8; 32]>()`): ShamirProtocol's
+ * generator is `RngType::from_entropy()` (shamir.rs:211-246) and no peer ever reproduces its draws, so the library runs a ChaCha12 generator of
+ * its own from that seed — `F::rand` per draw as in the reference, the preprocess(amount) batch of amount * (1 + 3t) draws on the GPU
+ * (cg_chacha12_fr_rand_dev), the lazy batches and O(1) draws on the host, all from the one stream in the reference's draw order. */
+int32_t cgh_session_prove_shamir_party_seeded(void* session, int32_t threshold, const uint64_t* pub_in, const uint64_t* wit, const cgh_shamir_net* net,
+                                              const uint8_t* seed32, size_t preprocess, uint64_t* out_proof, double* seconds);
 
 /* Transports and randomness sources for tests, benches and single-box deployments; each fills a callback table for the entry above.
  * cgh_loopback_*: three parties of one process joined by in-memory queues (the role of tests/src/rep3_network.rs).  record != 0 keeps

@@ -344,6 +344,8 @@ pub struct cgh_shamir_rand {
 extern "C" {
     fn cgh_session_prove_shamir_party(session: *mut c_void, threshold: i32, pub_in: *const u64, wit: *const u64, net: *const cgh_shamir_net,
                                       rnd: *const cgh_shamir_rand, preprocess: usize, out_proof: *mut u64, seconds: *mut f64) -> i32;
+    fn cgh_session_prove_shamir_party_seeded(session: *mut c_void, threshold: i32, pub_in: *const u64, wit: *const u64, net: *const cgh_shamir_net,
+                                             seed32: *const u8, preprocess: usize, out_proof: *mut u64, seconds: *mut f64) -> i32;
 }
 struct ShamirCallbacks<'a, F: PrimeField, R: rand::Rng> {
     net: &'a mut mpc_core::protocols::shamir::network::ShamirMpcNet,
@@ -397,9 +399,20 @@ impl Groth16Session {
         let rnd_cb = cgh_shamir_rand { user, random_field_elements: Some(sh_rand::<P::ScalarField, R>) };
         let fq = size_of::<<P::G1 as CurveGroup>::BaseField>() / 8;
         let mut proof = vec![0u64; 8 * fq];
-        let rc = unsafe {
-            cgh_session_prove_shamir_party(self.handle, threshold as i32, public_inputs.as_ptr() as *const u64, witness.as_ptr() as *const u64, &net_cb, &rnd_cb,
-                                           preprocess, proof.as_mut_ptr(), ptr::null_mut())
+        // ShamirProtocol's generator is private (`RngType::from_entropy()`, shamir.rs:211-246): with `preprocess` > 0 the party hands the library ONE
+        // 32-byte seed drawn from its rng and the amount * (1 + 3t) draws of the batch are made on the GPU from a ChaCha12 stream of that seed
+        // (the same generator type the reference seeds), instead of `sh_rand` filling them one F::rand at a time on this thread.
+        let rc = if preprocess > 0 {
+            let seed: [u8; 32] = state.rng.gen();
+            unsafe {
+                cgh_session_prove_shamir_party_seeded(self.handle, threshold as i32, public_inputs.as_ptr() as *const u64, witness.as_ptr() as *const u64, &net_cb,
+                                                      seed.as_ptr(), preprocess, proof.as_mut_ptr(), ptr::null_mut())
+            }
+        } else {
+            unsafe {
+                cgh_session_prove_shamir_party(self.handle, threshold as i32, public_inputs.as_ptr() as *const u64, witness.as_ptr() as *const u64, &net_cb, &rnd_cb,
+                                               preprocess, proof.as_mut_ptr(), ptr::null_mut())
+            }
         };
         if rc != 0 {
             return Err(state.error.take().unwrap_or_else(|| io::Error::new(io::ErrorKind::Other, host_error())));

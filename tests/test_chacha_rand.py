@@ -191,3 +191,42 @@ def test_parties_with_device_drawn_masks_give_the_oracle_proof(curve, log_m, tmp
             np.testing.assert_array_equal(results[None][0], want); assert results[None][1] == results[True][1]
     finally:
         for ses in sessions.values(): ses.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve,log_m,n,t", [(BN254, 13, 3, 1), (BLS12_381, 12, 5, 2)])
+def test_seeded_shamir_parties_give_the_oracle_proof(curve, log_m, n, t, tmp_path):
+    """cgh_session_prove_shamir_party_seeded: each party's private generator is a ChaCha12 stream run by the library from the party's seed —
+    the preprocess(amount) batch of amount * (1 + 3t) draws on the GPU, the rest on the host, one stream in the reference's draw order
+    (shamir.rs:923-1010).  The oracle proves with each party's stream = the oracle's own draws from the same seed."""
+    from test_rep3_party_abi import shamir_mesh
+    ensure_built()
+    threads = min(32, os.cpu_count() or 8)
+    zp, wp = str(tmp_path / "s.zkey"), str(tmp_path / "s.wtns")
+    orc.make_synthetic(curve, log_m, 43, zp, wp, threads=threads)
+    z = orc.ZKey(curve, zp); w = orc.read_wtns(curve, wp)
+    rng = np.random.default_rng(29)
+    wits = orc.shamir_share(curve, w[2:], n, t, rng)
+    amount = (2 * z.domain_size + 8) // (t + 1) + 1                       # one proof never refills (tests/test_shamir.py::full_amount)
+    assert amount * (1 + 3 * t) >= 1 << 14                                # the batch is drawn on the device
+    seeds = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n)]
+    length = (1024 + amount) * (1 + 3 * t) + t * (2 * z.domain_size + 8) + 64
+    streams = [orc.chacha12_fr_rand(curve, s, 0, length)[0] for s in seeds]
+    want = orc.prove_shamir(z, n, t, w[:2], wits, streams, threads=threads, preprocess=amount)
+    ses = cg.ProvingSession(curve, zp, precompute=False)
+    ends = shamir_mesh(n, streams)
+    out, errs = [None] * n, [None] * n
+
+    def party(i):
+        try: out[i], _ = cg.host_prove_shamir_party_seeded(ses, t, w[:2], wits[i], ends[i].net, seeds[i], preprocess=amount)
+        except Exception as e: errs[i] = e
+    try:
+        th = [threading.Thread(target=party, args=(i,)) for i in range(n)]
+        for x in th: x.start()
+        for x in th: x.join(300)
+        assert errs == [None] * n, errs
+        np.testing.assert_array_equal(np.stack(out), want)
+        assert all(e.k == 0 for e in ends)                                 # the callback randomness was never asked
+    finally:
+        for e in ends: e.close()
+        ses.close()
