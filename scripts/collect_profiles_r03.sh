@@ -28,3 +28,15 @@ find $O -name '*counter_collection.csv' -size +256k -delete
 find $O -name '*kernel_trace.csv' -size +256k -delete
 find $O -name '*agent_info.csv' -delete
 tail -3 $O/pytest_gpu.txt 2>/dev/null; tail -1 $O/smoke.txt; head -c 600 $O/bench.json; echo; tail -40 $O/summary.log
+# Rep3Rand's draws on the device (csrc/chacha_rand.hip): per-kernel times and HBM counters (separate passes)
+C=$R/gpurun_out/r03/chacha; mkdir -p $C
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $C/stats -- python $R/scripts/chacha_timing.py > $C/timing.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $C/pmc_fetch -- python $R/scripts/chacha_timing.py > $C/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $C/pmc_write -- python $R/scripts/chacha_timing.py > $C/pmc_write.log 2>&1
+cd $R
+python scripts/chacha_pmc_summary.py $C > $C/summary.txt 2>&1
+find $C -name '*counter_collection.csv' -size +256k -delete
+find $C -name '*kernel_trace.csv' -size +256k -delete
+find $C -name '*agent_info.csv' -delete
+grep draws $C/timing.txt; cat $C/summary.txt
