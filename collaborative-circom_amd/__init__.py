@@ -777,16 +777,17 @@ def plonk_prove_rep3(curve, zkey_path, pub, wit_a, wit_b, blind_a, blind_b, stre
     return out
 
 
-def plonk_prove_rep3_party(curve, zkey_path, pub, wit_a, wit_b, net_table, rand_table, blind_a=None, blind_b=None, upto=5, device=0):
+def plonk_prove_rep3_party(curve, zkey_path, pub, wit_a, wit_b, net_table, rand_table, blind_a=None, blind_b=None, upto=5, device=0, streams_table=None):
     """ONE REP3 party of co-plonk through the callback ABI (cgh_plonk_prove_rep3_party); blind_a/blind_b None = drawn with rand() first.
     Returns a dict like plonk_prove_plain.  Call it from one thread per party."""
     nq = 6 if curve == BLS12_381 else 4
     commits = np.zeros((9, 2 * nq), dtype=np.uint64); ch = np.zeros((5, 4), dtype=np.uint64); ev = np.zeros((6, 4), dtype=np.uint64)
     keep = [np.ascontiguousarray(x, dtype=np.uint64) for x in (pub, wit_a, wit_b)]
     bl = [None if x is None else _pad_blind(x) for x in (blind_a, blind_b)]
-    _hchk(load_host().cgh_plonk_prove_rep3_party(int(device), curve, zkey_path.encode(), _hp(keep[0]), _hp(keep[1]), _hp(keep[2]),
-                                                 None if bl[0] is None else _hp(bl[0]), None if bl[1] is None else _hp(bl[1]),
-                                                 C.byref(net_table), C.byref(rand_table), int(upto), _hp(commits), _hp(ev), _hp(ch)))
+    _hchk(load_host().cgh_plonk_prove_rep3_party_ex(int(device), curve, zkey_path.encode(), _hp(keep[0]), _hp(keep[1]), _hp(keep[2]),
+                                                    None if bl[0] is None else _hp(bl[0]), None if bl[1] is None else _hp(bl[1]),
+                                                    C.byref(net_table), C.byref(rand_table), C.byref(streams_table) if streams_table is not None else None,
+                                                    int(upto), _hp(commits), _hp(ev), _hp(ch)))
     dct = dict(zip(PLONK_COMMITS, commits)); dct.update(zip(PLONK_CHALLENGES, ch)); dct.update(zip(PLONK_EVALS, ev))
     return dct
 

@@ -176,6 +176,12 @@ int32_t cgh_plonk_prove_rep3(int32_t device, int32_t curve, const char* zkey_pat
 int32_t cgh_plonk_prove_rep3_party(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* wit_a, const uint64_t* wit_b,
                                    const uint64_t* blind_a, const uint64_t* blind_b, const cgh_rep3_net* net_cb, const cgh_rep3_rand* rnd_cb, int32_t upto,
                                    uint64_t* out_commits, uint64_t* out_evals, uint64_t* out_challenges) {
+    return cgh_plonk_prove_rep3_party_ex(device, curve, zkey_path, pub_in, wit_a, wit_b, blind_a, blind_b, net_cb, rnd_cb, nullptr, upto, out_commits, out_evals, out_challenges);
+}
+// streams_cb != NULL: the masking vectors of the rounds' mul_vec calls (round2.rs / round3.rs) are drawn on the GPU from the described generators
+int32_t cgh_plonk_prove_rep3_party_ex(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* wit_a, const uint64_t* wit_b,
+                                      const uint64_t* blind_a, const uint64_t* blind_b, const cgh_rep3_net* net_cb, const cgh_rep3_rand* rnd_cb,
+                                      const cgh_rep3_chacha* streams_cb, int32_t upto, uint64_t* out_commits, uint64_t* out_evals, uint64_t* out_challenges) {
     cg_ctx* ctx = nullptr; cg_bases* tau = nullptr;
     try {
         using namespace cgh;
@@ -192,6 +198,7 @@ int32_t cgh_plonk_prove_rep3_party(int32_t device, int32_t curve, const char* zk
         if (validate_by_default()) validate_bases(ctx, tau, "p_tau");
         CallbackNetwork net(*net_cb);
         CallbackRand rnd(*rnd_cb);
+        rnd.describe_streams(streams_cb);
         {
             HipDriver driver(ctx, c, Mode::Rep3, &net);
             driver.rsrc = &rnd;

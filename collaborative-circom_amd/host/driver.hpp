@@ -452,7 +452,7 @@ public:
     struct MaskSet { void* m1; void* m2; int32_t tk; size_t n, at; };
     // a randomness source that describes its ChaCha12 generators has its masks drawn by the backend (no host draws, no upload); short vectors
     // are not worth three launches and a stream synchronisation
-    const size_t DEVICE_MASKS_MIN = (size_t)1 << 14;
+    const size_t DEVICE_MASKS_MIN = getenv("CGH_DEVICE_MASKS_MIN") ? (size_t)atoll(getenv("CGH_DEVICE_MASKS_MIN")) : (size_t)1 << 14;   // (the override lets the small fixtures take the device path)
     bool masks_on_device(void* d_m, size_t n) {
         if (!rsrc || n < DEVICE_MASKS_MIN) return false;
         void* tmp = dalloc(n * 32);

@@ -140,7 +140,8 @@ int32_t cgh_session_prove_rep3_party(void* session, const uint64_t* pub_in, cons
  * in parallel, accepted ones compacted in order) and never moves a mask over PCIe: get_state reports seed and word position of rng1 / rng2
  * (ChaCha12Rng::get_seed, get_word_pos) right before a vector of masks is due, set_word_pos (ChaCha12Rng::set_word_pos) puts both
  * generators behind the draws taken, so the caller's next draw — random_fes, masking_ec_element, the next proof — is the one the reference
- * would make.  The O(1) draws stay with cgh_rep3_rand.  Vectors shorter than 2^14 elements still come through masking_field_elements. */
+ * would make.  The O(1) draws stay with cgh_rep3_rand.  Vectors shorter than 2^14 elements (CGH_DEVICE_MASKS_MIN overrides) still come
+ * through masking_field_elements. */
 typedef struct cgh_rep3_chacha {
     void* user;
     int32_t (*get_state)(void* user, uint8_t* seed1_32, uint64_t* word_pos1, uint8_t* seed2_32, uint64_t* word_pos2);
@@ -217,6 +218,10 @@ int32_t cgh_plonk_prove_rep3(int32_t device, int32_t curve, const char* zkey_pat
 int32_t cgh_plonk_prove_rep3_party(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* wit_a, const uint64_t* wit_b,
                                    const uint64_t* blind_a, const uint64_t* blind_b, const cgh_rep3_net* net, const cgh_rep3_rand* rand, int32_t upto,
                                    uint64_t* out_commits, uint64_t* out_evals, uint64_t* out_challenges);
+/* The same party with Rep3Rand's generators described (cgh_rep3_chacha, above): the masking vectors of the rounds' mul_vec calls are drawn on the GPU */
+int32_t cgh_plonk_prove_rep3_party_ex(int32_t device, int32_t curve, const char* zkey_path, const uint64_t* pub_in, const uint64_t* wit_a, const uint64_t* wit_b,
+                                      const uint64_t* blind_a, const uint64_t* blind_b, const cgh_rep3_net* net, const cgh_rep3_rand* rand,
+                                      const cgh_rep3_chacha* streams, int32_t upto, uint64_t* out_commits, uint64_t* out_evals, uint64_t* out_challenges);
 /* ShamirHipProtocol x n (threshold t) through rounds 1..upto; outputs as for cgh_plonk_prove_rep3, n parties. */
 int32_t cgh_plonk_prove_shamir(int32_t device, int32_t curve, const char* zkey_path, int32_t n, int32_t t, const uint64_t* pub_in, const uint64_t* const* wit,
                                const uint64_t* const* blind, const uint64_t* const* streams, size_t stream_len, int32_t upto,

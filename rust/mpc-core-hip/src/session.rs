@@ -58,6 +58,9 @@ extern "C" {
     fn cgh_plonk_prove_rep3_party(device: i32, curve: i32, zkey_path: *const c_char, pub_in: *const u64, wit_a: *const u64, wit_b: *const u64,
                                   blind_a: *const u64, blind_b: *const u64, net: *const cgh_rep3_net, rnd: *const cgh_rep3_rand, upto: i32,
                                   out_commits: *mut u64, out_evals: *mut u64, out_challenges: *mut u64) -> i32;
+    fn cgh_plonk_prove_rep3_party_ex(device: i32, curve: i32, zkey_path: *const c_char, pub_in: *const u64, wit_a: *const u64, wit_b: *const u64,
+                                     blind_a: *const u64, blind_b: *const u64, net: *const cgh_rep3_net, rnd: *const cgh_rep3_rand,
+                                     streams: *const cgh_rep3_chacha, upto: i32, out_commits: *mut u64, out_evals: *mut u64, out_challenges: *mut u64) -> i32;
     fn cgh_session_prove_rep3_party(session: *mut c_void, pub_in: *const u64, wit_a: *const u64, wit_b: *const u64, net: *const cgh_rep3_net,
                                     rnd: *const cgh_rep3_rand, out_proof: *mut u64, seconds: *mut f64) -> i32;
 }
@@ -200,10 +203,16 @@ where
     let fq = size_of::<<P::G1 as CurveGroup>::BaseField>() / 8;
     let mut commits = vec![0u64; 9 * 2 * fq];
     let mut evals = vec![P::ScalarField::zero(); 6];
+    // the masking vectors of the rounds' mul_vec calls are drawn on the GPU from the generators' seeds and positions (see prove_rep3)
+    let streams = cgh_rep3_chacha {
+        user: &mut state as *mut _ as *mut c_void,
+        get_state: Some(chacha_get_state::<P>),
+        set_word_pos: Some(chacha_set_word_pos::<P>),
+    };
     let rc = unsafe {
-        cgh_plonk_prove_rep3_party(device, curve_id::<P::ScalarField>(), path.as_ptr(), public_inputs.as_ptr() as *const u64, wit_a.as_ptr() as *const u64,
-                                   wit_b.as_ptr() as *const u64, ptr::null(), ptr::null(), &net, &rnd, 5, commits.as_mut_ptr(), evals.as_mut_ptr() as *mut u64,
-                                   ptr::null_mut())
+        cgh_plonk_prove_rep3_party_ex(device, curve_id::<P::ScalarField>(), path.as_ptr(), public_inputs.as_ptr() as *const u64, wit_a.as_ptr() as *const u64,
+                                      wit_b.as_ptr() as *const u64, ptr::null(), ptr::null(), &net, &rnd, &streams, 5, commits.as_mut_ptr(),
+                                      evals.as_mut_ptr() as *mut u64, ptr::null_mut())
     };
     if rc != 0 {
         return Err(state.error.take().unwrap_or_else(|| io::Error::new(io::ErrorKind::Other, host_error())));

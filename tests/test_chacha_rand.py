@@ -230,3 +230,43 @@ def test_seeded_shamir_parties_give_the_oracle_proof(curve, log_m, n, t, tmp_pat
     finally:
         for e in ends: e.close()
         ses.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_plonk_parties_with_device_drawn_masks(curve_name, monkeypatch):
+    """cgh_plonk_prove_rep3_party_ex: the mul_vec masks of rounds 2 and 3 (co-plonk/src/round2.rs, round3.rs) drawn on the GPU from the
+    described generators (threshold lowered so that the fixture's vectors qualify) — the same proof as with host-drawn masks, the
+    generators at the same positions afterwards, and the proof verifies; blinding drawn with rand() (round1.rs:93-99) in both runs"""
+    from test_plonk_rounds import fx as pfx, CURVES, rep3_share as share3
+    ensure_built()
+    monkeypatch.setenv("CGH_DEVICE_MASKS_MIN", "64")
+    curve = CURVES[curve_name]
+    zp = pfx(curve_name, "circuit.zkey")
+    npub = orc.plonk_zkey_info(curve, zp)["n_public"]
+    w = orc.read_wtns(curve, pfx(curve_name, "witness.wtns"))
+    rng = np.random.default_rng(77)
+    wa, wb = share3(curve, w[npub + 1:], rng)
+    seeds = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(3)]
+    runs = {}
+    for on_device in (True, False):
+        hub = cg.LoopbackHub()
+        rnds = [cg.ChaChaRand(curve, seeds[i], seeds[(i + 2) % 3]) for i in range(3)]
+        got, errs = [None] * 3, [None] * 3
+
+        def run(i):
+            try: got[i] = cg.plonk_prove_rep3_party(curve, zp, w[:npub + 1], wa[i], wb[i], hub.net(i), rnds[i].table, None, None, upto=5,
+                                                    streams_table=rnds[i].streams if on_device else None)
+            except Exception as e: errs[i] = e; hub.abort()
+        th = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+        for t in th: t.start()
+        for t in th: t.join(300)
+        assert errs == [None] * 3, errs
+        runs[on_device] = (got, [r.positions() for r in rnds])
+        for r in rnds: r.close()
+        hub.close()
+    for key in runs[True][0][0]:
+        for party in range(3):
+            np.testing.assert_array_equal(runs[True][0][party][key], runs[False][0][0][key], err_msg=f"{key} party {party}")
+    assert runs[True][1] == runs[False][1]
+    assert orc.plonk_verify(curve, zp, runs[True][0][0], w[1:npub + 1])
