@@ -65,6 +65,21 @@ def test_oracle_draws_follow_fp_rand(curve):
     assert [v for v in vals if v < MOD[curve]] == [to_int(x) for x in r3]
 
 
+def test_committed_regression_vectors():
+    """tests/golden/chacha_kats.json (written by make_chacha_kats.py from the oracle: regression vectors, not reference-produced): the oracle
+    and the host library still draw these values and end at these positions"""
+    import json
+    ensure_built()
+    kats = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chacha_kats.json")))
+    assert len(kats["cases"]) == 8
+    for c in kats["cases"]:
+        curve = {"bn254": BN254, "bls12_381": BLS12_381}[c["curve"]]
+        want = np.array([[int(l, 16) for l in v] for v in c["draws_montgomery_limbs_le"]], dtype=np.uint64)
+        for fn in (orc.chacha12_fr_rand, cg.chacha12_fr_rand_host):
+            got, after = fn(curve, bytes.fromhex(c["seed"]), c["word_pos"], c["n"])
+            np.testing.assert_array_equal(got, want); assert after == c["word_pos_after"]
+
+
 @pytest.mark.parametrize("curve", [BN254, BLS12_381])
 def test_host_library_draws_equal_the_oracle(curve):
     ensure_built()
