@@ -154,9 +154,10 @@ struct CallbackRand : Rep3RandSource {
         if (!has_streams) return false;
         uint8_t s1[32], s2[32]; uint64_t p1 = 0, p2 = 0, a1 = 0, a2 = 0;
         check(streams.get_state(streams.user, s1, &p1, s2, &p2), "get_state");
-        if (cg_chacha12_fr_rand_dev(ctx, curve, s1, p1, n, d_out, &a1) || cg_chacha12_fr_rand_dev(ctx, curve, s2, p2, n, d_tmp, &a2) ||
-            cg_vec_sub_dev(ctx, curve, d_out, d_out, d_tmp, n))
-            throw std::runtime_error(std::string("masks on the device: ") + cg_last_error());
+        int32_t rc = cg_chacha12_fr_rand_dev(ctx, curve, s1, p1, n, d_out, &a1);
+        if (!rc) rc = cg_chacha12_fr_rand_dev(ctx, curve, s2, p2, n, d_tmp, &a2);
+        if (rc == CG_ERR_OOM) return false;                            // no room for the candidates: the generators have not moved, the host callback draws instead
+        if (rc || cg_vec_sub_dev(ctx, curve, d_out, d_out, d_tmp, n)) throw std::runtime_error(std::string("masks on the device: ") + cg_last_error());
         check(streams.set_word_pos(streams.user, a1, a2), "set_word_pos");
         return true;
     }
