@@ -684,6 +684,21 @@ class ShamirRandTable(C.Structure):
     _fields_ = [("user", C.c_void_p), ("random_field_elements", _SH_RAND)]
 
 
+class ShamirLoopbackHub:
+    """n Shamir parties of one process joined by in-memory queues (cgh_shamir_loopback_*); net(i) is party i's callback table"""
+
+    def __init__(self, n):
+        self.h = C.c_void_p(); _hchk(load_host().cgh_shamir_loopback_create(int(n), C.byref(self.h)))
+
+    def net(self, party):
+        t = ShamirNetTable(); _hchk(load_host().cgh_shamir_loopback_net(self.h, int(party), C.byref(t))); return t
+
+    def abort(self): load_host().cgh_shamir_loopback_abort(self.h)
+
+    def close(self):
+        if self.h: load_host().cgh_shamir_loopback_destroy(self.h); self.h = None
+
+
 def host_prove_shamir_party(session, threshold, pub, wit, net_table, rand_table, preprocess=0):
     """ONE Shamir party on an open ProvingSession through the callback ABI; returns (proof, seconds).  Call it from one thread per party."""
     nq = 6 if session.curve == BLS12_381 else 4

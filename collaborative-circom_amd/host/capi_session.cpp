@@ -272,6 +272,31 @@ int32_t cgh_loopback_replay_net(void* hub, int32_t party, cgh_rep3_net* out) {
 int32_t cgh_loopback_abort(void* hub) { if (hub) ((Loopback*)hub)->hub.abort(); return 0; }
 int32_t cgh_loopback_destroy(void* hub) { delete (Loopback*)hub; return 0; }
 
+// ---- the Shamir twin of the loopback: n parties of one process joined by in-memory queues behind cgh_shamir_net tables ----------------------
+namespace {
+struct ShamirLoopback {
+    cgh::InProcShamirHub hub;
+    std::vector<std::unique_ptr<cgh::InProcShamirNet>> nets; std::mutex mu;
+    explicit ShamirLoopback(int n) : hub(n) {}
+};
+int32_t sl_send(void* u, int32_t to, const void* d, size_t b) { try { ((cgh::InProcShamirNet*)u)->send(to, d, b); return 0; } catch (const std::exception& e) { g_host_err = e.what(); return 1; } }
+int32_t sl_recv(void* u, int32_t from, void* d, size_t b) { try { ((cgh::InProcShamirNet*)u)->recv(from, d, b); return 0; } catch (const std::exception& e) { g_host_err = e.what(); return 1; } }
+}
+int32_t cgh_shamir_loopback_create(int32_t num_parties, void** out) {
+    if (!out || num_parties < 3 || num_parties > 64) { g_host_err = "cgh_shamir_loopback_create: bad argument"; return 1; }
+    try { *out = new ShamirLoopback(num_parties); return 0; } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+int32_t cgh_shamir_loopback_net(void* hub, int32_t party, cgh_shamir_net* out) {
+    ShamirLoopback* lb = (ShamirLoopback*)hub;
+    if (!lb || !out || party < 0 || party >= lb->hub.n) { g_host_err = "cgh_shamir_loopback_net: bad argument"; return 1; }
+    std::lock_guard<std::mutex> l(lb->mu);
+    lb->nets.emplace_back(new cgh::InProcShamirNet(&lb->hub, party));
+    out->user = lb->nets.back().get(); out->party_id = party; out->num_parties = lb->hub.n; out->send = sl_send; out->recv = sl_recv;
+    return 0;
+}
+int32_t cgh_shamir_loopback_abort(void* hub) { if (hub) ((ShamirLoopback*)hub)->hub.abort(); return 0; }
+int32_t cgh_shamir_loopback_destroy(void* hub) { delete (ShamirLoopback*)hub; return 0; }
+
 // ---- Rep3Rand over two pre-generated streams (rngs.rs:25-62 with the ChaCha draws done by the caller) -------------------------------------
 namespace {
 struct StreamRand {

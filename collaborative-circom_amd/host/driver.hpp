@@ -204,7 +204,7 @@ public:
         std::vector<void*> d_got(np);
         for (int from = 0; from < np; from++) d_got[from] = dalloc(2 * amount * 32);
         void* d_pairs = dalloc(2 * amount * 32);
-        std::vector<Fr> buf(2 * amount);
+        Fr* const buf = mask_scratch(2 * amount);                                      // page-locked staging (parked by the host cache between proofs): the copies are plain DMA
         for (int to = 0; to < np; to++) {                                              // ShamirCore::share for the receiver's point to + 1
             void* dst = to == me ? d_got[me] : d_pairs;
             const Fr x = fr_from_u64(curve, (uint64_t)to + 1);
@@ -216,10 +216,10 @@ public:
                 xp = fr_mul(curve, xp, x);
             }
             lincomb(dst, 0, 2, amount, a); lincomb(dst, 1, 2, amount, b);
-            if (to != me) { CG(cg_dev_download(ctx, buf.data(), d_pairs, 2 * amount * 32)); snet->send(to, buf.data(), 2 * amount * 32); }
+            if (to != me) { CG(cg_dev_download(ctx, buf, d_pairs, 2 * amount * 32)); snet->send(to, buf, 2 * amount * 32); }
         }
         mk.mark("share+send");
-        for (int from = 0; from < np; from++) if (from != me) { snet->recv(from, buf.data(), 2 * amount * 32); CG(cg_dev_upload(ctx, d_got[from], buf.data(), 2 * amount * 32)); check_received_dev(d_got[from], 2 * amount); }
+        for (int from = 0; from < np; from++) if (from != me) { snet->recv(from, buf, 2 * amount * 32); CG(cg_dev_upload(ctx, d_got[from], buf, 2 * amount * 32)); check_received_dev(d_got[from], 2 * amount); }
         mk.mark("recv+upload");
         // Vandermonde rows 1, x, .., x^t over the senders' points (shamir.rs:904-921): t + 1 outputs per secret
         const size_t outn = amount * (size_t)(t + 1);
@@ -268,22 +268,32 @@ public:
             CG(cg_dev_upload(ctx, tmp, r2t.data(), len * 32));
             CG(cg_vec_add_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));      // input += r_2t
         }
-        std::vector<Fr> buf(len);
+        Fr* const buf = mask_scratch(len);                                             // page-locked staging of the messages to / from the king
         mk.mark("add r_2t");
         if (me == 0) {                                                                 // KING_ID: interpolate at 0 from parties 0..2t, re-share with degree t
             CG(cg_vec_affine_dev(ctx, curve.id, local.c[0], local.c[0], len, mul_lagrange_2t[0].v, nullptr));   // acc = input * lagrange_0
             for (int other = 1; other <= 2 * sh_t; other++) {
-                snet->recv(other, buf.data(), len * 32);
-                CG(cg_dev_upload(ctx, tmp, buf.data(), len * 32)); check_received_dev(tmp, len);
+                snet->recv(other, buf, len * 32);
+                CG(cg_dev_upload(ctx, tmp, buf, len * 32)); check_received_dev(tmp, len);
                 CG(cg_vec_affine_dev(ctx, curve.id, tmp, tmp, len, mul_lagrange_2t[other].v, nullptr));
                 CG(cg_vec_add_dev(ctx, curve.id, local.c[0], local.c[0], tmp, len));
             }
             mk.mark("recv+interpolate");
             // ShamirCore::share per element: coefficients are drawn element by element (t per element)
-            std::vector<std::vector<Fr>> coeff(sh_t, std::vector<Fr>(len));
-            for (size_t k = 0; k < len; k++) for (int d = 0; d < sh_t; d++) coeff[d][k] = next_rand();
             std::vector<void*> d_coeff(sh_t);
-            for (int d = 0; d < sh_t; d++) { d_coeff[d] = dalloc(len * 32); CG(cg_dev_upload(ctx, d_coeff[d], coeff[d].data(), len * 32)); }
+            for (int d = 0; d < sh_t; d++) d_coeff[d] = dalloc(len * 32);
+            if (sh_gen_on && len * (size_t)sh_t >= DEVICE_MASKS_MIN) {
+                // the party's own ChaCha12 stream: draw k * t + d is coefficient d of element k — all len * t draws on the device, then de-interleaved
+                void* d_all = dalloc(len * (size_t)sh_t * 32); uint64_t after = 0;
+                CG(cg_chacha12_fr_rand_dev(ctx, curve.id, (const uint8_t*)sh_gen.key, sh_gen.word_pos, len * (size_t)sh_t, d_all, &after));
+                sh_gen.word_pos = after;
+                for (int d = 0; d < sh_t; d++) CG(cg_vec_gather_strided_dev(ctx, curve.id, d_coeff[d], d_all, len, (size_t)d, (size_t)sh_t));
+                CG(cg_dev_free(ctx, d_all));
+            } else {
+                std::vector<std::vector<Fr>> coeff(sh_t, std::vector<Fr>(len));
+                for (size_t k = 0; k < len; k++) for (int d = 0; d < sh_t; d++) coeff[d][k] = next_rand();
+                for (int d = 0; d < sh_t; d++) CG(cg_dev_upload(ctx, d_coeff[d], coeff[d].data(), len * 32));
+            }
             void* share = dalloc(len * 32); void* term = dalloc(len * 32);
             void* mine = dalloc(len * 32);
             for (int to = np - 1; to >= 0; to--) {                                     // any order: every share is a function of (acc, coeffs) only
@@ -297,18 +307,18 @@ public:
                 }
                 if (sh_t == 0) { CG(cg_dev_memset_zero(ctx, share, len * 32)); CG(cg_vec_add_dev(ctx, curve.id, share, share, local.c[0], len)); }
                 if (to == 0) { CG(cg_dev_memset_zero(ctx, mine, len * 32)); CG(cg_vec_add_dev(ctx, curve.id, mine, mine, share, len)); }
-                else { CG(cg_dev_download(ctx, buf.data(), share, len * 32)); snet->send(to, buf.data(), len * 32); }
+                else { CG(cg_dev_download(ctx, buf, share, len * 32)); snet->send(to, buf, len * 32); }
             }
             CG(cg_dev_free(ctx, local.c[0])); local.c[0] = mine;
             for (void* p : d_coeff) CG(cg_dev_free(ctx, p));
             CG(cg_dev_free(ctx, share)); CG(cg_dev_free(ctx, term));
             mk.mark("reshare+send");
         } else {
-            if (me <= 2 * sh_t) { CG(cg_dev_download(ctx, buf.data(), local.c[0], len * 32)); snet->send(0, buf.data(), len * 32); }   // only if my items are required
+            if (me <= 2 * sh_t) { CG(cg_dev_download(ctx, buf, local.c[0], len * 32)); snet->send(0, buf, len * 32); }   // only if my items are required
             mk.mark("download+send");
-            snet->recv(0, buf.data(), len * 32);
+            snet->recv(0, buf, len * 32);
             mk.mark("wait for king");
-            CG(cg_dev_upload(ctx, local.c[0], buf.data(), len * 32)); check_received_dev(local.c[0], len);
+            CG(cg_dev_upload(ctx, local.c[0], buf, len * 32)); check_received_dev(local.c[0], len);
             mk.mark("upload");
         }
         if (on_dev) {

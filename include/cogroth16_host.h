@@ -185,6 +185,12 @@ int32_t cgh_loopback_replay_net(void* hub, int32_t party, cgh_rep3_net* out);
 /* a party failed: the others' pending and later receives fail instead of waiting for messages that will never come */
 int32_t cgh_loopback_abort(void* hub);
 int32_t cgh_loopback_destroy(void* hub);
+/* The Shamir twin of the loopback: num_parties (3..64) parties of one process joined by in-memory queues, any to any
+ * (the role of tests/src/shamir_network.rs); net(party) fills that party's callback table. */
+int32_t cgh_shamir_loopback_create(int32_t num_parties, void** out_hub);
+int32_t cgh_shamir_loopback_net(void* hub, int32_t party, cgh_shamir_net* out);
+int32_t cgh_shamir_loopback_abort(void* hub);
+int32_t cgh_shamir_loopback_destroy(void* hub);
 /* Rep3Rand over two pre-generated streams of field elements (rng1[k], rng2[k] = the k-th F::rand of each ChaCha stream): masks are
  * rng1[k] - rng2[k] (computed here, once, into page-locked memory), random_fes returns (rng1[k], rng2[k]), masking_ec_element is
  * G * rng1[k] - G * rng2[k] (a stand-in for C::rand, which no caller can reproduce without arkworks; the proof does not depend on it).
