@@ -285,3 +285,40 @@ def test_plonk_parties_with_device_drawn_masks(curve_name, monkeypatch):
             np.testing.assert_array_equal(runs[True][0][party][key], runs[False][0][0][key], err_msg=f"{key} party {party}")
     assert runs[True][1] == runs[False][1]
     assert orc.plonk_verify(curve, zp, runs[True][0][0], w[1:npub + 1])
+
+
+@pytest.mark.gpu
+def test_seeded_shamir_parties_over_the_library_mesh(monkeypatch):
+    """the same entry over cgh_shamir_loopback_* (no Python in the data path) on the poseidon fixture, the device-draw threshold lowered so
+    that both the preprocess batch and the king's re-sharing coefficients (shamir.rs:347-360: t draws per element, element by element) come
+    from the kernels — the oracle's proof on the oracle's own draws from the same seeds"""
+    from test_shamir import fx as sfx
+    ensure_built()
+    monkeypatch.setenv("CGH_DEVICE_MASKS_MIN", "32")
+    curve, n, t = BN254, 5, 2
+    zp = sfx("bn254", "poseidon", "circuit.zkey")
+    z = orc.ZKey(curve, zp); w = orc.read_wtns(curve, sfx("bn254", "poseidon", "witness.wtns"))
+    rng = np.random.default_rng(31)
+    pub = w[:z.n_public + 1]
+    wits = orc.shamir_share(curve, w[z.n_public + 1:], n, t, rng)
+    amount = (2 * z.domain_size + 8) // (t + 1) + 1
+    seeds = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n)]
+    length = (1024 + amount) * (1 + 3 * t) + t * (2 * z.domain_size + 8) + 64
+    streams = [orc.chacha12_fr_rand(curve, s, 0, length)[0] for s in seeds]
+    want = orc.prove_shamir(z, n, t, pub, wits, streams, preprocess=amount)
+    ses = cg.ProvingSession(curve, zp, precompute=False)
+    hub = cg.ShamirLoopbackHub(n)
+    nets = [hub.net(i) for i in range(n)]
+    out, errs = [None] * n, [None] * n
+
+    def party(i):
+        try: out[i], _ = cg.host_prove_shamir_party_seeded(ses, t, pub, wits[i], nets[i], seeds[i], preprocess=amount)
+        except Exception as e: errs[i] = e; hub.abort()
+    try:
+        th = [threading.Thread(target=party, args=(i,)) for i in range(n)]
+        for x in th: x.start()
+        for x in th: x.join(300)
+        assert errs == [None] * n, errs
+        np.testing.assert_array_equal(np.stack(out), want)
+    finally:
+        hub.close(); ses.close()

@@ -179,6 +179,38 @@ def test_loopback_tables_move_messages_between_threads():
         hub.close()
 
 
+def test_shamir_loopback_mesh_moves_messages_any_to_any():
+    """cgh_shamir_loopback_*: n parties of one process behind cgh_shamir_net tables (shamir/network.rs:17-59: one message = one send / recv
+    pair between two parties, FIFO per directed pair); a wrong size is an error, abort wakes a waiting receiver"""
+    ensure_built()
+    with pytest.raises(cg.BackendError):
+        cg.ShamirLoopbackHub(2)                                                           # shamir/network.rs:75-77: at least three parties
+    hub = cg.ShamirLoopbackHub(4)
+    try:
+        with pytest.raises(cg.BackendError):
+            hub.net(4)
+        nets = [hub.net(i) for i in range(4)]
+        assert [(n.party_id, n.num_parties) for n in nets] == [(0, 4), (1, 4), (2, 4), (3, 4)]
+        a = np.arange(500, dtype=np.uint64); b = np.arange(7, dtype=np.uint64) + 1000
+        assert nets[0].send(nets[0].user, 3, a.ctypes.data, a.nbytes) == 0
+        assert nets[0].send(nets[0].user, 3, b.ctypes.data, b.nbytes) == 0                # second message on the same pair: FIFO
+        assert nets[2].send(nets[2].user, 1, b.ctypes.data, b.nbytes) == 0
+        ga = np.zeros_like(a); gb = np.zeros_like(b); gc = np.zeros_like(b)
+        t = threading.Thread(target=lambda: (nets[3].recv(nets[3].user, 0, ga.ctypes.data, ga.nbytes), nets[3].recv(nets[3].user, 0, gb.ctypes.data, gb.nbytes),
+                                             nets[1].recv(nets[1].user, 2, gc.ctypes.data, gc.nbytes)))
+        t.start(); t.join(30)
+        np.testing.assert_array_equal(ga, a); np.testing.assert_array_equal(gb, b); np.testing.assert_array_equal(gc, b)
+        assert nets[1].send(nets[1].user, 0, a.ctypes.data, 64) == 0
+        assert nets[0].recv(nets[0].user, 1, ga.ctypes.data, 32) != 0                      # shamir.rs:324-329
+        assert b"Invalid number of elements" in cg.load_host().cgh_last_error()
+        res = []
+        t = threading.Thread(target=lambda: res.append(nets[2].recv(nets[2].user, 3, ga.ctypes.data, 8)))
+        t.start(); hub.abort(); t.join(30)
+        assert res and res[0] != 0
+    finally:
+        hub.close()
+
+
 @pytest.mark.parametrize("curve", [BN254, BLS12_381])
 def test_stream_rand_follows_rep3rand(curve):
     """rngs.rs:37-46: masking element = rand(rng1) - rand(rng2), random_fes = the pair; every draw advances both streams by one"""
