@@ -40,6 +40,17 @@ namespace cgh {
 
 typedef std::vector<uint8_t> Bytes;
 struct Fr { uint64_t v[4]; };
+// std::vector storage whose resize() leaves new elements uninitialised: the 2 x 268 MB host mirrors of the preprocessed Shamir pairs are only
+// placeholders while the values live on the device, and value-initialising them costs ~100 ms of page faults per party at 2^22
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<Fr, NoInitAlloc<Fr>> FrLazyVec;
 
 [[noreturn]] static void die(const std::string& what) { throw std::runtime_error(what + ": " + cg_last_error()); }
 #define CG(call) do { if ((call) != 0) die(#call); } while (0)

@@ -85,7 +85,8 @@ public:
 
     // ---- Shamir state (shamir.rs:196-246): threshold, Lagrange tables, buffered double sharings; randomness = stream rng1
     ShamirNet* snet = nullptr; int sh_t = 0;
-    std::vector<Fr> open_lagrange_t, open_lagrange_2t, mul_lagrange_2t, sh_r_t, sh_r_2t;
+    std::vector<Fr> open_lagrange_t, open_lagrange_2t, mul_lagrange_2t;
+    FrLazyVec sh_r_t, sh_r_2t;                                                           // LIFO pair buffers (shamir.rs:873-880); resize() does not touch the new elements
     // preprocessed pairs stay on the device: entries [pre_base, pre_base + pre_n) of the two buffers above are held in d_pre_* and
     // copied to the host only when a scalar pop or the lazy path needs them
     void* d_pre_rt = nullptr; void* d_pre_r2t = nullptr; size_t pre_base = 0, pre_n = 0; bool pre_on_host = true;
@@ -141,7 +142,7 @@ public:
         }
         return shares;
     }
-    void vandermonde_mul(const std::vector<Fr>& in, std::vector<Fr>& out) {            // shamir.rs:904-921 (appends t + 1 values)
+    void vandermonde_mul(const std::vector<Fr>& in, FrLazyVec& out) {            // shamir.rs:904-921 (appends t + 1 values)
         const int np = snet->num_parties();
         std::vector<Fr> row(np), cur(np);
         for (int i = 0; i < np; i++) { row[i] = fr_from_u64(curve, (uint64_t)i + 1); cur[i] = row[i]; }
