@@ -690,8 +690,11 @@ class ShamirLoopbackHub:
     def __init__(self, n):
         self.h = C.c_void_p(); _hchk(load_host().cgh_shamir_loopback_create(int(n), C.byref(self.h)))
 
-    def net(self, party):
-        t = ShamirNetTable(); _hchk(load_host().cgh_shamir_loopback_net(self.h, int(party), C.byref(t))); return t
+    def net(self, party, record=False):
+        t = ShamirNetTable(); _hchk(load_host().cgh_shamir_loopback_net(self.h, int(party), int(bool(record)), C.byref(t))); return t
+
+    def replay_net(self, party):
+        t = ShamirNetTable(); _hchk(load_host().cgh_shamir_loopback_replay_net(self.h, int(party), C.byref(t))); return t
 
     def abort(self): load_host().cgh_shamir_loopback_abort(self.h)
 

@@ -274,25 +274,73 @@ int32_t cgh_loopback_destroy(void* hub) { delete (Loopback*)hub; return 0; }
 
 // ---- the Shamir twin of the loopback: n parties of one process joined by in-memory queues behind cgh_shamir_net tables ----------------------
 namespace {
+// what one party received, per sender, in order (large messages in page-locked memory): served again by ReplayShamirNet
+struct ShamirRecord {
+    struct Msg { void* p; size_t bytes; bool pinned; };
+    std::vector<std::vector<Msg>> from;
+    explicit ShamirRecord(int n) : from(n) {}
+    ~ShamirRecord() { for (auto& q : from) for (Msg& m : q) { if (m.pinned) cg_host_free(m.p); else free(m.p); } }
+    void keep(int sender, const void* d, size_t b) {
+        Msg m{nullptr, b, false};
+        if (b >= ((size_t)1 << 20) && cg_host_alloc(b, &m.p) == 0) m.pinned = true;
+        else if (!(m.p = malloc(std::max<size_t>(b, 1)))) throw std::runtime_error("out of memory");
+        memcpy(m.p, d, b); from[sender].push_back(m);
+    }
+};
+struct RecordingShamirNet : cgh::ShamirNet {
+    cgh::InProcShamirNet inner; ShamirRecord* rec;
+    RecordingShamirNet(cgh::InProcShamirHub* h, int i, ShamirRecord* r) : inner(h, i), rec(r) {}
+    int id() const override { return inner.id(); }
+    int num_parties() const override { return inner.num_parties(); }
+    void send(int to, const void* d, size_t b) override { inner.send(to, d, b); }
+    void recv(int from, void* d, size_t b) override { inner.recv(from, d, b); if (rec) rec->keep(from, d, b); }
+};
+// the party ALONE: its sends are dropped, its receives are the recorded messages (a wrong size or an empty record is an error)
+struct ReplayShamirNet : cgh::ShamirNet {
+    int me, n; const ShamirRecord* rec; std::vector<size_t> next;
+    ReplayShamirNet(int i, int np, const ShamirRecord* r) : me(i), n(np), rec(r), next(np, 0) {}
+    int id() const override { return me; }
+    int num_parties() const override { return n; }
+    void send(int, const void*, size_t) override {}
+    void recv(int from, void* d, size_t b) override {
+        if (from < 0 || from >= n || next[from] >= rec->from[from].size()) throw std::runtime_error("replay: no recorded message left from that party");
+        const ShamirRecord::Msg& m = rec->from[from][next[from]++];
+        if (m.bytes != b) throw std::runtime_error("During execution of MPC: Invalid number of elements received");
+        memcpy(d, m.p, b);
+    }
+};
 struct ShamirLoopback {
     cgh::InProcShamirHub hub;
-    std::vector<std::unique_ptr<cgh::InProcShamirNet>> nets; std::mutex mu;
-    explicit ShamirLoopback(int n) : hub(n) {}
+    std::vector<std::unique_ptr<cgh::ShamirNet>> nets; std::vector<std::unique_ptr<ShamirRecord>> recs; std::mutex mu;
+    explicit ShamirLoopback(int n) : hub(n), recs(n) {}
 };
-int32_t sl_send(void* u, int32_t to, const void* d, size_t b) { try { ((cgh::InProcShamirNet*)u)->send(to, d, b); return 0; } catch (const std::exception& e) { g_host_err = e.what(); return 1; } }
-int32_t sl_recv(void* u, int32_t from, void* d, size_t b) { try { ((cgh::InProcShamirNet*)u)->recv(from, d, b); return 0; } catch (const std::exception& e) { g_host_err = e.what(); return 1; } }
+int32_t sl_send(void* u, int32_t to, const void* d, size_t b) { try { ((cgh::ShamirNet*)u)->send(to, d, b); return 0; } catch (const std::exception& e) { g_host_err = e.what(); return 1; } }
+int32_t sl_recv(void* u, int32_t from, void* d, size_t b) { try { ((cgh::ShamirNet*)u)->recv(from, d, b); return 0; } catch (const std::exception& e) { g_host_err = e.what(); return 1; } }
 }
 int32_t cgh_shamir_loopback_create(int32_t num_parties, void** out) {
     if (!out || num_parties < 3 || num_parties > 64) { g_host_err = "cgh_shamir_loopback_create: bad argument"; return 1; }
     try { *out = new ShamirLoopback(num_parties); return 0; } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
-int32_t cgh_shamir_loopback_net(void* hub, int32_t party, cgh_shamir_net* out) {
+int32_t cgh_shamir_loopback_net(void* hub, int32_t party, int32_t record, cgh_shamir_net* out) {
     ShamirLoopback* lb = (ShamirLoopback*)hub;
     if (!lb || !out || party < 0 || party >= lb->hub.n) { g_host_err = "cgh_shamir_loopback_net: bad argument"; return 1; }
-    std::lock_guard<std::mutex> l(lb->mu);
-    lb->nets.emplace_back(new cgh::InProcShamirNet(&lb->hub, party));
-    out->user = lb->nets.back().get(); out->party_id = party; out->num_parties = lb->hub.n; out->send = sl_send; out->recv = sl_recv;
-    return 0;
+    try {
+        std::lock_guard<std::mutex> l(lb->mu);
+        if (record) lb->recs[party].reset(new ShamirRecord(lb->hub.n));
+        lb->nets.emplace_back(new RecordingShamirNet(&lb->hub, party, record ? lb->recs[party].get() : nullptr));
+        out->user = lb->nets.back().get(); out->party_id = party; out->num_parties = lb->hub.n; out->send = sl_send; out->recv = sl_recv;
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
+}
+int32_t cgh_shamir_loopback_replay_net(void* hub, int32_t party, cgh_shamir_net* out) {
+    ShamirLoopback* lb = (ShamirLoopback*)hub;
+    if (!lb || !out || party < 0 || party >= lb->hub.n || !lb->recs[party]) { g_host_err = "cgh_shamir_loopback_replay_net: bad argument or nothing recorded for that party"; return 1; }
+    try {
+        std::lock_guard<std::mutex> l(lb->mu);
+        lb->nets.emplace_back(new ReplayShamirNet(party, lb->hub.n, lb->recs[party].get()));
+        out->user = lb->nets.back().get(); out->party_id = party; out->num_parties = lb->hub.n; out->send = sl_send; out->recv = sl_recv;
+        return 0;
+    } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
 int32_t cgh_shamir_loopback_abort(void* hub) { if (hub) ((ShamirLoopback*)hub)->hub.abort(); return 0; }
 int32_t cgh_shamir_loopback_destroy(void* hub) { delete (ShamirLoopback*)hub; return 0; }

@@ -188,7 +188,10 @@ int32_t cgh_loopback_destroy(void* hub);
 /* The Shamir twin of the loopback: num_parties (3..64) parties of one process joined by in-memory queues, any to any
  * (the role of tests/src/shamir_network.rs); net(party) fills that party's callback table. */
 int32_t cgh_shamir_loopback_create(int32_t num_parties, void** out_hub);
-int32_t cgh_shamir_loopback_net(void* hub, int32_t party, cgh_shamir_net* out);
+int32_t cgh_shamir_loopback_net(void* hub, int32_t party, int32_t record, cgh_shamir_net* out);
+/* record != 0 keeps what that party receives (large messages in page-locked memory); the replay table then serves it again to the same
+ * party running ALONE, sends dropped — one party's cost with its peers elsewhere, network time excluded (as cgh_loopback_replay_net). */
+int32_t cgh_shamir_loopback_replay_net(void* hub, int32_t party, cgh_shamir_net* out);
 int32_t cgh_shamir_loopback_abort(void* hub);
 int32_t cgh_shamir_loopback_destroy(void* hub);
 /* Rep3Rand over two pre-generated streams of field elements (rng1[k], rng2[k] = the k-th F::rand of each ChaCha stream): masks are

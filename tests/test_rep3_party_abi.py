@@ -189,8 +189,10 @@ def test_shamir_loopback_mesh_moves_messages_any_to_any():
     try:
         with pytest.raises(cg.BackendError):
             hub.net(4)
-        nets = [hub.net(i) for i in range(4)]
+        nets = [hub.net(i, record=(i == 3)) for i in range(4)]
         assert [(n.party_id, n.num_parties) for n in nets] == [(0, 4), (1, 4), (2, 4), (3, 4)]
+        with pytest.raises(cg.BackendError):
+            hub.replay_net(1)                                                             # nothing was recorded for party 1
         a = np.arange(500, dtype=np.uint64); b = np.arange(7, dtype=np.uint64) + 1000
         assert nets[0].send(nets[0].user, 3, a.ctypes.data, a.nbytes) == 0
         assert nets[0].send(nets[0].user, 3, b.ctypes.data, b.nbytes) == 0                # second message on the same pair: FIFO
@@ -200,6 +202,14 @@ def test_shamir_loopback_mesh_moves_messages_any_to_any():
                                              nets[1].recv(nets[1].user, 2, gc.ctypes.data, gc.nbytes)))
         t.start(); t.join(30)
         np.testing.assert_array_equal(ga, a); np.testing.assert_array_equal(gb, b); np.testing.assert_array_equal(gc, b)
+        # party 3's traffic was recorded: the replay table serves it again (twice: every table starts from the first message), sends are dropped
+        for _ in range(2):
+            rp = hub.replay_net(3)
+            ga[:] = 0; gb[:] = 0
+            assert rp.send(rp.user, 0, a.ctypes.data, 8) == 0
+            assert rp.recv(rp.user, 0, ga.ctypes.data, ga.nbytes) == 0 and rp.recv(rp.user, 0, gb.ctypes.data, gb.nbytes) == 0
+            np.testing.assert_array_equal(ga, a); np.testing.assert_array_equal(gb, b)
+            assert rp.recv(rp.user, 0, ga.ctypes.data, 8) != 0 and rp.recv(rp.user, 1, ga.ctypes.data, 8) != 0      # nothing left / nothing from party 1
         assert nets[1].send(nets[1].user, 0, a.ctypes.data, 64) == 0
         assert nets[0].recv(nets[0].user, 1, ga.ctypes.data, 32) != 0                      # shamir.rs:324-329
         assert b"Invalid number of elements" in cg.load_host().cgh_last_error()
