@@ -542,6 +542,50 @@ def session_leg(ctx, log_m, device):
                               "reference's party does (rep3/rngs.rs:37-46)"}
         except Exception as e:                                                          # noqa: BLE001 (a secondary figure must not take the bench line down)
             chacha = {"error": str(e)[:300]}
+        # The Shamir twin (co-circom.rs:507-527), t = 1 of 3: three seeded parties over the library's in-memory mesh, then party 1 (and the king)
+        # ALONE on the GPU with the received messages replayed; preprocess of 2 m / (t + 1) secrets (its draws on the GPU) inside the call.
+        shamir = None
+        try:
+            dr = rand_fr(n_aux, device, g)
+            dw = torch.from_numpy(np.ascontiguousarray(w[2:]).view(np.int64)).to(device)
+            swits, cur = [], dw
+            for _ in range(3):                                                          # w + r x at x = 1, 2, 3 (shamir_core.rs:8-31)
+                nxt = torch.empty_like(dw); ctx.vec_add(CURVE, nxt, cur, dr, n_aux); ctx.sync(); torch.cuda.synchronize()
+                swits.append(pin(host(nxt))); cur = nxt
+            del dr, dw, cur, nxt
+            pre = (2 * m + 8) // 2 + 1
+            sseeds = [bytes((29 * i + 13 * k + 3) & 255 for k in range(32)) for i in range(3)]
+            hubs = cg.ShamirLoopbackHub(3)
+            snets = [hubs.net(i, record=True) for i in range(3)]
+            souts, serrs = [None] * 3, [None] * 3
+
+            def party_s(i):
+                try: souts[i], _ = cg.host_prove_shamir_party_seeded(ses, 1, w[:2], swits[i], snets[i], sseeds[i], preprocess=pre)
+                except Exception as e: serrs[i] = e; hubs.abort()
+            th = [threading.Thread(target=party_s, args=(i,)) for i in range(3)]
+            t0 = time.perf_counter()
+            for t in th: t.start()
+            for t in th: t.join()
+            t3 = time.perf_counter() - t0
+            if any(serrs): raise RuntimeError(f"Shamir parties failed: {serrs}")
+            alone = {}
+            for i in (1, 0):
+                secs = []
+                for _ in range(3):
+                    got, sec = cg.host_prove_shamir_party_seeded(ses, 1, w[:2], swits[i], hubs.replay_net(i), sseeds[i], preprocess=pre)
+                    if not (got == souts[0]).all(): raise RuntimeError("Shamir: replayed party produced a different proof")
+                    secs.append(sec * 1e3)
+                alone[i] = secs
+            hubs.close()
+            for x in swits: ctx.host_free(x)
+            shamir = {"entry": "cgh_session_prove_shamir_party_seeded (t = 1 of 3; the party's generator seeded by the caller, its draws on the GPU)",
+                      "party_ms": sum(alone[1]) / 3, "party_ms_min": min(alone[1]), "king_ms": sum(alone[0]) / 3, "three_parties_one_gpu_ms": t3 * 1e3,
+                      "party_constraints_per_s": (m - 2) / (sum(alone[1]) / 3 * 1e-3), "preprocess_secrets": pre, "draws_on_gpu": pre * 4,
+                      "three_parties_agree": bool((souts[0] == souts[1]).all() and (souts[1] == souts[2]).all()),
+                      "note": "one party alone on the GPU, the messages it received replayed from page-locked memory (network excluded); preprocessing, both "
+                              "degree reductions and every message crossing PCIe inside the timed call"}
+        except Exception as e:                                                          # noqa: BLE001
+            shamir = {"error": str(e)[:300]}
         ses.close()
         # The opt-in REP3 variant (CGH_SESSION_ADDITIVE_H): not the reference's message sequence — reported beside the product entry,
         # never as it.  Same shares, same randomness: the proofs must be the reference protocol's, bit for bit.
@@ -574,7 +618,7 @@ def session_leg(ctx, log_m, device):
         return {"entry_points": "cgh_session_prove_plain / cgh_session_prove_rep3_party (host buffers in, proof out; network and randomness through the callback tables)",
                 "pcie_inclusive": True, "plain_ms": t_plain * 1e3, "plain_constraints_per_s": nc / t_plain,
                 "rep3_party_ms": t_party_mean * 1e3, "rep3_party_ms_min": t_party * 1e3, "rep3_party_proofs": len(solo), "rep3_party_constraints_per_s": nc / t_party_mean,
-                "rep3_three_parties_one_gpu_ms": min(t_three) * 1e3, "three_parties_agree": agree, "chacha12_randomness": chacha, "additive_h_variant": variant,
+                "rep3_three_parties_one_gpu_ms": min(t_three) * 1e3, "three_parties_agree": agree, "chacha12_randomness": chacha, "shamir_party": shamir, "additive_h_variant": variant,
                 "zkey": {"generate_s": t_gen, "session_open_s": t_open, "file_bytes": os.path.getsize(zp),
                          "note": "session_open = map + decode the file, upload, validate every point on the GPU (on-curve + subgroup), precompute the window tables"}}
     finally:
