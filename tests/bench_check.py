@@ -10,25 +10,32 @@ TABLE_GROUP = {"h": G1, "l": G1, "a": G1, "b1": G1, "b2": G2}
 TABLE_FIRST = {"h": 1, "l": 3, "a": 5, "b1": 7, "b2": 1}     # mirrors bench.TABLE_FIRST (checked by the test)
 R_BN254 = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
-mul = lambda x, y: orc.field_op(BN254, FR, "mul", x, y)
-add = lambda x, y: orc.field_op(BN254, FR, "add", x, y)
-sub = lambda x, y: orc.field_op(BN254, FR, "sub", x, y)
+mul = lambda x, y, curve=BN254: orc.field_op(curve, FR, "mul", x, y)
+add = lambda x, y, curve=BN254: orc.field_op(curve, FR, "add", x, y)
+sub = lambda x, y, curve=BN254: orc.field_op(curve, FR, "sub", x, y)
 
 
-def to_mont(raw):
-    """(n, 4) canonical limbs -> Montgomery form: mont_mul(x, R^2) = x R"""
-    r2 = orc.from_dec(BN254, FR, str(pow(2, 256, R_BN254)))        # Montgomery representative of R = raw limbs of R^2 mod r
-    return mul(raw, np.broadcast_to(r2, raw.shape).copy())
+def to_mont(raw, curve=BN254):
+    """(n, 4) canonical limbs -> Montgomery form: mont_mul(x, R^2) = x R   (R = 2^256 for both scalar fields)"""
+    r2 = orc.from_dec(curve, FR, str(pow(2, 256, orc.MODULI[(curve, FR)])))   # Montgomery representative of R = raw limbs of R^2 mod r
+    return mul(raw, np.broadcast_to(r2, raw.shape).copy(), curve)
 
 
-def field_sum(x):
+def field_sum(x, curve=BN254):
     x = x.copy()
     while x.shape[0] > 1:
         if x.shape[0] & 1:
             x = np.concatenate([x, np.zeros((1, 4), dtype=np.uint64)])
         h = x.shape[0] // 2
-        x = add(x[:h], x[h:])
+        x = add(x[:h], x[h:], curve)
     return x[0]
+
+
+def synth_table_msm(curve, group, scalars, first):
+    """exact MSM value over the synthetic table [(first + i) G], i = 0 .. n-1: one generator multiplication by sum_i s_i (first + i)"""
+    n = scalars.shape[0]
+    idx = np.zeros((n, 4), dtype=np.uint64); idx[:, 0] = np.arange(n, dtype=np.uint64) + np.uint64(first)
+    return orc.generator_mul(curve, group, field_sum(mul(scalars, to_mont(idx, curve), curve), curve))
 
 
 def spmv_party0(rp, col, co, pub, wa, wb, n_inputs):

@@ -129,11 +129,10 @@ def test_ntt_matches_oracle(ctx, curve, lg):
     np.testing.assert_array_equal(cx, orc.distribute_powers(curve, orc.ntt(curve, x, w, inverse=True), g, orc.from_dec(curve, FR, 1)))
 
 
-@pytest.mark.parametrize("lg", [20, 24])
-def test_ntt_large_roundtrip_and_linearity(ctx, lg):
+@pytest.mark.parametrize("curve,lg", [(BN254, 20), (BN254, 24), (BLS12_381, 20), (BLS12_381, 22)])
+def test_ntt_large_roundtrip_and_linearity(ctx, curve, lg):
     """size-independent properties at BASELINE-scale lengths (2^20; 2^24 = configs[3]): iNTT(NTT(x)) == x, NTT(x+y) == NTT(x)+NTT(y),
-    and 64 outputs against the definition"""
-    curve = BN254
+    and 64 outputs against the definition; both scalar fields (the reference's e2e matrix proves on both curves, e2e_tests/mod.rs:20-106)"""
     n = 1 << lg
     rng = np.random.default_rng(7)
     _, roots, _ = orc.roots_of_unity(curve)
@@ -286,25 +285,22 @@ def test_msm_medium_and_linearity(ctx):
     bases.release()
 
 
-@pytest.mark.parametrize("group,lg", [(G1, 24), (G2, 22)])
-def test_msm_at_maximum_table_size(ctx, group, lg):
+@pytest.mark.parametrize("curve,group,lg", [(BN254, G1, 24), (BN254, G2, 22), (BLS12_381, G1, 22), (BLS12_381, G2, 20)])
+def test_msm_at_maximum_table_size(ctx, curve, group, lg):
     """BASELINE configs[3] table size (2^24 points; G2 at the 2^22 of configs[2]): synthetic table [(1 + i) G], so the exact answer is
     one generator multiplication by sum_i s_i (1 + i), evaluated with oracle field arithmetic.  Precomputed tables (window 20, 13
     windows, 2^24-point index range fully used) and the plain per-window path on a sub-slice; linearity across the two components."""
     import bench_check as bc
-    curve = BN254
     n = 1 << lg
     rng = np.random.default_rng(2400 + lg)
     a = orc.random_field(curve, FR, n, rng); b = orc.random_field(curve, FR, n, rng)
-    idx = np.zeros((n, 4), dtype=np.uint64); idx[:, 0] = np.arange(n, dtype=np.uint64) + np.uint64(1)
-    wts = bc.to_mont(idx)
-    want = [orc.generator_mul(curve, group, bc.field_sum(bc.mul(s, wts))) for s in (a, b)]
+    want = [bc.synth_table_msm(curve, group, s, 1) for s in (a, b)]
     bases = ctx.synth_bases(curve, group, 1, n)
     da, db = dev(ctx, a), dev(ctx, b)
     # per-window bucket sets on the last quarter of the table (offset + length as a caller slices a zkey query)
     off, m = 3 * n // 4, n // 4
     got = ctx.msm_dev(bases, [da.ptr + off * 32, db.ptr + off * 32], m, offset=off)
-    part = [orc.generator_mul(curve, group, bc.field_sum(bc.mul(s[off:], wts[off:]))) for s in (a, b)]
+    part = [bc.synth_table_msm(curve, group, s[off:], 1 + off) for s in (a, b)]
     for j in range(2):
         np.testing.assert_array_equal(cg.point_to_affine(curve, group, got[j]), part[j])
     ctx.precompute_bases(bases, 0)
@@ -317,13 +313,14 @@ def test_msm_at_maximum_table_size(ctx, group, lg):
     bases.release()
 
 
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
 @pytest.mark.parametrize("group", [G1, G2])
-def test_msm_witness_like_scalars_at_scale(ctx, group):
+def test_msm_witness_like_scalars_at_scale(ctx, curve, group):
     """what the plain driver multiplies on a real circuit: half the scalars 0, a third 1, some bytes, the rest full width, 2^20 of
     them — one bucket (digit 1 of the lowest window) holds a third of all entries.  Exact value through the synthetic table
     [(1 + i) G]; classic per-window bucket sets and precomputed window tables (one shared bucket set)."""
     import bench_check as bc
-    curve, n = BN254, 1 << 20
+    n = 1 << 20
     rng = np.random.default_rng(77)
     sc = orc.random_field(curve, FR, n, rng)
     sel = rng.random(n)
@@ -331,8 +328,7 @@ def test_msm_witness_like_scalars_at_scale(ctx, group):
     sc[sel < 0.5] = 0
     sc[(sel >= 0.5) & (sel < 0.83)] = small[1]
     m = (sel >= 0.83) & (sel < 0.93); sc[m] = small[rng.integers(2, 256, size=int(m.sum()))]
-    idx = np.zeros((n, 4), dtype=np.uint64); idx[:, 0] = np.arange(n, dtype=np.uint64) + np.uint64(1)
-    want = orc.generator_mul(curve, group, bc.field_sum(bc.mul(sc, bc.to_mont(idx))))
+    want = bc.synth_table_msm(curve, group, sc, 1)
     bases = ctx.synth_bases(curve, group, 1, n)
     d = dev(ctx, sc)
     got, = ctx.msm_dev(bases, [d], n)
@@ -366,11 +362,11 @@ def test_ntt_coset_pair_matches_the_three_reference_steps(ctx, curve):
         np.testing.assert_array_equal(dz.download((n, 4)), want[1], err_msg=f"2^{lg} single")
 
 
-@pytest.mark.parametrize("lg", [20, 24])
-def test_ntt_coset_pair_at_scale_equals_the_two_transforms(ctx, lg):
+@pytest.mark.parametrize("curve,lg", [(BN254, 20), (BN254, 24), (BLS12_381, 20), (BLS12_381, 22)])
+def test_ntt_coset_pair_at_scale_equals_the_two_transforms(ctx, curve, lg):
     """2^20 / 2^24 (BASELINE configs[3] size): the pair equals the inverse-with-coset transform followed by the forward transform, which
     the round-trip / linearity / decimated-DFT tests above pin"""
-    curve, n = BN254, 1 << lg
+    n = 1 << lg
     rng = np.random.default_rng(lg)
     _, roots, _ = orc.roots_of_unity(curve)
     x = orc.random_field(curve, FR, n, rng)
@@ -451,21 +447,20 @@ def test_msm_precomputed_windows(ctx, curve, c):
         bases.release()
 
 
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
 @pytest.mark.parametrize("group", [G1, G2])
-def test_msm_grid_reduction_dense_buckets(ctx, group):
+def test_msm_grid_reduction_dense_buckets(ctx, curve, group):
     """the row / column reduction with every bucket populated: 2^18 points of the synthetic table [(1 + i) G] against per-window tables
     with c = 18 (2^17 buckets, ~30 entries each); exact value = one generator multiplication by sum s_i (1 + i)"""
     import bench_check as bc
-    curve, n = BN254, 1 << 18
+    n = 1 << 18
     rng = np.random.default_rng(77)
     bases = ctx.synth_bases(curve, group, 1, n)
     ctx.precompute_bases(bases, 18)
     sa, sb = orc.random_field(curve, FR, n, rng), orc.random_field(curve, FR, n, rng)
-    idx = np.zeros((n, 4), dtype=np.uint64); idx[:, 0] = np.arange(n, dtype=np.uint64) + np.uint64(1)
-    wts = bc.to_mont(idx)
     got = ctx.msm_dev(bases, [dev(ctx, sa), dev(ctx, sb)], n)
     for j, sc in enumerate((sa, sb)):
-        np.testing.assert_array_equal(cg.point_to_affine(curve, group, got[j]), orc.generator_mul(curve, group, bc.field_sum(bc.mul(sc, wts))))
+        np.testing.assert_array_equal(cg.point_to_affine(curve, group, got[j]), bc.synth_table_msm(curve, group, sc, 1))
     bases.release()
 
 
