@@ -34,12 +34,15 @@ def build(bls=True, jobs=8):
     return LIB_PATH
 
 
+# per-context tuning options (include/cogroth16_hip.h)
+OPT_MSM_CHUNK, OPT_MSM_WINDOW, OPT_MSM_SCATTER_CAP, OPT_MSM_TABLE_ORDER, OPT_MSM_G2_SLICES, OPT_MSM_REDUCE_BATCH, OPT_MSM_ACC_SLOTS = 1, 2, 3, 4, 5, 6, 7
+
 # every symbol include/cogroth16_hip.h declares (checked by tests/test_abi_surface.py)
 ABI_SYMBOLS = [
     "cg_ctx_create", "cg_ctx_create_ex", "cg_ctx_destroy", "cg_ctx_sync", "cg_ctx_stream", "cg_ctx_set_stream", "cg_last_error", "cg_version",
     "cg_dev_alloc", "cg_dev_free", "cg_dev_upload", "cg_dev_download", "cg_dev_memset_zero",
     "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute", "cg_bases_check_on_curve", "cg_bases_check_subgroup",
-    "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_chunk", "cg_msm_scalars_after", "cg_msm_set_scatter_capacity",
+    "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_chunk", "cg_ctx_set_option", "cg_ctx_get_option", "cg_msm_scalars_after", "cg_msm_set_scatter_capacity",
     "cg_ntt", "cg_ntt_dev", "cg_ntt_coset_pair_dev", "cg_chacha12_fr_rand_dev",
     "cg_host_alloc", "cg_host_free", "cg_host_is_pinned", "cg_dev_download_begin", "cg_dev_upload_begin", "cg_copy_wait", "cg_copy_fence",
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev", "cg_vec_affine_dev", "cg_vec_fill_dev", "cg_vec_gather_strided_dev", "cg_vec_lincomb_dev", "cg_vec_prefix_prod_dev", "cg_vec_prefix_sum_dev", "cg_vec_inverse_dev",
@@ -162,6 +165,15 @@ class Context:
         _chk(load().cg_ctx_create_ex(int(device), C.c_uint32(int(flags)), C.byref(h)))
         self.h = h
         self.device = device
+
+    def set_option(self, option, value):
+        """per-context tuning table (include/cogroth16_hip.h: CG_OPT_*); never changes results"""
+        _chk(load().cg_ctx_set_option(self.h, int(option), C.c_int64(int(value))))
+
+    def get_option(self, option):
+        v = C.c_int64(0)
+        _chk(load().cg_ctx_get_option(self.h, int(option), C.byref(v)))
+        return int(v.value)
 
     def msm_set_chunk(self, entries):
         """entries per accumulation lane for this context's MSMs (0 = automatic): short-lived workgroups next to a latency chain"""

@@ -23,8 +23,10 @@ inline size_t msm_sort_direct_scratch_bytes(size_t n, int c, int nwin, int share
     const size_t nbuckets = (size_t)(shared ? 1 : nwin) << (c - 1);
     return align_up(nbuckets * cap * 4) + 2 * align_up(nbuckets * 4) + align_up(((nbuckets + 2047) / 2048) * 4) + 256;
 }
-template <class F> int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, hipEvent_t ev_merged, const Affine<F>* d_bases, size_t n, int c, int nwin,
-                                             size_t table_stride, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs, bool may_have_inf, uint32_t chunk_request);
+template <class F> int msm_accumulate_launch(hipStream_t st, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride, const uint32_t* sorted, const uint32_t* offsets,
+                                             const uint32_t* counts, uint32_t cap, char* scratch, hipEvent_t* evs, bool may_have_inf, uint32_t chunk_request, bool g2_slices);
+template <class F> int msm_reduce_batch(hipStream_t st2, const MsmRedSet* sets, int nsets, size_t n, int c, int nwin, bool shared, uint32_t cap, hipEvent_t* ev_merged, int n_merged,
+                                        hipEvent_t* evs, uint32_t chunk_request);
 template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared, uint32_t chunk_request);
 template <class F> int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c);
 template <class F> int check_on_curve_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, const F& b, unsigned long long* d_counters);
@@ -128,7 +130,8 @@ struct cg_ctx {
     hipStream_t joinst = nullptr; hipEvent_t park_ev[5] = {};   // cg_dev_free: a work-free stream that joins the context's streams behind a released block
     // priority class of each stream: +1 high, 0 normal, -1 low (pooled_stream)
     int prio_main = 0, prio_side = 1, prio_copy = 0;
-    uint32_t msm_chunk = 0;                               // cg_msm_set_chunk
+    uint32_t msm_chunk = 0;                               // cg_msm_set_chunk / CG_OPT_MSM_CHUNK
+    int table_order = 0, g2_slices = 0, red_batch = 2, acc_slots = 4;   // CG_OPT_MSM_TABLE_ORDER / _G2_SLICES / _REDUCE_BATCH / _ACC_SLOTS (cg_ctx_set_option)
     hipEvent_t ev_peer = nullptr;                         // cg_dev_copy_peer: "source stream reached this point"
     Arena arena;
     std::vector<void*> retired;                        // outgrown arena blocks that enqueued kernels may still use
@@ -422,7 +425,14 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // Four rotating scratch slots: an accumulation waits for the bucket reduction that used its slot, and beside the accumulations the
         // reduction chain of one MSM (merge, segment sums, window sums; 1 ms alone) takes 3-8 ms — with two slots the main stream stalled
         // on it (2^22 step: 71.0 -> 69.95 ms with four, no further gain with six or eight; CG_ACC_SLOTS = 2 .. 8 for A/B runs)
-        static const int acc_slots = [] { const char* e = getenv("CG_ACC_SLOTS"); const int v = e ? atoi(e) : 4; return std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(2, v)); }();
+        const int acc_slots_min = std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(2, ctx->acc_slots));
+        // Reduction batching (CG_OPT_MSM_REDUCE_BATCH): 2 (default) = the bucket sets of a call that share a coordinate field are merged and reduced TOGETHER,
+        // after the last accumulation of that field in the call (with the G2 table first in every component, the G2 sets go while the
+        // last component's G1 tables are still accumulated; only the G1 batch trails the call); 1 = per share component; 0 = every set on
+        // its own right behind its accumulation (rounds 1-3).  Beside lock-stepped accumulations a reduction costs the step its stand-alone
+        // duration whatever its width: 2^22 step with ten reductions 6.2 ms, with three.  A batch holds its sets' scratch slots until it has run: one slot per set.
+        const int red_batch = ctx->red_batch;
+        const int acc_slots = red_batch ? std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(acc_slots_min, red_batch == 2 ? nb * k : nb + 1)) : acc_slots_min;
         { int rc = ensure_arena(ctx, nsched * sort_bytes + (size_t)acc_slots * acc_slot); if (rc) return rc; }
         char* acc_scratch = ctx->arena.base + nsched * sort_bytes;
         HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));   // scalars (and the arena) are ready once the main stream gets here
@@ -451,33 +461,75 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         };
         int iter = 0;
         { int rc = launch_sort(0); if (rc) return rc; }
+        // bucket sets accumulated but not yet merged / reduced, by coordinate field (group) of their table
+        struct PendSet { MsmRedSet set; int slot, sched, table, comp; };
+        std::vector<PendSet> pend[2];
+        int tables_of_group[2] = {0, 0};
+        for (int b = 0; b < nb; b++) tables_of_group[bases[b]->group == CG_G1 ? 0 : 1]++;
+        auto flush = [&](int gi) -> int {
+            std::vector<PendSet>& pd = pend[gi];
+            if (pd.empty()) return 0;
+            // every accumulation of the batch sits on the main stream in front of this point: the reduction stream waits for the last one
+            hipEvent_t ea = ctx->ev_acc[pd.back().slot];
+            HIPCHK(hipEventRecord(ea, ctx->stream));
+            HIPCHK(hipStreamWaitEvent(ctx->aux, ea, 0));
+            hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
+            if (ctx->stats_on) { const int i2 = ev_open(ctx, TAG_REDUCE); evs[0] = ctx->ev_live[i2].a; evs[1] = ctx->ev_live[i2].b; pev = evs; }
+            hipEvent_t evm[2]; int nm = 0; bool seen[2] = {false, false};
+            std::vector<MsmRedSet> sets;
+            for (const PendSet& ps : pd) { sets.push_back(ps.set); if (!seen[ps.sched]) { seen[ps.sched] = true; evm[nm++] = ctx->ev_merged[ps.sched]; } }
+            int rc = with_coord_field(curve, gi == 0 ? CG_G1 : CG_G2, [&](auto ftag) -> int {
+                typedef decltype(ftag) F;
+                return msm_reduce_batch<F>(ctx->aux, sets.data(), (int)sets.size(), n, c, nwin, shared, sps[pd[0].comp].cap, evm, nm, pev, chunk_request);
+            });
+            if (rc) return rc;
+            for (const PendSet& ps : pd) {
+                HIPCHK(hipEventRecord(ctx->ev_red[ps.slot], ctx->aux));
+                ctx->slot_busy[ps.slot] = true; ctx->aux_pending = true; ctx->last_slot = ps.slot; ctx->merged_pending[ps.sched] = true;
+                if (ps.comp == k - 1) HIPCHK(hipEventRecord(ctx->tickets[slots[ps.table]].done, ctx->aux));   // this table's last component: its results are complete on the aux stream
+            }
+            pd.clear();
+            return 0;
+        };
         for (int j = 0; j < k; j++) {
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[j % nsched], 0));
             // the next component's schedule is enqueued BEFORE this component's accumulates so that the two streams run side by side
             if (j + 1 < k && nsched == 2 && j + 1 < nsched) { int rc = launch_sort(j + 1); if (rc) return rc; }
             const MsmSortPtrs& sp = sps[j];
-            for (int b = 0; b < nb; b++) {   // group side: once per table, reusing the schedule
+            int left_in_comp[2] = {tables_of_group[0], tables_of_group[1]};
+            for (int bi = 0; bi < nb; bi++) {   // group side: once per table, reusing the schedule
+                const int b = (ctx->table_order == 1 && (j & 1)) ? nb - 1 - bi : bi;      // serpentine: odd components run the tables in reverse
                 MsmTicket& t = ctx->tickets[slots[b]];
-                hipEvent_t evs[4]; hipEvent_t* pev = nullptr;
-                if (ctx->stats_on) {
-                    const int i1 = ev_open(ctx, t.group == CG_G1 ? TAG_ACC_G1 : TAG_ACC_G2), i2 = ev_open(ctx, TAG_REDUCE);
-                    evs[0] = ctx->ev_live[i1].a; evs[1] = ctx->ev_live[i1].b; evs[2] = ctx->ev_live[i2].a; evs[3] = ctx->ev_live[i2].b; pev = evs;
-                }
+                const int gi = t.group == CG_G1 ? 0 : 1;
+                hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
+                if (ctx->stats_on) { const int i1 = ev_open(ctx, t.group == CG_G1 ? TAG_ACC_G1 : TAG_ACC_G2); evs[0] = ctx->ev_live[i1].a; evs[1] = ctx->ev_live[i1].b; pev = evs; }
                 const int slot = iter++ % acc_slots;
+                for (int g2 = 0; g2 < 2; g2++) {                 // the slot still holds a set that waits for its batch: run that batch now
+                    bool held = false;
+                    for (const PendSet& ps : pend[g2]) held = held || ps.slot == slot;
+                    if (held) { int rc = flush(g2); if (rc) return rc; }
+                }
                 if (ctx->slot_busy[slot]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_red[slot], 0));   // slot's previous reduction must be done
+                char* scratch = acc_scratch + (size_t)slot * acc_slot;
                 int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
                     typedef decltype(ftag) F;
                     const Affine<F>* pts = (const Affine<F>*)(shared ? bases[b]->d_pre : bases[b]->d_pts) + (offsets ? offsets[b] : 0);
-                    return msm_accumulate_reduce<F>(ctx->stream, ctx->aux, ctx->ev_acc[slot], ctx->ev_red[slot], ctx->ev_merged[j % nsched], pts, n, c, nwin, shared ? bases[b]->n : 0,
-                                                    sp.sorted, sp.offsets, sp.counts, sp.cap, acc_scratch + (size_t)slot * acc_slot, (XYZZ<F>*)t.h_pinned + (size_t)j * nsums, pev, !bases[b]->no_inf, chunk_request);
+                    return msm_accumulate_launch<F>(ctx->stream, pts, n, c, nwin, shared ? bases[b]->n : 0, sp.sorted, sp.offsets, sp.counts, sp.cap, scratch, pev, !bases[b]->no_inf, chunk_request, ctx->g2_slices != 0);
                 });
                 if (rc) return rc;
-                ctx->slot_busy[slot] = true; ctx->aux_pending = true; ctx->last_slot = slot; ctx->merged_pending[j % nsched] = true;
-                if (j == k - 1) HIPCHK(hipEventRecord(t.done, ctx->aux));   // this table's last component: its results are complete on the aux stream
+                size_t pinned_stride = 0;
+                { int rc2 = with_coord_field(curve, t.group, [&](auto ftag) -> int { pinned_stride = sizeof(XYZZ<decltype(ftag)>); return 0; }); if (rc2) return rc2; }
+                pend[gi].push_back(PendSet{MsmRedSet{scratch, sp.offsets, sp.counts, (char*)t.h_pinned + (size_t)j * nsums * pinned_stride}, slot, j % nsched, b, j});
+                const bool last_here = --left_in_comp[gi] == 0;                           // this field's last table of the component
+                if (red_batch == 0 || (red_batch == 1 && last_here) || (last_here && j == k - 1) || (int)pend[gi].size() == RED_MAX_SETS) { int rc3 = flush(gi); if (rc3) return rc3; }
             }
             HIPCHK(hipEventRecord(ctx->ev_sched_free[j % nsched], ctx->stream));
-            if (j + 2 < k && nsched == 2) { int rc = launch_sort(j + 2); if (rc) return rc; }   // needs the slot this component just released
+            if (j + 2 < k && nsched == 2) {                      // needs the schedule slot this component just released: its pending sets are merged first
+                for (int g2 = 0; g2 < 2; g2++) { int rc = flush(g2); if (rc) return rc; }
+                int rc = launch_sort(j + 2); if (rc) return rc;
+            }
         }
+        for (int g2 = 0; g2 < 2; g2++) { int rc = flush(g2); if (rc) return rc; }
     }
     for (int b = 0; b < nb; b++) { if (n == 0) HIPCHK(hipEventRecord(ctx->tickets[slots[b]].done, ctx->stream)); tickets_out[b] = slots[b]; }
     return 0;
@@ -940,6 +992,11 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     HIPCHK(hipSetDevice(device));
     cg_ctx* c = new cg_ctx();
     c->device = device;
+    {   // A/B runs: environment variables seed the option table of new contexts (include/cogroth16_hip.h, cg_ctx_set_option)
+        auto seed = [](const char* name, int lo, int hi, int& field) { if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= lo && v <= hi) field = v; } };
+        seed("CG_MSM_TABLE_ORDER", 0, 1, c->table_order); seed("CG_MSM_G2_SLICES", 0, 1, c->g2_slices);
+        seed("CG_MSM_REDUCE_BATCH", 0, 2, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots);
+    }
     if (flags & 1u) { c->prio_main = 1; c->prio_copy = 1; c->prio_side = 0; }
     else if (flags & 2u) { static const int bulk_cls = getenv("CG_BULK_CLASS") ? atoi(getenv("CG_BULK_CLASS")) : -1; c->prio_main = bulk_cls; c->prio_side = 0; }   // CG_BULK_CLASS: tuning knob
     { int rc = pooled_stream(device, c->prio_main, &c->stream); if (rc) return rc; }
@@ -1439,6 +1496,33 @@ int32_t cg_msm_set_chunk(cg_ctx* ctx, int32_t entries_per_lane) {
     if (entries_per_lane < 0 || entries_per_lane > 4096) return fail(CG_ERR_ARG, "chunk length out of range");
     ctx->msm_chunk = (uint32_t)entries_per_lane;
     return 0;
+}
+int32_t cg_ctx_set_option(cg_ctx* ctx, int32_t option, int64_t value) {
+    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
+    switch (option) {
+        case CG_OPT_MSM_CHUNK: return cg_msm_set_chunk(ctx, (int32_t)value);
+        case CG_OPT_MSM_WINDOW: return cg_msm_set_window(ctx, (int32_t)value);
+        case CG_OPT_MSM_SCATTER_CAP: return cg_msm_set_scatter_capacity(ctx, (int32_t)value);
+        case CG_OPT_MSM_TABLE_ORDER: if (value < 0 || value > 1) break; ctx->table_order = (int)value; return 0;
+        case CG_OPT_MSM_G2_SLICES: if (value < 0 || value > 1) break; ctx->g2_slices = (int)value; return 0;
+        case CG_OPT_MSM_REDUCE_BATCH: if (value < 0 || value > 2) break; ctx->red_batch = (int)value; return 0;
+        case CG_OPT_MSM_ACC_SLOTS: if (value < 2 || value > cg_ctx::ACC_SLOTS_MAX) break; ctx->acc_slots = (int)value; return 0;
+        default: return fail(CG_ERR_ARG, "cg_ctx_set_option: unknown option");
+    }
+    return fail(CG_ERR_ARG, "cg_ctx_set_option: value out of range");
+}
+int32_t cg_ctx_get_option(const cg_ctx* ctx, int32_t option, int64_t* value) {
+    if (!ctx || !value) return fail(CG_ERR_ARG, "null argument");
+    switch (option) {
+        case CG_OPT_MSM_CHUNK: *value = ctx->msm_chunk; return 0;
+        case CG_OPT_MSM_WINDOW: *value = ctx->msm_window; return 0;
+        case CG_OPT_MSM_SCATTER_CAP: *value = ctx->scatter_cap; return 0;
+        case CG_OPT_MSM_TABLE_ORDER: *value = ctx->table_order; return 0;
+        case CG_OPT_MSM_G2_SLICES: *value = ctx->g2_slices; return 0;
+        case CG_OPT_MSM_REDUCE_BATCH: *value = ctx->red_batch; return 0;
+        case CG_OPT_MSM_ACC_SLOTS: *value = ctx->acc_slots; return 0;
+        default: return fail(CG_ERR_ARG, "cg_ctx_get_option: unknown option");
+    }
 }
 int32_t cg_msm_set_window(cg_ctx* ctx, int32_t c) {
     if (!ctx) return fail(CG_ERR_ARG, "null ctx");

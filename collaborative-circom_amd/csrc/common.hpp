@@ -57,6 +57,10 @@ struct MsmGeom {            // derived sizes shared by the host-side planner and
     size_t grid_partials() const { return grid ? ((size_t)1 << log_h) / GRID_TR * ((size_t)1 << log_l) + ((size_t)1 << log_h) * (((size_t)1 << log_l) / GRID_TC) : 0; }
 };
 constexpr int MSM_SHARED_GROUPS = 16;
+// One bucket set of a reduction batch (msm_impl.hpp: msm_reduce_batch): its scratch slot, the schedule it was accumulated from, and where
+// its sums go (pinned host memory).  Up to RED_MAX_SETS sets of one coordinate field and one launch geometry share the launches.
+constexpr int RED_MAX_SETS = 8;
+struct MsmRedSet { char* scratch; const uint32_t* offsets; const uint32_t* counts; void* h_out; };
 // resident_lanes: lanes of the accumulation kernel the chip holds at once (0 = unknown).  Its workgroups do equal work and finish
 // in lock step, so a launch of 2.16 residency rounds takes as long as 2.33 (the last 0.16 round runs one wave per SIMD, three
 // times as fast, on a sixth of the chip): when the list is long enough the chunk length is chosen so that the chunks fill a whole

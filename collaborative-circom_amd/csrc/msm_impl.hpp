@@ -21,34 +21,48 @@ template <class B> struct IsFp2<Fp2<B>> { static constexpr bool value = true; };
 
 template <class F>
 size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared, uint32_t chunk_request) {
-    MsmGeom g = msm_geom(n, c, nwin, shared, acc_resident_lanes<F>(), chunk_request, IsFp2<F>::value);
     typedef typename BucketOf<F>::type B;
+    MsmGeom g = msm_geom(n, c, nwin, shared, acc_resident_lanes<F>(), chunk_request, IsFp2<F>::value);
     g.bit_groups = bitsum_groups<B>(g.nb);
     return align_up(g.nbuckets * sizeof(B)) + align_up((size_t)g.nchunks * sizeof(B)) + align_up((size_t)g.nchunks * 4) +
            align_up(std::max({(size_t)g.nsets * g.segs, (size_t)64 * g.bit_groups, g.grid_partials()}) * sizeof(B)) + align_up((size_t)std::max(g.ngroups, 64) * sizeof(XYZZ<F>));
 }
 
-// buckets -> window sums for one (bases, sorted schedule) pair; the nwin window sums land in h_out (pinned) via an async copy.
-// table_stride != 0 selects the shared-bucket-set mode (d_bases = window-0 table of a [nwin][table_stride] precomputed block);
-// the host then receives g.ngroups partial sums to ADD (no doublings).  evs (optional, 4 events): accumulate [0,1], reduce [2,3]
-// Two streams: the accumulation (which fills the chip) runs on `st`; the merge of chunk-boundary pieces (signals `ev_merged`: the
-// schedule is no longer needed) and the latency-bound bucket reduction (a few hundred waves) run on `st2` behind `ev_acc` and signal `ev_red`, so it overlaps with the NEXT accumulation, which uses another scratch slot.
+// scratch of one bucket set (one rotating slot of the context's arena): the same layout for every set of a launch geometry
 template <class F>
-int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hipEvent_t ev_red, hipEvent_t ev_merged, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride,
-                          const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, XYZZ<F>* h_out, hipEvent_t* evs, bool may_have_inf, uint32_t chunk_request) {
-    const bool shared = table_stride != 0;
+struct AccScratch {
+    typedef typename BucketOf<F>::type B;
+    B* buckets; B* cont; uint32_t* cont_bucket; B* partials; XYZZ<F>* wsums;
+    AccScratch(char* scratch, const MsmGeom& g) {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { void* p = scratch + off; off += align_up(bytes); return p; };
+        buckets = (B*)take(g.nbuckets * sizeof(B));
+        cont = (B*)take((size_t)g.nchunks * sizeof(B));
+        cont_bucket = (uint32_t*)take((size_t)g.nchunks * 4);
+        partials = (B*)take(std::max({(size_t)g.nsets * g.segs, (size_t)64 * g.bit_groups, g.grid_partials()}) * sizeof(B));
+        wsums = (XYZZ<F>*)take((size_t)std::max(g.ngroups, 64) * sizeof(XYZZ<F>));
+    }
+};
+template <class F>
+MsmGeom msm_geom_of(size_t n, int c, int nwin, bool shared, uint32_t chunk_request) {
     MsmGeom g = msm_geom(n, c, nwin, shared, acc_resident_lanes<F>(), chunk_request, IsFp2<F>::value);
-    size_t off = 0;
-    auto take = [&](size_t bytes) { void* p = scratch + off; off += align_up(bytes); return p; };
+    g.bit_groups = bitsum_groups<typename BucketOf<F>::type>(g.nb);
+    return g;
+}
+
+// Bucket accumulation of one (bases, sorted schedule) pair into the bucket set of `scratch`, on `st` (the launch fills the chip).
+// table_stride != 0 selects the shared-bucket-set mode (d_bases = window-0 table of a [nwin][table_stride] precomputed block).
+// evs (optional, 2 events) bracket the accumulation KERNEL alone (what rocprofv3 lists per launch).
+template <class F>
+int msm_accumulate_launch(hipStream_t st, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride,
+                          const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, hipEvent_t* evs, bool may_have_inf, uint32_t chunk_request, bool g2_slices) {
+    const bool shared = table_stride != 0;
+    const MsmGeom g = msm_geom_of<F>(n, c, nwin, shared, chunk_request);
     typedef typename BucketOf<F>::type B;                 // limb-form points for the lazy pipelines, saturated XYZZ otherwise
-    g.bit_groups = bitsum_groups<B>(g.nb);
-    B* buckets = (B*)take(g.nbuckets * sizeof(B));
-    B* cont = (B*)take((size_t)g.nchunks * sizeof(B));
-    uint32_t* cont_bucket = (uint32_t*)take((size_t)g.nchunks * 4);
-    B* partials = (B*)take(std::max({(size_t)g.nsets * g.segs, (size_t)64 * g.bit_groups, g.grid_partials()}) * sizeof(B));
-    XYZZ<F>* wsums = (XYZZ<F>*)take((size_t)std::max(g.ngroups, 64) * sizeof(XYZZ<F>));
+    const AccScratch<F> sc(scratch, g);
+    B* buckets = sc.buckets; B* cont = sc.cont; uint32_t* cont_bucket = sc.cont_bucket;
     HIPCHK(hipMemsetAsync(buckets, 0, g.nbuckets * sizeof(B), st));                // all-zero = infinity (empty buckets are never written)
-    if (evs) HIPCHK(hipEventRecord(evs[0], st));                                     // [0, 1] bracket the accumulation KERNEL alone (what rocprofv3 lists per launch)
+    if (evs) HIPCHK(hipEventRecord(evs[0], st));
     auto launch_acc = [&](auto kern, int T, size_t lds) -> int {
         if (lds > 0) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((g.nchunks + T - 1) / T), dim3(T), lds, st, d_bases, sorted, offsets, counts,
@@ -66,15 +80,13 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     // 10 = 4-byte index reads two iterations ahead
     const char* var_s = getenv("CG_ACC_VARIANT");
     const int variant = var_s ? atoi(var_s) : 3;
-    // A context that runs next to a latency chain (cg_msm_set_chunk) launches the G2 accumulation one chip-load of workgroups at a
-    // time: its workgroups hold 147 of the CU's 160 KB of LDS, so nothing that needs LDS (an NTT pass: 72 KB) can start while the
-    // launch lasts — measured: a high-priority NTT pass waited 11 ms, the whole launch.  Between the slices the chip drains and the
-    // waiting kernels go first.
+    // CG_OPT_MSM_G2_SLICES: the G2 accumulation goes one chip-load of workgroups at a time: its workgroups hold 147 of the CU's 160 KB
+    // of LDS, so nothing that needs LDS (an NTT pass: 72 KB) can start while the launch lasts — measured: a high-priority NTT pass
+    // waited 11 ms, the whole launch.  Between the slices the chip drains and the waiting kernels go first; ~2 ms per launch when nothing waits.
     auto launch_pf = [&](auto kern, int T, size_t lds) -> int {
         if (lds > 0) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const uint32_t groups = (g.nchunks + T - 1) / T;
-        static const bool no_slice = getenv("CG_G2_NO_SLICE") != nullptr;       // tuning knob
-        const uint32_t slice = lds > 0 && chunk_request && !no_slice ? 256u * (uint32_t)std::max<size_t>(1, ((size_t)160 << 10) / lds) : groups;
+        const uint32_t slice = lds > 0 && g2_slices ? 256u * (uint32_t)std::max<size_t>(1, ((size_t)160 << 10) / lds) : groups;
         for (uint32_t first = 0; first < groups; first += slice)
             hipLaunchKernelGGL(kern, dim3(std::min(slice, groups - first)), dim3(T), lds, st, d_bases, sorted, offsets, counts,
                                (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, (uint32_t)table_stride, buckets, cont, cont_bucket, may_have_inf ? 1u : 0u, first * (uint32_t)T);
@@ -107,27 +119,49 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
     else rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc29<F>, 128>, 128, lds2);
     if (rc_acc) return rc_acc;
     if (evs) HIPCHK(hipEventRecord(evs[1], st));
-    // The merge of the chunk-boundary pieces belongs to the reduction side: a few hundred waves that would leave the chip idle for
-    // 0.3 (G1) to 1.5 ms (G2) per MSM in front of the next accumulation (measured in the 2^22 step: ~5 ms per step with no accumulation
-    // running), while the next accumulation works on the other scratch slot and needs nothing from them.
-    HIPCHK(hipEventRecord(ev_acc, st));
-    HIPCHK(hipStreamWaitEvent(st2, ev_acc, 0));
-    if (evs) HIPCHK(hipEventRecord(evs[2], st2));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// buckets -> partial sums for UP TO RED_MAX_SETS bucket sets of one coordinate field and one geometry in one sequence of launches on
+// `st2` (the caller has made st2 wait for the accumulations): merge of the chunk-boundary pieces (then `ev_merged[0 .. n_merged)` are
+// recorded: the schedules are no longer needed), bucket reduction, asynchronous copies of the g.ngroups sums of every set into its
+// h_out.  The host ADDs / Horner-folds them (msm_end_impl).  Beside the accumulations of the next tables these few hundred waves cost
+// the step their stand-alone duration, not their work: the sets of a call that share a field go through them together.
+// evs (optional, 2 events) bracket the whole batch.
+template <class F>
+int msm_reduce_batch(hipStream_t st2, const MsmRedSet* sets, int nsets, size_t n, int c, int nwin, bool shared, uint32_t cap, hipEvent_t* ev_merged, int n_merged,
+                     hipEvent_t* evs, uint32_t chunk_request) {
+    if (nsets < 1 || nsets > RED_MAX_SETS) return fail(CG_ERR_ARG, "internal: reduction batch size");
+    const MsmGeom g = msm_geom_of<F>(n, c, nwin, shared, chunk_request);
+    typedef typename BucketOf<F>::type B;
+    RedSets<B> S{};
+    XYZZ<F>* wsums[RED_MAX_SETS];
+    for (int i = 0; i < nsets; i++) {
+        const AccScratch<F> sc(sets[i].scratch, g);
+        S.buckets[i] = sc.buckets; S.cont[i] = sc.cont; S.cont_bucket[i] = sc.cont_bucket; S.partials[i] = sc.partials; S.wsums[i] = sc.wsums; wsums[i] = sc.wsums;
+        S.offsets[i] = sets[i].offsets; S.counts[i] = sets[i].counts;
+    }
+    const unsigned ys = (unsigned)nsets;
+    if (evs) HIPCHK(hipEventRecord(evs[0], st2));
+    auto merged = [&]() -> int { for (int i = 0; i < n_merged; i++) HIPCHK(hipEventRecord(ev_merged[i], st2)); return 0; };
+    auto deliver = [&](size_t count) -> int {
+        if (evs) HIPCHK(hipEventRecord(evs[1], st2));
+        HIPCHK(hipGetLastError());
+        for (int i = 0; i < nsets; i++) HIPCHK(hipMemcpyAsync(sets[i].h_out, wsums[i], count * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st2));
+        return 0;
+    };
     // measurement only (results are WRONG): what the merges (1: skipped too) and the bucket reduction (2: only it) cost the step beside the accumulations
     static const int skip_reduce = getenv("CG_DEBUG_NO_REDUCE") ? atoi(getenv("CG_DEBUG_NO_REDUCE")) : 0;
     auto fake_reduce = [&]() -> int {
-        if (evs) HIPCHK(hipEventRecord(evs[3], st2));
-        HIPCHK(hipMemsetAsync(wsums, 0, (size_t)g.ngroups * sizeof(XYZZ<F>), st2));
-        HIPCHK(hipMemcpyAsync(h_out, wsums, (size_t)g.ngroups * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st2));
-        HIPCHK(hipEventRecord(ev_red, st2));
-        return 0;
+        for (int i = 0; i < nsets; i++) HIPCHK(hipMemsetAsync(wsums[i], 0, (size_t)g.ngroups * sizeof(XYZZ<F>), st2));
+        return deliver((size_t)g.ngroups);
     };
-    if (skip_reduce == 1) { HIPCHK(hipEventRecord(ev_merged, st2)); return fake_reduce(); }
-    hipLaunchKernelGGL((k_msm_merge_direct<B>), dim3((unsigned)((g.nbuckets + 63) / 64)), dim3(64), 0, st2, buckets, cont, cont_bucket, offsets, counts,
-                       (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, cap);
-    hipLaunchKernelGGL((k_msm_merge_cont_l1<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st2, cont, cont_bucket, g.nchunks);
-    hipLaunchKernelGGL((k_msm_merge_cont<B>), dim3((g.nchunks + 63) / 64), dim3(64), 0, st2, buckets, cont, cont_bucket, g.nchunks);
-    HIPCHK(hipEventRecord(ev_merged, st2));                                          // the last reader of the sorted schedule (offsets / counts)
+    if (skip_reduce == 1) { if (int rc = merged()) return rc; return fake_reduce(); }
+    hipLaunchKernelGGL((k_msm_merge_direct<B>), dim3((unsigned)((g.nbuckets + 63) / 64), ys), dim3(64), 0, st2, S, (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, cap);
+    hipLaunchKernelGGL((k_msm_merge_cont_l1<B>), dim3((g.nchunks + 63) / 64, ys), dim3(64), 0, st2, S, g.nchunks);
+    hipLaunchKernelGGL((k_msm_merge_cont<B>), dim3((g.nchunks + 63) / 64, ys), dim3(64), 0, st2, S, g.nchunks);
+    if (int rc = merged()) return rc;                                               // the last readers of the sorted schedules (offsets / counts)
     if (skip_reduce == 2) return fake_reduce();
     if (g.bitsum) {
         static PerDeviceOnce attr_set2;
@@ -136,13 +170,9 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
             HIPCHK(hipFuncSetAttribute((const void*)k_msm_bitsum_final<F, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * sizeof(B))));
             attr_set2.mark();
         }
-        hipLaunchKernelGGL((k_msm_bitsum_partial<B, bitsum_items<B>()>), dim3((unsigned)(c * g.bit_groups)), dim3(256), 256 * sizeof(B), st2, buckets, g.nb, g.bit_groups, partials);
-        hipLaunchKernelGGL((k_msm_bitsum_final<F, B>), dim3((unsigned)c), dim3(64), 64 * sizeof(B), st2, partials, g.bit_groups, wsums);
-        if (evs) HIPCHK(hipEventRecord(evs[3], st2));
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h_out, wsums, (size_t)c * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st2));
-        HIPCHK(hipEventRecord(ev_red, st2));
-        return 0;
+        hipLaunchKernelGGL((k_msm_bitsum_partial<B, bitsum_items<B>()>), dim3((unsigned)(c * g.bit_groups), ys), dim3(256), 256 * sizeof(B), st2, S, g.nb, g.bit_groups);
+        hipLaunchKernelGGL((k_msm_bitsum_final<F, B>), dim3((unsigned)c, ys), dim3(64), 64 * sizeof(B), st2, S, g.bit_groups);
+        return deliver((size_t)c);
     }
     if (g.grid) {
         static PerDeviceOnce attr_set3;
@@ -152,28 +182,19 @@ int msm_accumulate_reduce(hipStream_t st, hipStream_t st2, hipEvent_t ev_acc, hi
             attr_set3.mark();
         }
         const uint32_t H = 1u << g.log_h, L = 1u << g.log_l;
-        B* colpart = partials; B* rowpart = partials + (size_t)(H / GRID_TR) * L;
-        hipLaunchKernelGGL((k_msm_grid_partial<B>), dim3((H / GRID_TR) * (L / GRID_TC)), dim3(256), 256 * sizeof(B), st2, buckets, (uint32_t)g.log_l, g.nb, colpart, rowpart);
-        hipLaunchKernelGGL((k_msm_grid_bitsum<F, B, BITSUM_ITEMS>), dim3((unsigned)g.ngroups), dim3(256), 256 * sizeof(B), st2, colpart, rowpart, (uint32_t)g.log_l, (uint32_t)g.log_h, g.gc, g.gr, wsums);
-        if (evs) HIPCHK(hipEventRecord(evs[3], st2));
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h_out, wsums, (size_t)g.ngroups * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st2));
-        HIPCHK(hipEventRecord(ev_red, st2));
-        return 0;
+        hipLaunchKernelGGL((k_msm_grid_partial<B>), dim3((H / GRID_TR) * (L / GRID_TC), ys), dim3(256), 256 * sizeof(B), st2, S, (uint32_t)g.log_l, g.nb);
+        hipLaunchKernelGGL((k_msm_grid_bitsum<F, B, BITSUM_ITEMS>), dim3((unsigned)g.ngroups, ys), dim3(256), 256 * sizeof(B), st2, S, (uint32_t)g.log_l, (uint32_t)g.log_h, g.gc, g.gr);
+        return deliver((size_t)g.ngroups);
     }
     const size_t nseg_threads = (size_t)g.nsets * g.segs;
-    hipLaunchKernelGGL((k_msm_reduce_segments<B>), dim3((unsigned)((nseg_threads + 63) / 64)), dim3(64), 0, st2, buckets, g.nb, g.seg_len, g.nsets, partials);
+    hipLaunchKernelGGL((k_msm_reduce_segments<B>), dim3((unsigned)((nseg_threads + 63) / 64), ys), dim3(64), 0, st2, S, g.nb, g.seg_len, g.nsets);
     constexpr int WT = sizeof(B) > 160 ? 128 : 256;
     {
         static PerDeviceOnce attr_set;
         if (attr_set.pending()) { HIPCHK(hipFuncSetAttribute((const void*)k_msm_window_sum<F, B, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WT * sizeof(B)))); attr_set.mark(); }
     }
-    hipLaunchKernelGGL((k_msm_window_sum<F, B, WT>), dim3(g.ngroups), dim3(WT), WT * sizeof(B), st2, partials, g.group_segs, wsums);
-    if (evs) HIPCHK(hipEventRecord(evs[3], st2));
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h_out, wsums, (size_t)g.ngroups * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st2));
-    HIPCHK(hipEventRecord(ev_red, st2));
-    return 0;
+    hipLaunchKernelGGL((k_msm_window_sum<F, B, WT>), dim3(g.ngroups, ys), dim3(WT), WT * sizeof(B), st2, S, g.group_segs);
+    return deliver((size_t)g.ngroups);
 }
 
 template <class F>
@@ -233,7 +254,8 @@ int fixed_base_mul_launch(hipStream_t st, const Affine<F>& g, const Fr* d_scalar
 
 #define CG_INSTANTIATE_MSM(F, Fr)                                                                                          \
     namespace cg {                                                                                                         \
-    template int msm_accumulate_reduce<F>(hipStream_t, hipStream_t, hipEvent_t, hipEvent_t, hipEvent_t, const Affine<F>*, size_t, int, int, size_t, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, char*, XYZZ<F>*, hipEvent_t*, bool, uint32_t); \
+    template int msm_accumulate_launch<F>(hipStream_t, const Affine<F>*, size_t, int, int, size_t, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, char*, hipEvent_t*, bool, uint32_t, bool); \
+    template int msm_reduce_batch<F>(hipStream_t, const MsmRedSet*, int, size_t, int, int, bool, uint32_t, hipEvent_t*, int, hipEvent_t*, uint32_t); \
     template size_t msm_acc_scratch_bytes<F>(size_t, int, int, bool, uint32_t);                                                      \
     template int precompute_window_launch<F>(hipStream_t, const Affine<F>*, Affine<F>*, size_t, int);                      \
     template int check_on_curve_launch<F>(hipStream_t, const Affine<F>*, size_t, const F&, unsigned long long*);           \

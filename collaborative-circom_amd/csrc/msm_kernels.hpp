@@ -494,10 +494,20 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate_pf(const Affin
 // lanes in four idle.  Here lane b adds the pieces of bucket b, whose chunk range follows from offsets / counts alone, and retires
 // them (tag -> none).  Buckets spread over more than MERGE_DIRECT_MAX chunks (skewed scalars) are left to the two levels below.
 constexpr uint32_t MERGE_DIRECT_MAX = 12;
+// The merge and reduction kernels below serve up to RED_MAX_SETS bucket sets of ONE launch geometry per launch (blockIdx.y = set): the
+// bucket sets of the tables of one MSM call that share a coordinate field — l, a, b1 and both share components — whose accumulations
+// have all finished.  Beside a lock-stepped accumulation a reduction costs the step its whole stand-alone DURATION (a chain of ~38
+// dependent additions on a few hundred waves), whatever its width: six sets in one launch cost what one does.
 template <class B>
-__global__ void __launch_bounds__(64) k_msm_merge_direct(B* __restrict__ buckets, const B* __restrict__ cont, uint32_t* __restrict__ cont_bucket,
-                                                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                                                         uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks, uint32_t cap) {
+struct RedSets {
+    B* buckets[RED_MAX_SETS]; B* cont[RED_MAX_SETS]; uint32_t* cont_bucket[RED_MAX_SETS];
+    const uint32_t* offsets[RED_MAX_SETS]; const uint32_t* counts[RED_MAX_SETS];     // the sorted schedule each set was accumulated from
+    B* partials[RED_MAX_SETS]; void* wsums[RED_MAX_SETS];                               // reduction scratch, final sums (XYZZ<F>) of each set
+};
+template <class B>
+__global__ void __launch_bounds__(64) k_msm_merge_direct(const RedSets<B> S, uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks, uint32_t cap) {
+    B* __restrict__ buckets = S.buckets[blockIdx.y]; const B* __restrict__ cont = S.cont[blockIdx.y]; uint32_t* __restrict__ cont_bucket = S.cont_bucket[blockIdx.y];
+    const uint32_t* __restrict__ offsets = S.offsets[blockIdx.y]; const uint32_t* __restrict__ counts = S.counts[blockIdx.y];
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbuckets) return;
     const uint32_t cnt = cap ? min(counts[b], cap) : counts[b];
@@ -511,7 +521,8 @@ __global__ void __launch_bounds__(64) k_msm_merge_direct(B* __restrict__ buckets
 }
 constexpr uint32_t MERGE_GROUP = 64;
 template <class B>
-__global__ void __launch_bounds__(64) k_msm_merge_cont_l1(B* __restrict__ cont, const uint32_t* __restrict__ cont_bucket, uint32_t nchunks) {
+__global__ void __launch_bounds__(64) k_msm_merge_cont_l1(const RedSets<B> S, uint32_t nchunks) {
+    B* __restrict__ cont = S.cont[blockIdx.y]; const uint32_t* __restrict__ cont_bucket = S.cont_bucket[blockIdx.y];
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nchunks) return;
     const uint32_t b = cont_bucket[q];
@@ -525,7 +536,8 @@ __global__ void __launch_bounds__(64) k_msm_merge_cont_l1(B* __restrict__ cont, 
     st_struct(cont + q, acc);                                                   // only group heads are written; nobody else reads them in this launch
 }
 template <class B>
-__global__ void __launch_bounds__(64) k_msm_merge_cont(B* __restrict__ buckets, const B* __restrict__ cont, const uint32_t* __restrict__ cont_bucket, uint32_t nchunks) {
+__global__ void __launch_bounds__(64) k_msm_merge_cont(const RedSets<B> S, uint32_t nchunks) {
+    B* __restrict__ buckets = S.buckets[blockIdx.y]; const B* __restrict__ cont = S.cont[blockIdx.y]; const uint32_t* __restrict__ cont_bucket = S.cont_bucket[blockIdx.y];
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nchunks) return;
     const uint32_t b = cont_bucket[q];
@@ -549,7 +561,8 @@ __device__ __forceinline__ B bk_mul_small(const B& p, uint32_t k) {
 
 // lane (w, seg): sum_{b in [lo, lo+L)} (b+1) * B[w][b]  =  sum (b-lo+1) B_b  +  lo * sum B_b
 template <class B>
-__global__ void __launch_bounds__(64) k_msm_reduce_segments(const B* __restrict__ buckets, uint32_t nb, uint32_t seg_len, int nwin, B* __restrict__ partials) {
+__global__ void __launch_bounds__(64) k_msm_reduce_segments(const RedSets<B> S, uint32_t nb, uint32_t seg_len, int nwin) {
+    const B* __restrict__ buckets = S.buckets[blockIdx.y]; B* __restrict__ partials = S.partials[blockIdx.y];
     const uint32_t segs = nb / seg_len;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)nwin * segs) return;
@@ -567,7 +580,8 @@ __global__ void __launch_bounds__(64) k_msm_reduce_segments(const B* __restrict_
 
 // workgroup g: sums[g] = sum of its `segs` partials (strided serial sums, then an LDS tree), converted to canonical XYZZ for the host
 template <class F, class B, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_msm_window_sum(const B* __restrict__ partials, uint32_t segs, XYZZ<F>* __restrict__ window_sums) {
+__global__ void __launch_bounds__(THREADS) k_msm_window_sum(const RedSets<B> S, uint32_t segs) {
+    const B* __restrict__ partials = S.partials[blockIdx.y]; XYZZ<F>* __restrict__ window_sums = (XYZZ<F>*)S.wsums[blockIdx.y];
     extern __shared__ uint4 lds_raw[];
     B* sh = reinterpret_cast<B*>(lds_raw);
     const B* P = partials + (size_t)blockIdx.x * segs;
@@ -592,7 +606,8 @@ __global__ void __launch_bounds__(THREADS) k_msm_window_sum(const B* __restrict_
 //   k_msm_bitsum_final:   one wave per bit folds the G workgroup results into T_k (canonical XYZZ for the host)
 // The host finishes with one Horner pass over the c sums (one doubling per bit).
 template <class B, int ITEMS>
-__global__ void __launch_bounds__(256) k_msm_bitsum_partial(const B* __restrict__ buckets, uint32_t nb, uint32_t groups, B* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_msm_bitsum_partial(const RedSets<B> S, uint32_t nb, uint32_t groups) {
+    const B* __restrict__ buckets = S.buckets[blockIdx.y]; B* __restrict__ partials = S.partials[blockIdx.y];
     extern __shared__ uint4 lds_raw[];
     B* sh = reinterpret_cast<B*>(lds_raw);
     const uint32_t k = blockIdx.x / groups, g = blockIdx.x % groups;
@@ -614,7 +629,8 @@ __global__ void __launch_bounds__(256) k_msm_bitsum_partial(const B* __restrict_
     if (threadIdx.x == 0) st_struct(partials + blockIdx.x, sh[0]);
 }
 template <class F, class B>
-__global__ void __launch_bounds__(64) k_msm_bitsum_final(const B* __restrict__ partials, uint32_t groups, XYZZ<F>* __restrict__ bit_sums) {
+__global__ void __launch_bounds__(64) k_msm_bitsum_final(const RedSets<B> S, uint32_t groups) {
+    const B* __restrict__ partials = S.partials[blockIdx.y]; XYZZ<F>* __restrict__ bit_sums = (XYZZ<F>*)S.wsums[blockIdx.y];
     extern __shared__ uint4 lds_raw[];
     B* sh = reinterpret_cast<B*>(lds_raw);
     const B* P = partials + (size_t)blockIdx.x * groups;
@@ -642,7 +658,9 @@ __global__ void __launch_bounds__(64) k_msm_bitsum_final(const B* __restrict__ p
 //   k_msm_grid_bitsum:  workgroup (side, bit k, group g): 256 lanes x ITEMS partials whose weight has bit k set + LDS tree -> one
 //       canonical XYZZ sum per workgroup for the host (62 of them at 2^19 buckets)
 template <class B>
-__global__ void __launch_bounds__(256) k_msm_grid_partial(const B* __restrict__ buckets, uint32_t log_l, uint32_t nb, B* __restrict__ colpart, B* __restrict__ rowpart) {
+__global__ void __launch_bounds__(256) k_msm_grid_partial(const RedSets<B> S, uint32_t log_l, uint32_t nb) {
+    const B* __restrict__ buckets = S.buckets[blockIdx.y];
+    B* __restrict__ colpart = S.partials[blockIdx.y]; B* __restrict__ rowpart = colpart + (size_t)((nb >> log_l) / GRID_TR) * ((size_t)1 << log_l);   // [H / TR][L], then [H][L / TC]
     extern __shared__ uint4 lds_raw[];
     B* sh = reinterpret_cast<B*>(lds_raw);
     const uint32_t L = 1u << log_l, ncb = L / GRID_TC;
@@ -684,8 +702,9 @@ __global__ void __launch_bounds__(256) k_msm_grid_partial(const B* __restrict__ 
 // j-th integer (j >= 0) whose bit k is set
 __device__ __forceinline__ uint32_t nth_with_bit(uint32_t j, uint32_t k) { return ((j >> k) << (k + 1)) | (1u << k) | (j & ((1u << k) - 1u)); }
 template <class F, class B, int ITEMS>
-__global__ void __launch_bounds__(256) k_msm_grid_bitsum(const B* __restrict__ colpart, const B* __restrict__ rowpart, uint32_t log_l, uint32_t log_h,
-                                                         uint32_t gc, uint32_t gr, XYZZ<F>* __restrict__ sums) {
+__global__ void __launch_bounds__(256) k_msm_grid_bitsum(const RedSets<B> S, uint32_t log_l, uint32_t log_h, uint32_t gc, uint32_t gr) {
+    const B* __restrict__ colpart = S.partials[blockIdx.y]; const B* __restrict__ rowpart = colpart + (size_t)(((size_t)1 << log_h) / GRID_TR) * ((size_t)1 << log_l);
+    XYZZ<F>* __restrict__ sums = (XYZZ<F>*)S.wsums[blockIdx.y];
     extern __shared__ uint4 lds_raw[];
     B* sh = reinterpret_cast<B*>(lds_raw);
     const uint32_t L = 1u << log_l, H = 1u << log_h, nrb = H / GRID_TR, ncb = L / GRID_TC, t = threadIdx.x;

@@ -161,7 +161,15 @@ int32_t cgh_session_prove_rep3_party_ex(void* h, const uint64_t* pub_in, const u
             HipDriver driver(ctx.c, z.curve, Mode::Rep3, &net);
             driver.aux = second.c; driver.owns_aux = false; driver.md = workers.get();
             driver.rsrc = &rnd; driver.additive_h = s->additive_h;
-            VecGuard wit(driver, driver.upload_vec((const Fr*)wit_a, (const Fr*)wit_b, n_aux));
+            // One device: the shares start crossing PCIe, and while they do (nothing else can run yet) the masks of the witness map's two
+            // mul_vec calls are drawn — the first draws of the proof in the reference's order too (rep3.rs:656-660 precede :595-598) —
+            // on this context's still idle stream; only then is the stream made to wait for the shares.
+            const bool early_masks = workers.get() == nullptr;
+            VecGuard wit(driver, driver.upload_vec((const Fr*)wit_a, (const Fr*)wit_b, n_aux, !early_masks));
+            if (early_masks) {
+                driver.prefetch_masks(2, groth16_domain(z.curve, z.pow, z.num_constraints, pub.size()).m);
+                driver.fence_uploads(wit.v);
+            }
             CoGroth16 prover(driver);
             Proof p = prover.prove(pz.dz, pub, wit.v, nullptr, nullptr);                 // groth16.rs:113-139
             if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

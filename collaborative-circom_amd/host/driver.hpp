@@ -383,19 +383,26 @@ public:
     void* dalloc(size_t bytes) { void* p; CG(cg_dev_alloc(ctx, bytes, &p)); return p; }
     ShareVec alloc_vec(size_t n) { ShareVec v; v.n = n; for (int j = 0; j < k(); j++) { v.c[j] = dalloc(n * 32); CG(cg_dev_memset_zero(ctx, v.c[j], n * 32)); } return v; }
     void free_vec(ShareVec& v) { for (int j = 0; j < 2; j++) if (v.c[j]) { CG(cg_dev_free(ctx, v.c[j])); v.c[j] = nullptr; } }
-    ShareVec upload_vec(const Fr* a, const Fr* b, size_t n) {
+    // fence = false: the copies are started and this context's stream is NOT yet made to wait for them — the caller enqueues work that
+    // does not read the shares (the masking draws of the two mul_vec calls) and then calls fence_uploads
+    ShareVec upload_vec(const Fr* a, const Fr* b, size_t n, bool fence = true) {
         ShareVec v; v.n = n;
         if (n >= XCHG_ASYNC_MIN && cg_host_is_pinned(a) && (!b || k() < 2 || cg_host_is_pinned(b))) {   // page-locked shares: asynchronous DMA, the stream waits
             v.c[0] = dalloc(n * 32);
-            int32_t tk = v.up[0] = upload_staged(v.c[0], a, n);
-            if (b && k() == 2) { v.c[1] = dalloc(n * 32); tk = v.up[1] = upload_staged(v.c[1], b, n); }
+            v.up[0] = upload_staged(v.c[0], a, n);
+            if (b && k() == 2) { v.c[1] = dalloc(n * 32); v.up[1] = upload_staged(v.c[1], b, n); }
             v.up_ctx = ctx;
-            if (tk >= 0) CG(cg_copy_fence(ctx, tk));                                   // this context's stream: behind the last copy (they complete in order)
+            if (fence) fence_uploads(v);
             return v;                                                                   // other readers: msm_begin_multi (per component, on the device)
         }
         v.c[0] = dalloc(n * 32); CG(cg_dev_upload(ctx, v.c[0], a, n * 32));
         if (k() == 2) { v.c[1] = dalloc(n * 32); CG(cg_dev_upload(ctx, v.c[1], b, n * 32)); }
         return v;
+    }
+    void fence_uploads(const ShareVec& v) {                                           // this context's stream: behind the last copy (they complete in order)
+        if (!v.up_ctx) return;
+        const int32_t tk = v.up[1] >= 0 ? v.up[1] : v.up[0];
+        if (tk >= 0) CG(cg_copy_fence(ctx, tk));
     }
     Fr draw(const Fr* s) const { if (cursor >= rng_len) throw std::runtime_error("randomness stream exhausted"); return s[cursor]; }
 
@@ -466,8 +473,13 @@ public:
     const size_t DEVICE_MASKS_MIN = getenv("CGH_DEVICE_MASKS_MIN") ? (size_t)atoll(getenv("CGH_DEVICE_MASKS_MIN")) : (size_t)1 << 14;   // (the override lets the small fixtures take the device path)
     bool masks_on_device(void* d_m, size_t n) {
         if (!rsrc || n < DEVICE_MASKS_MIN) return false;
-        void* tmp = dalloc(n * 32);
-        const bool done = rsrc->masks_on_device(ctx, curve.id, n, d_m, tmp);
+        void* tmp = nullptr;
+        if (const int32_t rc = cg_dev_alloc(ctx, n * 32, &tmp)) {                       // no room for the second stream's draws: the host callback draws instead (generators untouched)
+            if (rc == CG_ERR_OOM) return false;
+            throw std::runtime_error(cg_last_error());
+        }
+        bool done = false;
+        try { done = rsrc->masks_on_device(ctx, curve.id, n, d_m, tmp); } catch (...) { cg_dev_free(ctx, tmp); throw; }
         defer_free(tmp);
         return done;
     }
@@ -731,16 +743,22 @@ public:
         for (auto& part : p.parts) for (int j = 0; j < 2; j++) if (part.sc[j]) { cg_dev_free(part.on, part.sc[j]); part.sc[j] = nullptr; }
         p.parts.clear();
     }
-    // One cg_msm_dev_begin_multi call with the G2 tables FIRST in every share component's run of accumulations (tickets come back in the
-    // caller's table order).  The G2 accumulation of a context that runs beside a chain is launched one chip-load at a time, which costs
-    // ~2 ms per launch when nothing else wants the chip: with the G2 table last, the last MSM to finish — alone on the GPU, after the chain
-    // has long completed — was exactly that one (timeline of a 2^22 party: 14 ms for the final G2 accumulation against 11.8 unsliced).
+    // One cg_msm_dev_begin_multi call with the launch order of its tables chosen here (tickets come back in the caller's table order).
+    // Round 4: G1 tables first, the G2 table LAST, and the library runs odd share components in reverse (CG_OPT_MSM_TABLE_ORDER = 1):
+    // [a b1 l b2][b2 l b1 a].  The two G2 accumulations — whose workgroups hold 147 of a CU's 160 KB of LDS, so that no transform pass of
+    // the chain context can start while one lasts — then run back to back in the MIDDLE of the call, after the chain's transforms (which
+    // share the chip with the G1 accumulations of component a) and before the call's tail, which is G1 launches only; launching them one
+    // chip-load at a time (rounds 2-3, ~2 ms per launch, CG_OPT_MSM_G2_SLICES) is no longer needed.  CGH_G2_ORDER=first: the round-3
+    // order (G2 first in every component, sliced beside a chain) for A/B runs.
     void begin_multi_ordered(cg_ctx* on, const std::vector<const cg_bases*>& tables, const std::vector<size_t>& offsets, const std::vector<int>& groups, size_t n,
                              const void* const* sc, std::vector<int32_t>& tickets) {
-        static const bool g2_first = getenv("CGH_G2_LAST") == nullptr;                  // A/B knob: the round-2 order
+        static const bool g2_first = getenv("CGH_G2_ORDER") && !strcmp(getenv("CGH_G2_ORDER"), "first");   // A/B knob
         std::vector<size_t> ord;
-        for (size_t i = 0; i < tables.size(); i++) if (g2_first && groups[i] == CG_G2) ord.push_back(i);
-        for (size_t i = 0; i < tables.size(); i++) if (!(g2_first && groups[i] == CG_G2)) ord.push_back(i);
+        for (size_t i = 0; i < tables.size(); i++) if ((groups[i] == CG_G2) == g2_first) ord.push_back(i);
+        for (size_t i = 0; i < tables.size(); i++) if ((groups[i] == CG_G2) != g2_first) ord.push_back(i);
+        CG(cg_ctx_set_option(on, CG_OPT_MSM_TABLE_ORDER, g2_first ? 0 : 1));
+        int64_t chunk = 0; CG(cg_ctx_get_option(on, CG_OPT_MSM_CHUNK, &chunk));
+        CG(cg_ctx_set_option(on, CG_OPT_MSM_G2_SLICES, g2_first && chunk ? 1 : 0));
         std::vector<const cg_bases*> t(tables.size()); std::vector<size_t> o(tables.size()); std::vector<int32_t> tk(tables.size());
         for (size_t j = 0; j < ord.size(); j++) { t[j] = tables[ord[j]]; o[j] = offsets[ord[j]]; }
         CG(cg_msm_dev_begin_multi(on, (int32_t)t.size(), t.data(), o.data(), n, sc, k(), tk.data()));

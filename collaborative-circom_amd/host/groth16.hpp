@@ -139,7 +139,7 @@ public:
         } else {
         // the masks of the witness map's two mul_vec calls (:174, :190) start their way to the device now: behind the witness shares and the
         // few small synchronous uploads of the MSM set-up (the copy engine serves its requests in order), ahead of everything else
-        driver.prefetch_masks(2, groth16_domain(c, z.pow, z.num_constraints, public_inputs.size()).m);
+        if (driver.prefetched.empty()) driver.prefetch_masks(2, groth16_domain(c, z.pow, z.num_constraints, public_inputs.size()).m);   // (a party entry draws them before its shares have arrived)
         mk.mark("mask uploads enqueued");
         h = witness_map_from_matrices(dz, public_inputs, private_witness);
         mk.mark("witness map");

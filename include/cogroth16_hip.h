@@ -133,6 +133,31 @@ int32_t cg_msm_dev_begin_multi(cg_ctx* ctx, int32_t n_tables, const cg_bases* co
  * (`Rep3PrimeFieldShareVec{a, b}`, rep3/fieldshare.rs:233-236, arrives as two vectors).  Consumed by that one call; `owner` must stay alive
  * until that call has returned (the library keeps a reference to the copy's completion event, not to the context). */
 int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int32_t copy_ticket);
+/* ---- per-context tuning (never changes results).  One table instead of process-wide environment variables: every option belongs to the
+ * context it is set on (a party's chain and bulk contexts differ), is read at the next call that uses it, and can be read back.
+ *   option                         value                                                                                   default
+ *   CG_OPT_MSM_CHUNK               entries of the sorted list one lane folds in the bucket accumulation (0 = automatic: ~128,    0
+ *                                  whole residency rounds); shorter = shorter-lived workgroups, for a context whose MSMs run
+ *                                  beside a dependency chain on another context                       (= cg_msm_set_chunk)
+ *   CG_OPT_MSM_WINDOW              window size of tables without precomputed copies (0 = by size)     (= cg_msm_set_window)     0
+ *   CG_OPT_MSM_SCATTER_CAP         see cg_msm_set_scatter_capacity                                                              -1
+ *   CG_OPT_MSM_TABLE_ORDER         order of the tables of a cg_msm_dev_begin_multi call inside each share component:            0
+ *                                  0 = the caller's order in every component; 1 = serpentine (odd components run the tables in
+ *                                  reverse): with the G2 table LAST in the caller's order its two accumulations run back to back
+ *                                  in the middle of the call — [a b1 l b2][b2 l b1 a] — after a neighbouring chain context has
+ *                                  finished its transforms and before the call's tail, which then consists of G1 launches only
+ *   CG_OPT_MSM_G2_SLICES           1 = a context with CG_OPT_MSM_CHUNK set launches a G2 accumulation one chip-load of               0
+ *                                  workgroups at a time (its workgroups hold 147 of a CU's 160 KB of LDS: nothing that needs LDS,
+ *                                  e.g. a transform pass of the chain context, can start while a launch lasts); costs ~2 ms per
+ *                                  launch when nothing waits
+ *   CG_OPT_MSM_REDUCE_BATCH        bucket sets merged and reduced together: 2 = per call and coordinate field, 1 = per share        2
+ *                                  component and field, 0 = each on its own right behind its accumulation
+ *   CG_OPT_MSM_ACC_SLOTS           rotating scratch slots of the accumulate / reduce pipeline (2 .. 8; batches take one per set)    4
+ * Environment variables of the same names (CG_OPT_... without the prefix: CG_MSM_CHUNK, ...) seed the defaults of NEW contexts for A/B runs. */
+enum { CG_OPT_MSM_CHUNK = 1, CG_OPT_MSM_WINDOW = 2, CG_OPT_MSM_SCATTER_CAP = 3, CG_OPT_MSM_TABLE_ORDER = 4, CG_OPT_MSM_G2_SLICES = 5,
+       CG_OPT_MSM_REDUCE_BATCH = 6, CG_OPT_MSM_ACC_SLOTS = 7, CG_OPT_COUNT_ };
+int32_t cg_ctx_set_option(cg_ctx* ctx, int32_t option, int64_t value);
+int32_t cg_ctx_get_option(const cg_ctx* ctx, int32_t option, int64_t* value);
 /* window size override (0 = automatic); tuning knob only, never changes results */
 /* entries of the sorted list one lane folds in the bucket accumulation of THIS context's MSMs (0 = automatic: ~128, whole residency
  * rounds).  Shorter chunks = shorter-lived workgroups: for a context whose MSMs run beside a dependency chain on another context. */
