@@ -125,6 +125,8 @@ struct cg_ctx {
     // ticket = running copy number (31 bits); slot = ticket % COPY_TICKETS holds its event.  A slot is recycled only after its
     // previous copy has completed (copy_begin waits for it), so a ticket older than the slot's current owner names a finished copy.
     hipEvent_t copy_ev[COPY_TICKETS] = {}; uint32_t copy_id[COPY_TICKETS] = {}; hipEvent_t ev_copy_order = nullptr; uint32_t copy_next = 0;
+    static constexpr int MARKS = 16;                      // cg_stream_mark: points of the stream order that downloads can be ordered behind
+    hipEvent_t mark_ev[MARKS] = {}; uint32_t mark_next = 0;
     // cg_msm_scalars_after: the scalar-side schedule of component j of the NEXT begin call waits for this event (an upload still in flight)
     hipEvent_t comp_after[4] = {};
     hipStream_t joinst = nullptr; hipEvent_t park_ev[5] = {};   // cg_dev_free: a work-free stream that joins the context's streams behind a released block
@@ -1018,6 +1020,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     hipStreamSynchronize(ctx->aux);
     hipStreamSynchronize(ctx->sortst);
     for (int i = 0; i < cg_ctx::ACC_SLOTS_MAX; i++) { hipEventDestroy(ctx->ev_acc[i]); hipEventDestroy(ctx->ev_red[i]); }
+    for (hipEvent_t e : ctx->mark_ev) if (e) hipEventDestroy(e);
     for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_sorted[i]); hipEventDestroy(ctx->ev_sched_free[i]); hipEventDestroy(ctx->ev_merged[i]); }
     hipEventDestroy(ctx->ev_in);
     if (ctx->h2d) {
@@ -1208,12 +1211,13 @@ int32_t cg_host_is_pinned(const void* h_ptr) {
     if (hipPointerGetAttributes(&a, h_ptr) != hipSuccess) { (void)hipGetLastError(); return 0; }   // ordinary pageable memory is unknown to the runtime
     return a.type == hipMemoryTypeHost ? 1 : 0;
 }
-static int32_t copy_begin(cg_ctx* ctx, bool up, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, bool after_stream, int32_t* ticket) {
+static int32_t copy_begin(cg_ctx* ctx, bool up, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, bool after_stream, int32_t* ticket, hipEvent_t after_mark = nullptr) {
     if (!ctx || !ticket || ((!dst || !src) && bytes)) return fail(CG_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
     if (!ctx->h2d) { int rc = make_copy_streams(ctx); if (rc) return rc; }   // the copy streams exist from the first asynchronous copy on
     hipStream_t st = up ? ctx->h2d : ctx->d2h;
-    if (after_stream) {                                     // everything enqueued on the context's stream so far comes first
+    if (after_mark) HIPCHK(hipStreamWaitEvent(st, after_mark, 0));       // behind a marked point of the stream order, not behind its tail
+    else if (after_stream) {                                     // everything enqueued on the context's stream so far comes first
         HIPCHK(hipEventRecord(ctx->ev_copy_order, ctx->stream));
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_copy_order, 0));
     }
@@ -1228,6 +1232,20 @@ static int32_t copy_begin(cg_ctx* ctx, bool up, void* dst, const void* src, size
 }
 int32_t cg_dev_download_begin(cg_ctx* ctx, void* h_dst_pinned, const void* d_src, size_t bytes, int32_t* ticket) {
     return copy_begin(ctx, false, h_dst_pinned, d_src, bytes, hipMemcpyDeviceToHost, true, ticket);
+}
+int32_t cg_stream_mark(cg_ctx* ctx, int32_t* mark) {
+    if (!ctx || !mark) return fail(CG_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t id = ctx->mark_next++ & 0x7fffffffu, slot = id % cg_ctx::MARKS;
+    if (!ctx->mark_ev[slot]) HIPCHK(hipEventCreateWithFlags(&ctx->mark_ev[slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ctx->mark_ev[slot], ctx->stream));
+    *mark = (int32_t)id;
+    return 0;
+}
+int32_t cg_dev_download_begin_after(cg_ctx* ctx, void* h_dst_pinned, const void* d_src, size_t bytes, int32_t mark, int32_t* ticket) {
+    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
+    if (mark < 0 || (uint32_t)mark >= ctx->mark_next || ctx->mark_next - (uint32_t)mark > (uint32_t)cg_ctx::MARKS || !ctx->mark_ev[mark % cg_ctx::MARKS]) return fail(CG_ERR_ARG, "bad or expired stream mark");
+    return copy_begin(ctx, false, h_dst_pinned, d_src, bytes, hipMemcpyDeviceToHost, false, ticket, ctx->mark_ev[mark % cg_ctx::MARKS]);
 }
 int32_t cg_dev_upload_begin(cg_ctx* ctx, void* d_dst, const void* h_src_pinned, size_t bytes, int32_t after_stream, int32_t* ticket) {
     return copy_begin(ctx, true, d_dst, h_src_pinned, bytes, hipMemcpyHostToDevice, after_stream != 0, ticket);

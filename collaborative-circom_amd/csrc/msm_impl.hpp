@@ -113,7 +113,7 @@ int msm_accumulate_launch(hipStream_t st, const Affine<F>* d_bases, size_t n, in
             if (variant == 1) rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 1>, 128, lds2 + 128 * 4);
             else if (variant == 2) rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 2>, 128, lds2);
             else if (variant == 10) rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 0>, 128, lds2);
-            else rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 3>, 128, lds2);
+            else rc_acc = launch_pf(k_msm_accumulate_pf<F, LdsAcc29<F>, 128, 1, 3>, 128, lds2);   // (256-lane workgroups, two per CU, were A/B'd in round 4: no gain beside a chain, +2 ms alone)
         }
     } else if constexpr (!g2) rc_acc = launch_acc(k_msm_accumulate<F, RegAcc29<F>, 256>, 256, 0);
     else rc_acc = launch_acc(k_msm_accumulate<F, LdsAcc29<F>, 128>, 128, lds2);

@@ -505,14 +505,16 @@ public:
         }
     }
     struct Down { uint8_t* slot; int32_t tk; };
-    struct PendingMul { ShareVec out; bool exchange = false; std::deque<Down> down; size_t issued = 0; };
+    struct PendingMul { ShareVec out; bool exchange = false; std::deque<Down> down; size_t issued = 0; int32_t mark = -1; };   // mark: where the stream produced `out` (cg_stream_mark)
     // start streaming chunks of the local product to the host, as many as the ring has room for
     void issue_downloads(PendingMul& pm, size_t upto) {
         const size_t n = pm.out.n, ch = xchg_chunk(n), nch = (n + ch - 1) / ch;
         while (pm.issued < nch && pm.issued < upto) {
             const size_t off = pm.issued * ch, len = std::min(ch, n - off);
             Down d; d.slot = ring_slot(ring_out, ch);
-            CG(cg_dev_download_begin(ctx, d.slot, (const uint8_t*)pm.out.c[0] + off * 32, len * 32, &d.tk));
+            // behind the product kernel, NOT behind the transforms the prover has enqueued since (they used to hold chunks 8 .. 31 back for 20 ms)
+            if (pm.mark >= 0) CG(cg_dev_download_begin_after(ctx, d.slot, (const uint8_t*)pm.out.c[0] + off * 32, len * 32, pm.mark, &d.tk));
+            else CG(cg_dev_download_begin(ctx, d.slot, (const uint8_t*)pm.out.c[0] + off * 32, len * 32, &d.tk));
             ring_out.busy[ring_out.last] = d.tk;
             pm.down.push_back(d); pm.issued++;
         }
@@ -558,6 +560,7 @@ public:
         if (!exchange) return pm;
         out.c[1] = dalloc(a.n * 32);
         pm.exchange = true;
+        if (a.n >= XCHG_ASYNC_MIN) CG(cg_stream_mark(ctx, &pm.mark));
         if (a.n >= XCHG_ASYNC_MIN) issue_downloads(pm, XCHG_SLOTS - 1);                // ordered right behind the product, ahead of whatever the caller enqueues next
         return pm;
     }

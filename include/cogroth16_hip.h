@@ -83,6 +83,12 @@ int32_t cg_host_free(void* h_ptr);
  * source / destination of the asynchronous copies directly, without staging */
 int32_t cg_host_is_pinned(const void* h_ptr);
 int32_t cg_dev_download_begin(cg_ctx* ctx, void* h_dst_pinned, const void* d_src, size_t bytes, int32_t* ticket);
+/* A download begun with cg_dev_download_begin is ordered behind EVERYTHING the context's stream holds when it is begun.  A caller that
+ * streams a vector down chunk by chunk while it keeps enqueuing unrelated kernels (the mul_vec exchange under the transforms,
+ * groth16.rs:174-188) marks the point where the vector was produced — cg_stream_mark, up to 16 marks alive per context — and begins the
+ * chunks' downloads behind that mark: they then do not wait for the kernels enqueued after it. */
+int32_t cg_stream_mark(cg_ctx* ctx, int32_t* mark);
+int32_t cg_dev_download_begin_after(cg_ctx* ctx, void* h_dst_pinned, const void* d_src, size_t bytes, int32_t mark, int32_t* ticket);
 int32_t cg_dev_upload_begin(cg_ctx* ctx, void* d_dst, const void* h_src_pinned, size_t bytes, int32_t after_stream, int32_t* ticket);
 int32_t cg_copy_wait(cg_ctx* ctx, int32_t ticket);
 int32_t cg_copy_fence(cg_ctx* ctx, int32_t ticket);
