@@ -540,7 +540,7 @@ def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barri
         inner = [solo() for _ in range(proofs)]
         barrier()
         elapsed = time.perf_counter() - t0
-        out.update({"proofs": proofs, "warmup": warmup, "elapsed_s": elapsed, "ms_per_proof": elapsed / proofs * 1e3, "ms_per_proof_min_inner": min(inner) * 1e3, "ms_per_proof_mean_inner": sum(inner) / len(inner) * 1e3,
+        out.update({"proofs": proofs, "warmup": warmup, "elapsed_s": elapsed, "ms_per_proof": elapsed / proofs * 1e3, "ms_per_proof_min_inner": min(inner) * 1e3, "ms_per_proof_mean_inner": sum(inner) / len(inner) * 1e3, "ms_inner_each": [round(x * 1e3, 1) for x in inner],
                     "value": nc / (elapsed / proofs), "unit": "constraints/s"})
         if extras:
             try:                                                                         # the reference's way: the same generators drawn on one host thread inside the call

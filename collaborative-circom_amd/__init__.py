@@ -35,7 +35,7 @@ def build(bls=True, jobs=8):
 
 
 # per-context tuning options (include/cogroth16_hip.h)
-OPT_MSM_CHUNK, OPT_MSM_WINDOW, OPT_MSM_SCATTER_CAP, OPT_MSM_TABLE_ORDER, OPT_MSM_G2_SLICES, OPT_MSM_REDUCE_BATCH, OPT_MSM_ACC_SLOTS = 1, 2, 3, 4, 5, 6, 7
+OPT_MSM_CHUNK, OPT_MSM_WINDOW, OPT_MSM_SCATTER_CAP, OPT_MSM_TABLE_ORDER, OPT_MSM_G2_SLICES, OPT_MSM_REDUCE_BATCH, OPT_MSM_ACC_SLOTS, OPT_MSM_G2_AFTER = 1, 2, 3, 4, 5, 6, 7, 8
 
 # every symbol include/cogroth16_hip.h declares (checked by tests/test_abi_surface.py)
 ABI_SYMBOLS = [
@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "cg_host_alloc", "cg_host_free", "cg_host_is_pinned", "cg_dev_download_begin", "cg_dev_upload_begin", "cg_stream_mark", "cg_dev_download_begin_after", "cg_copy_wait", "cg_copy_fence",
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev", "cg_vec_affine_dev", "cg_vec_fill_dev", "cg_vec_gather_strided_dev", "cg_vec_lincomb_dev", "cg_vec_prefix_prod_dev", "cg_vec_prefix_sum_dev", "cg_vec_inverse_dev",
     "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
-    "cg_point_add", "cg_point_neg", "cg_point_scalar_mul", "cg_point_to_affine", "cg_point_from_affine", "cg_point_validate", "cg_fr_is_canonical", "cg_vec_check_canonical_dev", "cg_fr_op",
+    "cg_point_add", "cg_point_neg", "cg_point_scalar_mul", "cg_fixed_base_create", "cg_fixed_base_mul", "cg_fixed_base_destroy", "cg_point_to_affine", "cg_point_from_affine", "cg_point_validate", "cg_fr_is_canonical", "cg_vec_check_canonical_dev", "cg_fr_op",
     "cg_fr_from_canonical", "cg_fr_to_canonical", "cg_fq_to_canonical", "cg_fq_from_canonical", "cg_point_generator",
     "cg_bases_synth_multiples", "cg_bases_download", "cg_bases_from_scalars",
     "cg_dev_copy_peer", "cg_ctx_device", "cg_device_count",
@@ -438,6 +438,27 @@ def point_scalar_mul(curve, group, a, k):
     out = np.zeros(point_words(curve, group, 3), dtype=np.uint64)
     _chk(load().cg_point_scalar_mul(curve, group, _hp(np.ascontiguousarray(a)), _hp(np.ascontiguousarray(k)), _hp(out)))
     return out
+
+
+class FixedBase:
+    """8-bit window table of one base point (cg_fixed_base_*): host arithmetic, no device"""
+
+    def __init__(self, curve, group, point_jacobian):
+        self.curve, self.group, self.h = curve, group, C.c_void_p()
+        p = np.ascontiguousarray(point_jacobian, dtype=np.uint64)
+        _chk(load().cg_fixed_base_create(curve, group, _hp(p), C.byref(self.h)))
+
+    def mul(self, k):
+        out = np.zeros(point_words(self.curve, self.group, 3), dtype=np.uint64)
+        _chk(load().cg_fixed_base_mul(self.h, _hp(np.ascontiguousarray(k, dtype=np.uint64)), _hp(out)))
+        return out
+
+    def close(self):
+        if self.h: load().cg_fixed_base_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
 
 
 def point_generator(curve, group):

@@ -4,6 +4,7 @@
 #include "common.hpp"
 #include "curve.hpp"
 #include "subgroup.hpp"
+#include "host_ec64.hpp"
 #include "ntt_kernels.hpp"   // NttVecs, plan constants (no kernels are instantiated in this translation unit)
 
 #include <cmath>
@@ -133,7 +134,7 @@ struct cg_ctx {
     // priority class of each stream: +1 high, 0 normal, -1 low (pooled_stream)
     int prio_main = 0, prio_side = 1, prio_copy = 0;
     uint32_t msm_chunk = 0;                               // cg_msm_set_chunk / CG_OPT_MSM_CHUNK
-    int table_order = 0, g2_slices = 0, red_batch = 2, acc_slots = 4;   // CG_OPT_MSM_TABLE_ORDER / _G2_SLICES / _REDUCE_BATCH / _ACC_SLOTS (cg_ctx_set_option)
+    int table_order = 0, g2_after = -1, g2_slices = 0, red_batch = 2, acc_slots = 4;   // CG_OPT_MSM_TABLE_ORDER / _G2_SLICES / _REDUCE_BATCH / _ACC_SLOTS (cg_ctx_set_option)
     hipEvent_t ev_peer = nullptr;                         // cg_dev_copy_peer: "source stream reached this point"
     Arena arena;
     std::vector<void*> retired;                        // outgrown arena blocks that enqueued kernels may still use
@@ -493,35 +494,65 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
             pd.clear();
             return 0;
         };
+        // one accumulation: table b, share component j, into the next rotating scratch slot; its bucket set joins the batch of its field
+        auto do_acc = [&](int b, int j) -> int {
+            const MsmSortPtrs& sp = sps[j];
+            MsmTicket& t = ctx->tickets[slots[b]];
+            const int gi = t.group == CG_G1 ? 0 : 1;
+            hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
+            if (ctx->stats_on) { const int i1 = ev_open(ctx, t.group == CG_G1 ? TAG_ACC_G1 : TAG_ACC_G2); evs[0] = ctx->ev_live[i1].a; evs[1] = ctx->ev_live[i1].b; pev = evs; }
+            const int slot = iter++ % acc_slots;
+            for (int g2 = 0; g2 < 2; g2++) {                 // the slot still holds a set that waits for its batch: run that batch now
+                bool held = false;
+                for (const PendSet& ps : pend[g2]) held = held || ps.slot == slot;
+                if (held) { int rc = flush(g2); if (rc) return rc; }
+            }
+            if (ctx->slot_busy[slot]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_red[slot], 0));   // slot's previous reduction must be done
+            char* scratch = acc_scratch + (size_t)slot * acc_slot;
+            size_t pinned_stride = 0;
+            int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
+                typedef decltype(ftag) F;
+                pinned_stride = sizeof(XYZZ<F>);
+                const Affine<F>* pts = (const Affine<F>*)(shared ? bases[b]->d_pre : bases[b]->d_pts) + (offsets ? offsets[b] : 0);
+                return msm_accumulate_launch<F>(ctx->stream, pts, n, c, nwin, shared ? bases[b]->n : 0, sp.sorted, sp.offsets, sp.counts, sp.cap, scratch, pev, !bases[b]->no_inf, chunk_request, ctx->g2_slices != 0);
+            });
+            if (rc) return rc;
+            pend[gi].push_back(PendSet{MsmRedSet{scratch, sp.offsets, sp.counts, (char*)t.h_pinned + (size_t)j * nsums * pinned_stride}, slot, j % nsched, b, j});
+            return 0;
+        };
+        if (k <= 2 && ctx->table_order == 2) {
+            // CG_OPT_MSM_TABLE_ORDER = 2: ONE launch order over (table, component) pairs — the G1 pairs in serpentine order, the G2 pairs together
+            // after `g2_after` of them (CG_OPT_MSM_G2_AFTER; beyond the G1 count: at the end).  Both schedules are built up front.
+            if (k == 2) { int rc = launch_sort(1); if (rc) return rc; }
+            std::vector<std::pair<int, int>> g1o, g2o, order;
+            for (int j = 0; j < k; j++) for (int bi = 0; bi < nb; bi++) {
+                const int b = (j & 1) ? nb - 1 - bi : bi;
+                (bases[b]->group == CG_G1 ? g1o : g2o).push_back({b, j});
+            }
+            const size_t at = ctx->g2_after < 0 ? g1o.size() : std::min<size_t>((size_t)ctx->g2_after, g1o.size());
+            order.insert(order.end(), g1o.begin(), g1o.begin() + at); order.insert(order.end(), g2o.begin(), g2o.end()); order.insert(order.end(), g1o.begin() + at, g1o.end());
+            bool waited[2] = {false, false};
+            int left[2] = {(int)g1o.size(), (int)g2o.size()}, left_sched[2] = {0, 0};
+            for (auto& pr : order) left_sched[pr.second]++;
+            for (size_t i = 0; i < order.size(); i++) {
+                const int b = order[i].first, j = order[i].second, gi = bases[b]->group == CG_G1 ? 0 : 1;
+                if (!waited[j]) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[j], 0)); waited[j] = true; }
+                { int rc = do_acc(b, j); if (rc) return rc; }
+                const bool last_of_field = --left[gi] == 0;
+                const bool comp_changes = i + 1 == order.size() || order[i + 1].second != j || (bases[order[i + 1].first]->group == CG_G1 ? 0 : 1) != gi;
+                if (red_batch == 0 || (red_batch == 1 && comp_changes) || last_of_field || (int)pend[gi].size() == RED_MAX_SETS) { int rc3 = flush(gi); if (rc3) return rc3; }
+                if (--left_sched[j] == 0) HIPCHK(hipEventRecord(ctx->ev_sched_free[j], ctx->stream));
+            }
+        } else
         for (int j = 0; j < k; j++) {
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[j % nsched], 0));
             // the next component's schedule is enqueued BEFORE this component's accumulates so that the two streams run side by side
             if (j + 1 < k && nsched == 2 && j + 1 < nsched) { int rc = launch_sort(j + 1); if (rc) return rc; }
-            const MsmSortPtrs& sp = sps[j];
             int left_in_comp[2] = {tables_of_group[0], tables_of_group[1]};
             for (int bi = 0; bi < nb; bi++) {   // group side: once per table, reusing the schedule
-                const int b = (ctx->table_order == 1 && (j & 1)) ? nb - 1 - bi : bi;      // serpentine: odd components run the tables in reverse
-                MsmTicket& t = ctx->tickets[slots[b]];
-                const int gi = t.group == CG_G1 ? 0 : 1;
-                hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
-                if (ctx->stats_on) { const int i1 = ev_open(ctx, t.group == CG_G1 ? TAG_ACC_G1 : TAG_ACC_G2); evs[0] = ctx->ev_live[i1].a; evs[1] = ctx->ev_live[i1].b; pev = evs; }
-                const int slot = iter++ % acc_slots;
-                for (int g2 = 0; g2 < 2; g2++) {                 // the slot still holds a set that waits for its batch: run that batch now
-                    bool held = false;
-                    for (const PendSet& ps : pend[g2]) held = held || ps.slot == slot;
-                    if (held) { int rc = flush(g2); if (rc) return rc; }
-                }
-                if (ctx->slot_busy[slot]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_red[slot], 0));   // slot's previous reduction must be done
-                char* scratch = acc_scratch + (size_t)slot * acc_slot;
-                int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
-                    typedef decltype(ftag) F;
-                    const Affine<F>* pts = (const Affine<F>*)(shared ? bases[b]->d_pre : bases[b]->d_pts) + (offsets ? offsets[b] : 0);
-                    return msm_accumulate_launch<F>(ctx->stream, pts, n, c, nwin, shared ? bases[b]->n : 0, sp.sorted, sp.offsets, sp.counts, sp.cap, scratch, pev, !bases[b]->no_inf, chunk_request, ctx->g2_slices != 0);
-                });
-                if (rc) return rc;
-                size_t pinned_stride = 0;
-                { int rc2 = with_coord_field(curve, t.group, [&](auto ftag) -> int { pinned_stride = sizeof(XYZZ<decltype(ftag)>); return 0; }); if (rc2) return rc2; }
-                pend[gi].push_back(PendSet{MsmRedSet{scratch, sp.offsets, sp.counts, (char*)t.h_pinned + (size_t)j * nsums * pinned_stride}, slot, j % nsched, b, j});
+                const int b = (ctx->table_order >= 1 && (j & 1)) ? nb - 1 - bi : bi;      // serpentine: odd components run the tables in reverse
+                const int gi = bases[b]->group == CG_G1 ? 0 : 1;
+                { int rc = do_acc(b, j); if (rc) return rc; }
                 const bool last_here = --left_in_comp[gi] == 0;                           // this field's last table of the component
                 if (red_batch == 0 || (red_batch == 1 && last_here) || (last_here && j == k - 1) || (int)pend[gi].size() == RED_MAX_SETS) { int rc3 = flush(gi); if (rc3) return rc3; }
             }
@@ -939,6 +970,32 @@ template <class F> const FastSubgroup<F>* fast_subgroup() {
 }
 }  // namespace
 
+// ---- 64-bit-limb host arithmetic for the O(1) scalar multiplications of proof assembly (host_ec64.hpp)
+namespace {
+template <class P32, int N64> struct ModTag {
+    static constexpr int N = N64;
+    static const cg64::Mod<N64>& mod() { static const cg64::Mod<N64> m = [] { cg64::Mod<N64> x; x.init(P32::P); return x; }(); return m; }
+};
+typedef cg64::Fp<ModTag<Bn254Fq::Params, 4>> H64BnFq;
+typedef cg64::Fp<ModTag<Bn254Fr::Params, 4>> H64BnFr;
+#if CG_WITH_BLS
+typedef cg64::Fp<ModTag<Bls381Fq::Params, 6>> H64BlsFq;
+typedef cg64::Fp<ModTag<Bls381Fr::Params, 4>> H64BlsFr;
+#endif
+template <class Fn> int with_group64(int curve, int group, Fn&& fn) {
+    if (curve == CG_BN254 && group == CG_G1) return fn(H64BnFq{}, H64BnFr{});
+    if (curve == CG_BN254 && group == CG_G2) return fn(cg64::Fp2<H64BnFq>{}, H64BnFr{});
+#if CG_WITH_BLS
+    if (curve == CG_BLS12_381 && group == CG_G1) return fn(H64BlsFq{}, H64BlsFr{});
+    if (curve == CG_BLS12_381 && group == CG_G2) return fn(cg64::Fp2<H64BlsFq>{}, H64BlsFr{});
+#else
+    if (curve == CG_BLS12_381) return fail(CG_ERR_ARG, "library built without BLS12-381 (make BLS=1)");
+#endif
+    return fail(CG_ERR_ARG, "unknown curve/group id");
+}
+}  // namespace
+struct cg_fixed_base { int curve, group; void* impl; void (*destroy)(void*); };
+
 // ==================================================================================================== extern "C"
 extern "C" {
 
@@ -996,7 +1053,7 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     c->device = device;
     {   // A/B runs: environment variables seed the option table of new contexts (include/cogroth16_hip.h, cg_ctx_set_option)
         auto seed = [](const char* name, int lo, int hi, int& field) { if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= lo && v <= hi) field = v; } };
-        seed("CG_MSM_TABLE_ORDER", 0, 1, c->table_order); seed("CG_MSM_G2_SLICES", 0, 1, c->g2_slices);
+        seed("CG_MSM_TABLE_ORDER", 0, 2, c->table_order); seed("CG_MSM_G2_AFTER", -1, 64, c->g2_after); seed("CG_MSM_G2_SLICES", 0, 1, c->g2_slices);
         seed("CG_MSM_REDUCE_BATCH", 0, 2, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots);
     }
     if (flags & 1u) { c->prio_main = 1; c->prio_copy = 1; c->prio_side = 0; }
@@ -1521,7 +1578,8 @@ int32_t cg_ctx_set_option(cg_ctx* ctx, int32_t option, int64_t value) {
         case CG_OPT_MSM_CHUNK: return cg_msm_set_chunk(ctx, (int32_t)value);
         case CG_OPT_MSM_WINDOW: return cg_msm_set_window(ctx, (int32_t)value);
         case CG_OPT_MSM_SCATTER_CAP: return cg_msm_set_scatter_capacity(ctx, (int32_t)value);
-        case CG_OPT_MSM_TABLE_ORDER: if (value < 0 || value > 1) break; ctx->table_order = (int)value; return 0;
+        case CG_OPT_MSM_TABLE_ORDER: if (value < 0 || value > 2) break; ctx->table_order = (int)value; return 0;
+        case CG_OPT_MSM_G2_AFTER: if (value < -1 || value > 64) break; ctx->g2_after = (int)value; return 0;
         case CG_OPT_MSM_G2_SLICES: if (value < 0 || value > 1) break; ctx->g2_slices = (int)value; return 0;
         case CG_OPT_MSM_REDUCE_BATCH: if (value < 0 || value > 2) break; ctx->red_batch = (int)value; return 0;
         case CG_OPT_MSM_ACC_SLOTS: if (value < 2 || value > cg_ctx::ACC_SLOTS_MAX) break; ctx->acc_slots = (int)value; return 0;
@@ -1536,6 +1594,7 @@ int32_t cg_ctx_get_option(const cg_ctx* ctx, int32_t option, int64_t* value) {
         case CG_OPT_MSM_WINDOW: *value = ctx->msm_window; return 0;
         case CG_OPT_MSM_SCATTER_CAP: *value = ctx->scatter_cap; return 0;
         case CG_OPT_MSM_TABLE_ORDER: *value = ctx->table_order; return 0;
+        case CG_OPT_MSM_G2_AFTER: *value = ctx->g2_after; return 0;
         case CG_OPT_MSM_G2_SLICES: *value = ctx->g2_slices; return 0;
         case CG_OPT_MSM_REDUCE_BATCH: *value = ctx->red_batch; return 0;
         case CG_OPT_MSM_ACC_SLOTS: *value = ctx->acc_slots; return 0;
@@ -1826,14 +1885,38 @@ int32_t cg_point_neg(int32_t curve, int32_t group, const void* h_a, void* h_out)
     });
 }
 int32_t cg_point_scalar_mul(int32_t curve, int32_t group, const void* h_a, const void* h_k, void* h_out) {
-    return with_group(curve, group, [&](auto ftag, auto frtag) -> int {
+    if (!h_a || !h_k || !h_out) return fail(CG_ERR_ARG, "null argument");
+    return with_group64(curve, group, [&](auto ftag, auto frtag) -> int {     // 64-bit limbs, 4-bit windows (host_ec64.hpp)
         typedef decltype(ftag) F; typedef decltype(frtag) Fr;
-        Jacobian<F> a; memcpy(&a, h_a, sizeof a);
-        Fr k; copy_in(k, h_k); k = k.from_mont();
-        Jacobian<F> r = xyzz_to_jacobian(xyzz_scalar_mul(jacobian_to_xyzz(a), k.v, Fr::N));
+        cg64::Jac<F> a; static_assert(sizeof a == 3 * sizeof(F), ""); memcpy(&a, h_a, sizeof a);
+        Fr k; memcpy(k.v, h_k, sizeof k.v); k = k.from_mont();
+        const cg64::Jac<F> r = cg64::scalar_mul(a, k.v, Fr::N);
         memcpy(h_out, &r, sizeof r); return 0;
     });
 }
+// Fixed-base tables for the points a session multiplies in every proof (delta_1, delta_2, the generators, the public-input records of
+// the a / b1 / b2 queries): 8-bit windows, one mixed addition per scalar byte (~10 us for G1 against ~60 us variable-base).
+int32_t cg_fixed_base_create(int32_t curve, int32_t group, const void* h_point_jacobian, cg_fixed_base** out) {
+    if (!h_point_jacobian || !out) return fail(CG_ERR_ARG, "null argument");
+    return with_group64(curve, group, [&](auto ftag, auto frtag) -> int {
+        typedef decltype(ftag) F; typedef decltype(frtag) Fr;
+        cg64::Jac<F> a; memcpy(&a, h_point_jacobian, sizeof a);
+        auto* fb = new cg64::FixedBase<F>();
+        fb->build(a, Fr::N);
+        *out = new cg_fixed_base{curve, group, fb, [](void* p) { delete (cg64::FixedBase<F>*)p; }};
+        return 0;
+    });
+}
+int32_t cg_fixed_base_mul(const cg_fixed_base* t, const void* h_k, void* h_out_jacobian) {
+    if (!t || !h_k || !h_out_jacobian) return fail(CG_ERR_ARG, "null argument");
+    return with_group64(t->curve, t->group, [&](auto ftag, auto frtag) -> int {
+        typedef decltype(ftag) F; typedef decltype(frtag) Fr;
+        Fr k; memcpy(k.v, h_k, sizeof k.v); k = k.from_mont();
+        const cg64::Jac<F> r = ((const cg64::FixedBase<F>*)t->impl)->mul(k.v);
+        memcpy(h_out_jacobian, &r, sizeof r); return 0;
+    });
+}
+int32_t cg_fixed_base_destroy(cg_fixed_base* t) { if (t) { t->destroy(t->impl); delete t; } return 0; }
 int32_t cg_point_to_affine(int32_t curve, int32_t group, const void* h_a, void* h_out_affine) {
     return with_group(curve, group, [&](auto ftag, auto) -> int {
         typedef decltype(ftag) F;

@@ -85,6 +85,31 @@ static Point pt_sub(const Curve& c, const Point& a, const Point& b) { return pt_
 static Point pt_mul(const Curve& c, const Point& a, const Fr& k) { Point r{Bytes(a.b.size()), a.group}; CG(cg_point_scalar_mul(c.id, a.group, a.b.data(), k.v, r.b.data())); return r; }
 static Bytes pt_to_affine(const Curve& c, const Point& a) { Bytes r(c.aff(a.group)); CG(cg_point_to_affine(c.id, a.group, a.b.data(), r.data())); return r; }
 static Point pt_generator(const Curve& c, int g) { Point p{Bytes(c.jac(g)), g}; CG(cg_point_generator(c.id, g, p.b.data())); return p; }
+// bases multiplied in every proof: an 8-bit window table each (cg_fixed_base_*: host arithmetic on 64-bit limbs, ~10 us per G1 product
+// against ~60 us for a variable base).  nullptr table = no table: the variable-base product.
+struct FixedTable {
+    cg_fixed_base* t = nullptr;
+    FixedTable() {}
+    FixedTable(const Curve& c, const Point& p) { CG(cg_fixed_base_create(c.id, p.group, p.b.data(), &t)); }
+    ~FixedTable() { if (t) cg_fixed_base_destroy(t); }
+    FixedTable(const FixedTable&) = delete; FixedTable& operator=(const FixedTable&) = delete;
+    FixedTable(FixedTable&& o) noexcept : t(o.t) { o.t = nullptr; }
+    FixedTable& operator=(FixedTable&& o) noexcept { if (this != &o) { if (t) cg_fixed_base_destroy(t); t = o.t; o.t = nullptr; } return *this; }
+};
+static Point pt_mul_fixed(const Curve& c, const cg_fixed_base* tab, const Point& base, const Fr& k) {
+    if (!tab) return pt_mul(c, base, k);
+    Point r{Bytes(base.b.size()), base.group}; CG(cg_fixed_base_mul(tab, k.v, r.b.data())); return r;
+}
+// the generators' tables, one per (curve, group) and process, built at first use (the masking points G * rand of the in-library
+// randomness sources and of degree_reduce_point)
+static const cg_fixed_base* generator_table(const Curve& c, int g) {
+    static std::mutex mu; static FixedTable tabs[2][2];
+    std::lock_guard<std::mutex> l(mu);
+    FixedTable& t = tabs[c.id == CG_BLS12_381 ? 1 : 0][g == CG_G1 ? 0 : 1];
+    if (!t.t) t = FixedTable(c, pt_generator(c, g));
+    return t.t;
+}
+static Point pt_mul_generator(const Curve& c, int g, const Fr& k) { return pt_mul_fixed(c, generator_table(c, g), pt_generator(c, g), k); }
 
 
 // fn(lo, hi) over slices of [0, n) on a few threads; the first exception of a slice is re-thrown

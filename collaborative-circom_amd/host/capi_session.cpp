@@ -18,9 +18,11 @@ struct cgh_session {
     std::mutex mu; std::vector<std::vector<cg_ctx*>> idle, idle_chain;
     bool bulk_second = false;                                                            // the non-chain contexts run next to a chain context
     bool additive_h = false;                                                             // open flag bit 1: REP3 additive-quotient variant
+    cgh::SessionFixed fixed;                                                             // window tables of delta_1, delta_2 and the public-input records (host)
     cg_ctx* take(int slot = 0, bool chain = false) {
         auto& pool = chain ? idle_chain : idle;
-        { std::lock_guard<std::mutex> l(mu); if (!pool[slot].empty()) { cg_ctx* c = pool[slot].back(); pool[slot].pop_back(); return c; } }
+        // oldest first: the pair made at session open (below) serves a party that proves alone, always the same two contexts
+        { std::lock_guard<std::mutex> l(mu); if (!pool[slot].empty()) { cg_ctx* c = pool[slot].front(); pool[slot].erase(pool[slot].begin()); return c; } }
         static const uint32_t chain_flag = getenv("CGH_CHAIN_FLAG") ? (uint32_t)atoi(getenv("CGH_CHAIN_FLAG")) : 1u;     // tuning knobs (scripts/party_knobs_ab.sh)
         static const uint32_t bulk_flag = getenv("CGH_BULK_FLAG") ? (uint32_t)atoi(getenv("CGH_BULK_FLAG")) : 2u;
         cg_ctx* c = nullptr; if (cg_ctx_create_ex(devices[slot], chain ? chain_flag : (bulk_second && slot == 0 ? bulk_flag : 0u), &c)) cgh::die("cg_ctx_create"); return c;
@@ -90,10 +92,38 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
         }
         if (precompute) for (int d = 0; d < n_dev; d++) for (cg_bases* b : {s->dzs[d].a, s->dzs[d].b1, s->dzs[d].b2, s->dzs[d].l, s->dzs[d].h})
             if (cg_bases_len(b)) CG(cg_bases_precompute(s->ctx0[d], b, precompute > 0 ? precompute : 0));
+        {   // window tables of the bases every proof multiplies by a scalar, built side by side while the devices finish their set-up
+            const ZKey& z = s->z; const Curve& c = z.curve;
+            const size_t np = std::min<size_t>(z.n_public, SessionFixed::MAX_PUBLIC);
+            s->fixed.a_pub.resize(np); s->fixed.b1_pub.resize(np); s->fixed.b2_pub.resize(np);
+            std::vector<std::thread> th; std::vector<std::string> errs(2 + 3 * np);
+            auto job = [&](size_t slot, FixedTable* out, int group, const uint8_t* aff) {
+                th.emplace_back([&errs, slot, out, group, aff, c] { try { *out = FixedTable(c, pt_from_affine(c, group, aff)); } catch (const std::exception& e) { errs[slot] = e.what(); } });
+            };
+            job(0, &s->fixed.delta_g1, CG_G1, z.delta_g1.data()); job(1, &s->fixed.delta_g2, CG_G2, z.delta_g2.data());
+            for (size_t i = 0; i < np; i++) {
+                job(2 + 3 * i, &s->fixed.a_pub[i], CG_G1, z.a_query.data() + (1 + i) * c.aff(CG_G1));
+                job(3 + 3 * i, &s->fixed.b1_pub[i], CG_G1, z.b_g1_query.data() + (1 + i) * c.aff(CG_G1));
+                job(4 + 3 * i, &s->fixed.b2_pub[i], CG_G2, z.b_g2_query.data() + (1 + i) * c.aff(CG_G2));
+            }
+            generator_table(c, CG_G1); generator_table(c, CG_G2);
+            for (auto& t : th) t.join();
+            for (const std::string& e : errs) if (!e.empty()) throw std::runtime_error(e);
+            for (int d = 0; d < n_dev; d++) s->dzs[d].fixed = &s->fixed;
+        }
         for (int d = 0; d < n_dev; d++) CG(cg_ctx_sync(s->ctx0[d]));
-        s->second_context = s->z.n_vars >= ((size_t)1 << 19) && !getenv("CGH_ONE_CONTEXT");
+        static const int second_min = getenv("CGH_SECOND_CONTEXT_MIN") ? atoi(getenv("CGH_SECOND_CONTEXT_MIN")) : 15;    // tuning knob: log2 of the variables from which a proof uses two contexts
+        s->second_context = s->z.n_vars >= ((size_t)1 << second_min) && !getenv("CGH_ONE_CONTEXT");
         s->bulk_second = s->second_context && !getenv("CGH_NO_CHAIN_PRIORITY");
         s->additive_h = (flags & 2u) != 0;
+        // The contexts of ONE party are made here, on this thread, in a fixed order: the runtime hands a new stream the least used hardware
+        // queue of its priority class, so which streams end up sharing a queue — and with it a proof's time, by up to 4 ms at 2^22 — followed
+        // from the order in which the first proofs' threads happened to create them (three co-located parties racing).  Further parties'
+        // contexts are still made on demand.
+        if (s->second_context) for (int d = 0; d < n_dev; d++) {
+            cg_ctx* chain = s->take(d, !getenv("CGH_NO_CHAIN_PRIORITY")); cg_ctx* bulk = s->take(d, false);
+            s->give(chain, d, !getenv("CGH_NO_CHAIN_PRIORITY")); s->give(bulk, d, false);
+        }
         *out = s;
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); session_destroy(s); return 1; }
@@ -377,8 +407,7 @@ int32_t sr_masking_ec(void* u, int32_t group, uint64_t* out) {
     try {
         using namespace cgh;
         if (r->cursor >= r->len) throw std::runtime_error("randomness stream exhausted");
-        const Point gen = pt_generator(r->curve, group);
-        const Point m = pt_sub(r->curve, pt_mul(r->curve, gen, r->rng1[r->cursor]), pt_mul(r->curve, gen, r->rng2[r->cursor])); r->cursor++;
+        const Point m = pt_sub(r->curve, pt_mul_generator(r->curve, group, r->rng1[r->cursor]), pt_mul_generator(r->curve, group, r->rng2[r->cursor])); r->cursor++;
         memcpy(out, m.b.data(), m.b.size());
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
@@ -441,8 +470,7 @@ int32_t cr_masking_ec(void* u, int32_t group, uint64_t* out) {
         using namespace cgh;
         Fr a, b;
         r->rng1.fr_rand(r->mod(), r->bits(), a.v); r->rng2.fr_rand(r->mod(), r->bits(), b.v);
-        const Point gen = pt_generator(r->curve, group);
-        const Point m = pt_sub(r->curve, pt_mul(r->curve, gen, a), pt_mul(r->curve, gen, b));
+        const Point m = pt_sub(r->curve, pt_mul_generator(r->curve, group, a), pt_mul_generator(r->curve, group, b));
         memcpy(out, m.b.data(), m.b.size());
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }

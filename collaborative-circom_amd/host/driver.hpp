@@ -24,6 +24,13 @@ struct DeviceZKey {   // bases uploaded once and reused by every proof / party (
     // several GPUs: this device holds the records [aux_lo, aux_lo + aux_n) of the four private-witness queries (counted
     // from the first private variable) and [h_lo, h_lo + h_n) of h_query, registered as tables of their own (offset 0)
     bool sliced = false; size_t aux_lo = 0, aux_n = 0, h_lo = 0, h_n = 0;
+    const struct SessionFixed* fixed = nullptr;          // a session's window tables of delta_1, delta_2 and the public-input records (host arithmetic)
+};
+// Fixed for the life of a zkey (zkey.rs:48-71) and multiplied by a scalar in EVERY proof (groth16.rs:220, :259-297): 8-bit window tables
+struct SessionFixed {
+    FixedTable delta_g1, delta_g2;
+    std::vector<FixedTable> a_pub, b1_pub, b2_pub;       // query[1 + i], i < n_public
+    static constexpr size_t MAX_PUBLIC = 16;             // circuits with more public inputs multiply the remaining records variable-base
 };
 struct WorkerDevice {     // one further GPU of a party: a context on it (its MSM slices) + its table slices; `chain`: a second, high-priority
     cg_ctx* ctx = nullptr; const DeviceZKey* dz = nullptr; cg_ctx* chain = nullptr;   // context for its share of the witness map (multidev.hpp)
@@ -352,13 +359,13 @@ public:
         const int g = input.group;
         auto pr = get_pair();
         const Point gen = pt_generator(curve, g);
-        input = pt_add(curve, input, pt_mul(curve, gen, pr.second));
+        input = pt_add(curve, input, pt_mul_generator(curve, g, pr.second));
         Point my_share = pt_inf(curve, g);
         const size_t psz = curve.aff(g);
         if (me == 0) {
             Point acc = pt_mul(curve, input, mul_lagrange_2t[0]);
             for (int other = 1; other <= 2 * sh_t; other++) { Bytes a(psz); snet->recv(other, a.data(), psz); acc = pt_add(curve, acc, pt_mul(curve, received_point(g, a.data()), mul_lagrange_2t[other])); }
-            std::vector<Point> coeffs; for (int d = 0; d < sh_t; d++) coeffs.push_back(pt_mul(curve, gen, next_rand()));
+            std::vector<Point> coeffs; for (int d = 0; d < sh_t; d++) coeffs.push_back(pt_mul_generator(curve, g, next_rand()));
             for (int to = 0; to < np; to++) {
                 Point sh = acc; const Fr x = fr_from_u64(curve, (uint64_t)to + 1); Fr xp = x;
                 for (const Point& cf : coeffs) { sh = pt_add(curve, sh, pt_mul(curve, cf, xp)); xp = fr_mul(curve, xp, x); }
@@ -368,7 +375,7 @@ public:
             if (me <= 2 * sh_t) { Bytes a = pt_to_affine(curve, input); snet->send(0, a.data(), a.size()); }
             Bytes a(psz); snet->recv(0, a.data(), psz); my_share = received_point(g, a.data());
         }
-        return pt_sub(curve, my_share, pt_mul(curve, gen, pr.first));
+        return pt_sub(curve, my_share, pt_mul_generator(curve, g, pr.first));
     }
     // broadcast_next(t + 1) + reconstruct_point (network.rs:233-266, shamir.rs:778-782)
     Point shamir_open_point(const Point& mine) {
@@ -464,7 +471,7 @@ public:
     // the next party chunk by chunk while receiving the previous party's chunks, which go straight back up.  Plain / Shamir: `begin`
     // is the whole operation.
     // shorter vectors: one synchronous message (setting up rings and copy streams costs more than it hides); CGH_XCHG_ASYNC_MIN overrides (A/B runs)
-    const size_t XCHG_ASYNC_MIN = getenv("CGH_XCHG_ASYNC_MIN") ? (size_t)atoll(getenv("CGH_XCHG_ASYNC_MIN")) : (size_t)1 << 19;
+    const size_t XCHG_ASYNC_MIN = getenv("CGH_XCHG_ASYNC_MIN") ? (size_t)atoll(getenv("CGH_XCHG_ASYNC_MIN")) : (size_t)1 << 17;   // (2^19 until round 4; one REP3 party at 2^17: 8.1 -> 6.7 ms, at 2^16 the single message is faster)
     // masks of the coming mul_vec calls, uploaded ahead of time (only from page-locked randomness streams, where the copy is a plain
     // asynchronous DMA): the product kernel then never waits for PCIe
     struct MaskSet { void* m1; void* m2; int32_t tk; size_t n, at; };
@@ -485,16 +492,18 @@ public:
     }
     std::deque<MaskSet> prefetched;
     void prefetch_masks(int count, size_t n) {
-        if (mode != Mode::Rep3 || n < XCHG_ASYNC_MIN) return;
+        if (mode != Mode::Rep3) return;
         if (rsrc) {                                                                     // drawn now, in the reference's order (both mul_vec calls precede every other draw)
             for (int i = 0; i < count; i++) {
                 MaskSet ms{dalloc(n * 32), nullptr, -1, n, 0};
-                if (!masks_on_device(ms.m1, n)) ms.tk = upload_staged(ms.m1, rsrc->masking_field_elements(n, mask_scratch(n)), n);
+                if (masks_on_device(ms.m1, n)) {}                                       // any length from DEVICE_MASKS_MIN on
+                else if (n >= XCHG_ASYNC_MIN) ms.tk = upload_staged(ms.m1, rsrc->masking_field_elements(n, mask_scratch(n)), n);
+                else { CG(cg_dev_free(ctx, ms.m1)); return; }                           // short vectors from the host callback: drawn where mul_vec asks for them
                 prefetched.push_back(ms);
             }
             return;
         }
-        if (!rng1 || !rng2) return;
+        if (n < XCHG_ASYNC_MIN || !rng1 || !rng2) return;
         size_t at = cursor;
         for (int i = 0; i < count && at + n <= rng_len; i++, at += n) {
             if (!cg_host_is_pinned(rng1 + at) || !cg_host_is_pinned(rng2 + at)) return;
@@ -691,6 +700,14 @@ public:
     void ifft_coset_in_place(ShareVec& v, const Fr& group_gen, const Fr& g) { CG(cg_ntt_dev(ctx, curve.id, v.c, k(), v.n, group_gen.v, 1, g.v)); }
     // ifft_in_place; distribute_powers_and_mul_by_const(g, 1); fft_in_place (groth16.rs:175-188) as one call: no permutation passes in between
     void ifft_coset_fft_in_place(ShareVec& v, const Fr& group_gen, const Fr& g) { CG(cg_ntt_coset_pair_dev(ctx, curve.id, v.c, k(), v.n, group_gen.v, g.v)); }
+    // the same for two share vectors in ONE sequence of launches (a and b of groth16.rs:175-188: five kernels instead of ten — beside the
+    // accumulations of another context every launch waits for workgroup slots, so the chain's latency goes with the number of kernels)
+    void ifft_coset_fft_in_place2(ShareVec& u, ShareVec& v, const Fr& group_gen, const Fr& g) {
+        void* p[4]; int m = 0;
+        for (int j = 0; j < k(); j++) p[m++] = u.c[j];
+        for (int j = 0; j < k(); j++) p[m++] = v.c[j];
+        CG(cg_ntt_coset_pair_dev(ctx, curve.id, p, m, u.n, group_gen.v, g.v));
+    }
     void sub_assign_vec(ShareVec& a, const ShareVec& b) { for (int j = 0; j < k(); j++) CG(cg_vec_sub_dev(ctx, curve.id, a.c[j], a.c[j], b.c[j], a.n)); }
 
     // MSMProvider::msm_public_points (traits.rs:561-568) on a sub-slice of a registered table
@@ -746,20 +763,22 @@ public:
         for (auto& part : p.parts) for (int j = 0; j < 2; j++) if (part.sc[j]) { cg_dev_free(part.on, part.sc[j]); part.sc[j] = nullptr; }
         p.parts.clear();
     }
-    // One cg_msm_dev_begin_multi call with the launch order of its tables chosen here (tickets come back in the caller's table order).
-    // Round 4: G1 tables first, the G2 table LAST, and the library runs odd share components in reverse (CG_OPT_MSM_TABLE_ORDER = 1):
-    // [a b1 l b2][b2 l b1 a].  The two G2 accumulations — whose workgroups hold 147 of a CU's 160 KB of LDS, so that no transform pass of
-    // the chain context can start while one lasts — then run back to back in the MIDDLE of the call, after the chain's transforms (which
-    // share the chip with the G1 accumulations of component a) and before the call's tail, which is G1 launches only; launching them one
-    // chip-load at a time (rounds 2-3, ~2 ms per launch, CG_OPT_MSM_G2_SLICES) is no longer needed.  CGH_G2_ORDER=first: the round-3
-    // order (G2 first in every component, sliced beside a chain) for A/B runs.
+    // One cg_msm_dev_begin_multi call with the launch order of its (table, share component) pairs chosen here (tickets come back in the
+    // caller's table order).  Round 4: CG_OPT_MSM_TABLE_ORDER = 2 — the G1 pairs in serpentine order [a b1 l][l b1 a] with the two G2
+    // accumulations TOGETHER after the first CGH_G2_AFTER of them (default 2: [a b1 | b2 b2 | l l b1 a]).  The G2 launches are not cut into
+    // chip-loads any more (rounds 2-3: ~2 ms per launch, CG_OPT_MSM_G2_SLICES): they sit in the middle of the call, beside the chain
+    // context's transforms, and the call's tail — where a launch runs alone on the chip — is G1 launches only.  Same-box sweeps of the
+    // position (0 .. 6) all land within 1.5 ms of each other once the party's contexts are made in a fixed order (capi_session.cpp); the
+    // round-3 order (G2 first in every component, sliced) is 3-5 ms slower (profiles/r04_entry_ab_*.txt).  CGH_G2_ORDER=first restores it for A/B runs.
     void begin_multi_ordered(cg_ctx* on, const std::vector<const cg_bases*>& tables, const std::vector<size_t>& offsets, const std::vector<int>& groups, size_t n,
                              const void* const* sc, std::vector<int32_t>& tickets) {
         static const bool g2_first = getenv("CGH_G2_ORDER") && !strcmp(getenv("CGH_G2_ORDER"), "first");   // A/B knob
         std::vector<size_t> ord;
         for (size_t i = 0; i < tables.size(); i++) if ((groups[i] == CG_G2) == g2_first) ord.push_back(i);
         for (size_t i = 0; i < tables.size(); i++) if ((groups[i] == CG_G2) != g2_first) ord.push_back(i);
-        CG(cg_ctx_set_option(on, CG_OPT_MSM_TABLE_ORDER, g2_first ? 0 : 1));
+        static const int g2_after = getenv("CGH_G2_AFTER") ? atoi(getenv("CGH_G2_AFTER")) : 2;   // A/B knob: G1 accumulations in front of the two G2 ones
+        CG(cg_ctx_set_option(on, CG_OPT_MSM_TABLE_ORDER, g2_first ? 0 : 2));
+        CG(cg_ctx_set_option(on, CG_OPT_MSM_G2_AFTER, g2_after));
         int64_t chunk = 0; CG(cg_ctx_get_option(on, CG_OPT_MSM_CHUNK, &chunk));
         CG(cg_ctx_set_option(on, CG_OPT_MSM_G2_SLICES, g2_first && chunk ? 1 : 0));
         std::vector<const cg_bases*> t(tables.size()); std::vector<size_t> o(tables.size()); std::vector<int32_t> tk(tables.size());
@@ -775,7 +794,7 @@ public:
         // alone 107 -> 97 ms)
         static const uint32_t bulk_chunk = getenv("CGH_BULK_CHUNK") ? (uint32_t)atoi(getenv("CGH_BULK_CHUNK")) : 64u;   // tuning knob
         static const uint32_t plain_chunk = getenv("CGH_PLAIN_CHUNK") ? (uint32_t)atoi(getenv("CGH_PLAIN_CHUNK")) : 0u;  // tuning knob
-        if (p.on != ctx) CG(cg_msm_set_chunk(p.on, mode == Mode::Rep3 && n >= XCHG_ASYNC_MIN ? bulk_chunk : plain_chunk));
+        if (p.on != ctx) CG(cg_msm_set_chunk(p.on, mode == Mode::Rep3 && n >= ((size_t)1 << 20) ? bulk_chunk : plain_chunk));   // (below 2^20 the shorter chunks cost more than they return: 2^19 15.9 -> 13.9 ms)
         const void* sc[2] = {s.c[0], s.c[1]};
         if (p.on != ctx) {
             if (s.up_ctx) {                                                             // fresh uploads: component j's schedule waits for ITS copy on the device,
@@ -829,8 +848,8 @@ public:
         r.c[0] = local; r.c[1] = prev;
         return r;
     }
-    PointShare scalar_mul_public_point(const Point& p, const FieldShare& s) {   // rep3.rs:820-825
-        PointShare r; for (int j = 0; j < 2; j++) r.c[j] = j < k() ? pt_mul(curve, p, s.c[j]) : pt_inf(curve, p.group); return r;
+    PointShare scalar_mul_public_point(const Point& p, const FieldShare& s, const cg_fixed_base* tab = nullptr) {   // rep3.rs:820-825 (tab: p's window table, if the session holds one)
+        PointShare r; for (int j = 0; j < 2; j++) r.c[j] = j < k() ? pt_mul_fixed(curve, tab, p, s.c[j]) : pt_inf(curve, p.group); return r;
     }
     PointShare scalar_mul(const PointShare& a, const FieldShare& b) {           // rep3.rs:835-847, pointshare.rs:117-124
         PointShare r;
@@ -839,8 +858,8 @@ public:
         Point local = pt_add(curve, pt_add(curve, pt_mul(curve, a.c[0], b.c[0]), pt_mul(curve, a.c[1], b.c[0])), pt_mul(curve, a.c[0], b.c[1]));
         if (rsrc) { Point m{Bytes(curve.jac(a.c[0].group)), a.c[0].group}; rsrc->masking_ec_element(m.group, m.b.data()); local = pt_add(curve, local, m); }   // rngs.rs:48-51
         else {
-            const Point gen = pt_generator(curve, a.c[0].group);   // masking_ec_element: G*rand(rng1) - G*rand(rng2)
-            local = pt_add(curve, local, pt_sub(curve, pt_mul(curve, gen, draw(rng1)), pt_mul(curve, gen, draw(rng2)))); cursor++;
+            const int g = a.c[0].group;                            // masking_ec_element: G*rand(rng1) - G*rand(rng2)
+            local = pt_add(curve, local, pt_sub(curve, pt_mul_generator(curve, g, draw(rng1)), pt_mul_generator(curve, g, draw(rng2)))); cursor++;
         }
         Bytes aff = pt_to_affine(curve, local);                    // points cross the wire in affine form (ark-serialize)
         net->send_next(aff.data(), aff.size());

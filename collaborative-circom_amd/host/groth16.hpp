@@ -41,8 +41,7 @@ public:
             // order) are additive shares of a*b; the transforms are linear; so h_i = ab_i - c_i sums to the reference's h, and the only reader
             // of h is the MSM against h_query.  The 2 x 32 B x m exchange of :174 and :190 and the second component of c and h disappear.
             auto c_local = driver.mul_vec_begin(a, b, false);
-            driver.ifft_coset_fft_in_place(a, dom.omega, dom.coset_g);
-            driver.ifft_coset_fft_in_place(b, dom.omega, dom.coset_g);
+            driver.ifft_coset_fft_in_place2(a, b, dom.omega, dom.coset_g);
             ShareVec c = c_local.out;
             { HipDriver::Components own(driver, 1); driver.ifft_coset_fft_in_place(c, dom.omega, dom.coset_g); }
             ShareVec ab = driver.mul_vec_begin(a, b, false).out;
@@ -54,8 +53,7 @@ public:
         }
         auto c_pending = driver.mul_vec_begin(a, b);                                                   // :174
         mk.mark("mul_vec_begin");
-        driver.ifft_coset_fft_in_place(a, dom.omega, dom.coset_g);                                     // :175,177-181,187
-        driver.ifft_coset_fft_in_place(b, dom.omega, dom.coset_g);                                     // :176,182-186,188
+        driver.ifft_coset_fft_in_place2(a, b, dom.omega, dom.coset_g);                                 // :175-188: both vectors, both components, one sequence of launches
         mk.mark("ntt enqueue");
         ShareVec c = driver.mul_vec_finish(c_pending);
         mk.mark("mul_vec_finish");
@@ -74,11 +72,12 @@ public:
     // groth16.rs:206-235
     // priv_acc = msm_public_points(&query[1 + pub_len..], aux_assignment) (:221), started before the witness map (see prove)
     PointShare calculate_coeff(PointShare initial, const View& query_host, int group, const Bytes& vk_param,
-                               const std::vector<Fr>& input_assignment, const PointShare& priv_acc) {
+                               const std::vector<Fr>& input_assignment, const PointShare& priv_acc, const std::vector<FixedTable>* pub_tabs = nullptr) {
         const Curve& c = driver.curve;
         const size_t pub_len = input_assignment.size(), rec = c.aff(group);
         Point pub_acc = pt_inf(c, group);                                                              // :220 (tiny, plain scalars)
-        for (size_t i = 0; i < pub_len; i++) pub_acc = pt_add(c, pub_acc, pt_mul(c, pt_from_affine(c, group, query_host.data() + (1 + i) * rec), input_assignment[i]));
+        for (size_t i = 0; i < pub_len; i++)
+            pub_acc = pt_add(c, pub_acc, pt_mul_fixed(c, pub_tabs && i < pub_tabs->size() ? (*pub_tabs)[i].t : nullptr, pt_from_affine(c, group, query_host.data() + (1 + i) * rec), input_assignment[i]));
         PointShare res = initial;
         driver.add_assign_points_public(res, pt_from_affine(c, group, query_host.data()));             // :227
         driver.add_assign_points_public(res, pt_from_affine(c, group, vk_param.data()));               // :228
@@ -157,10 +156,11 @@ public:
         const Point delta_g1 = pt_from_affine(c, CG_G1, z.delta_g1.data());
         const Point delta_g2 = pt_from_affine(c, CG_G2, z.delta_g2.data());
         FieldShare rs = driver.mul(r, s);                                                              // :258
-        PointShare r_s_delta_g1 = driver.scalar_mul_public_point(delta_g1, rs);                        // :259
-        PointShare r_g1 = driver.scalar_mul_public_point(delta_g1, r);                                 // :265
-        PointShare s_g1 = driver.scalar_mul_public_point(delta_g1, s);                                 // :283
-        PointShare s_g2 = driver.scalar_mul_public_point(delta_g2, s);                                 // :297
+        const SessionFixed* fx = dz.fixed;                                                             // a session's window tables (else variable-base products)
+        PointShare r_s_delta_g1 = driver.scalar_mul_public_point(delta_g1, rs, fx ? fx->delta_g1.t : nullptr);   // :259
+        PointShare r_g1 = driver.scalar_mul_public_point(delta_g1, r, fx ? fx->delta_g1.t : nullptr);  // :265
+        PointShare s_g1 = driver.scalar_mul_public_point(delta_g1, s, fx ? fx->delta_g1.t : nullptr);  // :283
+        PointShare s_g2 = driver.scalar_mul_public_point(delta_g2, s, fx ? fx->delta_g2.t : nullptr);  // :297
         mk.mark("scalar steps under the msms");
         PointShare early[5]; bool have_early = false;
         if (add_h) {                                                                                   // all five results, then the one re-sharing round
@@ -172,12 +172,12 @@ public:
             mk.mark("msms + reshare (additive)");
         }
         auto aux_result = [&](int i) { return have_early ? early[i] : driver.msm_finish(aux_msm, i); };
-        PointShare g_a = calculate_coeff(r_g1, z.a_query, CG_G1, z.alpha_g1, input_assignment, aux_result(AUX_A));   // :267
+        PointShare g_a = calculate_coeff(r_g1, z.a_query, CG_G1, z.alpha_g1, input_assignment, aux_result(AUX_A), fx ? &fx->a_pub : nullptr);   // :267
         Point g_a_opened = driver.open_point(g_a);                                                     // :276
         PointShare s_g_a = driver.scalar_mul_public_point(g_a_opened, s);                              // :277
-        PointShare g1_b = calculate_coeff(s_g1, z.b_g1_query, CG_G1, z.beta_g1, input_assignment, aux_result(AUX_B1));   // :284
+        PointShare g1_b = calculate_coeff(s_g1, z.b_g1_query, CG_G1, z.beta_g1, input_assignment, aux_result(AUX_B1), fx ? &fx->b1_pub : nullptr);   // :284
         PointShare r_g1_b = driver.scalar_mul(g1_b, r);                                                // :291
-        PointShare g2_b = calculate_coeff(s_g2, z.b_g2_query, CG_G2, z.beta_g2, input_assignment, aux_result(AUX_B2));   // :298
+        PointShare g2_b = calculate_coeff(s_g2, z.b_g2_query, CG_G2, z.beta_g2, input_assignment, aux_result(AUX_B2), fx ? &fx->b2_pub : nullptr);   // :298
         mk.mark("msm a, b1, b2 + their scalar steps");
         PointShare l_aux_acc = aux_result(AUX_L);                                          // :251
         PointShare h_acc = have_early ? early[4] : driver.msm_finish(h_msm, 0);                                               // :248

@@ -152,6 +152,9 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *                                  reverse): with the G2 table LAST in the caller's order its two accumulations run back to back
  *                                  in the middle of the call — [a b1 l b2][b2 l b1 a] — after a neighbouring chain context has
  *                                  finished its transforms and before the call's tail, which then consists of G1 launches only
+ *                                  2 = one launch order over (table, component) pairs, share components <= 2: the G1 pairs in serpentine
+ *                                  order with the G2 pairs together after CG_OPT_MSM_G2_AFTER of them
+ *   CG_OPT_MSM_G2_AFTER            with order 2: G1 accumulations launched before the first G2 one (-1 = all of them: G2 at the end)    -1
  *   CG_OPT_MSM_G2_SLICES           1 = a context with CG_OPT_MSM_CHUNK set launches a G2 accumulation one chip-load of               0
  *                                  workgroups at a time (its workgroups hold 147 of a CU's 160 KB of LDS: nothing that needs LDS,
  *                                  e.g. a transform pass of the chain context, can start while a launch lasts); costs ~2 ms per
@@ -161,7 +164,7 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *   CG_OPT_MSM_ACC_SLOTS           rotating scratch slots of the accumulate / reduce pipeline (2 .. 8; batches take one per set)    4
  * Environment variables of the same names (CG_OPT_... without the prefix: CG_MSM_CHUNK, ...) seed the defaults of NEW contexts for A/B runs. */
 enum { CG_OPT_MSM_CHUNK = 1, CG_OPT_MSM_WINDOW = 2, CG_OPT_MSM_SCATTER_CAP = 3, CG_OPT_MSM_TABLE_ORDER = 4, CG_OPT_MSM_G2_SLICES = 5,
-       CG_OPT_MSM_REDUCE_BATCH = 6, CG_OPT_MSM_ACC_SLOTS = 7, CG_OPT_COUNT_ };
+       CG_OPT_MSM_REDUCE_BATCH = 6, CG_OPT_MSM_ACC_SLOTS = 7, CG_OPT_MSM_G2_AFTER = 8, CG_OPT_COUNT_ };
 int32_t cg_ctx_set_option(cg_ctx* ctx, int32_t option, int64_t value);
 int32_t cg_ctx_get_option(const cg_ctx* ctx, int32_t option, int64_t* value);
 /* window size override (0 = automatic); tuning knob only, never changes results */
@@ -244,6 +247,13 @@ int32_t cg_vec_rep3_mul_local(cg_ctx* ctx, int32_t curve, void* h_out, const voi
 int32_t cg_point_add(int32_t curve, int32_t group, const void* h_a, const void* h_b, void* h_out);
 int32_t cg_point_neg(int32_t curve, int32_t group, const void* h_a, void* h_out);
 int32_t cg_point_scalar_mul(int32_t curve, int32_t group, const void* h_a, const void* h_k, void* h_out);
+/* A base multiplied in every proof of a session (delta_1, delta_2 of groth16.rs:259-297, the generators behind the masking points of
+ * rep3/rngs.rs:48-51, the public-input records of calculate_coeff groth16.rs:220): an 8-bit window table built once, then one mixed
+ * addition per scalar byte.  Host arithmetic only (no device, no context); the table may be used from several threads at once. */
+typedef struct cg_fixed_base cg_fixed_base;
+int32_t cg_fixed_base_create(int32_t curve, int32_t group, const void* h_point_jacobian, cg_fixed_base** out);
+int32_t cg_fixed_base_mul(const cg_fixed_base* table, const void* h_scalar, void* h_out_jacobian);
+int32_t cg_fixed_base_destroy(cg_fixed_base* table);
 int32_t cg_point_to_affine(int32_t curve, int32_t group, const void* h_a, void* h_out_affine);
 int32_t cg_point_from_affine(int32_t curve, int32_t group, const void* h_affine, void* h_out);
 /* What the reference checks when it deserialises a point or field elements received from a peer (ark-serialize, Validate::Yes: mpc-net's

@@ -12,4 +12,5 @@ out = bench.entry_leg(ctx, log_m, dev, proofs, 1, extras=not os.environ.get("NO_
 res = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in out.items() if k.endswith("_ms") or k.startswith("ms_per_proof")}
 sh = out.get("shamir_party") or {}
 res.update({"shamir_" + k: round(x, 2) for k, x in sh.items() if k.endswith("_ms")})
+res["each"] = out.get("ms_inner_each")
 print(json.dumps(res))

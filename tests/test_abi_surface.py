@@ -79,6 +79,40 @@ def test_host_point_helpers_match_oracle(curve, group):
 
 
 @pytest.mark.parametrize("curve", [BN254, BLS12_381])
+@pytest.mark.parametrize("group", [G1, G2])
+def test_host_scalar_mul_and_fixed_base_tables(curve, group):
+    """the 64-bit-limb host arithmetic of proof assembly (csrc/host_ec64.hpp): windowed variable-base products and the 8-bit window tables
+    of a session's fixed bases (cg_fixed_base_*: delta_1, delta_2, generators, public-input records) against the oracle's scalar
+    multiplication, with the scalars 0, 1, r - 1 and the point at infinity"""
+    ensure_built()
+    rng = np.random.default_rng(71 + curve * 2 + group)
+    ks = orc.random_field(curve, FR, 8, rng)
+    ks[5] = 0; ks[6] = orc.from_dec(curve, FR, 1); ks[7] = orc.from_dec(curve, FR, orc.MODULI[(curve, FR)] - 1)
+    P = orc.generator_mul(curve, group, ks[0])
+    jp = jac_of(curve, group, P)
+    want = [orc.points_mul(curve, group, P[None, :], k[None, :])[0] for k in ks]
+    for k, w in zip(ks, want):
+        np.testing.assert_array_equal(cg.point_to_affine(curve, group, cg.point_scalar_mul(curve, group, jp, k)), w)
+    # a non-normalised Jacobian input (Z != 1): the product of a product
+    jq = cg.point_scalar_mul(curve, group, jp, ks[1])
+    k12 = orc.field_op(curve, FR, "mul", ks[1][None, :], ks[2][None, :])[0]
+    np.testing.assert_array_equal(cg.point_to_affine(curve, group, cg.point_scalar_mul(curve, group, jq, ks[2])), orc.points_mul(curve, group, P[None, :], k12[None, :])[0])
+    fb = cg.FixedBase(curve, group, jq)                                # table of a base with Z != 1
+    for k in ks:
+        np.testing.assert_array_equal(cg.point_to_affine(curve, group, fb.mul(k)), cg.point_to_affine(curve, group, cg.point_scalar_mul(curve, group, jq, k)))
+    fb.close()
+    fb = cg.FixedBase(curve, group, jp)
+    for k, w in zip(ks, want):
+        np.testing.assert_array_equal(cg.point_to_affine(curve, group, fb.mul(k)), w)
+    fb.close()
+    inf = jac_of(curve, group, np.zeros_like(P))
+    assert not cg.point_to_affine(curve, group, cg.point_scalar_mul(curve, group, inf, ks[1])).any()
+    fbi = cg.FixedBase(curve, group, inf)
+    assert not cg.point_to_affine(curve, group, fbi.mul(ks[1])).any()
+    fbi.close()
+
+
+@pytest.mark.parametrize("curve", [BN254, BLS12_381])
 def test_host_fr_ops_match_oracle(curve):
     ensure_built()
     rng = np.random.default_rng(33)
