@@ -149,8 +149,8 @@ TABLE_FIRST = {"h": 1, "l": 3, "a": 5, "b1": 7, "b2": 1}     # synthetic tables:
 # Cost model of the planner (ms on one MI355X; p = points of the unit / 2^20; both share components).  Measured with
 # scripts/sweep_precompute.py and the bench stage split (profiles/): a unit has a fixed cost (bucket reduction, launch tail) that
 # does not shrink with its size, which is why whole tables are preferred over splitting every MSM N ways.
-ACC_COST = {0: [(0.25, 1.19), (0.5, 1.71), (1.0, 2.82), (2.0, 5.7), (4.0, 10.08)],      # group -> [(p, ms)]: accumulate + reduce of a unit,
-            1: [(0.25, 3.08), (0.5, 4.83), (1.0, 8.79), (2.0, 15.59), (4.0, 27.24)]}      # excl. the sort schedule; interpolated (scripts/unit_cost_table.py)
+ACC_COST = {0: [(0.25, 0.85), (0.5, 1.51), (1.0, 2.69), (2.0, 5.06), (4.0, 9.0)],        # group -> [(p, ms)]: accumulate + reduce of a unit,
+            1: [(0.25, 2.42), (0.5, 4.37), (1.0, 8.49), (2.0, 14.22), (4.0, 26.16)]}      # excl. the sort schedule; interpolated (scripts/unit_cost_table.py, round 4: bucket sets reduced in batches)
 SORT_COST = (0.3, 1.2)                           # digit/sort schedule per (rank, scalar set, range), shared by the tables that use it
 WM_COST = 4.0                                    # whole witness map on the rank that owns h (N < 4), after overlap with its aux MSMs
 WM_VEC_COST = (0.75, 1.6)                        # distributed witness map: SpMV + products once, then per owned vector pipeline

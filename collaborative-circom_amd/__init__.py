@@ -422,6 +422,18 @@ class Context:
 
 
 # ---- O(1) host helpers (no device needed) --------------------------------------------------------------
+def device_count():
+    """HIP devices visible to the library (0 without a GPU)"""
+    return int(load().cg_device_count())
+
+
+def session_devices(world):
+    """device list of a `world`-device session on THIS box: distinct GPUs as far as they exist, then repeats (a one-GPU box runs every
+    context on GPU 0; on a node the hops between devices are real peer copies over xGMI)"""
+    n = max(1, device_count())
+    return [i % n for i in range(world)]
+
+
 def point_add(curve, group, a, b):
     out = np.zeros(point_words(curve, group, 3), dtype=np.uint64)
     _chk(load().cg_point_add(curve, group, _hp(np.ascontiguousarray(a)), _hp(np.ascontiguousarray(b)), _hp(out)))
