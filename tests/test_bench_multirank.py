@@ -19,8 +19,12 @@ def run_bench(tmp_path, world, extra=(), log_m=14, port=29611):
     if world == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *common]
     else:
+        import torch
+        # a node with enough GPUs runs one rank per GPU over RCCL (what the driver's scaling run does); a one-GPU box puts every rank on
+        # GPU 0 and stages the exchanges through the host (gloo)
+        one_box = [] if torch.cuda.device_count() >= world else ["--backend", "gloo", "--shared-device"]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-               "--master-port", str(port + world), os.path.join(ROOT, "bench.py"), *common, "--backend", "gloo", "--shared-device"]
+               "--master-port", str(port + world), os.path.join(ROOT, "bench.py"), *common, *one_box]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
