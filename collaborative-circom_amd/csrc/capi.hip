@@ -435,7 +435,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // its own right behind its accumulation (rounds 1-3).  Beside lock-stepped accumulations a reduction costs the step its stand-alone
         // duration whatever its width: 2^22 step with ten reductions 6.2 ms, with three.  A batch holds its sets' scratch slots until it has run: one slot per set.
         const int red_batch = ctx->red_batch;
-        const int acc_slots = red_batch ? std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(acc_slots_min, red_batch == 2 ? nb * k : nb + 1)) : acc_slots_min;
+        const int acc_slots = red_batch ? std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(acc_slots_min, red_batch >= 2 ? nb * k : nb + 1)) : acc_slots_min;
         { int rc = ensure_arena(ctx, nsched * sort_bytes + (size_t)acc_slots * acc_slot); if (rc) return rc; }
         char* acc_scratch = ctx->arena.base + nsched * sort_bytes;
         HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));   // scalars (and the arena) are ready once the main stream gets here
@@ -540,7 +540,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
                 { int rc = do_acc(b, j); if (rc) return rc; }
                 const bool last_of_field = --left[gi] == 0;
                 const bool comp_changes = i + 1 == order.size() || order[i + 1].second != j || (bases[order[i + 1].first]->group == CG_G1 ? 0 : 1) != gi;
-                if (red_batch == 0 || (red_batch == 1 && comp_changes) || last_of_field || (int)pend[gi].size() == RED_MAX_SETS) { int rc3 = flush(gi); if (rc3) return rc3; }
+                if (red_batch == 0 || (red_batch == 1 && comp_changes) || (last_of_field && red_batch != 3) || (int)pend[gi].size() == RED_MAX_SETS) { int rc3 = flush(gi); if (rc3) return rc3; }
                 if (--left_sched[j] == 0) HIPCHK(hipEventRecord(ctx->ev_sched_free[j], ctx->stream));
             }
         } else
@@ -554,7 +554,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
                 const int gi = bases[b]->group == CG_G1 ? 0 : 1;
                 { int rc = do_acc(b, j); if (rc) return rc; }
                 const bool last_here = --left_in_comp[gi] == 0;                           // this field's last table of the component
-                if (red_batch == 0 || (red_batch == 1 && last_here) || (last_here && j == k - 1) || (int)pend[gi].size() == RED_MAX_SETS) { int rc3 = flush(gi); if (rc3) return rc3; }
+                if (red_batch == 0 || (red_batch == 1 && last_here) || (last_here && j == k - 1 && red_batch != 3) || (int)pend[gi].size() == RED_MAX_SETS) { int rc3 = flush(gi); if (rc3) return rc3; }
             }
             HIPCHK(hipEventRecord(ctx->ev_sched_free[j % nsched], ctx->stream));
             if (j + 2 < k && nsched == 2) {                      // needs the schedule slot this component just released: its pending sets are merged first
@@ -1049,12 +1049,16 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
         return fail(CG_ERR_NODEVICE, "no HIP device visible: this backend has no CPU fallback");
     if (device < 0 || device >= count) return fail(CG_ERR_ARG, "device index out of range");
     HIPCHK(hipSetDevice(device));
+    {   // the kernels are written for 64-lane wavefronts (ballots, shuffles across 64 lanes, LDS tiles sized per wave): refuse anything else loudly
+        int ws = 0; HIPCHK(hipDeviceGetAttribute(&ws, hipDeviceAttributeWarpSize, device));
+        if (ws != 64) return fail(CG_ERR_NODEVICE, "device " + std::to_string(device) + " has " + std::to_string(ws) + "-lane wavefronts: this backend is written for wave64 (gfx950)");
+    }
     cg_ctx* c = new cg_ctx();
     c->device = device;
     {   // A/B runs: environment variables seed the option table of new contexts (include/cogroth16_hip.h, cg_ctx_set_option)
         auto seed = [](const char* name, int lo, int hi, int& field) { if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= lo && v <= hi) field = v; } };
         seed("CG_MSM_TABLE_ORDER", 0, 2, c->table_order); seed("CG_MSM_G2_AFTER", -1, 64, c->g2_after); seed("CG_MSM_G2_SLICES", 0, 1, c->g2_slices);
-        seed("CG_MSM_REDUCE_BATCH", 0, 2, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots);
+        seed("CG_MSM_REDUCE_BATCH", 0, 3, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots);
     }
     if (flags & 1u) { c->prio_main = 1; c->prio_copy = 1; c->prio_side = 0; }
     else if (flags & 2u) { static const int bulk_cls = getenv("CG_BULK_CLASS") ? atoi(getenv("CG_BULK_CLASS")) : -1; c->prio_main = bulk_cls; c->prio_side = 0; }   // CG_BULK_CLASS: tuning knob
@@ -1193,16 +1197,28 @@ int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr) {
     // The block's last users may sit on any of the context's streams.  None of them is made to wait for another (a chain context's main
     // stream must not queue behind its pending copies): a stream of the context that carries no work (`joinst`, low priority) waits for
     // the five, and ONE event behind it marks the block as free (an event per stream and block ran the runtime out of signals).
-    if (!ctx->joinst) {
-        { int rc = pooled_stream(ctx->device, -1, &ctx->joinst); if (rc) return rc; }
-        for (hipEvent_t& e : ctx->park_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    int i = 0;
-    for (hipStream_t st : {ctx->stream, ctx->aux, ctx->sortst, ctx->h2d, ctx->d2h}) { if (st) { HIPCHK(hipEventRecord(ctx->park_ev[i], st)); HIPCHK(hipStreamWaitEvent(ctx->joinst, ctx->park_ev[i], 0)); } i++; }
-    hipEvent_t ev = nullptr;
-    if (!dc.spare.empty()) { ev = dc.spare.back(); dc.spare.pop_back(); } else HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ev, ctx->joinst));
-    dc.parked.insert({rb, ParkedBlock{d_ptr, ev}}); dc.parked_bytes += rb;
+    // The block has left `live`: whatever fails from here on, it is released the synchronising way instead of being lost.
+    auto park = [&]() -> bool {
+        if (!ctx->joinst) {
+            if (pooled_stream(ctx->device, -1, &ctx->joinst)) return false;
+            for (hipEvent_t& e : ctx->park_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+        }
+        int i = 0;
+        for (hipStream_t st : {ctx->stream, ctx->aux, ctx->sortst, ctx->h2d, ctx->d2h}) {
+            if (st && (!ctx->park_ev[i] || hipEventRecord(ctx->park_ev[i], st) != hipSuccess || hipStreamWaitEvent(ctx->joinst, ctx->park_ev[i], 0) != hipSuccess)) return false;
+            i++;
+        }
+        hipEvent_t ev = nullptr;
+        if (!dc.spare.empty()) { ev = dc.spare.back(); dc.spare.pop_back(); } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventRecord(ev, ctx->joinst) != hipSuccess) { dc.spare.push_back(ev); return false; }
+        dc.parked.insert({rb, ParkedBlock{d_ptr, ev}}); dc.parked_bytes += rb;
+        return true;
+    };
+    if (park()) return 0;
+    (void)hipGetLastError();
+    l.unlock();
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipFree(d_ptr));
     return 0;
 }
 int32_t cg_dev_upload(cg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
@@ -1581,7 +1597,7 @@ int32_t cg_ctx_set_option(cg_ctx* ctx, int32_t option, int64_t value) {
         case CG_OPT_MSM_TABLE_ORDER: if (value < 0 || value > 2) break; ctx->table_order = (int)value; return 0;
         case CG_OPT_MSM_G2_AFTER: if (value < -1 || value > 64) break; ctx->g2_after = (int)value; return 0;
         case CG_OPT_MSM_G2_SLICES: if (value < 0 || value > 1) break; ctx->g2_slices = (int)value; return 0;
-        case CG_OPT_MSM_REDUCE_BATCH: if (value < 0 || value > 2) break; ctx->red_batch = (int)value; return 0;
+        case CG_OPT_MSM_REDUCE_BATCH: if (value < 0 || value > 3) break; ctx->red_batch = (int)value; return 0;
         case CG_OPT_MSM_ACC_SLOTS: if (value < 2 || value > cg_ctx::ACC_SLOTS_MAX) break; ctx->acc_slots = (int)value; return 0;
         default: return fail(CG_ERR_ARG, "cg_ctx_set_option: unknown option");
     }

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include "common.hpp"
 
+// (wave64 throughout: the compaction kernels rank with 64-lane ballots and shuffles; cg_ctx_create refuses a device whose wavefront is not 64 lanes)
 namespace cg {
 
 struct ChaChaArgs {

@@ -95,7 +95,9 @@ static void put_vec(const Curve& c, Bytes& o, const Fr* v, size_t n) {
     const uint8_t* p = (const uint8_t*)can.data(); o.insert(o.end(), p, p + n * 32);
 }
 static std::vector<Fr> get_vec(const Curve& c, Cursor& cur) {
-    const uint64_t n = cur.u64(); cur.need(n * 32);
+    const uint64_t n = cur.u64();
+    if (cur.off > cur.n || n > (cur.n - cur.off) / 32) throw std::runtime_error("invalid data: vector length exceeds the file");   // (n * 32 would wrap for n >= 2^59)
+    cur.need(n * 32);
     std::vector<Fr> raw(n), out(n); cur.bytes(raw.data(), n * 32);
     for (const Fr& e : raw) { for (int l = 3; l >= 0; l--) { if (e.v[l] < MOD_R[c.id][l]) break; if (e.v[l] > MOD_R[c.id][l] || l == 0) throw std::runtime_error("invalid data: field element not reduced"); } }
     if (n) CG(cg_fr_from_canonical(c.id, raw.data(), out.data(), n));

@@ -620,6 +620,10 @@ public:
         release_rings(); release_pre();
         if (aux) { if (owns_aux) cg_ctx_destroy(aux); aux = nullptr; }
     }
+    void sync_other_contexts() {                                                           // error paths: see VecGuard
+        if (aux) cg_ctx_sync(aux);
+        if (md) for (const WorkerDevice& w : md->workers) { if (w.ctx) cg_ctx_sync(w.ctx); if (w.chain) cg_ctx_sync(w.chain); }
+    }
     void use_second_context(cg_ctx* second) { aux = second; }                           // owned from here on (shutdown destroys it)
     ~HipDriver() { shutdown(); }
     // ---- vector forms of rand / mul_open_many / open_many used by co-plonk (rep3.rs:544-558,595-598,620-628,738-757)

@@ -10,7 +10,10 @@ struct VecGuard {   // device share vector released when the entry point leaves,
     HipDriver& d; ShareVec v;
     explicit VecGuard(HipDriver& drv) : d(drv) {}
     VecGuard(HipDriver& drv, ShareVec x) : d(drv), v(x) {}
-    ~VecGuard() { try { d.free_vec(v); } catch (...) {} }
+    // Leaving by an exception, kernels of the party's OTHER contexts (the witness-independent MSMs on the second context, the slices on
+    // further GPUs) may still read the vector: cg_dev_free parks a block behind the RELEASING context's streams only, so those contexts
+    // are drained first — on the regular path every MSM has been collected before the guard runs.
+    ~VecGuard() { try { if (std::uncaught_exceptions() > 0) d.sync_other_contexts(); d.free_vec(v); } catch (...) {} }
     VecGuard(const VecGuard&) = delete; VecGuard& operator=(const VecGuard&) = delete;
 };
 struct Proof { Bytes a, b, c; };   // packed affine, (0,0) = infinity  (Groth16Proof, groth16/proof.rs:8-29)

@@ -182,7 +182,9 @@ public:
     ShareVec mul(const ShareVec& a, const ShareVec& x, size_t len) { ShareVec av = view(a, 0, len), xv = view(x, 0, len); return keep(d.mul_vec(av, xv)); }                // mul_vec / mul_many
     Point commit_open(const ShareVec& p, size_t len) {
         if (len > z.domain_size + 6) throw std::runtime_error("polynomial degree too large");
-        return d.open_point(d.msm_public_points(tau, CG_G1, 0, len, p));
+        const PointShare cm = d.msm_public_points(tau, CG_G1, 0, len, p);
+        d.verify_received_vectors();       // what a peer sent for this round's products is refused BEFORE anything derived from it is opened (the reference refuses at deserialisation)
+        return d.open_point(cm);
     }
     void ntt(const ShareVec& s, size_t len, const Fr& g, bool inverse) { void* ptrs[2] = {s.c[0], s.c[1]}; CG(cg_ntt_dev(ctx, c.id, ptrs, k, len, g.v, inverse ? 1 : 0, nullptr)); }
     // inv_many (rep3.rs:544-558 / plain): element-wise inverse of a shared vector
@@ -274,6 +276,7 @@ public:
         }
         PointShare cm[3];
         for (int w = 0; w < 3; w++) cm[w] = d.msm_public_points(tau, CG_G1, 0, n + 2, poly[w]);   // :276-290
+        d.verify_received_vectors();
         for (int w = 0; w < 3; w++) commit[w] = d.open_point(cm[w]);                               // open_point_many (:292)
         release_tmp();
     }
@@ -405,6 +408,7 @@ public:
         set(tpart[2], 0, fs_sub(get(tpart[2], 0), b[10]));
         PointShare cm[3];
         for (int p = 0; p < 3; p++) { if (len[p] > z.domain_size + 6) throw std::runtime_error("polynomial degree too large"); cm[p] = d.msm_public_points(tau, CG_G1, 0, len[p], tpart[p]); }
+        d.verify_received_vectors();
         for (int p = 0; p < 3; p++) commit_t[p] = d.open_point(cm[p]);                     // :507-522
         release_tmp();
     }
@@ -413,6 +417,7 @@ public:
         { PlonkTranscript t(c); t.add_scalar(alpha); for (int p = 0; p < 3; p++) transcript_point(t, commit_t[p]); xi = t.get_challenge(); }
         const Fr xiw = M(xi, omega);
         std::vector<FieldShare> sh = {eval_share_poly(poly[0], n + 2, xi), eval_share_poly(poly[1], n + 2, xi), eval_share_poly(poly[2], n + 2, xi), eval_share_poly(poly_z, n + 3, xiw)};
+        d.verify_received_vectors();
         const std::vector<Fr> opened = d.open_many(sh);                                    // :131
         ev_a = opened[0]; ev_b = opened[1]; ev_c = opened[2]; ev_zw = opened[3];
         ev_s1 = eval_pub_poly(upload(z.sigma_coef[0]), n, xi); ev_s2 = eval_pub_poly(upload(z.sigma_coef[1]), n, xi);
@@ -448,6 +453,7 @@ public:
         set(W, 0, fs_addpub(get(W, 0), neg(ev_zw)));
         div_by_zerofier1(W, n + 3, M(xi, omega));
         PointShare c1 = d.msm_public_points(tau, CG_G1, 0, len - 1, R), c2 = d.msm_public_points(tau, CG_G1, 0, n + 2, W);   // :351-358
+        d.verify_received_vectors();
         commit_wxi = d.open_point(c1); commit_wxiw = d.open_point(c2);
         release_tmp();
     }

@@ -139,6 +139,23 @@ int32_t cg_msm_dev_begin_multi(cg_ctx* ctx, int32_t n_tables, const cg_bases* co
  * (`Rep3PrimeFieldShareVec{a, b}`, rep3/fieldshare.rs:233-236, arrives as two vectors).  Consumed by that one call; `owner` must stay alive
  * until that call has returned (the library keeps a reference to the copy's completion event, not to the context). */
 int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int32_t copy_ticket);
+/* ---- environment variables.  The product needs none.  The ones below exist for A/B measurements and debugging; they are PROCESS-WIDE,
+ * read ONCE at first use unless noted, never change results unless marked DEBUG, and are the complete list for libcogroth16_hip.so
+ * (tests/test_abi_surface.py checks this list against the sources).  What a deployment may want to tune per context is in the option
+ * table further down (cg_ctx_set_option), not here.
+ *   resources     CG_DEV_CACHE_MB (32768)    device bytes parked by cg_dev_free per device before blocks are given back to the runtime (0: never park)
+ *                 CG_HOST_CACHE_MB (2048)    page-locked host bytes parked by cg_host_free
+ *   A/B           CG_MSM_CHUNK (128) / CG_MSM_CHUNK_MIN (16) / CG_G2_CHUNK (64) / CG_MSM_NO_ROUNDS   chunk length of the bucket accumulation: cap, floor, cap
+ *                                            for G2, and "do not round to whole residency rounds"
+ *                 CG_ACC_VARIANT (3)         software-pipelining variant of k_msm_accumulate_pf (read per call; scripts/acc_variants.py)
+ *                 CG_NO_BITSUM / CG_NO_GRID_REDUCE   bucket reduction by the running-sum chain instead of per-bit sums / row-column sums
+ *                 CG_SORT_NO_STAGING         unstaged partition / counting-sort scatters
+ *                 CG_NO_COMPACT              no compacted copy for tables with many points at infinity
+ *                 CG_NTT_DIF / CG_NTT_NO_PAIR / CG_NTT_TILE (10)   canonical DIF passes; iNTT + coset + NTT as two calls; log2 of the lazy passes' LDS tile
+ *                 CG_SUBGROUP_FULL           subgroup checks by [r]P instead of the endomorphism tests
+ *                 CG_BULK_CLASS (-1)         priority class of a bulk context's main stream (cg_ctx_create_ex flag 2)
+ *                 CG_MSM_TABLE_ORDER, CG_MSM_G2_AFTER, CG_MSM_G2_SLICES, CG_MSM_REDUCE_BATCH, CG_MSM_ACC_SLOTS   seed the option table of NEW contexts
+ *   DEBUG         CG_DEBUG_NO_REDUCE = 1 | 2 skips the merges + bucket reductions | the reductions only: RESULTS ARE WRONG (what they cost a step) */
 /* ---- per-context tuning (never changes results).  One table instead of process-wide environment variables: every option belongs to the
  * context it is set on (a party's chain and bulk contexts differ), is read at the next call that uses it, and can be read back.
  *   option                         value                                                                                   default

@@ -9,6 +9,18 @@
  * zkey :482, read shares :487-495, construct the driver :497-499, prove :503-506, write proof :512-532) — with buffers instead of
  * files where the CLI reads them into memory first.  INTEGRATION.md shows the Rust-side binding.
  *
+ * Environment variables (complete list for libcogroth16_host.so; PROCESS-WIDE, read once unless noted; none is needed, none changes a proof):
+ *   CGH_SKIP_ZKEY_VALIDATION      sessions / one-shot proves skip the on-curve + subgroup validation of the zkey points (= cgh_set_zkey_validation(0))
+ *   CGH_TIMING                    wall-clock marks of the host-side protocol steps on stderr
+ *   thresholds    CGH_SECOND_CONTEXT_MIN (15)   log2 of the variables from which a proof uses a chain + a bulk context
+ *                 CGH_XCHG_ASYNC_MIN (2^17)     elements from which the mul_vec exchange streams in chunks over the copy streams
+ *                 CGH_DEVICE_MASKS_MIN (2^14)   elements from which described ChaCha12 generators are drawn on the device
+ *   A/B           CGH_ONE_CONTEXT, CGH_NO_CHAIN_PRIORITY, CGH_CHAIN_FLAG (1), CGH_BULK_FLAG (2)   one context per proof; no priorities; cg_ctx_create_ex flags
+ *                 CGH_BULK_CHUNK (64) / CGH_PLAIN_CHUNK (0)   CG_OPT_MSM_CHUNK of the bulk context beside a REP3 chain (>= 2^20 elements) / otherwise
+ *                 CGH_G2_ORDER=first, CGH_G2_AFTER (2)        launch order of the aux MSMs' (table, component) pairs (HipDriver::begin_multi_ordered)
+ *                 CGH_NO_DISTRIBUTED_MAP (read per proof)     multi-device sessions keep the witness map on the primary device
+ *   planning      CGH_EMULATE_PRIMARY_ONLY      times the primary device's share of a multi-device proof on one GPU: THE PROOF IS WRONG
+ *
  * Conventions: every function returns 0 on success; on failure a non-zero value, message from cgh_last_error() (thread local).
  * Field elements are 4 x u64 (6 for the BLS12-381 base field) little-endian Montgomery limbs, exactly arkworks' in-memory form
  * (circom-types/src/traits.rs:57-67).  Proofs are packed affine points A (G1) || B (G2) || C (G1), (0, 0) = infinity

@@ -41,6 +41,21 @@ def test_host_mirror_header_matches_the_library():
     assert exported == declared, f"exported but not declared: {sorted(set(exported) - set(declared))}"
 
 
+def test_environment_variables_are_documented():
+    """every getenv of the two libraries' sources appears in the table of its header (include/*.h): no undocumented process-wide knob"""
+    import glob, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for header, pattern in (("cogroth16_hip.h", "collaborative-circom_amd/csrc/*"), ("cogroth16_host.h", "collaborative-circom_amd/host/*")):
+        text = open(os.path.join(root, "include", header)).read()
+        names = set()
+        for f in glob.glob(os.path.join(root, pattern)):
+            if os.path.isfile(f) and f.endswith((".hip", ".hpp", ".cpp")):
+                names |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(f).read()))
+        names |= {"CG_MSM_TABLE_ORDER", "CG_MSM_G2_AFTER", "CG_MSM_G2_SLICES", "CG_MSM_REDUCE_BATCH", "CG_MSM_ACC_SLOTS"} if header == "cogroth16_hip.h" else set()
+        missing = sorted(n for n in names if n not in text)
+        assert not missing, f"{header} does not document {missing}"
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     ensure_built()
