@@ -21,6 +21,9 @@ extern "C" {
     pub fn cg_ctx_create(device: i32, out: *mut *mut cg_ctx) -> i32;
     pub fn cg_ctx_destroy(ctx: *mut cg_ctx) -> i32;
     pub fn cg_ctx_sync(ctx: *mut cg_ctx) -> i32;
+    /// per-context tuning table (include/cogroth16_hip.h: CG_OPT_MSM_CHUNK = 1 .. CG_OPT_MSM_G2_AFTER = 8); never changes results
+    pub fn cg_ctx_set_option(ctx: *mut cg_ctx, option: i32, value: i64) -> i32;
+    pub fn cg_ctx_get_option(ctx: *const cg_ctx, option: i32, value: *mut i64) -> i32;
     pub fn cg_bases_register(ctx: *mut cg_ctx, curve: i32, group: i32, h_points: *const c_void, n: usize, stride_bytes: usize,
                              infinity_offset: i64, out: *mut *mut cg_bases) -> i32;
     pub fn cg_bases_release(b: *mut cg_bases) -> i32;
