@@ -232,6 +232,19 @@ class Context:
         _chk(load().cg_dev_download_begin(self.h, _hp(h_dst), C.c_void_p(_dp(d_src).value + offset), C.c_size_t(h_dst.nbytes if nbytes is None else nbytes), C.byref(t)))
         return t.value
 
+    def stream_mark(self):
+        """a point of the context's stream order (everything enqueued so far) that later downloads can be ordered behind"""
+        m = C.c_int32(-1)
+        _chk(load().cg_stream_mark(self.h, C.byref(m)))
+        return int(m.value)
+
+    def download_begin_after(self, h_dst, d_src, mark, nbytes=None, offset=0):
+        """like download_begin, ordered behind `mark` instead of behind everything the stream holds now"""
+        t = C.c_int32(-1)
+        nb = h_dst.nbytes if nbytes is None else nbytes
+        _chk(load().cg_dev_download_begin_after(self.h, C.c_void_p(h_dst.ctypes.data), C.c_void_p(_dp(d_src).value + offset), C.c_size_t(nb), int(mark), C.byref(t)))
+        return int(t.value)
+
     def upload_begin(self, d_dst, h_src, after_stream=True, nbytes=None, offset=0):
         t = C.c_int32(-1)
         _chk(load().cg_dev_upload_begin(self.h, C.c_void_p(_dp(d_dst).value + offset), _hp(h_src), C.c_size_t(h_src.nbytes if nbytes is None else nbytes), int(bool(after_stream)), C.byref(t)))

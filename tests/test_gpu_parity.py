@@ -410,6 +410,43 @@ def test_msm_multi_table_shared_schedule(ctx):
         b.release()
 
 
+@pytest.mark.parametrize("order,g2_after", [(0, -1), (1, -1), (2, -1), (2, 0), (2, 2), (2, 5)])
+@pytest.mark.parametrize("batch", [0, 1, 2, 3])
+def test_msm_launch_orders_and_reduction_batches(order, g2_after, batch):
+    """the per-context option table (cg_ctx_set_option): every launch order of the (table, component) pairs of a multi-table call —
+    caller's order, serpentine, G1 pairs first with the G2 pairs inserted after `g2_after` of them — and every reduction batching
+    (each set on its own, per component, per call and field, everything at the end of the call) gives the oracle's sums; with
+    precomputed window tables (one shared bucket set) and without; two and three share components (three: the orders fall back to the
+    nested loops, the schedule slots are recycled)"""
+    curve, n = BN254, 1300
+    rng = np.random.default_rng(1000 + 10 * order + batch + g2_after)
+    c2 = cg.Context(0)
+    try:
+        c2.set_option(cg.OPT_MSM_TABLE_ORDER, order); c2.set_option(cg.OPT_MSM_G2_AFTER, g2_after); c2.set_option(cg.OPT_MSM_REDUCE_BATCH, batch)
+        assert (c2.get_option(cg.OPT_MSM_TABLE_ORDER), c2.get_option(cg.OPT_MSM_G2_AFTER), c2.get_option(cg.OPT_MSM_REDUCE_BATCH)) == (order, g2_after, batch)
+        tabs = [(G1, make_points(curve, G1, n, rng)), (G1, make_points(curve, G1, n + 2, rng)), (G2, make_points(curve, G2, n, rng)), (G1, make_points(curve, G1, n, rng))]
+        offs = [0, 2, 0, 0]
+        sc = [orc.random_field(curve, FR, n, rng) for _ in range(3)]
+        bases = [c2.register_bases(curve, g, p) for g, p in tabs]
+        for pre in (0, 13):
+            if pre:
+                for b in bases: c2.precompute_bases(b, pre)
+            for k in (2, 3):
+                tickets = c2.msm_dev_begin_multi(bases, [c2.to_device(x) for x in sc[:k]], n, offsets=offs)
+                for (g, p), o, t in zip(tabs, offs, tickets):
+                    got = c2.msm_end(t)
+                    for j in range(k):
+                        np.testing.assert_array_equal(cg.point_to_affine(curve, g, got[j]), orc.msm(curve, g, p[o:o + n], sc[j], threads=8), err_msg=f"pre {pre} k {k} component {j}")
+        for b in bases:
+            b.release()
+        with pytest.raises(cg.BackendError):
+            c2.set_option(cg.OPT_MSM_TABLE_ORDER, 7)
+        with pytest.raises(cg.BackendError):
+            c2.set_option(99, 1)
+    finally:
+        c2.close()
+
+
 @pytest.mark.parametrize("group", [G1, G2])
 def test_msm_skewed_scalars(ctx, group):
     """non-uniform digits: thousands of entries in a handful of buckets, so one bucket spans many work chunks
@@ -707,6 +744,18 @@ def test_async_copies_through_pinned_staging(ctx):
     ctx.vec_add(curve, d_b, d_a, d_a, n)                           # sees the uploaded b
     np.testing.assert_array_equal(d_o.download((n, 4)), orc.field_op(curve, FR, "add", orc.field_op(curve, FR, "add", a, b), b))
     np.testing.assert_array_equal(d_b.download((n, 4)), orc.field_op(curve, FR, "add", b, b))
+    # downloads ordered behind a MARK of the stream (cg_stream_mark), not behind what is enqueued after it: the product of the mul_vec
+    # exchange goes down in chunks while the prover keeps enqueuing transforms
+    ctx.vec_mul(curve, d_o, d_a, d_b, n)                           # d_a = b, d_b = 2 b
+    mark = ctx.stream_mark()
+    for _ in range(20): ctx.vec_add(curve, d_a, d_a, d_b, n)       # later work that must not hold the download back (and does not touch d_o)
+    tks = [(off, ctx.download_begin_after(pin_o[off:off + min(ch, n - off)], d_o, mark, offset=off * 32)) for off in range(0, n, ch)]
+    want = orc.field_op(curve, FR, "mul", b, orc.field_op(curve, FR, "add", b, b))
+    for off, t in tks:
+        ctx.copy_wait(t)
+        np.testing.assert_array_equal(pin_o[off:off + min(ch, n - off)], want[off:off + ch])
+    with pytest.raises(cg.BackendError):
+        ctx.download_begin_after(pin_o, d_o, mark + 1000)          # a mark that was never set
     with pytest.raises(cg.BackendError):
         ctx.copy_wait(255)                                         # a ticket that was never issued
     ctx.sync()
