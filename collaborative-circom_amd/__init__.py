@@ -35,7 +35,7 @@ def build(bls=True, jobs=8):
 
 
 # per-context tuning options (include/cogroth16_hip.h)
-OPT_MSM_CHUNK, OPT_MSM_WINDOW, OPT_MSM_SCATTER_CAP, OPT_MSM_TABLE_ORDER, OPT_MSM_G2_SLICES, OPT_MSM_REDUCE_BATCH, OPT_MSM_ACC_SLOTS, OPT_MSM_G2_AFTER = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_MSM_CHUNK, OPT_MSM_WINDOW, OPT_MSM_SCATTER_CAP, OPT_MSM_TABLE_ORDER, OPT_MSM_G2_SLICES, OPT_MSM_REDUCE_BATCH, OPT_MSM_ACC_SLOTS, OPT_MSM_G2_AFTER, OPT_MSM_WIDE_SMALL = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 # every symbol include/cogroth16_hip.h declares (checked by tests/test_abi_surface.py)
 ABI_SYMBOLS = [

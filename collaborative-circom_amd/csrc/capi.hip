@@ -24,8 +24,7 @@ inline size_t msm_sort_direct_scratch_bytes(size_t n, int c, int nwin, int share
     const size_t nbuckets = (size_t)(shared ? 1 : nwin) << (c - 1);
     return align_up(nbuckets * cap * 4) + 2 * align_up(nbuckets * 4) + align_up(((nbuckets + 2047) / 2048) * 4) + 256;
 }
-template <class F> int msm_accumulate_launch(hipStream_t st, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride, const uint32_t* sorted, const uint32_t* offsets,
-                                             const uint32_t* counts, uint32_t cap, char* scratch, hipEvent_t* evs, bool may_have_inf, uint32_t chunk_request, bool g2_slices);
+template <class F> int msm_accumulate_batch(hipStream_t st, const MsmAccSet* sets, int nsets, size_t n, int c, int nwin, bool shared, uint32_t cap, hipEvent_t* evs, uint32_t chunk_request, bool g2_slices);
 template <class F> int msm_reduce_batch(hipStream_t st2, const MsmRedSet* sets, int nsets, size_t n, int c, int nwin, bool shared, uint32_t cap, hipEvent_t* ev_merged, int n_merged,
                                         hipEvent_t* evs, uint32_t chunk_request);
 template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared, uint32_t chunk_request);
@@ -134,7 +133,7 @@ struct cg_ctx {
     // priority class of each stream: +1 high, 0 normal, -1 low (pooled_stream)
     int prio_main = 0, prio_side = 1, prio_copy = 0;
     uint32_t msm_chunk = 0;                               // cg_msm_set_chunk / CG_OPT_MSM_CHUNK
-    int table_order = 0, g2_after = -1, g2_slices = 0, red_batch = 2, acc_slots = 4;   // CG_OPT_MSM_TABLE_ORDER / _G2_SLICES / _REDUCE_BATCH / _ACC_SLOTS (cg_ctx_set_option)
+    int table_order = 0, g2_after = -1, g2_slices = 0, red_batch = 2, acc_slots = 4, wide_small = 1;   // CG_OPT_MSM_TABLE_ORDER / _G2_SLICES / _REDUCE_BATCH / _ACC_SLOTS (cg_ctx_set_option)
     hipEvent_t ev_peer = nullptr;                         // cg_dev_copy_peer: "source stream reached this point"
     Arena arena;
     std::vector<void*> retired;                        // outgrown arena blocks that enqueued kernels may still use
@@ -435,7 +434,8 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // its own right behind its accumulation (rounds 1-3).  Beside lock-stepped accumulations a reduction costs the step its stand-alone
         // duration whatever its width: 2^22 step with ten reductions 6.2 ms, with three.  A batch holds its sets' scratch slots until it has run: one slot per set.
         const int red_batch = ctx->red_batch;
-        const int acc_slots = red_batch ? std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(acc_slots_min, red_batch >= 2 ? nb * k : nb + 1)) : acc_slots_min;
+        const bool small_call = k <= 2 && (uint64_t)nwin * n <= ((uint64_t)1 << 22) && ctx->wide_small != 0;            // see `wide` below
+        const int acc_slots = red_batch || small_call ? std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(acc_slots_min, red_batch >= 2 || small_call ? nb * k : nb + 1)) : acc_slots_min;
         { int rc = ensure_arena(ctx, nsched * sort_bytes + (size_t)acc_slots * acc_slot); if (rc) return rc; }
         char* acc_scratch = ctx->arena.base + nsched * sort_bytes;
         HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));   // scalars (and the arena) are ready once the main stream gets here
@@ -469,13 +469,16 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         std::vector<PendSet> pend[2];
         int tables_of_group[2] = {0, 0};
         for (int b = 0; b < nb; b++) tables_of_group[bases[b]->group == CG_G1 ? 0 : 1]++;
+        std::vector<int> comps_left(nb, k);
+        hipStream_t red_stream[2] = {ctx->aux, ctx->aux};      // reduction stream per field (wide mode: G1 on the idle sort stream, beside G2 on aux)
         auto flush = [&](int gi) -> int {
             std::vector<PendSet>& pd = pend[gi];
             if (pd.empty()) return 0;
+            hipStream_t rst = red_stream[gi];
             // every accumulation of the batch sits on the main stream in front of this point: the reduction stream waits for the last one
             hipEvent_t ea = ctx->ev_acc[pd.back().slot];
             HIPCHK(hipEventRecord(ea, ctx->stream));
-            HIPCHK(hipStreamWaitEvent(ctx->aux, ea, 0));
+            HIPCHK(hipStreamWaitEvent(rst, ea, 0));
             hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
             if (ctx->stats_on) { const int i2 = ev_open(ctx, TAG_REDUCE); evs[0] = ctx->ev_live[i2].a; evs[1] = ctx->ev_live[i2].b; pev = evs; }
             hipEvent_t evm[2]; int nm = 0; bool seen[2] = {false, false};
@@ -483,17 +486,59 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
             for (const PendSet& ps : pd) { sets.push_back(ps.set); if (!seen[ps.sched]) { seen[ps.sched] = true; evm[nm++] = ctx->ev_merged[ps.sched]; } }
             int rc = with_coord_field(curve, gi == 0 ? CG_G1 : CG_G2, [&](auto ftag) -> int {
                 typedef decltype(ftag) F;
-                return msm_reduce_batch<F>(ctx->aux, sets.data(), (int)sets.size(), n, c, nwin, shared, sps[pd[0].comp].cap, evm, nm, pev, chunk_request);
+                return msm_reduce_batch<F>(rst, sets.data(), (int)sets.size(), n, c, nwin, shared, sps[pd[0].comp].cap, evm, nm, pev, chunk_request);
             });
             if (rc) return rc;
             for (const PendSet& ps : pd) {
-                HIPCHK(hipEventRecord(ctx->ev_red[ps.slot], ctx->aux));
+                HIPCHK(hipEventRecord(ctx->ev_red[ps.slot], rst));
                 ctx->slot_busy[ps.slot] = true; ctx->aux_pending = true; ctx->last_slot = ps.slot; ctx->merged_pending[ps.sched] = true;
-                if (ps.comp == k - 1) HIPCHK(hipEventRecord(ctx->tickets[slots[ps.table]].done, ctx->aux));   // this table's last component: its results are complete on the aux stream
             }
+            // a table's results are complete when the batch holding its LAST outstanding component has run (components may sit in different batches)
+            for (const PendSet& ps : pd) if (--comps_left[ps.table] == 0) HIPCHK(hipEventRecord(ctx->tickets[slots[ps.table]].done, rst));
             pd.clear();
             return 0;
         };
+        auto acc_set = [&](int b, int j, char* scratch) -> MsmAccSet {
+            const char* pts = (const char*)(shared ? bases[b]->d_pre : bases[b]->d_pts) + (offsets ? offsets[b] : 0) * bases[b]->pt_bytes;
+            return MsmAccSet{pts, shared ? bases[b]->n : 0, sps[j].sorted, sps[j].offsets, sps[j].counts, scratch, !bases[b]->no_inf};
+        };
+        auto red_set = [&](int b, int j, char* scratch) -> MsmRedSet {
+            const MsmTicket& t = ctx->tickets[slots[b]];
+            const size_t pinned_stride = (size_t)(t.group == CG_G1 ? 4 : 8) * (bases[b]->pt_bytes / (t.group == CG_G1 ? 2 : 4));     // sizeof(XYZZ<F>): four coordinates
+            return MsmRedSet{scratch, sps[j].offsets, sps[j].counts, (char*)t.h_pinned + (size_t)j * nsums * pinned_stride};
+        };
+        // WIDE mode (small calls, <= 2 share components, one scratch slot per set): all accumulations of a coordinate field in ONE launch
+        // (blockIdx.y = table x component), the G2 launch first and its reduction on the aux stream while the G1 launch runs, whose
+        // reduction goes to the then idle sort stream.  A 2^16-point launch is 256 workgroups and lasts as long as one lane's chain of
+        // additions; eight in a row cost eight chains (2^16 step: 3.2 ms), side by side one.
+        const bool wide = k <= 2 && nb * k <= std::min(acc_slots, (int)ACC_MAX_SETS) && (uint64_t)nwin * n <= ((uint64_t)1 << 22) && ctx->wide_small != 0;
+        if (wide) {
+            if (k == 2) { int rc = launch_sort(1); if (rc) return rc; }
+            for (int j = 0; j < k; j++) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[j], 0));
+            red_stream[0] = ctx->sortst;
+            for (int gi : {1, 0}) {
+                std::vector<MsmAccSet> sets;
+                for (int j = 0; j < k; j++) for (int b = 0; b < nb; b++) {
+                    if ((bases[b]->group == CG_G1 ? 0 : 1) != gi) continue;
+                    const int slot = iter++ % acc_slots;
+                    if (ctx->slot_busy[slot]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_red[slot], 0));
+                    char* scratch = acc_scratch + (size_t)slot * acc_slot;
+                    sets.push_back(acc_set(b, j, scratch));
+                    pend[gi].push_back(PendSet{red_set(b, j, scratch), slot, j, b, j});
+                }
+                if (sets.empty()) continue;
+                hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
+                if (ctx->stats_on) { const int i1 = ev_open(ctx, gi == 0 ? TAG_ACC_G1 : TAG_ACC_G2); evs[0] = ctx->ev_live[i1].a; evs[1] = ctx->ev_live[i1].b; pev = evs; }
+                int rc = with_coord_field(curve, gi == 0 ? CG_G1 : CG_G2, [&](auto ftag) -> int {
+                    typedef decltype(ftag) F;
+                    return msm_accumulate_batch<F>(ctx->stream, sets.data(), (int)sets.size(), n, c, nwin, shared, sps[0].cap, pev, chunk_request, false);
+                });
+                if (rc) return rc;
+                if (gi == 0) HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_sorted[k - 1], 0));     // (the sort stream has nothing else left in this call)
+                { int rc2 = flush(gi); if (rc2) return rc2; }
+            }
+            for (int j = 0; j < k; j++) HIPCHK(hipEventRecord(ctx->ev_sched_free[j], ctx->stream));
+        }
         // one accumulation: table b, share component j, into the next rotating scratch slot; its bucket set joins the batch of its field
         auto do_acc = [&](int b, int j) -> int {
             const MsmSortPtrs& sp = sps[j];
@@ -509,18 +554,17 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
             }
             if (ctx->slot_busy[slot]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_red[slot], 0));   // slot's previous reduction must be done
             char* scratch = acc_scratch + (size_t)slot * acc_slot;
-            size_t pinned_stride = 0;
+            const MsmAccSet as = acc_set(b, j, scratch);
             int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
                 typedef decltype(ftag) F;
-                pinned_stride = sizeof(XYZZ<F>);
-                const Affine<F>* pts = (const Affine<F>*)(shared ? bases[b]->d_pre : bases[b]->d_pts) + (offsets ? offsets[b] : 0);
-                return msm_accumulate_launch<F>(ctx->stream, pts, n, c, nwin, shared ? bases[b]->n : 0, sp.sorted, sp.offsets, sp.counts, sp.cap, scratch, pev, !bases[b]->no_inf, chunk_request, ctx->g2_slices != 0);
+                return msm_accumulate_batch<F>(ctx->stream, &as, 1, n, c, nwin, shared, sp.cap, pev, chunk_request, ctx->g2_slices != 0);
             });
             if (rc) return rc;
-            pend[gi].push_back(PendSet{MsmRedSet{scratch, sp.offsets, sp.counts, (char*)t.h_pinned + (size_t)j * nsums * pinned_stride}, slot, j % nsched, b, j});
+            pend[gi].push_back(PendSet{red_set(b, j, scratch), slot, j % nsched, b, j});
             return 0;
         };
-        if (k <= 2 && ctx->table_order == 2) {
+        if (wide) {}
+        else if (k <= 2 && ctx->table_order == 2) {
             // CG_OPT_MSM_TABLE_ORDER = 2: ONE launch order over (table, component) pairs — the G1 pairs in serpentine order, the G2 pairs together
             // after `g2_after` of them (CG_OPT_MSM_G2_AFTER; beyond the G1 count: at the end).  Both schedules are built up front.
             if (k == 2) { int rc = launch_sort(1); if (rc) return rc; }
@@ -1058,7 +1102,7 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     {   // A/B runs: environment variables seed the option table of new contexts (include/cogroth16_hip.h, cg_ctx_set_option)
         auto seed = [](const char* name, int lo, int hi, int& field) { if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= lo && v <= hi) field = v; } };
         seed("CG_MSM_TABLE_ORDER", 0, 2, c->table_order); seed("CG_MSM_G2_AFTER", -1, 64, c->g2_after); seed("CG_MSM_G2_SLICES", 0, 1, c->g2_slices);
-        seed("CG_MSM_REDUCE_BATCH", 0, 3, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots);
+        seed("CG_MSM_REDUCE_BATCH", 0, 3, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots); seed("CG_MSM_WIDE_SMALL", 0, 1, c->wide_small);
     }
     if (flags & 1u) { c->prio_main = 1; c->prio_copy = 1; c->prio_side = 0; }
     else if (flags & 2u) { static const int bulk_cls = getenv("CG_BULK_CLASS") ? atoi(getenv("CG_BULK_CLASS")) : -1; c->prio_main = bulk_cls; c->prio_side = 0; }   // CG_BULK_CLASS: tuning knob
@@ -1599,6 +1643,7 @@ int32_t cg_ctx_set_option(cg_ctx* ctx, int32_t option, int64_t value) {
         case CG_OPT_MSM_G2_SLICES: if (value < 0 || value > 1) break; ctx->g2_slices = (int)value; return 0;
         case CG_OPT_MSM_REDUCE_BATCH: if (value < 0 || value > 3) break; ctx->red_batch = (int)value; return 0;
         case CG_OPT_MSM_ACC_SLOTS: if (value < 2 || value > cg_ctx::ACC_SLOTS_MAX) break; ctx->acc_slots = (int)value; return 0;
+        case CG_OPT_MSM_WIDE_SMALL: if (value < 0 || value > 1) break; ctx->wide_small = (int)value; return 0;
         default: return fail(CG_ERR_ARG, "cg_ctx_set_option: unknown option");
     }
     return fail(CG_ERR_ARG, "cg_ctx_set_option: value out of range");
@@ -1614,6 +1659,7 @@ int32_t cg_ctx_get_option(const cg_ctx* ctx, int32_t option, int64_t* value) {
         case CG_OPT_MSM_G2_SLICES: *value = ctx->g2_slices; return 0;
         case CG_OPT_MSM_REDUCE_BATCH: *value = ctx->red_batch; return 0;
         case CG_OPT_MSM_ACC_SLOTS: *value = ctx->acc_slots; return 0;
+        case CG_OPT_MSM_WIDE_SMALL: *value = ctx->wide_small; return 0;
         default: return fail(CG_ERR_ARG, "cg_ctx_get_option: unknown option");
     }
 }

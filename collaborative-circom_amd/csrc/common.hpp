@@ -59,7 +59,10 @@ struct MsmGeom {            // derived sizes shared by the host-side planner and
 constexpr int MSM_SHARED_GROUPS = 16;
 // One bucket set of a reduction batch (msm_impl.hpp: msm_reduce_batch): its scratch slot, the schedule it was accumulated from, and where
 // its sums go (pinned host memory).  Up to RED_MAX_SETS sets of one coordinate field and one launch geometry share the launches.
-constexpr int RED_MAX_SETS = 8;
+constexpr int RED_MAX_SETS = 8, ACC_MAX_SETS = 8;
+// One accumulation of a batch (msm_impl.hpp: msm_accumulate_batch): table (window-0 records incl. the caller's offset; stride of the
+// per-window copies, 0 = none), the schedule of its share component, its scratch slot.
+struct MsmAccSet { const void* bases; size_t table_stride; const uint32_t* sorted; const uint32_t* offsets; const uint32_t* counts; char* scratch; bool may_have_inf; };
 struct MsmRedSet { char* scratch; const uint32_t* offsets; const uint32_t* counts; void* h_out; };
 // resident_lanes: lanes of the accumulation kernel the chip holds at once (0 = unknown).  Its workgroups do equal work and finish
 // in lock step, so a launch of 2.16 residency rounds takes as long as 2.33 (the last 0.16 round runs one wave per SIMD, three

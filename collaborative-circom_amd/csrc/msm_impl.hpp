@@ -50,23 +50,29 @@ MsmGeom msm_geom_of(size_t n, int c, int nwin, bool shared, uint32_t chunk_reque
     return g;
 }
 
-// Bucket accumulation of one (bases, sorted schedule) pair into the bucket set of `scratch`, on `st` (the launch fills the chip).
-// table_stride != 0 selects the shared-bucket-set mode (d_bases = window-0 table of a [nwin][table_stride] precomputed block).
-// evs (optional, 2 events) bracket the accumulation KERNEL alone (what rocprofv3 lists per launch).
+// Bucket accumulation of UP TO ACC_MAX_SETS (bases, sorted schedule) pairs of one coordinate field and one launch geometry, each into
+// the bucket set of its scratch slot, on `st`: one launch with blockIdx.y = set (a large call passes one set and fills the chip by
+// itself; the tables and components of a small call go side by side).  table_stride != 0 selects the shared-bucket-set mode (bases =
+// window-0 table of a [nwin][table_stride] precomputed block).  evs (optional, 2 events) bracket the accumulation KERNEL(s) alone.
 template <class F>
-int msm_accumulate_launch(hipStream_t st, const Affine<F>* d_bases, size_t n, int c, int nwin, size_t table_stride,
-                          const uint32_t* sorted, const uint32_t* offsets, const uint32_t* counts, uint32_t cap, char* scratch, hipEvent_t* evs, bool may_have_inf, uint32_t chunk_request, bool g2_slices) {
-    const bool shared = table_stride != 0;
+int msm_accumulate_batch(hipStream_t st, const MsmAccSet* sets, int nsets, size_t n, int c, int nwin, bool shared, uint32_t cap, hipEvent_t* evs, uint32_t chunk_request, bool g2_slices) {
+    if (nsets < 1 || nsets > ACC_MAX_SETS) return fail(CG_ERR_ARG, "internal: accumulation batch size");
     const MsmGeom g = msm_geom_of<F>(n, c, nwin, shared, chunk_request);
     typedef typename BucketOf<F>::type B;                 // limb-form points for the lazy pipelines, saturated XYZZ otherwise
-    const AccScratch<F> sc(scratch, g);
-    B* buckets = sc.buckets; B* cont = sc.cont; uint32_t* cont_bucket = sc.cont_bucket;
-    HIPCHK(hipMemsetAsync(buckets, 0, g.nbuckets * sizeof(B), st));                // all-zero = infinity (empty buckets are never written)
+    AccSets<F> S{};
+    for (int i = 0; i < nsets; i++) {
+        const AccScratch<F> sc(sets[i].scratch, g);
+        S.bases[i] = (const Affine<F>*)sets[i].bases; S.sorted[i] = sets[i].sorted; S.offsets[i] = sets[i].offsets; S.counts[i] = sets[i].counts;
+        S.buckets[i] = sc.buckets; S.cont[i] = sc.cont; S.cont_bucket[i] = sc.cont_bucket;
+        S.table_stride[i] = (uint32_t)sets[i].table_stride; S.may_have_inf[i] = sets[i].may_have_inf ? 1u : 0u;
+        HIPCHK(hipMemsetAsync(sc.buckets, 0, g.nbuckets * sizeof(B), st));                // all-zero = infinity (empty buckets are never written)
+    }
     if (evs) HIPCHK(hipEventRecord(evs[0], st));
-    auto launch_acc = [&](auto kern, int T, size_t lds) -> int {
+    auto launch_acc = [&](auto kern, int T, size_t lds) -> int {                         // one set per launch (padded lists, CG_ACC_VARIANT=0)
         if (lds > 0) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((g.nchunks + T - 1) / T), dim3(T), lds, st, d_bases, sorted, offsets, counts,
-                           (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, (uint32_t)table_stride, cap, buckets, cont, cont_bucket, may_have_inf ? 1u : 0u);
+        for (int i = 0; i < nsets; i++)
+            hipLaunchKernelGGL(kern, dim3((g.nchunks + T - 1) / T), dim3(T), lds, st, S.bases[i], S.sorted[i], S.offsets[i], S.counts[i],
+                               (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, S.table_stride[i], cap, S.buckets[i], S.cont[i], S.cont_bucket[i], S.may_have_inf[i]);
         return 0;
     };
     // accumulator policy per coordinate field (lazy limbs everywhere: 9 x 29 bits for BN254, 14 x 28 bits for BLS12-381 Fq):
@@ -88,8 +94,7 @@ int msm_accumulate_launch(hipStream_t st, const Affine<F>* d_bases, size_t n, in
         const uint32_t groups = (g.nchunks + T - 1) / T;
         const uint32_t slice = lds > 0 && g2_slices ? 256u * (uint32_t)std::max<size_t>(1, ((size_t)160 << 10) / lds) : groups;
         for (uint32_t first = 0; first < groups; first += slice)
-            hipLaunchKernelGGL(kern, dim3(std::min(slice, groups - first)), dim3(T), lds, st, d_bases, sorted, offsets, counts,
-                               (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, (uint32_t)table_stride, buckets, cont, cont_bucket, may_have_inf ? 1u : 0u, first * (uint32_t)T);
+            hipLaunchKernelGGL(kern, dim3(std::min(slice, groups - first), (unsigned)nsets), dim3(T), lds, st, S, (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, first * (uint32_t)T);
         return 0;
     };
     constexpr bool g2 = IsFp2<F>::value;
@@ -254,7 +259,7 @@ int fixed_base_mul_launch(hipStream_t st, const Affine<F>& g, const Fr* d_scalar
 
 #define CG_INSTANTIATE_MSM(F, Fr)                                                                                          \
     namespace cg {                                                                                                         \
-    template int msm_accumulate_launch<F>(hipStream_t, const Affine<F>*, size_t, int, int, size_t, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, char*, hipEvent_t*, bool, uint32_t, bool); \
+    template int msm_accumulate_batch<F>(hipStream_t, const MsmAccSet*, int, size_t, int, int, bool, uint32_t, hipEvent_t*, uint32_t, bool); \
     template int msm_reduce_batch<F>(hipStream_t, const MsmRedSet*, int, size_t, int, int, bool, uint32_t, hipEvent_t*, int, hipEvent_t*, uint32_t); \
     template size_t msm_acc_scratch_bytes<F>(size_t, int, int, bool, uint32_t);                                                      \
     template int precompute_window_launch<F>(hipStream_t, const Affine<F>*, Affine<F>*, size_t, int);                      \

@@ -399,15 +399,26 @@ __global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate(const Affine<F
 //   * PF == 1: the record of the next entry is pulled into L2 while the current addition runs: one global_load_lds_dword per
 //     64 bytes into a junk LDS slot (no VGPR destination, nothing to wait for), issued after the current record has arrived;
 //   * PF == 2: the next record itself is loaded into registers before the current addition (for a 2-wave-per-SIMD build).
+// Up to ACC_MAX_SETS accumulations of ONE launch geometry in one launch (blockIdx.y = set): the tables and share components of a small
+// MSM call (2^16 constraints: a launch of 256 workgroups leaves three quarters of the chip idle and lasts as long as one lane's chain
+// of additions, so eight launches in a row cost eight such chains; side by side they cost one).  Large calls pass one set.
+template <class F>
+struct AccSets {
+    const Affine<F>* bases[ACC_MAX_SETS];                  // window-0 table (+ the caller's offset) of each set
+    const uint32_t* sorted[ACC_MAX_SETS]; const uint32_t* offsets[ACC_MAX_SETS]; const uint32_t* counts[ACC_MAX_SETS];   // its schedule
+    typename BucketOf<F>::type* buckets[ACC_MAX_SETS]; typename BucketOf<F>::type* cont[ACC_MAX_SETS]; uint32_t* cont_bucket[ACC_MAX_SETS];
+    uint32_t table_stride[ACC_MAX_SETS]; uint32_t may_have_inf[ACC_MAX_SETS];
+};
 template <class Acc, int THREADS> __host__ __device__ constexpr size_t acc_lds_bytes() {
     if constexpr (Acc::USES_LDS) return (size_t)THREADS * Acc::LDS_BYTES_PER_LANE; else return 0;
 }
 template <class F, class Acc, int THREADS, int MINW, int PF, int DBG = 0>
-__global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate_pf(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                                                     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                                                                     uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks, uint32_t table_stride,
-                                                                     typename BucketOf<F>::type* __restrict__ buckets, typename BucketOf<F>::type* __restrict__ cont,
-                                                                     uint32_t* __restrict__ cont_bucket, uint32_t may_have_inf, uint32_t first_chunk) {
+__global__ void __launch_bounds__(THREADS, MINW) k_msm_accumulate_pf(const AccSets<F> S, uint32_t nbuckets, uint32_t chunk_len, uint32_t nchunks, uint32_t first_chunk) {
+    const Affine<F>* __restrict__ bases = S.bases[blockIdx.y]; const uint32_t* __restrict__ sorted = S.sorted[blockIdx.y];
+    const uint32_t* __restrict__ offsets = S.offsets[blockIdx.y]; const uint32_t* __restrict__ counts = S.counts[blockIdx.y];
+    typename BucketOf<F>::type* __restrict__ buckets = S.buckets[blockIdx.y]; typename BucketOf<F>::type* __restrict__ cont = S.cont[blockIdx.y];
+    uint32_t* __restrict__ cont_bucket = S.cont_bucket[blockIdx.y];
+    const uint32_t table_stride = S.table_stride[blockIdx.y], may_have_inf = S.may_have_inf[blockIdx.y];
     extern __shared__ uint4 acc_lds[];        // [accumulators (LDS policies)] [PF == 1: THREADS junk dwords, see PF_JUNK_OFFSET]
     const uint32_t q = first_chunk + blockIdx.x * THREADS + threadIdx.x;   // first_chunk: a launch may cover a slice of the chunks (msm_accumulate_reduce)
     if (q >= nchunks) return;

@@ -154,7 +154,7 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *                 CG_NTT_DIF / CG_NTT_NO_PAIR / CG_NTT_TILE (10)   canonical DIF passes; iNTT + coset + NTT as two calls; log2 of the lazy passes' LDS tile
  *                 CG_SUBGROUP_FULL           subgroup checks by [r]P instead of the endomorphism tests
  *                 CG_BULK_CLASS (-1)         priority class of a bulk context's main stream (cg_ctx_create_ex flag 2)
- *                 CG_MSM_TABLE_ORDER, CG_MSM_G2_AFTER, CG_MSM_G2_SLICES, CG_MSM_REDUCE_BATCH, CG_MSM_ACC_SLOTS   seed the option table of NEW contexts
+ *                 CG_MSM_TABLE_ORDER, CG_MSM_G2_AFTER, CG_MSM_G2_SLICES, CG_MSM_REDUCE_BATCH, CG_MSM_ACC_SLOTS, CG_MSM_WIDE_SMALL   seed the option table of NEW contexts
  *   DEBUG         CG_DEBUG_NO_REDUCE = 1 | 2 skips the merges + bucket reductions | the reductions only: RESULTS ARE WRONG (what they cost a step) */
 /* ---- per-context tuning (never changes results).  One table instead of process-wide environment variables: every option belongs to the
  * context it is set on (a party's chain and bulk contexts differ), is read at the next call that uses it, and can be read back.
@@ -179,9 +179,11 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *   CG_OPT_MSM_REDUCE_BATCH        bucket sets merged and reduced together: 2 = per call and coordinate field, 1 = per share        2
  *                                  component and field, 0 = each on its own right behind its accumulation
  *   CG_OPT_MSM_ACC_SLOTS           rotating scratch slots of the accumulate / reduce pipeline (2 .. 8; batches take one per set)    4
+ *   CG_OPT_MSM_WIDE_SMALL          1 = calls of at most 2^22 (point, window) entries and two share components launch all accumulations    1
+ *                                  of a coordinate field side by side (one launch, one reduction batch per field)
  * Environment variables of the same names (CG_OPT_... without the prefix: CG_MSM_CHUNK, ...) seed the defaults of NEW contexts for A/B runs. */
 enum { CG_OPT_MSM_CHUNK = 1, CG_OPT_MSM_WINDOW = 2, CG_OPT_MSM_SCATTER_CAP = 3, CG_OPT_MSM_TABLE_ORDER = 4, CG_OPT_MSM_G2_SLICES = 5,
-       CG_OPT_MSM_REDUCE_BATCH = 6, CG_OPT_MSM_ACC_SLOTS = 7, CG_OPT_MSM_G2_AFTER = 8, CG_OPT_COUNT_ };
+       CG_OPT_MSM_REDUCE_BATCH = 6, CG_OPT_MSM_ACC_SLOTS = 7, CG_OPT_MSM_G2_AFTER = 8, CG_OPT_MSM_WIDE_SMALL = 9, CG_OPT_COUNT_ };
 int32_t cg_ctx_set_option(cg_ctx* ctx, int32_t option, int64_t value);
 int32_t cg_ctx_get_option(const cg_ctx* ctx, int32_t option, int64_t* value);
 /* window size override (0 = automatic); tuning knob only, never changes results */
