@@ -434,7 +434,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // its own right behind its accumulation (rounds 1-3).  Beside lock-stepped accumulations a reduction costs the step its stand-alone
         // duration whatever its width: 2^22 step with ten reductions 6.2 ms, with three.  A batch holds its sets' scratch slots until it has run: one slot per set.
         const int red_batch = ctx->red_batch;
-        const bool small_call = k <= 2 && (uint64_t)nwin * n <= ((uint64_t)1 << 22) && ctx->wide_small != 0;            // see `wide` below
+        const bool small_call = k <= 2 && (uint64_t)nwin * n <= ((uint64_t)1 << 20) && ctx->wide_small != 0;            // see `wide` below
         const int acc_slots = red_batch || small_call ? std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(acc_slots_min, red_batch >= 2 || small_call ? nb * k : nb + 1)) : acc_slots_min;
         { int rc = ensure_arena(ctx, nsched * sort_bytes + (size_t)acc_slots * acc_slot); if (rc) return rc; }
         char* acc_scratch = ctx->arena.base + nsched * sort_bytes;
@@ -511,7 +511,8 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // (blockIdx.y = table x component), the G2 launch first and its reduction on the aux stream while the G1 launch runs, whose
         // reduction goes to the then idle sort stream.  A 2^16-point launch is 256 workgroups and lasts as long as one lane's chain of
         // additions; eight in a row cost eight chains (2^16 step: 3.2 ms), side by side one.
-        const bool wide = k <= 2 && nb * k <= std::min(acc_slots, (int)ACC_MAX_SETS) && (uint64_t)nwin * n <= ((uint64_t)1 << 22) && ctx->wide_small != 0;
+        // (measured, round 4: 2^14 step 2.63 -> 2.14 ms, 2^16 3.30 -> 3.09 ms and one REP3 party 5.85 -> 5.54 ms; from 2^17 points on — 2^21 entries — no gain)
+        const bool wide = k <= 2 && nb * k <= std::min(acc_slots, (int)ACC_MAX_SETS) && (uint64_t)nwin * n <= ((uint64_t)1 << 20) && ctx->wide_small != 0;
         if (wide) {
             if (k == 2) { int rc = launch_sort(1); if (rc) return rc; }
             for (int j = 0; j < k; j++) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[j], 0));

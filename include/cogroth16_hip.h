@@ -179,7 +179,7 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *   CG_OPT_MSM_REDUCE_BATCH        bucket sets merged and reduced together: 2 = per call and coordinate field, 1 = per share        2
  *                                  component and field, 0 = each on its own right behind its accumulation
  *   CG_OPT_MSM_ACC_SLOTS           rotating scratch slots of the accumulate / reduce pipeline (2 .. 8; batches take one per set)    4
- *   CG_OPT_MSM_WIDE_SMALL          1 = calls of at most 2^22 (point, window) entries and two share components launch all accumulations    1
+ *   CG_OPT_MSM_WIDE_SMALL          1 = calls of at most 2^20 (point, window) entries and two share components launch all accumulations    1
  *                                  of a coordinate field side by side (one launch, one reduction batch per field)
  * Environment variables of the same names (CG_OPT_... without the prefix: CG_MSM_CHUNK, ...) seed the defaults of NEW contexts for A/B runs. */
 enum { CG_OPT_MSM_CHUNK = 1, CG_OPT_MSM_WINDOW = 2, CG_OPT_MSM_SCATTER_CAP = 3, CG_OPT_MSM_TABLE_ORDER = 4, CG_OPT_MSM_G2_SLICES = 5,
