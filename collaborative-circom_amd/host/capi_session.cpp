@@ -194,7 +194,9 @@ int32_t cgh_session_prove_rep3_party_ex(void* h, const uint64_t* pub_in, const u
             // One device: the shares start crossing PCIe, and while they do (nothing else can run yet) the masks of the witness map's two
             // mul_vec calls are drawn — the first draws of the proof in the reference's order too (rep3.rs:656-660 precede :595-598) —
             // on this context's still idle stream; only then is the stream made to wait for the shares.
-            const bool early_masks = workers.get() == nullptr;
+            // (Shares that go up synchronously — short vectors, pageable memory — leave no such window: the prover then draws after it has
+            // enqueued the witness-independent MSMs, as before.)
+            const bool early_masks = workers.get() == nullptr && n_aux >= driver.XCHG_ASYNC_MIN && cg_host_is_pinned(wit_a) && cg_host_is_pinned(wit_b);
             VecGuard wit(driver, driver.upload_vec((const Fr*)wit_a, (const Fr*)wit_b, n_aux, !early_masks));
             if (early_masks) {
                 driver.prefetch_masks(2, groth16_domain(z.curve, z.pow, z.num_constraints, pub.size()).m);

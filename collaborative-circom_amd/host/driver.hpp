@@ -448,6 +448,7 @@ public:
     void release_rings() { for (PinRing* r : {&ring_out, &ring_in}) if (r->base) { cg_ctx_sync(ctx); cg_host_free(r->base); r->base = nullptr; r->chunk = 0; } }
     std::vector<void*> deferred;                                                        // device buffers freed at the next quiet point
     void defer_free(void* p) { if (p) deferred.push_back(p); }
+    void defer_vec(ShareVec& v) { for (int j = 0; j < 2; j++) { defer_free(v.c[j]); v.c[j] = nullptr; } }
     void free_deferred() { for (void* p : deferred) CG(cg_dev_free(ctx, p)); deferred.clear(); }
     // host (pageable) -> device through the ring, asynchronous; returns the ticket of the last chunk
     int32_t upload_staged(void* d_dst, const Fr* src, size_t n) {
@@ -474,7 +475,7 @@ public:
     const size_t XCHG_ASYNC_MIN = getenv("CGH_XCHG_ASYNC_MIN") ? (size_t)atoll(getenv("CGH_XCHG_ASYNC_MIN")) : (size_t)1 << 17;   // (2^19 until round 4; one REP3 party at 2^17: 8.1 -> 6.7 ms, at 2^16 the single message is faster)
     // masks of the coming mul_vec calls, uploaded ahead of time (only from page-locked randomness streams, where the copy is a plain
     // asynchronous DMA): the product kernel then never waits for PCIe
-    struct MaskSet { void* m1; void* m2; int32_t tk; size_t n, at; };
+    struct MaskSet { void* m1; void* m2; int32_t tk; size_t n, at; void* block = nullptr; bool owns = true; };   // block: m1 lies inside a block drawn for several calls; the LAST of them releases it
     // a randomness source that describes its ChaCha12 generators has its masks drawn by the backend (no host draws, no upload); short vectors
     // are not worth three launches and a stream synchronisation
     const size_t DEVICE_MASKS_MIN = getenv("CGH_DEVICE_MASKS_MIN") ? (size_t)atoll(getenv("CGH_DEVICE_MASKS_MIN")) : (size_t)1 << 14;   // (the override lets the small fixtures take the device path)
@@ -494,6 +495,18 @@ public:
     void prefetch_masks(int count, size_t n) {
         if (mode != Mode::Rep3) return;
         if (rsrc) {                                                                     // drawn now, in the reference's order (both mul_vec calls precede every other draw)
+            // the masks of `count` consecutive mul_vec calls are count * n consecutive draws of each generator: ONE device draw per generator
+            // (one stream synchronisation each instead of `count`), cut into the calls' vectors
+            if (count > 1) {
+                void* block = nullptr;
+                if (cg_dev_alloc(ctx, (size_t)count * n * 32, &block) == 0) {
+                    if (masks_on_device(block, (size_t)count * n)) {
+                        for (int i = 0; i < count; i++) { MaskSet ms{(char*)block + (size_t)i * n * 32, nullptr, -1, n, 0}; ms.block = block; ms.owns = i == count - 1; prefetched.push_back(ms); }
+                        return;
+                    }
+                    CG(cg_dev_free(ctx, block));
+                }
+            }
             for (int i = 0; i < count; i++) {
                 MaskSet ms{dalloc(n * 32), nullptr, -1, n, 0};
                 if (masks_on_device(ms.m1, n)) {}                                       // any length from DEVICE_MASKS_MIN on
@@ -534,11 +547,11 @@ public:
         if (mode != Mode::Rep3) CG(cg_vec_mul_dev(ctx, curve.id, out.c[0], a.c[0], b.c[0], a.n));
         if (mode == Mode::Plain) return pm;
         if (mode == Mode::Shamir) { if (exchange) out = degree_reduce_vec(out); return pm; }   // shamir.rs:609-623 (exchange = false: the degree-2t products)
-        void* m1 = nullptr; void* m2 = nullptr;
+        void* m1 = nullptr; void* m2 = nullptr; void* m1_block = nullptr; bool m1_owned = true;
         if (rsrc) {
             if (!prefetched.empty() && prefetched.front().n == a.n) {
                 const MaskSet ms = prefetched.front(); prefetched.pop_front();
-                m1 = ms.m1;
+                m1 = ms.m1; m1_owned = ms.owns; if (ms.block) m1_block = ms.block;
                 if (ms.tk >= 0) CG(cg_copy_fence(ctx, ms.tk));
             } else {
                 m1 = dalloc(a.n * 32);
@@ -565,7 +578,8 @@ public:
         CG(cg_vec_sub_dev(ctx, curve.id, m1, m1, m2, a.n));                           // masking_field_element = rand(rng1) - rand(rng2)
         }
         CG(cg_vec_rep3_mul_local_dev(ctx, curve.id, out.c[0], a.c[0], a.c[1], b.c[0], b.c[1], m1, a.n));
-        defer_free(m1); defer_free(m2);
+        if (m1_owned) defer_free(m1_block ? m1_block : m1);                            // (a block drawn for several calls is released with the last of them)
+        defer_free(m2);
         if (!exchange) return pm;
         out.c[1] = dalloc(a.n * 32);
         pm.exchange = true;
@@ -614,7 +628,7 @@ public:
         for (void* p : deferred) cg_dev_free(ctx, p);
         deferred.clear();
         if (d_bad) { cg_dev_free(ctx, d_bad); d_bad = nullptr; }
-        for (auto& ms : prefetched) { cg_dev_free(ctx, ms.m1); if (ms.m2) cg_dev_free(ctx, ms.m2); }
+        for (auto& ms : prefetched) { if (ms.owns) cg_dev_free(ctx, ms.block ? ms.block : ms.m1); if (ms.m2) cg_dev_free(ctx, ms.m2); }
         prefetched.clear();
         if (!mask_bufs.empty()) { cg_ctx_sync(ctx); for (void* p : mask_bufs) cg_host_free(p); mask_bufs.clear(); }   // uploads from them may still be in flight
         release_rings(); release_pre();
