@@ -755,6 +755,7 @@ public:
     PendingMsm msm_begin_sharded(const DeviceZKey& dz, bool aux_tables, const ShareVec& s) {
         const size_t lo = aux_tables ? dz.aux_lo : dz.h_lo, n = aux_tables ? dz.aux_n : dz.h_n;
         ShareVec mine; mine.n = n; for (int j = 0; j < k(); j++) mine.c[j] = (char*)s.c[j] + lo * 32;
+        mine.up_ctx = s.up_ctx; mine.up[0] = s.up[0]; mine.up[1] = s.up[1];            // a slice of shares still crossing PCIe: the schedules wait on the device, not the host (it used to block 5 ms here at 2^22)
         PendingMsm p = aux_tables ? msm_begin_multi({dz.a, dz.b1, dz.b2, dz.l}, {0, 0, 0, 0}, {CG_G1, CG_G1, CG_G2, CG_G1}, n, mine, true)   // table order = CoGroth16::prove's AUX_* indices
                                   : msm_begin_multi({dz.h}, {0}, {CG_G1}, n, mine, false);
         if (!md) return p;
