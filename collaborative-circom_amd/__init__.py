@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "cg_dev_alloc", "cg_dev_free", "cg_dev_upload", "cg_dev_download", "cg_dev_memset_zero",
     "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute", "cg_bases_check_on_curve", "cg_bases_check_subgroup",
     "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_chunk", "cg_ctx_set_option", "cg_ctx_get_option", "cg_msm_scalars_after", "cg_msm_set_scatter_capacity",
-    "cg_ntt", "cg_ntt_dev", "cg_ntt_coset_pair_dev", "cg_chacha12_fr_rand_dev",
+    "cg_ntt", "cg_ntt_dev", "cg_ntt_coset_pair_dev", "cg_chacha12_fr_rand_dev", "cg_chacha12_fr_rand_dev_begin", "cg_chacha12_fr_rand_dev_finish",
     "cg_host_alloc", "cg_host_free", "cg_host_is_pinned", "cg_dev_download_begin", "cg_dev_upload_begin", "cg_stream_mark", "cg_dev_download_begin_after", "cg_copy_wait", "cg_copy_fence",
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev", "cg_vec_affine_dev", "cg_vec_fill_dev", "cg_vec_gather_strided_dev", "cg_vec_lincomb_dev", "cg_vec_prefix_prod_dev", "cg_vec_prefix_sum_dev", "cg_vec_inverse_dev",
     "cg_spmv_csr_dev", "cg_vec_mul", "cg_vec_rep3_mul_local",
@@ -215,6 +215,18 @@ class Context:
         buf = self.alloc(max(n * 32, 16)); after = C.c_uint64(0)
         _chk(load().cg_chacha12_fr_rand_dev(self.h, curve, bytes(seed), C.c_uint64(word_pos), C.c_size_t(n), C.c_void_p(buf.ptr), C.byref(after)))
         return buf, after.value
+
+    def chacha12_fr_rand_begin(self, curve, seed, word_pos, n):
+        """the same draws enqueued and not waited for: (DevBuf, ticket for chacha12_fr_rand_finish)"""
+        buf = self.alloc(max(n * 32, 16)); tk = C.c_int32(-1)
+        _chk(load().cg_chacha12_fr_rand_dev_begin(self.h, curve, bytes(seed), C.c_uint64(word_pos), C.c_size_t(n), C.c_void_p(buf.ptr), C.byref(tk)))
+        return buf, tk.value
+
+    def chacha12_fr_rand_finish(self, ticket):
+        """waits for the draw of that ticket: word position afterwards"""
+        after = C.c_uint64(0)
+        _chk(load().cg_chacha12_fr_rand_dev_finish(self.h, C.c_int32(ticket), C.byref(after)))
+        return after.value
 
     # ---- page-locked staging + asynchronous copies (exchange chunks move under the compute)
     def host_alloc(self, shape, dtype=np.uint64):

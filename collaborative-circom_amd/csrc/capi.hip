@@ -127,6 +127,10 @@ struct cg_ctx {
     hipEvent_t copy_ev[COPY_TICKETS] = {}; uint32_t copy_id[COPY_TICKETS] = {}; hipEvent_t ev_copy_order = nullptr; uint32_t copy_next = 0;
     static constexpr int MARKS = 16;                      // cg_stream_mark: points of the stream order that downloads can be ordered behind
     hipEvent_t mark_ev[MARKS] = {}; uint32_t mark_next = 0;
+    // cg_chacha12_fr_rand_dev_begin / _finish: draws in flight (candidate buffers, the event behind the count's download, the page-locked count)
+    struct RandDraw { bool live = false; void* d_cand = nullptr; void* d_small = nullptr; hipEvent_t ev = nullptr; uint64_t word_pos = 0; size_t n = 0; };
+    static constexpr int RAND_DRAWS = 8;
+    RandDraw rand_draw[RAND_DRAWS]; unsigned long long* rand_result = nullptr;   // [RAND_DRAWS][2] page-locked: accepted candidates, index of the last pair used
     // cg_msm_scalars_after: the scalar-side schedule of component j of the NEXT begin call waits for this event (an upload still in flight)
     hipEvent_t comp_after[4] = {};
     hipStream_t joinst = nullptr; hipEvent_t park_ev[5] = {};   // cg_dev_free: a work-free stream that joins the context's streams behind a released block
@@ -1132,6 +1136,8 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     hipStreamSynchronize(ctx->sortst);
     for (int i = 0; i < cg_ctx::ACC_SLOTS_MAX; i++) { hipEventDestroy(ctx->ev_acc[i]); hipEventDestroy(ctx->ev_red[i]); }
     for (hipEvent_t e : ctx->mark_ev) if (e) hipEventDestroy(e);
+    for (auto& d : ctx->rand_draw) { if (d.live) { hipFree(d.d_cand); hipFree(d.d_small); } if (d.ev) hipEventDestroy(d.ev); }
+    if (ctx->rand_result) hipHostFree(ctx->rand_result);
     for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_sorted[i]); hipEventDestroy(ctx->ev_sched_free[i]); hipEventDestroy(ctx->ev_merged[i]); }
     hipEventDestroy(ctx->ev_in);
     if (ctx->h2d) {
@@ -1769,39 +1775,87 @@ int32_t cg_vec_rep3_mul_local_dev(cg_ctx* ctx, int32_t curve, void* d_out, const
         return launch_rep3_mul_local<Fr>(ctx->stream, (Fr*)d_out, (const Fr*)d_aa, (const Fr*)d_ab, (const Fr*)d_ba, (const Fr*)d_bb, (const Fr*)d_mask, n);
     });
 }
-int32_t cg_chacha12_fr_rand_dev(cg_ctx* ctx, int32_t curve, const uint8_t* seed32, uint64_t word_pos, size_t n, void* d_out, uint64_t* word_pos_after) {
-    if (!ctx || !seed32 || (n && !d_out)) return fail(CG_ERR_ARG, "null argument");
-    if (n >= ((size_t)1 << 31) || word_pos > (~0ull >> 1)) return fail(CG_ERR_ARG, "cg_chacha12_fr_rand_dev: size or position out of range");
-    if (n == 0) { if (word_pos_after) *word_pos_after = word_pos; return 0; }
-    HIPCHK(hipSetDevice(ctx->device));
+// one attempt of n draws with `margin` surplus draws' worth of candidates: kernels + the count's download enqueued, nothing waited for
+static int rand_draw_begin(cg_ctx* ctx, int32_t curve, const uint8_t* seed32, uint64_t word_pos, size_t n, void* d_out, double margin, int* slot_out) {
+    int slot = -1;
+    for (int i = 0; i < cg_ctx::RAND_DRAWS; i++) if (!ctx->rand_draw[i].live) { slot = i; break; }
+    if (slot < 0) return fail(CG_ERR_ARG, "cg_chacha12_fr_rand_dev_begin: too many draws in flight (finish one first)");
+    if (!ctx->rand_result) HIPCHK(hipHostMalloc((void**)&ctx->rand_result, sizeof(unsigned long long) * 2 * cg_ctx::RAND_DRAWS, hipHostMallocDefault));
+    cg_ctx::RandDraw& d = ctx->rand_draw[slot];
+    if (!d.ev) HIPCHK(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
     return with_fr(curve, [&](auto tag) -> int {
         typedef decltype(tag) Fr;
         typedef typename Fr::Params P;
         StatScope ss(ctx, TAG_VEC);
         uint32_t key[8];
         for (int i = 0; i < 8; i++) key[i] = (uint32_t)seed32[4 * i] | (uint32_t)seed32[4 * i + 1] << 8 | (uint32_t)seed32[4 * i + 2] << 16 | (uint32_t)seed32[4 * i + 3] << 24;
-        // acceptance rate = modulus / 2^BITS (BN254 Fr 0.756, BLS12-381 Fr 0.906); candidates for n draws + 8 standard deviations + a floor
+        // acceptance rate = modulus / 2^BITS (BN254 Fr 0.756, BLS12-381 Fr 0.906)
         const double accept = (double)P::P[7] / (double)(1ull << (P::BITS - 224));
-        double margin = 8.0 * std::sqrt((double)n) + 64.0;
-        for (int attempt = 0; attempt < 4; attempt++, margin *= 4.0) {
-            const uint64_t n_cand = (uint64_t)(((double)n + margin) / accept) + 2;
-            const uint64_t n_pairs = n_cand / 2 + 2;
-            const uint64_t tiles = (n_pairs + 255) / 256;
-            void* d_cand = nullptr; void* d_small = nullptr;
-            if (int rc = cg_dev_alloc(ctx, n_pairs * 64, &d_cand)) return rc;
-            if (int rc = cg_dev_alloc(ctx, tiles * 4 + 16, &d_small)) { cg_dev_free(ctx, d_cand); return rc; }
-            unsigned long long* d_result = (unsigned long long*)d_small;
-            unsigned long long h_result[2] = {0, 0};
-            int rc = chacha12_fr_rand_launch(ctx->stream, key, P::P, P::BITS, word_pos, n_pairs, n, d_cand, (uint32_t*)((char*)d_small + 16), d_result, d_out);
-            hipError_t e = rc ? hipSuccess : hipMemcpyAsync(h_result, d_result, sizeof h_result, hipMemcpyDeviceToHost, ctx->stream);
-            if (!rc && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            cg_dev_free(ctx, d_cand); cg_dev_free(ctx, d_small);
-            if (rc) return rc;
-            HIPCHK(e);
-            if (h_result[0] >= n) { if (word_pos_after) *word_pos_after = word_pos + 8 * ((uint64_t)h_result[1] + 1); return 0; }
-        }
-        return fail(CG_ERR_HIP, "cg_chacha12_fr_rand_dev: too few accepted candidates");
+        const uint64_t n_cand = (uint64_t)(((double)n + margin) / accept) + 2;
+        const uint64_t n_pairs = n_cand / 2 + 2;
+        const uint64_t tiles = (n_pairs + 255) / 256;
+        d.d_cand = d.d_small = nullptr;
+        if (int rc = cg_dev_alloc(ctx, n_pairs * 64, &d.d_cand)) return rc;
+        if (int rc = cg_dev_alloc(ctx, tiles * 4 + 16, &d.d_small)) { cg_dev_free(ctx, d.d_cand); return rc; }
+        unsigned long long* h = ctx->rand_result + 2 * slot; h[0] = h[1] = 0;
+        int rc = chacha12_fr_rand_launch(ctx->stream, key, P::P, P::BITS, word_pos, n_pairs, n, d.d_cand, (uint32_t*)((char*)d.d_small + 16), (unsigned long long*)d.d_small, d_out);
+        hipError_t e = rc ? hipSuccess : hipMemcpyAsync(h, d.d_small, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+        if (!rc && e == hipSuccess) e = hipEventRecord(d.ev, ctx->stream);
+        if (rc || e != hipSuccess) { hipStreamSynchronize(ctx->stream); cg_dev_free(ctx, d.d_cand); cg_dev_free(ctx, d.d_small); if (rc) return rc; HIPCHK(e); }
+        d.live = true; d.word_pos = word_pos; d.n = n;
+        *slot_out = slot;
+        return 0;
     });
+}
+// waits for the attempt; *enough = the n-th accepted candidate was among those generated
+static int rand_draw_finish(cg_ctx* ctx, int slot, bool* enough, uint64_t* word_pos_after) {
+    cg_ctx::RandDraw& d = ctx->rand_draw[slot];
+    hipError_t e = hipEventSynchronize(d.ev);
+    cg_dev_free(ctx, d.d_cand); cg_dev_free(ctx, d.d_small);
+    d.live = false;
+    HIPCHK(e);
+    const unsigned long long* h = ctx->rand_result + 2 * slot;
+    *enough = h[0] >= d.n;
+    if (*enough && word_pos_after) *word_pos_after = d.word_pos + 8 * ((uint64_t)h[1] + 1);
+    return 0;
+}
+static int rand_draw_args(cg_ctx* ctx, const uint8_t* seed32, uint64_t word_pos, size_t n, void* d_out, const char* who) {
+    if (!ctx || !seed32 || (n && !d_out)) return fail(CG_ERR_ARG, "null argument");
+    if (n >= ((size_t)1 << 31) || word_pos > (~0ull >> 1)) return fail(CG_ERR_ARG, std::string(who) + ": size or position out of range");
+    return 0;
+}
+int32_t cg_chacha12_fr_rand_dev(cg_ctx* ctx, int32_t curve, const uint8_t* seed32, uint64_t word_pos, size_t n, void* d_out, uint64_t* word_pos_after) {
+    if (int rc = rand_draw_args(ctx, seed32, word_pos, n, d_out, "cg_chacha12_fr_rand_dev")) return rc;
+    if (n == 0) { if (word_pos_after) *word_pos_after = word_pos; return 0; }
+    HIPCHK(hipSetDevice(ctx->device));
+    double margin = 8.0 * std::sqrt((double)n) + 64.0;           // candidates for n draws + 8 standard deviations + a floor; four times as many after a shortfall
+    for (int attempt = 0; attempt < 4; attempt++, margin *= 4.0) {
+        int slot = -1; bool enough = false;
+        if (int rc = rand_draw_begin(ctx, curve, seed32, word_pos, n, d_out, margin, &slot)) return rc;
+        if (int rc = rand_draw_finish(ctx, slot, &enough, word_pos_after)) return rc;
+        if (enough) return 0;
+    }
+    return fail(CG_ERR_HIP, "cg_chacha12_fr_rand_dev: too few accepted candidates");
+}
+int32_t cg_chacha12_fr_rand_dev_begin(cg_ctx* ctx, int32_t curve, const uint8_t* seed32, uint64_t word_pos, size_t n, void* d_out, int32_t* ticket) {
+    if (!ticket) return fail(CG_ERR_ARG, "null argument");
+    if (int rc = rand_draw_args(ctx, seed32, word_pos, n, d_out, "cg_chacha12_fr_rand_dev_begin")) return rc;
+    if (n == 0) return fail(CG_ERR_ARG, "cg_chacha12_fr_rand_dev_begin: nothing to draw");
+    HIPCHK(hipSetDevice(ctx->device));
+    int slot = -1;
+    // no second attempt is possible once the consumers of d_out are enqueued: 12 standard deviations of surplus (a shortfall every ~10^32 calls)
+    if (int rc = rand_draw_begin(ctx, curve, seed32, word_pos, n, d_out, 12.0 * std::sqrt((double)n) + 64.0, &slot)) return rc;
+    *ticket = slot;
+    return 0;
+}
+int32_t cg_chacha12_fr_rand_dev_finish(cg_ctx* ctx, int32_t ticket, uint64_t* word_pos_after) {
+    if (!ctx) return fail(CG_ERR_ARG, "null argument");
+    if (ticket < 0 || ticket >= cg_ctx::RAND_DRAWS || !ctx->rand_draw[ticket].live) return fail(CG_ERR_ARG, "cg_chacha12_fr_rand_dev_finish: no such draw in flight");
+    HIPCHK(hipSetDevice(ctx->device));
+    bool enough = false;
+    if (int rc = rand_draw_finish(ctx, ticket, &enough, word_pos_after)) return rc;
+    if (!enough) return fail(CG_ERR_HIP, "cg_chacha12_fr_rand_dev_finish: too few accepted candidates (d_out is incomplete: draw again with cg_chacha12_fr_rand_dev)");
+    return 0;
 }
 int32_t cg_vec_check_canonical_dev(cg_ctx* ctx, int32_t curve, const void* d_vec, size_t n, void* d_count) {
     if (!ctx || !d_vec || !d_count) return fail(CG_ERR_ARG, "null argument");

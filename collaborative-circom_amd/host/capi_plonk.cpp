@@ -211,6 +211,7 @@ int32_t cgh_plonk_prove_rep3_party_ex(int32_t device, int32_t curve, const char*
             try { plonk_run(driver, z, tau, pub, wit, b, upto, PlonkOut{out_commits, out_challenges, out_evals, nullptr, nullptr}); }
             catch (...) { driver.free_vec(wit); throw; }
             driver.free_vec(wit);
+            rnd.settle();
         }
         cg_bases_release(tau);
         cg_ctx_destroy(ctx);

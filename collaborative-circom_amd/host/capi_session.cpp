@@ -180,10 +180,10 @@ int32_t cgh_session_prove_rep3_party_ex(void* h, const uint64_t* pub_in, const u
         const size_t n_aux = z.n_vars - z.n_public - 1;
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
         CallbackNetwork net(*net_cb);
-        CallbackRand rnd(*rnd_cb);
-        rnd.describe_streams(streams_cb);
         static const bool no_prio = getenv("CGH_NO_CHAIN_PRIORITY") != nullptr;          // tuning knob
         Borrowed ctx(s, true, 0, s->second_context && !no_prio), second(s, s->second_context);
+        CallbackRand rnd(*rnd_cb);                                                       // (after the contexts: draws in flight are finished on a context that still exists)
+        rnd.describe_streams(streams_cb);
         ProofWorkers workers(s);
         ProofZKey pz(s, ctx.c, pub);
         const auto t0 = std::chrono::steady_clock::now();
@@ -191,19 +191,18 @@ int32_t cgh_session_prove_rep3_party_ex(void* h, const uint64_t* pub_in, const u
             HipDriver driver(ctx.c, z.curve, Mode::Rep3, &net);
             driver.aux = second.c; driver.owns_aux = false; driver.md = workers.get();
             driver.rsrc = &rnd; driver.additive_h = s->additive_h;
-            // One device: the shares start crossing PCIe, and while they do (nothing else can run yet) the masks of the witness map's two
-            // mul_vec calls are drawn — the first draws of the proof in the reference's order too (rep3.rs:656-660 precede :595-598) —
-            // on this context's still idle stream; only then is the stream made to wait for the shares.
-            // (Shares that go up synchronously — short vectors, pageable memory — leave no such window: the prover then draws after it has
-            // enqueued the witness-independent MSMs, as before.)
-            const bool early_masks = workers.get() == nullptr && n_aux >= driver.XCHG_ASYNC_MIN && cg_host_is_pinned(wit_a) && cg_host_is_pinned(wit_b);
-            VecGuard wit(driver, driver.upload_vec((const Fr*)wit_a, (const Fr*)wit_b, n_aux, !early_masks));
-            if (early_masks) {
-                driver.prefetch_masks(2, groth16_domain(z.curve, z.pow, z.num_constraints, pub.size()).m);
-                driver.fence_uploads(wit.v);
-            }
+            // One device: the masks of the witness map's two mul_vec calls are the first thing enqueued — the first draws of the proof in the
+            // reference's order too (rep3.rs:656-660 precede :595-598).  Device draws are not waited for (CallbackRand::settle), so they cost
+            // the host a few launches; shares that go up asynchronously are still crossing PCIe while the draws run on the idle chip, and
+            // only then is the stream made to wait for them.
+            const bool early_masks = workers.get() == nullptr;
+            const bool unfenced = early_masks && n_aux >= driver.XCHG_ASYNC_MIN && cg_host_is_pinned(wit_a) && cg_host_is_pinned(wit_b);
+            VecGuard wit(driver, driver.upload_vec((const Fr*)wit_a, (const Fr*)wit_b, n_aux, !unfenced));
+            if (early_masks) driver.prefetch_masks(2, groth16_domain(z.curve, z.pow, z.num_constraints, pub.size()).m);
+            if (unfenced) driver.fence_uploads(wit.v);
             CoGroth16 prover(driver);
             Proof p = prover.prove(pz.dz, pub, wit.v, nullptr, nullptr);                 // groth16.rs:113-139
+            rnd.settle();                                                                // the caller's generators stand behind the last draw when the call returns
             if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             store_proof(p, (uint8_t*)out_proof);
         }

@@ -128,6 +128,9 @@ struct Rep3RandSource {
     virtual void masking_ec_element(int group, uint8_t* out_jacobian) = 0;
     // optional: the n masks drawn ON THE DEVICE into d_out (d_tmp: n elements of scratch), both generators advanced; false = not offered
     virtual bool masks_on_device(cg_ctx*, int /*curve*/, size_t /*n*/, void* /*d_out*/, void* /*d_tmp*/) { return false; }
+    // device draws may still be in flight when masks_on_device returns: settle() waits for them and moves the caller's generators; the other
+    // draws settle first by themselves, the owner settles once more when the proof is done
+    virtual void settle() {}
 };
 struct CallbackRand : Rep3RandSource {
     cgh_rep3_rand cb;
@@ -136,13 +139,14 @@ struct CallbackRand : Rep3RandSource {
     }
     static void check(int32_t rc, const char* what) { if (rc) throw std::runtime_error(std::string("randomness source: ") + what + " failed with code " + std::to_string(rc)); }
     const Fr* masking_field_elements(size_t n, Fr* buf) override {
+        settle();
         const uint64_t* out = nullptr;
         check(cb.masking_field_elements(cb.user, n, (uint64_t*)buf, &out), "masking_field_elements");
         if (!out) throw std::runtime_error("randomness source: masking_field_elements returned no data");
         return (const Fr*)out;
     }
-    void random_fes(Fr& a, Fr& b) override { check(cb.random_fes(cb.user, a.v, b.v), "random_fes"); }
-    void masking_ec_element(int group, uint8_t* out) override { check(cb.masking_ec_element(cb.user, group, (uint64_t*)out), "masking_ec_element"); }
+    void random_fes(Fr& a, Fr& b) override { settle(); check(cb.random_fes(cb.user, a.v, b.v), "random_fes"); }
+    void masking_ec_element(int group, uint8_t* out) override { settle(); check(cb.masking_ec_element(cb.user, group, (uint64_t*)out), "masking_ec_element"); }
     // cgh_rep3_chacha: rng1 / rng2 are ChaCha12 streams the caller can position — the backend draws F::rand(rng1) - F::rand(rng2) itself
     cgh_rep3_chacha streams{}; bool has_streams = false;
     void describe_streams(const cgh_rep3_chacha* st) {
@@ -150,15 +154,32 @@ struct CallbackRand : Rep3RandSource {
         if (!st->get_state || !st->set_word_pos) throw std::runtime_error("cgh_rep3_chacha: both callbacks are required");
         streams = *st; has_streams = true;
     }
+    // The two draws are enqueued and NOT waited for: the generators' positions are asked for (settle) before the next draw of any kind.
+    struct InFlight { cg_ctx* ctx = nullptr; int32_t t1 = -1, t2 = -1; } inflight;
+    void settle() override {
+        if (!inflight.ctx) return;
+        cg_ctx* c = inflight.ctx; inflight.ctx = nullptr;
+        uint64_t a1 = 0, a2 = 0;
+        const int32_t r1 = cg_chacha12_fr_rand_dev_finish(c, inflight.t1, &a1);
+        const std::string m1 = r1 ? cg_last_error() : "";
+        const int32_t r2 = cg_chacha12_fr_rand_dev_finish(c, inflight.t2, &a2);
+        if (r1 || r2) throw std::runtime_error(std::string("masks on the device: ") + (r1 ? m1 : std::string(cg_last_error())));
+        check(streams.set_word_pos(streams.user, a1, a2), "set_word_pos");
+    }
+    ~CallbackRand() { if (inflight.ctx) { cg_chacha12_fr_rand_dev_finish(inflight.ctx, inflight.t1, nullptr); cg_chacha12_fr_rand_dev_finish(inflight.ctx, inflight.t2, nullptr); } }
     bool masks_on_device(cg_ctx* ctx, int curve, size_t n, void* d_out, void* d_tmp) override {
         if (!has_streams) return false;
-        uint8_t s1[32], s2[32]; uint64_t p1 = 0, p2 = 0, a1 = 0, a2 = 0;
+        settle();
+        uint8_t s1[32], s2[32]; uint64_t p1 = 0, p2 = 0;
         check(streams.get_state(streams.user, s1, &p1, s2, &p2), "get_state");
-        int32_t rc = cg_chacha12_fr_rand_dev(ctx, curve, s1, p1, n, d_out, &a1);
-        if (!rc) rc = cg_chacha12_fr_rand_dev(ctx, curve, s2, p2, n, d_tmp, &a2);
+        int32_t t1 = -1, t2 = -1;
+        int32_t rc = cg_chacha12_fr_rand_dev_begin(ctx, curve, s1, p1, n, d_out, &t1);
         if (rc == CG_ERR_OOM) return false;                            // no room for the candidates: the generators have not moved, the host callback draws instead
-        if (rc || cg_vec_sub_dev(ctx, curve, d_out, d_out, d_tmp, n)) throw std::runtime_error(std::string("masks on the device: ") + cg_last_error());
-        check(streams.set_word_pos(streams.user, a1, a2), "set_word_pos");
+        if (!rc) { rc = cg_chacha12_fr_rand_dev_begin(ctx, curve, s2, p2, n, d_tmp, &t2); if (rc) cg_chacha12_fr_rand_dev_finish(ctx, t1, nullptr); }
+        if (rc == CG_ERR_OOM) return false;
+        if (rc) throw std::runtime_error(std::string("masks on the device: ") + cg_last_error());
+        inflight.ctx = ctx; inflight.t1 = t1; inflight.t2 = t2;
+        if (cg_vec_sub_dev(ctx, curve, d_out, d_out, d_tmp, n)) throw std::runtime_error(std::string("masks on the device: ") + cg_last_error());
         return true;
     }
 };

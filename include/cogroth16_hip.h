@@ -228,6 +228,13 @@ int32_t cg_vec_rep3_mul_local_dev(cg_ctx* ctx, int32_t curve, void* d_out, const
  * d_out receives the n elements in draw order; *word_pos_after is what the caller hands to ChaCha12Rng::set_word_pos so that its
  * next draw continues behind the last one taken here.  Synchronises the context's stream (the position is known only after the draws). */
 int32_t cg_chacha12_fr_rand_dev(cg_ctx* ctx, int32_t curve, const uint8_t* seed32, uint64_t word_pos, size_t n, void* d_out, uint64_t* word_pos_after);
+/* The same draws without the wait: _begin enqueues them on the context's stream (what follows on that stream sees d_out filled) and returns
+ * a ticket (at most 8 in flight per context); _finish waits for the draw alone and reports the position.  The party's two mask vectors are
+ * drawn this way before anything else of a proof is enqueued: the host goes on enqueuing while the generators' positions are still unknown
+ * and asks for them before its next HOST draw (rep3.rs:595-598 follow :656-660 in the reference's order too).  The candidates are generated
+ * with 12 standard deviations of surplus; a shortfall (never observed, ~1e-32 per call) makes _finish fail and leaves d_out incomplete. */
+int32_t cg_chacha12_fr_rand_dev_begin(cg_ctx* ctx, int32_t curve, const uint8_t* seed32, uint64_t word_pos, size_t n, void* d_out, int32_t* ticket);
+int32_t cg_chacha12_fr_rand_dev_finish(cg_ctx* ctx, int32_t ticket, uint64_t* word_pos_after);
 /* distribute_powers_and_mul_by_const (traits.rs:177): v[i] *= c * g^i */
 int32_t cg_vec_distribute_powers_dev(cg_ctx* ctx, int32_t curve, void* d_v, size_t n, const void* h_g, const void* h_c);
 /* Single-component pointwise helpers (plain / Shamir shares, co-plonk round 2):

@@ -11,7 +11,7 @@ for f in glob.glob(root + "/**/*memory_copy_trace.csv", recursive=True):
     for r in rows:
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "C", r.get("Direction", "") + " " + r.get("Bytes", r.get("Size", "?")), ""))
 ev.sort()
-end = ev[-1][1]; t0 = end - int(125e6)
+end = ev[-1][1]; t0 = end - int((float(sys.argv[4]) if len(sys.argv) > 4 else 125.0) * 1e6)   # origin: that many ms before the last event
 for s, e, k, n, q in ev:
     t = (s - t0) / 1e6
     if lo <= t <= hi: print(f"{t:8.2f} +{(e - s) / 1e6:7.3f} {k} {n} q={q}")

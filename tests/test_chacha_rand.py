@@ -140,6 +140,41 @@ def test_device_draws_equal_the_oracle(curve):
 
 
 @pytest.mark.gpu
+def test_device_draws_without_the_wait():
+    """cg_chacha12_fr_rand_dev_begin / _finish: several draws in flight on one context, finished in another order; the values and positions
+    are those of the waiting call (and of the oracle); tickets are refused once used, and a ninth draw in flight is refused"""
+    ensure_built()
+    ctx = cg.Context()
+    rng = np.random.default_rng(77)
+    try:
+        cases = [(BN254, 70001, 64), (BLS12_381, 12345, 2**36 + 5), (BN254, 1, 0), (BN254, 1 << 16, 7)]
+        seeds = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in cases]
+        inflight = [ctx.chacha12_fr_rand_begin(c, s, pos, n) for (c, n, pos), s in zip(cases, seeds)]
+        # a consumer enqueued behind the draw on the same stream sees the values: add the drawn vector to itself before anything is waited for
+        dbl = ctx.alloc(cases[0][1] * 32)
+        cg._chk(cg.load().cg_vec_add_dev(ctx.h, BN254, cg.C.c_void_p(dbl.ptr), cg.C.c_void_p(inflight[0][0].ptr), cg.C.c_void_p(inflight[0][0].ptr), cg.C.c_size_t(cases[0][1])))
+        for i in (2, 0, 3, 1):
+            (c, n, pos), s = cases[i], seeds[i]
+            after = ctx.chacha12_fr_rand_finish(inflight[i][1])
+            want, wa = orc.chacha12_fr_rand(c, s, pos, n)
+            np.testing.assert_array_equal(inflight[i][0].download((n, 4)), want); assert after == wa, i
+        want0, _ = orc.chacha12_fr_rand(BN254, seeds[0], cases[0][2], cases[0][1])
+        np.testing.assert_array_equal(dbl.download((cases[0][1], 4)), orc.field_op(BN254, FR, "add", want0, want0))
+        with pytest.raises(cg.BackendError):
+            ctx.chacha12_fr_rand_finish(inflight[0][1])                      # already finished
+        with pytest.raises(cg.BackendError):
+            ctx.chacha12_fr_rand_finish(99)
+        for b, _ in inflight: b.free()
+        dbl.free()
+        many = [ctx.chacha12_fr_rand_begin(BN254, seeds[0], 0, 100) for _ in range(8)]
+        with pytest.raises(cg.BackendError):
+            ctx.chacha12_fr_rand_begin(BN254, seeds[0], 0, 100)               # eight in flight is the limit
+        for b, tk in many: ctx.chacha12_fr_rand_finish(tk); b.free()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_device_draws_at_full_size():
     """2^22 draws (one masking vector of the headline circuit) against the host library's single-thread draws"""
     import time
