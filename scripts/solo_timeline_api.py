@@ -16,7 +16,7 @@ for f in glob.glob(root + "/**/*hip_api_trace.csv", recursive=True):
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         if (e - s) / 1e6 >= min_api or r["Function"] in ("hipMemcpyAsync",): ev.append((s, e, "A", r["Function"], "t" + r.get("Thread_Id", "")))
 ev.sort()
-t0 = kend - int(125e6)
+t0 = kend - int((float(sys.argv[5]) if len(sys.argv) > 5 else 125.0) * 1e6)
 for s, e, k, n, q in ev:
     t = (s - t0) / 1e6
     if lo <= t <= hi: print(f"{t:8.2f} +{(e - s) / 1e6:7.3f} {k} {n} {q}")
