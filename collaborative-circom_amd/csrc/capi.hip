@@ -1136,7 +1136,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     hipStreamSynchronize(ctx->sortst);
     for (int i = 0; i < cg_ctx::ACC_SLOTS_MAX; i++) { hipEventDestroy(ctx->ev_acc[i]); hipEventDestroy(ctx->ev_red[i]); }
     for (hipEvent_t e : ctx->mark_ev) if (e) hipEventDestroy(e);
-    for (auto& d : ctx->rand_draw) { if (d.live) { hipFree(d.d_cand); hipFree(d.d_small); } if (d.ev) hipEventDestroy(d.ev); }
+    for (auto& d : ctx->rand_draw) { if (d.live) { cg_dev_free(ctx, d.d_cand); cg_dev_free(ctx, d.d_small); d.live = false; } if (d.ev) hipEventDestroy(d.ev); }   // (draws begun and never finished)
     if (ctx->rand_result) hipHostFree(ctx->rand_result);
     for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_sorted[i]); hipEventDestroy(ctx->ev_sched_free[i]); hipEventDestroy(ctx->ev_merged[i]); }
     hipEventDestroy(ctx->ev_in);

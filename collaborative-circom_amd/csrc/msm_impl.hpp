@@ -12,12 +12,13 @@ namespace cg {
 template <class B> constexpr int bitsum_items() { return BITSUM_ITEMS; }   // 2 for G2 measured slower (four times the LDS trees): 2^18 step 8.5 -> 10.1 ms
 template <class B> uint32_t bitsum_groups(uint32_t nb) { return std::max<uint32_t>(1, (nb / 2 + 256 * bitsum_items<B>() - 1) / (256 * bitsum_items<B>())); }
 
-// lanes of the accumulation kernel resident at once on a 256-CU gfx950: G1 (32-byte coordinates, 167 VGPRs) runs 3 workgroups of 256
-// per CU in lock step; the G2 workgroups (2 waves per SIMD, one of them favoured by the arbiter) do not, so no rounding there (0)
-template <class F> constexpr size_t acc_resident_lanes() { return sizeof(F) == 32 ? (size_t)256 * 3 * 256 : 0; }
 // coordinates in the base field (G1: VGPR accumulator) or its quadratic extension (G2: LDS accumulator)
 template <class F> struct IsFp2 { static constexpr bool value = false; };
 template <class B> struct IsFp2<Fp2<B>> { static constexpr bool value = true; };
+// lanes of the accumulation kernel resident at once on a 256-CU gfx950: G1 runs its workgroups of 256 in lock step — 3 per CU for BN254
+// (32-byte coordinates, 167 VGPRs), 2 per CU for BLS12-381 (48-byte coordinates on 14 limbs, 233 VGPRs); the G2 workgroups (2 waves per
+// SIMD, one of them favoured by the arbiter) do not, so no rounding there (0)
+template <class F> constexpr size_t acc_resident_lanes() { return IsFp2<F>::value ? 0 : (size_t)256 * (sizeof(F) == 32 ? 3 : 2) * 256; }
 
 template <class F>
 size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared, uint32_t chunk_request) {

@@ -41,7 +41,9 @@ struct cgh_session {
         { std::lock_guard<std::mutex> l(mu); serial[c] = next_serial++; }
         return c;
     }
-    void give(cg_ctx* c, int slot = 0, bool chain = false) { if (!c) return; cg_ctx_sync(c); std::lock_guard<std::mutex> l(mu); (chain ? idle_chain : idle)[slot].push_back(c); }
+    // (a context comes back from a proof that read all its results: what its streams still hold are the release marks of freed blocks, and
+    // the next proof is ordered behind them stream by stream — no synchronisation here; a failed proof's context is destroyed, not returned)
+    void give(cg_ctx* c, int slot = 0, bool chain = false) { if (!c) return; std::lock_guard<std::mutex> l(mu); (chain ? idle_chain : idle)[slot].push_back(c); }
     void forget(cg_ctx* c) { std::lock_guard<std::mutex> l(mu); serial.erase(c); }
 };
 namespace {

@@ -445,7 +445,16 @@ public:
         if (r.busy[r.last] >= 0) { CG(cg_copy_wait(ctx, r.busy[r.last])); r.busy[r.last] = -1; }
         return r.base + (size_t)r.last * r.chunk * 32;
     }
-    void release_rings() { for (PinRing* r : {&ring_out, &ring_in}) if (r->base) { cg_ctx_sync(ctx); cg_host_free(r->base); r->base = nullptr; r->chunk = 0; } }
+    // (every copy that touches a slot holds that slot's ticket: waiting for the tickets still marked busy is enough, a whole-context
+    // synchronisation — five streams — per ring cost a finished proof 0.1 ms of tear-down)
+    void release_rings() {
+        for (PinRing* r : {&ring_out, &ring_in}) if (r->base) {
+            bool waited = true;
+            for (int32_t& b : r->busy) if (b >= 0) { if (cg_copy_wait(ctx, b)) waited = false; b = -1; }
+            if (!waited) cg_ctx_sync(ctx);
+            cg_host_free(r->base); r->base = nullptr; r->chunk = 0;
+        }
+    }
     std::vector<void*> deferred;                                                        // device buffers freed at the next quiet point
     void defer_free(void* p) { if (p) deferred.push_back(p); }
     void defer_vec(ShareVec& v) { for (int j = 0; j < 2; j++) { defer_free(v.c[j]); v.c[j] = nullptr; } }
