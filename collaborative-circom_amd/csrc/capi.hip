@@ -1061,26 +1061,44 @@ const char* cg_version(void) { return "cogroth16-hip 0.1 (gfx950)"; }
 // the test-suite) instead of being destroyed.  A parked stream is idle: cg_ctx_destroy synchronises it first.
 namespace {
 std::mutex g_stream_pool_mu;
-std::map<std::pair<int, int>, std::vector<hipStream_t>> g_stream_pool;      // (device, priority class) -> idle streams
-// cls: +1 high, 0 normal, -1 low.  The runtime keeps one set of hardware queues per priority and hands a new stream the least used
-// queue of its set: streams of one class that are created one after the other land on different queues (while the set lasts).
+// cls: +1 high, 0 normal, -1 low.  The runtime keeps one set of (four) hardware queues per priority and hands a NEW stream the least used
+// queue of its set, so the k-th stream this library creates in a class sits on queue k mod 4 of that class (other users of the process
+// shift the numbering, not the spacing).  A queue serves its streams' packets in order — two busy streams on one queue wait for each
+// other — so which parked stream a new context gets matters: last-in-first-out handed a process's second session pairs of streams on
+// the same queue (a 2^22 resident step made after a session had come and gone: 70.6 ms against 66.3).  The pool therefore remembers each
+// stream's slot (creation number mod 4) and hands out the idle stream whose slot has the fewest streams checked out.
+constexpr int HWQ = 4;
+struct StreamClassPool { std::vector<std::pair<hipStream_t, int>> idle; int created = 0; int out[HWQ] = {0, 0, 0, 0}; };
+std::map<std::pair<int, int>, StreamClassPool> g_stream_pool;      // (device, priority class)
+std::map<hipStream_t, int> g_stream_slot;                         // every stream made here -> its slot
 int pooled_stream(int device, int cls, hipStream_t* out) {
-    {
-        std::lock_guard<std::mutex> l(g_stream_pool_mu);
-        auto& v = g_stream_pool[{device, cls}];
-        if (!v.empty()) { *out = v.back(); v.pop_back(); return 0; }
+    std::lock_guard<std::mutex> l(g_stream_pool_mu);
+    StreamClassPool& p = g_stream_pool[{device, cls}];
+    if (!p.idle.empty()) {
+        size_t best = 0;
+        for (size_t i = 1; i < p.idle.size(); i++) if (p.out[p.idle[i].second] < p.out[p.idle[best].second]) best = i;   // (ties: the longest parked)
+        *out = p.idle[best].first; p.out[p.idle[best].second]++;
+        p.idle.erase(p.idle.begin() + best);
+        return 0;
     }
-    if (cls == 0) { HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking)); return 0; }
-    int prio_least = 0, prio_greatest = 0;                                   // numerically: least >= greatest
-    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, cls > 0 ? prio_greatest : prio_least));
+    if (cls == 0) HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    else {
+        int prio_least = 0, prio_greatest = 0;                                   // numerically: least >= greatest
+        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, cls > 0 ? prio_greatest : prio_least));
+    }
+    const int slot = p.created++ % HWQ;
+    g_stream_slot[*out] = slot; p.out[slot]++;
     return 0;
 }
 void park_stream(int device, int cls, hipStream_t st) {
     if (!st) return;
     std::lock_guard<std::mutex> l(g_stream_pool_mu);
-    auto& v = g_stream_pool[{device, cls}];
-    if (v.size() < 32) v.push_back(st); else hipStreamDestroy(st);
+    StreamClassPool& p = g_stream_pool[{device, cls}];
+    auto it = g_stream_slot.find(st);
+    if (it == g_stream_slot.end()) { hipStreamDestroy(st); return; }             // not one of ours
+    if (p.out[it->second] > 0) p.out[it->second]--;
+    if (p.idle.size() < 32) p.idle.push_back({st, it->second}); else { g_stream_slot.erase(it); hipStreamDestroy(st); }
 }
 int make_copy_streams(cg_ctx* c) {
     { int rc = pooled_stream(c->device, c->prio_copy, &c->h2d); if (rc) return rc; }
