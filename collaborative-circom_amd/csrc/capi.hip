@@ -1071,25 +1071,44 @@ constexpr int HWQ = 4;
 struct StreamClassPool { std::vector<std::pair<hipStream_t, int>> idle; int created = 0; int out[HWQ] = {0, 0, 0, 0}; };
 std::map<std::pair<int, int>, StreamClassPool> g_stream_pool;      // (device, priority class)
 std::map<hipStream_t, int> g_stream_slot;                         // every stream made here -> its slot
+// cg_stream_group_begin / _end (per thread): the contexts made in between belong to ONE party — within each priority class their streams
+// get slots of their own as long as the class has any left (the streams they then share a queue with belong to somebody else's, mostly
+// idle, contexts): a chain context's sort stream must not sit behind the bulk context's reduction batch and vice versa.
+thread_local int g_group_depth = 0;
+thread_local uint8_t g_group_used[3] = {0, 0, 0};                   // [class + 1]: slots taken by the group so far
+int new_stream(int cls, hipStream_t* out) {
+    if (cls == 0) { HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking)); return 0; }
+    int prio_least = 0, prio_greatest = 0;                           // numerically: least >= greatest
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, cls > 0 ? prio_greatest : prio_least));
+    return 0;
+}
 int pooled_stream(int device, int cls, hipStream_t* out) {
     std::lock_guard<std::mutex> l(g_stream_pool_mu);
     StreamClassPool& p = g_stream_pool[{device, cls}];
-    if (!p.idle.empty()) {
-        size_t best = 0;
-        for (size_t i = 1; i < p.idle.size(); i++) if (p.out[p.idle[i].second] < p.out[p.idle[best].second]) best = i;   // (ties: the longest parked)
-        *out = p.idle[best].first; p.out[p.idle[best].second]++;
-        p.idle.erase(p.idle.begin() + best);
-        return 0;
+    const bool grp = g_group_depth > 0 && cls >= -1 && cls <= 1;
+    uint8_t none = 0; uint8_t& used = grp ? g_group_used[cls + 1] : none;
+    const bool slots_left = grp && used != (1u << HWQ) - 1;
+    auto taken = [&](int slot) { return slots_left && ((used >> slot) & 1u); };
+    for (int tries = 0; tries <= HWQ; tries++) {
+        long best = -1;
+        for (size_t i = 0; i < p.idle.size(); i++) {
+            if (taken(p.idle[i].second)) continue;
+            if (best < 0 || p.out[p.idle[i].second] < p.out[p.idle[best].second]) best = (long)i;                     // (ties: the longest parked)
+        }
+        if (best >= 0) {
+            const int slot = p.idle[best].second;
+            *out = p.idle[best].first; p.out[slot]++; if (grp) used |= (uint8_t)(1u << slot);
+            if (getenv("CG_DEBUG_STREAMS")) fprintf(stderr, "stream: class %d slot %d (out %d %d %d %d, idle %zu%s)\n", cls, slot, p.out[0], p.out[1], p.out[2], p.out[3], p.idle.size() - 1, grp ? ", group" : "");
+            p.idle.erase(p.idle.begin() + best);
+            return 0;
+        }
+        hipStream_t st = nullptr;                                    // nothing suitable parked: a new stream joins the idle list and the choice is made again
+        if (int rc = new_stream(cls, &st)) return rc;
+        const int slot = p.created++ % HWQ;
+        g_stream_slot[st] = slot; p.idle.push_back({st, slot});
     }
-    if (cls == 0) HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
-    else {
-        int prio_least = 0, prio_greatest = 0;                                   // numerically: least >= greatest
-        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, cls > 0 ? prio_greatest : prio_least));
-    }
-    const int slot = p.created++ % HWQ;
-    g_stream_slot[*out] = slot; p.out[slot]++;
-    return 0;
+    return fail(CG_ERR_HIP, "internal: stream pool");
 }
 void park_stream(int device, int cls, hipStream_t st) {
     if (!st) return;
@@ -1108,6 +1127,8 @@ int make_copy_streams(cg_ctx* c) {
 }
 }  // namespace
 
+int32_t cg_stream_group_begin(void) { if (g_group_depth++ == 0) for (uint8_t& u : g_group_used) u = 0; return 0; }
+int32_t cg_stream_group_end(void) { if (g_group_depth > 0) g_group_depth--; return 0; }
 int32_t cg_ctx_create(int32_t device, cg_ctx** out) { return cg_ctx_create_ex(device, 0, out); }
 // flags bit 0 ("chain"): for the context that carries a dependency chain (witness map with its party-to-party exchanges) while another
 // context of the same party keeps the chip full with independent bucket accumulations — main stream and copy streams (created here,
@@ -1140,6 +1161,10 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     // jump the backlog of accumulate workgroups (one priority class above the main stream's, except next to a chain)
     { int rc = pooled_stream(device, c->prio_side, &c->aux); if (rc) return rc; }
     { int rc = pooled_stream(device, c->prio_side, &c->sortst); if (rc) return rc; }
+    // the work-free stream behind released blocks (cg_dev_free) is made here, not at the first release: inside a stream group it then gets a
+    // queue apart from a bulk context's low-priority main stream (its packets are waits for OTHER streams' progress: nothing may queue behind them)
+    { int rc = pooled_stream(device, -1, &c->joinst); if (rc) return rc; }
+    for (hipEvent_t& e : c->park_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_sched_free[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_merged[i], hipEventDisableTiming)); }
     for (int i = 0; i < cg_ctx::ACC_SLOTS_MAX; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming)); }
@@ -1210,6 +1235,7 @@ struct DevCache {
     std::multimap<size_t, ParkedBlock> parked; size_t parked_bytes = 0;
     std::map<void*, size_t> live;                        // blocks handed out by cg_dev_alloc -> rounded size
     std::vector<hipEvent_t> spare;
+    unsigned long long n_hit = 0, n_pending = 0, n_fresh = 0, n_sync_free = 0;   // CG_DEBUG_ALLOC: reuse / same size parked but still busy / nothing of that size / releases that took the synchronising path
 };
 DevCache& dev_cache(int device) {
     static std::mutex mu; static std::map<int, DevCache*> m;
@@ -1242,15 +1268,29 @@ int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr) {
     DevCache& dc = dev_cache(ctx->device);
     std::lock_guard<std::mutex> l(dc.mu);
     auto range = dc.parked.equal_range(rb);
+    bool pending = false;
     for (auto it = range.first; it != range.second; ++it) {
-        if (hipEventQuery(it->second.ev) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (hipEventQuery(it->second.ev) != hipSuccess) { (void)hipGetLastError(); pending = true; continue; }
         *d_ptr = it->second.p; dc.spare.push_back(it->second.ev); dc.parked.erase(it); dc.parked_bytes -= rb; dc.live[*d_ptr] = rb;
+        dc.n_hit++;
         return 0;
     }
+    if (pending) dc.n_pending++; else dc.n_fresh++;
     hipError_t e = hipMalloc(d_ptr, rb);
     if (e == hipErrorOutOfMemory && !dc.parked.empty()) { (void)hipGetLastError(); dev_cache_flush(dc); e = hipMalloc(d_ptr, rb); }
     HIPCHK(e);
     dc.live[*d_ptr] = rb;
+    return 0;
+}
+int32_t cg_dev_cache_trim(int32_t device, size_t* bytes) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return fail(CG_ERR_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    DevCache& dc = dev_cache(device);
+    std::lock_guard<std::mutex> l(dc.mu);
+    if (bytes) *bytes = dc.parked_bytes;
+    if (getenv("CG_DEBUG_ALLOC")) { fprintf(stderr, "dev cache: %llu reused, %llu found their size parked but busy, %llu found nothing parked, %llu synchronising releases; %zu MB parked\n", dc.n_hit, dc.n_pending, dc.n_fresh, dc.n_sync_free, dc.parked_bytes >> 20); dc.n_hit = dc.n_pending = dc.n_fresh = dc.n_sync_free = 0; }
+    dev_cache_flush(dc);
     return 0;
 }
 int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr) {
@@ -1263,6 +1303,7 @@ int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr) {
     const size_t rb = it == dc.live.end() ? 0 : it->second;
     if (it != dc.live.end()) dc.live.erase(it);
     if (!rb || dc.parked_bytes + rb > dev_cache_cap()) {  // not one of ours, or no room to park it: the synchronising release
+        dc.n_sync_free++;
         l.unlock();
         HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipFree(d_ptr));

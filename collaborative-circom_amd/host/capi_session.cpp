@@ -47,6 +47,8 @@ struct cgh_session {
     void forget(cg_ctx* c) { std::lock_guard<std::mutex> l(mu); serial.erase(c); }
 };
 namespace {
+// the contexts made while one of these lives are one party's: their streams are spread over hardware queues of their own (cg_stream_group_begin)
+struct StreamGroup { StreamGroup() { cg_stream_group_begin(); } ~StreamGroup() { cg_stream_group_end(); } StreamGroup(const StreamGroup&) = delete; StreamGroup& operator=(const StreamGroup&) = delete; };
 // a context borrowed from the session: returned to the pool on success, destroyed when the proof failed (its streams may hold
 // half-finished work)
 struct Borrowed {
@@ -86,7 +88,16 @@ void session_destroy(cgh_session* s) {
     if (!s) return;
     for (auto& pool : s->idle) for (cg_ctx* c : pool) cg_ctx_destroy(c);
     for (auto& pool : s->idle_chain) for (cg_ctx* c : pool) cg_ctx_destroy(c);
-    for (size_t d = 0; d < s->ctx0.size(); d++) if (s->ctx0[d]) { cgh::release_zkey(s->ctx0[d], s->dzs[d]); cg_ctx_destroy(s->ctx0[d]); }
+    // the tables and matrices of device d are released through the context they were registered with (a session that failed while it
+    // was being opened still has it) or, once the session is open, through one made for the purpose (the registration context's streams
+    // went back to the pool at the end of cgh_session_open, see there)
+    for (size_t d = 0; d < s->dzs.size(); d++) {
+        cg_ctx* c = d < s->ctx0.size() ? s->ctx0[d] : nullptr;
+        if (!c && cg_ctx_create(s->devices[d], &c)) continue;
+        cgh::release_zkey(c, s->dzs[d]);
+        cg_ctx_destroy(c);
+    }
+    for (int dev : s->devices) cg_dev_cache_trim(dev, nullptr);      // the parked blocks were sized for this circuit: back to the runtime with them (the devices are idle now)
     delete s;
 }
 }
@@ -129,6 +140,11 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
             for (int d = 0; d < n_dev; d++) s->dzs[d].fixed = &s->fixed;
         }
         for (int d = 0; d < n_dev; d++) CG(cg_ctx_sync(s->ctx0[d]));
+        // The registration contexts are done: their streams go back to the pool NOW, so that the proving contexts made below (and later)
+        // take them over instead of sharing hardware queues with three streams that would sit idle for the life of the session — with
+        // them held, the fifth normal-class stream of a party's pair landed on the queue of another BUSY stream of the pair whenever the
+        // process had one more context of its own (a 2^16 party in such a process: 7.8 ms against 4.1).
+        for (int d = 0; d < n_dev; d++) { s->dzs[d].owner = nullptr; cg_ctx_destroy(s->ctx0[d]); s->ctx0[d] = nullptr; }
         static const int second_min = getenv("CGH_SECOND_CONTEXT_MIN") ? atoi(getenv("CGH_SECOND_CONTEXT_MIN")) : 15;    // tuning knob: log2 of the variables from which a proof uses two contexts
         s->second_context = s->z.n_vars >= ((size_t)1 << second_min) && !getenv("CGH_ONE_CONTEXT");
         s->bulk_second = s->second_context && !getenv("CGH_NO_CHAIN_PRIORITY");
@@ -138,6 +154,7 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
         // from the order in which the first proofs' threads happened to create them (three co-located parties racing).  Further parties'
         // contexts are still made on demand.
         if (s->second_context) for (int d = 0; d < n_dev; d++) {
+            StreamGroup one_party;
             cg_ctx* chain = s->take(d, !getenv("CGH_NO_CHAIN_PRIORITY")); cg_ctx* bulk = s->take(d, false);
             s->give(chain, d, !getenv("CGH_NO_CHAIN_PRIORITY")); s->give(bulk, d, false);
         }
@@ -163,6 +180,7 @@ int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uin
         const Fr* w = (const Fr*)full_witness;
         std::vector<Fr> pub(w, w + z.n_public + 1);
         static const bool no_prio = getenv("CGH_NO_CHAIN_PRIORITY") != nullptr;          // tuning knob
+        StreamGroup one_party;   // (contexts made here, when the pool has none, are this party's)
         Borrowed ctx(s, true, 0, s->second_context && !no_prio), second(s, s->second_context);
         ProofWorkers workers(s);
         ProofZKey pz(s, ctx.c, pub);
@@ -198,6 +216,7 @@ int32_t cgh_session_prove_rep3_party_ex(void* h, const uint64_t* pub_in, const u
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
         CallbackNetwork net(*net_cb);
         static const bool no_prio = getenv("CGH_NO_CHAIN_PRIORITY") != nullptr;          // tuning knob
+        StreamGroup one_party;   // (contexts made here, when the pool has none, are this party's)
         Borrowed ctx(s, true, 0, s->second_context && !no_prio), second(s, s->second_context);
         CallbackRand rnd(*rnd_cb);                                                       // (after the contexts: draws in flight are finished on a context that still exists)
         rnd.describe_streams(streams_cb);
@@ -252,6 +271,7 @@ static int32_t shamir_party_impl(void* h, int32_t threshold, const uint64_t* pub
         const size_t n_aux = z.n_vars - z.n_public - 1;
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
         CallbackShamirNet net(*net_cb);
+        StreamGroup one_party;   // (contexts made here, when the pool has none, are this party's)
         Borrowed ctx(s, true, 0, false), second(s, s->second_context);
         ProofWorkers workers(s);
         ProofZKey pz(s, ctx.c, pub);

@@ -42,6 +42,12 @@ enum { CG_OK = 0, CG_ERR_ARG = 1, CG_ERR_HIP = 2, CG_ERR_NODEVICE = 3, CG_ERR_OO
 
 /* ---- context ------------------------------------------------------------------------------------------------- */
 int32_t cg_ctx_create(int32_t device, cg_ctx** out);
+/* Contexts created on this thread between _begin and _end belong to ONE party (a chain context and the bulk context beside it): within each
+ * priority class their streams are placed on hardware queues of their own while the class has queues left (four per class; a queue serves
+ * its streams' packets in order, so a busy stream behind another busy stream's wait stands still with it).  Calls nest; without a group
+ * a new context's streams go to the least used queues.  Placement only: results never depend on it. */
+int32_t cg_stream_group_begin(void);
+int32_t cg_stream_group_end(void);
 /* flags bit 0 ("chain"): for the context that carries a dependency chain (the witness map with its party-to-party exchanges,
  * groth16.rs:141-204) while another context of the same party keeps the chip full with independent MSMs — high-priority main and copy
  * streams on hardware queues of their own.  flags bit 1 ("bulk"): the context next to it — low-priority main stream. */
@@ -61,6 +67,11 @@ const char* cg_version(void);
  * completed before the call.  CG_DEV_CACHE_MB bounds the parked bytes per device (0: release at once, which waits for the device). */
 int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr);
 int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr);
+/* Gives the blocks parked by cg_dev_free on `device` back to the runtime (hipFree: stalls until the device is idle — call it when it is:
+ * between proofs of different circuits, when a session closes).  Parked blocks are only reused by allocations of exactly their size;
+ * without this a process that moves on to another circuit keeps up to CG_DEV_CACHE_MB of them, and once that bound is reached every
+ * further cg_dev_free takes the synchronising path.  Returns the bytes released in *bytes (may be NULL). */
+int32_t cg_dev_cache_trim(int32_t device, size_t* bytes);
 int32_t cg_dev_upload(cg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);     /* synchronous */
 int32_t cg_dev_download(cg_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* synchronous */
 int32_t cg_dev_memset_zero(cg_ctx* ctx, void* d_dst, size_t bytes);
@@ -155,7 +166,9 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *                 CG_SUBGROUP_FULL           subgroup checks by [r]P instead of the endomorphism tests
  *                 CG_BULK_CLASS (-1)         priority class of a bulk context's main stream (cg_ctx_create_ex flag 2)
  *                 CG_MSM_TABLE_ORDER, CG_MSM_G2_AFTER, CG_MSM_G2_SLICES, CG_MSM_REDUCE_BATCH, CG_MSM_ACC_SLOTS, CG_MSM_WIDE_SMALL   seed the option table of NEW contexts
- *   DEBUG         CG_DEBUG_NO_REDUCE = 1 | 2 skips the merges + bucket reductions | the reductions only: RESULTS ARE WRONG (what they cost a step) */
+ *   DEBUG         CG_DEBUG_NO_REDUCE = 1 | 2 skips the merges + bucket reductions | the reductions only: RESULTS ARE WRONG (what they cost a step)
+ *                 CG_DEBUG_ALLOC             cg_dev_cache_trim prints how the device block cache fared since the last trim (read per call)
+ *                 CG_DEBUG_STREAMS           one stderr line per stream handed out: priority class, hardware-queue slot, streams checked out per slot (read per call) */
 /* ---- per-context tuning (never changes results).  One table instead of process-wide environment variables: every option belongs to the
  * context it is set on (a party's chain and bulk contexts differ), is read at the next call that uses it, and can be read back.
  *   option                         value                                                                                   default

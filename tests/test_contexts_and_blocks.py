@@ -76,6 +76,16 @@ def test_released_blocks_are_handed_out_again_and_hold_no_stale_work(built):
     # a size nobody released: a fresh block; zero-size and odd sizes round up
     for nbytes in (1, 17, 4097, (1 << 16) + 8):
         blk = c.alloc(nbytes); blk.zero(); blk.free()
+    # cg_dev_cache_trim: the parked blocks go back to the runtime (at least the ones released above), live blocks are untouched
+    keep = c.to_device(a)
+    big = c.alloc(3 << 20); big.zero(); c.sync(); big.free()
+    released = cg.dev_cache_trim(0)
+    assert released >= (3 << 20), released
+    assert cg.dev_cache_trim(0) == 0                                # nothing parked any more
+    np.testing.assert_array_equal(keep.download((n, 4)), a)         # a live block survives the trim
+    again = c.alloc(3 << 20); again.zero(); again.free(); keep.free()
+    with pytest.raises(cg.BackendError):
+        cg.dev_cache_trim(1 << 20)                                  # no such device
     c.close()
 
 
