@@ -8,6 +8,7 @@
 #include "ntt_kernels.hpp"   // NttVecs, plan constants (no kernels are instantiated in this translation unit)
 
 #include <cmath>
+#include <chrono>
 #include <map>
 #include <set>
 #include <mutex>
