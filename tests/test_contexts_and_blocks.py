@@ -41,6 +41,40 @@ def test_chain_and_bulk_contexts_compute_the_same(built):
         bases.release(); c.close()
 
 
+def test_contexts_of_a_stream_group_compute_the_same(built):
+    """cg_stream_group_begin / _end place the streams of one party's contexts on hardware queues of their own: placement only.  Groups nest,
+    an unmatched _end is harmless, contexts made in a group work after it has ended and after other contexts have come and gone"""
+    rng = np.random.default_rng(78)
+    n = 4096
+    a, b = orc.random_field(BN254, FR, n, rng), orc.random_field(BN254, FR, n, rng)
+    want = orc.field_op(BN254, FR, "mul", a, b)
+    lib = cg.load()
+    cg._chk(lib.cg_stream_group_end())                              # nothing open: no effect
+    cg._chk(lib.cg_stream_group_begin()); cg._chk(lib.cg_stream_group_begin())
+    chain, bulk = cg.Context(0, cg.Context.CHAIN), cg.Context(0, cg.Context.BULK)
+    cg._chk(lib.cg_stream_group_end())
+    third = cg.Context(0)                                           # still inside the outer group
+    cg._chk(lib.cg_stream_group_end())
+    outside = cg.Context(0)
+    outside.close()
+    for c in (chain, bulk, third):
+        da, db = c.to_device(a), c.to_device(b)
+        out = c.alloc(n * 32)
+        c.vec_mul(BN254, out, da, db, n)
+        np.testing.assert_array_equal(out.download((n, 4)), want)
+        for x in (da, db, out): x.free()
+    for c in (chain, bulk, third): c.close()
+    # the parked streams serve the next group as well
+    cg._chk(lib.cg_stream_group_begin())
+    again = [cg.Context(0, f) for f in (cg.Context.CHAIN, cg.Context.BULK, 0, 0)]
+    cg._chk(lib.cg_stream_group_end())
+    for c in again:
+        da, db = c.to_device(a), c.to_device(b); out = c.alloc(n * 32)
+        c.vec_mul(BN254, out, da, db, n)
+        np.testing.assert_array_equal(out.download((n, 4)), want)
+        c.close()
+
+
 def test_released_blocks_are_handed_out_again_and_hold_no_stale_work(built):
     """cg_dev_free parks a block behind the work enqueued so far; the next allocation of that size gets it back only once that work is done"""
     c = cg.Context(0)
