@@ -17,8 +17,10 @@ shares, masks, the vectors "received" from the previous party, the five zkey-siz
 `sizes` = both figures at the other sizes BASELINE.json's north_star names (2^16, 2^20, 2^24), each with its own roofline triple;
 `session.bls12_381` = the second curve of the reference's e2e matrix (tests/tests/circom/e2e_tests/mod.rs:20-106) through the same entry.
 
-N > 1 (one process per GPU, torch.distributed / RCCL): STRONG scaling of the RESIDENT step (`value_basis` says so; compare with
-`step_resident.value` of the N = 1 line, not with its `value`) — the ten MSMs are cut into work units
+N > 1 (one process per GPU, torch.distributed / RCCL; `python bench.py --gpus N` without a launcher starts its own N ranks and refuses a box
+with fewer GPUs).  `value` keeps the N = 1 basis: ONE REP3 party through the same entry on a session opened over the job's N GPUs
+(cgh_session_open_multi — rank 0's process drives them, as one co-circom process would; the other ranks wait in a host-side barrier).
+`step_resident` = STRONG scaling of the resident step over the ranks — the ten MSMs are cut into work units
 (whole zkey tables, range-split only as far as balance needs it: full-size launches are the efficient ones) that plan_units()
 assigns to ranks; every rank holds only its own table slices, and one all_gather of the unit results (a few KB) + host EC
 additions fold the slices (RCCL has no EC-add reduction).  The witness map (NTT stage) runs only where its result is needed:
@@ -463,7 +465,7 @@ def cpu_baseline(log_m_target=22, threads_cap=None, budget_s=45.0):
                            "note": "same inputs; " + ("both settings cover all 15 MSM windows, so the MSM stage times are shared and only the other stages were re-timed" if shared else "full second run")}}
 
 
-def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barrier=None):
+def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barrier=None, devices=None):
     """The product's entry under the driver's clock — what co-circom.rs:503-506 times: a proving session on a zkey FILE (product-side
     synthetic circuit with a valid CRS, cgh_synth_circuit) and ONE REP3 party through cgh_session_prove_rep3_party_ex, the entry the CLI
     patch binds.  Host buffers in, proof out: witness shares cross PCIe, the masks of both mul_vec calls are drawn INSIDE the call on the
@@ -471,17 +473,23 @@ def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barri
     with the peers cross PCIe both ways.  The party is party 0 ALONE on the GPU, as in a deployment (one party per machine), served what its
     peers sent in a three-party run on the same session from page-locked memory: network time excluded; its proof must repeat bit for bit.
     Timed region = `proofs` consecutive calls between two barriers, wall clock.  extras: plain driver, the same party with host draws /
-    pre-drawn masks, the Shamir twin."""
+    pre-drawn masks, the Shamir twin.  devices: the party's GPUs — the session is then opened with cgh_session_open_multi over them (the product's
+    multi-GPU path, SURVEY.md §8e: table slices per device, witness map distributed, partial sums folded on the host)."""
     import shutil
     import tempfile
     import threading
     curve = CURVE if curve is None else curve
-    barrier = barrier or (lambda: (torch.cuda.synchronize(), ctx.sync()))
+    devs = None if devices is None else [int(x) for x in devices]
+    def sync_all():
+        for dv in sorted(set(devs or [device.index])):
+            torch.cuda.synchronize(dv)
+        ctx.sync()
+    barrier = barrier or sync_all
     d = tempfile.mkdtemp(prefix="cg_bench_")
     try:
         zp, wp = os.path.join(d, "s.zkey"), os.path.join(d, "s.wtns")
         t0 = time.perf_counter(); cg.host_synth_circuit(curve, log_m, 0xC0C1C0DE, zp, wp, device=device.index); t_gen = time.perf_counter() - t0
-        t0 = time.perf_counter(); ses = cg.ProvingSession(curve, zp, precompute=True, device=device.index); t_open = time.perf_counter() - t0
+        t0 = time.perf_counter(); ses = cg.ProvingSession(curve, zp, precompute=True, device=device.index, devices=devs); t_open = time.perf_counter() - t0
         zkey_bytes = os.path.getsize(zp)
         w = cg.host_read_wtns(curve, wp)
         m, n_aux = 1 << log_m, w.shape[0] - 2
@@ -500,6 +508,7 @@ def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barri
         pinned = [a, b, c]
         out = {"entry": "cgh_session_prove_rep3_party_ex (host buffers in, proof out; network and randomness through the callback tables, cgh_rep3_chacha: "
                         "generators described by seed + word position)", "log_m": log_m, "curve": CURVE_NAME[curve], "pcie_inclusive": True,
+               "devices": devs or [device.index], "session": "cgh_session_open_multi over %d device(s)" % len(devs or [0]),
                "network": "loopback replay from page-locked memory (excluded, SURVEY.md 8d)",
                "randomness": "4 x m ChaCha12 / F::rand masking draws per proof INSIDE the timed call, on the GPU (cg_chacha12_fr_rand_dev); draw order restated from "
                              "rand_chacha 0.3 / ark-ff 0.4.2: parity unpinned (no reference-held vector exists)"}
@@ -791,33 +800,58 @@ def main():
     global CURVE
     CURVE = cg.BN254 if args.curve == "bn254" else cg.BLS12_381
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    emulate = None
+    if args.emulate:
+        emulate = tuple(int(x) for x in args.emulate.split(":"))
+    # `python bench.py --gpus N` with no launcher around it (the driver's N = 1 command shape): start the N ranks here, one per GPU, under
+    # torch.distributed.run — and refuse loudly when the box has fewer GPUs than ranks (test mode --shared-device puts every rank on GPU 0)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not emulate:
+        have = torch.cuda.device_count()
+        if have < args.gpus and not args.shared_device:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (one rank per GPU; --shared-device --backend gloo is the one-GPU test mode)")
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if world != args.gpus and not (emulate and world == 1):
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without a launcher: bench.py starts its own ranks)")
+    if world > 1 and not args.shared_device and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     if args.shared_device:
         local_rank = 0
-    emulate = None
-    if args.emulate:
+    if emulate:
         assert world == 1, "--emulate runs as a single process"
-        emulate = tuple(int(x) for x in args.emulate.split(":"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    host_group = None                                  # host-side barrier (gloo): a waiting rank must not spin a kernel on its GPU while rank 0's session uses that GPU
     if args.force_dist:
         global WM_DISTRIBUTE_MIN_WORLD
         WM_DISTRIBUTE_MIN_WORLD = 1
         os.environ.setdefault("MASTER_PORT", "29655"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    ranks_seen = 1
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            host_group = dist.new_group(backend="gloo")
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        ones = torch.ones(1, dtype=torch.int64, device=device if args.backend == "nccl" else None)
+        dist.all_reduce(ones)                              # every rank of the job answered through the data-path backend (nccl = RCCL)
+        ranks_seen = int(ones.item())
+        if ranks_seen != world:
+            raise SystemExit(f"bench.py: all_reduce of ones over {world} ranks returned {ranks_seen}")
     comm = Comm(dist, world, device)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     ctx = cg.Context(local_rank)
     stream = torch.cuda.Stream(device=device)      # torch is plumbing: one stream shared by its copies/slices and the library's kernels
@@ -865,6 +899,7 @@ def main():
 
     single = rank == 0 and not emulate and world == 1
     iso = isolated_kernels(w, ctx, barrier) if single else None
+    g1_pts = [hi - lo for (t, i, parts), (b, lo, hi) in w.tables.items() if TABLE_GROUP[t] == 0]
 
     if rank == 0 and args.dump_result:
         dump = {t: np.stack([cg.point_to_affine(CURVE, cg.G1 if TABLE_GROUP[t] == 0 else cg.G2, res[t][j]) for j in range(2)]) for t in TABLES}
@@ -879,11 +914,28 @@ def main():
         print(json.dumps({"emulated_world": emulate[0], "emulated_rank": emulate[1], "ms_per_step": elapsed / args.steps * 1e3,
                           "units": [f"{t}{i}/{p}" for (t, i, p) in w.mine], "vectors": w.my_vecs, "stage_ms": {k: v / args.steps for k, v in st.items() if k.endswith("_ms")}}))
         return
+    # N > 1: the SAME basis as the N = 1 line — one REP3 party through the product's entry, on a session opened over the job's N GPUs
+    # (cgh_session_open_multi: one process drives the party's devices, as one `co-circom` process would).  Rank 0 is that process; the
+    # other ranks have done their part in the resident leg above and wait in a HOST-side barrier, their GPUs free for the session.
+    multi_ent = None
+    if world > 1 and not emulate and not args.no_session:
+        w.release()
+        for c in (w.ctx_aux,):
+            if c is not None and rank != 0:
+                c.close()
+        host_barrier = (lambda: dist.barrier(group=host_group)) if host_group is not None else dist.barrier
+        torch.cuda.synchronize(); host_barrier()
+        if rank == 0:
+            devs = [0] * world if args.shared_device else list(range(world))
+            try:
+                multi_ent = entry_leg(ctx, args.log_m, device, args.steps, args.warmup, CURVE, extras=False, devices=devs)
+            except Exception as e:                                                       # noqa: BLE001 (the line survives: `value` stays the resident step and says so)
+                multi_ent = {"error": f"{type(e).__name__}: {e}"[:400], "devices": devs}
+        host_barrier()
     if rank == 0:
         step_ms = elapsed / args.steps * 1e3
         step_value = w.nc / (elapsed / args.steps)
         ptb = G1_POINT_BYTES[CURVE]
-        g1_pts = [hi - lo for (t, i, parts), (b, lo, hi) in w.tables.items() if TABLE_GROUP[t] == 0]
         # dominant kernel: G1 bucket accumulation. Algorithmic bytes per launch: each base read once (64 B; 96 B on BLS12-381)
         # + its scalar read once (32 B) per point of the launch's range.
         acc_calls = max(1, st["msm_acc_g1_calls"])
@@ -934,7 +986,7 @@ def main():
             "metric": f"Groth16 constraints/sec ({cname}, 2^{args.log_m} R1CS), one REP3 party's prove",
             "value": step_value, "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "value_basis": "step_resident (inputs resident in HBM)" + (": N > 1 lines scale the resident step; compare with step_resident.value of the N = 1 line" if world > 1 else ""),
+            "value_basis": "step_resident (inputs resident in HBM)", "rccl_ranks_seen": ranks_seen, "backend": (args.backend if dist is not None else None),
             "dtype": "u32 limbs (%d-bit modular integer arithmetic)" % FR[CURVE][2], "data": "synthetic",
             "config": {"workload": f"synthetic R1CS 2^{args.log_m} constraints-domain {cname}, REP3 co-groth16 (configs[2])",
                        "num_constraints": w.nc, "domain_size": w.m, "n_vars": w.m, "nnz": w.nnz, "share_components": 2,
@@ -968,6 +1020,18 @@ def main():
             "step_resident": step_resident,
             "setup_s": {"synthetic_bases": w.setup_bases_s, "precompute_tables": w.setup_precompute_s},
         }
+        if world > 1:
+            step_resident["what"] += "; N > 1: one process per GPU, MSM work units planned over the ranks, witness map distributed for N >= 4, one all_gather of unit results + host EC fold"
+            step_resident["plan"] = ",".join(f"{t}{i}/{p}->r{o}" for t, i, p, o in w.plan)
+            if multi_ent is not None:
+                out["product_entry"] = multi_ent
+                if "value" in multi_ent:
+                    out["value"], out["ms_per_step"] = multi_ent["value"], multi_ent["ms_per_proof"]
+                    out["value_basis"] = (f"product entry over {world} GPUs, the N = 1 line's basis: ONE REP3 party through cgh_session_prove_rep3_party_ex on a cgh_session_open_multi session over the job's "
+                                          f"{world} devices (rank 0's process drives them, as one co-circom process would; the other ranks wait in a host-side barrier) — witness shares in host memory in, proof out, "
+                                          "mask draws, mul_vec exchanges over PCIe and the host steps inside the timed call; step_resident = the per-rank resident scaling of the same proof's kernels (one process per GPU over RCCL)")
+                else:
+                    out["value_basis"] = "step_resident (inputs resident in HBM): the multi-device product entry FAILED on this box (product_entry.error), so this line is NOT on the N = 1 line's basis — compare with step_resident.value there"
         legs = not args.no_session and world == 1
         if legs:
             w.release()                                                 # the session registers its own tables (another 21 GB of window copies at 2^22)

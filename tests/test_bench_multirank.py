@@ -104,3 +104,36 @@ def test_ranks_fold_to_the_single_rank_result(tmp_path):
         assert jw["n_gpus"] == world
         for t in r1:
             np.testing.assert_array_equal(r1[t], rw[t], err_msg=f"world {world}, table {t}")
+
+
+def test_gpus_flag_starts_its_own_ranks_and_keeps_the_entry_basis(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher around it (the shape of the driver's command) starts two ranks itself and prints a
+    two-rank line whose `value` is on the N = 1 line's basis: one REP3 party through the product entry on a cgh_session_open_multi
+    session over the job's devices.  On a one-GPU box the ranks share GPU 0 (gloo); a box with two GPUs runs RCCL between them."""
+    import torch
+    one_box = [] if torch.cuda.device_count() >= 2 else ["--backend", "gloo", "--shared-device"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-m", "14", "--no-cpu-baseline", *one_box]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["rccl_ranks_seen"] == 2
+    ent = j["product_entry"]
+    assert "error" not in ent, ent
+    assert len(ent["devices"]) == 2 and ent["three_parties_agree"]
+    assert j["value_basis"].startswith("product entry over 2 GPUs")
+    assert j["value"] == ent["value"] and j["step_resident"]["value"] > 0
+
+
+def test_gpus_flag_refuses_a_box_with_too_few_gpus():
+    """without --shared-device a rank count above the visible GPUs is an error, not a silent one-GPU line"""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout)
+    # a launcher that started the wrong number of ranks is refused as well
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], cwd=ROOT, env=env2, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
