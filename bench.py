@@ -465,7 +465,7 @@ def cpu_baseline(log_m_target=22, threads_cap=None, budget_s=45.0):
                            "note": "same inputs; " + ("both settings cover all 15 MSM windows, so the MSM stage times are shared and only the other stages were re-timed" if shared else "full second run")}}
 
 
-def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barrier=None, devices=None):
+def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barrier=None, devices=None, files=None):
     """The product's entry under the driver's clock — what co-circom.rs:503-506 times: a proving session on a zkey FILE (product-side
     synthetic circuit with a valid CRS, cgh_synth_circuit) and ONE REP3 party through cgh_session_prove_rep3_party_ex, the entry the CLI
     patch binds.  Host buffers in, proof out: witness shares cross PCIe, the masks of both mul_vec calls are drawn INSIDE the call on the
@@ -474,7 +474,9 @@ def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barri
     peers sent in a three-party run on the same session from page-locked memory: network time excluded; its proof must repeat bit for bit.
     Timed region = `proofs` consecutive calls between two barriers, wall clock.  extras: plain driver, the same party with host draws /
     pre-drawn masks, the Shamir twin.  devices: the party's GPUs — the session is then opened with cgh_session_open_multi over them (the product's
-    multi-GPU path, SURVEY.md §8e: table slices per device, witness map distributed, partial sums folded on the host)."""
+    multi-GPU path, SURVEY.md §8e: table slices per device, witness map distributed, partial sums folded on the host).  files = (zkey, wtns):
+    an existing circuit instead of the synthetic one (log_m is then read from the zkey) — the reference's own bench circuit, Poseidon(2),
+    tests/benches/poseidon_hash2.rs:175-223, is the fixture tests/golden/groth16/bn254/poseidon."""
     import shutil
     import tempfile
     import threading
@@ -488,17 +490,22 @@ def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barri
     d = tempfile.mkdtemp(prefix="cg_bench_")
     try:
         zp, wp = os.path.join(d, "s.zkey"), os.path.join(d, "s.wtns")
-        t0 = time.perf_counter(); cg.host_synth_circuit(curve, log_m, 0xC0C1C0DE, zp, wp, device=device.index); t_gen = time.perf_counter() - t0
+        t_gen = 0.0
+        if files is not None:
+            zp, wp = files
+        else:
+            t0 = time.perf_counter(); cg.host_synth_circuit(curve, log_m, 0xC0C1C0DE, zp, wp, device=device.index); t_gen = time.perf_counter() - t0
         t0 = time.perf_counter(); ses = cg.ProvingSession(curve, zp, precompute=True, device=device.index, devices=devs); t_open = time.perf_counter() - t0
         zkey_bytes = os.path.getsize(zp)
         w = cg.host_read_wtns(curve, wp)
-        m, n_aux = 1 << log_m, w.shape[0] - 2
-        nc = m - 2
+        info = cg.host_zkey_info(curve, zp)
+        n_in = info["n_public"] + 1                          # the leading one + the public inputs
+        m, log_m, nc, n_aux = info["domain_size"], info["pow"], info["num_constraints"], w.shape[0] - n_in
         g = torch.Generator(device=device); g.manual_seed(0x5E55)
         host = lambda t: t.cpu().numpy().view(np.uint64)
         # additive shares of the aux witness: a, b uniform, c = w - a - b (on the device, through the ABI's own subtraction)
         da, db = rand_fr(n_aux, device, g, curve), rand_fr(n_aux, device, g, curve)
-        dw = torch.from_numpy(np.ascontiguousarray(w[2:]).view(np.int64)).to(device)
+        dw = torch.from_numpy(np.ascontiguousarray(w[n_in:]).view(np.int64)).to(device)
         dc = torch.empty_like(dw)
         ctx.vec_sub(curve, dc, dw, da, n_aux); ctx.vec_sub(curve, dc, dc, db, n_aux); ctx.sync(); torch.cuda.synchronize()
         pin = lambda x: (lambda p_: (p_.__setitem__(slice(None), x), p_)[1])(ctx.host_alloc(x.shape))
@@ -509,6 +516,7 @@ def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barri
         out = {"entry": "cgh_session_prove_rep3_party_ex (host buffers in, proof out; network and randomness through the callback tables, cgh_rep3_chacha: "
                         "generators described by seed + word position)", "log_m": log_m, "curve": CURVE_NAME[curve], "pcie_inclusive": True,
                "devices": devs or [device.index], "session": "cgh_session_open_multi over %d device(s)" % len(devs or [0]),
+               "circuit": dict(info, source=("file " + os.path.relpath(zp, ROOT)) if files is not None else "synthetic (cgh_synth_circuit, seed 0xC0C1C0DE)"),
                "network": "loopback replay from page-locked memory (excluded, SURVEY.md 8d)",
                "randomness": "4 x m ChaCha12 / F::rand masking draws per proof INSIDE the timed call, on the GPU (cg_chacha12_fr_rand_dev); draw order restated from "
                              "rand_chacha 0.3 / ark-ff 0.4.2: parity unpinned (no reference-held vector exists)"}
@@ -523,7 +531,7 @@ def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barri
             res, errs = [None] * 3, [None] * 3
 
             def party(i):
-                try: res[i], _ = cg.host_prove_rep3_party(ses, w[:2], wa[i], wb[i], nets[i], rnd[i].table, rnd[i].streams)
+                try: res[i], _ = cg.host_prove_rep3_party(ses, w[:n_in], wa[i], wb[i], nets[i], rnd[i].table, rnd[i].streams)
                 except Exception as e: errs[i] = e; hub.abort()
             th = [threading.Thread(target=party, args=(i,)) for i in range(3)]
             t0 = time.perf_counter()
@@ -541,7 +549,7 @@ def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barri
         def solo(on_device=True, prepared=None):
             # the party's network and Rep3Rand exist before the reference starts its clock (co-circom.rs:484-502 set them up, :503-506 time prove)
             rnd, net = prepared or (cg.ChaChaRand(curve, seeds[0], seeds[2]), hub.replay_net(0))
-            got, sec = cg.host_prove_rep3_party(ses, w[:2], wa[0], wb[0], net, rnd.table, rnd.streams if on_device else None)
+            got, sec = cg.host_prove_rep3_party(ses, w[:n_in], wa[0], wb[0], net, rnd.table, rnd.streams if on_device else None)
             if prepared is None:
                 rnd.close()
                 if not (got == proofs3[0]).all(): raise RuntimeError("the party served its recorded traffic produced a different proof")
@@ -584,7 +592,7 @@ def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barri
         if extras:
             try:
                 dr = rand_fr(n_aux, device, g, curve)
-                dw = torch.from_numpy(np.ascontiguousarray(w[2:]).view(np.int64)).to(device)
+                dw = torch.from_numpy(np.ascontiguousarray(w[n_in:]).view(np.int64)).to(device)
                 swits, cur = [], dw
                 for _ in range(3):                                                          # w + r x at x = 1, 2, 3 (shamir_core.rs:8-31)
                     nxt = torch.empty_like(dw); ctx.vec_add(curve, nxt, cur, dr, n_aux); ctx.sync(); torch.cuda.synchronize()
@@ -598,7 +606,7 @@ def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barri
                 souts, serrs = [None] * 3, [None] * 3
 
                 def party_s(i):
-                    try: souts[i], _ = cg.host_prove_shamir_party_seeded(ses, 1, w[:2], swits[i], snets[i], sseeds[i], preprocess=pre)
+                    try: souts[i], _ = cg.host_prove_shamir_party_seeded(ses, 1, w[:n_in], swits[i], snets[i], sseeds[i], preprocess=pre)
                     except Exception as e: serrs[i] = e; hubs.abort()
                 th = [threading.Thread(target=party_s, args=(i,)) for i in range(3)]
                 t0 = time.perf_counter()
@@ -610,7 +618,7 @@ def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barri
                 for i in (1, 0):
                     secs = []
                     for _ in range(3):
-                        got, sec = cg.host_prove_shamir_party_seeded(ses, 1, w[:2], swits[i], hubs.replay_net(i), sseeds[i], preprocess=pre)
+                        got, sec = cg.host_prove_shamir_party_seeded(ses, 1, w[:n_in], swits[i], hubs.replay_net(i), sseeds[i], preprocess=pre)
                         if not (got == souts[0]).all(): raise RuntimeError("Shamir: replayed party produced a different proof")
                         secs.append(sec * 1e3)
                     alone[i] = secs
@@ -1060,6 +1068,14 @@ def main():
                 except Exception as e:                                  # noqa: BLE001
                     sizes["2^%d" % lg] = {"error": f"{type(e).__name__}: {e}"[:400]}
             out["sizes"] = sizes
+            # the reference's own benchmark: Poseidon(2) Groth16 REP3 (tests/benches/poseidon_hash2.rs:175-223) = the fixture circuit, m = 256
+            try:
+                fxd = os.path.join(ROOT, "tests", "golden", "groth16", "bn254" if CURVE == cg.BN254 else "bls12_381", "poseidon")
+                p_ = entry_leg(ctx, 0, device, 20, 3, CURVE, extras=False, files=(os.path.join(fxd, "circuit.zkey"), os.path.join(fxd, "witness.wtns")))
+                out["poseidon_fixture"] = {k: p_[k] for k in ("ms_per_proof", "ms_per_proof_min_inner", "ms_inner_each", "value", "unit", "proofs", "three_parties_agree", "circuit", "entry")}
+                out["poseidon_fixture"]["what"] = "one REP3 party of the reference's own bench circuit (Poseidon(2), tests/benches/poseidon_hash2.rs:175-223; 213 constraints, domain 256) through the same entry"
+            except Exception as e:                                      # noqa: BLE001
+                out["poseidon_fixture"] = {"error": f"{type(e).__name__}: {e}"[:400]}
             other = cg.BLS12_381 if CURVE == cg.BN254 else cg.BN254
             try:                                                        # the second curve of the reference's e2e matrix, same legs at the line's size
                 r_ = resident_leg(ctx, w.ctx_aux, device, args.log_m, 5, 2, other, args.precompute, args.scatter_cap)

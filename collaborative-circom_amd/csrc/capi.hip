@@ -119,7 +119,9 @@ struct cg_ctx {
     hipStream_t sortst = nullptr;
     hipEvent_t ev_in = nullptr, ev_sorted[2] = {nullptr, nullptr}, ev_sched_free[2] = {nullptr, nullptr};
     // the merge kernels on the aux stream are the last readers of a schedule: [slot] = the most recent one per schedule slot
-    hipEvent_t ev_merged[2] = {nullptr, nullptr}; bool merged_pending[2] = {false, false};
+    // ([reduction stream: 0 = aux, 1 = the sort stream (wide mode runs the G1 batch there beside the G2 batch on aux)][schedule slot]: one event
+    // per stream, so that the later record of one batch cannot replace the other batch's mark)
+    hipEvent_t ev_merged[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; bool merged_pending[2][2] = {{false, false}, {false, false}};
     // copy streams of the asynchronous host <-> device transfers (cg_dev_*_begin): MPC exchanges move under the compute
     static constexpr int COPY_TICKETS = 256;
     hipStream_t h2d = nullptr, d2h = nullptr;
@@ -445,14 +447,14 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         char* acc_scratch = ctx->arena.base + nsched * sort_bytes;
         HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));   // scalars (and the arena) are ready once the main stream gets here
         HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_in, 0));
-        for (int i = 0; i < 2; i++) if (ctx->merged_pending[i]) HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_merged[i], 0));   // ... and the previous call's merges have read the old schedules
+        for (int rs = 0; rs < 2; rs++) for (int i = 0; i < 2; i++) if (ctx->merged_pending[rs][i]) { HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_merged[rs][i], 0)); ctx->merged_pending[rs][i] = false; }   // ... and the previous call's merges have read the old schedules
         std::vector<MsmSortPtrs> sps(k);
         auto launch_sort = [&](int j) -> int {             // scalar side: once per scalar vector, on the sort stream
             const int ss_ = j % nsched;
             if (j < 4 && ctx->comp_after[j]) HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->comp_after[j], 0));   // this component's scalars are still on their way up
             if (j >= nsched) {                                   // accumulates and merges of component j-2 have consumed the slot
                 HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_sched_free[ss_], 0));
-                HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_merged[ss_], 0));
+                for (int rs = 0; rs < 2; rs++) if (ctx->merged_pending[rs][ss_]) HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_merged[rs][ss_], 0));
             }
             hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
             if (ctx->stats_on) { const int i0 = ev_open(ctx, TAG_SORT); evs[0] = ctx->ev_live[i0].a; evs[1] = ctx->ev_live[i0].b; pev = evs; }
@@ -488,7 +490,8 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
             if (ctx->stats_on) { const int i2 = ev_open(ctx, TAG_REDUCE); evs[0] = ctx->ev_live[i2].a; evs[1] = ctx->ev_live[i2].b; pev = evs; }
             hipEvent_t evm[2]; int nm = 0; bool seen[2] = {false, false};
             std::vector<MsmRedSet> sets;
-            for (const PendSet& ps : pd) { sets.push_back(ps.set); if (!seen[ps.sched]) { seen[ps.sched] = true; evm[nm++] = ctx->ev_merged[ps.sched]; } }
+            const int rs = rst == ctx->sortst ? 1 : 0;
+            for (const PendSet& ps : pd) { sets.push_back(ps.set); if (!seen[ps.sched]) { seen[ps.sched] = true; evm[nm++] = ctx->ev_merged[rs][ps.sched]; } }
             int rc = with_coord_field(curve, gi == 0 ? CG_G1 : CG_G2, [&](auto ftag) -> int {
                 typedef decltype(ftag) F;
                 return msm_reduce_batch<F>(rst, sets.data(), (int)sets.size(), n, c, nwin, shared, sps[pd[0].comp].cap, evm, nm, pev, chunk_request);
@@ -496,7 +499,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
             if (rc) return rc;
             for (const PendSet& ps : pd) {
                 HIPCHK(hipEventRecord(ctx->ev_red[ps.slot], rst));
-                ctx->slot_busy[ps.slot] = true; ctx->aux_pending = true; ctx->last_slot = ps.slot; ctx->merged_pending[ps.sched] = true;
+                ctx->slot_busy[ps.slot] = true; ctx->aux_pending = true; ctx->last_slot = ps.slot; ctx->merged_pending[rs][ps.sched] = true;
             }
             // a table's results are complete when the batch holding its LAST outstanding component has run (components may sit in different batches)
             for (const PendSet& ps : pd) if (--comps_left[ps.table] == 0) HIPCHK(hipEventRecord(ctx->tickets[slots[ps.table]].done, rst));
@@ -1167,7 +1170,7 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     { int rc = pooled_stream(device, -1, &c->joinst); if (rc) return rc; }
     for (hipEvent_t& e : c->park_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-    for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_sched_free[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_merged[i], hipEventDisableTiming)); }
+    for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_sched_free[i], hipEventDisableTiming)); for (int rs = 0; rs < 2; rs++) HIPCHK(hipEventCreateWithFlags(&c->ev_merged[rs][i], hipEventDisableTiming)); }
     for (int i = 0; i < cg_ctx::ACC_SLOTS_MAX; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming)); }
     *out = c;
     return 0;
@@ -1182,7 +1185,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     for (hipEvent_t e : ctx->mark_ev) if (e) hipEventDestroy(e);
     for (auto& d : ctx->rand_draw) { if (d.live) { cg_dev_free(ctx, d.d_cand); cg_dev_free(ctx, d.d_small); d.live = false; } if (d.ev) hipEventDestroy(d.ev); }   // (draws begun and never finished)
     if (ctx->rand_result) hipHostFree(ctx->rand_result);
-    for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_sorted[i]); hipEventDestroy(ctx->ev_sched_free[i]); hipEventDestroy(ctx->ev_merged[i]); }
+    for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_sorted[i]); hipEventDestroy(ctx->ev_sched_free[i]); for (int rs = 0; rs < 2; rs++) hipEventDestroy(ctx->ev_merged[rs][i]); }
     hipEventDestroy(ctx->ev_in);
     if (ctx->h2d) {
         hipStreamSynchronize(ctx->h2d); hipStreamSynchronize(ctx->d2h);

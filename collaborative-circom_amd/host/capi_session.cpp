@@ -19,6 +19,7 @@ struct cgh_session {
     std::mutex mu; std::vector<std::vector<cg_ctx*>> idle, idle_chain;
     bool bulk_second = false;                                                            // the non-chain contexts run next to a chain context
     bool additive_h = false;                                                             // open flag bit 1: REP3 additive-quotient variant
+    bool counted = false;                                                                // the session was opened successfully (it counts as open until closed)
     cgh::SessionFixed fixed;                                                             // window tables of delta_1, delta_2 and the public-input records (host)
     // A free context is handed out in order of CREATION (lowest serial first), not of return: the pair made at session open serves a party
     // that proves alone in EVERY proof.  Contexts differ in how their streams fell onto the hardware queues; a first-returned-first-out
@@ -47,6 +48,7 @@ struct cgh_session {
     void forget(cg_ctx* c) { std::lock_guard<std::mutex> l(mu); serial.erase(c); }
 };
 namespace {
+std::atomic<int> g_open_sessions{0};                    // sessions handed to callers and not yet closed (session_destroy)
 // the contexts made while one of these lives are one party's: their streams are spread over hardware queues of their own (cg_stream_group_begin)
 struct StreamGroup { StreamGroup() { cg_stream_group_begin(); } ~StreamGroup() { cg_stream_group_end(); } StreamGroup(const StreamGroup&) = delete; StreamGroup& operator=(const StreamGroup&) = delete; };
 // a context borrowed from the session: returned to the pool on success, destroyed when the proof failed (its streams may hold
@@ -97,7 +99,11 @@ void session_destroy(cgh_session* s) {
         cgh::release_zkey(c, s->dzs[d]);
         cg_ctx_destroy(c);
     }
-    for (int dev : s->devices) cg_dev_cache_trim(dev, nullptr);      // the parked blocks were sized for this circuit: back to the runtime with them (the devices are idle now)
+    // The parked blocks were sized for this circuit: back to the runtime with them — but only when this was the process's last open session.
+    // The block cache is per device and process-wide, and giving blocks back is hipFree, which waits for the whole device: beside another
+    // session's proofs it would stall them and empty the cache they are reusing.
+    const bool last = s->counted && g_open_sessions.fetch_sub(1) == 1;
+    if (last) for (int dev : s->devices) cg_dev_cache_trim(dev, nullptr);
     delete s;
 }
 }
@@ -124,7 +130,11 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
             const ZKey& z = s->z; const Curve& c = z.curve;
             const size_t np = std::min<size_t>(z.n_public, SessionFixed::MAX_PUBLIC);
             s->fixed.a_pub.resize(np); s->fixed.b1_pub.resize(np); s->fixed.b2_pub.resize(np);
-            std::vector<std::thread> th; std::vector<std::string> errs(2 + 3 * np);
+            generator_table(c, CG_G1); generator_table(c, CG_G2);                      // (before any thread exists: these may throw)
+            // joined however this block is left: an exception past joinable threads would be std::terminate instead of an error code
+            struct Joined { std::vector<std::thread> th; ~Joined() { for (auto& t : th) if (t.joinable()) t.join(); } } workers;
+            std::vector<std::thread>& th = workers.th; std::vector<std::string> errs(2 + 3 * np);
+            th.reserve(2 + 3 * np);
             auto job = [&](size_t slot, FixedTable* out, int group, const uint8_t* aff) {
                 th.emplace_back([&errs, slot, out, group, aff, c] { try { *out = FixedTable(c, pt_from_affine(c, group, aff)); } catch (const std::exception& e) { errs[slot] = e.what(); } });
             };
@@ -134,7 +144,6 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
                 job(3 + 3 * i, &s->fixed.b1_pub[i], CG_G1, z.b_g1_query.data() + (1 + i) * c.aff(CG_G1));
                 job(4 + 3 * i, &s->fixed.b2_pub[i], CG_G2, z.b_g2_query.data() + (1 + i) * c.aff(CG_G2));
             }
-            generator_table(c, CG_G1); generator_table(c, CG_G2);
             for (auto& t : th) t.join();
             for (const std::string& e : errs) if (!e.empty()) throw std::runtime_error(e);
             for (int d = 0; d < n_dev; d++) s->dzs[d].fixed = &s->fixed;
@@ -158,6 +167,7 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
             cg_ctx* chain = s->take(d, !getenv("CGH_NO_CHAIN_PRIORITY")); cg_ctx* bulk = s->take(d, false);
             s->give(chain, d, !getenv("CGH_NO_CHAIN_PRIORITY")); s->give(bulk, d, false);
         }
+        s->counted = true; g_open_sessions.fetch_add(1);
         *out = s;
         return 0;
     } catch (const std::exception& e) { g_host_err = e.what(); session_destroy(s); return 1; }

@@ -155,18 +155,31 @@ struct CallbackRand : Rep3RandSource {
         streams = *st; has_streams = true;
     }
     // The two draws are enqueued and NOT waited for: the generators' positions are asked for (settle) before the next draw of any kind.
-    struct InFlight { cg_ctx* ctx = nullptr; int32_t t1 = -1, t2 = -1; } inflight;
-    void settle() override {
-        if (!inflight.ctx) return;
+    // Masks made from stream words [p, p') may have LEFT the party (a local product sent to the next party) long before settle() runs, so
+    // the caller's generators must end up behind those words on EVERY path out of the proof — a failed proof whose generators stayed at p
+    // would hand the next proof the same masks, and the difference of two messages would then give away the difference of two local products.
+    // finish_inflight moves them whatever happened: behind the accepted draws when the draw reported its position, behind every candidate
+    // the draw can have generated when it did not (a device error, a shortfall).
+    struct InFlight { cg_ctx* ctx = nullptr; int32_t t1 = -1, t2 = -1; uint64_t p1 = 0, p2 = 0; size_t n = 0; } inflight;
+    // words past every candidate of an n-element draw: cg_chacha12_fr_rand_dev_begin generates (n + 12 sqrt(n) + 64) / accept + 6 candidates of
+    // 8 words, accept >= 0.75 for both scalar fields — 2 n + 4096 candidates bound that for every n
+    static uint64_t words_bound(size_t n) { return 8 * (2 * (uint64_t)n + 4096); }
+    void finish_inflight(bool strict) {
         cg_ctx* c = inflight.ctx; inflight.ctx = nullptr;
         uint64_t a1 = 0, a2 = 0;
         const int32_t r1 = cg_chacha12_fr_rand_dev_finish(c, inflight.t1, &a1);
         const std::string m1 = r1 ? cg_last_error() : "";
         const int32_t r2 = cg_chacha12_fr_rand_dev_finish(c, inflight.t2, &a2);
-        if (r1 || r2) throw std::runtime_error(std::string("masks on the device: ") + (r1 ? m1 : std::string(cg_last_error())));
-        check(streams.set_word_pos(streams.user, a1, a2), "set_word_pos");
+        const std::string m2 = r2 ? cg_last_error() : "";
+        if (r1) a1 = inflight.p1 + words_bound(inflight.n);
+        if (r2) a2 = inflight.p2 + words_bound(inflight.n);
+        const int32_t rs = streams.set_word_pos(streams.user, a1, a2);
+        if (!strict) return;
+        if (r1 || r2) throw std::runtime_error(std::string("masks on the device: ") + (r1 ? m1 : m2));
+        check(rs, "set_word_pos");
     }
-    ~CallbackRand() { if (inflight.ctx) { cg_chacha12_fr_rand_dev_finish(inflight.ctx, inflight.t1, nullptr); cg_chacha12_fr_rand_dev_finish(inflight.ctx, inflight.t2, nullptr); } }
+    void settle() override { if (inflight.ctx) finish_inflight(true); }
+    ~CallbackRand() { if (inflight.ctx) { try { finish_inflight(false); } catch (...) {} } }   // a proof that died between the draws and its next settle()
     bool masks_on_device(cg_ctx* ctx, int curve, size_t n, void* d_out, void* d_tmp) override {
         if (!has_streams) return false;
         settle();
@@ -178,7 +191,7 @@ struct CallbackRand : Rep3RandSource {
         if (!rc) { rc = cg_chacha12_fr_rand_dev_begin(ctx, curve, s2, p2, n, d_tmp, &t2); if (rc) cg_chacha12_fr_rand_dev_finish(ctx, t1, nullptr); }
         if (rc == CG_ERR_OOM) return false;
         if (rc) throw std::runtime_error(std::string("masks on the device: ") + cg_last_error());
-        inflight.ctx = ctx; inflight.t1 = t1; inflight.t2 = t2;
+        inflight.ctx = ctx; inflight.t1 = t1; inflight.t2 = t2; inflight.p1 = p1; inflight.p2 = p2; inflight.n = n;
         if (cg_vec_sub_dev(ctx, curve, d_out, d_out, d_tmp, n)) throw std::runtime_error(std::string("masks on the device: ") + cg_last_error());
         return true;
     }

@@ -25,6 +25,29 @@ def test_header_symbols_exported():
     assert b"gfx950" in cg.load().cg_version()
 
 
+def test_rust_ffi_declares_every_header_function():
+    """rust/mpc-core-hip/src/ffi.rs is generated from include/cogroth16_hip.h (scripts/gen_rust_ffi.py): the committed file equals a fresh
+    generation, and the functions it declares are exactly the ones the header does — the Rust binding cannot lag the C ABI"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(ROOT, "scripts", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    committed = open(os.path.join(ROOT, "rust", "mpc-core-hip", "src", "ffi.rs")).read()
+    assert committed == gen.generate(), "rust/mpc-core-hip/src/ffi.rs is stale: run python scripts/gen_rust_ffi.py"
+    hdr = open(os.path.join(ROOT, "include", "cogroth16_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(cg_[a-z0-9_]+)\s*\(", hdr)))
+    in_rust = sorted(set(re.findall(r"pub fn (cg_[a-z0-9_]+)\(", committed)))
+    assert in_rust == declared
+    # the option ids and the statistics record travel by value: same numbers, same field order
+    for k, v in re.findall(r"(CG_OPT_[A-Z0-9_]+) = (\d+)", hdr):
+        if not k.endswith("_"):
+            assert f"pub const {k}: i32 = {v};" in committed
+    # the other Rust sources only call functions the binding declares
+    for f in ("gpu.rs", "rep3.rs", "plain.rs", "shamir.rs", "session.rs"):
+        src = open(os.path.join(ROOT, "rust", "mpc-core-hip", "src", f)).read()
+        used = set(re.findall(r"\b(cg_[a-z0-9_]+)\s*\(", src))
+        assert used <= set(declared) | {"cg_last_error"}, (f, sorted(used - set(declared)))
+
+
 def test_host_mirror_header_matches_the_library():
     """include/cogroth16_host.h declares exactly the cgh_* entry points libcogroth16_host.so exports (the host mirror is compiled against
     the header, so the signatures agree as well)"""

@@ -244,6 +244,46 @@ def test_parties_with_device_drawn_masks_give_the_oracle_proof(curve, log_m, tmp
 
 
 @pytest.mark.gpu
+def test_a_failed_proof_leaves_the_generators_behind_the_masks_it_drew(tmp_path):
+    """Device draws are not waited for, and a mask may already be on its way to a peer when the proof dies (here: the first chunk of the first
+    mul_vec message never leaves party 1).  Whatever path the proof leaves by, the caller's ChaCha12 generators must stand behind the words
+    those masks were made from — a later proof from the same Rep3Rand must never repeat a mask (rep3.rs:656-660: the mask hides the local product)."""
+    from test_rep3_party_abi import socket_ring
+    ensure_built()
+    curve, log_m = BN254, 15
+    zp, wp = str(tmp_path / "s.zkey"), str(tmp_path / "s.wtns")
+    orc.make_synthetic(curve, log_m, 47, zp, wp, threads=min(32, os.cpu_count() or 8))
+    z = orc.ZKey(curve, zp); w = orc.read_wtns(curve, wp)
+    rng = np.random.default_rng(31)
+    wa, wb = rep3_share(curve, w[2:], rng)
+    seeds = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(3)]
+    ses = cg.ProvingSession(curve, zp, precompute=False)
+    try:
+        ends = socket_ring()
+        ends[1].fail_send_next_at = 0
+        rands = [cg.ChaChaRand(curve, seeds[i], seeds[(i + 2) % 3]) for i in range(3)]
+        errs = [None] * 3
+
+        def party(i):
+            try: cg.host_prove_rep3_party(ses, w[:2], wa[i], wb[i], ends[i].table, rands[i].table, rands[i].streams)
+            except Exception as e: errs[i] = e
+            finally: ends[i].close()
+        th = [threading.Thread(target=party, args=(i,)) for i in range(3)]
+        for t in th: t.start()
+        for t in th: t.join(120)
+        assert not any(t.is_alive() for t in th)
+        assert errs[1] is not None and "send_next failed" in str(errs[1])
+        # both masking vectors of the witness map (2 x domain_size draws per generator, >= 8 words each) were drawn before anything was sent
+        for i, r in enumerate(rands):
+            if errs[i] is None: continue
+            p1, p2 = r.positions()
+            assert p1 >= 8 * 2 * z.domain_size and p2 >= 8 * 2 * z.domain_size, (i, p1, p2)
+        for r in rands: r.close()
+    finally:
+        ses.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("curve,log_m,n,t", [(BN254, 13, 3, 1), (BLS12_381, 12, 5, 2)])
 def test_seeded_shamir_parties_give_the_oracle_proof(curve, log_m, n, t, tmp_path):
     """cgh_session_prove_shamir_party_seeded: each party's private generator is a ChaCha12 stream run by the library from the party's seed —
