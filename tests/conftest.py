@@ -10,6 +10,20 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "variant: opt-in protocol variants that are NOT the reference's message sequence (CGH_SESSION_ADDITIVE_H); they need a GPU and run "
+                                       "only when asked for: pytest -m variant")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`variant` tests stay out of both default runs (-m gpu on the GPU box, -m "not gpu" on CPU): selected only by an -m expression that names them"""
+    if "variant" in (config.getoption("-m") or ""):
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("variant") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 GOLDEN = os.path.join(HERE, "golden")

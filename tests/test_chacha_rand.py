@@ -397,3 +397,61 @@ def test_seeded_shamir_parties_over_the_library_mesh(monkeypatch):
         np.testing.assert_array_equal(np.stack(out), want)
     finally:
         hub.close(); ses.close()
+
+
+# ---- the day a Rust toolchain exists: rust/pin-vectors prints the reference crates' own values into tests/golden/rust_pins.json ------------
+RUST_PINS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rust_pins.json")
+PINS_MISSING = ("tests/golden/rust_pins.json is absent: PARITY UNPINNED for the F::rand draw order (no Rust toolchain in the image that built this "
+                "tree; `cargo run --release --manifest-path rust/pin-vectors/Cargo.toml -- tests/golden` next to a reference checkout writes it, rust/README.md)")
+
+
+def _pins():
+    import json
+    if not os.path.exists(RUST_PINS):
+        pytest.skip(PINS_MISSING)
+    return json.load(open(RUST_PINS))
+
+
+def _limbs(v):
+    return np.array([int(x, 16) for x in v["montgomery_limbs_le"]], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_rust_pins_fr_rand_oracle_and_host(curve_name):
+    """ark-ff's `Fr::rand(&mut ChaCha12Rng::from_seed(s))` as printed by the reference's crates: the oracle's and the host library's draws
+    must be those values, from stream positions 0, unaligned and above 2^32 blocks, and end at the same word position"""
+    pins = _pins()[curve_name]
+    curve = BN254 if curve_name == "bn254" else BLS12_381
+    ensure_built()
+    for case in pins["fr_rand"]:
+        seed, pos, want = bytes.fromhex(case["seed_hex"]), int(case["word_pos"]), np.stack([_limbs(v) for v in case["draws"]])
+        got, after = orc.chacha12_fr_rand(curve, seed, pos, want.shape[0])
+        np.testing.assert_array_equal(got, want); assert after == int(case["word_pos_after"])
+        got, after = cg.chacha12_fr_rand_host(curve, seed, pos, want.shape[0])
+        np.testing.assert_array_equal(got, want); assert after == int(case["word_pos_after"])
+        for v, x in zip(case["draws"], got):                                   # the Montgomery limbs decode to the canonical integers printed beside them
+            assert orc.to_dec(curve, FR, x) == v["canonical_decimal"]
+    m = pins["rep3_masks"]
+    s1, s2 = bytes.fromhex(m["seed1_hex"]), bytes.fromhex(m["seed2_hex"])
+    want = np.stack([_limbs(v) for v in m["masking_field_elements"]])
+    a, p1 = orc.chacha12_fr_rand(curve, s1, 0, want.shape[0]); b, p2 = orc.chacha12_fr_rand(curve, s2, 0, want.shape[0])
+    np.testing.assert_array_equal(orc.field_op(curve, FR, "sub", a, b), want)          # Rep3Rand::masking_field_element, rngs.rs:37-40
+    assert (p1, p2) == (int(m["word_pos1_after"]), int(m["word_pos2_after"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
+def test_rust_pins_fr_rand_device(curve_name):
+    """the same values from cg_chacha12_fr_rand_dev (the draws the product's timed region makes)"""
+    pins = _pins()[curve_name]
+    curve = BN254 if curve_name == "bn254" else BLS12_381
+    ensure_built()
+    ctx = cg.Context(0)
+    try:
+        for case in pins["fr_rand"]:
+            seed, pos, want = bytes.fromhex(case["seed_hex"]), int(case["word_pos"]), np.stack([_limbs(v) for v in case["draws"]])
+            buf, after = ctx.chacha12_fr_rand(curve, seed, pos, want.shape[0])
+            np.testing.assert_array_equal(buf.download((want.shape[0], 4)), want); assert after == int(case["word_pos_after"])
+            buf.free()
+    finally:
+        ctx.close()

@@ -457,7 +457,7 @@ def test_shamir_parties_over_sockets_give_the_oracle_proof(curve_name, n, t, pre
         ses.close()
 
 
-@pytest.mark.gpu
+@pytest.mark.variant
 @pytest.mark.parametrize("curve_name,circuit", [("bn254", "poseidon"), ("bls12_381", "multiplier2")])
 def test_additive_quotient_variant_gives_the_same_proofs(curve_name, circuit):
     """CGH_SESSION_ADDITIVE_H (opt-in, not the reference's message sequence): the witness map's products stay masked local products, MSMs run
@@ -490,7 +490,7 @@ def test_additive_quotient_variant_gives_the_same_proofs(curve_name, circuit):
     assert sent[False] - sent[True] == 2 * 32 * z.domain_size - (4 * 2 * nq + 4 * nq)    # two vector messages fewer, one message of 4 G1 + 1 G2 more
 
 
-@pytest.mark.gpu
+@pytest.mark.variant
 def test_additive_quotient_variant_at_2_16(tmp_path):
     """the variant on the chunked-exchange sizes (precomputed tables, second context, prefetched masks) and on a two-device session"""
     ensure_built()
@@ -516,7 +516,7 @@ def test_additive_quotient_variant_at_2_16(tmp_path):
             hub.close(); ses.close()
 
 
-@pytest.mark.gpu
+@pytest.mark.variant
 @pytest.mark.parametrize("curve_name,n,t", [("bn254", 3, 1), ("bn254", 5, 2), ("bls12_381", 3, 1)])
 def test_shamir_degree_2t_quotient_variant(curve_name, n, t):
     """CGH_SESSION_ADDITIVE_H with Shamir parties: the witness map's products stay degree-2t sharings (no vector degree reduction, so a
