@@ -215,7 +215,7 @@ template <class B> __device__ __forceinline__ B bk_inf() { B r; uint32_t* w = re
 // add-2008-s / dbl-2008-s-1 on lazy limbs (same value classes as the mixed addition: X in (-4.8, 2.8), Y in (-1.9, 1.9),
 // ZZ, ZZZ in (-0.45, 1.45) times p; every product below stays under 72 p^2).  Out of line on purpose (latency-bound kernels).
 template <class F>
-__device__ __attribute__((noinline)) XYZZL<F> bk_dbl(const XYZZL<F>& a) {
+__device__ __forceinline__ XYZZL<F> bk_dbl_inl(const XYZZL<F>& a) {
     typedef typename LazyOf<F>::type L;
     if (bk_is_inf(a) || L::is_zero_mod_p(a.c[1].norm())) return bk_inf<XYZZL<F>>();
     L U = a.c[1].dbl().norm(), V = L::sqr(U), W = L::mul(U, V), S = L::mul(a.c[0], V);
@@ -229,7 +229,10 @@ __device__ __attribute__((noinline)) XYZZL<F> bk_dbl(const XYZZL<F>& a) {
     r.c[3] = L::mul(W, a.c[3]);
     return r;
 }
-// bk_add_inl: the same addition inlined into its caller.  Out of line, both operands and the result travel through scratch memory
+template <class F> __device__ __attribute__((noinline)) XYZZL<F> bk_dbl(const XYZZL<F>& a) { return bk_dbl_inl(a); }
+// bk_add_inl: the same addition inlined into its caller — INCLUDING its doubling branch (equal operands; never taken on random points): a call
+// there takes its operand's address, which put the caller's running sum into scratch memory on EVERY addition (round 4: 304 B / 592 B of private
+// segment per lane in the merge and reduction kernels, ~30 scratch accesses on the hot path of each addition).  Out of line, both operands and the result travel through scratch memory
 // (3 x 144 / 288 bytes per call and lane): in the reduction kernels, whose lanes run short serial chains of additions at one wave
 // per SIMD, those round trips are on the critical path.
 template <class F>
@@ -240,7 +243,7 @@ __device__ __forceinline__ XYZZL<F> bk_add_inl(const XYZZL<F>& a, const XYZZL<F>
     L U1 = L::mul(a.c[0], b.c[2]), S1 = L::mul(a.c[1], b.c[3]);
     L P = L::mul(b.c[0], a.c[2]) - U1, R = L::mul(b.c[1], a.c[3]) - S1;
     if (L::is_zero_mod_p(P.norm())) {
-        if (L::is_zero_mod_p(R.norm())) return bk_dbl(a);
+        if (L::is_zero_mod_p(R.norm())) return bk_dbl_inl(a);
         return bk_inf<XYZZL<F>>();
     }
     L PP = L::sqr(P), PPP = L::mul(P, PP), Q = L::mul(U1, PP);
