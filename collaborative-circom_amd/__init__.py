@@ -40,7 +40,7 @@ OPT_MSM_CHUNK, OPT_MSM_WINDOW, OPT_MSM_SCATTER_CAP, OPT_MSM_TABLE_ORDER, OPT_MSM
 # every symbol include/cogroth16_hip.h declares (checked by tests/test_abi_surface.py)
 ABI_SYMBOLS = [
     "cg_ctx_create", "cg_ctx_create_ex", "cg_ctx_destroy", "cg_ctx_sync", "cg_ctx_stream", "cg_ctx_set_stream", "cg_last_error", "cg_version",
-    "cg_dev_alloc", "cg_dev_free", "cg_dev_cache_trim", "cg_stream_group_begin", "cg_stream_group_end", "cg_dev_upload", "cg_dev_download", "cg_dev_memset_zero",
+    "cg_dev_alloc", "cg_dev_free", "cg_dev_free_many", "cg_dev_cache_trim", "cg_stream_group_begin", "cg_stream_group_end", "cg_dev_upload", "cg_dev_download", "cg_dev_memset_zero",
     "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute", "cg_bases_check_on_curve", "cg_bases_check_subgroup",
     "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_chunk", "cg_ctx_set_option", "cg_ctx_get_option", "cg_msm_scalars_after", "cg_msm_set_scatter_capacity",
     "cg_ntt", "cg_ntt_dev", "cg_ntt_coset_pair_dev", "cg_chacha12_fr_rand_dev", "cg_chacha12_fr_rand_dev_begin", "cg_chacha12_fr_rand_dev_finish",

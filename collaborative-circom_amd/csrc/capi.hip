@@ -441,7 +441,9 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // its own right behind its accumulation (rounds 1-3).  Beside lock-stepped accumulations a reduction costs the step its stand-alone
         // duration whatever its width: 2^22 step with ten reductions 6.2 ms, with three.  A batch holds its sets' scratch slots until it has run: one slot per set.
         const int red_batch = ctx->red_batch;
-        const bool small_call = k <= 2 && (uint64_t)nwin * n <= ((uint64_t)1 << 20) && ctx->wide_small != 0;            // see `wide` below
+        // CG_OPT_MSM_WIDE_SMALL: 0 = off, 1 = calls of at most 2^20 (point, window) entries, 10 .. 30 = log2 of that bound
+        const uint64_t wide_max = ctx->wide_small == 0 ? 0 : (uint64_t)1 << (ctx->wide_small == 1 ? 20 : ctx->wide_small);
+        const bool small_call = k <= 2 && (uint64_t)nwin * n <= wide_max;            // see `wide` below
         const int acc_slots = red_batch || small_call ? std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(acc_slots_min, red_batch >= 2 || small_call ? nb * k : nb + 1)) : acc_slots_min;
         { int rc = ensure_arena(ctx, nsched * sort_bytes + (size_t)acc_slots * acc_slot); if (rc) return rc; }
         char* acc_scratch = ctx->arena.base + nsched * sort_bytes;
@@ -520,7 +522,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // reduction goes to the then idle sort stream.  A 2^16-point launch is 256 workgroups and lasts as long as one lane's chain of
         // additions; eight in a row cost eight chains (2^16 step: 3.2 ms), side by side one.
         // (measured, round 4: 2^14 step 2.63 -> 2.14 ms, 2^16 3.30 -> 3.09 ms and one REP3 party 5.85 -> 5.54 ms; from 2^17 points on — 2^21 entries — no gain)
-        const bool wide = k <= 2 && nb * k <= std::min(acc_slots, (int)ACC_MAX_SETS) && (uint64_t)nwin * n <= ((uint64_t)1 << 20) && ctx->wide_small != 0;
+        const bool wide = k <= 2 && nb * k <= std::min(acc_slots, (int)ACC_MAX_SETS) && (uint64_t)nwin * n <= wide_max;
         if (wide) {
             if (k == 2) { int rc = launch_sort(1); if (rc) return rc; }
             for (int j = 0; j < k; j++) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[j], 0));
@@ -1155,7 +1157,7 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     {   // A/B runs: environment variables seed the option table of new contexts (include/cogroth16_hip.h, cg_ctx_set_option)
         auto seed = [](const char* name, int lo, int hi, int& field) { if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= lo && v <= hi) field = v; } };
         seed("CG_MSM_TABLE_ORDER", 0, 2, c->table_order); seed("CG_MSM_G2_AFTER", -1, 64, c->g2_after); seed("CG_MSM_G2_SLICES", 0, 1, c->g2_slices);
-        seed("CG_MSM_REDUCE_BATCH", 0, 3, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots); seed("CG_MSM_WIDE_SMALL", 0, 1, c->wide_small);
+        seed("CG_MSM_REDUCE_BATCH", 0, 3, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots); seed("CG_MSM_WIDE_SMALL", 0, 30, c->wide_small);
     }
     if (flags & 1u) { c->prio_main = 1; c->prio_copy = 1; c->prio_side = 0; }
     else if (flags & 2u) { static const int bulk_cls = getenv("CG_BULK_CLASS") ? atoi(getenv("CG_BULK_CLASS")) : -1; c->prio_main = bulk_cls; c->prio_side = 0; }   // CG_BULK_CLASS: tuning knob
@@ -1233,7 +1235,9 @@ int32_t cg_ctx_set_stream(cg_ctx* ctx, void* hip_stream) {
 // then on nothing enqueued before the release can touch the block.  CG_DEV_CACHE_MB bounds the parked bytes per device (default 32768,
 // 0 = release at once); when an allocation fails the parked blocks are released and it is tried again.
 namespace {
-struct ParkedBlock { void* p; hipEvent_t ev; };
+// the release mark of one cg_dev_free / cg_dev_free_many call: one event behind the context's streams, shared by every block of the call
+struct ReleaseMark { hipEvent_t ev; int refs; };
+struct ParkedBlock { void* p; ReleaseMark* mark; };
 struct DevCache {
     std::mutex mu;
     std::multimap<size_t, ParkedBlock> parked; size_t parked_bytes = 0;
@@ -1248,8 +1252,9 @@ DevCache& dev_cache(int device) {
 }
 size_t dev_cache_cap() { static const size_t cap = [] { const char* e = getenv("CG_DEV_CACHE_MB"); return (e ? (size_t)atoll(e) : (size_t)32768) << 20; }(); return cap; }
 size_t dev_round(size_t bytes) { const size_t q = bytes >= (64u << 10) ? 4096 : 256; return (std::max<size_t>(bytes, 16) + q - 1) / q * q; }
+void mark_unref(DevCache& dc, ReleaseMark* m) { if (--m->refs == 0) { dc.spare.push_back(m->ev); delete m; } }   // caller holds dc.mu
 void dev_cache_flush(DevCache& dc) {                     // caller holds dc.mu
-    for (auto& kv : dc.parked) { (void)hipFree(kv.second.p); dc.spare.push_back(kv.second.ev); }
+    for (auto& kv : dc.parked) { (void)hipFree(kv.second.p); mark_unref(dc, kv.second.mark); }
     dc.parked.clear(); dc.parked_bytes = 0;
 }
 }  // namespace
@@ -1274,8 +1279,8 @@ int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr) {
     auto range = dc.parked.equal_range(rb);
     bool pending = false;
     for (auto it = range.first; it != range.second; ++it) {
-        if (hipEventQuery(it->second.ev) != hipSuccess) { (void)hipGetLastError(); pending = true; continue; }
-        *d_ptr = it->second.p; dc.spare.push_back(it->second.ev); dc.parked.erase(it); dc.parked_bytes -= rb; dc.live[*d_ptr] = rb;
+        if (hipEventQuery(it->second.mark->ev) != hipSuccess) { (void)hipGetLastError(); pending = true; continue; }
+        *d_ptr = it->second.p; mark_unref(dc, it->second.mark); dc.parked.erase(it); dc.parked_bytes -= rb; dc.live[*d_ptr] = rb;
         dc.n_hit++;
         return 0;
     }
@@ -1297,27 +1302,32 @@ int32_t cg_dev_cache_trim(int32_t device, size_t* bytes) {
     dev_cache_flush(dc);
     return 0;
 }
-int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr) {
-    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
-    if (!d_ptr) return 0;
+int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr) { return cg_dev_free_many(ctx, &d_ptr, 1); }
+// Several blocks released at one point of the context's work share ONE release mark: the join of the context's streams (an event
+// recorded on each, a wait for each on the work-free stream, the mark behind it) costs eleven runtime calls whatever the number of blocks —
+// a proof that gives back twenty vectors one by one spent 0.5 ms of host time on it, an eight-device proof 4 ms.
+int32_t cg_dev_free_many(cg_ctx* ctx, void* const* d_ptrs, size_t n) {
+    if (!ctx || (n && !d_ptrs)) return fail(CG_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
     DevCache& dc = dev_cache(ctx->device);
     std::unique_lock<std::mutex> l(dc.mu);
-    auto it = dc.live.find(d_ptr);
-    const size_t rb = it == dc.live.end() ? 0 : it->second;
-    if (it != dc.live.end()) dc.live.erase(it);
-    if (!rb || dc.parked_bytes + rb > dev_cache_cap()) {  // not one of ours, or no room to park it: the synchronising release
-        dc.n_sync_free++;
-        l.unlock();
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        HIPCHK(hipFree(d_ptr));
-        return 0;
+    std::vector<std::pair<void*, size_t>> park_list; std::vector<void*> sync_list;
+    size_t parked_after = dc.parked_bytes;
+    for (size_t i = 0; i < n; i++) {
+        void* p = d_ptrs[i];
+        if (!p) continue;
+        auto it = dc.live.find(p);
+        const size_t rb = it == dc.live.end() ? 0 : it->second;
+        if (it != dc.live.end()) dc.live.erase(it);
+        if (!rb || parked_after + rb > dev_cache_cap()) { sync_list.push_back(p); dc.n_sync_free++; }   // not one of ours, or no room to park it: the synchronising release
+        else { park_list.push_back({p, rb}); parked_after += rb; }
     }
-    // The block's last users may sit on any of the context's streams.  None of them is made to wait for another (a chain context's main
+    // The blocks' last users may sit on any of the context's streams.  None of them is made to wait for another (a chain context's main
     // stream must not queue behind its pending copies): a stream of the context that carries no work (`joinst`, low priority) waits for
-    // the five, and ONE event behind it marks the block as free (an event per stream and block ran the runtime out of signals).
-    // The block has left `live`: whatever fails from here on, it is released the synchronising way instead of being lost.
+    // the five, and ONE event behind it marks the blocks as free (an event per stream and block ran the runtime out of signals).
+    // The blocks have left `live`: whatever fails from here on, they are released the synchronising way instead of being lost.
     auto park = [&]() -> bool {
+        if (park_list.empty()) return true;
         if (!ctx->joinst) {
             if (pooled_stream(ctx->device, -1, &ctx->joinst)) return false;
             for (hipEvent_t& e : ctx->park_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
@@ -1330,14 +1340,16 @@ int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr) {
         hipEvent_t ev = nullptr;
         if (!dc.spare.empty()) { ev = dc.spare.back(); dc.spare.pop_back(); } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
         if (hipEventRecord(ev, ctx->joinst) != hipSuccess) { dc.spare.push_back(ev); return false; }
-        dc.parked.insert({rb, ParkedBlock{d_ptr, ev}}); dc.parked_bytes += rb;
+        ReleaseMark* m = new ReleaseMark{ev, (int)park_list.size()};
+        for (auto& pr : park_list) { dc.parked.insert({pr.second, ParkedBlock{pr.first, m}}); dc.parked_bytes += pr.second; }
         return true;
     };
-    if (park()) return 0;
-    (void)hipGetLastError();
+    if (!park()) { (void)hipGetLastError(); for (auto& pr : park_list) sync_list.push_back(pr.first); }
     l.unlock();
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipFree(d_ptr));
+    if (!sync_list.empty()) {
+        HIPCHK(hipDeviceSynchronize());
+        for (void* p : sync_list) HIPCHK(hipFree(p));
+    }
     return 0;
 }
 int32_t cg_dev_upload(cg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
@@ -1718,7 +1730,7 @@ int32_t cg_ctx_set_option(cg_ctx* ctx, int32_t option, int64_t value) {
         case CG_OPT_MSM_G2_SLICES: if (value < 0 || value > 1) break; ctx->g2_slices = (int)value; return 0;
         case CG_OPT_MSM_REDUCE_BATCH: if (value < 0 || value > 3) break; ctx->red_batch = (int)value; return 0;
         case CG_OPT_MSM_ACC_SLOTS: if (value < 2 || value > cg_ctx::ACC_SLOTS_MAX) break; ctx->acc_slots = (int)value; return 0;
-        case CG_OPT_MSM_WIDE_SMALL: if (value < 0 || value > 1) break; ctx->wide_small = (int)value; return 0;
+        case CG_OPT_MSM_WIDE_SMALL: if (value < 0 || value > 30 || (value > 1 && value < 10)) break; ctx->wide_small = (int)value; return 0;
         default: return fail(CG_ERR_ARG, "cg_ctx_set_option: unknown option");
     }
     return fail(CG_ERR_ARG, "cg_ctx_set_option: value out of range");
@@ -1874,7 +1886,7 @@ static int rand_draw_begin(cg_ctx* ctx, int32_t curve, const uint8_t* seed32, ui
 static int rand_draw_finish(cg_ctx* ctx, int slot, bool* enough, uint64_t* word_pos_after) {
     cg_ctx::RandDraw& d = ctx->rand_draw[slot];
     hipError_t e = hipEventSynchronize(d.ev);
-    cg_dev_free(ctx, d.d_cand); cg_dev_free(ctx, d.d_small);
+    { void* two[2] = {d.d_cand, d.d_small}; cg_dev_free_many(ctx, two, 2); }
     d.live = false;
     HIPCHK(e);
     const unsigned long long* h = ctx->rand_result + 2 * slot;

@@ -84,7 +84,7 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_
     g.ngroups = shared ? (g.segs >= (uint32_t)MSM_SHARED_GROUPS ? MSM_SHARED_GROUPS : 1) : nwin;
     g.group_segs = shared ? g.segs / g.ngroups : g.segs;
     static const bool no_bitsum = getenv("CG_NO_BITSUM") != nullptr;                     // tuning knob
-    g.bitsum = shared && g.nb <= (1u << 16) && g.nb >= 4096 && !no_bitsum;
+    g.bitsum = shared && g.nb <= (1u << 16) && g.nb >= 128 && !no_bitsum;                  // (from 2^7 buckets: the windows of circuits with a few hundred constraints)
     g.bit_groups = std::max<uint32_t>(1, (g.nb / 2 + 256 * BITSUM_ITEMS - 1) / (256 * BITSUM_ITEMS));
     if (g.bitsum) g.ngroups = c;
     static const bool no_grid = getenv("CG_NO_GRID_REDUCE") != nullptr;                  // tuning knob (A/B against the running-sum chain)

@@ -198,7 +198,10 @@ int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uin
         {
             HipDriver driver(ctx.c, z.curve, Mode::Plain, nullptr);
             driver.aux = second.c; driver.owns_aux = false; driver.md = workers.get();
-            VecGuard wit(driver, driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_public - 1));
+            // several GPUs: the witness stays on the host here and goes up by rows, every device's rows over its own link (multidev.hpp)
+            VecGuard wit(driver);
+            if (DistributedWitnessMap::usable(driver, pz.dz)) { wit.v.n = z.n_vars - z.n_public - 1; driver.host_wit[0] = w + z.n_public + 1; }
+            else wit.v = driver.upload_vec(w + z.n_public + 1, nullptr, z.n_vars - z.n_public - 1);
             FieldShare rs[2]; memcpy(rs[0].c[0].v, r, 32); rs[0].c[1] = rs[0].c[0]; memcpy(rs[1].c[0].v, sc, 32); rs[1].c[1] = rs[1].c[0];
             CoGroth16 prover(driver);
             Proof p = prover.prove(pz.dz, pub, wit.v, rs, nullptr);
@@ -243,7 +246,9 @@ int32_t cgh_session_prove_rep3_party_ex(void* h, const uint64_t* pub_in, const u
             // only then is the stream made to wait for them.
             const bool early_masks = workers.get() == nullptr;
             const bool unfenced = early_masks && n_aux >= driver.XCHG_ASYNC_MIN && cg_host_is_pinned(wit_a) && cg_host_is_pinned(wit_b);
-            VecGuard wit(driver, driver.upload_vec((const Fr*)wit_a, (const Fr*)wit_b, n_aux, !unfenced));
+            VecGuard wit(driver);
+            if (DistributedWitnessMap::usable(driver, pz.dz)) { wit.v.n = n_aux; driver.host_wit[0] = (const Fr*)wit_a; driver.host_wit[1] = (const Fr*)wit_b; }   // up by rows (multidev.hpp)
+            else wit.v = driver.upload_vec((const Fr*)wit_a, (const Fr*)wit_b, n_aux, !unfenced);
             if (early_masks) driver.prefetch_masks(2, groth16_domain(z.curve, z.pow, z.num_constraints, pub.size()).m);
             if (unfenced) driver.fence_uploads(wit.v);
             CoGroth16 prover(driver);

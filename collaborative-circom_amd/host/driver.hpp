@@ -10,6 +10,7 @@ namespace cgh {
 struct ShareVec {   // device; REP3 uses c[0] = a, c[1] = b; plain only c[0]
     void* c[2] = {nullptr, nullptr}; size_t n = 0;
     int32_t up[2] = {-1, -1}; cg_ctx* up_ctx = nullptr;   // asynchronous uploads still filling the components (copy tickets of up_ctx)
+    bool ready = false;                                   // filled by copies that had completed when the vector was handed out (no stream holds work on it)
 };
 struct FieldShare { Fr c[2]; };
 struct PointShare { Point c[2]; };
@@ -24,6 +25,9 @@ struct DeviceZKey {   // bases uploaded once and reused by every proof / party (
     // several GPUs: this device holds the records [aux_lo, aux_lo + aux_n) of the four private-witness queries (counted
     // from the first private variable) and [h_lo, h_lo + h_n) of h_query, registered as tables of their own (offset 0)
     bool sliced = false; size_t aux_lo = 0, aux_n = 0, h_lo = 0, h_n = 0;
+    // ... and the ROWS [h_lo, h_lo + h_n) of the two constraint matrices that are real constraints (rows_n of them; row_ptr rebased to 0):
+    // evaluate_constraint (groth16.rs:156-166) runs by rows on every device (multidev.hpp)
+    DeviceMatrix mat_rows[2] = {{nullptr, nullptr, nullptr, 0}, {nullptr, nullptr, nullptr, 0}};
     const struct SessionFixed* fixed = nullptr;          // a session's window tables of delta_1, delta_2 and the public-input records (host arithmetic)
 };
 // Fixed for the life of a zkey (zkey.rs:48-71) and multiplied by a scalar in EVERY proof (groth16.rs:220, :259-297): 8-bit window tables
@@ -389,7 +393,7 @@ public:
 
     void* dalloc(size_t bytes) { void* p; CG(cg_dev_alloc(ctx, bytes, &p)); return p; }
     ShareVec alloc_vec(size_t n) { ShareVec v; v.n = n; for (int j = 0; j < k(); j++) { v.c[j] = dalloc(n * 32); CG(cg_dev_memset_zero(ctx, v.c[j], n * 32)); } return v; }
-    void free_vec(ShareVec& v) { for (int j = 0; j < 2; j++) if (v.c[j]) { CG(cg_dev_free(ctx, v.c[j])); v.c[j] = nullptr; } }
+    void free_vec(ShareVec& v) { CG(cg_dev_free_many(ctx, v.c, 2)); v.c[0] = v.c[1] = nullptr; }
     // fence = false: the copies are started and this context's stream is NOT yet made to wait for them — the caller enqueues work that
     // does not read the shares (the masking draws of the two mul_vec calls) and then calls fence_uploads
     ShareVec upload_vec(const Fr* a, const Fr* b, size_t n, bool fence = true) {
@@ -404,6 +408,7 @@ public:
         }
         v.c[0] = dalloc(n * 32); CG(cg_dev_upload(ctx, v.c[0], a, n * 32));
         if (k() == 2) { v.c[1] = dalloc(n * 32); CG(cg_dev_upload(ctx, v.c[1], b, n * 32)); }
+        v.ready = true;
         return v;
     }
     void fence_uploads(const ShareVec& v) {                                           // this context's stream: behind the last copy (they complete in order)
@@ -458,7 +463,7 @@ public:
     std::vector<void*> deferred;                                                        // device buffers freed at the next quiet point
     void defer_free(void* p) { if (p) deferred.push_back(p); }
     void defer_vec(ShareVec& v) { for (int j = 0; j < 2; j++) { defer_free(v.c[j]); v.c[j] = nullptr; } }
-    void free_deferred() { for (void* p : deferred) CG(cg_dev_free(ctx, p)); deferred.clear(); }
+    void free_deferred() { if (!deferred.empty()) CG(cg_dev_free_many(ctx, deferred.data(), deferred.size())); deferred.clear(); }   // one release mark for all of them
     // host (pageable) -> device through the ring, asynchronous; returns the ticket of the last chunk
     int32_t upload_staged(void* d_dst, const Fr* src, size_t n) {
         int32_t tk = -1;
@@ -634,11 +639,11 @@ public:
     ShareVec mul_vec(const ShareVec& a, const ShareVec& b) { PendingMul pm = mul_vec_begin(a, b); ShareVec r = mul_vec_finish(pm); free_deferred(); return r; }
     // before the context goes away (idempotent; also run by the destructor when a party dies with an exception)
     void shutdown() {
-        for (void* p : deferred) cg_dev_free(ctx, p);
-        deferred.clear();
-        if (d_bad) { cg_dev_free(ctx, d_bad); d_bad = nullptr; }
-        for (auto& ms : prefetched) { if (ms.owns) cg_dev_free(ctx, ms.block ? ms.block : ms.m1); if (ms.m2) cg_dev_free(ctx, ms.m2); }
+        if (d_bad) { deferred.push_back(d_bad); d_bad = nullptr; }
+        for (auto& ms : prefetched) { if (ms.owns) deferred.push_back(ms.block ? ms.block : ms.m1); if (ms.m2) deferred.push_back(ms.m2); }
         prefetched.clear();
+        if (!deferred.empty()) cg_dev_free_many(ctx, deferred.data(), deferred.size());
+        deferred.clear();
         if (!mask_bufs.empty()) { cg_ctx_sync(ctx); for (void* p : mask_bufs) cg_host_free(p); mask_bufs.clear(); }   // uploads from them may still be in flight
         release_rings(); release_pre();
         if (aux) { if (owns_aux) cg_ctx_destroy(aux); aux = nullptr; }
@@ -761,6 +766,9 @@ public:
     // — one Jacobian point per table, component and device — are added on the host (RCCL has no EC-add reduction, and a few hundred
     // bytes per proof need no collective).  MSMProvider::msm_public_points (rep3.rs:934-947) is linear in the (scalar, point) pairs.
     const MultiDevice* md = nullptr;
+    // multi-device proofs whose entry point left the private witness on the HOST (ShareVec with null components): the distributed witness
+    // map uploads rows of these vectors over every device's own link (multidev.hpp)
+    const Fr* host_wit[2] = {nullptr, nullptr};
     PendingMsm msm_begin_sharded(const DeviceZKey& dz, bool aux_tables, const ShareVec& s) {
         const size_t lo = aux_tables ? dz.aux_lo : dz.h_lo, n = aux_tables ? dz.aux_n : dz.h_n;
         ShareVec mine; mine.n = n; for (int j = 0; j < k(); j++) mine.c[j] = (char*)s.c[j] + lo * 32;
@@ -827,7 +835,7 @@ public:
         if (p.on != ctx) {
             if (s.up_ctx) {                                                             // fresh uploads: component j's schedule waits for ITS copy on the device,
                 for (int j = 0; j < k(); j++) if (s.up[j] >= 0) CG(cg_msm_scalars_after(p.on, j, s.up_ctx, s.up[j]));   // a is accumulated while b is still crossing PCIe
-            } else CG(cg_ctx_sync(ctx));                                                // the scalars were produced on this driver's stream
+            } else if (!s.ready) CG(cg_ctx_sync(ctx));                                  // the scalars were produced on this driver's stream
         }
         begin_multi_ordered(p.on, tables, offsets, groups, n, sc, p.tickets);
         return p;

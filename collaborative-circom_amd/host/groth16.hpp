@@ -25,7 +25,9 @@ public:
     bool additive() const { return driver.additive_h && driver.mode != Mode::Plain; }
 
     // groth16.rs:141-204
-    ShareVec witness_map_from_matrices(const DeviceZKey& dz, const std::vector<Fr>& public_inputs, const ShareVec& private_witness) {
+    // after_first_launches (optional): called once the constraint evaluations, the first local product and the transforms of a and b are
+    // enqueued, before the host waits for the first exchange (prove() starts the witness-independent MSMs there on small circuits)
+    ShareVec witness_map_from_matrices(const DeviceZKey& dz, const std::vector<Fr>& public_inputs, const ShareVec& private_witness, const std::function<void()>& after_first_launches = nullptr) {
         const ZKey& z = *dz.z;
         const size_t num_inputs = z.n_public + 1, num_constraints = z.num_constraints;
         const Domain dom = groth16_domain(driver.curve, z.pow, num_constraints, num_inputs);          // :150-153
@@ -57,6 +59,7 @@ public:
         mk.mark("mul_vec_begin");
         driver.ifft_coset_fft_in_place2(a, b, dom.omega, dom.coset_g);                                 // :175-188: both vectors, both components, one sequence of launches
         mk.mark("ntt enqueue");
+        if (after_first_launches) { after_first_launches(); mk.mark("aux msm enqueued (late)"); }
         ShareVec c = driver.mul_vec_finish(c_pending);
         mk.mark("mul_vec_finish");
         auto ab_pending = driver.mul_vec_begin(a, b);                                                  // :190
@@ -106,23 +109,42 @@ public:
         // 384-byte (BN254) message is added; all three parties must run the variant.
         const bool add_h = additive();
         std::unique_ptr<HipDriver::Components> own(add_h ? new HipDriver::Components(driver, 1) : nullptr);   // (Shamir has one component anyway)
-        auto aux_msm = dz.sliced ? driver.msm_begin_sharded(dz, true, private_witness)
-                                 : driver.msm_begin_multi({dz.a, dz.b1, dz.b2, dz.l}, {first_aux, first_aux, first_aux, 0}, {CG_G1, CG_G1, CG_G2, CG_G1}, private_witness.n, private_witness, true);
-        own.reset();
-        mk.mark("aux msm enqueued");
-        // Several GPUs: the witness map itself is spread over them (multidev.hpp) and every device multiplies its own rows of h
+        // Several GPUs: the witness goes up by rows, the witness map itself is spread over the devices (multidev.hpp) and every device
+        // multiplies its own rows of the witness and of h
         const bool distributed = DistributedWitnessMap::usable(driver, dz);
         std::unique_ptr<DistributedWitnessMap> dmap;
+        HipDriver::PendingMsm aux_msm;
+        if (distributed) {
+            dmap.reset(new DistributedWitnessMap(driver, dz, *driver.md));
+            const bool from_host = private_witness.c[0] == nullptr;                                   // the entry left the vectors on the host (driver.host_wit)
+            if (from_host && !driver.host_wit[0]) throw std::runtime_error("multi-device proof: no witness given");
+            dmap->place_witness(driver.host_wit[0], driver.host_wit[1], from_host ? nullptr : &private_witness, private_witness.n, public_inputs);
+            aux_msm = dmap->begin_aux_msms();
+            dmap->gather_witness(from_host);
+        }
+        // Small REP3 circuits (the two mul_vec exchanges are single synchronous messages): the witness map is a chain of short kernels and
+        // two host round trips, and kernels of another stream only get onto the chip as the accumulations' workgroups retire (a 2^16 party:
+        // the chain's first kernel waited 1.3 ms for a slot).  The chain's first leg — constraint rows, first product, transforms of a and
+        // b — is therefore enqueued FIRST, on an idle chip, and the witness-independent MSMs right behind it, while the host would wait
+        // for the first exchange anyway.  MSMs involve no network: the message order is untouched.
+        static const bool late_knob = !getenv("CGH_NO_LATE_AUX");                                     // A/B knob
+        const bool late_aux = late_knob && !distributed && !dz.sliced && !add_h && driver.mode == Mode::Rep3 && private_witness.n < driver.XCHG_ASYNC_MIN;
+        auto begin_aux = [&] {
+            aux_msm = dz.sliced ? driver.msm_begin_sharded(dz, true, private_witness)
+                                : driver.msm_begin_multi({dz.a, dz.b1, dz.b2, dz.l}, {first_aux, first_aux, first_aux, 0}, {CG_G1, CG_G1, CG_G2, CG_G1}, private_witness.n, private_witness, true);
+        };
+        if (!distributed && !late_aux) begin_aux();
+        own.reset();
+        mk.mark("aux msm enqueued");
         struct HParts : DistributedH {     // the rows of h on their devices: released when prove leaves, however it leaves (after the map's own buffers)
-            ~HParts() { for (auto& part : parts) for (int j = 0; j < 2; j++) if (part.h.c[j]) cg_dev_free(part.ctx, part.h.c[j]); }
+            ~HParts() { for (auto& part : parts) cg_dev_free_many(part.ctx, part.h.c, 2); }
         } dh;
         VecGuard hg(driver);               // the quotient vector is released when prove leaves, however it leaves (a failing network round, invalid data)
         ShareVec& h = hg.v;
         HipDriver::PendingMsm h_msm;
         if (distributed) {
             if (h_out) throw std::runtime_error("the quotient vector of a multi-device proof stays distributed (h_out is a single-device option)");
-            dmap.reset(new DistributedWitnessMap(driver, dz, *driver.md));
-            static_cast<DistributedH&>(dh) = dmap->run(dz, public_inputs, private_witness);
+            static_cast<DistributedH&>(dh) = dmap->run(dz, public_inputs);
             mk.mark("witness map (distributed)");
             const int hk = add_h ? 1 : driver.k();                                                     // the variant's h has one component
             h_msm.on = driver.ctx; h_msm.groups = {CG_G1}; h_msm.tickets.resize(1); h_msm.k = hk;
@@ -143,7 +165,7 @@ public:
         // few small synchronous uploads of the MSM set-up (the copy engine serves its requests in order), ahead of everything else
         if (driver.prefetched.empty()) driver.prefetch_masks(2, groth16_domain(c, z.pow, z.num_constraints, public_inputs.size()).m);   // (a party entry draws them before its shares have arrived)
         mk.mark("mask uploads enqueued");
-        h = witness_map_from_matrices(dz, public_inputs, private_witness);
+        h = witness_map_from_matrices(dz, public_inputs, private_witness, late_aux ? std::function<void()>(begin_aux) : nullptr);
         mk.mark("witness map");
         if (add_h) own.reset(new HipDriver::Components(driver, 1));
         h_msm = dz.sliced ? driver.msm_begin_sharded(dz, false, h) : driver.msm_begin_multi({dz.h}, {0}, {CG_G1}, h.n, h, false);   // :248
@@ -260,6 +282,17 @@ static DeviceZKey upload_zkey(cg_ctx* ctx, const ZKey& z, const std::vector<Fr>&
         d.a = reg(cut(z.a_query, CG_G1, first_aux + d.aux_lo, d.aux_n), CG_G1, "a_query"); d.b1 = reg(cut(z.b_g1_query, CG_G1, first_aux + d.aux_lo, d.aux_n), CG_G1, "b_g1_query");
         d.b2 = reg(cut(z.b_g2_query, CG_G2, first_aux + d.aux_lo, d.aux_n), CG_G2, "b_g2_query");
         d.l = reg(cut(z.l_query, CG_G1, d.aux_lo, d.aux_n), CG_G1, "l_query"); d.h = reg(cut(z.h_query, CG_G1, d.h_lo, d.h_n), CG_G1, "h_query");
+        // this device's rows of the two matrices (constraint rows only: rows past num_constraints are the zero / public-input rows of the domain)
+        const size_t r0 = std::min<size_t>(d.h_lo, z.num_constraints), r1 = std::min<size_t>(d.h_lo + d.h_n, z.num_constraints);
+        for (int m = 0; m < 2; m++) {
+            const uint32_t base = z.row_ptr[m][r0];
+            std::vector<uint32_t> rp(r1 - r0 + 1);
+            for (size_t i = 0; i <= r1 - r0; i++) rp[i] = z.row_ptr[m][r0 + i] - base;
+            d.mat_rows[m].row_ptr = (uint32_t*)up(rp.data(), rp.size() * 4);
+            d.mat_rows[m].col = (uint32_t*)up(z.col[m].data() + base, (size_t)rp.back() * 4);
+            d.mat_rows[m].coeff = up(z.coeff[m].data() + base, (size_t)rp.back() * 32);
+            d.mat_rows[m].rows = r1 - r0;
+        }
         if (rank != 0) { undo.armed = false; return d; }
     } else {
         d.a = reg(z.a_query, CG_G1, "a_query"); d.b1 = reg(z.b_g1_query, CG_G1, "b_g1_query"); d.b2 = reg(z.b_g2_query, CG_G2, "b_g2_query");
@@ -277,9 +310,9 @@ static DeviceZKey upload_zkey(cg_ctx* ctx, const ZKey& z, const std::vector<Fr>&
 }
 static void release_zkey(cg_ctx* ctx, DeviceZKey& d) {
     for (cg_bases** b : {&d.a, &d.b1, &d.b2, &d.l, &d.h}) { if (*b) cg_bases_release(*b); *b = nullptr; }
-    for (int m = 0; m < 2; m++) {
-        if (d.mat[m].row_ptr) cg_dev_free(ctx, d.mat[m].row_ptr); if (d.mat[m].col) cg_dev_free(ctx, d.mat[m].col); if (d.mat[m].coeff) cg_dev_free(ctx, d.mat[m].coeff);
-        d.mat[m] = DeviceMatrix{nullptr, nullptr, nullptr, 0};
+    for (int m = 0; m < 2; m++) for (DeviceMatrix* mt : {&d.mat[m], &d.mat_rows[m]}) {
+        if (mt->row_ptr) cg_dev_free(ctx, mt->row_ptr); if (mt->col) cg_dev_free(ctx, mt->col); if (mt->coeff) cg_dev_free(ctx, mt->coeff);
+        *mt = DeviceMatrix{nullptr, nullptr, nullptr, 0};
     }
     if (d.pub_dev) cg_dev_free(ctx, d.pub_dev);
     d.pub_dev = nullptr;

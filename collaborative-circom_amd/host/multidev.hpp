@@ -1,14 +1,19 @@
 // witness_map_from_matrices (co-circom/co-groth16/src/groth16.rs:141-204) of ONE party over SEVERAL GPUs of its node:
+//   * the private witness goes up BY ROWS: device d uploads rows [aux_lo_d, aux_lo_d + aux_n_d) of the caller's host vectors over ITS PCIe link
+//     (1/N of 2 x 32 B x n_aux per link instead of all of it over the primary's) — the rows its slices of the four aux queries multiply, so its
+//     MSMs start as soon as they land — and the devices then complete their copies from each other (all-gather of row blocks, xGMI);
+//   * evaluate_constraint (:156-166) runs by ROWS as well: device d holds rows [lo_d, lo_d + n_d) of both matrices (DeviceZKey::mat_rows, the
+//     same split as its slice of h_query) and evaluates them against its full copy of the witness;
 //   * the six vector pipelines iNTT -> coset shift -> NTT (a.a, a.b, b.a, b.b, then c.a, c.b; groth16.rs:175-200) run one vector per device
-//     ("owner" of the vector), whole vectors travelling device to device (cg_dev_copy_peer: xGMI between different GPUs);
-//   * the two mul_vec calls (:174, :190; rep3.rs:650-670) are cut by ROWS: device d multiplies rows [lo_d, lo_d + n_d) — the same split as
-//     its slice of h_query — with its slice of the masks uploaded over its own PCIe link, its slice of the local product downloaded
-//     over its own link, and the previous party's slice uploaded to it; the host thread moves the messages in the reference's order
-//     (one vector = chunks of at most 4 MiB in index order, whatever devices they come from: the peers need not know);
+//     ("owner" of the vector), which gathers the vector's rows from the devices that hold them and hands rows back (cg_dev_copy_peer);
+//   * the two mul_vec calls (:174, :190; rep3.rs:650-670) are cut by the same rows: device d multiplies its rows with its slice of the masks,
+//     its slice of the local product goes down over its own link and the previous party's slice comes up over it; the host thread moves the
+//     messages in the reference's order (one vector = chunks of at most 4 MiB in index order, whatever devices they come from: the peers need
+//     not know);
 //   * h = a.b - c (:202) is formed where its rows are, and the h MSM of a device runs over its own table slice and its own rows: the
 //     quotient vector is never gathered.
-// The primary device (the driver's context) evaluates the constraints (:156-171) and hands out the rows and vectors.  Values are those
-// of the single-device path bit for bit: the same kernels on the same numbers, only placed elsewhere.
+// Nothing but the draws of the masking vectors (one stream position depends on the rejections before it) is left to the primary device.
+// Values are those of the single-device path bit for bit: the same kernels on the same numbers, only placed elsewhere.
 // Modes: Plain and Rep3 (Shamir's degree reduction keeps the single-device path).  Devices: [primary] + md->workers, in table-slice order.
 #pragma once
 #include "driver.hpp"
@@ -28,6 +33,9 @@ public:
     const int kc;                              // components of c and h
     struct Dev {
         cg_ctx* ctx = nullptr; const DeviceZKey* dz = nullptr; size_t lo = 0, n = 0;
+        cg_ctx* msm = nullptr;                                                     // the context that carries this device's MSM slices
+        void* wit[2] = {nullptr, nullptr}; int32_t wit_up[2] = {-1, -1};          // full copy of the private witness (components); upload of its own rows
+        void* pub = nullptr;                                                       // the public inputs on this device
         void* av[2] = {nullptr, nullptr}; void* bv[2] = {nullptr, nullptr};      // rows of a and b (components)
         void* prod = nullptr; void* recv = nullptr;                                // mul_vec result rows: local component, received component
         int32_t up_tk = -1;                                                        // last upload into this device
@@ -40,16 +48,16 @@ public:
 
     DistributedWitnessMap(HipDriver& d, const DeviceZKey& dz0, const MultiDevice& md)
         : drv(d), curve(d.curve), k(d.k()), additive(d.additive_h && d.mode == Mode::Rep3), kc(additive ? 1 : d.k()), primary_only(getenv("CGH_EMULATE_PRIMARY_ONLY") != nullptr) {
-        Dev p; p.ctx = d.ctx; p.dz = &dz0; p.lo = dz0.h_lo; p.n = dz0.h_n; devs.push_back(p);
-        for (const WorkerDevice& w : md.workers) { Dev x; x.ctx = w.chain ? w.chain : w.ctx; x.dz = w.dz; x.lo = w.dz->h_lo; x.n = w.dz->h_n; devs.push_back(x); }
+        Dev p; p.ctx = d.ctx; p.msm = d.aux ? d.aux : d.ctx; p.dz = &dz0; p.lo = dz0.h_lo; p.n = dz0.h_n; devs.push_back(p);
+        for (const WorkerDevice& w : md.workers) { Dev x; x.ctx = w.chain ? w.chain : w.ctx; x.msm = w.ctx; x.dz = w.dz; x.lo = w.dz->h_lo; x.n = w.dz->h_n; devs.push_back(x); }
     }
     static bool usable(const HipDriver& d, const DeviceZKey& dz0) {
         const bool off = getenv("CGH_NO_DISTRIBUTED_MAP") != nullptr;              // A/B knob (read per proof): keep the whole witness map on the primary device
         return !off && d.md && !d.md->workers.empty() && dz0.sliced && (d.mode == Mode::Plain || d.mode == Mode::Rep3);
     }
     ~DistributedWitnessMap() {
-        for (Dev& d : devs) cg_ctx_sync(d.ctx);                                    // blocks of one device are read by the others' peer copies: all quiet first
-        for (Dev& d : devs) for (void* p : d.owned) cg_dev_free(d.ctx, p);
+        for (Dev& d : devs) { cg_ctx_sync(d.ctx); if (d.msm && d.msm != d.ctx && std::uncaught_exceptions() > 0) cg_ctx_sync(d.msm); }   // blocks of one device are read by the others' peer copies: all quiet first (a proof that died may have MSMs in flight over its witness copy)
+        for (Dev& d : devs) if (!d.owned.empty()) cg_dev_free_many(d.ctx, d.owned.data(), d.owned.size());   // one release mark per device
         for (void* p : pinned) cg_host_free(p);
         for (void* p : host_tmp) free(p);
     }
@@ -182,60 +190,134 @@ public:
         for (Dev& D : devs) if (D.bad) { uint64_t bad = 0; CG(cg_dev_download(D.ctx, &bad, D.bad, 8)); total += bad; }
         if (total) throw std::runtime_error("invalid data: " + std::to_string(total) + " field element(s) of a vector received from a peer are not below the modulus");
     }
-    // rows [D.lo, D.lo + D.n) of whole vectors `src[j]` (on device `from`) into D's row buffers dst[j]
-    void rows_to(Dev& D, void* const* dst, Dev& from, void* const* src) {
-        for (int j = 0; j < k; j++) CG(cg_dev_copy_peer(D.ctx, dst[j], from.ctx, (const uint8_t*)src[j] + D.lo * 32, D.n * 32));
+    // ---- step 0: the private witness on every device.  host_a / host_b (the caller's vectors): every device uploads its own rows over its own
+    // link, then the row blocks travel device to device.  resident (a vector the caller already holds on the primary device): whole copies.
+    size_t n_aux = 0;
+    void place_witness(const Fr* host_a, const Fr* host_b, const ShareVec* resident, size_t n, const std::vector<Fr>& public_inputs) {
+        n_aux = n;
+        const bool async = n >= drv.XCHG_ASYNC_MIN;
+        // the public inputs first (a few elements, read by the constraint rows that mention them): one page-locked copy, uploaded everywhere
+        void* pp = nullptr; CG(cg_host_alloc(std::max<size_t>(public_inputs.size(), 1) * 32, &pp)); pinned.push_back(pp);
+        memcpy(pp, public_inputs.data(), public_inputs.size() * 32);
+        for (size_t d = 0; d < devs.size(); d++) {
+            Dev& D = devs[d];
+            D.pub = dalloc(D, public_inputs.size() * 32);
+            for (int j = 0; j < k; j++) D.wit[j] = dalloc(D, n * 32);
+            if (skip(d)) continue;
+            CG(cg_dev_upload_begin(D.ctx, D.pub, pp, public_inputs.size() * 32, 0, &D.up_tk));
+            if (resident) continue;
+            const size_t lo = D.dz->aux_lo, cnt = D.dz->aux_n;
+            for (int j = 0; j < k; j++) {
+                const Fr* src = (j == 0 ? host_a : host_b) + lo;
+                if (!cnt) continue;
+                if (async && cg_host_is_pinned(src)) { CG(cg_dev_upload_begin(D.ctx, (uint8_t*)D.wit[j] + lo * 32, src, cnt * 32, 0, &D.wit_up[j])); D.up_tk = D.wit_up[j]; }
+                else CG(cg_dev_upload(D.ctx, (uint8_t*)D.wit[j] + lo * 32, src, cnt * 32));
+            }
+        }
+        if (resident) {
+            for (size_t d = 0; d < devs.size(); d++) if (!skip(d)) for (int j = 0; j < k; j++)
+                CG(cg_dev_copy_peer(devs[d].ctx, devs[d].wit[j], drv.ctx, resident->c[j], n * 32));
+        }
+    }
+    // the rows device d multiplies in its MSM slices of the four aux queries: [aux_lo_d, aux_lo_d + aux_n_d) of its own copy (still on their
+    // way up, possibly: the schedules wait for the copies on the device)
+    ShareVec aux_rows(size_t d) const {
+        const Dev& D = devs[d];
+        ShareVec v; v.n = D.dz->aux_n;
+        for (int j = 0; j < k; j++) { v.c[j] = (uint8_t*)D.wit[j] + D.dz->aux_lo * 32; v.up[j] = D.wit_up[j]; }
+        if (D.wit_up[0] >= 0) v.up_ctx = D.ctx;
+        return v;
+    }
+    // the four aux MSMs (groth16.rs:251,267,284,298), every device over its own table slices and its own rows, enqueued from one host
+    // thread per device (a launch sequence costs the host ~0.3 ms; eight in a row would be the critical path of an eight-GPU proof)
+    HipDriver::PendingMsm begin_aux_msms() {
+        HipDriver::PendingMsm p;
+        const DeviceZKey& dz0 = *devs[0].dz;
+        const int kk = drv.k();                                                        // share components multiplied (the additive variant: the own one)
+        std::vector<std::thread> th; std::vector<std::string> errs(devs.size());
+        std::vector<HipDriver::PendingMsm::Part> parts(devs.size());
+        struct Joined { std::vector<std::thread>& t; ~Joined() { for (auto& x : t) if (x.joinable()) x.join(); } } joined{th};
+        for (size_t d = 1; d < devs.size(); d++) {
+            if (skip(d)) continue;
+            th.emplace_back([this, d, kk, &parts, &errs] {
+                try {
+                    const Dev& D = devs[d]; const DeviceZKey& wz = *D.dz;
+                    const ShareVec sv = aux_rows(d);
+                    HipDriver::PendingMsm::Part part{D.msm, std::vector<int32_t>(4), {nullptr, nullptr}};
+                    if (sv.up_ctx) { for (int j = 0; j < kk; j++) if (sv.up[j] >= 0) CG(cg_msm_scalars_after(D.msm, j, sv.up_ctx, sv.up[j])); }
+                    else CG(cg_ctx_sync(D.ctx));                                         // synchronous uploads / peer copies on the chain context's stream
+                    const void* sc[2] = {sv.c[0], sv.c[1]};
+                    drv.begin_multi_ordered(D.msm, {wz.a, wz.b1, wz.b2, wz.l}, {0, 0, 0, 0}, {CG_G1, CG_G1, CG_G2, CG_G1}, sv.n, sc, part.tickets);
+                    parts[d] = part;
+                } catch (const std::exception& e) { errs[d] = e.what(); }
+            });
+        }
+        if (!drv.aux && devs[0].up_tk >= 0) CG(cg_copy_fence(drv.ctx, devs[0].up_tk));    // one context: its own stream carries the schedules
+        p = drv.msm_begin_multi({dz0.a, dz0.b1, dz0.b2, dz0.l}, {0, 0, 0, 0}, {CG_G1, CG_G1, CG_G2, CG_G1}, dz0.aux_n, aux_rows(0), true);
+        for (auto& x : th) x.join();
+        for (const std::string& e : errs) if (!e.empty()) throw std::runtime_error(e);
+        for (size_t d = 1; d < devs.size(); d++) if (!skip(d)) p.parts.push_back(parts[d]);
+        return p;
+    }
+    // all-gather of the row blocks: every device completes its copy of the witness from the devices that uploaded the other rows
+    void gather_witness(bool from_rows) {
+        if (!from_rows) return;
+        for (size_t d = 0; d < devs.size(); d++) if (!skip(d) && devs[d].up_tk >= 0) CG(cg_copy_fence(devs[d].ctx, devs[d].up_tk));   // own rows (and the public inputs) have landed
+        for (size_t d = 0; d < devs.size(); d++) {
+            if (skip(d)) continue;
+            Dev& D = devs[d];
+            for (size_t s_ = 0; s_ < devs.size(); s_++) {
+                if (s_ == d) continue;
+                const Dev& S = devs[s_];
+                const size_t lo = S.dz->aux_lo, cnt = S.dz->aux_n;
+                if (!cnt) continue;
+                for (int j = 0; j < k; j++) CG(cg_dev_copy_peer(D.ctx, (uint8_t*)D.wit[j] + lo * 32, S.ctx, (const uint8_t*)S.wit[j] + lo * 32, cnt * 32));
+            }
+        }
     }
 
-    DistributedH run(const DeviceZKey& dz, const std::vector<Fr>& public_inputs, const ShareVec& private_witness) {
+    DistributedH run(const DeviceZKey& dz, const std::vector<Fr>& public_inputs) {
         const ZKey& z = *dz.z;
         const size_t num_inputs = z.n_public + 1, num_constraints = z.num_constraints;
         const Domain dom = groth16_domain(curve, z.pow, num_constraints, num_inputs);          // groth16.rs:150-153
         const size_t m = dom.m, nd = devs.size();
-        Dev& P0 = devs[0];
-        // :156-171 on the primary device
-        ShareVec a = drv.evaluate_constraints(dz.mat[0], dz.pub_dev, (uint32_t)num_inputs, private_witness, m);
-        ShareVec b = drv.evaluate_constraints(dz.mat[1], dz.pub_dev, (uint32_t)num_inputs, private_witness, m);
-        for (int j = 0; j < k; j++) { P0.owned.push_back(a.c[j]); P0.owned.push_back(b.c[j]); }
-        drv.clone_public_into(a, num_constraints, public_inputs, dz.pub_dev);
-        // whole vectors to their owners (vector index: a components 0..k-1, b components k..2k-1, c components 2k..3k-1)
-        std::vector<void*> vec((size_t)2 * k + kc, nullptr);
-        for (int j = 0; j < k; j++) { vec[j] = a.c[j]; vec[k + j] = b.c[j]; }
-        for (int v = 0; v < 2 * k; v++) {
-            const size_t o = owner(v);
-            if (o == 0) continue;
-            void* dst = dalloc(devs[o], m * 32);
-            CG(cg_dev_copy_peer(devs[o].ctx, dst, P0.ctx, vec[v], m * 32));
-            vec[v] = dst;
-        }
-        // rows of a and b for the first product (:174), then the pipelines of a and b on their owners (:175-188) under the exchange
+        const int party = drv.party();
+        const int holder = drv.public_component();                                             // promote_to_trivial_shares: who holds a public value (fieldshare.rs:262-283)
+        // :156-171 by rows: rows [lo_d, lo_d + n_d) of a and b on device d (zero past the constraints, the public inputs spliced in at
+        // [num_constraints, num_constraints + num_inputs) of a)
         for (size_t d = 0; d < nd; d++) {
             Dev& D = devs[d];
-            if (d == 0) { for (int j = 0; j < k; j++) { D.av[j] = (uint8_t*)a.c[j] + D.lo * 32; D.bv[j] = (uint8_t*)b.c[j] + D.lo * 32; } continue; }
             for (int j = 0; j < k; j++) { D.av[j] = dalloc(D, D.n * 32); D.bv[j] = dalloc(D, D.n * 32); }
-            rows_to(D, D.av, P0, a.c); rows_to(D, D.bv, P0, b.c);
+            if (skip(d) || !D.n) continue;
+            if (D.up_tk >= 0) CG(cg_copy_fence(D.ctx, D.up_tk));
+            for (int j = 0; j < k; j++) { CG(cg_dev_memset_zero(D.ctx, D.av[j], D.n * 32)); CG(cg_dev_memset_zero(D.ctx, D.bv[j], D.n * 32)); }
+            const DeviceMatrix* mt = D.dz->mat_rows;
+            if (mt[0].rows) CG(cg_spmv_csr_dev(D.ctx, curve.id, mt[0].row_ptr, mt[0].col, mt[0].coeff, mt[0].rows, D.pub, (uint32_t)num_inputs, party, D.wit[0], D.wit[1], D.av[0], D.av[1]));
+            if (mt[1].rows) CG(cg_spmv_csr_dev(D.ctx, curve.id, mt[1].row_ptr, mt[1].col, mt[1].coeff, mt[1].rows, D.pub, (uint32_t)num_inputs, party, D.wit[0], D.wit[1], D.bv[0], D.bv[1]));
+            const size_t p0 = std::max(num_constraints, D.lo), p1 = std::min(num_constraints + num_inputs, D.lo + D.n);
+            if (holder >= 0 && p0 < p1) CG(cg_dev_copy_peer(D.ctx, (uint8_t*)D.av[holder] + (p0 - D.lo) * 32, D.ctx, (const uint8_t*)D.pub + (p0 - num_constraints) * 32, (p1 - p0) * 32));
         }
-        // the primary's own rows are read in place by its product; its copies of a / b must not be transformed before that product ran:
-        // vectors the primary owns are transformed in a private copy
-        for (int v = 0; v < 2 * k; v++) if (owner(v) == 0) { void* cp = dalloc(P0, m * 32); CG(cg_dev_copy_peer(P0.ctx, cp, P0.ctx, vec[v], m * 32)); vec[v] = cp; }
+        // whole vectors on their owners, gathered from the rows (vector index: a components 0..k-1, b components k..2k-1, c components 2k..3k-1)
+        std::vector<void*> vec((size_t)2 * k + kc, nullptr);
+        auto gather_vector = [&](int v, auto&& rows_of) {                                       // rows_of(d): device d's rows of vector v
+            Dev& O = devs[owner(v)];
+            vec[v] = dalloc(O, m * 32);
+            if (skip(owner(v))) return;
+            for (size_t d = 0; d < nd; d++) { Dev& D = devs[d]; if (D.n) CG(cg_dev_copy_peer(O.ctx, (uint8_t*)vec[v] + D.lo * 32, D.ctx, rows_of(d), D.n * 32)); }
+        };
+        for (int j = 0; j < k; j++) { gather_vector(j, [&](size_t d) { return devs[d].av[j]; }); gather_vector(k + j, [&](size_t d) { return devs[d].bv[j]; }); }
+        // the pipelines of a and b on their owners (:175-188) under the first product's exchange (:174)
         mul_rows_begin_pipelines(vec, 0, 2 * k, dom);                                          // enqueued on the owners' streams
         mul_rows(m);                                                                           // :174 -> rows of c on every device
         // c: rows to the owners of its components, pipelines there (:194-200)
         std::vector<void*> crow_a(nd), crow_b(nd);
         for (size_t d = 0; d < nd; d++) { crow_a[d] = devs[d].prod; crow_b[d] = devs[d].recv; }
-        for (int j = 0; j < kc; j++) {
-            Dev& O = devs[owner(2 * k + j)];
-            vec[2 * k + j] = dalloc(O, m * 32);
-            for (size_t d = 0; d < nd; d++) {
-                Dev& D = devs[d];
-                if (D.n) CG(cg_dev_copy_peer(O.ctx, (uint8_t*)vec[2 * k + j] + D.lo * 32, D.ctx, j == 0 ? crow_a[d] : crow_b[d], D.n * 32));
-            }
-        }
+        for (int j = 0; j < kc; j++) gather_vector(2 * k + j, [&](size_t d) { return j == 0 ? crow_a[d] : crow_b[d]; });
         mul_rows_begin_pipelines(vec, 2 * k, 2 * k + kc, dom);
-        // rows of the transformed a and b for the second product (:190)
+        // rows of the transformed a and b for the second product (:190): back into the row buffers the first product has read
         for (size_t d = 0; d < nd; d++) {
             Dev& D = devs[d];
-            if (d == 0) for (int j = 0; j < k; j++) { D.av[j] = dalloc(D, D.n * 32); D.bv[j] = dalloc(D, D.n * 32); }
+            if (skip(d) || !D.n) continue;
             for (int j = 0; j < k; j++) {
                 CG(cg_dev_copy_peer(D.ctx, D.av[j], devs[owner(j)].ctx, (const uint8_t*)vec[j] + D.lo * 32, D.n * 32));
                 CG(cg_dev_copy_peer(D.ctx, D.bv[j], devs[owner(k + j)].ctx, (const uint8_t*)vec[k + j] + D.lo * 32, D.n * 32));
@@ -249,8 +331,9 @@ public:
             ShareVec h; h.n = D.n; h.c[0] = D.prod; h.c[1] = kc == 2 ? D.recv : nullptr;
             for (int j = 0; j < kc; j++) {
                 void* crow = dalloc(D, D.n * 32);
+                if (skip(d) || !D.n) continue;
                 CG(cg_dev_copy_peer(D.ctx, crow, devs[owner(2 * k + j)].ctx, (const uint8_t*)vec[2 * k + j] + D.lo * 32, D.n * 32));
-                if (!skip(d) && D.n) CG(cg_vec_sub_dev(D.ctx, curve.id, h.c[j], h.c[j], crow, D.n));
+                CG(cg_vec_sub_dev(D.ctx, curve.id, h.c[j], h.c[j], crow, D.n));
             }
             release(D, h.c[0]); if (h.c[1]) release(D, h.c[1]);                                // handed to the caller
             out.parts.push_back({D.ctx, h});

@@ -67,6 +67,9 @@ const char* cg_version(void);
  * completed before the call.  CG_DEV_CACHE_MB bounds the parked bytes per device (0: release at once, which waits for the device). */
 int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr);
 int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr);
+/* n blocks released together (NULL entries are skipped): one release mark behind the context's streams for all of them instead of one each —
+ * what a prover does with the vectors of a finished witness map */
+int32_t cg_dev_free_many(cg_ctx* ctx, void* const* d_ptrs, size_t n);
 /* Gives the blocks parked by cg_dev_free on `device` back to the runtime (hipFree: stalls until the device is idle — call it when it is:
  * between proofs of different circuits, when a session closes).  Parked blocks are only reused by allocations of exactly their size;
  * without this a process that moves on to another circuit keeps up to CG_DEV_CACHE_MB of them, and once that bound is reached every
@@ -193,7 +196,8 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *                                  component and field, 0 = each on its own right behind its accumulation
  *   CG_OPT_MSM_ACC_SLOTS           rotating scratch slots of the accumulate / reduce pipeline (2 .. 8; batches take one per set)    4
  *   CG_OPT_MSM_WIDE_SMALL          1 = calls of at most 2^20 (point, window) entries and two share components launch all accumulations    1
- *                                  of a coordinate field side by side (one launch, one reduction batch per field)
+ *                                  of a coordinate field side by side (one launch, one reduction batch per field); 10 .. 30 = the same
+ *                                  with 2^value entries as the bound (table slices of a multi-GPU plan: 2^19 points x 15 windows); 0 = off
  * Environment variables of the same names (CG_OPT_... without the prefix: CG_MSM_CHUNK, ...) seed the defaults of NEW contexts for A/B runs. */
 enum { CG_OPT_MSM_CHUNK = 1, CG_OPT_MSM_WINDOW = 2, CG_OPT_MSM_SCATTER_CAP = 3, CG_OPT_MSM_TABLE_ORDER = 4, CG_OPT_MSM_G2_SLICES = 5,
        CG_OPT_MSM_REDUCE_BATCH = 6, CG_OPT_MSM_ACC_SLOTS = 7, CG_OPT_MSM_G2_AFTER = 8, CG_OPT_MSM_WIDE_SMALL = 9, CG_OPT_COUNT_ };
