@@ -124,8 +124,18 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
             s->dzs[d] = upload_zkey(s->ctx0[d], s->z, pub, (flags & 1u) ? 0 : -1, d, n_dev);
             s->dzs[d].z = &s->z;
         }
+        // Window of the per-window tables.  Large tables: the library's choice by table size (c = 0).  SMALL circuits get ONE window for all five
+        // tables (tables of one MSM call that differ in window run as separate sub-calls), chosen for latency: few buckets — the bucket
+        // reduction is a tree of full additions, 12 us a level — and a top window that is nearly full (254 = 8 * 31 + 6 = 13 * 19 + 7: with
+        // c = 12 the top window has 2 bits and a quarter of all points land in each of its 4 buckets).  Measured on the Poseidon fixture
+        // (m = 256) and at 2^12, one REP3 party: c = 16 3.66 / 3.13 ms, c = 13 3.00 / 2.94, c = 8 2.84 / - (profiles/r05_small_circuit_ab2.txt).
+        int window = precompute > 0 ? precompute : 0;
+        if (precompute < 0) {
+            const size_t nmax = std::max<size_t>(s->z.n_vars, s->z.domain_size) / (size_t)n_dev;
+            if (nmax <= ((size_t)1 << 10)) window = 8; else if (nmax <= ((size_t)1 << 13)) window = 13;
+        }
         if (precompute) for (int d = 0; d < n_dev; d++) for (cg_bases* b : {s->dzs[d].a, s->dzs[d].b1, s->dzs[d].b2, s->dzs[d].l, s->dzs[d].h})
-            if (cg_bases_len(b)) CG(cg_bases_precompute(s->ctx0[d], b, precompute > 0 ? precompute : 0));
+            if (cg_bases_len(b)) CG(cg_bases_precompute(s->ctx0[d], b, window));
         {   // window tables of the bases every proof multiplies by a scalar, built side by side while the devices finish their set-up
             const ZKey& z = s->z; const Curve& c = z.curve;
             const size_t np = std::min<size_t>(z.n_public, SessionFixed::MAX_PUBLIC);

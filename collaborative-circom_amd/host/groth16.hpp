@@ -127,7 +127,7 @@ public:
         // the chain's first kernel waited 1.3 ms for a slot).  The chain's first leg — constraint rows, first product, transforms of a and
         // b — is therefore enqueued FIRST, on an idle chip, and the witness-independent MSMs right behind it, while the host would wait
         // for the first exchange anyway.  MSMs involve no network: the message order is untouched.
-        static const bool late_knob = !getenv("CGH_NO_LATE_AUX");                                     // A/B knob
+        static const bool late_knob = getenv("CGH_LATE_AUX") != nullptr;                              // A/B knob; measured SLOWER on MI355X (2^16: 3.68 -> 3.86 ms, 2^14: 2.73 -> 2.94, profiles/r05_small_circuit_ab2.txt): off
         const bool late_aux = late_knob && !distributed && !dz.sliced && !add_h && driver.mode == Mode::Rep3 && private_witness.n < driver.XCHG_ASYNC_MIN;
         auto begin_aux = [&] {
             aux_msm = dz.sliced ? driver.msm_begin_sharded(dz, true, private_witness)

@@ -19,7 +19,7 @@
  *                 CGH_BULK_CHUNK (64) / CGH_PLAIN_CHUNK (0)   CG_OPT_MSM_CHUNK of the bulk context beside a REP3 chain (>= 2^20 elements) / otherwise
  *                 CGH_G2_ORDER=first, CGH_G2_AFTER (2)        launch order of the aux MSMs' (table, component) pairs (HipDriver::begin_multi_ordered)
  *                 CGH_NO_DISTRIBUTED_MAP (read per proof)     multi-device sessions keep the witness map on the primary device
- *                 CGH_NO_LATE_AUX                             small REP3 proofs start the witness-independent MSMs before the witness map, as large ones do
+ *                 CGH_LATE_AUX                                small REP3 proofs start the witness-independent MSMs behind the witness map's first leg (measured slower: off)
  *   planning      CGH_EMULATE_PRIMARY_ONLY      times the primary device's share of a multi-device proof on one GPU: THE PROOF IS WRONG
  *
  * Conventions: every function returns 0 on success; on failure a non-zero value, message from cgh_last_error() (thread local).
