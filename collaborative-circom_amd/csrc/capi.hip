@@ -1533,7 +1533,12 @@ static int32_t bases_register_impl(cg_ctx* ctx, int32_t curve, int32_t group, co
             const size_t words = pt / 8;
             for (size_t i = 0; i < n; i++) { uint64_t any = 0; for (size_t q = 0; q < words; q++) any |= w[i * words + q]; if (any) live.push_back((uint32_t)i); }
             b->no_inf = live.size() == n;
-            if (live.size() * 8 <= n * 7) {
+            // (small tables keep their records: a compacted copy gives the tables of one MSM call different scalar sets, i.e. a schedule and an
+            // accumulate / reduce sequence of their own — at a few thousand points that sequence costs 0.5 ms and saves nothing.  CG_COMPACT_MIN,
+            // read per call: log2 of the smallest table that gets one)
+            const char* cmin_s = getenv("CG_COMPACT_MIN");
+            const size_t compact_min = (size_t)1 << std::min(31, std::max(6, cmin_s ? atoi(cmin_s) : 14));
+            if (live.size() * 8 <= n * 7 && n >= compact_min) {
                 cg_bases* cb = new cg_bases{ctx->device, curve, group, live.size(), pt, nullptr};
                 cb->no_inf = true;
                 HIPCHK(hip_malloc_flush(&cb->d_pts, std::max<size_t>(live.size() * pt, 16)));

@@ -88,7 +88,8 @@ template <class Fr> int launch_vec_inverse(hipStream_t st, Fr* out, const Fr* in
 template <class Fr> int launch_spmv_csr(hipStream_t st, const uint32_t* row_ptr, const uint32_t* col, const Fr* coeff, size_t n_rows, const Fr* pub,
                                         uint32_t n_inputs, int party, const Fr* wit_a, const Fr* wit_b, Fr* out_a, Fr* out_b) {
     if (!n_rows) return 0;
-    hipLaunchKernelGGL((k_spmv_csr<Fr>), dim3(grid_for(n_rows)), dim3(256), 0, st, row_ptr, col, coeff, n_rows, pub, n_inputs, party, wit_a, wit_b, out_a, out_b);
+    if (n_rows <= ((size_t)1 << 13)) hipLaunchKernelGGL((k_spmv_csr_wave<Fr>), dim3(grid_for(n_rows * 64)), dim3(256), 0, st, row_ptr, col, coeff, n_rows, pub, n_inputs, party, wit_a, wit_b, out_a, out_b);   // a wave per row
+    else hipLaunchKernelGGL((k_spmv_csr<Fr>), dim3(grid_for(n_rows)), dim3(256), 0, st, row_ptr, col, coeff, n_rows, pub, n_inputs, party, wit_a, wit_b, out_a, out_b);
     HIPCHK(hipGetLastError());
     return 0;
 }

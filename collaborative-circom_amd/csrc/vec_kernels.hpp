@@ -96,6 +96,40 @@ __global__ void __launch_bounds__(256) k_spmv_csr(const uint32_t* __restrict__ r
     }
 }
 
+// The same rows with one 64-lane WAVE per row (small circuits: a few hundred rows cannot fill the chip with a lane each, and the launch then
+// lasts as long as its longest row — the Poseidon fixture's 213 rows took 107 us, one row of ~100 terms at ~1 us per term).  Lanes stride over
+// the row's terms and their partial sums are folded across the wave; field addition is exact, so the order of the additions changes nothing.
+template <class F>
+__device__ __forceinline__ F shfl_down_fp(const F& x, int off) {
+    F r;
+    _Pragma("unroll") for (int i = 0; i < F::N; i++) r.v[i] = (uint32_t)__shfl_down((int)x.v[i], off, 64);
+    return r;
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_spmv_csr_wave(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const F* __restrict__ coeff,
+                                                       size_t n_rows, const F* __restrict__ pub, uint32_t n_inputs, int party,
+                                                       const F* __restrict__ wit_a, const F* __restrict__ wit_b, F* __restrict__ out_a, F* __restrict__ out_b) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (size_t row = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < n_rows; row += ((size_t)gridDim.x * blockDim.x) >> 6) {
+        F acc_a = F::zero(), acc_b = F::zero();
+        const uint32_t e = row_ptr[row + 1];
+        for (uint32_t k = row_ptr[row] + lane; k < e; k += 64) {
+            const uint32_t idx = col[k];
+            const F c = ld_fp(coeff + k);
+            if (idx < n_inputs) {
+                F t = c * ld_fp(pub + idx);
+                if (party <= 0) acc_a = acc_a + t;
+                else if (party == 1) acc_b = acc_b + t;
+            } else {
+                acc_a = acc_a + c * ld_fp(wit_a + (idx - n_inputs));
+                if (wit_b) acc_b = acc_b + c * ld_fp(wit_b + (idx - n_inputs));
+            }
+        }
+        for (int off = 32; off >= 1; off >>= 1) { acc_a = acc_a + shfl_down_fp(acc_a, off); if (out_b) acc_b = acc_b + shfl_down_fp(acc_b, off); }
+        if (lane == 0) { st_fp(out_a + row, acc_a); if (out_b) st_fp(out_b + row, acc_b); }
+    }
+}
+
 // dst[i] = src[i] for i < n else 0, for dst of length m (building the zero-padded evaluation vectors, groth16.rs:156-171)
 template <class F>
 __global__ void __launch_bounds__(256) k_zero_tail(F* __restrict__ v, size_t from, size_t to) {

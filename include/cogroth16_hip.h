@@ -165,6 +165,7 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *                 CG_NO_BITSUM / CG_NO_GRID_REDUCE   bucket reduction by the running-sum chain instead of per-bit sums / row-column sums
  *                 CG_SORT_NO_STAGING         unstaged partition / counting-sort scatters
  *                 CG_NO_COMPACT              no compacted copy for tables with many points at infinity
+ *                 CG_COMPACT_MIN (14)        log2 of the smallest table that gets a compacted copy (read per registration)
  *                 CG_NTT_DIF / CG_NTT_NO_PAIR / CG_NTT_TILE (10)   canonical DIF passes; iNTT + coset + NTT as two calls; log2 of the lazy passes' LDS tile
  *                 CG_SUBGROUP_FULL           subgroup checks by [r]P instead of the endomorphism tests
  *                 CG_BULK_CLASS (-1)         priority class of a bulk context's main stream (cg_ctx_create_ex flag 2)

@@ -793,9 +793,12 @@ def test_vec_lincomb_strided(ctx, curve):
 
 
 @pytest.mark.parametrize("group", [G1, G2])
-def test_msm_table_with_many_infinity_points(ctx, group):
-    """tables that are sparse in points (B queries of real zkeys) are compacted at registration: results must not change — whole table,
-    sub-slices, with and without precomputed window tables, two tables with the same pattern sharing a call, an all-infinity range"""
+@pytest.mark.parametrize("compact", [True, False])
+def test_msm_table_with_many_infinity_points(ctx, group, compact, monkeypatch):
+    """tables that are sparse in points (B queries of real zkeys) are compacted at registration (from 2^14 points on; CG_COMPACT_MIN brings
+    this 3000-point table under it) or keep their infinity records: results must not change — whole table, sub-slices, with and without
+    precomputed window tables, two tables with the same pattern sharing a call, an all-infinity range"""
+    monkeypatch.setenv("CG_COMPACT_MIN", "6" if compact else "20")
     curve = BN254
     rng = np.random.default_rng(808)
     n = 3000
