@@ -724,6 +724,50 @@ def isolated_kernels(w, ctx, barrier, reps=3):
     return iso
 
 
+def measure_acc_traffic(log_m, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two rocprofv3 passes (--pmc FETCH_SIZE, then --pmc WRITE_SIZE, each with
+    --kernel-trace only: MI355X_MICROARCH.md's recipe) over scripts/acc_traffic.py, which runs the same accumulation alone.  The counters
+    come in KiB; FETCH_SIZE under-reports this kernel's scattered 64-byte gathers by the factor calibrated on known byte counts in
+    profiles/r04_pmc_calibration.json (gather64_read), WRITE_SIZE needs none.  Returns (bytes, note) or (None, why not)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 is not on PATH"
+    if os.environ.get("BENCH_NO_PMC") or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return None, "skipped (BENCH_NO_PMC set, or this process already runs under a profiler)"
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_calibration.json")) as f:
+            cal = json.load(f)["true_bytes_over_counter_bytes"]
+    except Exception:                                                                        # noqa: BLE001
+        cal = {"gather64_read": 1.0, "dword_write": 1.0}
+    total, parts = 0.0, {}
+    d = tempfile.mkdtemp(prefix="cg_pmc_")
+    try:
+        for counter, factor in (("FETCH_SIZE", cal.get("gather64_read", 1.0)), ("WRITE_SIZE", cal.get("dword_write", 1.0))):
+            out = os.path.join(d, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            p = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                                os.path.join(ROOT, "scripts", "acc_traffic.py"), str(log_m), "2"], cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if p.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): {p.stderr[-200:]}"
+            vals = []
+            for fcsv in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(fcsv)):
+                    if "k_msm_accumulate_pf" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"no {counter} rows for k_msm_accumulate_pf in the counter collection"
+            # one row per dispatch (summed over the XCDs by the tool) or one per (dispatch, dimension): sum, then per launch (2 launches)
+            per_launch = sum(vals) / 2.0 * 1024.0 * factor
+            parts[counter] = per_launch; total += per_launch
+        return total, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over scripts/acc_traffic.py; read %.3g B x gather calibration %.3f "
+                       "(profiles/r04_pmc_calibration.json) + written %.3g B per launch" % (parts["FETCH_SIZE"], cal.get("gather64_read", 1.0), parts["WRITE_SIZE"]))
+    except Exception as e:                                                                   # noqa: BLE001 (a side figure must not take the line down)
+        return None, f"{type(e).__name__}: {e}"[:300]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def roof(bytes_, ms, **extra):
     if not ms:
         return None
@@ -955,7 +999,7 @@ def main():
         c_eff = window_of(avg_pts, args.precompute)
         nwin_g1 = FR[CURVE][2] // c_eff + 1
         mads = MADS_PER_G1_ADD[CURVE]
-        traffic, traffic_src = None, None    # HBM bytes per launch of the dominant kernel: NOT measured in this run — read from the committed rocprofv3 --pmc collection
+        traffic, traffic_src = None, None    # HBM bytes per launch of the dominant kernel: measured after the legs (measure_acc_traffic) when rocprofv3 is here, else the committed collection
         if world == 1 and args.log_m == 22 and CURVE == cg.BN254:
             for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
                 try:
@@ -1088,6 +1132,16 @@ def main():
                     "roofline": r_["roofline"], "roofline_g2": r_["roofline_g2"], "roofline_ntt": r_["roofline_ntt"], "isolated_ms": r_["isolated_ms"], "stages": r_["stages"]}
             except Exception as e:                                      # noqa: BLE001
                 out.setdefault("session", {})["bls12_381" if CURVE == cg.BN254 else "bn254"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        if world == 1 and CURVE == cg.BN254 and not args.no_session:
+            try:
+                w.release()
+            except Exception:                                                                # noqa: BLE001
+                pass
+            measured, why = measure_acc_traffic(args.log_m)
+            if measured is not None:
+                out["roofline"]["traffic"] = measured; out["roofline"]["traffic_note"] = why
+            else:
+                out["roofline"]["traffic_note"] += "; in-run measurement: " + why
         if not args.no_cpu_baseline and world == 1 and CURVE == cg.BN254:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.log_m)
