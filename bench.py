@@ -56,6 +56,7 @@ FR = {cg.BN254: (218882428718392752222464057452572750885483644004160343436982041
       cg.BLS12_381: (0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001, 32, 255)}
 CURVE_NAME = {cg.BN254: "BN254", cg.BLS12_381: "BLS12-381"}
 G1_POINT_BYTES = {cg.BN254: 64, cg.BLS12_381: 96}          # packed affine x || y; G2 twice that
+MADS_PER_G2_ADD = {cg.BN254: 4538, cg.BLS12_381: 10978}   # Fq2 mixed addition, counted in the gfx950 code (profiles/r05_isa_census_acc_g2.txt, ..._bls12_381.txt)
 MADS_PER_G1_ADD = {cg.BN254: 1467, cg.BLS12_381: 3542}     # v_mad_u64_u32 per mixed addition on NL = 9 x 29-bit / 14 x 28-bit lazy limbs: 6 products (2 NL^2) + 2 squarings
                                                            # (NL (NL + 1) / 2 + NL^2) + one fused a*b - c*d (3 NL^2)
 
@@ -817,6 +818,15 @@ def resident_leg(ctx, ctx_aux, device, log_m, steps, warmup, curve, precompute=-
                "roofline_ntt": roof(64.0 * w.m, iso["ntt_ms"], kernel="one 2^%d transform" % log_m),
                "isolated_ms": iso, "stages": stage_table(iso),
                "step_hbm": {"algorithmic_bytes_per_step": 2048.0 * w.nc, "achieved_GBs": 2048.0 * w.nc / (elapsed / steps) / 1e9, "frac": 2048.0 * w.nc / (elapsed / steps) / 1e9 / HBM_PEAK_GBS}}
+        # SURVEY §8d "also report achieved 32-bit mul-add rate": every point is added once per window
+        nw = lambda pts: FR[curve][2] // window_of(pts, precompute) + 1
+        valu = {}
+        for name, mads in (("g1", MADS_PER_G1_ADD[curve]), ("g2", MADS_PER_G2_ADD[curve])):
+            ms, pts = iso.get("acc_%s_ms" % name), iso.get("points_%s" % name)
+            if ms and pts:
+                rate = mads * pts * nw(pts) / (ms * 1e-3) / 1e12
+                valu[name] = {"mads_per_point_addition": mads, "achieved_Tmad_s": rate, "peak_Tmad_s": MAD_PEAK_T, "frac": rate / MAD_PEAK_T, "launch_ms": ms}
+        out["valu_roofline"] = valu
         return out
     finally:
         w.release()
@@ -894,11 +904,18 @@ def main():
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-            host_group = dist.new_group(backend="gloo")
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        # (gloo announces its connections on STDOUT from C++: the line this script prints must stay the only thing there, so the
+        # descriptor points at stderr while the process groups are made)
+        sys.stdout.flush(); saved_out = os.dup(1); os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+                host_group = dist.new_group(backend="gloo")
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier(group=host_group) if host_group is not None else dist.barrier()
+        finally:
+            sys.stdout.flush(); os.dup2(saved_out, 1); os.close(saved_out)
         ones = torch.ones(1, dtype=torch.int64, device=device if args.backend == "nccl" else None)
         dist.all_reduce(ones)                              # every rank of the job answered through the data-path backend (nccl = RCCL)
         ranks_seen = int(ones.item())
@@ -1109,7 +1126,7 @@ def main():
                     e_ = entry_leg(ctx, lg, device, k_, 1, CURVE, extras=False)
                     sizes["2^%d" % lg] = {"step_resident": {k: r_[k] for k in ("ms_per_step", "value", "unit", "steps", "step_hbm")},
                                           "product_entry": {k: e_[k] for k in ("ms_per_proof", "ms_per_proof_min_inner", "ms_inner_each", "value", "unit", "proofs", "three_parties_agree", "zkey")},
-                                          "roofline": r_["roofline"], "roofline_g2": r_["roofline_g2"], "roofline_ntt": r_["roofline_ntt"], "isolated_ms": r_["isolated_ms"]}
+                                          "roofline": r_["roofline"], "roofline_g2": r_["roofline_g2"], "roofline_ntt": r_["roofline_ntt"], "valu_roofline": r_["valu_roofline"], "isolated_ms": r_["isolated_ms"]}
                 except Exception as e:                                  # noqa: BLE001
                     sizes["2^%d" % lg] = {"error": f"{type(e).__name__}: {e}"[:400]}
             out["sizes"] = sizes
@@ -1129,7 +1146,7 @@ def main():
                     "curve": CURVE_NAME[other], "log_m": args.log_m,
                     "step_resident": {k: r_[k] for k in ("ms_per_step", "value", "unit", "steps", "step_hbm")},
                     "product_entry": {k: e_[k] for k in ("ms_per_proof", "ms_per_proof_min_inner", "ms_inner_each", "value", "unit", "proofs", "three_parties_agree", "zkey")},
-                    "roofline": r_["roofline"], "roofline_g2": r_["roofline_g2"], "roofline_ntt": r_["roofline_ntt"], "isolated_ms": r_["isolated_ms"], "stages": r_["stages"]}
+                    "roofline": r_["roofline"], "roofline_g2": r_["roofline_g2"], "roofline_ntt": r_["roofline_ntt"], "valu_roofline": r_["valu_roofline"], "isolated_ms": r_["isolated_ms"], "stages": r_["stages"]}
             except Exception as e:                                      # noqa: BLE001
                 out.setdefault("session", {})["bls12_381" if CURVE == cg.BN254 else "bn254"] = {"error": f"{type(e).__name__}: {e}"[:400]}
         if world == 1 and CURVE == cg.BN254 and not args.no_session:

@@ -1,0 +1,18 @@
+"""Does a small proof get slower as a LATER leg of a process that has had other sessions?  The Poseidon-fixture party before and after legs at
+other sizes, in one process.  usage: python scripts/later_leg.py"""
+import importlib, json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+cg = importlib.import_module("collaborative-circom_amd")
+import bench
+dev = torch.device("cuda", 0); torch.cuda.set_device(0); ctx = cg.Context(0)
+fx = os.path.join(ROOT, "tests", "golden", "groth16", "bn254", "poseidon")
+files = (os.path.join(fx, "circuit.zkey"), os.path.join(fx, "witness.wtns"))
+def leg(what):
+    out = bench.entry_leg(ctx, 0 if what == "poseidon" else what, dev, 20 if what == "poseidon" or what <= 16 else 5, 2, extras=False, files=files if what == "poseidon" else None)
+    print(what, round(out["ms_per_proof"], 2), "min inner", round(out["ms_per_proof_min_inner"], 2), flush=True)
+for what in ("poseidon", 16, "poseidon", 20, "poseidon", 22, "poseidon", 16):
+    leg(what)
+if os.environ.get("RESIDENT_BETWEEN"):
+    r = bench.resident_leg(ctx, cg.Context(0), dev, 20, 5, 2, cg.BN254)
+    print("resident 2^20", round(r["ms_per_step"], 2)); leg("poseidon")
