@@ -140,6 +140,7 @@ struct cg_ctx {
     // priority class of each stream: +1 high, 0 normal, -1 low (pooled_stream)
     int prio_main = 0, prio_side = 1, prio_copy = 0;
     uint32_t msm_chunk = 0;                               // cg_msm_set_chunk / CG_OPT_MSM_CHUNK
+    int one_stream_log = 18;                              // CG_MSM_ONE_STREAM_LOG: calls of at most 2^this entries run on the main stream alone (0 = never)
     int table_order = 0, g2_after = -1, g2_slices = 0, red_batch = 2, acc_slots = 4, wide_small = 1;   // CG_OPT_MSM_TABLE_ORDER / _G2_SLICES / _REDUCE_BATCH / _ACC_SLOTS (cg_ctx_set_option)
     hipEvent_t ev_peer = nullptr;                         // cg_dev_copy_peer: "source stream reached this point"
     Arena arena;
@@ -444,31 +445,36 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // CG_OPT_MSM_WIDE_SMALL: 0 = off, 1 = calls of at most 2^20 (point, window) entries, 10 .. 30 = log2 of that bound
         const uint64_t wide_max = ctx->wide_small == 0 ? 0 : (uint64_t)1 << (ctx->wide_small == 1 ? 20 : ctx->wide_small);
         const bool small_call = k <= 2 && (uint64_t)nwin * n <= wide_max;            // see `wide` below
+        // TINY calls (at most 2^18 entries by default): schedule, accumulation and reduction in stream order on the MAIN stream.  Their kernels
+        // last 5-100 us; a hop to another stream costs an event round trip of the same order, and which hardware queues the context's three
+        // streams share — it differs from context to context — made the same party 2.2 or 3.7 ms on the Poseidon fixture.
+        const bool one_stream = small_call && ctx->one_stream_log > 0 && (uint64_t)nwin * n <= ((uint64_t)1 << ctx->one_stream_log);
+        const hipStream_t sortst = one_stream ? ctx->stream : ctx->sortst, auxst = one_stream ? ctx->stream : ctx->aux;
         const int acc_slots = red_batch || small_call ? std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(acc_slots_min, red_batch >= 2 || small_call ? nb * k : nb + 1)) : acc_slots_min;
         { int rc = ensure_arena(ctx, nsched * sort_bytes + (size_t)acc_slots * acc_slot); if (rc) return rc; }
         char* acc_scratch = ctx->arena.base + nsched * sort_bytes;
         HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));   // scalars (and the arena) are ready once the main stream gets here
-        HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_in, 0));
-        for (int rs = 0; rs < 2; rs++) for (int i = 0; i < 2; i++) if (ctx->merged_pending[rs][i]) { HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_merged[rs][i], 0)); ctx->merged_pending[rs][i] = false; }   // ... and the previous call's merges have read the old schedules
+        HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_in, 0));
+        for (int rs = 0; rs < 2; rs++) for (int i = 0; i < 2; i++) if (ctx->merged_pending[rs][i]) { HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_merged[rs][i], 0)); ctx->merged_pending[rs][i] = false; }   // ... and the previous call's merges have read the old schedules
         std::vector<MsmSortPtrs> sps(k);
         auto launch_sort = [&](int j) -> int {             // scalar side: once per scalar vector, on the sort stream
             const int ss_ = j % nsched;
-            if (j < 4 && ctx->comp_after[j]) HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->comp_after[j], 0));   // this component's scalars are still on their way up
+            if (j < 4 && ctx->comp_after[j]) HIPCHK(hipStreamWaitEvent(sortst, ctx->comp_after[j], 0));   // this component's scalars are still on their way up
             if (j >= nsched) {                                   // accumulates and merges of component j-2 have consumed the slot
-                HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_sched_free[ss_], 0));
-                for (int rs = 0; rs < 2; rs++) if (ctx->merged_pending[rs][ss_]) HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_merged[rs][ss_], 0));
+                HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_sched_free[ss_], 0));
+                for (int rs = 0; rs < 2; rs++) if (ctx->merged_pending[rs][ss_]) HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_merged[rs][ss_], 0));
             }
             hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
             if (ctx->stats_on) { const int i0 = ev_open(ctx, TAG_SORT); evs[0] = ctx->ev_live[i0].a; evs[1] = ctx->ev_live[i0].b; pev = evs; }
             char* sort_scratch = ctx->arena.base + (size_t)ss_ * sort_bytes;
             int rc = with_fr(curve, [&](auto tag) -> int {
                 typedef decltype(tag) Fr;
-                return cap ? msm_sort_direct_launch<Fr>(ctx->sortst, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, cap, sort_scratch, &sps[j], pev)
-                           : msm_sort_launch<Fr>(ctx->sortst, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, sort_scratch, &sps[j], pev);
+                return cap ? msm_sort_direct_launch<Fr>(sortst, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, cap, sort_scratch, &sps[j], pev)
+                           : msm_sort_launch<Fr>(sortst, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, sort_scratch, &sps[j], pev);
             });
             if (rc) return rc;
-            if (cap) for (int b = 0; b < nb; b++) HIPCHK(hipMemcpyAsync(ctx->tickets[slots[b]].h_flags + j, sps[j].overflow, 4, hipMemcpyDeviceToHost, ctx->sortst));
-            HIPCHK(hipEventRecord(ctx->ev_sorted[ss_], ctx->sortst));
+            if (cap) for (int b = 0; b < nb; b++) HIPCHK(hipMemcpyAsync(ctx->tickets[slots[b]].h_flags + j, sps[j].overflow, 4, hipMemcpyDeviceToHost, sortst));
+            HIPCHK(hipEventRecord(ctx->ev_sorted[ss_], sortst));
             return 0;
         };
         int iter = 0;
@@ -479,7 +485,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         int tables_of_group[2] = {0, 0};
         for (int b = 0; b < nb; b++) tables_of_group[bases[b]->group == CG_G1 ? 0 : 1]++;
         std::vector<int> comps_left(nb, k);
-        hipStream_t red_stream[2] = {ctx->aux, ctx->aux};      // reduction stream per field (wide mode: G1 on the idle sort stream, beside G2 on aux)
+        hipStream_t red_stream[2] = {auxst, auxst};      // reduction stream per field (wide mode: G1 on the idle sort stream, beside G2 on aux)
         auto flush = [&](int gi) -> int {
             std::vector<PendSet>& pd = pend[gi];
             if (pd.empty()) return 0;
@@ -492,7 +498,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
             if (ctx->stats_on) { const int i2 = ev_open(ctx, TAG_REDUCE); evs[0] = ctx->ev_live[i2].a; evs[1] = ctx->ev_live[i2].b; pev = evs; }
             hipEvent_t evm[2]; int nm = 0; bool seen[2] = {false, false};
             std::vector<MsmRedSet> sets;
-            const int rs = rst == ctx->sortst ? 1 : 0;
+            const int rs = rst == sortst ? 1 : 0;
             for (const PendSet& ps : pd) { sets.push_back(ps.set); if (!seen[ps.sched]) { seen[ps.sched] = true; evm[nm++] = ctx->ev_merged[rs][ps.sched]; } }
             int rc = with_coord_field(curve, gi == 0 ? CG_G1 : CG_G2, [&](auto ftag) -> int {
                 typedef decltype(ftag) F;
@@ -526,7 +532,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         if (wide) {
             if (k == 2) { int rc = launch_sort(1); if (rc) return rc; }
             for (int j = 0; j < k; j++) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[j], 0));
-            red_stream[0] = ctx->sortst;
+            red_stream[0] = sortst;
             for (int gi : {1, 0}) {
                 std::vector<MsmAccSet> sets;
                 for (int j = 0; j < k; j++) for (int b = 0; b < nb; b++) {
@@ -545,7 +551,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
                     return msm_accumulate_batch<F>(ctx->stream, sets.data(), (int)sets.size(), n, c, nwin, shared, sps[0].cap, pev, chunk_request, false);
                 });
                 if (rc) return rc;
-                if (gi == 0) HIPCHK(hipStreamWaitEvent(ctx->sortst, ctx->ev_sorted[k - 1], 0));     // (the sort stream has nothing else left in this call)
+                if (gi == 0) HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_sorted[k - 1], 0));     // (the sort stream has nothing else left in this call)
                 { int rc2 = flush(gi); if (rc2) return rc2; }
             }
             for (int j = 0; j < k; j++) HIPCHK(hipEventRecord(ctx->ev_sched_free[j], ctx->stream));
@@ -1157,7 +1163,7 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     {   // A/B runs: environment variables seed the option table of new contexts (include/cogroth16_hip.h, cg_ctx_set_option)
         auto seed = [](const char* name, int lo, int hi, int& field) { if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= lo && v <= hi) field = v; } };
         seed("CG_MSM_TABLE_ORDER", 0, 2, c->table_order); seed("CG_MSM_G2_AFTER", -1, 64, c->g2_after); seed("CG_MSM_G2_SLICES", 0, 1, c->g2_slices);
-        seed("CG_MSM_REDUCE_BATCH", 0, 3, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots); seed("CG_MSM_WIDE_SMALL", 0, 30, c->wide_small);
+        seed("CG_MSM_REDUCE_BATCH", 0, 3, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots); seed("CG_MSM_WIDE_SMALL", 0, 30, c->wide_small); seed("CG_MSM_ONE_STREAM_LOG", 0, 30, c->one_stream_log);
     }
     if (flags & 1u) { c->prio_main = 1; c->prio_copy = 1; c->prio_side = 0; }
     else if (flags & 2u) { static const int bulk_cls = getenv("CG_BULK_CLASS") ? atoi(getenv("CG_BULK_CLASS")) : -1; c->prio_main = bulk_cls; c->prio_side = 0; }   // CG_BULK_CLASS: tuning knob

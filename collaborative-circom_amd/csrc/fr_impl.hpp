@@ -191,6 +191,17 @@ template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, siz
     const size_t ntiles = (nbuckets + SCAN_TILE - 1) / SCAN_TILE;
     uint32_t* tile_sums = (uint32_t*)take(ntiles * 4);
     if (evs) HIPCHK(hipEventRecord(evs[0], st));
+    static const bool no_small = getenv("CG_SORT_NO_SMALL") != nullptr;                  // measurement knob
+    if (shared && !no_small && nbuckets <= SORT_SMALL_MAX_BUCKETS && (size_t)nwin * n <= SORT_SMALL_MAX_ENTRIES && n <= (1u << 24)) {   // small vectors: one launch
+        const size_t lds = (2 * nbuckets + 1024) * 4;
+        static PerDeviceOnce attr_small;
+        if (attr_small.pending()) { HIPCHK(hipFuncSetAttribute((const void*)k_msm_sort_small<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * SORT_SMALL_MAX_BUCKETS + 1024) * 4))); attr_small.mark(); }
+        hipLaunchKernelGGL((k_msm_sort_small<Fr>), dim3(1), dim3(1024), lds, st, d_scalars, (uint32_t)n, c, nwin, counts, offsets, sorted);
+        if (evs) HIPCHK(hipEventRecord(evs[1], st));
+        HIPCHK(hipGetLastError());
+        out->sorted = sorted; out->offsets = offsets; out->counts = counts; out->cap = 0; out->overflow = nullptr;
+        return 0;
+    }
     HIPCHK(hipMemsetAsync(counts, 0, align_up(nbuckets * 4) * 2, st));   // counts + cursors are adjacent
     if (msm_sort_use_partition(n, c, nwin, shared)) {
         const size_t entries = (size_t)nwin * n, ptiles = (entries + PART_TILE - 1) / PART_TILE;

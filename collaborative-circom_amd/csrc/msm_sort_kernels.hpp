@@ -96,6 +96,53 @@ static __global__ void __launch_bounds__(256) k_msm_scatter(const int32_t* __res
     }
 }
 
+// The whole schedule of a SMALL scalar vector in ONE launch of one workgroup (shared bucket set, <= 2^13 buckets, <= 2^18 entries): digits ->
+// LDS histogram -> LDS scan -> scatter through LDS cursors.  The six launches above cost a few-hundred-constraint circuit 85 us per scalar
+// vector in launch gaps alone (four vectors per proof); here the digits are simply recomputed for the scatter.  The order of the entries
+// inside a bucket differs from run to run (atomics), as it does for k_msm_scatter: the bucket sums do not depend on it.
+constexpr uint32_t SORT_SMALL_MAX_BUCKETS = 1u << 13, SORT_SMALL_MAX_ENTRIES = 1u << 18;
+template <class Fr>
+__global__ void __launch_bounds__(1024) k_msm_sort_small(const Fr* __restrict__ scalars, uint32_t n, int c, int nwin,
+                                                         uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
+    extern __shared__ uint32_t sort_lds[];                      // [nb counters] [nb cursors] [1024 partial sums]
+    const uint32_t nb = 1u << (c - 1), mask = (1u << c) - 1, t = threadIdx.x;
+    uint32_t* cnt = sort_lds; uint32_t* cur = sort_lds + nb; uint32_t* part = sort_lds + 2 * nb;
+    for (uint32_t b = t; b < nb; b += 1024) cnt[b] = 0;
+    __syncthreads();
+    // signed digits of scalar i, least significant window first; f(w, bucket, negative) for every non-zero digit
+    auto digits_of = [&](uint32_t i, auto&& f) {
+        Fr s = ld_fp(scalars + i).from_mont();
+        uint32_t carry = 0;
+        for (int w = 0; w < nwin; w++) {
+            const uint32_t d = (s.v[0] & mask) + carry;
+            _Pragma("unroll") for (int l = 0; l < Fr::N; l++) {
+                const uint64_t two = ((uint64_t)(l + 1 < Fr::N ? s.v[l + 1] : 0u) << 32) | s.v[l];
+                s.v[l] = (uint32_t)(two >> c);
+            }
+            if (d > nb) { carry = 1; f((uint32_t)w, (1u << c) - d - 1, true); }
+            else { carry = 0; if (d) f((uint32_t)w, d - 1, false); }
+        }
+    };
+    for (uint32_t i = t; i < n; i += 1024) digits_of(i, [&](uint32_t, uint32_t b, bool) { atomicAdd(&cnt[b], 1u); });
+    __syncthreads();
+    const uint32_t chunk = (nb + 1023) / 1024, lo = min(t * chunk, nb), hi = min(lo + chunk, nb);
+    uint32_t mine = 0;
+    for (uint32_t b = lo; b < hi; b++) mine += cnt[b];
+    part[t] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {             // inclusive scan of the 1024 partial sums
+        const uint32_t v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - mine;
+    for (uint32_t b = lo; b < hi; b++) { const uint32_t k = cnt[b]; offsets[b] = run; cur[b] = run; counts[b] = k; run += k; }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 1024)
+        digits_of(i, [&](uint32_t w, uint32_t b, bool neg) { sorted[atomicAdd(&cur[b], 1u)] = (w << 24) | i | (neg ? 0x80000000u : 0u); });
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // MSD partition in front of the counting sort.  A direct counting sort of 54 M (window, scalar) entries into 524 k buckets
 // issues 54 M scattered 4-byte stores (and as many scattered atomics): ~5 ms per schedule, all of it DRAM sector traffic.

@@ -164,12 +164,15 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *                 CG_ACC_VARIANT (3)         software-pipelining variant of k_msm_accumulate_pf (read per call; scripts/acc_variants.py)
  *                 CG_NO_BITSUM / CG_NO_GRID_REDUCE   bucket reduction by the running-sum chain instead of per-bit sums / row-column sums
  *                 CG_SORT_NO_STAGING         unstaged partition / counting-sort scatters
+ *                 CG_SORT_NO_SMALL           small scalar vectors through the six-launch schedule instead of the one-workgroup kernel
  *                 CG_NO_COMPACT              no compacted copy for tables with many points at infinity
  *                 CG_COMPACT_MIN (14)        log2 of the smallest table that gets a compacted copy (read per registration)
  *                 CG_NTT_DIF / CG_NTT_NO_PAIR / CG_NTT_TILE (10)   canonical DIF passes; iNTT + coset + NTT as two calls; log2 of the lazy passes' LDS tile
  *                 CG_SUBGROUP_FULL           subgroup checks by [r]P instead of the endomorphism tests
  *                 CG_BULK_CLASS (-1)         priority class of a bulk context's main stream (cg_ctx_create_ex flag 2)
  *                 CG_MSM_TABLE_ORDER, CG_MSM_G2_AFTER, CG_MSM_G2_SLICES, CG_MSM_REDUCE_BATCH, CG_MSM_ACC_SLOTS, CG_MSM_WIDE_SMALL   seed the option table of NEW contexts
+ *                 CG_MSM_ONE_STREAM_LOG (18)  MSM calls of at most 2^this (point, window) entries run schedule, accumulation and reduction in stream order on the
+ *                                            context's main stream (0 = never); seeds new contexts
  *   DEBUG         CG_DEBUG_NO_REDUCE = 1 | 2 skips the merges + bucket reductions | the reductions only: RESULTS ARE WRONG (what they cost a step)
  *                 CG_DEBUG_ALLOC             cg_dev_cache_trim prints how the device block cache fared since the last trim (read per call)
  *                 CG_DEBUG_STREAMS           one stderr line per stream handed out: priority class, hardware-queue slot, streams checked out per slot (read per call) */

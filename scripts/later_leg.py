@@ -16,3 +16,11 @@ for what in ("poseidon", 16, "poseidon", 20, "poseidon", 22, "poseidon", 16):
 if os.environ.get("RESIDENT_BETWEEN"):
     r = bench.resident_leg(ctx, cg.Context(0), dev, 20, 5, 2, cg.BN254)
     print("resident 2^20", round(r["ms_per_step"], 2)); leg("poseidon")
+if os.environ.get("WARM_TEST"):
+    # hypothesis: the slow legs are the GPU's clock state after a lightly loaded stretch.  A 16-legs-then-poseidon pair, once as is and once with
+    # 300 ms of dense work right in front of the small leg
+    leg(16); leg("poseidon")
+    leg(16)
+    a = torch.randn(8192, 8192, device=dev); t0 = __import__("time").time()
+    while __import__("time").time() - t0 < 0.3: b = a @ a
+    torch.cuda.synchronize(); print("(300 ms of dense work)"); leg("poseidon")
