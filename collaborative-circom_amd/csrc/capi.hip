@@ -140,7 +140,7 @@ struct cg_ctx {
     // priority class of each stream: +1 high, 0 normal, -1 low (pooled_stream)
     int prio_main = 0, prio_side = 1, prio_copy = 0;
     uint32_t msm_chunk = 0;                               // cg_msm_set_chunk / CG_OPT_MSM_CHUNK
-    int one_stream_log = 18;                              // CG_MSM_ONE_STREAM_LOG: calls of at most 2^this entries run on the main stream alone (0 = never)
+    int one_stream_log = 0;                               // CG_MSM_ONE_STREAM_LOG: calls of at most 2^this entries run on the main stream alone (0 = never, the default: measured slower)
     int table_order = 0, g2_after = -1, g2_slices = 0, red_batch = 2, acc_slots = 4, wide_small = 1;   // CG_OPT_MSM_TABLE_ORDER / _G2_SLICES / _REDUCE_BATCH / _ACC_SLOTS (cg_ctx_set_option)
     hipEvent_t ev_peer = nullptr;                         // cg_dev_copy_peer: "source stream reached this point"
     Arena arena;
@@ -445,9 +445,10 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // CG_OPT_MSM_WIDE_SMALL: 0 = off, 1 = calls of at most 2^20 (point, window) entries, 10 .. 30 = log2 of that bound
         const uint64_t wide_max = ctx->wide_small == 0 ? 0 : (uint64_t)1 << (ctx->wide_small == 1 ? 20 : ctx->wide_small);
         const bool small_call = k <= 2 && (uint64_t)nwin * n <= wide_max;            // see `wide` below
-        // TINY calls (at most 2^18 entries by default): schedule, accumulation and reduction in stream order on the MAIN stream.  Their kernels
-        // last 5-100 us; a hop to another stream costs an event round trip of the same order, and which hardware queues the context's three
-        // streams share — it differs from context to context — made the same party 2.2 or 3.7 ms on the Poseidon fixture.
+        // A/B knob CG_MSM_ONE_STREAM_LOG (off by default): tiny calls with schedule, accumulation and reduction in stream order on the MAIN stream.
+        // It takes the context's hardware-queue placement out of the picture — the same Poseidon-fixture party takes 1.9 to 3.7 ms from one
+        // session of a process to the next with three streams, 2.5-2.8 ms with one — but the G2 reduction then no longer runs under the G1
+        // accumulation, and the best placement is what the default keeps (profiles/r05_small_circuit_ab3.txt).
         const bool one_stream = small_call && ctx->one_stream_log > 0 && (uint64_t)nwin * n <= ((uint64_t)1 << ctx->one_stream_log);
         const hipStream_t sortst = one_stream ? ctx->stream : ctx->sortst, auxst = one_stream ? ctx->stream : ctx->aux;
         const int acc_slots = red_batch || small_call ? std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(acc_slots_min, red_batch >= 2 || small_call ? nb * k : nb + 1)) : acc_slots_min;

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(1024) k_msm_sort_small(const Fr* __restrict__ 
                 const uint64_t two = ((uint64_t)(l + 1 < Fr::N ? s.v[l + 1] : 0u) << 32) | s.v[l];
                 s.v[l] = (uint32_t)(two >> c);
             }
-            if (d > nb) { carry = 1; f((uint32_t)w, (1u << c) - d - 1, true); }
+            if (d > nb) { carry = 1; if (d != (1u << c)) f((uint32_t)w, (1u << c) - d - 1, true); }      // (d = 2^c: digit 0 with a carry)
             else { carry = 0; if (d) f((uint32_t)w, d - 1, false); }
         }
     };

@@ -171,8 +171,8 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *                 CG_SUBGROUP_FULL           subgroup checks by [r]P instead of the endomorphism tests
  *                 CG_BULK_CLASS (-1)         priority class of a bulk context's main stream (cg_ctx_create_ex flag 2)
  *                 CG_MSM_TABLE_ORDER, CG_MSM_G2_AFTER, CG_MSM_G2_SLICES, CG_MSM_REDUCE_BATCH, CG_MSM_ACC_SLOTS, CG_MSM_WIDE_SMALL   seed the option table of NEW contexts
- *                 CG_MSM_ONE_STREAM_LOG (18)  MSM calls of at most 2^this (point, window) entries run schedule, accumulation and reduction in stream order on the
- *                                            context's main stream (0 = never); seeds new contexts
+ *                 CG_MSM_ONE_STREAM_LOG (0)  MSM calls of at most 2^this (point, window) entries run schedule, accumulation and reduction in stream order on the
+ *                                            context's main stream (0 = never: measured slower than three streams); seeds new contexts
  *   DEBUG         CG_DEBUG_NO_REDUCE = 1 | 2 skips the merges + bucket reductions | the reductions only: RESULTS ARE WRONG (what they cost a step)
  *                 CG_DEBUG_ALLOC             cg_dev_cache_trim prints how the device block cache fared since the last trim (read per call)
  *                 CG_DEBUG_STREAMS           one stderr line per stream handed out: priority class, hardware-queue slot, streams checked out per slot (read per call) */
