@@ -202,6 +202,13 @@ class Context:
         _chk(load().cg_ctx_set_stream(self.h, C.c_void_p(int(hip_stream))))
 
     # ---- memory
+    def free_many(self, bufs):
+        """several DevBufs released behind ONE release mark (cg_dev_free_many)"""
+        live = [b for b in bufs if b.ptr]
+        arr = (C.c_void_p * max(1, len(live)))(*[b.ptr for b in live])
+        _chk(load().cg_dev_free_many(self.h, arr, C.c_size_t(len(live))))
+        for b in live: b.ptr = 0
+
     def alloc(self, nbytes):
         return DevBuf(self, nbytes)
 

@@ -123,6 +123,48 @@ def test_released_blocks_are_handed_out_again_and_hold_no_stale_work(built):
     c.close()
 
 
+def test_blocks_released_together_share_one_mark(built):
+    """cg_dev_free_many: n blocks parked behind one release mark — none of them is handed out while the work enqueued before the release is
+    pending, all of them come back afterwards, NULL entries are skipped, the cache accounting (cg_dev_cache_trim) sees every block"""
+    import time
+    c = cg.Context(0)
+    cg.dev_cache_trim(0)
+    rng = np.random.default_rng(6)
+    n = 1 << 15
+    a, b = orc.random_field(BN254, FR, n, rng), orc.random_field(BN254, FR, n, rng)
+    da, db = c.to_device(a), c.to_device(b)
+    want = orc.field_op(BN254, FR, "mul", a, b)
+    sizes = [n * 32, n * 32 + 4096, n * 32 + 8192, n * 32 + 12288]
+    outs = [c.alloc(sz) for sz in sizes]
+    ptrs = {o.ptr for o in outs}
+    for o in outs:
+        for _ in range(10): c.vec_mul(BN254, o, da, db, n)
+    np.testing.assert_array_equal(outs[3].download((n, 4)), want)
+    for o in outs: c.vec_mul(BN254, o, db, da, n)                   # enqueued, not waited for
+    c.free_many(outs)
+    assert all(o.ptr == 0 for o in outs)
+    # same sizes again: zeroed and read back — a block handed out too early would still be written by the products above
+    again = [c.alloc(sz) for sz in sizes]
+    for o in again: o.zero()
+    for o in again: np.testing.assert_array_equal(o.download((n, 4)), np.zeros((n, 4), dtype=np.uint64))
+    c.free_many(again); c.sync()
+    got_back = set()
+    for _ in range(200):
+        trial = [c.alloc(sz) for sz in sizes]
+        got_back |= {t.ptr for t in trial} & (ptrs | {o.ptr for o in again})
+        c.free_many(trial)
+        if len(got_back) >= 2: break
+        time.sleep(0.002)
+    assert len(got_back) >= 2, "blocks released together were not reused"
+    c.sync()
+    assert cg.dev_cache_trim(0) >= sum(sizes)                       # every block of the batch was parked
+    # an empty batch and a batch of NULLs are fine
+    import ctypes as C
+    assert cg.load().cg_dev_free_many(c.h, (C.c_void_p * 2)(None, None), C.c_size_t(2)) == 0
+    assert cg.load().cg_dev_free_many(c.h, None, C.c_size_t(0)) == 0
+    da.free(); db.free(); c.close()
+
+
 def test_pinned_blocks_are_parked(built):
     c = cg.Context(0)
     h1 = c.host_alloc((1 << 18, 4)); h1[:] = 7
