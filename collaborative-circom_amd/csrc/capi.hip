@@ -1284,13 +1284,23 @@ int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr) {
     DevCache& dc = dev_cache(ctx->device);
     std::lock_guard<std::mutex> l(dc.mu);
     auto range = dc.parked.equal_range(rb);
-    bool pending = false;
+    bool pending = false; auto first_pending = range.second;
     for (auto it = range.first; it != range.second; ++it) {
-        if (hipEventQuery(it->second.mark->ev) != hipSuccess) { (void)hipGetLastError(); pending = true; continue; }
+        if (hipEventQuery(it->second.mark->ev) != hipSuccess) { (void)hipGetLastError(); if (!pending) first_pending = it; pending = true; continue; }
         *d_ptr = it->second.p; mark_unref(dc, it->second.mark); dc.parked.erase(it); dc.parked_bytes -= rb; dc.live[*d_ptr] = rb;
         dc.n_hit++;
         return 0;
     }
+    // SMALL blocks whose size is parked but still behind its release mark: wait for the mark instead of asking the runtime for a new block.
+    // The mark stands behind the tail of the previous proof (a few tens of microseconds of work when the next proof of a small circuit asks
+    // for the same sizes again), hipMalloc costs 100-200 us — a Poseidon-sized party took that path 1.5 times per proof.  Large blocks keep
+    // the fresh allocation: their mark may stand behind milliseconds of accumulation.
+    if (pending && rb <= ((size_t)1 << 20) && hipEventSynchronize(first_pending->second.mark->ev) == hipSuccess) {
+        *d_ptr = first_pending->second.p; mark_unref(dc, first_pending->second.mark); dc.parked.erase(first_pending); dc.parked_bytes -= rb; dc.live[*d_ptr] = rb;
+        dc.n_hit++;
+        return 0;
+    }
+    (void)hipGetLastError();
     if (pending) dc.n_pending++; else dc.n_fresh++;
     hipError_t e = hipMalloc(d_ptr, rb);
     if (e == hipErrorOutOfMemory && !dc.parked.empty()) { (void)hipGetLastError(); dev_cache_flush(dc); e = hipMalloc(d_ptr, rb); }

@@ -5,6 +5,8 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include "cogroth16_hip.h"
 
@@ -33,7 +35,20 @@ struct PerDeviceOnce {
     bool pending() const { const int d = dev(); return d < 0 || !done[d].load(std::memory_order_acquire); }
     void mark() { const int d = dev(); if (d >= 0) done[d].store(true, std::memory_order_release); }
 };
+// the same for call sites that launch one of several kernels of ONE pointer type (the variants of k_msm_accumulate_pf): keyed by function and
+// device, set under the lock (a second thread launches only after the first one's call has returned), raised when a larger size is asked for
+inline int ensure_dynamic_lds(const void* fn, size_t bytes);
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+inline int ensure_dynamic_lds(const void* fn, size_t bytes) {
+    static std::mutex mu; static std::map<std::pair<const void*, int>, size_t> done;
+    int d = 0; if (hipGetDevice(&d) != hipSuccess) d = -1;
+    std::lock_guard<std::mutex> l(mu);
+    size_t& have = done[{fn, d}];
+    if (have >= bytes) return 0;
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+    return 0;
+}
 inline int log2_floor(size_t n) { int l = 0; while (((size_t)2 << l) <= n) l++; return l; }
 
 // ---- MSM launch geometry: shared by the kernel launchers (msm_impl.hpp) and the host-side planner (capi.hip) --------------------------

@@ -70,7 +70,7 @@ int msm_accumulate_batch(hipStream_t st, const MsmAccSet* sets, int nsets, size_
     }
     if (evs) HIPCHK(hipEventRecord(evs[0], st));
     auto launch_acc = [&](auto kern, int T, size_t lds) -> int {                         // one set per launch (padded lists, CG_ACC_VARIANT=0)
-        if (lds > 0) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 0) { if (int rc = ensure_dynamic_lds((const void*)kern, lds)) return rc; }   // once per (kernel, device), not per launch
         for (int i = 0; i < nsets; i++)
             hipLaunchKernelGGL(kern, dim3((g.nchunks + T - 1) / T), dim3(T), lds, st, S.bases[i], S.sorted[i], S.offsets[i], S.counts[i],
                                (uint32_t)g.nbuckets, g.chunk_len, g.nchunks, S.table_stride[i], cap, S.buckets[i], S.cont[i], S.cont_bucket[i], S.may_have_inf[i]);
@@ -91,7 +91,7 @@ int msm_accumulate_batch(hipStream_t st, const MsmAccSet* sets, int nsets, size_
     // of LDS, so nothing that needs LDS (an NTT pass: 72 KB) can start while the launch lasts — measured: a high-priority NTT pass
     // waited 11 ms, the whole launch.  Between the slices the chip drains and the waiting kernels go first; ~2 ms per launch when nothing waits.
     auto launch_pf = [&](auto kern, int T, size_t lds) -> int {
-        if (lds > 0) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 0) { if (int rc = ensure_dynamic_lds((const void*)kern, lds)) return rc; }   // once per (kernel, device), not per launch
         const uint32_t groups = (g.nchunks + T - 1) / T;
         const uint32_t slice = lds > 0 && g2_slices ? 256u * (uint32_t)std::max<size_t>(1, ((size_t)160 << 10) / lds) : groups;
         for (uint32_t first = 0; first < groups; first += slice)

@@ -3,6 +3,7 @@
 #include "formats.hpp"
 #include "network.hpp"
 #include "chacha.hpp"
+#include <future>
 
 namespace cgh {
 
@@ -885,13 +886,24 @@ public:
         return r;
     }
     PointShare scalar_mul_public_point(const Point& p, const FieldShare& s, const cg_fixed_base* tab = nullptr) {   // rep3.rs:820-825 (tab: p's window table, if the session holds one)
-        PointShare r; for (int j = 0; j < 2; j++) r.c[j] = j < k() ? pt_mul_fixed(curve, tab, p, s.c[j]) : pt_inf(curve, p.group); return r;
+        PointShare r;
+        if (!tab && k() == 2) {                                                          // two variable-base products: side by side (see scalar_mul)
+            auto other = std::async(std::launch::async, [&] { return pt_mul_fixed(curve, nullptr, p, s.c[1]); });
+            r.c[0] = pt_mul_fixed(curve, nullptr, p, s.c[0]); r.c[1] = other.get();
+            return r;
+        }
+        for (int j = 0; j < 2; j++) r.c[j] = j < k() ? pt_mul_fixed(curve, tab, p, s.c[j]) : pt_inf(curve, p.group); return r;
     }
     PointShare scalar_mul(const PointShare& a, const FieldShare& b) {           // rep3.rs:835-847, pointshare.rs:117-124
         PointShare r;
         if (mode == Mode::Plain) { r.c[0] = pt_mul(curve, a.c[0], b.c[0]); r.c[1] = pt_inf(curve, a.c[0].group); return r; }
         if (mode == Mode::Shamir) { r.c[0] = degree_reduce_point(pt_mul(curve, a.c[0], b.c[0])); r.c[1] = pt_inf(curve, a.c[0].group); return r; }   // shamir.rs:769-776
-        Point local = pt_add(curve, pt_add(curve, pt_mul(curve, a.c[0], b.c[0]), pt_mul(curve, a.c[1], b.c[0])), pt_mul(curve, a.c[0], b.c[1]));
+        // three independent variable-base products (~60 us each in G1 on the host): two of them on helper threads — they sit between the last MSM
+        // result and the proof, on every proof's tail (a thread start costs ~20 us)
+        auto p1 = std::async(std::launch::async, [&] { return pt_mul(curve, a.c[1], b.c[0]); });
+        auto p2 = std::async(std::launch::async, [&] { return pt_mul(curve, a.c[0], b.c[1]); });
+        const Point p0 = pt_mul(curve, a.c[0], b.c[0]);
+        Point local = pt_add(curve, pt_add(curve, p0, p1.get()), p2.get());
         if (rsrc) { Point m{Bytes(curve.jac(a.c[0].group)), a.c[0].group}; rsrc->masking_ec_element(m.group, m.b.data()); local = pt_add(curve, local, m); }   // rngs.rs:48-51
         else {
             const int g = a.c[0].group;                            // masking_ec_element: G*rand(rng1) - G*rand(rng2)
