@@ -113,14 +113,17 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_
     const size_t entries = (size_t)nwin * n;
     static const size_t chunk_max = [] { const char* e = getenv("CG_MSM_CHUNK"); return e ? (size_t)atoi(e) : (size_t)128; }();   // tuning knob
     static const size_t chunk_min = [] { const char* e = getenv("CG_MSM_CHUNK_MIN"); return e ? (size_t)atoi(e) : (size_t)16; }();  // tuning knob (8 -> 16: 2^17-constraint step 7.3 -> 5.8 ms: half the continuation pieces)
-    g.chunk_len = (uint32_t)std::min<size_t>(chunk_max, std::max<size_t>(chunk_min, entries / (256 * 1024)));
+    // (lists of at most 2^16 entries — circuits of a few hundred constraints — take chunks of 8: the launch is a handful of workgroups and lasts as
+    // long as one lane's chain of additions, 14 us each in G2)
+    const size_t chunk_floor = entries <= ((size_t)1 << 16) ? std::min<size_t>(chunk_min, 8) : chunk_min;
+    g.chunk_len = (uint32_t)std::min<size_t>(chunk_max, std::max<size_t>(chunk_floor, entries / (256 * 1024)));
     // kernels without a lock-stepped residency (G2: two waves per SIMD, one of them favoured by the arbiter): shorter chunks let the
     // hardware's workgroup scheduler even out what the waves do not — 2^22 points: 12.4 -> 11.7 ms per launch alone, the step 71.5 -> 70.7 ms
     // (48: no better, the merge of twice as many boundary pieces takes it back).  CG_G2_CHUNK overrides (0 = no cap).
     static const size_t g2_chunk = [] { const char* e = getenv("CG_G2_CHUNK"); return e ? (size_t)atoi(e) : (size_t)64; }();
-    if (g2 && g2_chunk) g.chunk_len = (uint32_t)std::min<size_t>(g.chunk_len, std::max<size_t>(chunk_min, g2_chunk));
+    if (g2 && g2_chunk) g.chunk_len = (uint32_t)std::min<size_t>(g.chunk_len, std::max<size_t>(chunk_floor, g2_chunk));
     static const bool no_rounds = getenv("CG_MSM_NO_ROUNDS") != nullptr;                  // tuning knob
-    if (chunk_request) g.chunk_len = (uint32_t)std::min<size_t>(g.chunk_len, std::max<size_t>(chunk_min, chunk_request));
+    if (chunk_request) g.chunk_len = (uint32_t)std::min<size_t>(g.chunk_len, std::max<size_t>(chunk_floor, chunk_request));
     else if (resident_lanes && !no_rounds && entries >= resident_lanes * 2 * chunk_min) {      // from 32 entries per lane on (table slices of a multi-GPU plan:
         const size_t rounds = std::max<size_t>(1, (entries + resident_lanes * chunk_max / 2) / (resident_lanes * chunk_max));   // 2^20 points x 15 windows = one round of 80)
         g.chunk_len = (uint32_t)((entries + rounds * resident_lanes - 1) / (rounds * resident_lanes));   // between 2/3 and 3/2 of chunk_max (up to 192 entries): whole rounds matter more than the cap

@@ -10,7 +10,10 @@ namespace cg {
 
 // buckets per lane of k_msm_bitsum_partial and the resulting workgroups per bit
 template <class B> constexpr int bitsum_items() { return BITSUM_ITEMS; }   // 2 for G2 measured slower (four times the LDS trees): 2^18 step 8.5 -> 10.1 ms
-template <class B> uint32_t bitsum_groups(uint32_t nb) { return std::max<uint32_t>(1, (nb / 2 + 256 * bitsum_items<B>() - 1) / (256 * bitsum_items<B>())); }
+// TINY bucket sets (<= 2^10 buckets: circuits of a few hundred constraints) take ONE bucket per lane: with 8 a 128-bucket set is summed by 8 lanes in
+// 8 serial additions + 3 tree levels (11 x 22 us for G2), with 1 by 64 lanes in 1 + 6
+inline int bitsum_items_for(uint32_t nb) { return nb <= 1024u ? 1 : BITSUM_ITEMS; }
+template <class B> uint32_t bitsum_groups(uint32_t nb) { const uint32_t it = (uint32_t)bitsum_items_for(nb); return std::max<uint32_t>(1, (nb / 2 + 256 * it - 1) / (256 * it)); }
 
 // coordinates in the base field (G1: VGPR accumulator) or its quadratic extension (G2: LDS accumulator)
 template <class F> struct IsFp2 { static constexpr bool value = false; };
@@ -173,10 +176,12 @@ int msm_reduce_batch(hipStream_t st2, const MsmRedSet* sets, int nsets, size_t n
         static PerDeviceOnce attr_set2;
         if (attr_set2.pending()) {
             HIPCHK(hipFuncSetAttribute((const void*)k_msm_bitsum_partial<B, bitsum_items<B>()>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * sizeof(B))));
+            HIPCHK(hipFuncSetAttribute((const void*)k_msm_bitsum_partial<B, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * sizeof(B))));
             HIPCHK(hipFuncSetAttribute((const void*)k_msm_bitsum_final<F, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * sizeof(B))));
             attr_set2.mark();
         }
-        hipLaunchKernelGGL((k_msm_bitsum_partial<B, bitsum_items<B>()>), dim3((unsigned)(c * g.bit_groups), ys), dim3(256), 256 * sizeof(B), st2, S, g.nb, g.bit_groups);
+        if (bitsum_items_for(g.nb) == 1) hipLaunchKernelGGL((k_msm_bitsum_partial<B, 1>), dim3((unsigned)(c * g.bit_groups), ys), dim3(256), 256 * sizeof(B), st2, S, g.nb, g.bit_groups);
+        else hipLaunchKernelGGL((k_msm_bitsum_partial<B, bitsum_items<B>()>), dim3((unsigned)(c * g.bit_groups), ys), dim3(256), 256 * sizeof(B), st2, S, g.nb, g.bit_groups);
         hipLaunchKernelGGL((k_msm_bitsum_final<F, B>), dim3((unsigned)c, ys), dim3(64), 64 * sizeof(B), st2, S, g.bit_groups);
         return deliver((size_t)c);
     }

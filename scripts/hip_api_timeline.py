@@ -6,7 +6,10 @@ min_us = float(sys.argv[3]) if len(sys.argv) > 3 else 15.0
 rows = []
 for f in glob.glob(root + "/**/*hip_api_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
-end = max(int(r["End_Timestamp"]) for r in rows); t0 = end - int(window * 1e6)
+# anchor: the end of the last KERNEL (the last proof's last reduction), not the end of the process (its tear-down frees everything)
+kend = [int(r["End_Timestamp"]) for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True) for r in csv.DictReader(open(f))]
+end = (max(kend) + 400000) if kend else max(int(r["End_Timestamp"]) for r in rows); t0 = end - int(window * 1e6)
+rows = [r for r in rows if int(r["Start_Timestamp"]) <= end]
 tot = collections.defaultdict(lambda: [0, 0.0])
 print(f"calls of at least {min_us} us in the last {window} ms:")
 for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
