@@ -990,7 +990,7 @@ def main():
     multi_ent = None
     if world > 1 and not emulate and not args.no_session:
         w.release()
-        for c in (w.ctx_aux,):
+        for c in (w.ctx_aux, ctx):                    # the waiting ranks give their contexts back: rank 0's session is alone on the job's GPUs
             if c is not None and rank != 0:
                 c.close()
         host_barrier = (lambda: dist.barrier(group=host_group)) if host_group is not None else dist.barrier

@@ -1291,14 +1291,20 @@ int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr) {
         dc.n_hit++;
         return 0;
     }
-    // SMALL blocks whose size is parked but still behind its release mark: wait for the mark instead of asking the runtime for a new block.
-    // The mark stands behind the tail of the previous proof (a few tens of microseconds of work when the next proof of a small circuit asks
-    // for the same sizes again), hipMalloc costs 100-200 us — a Poseidon-sized party took that path 1.5 times per proof.  Large blocks keep
-    // the fresh allocation: their mark may stand behind milliseconds of accumulation.
-    if (pending && rb <= ((size_t)1 << 20) && hipEventSynchronize(first_pending->second.mark->ev) == hipSuccess) {
-        *d_ptr = first_pending->second.p; mark_unref(dc, first_pending->second.mark); dc.parked.erase(first_pending); dc.parked_bytes -= rb; dc.live[*d_ptr] = rb;
-        dc.n_hit++;
-        return 0;
+    // SMALL blocks whose size is parked but still behind its release mark: give the mark a moment (at most 40 us of polling) before asking the
+    // runtime for a new block.  When the next proof of a small circuit asks for the same sizes again the mark stands behind the tail of the
+    // previous proof, a few tens of microseconds of work, and hipMalloc costs 100-200 us (a Poseidon-sized party took that path 1.5 times per
+    // proof).  The wait is BOUNDED: a mark may just as well stand behind tens of milliseconds of another context's accumulations (an
+    // unbounded wait made a four-device 2^18 proof 155 ms).
+    if (pending && rb <= ((size_t)1 << 20)) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(40)) {
+            if (hipEventQuery(first_pending->second.mark->ev) == hipSuccess) {
+                *d_ptr = first_pending->second.p; mark_unref(dc, first_pending->second.mark); dc.parked.erase(first_pending); dc.parked_bytes -= rb; dc.live[*d_ptr] = rb;
+                dc.n_hit++;
+                return 0;
+            }
+        }
     }
     (void)hipGetLastError();
     if (pending) dc.n_pending++; else dc.n_fresh++;

@@ -69,6 +69,7 @@ struct ProofZKey {
         CG(cg_dev_upload(ctx, dz.pub_dev, pub.data(), pub.size() * 32));
     }
     ~ProofZKey() { if (dz.pub_dev) cg_dev_free(ctx, dz.pub_dev); }
+    void* release_pub() { void* p = dz.pub_dev; dz.pub_dev = nullptr; return p; }     // handed to the driver's batch of deferred releases
     ProofZKey(const ProofZKey&) = delete; ProofZKey& operator=(const ProofZKey&) = delete;
 };
 // the further GPUs of a multi-device session for one proof: a borrowed context per device, bound to that device's table slices
@@ -217,6 +218,7 @@ int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uin
             Proof p = prover.prove(pz.dz, pub, wit.v, rs, nullptr);
             if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             store_proof(p, (uint8_t*)out_proof);
+            driver.defer_free(pz.release_pub());
         }
         ctx.ok = second.ok = true; workers.ok();
         return 0;
@@ -266,6 +268,7 @@ int32_t cgh_session_prove_rep3_party_ex(void* h, const uint64_t* pub_in, const u
             rnd.settle();                                                                // the caller's generators stand behind the last draw when the call returns
             if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             store_proof(p, (uint8_t*)out_proof);
+            driver.defer_free(pz.release_pub());
         }
         ctx.ok = second.ok = true; workers.ok();
         return 0;
@@ -313,6 +316,7 @@ static int32_t shamir_party_impl(void* h, int32_t threshold, const uint64_t* pub
             Proof p = prover.prove(pz.dz, pub, wit.v, nullptr, nullptr);
             if (seconds) seconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             store_proof(p, (uint8_t*)out_proof);
+            driver.defer_free(pz.release_pub());
         }
         ctx.ok = second.ok = true; workers.ok();
         return 0;

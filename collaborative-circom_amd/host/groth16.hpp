@@ -13,7 +13,8 @@ struct VecGuard {   // device share vector released when the entry point leaves,
     // Leaving by an exception, kernels of the party's OTHER contexts (the witness-independent MSMs on the second context, the slices on
     // further GPUs) may still read the vector: cg_dev_free parks a block behind the RELEASING context's streams only, so those contexts
     // are drained first — on the regular path every MSM has been collected before the guard runs.
-    ~VecGuard() { try { if (std::uncaught_exceptions() > 0) d.sync_other_contexts(); d.free_vec(v); } catch (...) {} }
+    // (the block itself joins the driver's list of deferred releases: one release mark for everything a proof gives back, see HipDriver::shutdown)
+    ~VecGuard() { try { if (std::uncaught_exceptions() > 0) d.sync_other_contexts(); d.defer_vec(v); } catch (...) {} }
     VecGuard(const VecGuard&) = delete; VecGuard& operator=(const VecGuard&) = delete;
 };
 struct Proof { Bytes a, b, c; };   // packed affine, (0,0) = infinity  (Groth16Proof, groth16/proof.rs:8-29)
@@ -170,7 +171,7 @@ public:
         if (add_h) own.reset(new HipDriver::Components(driver, 1));
         h_msm = dz.sliced ? driver.msm_begin_sharded(dz, false, h) : driver.msm_begin_multi({dz.h}, {0}, {CG_G1}, h.n, h, false);   // :248
         own.reset();
-        driver.free_deferred();
+        if (h.n >= driver.XCHG_ASYNC_MIN) driver.free_deferred();     // large circuits give the witness map's vectors back now (GBs); small ones with everything else at the end: one release mark per proof
         mk.mark("h msm enqueued, vectors released");
         }
         FieldShare r = rs_plain ? rs_plain[0] : driver.rand();                                         // :134-135

@@ -64,7 +64,7 @@ const char* cg_version(void);
 /* ---- device memory (thin wrappers so non-HIP hosts can keep vectors resident between calls) ------------------- */
 /* cg_dev_free does not wait: the block is parked behind the work the context's streams hold at that moment and handed out again by a
  * later cg_dev_alloc (any context of the device) once that work has completed (a request of at most 1 MiB whose size is parked but not yet
- * released WAITS for that release — the tail of the previous proof of a small circuit — instead of asking the runtime for a new block).  Work on OTHER contexts that uses the block must have
+ * released polls that release for up to 40 us — the tail of the previous proof of a small circuit — before asking the runtime for a new block).  Work on OTHER contexts that uses the block must have
  * completed before the call.  CG_DEV_CACHE_MB bounds the parked bytes per device (0: release at once, which waits for the device). */
 int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr);
 int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr);
