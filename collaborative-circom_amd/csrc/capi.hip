@@ -1140,6 +1140,47 @@ int make_copy_streams(cg_ctx* c) {
 }
 }  // namespace
 
+// ---- which streams share a hardware queue?  Measured, not guessed.  The runtime maps streams onto a few hardware queues per priority class, and
+// two busy streams on one queue wait for each other's packets — in particular for each other's WAITS: a context whose reduction stream shares
+// a queue with its sort stream has the next schedule's kernels parked behind "wait for the accumulation" (the same small proof took 1.9 or
+// 3.7 ms from one session of a process to the next).  The slot bookkeeping of the pool above is a model of the runtime's choice; the probe is
+// the fact: two 120 us spin kernels, one per stream, started together — side by side they take 120 us, on one queue 240.
+__global__ void k_probe_spin(unsigned long long ticks) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) { } }
+namespace {
+bool streams_share_queue(hipStream_t a, hipStream_t b) {
+    if (!a || !b || a == b) return false;
+    double best = 1e9;
+    for (int rep = 0; rep < 2 && best > 190.0; rep++) {                          // (a second try settles a launch hiccup)
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return false; }
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, 12000ull);     // wall_clock64 ticks at 100 MHz: 120 us
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, b, 12000ull);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return false; }
+        best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    return best > 190.0;
+}
+// make `moving` not share a queue with any of `fixed` (same priority class): streams that do are parked again and others tried
+int separate_stream(int device, int cls, hipStream_t* moving, std::initializer_list<hipStream_t> fixed) {
+    static const bool off = getenv("CG_NO_STREAM_PROBE") != nullptr;            // A/B knob
+    if (off) return 0;
+    std::vector<hipStream_t> rejected;
+    for (int tries = 0; tries < 6; tries++) {
+        bool clash = false;
+        for (hipStream_t f : fixed) clash = clash || streams_share_queue(f, *moving);
+        if (!clash) break;
+        if (getenv("CG_DEBUG_STREAMS")) fprintf(stderr, "stream probe: class %d stream shares a hardware queue with another stream of its context: replaced (try %d)\n", cls, tries);
+        rejected.push_back(*moving);
+        hipStream_t st = nullptr;
+        if (int rc = new_stream(cls, &st)) { for (hipStream_t r : rejected) park_stream(device, cls, r); return rc; }
+        { std::lock_guard<std::mutex> l(g_stream_pool_mu); StreamClassPool& p = g_stream_pool[{device, cls}]; const int slot = p.created++ % HWQ; g_stream_slot[st] = slot; p.out[slot]++; }
+        *moving = st;
+    }
+    for (hipStream_t r : rejected) park_stream(device, cls, r);
+    return 0;
+}
+}  // namespace
+
 int32_t cg_stream_group_begin(void) { if (g_group_depth++ == 0) for (uint8_t& u : g_group_used) u = 0; return 0; }
 int32_t cg_stream_group_end(void) { if (g_group_depth > 0) g_group_depth--; return 0; }
 int32_t cg_ctx_create(int32_t device, cg_ctx** out) { return cg_ctx_create_ex(device, 0, out); }
@@ -1177,6 +1218,17 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     // the work-free stream behind released blocks (cg_dev_free) is made here, not at the first release: inside a stream group it then gets a
     // queue apart from a bulk context's low-priority main stream (its packets are waits for OTHER streams' progress: nothing may queue behind them)
     { int rc = pooled_stream(device, -1, &c->joinst); if (rc) return rc; }
+    // the context's busy streams of one priority class on hardware queues of their own (measured, see streams_share_queue): the two side
+    // streams against each other and against whatever else of the context lives in their class; a chain context's copy streams against its main stream
+    {
+        const bool side_with_main = c->prio_side == c->prio_main;
+        if (int rc = separate_stream(device, c->prio_side, &c->sortst, side_with_main ? std::initializer_list<hipStream_t>{c->aux, c->stream} : std::initializer_list<hipStream_t>{c->aux})) return rc;
+        if (side_with_main) { if (int rc = separate_stream(device, c->prio_side, &c->aux, {c->stream, c->sortst})) return rc; }
+        if (c->h2d && c->prio_copy == c->prio_main) {
+            if (int rc = separate_stream(device, c->prio_copy, &c->h2d, {c->stream})) return rc;
+            if (int rc = separate_stream(device, c->prio_copy, &c->d2h, {c->stream, c->h2d})) return rc;
+        }
+    }
     for (hipEvent_t& e : c->park_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_sched_free[i], hipEventDisableTiming)); for (int rs = 0; rs < 2; rs++) HIPCHK(hipEventCreateWithFlags(&c->ev_merged[rs][i], hipEventDisableTiming)); }

@@ -171,6 +171,7 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *                 CG_NTT_DIF / CG_NTT_NO_PAIR / CG_NTT_TILE (10)   canonical DIF passes; iNTT + coset + NTT as two calls; log2 of the lazy passes' LDS tile
  *                 CG_SUBGROUP_FULL           subgroup checks by [r]P instead of the endomorphism tests
  *                 CG_BULK_CLASS (-1)         priority class of a bulk context's main stream (cg_ctx_create_ex flag 2)
+ *                 CG_NO_STREAM_PROBE         new contexts keep the streams the pool hands them without measuring which of them share a hardware queue
  *                 CG_MSM_TABLE_ORDER, CG_MSM_G2_AFTER, CG_MSM_G2_SLICES, CG_MSM_REDUCE_BATCH, CG_MSM_ACC_SLOTS, CG_MSM_WIDE_SMALL   seed the option table of NEW contexts
  *                 CG_MSM_ONE_STREAM_LOG (0)  MSM calls of at most 2^this (point, window) entries run schedule, accumulation and reduction in stream order on the
  *                                            context's main stream (0 = never: measured slower than three streams); seeds new contexts
