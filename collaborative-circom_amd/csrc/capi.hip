@@ -1161,7 +1161,8 @@ bool streams_share_queue(hipStream_t a, hipStream_t b) {
     return best > 190.0;
 }
 // make `moving` not share a queue with any of `fixed` (same priority class): streams that do are parked again and others tried
-int separate_stream(int device, int cls, hipStream_t* moving, std::initializer_list<hipStream_t> fixed) {
+thread_local std::vector<hipStream_t> g_group_busy[3];                        // [class + 1]: streams of the contexts made so far in this thread's stream group
+int separate_stream(int device, int cls, hipStream_t* moving, std::vector<hipStream_t> fixed) {
     static const bool off = getenv("CG_NO_STREAM_PROBE") != nullptr;            // A/B knob
     if (off) return 0;
     std::vector<hipStream_t> rejected;
@@ -1181,7 +1182,7 @@ int separate_stream(int device, int cls, hipStream_t* moving, std::initializer_l
 }
 }  // namespace
 
-int32_t cg_stream_group_begin(void) { if (g_group_depth++ == 0) for (uint8_t& u : g_group_used) u = 0; return 0; }
+int32_t cg_stream_group_begin(void) { if (g_group_depth++ == 0) { for (uint8_t& u : g_group_used) u = 0; for (auto& v : g_group_busy) v.clear(); } return 0; }
 int32_t cg_stream_group_end(void) { if (g_group_depth > 0) g_group_depth--; return 0; }
 int32_t cg_ctx_create(int32_t device, cg_ctx** out) { return cg_ctx_create_ex(device, 0, out); }
 // flags bit 0 ("chain"): for the context that carries a dependency chain (witness map with its party-to-party exchanges) while another
@@ -1220,14 +1221,33 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     { int rc = pooled_stream(device, -1, &c->joinst); if (rc) return rc; }
     // the context's busy streams of one priority class on hardware queues of their own (measured, see streams_share_queue): the two side
     // streams against each other and against whatever else of the context lives in their class; a chain context's copy streams against its main stream
+    // Inside a stream group (one party's chain + bulk contexts) the streams of the contexts made before count as well: a class has four
+    // hardware queues, a pair of contexts puts at most four streams into one class.
     {
-        const bool side_with_main = c->prio_side == c->prio_main;
-        if (int rc = separate_stream(device, c->prio_side, &c->sortst, side_with_main ? std::initializer_list<hipStream_t>{c->aux, c->stream} : std::initializer_list<hipStream_t>{c->aux})) return rc;
-        if (side_with_main) { if (int rc = separate_stream(device, c->prio_side, &c->aux, {c->stream, c->sortst})) return rc; }
-        if (c->h2d && c->prio_copy == c->prio_main) {
-            if (int rc = separate_stream(device, c->prio_copy, &c->h2d, {c->stream})) return rc;
-            if (int rc = separate_stream(device, c->prio_copy, &c->d2h, {c->stream, c->h2d})) return rc;
+        const bool grp = g_group_depth > 0;
+        auto others = [&](int cls, std::initializer_list<hipStream_t> own) {
+            std::vector<hipStream_t> v;
+            for (hipStream_t o : own) if (o) v.push_back(o);
+            if (grp && cls >= -1 && cls <= 1) for (hipStream_t o : g_group_busy[cls + 1]) if (v.size() < (size_t)HWQ - 1) v.push_back(o);
+            return v;
+        };
+        auto placed = [&](int cls, hipStream_t st) { if (grp && cls >= -1 && cls <= 1) g_group_busy[cls + 1].push_back(st); };
+        if (int rc = separate_stream(device, c->prio_main, &c->stream, others(c->prio_main, {}))) return rc;
+        placed(c->prio_main, c->stream);
+        if (int rc = separate_stream(device, c->prio_side, &c->aux, others(c->prio_side, {c->prio_side == c->prio_main ? c->stream : nullptr}))) return rc;
+        placed(c->prio_side, c->aux);
+        if (int rc = separate_stream(device, c->prio_side, &c->sortst, others(c->prio_side, {c->aux, c->prio_side == c->prio_main ? c->stream : nullptr}))) return rc;
+        placed(c->prio_side, c->sortst);
+        if (c->h2d) {
+            if (int rc = separate_stream(device, c->prio_copy, &c->h2d, others(c->prio_copy, {c->prio_copy == c->prio_main ? c->stream : nullptr}))) return rc;
+            placed(c->prio_copy, c->h2d);
+            if (int rc = separate_stream(device, c->prio_copy, &c->d2h, others(c->prio_copy, {c->h2d, c->prio_copy == c->prio_main ? c->stream : nullptr}))) return rc;
+            placed(c->prio_copy, c->d2h);
         }
+        // the work-free join stream carries only waits for the context's other streams: it must not sit in front of a BUSY stream of its class
+        // (a bulk context's low-priority main stream)
+        if (int rc = separate_stream(device, -1, &c->joinst, others(-1, {c->prio_main == -1 ? c->stream : nullptr}))) return rc;
+        placed(-1, c->joinst);                                                      // (a later busy stream of the group keeps off its queue as well)
     }
     for (hipEvent_t& e : c->park_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
