@@ -1158,7 +1158,7 @@ bool streams_share_queue(hipStream_t a, hipStream_t b) {
         if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return false; }
         best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     }
-    return best > 190.0;
+    return best > 190.0 && best < 420.0;        // (far beyond 240 us: the device is busy with somebody else's work and the probe says nothing)
 }
 // make `moving` not share a queue with any of `fixed` (same priority class): streams that do are parked again and others tried
 thread_local std::vector<hipStream_t> g_group_busy[3];                        // [class + 1]: streams of the contexts made so far in this thread's stream group
@@ -1171,10 +1171,9 @@ int separate_stream(int device, int cls, hipStream_t* moving, std::vector<hipStr
         for (hipStream_t f : fixed) clash = clash || streams_share_queue(f, *moving);
         if (!clash) break;
         if (getenv("CG_DEBUG_STREAMS")) fprintf(stderr, "stream probe: class %d stream shares a hardware queue with another stream of its context: replaced (try %d)\n", cls, tries);
-        rejected.push_back(*moving);
+        rejected.push_back(*moving);                                              // (kept out of the pool until the choice is made)
         hipStream_t st = nullptr;
-        if (int rc = new_stream(cls, &st)) { for (hipStream_t r : rejected) park_stream(device, cls, r); return rc; }
-        { std::lock_guard<std::mutex> l(g_stream_pool_mu); StreamClassPool& p = g_stream_pool[{device, cls}]; const int slot = p.created++ % HWQ; g_stream_slot[st] = slot; p.out[slot]++; }
+        if (int rc = pooled_stream(device, cls, &st)) { for (hipStream_t r : rejected) park_stream(device, cls, r); return rc; }   // a parked stream first, a new one (4-10 ms) only when none is left
         *moving = st;
     }
     for (hipStream_t r : rejected) park_stream(device, cls, r);
