@@ -140,10 +140,12 @@ struct cg_ctx {
     // priority class of each stream: +1 high, 0 normal, -1 low (pooled_stream)
     int prio_main = 0, prio_side = 1, prio_copy = 0;
     uint32_t msm_chunk = 0;                               // cg_msm_set_chunk / CG_OPT_MSM_CHUNK
+    int off_main_log = 19;                                // CG_MSM_OFF_MAIN_LOG: wide calls of at most 2^this entries keep their accumulations OFF the main stream (0 = never), see msm_begin_multi_impl_
     int one_stream_log = 0;                               // CG_MSM_ONE_STREAM_LOG: calls of at most 2^this entries run on the main stream alone (0 = never, the default: measured slower)
     int table_order = 0, g2_after = -1, g2_slices = 0, red_batch = 2, acc_slots = 4, wide_small = 1;   // CG_OPT_MSM_TABLE_ORDER / _G2_SLICES / _REDUCE_BATCH / _ACC_SLOTS (cg_ctx_set_option)
     hipEvent_t ev_peer = nullptr;                         // cg_dev_copy_peer: "source stream reached this point"
     Arena arena;
+    Arena ntt_arena;                                      // limb-form scratch of the transforms: NOT the MSM arena (ensure_ntt_arena)
     std::vector<void*> retired;                        // outgrown arena blocks that enqueued kernels may still use
     void* gather_buf = nullptr; size_t gather_cap = 0;   // scalars gathered for compacted tables (see cg_bases::compact)
     std::map<TwKey, void*> twiddles;
@@ -189,6 +191,23 @@ int ensure_arena(cg_ctx* ctx, size_t bytes) {
     size_t want = align_up(bytes + bytes / 8, 1 << 20);
     HIPCHK(hip_malloc_flush((void**)&ctx->arena.base, want));
     ctx->arena.cap = want;
+    return 0;
+}
+
+// The transforms' scratch is a block of its own.  It used to be the front of the MSM arena, and a transform therefore had to wait for every bucket
+// reduction still reading that arena on the side streams: a one-context party's witness map — constraint rows, product, TRANSFORMS, first
+// exchange — stood still until the witness-independent MSMs it had started first were completely done (Poseidon fixture: the first exchange's
+// download waited 0.2-0.46 ms of a 1.5 ms proof; with the reductions switched off it took 45 us).  Transforms run on the main stream only,
+// so successive users of this block are ordered by the stream itself.
+int ensure_ntt_arena(cg_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ntt_arena.cap) return 0;
+    const bool idle = hipStreamQuery(ctx->stream) == hipSuccess;
+    (void)hipGetLastError();
+    if (ctx->ntt_arena.base) { if (idle) HIPCHK(hipFree(ctx->ntt_arena.base)); else ctx->retired.push_back(ctx->ntt_arena.base); }   // (enqueued kernels keep the old block: freed when the context is idle or goes away)
+    ctx->ntt_arena.base = nullptr; ctx->ntt_arena.cap = 0;
+    const size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    HIPCHK(hip_malloc_flush((void**)&ctx->ntt_arena.base, want));
+    ctx->ntt_arena.cap = want;
     return 0;
 }
 
@@ -487,14 +506,17 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         for (int b = 0; b < nb; b++) tables_of_group[bases[b]->group == CG_G1 ? 0 : 1]++;
         std::vector<int> comps_left(nb, k);
         hipStream_t red_stream[2] = {auxst, auxst};      // reduction stream per field (wide mode: G1 on the idle sort stream, beside G2 on aux)
+        hipStream_t acc_stream[2] = {ctx->stream, ctx->stream};   // accumulation stream per field (the main stream, except for tiny wide calls: see `off_main`)
+        hipEvent_t last_acc[2] = {nullptr, nullptr};      // behind the last accumulation of a field's flushed batch
         auto flush = [&](int gi) -> int {
             std::vector<PendSet>& pd = pend[gi];
             if (pd.empty()) return 0;
             hipStream_t rst = red_stream[gi];
             // every accumulation of the batch sits on the main stream in front of this point: the reduction stream waits for the last one
             hipEvent_t ea = ctx->ev_acc[pd.back().slot];
-            HIPCHK(hipEventRecord(ea, ctx->stream));
-            HIPCHK(hipStreamWaitEvent(rst, ea, 0));
+            HIPCHK(hipEventRecord(ea, acc_stream[gi]));
+            if (rst != acc_stream[gi]) HIPCHK(hipStreamWaitEvent(rst, ea, 0));
+            last_acc[gi] = ea;
             hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
             if (ctx->stats_on) { const int i2 = ev_open(ctx, TAG_REDUCE); evs[0] = ctx->ev_live[i2].a; evs[1] = ctx->ev_live[i2].b; pev = evs; }
             hipEvent_t evm[2]; int nm = 0; bool seen[2] = {false, false};
@@ -530,16 +552,23 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // additions; eight in a row cost eight chains (2^16 step: 3.2 ms), side by side one.
         // (measured, round 4: 2^14 step 2.63 -> 2.14 ms, 2^16 3.30 -> 3.09 ms and one REP3 party 5.85 -> 5.54 ms; from 2^17 points on — 2^21 entries — no gain)
         const bool wide = k <= 2 && nb * k <= std::min(acc_slots, (int)ACC_MAX_SETS) && (uint64_t)nwin * n <= wide_max;
+        // TINY wide calls (CG_OPT_MSM_OFF_MAIN_LOG, default 2^19 entries) keep the main stream free: the G2 sets are accumulated on the aux stream
+        // and the G1 sets on the sort stream, each in front of its own reduction, and the main stream only marks where the scalars are
+        // ready.  Such a call fills a fraction of the chip, so nothing is gained by queueing the caller's next kernels behind its accumulations
+        // — a one-context party's witness map (a chain of short kernels and two host round trips) started 0.3 ms late behind the
+        // witness-independent MSMs, and later still whenever their streams had fallen onto a shared hardware queue.
+        const bool off_main = wide && !one_stream && ctx->off_main_log > 0 && (uint64_t)nwin * n <= ((uint64_t)1 << ctx->off_main_log);
         if (wide) {
             if (k == 2) { int rc = launch_sort(1); if (rc) return rc; }
-            for (int j = 0; j < k; j++) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[j], 0));
+            if (off_main) { acc_stream[0] = sortst; acc_stream[1] = auxst; }
+            for (int j = 0; j < k; j++) HIPCHK(hipStreamWaitEvent(acc_stream[1], ctx->ev_sorted[j], 0));      // (main stream, or aux; the sort stream is behind its own sorts anyway)
             red_stream[0] = sortst;
             for (int gi : {1, 0}) {
                 std::vector<MsmAccSet> sets;
                 for (int j = 0; j < k; j++) for (int b = 0; b < nb; b++) {
                     if ((bases[b]->group == CG_G1 ? 0 : 1) != gi) continue;
                     const int slot = iter++ % acc_slots;
-                    if (ctx->slot_busy[slot]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_red[slot], 0));
+                    if (ctx->slot_busy[slot]) HIPCHK(hipStreamWaitEvent(acc_stream[gi], ctx->ev_red[slot], 0));
                     char* scratch = acc_scratch + (size_t)slot * acc_slot;
                     sets.push_back(acc_set(b, j, scratch));
                     pend[gi].push_back(PendSet{red_set(b, j, scratch), slot, j, b, j});
@@ -549,13 +578,16 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
                 if (ctx->stats_on) { const int i1 = ev_open(ctx, gi == 0 ? TAG_ACC_G1 : TAG_ACC_G2); evs[0] = ctx->ev_live[i1].a; evs[1] = ctx->ev_live[i1].b; pev = evs; }
                 int rc = with_coord_field(curve, gi == 0 ? CG_G1 : CG_G2, [&](auto ftag) -> int {
                     typedef decltype(ftag) F;
-                    return msm_accumulate_batch<F>(ctx->stream, sets.data(), (int)sets.size(), n, c, nwin, shared, sps[0].cap, pev, chunk_request, false);
+                    return msm_accumulate_batch<F>(acc_stream[gi], sets.data(), (int)sets.size(), n, c, nwin, shared, sps[0].cap, pev, chunk_request, false);
                 });
                 if (rc) return rc;
                 if (gi == 0) HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_sorted[k - 1], 0));     // (the sort stream has nothing else left in this call)
                 { int rc2 = flush(gi); if (rc2) return rc2; }
             }
-            for (int j = 0; j < k; j++) HIPCHK(hipEventRecord(ctx->ev_sched_free[j], ctx->stream));
+            // the schedules are free once every accumulation has read them: behind them all on the main stream, or (off the main stream) on the
+            // sort stream, which holds the G1 accumulations itself and waits here for the G2 ones
+            if (off_main && last_acc[1]) HIPCHK(hipStreamWaitEvent(sortst, last_acc[1], 0));
+            for (int j = 0; j < k; j++) HIPCHK(hipEventRecord(ctx->ev_sched_free[j], off_main ? sortst : ctx->stream));
         }
         // one accumulation: table b, share component j, into the next rotating scratch slot; its bucket set joins the batch of its field
         auto do_acc = [&](int b, int j) -> int {
@@ -900,7 +932,7 @@ int ntt_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_t n, const 
         int rc = get_twiddles_lazy<Fr>(ctx, curve, log_m, w, &twl);
         if (rc) return rc;
         NttVecs data{}, tmp{};
-        for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->arena.base + arena_off + (size_t)j * lazy29_bytes(n); }
+        for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->ntt_arena.base + arena_off + (size_t)j * lazy29_bytes(n); }
         hipStream_t st = ctx->stream;
         bool first = true;
         static const int lazy_tile = [] { const char* e = getenv("CG_NTT_TILE"); const int v = e ? atoi(e) : NTT_TILE_LOG_LAZY; return std::min(NTT_TILE_LOG, std::max(8, v)); }();   // tuning knob
@@ -921,7 +953,7 @@ int ntt_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_t n, const 
     int rc = get_twiddles<Fr>(ctx, curve, log_m, w, &tw);
     if (rc) return rc;
     NttVecs data{}, tmp{};
-    for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->arena.base + arena_off + (size_t)j * n * sizeof(Fr); }
+    for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->ntt_arena.base + arena_off + (size_t)j * n * sizeof(Fr); }
     hipStream_t st = ctx->stream;
     {   // first pass reads the caller's vectors and writes the scratch copies; later passes run in the scratch copies
         bool first = true;
@@ -960,7 +992,7 @@ int ntt_coset_pair_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_
     CosetTables ct;
     rc = get_coset_tables<Fr>(ctx, curve, log_m, coset, c32 * fp_inverse(nn.to_mont()), &ct); if (rc) return rc;
     NttVecs data{}, tmp{};
-    for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->arena.base + arena_off + (size_t)j * lazy29_bytes(n); }
+    for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->ntt_arena.base + arena_off + (size_t)j * lazy29_bytes(n); }
     hipStream_t st = ctx->stream;
     static const int lazy_tile = [] { const char* e_ = getenv("CG_NTT_TILE"); const int v = e_ ? atoi(e_) : NTT_TILE_LOG_LAZY; return std::min(NTT_TILE_LOG, std::max(8, v)); }();
     const std::vector<NttPass> plan = ntt_plan(log_m, lazy_tile);
@@ -1205,7 +1237,7 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     {   // A/B runs: environment variables seed the option table of new contexts (include/cogroth16_hip.h, cg_ctx_set_option)
         auto seed = [](const char* name, int lo, int hi, int& field) { if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= lo && v <= hi) field = v; } };
         seed("CG_MSM_TABLE_ORDER", 0, 2, c->table_order); seed("CG_MSM_G2_AFTER", -1, 64, c->g2_after); seed("CG_MSM_G2_SLICES", 0, 1, c->g2_slices);
-        seed("CG_MSM_REDUCE_BATCH", 0, 3, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots); seed("CG_MSM_WIDE_SMALL", 0, 30, c->wide_small); seed("CG_MSM_ONE_STREAM_LOG", 0, 30, c->one_stream_log);
+        seed("CG_MSM_REDUCE_BATCH", 0, 3, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots); seed("CG_MSM_WIDE_SMALL", 0, 30, c->wide_small); seed("CG_MSM_ONE_STREAM_LOG", 0, 30, c->one_stream_log); seed("CG_MSM_OFF_MAIN_LOG", 0, 30, c->off_main_log);
     }
     if (flags & 1u) { c->prio_main = 1; c->prio_copy = 1; c->prio_side = 0; }
     else if (flags & 2u) { static const int bulk_cls = getenv("CG_BULK_CLASS") ? atoi(getenv("CG_BULK_CLASS")) : -1; c->prio_main = bulk_cls; c->prio_side = 0; }   // CG_BULK_CLASS: tuning knob
@@ -1281,6 +1313,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
     for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.h_flags) hipHostFree(t.h_flags); if (t.done) hipEventDestroy(t.done); }
     if (ctx->arena.base) hipFree(ctx->arena.base);
+    if (ctx->ntt_arena.base) hipFree(ctx->ntt_arena.base);
     for (void* p : ctx->retired) hipFree(p);
     if (ctx->gather_buf) hipFree(ctx->gather_buf);
     for (auto& p : ctx->ev_live) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
@@ -1904,7 +1937,7 @@ int32_t cg_ntt_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, int32_t k, s
         typedef decltype(tag) Fr;
         Fr gen, cos; copy_in(gen, h_group_gen);
         if (h_coset_gen) copy_in(cos, h_coset_gen);
-        if (n > 1) { int rc = ensure_arena(ctx, (size_t)k * lazy29_bytes(n)); if (rc) return rc; }
+        if (n > 1) { int rc = ensure_ntt_arena(ctx, (size_t)k * lazy29_bytes(n)); if (rc) return rc; }
         StatScope ss(ctx, TAG_NTT);
         return ntt_run<Fr>(ctx, curve, d_vecs, k, n, gen, inverse != 0, h_coset_gen ? &cos : nullptr, 0);
     });
@@ -1917,7 +1950,7 @@ int32_t cg_ntt_coset_pair_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, i
     return with_fr(curve, [&](auto tag) -> int {
         typedef decltype(tag) Fr;
         Fr gen, cos; copy_in(gen, h_group_gen); copy_in(cos, h_coset_gen);
-        if (n > 1) { int rc = ensure_arena(ctx, (size_t)k * lazy29_bytes(n)); if (rc) return rc; }
+        if (n > 1) { int rc = ensure_ntt_arena(ctx, (size_t)k * lazy29_bytes(n)); if (rc) return rc; }
         StatScope ss(ctx, TAG_NTT);
         return ntt_coset_pair_run<Fr>(ctx, curve, d_vecs, k, n, gen, cos, 0);
     });

@@ -3,9 +3,46 @@
 #include "formats.hpp"
 #include "network.hpp"
 #include "chacha.hpp"
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <future>
+#include <thread>
 
 namespace cgh {
+
+// Helper threads for the few independent host steps of a proof's tail (variable-base products, ~60 us each in G1): kept for the life of the
+// process — starting a thread per product (std::async) cost ~20 us of the 60 it saved.  A product finds a waiting helper or, when all
+// HELPERS_MAX are busy (several parties proving in one process), runs on the calling thread.  Never destroyed: the helpers sleep until exit.
+class Helpers {
+    static constexpr size_t HELPERS_MAX = 8;
+    std::mutex mu; std::condition_variable cv; std::deque<std::function<void()>> q; size_t threads = 0, waiting = 0;
+    void loop() {
+        std::unique_lock<std::mutex> l(mu);
+        for (;;) {
+            waiting++; cv.wait(l, [this] { return !q.empty(); }); waiting--;
+            std::function<void()> job = std::move(q.front()); q.pop_front();
+            l.unlock(); job(); l.lock();
+        }
+    }
+public:
+    static Helpers& get() { static Helpers* h = new Helpers(); return *h; }
+    template <class F> auto run(F f) -> std::future<decltype(f())> {
+        typedef decltype(f()) R;
+        auto task = std::make_shared<std::packaged_task<R()>>(std::move(f));
+        std::future<R> fut = task->get_future();
+        {
+            std::unique_lock<std::mutex> l(mu);
+            if (waiting <= q.size()) {                                               // nobody free for it
+                if (threads >= HELPERS_MAX) { l.unlock(); (*task)(); return fut; }
+                threads++; std::thread([this] { loop(); }).detach();
+            }
+            q.push_back([task] { (*task)(); });
+        }
+        cv.notify_one();
+        return fut;
+    }
+};
 
 // ---- driver ------------------------------------------------------------------------------------------------------------
 struct ShareVec {   // device; REP3 uses c[0] = a, c[1] = b; plain only c[0]
@@ -83,16 +120,16 @@ public:
     int party() const { return mode == Mode::Rep3 ? net->id() : -1; }
 
     HipDriver(cg_ctx* c, Curve cv, Mode m, Rep3Network* n) : ctx(c), curve(cv), mode(m), net(n) {}
-    // CGH_TIMING=1: wall-clock marks of the host-side protocol steps (stderr)
+    // CGH_TIMING=1: wall-clock marks of the host-side protocol steps (stderr, microseconds since the previous mark)
     struct Marks {
         bool on; const char* what; std::chrono::steady_clock::time_point last; std::string line;
         Marks(const char* w, bool enabled) : on(enabled && getenv("CGH_TIMING")), what(w), last(std::chrono::steady_clock::now()) {}
         void mark(const char* name) {
             if (!on) return;
             const auto t = std::chrono::steady_clock::now(); char b[96];
-            snprintf(b, sizeof b, " %s %.1f", name, std::chrono::duration<double, std::milli>(t - last).count()); line += b; last = t;
+            snprintf(b, sizeof b, " %s %.0f", name, std::chrono::duration<double, std::micro>(t - last).count()); line += b; last = t;
         }
-        ~Marks() { if (on) fprintf(stderr, "%s [ms]:%s\n", what, line.c_str()); }
+        ~Marks() { if (on) fprintf(stderr, "%s [us]:%s\n", what, line.c_str()); }
     };
 
     // ---- Shamir state (shamir.rs:196-246): threshold, Lagrange tables, buffered double sharings; randomness = stream rng1
@@ -509,6 +546,9 @@ public:
     std::deque<MaskSet> prefetched;
     void prefetch_masks(int count, size_t n) {
         if (mode != Mode::Rep3) return;
+        // short vectors are drawn where mul_vec asks for them: nothing to prepare — and nothing to allocate and release again (a released
+        // block costs a mark on every stream of the context: the two attempts of a small proof took 0.2 ms of its 1.6)
+        if (n < XCHG_ASYNC_MIN && (!rsrc || n < DEVICE_MASKS_MIN)) return;
         if (rsrc) {                                                                     // drawn now, in the reference's order (both mul_vec calls precede every other draw)
             // the masks of `count` consecutive mul_vec calls are count * n consecutive draws of each generator: ONE device draw per generator
             // (one stream synchronisation each instead of `count`), cut into the calls' vectors
@@ -607,11 +647,15 @@ public:
         ShareVec& out = pm.out;
         pm.exchange = false;
         if (out.n < XCHG_ASYNC_MIN) {                                                  // rep3.rs:661-669 as one message
+            Marks mk("  mul_vec_finish (one message)", party() <= 0);
             std::vector<Fr> local(out.n), recv(out.n);
             CG(cg_dev_download(ctx, local.data(), out.c[0], out.n * 32));
+            mk.mark("download");
             net->send_next(local.data(), out.n * 32);
             net->recv_prev(recv.data(), out.n * 32); check_received(recv.data(), out.n);
+            mk.mark("send + receive");
             CG(cg_dev_upload(ctx, out.c[1], recv.data(), out.n * 32));
+            mk.mark("upload");
             return out;
         }
         const size_t n = out.n, XCHG_CHUNK = xchg_chunk(n), nch = (n + XCHG_CHUNK - 1) / XCHG_CHUNK;
@@ -888,8 +932,9 @@ public:
     PointShare scalar_mul_public_point(const Point& p, const FieldShare& s, const cg_fixed_base* tab = nullptr) {   // rep3.rs:820-825 (tab: p's window table, if the session holds one)
         PointShare r;
         if (!tab && k() == 2) {                                                          // two variable-base products: side by side (see scalar_mul)
-            auto other = std::async(std::launch::async, [&] { return pt_mul_fixed(curve, nullptr, p, s.c[1]); });
-            r.c[0] = pt_mul_fixed(curve, nullptr, p, s.c[0]); r.c[1] = other.get();
+            auto other = Helpers::get().run([&] { return pt_mul_fixed(curve, nullptr, p, s.c[1]); });
+            try { r.c[0] = pt_mul_fixed(curve, nullptr, p, s.c[0]); } catch (...) { other.wait(); throw; }   // (the helper reads this frame)
+            r.c[1] = other.get();
             return r;
         }
         for (int j = 0; j < 2; j++) r.c[j] = j < k() ? pt_mul_fixed(curve, tab, p, s.c[j]) : pt_inf(curve, p.group); return r;
@@ -898,11 +943,12 @@ public:
         PointShare r;
         if (mode == Mode::Plain) { r.c[0] = pt_mul(curve, a.c[0], b.c[0]); r.c[1] = pt_inf(curve, a.c[0].group); return r; }
         if (mode == Mode::Shamir) { r.c[0] = degree_reduce_point(pt_mul(curve, a.c[0], b.c[0])); r.c[1] = pt_inf(curve, a.c[0].group); return r; }   // shamir.rs:769-776
-        // three independent variable-base products (~60 us each in G1 on the host): two of them on helper threads — they sit between the last MSM
-        // result and the proof, on every proof's tail (a thread start costs ~20 us)
-        auto p1 = std::async(std::launch::async, [&] { return pt_mul(curve, a.c[1], b.c[0]); });
-        auto p2 = std::async(std::launch::async, [&] { return pt_mul(curve, a.c[0], b.c[1]); });
-        const Point p0 = pt_mul(curve, a.c[0], b.c[0]);
+        // three independent variable-base products (~60 us each in G1 on the host): two of them on helper threads (Helpers) — they sit between the
+        // last MSM result and the proof, on every proof's tail
+        auto p1 = Helpers::get().run([&] { return pt_mul(curve, a.c[1], b.c[0]); });
+        auto p2 = Helpers::get().run([&] { return pt_mul(curve, a.c[0], b.c[1]); });
+        Point p0; try { p0 = pt_mul(curve, a.c[0], b.c[0]); } catch (...) { p1.wait(); p2.wait(); throw; }   // (the helpers read this frame)
+        p1.wait(); p2.wait();                                      // both done before either result (or exception) leaves this frame
         Point local = pt_add(curve, pt_add(curve, p0, p1.get()), p2.get());
         if (rsrc) { Point m{Bytes(curve.jac(a.c[0].group)), a.c[0].group}; rsrc->masking_ec_element(m.group, m.b.data()); local = pt_add(curve, local, m); }   // rngs.rs:48-51
         else {

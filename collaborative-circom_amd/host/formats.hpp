@@ -167,8 +167,17 @@ static SnarkjsRoots snarkjs_roots(const Curve& c) {
     for (int i = 1; i <= s; i++) roots[i] = fr_mul(c, roots[i - 1], roots[i - 1]);
     return SnarkjsRoots{q, std::vector<Fr>(roots.rbegin(), roots.rend()), s};
 }
+// (computed once per curve: the search for the non-residue is half a dozen 254-bit exponentiations, ~80 us through the ABI's field calls — and a
+// party's proof asks for its domain three times)
+static const SnarkjsRoots& snarkjs_roots_cached(const Curve& c) {
+    static std::mutex mu; static std::map<int, SnarkjsRoots> table;
+    std::lock_guard<std::mutex> l(mu);
+    auto it = table.find(c.id);
+    if (it == table.end()) it = table.emplace(c.id, snarkjs_roots(c)).first;
+    return it->second;                                                               // (entries are never removed: the reference stays valid)
+}
 static Domain groth16_domain(const Curve& c, size_t pow, size_t num_constraints, size_t num_inputs) {
-    const SnarkjsRoots rt = snarkjs_roots(c);
+    const SnarkjsRoots& rt = snarkjs_roots_cached(c);
     Domain d; d.m = 1; d.log_m = 0;
     while (d.m < num_constraints + num_inputs) { d.m <<= 1; d.log_m++; }
     d.omega = rt.roots[pow];

@@ -201,12 +201,17 @@ public:
         }
         auto aux_result = [&](int i) { return have_early ? early[i] : driver.msm_finish(aux_msm, i); };
         PointShare g_a = calculate_coeff(r_g1, z.a_query, CG_G1, z.alpha_g1, input_assignment, aux_result(AUX_A), fx ? &fx->a_pub : nullptr);   // :267
+        mk.mark("msm a");
         Point g_a_opened = driver.open_point(g_a);                                                     // :276
+        mk.mark("open a");
         PointShare s_g_a = driver.scalar_mul_public_point(g_a_opened, s);                              // :277
+        mk.mark("s * a");
         PointShare g1_b = calculate_coeff(s_g1, z.b_g1_query, CG_G1, z.beta_g1, input_assignment, aux_result(AUX_B1), fx ? &fx->b1_pub : nullptr);   // :284
+        mk.mark("msm b1");
         PointShare r_g1_b = driver.scalar_mul(g1_b, r);                                                // :291
+        mk.mark("r * b1");
         PointShare g2_b = calculate_coeff(s_g2, z.b_g2_query, CG_G2, z.beta_g2, input_assignment, aux_result(AUX_B2), fx ? &fx->b2_pub : nullptr);   // :298
-        mk.mark("msm a, b1, b2 + their scalar steps");
+        mk.mark("msm b2");
         PointShare l_aux_acc = aux_result(AUX_L);                                          // :251
         PointShare h_acc = have_early ? early[4] : driver.msm_finish(h_msm, 0);                                               // :248
         mk.mark("msm l + h");

@@ -7,7 +7,7 @@ rows = []
 for f in glob.glob(root + "/**/*hip_api_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 # anchor: the end of the last KERNEL (the last proof's last reduction), not the end of the process (its tear-down frees everything)
-kend = [int(r["End_Timestamp"]) for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True) for r in csv.DictReader(open(f))]
+kend = [int(r["End_Timestamp"]) for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True) for r in csv.DictReader(open(f)) if "k_probe_spin" not in r["Kernel_Name"]]     # (contexts made at the very end of a process probe their streams)
 end = (max(kend) + 400000) if kend else max(int(r["End_Timestamp"]) for r in rows); t0 = end - int(window * 1e6)
 rows = [r for r in rows if int(r["Start_Timestamp"]) <= end]
 tot = collections.defaultdict(lambda: [0, 0.0])

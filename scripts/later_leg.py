@@ -11,7 +11,8 @@ files = (os.path.join(fx, "circuit.zkey"), os.path.join(fx, "witness.wtns"))
 def leg(what):
     out = bench.entry_leg(ctx, 0 if what == "poseidon" else what, dev, 20 if what == "poseidon" or what <= 16 else 5, 2, extras=False, files=files if what == "poseidon" else None)
     print(what, round(out["ms_per_proof"], 2), "min inner", round(out["ms_per_proof_min_inner"], 2), flush=True)
-for what in ("poseidon", 16, "poseidon", 20, "poseidon", 22, "poseidon", 16):
+legs = os.environ.get("LEGS")            # e.g. LEGS=poseidon,16,poseidon for a short traced run
+for what in ([x if x == "poseidon" else int(x) for x in legs.split(",")] if legs else ("poseidon", 16, "poseidon", 20, "poseidon", 22, "poseidon", 16)):
     leg(what)
 if os.environ.get("RESIDENT_BETWEEN"):
     r = bench.resident_leg(ctx, cg.Context(0), dev, 20, 5, 2, cg.BN254)
