@@ -1103,10 +1103,23 @@ def main():
                 else:
                     out["value_basis"] = "step_resident (inputs resident in HBM): the multi-device product entry FAILED on this box (product_entry.error), so this line is NOT on the N = 1 line's basis — compare with step_resident.value there"
         legs = not args.no_session and world == 1
+
+        def entry_alone(*a, **kw):
+            """An entry leg with the harness's second context closed: that context belongs to the resident legs, and its idle streams would sit on
+            hardware queues next to the session's own (a 2^16 party as a leg of this process: 3.8 ms with it open, 3.2 in a process that holds
+            only the session, scripts/later_leg.py).  The resident legs get a new one afterwards."""
+            had = w.ctx_aux is not None
+            if had:
+                w.ctx_aux.sync(); w.ctx_aux.close(); w.ctx_aux = None
+            try:
+                return entry_leg(*a, **kw)
+            finally:
+                if had:
+                    w.ctx_aux = cg.Context(local_rank); w.ctx_aux.set_scatter_capacity(args.scatter_cap)
         if legs:
             w.release()                                                 # the session registers its own tables (another 21 GB of window copies at 2^22)
             try:
-                ent = entry_leg(ctx, args.log_m, device, args.steps, args.warmup, CURVE, extras=True)
+                ent = entry_alone(ctx, args.log_m, device, args.steps, args.warmup, CURVE, extras=True)
                 # THE HEADLINE: the reference's timed region through the product's entry
                 out["value"], out["ms_per_step"] = ent["value"], ent["ms_per_proof"]
                 out["value_basis"] = ("product entry: ONE REP3 party through cgh_session_prove_rep3_party_ex — witness shares in host memory in, proof out, the party's ChaCha12 mask draws, both "
@@ -1123,7 +1136,7 @@ def main():
                 k_ = 10 if lg <= 20 else 5
                 try:
                     r_ = resident_leg(ctx, w.ctx_aux, device, lg, k_, 2, CURVE, args.precompute, args.scatter_cap)
-                    e_ = entry_leg(ctx, lg, device, k_, 1, CURVE, extras=False)
+                    e_ = entry_alone(ctx, lg, device, k_, 1, CURVE, extras=False)
                     sizes["2^%d" % lg] = {"step_resident": {k: r_[k] for k in ("ms_per_step", "value", "unit", "steps", "step_hbm")},
                                           "product_entry": {k: e_[k] for k in ("ms_per_proof", "ms_per_proof_min_inner", "ms_inner_each", "value", "unit", "proofs", "three_parties_agree", "zkey")},
                                           "roofline": r_["roofline"], "roofline_g2": r_["roofline_g2"], "roofline_ntt": r_["roofline_ntt"], "valu_roofline": r_["valu_roofline"], "isolated_ms": r_["isolated_ms"]}
@@ -1133,7 +1146,7 @@ def main():
             # the reference's own benchmark: Poseidon(2) Groth16 REP3 (tests/benches/poseidon_hash2.rs:175-223) = the fixture circuit, m = 256
             try:
                 fxd = os.path.join(ROOT, "tests", "golden", "groth16", "bn254" if CURVE == cg.BN254 else "bls12_381", "poseidon")
-                p_ = entry_leg(ctx, 0, device, 20, 3, CURVE, extras=False, files=(os.path.join(fxd, "circuit.zkey"), os.path.join(fxd, "witness.wtns")))
+                p_ = entry_alone(ctx, 0, device, 20, 3, CURVE, extras=False, files=(os.path.join(fxd, "circuit.zkey"), os.path.join(fxd, "witness.wtns")))
                 out["poseidon_fixture"] = {k: p_[k] for k in ("ms_per_proof", "ms_per_proof_min_inner", "ms_inner_each", "value", "unit", "proofs", "three_parties_agree", "circuit", "entry")}
                 out["poseidon_fixture"]["what"] = "one REP3 party of the reference's own bench circuit (Poseidon(2), tests/benches/poseidon_hash2.rs:175-223; 213 constraints, domain 256) through the same entry"
             except Exception as e:                                      # noqa: BLE001
@@ -1141,7 +1154,7 @@ def main():
             other = cg.BLS12_381 if CURVE == cg.BN254 else cg.BN254
             try:                                                        # the second curve of the reference's e2e matrix, same legs at the line's size
                 r_ = resident_leg(ctx, w.ctx_aux, device, args.log_m, 5, 2, other, args.precompute, args.scatter_cap)
-                e_ = entry_leg(ctx, args.log_m, device, 5, 1, other, extras=False)
+                e_ = entry_alone(ctx, args.log_m, device, 5, 1, other, extras=False)
                 out.setdefault("session", {})[args.curve == "bn254" and "bls12_381" or "bn254"] = {
                     "curve": CURVE_NAME[other], "log_m": args.log_m,
                     "step_resident": {k: r_[k] for k in ("ms_per_step", "value", "unit", "steps", "step_hbm")},

@@ -2199,11 +2199,15 @@ int32_t cg_vec_rep3_mul_local(cg_ctx* ctx, int32_t curve, void* h_out, const voi
 }
 
 // ---------------------------------------------------------------------------------------------------- O(1) host helpers
+// (all on 64-bit limbs, host_ec64.hpp: a small proof's tail is a few dozen of these calls and nothing else — the additions, the seven
+// conversions to affine form (an inversion each) and the subgroup test of the one G2 point a REP3 party receives were 0.25 ms of a 1.1 ms
+// proof on the 32-bit-limb field code the kernels share with the host)
 int32_t cg_point_add(int32_t curve, int32_t group, const void* h_a, const void* h_b, void* h_out) {
-    return with_group(curve, group, [&](auto ftag, auto) -> int {
+    if (!h_a || !h_b || !h_out) return fail(CG_ERR_ARG, "null argument");
+    return with_group64(curve, group, [&](auto ftag, auto) -> int {
         typedef decltype(ftag) F;
-        Jacobian<F> a, b; memcpy(&a, h_a, sizeof a); memcpy(&b, h_b, sizeof b);
-        Jacobian<F> r = xyzz_to_jacobian(xyzz_add(jacobian_to_xyzz(a), jacobian_to_xyzz(b)));
+        cg64::Jac<F> a, b; memcpy(&a, h_a, sizeof a); memcpy(&b, h_b, sizeof b);
+        const cg64::Jac<F> r = cg64::add(a, b);
         memcpy(h_out, &r, sizeof r); return 0;
     });
 }
@@ -2247,10 +2251,11 @@ int32_t cg_fixed_base_mul(const cg_fixed_base* t, const void* h_k, void* h_out_j
 }
 int32_t cg_fixed_base_destroy(cg_fixed_base* t) { if (t) { t->destroy(t->impl); delete t; } return 0; }
 int32_t cg_point_to_affine(int32_t curve, int32_t group, const void* h_a, void* h_out_affine) {
-    return with_group(curve, group, [&](auto ftag, auto) -> int {
+    if (!h_a || !h_out_affine) return fail(CG_ERR_ARG, "null argument");
+    return with_group64(curve, group, [&](auto ftag, auto) -> int {
         typedef decltype(ftag) F;
-        Jacobian<F> a; memcpy(&a, h_a, sizeof a);
-        Affine<F> r = xyzz_to_affine(jacobian_to_xyzz(a));
+        cg64::Jac<F> a; memcpy(&a, h_a, sizeof a);
+        const cg64::Aff<F> r = cg64::to_affine(a);
         memcpy(h_out_affine, &r, sizeof r); return 0;
     });
 }
@@ -2271,6 +2276,42 @@ template <class P> bool limbs_below_modulus(const cg::Fp<P>& a) {
     return false;
 }
 template <class B> bool limbs_below_modulus(const cg::Fp2<B>& a) { return limbs_below_modulus(a.c0) && limbs_below_modulus(a.c1); }
+// the 64-bit-limb twin of a coordinate field, and a value carried over (both are little-endian Montgomery forms with the same R: the same bytes)
+template <class F32> struct Host64;
+template <> struct Host64<Bn254Fq> { typedef H64BnFq type; };
+template <> struct Host64<cg::Fp2<Bn254Fq>> { typedef cg64::Fp2<H64BnFq> type; };
+#if CG_WITH_BLS
+template <> struct Host64<Bls381Fq> { typedef H64BlsFq type; };
+template <> struct Host64<cg::Fp2<Bls381Fq>> { typedef cg64::Fp2<H64BlsFq> type; };
+#endif
+template <class F32> typename Host64<F32>::type as64(const F32& v) { typename Host64<F32>::type r; static_assert(sizeof r == sizeof v, "limb forms differ in size"); memcpy(&r, &v, sizeof r); return r; }
+template <class B64> cg64::Jac<cg64::Fp2<B64>> psi64(const cg64::Jac<cg64::Fp2<B64>>& p, const cg64::Fp2<B64>& gx, const cg64::Fp2<B64>& gy) {
+    if (p.is_inf()) return p;
+    return {p.x.conj() * gx, p.y.conj() * gy, p.z.conj()};                             // (conj(X) gx, conj(Y) gy, conj(Z)): the affine map on x = X / Z^2, y = Y / Z^3
+}
+// the endomorphism tests of subgroup.hpp (FastSubgroup<F>::contains) with the same constants, on 64-bit limbs
+bool subgroup64(const FastSubgroup<cg::Fp2<Bn254Fq>>& t, const cg64::Aff<cg64::Fp2<H64BnFq>>& p) {
+    const auto gx = as64(t.psi.gx), gy = as64(t.psi.gy);
+    auto e = cg64::mul_u64(p, FastSubgroup<cg::Fp2<Bn254Fq>>::X);                       // [x]P
+    auto lhs = cg64::madd(e, p);                                                       // [x + 1]P
+    e = psi64(e, gx, gy); lhs = cg64::add(lhs, e);
+    e = psi64(e, gx, gy); lhs = cg64::add(lhs, e);
+    e = psi64(e, gx, gy);
+    return cg64::same_point(lhs, cg64::dbl(e));
+}
+#if CG_WITH_BLS
+bool subgroup64(const FastSubgroup<cg::Fp2<Bls381Fq>>& t, const cg64::Aff<cg64::Fp2<H64BlsFq>>& p) {
+    typedef cg64::Fp2<H64BlsFq> F;
+    const cg64::Jac<F> q = cg64::mul_u64(p, FastSubgroup<cg::Fp2<Bls381Fq>>::X_ABS);
+    return cg64::same_point(psi64(cg64::Jac<F>{p.x, p.y, F::one()}, as64(t.psi.gx), as64(t.psi.gy)), cg64::neg(q));
+}
+bool subgroup64(const FastSubgroup<Bls381Fq>& t, const cg64::Aff<H64BlsFq>& p) {
+    typedef H64BlsFq F;
+    const cg64::Jac<F> q = cg64::mul_u64(cg64::mul_u64(p, FastSubgroup<Bls381Fq>::X_ABS), FastSubgroup<Bls381Fq>::X_ABS);   // [x^2]P
+    return cg64::same_point(cg64::Jac<F>{p.x * as64(t.beta), p.y, F::one()}, cg64::neg(q));
+}
+#endif
+template <class F32, class A64> bool subgroup64(const FastSubgroup<F32>&, const A64&) { return true; }   // (groups without a fast test never get here)
 }
 }  // extern "C++"
 int32_t cg_point_validate(int32_t curve, int32_t group, const void* h_affine, int32_t* ok) {
@@ -2281,8 +2322,10 @@ int32_t cg_point_validate(int32_t curve, int32_t group, const void* h_affine, in
         *ok = 0;
         if (!limbs_below_modulus(a.x) || !limbs_below_modulus(a.y)) return 0;
         if (a.is_inf()) { *ok = 1; return 0; }
-        if (a.y.sqr() != a.x.sqr() * a.x + CurveB<F>::get()) return 0;
-        if (const FastSubgroup<F>* fast = fast_subgroup<F>()) { *ok = fast->contains(a) ? 1 : 0; return 0; }
+        typedef typename Host64<F>::type F64;
+        const cg64::Aff<F64> a64{as64(a.x), as64(a.y)};
+        if (!(a64.y.sqr() == a64.x.sqr() * a64.x + as64(CurveB<F>::get()))) return 0;
+        if (const FastSubgroup<F>* fast = fast_subgroup<F>()) { *ok = subgroup64(*fast, a64) ? 1 : 0; return 0; }
         if (!(curve == CG_BN254 && group == CG_G1)) {                                    // cofactor 1 there
             XYZZ<F> r = XYZZ<F>::infinity();
             for (int b = Fr::Params::BITS - 1; b >= 0; b--) {

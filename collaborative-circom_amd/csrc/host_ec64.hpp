@@ -90,6 +90,7 @@ struct Fp2 {
     Fp2 operator+(const Fp2& b) const { return {c0 + b.c0, c1 + b.c1}; }
     Fp2 operator-(const Fp2& b) const { return {c0 - b.c0, c1 - b.c1}; }
     Fp2 neg() const { return {c0.neg(), c1.neg()}; }
+    Fp2 conj() const { return {c0, c1.neg()}; }
     Fp2 dbl() const { return {c0.dbl(), c1.dbl()}; }
     Fp2 operator*(const Fp2& b) const { const B t0 = c0 * b.c0, t1 = c1 * b.c1; return {t0 - t1, (c0 + c1) * (b.c0 + b.c1) - t0 - t1}; }
     Fp2 sqr() const { return {(c0 + c1) * (c0 - c1), (c0 * c1).dbl()}; }
@@ -135,6 +136,22 @@ Jac<F> madd(const Jac<F>& p, const Aff<F>& q) {                           // mad
     const F Y3 = rr * (V - X3) - (p.y * J).dbl();
     return {X3, Y3, (p.z + H).sqr() - Z1Z1 - HH};
 }
+// affine (x, y) = (X / Z^2, Y / Z^3), the point at infinity as (0, 0): what crosses the wire and what a proof holds
+template <class F>
+Aff<F> to_affine(const Jac<F>& p) { if (p.is_inf()) return {F::zero(), F::zero()}; const F iz = p.z.inverse(), iz2 = iz.sqr(); return {p.x * iz2, p.y * iz2 * iz}; }
+template <class F>
+Jac<F> neg(const Jac<F>& p) { return {p.x, p.y.neg(), p.z}; }
+template <class F>
+bool same_point(const Jac<F>& a, const Jac<F>& b) {
+    if (a.is_inf() || b.is_inf()) return a.is_inf() && b.is_inf();
+    const F za = a.z.sqr(), zb = b.z.sqr();
+    return a.x * zb == b.x * za && a.y * zb * b.z == b.y * za * a.z;
+}
+// k * p for a 64-bit k, double-and-add from the top bit (the subgroup tests: k = the curve parameter)
+template <class F>
+Jac<F> mul_u64(const Aff<F>& p, uint64_t k) { Jac<F> r = Jac<F>::inf(); for (int i = 63; i >= 0; i--) { r = dbl(r); if ((k >> i) & 1) r = madd(r, p); } return r; }
+template <class F>
+Jac<F> mul_u64(const Jac<F>& p, uint64_t k) { Jac<F> r = Jac<F>::inf(); for (int i = 63; i >= 0; i--) { r = dbl(r); if ((k >> i) & 1) r = add(r, p); } return r; }
 // XYZZ coordinates (x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2; all-zero ZZ = infinity): what the reduction kernels hand the host, folded here
 // (msm_end_impl: ~100 additions per MSM result) on the same 64-bit limbs
 template <class F> struct Xyzz { F x, y, zz, zzz; bool is_inf() const { return zz.is_zero(); } static Xyzz inf() { return {F::zero(), F::zero(), F::zero(), F::zero()}; } };

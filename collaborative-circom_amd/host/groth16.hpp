@@ -185,10 +185,13 @@ public:
         const Point delta_g2 = pt_from_affine(c, CG_G2, z.delta_g2.data());
         FieldShare rs = driver.mul(r, s);                                                              // :258
         const SessionFixed* fx = dz.fixed;                                                             // a session's window tables (else variable-base products)
+        // (the G2 product costs as much as the three G1 products together: it runs on a helper thread beside them)
+        auto s_g2_pending = Helpers::get().run([&] { return driver.scalar_mul_public_point(delta_g2, s, fx ? fx->delta_g2.t : nullptr); });   // :297
+        struct Joined { std::future<PointShare>& f; ~Joined() { if (f.valid()) f.wait(); } } s_g2_joined{s_g2_pending};   // (the helper reads this frame: never left behind)
         PointShare r_s_delta_g1 = driver.scalar_mul_public_point(delta_g1, rs, fx ? fx->delta_g1.t : nullptr);   // :259
         PointShare r_g1 = driver.scalar_mul_public_point(delta_g1, r, fx ? fx->delta_g1.t : nullptr);  // :265
         PointShare s_g1 = driver.scalar_mul_public_point(delta_g1, s, fx ? fx->delta_g1.t : nullptr);  // :283
-        PointShare s_g2 = driver.scalar_mul_public_point(delta_g2, s, fx ? fx->delta_g2.t : nullptr);  // :297
+        PointShare s_g2 = s_g2_pending.get();
         mk.mark("scalar steps under the msms");
         PointShare early[5]; bool have_early = false;
         if (add_h) {                                                                                   // all five results, then the one re-sharing round

@@ -178,6 +178,8 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *                 CG_MSM_OFF_MAIN_LOG (19)   wide MSM calls (CG_OPT_MSM_WIDE_SMALL) of at most 2^this (point, window) entries accumulate their G2 sets on the
  *                                            context's aux stream and their G1 sets on its sort stream instead of the main stream, which stays free for
  *                                            the caller's next kernels (0 = never); seeds new contexts
+ *                 CG_MSM_STAGED_OUT          the sums of a bucket reduction are written to device scratch and copied to the ticket's page-locked buffer
+ *                                            (one copy per bucket set) instead of being written there by the reduction's last kernel (A/B knob)
  *   DEBUG         CG_DEBUG_NO_REDUCE = 1 | 2 skips the merges + bucket reductions | the reductions only: RESULTS ARE WRONG (what they cost a step)
  *                 CG_DEBUG_ALLOC             cg_dev_cache_trim prints how the device block cache fared since the last trim (read per call)
  *                 CG_DEBUG_STREAMS           one stderr line per stream handed out: priority class, hardware-queue slot, streams checked out per slot (read per call) */

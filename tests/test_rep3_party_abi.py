@@ -588,8 +588,9 @@ def test_a_corrupted_point_from_a_peer_is_invalid_data():
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunked", [False, True])
 def test_a_non_canonical_element_in_a_mul_vec_message_is_invalid_data(chunked, tmp_path, monkeypatch):
-    """the m-element messages of mul_vec are range-checked too — on the host when they travel as one message, on the device (behind the
-    upload, read at the end of the prove) when they travel in chunks: an element whose limbs are not below the modulus = InvalidData"""
+    """the m-element messages of mul_vec are range-checked too — on the host when they are short single messages, on the device (behind the
+    upload, read at the end of the prove) from 2^12 elements on and when they travel in chunks: an element whose limbs are not below the
+    modulus = InvalidData"""
     ensure_built()
     if chunked: monkeypatch.setenv("CGH_XCHG_ASYNC_MIN", "4096")
     curve, log_m = BN254, 14
