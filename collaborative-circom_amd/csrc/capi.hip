@@ -2223,7 +2223,12 @@ int32_t cg_point_scalar_mul(int32_t curve, int32_t group, const void* h_a, const
         typedef decltype(ftag) F; typedef decltype(frtag) Fr;
         cg64::Jac<F> a; static_assert(sizeof a == 3 * sizeof(F), ""); memcpy(&a, h_a, sizeof a);
         Fr k; memcpy(k.v, h_k, sizeof k.v); k = k.from_mont();
-        const cg64::Jac<F> r = cg64::scalar_mul(a, k.v, Fr::N);
+        // a scalar just below the group order is a small negative number (the Lagrange coefficients of Shamir's openings: -1, -2, -3): multiply
+        // by its negation — a handful of window steps instead of 64 — and negate the point
+        const Fr kn = k.neg();                                                         // (limbs are canonical either way: from_mont reduces)
+        bool small_neg = !kn.is_zero(); for (int i = 1; i < Fr::N; i++) small_neg = small_neg && kn.v[i] == 0;
+        cg64::Jac<F> r = cg64::scalar_mul(a, small_neg ? kn.v : k.v, Fr::N);
+        if (small_neg) r = cg64::neg(r);
         memcpy(h_out, &r, sizeof r); return 0;
     });
 }

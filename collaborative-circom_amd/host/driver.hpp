@@ -987,7 +987,26 @@ public:
     }
     std::pair<Point, Point> open_two_points(const PointShare& a, const PointShare& b) {   // rep3.rs:865-877
         if (mode == Mode::Plain) return {a.c[0], b.c[0]};
-        if (mode == Mode::Shamir) { Point p1 = shamir_open_point(a.c[0]); return {p1, shamir_open_point(b.c[0])}; }   // shamir.rs:808-824 (one message per point here)
+        if (mode == Mode::Shamir) {   // shamir.rs:808-824 (one message per point here)
+            // both points are sent first, the G2 point's own term (a 254-bit product, as long as the whole G1 opening) runs on a helper under the G1
+            // opening; the messages keep their order on every channel (G1 then G2)
+            const int np = snet->num_parties(), me = snet->id();
+            const Bytes m1 = pt_to_affine(curve, a.c[0]), m2 = pt_to_affine(curve, b.c[0]);
+            for (int sft = 1; sft <= sh_t; sft++) { snet->send((me + sft) % np, m1.data(), m1.size()); snet->send((me + sft) % np, m2.data(), m2.size()); }
+            auto own2 = Helpers::get().run([&] { return pt_mul(curve, b.c[0], open_lagrange_t[0]); });
+            struct Joined { std::future<Point>& f; ~Joined() { if (f.valid()) f.wait(); } } joined{own2};     // (the helper reads this frame)
+            Point r1 = pt_mul(curve, a.c[0], open_lagrange_t[0]);
+            std::vector<Point> theirs2;
+            for (int r = 1; r <= sh_t; r++) {
+                Bytes b1(m1.size()), b2(m2.size());
+                snet->recv((me + np - r) % np, b1.data(), b1.size()); snet->recv((me + np - r) % np, b2.data(), b2.size());
+                theirs2.push_back(received_point(CG_G2, b2.data()));
+                r1 = pt_add(curve, r1, pt_mul(curve, received_point(CG_G1, b1.data()), open_lagrange_t[r]));
+            }
+            Point r2 = own2.get();
+            for (int r = 1; r <= sh_t; r++) r2 = pt_add(curve, r2, pt_mul(curve, theirs2[(size_t)r - 1], open_lagrange_t[r]));
+            return {r1, r2};
+        }
         Bytes m1 = pt_to_affine(curve, a.c[1]), m2 = pt_to_affine(curve, b.c[1]);
         Bytes msg(m1); msg.insert(msg.end(), m2.begin(), m2.end());
         net->send_next(msg.data(), msg.size());

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0); torch.cuda.set_device(0); ctx = cg.Context(0)
 fx = os.path.join(ROOT, "tests", "golden", "groth16", "bn254", "poseidon")
 curve = cg.BLS12_381 if os.environ.get("CURVE", "").startswith("bls") else cg.BN254             # CURVE=bls12_381: the second curve
 if fixture and curve == cg.BLS12_381: fx = fx.replace("bn254", "bls12_381")
-out = bench.entry_leg(ctx, log_m, dev, proofs, 1, curve=curve, extras=not os.environ.get("NO_EXTRAS") and not fixture,
+out = bench.entry_leg(ctx, log_m, dev, proofs, 1, curve=curve, extras=bool(os.environ.get("EXTRAS")) or (not os.environ.get("NO_EXTRAS") and not fixture),
                       files=(os.path.join(fx, "circuit.zkey"), os.path.join(fx, "witness.wtns")) if fixture else None)
 res = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in out.items() if k.endswith("_ms") or k.startswith("ms_per_proof")}
 sh = out.get("shamir_party") or {}

@@ -121,11 +121,12 @@ def test_host_point_helpers_match_oracle(curve, group):
 def test_host_scalar_mul_and_fixed_base_tables(curve, group):
     """the 64-bit-limb host arithmetic of proof assembly (csrc/host_ec64.hpp): windowed variable-base products and the 8-bit window tables
     of a session's fixed bases (cg_fixed_base_*: delta_1, delta_2, generators, public-input records) against the oracle's scalar
-    multiplication, with the scalars 0, 1, r - 1 and the point at infinity"""
+    multiplication, with the scalars 0, 1, r - 1, r - 3, r - 2^64 and the point at infinity"""
     ensure_built()
     rng = np.random.default_rng(71 + curve * 2 + group)
     ks = orc.random_field(curve, FR, 8, rng)
     ks[5] = 0; ks[6] = orc.from_dec(curve, FR, 1); ks[7] = orc.from_dec(curve, FR, orc.MODULI[(curve, FR)] - 1)
+    ks[3] = orc.from_dec(curve, FR, orc.MODULI[(curve, FR)] - 3); ks[4] = orc.from_dec(curve, FR, orc.MODULI[(curve, FR)] - (1 << 64))   # small negative (negated product) / just not small
     P = orc.generator_mul(curve, group, ks[0])
     jp = jac_of(curve, group, P)
     want = [orc.points_mul(curve, group, P[None, :], k[None, :])[0] for k in ks]

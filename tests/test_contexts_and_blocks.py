@@ -208,6 +208,38 @@ def test_msm_next_to_a_chain_equals_the_default(built, group):
     np.testing.assert_array_equal(outs[0], orc.generator_mul(BN254, group, acc[0]))
 
 
+@pytest.mark.parametrize("log_n,window", [(10, 8), (14, 0), (17, 0)])
+def test_transforms_run_beside_the_reductions_of_an_msm_in_flight(built, log_n, window):
+    """one context: an MSM is begun (schedule, accumulation and reductions enqueued on the side streams), transforms of the same length follow
+    at once on the main stream, then the MSM is collected.  The transforms' scratch is a block of its own — they no longer wait for the bucket
+    reductions that read the MSM arena — so both must still be exact: the transform against the oracle, the MSM against its closed form.
+    Sizes on both sides of the off-main-stream accumulation bound; twice, so that the second MSM finds the first one's scratch slots busy."""
+    n = 1 << log_n
+    rng = np.random.default_rng(1234 + log_n)
+    _, roots, _ = orc.roots_of_unity(BN254)
+    c = cg.Context(0)
+    base_scalars, sc = orc.random_field(BN254, FR, n, rng), orc.random_field(BN254, FR, n, rng)
+    d_base, d_sc = c.to_device(base_scalars), c.to_device(sc)
+    tables = []
+    for group in (G1, G2):
+        bases = c.bases_from_scalars(BN254, group, d_base, n)
+        c.precompute_bases(bases, window)
+        tables.append(bases)
+    x = orc.random_field(BN254, FR, n, rng)
+    want_x = orc.ntt(BN254, x, roots[log_n])
+    for _ in range(2):
+        dx = c.to_device(x)
+        tickets = c.msm_dev_begin_multi(tables, [d_sc], n)
+        c.ntt_dev(BN254, [dx], n, roots[log_n])
+        np.testing.assert_array_equal(dx.download((n, 4)), want_x)
+        c.ntt_dev(BN254, [dx], n, roots[log_n], inverse=True)
+        for group, t in zip((G1, G2), tickets):
+            np.testing.assert_array_equal(cg.point_to_affine(BN254, group, c.msm_end(t)[0]), _closed_form(base_scalars, sc, group))
+        np.testing.assert_array_equal(dx.download((n, 4)), x)
+    for bases in tables: bases.release()
+    c.close()
+
+
 def _closed_form(base_scalars, sc, group):
     acc = orc.field_op(BN254, FR, "mul", base_scalars, sc)
     while acc.shape[0] > 1:
