@@ -96,11 +96,13 @@ static __global__ void __launch_bounds__(256) k_msm_scatter(const int32_t* __res
     }
 }
 
-// The whole schedule of a SMALL scalar vector in ONE launch of one workgroup (shared bucket set, <= 2^13 buckets, <= 2^18 entries): digits ->
+// The whole schedule of a SMALL scalar vector in ONE launch of one workgroup (shared bucket set, <= 2^13 buckets, <= 2^15 entries): digits ->
 // LDS histogram -> LDS scan -> scatter through LDS cursors.  The six launches above cost a few-hundred-constraint circuit 85 us per scalar
 // vector in launch gaps alone (four vectors per proof); here the digits are simply recomputed for the scatter.  The order of the entries
 // inside a bucket differs from run to run (atomics), as it does for k_msm_scatter: the bucket sums do not depend on it.
-constexpr uint32_t SORT_SMALL_MAX_BUCKETS = 1u << 13, SORT_SMALL_MAX_ENTRIES = 1u << 18;
+// (one REP3 party, round 5: 20 k entries 1.25 ms with this kernel, 1.39 with the general schedule | 41 k: 1.47 / 1.42 | 82 k: 1.72 / 1.59 | 164 k: 2.15 / 1.85 —
+// one workgroup pays for itself up to ~2^15 entries)
+constexpr uint32_t SORT_SMALL_MAX_BUCKETS = 1u << 13, SORT_SMALL_MAX_ENTRIES = 1u << 15;
 template <class Fr>
 __global__ void __launch_bounds__(1024) k_msm_sort_small(const Fr* __restrict__ scalars, uint32_t n, int c, int nwin,
                                                          uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {

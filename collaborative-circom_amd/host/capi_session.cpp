@@ -133,7 +133,9 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
         int window = precompute > 0 ? precompute : 0;
         if (precompute < 0) {
             const size_t nmax = std::max<size_t>(s->z.n_vars, s->z.domain_size) / (size_t)n_dev;
-            if (nmax <= ((size_t)1 << 10)) window = 8; else if (nmax <= ((size_t)1 << 13)) window = 13;
+            // (round 5, after the small-proof work, one REP3 party: 2^8 1.07 ms at c = 8 | 2^9 1.88 at 8, 1.17 at 10 | 2^10 2.55 at 8, 1.34 at 13 |
+            // 2^12 1.86 at 13, 1.99 at 15 | 2^14 2.23 at 15, 2.28 at 16 | c = 11 is always bad: its top window has one bit)
+            if (nmax <= ((size_t)1 << 8)) window = 8; else if (nmax <= ((size_t)1 << 9)) window = 10; else if (nmax <= ((size_t)1 << 13)) window = 13;
         }
         if (precompute) for (int d = 0; d < n_dev; d++) for (cg_bases* b : {s->dzs[d].a, s->dzs[d].b1, s->dzs[d].b2, s->dzs[d].l, s->dzs[d].h})
             if (cg_bases_len(b)) CG(cg_bases_precompute(s->ctx0[d], b, window));

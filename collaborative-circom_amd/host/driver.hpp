@@ -529,8 +529,9 @@ public:
     // asynchronous DMA): the product kernel then never waits for PCIe
     struct MaskSet { void* m1; void* m2; int32_t tk; size_t n, at; void* block = nullptr; bool owns = true; };   // block: m1 lies inside a block drawn for several calls; the LAST of them releases it
     // a randomness source that describes its ChaCha12 generators has its masks drawn by the backend (no host draws, no upload); short vectors
-    // are not worth three launches and a stream synchronisation
-    const size_t DEVICE_MASKS_MIN = getenv("CGH_DEVICE_MASKS_MIN") ? (size_t)atoll(getenv("CGH_DEVICE_MASKS_MIN")) : (size_t)1 << 14;   // (the override lets the small fixtures take the device path)
+    // are not worth three launches and a stream synchronisation — up to 2^10 elements: a host draw costs ~70 ns per element (two generators,
+    // rejection sampling), 0.6 ms per mul_vec at 2^13 (one REP3 party there: 2.75 ms with host draws, 2.14 with device draws; 2^11: 1.52 -> 1.40)
+    const size_t DEVICE_MASKS_MIN = getenv("CGH_DEVICE_MASKS_MIN") ? (size_t)atoll(getenv("CGH_DEVICE_MASKS_MIN")) : (size_t)1 << 11;   // (the override lets the small fixtures take the device path)
     bool masks_on_device(void* d_m, size_t n) {
         if (!rsrc || n < DEVICE_MASKS_MIN) return false;
         void* tmp = nullptr;

@@ -14,7 +14,7 @@
  *   CGH_TIMING                    wall-clock marks of the host-side protocol steps on stderr
  *   thresholds    CGH_SECOND_CONTEXT_MIN (15)   log2 of the variables from which a proof uses a chain + a bulk context
  *                 CGH_XCHG_ASYNC_MIN (2^17)     elements from which the mul_vec exchange streams in chunks over the copy streams
- *                 CGH_DEVICE_MASKS_MIN (2^14)   elements from which described ChaCha12 generators are drawn on the device
+ *                 CGH_DEVICE_MASKS_MIN (2^11)   elements from which described ChaCha12 generators are drawn on the device
  *   A/B           CGH_ONE_CONTEXT, CGH_NO_CHAIN_PRIORITY, CGH_CHAIN_FLAG (1), CGH_BULK_FLAG (2)   one context per proof; no priorities; cg_ctx_create_ex flags
  *                 CGH_BULK_CHUNK (64) / CGH_PLAIN_CHUNK (0)   CG_OPT_MSM_CHUNK of the bulk context beside a REP3 chain (>= 2^20 elements) / otherwise
  *                 CGH_G2_ORDER=first, CGH_G2_AFTER (2)        launch order of the aux MSMs' (table, component) pairs (HipDriver::begin_multi_ordered)
@@ -153,7 +153,7 @@ int32_t cgh_session_prove_rep3_party(void* session, const uint64_t* pub_in, cons
  * in parallel, accepted ones compacted in order) and never moves a mask over PCIe: get_state reports seed and word position of rng1 / rng2
  * (ChaCha12Rng::get_seed, get_word_pos) right before a vector of masks is due, set_word_pos (ChaCha12Rng::set_word_pos) puts both
  * generators behind the draws taken, so the caller's next draw — random_fes, masking_ec_element, the next proof — is the one the reference
- * would make.  The O(1) draws stay with cgh_rep3_rand.  Vectors shorter than 2^14 elements (CGH_DEVICE_MASKS_MIN overrides) still come
+ * would make.  The O(1) draws stay with cgh_rep3_rand.  Vectors shorter than 2^11 elements (CGH_DEVICE_MASKS_MIN overrides) still come
  * through masking_field_elements. */
 typedef struct cgh_rep3_chacha {
     void* user;
