@@ -301,3 +301,43 @@ print("child ok")
     env = dict(os.environ, CG_SORT_NO_STAGING="1", CG_DEV_CACHE_MB="0", CG_HOST_CACHE_MB="0")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("knobs", [{"CG_MSM_STAGED_OUT": "1"}, {"CG_MSM_OFF_MAIN_LOG": "0"}, {"CG_MSM_STAGED_OUT": "1", "CG_MSM_OFF_MAIN_LOG": "0", "CG_SORT_NO_SMALL": "1"}])
+def test_small_call_knobs_do_not_change_results_in_a_fresh_process(built, knobs):
+    """the round-5 defaults for small MSM calls — sums written straight into the ticket's page-locked buffer, accumulations off the main
+    stream, the one-workgroup schedule kernel — against their A/B knobs (read once per process / per new context): a child process runs G1 and G2
+    MSMs of 2^6 .. 2^13 points with a transform enqueued beside them and checks the closed forms"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+import oracle_lib as orc
+from oracle_lib import BN254, FR, G1, G2
+from product import cg, ensure_built
+ensure_built()
+rng = np.random.default_rng(5)
+_, roots, _ = orc.roots_of_unity(BN254)
+c = cg.Context(0)
+for log_n, window in ((6, 8), (9, 10), (11, 13), (13, 13)):
+    n = 1 << log_n
+    b, s = orc.random_field(BN254, FR, n, rng), orc.random_field(BN254, FR, n, rng)
+    acc = orc.field_op(BN254, FR, "mul", b, s)
+    while acc.shape[0] > 1: acc = orc.field_op(BN254, FR, "add", acc[: acc.shape[0] // 2], acc[acc.shape[0] // 2:])
+    db, ds = c.to_device(b), c.to_device(s)
+    tables = []
+    for group in (G1, G2):
+        bases = c.bases_from_scalars(BN254, group, db, n); c.precompute_bases(bases, window); tables.append(bases)
+    x = orc.random_field(BN254, FR, n, rng); dx = c.to_device(x)
+    tickets = c.msm_dev_begin_multi(tables, [ds], n)
+    c.ntt_dev(BN254, [dx], n, roots[log_n])
+    for group, t in zip((G1, G2), tickets):
+        assert (cg.point_to_affine(BN254, group, c.msm_end(t)[0]) == orc.generator_mul(BN254, group, acc[0])).all(), (log_n, group)
+    assert (dx.download((n, 4)) == orc.ntt(BN254, x, roots[log_n])).all(), log_n
+    for bases in tables: bases.release()
+c.close()
+print("child ok")
+'''
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **knobs), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
