@@ -11,7 +11,7 @@
  *
  * Environment variables (complete list for libcogroth16_host.so; PROCESS-WIDE, read once unless noted; none is needed, none changes a proof):
  *   CGH_SKIP_ZKEY_VALIDATION      sessions / one-shot proves skip the on-curve + subgroup validation of the zkey points (= cgh_set_zkey_validation(0))
- *   CGH_TIMING                    wall-clock marks of the host-side protocol steps on stderr
+ *   CGH_TIMING                    wall-clock marks of the host-side protocol steps on stderr (microseconds since the previous mark)
  *   thresholds    CGH_SECOND_CONTEXT_MIN (15)   log2 of the variables from which a proof uses a chain + a bulk context
  *                 CGH_XCHG_ASYNC_MIN (2^17)     elements from which the mul_vec exchange streams in chunks over the copy streams
  *                 CGH_DEVICE_MASKS_MIN (2^11)   elements from which described ChaCha12 generators are drawn on the device
