@@ -146,6 +146,7 @@ struct cg_ctx {
     hipEvent_t ev_peer = nullptr;                         // cg_dev_copy_peer: "source stream reached this point"
     Arena arena;
     Arena ntt_arena;                                      // limb-form scratch of the transforms: NOT the MSM arena (ensure_ntt_arena)
+    Arena solo_arena;                                     // scratch of tiny single-field MSM calls that run in stream order on the main stream (`solo` in msm_begin_multi_impl_)
     std::vector<void*> retired;                        // outgrown arena blocks that enqueued kernels may still use
     void* gather_buf = nullptr; size_t gather_cap = 0;   // scalars gathered for compacted tables (see cg_bases::compact)
     std::map<TwKey, void*> twiddles;
@@ -199,17 +200,18 @@ int ensure_arena(cg_ctx* ctx, size_t bytes) {
 // exchange — stood still until the witness-independent MSMs it had started first were completely done (Poseidon fixture: the first exchange's
 // download waited 0.2-0.46 ms of a 1.5 ms proof; with the reductions switched off it took 45 us).  Transforms run on the main stream only,
 // so successive users of this block are ordered by the stream itself.
-int ensure_ntt_arena(cg_ctx* ctx, size_t bytes) {
-    if (bytes <= ctx->ntt_arena.cap) return 0;
+int ensure_main_stream_block(cg_ctx* ctx, Arena& a, size_t bytes) {
+    if (bytes <= a.cap) return 0;
     const bool idle = hipStreamQuery(ctx->stream) == hipSuccess;
     (void)hipGetLastError();
-    if (ctx->ntt_arena.base) { if (idle) HIPCHK(hipFree(ctx->ntt_arena.base)); else ctx->retired.push_back(ctx->ntt_arena.base); }   // (enqueued kernels keep the old block: freed when the context is idle or goes away)
-    ctx->ntt_arena.base = nullptr; ctx->ntt_arena.cap = 0;
+    if (a.base) { if (idle) HIPCHK(hipFree(a.base)); else ctx->retired.push_back(a.base); }   // (enqueued kernels keep the old block: freed when the context is idle or goes away)
+    a.base = nullptr; a.cap = 0;
     const size_t want = align_up(bytes + bytes / 8, 1 << 20);
-    HIPCHK(hip_malloc_flush((void**)&ctx->ntt_arena.base, want));
-    ctx->ntt_arena.cap = want;
+    HIPCHK(hip_malloc_flush((void**)&a.base, want));
+    a.cap = want;
     return 0;
 }
+int ensure_ntt_arena(cg_ctx* ctx, size_t bytes) { return ensure_main_stream_block(ctx, ctx->ntt_arena, bytes); }
 
 // non-blocking timing: a pair of events per measured span, drained in cg_stats()
 hipEvent_t ev_new(cg_ctx* ctx) { hipEvent_t e = nullptr; hipEventCreate(&e); return e; }
@@ -468,25 +470,39 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // It takes the context's hardware-queue placement out of the picture — the same Poseidon-fixture party takes 1.9 to 3.7 ms from one
         // session of a process to the next with three streams, 2.5-2.8 ms with one — but the G2 reduction then no longer runs under the G1
         // accumulation, and the best placement is what the default keeps (profiles/r05_small_circuit_ab3.txt).
-        const bool one_stream = small_call && ctx->one_stream_log > 0 && (uint64_t)nwin * n <= ((uint64_t)1 << ctx->one_stream_log);
-        const hipStream_t sortst = one_stream ? ctx->stream : ctx->sortst, auxst = one_stream ? ctx->stream : ctx->aux;
+        // ... except for a tiny call whose tables all lie in ONE coordinate field (the quotient's MSM at the end of a small proof): nothing would run
+        // beside anything, and on the main stream — another priority class than the side streams, so never on their hardware queues — its
+        // schedule, accumulation and reduction do not queue behind the G2 reductions of the call before (the same Poseidon party waited 14 or
+        // 200 us for this result, depending on where the two side streams had landed)
+        bool single_field = true;
+        for (int b = 1; b < nb; b++) single_field = single_field && bases[b]->group == bases[0]->group;
         const int acc_slots = red_batch || small_call ? std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(acc_slots_min, red_batch >= 2 || small_call ? nb * k : nb + 1)) : acc_slots_min;
-        { int rc = ensure_arena(ctx, nsched * sort_bytes + (size_t)acc_slots * acc_slot); if (rc) return rc; }
-        char* acc_scratch = ctx->arena.base + nsched * sort_bytes;
+        const bool wide = k <= 2 && nb * k <= std::min(acc_slots, (int)ACC_MAX_SETS) && (uint64_t)nwin * n <= wide_max;      // see the WIDE mode below
+        // `solo`: such a call is a closed sequence on ONE stream — it takes its scratch from a block of its own (ordered by that stream alone) and
+        // leaves the context's cross-stream bookkeeping (slot / schedule events of the shared arena) untouched: it neither waits for the
+        // reductions of the call before, which still read the shared arena, nor hides them from the call after
+        const bool solo = wide && small_call && single_field && ctx->off_main_log > 0 && (uint64_t)nwin * n <= ((uint64_t)1 << ctx->off_main_log);
+        const bool one_stream = solo || (small_call && ctx->one_stream_log > 0 && (uint64_t)nwin * n <= ((uint64_t)1 << ctx->one_stream_log));
+        const hipStream_t sortst = one_stream ? ctx->stream : ctx->sortst, auxst = one_stream ? ctx->stream : ctx->aux;
+        { int rc = solo ? ensure_main_stream_block(ctx, ctx->solo_arena, nsched * sort_bytes + (size_t)acc_slots * acc_slot) : ensure_arena(ctx, nsched * sort_bytes + (size_t)acc_slots * acc_slot); if (rc) return rc; }
+        char* const arena_base = solo ? ctx->solo_arena.base : ctx->arena.base;
+        char* acc_scratch = arena_base + nsched * sort_bytes;
+        if (!solo) {
         HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));   // scalars (and the arena) are ready once the main stream gets here
         HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_in, 0));
         for (int rs = 0; rs < 2; rs++) for (int i = 0; i < 2; i++) if (ctx->merged_pending[rs][i]) { HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_merged[rs][i], 0)); ctx->merged_pending[rs][i] = false; }   // ... and the previous call's merges have read the old schedules
+        }
         std::vector<MsmSortPtrs> sps(k);
         auto launch_sort = [&](int j) -> int {             // scalar side: once per scalar vector, on the sort stream
             const int ss_ = j % nsched;
             if (j < 4 && ctx->comp_after[j]) HIPCHK(hipStreamWaitEvent(sortst, ctx->comp_after[j], 0));   // this component's scalars are still on their way up
-            if (j >= nsched) {                                   // accumulates and merges of component j-2 have consumed the slot
+            if (j >= nsched && !solo) {                          // accumulates and merges of component j-2 have consumed the slot
                 HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_sched_free[ss_], 0));
                 for (int rs = 0; rs < 2; rs++) if (ctx->merged_pending[rs][ss_]) HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_merged[rs][ss_], 0));
             }
             hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
             if (ctx->stats_on) { const int i0 = ev_open(ctx, TAG_SORT); evs[0] = ctx->ev_live[i0].a; evs[1] = ctx->ev_live[i0].b; pev = evs; }
-            char* sort_scratch = ctx->arena.base + (size_t)ss_ * sort_bytes;
+            char* sort_scratch = arena_base + (size_t)ss_ * sort_bytes;
             int rc = with_fr(curve, [&](auto tag) -> int {
                 typedef decltype(tag) Fr;
                 return cap ? msm_sort_direct_launch<Fr>(sortst, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, cap, sort_scratch, &sps[j], pev)
@@ -494,7 +510,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
             });
             if (rc) return rc;
             if (cap) for (int b = 0; b < nb; b++) HIPCHK(hipMemcpyAsync(ctx->tickets[slots[b]].h_flags + j, sps[j].overflow, 4, hipMemcpyDeviceToHost, sortst));
-            HIPCHK(hipEventRecord(ctx->ev_sorted[ss_], sortst));
+            if (!solo) HIPCHK(hipEventRecord(ctx->ev_sorted[ss_], sortst));
             return 0;
         };
         int iter = 0;
@@ -514,21 +530,23 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
             hipStream_t rst = red_stream[gi];
             // every accumulation of the batch sits on the main stream in front of this point: the reduction stream waits for the last one
             hipEvent_t ea = ctx->ev_acc[pd.back().slot];
-            HIPCHK(hipEventRecord(ea, acc_stream[gi]));
-            if (rst != acc_stream[gi]) HIPCHK(hipStreamWaitEvent(rst, ea, 0));
-            last_acc[gi] = ea;
+            if (!solo) {
+                HIPCHK(hipEventRecord(ea, acc_stream[gi]));
+                if (rst != acc_stream[gi]) HIPCHK(hipStreamWaitEvent(rst, ea, 0));
+                last_acc[gi] = ea;
+            }
             hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
             if (ctx->stats_on) { const int i2 = ev_open(ctx, TAG_REDUCE); evs[0] = ctx->ev_live[i2].a; evs[1] = ctx->ev_live[i2].b; pev = evs; }
             hipEvent_t evm[2]; int nm = 0; bool seen[2] = {false, false};
             std::vector<MsmRedSet> sets;
             const int rs = rst == sortst ? 1 : 0;
-            for (const PendSet& ps : pd) { sets.push_back(ps.set); if (!seen[ps.sched]) { seen[ps.sched] = true; evm[nm++] = ctx->ev_merged[rs][ps.sched]; } }
+            for (const PendSet& ps : pd) { sets.push_back(ps.set); if (!solo && !seen[ps.sched]) { seen[ps.sched] = true; evm[nm++] = ctx->ev_merged[rs][ps.sched]; } }
             int rc = with_coord_field(curve, gi == 0 ? CG_G1 : CG_G2, [&](auto ftag) -> int {
                 typedef decltype(ftag) F;
                 return msm_reduce_batch<F>(rst, sets.data(), (int)sets.size(), n, c, nwin, shared, sps[pd[0].comp].cap, evm, nm, pev, chunk_request);
             });
             if (rc) return rc;
-            for (const PendSet& ps : pd) {
+            if (!solo) for (const PendSet& ps : pd) {
                 HIPCHK(hipEventRecord(ctx->ev_red[ps.slot], rst));
                 ctx->slot_busy[ps.slot] = true; ctx->aux_pending = true; ctx->last_slot = ps.slot; ctx->merged_pending[rs][ps.sched] = true;
             }
@@ -551,7 +569,6 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // reduction goes to the then idle sort stream.  A 2^16-point launch is 256 workgroups and lasts as long as one lane's chain of
         // additions; eight in a row cost eight chains (2^16 step: 3.2 ms), side by side one.
         // (measured, round 4: 2^14 step 2.63 -> 2.14 ms, 2^16 3.30 -> 3.09 ms and one REP3 party 5.85 -> 5.54 ms; from 2^17 points on — 2^21 entries — no gain)
-        const bool wide = k <= 2 && nb * k <= std::min(acc_slots, (int)ACC_MAX_SETS) && (uint64_t)nwin * n <= wide_max;
         // TINY wide calls (CG_OPT_MSM_OFF_MAIN_LOG, default 2^19 entries) keep the main stream free: the G2 sets are accumulated on the aux stream
         // and the G1 sets on the sort stream, each in front of its own reduction, and the main stream only marks where the scalars are
         // ready.  Such a call fills a fraction of the chip, so nothing is gained by queueing the caller's next kernels behind its accumulations
@@ -561,14 +578,14 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         if (wide) {
             if (k == 2) { int rc = launch_sort(1); if (rc) return rc; }
             if (off_main) { acc_stream[0] = sortst; acc_stream[1] = auxst; }
-            for (int j = 0; j < k; j++) HIPCHK(hipStreamWaitEvent(acc_stream[1], ctx->ev_sorted[j], 0));      // (main stream, or aux; the sort stream is behind its own sorts anyway)
+            if (!solo) for (int j = 0; j < k; j++) HIPCHK(hipStreamWaitEvent(acc_stream[1], ctx->ev_sorted[j], 0));      // (main stream, or aux; the sort stream is behind its own sorts anyway)
             red_stream[0] = sortst;
             for (int gi : {1, 0}) {
                 std::vector<MsmAccSet> sets;
                 for (int j = 0; j < k; j++) for (int b = 0; b < nb; b++) {
                     if ((bases[b]->group == CG_G1 ? 0 : 1) != gi) continue;
                     const int slot = iter++ % acc_slots;
-                    if (ctx->slot_busy[slot]) HIPCHK(hipStreamWaitEvent(acc_stream[gi], ctx->ev_red[slot], 0));
+                    if (!solo && ctx->slot_busy[slot]) HIPCHK(hipStreamWaitEvent(acc_stream[gi], ctx->ev_red[slot], 0));
                     char* scratch = acc_scratch + (size_t)slot * acc_slot;
                     sets.push_back(acc_set(b, j, scratch));
                     pend[gi].push_back(PendSet{red_set(b, j, scratch), slot, j, b, j});
@@ -581,13 +598,13 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
                     return msm_accumulate_batch<F>(acc_stream[gi], sets.data(), (int)sets.size(), n, c, nwin, shared, sps[0].cap, pev, chunk_request, false);
                 });
                 if (rc) return rc;
-                if (gi == 0) HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_sorted[k - 1], 0));     // (the sort stream has nothing else left in this call)
+                if (gi == 0 && !solo) HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_sorted[k - 1], 0));     // (the sort stream has nothing else left in this call)
                 { int rc2 = flush(gi); if (rc2) return rc2; }
             }
             // the schedules are free once every accumulation has read them: behind them all on the main stream, or (off the main stream) on the
             // sort stream, which holds the G1 accumulations itself and waits here for the G2 ones
             if (off_main && last_acc[1]) HIPCHK(hipStreamWaitEvent(sortst, last_acc[1], 0));
-            for (int j = 0; j < k; j++) HIPCHK(hipEventRecord(ctx->ev_sched_free[j], off_main ? sortst : ctx->stream));
+            if (!solo) for (int j = 0; j < k; j++) HIPCHK(hipEventRecord(ctx->ev_sched_free[j], off_main ? sortst : ctx->stream));
         }
         // one accumulation: table b, share component j, into the next rotating scratch slot; its bucket set joins the batch of its field
         auto do_acc = [&](int b, int j) -> int {
@@ -1255,6 +1272,10 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     // Inside a stream group (one party's chain + bulk contexts) the streams of the contexts made before count as well: a class has four
     // hardware queues, a pair of contexts puts at most four streams into one class.
     {
+        // one context at a time: three parties of one process make their contexts at the same moment, and two threads' spin kernels on one
+        // queue read as "shared" (or as "busy") for both
+        static std::mutex probe_mu;
+        std::lock_guard<std::mutex> probing(probe_mu);
         const bool grp = g_group_depth > 0;
         auto others = [&](int cls, std::initializer_list<hipStream_t> own) {
             std::vector<hipStream_t> v;
@@ -1314,6 +1335,7 @@ int32_t cg_ctx_destroy(cg_ctx* ctx) {
     for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.h_flags) hipHostFree(t.h_flags); if (t.done) hipEventDestroy(t.done); }
     if (ctx->arena.base) hipFree(ctx->arena.base);
     if (ctx->ntt_arena.base) hipFree(ctx->ntt_arena.base);
+    if (ctx->solo_arena.base) hipFree(ctx->solo_arena.base);
     for (void* p : ctx->retired) hipFree(p);
     if (ctx->gather_buf) hipFree(ctx->gather_buf);
     for (auto& p : ctx->ev_live) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
