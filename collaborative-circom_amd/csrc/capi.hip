@@ -140,9 +140,9 @@ struct cg_ctx {
     // priority class of each stream: +1 high, 0 normal, -1 low (pooled_stream)
     int prio_main = 0, prio_side = 1, prio_copy = 0;
     uint32_t msm_chunk = 0;                               // cg_msm_set_chunk / CG_OPT_MSM_CHUNK
-    int off_main_log = 19;                                // CG_MSM_OFF_MAIN_LOG: wide calls of at most 2^this entries keep their accumulations OFF the main stream (0 = never), see msm_begin_multi_impl_
+    int off_main_log = 22;                                // CG_MSM_OFF_MAIN_LOG: wide calls of at most 2^this entries keep their accumulations OFF the main stream (0 = never), see msm_begin_multi_impl_
     int one_stream_log = 0;                               // CG_MSM_ONE_STREAM_LOG: calls of at most 2^this entries run on the main stream alone (0 = never, the default: measured slower)
-    int table_order = 0, g2_after = -1, g2_slices = 0, red_batch = 2, acc_slots = 4, wide_small = 1;   // CG_OPT_MSM_TABLE_ORDER / _G2_SLICES / _REDUCE_BATCH / _ACC_SLOTS (cg_ctx_set_option)
+    int table_order = 0, g2_after = -1, g2_slices = 0, red_batch = 2, acc_slots = 4, wide_small = 22;   // CG_OPT_MSM_TABLE_ORDER / _G2_SLICES / _REDUCE_BATCH / _ACC_SLOTS (cg_ctx_set_option)
     hipEvent_t ev_peer = nullptr;                         // cg_dev_copy_peer: "source stream reached this point"
     Arena arena;
     Arena ntt_arena;                                      // limb-form scratch of the transforms: NOT the MSM arena (ensure_ntt_arena)
@@ -569,11 +569,14 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // reduction goes to the then idle sort stream.  A 2^16-point launch is 256 workgroups and lasts as long as one lane's chain of
         // additions; eight in a row cost eight chains (2^16 step: 3.2 ms), side by side one.
         // (measured, round 4: 2^14 step 2.63 -> 2.14 ms, 2^16 3.30 -> 3.09 ms and one REP3 party 5.85 -> 5.54 ms; from 2^17 points on — 2^21 entries — no gain)
-        // TINY wide calls (CG_OPT_MSM_OFF_MAIN_LOG, default 2^19 entries) keep the main stream free: the G2 sets are accumulated on the aux stream
+        // Wide calls up to CG_MSM_OFF_MAIN_LOG entries (default 2^22: 2^18 points) keep the main stream free: the G2 sets are accumulated on the aux stream
         // and the G1 sets on the sort stream, each in front of its own reduction, and the main stream only marks where the scalars are
         // ready.  Such a call fills a fraction of the chip, so nothing is gained by queueing the caller's next kernels behind its accumulations
         // — a one-context party's witness map (a chain of short kernels and two host round trips) started 0.3 ms late behind the
-        // witness-independent MSMs, and later still whenever their streams had fallen onto a shared hardware queue.
+        // witness-independent MSMs, and later still whenever their streams had fallen onto a shared hardware queue.  Beside a chain context the
+        // gain is the two fields' accumulations running side by side instead of one after the other (one REP3 party, bounds 2^20 / 2^19 -> 2^22 / 2^22
+        // entries for wide / off-main: 2^16 3.23 -> 2.78 ms, 2^17 4.97 -> 4.50, 2^18 7.3 -> 6.9.  Not beyond: with 2^24 the 2^19 / 2^20 parties stand
+        // at 12.1 -> 12.0 / 21.8 -> 21.2 ms, but a party over four devices (2^20-point slices) goes from 23.0 to 24.5 ms, and 2^21 / 2^22 lose 0.3 / 1.8 ms).
         const bool off_main = wide && !one_stream && ctx->off_main_log > 0 && (uint64_t)nwin * n <= ((uint64_t)1 << ctx->off_main_log);
         if (wide) {
             if (k == 2) { int rc = launch_sort(1); if (rc) return rc; }

@@ -175,7 +175,7 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *                 CG_MSM_TABLE_ORDER, CG_MSM_G2_AFTER, CG_MSM_G2_SLICES, CG_MSM_REDUCE_BATCH, CG_MSM_ACC_SLOTS, CG_MSM_WIDE_SMALL   seed the option table of NEW contexts
  *                 CG_MSM_ONE_STREAM_LOG (0)  MSM calls of at most 2^this (point, window) entries run schedule, accumulation and reduction in stream order on the
  *                                            context's main stream (0 = never: measured slower than three streams); seeds new contexts
- *                 CG_MSM_OFF_MAIN_LOG (19)   wide MSM calls (CG_OPT_MSM_WIDE_SMALL) of at most 2^this (point, window) entries accumulate their G2 sets on the
+ *                 CG_MSM_OFF_MAIN_LOG (22)   wide MSM calls (CG_OPT_MSM_WIDE_SMALL) of at most 2^this (point, window) entries accumulate their G2 sets on the
  *                                            context's aux stream and their G1 sets on its sort stream instead of the main stream, which stays free for
  *                                            the caller's next kernels (0 = never); seeds new contexts
  *                 CG_MSM_STAGED_OUT          the sums of a bucket reduction are written to device scratch and copied to the ticket's page-locked buffer
@@ -206,9 +206,9 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *   CG_OPT_MSM_REDUCE_BATCH        bucket sets merged and reduced together: 2 = per call and coordinate field, 1 = per share        2
  *                                  component and field, 0 = each on its own right behind its accumulation
  *   CG_OPT_MSM_ACC_SLOTS           rotating scratch slots of the accumulate / reduce pipeline (2 .. 8; batches take one per set)    4
- *   CG_OPT_MSM_WIDE_SMALL          1 = calls of at most 2^20 (point, window) entries and two share components launch all accumulations    1
- *                                  of a coordinate field side by side (one launch, one reduction batch per field); 10 .. 30 = the same
- *                                  with 2^value entries as the bound (table slices of a multi-GPU plan: 2^19 points x 15 windows); 0 = off
+ *   CG_OPT_MSM_WIDE_SMALL          10 .. 30 = calls of at most 2^value (point, window) entries and two share components launch all          22
+ *                                  accumulations of a coordinate field side by side (one launch, one reduction batch per field; the two
+ *                                  fields on two streams up to CG_MSM_OFF_MAIN_LOG entries); 1 = 2^20 entries (the bound of round 4); 0 = off
  * Environment variables of the same names (CG_OPT_... without the prefix: CG_MSM_CHUNK, ...) seed the defaults of NEW contexts for A/B runs. */
 enum { CG_OPT_MSM_CHUNK = 1, CG_OPT_MSM_WINDOW = 2, CG_OPT_MSM_SCATTER_CAP = 3, CG_OPT_MSM_TABLE_ORDER = 4, CG_OPT_MSM_G2_SLICES = 5,
        CG_OPT_MSM_REDUCE_BATCH = 6, CG_OPT_MSM_ACC_SLOTS = 7, CG_OPT_MSM_G2_AFTER = 8, CG_OPT_MSM_WIDE_SMALL = 9, CG_OPT_COUNT_ };

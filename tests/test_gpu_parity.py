@@ -424,6 +424,10 @@ def test_msm_launch_orders_and_reduction_batches(order, g2_after, batch):
     try:
         c2.set_option(cg.OPT_MSM_TABLE_ORDER, order); c2.set_option(cg.OPT_MSM_G2_AFTER, g2_after); c2.set_option(cg.OPT_MSM_REDUCE_BATCH, batch)
         assert (c2.get_option(cg.OPT_MSM_TABLE_ORDER), c2.get_option(cg.OPT_MSM_G2_AFTER), c2.get_option(cg.OPT_MSM_REDUCE_BATCH)) == (order, g2_after, batch)
+        if batch in (1, 3):                       # two-component calls of this size take the wide path (all sets of a field in one launch) by default: off here, so that the orders above run
+            c2.set_option(cg.OPT_MSM_WIDE_SMALL, 0); assert c2.get_option(cg.OPT_MSM_WIDE_SMALL) == 0
+        else:
+            assert c2.get_option(cg.OPT_MSM_WIDE_SMALL) == 22
         tabs = [(G1, make_points(curve, G1, n, rng)), (G1, make_points(curve, G1, n + 2, rng)), (G2, make_points(curve, G2, n, rng)), (G1, make_points(curve, G1, n, rng))]
         offs = [0, 2, 0, 0]
         sc = [orc.random_field(curve, FR, n, rng) for _ in range(3)]
