@@ -583,7 +583,13 @@ public:
         }
     }
     struct Down { uint8_t* slot; int32_t tk; };
-    struct PendingMul { ShareVec out; bool exchange = false; std::deque<Down> down; size_t issued = 0; int32_t mark = -1; };   // mark: where the stream produced `out` (cg_stream_mark)
+    struct PendingMul { ShareVec out; bool exchange = false; std::deque<Down> down; size_t issued = 0; int32_t mark = -1;    // mark: where the stream produced `out` (cg_stream_mark)
+                        std::shared_ptr<void> stage; int32_t stage_tk = -1; };                                                // single staged message: page-locked block [local | received], ticket of the download
+    // single-message exchanges are staged in page-locked memory from 2^12 elements on; in a party with two contexts (from 2^15 variables) and from 2^14
+    // elements on they cross PCIe on the chain context's copy streams, beside the main stream (one REP3 party, never / with two contexts / from 2^12 on:
+    // 2^13 1.63-1.79 / - / 1.86-2.20 ms | 2^14, one context 2.04-2.09 / - / 2.23-2.46 | 2^15 2.42-2.53 / 2.17-2.27 / 2.30-2.33 | 2^16 2.83-2.99 / 2.91-2.95 / 2.85-2.93)
+    static constexpr size_t XCHG_STAGED_MIN = (size_t)1 << 12;
+    const size_t XCHG_COPY_STREAM_MIN = getenv("CGH_XCHG_COPY_STREAM_MIN") ? (size_t)atoll(getenv("CGH_XCHG_COPY_STREAM_MIN")) : (size_t)1 << 14;   // (A/B knob)
     // start streaming chunks of the local product to the host, as many as the ring has room for
     void issue_downloads(PendingMul& pm, size_t upto) {
         const size_t n = pm.out.n, ch = xchg_chunk(n), nch = (n + ch - 1) / ch;
@@ -641,6 +647,14 @@ public:
         pm.exchange = true;
         if (a.n >= XCHG_ASYNC_MIN) CG(cg_stream_mark(ctx, &pm.mark));
         if (a.n >= XCHG_ASYNC_MIN) issue_downloads(pm, XCHG_SLOTS - 1);                // ordered right behind the product, ahead of whatever the caller enqueues next
+        else if (a.n >= XCHG_COPY_STREAM_MIN && aux) {                                 // (a party with a second context: this one is its chain context, with copy streams of its own)
+            // One message, but not on the main stream: the download starts behind the PRODUCT (a mark), on the copy stream — the synchronous copy it
+            // replaces queued behind the transforms the prover enqueues next (a 2^16 party: the first exchange waited for the four transforms of a and b,
+            // themselves slowed by the accumulations running beside them)
+            void* p = nullptr; CG(cg_host_alloc(2 * a.n * 32, &p)); pm.stage.reset(p, [](void* q) { cg_host_free(q); });
+            CG(cg_stream_mark(ctx, &pm.mark));
+            CG(cg_dev_download_begin_after(ctx, p, out.c[0], a.n * 32, pm.mark, &pm.stage_tk));
+        }
         return pm;
     }
     ShareVec mul_vec_finish(PendingMul& pm) {
@@ -649,10 +663,26 @@ public:
         pm.exchange = false;
         if (out.n < XCHG_ASYNC_MIN) {                                                  // rep3.rs:661-669 as one message
             Marks mk("  mul_vec_finish (one message)", party() <= 0);
-            // From 2^12 elements on the message is staged in page-locked memory (parked blocks of the host cache: a pageable 2 MB copy
-            // crosses PCIe at a fifth of the speed — the two exchanges of a 2^16 party were 1.2 ms of its 3.0) and the range check of what
-            // arrived runs on the device behind the upload, as for the chunked exchange.
-            const bool staged = out.n >= ((size_t)1 << 12);
+            // From 2^12 elements on the message is staged in page-locked memory (parked blocks of the host cache) and copied on the copy streams;
+            // the range check of what arrived runs on the device behind the upload, as for the chunked exchange.
+            if (pm.stage) {                                                            // from XCHG_COPY_STREAM_MIN elements on (mul_vec_begin)
+                Fr* local = (Fr*)pm.stage.get(); Fr* recv = local + out.n;
+                CG(cg_copy_wait(ctx, pm.stage_tk));
+                mk.mark("download");
+                net->send_next(local, out.n * 32);
+                const void* direct = net->recv_prev_pinned(out.n * 32);                // the transport holds it in page-locked memory already
+                if (!direct) { net->recv_prev(recv, out.n * 32); direct = recv; }
+                mk.mark("send + receive");
+                int32_t up = -1;
+                CG(cg_dev_upload_begin(ctx, out.c[1], direct, out.n * 32, 0, &up));
+                CG(cg_copy_fence(ctx, up));                                            // later launches see the received component ...
+                check_received_dev(out.c[1], out.n);                                   // ... the range check first (read before the last opening, verify_received_vectors)
+                CG(cg_copy_wait(ctx, up));                                             // the staging block / the transport's buffer is free again
+                pm.stage.reset();
+                mk.mark("upload");
+                return out;
+            }
+            const bool staged = out.n >= XCHG_STAGED_MIN;                                // page-locked, but in stream order on the main stream
             struct Pinned { void* p = nullptr; ~Pinned() { if (p) cg_host_free(p); } } stage;
             std::vector<Fr> pageable(staged ? 0 : 2 * out.n);
             if (staged) CG(cg_host_alloc(2 * out.n * 32, &stage.p));

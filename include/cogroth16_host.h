@@ -15,6 +15,8 @@
  *   thresholds    CGH_SECOND_CONTEXT_MIN (15)   log2 of the variables from which a proof uses a chain + a bulk context
  *                 CGH_XCHG_ASYNC_MIN (2^17)     elements from which the mul_vec exchange streams in chunks over the copy streams
  *                 CGH_DEVICE_MASKS_MIN (2^11)   elements from which described ChaCha12 generators are drawn on the device
+ *                 CGH_XCHG_COPY_STREAM_MIN (2^14)  elements from which a single-message mul_vec exchange of a two-context party crosses PCIe on the copy streams, behind the product
+ *                                               and beside the transforms, instead of in stream order on the main stream
  *   A/B           CGH_ONE_CONTEXT, CGH_NO_CHAIN_PRIORITY, CGH_CHAIN_FLAG (1), CGH_BULK_FLAG (2)   one context per proof; no priorities; cg_ctx_create_ex flags
  *                 CGH_BULK_CHUNK (64) / CGH_PLAIN_CHUNK (0)   CG_OPT_MSM_CHUNK of the bulk context beside a REP3 chain (>= 2^20 elements) / otherwise
  *                 CGH_G2_ORDER=first, CGH_G2_AFTER (2)        launch order of the aux MSMs' (table, component) pairs (HipDriver::begin_multi_ordered)
