@@ -1148,9 +1148,30 @@ int new_stream(int cls, hipStream_t* out) {
     HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, cls > 0 ? prio_greatest : prio_least));
     return 0;
 }
-int pooled_stream(int device, int cls, hipStream_t* out) {
+// The queues of the three classes that carry the same index sit on one PIPE of the command processor, and streams on one pipe delay each other's
+// dispatches by ~25 us even across classes (scripts/queue_map.hip: 140 us for two 120 us spin kernels side by side, 165 on one pipe, 260 on one queue).
+// measured_pipe() finds the pipe of a new stream against idle reference streams (defined below, with the probe kernel); `want` asks for a stream on
+// a given pipe: a parked one, or new ones until one lands there (the others are parked for later).
+int measured_pipe(int device, int cls, hipStream_t st);
+thread_local int g_group_rot = 0;                                     // pipes of this thread's stream group are rotated by this (parties of one process differ)
+int pooled_stream(int device, int cls, hipStream_t* out, int want = -1) {
     std::lock_guard<std::mutex> l(g_stream_pool_mu);
     StreamClassPool& p = g_stream_pool[{device, cls}];
+    if (want >= 0 && cls >= -1 && cls <= 1) {
+        for (int tries = 0; tries < 2 * HWQ; tries++) {
+            for (size_t i = 0; i < p.idle.size(); i++) if (p.idle[i].second == want) {
+                *out = p.idle[i].first; p.out[want]++; if (g_group_depth > 0) g_group_used[cls + 1] |= (uint8_t)(1u << want);
+                if (getenv("CG_DEBUG_STREAMS")) fprintf(stderr, "stream: class %d on pipe %d as asked (idle %zu)\n", cls, want, p.idle.size() - 1);
+                p.idle.erase(p.idle.begin() + i);
+                return 0;
+            }
+            hipStream_t st = nullptr;
+            if (int rc = new_stream(cls, &st)) return rc;
+            const int model = p.created++ % HWQ, seen = measured_pipe(device, cls, st);
+            if (seen < 0) { g_stream_slot[st] = model; p.idle.push_back({st, model}); break; }      // no map on this device: the choice below
+            g_stream_slot[st] = seen; p.idle.push_back({st, seen});
+        }
+    }
     const bool grp = g_group_depth > 0 && cls >= -1 && cls <= 1;
     uint8_t none = 0; uint8_t& used = grp ? g_group_used[cls + 1] : none;
     const bool slots_left = grp && used != (1u << HWQ) - 1;
@@ -1170,7 +1191,8 @@ int pooled_stream(int device, int cls, hipStream_t* out) {
         }
         hipStream_t st = nullptr;                                    // nothing suitable parked: a new stream joins the idle list and the choice is made again
         if (int rc = new_stream(cls, &st)) return rc;
-        const int slot = p.created++ % HWQ;
+        const int model = p.created++ % HWQ, seen = measured_pipe(device, cls, st);
+        const int slot = seen >= 0 ? seen : model;
         g_stream_slot[st] = slot; p.idle.push_back({st, slot});
     }
     return fail(CG_ERR_HIP, "internal: stream pool");
@@ -1184,9 +1206,9 @@ void park_stream(int device, int cls, hipStream_t st) {
     if (p.out[it->second] > 0) p.out[it->second]--;
     if (p.idle.size() < 32) p.idle.push_back({st, it->second}); else { g_stream_slot.erase(it); hipStreamDestroy(st); }
 }
-int make_copy_streams(cg_ctx* c) {
-    { int rc = pooled_stream(c->device, c->prio_copy, &c->h2d); if (rc) return rc; }
-    { int rc = pooled_stream(c->device, c->prio_copy, &c->d2h); if (rc) return rc; }
+int make_copy_streams(cg_ctx* c, int want_h2d = -1, int want_d2h = -1) {
+    { int rc = pooled_stream(c->device, c->prio_copy, &c->h2d, want_h2d); if (rc) return rc; }
+    { int rc = pooled_stream(c->device, c->prio_copy, &c->d2h, want_d2h); if (rc) return rc; }
     HIPCHK(hipEventCreateWithFlags(&c->ev_copy_order, hipEventDisableTiming));
     return 0;
 }
@@ -1212,6 +1234,64 @@ bool streams_share_queue(hipStream_t a, hipStream_t b) {
     }
     return best > 190.0 && best < 420.0;        // (far beyond 240 us: the device is busy with somebody else's work and the probe says nothing)
 }
+// ---- the pipe of a stream (see pooled_stream).  Per device, once: four idle reference streams of the low class and four of the high class, each set on
+// four different queues; the low set names the pipes, the high set is matched to it.  A new stream of the normal or high class is timed against the low
+// set, one of the low class against the high set: the one pair that takes ~165 us instead of ~140 names its pipe.  Anything inconsistent (another party's
+// work on the device, a runtime that maps differently) gives -1: the pool then falls back on its creation-order model.  CG_NO_PIPE_MAP: off.
+struct PipeRefs { hipStream_t low[HWQ] = {nullptr, nullptr, nullptr, nullptr}, high[HWQ] = {nullptr, nullptr, nullptr, nullptr}; bool ok = false, tried = false; };
+std::map<int, PipeRefs> g_pipe_refs;
+std::mutex g_pipe_mu;
+double spin_pair_us(hipStream_t a, hipStream_t b) {
+    double best = 1e9;
+    for (int rep = 0; rep < 3; rep++) {
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, 12000ull);
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, b, 12000ull);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
+        best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    return best;
+}
+// index of the ONE reference the stream is coupled to (same pipe: >= 152 us; same queue, 260 us, counts as well), -1 if none or several
+int coupled_reference(const hipStream_t* refs, hipStream_t st) {
+    int found = -1;
+    for (int i = 0; i < HWQ; i++) {
+        const double us = spin_pair_us(refs[i], st);
+        if (us < 0 || us > 420.0) return -1;                                         // the device is busy: the probe says nothing
+        if (us >= 152.0) { if (found >= 0) return -1; found = i; }
+    }
+    return found;
+}
+int measured_pipe(int device, int cls, hipStream_t st) {
+    static const bool off = getenv("CG_NO_PIPE_MAP") != nullptr || getenv("CG_NO_STREAM_PROBE") != nullptr;
+    if (off || cls < -1 || cls > 1) return -1;
+    std::lock_guard<std::mutex> l(g_pipe_mu);
+    PipeRefs& r = g_pipe_refs[device];
+    if (!r.tried) {
+        r.tried = true;
+        bool ok = true;
+        for (int i = 0; i < HWQ && ok; i++) ok = new_stream(-1, &r.low[i]) == 0;
+        for (int i = 0; i < HWQ && ok; i++) ok = new_stream(1, &r.high[i]) == 0;
+        for (int i = 0; i < HWQ && ok; i++) for (int j = i + 1; j < HWQ && ok; j++) {   // each set on four different queues
+            const double a = spin_pair_us(r.low[i], r.low[j]), b = spin_pair_us(r.high[i], r.high[j]);
+            ok = a > 0 && a < 152.0 && b > 0 && b < 152.0;
+        }
+        hipStream_t matched[HWQ] = {nullptr, nullptr, nullptr, nullptr};
+        for (int j = 0; j < HWQ && ok; j++) {                                          // every high reference on the pipe of exactly one low reference, and all four used
+            const int pipe = coupled_reference(r.low, r.high[j]);
+            ok = pipe >= 0 && !matched[pipe];
+            if (ok) matched[pipe] = r.high[j];
+        }
+        if (ok) for (int i = 0; i < HWQ; i++) r.high[i] = matched[i];
+        r.ok = ok;
+        if (getenv("CG_DEBUG_STREAMS")) fprintf(stderr, "pipe map of device %d: %s\n", device, ok ? "references in place" : "not available (the pool keeps its creation-order model)");
+    }
+    if (!r.ok) return -1;
+    int pipe = coupled_reference(cls == -1 ? r.high : r.low, st);
+    if (pipe < 0) pipe = coupled_reference(cls == -1 ? r.high : r.low, st);             // (a second try settles a launch hiccup)
+    return pipe;
+}
 // make `moving` not share a queue with any of `fixed` (same priority class): streams that do are parked again and others tried
 thread_local std::vector<hipStream_t> g_group_busy[3];                        // [class + 1]: streams of the contexts made so far in this thread's stream group
 int separate_stream(int device, int cls, hipStream_t* moving, std::vector<hipStream_t> fixed) {
@@ -1233,7 +1313,11 @@ int separate_stream(int device, int cls, hipStream_t* moving, std::vector<hipStr
 }
 }  // namespace
 
-int32_t cg_stream_group_begin(void) { if (g_group_depth++ == 0) { for (uint8_t& u : g_group_used) u = 0; for (auto& v : g_group_busy) v.clear(); } return 0; }
+int32_t cg_stream_group_begin(void) {
+    static std::atomic<int> groups{0};
+    if (g_group_depth++ == 0) { for (uint8_t& u : g_group_used) u = 0; for (auto& v : g_group_busy) v.clear(); g_group_rot = groups.fetch_add(1) % HWQ; }
+    return 0;
+}
 int32_t cg_stream_group_end(void) { if (g_group_depth > 0) g_group_depth--; return 0; }
 int32_t cg_ctx_create(int32_t device, cg_ctx** out) { return cg_ctx_create_ex(device, 0, out); }
 // flags bit 0 ("chain"): for the context that carries a dependency chain (witness map with its party-to-party exchanges) while another
@@ -1261,15 +1345,24 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     }
     if (flags & 1u) { c->prio_main = 1; c->prio_copy = 1; c->prio_side = 0; }
     else if (flags & 2u) { static const int bulk_cls = getenv("CG_BULK_CLASS") ? atoi(getenv("CG_BULK_CLASS")) : -1; c->prio_main = bulk_cls; c->prio_side = 0; }   // CG_BULK_CLASS: tuning knob
-    { int rc = pooled_stream(device, c->prio_main, &c->stream); if (rc) return rc; }
-    if (flags & 1u) { int rc = make_copy_streams(c); if (rc) return rc; }
+    // Inside a stream group (one party's contexts) every stream is asked for on a PIPE: the chain's main stream alone on one (the streams it shares it
+    // with are idle while it works: its own sort stream, the bulk context's main stream when the accumulations run on the side streams), the two
+    // accumulation / reduction streams of the bulk context on two others, the copy streams on the fourth and beside the G1 accumulations.  A party
+    // with one context: main, aux and sort stream on three pipes.  (The first session of a process used to fall into this arrangement by the order in
+    // which its streams were created — a 2^16 party 2.9 ms — and later ones did not: 3.2-3.5 ms.)
+    const bool piped = g_group_depth > 0;
+    auto pipe = [&](int k) { return piped ? (k + g_group_rot) % HWQ : -1; };
+    const int w_main = (flags & 1u) ? pipe(0) : (flags & 2u) ? pipe(1) : pipe(0), w_aux = (flags & 1u) ? pipe(3) : pipe(1), w_sort = (flags & 1u) ? pipe(0) : pipe(2);
+    const int w_join = (flags & 1u) ? pipe(3) : (flags & 2u) ? pipe(2) : pipe(3);
+    { int rc = pooled_stream(device, c->prio_main, &c->stream, w_main); if (rc) return rc; }
+    if (flags & 1u) { int rc = make_copy_streams(c, pipe(3), pipe(2)); if (rc) return rc; }
     // the side streams carry short, latency-bound kernels the main stream's next accumulate waits for: let their workgroups
     // jump the backlog of accumulate workgroups (one priority class above the main stream's, except next to a chain)
-    { int rc = pooled_stream(device, c->prio_side, &c->aux); if (rc) return rc; }
-    { int rc = pooled_stream(device, c->prio_side, &c->sortst); if (rc) return rc; }
+    { int rc = pooled_stream(device, c->prio_side, &c->aux, w_aux); if (rc) return rc; }
+    { int rc = pooled_stream(device, c->prio_side, &c->sortst, w_sort); if (rc) return rc; }
     // the work-free stream behind released blocks (cg_dev_free) is made here, not at the first release: inside a stream group it then gets a
     // queue apart from a bulk context's low-priority main stream (its packets are waits for OTHER streams' progress: nothing may queue behind them)
-    { int rc = pooled_stream(device, -1, &c->joinst); if (rc) return rc; }
+    { int rc = pooled_stream(device, -1, &c->joinst, w_join); if (rc) return rc; }
     // the context's busy streams of one priority class on hardware queues of their own (measured, see streams_share_queue): the two side
     // streams against each other and against whatever else of the context lives in their class; a chain context's copy streams against its main stream
     // Inside a stream group (one party's chain + bulk contexts) the streams of the contexts made before count as well: a class has four

@@ -172,6 +172,9 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *                 CG_SUBGROUP_FULL           subgroup checks by [r]P instead of the endomorphism tests
  *                 CG_BULK_CLASS (-1)         priority class of a bulk context's main stream (cg_ctx_create_ex flag 2)
  *                 CG_NO_STREAM_PROBE         new contexts keep the streams the pool hands them without measuring which of them share a hardware queue
+ *                 CG_NO_PIPE_MAP             the contexts of a stream group take their streams by the pool's creation-order model instead of by measured pipe:
+ *                                            queues of the three priority classes with the same index share a pipe of the command processor and delay each
+ *                                            other's dispatches by ~25 us (scripts/queue_map.hip); a party's busy streams are therefore placed on pipes
  *                 CG_MSM_TABLE_ORDER, CG_MSM_G2_AFTER, CG_MSM_G2_SLICES, CG_MSM_REDUCE_BATCH, CG_MSM_ACC_SLOTS, CG_MSM_WIDE_SMALL   seed the option table of NEW contexts
  *                 CG_MSM_ONE_STREAM_LOG (0)  MSM calls of at most 2^this (point, window) entries run schedule, accumulation and reduction in stream order on the
  *                                            context's main stream (0 = never: measured slower than three streams); seeds new contexts
