@@ -1238,7 +1238,7 @@ bool streams_share_queue(hipStream_t a, hipStream_t b) {
 // four different queues; the low set names the pipes, the high set is matched to it.  A new stream of the normal or high class is timed against the low
 // set, one of the low class against the high set: the one pair that takes ~165 us instead of ~140 names its pipe.  Anything inconsistent (another party's
 // work on the device, a runtime that maps differently) gives -1: the pool then falls back on its creation-order model.  CG_NO_PIPE_MAP: off.
-struct PipeRefs { hipStream_t low[HWQ] = {nullptr, nullptr, nullptr, nullptr}, high[HWQ] = {nullptr, nullptr, nullptr, nullptr}; bool ok = false, tried = false; };
+struct PipeRefs { hipStream_t low[HWQ] = {nullptr, nullptr, nullptr, nullptr}, high[HWQ] = {nullptr, nullptr, nullptr, nullptr}; bool ok = false; int attempts = 0; };
 std::map<int, PipeRefs> g_pipe_refs;
 std::mutex g_pipe_mu;
 double spin_pair_us(hipStream_t a, hipStream_t b) {
@@ -1268,8 +1268,10 @@ int measured_pipe(int device, int cls, hipStream_t st) {
     if (off || cls < -1 || cls > 1) return -1;
     std::lock_guard<std::mutex> l(g_pipe_mu);
     PipeRefs& r = g_pipe_refs[device];
-    if (!r.tried) {
-        r.tried = true;
+    if (!r.ok && r.attempts < 3) {                                                     // (an attempt made while somebody else's work held the device may fail: twice more, later)
+        r.attempts++;
+        for (hipStream_t& x : r.low) if (x) { hipStreamDestroy(x); x = nullptr; }
+        for (hipStream_t& x : r.high) if (x) { hipStreamDestroy(x); x = nullptr; }
         bool ok = true;
         for (int i = 0; i < HWQ && ok; i++) ok = new_stream(-1, &r.low[i]) == 0;
         for (int i = 0; i < HWQ && ok; i++) ok = new_stream(1, &r.high[i]) == 0;
