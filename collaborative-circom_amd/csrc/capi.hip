@@ -1348,13 +1348,14 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     if (flags & 1u) { c->prio_main = 1; c->prio_copy = 1; c->prio_side = 0; }
     else if (flags & 2u) { static const int bulk_cls = getenv("CG_BULK_CLASS") ? atoi(getenv("CG_BULK_CLASS")) : -1; c->prio_main = bulk_cls; c->prio_side = 0; }   // CG_BULK_CLASS: tuning knob
     // Inside a stream group (one party's contexts) every stream is asked for on a PIPE: the chain's main stream alone on one (the streams it shares it
-    // with are idle while it works: its own sort stream, the bulk context's main stream when the accumulations run on the side streams), the two
-    // accumulation / reduction streams of the bulk context on two others, the copy streams on the fourth and beside the G1 accumulations.  A party
-    // with one context: main, aux and sort stream on three pipes.  (The first session of a process used to fall into this arrangement by the order in
+    // with is idle while it works: its own sort stream), the bulk context's main, sort and reduction streams on the three others — the reduction stream
+    // NOT on the pipe of the main stream, whose accumulations it runs beside at large sizes (one REP3 party, reduction stream on the main stream's pipe /
+    // on its own: 2^22 73.2, 72.3 / 71.5, 71.6 ms, 2^20 23.3, 23.5 / 23.1, 23.1) — the copy streams beside the sort and reduction streams.  A party with
+    // one context: main, aux and sort stream on three pipes.  (The first session of a process used to fall into this arrangement by the order in
     // which its streams were created — a 2^16 party 2.9 ms — and later ones did not: 3.2-3.5 ms.)
     const bool piped = g_group_depth > 0;
     auto pipe = [&](int k) { return piped ? (k + g_group_rot) % HWQ : -1; };
-    const int w_main = (flags & 1u) ? pipe(0) : (flags & 2u) ? pipe(1) : pipe(0), w_aux = (flags & 1u) ? pipe(3) : pipe(1), w_sort = (flags & 1u) ? pipe(0) : pipe(2);
+    const int w_main = (flags & 1u) ? pipe(0) : (flags & 2u) ? pipe(1) : pipe(0), w_aux = (flags & 1u) ? pipe(1) : (flags & 2u) ? pipe(3) : pipe(1), w_sort = (flags & 1u) ? pipe(0) : pipe(2);
     const int w_join = (flags & 1u) ? pipe(3) : (flags & 2u) ? pipe(2) : pipe(3);
     { int rc = pooled_stream(device, c->prio_main, &c->stream, w_main); if (rc) return rc; }
     if (flags & 1u) { int rc = make_copy_streams(c, pipe(3), pipe(2)); if (rc) return rc; }
