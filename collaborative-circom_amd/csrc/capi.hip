@@ -1140,7 +1140,8 @@ std::map<hipStream_t, int> g_stream_slot;                         // every strea
 // get slots of their own as long as the class has any left (the streams they then share a queue with belong to somebody else's, mostly
 // idle, contexts): a chain context's sort stream must not sit behind the bulk context's reduction batch and vice versa.
 thread_local int g_group_depth = 0;
-thread_local uint8_t g_group_used[3] = {0, 0, 0};                   // [class + 1]: slots taken by the group so far
+thread_local std::map<int, std::array<uint8_t, 3>> g_group_used_by_device;   // device -> [class + 1]: slots taken by the group so far
+#define g_group_used (g_group_used_by_device[device])
 int new_stream(int cls, hipStream_t* out) {
     if (cls == 0) { HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking)); return 0; }
     int prio_least = 0, prio_greatest = 0;                           // numerically: least >= greatest
@@ -1158,6 +1159,9 @@ int pooled_stream(int device, int cls, hipStream_t* out, int want = -1) {
     std::lock_guard<std::mutex> l(g_stream_pool_mu);
     StreamClassPool& p = g_stream_pool[{device, cls}];
     if (want >= 0 && cls >= -1 && cls <= 1) {
+        // (a pipe the group already uses in this class on this device — a second chain / bulk pair on the SAME device, as the tests' shared-device
+        // sessions make them — would be the same hardware queue: the next pipe the class has left)
+        if (g_group_depth > 0) for (int k = 0; k < HWQ && ((g_group_used[cls + 1] >> want) & 1u); k++) want = (want + 1) % HWQ;
         for (int tries = 0; tries < 2 * HWQ; tries++) {
             for (size_t i = 0; i < p.idle.size(); i++) if (p.idle[i].second == want) {
                 *out = p.idle[i].first; p.out[want]++; if (g_group_depth > 0) g_group_used[cls + 1] |= (uint8_t)(1u << want);
@@ -1317,7 +1321,7 @@ int separate_stream(int device, int cls, hipStream_t* moving, std::vector<hipStr
 
 int32_t cg_stream_group_begin(void) {
     static std::atomic<int> groups{0};
-    if (g_group_depth++ == 0) { for (uint8_t& u : g_group_used) u = 0; for (auto& v : g_group_busy) v.clear(); g_group_rot = groups.fetch_add(1) % HWQ; }
+    if (g_group_depth++ == 0) { g_group_used_by_device.clear(); for (auto& v : g_group_busy) v.clear(); g_group_rot = groups.fetch_add(1) % HWQ; }
     return 0;
 }
 int32_t cg_stream_group_end(void) { if (g_group_depth > 0) g_group_depth--; return 0; }
