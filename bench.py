@@ -504,7 +504,8 @@ def compact_line(out, detail_path):
         else:
             line.setdefault("second_curve", {})[name] = {"log_m": leg.get("log_m"), "step_ms": _r(leg["step_resident"]["ms_per_step"]), "entry_ms": _r(leg["product_entry"]["ms_per_proof"])}
     if "speedup_vs_cpu_baseline" in out:
-        line["speedup_vs_cpu_baseline"] = {k: _r(v) for k, v in out["speedup_vs_cpu_baseline"].items()}
+        sp = out["speedup_vs_cpu_baseline"]
+        line["speedup_vs_cpu_baseline"] = {k: _r(v) for k, v in sp.items()} if isinstance(sp, dict) else _r(sp)
     line["detail"] = detail_path
     text = json.dumps(line, separators=(",", ":"))
     for drop in ("second_curve", "sizes", "valu_roofline", "roofline_ntt", "roofline_g2", "speedup_vs_cpu_baseline"):     # never reached with today's legs; the limit is a contract
