@@ -149,6 +149,7 @@ struct cg_ctx {
     Arena solo_arena;                                     // scratch of tiny single-field MSM calls that run in stream order on the main stream (`solo` in msm_begin_multi_impl_)
     std::vector<void*> retired;                        // outgrown arena blocks that enqueued kernels may still use
     void* gather_buf = nullptr; size_t gather_cap = 0;   // scalars gathered for compacted tables (see cg_bases::compact)
+    bool sorts_unordered = false;                         // the last call's sorts ran off the main stream and the main stream has not waited for them (off_main): the next gather must
     std::map<TwKey, void*> twiddles;
     std::map<CosetKey, CosetTables> cosets;
     std::vector<MsmTicket> tickets;
@@ -351,6 +352,9 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
                 ctx->gather_buf = nullptr; ctx->gather_cap = 0;
                 HIPCHK(hip_malloc_flush(&ctx->gather_buf, need)); ctx->gather_cap = need;
             }
+            // gather_buf is rewritten from offset 0 by this call: an off-main call before it (no cg_msm_end in between) may still be reading it in
+            // its digit / sort kernels, which the main stream no longer waits for — a stream wait, no host stall
+            if (ctx->sorts_unordered) { for (int j = 0; j < 2; j++) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[j], 0)); ctx->sorts_unordered = false; }
             size_t used = 0;
             for (auto& g : groups) {
                 std::vector<const cg_bases*> gb; std::vector<size_t> go; std::vector<const void*> gs(k);
@@ -607,6 +611,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
             // the schedules are free once every accumulation has read them: behind them all on the main stream, or (off the main stream) on the
             // sort stream, which holds the G1 accumulations itself and waits here for the G2 ones
             if (off_main && last_acc[1]) HIPCHK(hipStreamWaitEvent(sortst, last_acc[1], 0));
+            if (off_main) ctx->sorts_unordered = true;
             if (!solo) for (int j = 0; j < k; j++) HIPCHK(hipEventRecord(ctx->ev_sched_free[j], off_main ? sortst : ctx->stream));
         }
         // one accumulation: table b, share component j, into the next rotating scratch slot; its bucket set joins the batch of its field

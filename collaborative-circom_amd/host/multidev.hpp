@@ -47,7 +47,8 @@ public:
     std::vector<void*> pinned;                 // page-locked staging released at the end
 
     DistributedWitnessMap(HipDriver& d, const DeviceZKey& dz0, const MultiDevice& md)
-        : drv(d), curve(d.curve), k(d.k()), additive(d.additive_h && d.mode == Mode::Rep3), kc(additive ? 1 : d.k()), primary_only(getenv("CGH_EMULATE_PRIMARY_ONLY") != nullptr) {
+        // (k comes from the MODE, not from d.k(): prove() builds the map while its one-component override for the additive variant's MSMs is live — ADVICE r5)
+        : drv(d), curve(d.curve), k(d.mode == Mode::Rep3 ? 2 : 1), additive(d.additive_h && d.mode == Mode::Rep3), kc(additive ? 1 : d.k()), primary_only(getenv("CGH_EMULATE_PRIMARY_ONLY") != nullptr) {
         Dev p; p.ctx = d.ctx; p.msm = d.aux ? d.aux : d.ctx; p.dz = &dz0; p.lo = dz0.h_lo; p.n = dz0.h_n; devs.push_back(p);
         for (const WorkerDevice& w : md.workers) { Dev x; x.ctx = w.chain ? w.chain : w.ctx; x.msm = w.ctx; x.dz = w.dz; x.lo = w.dz->h_lo; x.n = w.dz->h_n; devs.push_back(x); }
     }

@@ -145,7 +145,10 @@ int32_t cg_msm_dev_begin(cg_ctx* ctx, const cg_bases* bases, size_t offset, size
 int32_t cg_msm_end(cg_ctx* ctx, int32_t ticket, void* h_out_jacobian);
 /* Several base tables times the SAME k scalar vectors (calculate_coeff for a_query, b_g1_query, b_g2_query and the l_query MSM
  * all take `aux_assignment`, groth16.rs:251,267,284,298): the scalar decomposition and bucket sort are done once per vector and
- * reused by every table.  tables[i] is read from offsets[i] (offsets may be NULL = all zero); tickets[i] collects table i. */
+ * reused by every table.  tables[i] is read from offsets[i] (offsets may be NULL = all zero); tickets[i] collects table i.
+ * LIFETIME of d_scalars (every cg_msm_dev_begin* form): the vectors must stay untouched until cg_msm_end has returned for the call's
+ * tickets — the digit / sort kernels read them on a side stream, and for small calls the context's main stream is NOT ordered behind
+ * those reads (work enqueued on it after the begin call may run beside them). */
 int32_t cg_msm_dev_begin_multi(cg_ctx* ctx, int32_t n_tables, const cg_bases* const* tables, const size_t* offsets, size_t n,
                                const void* const* d_scalars, int32_t k, int32_t* tickets);
 /* Scalars still crossing PCIe: the NEXT cg_msm_dev_begin / _begin_multi on `ctx` lets the digit / sort schedule of share component

@@ -8,6 +8,8 @@
 // (at most ceil(254/c) useful threads) and data-parallel FFT stages / pointwise loops.  Network rounds are excluded on both sides.
 #pragma once
 #include "groth16.hpp"
+#include "rngs.hpp"
+#include "formats.hpp"
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -221,6 +223,128 @@ static double bench_rep3_party(int log_m, int threads, uint64_t seed, double* st
         if (msm_shared) *msm_shared = shared ? 1 : 0;
     }
     return sa[0] + sa[1] + sa[2] + sa[3];
+}
+
+// The masks of the two mul_vec calls of one proof as the reference draws them (rep3.rs:657-661 inside the serial izip map, rngs.rs:37-46):
+// per element F::rand(rng1) - F::rand(rng2), on ONE thread — 4 x m ChaCha12 rejection-sampled draws per proof.  Seconds.
+template <class C>
+static double bench_mask_draws(size_t m, uint64_t seed, typename C::Fr* sink_out = nullptr) {
+    typedef typename C::Fr Fr;
+    C::init();
+    uint8_t s1[32], s2[32];
+    for (int i = 0; i < 32; i++) { s1[i] = (uint8_t)(seed >> (i % 8 * 8)) ^ (uint8_t)i; s2[i] = (uint8_t)~s1[i]; }
+    ChaCha12Stream r1(s1), r2(s2);
+    auto t0 = std::chrono::steady_clock::now();
+    Fr acc = Fr::zero();
+    for (int call = 0; call < 2; call++)
+        for (size_t i = 0; i < m; i++) {
+            Fr a, b; fr_rand(r1, Fr::K.p, Fr::K.bits, a.v); fr_rand(r2, Fr::K.p, Fr::K.bits, b.v);
+            acc = acc + (a - b);
+        }
+    auto t1 = std::chrono::steady_clock::now();
+    if (sink_out) *sink_out = acc;
+    volatile uint64_t sink = acc.v[0]; (void)sink;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// ONE REP3 party (party 0) of `CoGroth16::prove` on a zkey + wtns pair — the CPU twin of the GPU bench's entry legs (the reference's own
+// bench circuit, tests/benches/poseidon_hash2.rs:175-223, is such a pair).  Everything the party computes between witness shares in and
+// proof shares out: constraint rows, both mul_vec products WITH their mask draws (serial, as above), the six transform pipelines, the ten
+// MSMs + the public-input MSMs of calculate_coeff, r / s, the five scalar products of the tail.  What the peers send is taken as given
+// (random vectors / points): network time excluded, like on the GPU side.  Seconds per proof (mean of `reps`), stage[0..4] = rows + products,
+// transforms, MSM G1, MSM G2 + tail, mask draws.
+template <class C>
+static double bench_rep3_party_file(const std::string& zkey_path, const std::string& wtns_path, int threads, int reps, double* stage) {
+    typedef typename C::Fr Fr; typedef typename C::G1 G1; typedef typename C::G2 G2;
+    C::init();
+    const ZKey<C> z = read_zkey<C>(zkey_path, false);
+    const std::vector<Fr> w = read_wtns<Fr>(wtns_path);
+    if (w.size() != z.n_vars) throw std::runtime_error("witness length does not match the zkey");
+    const size_t n_inputs = z.n_public + 1, n_aux = z.n_vars - n_inputs, nc = z.num_constraints;
+    auto dom = groth16_domain<Fr>(z.pow, nc, n_inputs);
+    const size_t m = dom.m;
+    XorShift rng{0x5eed5eedull};
+    std::vector<Fr> pub(w.begin(), w.begin() + n_inputs), wa(n_aux), wb(n_aux), recv1(m), recv2(m);
+    for (size_t i = 0; i < n_aux; i++) { wb[i] = rand_fp<Fr>(rng); wa[i] = w[n_inputs + i] - wb[i]; }      // a share pair of the real witness (the third share is the peers')
+    for (auto* v : {&recv1, &recv2}) for (auto& x : *v) x = rand_fp<Fr>(rng);
+    std::vector<Fr> tw(std::max<size_t>(1, m / 2)), twi(std::max<size_t>(1, m / 2));
+    { Fr wi = dom.omega.inverse(); tw[0] = twi[0] = Fr::one(); for (size_t i = 1; i < m / 2; i++) { tw[i] = tw[i - 1] * dom.omega; twi[i] = twi[i - 1] * wi; } }
+    const Fr ninv = Fr::from_u64((uint64_t)m).inverse();
+    uint8_t s1[32], s2[32]; for (int i = 0; i < 32; i++) { s1[i] = (uint8_t)(7 * i + 1); s2[i] = (uint8_t)(11 * i + 3); }
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+    double st[5] = {0, 0, 0, 0, 0};
+    Pool pool(threads);
+    const auto t_begin = now();
+    for (int rep = 0; rep < reps; rep++) {
+        ChaCha12Stream r1(s1, (uint64_t)rep << 40), r2(s2, (uint64_t)rep << 40);
+        auto t0 = now();
+        std::vector<Fr> aa(m, Fr::zero()), ab(m, Fr::zero()), ba(m, Fr::zero()), bb(m, Fr::zero()), ca(m), cb, ha(m), hb, mask(m);
+        auto rows = [&](int mat, std::vector<Fr>& oa, std::vector<Fr>& ob) {
+            const auto& rp = z.row_ptr[mat]; const auto& col = z.col[mat]; const auto& co = z.coeff[mat];
+            pool.run(nc, 1024, [&](size_t lo, size_t hi) {
+                for (size_t r = lo; r < hi; r++) {
+                    Fr xa = Fr::zero(), xb = Fr::zero();
+                    for (uint32_t k = rp[r]; k < rp[r + 1]; k++) {
+                        const size_t idx = col[k];
+                        if (idx < n_inputs) xa = xa + co[k] * pub[idx];
+                        else { xa = xa + co[k] * wa[idx - n_inputs]; xb = xb + co[k] * wb[idx - n_inputs]; }
+                    }
+                    oa[r] = xa; ob[r] = xb;
+                }
+            });
+        };
+        rows(0, aa, ab); rows(1, ba, bb);
+        for (size_t i = 0; i < n_inputs; i++) aa[nc + i] = pub[i];
+        double t_draw = 0;
+        auto draw = [&] { auto d0 = now(); for (size_t i = 0; i < m; i++) { Fr a, b; fr_rand(r1, Fr::K.p, Fr::K.bits, a.v); fr_rand(r2, Fr::K.p, Fr::K.bits, b.v); mask[i] = a - b; } t_draw += secs(d0, now()); };
+        auto mul_local = [&](std::vector<Fr>& out) {
+            draw();
+            pool.run(m, 1024, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) out[i] = aa[i] * ba[i] + aa[i] * bb[i] + ab[i] * ba[i] + mask[i]; });
+        };
+        mul_local(ca); cb = recv1;
+        auto t1 = now();
+        auto pipeline = [&](std::vector<Fr>& v) {
+            ntt_inverse_mt(v.data(), m, twi, ninv, pool);
+            Fr pw = Fr::one(); for (auto& x : v) { x = x * pw; pw = pw * dom.coset_g; }
+            ntt_forward_mt(v.data(), m, tw, pool);
+        };
+        pipeline(aa); pipeline(ab); pipeline(ba); pipeline(bb);
+        auto t2 = now();
+        mul_local(ha); hb = recv2;
+        auto t3 = now();
+        pipeline(ca); pipeline(cb);
+        auto t4 = now();
+        for (size_t i = 0; i < m; i++) { ha[i] = ha[i] - ca[i]; hb[i] = hb[i] - cb[i]; }
+        auto t5 = now();
+        G1 acc1 = G1::infinity();
+        auto m1 = [&](const typename G1::Affine* q, const Fr* sc, size_t n) { acc1 = acc1.add(msm_auto<G1, Fr>(q, sc, n, threads)); };
+        const size_t hn = std::min(m, z.h_query.size());
+        m1(z.h_query.data(), ha.data(), hn); m1(z.h_query.data(), hb.data(), hn);
+        m1(z.l_query.data(), wa.data(), n_aux); m1(z.l_query.data(), wb.data(), n_aux);
+        for (const auto* q : {&z.a_query, &z.b_g1_query}) {
+            m1(q->data() + 1, pub.data() + 1, z.n_public); m1(q->data() + n_inputs, wa.data(), n_aux); m1(q->data() + n_inputs, wb.data(), n_aux);
+        }
+        auto t6 = now();
+        G2 acc2 = msm_auto<G2, Fr>(z.b_g2_query.data() + 1, pub.data() + 1, z.n_public, 1)
+                      .add(msm_auto<G2, Fr>(z.b_g2_query.data() + n_inputs, wa.data(), n_aux, threads)).add(msm_auto<G2, Fr>(z.b_g2_query.data() + n_inputs, wb.data(), n_aux, threads));
+        // tail (groth16.rs:258-297): r, s, r*s; delta_g1 * {rs, r, s} and g_a_open * s and g1_b * r (three terms) per component; delta_g2 * s
+        Fr r_[2], s_[2], rs_[2];
+        for (int j = 0; j < 2; j++) { fr_rand(j ? r2 : r1, Fr::K.p, Fr::K.bits, r_[j].v); fr_rand(j ? r2 : r1, Fr::K.p, Fr::K.bits, s_[j].v); }
+        rs_[0] = r_[0] * s_[0] + r_[0] * s_[1] + r_[1] * s_[0]; rs_[1] = rand_fp<Fr>(rng);
+        const G1 d1 = G1::from_affine(z.delta_g1); const G2 d2 = G2::from_affine(z.delta_g2);
+        for (int j = 0; j < 2; j++) {
+            acc1 = acc1.add(scalar_mul(d1, rs_[j])).add(scalar_mul(d1, r_[j])).add(scalar_mul(d1, s_[j])).add(scalar_mul(acc1, s_[j]));
+            acc2 = acc2.add(scalar_mul(d2, s_[j]));
+        }
+        acc1 = acc1.add(scalar_mul(acc1, r_[0])).add(scalar_mul(acc1, r_[1])).add(scalar_mul(d1, r_[0]));     // local part of scalar_mul (rep3.rs:835-847)
+        auto t7 = now();
+        volatile bool sink = acc1.is_inf() || acc2.is_inf(); (void)sink;
+        st[0] += secs(t0, t1) + secs(t2, t3) + secs(t4, t5) - t_draw; st[1] += secs(t1, t2) + secs(t3, t4); st[2] += secs(t5, t6); st[3] += secs(t6, t7); st[4] += t_draw;
+    }
+    const double total = secs(t_begin, now());
+    if (stage) for (int i = 0; i < 5; i++) stage[i] = st[i] / reps;
+    return total / reps;
 }
 
 }  // namespace orc

@@ -541,6 +541,23 @@ double orc_bench_rep3_party2(int curve, int log_m, int threads, int threads_b, u
     } catch (const std::exception& e) { g_err = e.what(); return -2.0; }
 }
 
+// the party's host mask draws of one proof (4 x m draws on one thread, rngs.rs:37-46), seconds
+double orc_bench_mask_draws(int curve, size_t m, uint64_t seed) {
+    try {
+        if (curve == 0) return bench_mask_draws<Bn254>(m, seed);
+        if (curve == 1) return bench_mask_draws<Bls12_381>(m, seed);
+        g_err = "bad curve id"; return -1.0;
+    } catch (const std::exception& e) { g_err = e.what(); return -2.0; }
+}
+// one REP3 party on a zkey + wtns pair, mask draws included (stage = 5 doubles, optional), seconds per proof
+double orc_bench_rep3_party_file(int curve, const char* zkey_path, const char* wtns_path, int threads, int reps, double* stage) {
+    try {
+        if (curve == 0) return bench_rep3_party_file<Bn254>(zkey_path, wtns_path, threads, reps, stage);
+        if (curve == 1) return bench_rep3_party_file<Bls12_381>(zkey_path, wtns_path, threads, reps, stage);
+        g_err = "bad curve id"; return -1.0;
+    } catch (const std::exception& e) { g_err = e.what(); return -2.0; }
+}
+
 // synthetic satisfiable circuit + valid CRS of domain size 2^log_m written as .zkey / .wtns (test tooling)
 int orc_make_synthetic(int curve, int log_m, uint64_t seed, const char* zkey_path, const char* wtns_path, int threads) {
     DISPATCH(curve, { make_synthetic<C>(log_m, seed, zkey_path, wtns_path, threads); });

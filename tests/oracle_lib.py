@@ -307,6 +307,25 @@ def bench_rep3_party2(curve, log_m, threads, threads_b, seed=1):
     return (t, dict(zip(names, sa))), (tb.value, dict(zip(names, sb))), bool(shared.value)
 
 
+def bench_mask_draws(curve, m, seed=1):
+    """seconds for the 4 x m host F::rand draws (two mul_vec calls, rngs.rs:37-46) of one proof, one thread"""
+    lib().orc_bench_mask_draws.restype = C.c_double
+    t = lib().orc_bench_mask_draws(curve, C.c_size_t(int(m)), C.c_uint64(seed))
+    if t < 0:
+        raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+    return t
+
+
+def bench_rep3_party_file(curve, zkey_path, wtns_path, threads, reps=1):
+    """seconds per proof for ONE REP3 party on a zkey + wtns pair, host mask draws included (+ per-stage seconds)"""
+    lib().orc_bench_rep3_party_file.restype = C.c_double
+    stage = (C.c_double * 5)()
+    t = lib().orc_bench_rep3_party_file(curve, zkey_path.encode(), wtns_path.encode(), int(threads), int(reps), stage)
+    if t < 0:
+        raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+    return t, dict(zip(("rows_products_s", "ntt_s", "msm_g1_s", "msm_g2_tail_s", "mask_draws_s"), stage))
+
+
 def make_synthetic(curve, log_m, seed, zkey_path, wtns_path, threads=8, n_public=1):
     """synthetic satisfiable R1CS (m - n_public - 1 constraints, n_public public inputs) with a valid Groth16 CRS, as .zkey + .wtns files"""
     if n_public == 1:

@@ -60,3 +60,13 @@ def test_compact_line_sheds_legs_before_it_breaks_the_limit(bench):
     assert len(text) <= bench.COMPACT_LIMIT
     line = json.loads(text)
     assert "sizes" not in line and "roofline" in line and "cpu_baseline" in line
+
+
+def test_cpu_twins_of_the_headline_legs_run_on_the_host():
+    """cpu_baseline's twins: one oracle party on the reference's bench circuit, and the host mask draws of one proof"""
+    import oracle_lib as orc
+    fx = os.path.join(ROOT, "tests", "golden", "groth16", "bn254", "poseidon")
+    t, st = orc.bench_rep3_party_file(orc.BN254, os.path.join(fx, "circuit.zkey"), os.path.join(fx, "witness.wtns"), 2, 2)
+    assert 0 < t < 5 and set(st) == {"rows_products_s", "ntt_s", "msm_g1_s", "msm_g2_tail_s", "mask_draws_s"}
+    assert abs(sum(st.values()) - t) < 0.2 * t + 1e-3
+    assert 0 < orc.bench_mask_draws(orc.BN254, 1 << 10) < 1
