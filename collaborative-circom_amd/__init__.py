@@ -15,6 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(HERE, "libcogroth16_hip.so")
 HOST_LIB_PATH = os.path.join(HERE, "libcogroth16_host.so")
+# planning scripts only (scripts/multi_device_emulation.py): the -DCG_DEBUG_KNOBS build of the host library, `make -C host KNOBS=1`
+if os.environ.get("COGROTH16_HOST_LIB"):
+    HOST_LIB_PATH = os.path.abspath(os.environ["COGROTH16_HOST_LIB"])
 
 BN254, BLS12_381 = 0, 1
 G1, G2 = 0, 1

@@ -173,7 +173,12 @@ int msm_reduce_batch(hipStream_t st2, const MsmRedSet* sets, int nsets, size_t n
         return 0;
     };
     // measurement only (results are WRONG): what the merges (1: skipped too) and the bucket reduction (2: only it) cost the step beside the accumulations
+    // compiled only into -DCG_DEBUG_KNOBS builds (make EXTRA=-DCG_DEBUG_KNOBS OUT=...): the release library has no knob that changes results
+#ifdef CG_DEBUG_KNOBS
     static const int skip_reduce = getenv("CG_DEBUG_NO_REDUCE") ? atoi(getenv("CG_DEBUG_NO_REDUCE")) : 0;
+#else
+    constexpr int skip_reduce = 0;
+#endif
     auto fake_reduce = [&]() -> int {
         for (int i = 0; i < nsets; i++) HIPCHK(hipMemsetAsync(wsums[i], 0, (size_t)g.ngroups * sizeof(XYZZ<F>), st2));
         return deliver((size_t)g.ngroups);

@@ -112,6 +112,17 @@ static const cg_fixed_base* generator_table(const Curve& c, int g) {
 static Point pt_mul_generator(const Curve& c, int g, const Fr& k) { return pt_mul_fixed(c, generator_table(c, g), pt_generator(c, g), k); }
 
 
+// Planning knob of scripts/multi_device_emulation.py, compiled ONLY into -DCG_DEBUG_KNOBS builds (make -C host KNOBS=1 -> libcogroth16_host_knobs.so):
+// CGH_EMULATE_DEVICE=d makes every device but d of an N-device session a no-op, so that one GPU times device d's share of the proof.  The
+// proof is then WRONG — which is why the release library does not contain the knob (tests/test_abi_surface.py checks that it ignores the
+// variable).  -1 = off.
+inline int emulate_only_device() {
+#ifdef CG_DEBUG_KNOBS
+    const char* e = getenv("CGH_EMULATE_DEVICE"); return e ? atoi(e) : -1;
+#else
+    return -1;
+#endif
+}
 // fn(lo, hi) over slices of [0, n) on a few threads; the first exception of a slice is re-thrown
 static void parallel_for(size_t n, const std::function<void(size_t, size_t)>& fn) {
     const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::thread::hardware_concurrency(), n / 4096 + 1}));

@@ -606,8 +606,8 @@ int32_t cgh_session_prove_rep3(void* h, const uint64_t* pub_in, const uint64_t* 
             cgh_rep3_net replay;
             if (cgh_loopback_replay_net(hub, 0, &replay)) throw std::runtime_error(g_host_err);
             if (cgh_session_prove_rep3_party(h, pub_in, wit_a[0], wit_b[0], &replay, &rnd[3], (uint64_t*)solo.data(), &seconds[1])) throw std::runtime_error(g_host_err);
-            // (CGH_EMULATE_PRIMARY_ONLY times the primary device's share of a multi-device proof on uninitialised stand-ins: nothing to compare)
-            if (!getenv("CGH_EMULATE_PRIMARY_ONLY") && memcmp(solo.data(), out_proofs, psz)) throw std::runtime_error("replayed party produced a different proof");
+            // (planning builds: CGH_EMULATE_DEVICE times one device's share of a multi-device proof on uninitialised stand-ins — nothing to compare)
+            if (emulate_only_device() < 0 && memcmp(solo.data(), out_proofs, psz)) throw std::runtime_error("replayed party produced a different proof");
         }
         cleanup();
         return 0;

@@ -862,8 +862,7 @@ public:
         PendingMsm p = aux_tables ? msm_begin_multi({dz.a, dz.b1, dz.b2, dz.l}, {0, 0, 0, 0}, {CG_G1, CG_G1, CG_G2, CG_G1}, n, mine, true)   // table order = CoGroth16::prove's AUX_* indices
                                   : msm_begin_multi({dz.h}, {0}, {CG_G1}, n, mine, false);
         if (!md) return p;
-        static const bool primary_only = getenv("CGH_EMULATE_PRIMARY_ONLY") != nullptr;    // planning knob: time the primary device's share of an
-        if (primary_only) return p;                                                       // N-device proof on one GPU (the proof is then wrong)
+        if (emulate_only_device() >= 0) return p;                                         // planning builds only (base.hpp): the primary device's share alone
         for (const WorkerDevice& w : md->workers) {
             const DeviceZKey& wz = *w.dz;
             const size_t wlo = aux_tables ? wz.aux_lo : wz.h_lo, wn = aux_tables ? wz.aux_n : wz.h_n;

@@ -151,10 +151,10 @@ public:
             h_msm.on = driver.ctx; h_msm.groups = {CG_G1}; h_msm.tickets.resize(1); h_msm.k = hk;
             for (size_t d = 0; d < dh.parts.size(); d++) {                                             // :248, rows of device d against its slice of h_query
                 const DistributedH::Part& part = dh.parts[d];
-                if (d && dmap->primary_only) break;
+                if (d && dmap->skip(d)) continue;
                 const cg_bases* tab = dmap->devs[d].dz->h; const size_t off0 = 0;
                 const void* sc[2] = {part.h.c[0], part.h.c[1]};
-                if (d == 0) CG(cg_msm_dev_begin_multi(part.ctx, 1, &tab, &off0, part.h.n, sc, hk, h_msm.tickets.data()));
+                if (d == 0) CG(cg_msm_dev_begin_multi(part.ctx, 1, &tab, &off0, dmap->skip(0) ? 0 : part.h.n, sc, hk, h_msm.tickets.data()));
                 else {
                     HipDriver::PendingMsm::Part p{part.ctx, std::vector<int32_t>(1), {nullptr, nullptr}};
                     CG(cg_msm_dev_begin_multi(part.ctx, 1, &tab, &off0, part.h.n, sc, hk, p.tickets.data()));

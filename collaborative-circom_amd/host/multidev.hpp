@@ -43,12 +43,12 @@ public:
         std::vector<void*> owned;                                                  // device allocations to release at the end
     };
     std::vector<Dev> devs;
-    const bool primary_only;                   // CGH_EMULATE_PRIMARY_ONLY: time the primary device's share (results are then wrong)
+    const int only_dev;                        // planning builds only (emulate_only_device, base.hpp): the one device whose share runs; -1 = all (always, in the release library)
     std::vector<void*> pinned;                 // page-locked staging released at the end
 
     DistributedWitnessMap(HipDriver& d, const DeviceZKey& dz0, const MultiDevice& md)
         // (k comes from the MODE, not from d.k(): prove() builds the map while its one-component override for the additive variant's MSMs is live — ADVICE r5)
-        : drv(d), curve(d.curve), k(d.mode == Mode::Rep3 ? 2 : 1), additive(d.additive_h && d.mode == Mode::Rep3), kc(additive ? 1 : d.k()), primary_only(getenv("CGH_EMULATE_PRIMARY_ONLY") != nullptr) {
+        : drv(d), curve(d.curve), k(d.mode == Mode::Rep3 ? 2 : 1), additive(d.additive_h && d.mode == Mode::Rep3), kc(additive ? 1 : d.k()), only_dev(emulate_only_device()) {
         Dev p; p.ctx = d.ctx; p.msm = d.aux ? d.aux : d.ctx; p.dz = &dz0; p.lo = dz0.h_lo; p.n = dz0.h_n; devs.push_back(p);
         for (const WorkerDevice& w : md.workers) { Dev x; x.ctx = w.chain ? w.chain : w.ctx; x.msm = w.ctx; x.dz = w.dz; x.lo = w.dz->h_lo; x.n = w.dz->h_n; devs.push_back(x); }
     }
@@ -62,7 +62,7 @@ public:
         for (void* p : pinned) cg_host_free(p);
         for (void* p : host_tmp) free(p);
     }
-    bool skip(size_t d) const { return primary_only && d != 0; }
+    bool skip(size_t d) const { return only_dev >= 0 && d != (size_t)only_dev; }
     void* dalloc(Dev& d, size_t bytes) { void* p; CG(cg_dev_alloc(d.ctx, std::max<size_t>(bytes, 32), &p)); d.owned.push_back(p); return p; }
     void release(Dev& d, void* p) { for (auto it = d.owned.begin(); it != d.owned.end(); ++it) if (*it == p) { d.owned.erase(it); break; } }
     size_t owner(int v) const { return (size_t)(v + 1) % devs.size(); }            // vector v = 0 .. 3k-1 (a components, b components, c components)
@@ -74,7 +74,7 @@ public:
         const Fr* whole = nullptr; const Fr* s1 = nullptr; const Fr* s2 = nullptr;
         // generators described (cgh_rep3_chacha): the whole vector is drawn on the primary device — a row's stream position depends on the
         // rejections before it — and every device takes its rows over its link to the primary
-        if (drv.rsrc && m >= drv.DEVICE_MASKS_MIN && !primary_only) {
+        if (drv.rsrc && m >= drv.DEVICE_MASKS_MIN && only_dev < 0) {
             Dev& P = devs[0];
             void* all = dalloc(P, m * 32); void* tmp = dalloc(P, m * 32);
             if (drv.rsrc->masks_on_device(P.ctx, curve.id, m, all, tmp)) {
@@ -254,7 +254,7 @@ public:
             });
         }
         if (!drv.aux && devs[0].up_tk >= 0) CG(cg_copy_fence(drv.ctx, devs[0].up_tk));    // one context: its own stream carries the schedules
-        p = drv.msm_begin_multi({dz0.a, dz0.b1, dz0.b2, dz0.l}, {0, 0, 0, 0}, {CG_G1, CG_G1, CG_G2, CG_G1}, dz0.aux_n, aux_rows(0), true);
+        p = drv.msm_begin_multi({dz0.a, dz0.b1, dz0.b2, dz0.l}, {0, 0, 0, 0}, {CG_G1, CG_G1, CG_G2, CG_G1}, skip(0) ? 0 : dz0.aux_n, aux_rows(0), true);   // (a skipped device: empty MSMs = infinity)
         for (auto& x : th) x.join();
         for (const std::string& e : errs) if (!e.empty()) throw std::runtime_error(e);
         for (size_t d = 1; d < devs.size(); d++) if (!skip(d)) p.parts.push_back(parts[d]);

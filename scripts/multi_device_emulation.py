@@ -1,7 +1,12 @@
-"""Critical path of the PRIMARY device of an N-GPU proving session, timed on one GPU (no multi-GPU box here): the session is opened
-over N contexts on GPU 0 and CGH_EMULATE_PRIMARY_ONLY makes the further devices' MSM slices no-ops, so that the timed proof is what
-device 0 of N does — witness map, its table slices, folding — while the others would work beside it (their share is never larger).
-usage: CGH_EMULATE_PRIMARY_ONLY=1 python scripts/multi_device_emulation.py [log_m=22] [worlds=1,2,4,8] [additive]
+"""Critical path of EVERY device of an N-GPU proving session, timed on one GPU (no multi-GPU box here): the session is opened over N
+contexts on GPU 0 and, for d = 0 .. N-1 in turn, CGH_EMULATE_DEVICE=d makes every device but d a no-op — the timed proof is what device d of
+N does (its rows of the witness map, its vector pipeline if it owns one, its table slices; d = 0 also the host's folding and the exchange
+bookkeeping) while the others would work beside it.  Reported: every device's time and the MAX over devices (VERDICT r5 #4a; round 5
+reported the primary only).  What the emulation cannot show: waiting for ANOTHER device's pipeline (a device without one is timed as if the
+owners' transforms took no time), and xGMI — peer copies are local HBM copies here.
+Needs the planning build of the host library (the release library does not contain the knob):
+    make -C collaborative-circom_amd/host KNOBS=1
+    COGROTH16_HOST_LIB=collaborative-circom_amd/libcogroth16_host_knobs.so python scripts/multi_device_emulation.py [log_m=22] [worlds=1,2,4,8] [additive]
 (additive: sessions opened with CGH_SESSION_ADDITIVE_H, the opt-in protocol variant)"""
 import importlib, os, sys, tempfile, time
 import numpy as np, torch
@@ -11,7 +16,7 @@ import bench
 log_m = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 worlds = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,2,4,8").split(",")]
 additive = len(sys.argv) > 3 and sys.argv[3] == "additive"
-assert os.environ.get("CGH_EMULATE_PRIMARY_ONLY") or worlds == [1], "set CGH_EMULATE_PRIMARY_ONLY=1 (otherwise all slices run on the one GPU)"
+assert os.environ.get("COGROTH16_HOST_LIB") or worlds == [1], "set COGROTH16_HOST_LIB to the KNOBS=1 build (the release library ignores CGH_EMULATE_DEVICE: all slices would run on the one GPU)"
 dev = torch.device("cuda", 0); ctx = cg.Context(0)
 d = tempfile.mkdtemp(); zp, wp = os.path.join(d, "s.zkey"), os.path.join(d, "s.wtns")
 cg.host_synth_circuit(cg.BN254, log_m, 5, zp, wp)
@@ -29,9 +34,15 @@ del da, db, dc, dw
 tag = ", additive-quotient variant" if additive else ""
 for world in worlds:
     ses = cg.ProvingSession(cg.BN254, zp, precompute=True, devices=[0] * world, validate=False, additive_h=additive)
-    ses.prove_plain(w, r, s)
-    tp = min(ses.prove_plain(w, r, s)[1] for _ in range(3))
-    ses.prove_rep3(w[:2], [a, b, c], [c, a, b], streams, solo=False)
-    t1 = min(ses.prove_rep3(w[:2], [a, b, c], [c, a, b], streams)[2] for _ in range(2))
+    plain, party = [], []
+    for d in range(world):
+        if world > 1: os.environ["CGH_EMULATE_DEVICE"] = str(d)
+        ses.prove_plain(w, r, s)
+        plain.append(min(ses.prove_plain(w, r, s)[1] for _ in range(3)) * 1e3)
+        ses.prove_rep3(w[:2], [a, b, c], [c, a, b], streams, solo=False)
+        party.append(min(ses.prove_rep3(w[:2], [a, b, c], [c, a, b], streams)[2] for _ in range(3)) * 1e3)
+    os.environ.pop("CGH_EMULATE_DEVICE", None)
     ses.close()
-    print(f"2^{log_m}, {world} device(s), primary device only{tag}: plain {tp * 1e3:.1f} ms, one REP3 party alone {t1 * 1e3:.1f} ms", flush=True)
+    fmt = lambda v: " ".join(f"{x:.1f}" for x in v)
+    print(f"2^{log_m}, {world} device(s){tag}: plain max {max(plain):.1f} ms (device {int(np.argmax(plain))}; per device {fmt(plain)}), "
+          f"one REP3 party alone max {max(party):.1f} ms (device {int(np.argmax(party))}; per device {fmt(party)})", flush=True)

@@ -79,6 +79,17 @@ def test_environment_variables_are_documented():
         assert not missing, f"{header} does not document {missing}"
 
 
+def test_release_libraries_hold_no_knob_that_changes_results():
+    """CG_DEBUG_NO_REDUCE (skips the bucket reductions) and CGH_EMULATE_DEVICE / CGH_EMULATE_PRIMARY_ONLY (turn devices of a multi-device
+    proof into no-ops) exist only in -DCG_DEBUG_KNOBS builds: the shipped binaries do not even contain the names, so no
+    environment can make them return wrong results."""
+    ensure_built()
+    for path in (cg.LIB_PATH, os.path.join(os.path.dirname(cg.LIB_PATH), "libcogroth16_host.so")):
+        blob = open(path, "rb").read()
+        for name in (b"CG_DEBUG_NO_REDUCE", b"CGH_EMULATE_DEVICE", b"CGH_EMULATE_PRIMARY_ONLY"):
+            assert name not in blob, f"{os.path.basename(path)} contains {name.decode()}"
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     ensure_built()
