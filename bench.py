@@ -506,6 +506,10 @@ def compact_line(out, detail_path):
     if "speedup_vs_cpu_baseline" in out:
         sp = out["speedup_vs_cpu_baseline"]
         line["speedup_vs_cpu_baseline"] = {k: _r(v) for k, v in sp.items()} if isinstance(sp, dict) else _r(sp)
+    if isinstance(out.get("preflight"), dict):
+        pf = out["preflight"]; pairs = [p for p in pf.get("pairs", []) if not p.get("same_gpu")]
+        line["preflight"] = {"distinct_gpus": len({d["pci"] for d in pf.get("devices", [])}), "peer_pairs_checked": len(pairs),
+                             "min_pair_GBs": _r(min((p["GBs"] for p in pairs), default=None))}
     line["detail"] = detail_path
     text = json.dumps(line, separators=(",", ":"))
     for drop in ("second_curve", "sizes", "valu_roofline", "roofline_ntt", "roofline_g2", "speedup_vs_cpu_baseline"):     # never reached with today's legs; the limit is a contract
@@ -613,7 +617,7 @@ def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barri
         else:
             t0 = time.perf_counter(); cg.host_synth_circuit(curve, log_m, 0xC0C1C0DE, zp, wp, device=device.index); t_gen = time.perf_counter() - t0
         pre = int(os.environ["BENCH_PRECOMPUTE"]) if os.environ.get("BENCH_PRECOMPUTE") else True      # A/B knob (scripts/): window of the precomputed tables, 0 = none
-        t0 = time.perf_counter(); ses = cg.ProvingSession(curve, zp, precompute=pre, device=device.index, devices=devs); t_open = time.perf_counter() - t0
+        t0 = time.perf_counter(); ses = cg.ProvingSession(curve, zp, precompute=pre, device=device.index, devices=devs, shared_devices=len(set(devs)) < len(devs)); t_open = time.perf_counter() - t0
         zkey_bytes = os.path.getsize(zp)
         w = cg.host_read_wtns(curve, wp)
         info = cg.host_zkey_info(curve, zp)
@@ -1037,6 +1041,15 @@ def main():
         ranks_seen = int(ones.item())
         if ranks_seen != world:
             raise SystemExit(f"bench.py: all_reduce of ones over {world} ranks returned {ranks_seen}")
+    # N > 1, first contact with the node: N DISTINCT GPUs that reach each other over peer copies (cg_device_preflight: PCI bus ids, peer access,
+    # one checked 1 MiB copy per ordered pair), or no number is printed.  --shared-device (the one-GPU test mode) allows the repeats and says so.
+    preflight = None
+    if world > 1 and rank == 0:
+        devs = [0] * world if args.shared_device else list(range(world))
+        preflight = cg.device_preflight(devs, allow_shared=args.shared_device)
+        pairs = [p for p in preflight["pairs"] if not p["same_gpu"]]
+        print(f"bench.py preflight: {len(set(d['pci'] for d in preflight['devices']))} distinct GPU(s) for {world} rank(s), {len(pairs)} peer pairs checked"
+              + (f", slowest 1 MiB copy {min(p['GBs'] for p in pairs):.1f} GB/s" if pairs else " (shared-device test mode)"), file=sys.stderr)
     comm = Comm(dist, world, device)
 
     ctx = cg.Context(local_rank)
@@ -1206,6 +1219,8 @@ def main():
             "step_resident": step_resident,
             "setup_s": {"synthetic_bases": w.setup_bases_s, "precompute_tables": w.setup_precompute_s},
         }
+        if preflight is not None:
+            out["preflight"] = preflight
         if world > 1:
             step_resident["what"] += "; N > 1: one process per GPU, MSM work units planned over the ranks, witness map distributed for N >= 4, one all_gather of unit results + host EC fold"
             step_resident["plan"] = ",".join(f"{t}{i}/{p}->r{o}" for t, i, p, o in w.plan)

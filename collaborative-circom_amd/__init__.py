@@ -15,7 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(HERE, "libcogroth16_hip.so")
 HOST_LIB_PATH = os.path.join(HERE, "libcogroth16_host.so")
-# planning scripts only (scripts/multi_device_emulation.py): the -DCG_DEBUG_KNOBS build of the host library, `make -C host KNOBS=1`
+# planning / A-B scripts only: another build of a library (scripts/multi_device_emulation.py: the -DCG_DEBUG_KNOBS build of the host library,
+# `make -C host KNOBS=1`; scripts/ntt_timing.py: a hip library built with other -D switches)
+if os.environ.get("COGROTH16_HIP_LIB"):
+    LIB_PATH = os.path.abspath(os.environ["COGROTH16_HIP_LIB"])
 if os.environ.get("COGROTH16_HOST_LIB"):
     HOST_LIB_PATH = os.path.abspath(os.environ["COGROTH16_HOST_LIB"])
 
@@ -53,7 +56,7 @@ ABI_SYMBOLS = [
     "cg_point_add", "cg_point_neg", "cg_point_scalar_mul", "cg_fixed_base_create", "cg_fixed_base_mul", "cg_fixed_base_destroy", "cg_point_to_affine", "cg_point_from_affine", "cg_point_validate", "cg_fr_is_canonical", "cg_vec_check_canonical_dev", "cg_fr_op",
     "cg_fr_from_canonical", "cg_fr_to_canonical", "cg_fq_to_canonical", "cg_fq_from_canonical", "cg_point_generator",
     "cg_bases_synth_multiples", "cg_bases_download", "cg_bases_from_scalars",
-    "cg_dev_copy_peer", "cg_ctx_device", "cg_device_count",
+    "cg_dev_copy_peer", "cg_ctx_device", "cg_device_count", "cg_device_preflight",
     "cg_stats_enable", "cg_stats",
 ]
 
@@ -476,6 +479,19 @@ def session_devices(world):
     return [i % n for i in range(world)]
 
 
+PREFLIGHT_ALLOW_SHARED, PREFLIGHT_ALLOW_STAGED = 1, 2
+
+
+def device_preflight(devices, allow_shared=False, allow_staged=False):
+    """cg_device_preflight: raises BackendError unless `devices` are distinct GPUs with peer access whose pairwise 1 MiB copies arrive intact;
+    returns the report (bus ids, per-pair peer access and copy rate) as a dict"""
+    import json
+    devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+    buf = C.create_string_buffer(1 << 16)
+    _chk(load().cg_device_preflight(devs, len(devices), C.c_uint32((1 if allow_shared else 0) | (2 if allow_staged else 0)), buf, C.c_size_t(len(buf))))
+    return json.loads(buf.value.decode())
+
+
 def point_add(curve, group, a, b):
     out = np.zeros(point_words(curve, group, 3), dtype=np.uint64)
     _chk(load().cg_point_add(curve, group, _hp(np.ascontiguousarray(a)), _hp(np.ascontiguousarray(b)), _hp(out)))
@@ -639,15 +655,16 @@ def host_set_zkey_validation(on):
 class ProvingSession:
     """zkey read, uploaded and (optionally) given per-window precomputed tables once; proofs then cost what co-circom.rs:503-506 times"""
 
-    def __init__(self, curve, zkey_path, precompute=True, device=0, validate=True, devices=None, additive_h=False):
+    def __init__(self, curve, zkey_path, precompute=True, device=0, validate=True, devices=None, additive_h=False, shared_devices=False):
         """devices: several GPUs of one node for this party (cgh_session_open_multi): devices[0] runs the witness map and slice 0 of
         every MSM, devices[i] slice i.  additive_h: REP3 proofs run the additive-quotient variant (CGH_SESSION_ADDITIVE_H, opt-in: not the
-        reference's message sequence, same proof)"""
+        reference's message sequence, same proof).  shared_devices: the list may name one GPU several times (CGH_SESSION_SHARED_DEVICES:
+        one-GPU tests and planning runs) — without it a multi-device session opens only on DISTINCT GPUs that pass cg_device_preflight"""
         self.curve, self.info = curve, host_zkey_info(curve, zkey_path)
         h = C.c_void_p()
         devs = [int(device)] if devices is None else [int(d) for d in devices]
         arr = (C.c_int32 * len(devs))(*devs)
-        _hchk(load_host().cgh_session_open_multi(arr, len(devs), curve, zkey_path.encode(), -1 if precompute is True else int(precompute), C.c_uint32((0 if validate else 1) | (2 if additive_h else 0)), C.byref(h)))
+        _hchk(load_host().cgh_session_open_multi(arr, len(devs), curve, zkey_path.encode(), -1 if precompute is True else int(precompute), C.c_uint32((0 if validate else 1) | (2 if additive_h else 0) | (4 if shared_devices else 0)), C.byref(h)))
         self.h = h
 
     def close(self):

@@ -1750,6 +1750,70 @@ int32_t cg_dev_copy_peer(cg_ctx* dst, void* d_dst, cg_ctx* src, const void* d_sr
 }
 int32_t cg_ctx_device(const cg_ctx* ctx) { return ctx ? ctx->device : -1; }
 int32_t cg_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
+// First contact with a multi-GPU node (VERDICT r5 #4c): before a session spreads a party over `n` devices — and before a benchmark prints
+// a number for them — prove that they ARE n GPUs and that every pair moves data correctly: distinct PCI bus ids, peer access, and one 1 MiB
+// peer copy per ordered pair whose contents are compared word for word with the pattern the source was filled with (pattern = f(src, dst,
+// index), so a copy that silently came from the wrong device fails too).  `report` (optional) receives one JSON object: bus ids, peer
+// access and the copy rate of every pair.  flags: CG_PREFLIGHT_ALLOW_SHARED lets a device appear more than once (one-GPU tests: such
+// pairs are local copies and say so); CG_PREFLIGHT_ALLOW_STAGED accepts pairs without peer access (copies staged through the host).
+__global__ void k_preflight_fill(uint32_t* p, uint32_t n, uint32_t seed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (i * 2654435761u) ^ seed;
+}
+int32_t cg_device_preflight(const int32_t* devices, int32_t n, uint32_t flags, char* report, size_t report_cap) {
+    if (!devices || n < 1 || n > 64) return fail(CG_ERR_ARG, "cg_device_preflight: bad device list");
+    int have = 0; HIPCHK(hipGetDeviceCount(&have));
+    std::vector<std::string> bus((size_t)n);
+    for (int i = 0; i < n; i++) {
+        if (devices[i] < 0 || devices[i] >= have) return fail(CG_ERR_ARG, "cg_device_preflight: device " + std::to_string(devices[i]) + " does not exist (" + std::to_string(have) + " visible)");
+        char id[64] = {0}; HIPCHK(hipDeviceGetPCIBusId(id, sizeof id, devices[i])); bus[i] = id;
+    }
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++)
+        if ((devices[i] == devices[j] || bus[i] == bus[j]) && !(flags & CG_PREFLIGHT_ALLOW_SHARED))
+            return fail(CG_ERR_ARG, "cg_device_preflight: entries " + std::to_string(i) + " and " + std::to_string(j) + " of the device list are the SAME GPU (device " + std::to_string(devices[i]) + " / " +
+                                    std::to_string(devices[j]) + ", PCI " + bus[i] + "): a party's devices must be distinct");
+    const uint32_t words = 1u << 18;                                               // 1 MiB
+    struct Block { int dev; void* p = nullptr; ~Block() { if (p) { hipSetDevice(dev); hipFree(p); } } };
+    std::string js = "{\"devices\":[";
+    for (int i = 0; i < n; i++) js += std::string(i ? "," : "") + "{\"device\":" + std::to_string(devices[i]) + ",\"pci\":\"" + bus[i] + "\"}";
+    js += "],\"pairs\":[";
+    std::vector<uint32_t> back(words);
+    bool first = true;
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) {
+        if (i == j) continue;
+        const int sd = devices[i], dd = devices[j];
+        const bool local = sd == dd;
+        int can = 1;
+        if (!local) {
+            HIPCHK(hipDeviceCanAccessPeer(&can, dd, sd));
+            if (!can && !(flags & CG_PREFLIGHT_ALLOW_STAGED)) return fail(CG_ERR_HIP, "cg_device_preflight: device " + std::to_string(dd) + " has no peer access to device " + std::to_string(sd) + " (no xGMI / P2P path)");
+            if (can) { HIPCHK(hipSetDevice(dd)); hipError_t e = hipDeviceEnablePeerAccess(sd, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCHK(e); (void)hipGetLastError(); }
+        }
+        Block src{sd}, dst{dd};
+        const uint32_t seed = 0x9e3779b9u * (uint32_t)(i * 64 + j + 1);
+        HIPCHK(hipSetDevice(sd)); HIPCHK(hipMalloc(&src.p, words * 4));
+        hipLaunchKernelGGL(k_preflight_fill, dim3(words / 256), dim3(256), 0, 0, (uint32_t*)src.p, words, seed);
+        HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipSetDevice(dd)); HIPCHK(hipMalloc(&dst.p, words * 4)); HIPCHK(hipMemset(dst.p, 0, words * 4)); HIPCHK(hipDeviceSynchronize());
+        hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, 0));
+        if (local) HIPCHK(hipMemcpyAsync(dst.p, src.p, words * 4, hipMemcpyDeviceToDevice, 0));
+        else HIPCHK(hipMemcpyPeerAsync(dst.p, dd, src.p, sd, words * 4, 0));
+        HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); hipEventDestroy(e0); hipEventDestroy(e1);
+        HIPCHK(hipMemcpy(back.data(), dst.p, words * 4, hipMemcpyDeviceToHost));
+        uint64_t bad = 0, sum = 0;
+        for (uint32_t w = 0; w < words; w++) { bad += back[w] != ((w * 2654435761u) ^ seed); sum += back[w]; }
+        if (bad) return fail(CG_ERR_HIP, "cg_device_preflight: the 1 MiB copy from device " + std::to_string(sd) + " to device " + std::to_string(dd) + " arrived with " + std::to_string(bad) + " wrong words");
+        char line[256];
+        snprintf(line, sizeof line, "%s{\"src\":%d,\"dst\":%d,\"peer_access\":%s,\"same_gpu\":%s,\"copy_us\":%.1f,\"GBs\":%.2f,\"checksum\":%llu}", first ? "" : ",", sd, dd, can ? "true" : "false",
+                 local ? "true" : "false", ms * 1e3, words * 4 / (ms * 1e-3) / 1e9, (unsigned long long)sum);
+        js += line; first = false;
+    }
+    js += "]}";
+    if (report && report_cap) { strncpy(report, js.c_str(), report_cap - 1); report[report_cap - 1] = 0; }
+    return 0;
+}
 int32_t cg_dev_memset_zero(cg_ctx* ctx, void* d_dst, size_t bytes) {
     if (!ctx) return fail(CG_ERR_ARG, "null ctx");
     HIPCHK(hipMemsetAsync(d_dst, 0, bytes, ctx->stream));

@@ -103,6 +103,58 @@ struct L29 {
         }
         return upper_half(T);
     }
+    // The same product by COLUMNS (product scanning, one running accumulator): column k takes its a_i b_(k-i) and m_i p_(k-i) terms, gives
+    // m_k (lower half) or limb k - NL (upper half), and moves on with ONE 64-bit shift — the row form above pays shift + 64-bit add per
+    // reduction round and mask + shift + 64-bit add per result limb (34 more vector instructions per product).  Same value, same bounds
+    // (a column holds the same <= 2 NL products + carry).  The multiply-adds of a column form a dependency chain: used where a lane has
+    // two or more independent products in flight (the NTT butterflies).
+    __device__ __forceinline__ static L29 mul_cols(const L29& a, const L29& b) {
+        // (the empty asm statements pin the ORDER of the additions: left alone, the compiler sums a column's products first and adds the shifted
+        // carry last — one more 64-bit addition per column, which is exactly what this form is there to save)
+#define CG_CHAIN(x) asm("" : "+v"(x))
+        int32_t m[NL]; L29 r; int64_t T = 0;
+        _Pragma("unroll") for (int k = 0; k < NL; k++) {
+            _Pragma("unroll") for (int i = 0; i <= k; i++) { T += (int64_t)a.l[i] * b.l[k - i]; CG_CHAIN(T); }
+            _Pragma("unroll") for (int i = 0; i < k; i++) { T += (int64_t)m[i] * pl(k - i); CG_CHAIN(T); }
+            m[k] = (int32_t)(((uint32_t)T * (P::INV & MASK)) & MASK);
+            T += (int64_t)m[k] * pl(0);
+            T >>= W;                                     // exact: the column sum is a multiple of 2^W
+            CG_CHAIN(T);
+        }
+        _Pragma("unroll") for (int k = NL; k < 2 * NL - 1; k++) {
+            _Pragma("unroll") for (int i = k - NL + 1; i < NL; i++) { T += (int64_t)a.l[i] * b.l[k - i]; CG_CHAIN(T); }
+            _Pragma("unroll") for (int i = k - NL + 1; i < NL; i++) { T += (int64_t)m[i] * pl(k - i); CG_CHAIN(T); }
+            r.l[k - NL] = (int32_t)((uint32_t)T & MASK);
+            T >>= W;
+            CG_CHAIN(T);
+        }
+#undef CG_CHAIN
+        r.l[NL - 1] = (int32_t)T;
+        return r;
+    }
+    // two independent products by columns, their chains interleaved statement by statement (a dependent v_mad_u64_u32 pair costs a wait state:
+    // the second chain fills it)
+    __device__ __forceinline__ static void mul2_cols(const L29& a, const L29& b, const L29& c, const L29& d, L29& ab, L29& cd) {
+#define CG_CHAIN(x) asm("" : "+v"(x))
+        int32_t m[NL], n[NL]; int64_t T = 0, U = 0;
+        _Pragma("unroll") for (int k = 0; k < NL; k++) {
+            _Pragma("unroll") for (int i = 0; i <= k; i++) { T += (int64_t)a.l[i] * b.l[k - i]; CG_CHAIN(T); U += (int64_t)c.l[i] * d.l[k - i]; CG_CHAIN(U); }
+            _Pragma("unroll") for (int i = 0; i < k; i++) { T += (int64_t)m[i] * pl(k - i); CG_CHAIN(T); U += (int64_t)n[i] * pl(k - i); CG_CHAIN(U); }
+            m[k] = (int32_t)(((uint32_t)T * (P::INV & MASK)) & MASK); n[k] = (int32_t)(((uint32_t)U * (P::INV & MASK)) & MASK);
+            T += (int64_t)m[k] * pl(0); U += (int64_t)n[k] * pl(0);
+            T >>= W; U >>= W;
+            CG_CHAIN(T); CG_CHAIN(U);
+        }
+        _Pragma("unroll") for (int k = NL; k < 2 * NL - 1; k++) {
+            _Pragma("unroll") for (int i = k - NL + 1; i < NL; i++) { T += (int64_t)a.l[i] * b.l[k - i]; CG_CHAIN(T); U += (int64_t)c.l[i] * d.l[k - i]; CG_CHAIN(U); }
+            _Pragma("unroll") for (int i = k - NL + 1; i < NL; i++) { T += (int64_t)m[i] * pl(k - i); CG_CHAIN(T); U += (int64_t)n[i] * pl(k - i); CG_CHAIN(U); }
+            ab.l[k - NL] = (int32_t)((uint32_t)T & MASK); cd.l[k - NL] = (int32_t)((uint32_t)U & MASK);
+            T >>= W; U >>= W;
+            CG_CHAIN(T); CG_CHAIN(U);
+        }
+#undef CG_CHAIN
+        ab.l[NL - 1] = (int32_t)T; cd.l[NL - 1] = (int32_t)U;
+    }
     // cheap necessary condition for x = 0 (mod p) on an UNNORMALISED value: carries only travel upwards, so the lowest W bits of
     // limb 0 already are the normalised limb 0 and must equal limb 0 of one of the candidates k*p (a non-zero residue passes with
     // probability ~10 / 2^W).  Lets the hot loop skip the carry propagation it would otherwise do only for this test.

@@ -22,6 +22,17 @@ constexpr int NTT_TILE_LOG = 11;                       // 2048 elements x 32 B =
 constexpr int NTT_THREADS = 256;
 constexpr int NTT_TILE_LOG_LAZY = 10;                  // lazy passes: 1024 elements x 36 B = 36 KiB, four workgroups per CU
 constexpr int BITREV_B_LAZY = 5;
+// Product form of the butterflies (lazy29.hpp).  Default: by COLUMNS, the two independent products of a radix-4 step interleaved
+// (-34 vector instructions per product against the row form; round 6).  -DNTT_FORM_ROWS restores the row form of rounds 2-5 for A/B runs.
+#ifdef NTT_FORM_ROWS
+#define NTT_MUL mul
+#define NTT_MUL2(a, wa, b, wb, ra, rb) do { ra = L::mul(a, wa); rb = L::mul(b, wb); } while (0)
+#define NTT_KEEP(x) (x).norm()
+#else
+#define NTT_MUL mul_cols
+#define NTT_MUL2(a, wa, b, wb, ra, rb) L::mul2_cols(a, wa, b, wb, ra, rb)
+#define NTT_KEEP(x) (x)
+#endif
 
 __host__ __device__ inline size_t tw_stage_offset(size_t m, int s) { return m - (m >> s); }
 
@@ -181,11 +192,11 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_ct_pass(NttVecs src_vecs, N
             L a0 = lazy29_load<L>(pl0, pl1, pl2, i00), a1 = lazy29_load<L>(pl0, pl1, pl2, i00 + d1);
             const L a2 = lazy29_load<L>(pl0, pl1, pl2, i00 + d0), a3 = lazy29_load<L>(pl0, pl1, pl2, i00 + d0 + d1);
             const L w = lazy29_load<L>(tw.p0, tw.p1, tw.p2, blk);
-            const L v2 = L::mul(a2, w), v3 = L::mul(a3, w);
-            const L b0 = a0 + v2, b2 = (a0 - v2).norm();            // b0 is only added to below: its limbs may stay unnormalised
+            L v2, v3; NTT_MUL2(a2, w, a3, w, v2, v3);
+            const L b0 = a0 + v2, b2 = NTT_KEEP(a0 - v2);                   // only added to below: their limbs stay unnormalised (|limb| < 2^30, < 2^31 after stage q + 1)
             const L b1 = (a1 + v3).norm(), b3 = (a1 - v3).norm();
             const L w0 = lazy29_load<L>(tw.p0, tw.p1, tw.p2, 2 * blk), w1 = lazy29_load<L>(tw.p0, tw.p1, tw.p2, 2 * blk + 1);
-            const L y1 = L::mul(b1, w0), y3 = L::mul(b3, w1);
+            L y1, y3; NTT_MUL2(b1, w0, b3, w1, y1, y3);
             lazy29_store<L>(pl0, pl1, pl2, i00, (b0 + y1).norm());
             lazy29_store<L>(pl0, pl1, pl2, i00 + d1, (b0 - y1).norm());
             lazy29_store<L>(pl0, pl1, pl2, i00 + d0, (b2 + y3).norm());
@@ -204,7 +215,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_ct_pass(NttVecs src_vecs, N
             const size_t blk = (hi << q) | (size_t)(mid0 >> (k - q));       // index of the butterfly's block at stage s0 + q
             const L a = lazy29_load<L>(pl0, pl1, pl2, i0), b = lazy29_load<L>(pl0, pl1, pl2, i1);
             const L w = lazy29_load<L>(tw.p0, tw.p1, tw.p2, blk);
-            const L v = L::mul(b, w);
+            const L v = L::NTT_MUL(b, w);
             lazy29_store<L>(pl0, pl1, pl2, i0, (a + v).norm());
             lazy29_store<L>(pl0, pl1, pl2, i1, (a - v).norm());
         }
@@ -262,7 +273,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_dit_pass(NttVecs out_vecs, 
         if constexpr (FIRST) {
             const size_t i = (size_t)(__brevll((unsigned long long)g) >> (64 - log_m));
             const F c = ld_fp(cos_lo + (i & (((size_t)1 << log_lo) - 1))) * ld_fp(cos_hi + (i >> log_lo));
-            v = L::mul(v, L::template unpack<0>(c));
+            v = L::NTT_MUL(v, L::template unpack<0>(c));
         }
         lazy29_store<L>(pl0, pl1, pl2, idx, v);
     }
@@ -280,11 +291,11 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_dit_pass(NttVecs out_vecs, 
             const L a00 = lazy29_load<L>(pl0, pl1, pl2, i00), a01 = lazy29_load<L>(pl0, pl1, pl2, i00 + d);
             const L a10 = lazy29_load<L>(pl0, pl1, pl2, i00 + 2 * d), a11 = lazy29_load<L>(pl0, pl1, pl2, i00 + 3 * d);
             const L w0 = lazy29_load<L>(tw.p0, tw.p1, tw.p2, e0);
-            const L v1 = L::mul(a01, w0), v3 = L::mul(a11, w0);
+            L v1, v3; NTT_MUL2(a01, w0, a11, w0, v1, v3);
             const L b00 = a00 + v1, b01 = a00 - v1;                  // only added to below: no carry normalisation
             const L b10 = (a10 + v3).norm(), b11 = (a10 - v3).norm();
             const L w1a = lazy29_load<L>(tw.p0, tw.p1, tw.p2, e1), w1b = lazy29_load<L>(tw.p0, tw.p1, tw.p2, e1 + (m >> 2));
-            const L y2 = L::mul(b10, w1a), y3 = L::mul(b11, w1b);
+            L y2, y3; NTT_MUL2(b10, w1a, b11, w1b, y2, y3);
             lazy29_store<L>(pl0, pl1, pl2, i00, (b00 + y2).norm());
             lazy29_store<L>(pl0, pl1, pl2, i00 + 2 * d, (b00 - y2).norm());
             lazy29_store<L>(pl0, pl1, pl2, i00 + d, (b01 + y3).norm());
@@ -301,7 +312,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_dit_pass(NttVecs out_vecs, 
             const int i0 = (mid0 << t) | lo_local, i1 = i0 + (1 << (q + t));
             const size_t j = ((size_t)(mid0 & ((1 << q) - 1)) << lo_bits) + lo0 + lo_local;
             const L a = lazy29_load<L>(pl0, pl1, pl2, i0), b = lazy29_load<L>(pl0, pl1, pl2, i1);
-            const L v = L::mul(b, lazy29_load<L>(tw.p0, tw.p1, tw.p2, j << (log_m - 1 - s)));
+            const L v = L::NTT_MUL(b, lazy29_load<L>(tw.p0, tw.p1, tw.p2, j << (log_m - 1 - s)));
             lazy29_store<L>(pl0, pl1, pl2, i0, (a + v).norm());
             lazy29_store<L>(pl0, pl1, pl2, i1, (a - v).norm());
         }
@@ -310,7 +321,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_dit_pass(NttVecs out_vecs, 
     for (int idx = threadIdx.x; idx < E; idx += NTT_THREADS) {
         const size_t g = base + ((size_t)(idx >> t) << lo_bits) + (idx & tmask);
         const L v = lazy29_load<L>(pl0, pl1, pl2, idx);
-        if constexpr (LAST) st_fp(reinterpret_cast<F*>(out_vecs.p[blockIdx.y]) + g, L::pack_reduced(L::mul(v, L::template unpack<0>(c32))));
+        if constexpr (LAST) st_fp(reinterpret_cast<F*>(out_vecs.p[blockIdx.y]) + g, L::pack_reduced(L::NTT_MUL(v, L::template unpack<0>(c32))));
         else lazy29_store<L>(buf.p0, buf.p1, buf.p2, g, v);
     }
 }
@@ -343,7 +354,7 @@ __global__ void __launch_bounds__(256) k_bitrev_finish_lazy(NttVecs dst, NttVecs
         const size_t o = ((size_t)rl << (log_m - B)) | (rmid << B) | (size_t)rh;
         const L v = lazy29_load<L>(tile0, tile1, tile2, (size_t)(h * (S + 1) + l));
         const F c = cos_lo ? ld_fp(cos_lo + (o & (((size_t)1 << log_lo) - 1))) * ld_fp(cos_hi + (o >> log_lo)) : ld_fp(scale);
-        st_fp(out + o, L::pack_reduced(L::mul(v, L::template unpack<0>(c))));
+        st_fp(out + o, L::pack_reduced(L::NTT_MUL(v, L::template unpack<0>(c))));
     }
 }
 template <class F>
@@ -357,7 +368,7 @@ __global__ void __launch_bounds__(256) k_bitrev_finish_lazy_small(NttVecs dst, N
         const size_t o = log_m ? (__brevll((unsigned long long)i) >> (64 - log_m)) : 0;
         const L v = lazy29_load<L>(in.p0, in.p1, in.p2, i);
         const F c = cos_lo ? ld_fp(cos_lo + (o & (((size_t)1 << log_lo) - 1))) * ld_fp(cos_hi + (o >> log_lo)) : ld_fp(scale);
-        st_fp(out + o, L::pack_reduced(L::mul(v, L::template unpack<0>(c))));
+        st_fp(out + o, L::pack_reduced(L::NTT_MUL(v, L::template unpack<0>(c))));
     }
 }
 

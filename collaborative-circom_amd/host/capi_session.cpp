@@ -110,7 +110,8 @@ void session_destroy(cgh_session* s) {
 }
 // Several GPUs of one node for one party: devices[0] runs the witness map and slice 0 of every MSM, devices[i]
 // slice i (table slices registered, validated and given their window tables on their own device); partial sums are folded on the
-// host.  The prove calls below work on either kind of session.  The same device may be listed more than once (tests).
+// host.  The prove calls below work on either kind of session.  The same device may be listed more than once only with
+// CGH_SESSION_SHARED_DEVICES (tests, planning runs).
 int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t curve, const char* zkey_path, int32_t precompute, uint32_t flags, void** out) {
     cgh_session* s = nullptr;
     try {
@@ -118,6 +119,8 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
         if (!devices || n_dev < 1 || n_dev > 64) throw std::runtime_error("cgh_session_open_multi: bad device list");
         s = new cgh_session(); s->device = devices[0];
         s->devices.assign(devices, devices + n_dev); s->ctx0.assign(n_dev, nullptr); s->dzs.resize(n_dev); s->idle.resize(n_dev); s->idle_chain.resize(n_dev);
+        // first contact with the node: the list names n DISTINCT GPUs that reach each other, or the session does not open (cg_device_preflight)
+        if (n_dev > 1) CG(cg_device_preflight(devices, n_dev, (flags & CGH_SESSION_SHARED_DEVICES) ? CG_PREFLIGHT_ALLOW_SHARED : 0u, nullptr, 0));
         s->z = read_zkey(curve, zkey_path);
         std::vector<Fr> pub(s->z.n_public + 1);
         for (int d = 0; d < n_dev; d++) {

@@ -85,6 +85,15 @@ int32_t cg_dev_memset_zero(cg_ctx* ctx, void* d_dst, size_t bytes);
 int32_t cg_dev_copy_peer(cg_ctx* dst, void* d_dst, cg_ctx* src, const void* d_src, size_t bytes);
 int32_t cg_ctx_device(const cg_ctx* ctx);
 int32_t cg_device_count(void);
+/* Preflight of a party's device list (first contact with a multi-GPU node): distinct PCI bus ids, peer access between every pair, and one
+ * 1 MiB peer copy per ordered pair checked word for word against the pattern its source was filled with.  Fails loudly (CG_ERR_ARG for a
+ * repeated GPU, CG_ERR_HIP for a missing peer path or a corrupted copy; cg_last_error says which pair).  `report` (optional, NUL-terminated,
+ * truncated to report_cap): one JSON object with the bus ids and every pair's peer access, copy time and rate.  Flags: ALLOW_SHARED lets a
+ * device appear more than once (one-GPU tests; such pairs are local copies), ALLOW_STAGED accepts pairs without peer access.
+ * cgh_session_open_multi runs it for n > 1 (include/cogroth16_host.h), bench.py --gpus N before it prints anything. */
+#define CG_PREFLIGHT_ALLOW_SHARED 1u
+#define CG_PREFLIGHT_ALLOW_STAGED 2u
+int32_t cg_device_preflight(const int32_t* devices, int32_t n, uint32_t flags, char* report, size_t report_cap);
 /* Page-locked staging buffers and asynchronous copies on the context's two copy streams, so that the MPC exchanges of mul_vec
  * (rep3.rs:650-670) and degree_reduce_vec (shamir.rs:302-384) can move in chunks under the compute.
  *   download_begin: the copy is ordered after everything enqueued on the context's stream so far.

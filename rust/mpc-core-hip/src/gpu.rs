@@ -64,6 +64,8 @@ pub struct Gpu {
     by_start: HashMap<usize, usize>,
     /// window of `cg_bases_precompute` for tables registered from here on (0 = none, -1 = by table size)
     pub precompute: i32,
+    /// constraint matrices kept on the device (`Gpu::matrix`)
+    matrices: Vec<DeviceMatrix>,
 }
 // a context is used by one thread at a time; moving the driver to another thread between calls is fine (no thread-local HIP state)
 unsafe impl Send for Gpu {}
@@ -75,7 +77,7 @@ impl Gpu {
         if rc != 0 {
             eyre::bail!("cg_ctx_create({device}): {}", last_error());
         }
-        Ok(Self { ctx, tables: Vec::new(), by_start: HashMap::new(), precompute: 0 })
+        Ok(Self { ctx, tables: Vec::new(), by_start: HashMap::new(), precompute: 0, matrices: Vec::new() })
     }
 
     /// Registers a whole zkey query (`ZKey::a_query` … `h_query`, circom-types/src/groth16/zkey.rs:48-71) once.  The vectors live for the
@@ -224,8 +226,124 @@ impl Gpu {
     }
 }
 
+// ---- device-resident helpers of the trait-level drivers (round 6: the per-call drivers are not host-bound any more) ---------------------------
+/// A device block that is given back (parked for reuse, cg_dev_free) when it goes out of scope.
+struct DevBuf {
+    ctx: *mut cg_ctx,
+    p: *mut c_void,
+}
+impl DevBuf {
+    fn new(ctx: *mut cg_ctx, bytes: usize) -> Self {
+        let mut p = ptr::null_mut();
+        check(unsafe { cg_dev_alloc(ctx, bytes.max(32), &mut p) }, "cg_dev_alloc");
+        Self { ctx, p }
+    }
+    fn from_slice<T>(ctx: *mut cg_ctx, v: &[T]) -> Self {
+        let b = Self::new(ctx, std::mem::size_of_val(v));
+        if !v.is_empty() {
+            check(unsafe { cg_dev_upload(ctx, b.p, v.as_ptr() as *const c_void, std::mem::size_of_val(v)) }, "cg_dev_upload");
+        }
+        b
+    }
+}
+impl Drop for DevBuf {
+    fn drop(&mut self) {
+        unsafe { cg_dev_free(self.ctx, self.p) };
+    }
+}
+
+/// A constraint matrix resident on the device in CSR form (`ConstraintMatrices::a` / `::b` are `Vec<Vec<(F, usize)>>`, one inner vector per
+/// constraint): flattened and uploaded ONCE per zkey, then every proof evaluates all of its rows in one `cg_spmv_csr_dev` launch
+/// instead of `num_constraints` calls of `evaluate_constraint` on the host (groth16.rs:159-166).
+pub struct DeviceMatrix {
+    row_ptr: DevBuf,
+    col: DevBuf,
+    coeff: DevBuf,
+    rows: usize,
+    /// address and length of the host matrix this copy was made from (the cache key of `Gpu::matrix`)
+    host: (usize, usize),
+}
+
+impl Gpu {
+    /// The resident copy of `rows` (made on first use; the zkey's matrices live, unchanged, as long as the zkey does).
+    pub fn matrix<F: PrimeField>(&mut self, rows: &[Vec<(F, usize)>]) -> usize {
+        let key = (rows.as_ptr() as usize, rows.len());
+        if let Some(i) = self.matrices.iter().position(|m| m.host == key) {
+            return i;
+        }
+        let nnz: usize = rows.iter().map(Vec::len).sum();
+        assert!(nnz < u32::MAX as usize, "constraint matrix with 2^32 or more entries");
+        let (mut row_ptr, mut col, mut coeff) = (Vec::with_capacity(rows.len() + 1), Vec::with_capacity(nnz), Vec::with_capacity(nnz));
+        row_ptr.push(0u32);
+        for r in rows {
+            for (c, i) in r {
+                coeff.push(*c);
+                col.push(u32::try_from(*i).expect("signal index above 2^32"));
+            }
+            row_ptr.push(col.len() as u32);
+        }
+        let m = DeviceMatrix { row_ptr: DevBuf::from_slice(self.ctx, &row_ptr), col: DevBuf::from_slice(self.ctx, &col), coeff: DevBuf::from_slice(self.ctx, &coeff), rows: rows.len(), host: key };
+        self.matrices.push(m);
+        self.matrices.len() - 1
+    }
+
+    /// `evaluate_constraint` for EVERY row of a resident matrix (traits.rs:180 / rep3.rs:690-708 with the add_with_public asymmetry of
+    /// rep3.rs:600-608): `party` = -1 for one share component (plain, Shamir: `wit_b` empty), 0..2 = the REP3 party id.  Returns the two
+    /// component vectors, `domain_size` long (rows past the matrix stay zero, as `vec![FieldShare::default(); domain_size]` leaves them).
+    pub fn evaluate_constraints<F: PrimeField>(&mut self, matrix: usize, domain_size: usize, public_inputs: &[F], party: i32, wit_a: &[F], wit_b: &[F]) -> (Vec<F>, Vec<F>) {
+        let m = &self.matrices[matrix];
+        assert!(m.rows <= domain_size && (party < 0 || wit_b.len() == wit_a.len()));
+        let bytes = domain_size * size_of::<F>();
+        let (d_pub, d_a, d_b) = (DevBuf::from_slice(self.ctx, public_inputs), DevBuf::from_slice(self.ctx, wit_a), DevBuf::from_slice(self.ctx, wit_b));
+        let (o_a, o_b) = (DevBuf::new(self.ctx, bytes), DevBuf::new(self.ctx, bytes));
+        let two = party >= 0;
+        check(unsafe { cg_dev_memset_zero(self.ctx, o_a.p, bytes) }, "cg_dev_memset_zero");
+        if two {
+            check(unsafe { cg_dev_memset_zero(self.ctx, o_b.p, bytes) }, "cg_dev_memset_zero");
+        }
+        check(
+            unsafe {
+                cg_spmv_csr_dev(self.ctx, curve_id::<F>(), m.row_ptr.p as *const u32, m.col.p as *const u32, m.coeff.p, m.rows, d_pub.p, public_inputs.len() as u32, party,
+                                d_a.p, if two { d_b.p as *const c_void } else { ptr::null() }, o_a.p, if two { o_b.p } else { ptr::null_mut() })
+            },
+            "cg_spmv_csr_dev",
+        );
+        let mut out_a = vec![F::zero(); domain_size];
+        let mut out_b = vec![F::zero(); if two { domain_size } else { 0 }];
+        check(unsafe { cg_dev_download(self.ctx, out_a.as_mut_ptr() as *mut c_void, o_a.p, bytes) }, "cg_dev_download");
+        if two {
+            check(unsafe { cg_dev_download(self.ctx, out_b.as_mut_ptr() as *mut c_void, o_b.p, bytes) }, "cg_dev_download");
+        }
+        (out_a, out_b)
+    }
+
+    /// The local part of REP3 `mul_vec` (rep3.rs:656-660) with the masks DRAWN ON THE DEVICE: n x `F::rand` from each of the party's two
+    /// ChaCha12 generators, described by seed and 32-bit word position (`ChaCha12Rng::get_seed` / `get_word_pos`), mask_i = r1_i - r2_i
+    /// (rngs.rs:37-40) — the draws the stock implementation makes one by one on a host thread (~70 ns each: 0.6 s per proof at 2^22).
+    /// Returns the masked local products and the positions both generators have to be set to (`set_word_pos`) so that the next host draw
+    /// is the one the stock implementation would make.
+    #[allow(clippy::too_many_arguments)]
+    pub fn rep3_mul_local_drawn<F: PrimeField>(&mut self, aa: &[F], ab: &[F], ba: &[F], bb: &[F], seed1: &[u8; 32], pos1: u64, seed2: &[u8; 32], pos2: u64) -> (Vec<F>, u64, u64) {
+        let n = aa.len();
+        assert!(ab.len() == n && ba.len() == n && bb.len() == n);
+        let bytes = n * size_of::<F>();
+        let curve = curve_id::<F>();
+        let (d_aa, d_ab, d_ba, d_bb) = (DevBuf::from_slice(self.ctx, aa), DevBuf::from_slice(self.ctx, ab), DevBuf::from_slice(self.ctx, ba), DevBuf::from_slice(self.ctx, bb));
+        let (r1, r2) = (DevBuf::new(self.ctx, bytes), DevBuf::new(self.ctx, bytes));
+        let (mut after1, mut after2) = (0u64, 0u64);
+        check(unsafe { cg_chacha12_fr_rand_dev(self.ctx, curve, seed1.as_ptr(), pos1, n, r1.p, &mut after1) }, "cg_chacha12_fr_rand_dev");
+        check(unsafe { cg_chacha12_fr_rand_dev(self.ctx, curve, seed2.as_ptr(), pos2, n, r2.p, &mut after2) }, "cg_chacha12_fr_rand_dev");
+        check(unsafe { cg_vec_sub_dev(self.ctx, curve, r1.p, r1.p, r2.p, n) }, "cg_vec_sub_dev");
+        check(unsafe { cg_vec_rep3_mul_local_dev(self.ctx, curve, r2.p, d_aa.p, d_ab.p, d_ba.p, d_bb.p, r1.p, n) }, "cg_vec_rep3_mul_local_dev");
+        let mut out = vec![F::zero(); n];
+        check(unsafe { cg_dev_download(self.ctx, out.as_mut_ptr() as *mut c_void, r2.p, bytes) }, "cg_dev_download");
+        (out, after1, after2)
+    }
+}
+
 impl Drop for Gpu {
     fn drop(&mut self) {
+        self.matrices.clear(); // (their blocks go back through the context that is destroyed below)
         unsafe {
             for t in &self.tables {
                 if !t.bases.is_null() {

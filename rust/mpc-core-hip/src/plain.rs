@@ -49,6 +49,11 @@ impl<F: PrimeField> PrimeFieldMpcProtocol<F> for PlainHipDriver<F> {
     fn promote_to_trivial_shares(&self, public_values: &[F]) -> Vec<F> { self.inner.promote_to_trivial_shares(public_values) }
     fn distribute_powers_and_mul_by_const(&mut self, coeffs: &mut Vec<F>, g: F, c: F) { self.inner.distribute_powers_and_mul_by_const(coeffs, g, c) }
     fn evaluate_constraint(&mut self, lhs: &[(F, usize)], public_inputs: &[F], private_witness: &Vec<F>) -> F { self.inner.evaluate_constraint(lhs, public_inputs, private_witness) }
+    /// all rows of one (device-resident) constraint matrix in one launch: overrides the row-by-row default (rust/co-groth16-evaluate-constraints.patch)
+    fn evaluate_constraints(&mut self, matrix: &[Vec<(F, usize)>], domain_size: usize, public_inputs: &[F], private_witness: &Vec<F>) -> Vec<F> {
+        let m = self.gpu.matrix(matrix);
+        self.gpu.evaluate_constraints(m, domain_size, public_inputs, -1, private_witness, &[]).0
+    }
     fn clone_from_slice(&self, dst: &mut Vec<F>, src: &Vec<F>, dst_offset: usize, src_offset: usize, len: usize) { self.inner.clone_from_slice(dst, src, dst_offset, src_offset, len) }
     fn mul_open(&mut self, a: &F, b: &F) -> IoResult<F> { self.inner.mul_open(a, b) }
     fn mul_open_many(&mut self, a: &[F], b: &[F]) -> IoResult<Vec<F>> { self.inner.mul_open_many(a, b) }

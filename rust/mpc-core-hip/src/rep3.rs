@@ -11,6 +11,10 @@ use mpc_core::{
 };
 use std::io::Result as IoResult;
 
+/// `mul_vec` calls of at least this many elements draw their masks on the GPU (a host draw is ~70 ns per element, a device call ~60 us:
+/// the C++ mirror's threshold, host/driver.hpp DEVICE_MASKS_MIN)
+pub const DEVICE_MASKS_MIN: usize = 1 << 11;
+
 pub struct Rep3HipProtocol<F: PrimeField, N: Rep3Network> {
     inner: Rep3Protocol<F, N>,
     gpu: Gpu,
@@ -55,15 +59,27 @@ impl<F: PrimeField, N: Rep3Network> PrimeFieldMpcProtocol<F> for Rep3HipProtocol
     fn open_many(&mut self, a: &[Self::FieldShare]) -> IoResult<Vec<F>> { self.inner.open_many(a) }
     fn add_vec(&mut self, a: &Self::FieldShareVec, b: &Self::FieldShareVec) -> Self::FieldShareVec { self.inner.add_vec(a, b) }
 
-    /// rep3.rs:650-670.  Same values, same messages: the masks are drawn from the party's own streams in the reference's order (one
-    /// `masking_field_element` per element), only the three products per element run on the GPU.
+    /// rep3.rs:650-670.  Same values, same messages.  From `DEVICE_MASKS_MIN` elements on the masks are drawn ON THE GPU from the party's
+    /// own two ChaCha12 generators — read by seed and word position, both set behind the draws afterwards (`rand_stream_state` /
+    /// `set_rand_stream_positions`, rust/mpc-core-accessors.patch), so the next draw of the stock implementation is the one it would
+    /// have made — instead of n `masking_field_element` calls on this thread (~70 ns each: 0.6 s per proof at 2^22, more than the GPU
+    /// needs for the whole proof).  Below the threshold the masks are drawn on the host in the reference's order, as before.
     fn mul_vec(&mut self, a: &Self::FieldShareVec, b: &Self::FieldShareVec) -> IoResult<Self::FieldShareVec> {
         debug_assert_eq!(a.get_len(), b.get_len());
         let n = a.get_len();
-        let mask: Vec<F> = self.inner.masking_field_elements(n);
         let (aa, ab) = a.clone().get_ab();
         let (ba, bb) = b.clone().get_ab();
-        let local_a = self.gpu.rep3_mul_local(&aa, &ab, &ba, &bb, &mask);
+        let local_a = if n >= DEVICE_MASKS_MIN {
+            let (seed1, pos1, seed2, pos2) = self.inner.rand_stream_state();
+            // (a ChaCha12Rng stream is 2^68 words long; the device addresses the first 2^64 of them — 2^59 draws)
+            let (pos1, pos2) = (u64::try_from(pos1).expect("stream position above 2^64"), u64::try_from(pos2).expect("stream position above 2^64"));
+            let (local_a, after1, after2) = self.gpu.rep3_mul_local_drawn(&aa, &ab, &ba, &bb, &seed1, pos1, &seed2, pos2);
+            self.inner.set_rand_stream_positions(after1 as u128, after2 as u128);
+            local_a
+        } else {
+            let mask: Vec<F> = self.inner.masking_field_elements(n);
+            self.gpu.rep3_mul_local(&aa, &ab, &ba, &bb, &mask)
+        };
         self.inner.network_mut().send_next_many(&local_a)?;
         let local_b: Vec<F> = self.inner.network_mut().recv_prev_many()?;
         if local_b.len() != local_a.len() {
@@ -78,11 +94,19 @@ impl<F: PrimeField, N: Rep3Network> PrimeFieldMpcProtocol<F> for Rep3HipProtocol
     /// `ifft_in_place; distribute_powers_and_mul_by_const(g, 1); fft_in_place` is better served by `ifft_coset_in_place` below
     /// (one kernel less, no host pass); called on its own it stays on the host.
     fn distribute_powers_and_mul_by_const(&mut self, coeffs: &mut Self::FieldShareVec, g: F, c: F) { self.inner.distribute_powers_and_mul_by_const(coeffs, g, c) }
-    /// one row of the constraint matrices.  The prover calls it once per constraint (groth16.rs:159-166); the whole loop is one
-    /// `cg_spmv_csr_dev` launch in the host mirror — a shim that wants it keeps the matrices resident and overrides the LOOP (see
-    /// `evaluate_constraints` in README.md), the per-row method keeps the reference's semantics.
+    /// one row of the constraint matrices, on the host with the reference's semantics.  The prover's loop over all rows
+    /// (groth16.rs:159-166) goes through `evaluate_constraints` below instead (rust/co-groth16-evaluate-constraints.patch).
     fn evaluate_constraint(&mut self, lhs: &[(F, usize)], public_inputs: &[F], private_witness: &Self::FieldShareVec) -> Self::FieldShare {
         self.inner.evaluate_constraint(lhs, public_inputs, private_witness)
+    }
+    /// ALL rows of one constraint matrix in one launch (the matrix is flattened to CSR and kept on the device at its first use):
+    /// overrides the default body the patch gives the trait method (the row-by-row loop).
+    fn evaluate_constraints(&mut self, matrix: &[Vec<(F, usize)>], domain_size: usize, public_inputs: &[F], private_witness: &Self::FieldShareVec) -> Self::FieldShareVec {
+        let (wit_a, wit_b) = private_witness.clone().get_ab();
+        let id = self.inner.network_mut().get_id() as usize as i32;      // PartyID::ID0..ID2 (rep3/id.rs): who adds the public inputs (rep3.rs:600-608)
+        let m = self.gpu.matrix(matrix);
+        let (a, b) = self.gpu.evaluate_constraints(m, domain_size, public_inputs, id, &wit_a, &wit_b);
+        Rep3PrimeFieldShareVec::new(a, b)
     }
     fn clone_from_slice(&self, dst: &mut Self::FieldShareVec, src: &Self::FieldShareVec, dst_offset: usize, src_offset: usize, len: usize) {
         self.inner.clone_from_slice(dst, src, dst_offset, src_offset, len)

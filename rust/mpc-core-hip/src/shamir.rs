@@ -49,6 +49,13 @@ impl<F: PrimeField, N: ShamirNetwork> PrimeFieldMpcProtocol<F> for ShamirHipProt
     fn promote_to_trivial_shares(&self, public_values: &[F]) -> Self::FieldShareVec { self.inner.promote_to_trivial_shares(public_values) }
     fn distribute_powers_and_mul_by_const(&mut self, coeffs: &mut Self::FieldShareVec, g: F, c: F) { self.inner.distribute_powers_and_mul_by_const(coeffs, g, c) }
     fn evaluate_constraint(&mut self, lhs: &[(F, usize)], public_inputs: &[F], private_witness: &Self::FieldShareVec) -> Self::FieldShare { self.inner.evaluate_constraint(lhs, public_inputs, private_witness) }
+    /// all rows of one (device-resident) constraint matrix in one launch (shamir.rs:645-663: every party adds the public inputs, one share
+    /// component): overrides the row-by-row default (rust/co-groth16-evaluate-constraints.patch)
+    fn evaluate_constraints(&mut self, matrix: &[Vec<(F, usize)>], domain_size: usize, public_inputs: &[F], private_witness: &Self::FieldShareVec) -> Self::FieldShareVec {
+        let wit = private_witness.clone().get_inner();
+        let m = self.gpu.matrix(matrix);
+        ShamirPrimeFieldShareVec::new(self.gpu.evaluate_constraints(m, domain_size, public_inputs, -1, &wit, &[]).0)
+    }
     fn clone_from_slice(&self, dst: &mut Self::FieldShareVec, src: &Self::FieldShareVec, dst_offset: usize, src_offset: usize, len: usize) { self.inner.clone_from_slice(dst, src, dst_offset, src_offset, len) }
     fn mul_open(&mut self, a: &Self::FieldShare, b: &Self::FieldShare) -> IoResult<F> { self.inner.mul_open(a, b) }
     fn mul_open_many(&mut self, a: &[Self::FieldShare], b: &[Self::FieldShare]) -> IoResult<Vec<F>> { self.inner.mul_open_many(a, b) }

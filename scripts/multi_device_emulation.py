@@ -33,7 +33,7 @@ streams = [pin(host(bench.rand_fr(2 * m + 4, dev, g))) for _ in range(3)]
 del da, db, dc, dw
 tag = ", additive-quotient variant" if additive else ""
 for world in worlds:
-    ses = cg.ProvingSession(cg.BN254, zp, precompute=True, devices=[0] * world, validate=False, additive_h=additive)
+    ses = cg.ProvingSession(cg.BN254, zp, precompute=True, devices=[0] * world, shared_devices=True, validate=False, additive_h=additive)
     plain, party = [], []
     for d in range(world):
         if world > 1: os.environ["CGH_EMULATE_DEVICE"] = str(d)

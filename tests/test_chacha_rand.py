@@ -215,7 +215,7 @@ def test_parties_with_device_drawn_masks_give_the_oracle_proof(curve, log_m, tmp
     streams = [orc.chacha12_fr_rand(curve, s, 0, 2 * z.domain_size + 4)[0] for s in seeds]
     want = z.prove_rep3(w[:2], wa, wb, streams, threads=threads)
     sessions = {"one": cg.ProvingSession(curve, zp, precompute=False)}
-    if curve == BN254: sessions["three contexts as devices"] = cg.ProvingSession(curve, zp, precompute=False, devices=[0, 0, 0])   # host/multidev.hpp: drawn on the primary, rows peer-copied
+    if curve == BN254: sessions["three contexts as devices"] = cg.ProvingSession(curve, zp, precompute=False, devices=[0, 0, 0], shared_devices=True)   # host/multidev.hpp: drawn on the primary, rows peer-copied
     try:
         results = {}
         for on_device, ses in ((True, sessions["one"]), (False, sessions["one"])) + (((None, sessions["three contexts as devices"]),) if len(sessions) > 1 else ()):

@@ -341,3 +341,30 @@ print("child ok")
 '''
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **knobs), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_device_preflight_accepts_one_gpu_and_refuses_a_repeated_one(tmp_path):
+    """cg_device_preflight (VERDICT r5 #4c): the first contact of a multi-device session / `bench.py --gpus N` with a node.  On one GPU: a
+    single device passes; the same GPU listed twice is refused with both entries and the PCI bus id named, and passes only under the
+    explicit shared-device flag (then as a checked LOCAL copy); a device that does not exist is refused; a session over a repeated GPU does
+    not open without CGH_SESSION_SHARED_DEVICES."""
+    cg = ensure_built()
+    rep = cg.device_preflight([0])
+    assert len(rep["devices"]) == 1 and rep["devices"][0]["pci"] and rep["pairs"] == []
+    with pytest.raises(cg.BackendError) as e:
+        cg.device_preflight([0, 0])
+    assert "SAME GPU" in str(e.value) and rep["devices"][0]["pci"] in str(e.value)
+    with pytest.raises(cg.BackendError):
+        cg.device_preflight([0, cg.device_count() + 3])
+    rep = cg.device_preflight([0, 0, 0], allow_shared=True)
+    assert len(rep["pairs"]) == 6 and all(p["same_gpu"] and p["GBs"] > 0 and p["checksum"] > 0 for p in rep["pairs"])
+    if cg.device_count() > 1:                                                  # a node: the real thing
+        rep = cg.device_preflight(list(range(cg.device_count())))
+        assert all(p["peer_access"] and not p["same_gpu"] for p in rep["pairs"])
+    zp, wp = str(tmp_path / "s.zkey"), str(tmp_path / "s.wtns")
+    cg.host_synth_circuit(cg.BN254, 8, 3, zp, wp)
+    with pytest.raises(cg.BackendError) as e:
+        cg.ProvingSession(cg.BN254, zp, precompute=False, devices=[0, 0])
+    assert "SAME GPU" in str(e.value)
+    cg.ProvingSession(cg.BN254, zp, precompute=False, devices=[0, 0], shared_devices=True).close()

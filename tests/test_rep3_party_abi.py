@@ -504,7 +504,7 @@ def test_additive_quotient_variant_at_2_16(tmp_path):
     streams = [orc.random_field(curve, FR, 2 * z.domain_size + 4, rng) for _ in range(3)]
     want = z.prove_rep3(w[:2], wa, wb, streams, threads=threads)
     for devices in (None, [0, 0]):
-        ses = cg.ProvingSession(curve, zp, precompute=True, additive_h=True, devices=devices)
+        ses = cg.ProvingSession(curve, zp, precompute=True, additive_h=True, devices=devices, shared_devices=True)
         hub = cg.LoopbackHub()
         rands = [cg.StreamRand(curve, streams[i], streams[(i + 2) % 3]) for i in range(3)]
         try:
