@@ -42,13 +42,16 @@ def build(bls=True, jobs=8):
 
 # per-context tuning options (include/cogroth16_hip.h)
 OPT_MSM_CHUNK, OPT_MSM_WINDOW, OPT_MSM_SCATTER_CAP, OPT_MSM_TABLE_ORDER, OPT_MSM_G2_SLICES, OPT_MSM_REDUCE_BATCH, OPT_MSM_ACC_SLOTS, OPT_MSM_G2_AFTER, OPT_MSM_WIDE_SMALL = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_MSM_ONE_STREAM_LOG, OPT_MSM_OFF_MAIN_LOG, OPT_MSM_SOLO_LOG = 10, 11, 12
+# process-wide options (cg_set_option)
+GOPT_SUBGROUP_FULL, GOPT_COMPACT_MIN_LOG, GOPT_SORT_STAGING, GOPT_SORT_SMALL, GOPT_MSM_STAGED_OUT = 1, 2, 3, 4, 5
 
 # every symbol include/cogroth16_hip.h declares (checked by tests/test_abi_surface.py)
 ABI_SYMBOLS = [
     "cg_ctx_create", "cg_ctx_create_ex", "cg_ctx_destroy", "cg_ctx_sync", "cg_ctx_stream", "cg_ctx_set_stream", "cg_last_error", "cg_version",
     "cg_dev_alloc", "cg_dev_free", "cg_dev_free_many", "cg_dev_cache_trim", "cg_stream_group_begin", "cg_stream_group_end", "cg_dev_upload", "cg_dev_download", "cg_dev_memset_zero",
     "cg_bases_register", "cg_bases_register_device", "cg_bases_release", "cg_bases_len", "cg_bases_precompute", "cg_bases_check_on_curve", "cg_bases_check_subgroup",
-    "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_chunk", "cg_ctx_set_option", "cg_ctx_get_option", "cg_msm_scalars_after", "cg_msm_set_scatter_capacity",
+    "cg_msm", "cg_msm_dev", "cg_msm_dev_begin", "cg_msm_dev_begin_multi", "cg_msm_end", "cg_msm_set_window", "cg_msm_set_chunk", "cg_ctx_set_option", "cg_ctx_get_option", "cg_set_option", "cg_get_option", "cg_msm_scalars_after", "cg_msm_set_scatter_capacity",
     "cg_ntt", "cg_ntt_dev", "cg_ntt_coset_pair_dev", "cg_chacha12_fr_rand_dev", "cg_chacha12_fr_rand_dev_begin", "cg_chacha12_fr_rand_dev_finish",
     "cg_host_alloc", "cg_host_free", "cg_host_is_pinned", "cg_dev_download_begin", "cg_dev_upload_begin", "cg_stream_mark", "cg_dev_download_begin_after", "cg_copy_wait", "cg_copy_fence",
     "cg_vec_add_dev", "cg_vec_sub_dev", "cg_vec_mul_dev", "cg_vec_rep3_mul_local_dev", "cg_vec_distribute_powers_dev", "cg_vec_affine_dev", "cg_vec_fill_dev", "cg_vec_gather_strided_dev", "cg_vec_lincomb_dev", "cg_vec_prefix_prod_dev", "cg_vec_prefix_sum_dev", "cg_vec_inverse_dev",
@@ -479,6 +482,17 @@ def session_devices(world):
     return [i % n for i in range(world)]
 
 
+def set_option(option, value):
+    """process-wide option of the hip library (cg_set_option)"""
+    _chk(load().cg_set_option(int(option), C.c_int64(int(value))))
+
+
+def get_option(option):
+    v = C.c_int64(0)
+    _chk(load().cg_get_option(int(option), C.byref(v)))
+    return v.value
+
+
 PREFLIGHT_ALLOW_SHARED, PREFLIGHT_ALLOW_STAGED = 1, 2
 
 
@@ -650,6 +664,37 @@ def host_set_zkey_validation(on):
     """the prove entry points and session_open validate every zkey point on the GPU by default (the reference's parser does);
     callers that validated the file before can switch it off"""
     _hchk(load_host().cgh_set_zkey_validation(int(bool(on))))
+
+
+# process-wide options of the host library (include/cogroth16_host.h: cgh_set_option)
+HOST_OPT_XCHG_ASYNC_MIN, HOST_OPT_DEVICE_MASKS_MIN, HOST_OPT_XCHG_COPY_STREAM_MIN, HOST_OPT_SECOND_CONTEXT_MIN_LOG, HOST_OPT_DISTRIBUTED_MAP, HOST_OPT_ONE_CONTEXT, HOST_OPT_SPLIT_FIRST_MSM_MIN = 1, 2, 3, 4, 5, 6, 7
+
+
+def host_set_option(option, value):
+    _hchk(load_host().cgh_set_option(int(option), C.c_int64(int(value))))
+
+
+def host_get_option(option):
+    v = C.c_int64(0)
+    _hchk(load_host().cgh_get_option(int(option), C.byref(v)))
+    return v.value
+
+
+class host_options:
+    """with cg.host_options({cg.HOST_OPT_XCHG_ASYNC_MIN: 4096}): ... — set for the block, restored afterwards (tests)"""
+
+    def __init__(self, values):
+        self.values, self.saved = dict(values), {}
+
+    def __enter__(self):
+        for k, v in self.values.items():
+            self.saved[k] = host_get_option(k); host_set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            host_set_option(k, v)
+        return False
 
 
 class ProvingSession:

@@ -140,6 +140,7 @@ struct cg_ctx {
     // priority class of each stream: +1 high, 0 normal, -1 low (pooled_stream)
     int prio_main = 0, prio_side = 1, prio_copy = 0;
     uint32_t msm_chunk = 0;                               // cg_msm_set_chunk / CG_OPT_MSM_CHUNK
+    int solo_log = 18;                                    // CG_OPT_MSM_SOLO_LOG: `solo` calls (msm_begin_multi_impl_) of at most 2^this entries
     int off_main_log = 22;                                // CG_MSM_OFF_MAIN_LOG: wide calls of at most 2^this entries keep their accumulations OFF the main stream (0 = never), see msm_begin_multi_impl_
     int one_stream_log = 0;                               // CG_MSM_ONE_STREAM_LOG: calls of at most 2^this entries run on the main stream alone (0 = never, the default: measured slower)
     int table_order = 0, g2_after = -1, g2_slices = 0, red_batch = 2, acc_slots = 4, wide_small = 22;   // CG_OPT_MSM_TABLE_ORDER / _G2_SLICES / _REDUCE_BATCH / _ACC_SLOTS (cg_ctx_set_option)
@@ -485,7 +486,7 @@ int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, con
         // `solo`: such a call is a closed sequence on ONE stream — it takes its scratch from a block of its own (ordered by that stream alone) and
         // leaves the context's cross-stream bookkeeping (slot / schedule events of the shared arena) untouched: it neither waits for the
         // reductions of the call before, which still read the shared arena, nor hides them from the call after
-        const bool solo = wide && small_call && single_field && ctx->off_main_log > 0 && (uint64_t)nwin * n <= ((uint64_t)1 << ctx->off_main_log);
+        const bool solo = wide && small_call && single_field && ctx->solo_log > 0 && (uint64_t)nwin * n <= ((uint64_t)1 << ctx->solo_log);
         const bool one_stream = solo || (small_call && ctx->one_stream_log > 0 && (uint64_t)nwin * n <= ((uint64_t)1 << ctx->one_stream_log));
         const hipStream_t sortst = one_stream ? ctx->stream : ctx->sortst, auxst = one_stream ? ctx->stream : ctx->aux;
         { int rc = solo ? ensure_main_stream_block(ctx, ctx->solo_arena, nsched * sort_bytes + (size_t)acc_slots * acc_slot) : ensure_arena(ctx, nsched * sort_bytes + (size_t)acc_slots * acc_slot); if (rc) return rc; }
@@ -948,7 +949,7 @@ int ntt_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_t n, const 
     if (k < 1 || k > NTT_MAX_VECS) return fail(CG_ERR_ARG, "k out of range");
     if (n == 1) return 0;
     const Fr w = inverse ? fp_inverse(gen) : gen;
-    static const bool legacy = getenv("CG_NTT_DIF") != nullptr;                 // A/B knob: the canonical DIF passes
+    static const bool legacy = tune_env("CG_NTT_DIF") != nullptr;                 // A/B knob: the canonical DIF passes
     if (!legacy) {
         // lazy Cooley-Tukey passes (ntt_kernels.hpp): packed vectors -> limb-form scratch -> ... -> permutation back into the vectors,
         // which multiplies by 32 * (1/m) * coset power (32: the lazy core divides by 2^261, the ABI's R is 2^256)
@@ -960,7 +961,7 @@ int ntt_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_t n, const 
         for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->ntt_arena.base + arena_off + (size_t)j * lazy29_bytes(n); }
         hipStream_t st = ctx->stream;
         bool first = true;
-        static const int lazy_tile = [] { const char* e = getenv("CG_NTT_TILE"); const int v = e ? atoi(e) : NTT_TILE_LOG_LAZY; return std::min(NTT_TILE_LOG, std::max(8, v)); }();   // tuning knob
+        static const int lazy_tile = [] { const char* e = tune_env("CG_NTT_TILE"); const int v = e ? atoi(e) : NTT_TILE_LOG_LAZY; return std::min(NTT_TILE_LOG, std::max(8, v)); }();   // tuning knob
         for (const NttPass& p : ntt_plan(log_m, lazy_tile)) { rc = launch_ntt_ct_pass<Fr>(st, first, first ? data : tmp, tmp, k, n, log_m, p.s0, p.k, p.t, twl); if (rc) return rc; first = false; }
         Fr scale32 = Fr::one(); for (int i = 0; i < 5; i++) scale32 = scale32 + scale32;
         if (inverse) {
@@ -1019,7 +1020,7 @@ int ntt_coset_pair_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_
     NttVecs data{}, tmp{};
     for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->ntt_arena.base + arena_off + (size_t)j * lazy29_bytes(n); }
     hipStream_t st = ctx->stream;
-    static const int lazy_tile = [] { const char* e_ = getenv("CG_NTT_TILE"); const int v = e_ ? atoi(e_) : NTT_TILE_LOG_LAZY; return std::min(NTT_TILE_LOG, std::max(8, v)); }();
+    static const int lazy_tile = [] { const char* e_ = tune_env("CG_NTT_TILE"); const int v = e_ ? atoi(e_) : NTT_TILE_LOG_LAZY; return std::min(NTT_TILE_LOG, std::max(8, v)); }();
     const std::vector<NttPass> plan = ntt_plan(log_m, lazy_tile);
     bool first = true;
     for (const NttPass& p : plan) { rc = launch_ntt_ct_pass<Fr>(st, first, first ? data : tmp, tmp, k, n, log_m, p.s0, p.k, p.t, tw_inv); if (rc) return rc; first = false; }
@@ -1110,7 +1111,7 @@ template <> struct FastSubgroupFactory<Bls381Fq> { static FastSubgroup<Bls381Fq>
 #endif
 // nullptr (and the [r]P path) when the group has no fast test, when CG_SUBGROUP_FULL is set, or when the constants could not be made
 template <class F> const FastSubgroup<F>* fast_subgroup() {
-    if (!FastSubgroup<F>::available || getenv("CG_SUBGROUP_FULL")) return nullptr;
+    if (!FastSubgroup<F>::available || global_option(CG_GOPT_SUBGROUP_FULL)) return nullptr;
     static const std::pair<bool, FastSubgroup<F>> made = [] {
         try { return std::make_pair(true, FastSubgroupFactory<F>::make()); } catch (const std::exception&) { return std::make_pair(false, FastSubgroup<F>()); }
     }();
@@ -1273,7 +1274,7 @@ int coupled_reference(const hipStream_t* refs, hipStream_t st) {
     return found;
 }
 int measured_pipe(int device, int cls, hipStream_t st) {
-    static const bool off = getenv("CG_NO_PIPE_MAP") != nullptr || getenv("CG_NO_STREAM_PROBE") != nullptr;
+    static const bool off = tune_env("CG_NO_PIPE_MAP") != nullptr || tune_env("CG_NO_STREAM_PROBE") != nullptr;
     if (off || cls < -1 || cls > 1) return -1;
     std::lock_guard<std::mutex> l(g_pipe_mu);
     PipeRefs& r = g_pipe_refs[device];
@@ -1306,7 +1307,7 @@ int measured_pipe(int device, int cls, hipStream_t st) {
 // make `moving` not share a queue with any of `fixed` (same priority class): streams that do are parked again and others tried
 thread_local std::vector<hipStream_t> g_group_busy[3];                        // [class + 1]: streams of the contexts made so far in this thread's stream group
 int separate_stream(int device, int cls, hipStream_t* moving, std::vector<hipStream_t> fixed) {
-    static const bool off = getenv("CG_NO_STREAM_PROBE") != nullptr;            // A/B knob
+    static const bool off = tune_env("CG_NO_STREAM_PROBE") != nullptr;            // A/B knob
     if (off) return 0;
     std::vector<hipStream_t> rejected;
     for (int tries = 0; tries < 6; tries++) {
@@ -1349,13 +1350,13 @@ int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
     }
     cg_ctx* c = new cg_ctx();
     c->device = device;
-    {   // A/B runs: environment variables seed the option table of new contexts (include/cogroth16_hip.h, cg_ctx_set_option)
-        auto seed = [](const char* name, int lo, int hi, int& field) { if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= lo && v <= hi) field = v; } };
+    {   // planning builds (-DCG_DEBUG_KNOBS) only: environment variables seed the option table of new contexts (cg_ctx_set_option is the release interface)
+        auto seed = [](const char* name, int lo, int hi, int& field) { if (const char* e = tune_env(name)) { const int v = atoi(e); if (v >= lo && v <= hi) field = v; } };
         seed("CG_MSM_TABLE_ORDER", 0, 2, c->table_order); seed("CG_MSM_G2_AFTER", -1, 64, c->g2_after); seed("CG_MSM_G2_SLICES", 0, 1, c->g2_slices);
-        seed("CG_MSM_REDUCE_BATCH", 0, 3, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots); seed("CG_MSM_WIDE_SMALL", 0, 30, c->wide_small); seed("CG_MSM_ONE_STREAM_LOG", 0, 30, c->one_stream_log); seed("CG_MSM_OFF_MAIN_LOG", 0, 30, c->off_main_log);
+        seed("CG_MSM_REDUCE_BATCH", 0, 3, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots); seed("CG_MSM_WIDE_SMALL", 0, 30, c->wide_small); seed("CG_MSM_ONE_STREAM_LOG", 0, 30, c->one_stream_log); seed("CG_MSM_OFF_MAIN_LOG", 0, 30, c->off_main_log); seed("CG_MSM_SOLO_LOG", 0, 30, c->solo_log);
     }
     if (flags & 1u) { c->prio_main = 1; c->prio_copy = 1; c->prio_side = 0; }
-    else if (flags & 2u) { static const int bulk_cls = getenv("CG_BULK_CLASS") ? atoi(getenv("CG_BULK_CLASS")) : -1; c->prio_main = bulk_cls; c->prio_side = 0; }   // CG_BULK_CLASS: tuning knob
+    else if (flags & 2u) { static const int bulk_cls = tune_env("CG_BULK_CLASS") ? atoi(tune_env("CG_BULK_CLASS")) : -1; c->prio_main = bulk_cls; c->prio_side = 0; }   // CG_BULK_CLASS: tuning knob
     // Inside a stream group (one party's contexts) every stream is asked for on a PIPE: the chain's main stream alone on one (the streams it shares it
     // with is idle while it works: its own sort stream), the bulk context's main, sort and reduction streams on the three others — the reduction stream
     // NOT on the pipe of the main stream, whose accumulations it runs beside at large sizes (one REP3 party, reduction stream on the main stream's pipe /
@@ -1844,8 +1845,8 @@ static int32_t bases_register_impl(cg_ctx* ctx, int32_t curve, int32_t group, co
             }
             HIPCHK(hipStreamSynchronize(ctx->stream));
         }
-        static const bool no_compact = getenv("CG_NO_COMPACT") != nullptr;          // measurement knob
-        if (n >= 64 && n < ((size_t)1 << 32) && !no_compact) {   // infinity census on the packed table (registration-time work, like parsing)
+        const int64_t compact_min_log = global_option(CG_GOPT_COMPACT_MIN_LOG);      // cg_set_option; 64 = never
+        if (n >= 64 && n < ((size_t)1 << 32) && compact_min_log < 64) {   // infinity census on the packed table (registration-time work, like parsing)
             std::vector<uint8_t> host;
             const uint64_t* w = nullptr;
             if (!src_on_device && stride == pt && inf_off < 0) w = reinterpret_cast<const uint64_t*>(src);     // packed host table: scan it where it lies
@@ -1855,10 +1856,9 @@ static int32_t bases_register_impl(cg_ctx* ctx, int32_t curve, int32_t group, co
             for (size_t i = 0; i < n; i++) { uint64_t any = 0; for (size_t q = 0; q < words; q++) any |= w[i * words + q]; if (any) live.push_back((uint32_t)i); }
             b->no_inf = live.size() == n;
             // (small tables keep their records: a compacted copy gives the tables of one MSM call different scalar sets, i.e. a schedule and an
-            // accumulate / reduce sequence of their own — at a few thousand points that sequence costs 0.5 ms and saves nothing.  CG_COMPACT_MIN,
+            // accumulate / reduce sequence of their own — at a few thousand points that sequence costs 0.5 ms and saves nothing.  CG_GOPT_COMPACT_MIN_LOG,
             // read per call: log2 of the smallest table that gets one)
-            const char* cmin_s = getenv("CG_COMPACT_MIN");
-            const size_t compact_min = (size_t)1 << std::min(31, std::max(6, cmin_s ? atoi(cmin_s) : 14));
+            const size_t compact_min = (size_t)1 << std::min<int64_t>(31, std::max<int64_t>(6, compact_min_log));
             if (live.size() * 8 <= n * 7 && n >= compact_min) {
                 cg_bases* cb = new cg_bases{ctx->device, curve, group, live.size(), pt, nullptr};
                 cb->no_inf = true;
@@ -2057,6 +2057,9 @@ int32_t cg_ctx_set_option(cg_ctx* ctx, int32_t option, int64_t value) {
         case CG_OPT_MSM_REDUCE_BATCH: if (value < 0 || value > 3) break; ctx->red_batch = (int)value; return 0;
         case CG_OPT_MSM_ACC_SLOTS: if (value < 2 || value > cg_ctx::ACC_SLOTS_MAX) break; ctx->acc_slots = (int)value; return 0;
         case CG_OPT_MSM_WIDE_SMALL: if (value < 0 || value > 30 || (value > 1 && value < 10)) break; ctx->wide_small = (int)value; return 0;
+        case CG_OPT_MSM_ONE_STREAM_LOG: if (value < 0 || value > 30) break; ctx->one_stream_log = (int)value; return 0;
+        case CG_OPT_MSM_OFF_MAIN_LOG: if (value < 0 || value > 30) break; ctx->off_main_log = (int)value; return 0;
+        case CG_OPT_MSM_SOLO_LOG: if (value < 0 || value > 30) break; ctx->solo_log = (int)value; return 0;
         default: return fail(CG_ERR_ARG, "cg_ctx_set_option: unknown option");
     }
     return fail(CG_ERR_ARG, "cg_ctx_set_option: value out of range");
@@ -2073,8 +2076,20 @@ int32_t cg_ctx_get_option(const cg_ctx* ctx, int32_t option, int64_t* value) {
         case CG_OPT_MSM_REDUCE_BATCH: *value = ctx->red_batch; return 0;
         case CG_OPT_MSM_ACC_SLOTS: *value = ctx->acc_slots; return 0;
         case CG_OPT_MSM_WIDE_SMALL: *value = ctx->wide_small; return 0;
+        case CG_OPT_MSM_ONE_STREAM_LOG: *value = ctx->one_stream_log; return 0;
+        case CG_OPT_MSM_OFF_MAIN_LOG: *value = ctx->off_main_log; return 0;
+        case CG_OPT_MSM_SOLO_LOG: *value = ctx->solo_log; return 0;
         default: return fail(CG_ERR_ARG, "cg_ctx_get_option: unknown option");
     }
+}
+int32_t cg_set_option(int32_t option, int64_t value) {
+    if (option < 1 || option >= CG_GOPT_COUNT) return fail(CG_ERR_ARG, "cg_set_option: unknown option");
+    if (value < 0 || (option != CG_GOPT_COMPACT_MIN_LOG && value > 1) || value > 64) return fail(CG_ERR_ARG, "cg_set_option: value out of range");
+    g_options.v[option].store(value); return 0;
+}
+int32_t cg_get_option(int32_t option, int64_t* value) {
+    if (option < 1 || option >= CG_GOPT_COUNT || !value) return fail(CG_ERR_ARG, "cg_get_option: unknown option");
+    *value = g_options.v[option].load(); return 0;
 }
 int32_t cg_msm_set_window(cg_ctx* ctx, int32_t c) {
     if (!ctx) return fail(CG_ERR_ARG, "null ctx");
@@ -2139,7 +2154,7 @@ int32_t cg_ntt_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, int32_t k, s
 int32_t cg_ntt_coset_pair_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, int32_t k, size_t n, const void* h_group_gen, const void* h_coset_gen) {
     if (!ctx || !d_vecs || !h_group_gen || !h_coset_gen) return fail(CG_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
-    static const bool two_calls = getenv("CG_NTT_NO_PAIR") != nullptr;         // A/B knob: the two separate transforms
+    static const bool two_calls = tune_env("CG_NTT_NO_PAIR") != nullptr;         // A/B knob: the two separate transforms
     if (two_calls) { int rc = cg_ntt_dev(ctx, curve, d_vecs, k, n, h_group_gen, 1, h_coset_gen); return rc ? rc : cg_ntt_dev(ctx, curve, d_vecs, k, n, h_group_gen, 0, nullptr); }
     return with_fr(curve, [&](auto tag) -> int {
         typedef decltype(tag) Fr;

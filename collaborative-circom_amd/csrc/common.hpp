@@ -22,6 +22,26 @@ inline int fail(int code, const std::string& msg) { g_err = msg; return code; }
                                                 std::string(#expr) + ": " + hipGetErrorString(e_));            \
     } while (0)
 
+// A/B knobs of the measurement scripts: environment variables in -DCG_DEBUG_KNOBS builds (make KNOBS=1 -> libcogroth16_hip_knobs.so), compiled
+// out of the release library — every call site then folds to its default.  What a deployment or a test may want to move is an OPTION:
+// per context (cg_ctx_set_option) or process-wide (cg_set_option, the table below).  Neither kind changes a result.
+inline const char* tune_env(const char* name) {
+#ifdef CG_DEBUG_KNOBS
+    return getenv(name);
+#else
+    (void)name; return nullptr;
+#endif
+}
+struct GlobalOptions {
+    std::atomic<int64_t> v[CG_GOPT_COUNT];
+    GlobalOptions() {
+        for (auto& x : v) x.store(0);
+        v[CG_GOPT_COMPACT_MIN_LOG].store(14); v[CG_GOPT_SORT_STAGING].store(1); v[CG_GOPT_SORT_SMALL].store(1);
+    }
+};
+inline GlobalOptions g_options;
+inline int64_t global_option(int id) { return g_options.v[id].load(std::memory_order_relaxed); }
+
 constexpr int GRID_CAP = 2048;   // grid-stride kernels: 256 CUs x 8 workgroups
 inline int grid_for(size_t n, int block = 256) { size_t g = (n + block - 1) / block; return (int)std::min<size_t>(std::max<size_t>(g, 1), GRID_CAP); }
 // Launch attributes (the dynamic-LDS ceiling) belong to the (function, device) pair: call sites set them the first time they run on each
@@ -98,11 +118,11 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_
     g.segs = g.nb / g.seg_len;
     g.ngroups = shared ? (g.segs >= (uint32_t)MSM_SHARED_GROUPS ? MSM_SHARED_GROUPS : 1) : nwin;
     g.group_segs = shared ? g.segs / g.ngroups : g.segs;
-    static const bool no_bitsum = getenv("CG_NO_BITSUM") != nullptr;                     // tuning knob
+    static const bool no_bitsum = tune_env("CG_NO_BITSUM") != nullptr;                     // tuning knob
     g.bitsum = shared && g.nb <= (1u << 16) && g.nb >= 128 && !no_bitsum;                  // (from 2^7 buckets: the windows of circuits with a few hundred constraints)
     g.bit_groups = std::max<uint32_t>(1, (g.nb / 2 + 256 * BITSUM_ITEMS - 1) / (256 * BITSUM_ITEMS));
     if (g.bitsum) g.ngroups = c;
-    static const bool no_grid = getenv("CG_NO_GRID_REDUCE") != nullptr;                  // tuning knob (A/B against the running-sum chain)
+    static const bool no_grid = tune_env("CG_NO_GRID_REDUCE") != nullptr;                  // tuning knob (A/B against the running-sum chain)
     g.grid = shared && g.nb > (1u << 16) && !no_grid; g.log_l = 10; g.log_h = c - 1 - 10; g.gc = g.gr = 1;
     if (g.grid) {
         const size_t H = (size_t)1 << g.log_h, L = (size_t)1 << g.log_l, per_group = 256 * BITSUM_ITEMS;
@@ -111,8 +131,8 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_
         g.ngroups = (int)((g.log_l + 1) * g.gc + g.log_h * g.gr);
     }
     const size_t entries = (size_t)nwin * n;
-    static const size_t chunk_max = [] { const char* e = getenv("CG_MSM_CHUNK"); return e ? (size_t)atoi(e) : (size_t)128; }();   // tuning knob
-    static const size_t chunk_min = [] { const char* e = getenv("CG_MSM_CHUNK_MIN"); return e ? (size_t)atoi(e) : (size_t)16; }();  // tuning knob (8 -> 16: 2^17-constraint step 7.3 -> 5.8 ms: half the continuation pieces)
+    static const size_t chunk_max = [] { const char* e = tune_env("CG_MSM_CHUNK"); return e ? (size_t)atoi(e) : (size_t)128; }();   // tuning knob
+    static const size_t chunk_min = [] { const char* e = tune_env("CG_MSM_CHUNK_MIN"); return e ? (size_t)atoi(e) : (size_t)16; }();  // tuning knob (8 -> 16: 2^17-constraint step 7.3 -> 5.8 ms: half the continuation pieces)
     // (lists of at most 2^16 entries — circuits of a few hundred constraints — take chunks of 8: the launch is a handful of workgroups and lasts as
     // long as one lane's chain of additions, 14 us each in G2)
     const size_t chunk_floor = entries <= ((size_t)1 << 16) ? std::min<size_t>(chunk_min, 8) : chunk_min;
@@ -120,9 +140,9 @@ inline MsmGeom msm_geom(size_t n, int c, int nwin, bool shared, size_t resident_
     // kernels without a lock-stepped residency (G2: two waves per SIMD, one of them favoured by the arbiter): shorter chunks let the
     // hardware's workgroup scheduler even out what the waves do not — 2^22 points: 12.4 -> 11.7 ms per launch alone, the step 71.5 -> 70.7 ms
     // (48: no better, the merge of twice as many boundary pieces takes it back).  CG_G2_CHUNK overrides (0 = no cap).
-    static const size_t g2_chunk = [] { const char* e = getenv("CG_G2_CHUNK"); return e ? (size_t)atoi(e) : (size_t)64; }();
+    static const size_t g2_chunk = [] { const char* e = tune_env("CG_G2_CHUNK"); return e ? (size_t)atoi(e) : (size_t)64; }();
     if (g2 && g2_chunk) g.chunk_len = (uint32_t)std::min<size_t>(g.chunk_len, std::max<size_t>(chunk_floor, g2_chunk));
-    static const bool no_rounds = getenv("CG_MSM_NO_ROUNDS") != nullptr;                  // tuning knob
+    static const bool no_rounds = tune_env("CG_MSM_NO_ROUNDS") != nullptr;                  // tuning knob
     if (chunk_request) g.chunk_len = (uint32_t)std::min<size_t>(g.chunk_len, std::max<size_t>(chunk_floor, chunk_request));
     else if (resident_lanes && !no_rounds && entries >= resident_lanes * 2 * chunk_min) {      // from 32 entries per lane on (table slices of a multi-GPU plan:
         const size_t rounds = std::max<size_t>(1, (entries + resident_lanes * chunk_max / 2) / (resident_lanes * chunk_max));   // 2^20 points x 15 windows = one round of 80)

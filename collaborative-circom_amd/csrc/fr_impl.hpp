@@ -191,11 +191,16 @@ template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, siz
     const size_t ntiles = (nbuckets + SCAN_TILE - 1) / SCAN_TILE;
     uint32_t* tile_sums = (uint32_t*)take(ntiles * 4);
     if (evs) HIPCHK(hipEventRecord(evs[0], st));
-    static const bool no_small = getenv("CG_SORT_NO_SMALL") != nullptr;                  // measurement knob
-    if (shared && !no_small && nbuckets <= SORT_SMALL_MAX_BUCKETS && (size_t)nwin * n <= SORT_SMALL_MAX_ENTRIES && n <= (1u << 24)) {   // small vectors: one launch
+    const bool no_small = !global_option(CG_GOPT_SORT_SMALL);                            // cg_set_option: the general six-launch schedule for every size
+    // (the kernel asks for up to 68 KiB of dynamic LDS: a device whose workgroups cannot have that — the attribute call fails — takes the general
+    // schedule below instead of failing the MSM: ADVICE r5)
+    static PerDeviceOnce attr_small; static std::atomic<bool> small_unavailable{false};
+    if (shared && !no_small && !small_unavailable.load(std::memory_order_relaxed) && attr_small.pending()) {
+        if (hipFuncSetAttribute((const void*)k_msm_sort_small<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * SORT_SMALL_MAX_BUCKETS + 1024) * 4)) == hipSuccess) attr_small.mark();
+        else { (void)hipGetLastError(); small_unavailable.store(true); }
+    }
+    if (shared && !no_small && !small_unavailable.load(std::memory_order_relaxed) && nbuckets <= SORT_SMALL_MAX_BUCKETS && (size_t)nwin * n <= SORT_SMALL_MAX_ENTRIES && n <= (1u << 24)) {   // small vectors: one launch
         const size_t lds = (2 * nbuckets + 1024) * 4;
-        static PerDeviceOnce attr_small;
-        if (attr_small.pending()) { HIPCHK(hipFuncSetAttribute((const void*)k_msm_sort_small<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * SORT_SMALL_MAX_BUCKETS + 1024) * 4))); attr_small.mark(); }
         hipLaunchKernelGGL((k_msm_sort_small<Fr>), dim3(1), dim3(1024), lds, st, d_scalars, (uint32_t)n, c, nwin, counts, offsets, sorted);
         if (evs) HIPCHK(hipEventRecord(evs[1], st));
         HIPCHK(hipGetLastError());
@@ -215,7 +220,7 @@ template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, siz
         hipLaunchKernelGGL((k_msm_digits_only<Fr>), dim3(grid_for(n)), dim3(256), 0, st, d_scalars, n, c, nwin, digits);
         hipLaunchKernelGGL(k_part_hist, dim3((unsigned)ptiles), dim3(256), nregions * 4, st, digits, n, c, nwin, shared, nregions, region_total);
         hipLaunchKernelGGL(k_part_region_scan, dim3(1), dim3(1024), 0, st, region_total, nregions, region_cursor, total_items);
-        static const bool staged = getenv("CG_SORT_NO_STAGING") == nullptr;        // measurement knob
+        const bool staged = global_option(CG_GOPT_SORT_STAGING) != 0;              // cg_set_option
         if (staged && nregions <= STAGE_MAX_REGIONS) {
             static PerDeviceOnce attr_set;
             if (attr_set.pending()) {

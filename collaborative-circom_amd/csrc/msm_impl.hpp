@@ -95,7 +95,7 @@ int msm_accumulate_batch(hipStream_t st, const MsmAccSet* sets, int nsets, size_
     // record in registers (one wave per SIMD less), 3 / unset = pipelined boundary reads + index list read 16 bytes at a time (the default:
     // the record prefetches measured no faster, the launch is bound by vector issue and not by the latency of the gather),
     // 10 = 4-byte index reads two iterations ahead
-    const char* var_s = getenv("CG_ACC_VARIANT");
+    const char* var_s = tune_env("CG_ACC_VARIANT");
     const int variant = var_s ? atoi(var_s) : 3;
     // CG_OPT_MSM_G2_SLICES: the G2 accumulation goes one chip-load of workgroups at a time: its workgroups hold 147 of the CU's 160 KB
     // of LDS, so nothing that needs LDS (an NTT pass: 72 KB) can start while the launch lasts — measured: a high-priority NTT pass
@@ -156,7 +156,7 @@ int msm_reduce_batch(hipStream_t st2, const MsmRedSet* sets, int nsets, size_t n
     // The final kernel of every reduction kind only WRITES its sums, one struct per workgroup: it writes them straight into the caller's
     // page-locked result buffer (device-visible like all hipHostMalloc memory; the ticket's event, recorded behind this batch, orders the
     // host's reads) — no copy per set behind the reduction (eight copy launches per small proof).  CG_MSM_STAGED_OUT: A/B knob, the copies back.
-    static const bool direct_out = getenv("CG_MSM_STAGED_OUT") == nullptr;
+    const bool direct_out = !global_option(CG_GOPT_MSM_STAGED_OUT);     // cg_set_option: 1 = results copied to the ticket buffer (one copy per bucket set)
     for (int i = 0; i < nsets; i++) {
         const AccScratch<F> sc(sets[i].scratch, g);
         S.buckets[i] = sc.buckets; S.cont[i] = sc.cont; S.cont_bucket[i] = sc.cont_bucket; S.partials[i] = sc.partials;

@@ -112,6 +112,32 @@ static const cg_fixed_base* generator_table(const Curve& c, int g) {
 static Point pt_mul_generator(const Curve& c, int g, const Fr& k) { return pt_mul_fixed(c, generator_table(c, g), pt_generator(c, g), k); }
 
 
+// Process-wide options of the host library (cgh_set_option / cgh_get_option, include/cogroth16_host.h): the thresholds and layout switches a
+// deployment — and the tests — may want to move.  They were environment variables until round 5; none changes a proof.
+struct HostOptions {
+    std::atomic<int64_t> v[CGH_OPT_COUNT];
+    HostOptions() {
+        for (auto& x : v) x.store(0);
+        v[CGH_OPT_XCHG_ASYNC_MIN].store((int64_t)1 << 17);        // (2^19 until round 4; one REP3 party at 2^17 / 2^18: chunked exchange 4.9 / 7.6 ms against 5.5 / 8.9 as one message)
+        v[CGH_OPT_DEVICE_MASKS_MIN].store((int64_t)1 << 11);      // (a host draw is ~70 ns per element: 0.6 ms per mul_vec at 2^13)
+        v[CGH_OPT_XCHG_COPY_STREAM_MIN].store((int64_t)1 << 14);
+        v[CGH_OPT_SECOND_CONTEXT_MIN_LOG].store(15);
+        v[CGH_OPT_DISTRIBUTED_MAP].store(1);
+        v[CGH_OPT_ONE_CONTEXT].store(0);
+        v[CGH_OPT_SPLIT_FIRST_MSM_MIN].store((int64_t)1 << 21);
+    }
+};
+inline HostOptions g_host_options;
+inline int64_t host_option(int id) { return g_host_options.v[id].load(std::memory_order_relaxed); }
+// A/B knobs of the measurement scripts (scripts/party_knobs_ab.sh ...): environment variables in -DCG_DEBUG_KNOBS builds, compiled out of
+// the release library (every call site then folds to its default)
+inline const char* tune_env(const char* name) {
+#ifdef CG_DEBUG_KNOBS
+    return getenv(name);
+#else
+    (void)name; return nullptr;
+#endif
+}
 // Planning knob of scripts/multi_device_emulation.py, compiled ONLY into -DCG_DEBUG_KNOBS builds (make -C host KNOBS=1 -> libcogroth16_host_knobs.so):
 // CGH_EMULATE_DEVICE=d makes every device but d of an N-device session a no-op, so that one GPU times device d's share of the proof.  The
 // proof is then WRONG — which is why the release library does not contain the knob (tests/test_abi_surface.py checks that it ignores the

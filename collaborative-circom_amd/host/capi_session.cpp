@@ -36,9 +36,9 @@ struct cgh_session {
                 cg_ctx* c = pool[slot][best]; pool[slot].erase(pool[slot].begin() + best); return c;
             }
         }
-        static const uint32_t chain_flag = getenv("CGH_CHAIN_FLAG") ? (uint32_t)atoi(getenv("CGH_CHAIN_FLAG")) : 1u;     // tuning knobs (scripts/party_knobs_ab.sh)
-        static const uint32_t bulk_flag = getenv("CGH_BULK_FLAG") ? (uint32_t)atoi(getenv("CGH_BULK_FLAG")) : 2u;
-        cg_ctx* c = nullptr; if (cg_ctx_create_ex(devices[slot], chain ? chain_flag : (bulk_second && slot == 0 ? bulk_flag : 0u), &c)) cgh::die("cg_ctx_create");
+        static const uint32_t chain_flag = cgh::tune_env("CGH_CHAIN_FLAG") ? (uint32_t)atoi(cgh::tune_env("CGH_CHAIN_FLAG")) : 1u;     // tuning knobs (scripts/party_knobs_ab.sh)
+        static const uint32_t bulk_flag = cgh::tune_env("CGH_BULK_FLAG") ? (uint32_t)atoi(cgh::tune_env("CGH_BULK_FLAG")) : 2u;
+        cg_ctx* c = nullptr; if (cg_ctx_create_ex(devices[slot], chain ? chain_flag : (bulk_second ? bulk_flag : 0u), &c)) cgh::die("cg_ctx_create");
         { std::lock_guard<std::mutex> l(mu); serial[c] = next_serial++; }
         return c;
     }
@@ -170,9 +170,9 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
         // them held, the fifth normal-class stream of a party's pair landed on the queue of another BUSY stream of the pair whenever the
         // process had one more context of its own (a 2^16 party in such a process: 7.8 ms against 4.1).
         for (int d = 0; d < n_dev; d++) { s->dzs[d].owner = nullptr; cg_ctx_destroy(s->ctx0[d]); s->ctx0[d] = nullptr; }
-        static const int second_min = getenv("CGH_SECOND_CONTEXT_MIN") ? atoi(getenv("CGH_SECOND_CONTEXT_MIN")) : 15;    // tuning knob: log2 of the variables from which a proof uses two contexts
-        s->second_context = s->z.n_vars >= ((size_t)1 << second_min) && !getenv("CGH_ONE_CONTEXT");
-        s->bulk_second = s->second_context && !getenv("CGH_NO_CHAIN_PRIORITY");
+        const int second_min = (int)cgh::host_option(CGH_OPT_SECOND_CONTEXT_MIN_LOG);    // tuning knob: log2 of the variables from which a proof uses two contexts
+        s->second_context = s->z.n_vars >= ((size_t)1 << second_min) && !cgh::host_option(CGH_OPT_ONE_CONTEXT);
+        s->bulk_second = s->second_context && !cgh::tune_env("CGH_NO_CHAIN_PRIORITY");
         s->additive_h = (flags & 2u) != 0;
         // The contexts of ONE party are made here, on this thread, in a fixed order: the runtime hands a new stream the least used hardware
         // queue of its priority class, so which streams end up sharing a queue — and with it a proof's time, by up to 4 ms at 2^22 — followed
@@ -180,8 +180,8 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
         // contexts are still made on demand.
         if (s->second_context) for (int d = 0; d < n_dev; d++) {
             StreamGroup one_party;
-            cg_ctx* chain = s->take(d, !getenv("CGH_NO_CHAIN_PRIORITY")); cg_ctx* bulk = s->take(d, false);
-            s->give(chain, d, !getenv("CGH_NO_CHAIN_PRIORITY")); s->give(bulk, d, false);
+            cg_ctx* chain = s->take(d, !cgh::tune_env("CGH_NO_CHAIN_PRIORITY")); cg_ctx* bulk = s->take(d, false);
+            s->give(chain, d, !cgh::tune_env("CGH_NO_CHAIN_PRIORITY")); s->give(bulk, d, false);
         }
         s->counted = true; g_open_sessions.fetch_add(1);
         *out = s;
@@ -205,7 +205,7 @@ int32_t cgh_session_prove_plain(void* h, const uint64_t* full_witness, const uin
         const ZKey& z = s->z;
         const Fr* w = (const Fr*)full_witness;
         std::vector<Fr> pub(w, w + z.n_public + 1);
-        static const bool no_prio = getenv("CGH_NO_CHAIN_PRIORITY") != nullptr;          // tuning knob
+        static const bool no_prio = cgh::tune_env("CGH_NO_CHAIN_PRIORITY") != nullptr;          // tuning knob
         StreamGroup one_party;   // (contexts made here, when the pool has none, are this party's)
         Borrowed ctx(s, true, 0, s->second_context && !no_prio), second(s, s->second_context);
         ProofWorkers workers(s);
@@ -245,7 +245,7 @@ int32_t cgh_session_prove_rep3_party_ex(void* h, const uint64_t* pub_in, const u
         const size_t n_aux = z.n_vars - z.n_public - 1;
         std::vector<Fr> pub((const Fr*)pub_in, (const Fr*)pub_in + z.n_public + 1);
         CallbackNetwork net(*net_cb);
-        static const bool no_prio = getenv("CGH_NO_CHAIN_PRIORITY") != nullptr;          // tuning knob
+        static const bool no_prio = cgh::tune_env("CGH_NO_CHAIN_PRIORITY") != nullptr;          // tuning knob
         StreamGroup one_party;   // (contexts made here, when the pool has none, are this party's)
         Borrowed ctx(s, true, 0, s->second_context && !no_prio), second(s, s->second_context);
         CallbackRand rnd(*rnd_cb);                                                       // (after the contexts: draws in flight are finished on a context that still exists)

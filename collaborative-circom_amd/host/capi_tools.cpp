@@ -102,6 +102,14 @@ int32_t cgh_read_wtns(int32_t curve, const char* path, uint64_t* out, size_t cap
     } catch (const std::exception& e) { g_host_err = e.what(); return 1; }
 }
 int32_t cgh_set_zkey_validation(int32_t on) { cgh::g_validate_zkey.store(on ? 1 : 0); return 0; }
+int32_t cgh_set_option(int32_t option, int64_t value) {
+    if (option < 1 || option >= CGH_OPT_COUNT || value < 0) { g_host_err = "cgh_set_option: unknown option or negative value"; return 1; }
+    cgh::g_host_options.v[option].store(value); return 0;
+}
+int32_t cgh_get_option(int32_t option, int64_t* value) {
+    if (option < 1 || option >= CGH_OPT_COUNT || !value) { g_host_err = "cgh_get_option: unknown option"; return 1; }
+    *value = cgh::g_host_options.v[option].load(); return 0;
+}
 // synthetic satisfiable circuit of 2^log_m - 2 constraints with a valid CRS, written as .zkey + .wtns (bench / test tooling)
 int32_t cgh_synth_circuit(int32_t device, int32_t curve, int32_t log_m, uint64_t seed, const char* zkey_path, const char* wtns_path) {
     try { cgh::synth_circuit(device, curve, log_m, seed, zkey_path, wtns_path); return 0; }

@@ -48,6 +48,7 @@ public:
 struct ShareVec {   // device; REP3 uses c[0] = a, c[1] = b; plain only c[0]
     void* c[2] = {nullptr, nullptr}; size_t n = 0;
     int32_t up[2] = {-1, -1}; cg_ctx* up_ctx = nullptr;   // asynchronous uploads still filling the components (copy tickets of up_ctx)
+    int32_t up_first = -1; size_t first_n = 0;            // component 0 went up in two pieces: the first first_n elements have landed at copy ticket up_first (upload_vec)
     bool ready = false;                                   // filled by copies that had completed when the vector was handed out (no stream holds work on it)
 };
 struct FieldShare { Fr c[2]; };
@@ -438,7 +439,14 @@ public:
         ShareVec v; v.n = n;
         if (n >= XCHG_ASYNC_MIN && cg_host_is_pinned(a) && (!b || k() < 2 || cg_host_is_pinned(b))) {   // page-locked shares: asynchronous DMA, the stream waits
             v.c[0] = dalloc(n * 32);
-            v.up[0] = upload_staged(v.c[0], a, n);
+            // large proofs: component a in two pieces, so that the first MSM over it can start on the first piece while the rest is still
+            // crossing PCIe (msm_begin_aux_split; 2.4 ms per component at 2^22)
+            const size_t split_min = (size_t)host_option(CGH_OPT_SPLIT_FIRST_MSM_MIN);
+            if (split_min && n >= split_min && cg_host_is_pinned(a)) {
+                v.first_n = (n / 2 + 63) / 64 * 64;
+                v.up_first = upload_staged(v.c[0], a, v.first_n);
+                v.up[0] = upload_staged((uint8_t*)v.c[0] + v.first_n * 32, a + v.first_n, n - v.first_n);
+            } else v.up[0] = upload_staged(v.c[0], a, n);
             if (b && k() == 2) { v.c[1] = dalloc(n * 32); v.up[1] = upload_staged(v.c[1], b, n); }
             v.up_ctx = ctx;
             if (fence) fence_uploads(v);
@@ -524,14 +532,14 @@ public:
     // the next party chunk by chunk while receiving the previous party's chunks, which go straight back up.  Plain / Shamir: `begin`
     // is the whole operation.
     // shorter vectors: one synchronous message (setting up rings and copy streams costs more than it hides); CGH_XCHG_ASYNC_MIN overrides (A/B runs)
-    const size_t XCHG_ASYNC_MIN = getenv("CGH_XCHG_ASYNC_MIN") ? (size_t)atoll(getenv("CGH_XCHG_ASYNC_MIN")) : (size_t)1 << 17;   // (2^19 until round 4; one REP3 party at 2^17: 8.1 -> 6.7 ms, at 2^16 the single message is faster)
+    const size_t XCHG_ASYNC_MIN = (size_t)host_option(CGH_OPT_XCHG_ASYNC_MIN);   // (2^19 until round 4; one REP3 party at 2^17: 8.1 -> 6.7 ms, at 2^16 the single message is faster)
     // masks of the coming mul_vec calls, uploaded ahead of time (only from page-locked randomness streams, where the copy is a plain
     // asynchronous DMA): the product kernel then never waits for PCIe
     struct MaskSet { void* m1; void* m2; int32_t tk; size_t n, at; void* block = nullptr; bool owns = true; };   // block: m1 lies inside a block drawn for several calls; the LAST of them releases it
     // a randomness source that describes its ChaCha12 generators has its masks drawn by the backend (no host draws, no upload); short vectors
     // are not worth three launches and a stream synchronisation — up to 2^10 elements: a host draw costs ~70 ns per element (two generators,
     // rejection sampling), 0.6 ms per mul_vec at 2^13 (one REP3 party there: 2.75 ms with host draws, 2.14 with device draws; 2^11: 1.52 -> 1.40)
-    const size_t DEVICE_MASKS_MIN = getenv("CGH_DEVICE_MASKS_MIN") ? (size_t)atoll(getenv("CGH_DEVICE_MASKS_MIN")) : (size_t)1 << 11;   // (the override lets the small fixtures take the device path)
+    const size_t DEVICE_MASKS_MIN = (size_t)host_option(CGH_OPT_DEVICE_MASKS_MIN);   // (the override lets the small fixtures take the device path)
     bool masks_on_device(void* d_m, size_t n) {
         if (!rsrc || n < DEVICE_MASKS_MIN) return false;
         void* tmp = nullptr;
@@ -589,7 +597,7 @@ public:
     // elements on they cross PCIe on the chain context's copy streams, beside the main stream (one REP3 party, never / with two contexts / from 2^12 on:
     // 2^13 1.63-1.79 / - / 1.86-2.20 ms | 2^14, one context 2.04-2.09 / - / 2.23-2.46 | 2^15 2.42-2.53 / 2.17-2.27 / 2.30-2.33 | 2^16 2.83-2.99 / 2.91-2.95 / 2.85-2.93)
     static constexpr size_t XCHG_STAGED_MIN = (size_t)1 << 12;
-    const size_t XCHG_COPY_STREAM_MIN = getenv("CGH_XCHG_COPY_STREAM_MIN") ? (size_t)atoll(getenv("CGH_XCHG_COPY_STREAM_MIN")) : (size_t)1 << 14;   // (A/B knob)
+    const size_t XCHG_COPY_STREAM_MIN = (size_t)host_option(CGH_OPT_XCHG_COPY_STREAM_MIN);   // (A/B knob)
     // start streaming chunks of the local product to the host, as many as the ring has room for
     void issue_downloads(PendingMul& pm, size_t upto) {
         const size_t n = pm.out.n, ch = xchg_chunk(n), nch = (n + ch - 1) / ch;
@@ -846,6 +854,9 @@ public:
         cg_ctx* on = nullptr; std::vector<int32_t> tickets; std::vector<int> groups; int k = 0;     // k: share components multiplied (0 = the driver's)
         struct Part { cg_ctx* on; std::vector<int32_t> tickets; void* sc[2]; };     // the same MSMs over the slices held by further GPUs
         std::vector<Part> parts;
+        // msm_begin_aux_split: table `split_table` was multiplied in pieces — component a over two point ranges (tickets lo, hi), component b
+        // on its own (ticket b, -1 for one-component drivers); tickets[split_table] is unused
+        int split_table = -1; int32_t split_lo = -1, split_hi = -1, split_b = -1;
     };
     // Several GPUs: every MSM range is cut into one contiguous slice per device (the primary context's device holds slice 0); the scalar
     // slices travel device to device (cg_dev_copy_peer, xGMI), each device runs the bucket method on its slice, and the partial sums
@@ -893,11 +904,11 @@ public:
     // round-3 order (G2 first in every component, sliced) is 3-5 ms slower (profiles/r04_entry_ab_*.txt).  CGH_G2_ORDER=first restores it for A/B runs.
     void begin_multi_ordered(cg_ctx* on, const std::vector<const cg_bases*>& tables, const std::vector<size_t>& offsets, const std::vector<int>& groups, size_t n,
                              const void* const* sc, std::vector<int32_t>& tickets) {
-        static const bool g2_first = getenv("CGH_G2_ORDER") && !strcmp(getenv("CGH_G2_ORDER"), "first");   // A/B knob
+        static const bool g2_first = tune_env("CGH_G2_ORDER") && !strcmp(tune_env("CGH_G2_ORDER"), "first");   // A/B knob
         std::vector<size_t> ord;
         for (size_t i = 0; i < tables.size(); i++) if ((groups[i] == CG_G2) == g2_first) ord.push_back(i);
         for (size_t i = 0; i < tables.size(); i++) if ((groups[i] == CG_G2) != g2_first) ord.push_back(i);
-        static const int g2_after = getenv("CGH_G2_AFTER") ? atoi(getenv("CGH_G2_AFTER")) : 2;   // A/B knob: G1 accumulations in front of the two G2 ones
+        static const int g2_after = tune_env("CGH_G2_AFTER") ? atoi(tune_env("CGH_G2_AFTER")) : 2;   // A/B knob: G1 accumulations in front of the two G2 ones
         CG(cg_ctx_set_option(on, CG_OPT_MSM_TABLE_ORDER, g2_first ? 0 : 2));
         CG(cg_ctx_set_option(on, CG_OPT_MSM_G2_AFTER, g2_after));
         int64_t chunk = 0; CG(cg_ctx_get_option(on, CG_OPT_MSM_CHUNK, &chunk));
@@ -913,8 +924,8 @@ public:
         // REP3 at sizes where the exchanges are asynchronous: these MSMs run beside the witness map's dependency chain (product -> down ->
         // peer -> up, twice) on the other context; shorter-lived workgroups let the chain's kernels onto the chip sooner (2^22: one party
         // alone 107 -> 97 ms)
-        static const uint32_t bulk_chunk = getenv("CGH_BULK_CHUNK") ? (uint32_t)atoi(getenv("CGH_BULK_CHUNK")) : 64u;   // tuning knob
-        static const uint32_t plain_chunk = getenv("CGH_PLAIN_CHUNK") ? (uint32_t)atoi(getenv("CGH_PLAIN_CHUNK")) : 0u;  // tuning knob
+        static const uint32_t bulk_chunk = tune_env("CGH_BULK_CHUNK") ? (uint32_t)atoi(tune_env("CGH_BULK_CHUNK")) : 64u;   // tuning knob
+        static const uint32_t plain_chunk = tune_env("CGH_PLAIN_CHUNK") ? (uint32_t)atoi(tune_env("CGH_PLAIN_CHUNK")) : 0u;  // tuning knob
         if (p.on != ctx) CG(cg_msm_set_chunk(p.on, mode == Mode::Rep3 && n >= ((size_t)1 << 20) ? bulk_chunk : plain_chunk));   // (below 2^20 the shorter chunks cost more than they return: 2^19 15.9 -> 13.9 ms)
         const void* sc[2] = {s.c[0], s.c[1]};
         if (p.on != ctx) {
@@ -925,8 +936,47 @@ public:
         begin_multi_ordered(p.on, tables, offsets, groups, n, sc, p.tickets);
         return p;
     }
+    // The aux MSMs of a LARGE proof whose witness is still crossing PCIe (ShareVec::up_first): the chip used to idle until component a had
+    // landed completely and been scheduled (2.4 + 0.8 ms at 2^22: most of what the entry costs beyond the resident step).  Now
+    // the FIRST table of the call is multiplied in pieces — component a over the first half of the points as soon as that half is on the
+    // device, then over the second half, then (after the other tables) component b — while the other tables keep the one call with one
+    // schedule per scalar vector.  Costs two half-size schedules, one more schedule of b and two more bucket sets (side streams), and the
+    // 6 % a half-size accumulation is slower; buys ~1.6 ms of otherwise idle chip.  Same points: MSMs are linear in the (scalar, point) pairs.
+    PendingMsm msm_begin_aux_split(const std::vector<const cg_bases*>& tables, const std::vector<size_t>& offsets, const std::vector<int>& groups, size_t n, const ShareVec& s, size_t first) {
+        PendingMsm p; p.on = aux ? aux : ctx; p.groups = groups; p.tickets.assign(tables.size(), -1); p.k = k();
+        static const uint32_t bulk_chunk = tune_env("CGH_BULK_CHUNK") ? (uint32_t)atoi(tune_env("CGH_BULK_CHUNK")) : 64u;
+        if (p.on != ctx) CG(cg_msm_set_chunk(p.on, mode == Mode::Rep3 && n >= ((size_t)1 << 20) ? bulk_chunk : 0u));
+        p.split_table = (int)first;
+        const cg_bases* t0 = tables[first]; const size_t h = s.first_n;
+        auto one = [&](size_t off, size_t cnt, const void* sc, int32_t after, int32_t* tk) {
+            if (after >= 0) CG(cg_msm_scalars_after(p.on, 0, s.up_ctx, after));
+            const size_t o = offsets[first] + off; const void* scs[1] = {sc};
+            CG(cg_msm_dev_begin_multi(p.on, 1, &t0, &o, cnt, scs, 1, tk));
+        };
+        one(0, h, s.c[0], s.up_first, &p.split_lo);
+        one(h, n - h, (const uint8_t*)s.c[0] + h * 32, s.up[0], &p.split_hi);
+        {   // the other tables: one call, one schedule per component
+            std::vector<const cg_bases*> t; std::vector<size_t> o; std::vector<int> g; std::vector<size_t> idx;
+            for (size_t i = 0; i < tables.size(); i++) if (i != first) { t.push_back(tables[i]); o.push_back(offsets[i]); g.push_back(groups[i]); idx.push_back(i); }
+            for (int j = 0; j < k(); j++) if (s.up[j] >= 0) CG(cg_msm_scalars_after(p.on, j, s.up_ctx, s.up[j]));
+            const void* sc[2] = {s.c[0], s.c[1]};
+            std::vector<int32_t> tk;
+            begin_multi_ordered(p.on, t, o, g, n, sc, tk);
+            for (size_t i = 0; i < idx.size(); i++) p.tickets[idx[i]] = tk[i];
+        }
+        if (k() == 2) one(0, n, s.c[1], s.up[1], &p.split_b);
+        return p;
+    }
     PointShare msm_finish(PendingMsm& p, size_t i) {
         const int group = p.groups[i], kk = p.k ? p.k : k();
+        if ((int)i == p.split_table) {                                                  // the pieces of msm_begin_aux_split, folded (MSMs are linear in the pairs)
+            Bytes one(curve.jac(group));
+            auto take = [&](int32_t tk) { CG(cg_msm_end(p.on, tk, one.data())); return Point{one, group}; };
+            PointShare r;
+            r.c[0] = take(p.split_lo); r.c[0] = pt_add(curve, r.c[0], take(p.split_hi));
+            r.c[1] = p.split_b >= 0 ? take(p.split_b) : pt_inf(curve, group);
+            return r;
+        }
         Bytes out(curve.jac(group) * kk);
         CG(cg_msm_end(p.on, p.tickets[i], out.data()));
         PointShare r;

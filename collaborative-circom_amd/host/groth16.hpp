@@ -128,9 +128,12 @@ public:
         // the chain's first kernel waited 1.3 ms for a slot).  The chain's first leg — constraint rows, first product, transforms of a and
         // b — is therefore enqueued FIRST, on an idle chip, and the witness-independent MSMs right behind it, while the host would wait
         // for the first exchange anyway.  MSMs involve no network: the message order is untouched.
-        static const bool late_knob = getenv("CGH_LATE_AUX") != nullptr;                              // A/B knob; measured SLOWER on MI355X (2^16: 3.68 -> 3.86 ms, 2^14: 2.73 -> 2.94, profiles/r05_small_circuit_ab2.txt): off
+        static const bool late_knob = tune_env("CGH_LATE_AUX") != nullptr;                              // A/B knob; measured SLOWER on MI355X (2^16: 3.68 -> 3.86 ms, 2^14: 2.73 -> 2.94, profiles/r05_small_circuit_ab2.txt): off
         const bool late_aux = late_knob && !distributed && !dz.sliced && !add_h && driver.mode == Mode::Rep3 && private_witness.n < driver.XCHG_ASYNC_MIN;
         auto begin_aux = [&] {
+            if (!dz.sliced && !add_h && driver.aux && private_witness.up_ctx && private_witness.up_first >= 0)      // a large witness still on its way up: first table in pieces
+                aux_msm = driver.msm_begin_aux_split({dz.a, dz.b1, dz.b2, dz.l}, {first_aux, first_aux, first_aux, 0}, {CG_G1, CG_G1, CG_G2, CG_G1}, private_witness.n, private_witness, AUX_A);
+            else
             aux_msm = dz.sliced ? driver.msm_begin_sharded(dz, true, private_witness)
                                 : driver.msm_begin_multi({dz.a, dz.b1, dz.b2, dz.l}, {first_aux, first_aux, first_aux, 0}, {CG_G1, CG_G1, CG_G2, CG_G1}, private_witness.n, private_witness, true);
         };
@@ -347,7 +350,7 @@ struct SecondContexts {
     std::vector<cg_ctx*> made; std::thread worker;
     SecondContexts(int device, const char* zkey_path, int count) : made(count, nullptr) {
         struct stat st{};
-        if (getenv("CGH_ONE_CONTEXT") || stat(zkey_path, &st) != 0 || st.st_size < (off_t)200 << 20) return;
+        if (host_option(CGH_OPT_ONE_CONTEXT) || stat(zkey_path, &st) != 0 || st.st_size < (off_t)200 << 20) return;
         worker = std::thread([this, device] { for (auto& c : made) if (cg_ctx_create(device, &c) != 0) c = nullptr; });
     }
     void ready() { if (worker.joinable()) worker.join(); }

@@ -53,7 +53,7 @@ public:
         for (const WorkerDevice& w : md.workers) { Dev x; x.ctx = w.chain ? w.chain : w.ctx; x.msm = w.ctx; x.dz = w.dz; x.lo = w.dz->h_lo; x.n = w.dz->h_n; devs.push_back(x); }
     }
     static bool usable(const HipDriver& d, const DeviceZKey& dz0) {
-        const bool off = getenv("CGH_NO_DISTRIBUTED_MAP") != nullptr;              // A/B knob (read per proof): keep the whole witness map on the primary device
+        const bool off = !host_option(CGH_OPT_DISTRIBUTED_MAP);                    // (read per proof) 0: keep the whole witness map on the primary device (round-2 layout)
         return !off && d.md && !d.md->workers.empty() && dz0.sliced && (d.mode == Mode::Plain || d.mode == Mode::Rep3);
     }
     ~DistributedWitnessMap() {

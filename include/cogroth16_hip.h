@@ -166,38 +166,19 @@ int32_t cg_msm_dev_begin_multi(cg_ctx* ctx, int32_t n_tables, const cg_bases* co
  * (`Rep3PrimeFieldShareVec{a, b}`, rep3/fieldshare.rs:233-236, arrives as two vectors).  Consumed by that one call; `owner` must stay alive
  * until that call has returned (the library keeps a reference to the copy's completion event, not to the context). */
 int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int32_t copy_ticket);
-/* ---- environment variables.  The product needs none.  The ones below exist for A/B measurements and debugging; they are PROCESS-WIDE,
- * read ONCE at first use unless noted, never change results unless marked DEBUG, and are the complete list for libcogroth16_hip.so
- * (tests/test_abi_surface.py checks this list against the sources).  What a deployment may want to tune per context is in the option
- * table further down (cg_ctx_set_option), not here.
- *   resources     CG_DEV_CACHE_MB (32768)    device bytes parked by cg_dev_free per device before blocks are given back to the runtime (0: never park)
- *                 CG_HOST_CACHE_MB (2048)    page-locked host bytes parked by cg_host_free
- *   A/B           CG_MSM_CHUNK (128) / CG_MSM_CHUNK_MIN (16) / CG_G2_CHUNK (64) / CG_MSM_NO_ROUNDS   chunk length of the bucket accumulation: cap, floor, cap
- *                                            for G2, and "do not round to whole residency rounds"
- *                 CG_ACC_VARIANT (3)         software-pipelining variant of k_msm_accumulate_pf (read per call; scripts/acc_variants.py)
- *                 CG_NO_BITSUM / CG_NO_GRID_REDUCE   bucket reduction by the running-sum chain instead of per-bit sums / row-column sums
- *                 CG_SORT_NO_STAGING         unstaged partition / counting-sort scatters
- *                 CG_SORT_NO_SMALL           small scalar vectors through the six-launch schedule instead of the one-workgroup kernel
- *                 CG_NO_COMPACT              no compacted copy for tables with many points at infinity
- *                 CG_COMPACT_MIN (14)        log2 of the smallest table that gets a compacted copy (read per registration)
- *                 CG_NTT_DIF / CG_NTT_NO_PAIR / CG_NTT_TILE (10)   canonical DIF passes; iNTT + coset + NTT as two calls; log2 of the lazy passes' LDS tile
- *                 CG_SUBGROUP_FULL           subgroup checks by [r]P instead of the endomorphism tests
- *                 CG_BULK_CLASS (-1)         priority class of a bulk context's main stream (cg_ctx_create_ex flag 2)
- *                 CG_NO_STREAM_PROBE         new contexts keep the streams the pool hands them without measuring which of them share a hardware queue
- *                 CG_NO_PIPE_MAP             the contexts of a stream group take their streams by the pool's creation-order model instead of by measured pipe:
- *                                            queues of the three priority classes with the same index share a pipe of the command processor and delay each
- *                                            other's dispatches by ~25 us (scripts/queue_map.hip); a party's busy streams are therefore placed on pipes
- *                 CG_MSM_TABLE_ORDER, CG_MSM_G2_AFTER, CG_MSM_G2_SLICES, CG_MSM_REDUCE_BATCH, CG_MSM_ACC_SLOTS, CG_MSM_WIDE_SMALL   seed the option table of NEW contexts
- *                 CG_MSM_ONE_STREAM_LOG (0)  MSM calls of at most 2^this (point, window) entries run schedule, accumulation and reduction in stream order on the
- *                                            context's main stream (0 = never: measured slower than three streams); seeds new contexts
- *                 CG_MSM_OFF_MAIN_LOG (22)   wide MSM calls (CG_OPT_MSM_WIDE_SMALL) of at most 2^this (point, window) entries accumulate their G2 sets on the
- *                                            context's aux stream and their G1 sets on its sort stream instead of the main stream, which stays free for
- *                                            the caller's next kernels (0 = never); seeds new contexts
- *                 CG_MSM_STAGED_OUT          the sums of a bucket reduction are written to device scratch and copied to the ticket's page-locked buffer
- *                                            (one copy per bucket set) instead of being written there by the reduction's last kernel (A/B knob)
- *   DEBUG         CG_DEBUG_NO_REDUCE = 1 | 2 skips the merges + bucket reductions | the reductions only: RESULTS ARE WRONG (what they cost a step)
- *                 CG_DEBUG_ALLOC             cg_dev_cache_trim prints how the device block cache fared since the last trim (read per call)
- *                 CG_DEBUG_STREAMS           one stderr line per stream handed out: priority class, hardware-queue slot, streams checked out per slot (read per call) */
+/* ---- environment variables.  The product needs none.  Complete list for libcogroth16_hip.so (tests/test_abi_surface.py checks it against the
+ * sources): PROCESS-WIDE, none changes a result.
+ *   resources     CG_DEV_CACHE_MB (32768)    device bytes parked by cg_dev_free per device before blocks are given back to the runtime (0: never park; read once)
+ *                 CG_HOST_CACHE_MB (2048)    page-locked host bytes parked by cg_host_free (read once)
+ *   diagnostics   CG_DEBUG_ALLOC             cg_dev_cache_trim prints how the device block cache fared since the last trim (read per call)
+ *                 CG_DEBUG_STREAMS           one stderr line per stream handed out: priority class, hardware-queue slot, streams checked out per slot (read per call)
+ * Everything else that was an environment variable until round 5 is now one of:
+ *   * a per-context option (cg_ctx_set_option, table below) or a process-wide option (cg_set_option, table further down);
+ *   * an A/B knob of the measurement scripts that exists ONLY in the planning build (make -C collaborative-circom_amd/csrc KNOBS=1 ->
+ *     libcogroth16_hip_knobs.so, -DCG_DEBUG_KNOBS): CG_MSM_CHUNK, CG_MSM_CHUNK_MIN, CG_G2_CHUNK, CG_MSM_NO_ROUNDS, CG_ACC_VARIANT, CG_NO_BITSUM,
+ *     CG_NO_GRID_REDUCE, CG_NTT_DIF, CG_NTT_NO_PAIR, CG_NTT_TILE, CG_BULK_CLASS, CG_NO_STREAM_PROBE, CG_NO_PIPE_MAP, the CG_MSM_* seeds of new contexts'
+ *     option tables, and CG_DEBUG_NO_REDUCE (skips the bucket reductions: RESULTS ARE WRONG — what they cost a step).  The release library
+ *     does not contain these names. */
 /* ---- per-context tuning (never changes results).  One table instead of process-wide environment variables: every option belongs to the
  * context it is set on (a party's chain and bulk contexts differ), is read at the next call that uses it, and can be read back.
  *   option                         value                                                                                   default
@@ -223,12 +204,34 @@ int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int3
  *   CG_OPT_MSM_ACC_SLOTS           rotating scratch slots of the accumulate / reduce pipeline (2 .. 8; batches take one per set)    4
  *   CG_OPT_MSM_WIDE_SMALL          10 .. 30 = calls of at most 2^value (point, window) entries and two share components launch all          22
  *                                  accumulations of a coordinate field side by side (one launch, one reduction batch per field; the two
- *                                  fields on two streams up to CG_MSM_OFF_MAIN_LOG entries); 1 = 2^20 entries (the bound of round 4); 0 = off
- * Environment variables of the same names (CG_OPT_... without the prefix: CG_MSM_CHUNK, ...) seed the defaults of NEW contexts for A/B runs. */
+ *                                  fields on two streams up to CG_OPT_MSM_OFF_MAIN_LOG entries); 1 = 2^20 entries (the bound of round 4); 0 = off
+ *   CG_OPT_MSM_ONE_STREAM_LOG      MSM calls of at most 2^value (point, window) entries run schedule, accumulation and reduction in stream      0
+ *                                  order on the context's main stream (0 = never: measured slower than three streams)
+ *   CG_OPT_MSM_OFF_MAIN_LOG        wide calls of at most 2^value (point, window) entries accumulate their G2 sets on the context's aux          22
+ *                                  stream and their G1 sets on its sort stream; the main stream stays free for the caller's next kernels
+ *                                  (and is NOT ordered behind the reads of d_scalars: see cg_msm_dev_begin_multi); 0 = never
+ *   CG_OPT_MSM_SOLO_LOG            wide single-field calls (one coordinate field, <= 2 components) of at most 2^value entries run as a closed   18
+ *                                  sequence on the main stream with scratch of their own (the quotient MSM at the end of a SMALL proof: it
+ *                                  then does not queue behind the aux call's G2 reductions); above it the call keeps the sort / accumulate /
+ *                                  reduce overlap of three streams (it shared CG_OPT_MSM_OFF_MAIN_LOG's bound of 2^22 entries); 0 = never */
 enum { CG_OPT_MSM_CHUNK = 1, CG_OPT_MSM_WINDOW = 2, CG_OPT_MSM_SCATTER_CAP = 3, CG_OPT_MSM_TABLE_ORDER = 4, CG_OPT_MSM_G2_SLICES = 5,
-       CG_OPT_MSM_REDUCE_BATCH = 6, CG_OPT_MSM_ACC_SLOTS = 7, CG_OPT_MSM_G2_AFTER = 8, CG_OPT_MSM_WIDE_SMALL = 9, CG_OPT_COUNT_ };
+       CG_OPT_MSM_REDUCE_BATCH = 6, CG_OPT_MSM_ACC_SLOTS = 7, CG_OPT_MSM_G2_AFTER = 8, CG_OPT_MSM_WIDE_SMALL = 9, CG_OPT_MSM_ONE_STREAM_LOG = 10,
+       CG_OPT_MSM_OFF_MAIN_LOG = 11, CG_OPT_MSM_SOLO_LOG = 12, CG_OPT_COUNT_ };
 int32_t cg_ctx_set_option(cg_ctx* ctx, int32_t option, int64_t value);
 int32_t cg_ctx_get_option(const cg_ctx* ctx, int32_t option, int64_t* value);
+/* ---- process-wide options (policies that are not tied to a context; none changes a result; read at the call that uses them):
+ *   option                         value                                                                                   default
+ *   CG_GOPT_SUBGROUP_FULL          1 = subgroup checks by [r]P instead of the endomorphism tests (cg_bases_check_subgroup)       0
+ *   CG_GOPT_COMPACT_MIN_LOG        log2 of the smallest table with >= 1/8 points at infinity that gets a compacted copy          14
+ *                                  (cg_bases_register; 64 = no table does)
+ *   CG_GOPT_SORT_STAGING           0 = unstaged partition / counting-sort scatters in the MSM schedule                            1
+ *   CG_GOPT_SORT_SMALL             0 = small scalar vectors go through the general six-launch schedule instead of the             1
+ *                                  one-workgroup kernel
+ *   CG_GOPT_MSM_STAGED_OUT         1 = the sums of a bucket reduction are written to device scratch and copied to the ticket's   0
+ *                                  page-locked buffer (one copy per bucket set) instead of being written there by the last kernel */
+enum { CG_GOPT_SUBGROUP_FULL = 1, CG_GOPT_COMPACT_MIN_LOG = 2, CG_GOPT_SORT_STAGING = 3, CG_GOPT_SORT_SMALL = 4, CG_GOPT_MSM_STAGED_OUT = 5, CG_GOPT_COUNT = 6 };
+int32_t cg_set_option(int32_t option, int64_t value);
+int32_t cg_get_option(int32_t option, int64_t* value);
 /* window size override (0 = automatic); tuning knob only, never changes results */
 /* entries of the sorted list one lane folds in the bucket accumulation of THIS context's MSMs (0 = automatic: ~128, whole residency
  * rounds).  Shorter chunks = shorter-lived workgroups: for a context whose MSMs run beside a dependency chain on another context. */

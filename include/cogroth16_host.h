@@ -9,20 +9,14 @@
  * zkey :482, read shares :487-495, construct the driver :497-499, prove :503-506, write proof :512-532) — with buffers instead of
  * files where the CLI reads them into memory first.  INTEGRATION.md shows the Rust-side binding.
  *
- * Environment variables (complete list for libcogroth16_host.so; PROCESS-WIDE, read once unless noted; none is needed, none changes a proof):
+ * Environment variables (complete list for libcogroth16_host.so; process-wide; none is needed, none changes a proof):
  *   CGH_SKIP_ZKEY_VALIDATION      sessions / one-shot proves skip the on-curve + subgroup validation of the zkey points (= cgh_set_zkey_validation(0))
  *   CGH_TIMING                    wall-clock marks of the host-side protocol steps on stderr (microseconds since the previous mark)
- *   thresholds    CGH_SECOND_CONTEXT_MIN (15)   log2 of the variables from which a proof uses a chain + a bulk context
- *                 CGH_XCHG_ASYNC_MIN (2^17)     elements from which the mul_vec exchange streams in chunks over the copy streams
- *                 CGH_DEVICE_MASKS_MIN (2^11)   elements from which described ChaCha12 generators are drawn on the device
- *                 CGH_XCHG_COPY_STREAM_MIN (2^14)  elements from which a single-message mul_vec exchange of a two-context party crosses PCIe on the copy streams, behind the product
- *                                               and beside the transforms, instead of in stream order on the main stream
- *   A/B           CGH_ONE_CONTEXT, CGH_NO_CHAIN_PRIORITY, CGH_CHAIN_FLAG (1), CGH_BULK_FLAG (2)   one context per proof; no priorities; cg_ctx_create_ex flags
- *                 CGH_BULK_CHUNK (64) / CGH_PLAIN_CHUNK (0)   CG_OPT_MSM_CHUNK of the bulk context beside a REP3 chain (>= 2^20 elements) / otherwise
- *                 CGH_G2_ORDER=first, CGH_G2_AFTER (2)        launch order of the aux MSMs' (table, component) pairs (HipDriver::begin_multi_ordered)
- *                 CGH_NO_DISTRIBUTED_MAP (read per proof)     multi-device sessions keep the witness map on the primary device
- *                 CGH_LATE_AUX                                small REP3 proofs start the witness-independent MSMs behind the witness map's first leg (measured slower: off)
- *   planning      CGH_EMULATE_PRIMARY_ONLY      times the primary device's share of a multi-device proof on one GPU: THE PROOF IS WRONG
+ * Everything else that used to be an environment variable is an OPTION (cgh_set_option below: thresholds and layout switches) or exists only in
+ * the planning build (`make -C collaborative-circom_amd/host KNOBS=1` -> libcogroth16_host_knobs.so, -DCG_DEBUG_KNOBS): the A/B knobs of the
+ * measurement scripts (CGH_NO_CHAIN_PRIORITY, CGH_CHAIN_FLAG, CGH_BULK_FLAG, CGH_BULK_CHUNK, CGH_PLAIN_CHUNK, CGH_G2_ORDER, CGH_G2_AFTER,
+ * CGH_LATE_AUX) and CGH_EMULATE_DEVICE, which makes proofs WRONG on purpose (one device's share of a multi-device proof timed on one GPU).
+ * The release library does not contain those names (tests/test_abi_surface.py).
  *
  * Conventions: every function returns 0 on success; on failure a non-zero value, message from cgh_last_error() (thread local).
  * Field elements are 4 x u64 (6 for the BLS12-381 base field) little-endian Montgomery limbs, exactly arkworks' in-memory form
@@ -48,6 +42,22 @@ int32_t cgh_zkey_validate(int32_t device, int32_t curve, const char* path, doubl
 /* The prove entry points and cgh_session_open run that validation themselves, as the reference's parser does.  Callers that validated
  * the file before can switch it off process-wide (or set the environment variable CGH_SKIP_ZKEY_VALIDATION). */
 int32_t cgh_set_zkey_validation(int32_t on);
+/* Process-wide options (thresholds and layout switches; none changes a proof; read when a driver / session is made unless noted):
+ *   option                           value                                                                                   default
+ *   CGH_OPT_XCHG_ASYNC_MIN           elements from which a mul_vec exchange streams in chunks over the copy streams         2^17
+ *   CGH_OPT_DEVICE_MASKS_MIN         elements from which described ChaCha12 generators are drawn on the device              2^11
+ *   CGH_OPT_XCHG_COPY_STREAM_MIN     elements from which a single-message exchange of a two-context party crosses PCIe on   2^14
+ *                                    the copy streams (behind the product, beside the transforms)
+ *   CGH_OPT_SECOND_CONTEXT_MIN_LOG   log2 of the variables from which a session's proofs use a chain + a bulk context       15
+ *   CGH_OPT_DISTRIBUTED_MAP          multi-device sessions spread the witness map over the devices (read per proof);        1
+ *                                    0 = the whole map on the primary device (round-2 layout)
+ *   CGH_OPT_ONE_CONTEXT              1 = one context per proof (no second context for the witness-independent MSMs)         0
+ *   CGH_OPT_SPLIT_FIRST_MSM_MIN      private-witness elements from which a page-locked witness goes up with component a in  2^21
+ *                                    two pieces and the first aux MSM starts on the first piece (HipDriver::msm_begin_aux_split); 0 = never */
+enum { CGH_OPT_XCHG_ASYNC_MIN = 1, CGH_OPT_DEVICE_MASKS_MIN = 2, CGH_OPT_XCHG_COPY_STREAM_MIN = 3, CGH_OPT_SECOND_CONTEXT_MIN_LOG = 4,
+       CGH_OPT_DISTRIBUTED_MAP = 5, CGH_OPT_ONE_CONTEXT = 6, CGH_OPT_SPLIT_FIRST_MSM_MIN = 7, CGH_OPT_COUNT = 8 };
+int32_t cgh_set_option(int32_t option, int64_t value);
+int32_t cgh_get_option(int32_t option, int64_t* value);
 /* witness.rs:51-91: n values in Montgomery form; out == NULL: only *n */
 int32_t cgh_read_wtns(int32_t curve, const char* path, uint64_t* out, size_t cap, size_t* n);
 /* info[6]: n_vars, n_public, domain_size, power, n_additions, n_constraints */

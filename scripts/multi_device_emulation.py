@@ -35,7 +35,8 @@ tag = ", additive-quotient variant" if additive else ""
 for world in worlds:
     ses = cg.ProvingSession(cg.BN254, zp, precompute=True, devices=[0] * world, shared_devices=True, validate=False, additive_h=additive)
     plain, party = [], []
-    for d in range(world):
+    only = os.environ.get("EMU_DEVICES")                      # e.g. EMU_DEVICES=7 under rocprofv3: the trace then ends with device 7's REP3 party
+    for d in ([int(x) for x in only.split(",")] if only else range(world)):
         if world > 1: os.environ["CGH_EMULATE_DEVICE"] = str(d)
         ses.prove_plain(w, r, s)
         plain.append(min(ses.prove_plain(w, r, s)[1] for _ in range(3)) * 1e3)

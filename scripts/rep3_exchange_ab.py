@@ -17,7 +17,7 @@ wa, wb = [a, b, c], [c, a, b]
 streams = [orc.random_field(BN254, FR, 2 * m + 4, rng) for _ in range(3)]
 for rnd in range(2):
     for name, thr in (("one synchronous message", 1 << 40), ("chunked, asynchronous", 1 << 19)):
-        os.environ["CGH_XCHG_ASYNC_MIN"] = str(thr)
+        cg.host_set_option(cg.HOST_OPT_XCHG_ASYNC_MIN, thr)
         ts = []
         for _ in range(3):
             t0 = time.time(); cg.prove_rep3(BN254, zp, w[:2], wa, wb, streams); ts.append(round((time.time() - t0) * 1e3, 1))

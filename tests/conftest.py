@@ -32,3 +32,33 @@ GOLDEN = os.path.join(HERE, "golden")
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def host_option():
+    """set(option, value): a process-wide option of the host library (cgh_set_option) for the duration of one test"""
+    from product import cg
+    saved = {}
+
+    def set_(option, value):
+        if option not in saved:
+            saved[option] = cg.host_get_option(option)
+        cg.host_set_option(option, value)
+    yield set_
+    for k, v in saved.items():
+        cg.host_set_option(k, v)
+
+
+@pytest.fixture
+def lib_option():
+    """set(option, value): a process-wide option of the hip library (cg_set_option) for the duration of one test"""
+    from product import cg
+    saved = {}
+
+    def set_(option, value):
+        if option not in saved:
+            saved[option] = cg.get_option(option)
+        cg.set_option(option, value)
+    yield set_
+    for k, v in saved.items():
+        cg.set_option(k, v)

@@ -27,8 +27,8 @@ FULL = sorted(glob.glob(os.path.join(ROOT, "profiles", "bench_r0[3-9]*.json")) +
 def test_compact_line_is_small_and_carries_the_contract(bench, path, tmp_path, monkeypatch):
     with open(path) as f:
         full = json.load(f)
-    if "metric" not in full:
-        pytest.skip("not a bench line")
+    if "metric" not in full or "detail" in full:
+        pytest.skip("not a full bench object (a compact line or another record)")
     detail = tmp_path / "bench_detail.json"
     buf = io.StringIO()
     monkeypatch.setattr(sys, "stdout", buf)

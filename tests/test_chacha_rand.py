@@ -324,13 +324,13 @@ def test_seeded_shamir_parties_give_the_oracle_proof(curve, log_m, n, t, tmp_pat
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
-def test_plonk_parties_with_device_drawn_masks(curve_name, monkeypatch):
+def test_plonk_parties_with_device_drawn_masks(curve_name, host_option):
     """cgh_plonk_prove_rep3_party_ex: the mul_vec masks of rounds 2 and 3 (co-plonk/src/round2.rs, round3.rs) drawn on the GPU from the
     described generators (threshold lowered so that the fixture's vectors qualify) — the same proof as with host-drawn masks, the
     generators at the same positions afterwards, and the proof verifies; blinding drawn with rand() (round1.rs:93-99) in both runs"""
     from test_plonk_rounds import fx as pfx, CURVES, rep3_share as share3
     ensure_built()
-    monkeypatch.setenv("CGH_DEVICE_MASKS_MIN", "64")
+    host_option(cg.HOST_OPT_DEVICE_MASKS_MIN, 64)
     curve = CURVES[curve_name]
     zp = pfx(curve_name, "circuit.zkey")
     npub = orc.plonk_zkey_info(curve, zp)["n_public"]
@@ -363,13 +363,13 @@ def test_plonk_parties_with_device_drawn_masks(curve_name, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_seeded_shamir_parties_over_the_library_mesh(monkeypatch):
+def test_seeded_shamir_parties_over_the_library_mesh(host_option):
     """the same entry over cgh_shamir_loopback_* (no Python in the data path) on the poseidon fixture, the device-draw threshold lowered so
     that both the preprocess batch and the king's re-sharing coefficients (shamir.rs:347-360: t draws per element, element by element) come
     from the kernels — the oracle's proof on the oracle's own draws from the same seeds"""
     from test_shamir import fx as sfx
     ensure_built()
-    monkeypatch.setenv("CGH_DEVICE_MASKS_MIN", "32")
+    host_option(cg.HOST_OPT_DEVICE_MASKS_MIN, 32)
     curve, n, t = BN254, 5, 2
     zp = sfx("bn254", "poseidon", "circuit.zkey")
     z = orc.ZKey(curve, zp); w = orc.read_wtns(curve, sfx("bn254", "poseidon", "witness.wtns"))

@@ -270,8 +270,8 @@ def test_sort_schedule_variants_agree(built):
 
 
 def test_legacy_scatters_and_release_at_once_in_a_fresh_process(built):
-    """CG_SORT_NO_STAGING (the former scatter kernels on the default shape) and CG_DEV_CACHE_MB=0 / CG_HOST_CACHE_MB=0 (blocks released at
-    once) are read when the library is loaded: a child process runs an MSM and a REP3 product against the closed forms under them"""
+    """CG_GOPT_SORT_STAGING = 0 (the former scatter kernels on the default shape; cg_set_option) and CG_DEV_CACHE_MB=0 / CG_HOST_CACHE_MB=0
+    (blocks released at once; read when the library is loaded): a child process runs an MSM and a REP3 product against the closed forms under them"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = r'''
@@ -287,6 +287,7 @@ b, s = orc.random_field(BN254, FR, n, rng), orc.random_field(BN254, FR, n, rng)
 acc = orc.field_op(BN254, FR, "mul", b, s)
 while acc.shape[0] > 1: acc = orc.field_op(BN254, FR, "add", acc[: acc.shape[0] // 2], acc[acc.shape[0] // 2:])
 want = orc.generator_mul(BN254, G1, acc[0])
+cg.set_option(cg.GOPT_SORT_STAGING, 0)
 c = cg.Context(0)
 for rep in range(3):
     db, ds = c.to_device(b), c.to_device(s)
@@ -298,16 +299,17 @@ for rep in range(3):
 c.close()
 print("child ok")
 '''
-    env = dict(os.environ, CG_SORT_NO_STAGING="1", CG_DEV_CACHE_MB="0", CG_HOST_CACHE_MB="0")
+    env = dict(os.environ, CG_DEV_CACHE_MB="0", CG_HOST_CACHE_MB="0")            # (the two resource variables the library still reads; the sort staging is an option)
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("knobs", [{"CG_MSM_STAGED_OUT": "1"}, {"CG_MSM_OFF_MAIN_LOG": "0"}, {"CG_MSM_STAGED_OUT": "1", "CG_MSM_OFF_MAIN_LOG": "0", "CG_SORT_NO_SMALL": "1"}])
-def test_small_call_knobs_do_not_change_results_in_a_fresh_process(built, knobs):
-    """the round-5 defaults for small MSM calls — sums written straight into the ticket's page-locked buffer, accumulations off the main
-    stream, the one-workgroup schedule kernel — against their A/B knobs (read once per process / per new context): a child process runs G1 and G2
-    MSMs of 2^6 .. 2^13 points with a transform enqueued beside them and checks the closed forms"""
+@pytest.mark.parametrize("knobs", [{"staged_out": 1}, {"off_main_log": 0}, {"solo_log": 0}, {"staged_out": 1, "off_main_log": 0, "sort_small": 0}, {"one_stream_log": 20}])
+def test_small_call_options_do_not_change_results_in_a_fresh_process(built, knobs):
+    """the defaults for small MSM calls — sums written straight into the ticket's page-locked buffer, accumulations off the main stream, the
+    closed main-stream sequence of single-field calls, the one-workgroup schedule kernel — against the other value of their options
+    (cg_set_option / cg_ctx_set_option; environment variables until round 5): a child process runs G1 and G2 MSMs of 2^6 .. 2^13 points
+    with a transform enqueued beside them and checks the closed forms"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = r'''
@@ -319,7 +321,13 @@ from product import cg, ensure_built
 ensure_built()
 rng = np.random.default_rng(5)
 _, roots, _ = orc.roots_of_unity(BN254)
+knobs = KNOBS
+if "staged_out" in knobs: cg.set_option(cg.GOPT_MSM_STAGED_OUT, knobs["staged_out"])
+if "sort_small" in knobs: cg.set_option(cg.GOPT_SORT_SMALL, knobs["sort_small"])
 c = cg.Context(0)
+for name, opt in (("off_main_log", cg.OPT_MSM_OFF_MAIN_LOG), ("solo_log", cg.OPT_MSM_SOLO_LOG), ("one_stream_log", cg.OPT_MSM_ONE_STREAM_LOG)):
+    if name in knobs:
+        c.set_option(opt, knobs[name]); assert c.get_option(opt) == knobs[name]
 for log_n, window in ((6, 8), (9, 10), (11, 13), (13, 13)):
     n = 1 << log_n
     b, s = orc.random_field(BN254, FR, n, rng), orc.random_field(BN254, FR, n, rng)
@@ -339,7 +347,7 @@ for log_n, window in ((6, 8), (9, 10), (11, 13), (13, 13)):
 c.close()
 print("child ok")
 '''
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **knobs), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code.replace("KNOBS", repr(knobs))], cwd=root, env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
 
 

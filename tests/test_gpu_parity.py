@@ -639,10 +639,10 @@ def off_subgroup_point(curve, group, skip=0):
 
 @pytest.mark.parametrize("curve_name,group", [("bn254", G2), ("bls12_381", G1), ("bls12_381", G2), ("bn254", G1)])
 @pytest.mark.parametrize("full", [False, True])
-def test_bases_subgroup_check(ctx, curve_name, group, full, monkeypatch):
+def test_bases_subgroup_check(ctx, curve_name, group, full, lib_option):
     """device-side subgroup validation (is_in_correct_subgroup_assuming_on_curve, circom-types/src/traits.rs:121,151): through the
-    curve's endomorphisms (csrc/subgroup.hpp, the default) and as [r]P (CG_SUBGROUP_FULL=1)"""
-    if full: monkeypatch.setenv("CG_SUBGROUP_FULL", "1")
+    curve's endomorphisms (csrc/subgroup.hpp, the default) and as [r]P (cg_set_option CG_GOPT_SUBGROUP_FULL)"""
+    if full: lib_option(cg.GOPT_SUBGROUP_FULL, 1)
     curve = {"bn254": BN254, "bls12_381": BLS12_381}[curve_name]
     z = orc.ZKey(curve, os.path.join(GOLDEN, "groth16", curve_name, "poseidon", "circuit.zkey"))
     pts = z.points("a_query" if group == G1 else "b_g2_query")
@@ -798,11 +798,11 @@ def test_vec_lincomb_strided(ctx, curve):
 
 @pytest.mark.parametrize("group", [G1, G2])
 @pytest.mark.parametrize("compact", [True, False])
-def test_msm_table_with_many_infinity_points(ctx, group, compact, monkeypatch):
-    """tables that are sparse in points (B queries of real zkeys) are compacted at registration (from 2^14 points on; CG_COMPACT_MIN brings
+def test_msm_table_with_many_infinity_points(ctx, group, compact, lib_option):
+    """tables that are sparse in points (B queries of real zkeys) are compacted at registration (from 2^14 points on; CG_GOPT_COMPACT_MIN_LOG brings
     this 3000-point table under it) or keep their infinity records: results must not change — whole table, sub-slices, with and without
     precomputed window tables, two tables with the same pattern sharing a call, an all-infinity range"""
-    monkeypatch.setenv("CG_COMPACT_MIN", "6" if compact else "20")
+    lib_option(cg.GOPT_COMPACT_MIN_LOG, 6 if compact else 20)
     curve = BN254
     rng = np.random.default_rng(808)
     n = 3000
@@ -859,7 +859,7 @@ def test_msm_randomised_against_oracle():
 
 
 @pytest.mark.parametrize("curve_name,group", [("bn254", G2), ("bls12_381", G1), ("bls12_381", G2)])
-def test_subgroup_check_fast_and_full_agree_on_mixed_tables(ctx, curve_name, group, monkeypatch):
+def test_subgroup_check_fast_and_full_agree_on_mixed_tables(ctx, curve_name, group, lib_option):
     """a table of 384 curve points — multiples of the generator, points outside the subgroup, and sums of both — gets the same verdict
     from the endomorphism-based kernel and from [r]P, and the verdict is the expected one (count and first index)"""
     curve = {"bn254": BN254, "bls12_381": BLS12_381}[curve_name]
@@ -878,8 +878,7 @@ def test_subgroup_check_fast_and_full_agree_on_mixed_tables(ctx, curve_name, gro
     pts = np.stack(pts)
     want = (len(bad), bad[0])
     for full in (False, True):
-        if full: monkeypatch.setenv("CG_SUBGROUP_FULL", "1")
-        else: monkeypatch.delenv("CG_SUBGROUP_FULL", raising=False)
+        lib_option(cg.GOPT_SUBGROUP_FULL, 1 if full else 0)
         bases = ctx.register_bases(curve, group, pts)
         assert ctx.check_on_curve(bases) == (0, None)
         assert ctx.check_subgroup(bases) == want

@@ -353,7 +353,7 @@ def test_endomorphism_subgroup_tests_are_sufficient_for_these_curves():
 
 
 @pytest.mark.parametrize("curve_name", ["bn254", "bls12_381"])
-def test_endomorphism_subgroup_tests_agree_with_r_times_p(curve_name, monkeypatch):
+def test_endomorphism_subgroup_tests_agree_with_r_times_p(curve_name, lib_option):
     """the fast membership tests and [r]P give the same verdict on multiples of the generator, on curve points outside the subgroup, and on
     sums of both (host code, the same functions the device kernel runs)"""
     from test_gpu_parity import off_subgroup_point
@@ -373,7 +373,6 @@ def test_endomorphism_subgroup_tests_agree_with_r_times_p(curve_name, monkeypatc
                 mixed = cg.point_add(curve, group, cg.point_from_affine(curve, group, off), cg.point_scalar_mul(curve, group, gen, orc.random_field(curve, FR, 1, rng)[0]))
                 cases.append((cg.point_to_affine(curve, group, mixed), False))
         for full in (False, True):
-            if full: monkeypatch.setenv("CG_SUBGROUP_FULL", "1")
-            else: monkeypatch.delenv("CG_SUBGROUP_FULL", raising=False)
+            lib_option(cg.GOPT_SUBGROUP_FULL, 1 if full else 0)
             for pt, want in cases:
                 assert cg.point_validate(curve, group, pt) == want

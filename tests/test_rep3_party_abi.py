@@ -303,11 +303,11 @@ def test_three_parties_over_sockets_give_the_oracle_proof(curve_name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunked", [False, True])
-def test_three_parties_over_sockets_at_2_16(chunked, tmp_path, monkeypatch):
+def test_three_parties_over_sockets_at_2_16(chunked, tmp_path, host_option):
     """BASELINE configs[1] scale.  chunked: the two mul_vec exchanges travel as asynchronous 128 KiB chunks (the path a 2^22 proof
     takes with 4 MiB chunks), forced here by lowering the threshold"""
     ensure_built()
-    if chunked: monkeypatch.setenv("CGH_XCHG_ASYNC_MIN", "4096")
+    if chunked: host_option(cg.HOST_OPT_XCHG_ASYNC_MIN, 4096)
     curve, log_m = BN254, 16
     threads = min(32, os.cpu_count() or 8)
     zp, wp = str(tmp_path / "s.zkey"), str(tmp_path / "s.wtns")
@@ -587,12 +587,12 @@ def test_a_corrupted_point_from_a_peer_is_invalid_data():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunked", [False, True])
-def test_a_non_canonical_element_in_a_mul_vec_message_is_invalid_data(chunked, tmp_path, monkeypatch):
+def test_a_non_canonical_element_in_a_mul_vec_message_is_invalid_data(chunked, tmp_path, host_option):
     """the m-element messages of mul_vec are range-checked too — on the host when they are short single messages, on the device (behind the
     upload, read at the end of the prove) from 2^12 elements on and when they travel in chunks: an element whose limbs are not below the
     modulus = InvalidData"""
     ensure_built()
-    if chunked: monkeypatch.setenv("CGH_XCHG_ASYNC_MIN", "4096")
+    if chunked: host_option(cg.HOST_OPT_XCHG_ASYNC_MIN, 4096)
     curve, log_m = BN254, 14
     zp, wp = str(tmp_path / "s.zkey"), str(tmp_path / "s.wtns")
     orc.make_synthetic(curve, log_m, 35, zp, wp, threads=min(32, os.cpu_count() or 8))
