@@ -1,1040 +1,8 @@
 // C ABI of the gfx950 co-groth16 backend (declared in include/cogroth16_hip.h).  Host-side launch logic only:
 // every O(n) computation happens in the kernels of vec_kernels.hpp / ntt_kernels.hpp / msm_kernels.hpp.
 // There is deliberately no CPU fallback here: without a HIP device cg_ctx_create fails.
-#include "common.hpp"
-#include "curve.hpp"
-#include "subgroup.hpp"
-#include "host_ec64.hpp"
-#include "ntt_kernels.hpp"   // NttVecs, plan constants (no kernels are instantiated in this translation unit)
+#include "capi_internal.hpp"
 
-#include <cmath>
-#include <chrono>
-#include <map>
-#include <set>
-#include <mutex>
-#include <vector>
-
-using namespace cg;
-
-// launchers living in msm_inst_*.hip / fr_inst_*.hip (explicit instantiations)
-namespace cg {
-struct MsmSortPtrs { const uint32_t* sorted; const uint32_t* offsets; const uint32_t* counts; uint32_t cap; const uint32_t* overflow; };
-template <class Fr> int msm_sort_launch(hipStream_t st, const Fr* d_scalars, size_t n, int c, int nwin, int shared, char* scratch, MsmSortPtrs* out, hipEvent_t* evs);
-template <class Fr> int msm_sort_direct_launch(hipStream_t st, const Fr* d_scalars, size_t n, int c, int nwin, int shared, uint32_t cap, char* scratch, MsmSortPtrs* out, hipEvent_t* evs);
-inline size_t msm_sort_direct_scratch_bytes(size_t n, int c, int nwin, int shared, uint32_t cap) {
-    const size_t nbuckets = (size_t)(shared ? 1 : nwin) << (c - 1);
-    return align_up(nbuckets * cap * 4) + 2 * align_up(nbuckets * 4) + align_up(((nbuckets + 2047) / 2048) * 4) + 256;
-}
-template <class F> int msm_accumulate_batch(hipStream_t st, const MsmAccSet* sets, int nsets, size_t n, int c, int nwin, bool shared, uint32_t cap, hipEvent_t* evs, uint32_t chunk_request, bool g2_slices);
-template <class F> int msm_reduce_batch(hipStream_t st2, const MsmRedSet* sets, int nsets, size_t n, int c, int nwin, bool shared, uint32_t cap, hipEvent_t* ev_merged, int n_merged,
-                                        hipEvent_t* evs, uint32_t chunk_request);
-template <class F> size_t msm_acc_scratch_bytes(size_t n, int c, int nwin, bool shared, uint32_t chunk_request);
-template <class F> int precompute_window_launch(hipStream_t st, const Affine<F>* d_src, Affine<F>* d_dst, size_t n, int c);
-template <class F> int check_on_curve_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, const F& b, unsigned long long* d_counters);
-template <class F, class Fr> int check_subgroup_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, unsigned long long* d_counters);
-template <class F> int check_subgroup_fast_launch(hipStream_t st, const Affine<F>* d_pts, size_t n, const FastSubgroup<F>& c, unsigned long long* d_counters);
-inline size_t msm_sort_scratch_bytes(size_t n, int c, int nwin) {   // must match fr_impl.hpp
-    const size_t nbuckets = (size_t)nwin << (c - 1);
-    const size_t entries = (size_t)nwin * n;
-    return 2 * align_up(entries * 4) + 3 * align_up(nbuckets * 4) + align_up(((nbuckets + 2047) / 2048) * 4) + align_up(entries * 8) + 2 * align_up(4096 * 4) + 256;
-}
-template <class F> int pack_bases_launch(hipStream_t st, const uint8_t* d_raw, size_t n, size_t stride, long inf_off, Affine<F>* d_dst);
-template <class F> int gather_points_launch(hipStream_t st, Affine<F>* d_dst, const Affine<F>* d_src, const uint32_t* d_idx, size_t n);
-template <class Fr> int launch_vec_gather_idx(hipStream_t st, Fr* out, const Fr* in, const uint32_t* idx, size_t n, uint32_t base);
-template <class F> int synth_points_launch(hipStream_t st, const XYZZ<F>* d_lo, const XYZZ<F>* d_hi, int log_t, size_t n, Affine<F>* d_out);
-template <class F, class Fr> int fixed_base_mul_launch(hipStream_t st, const Affine<F>& g, const Fr* d_scalars, size_t n, Affine<F>* d_tab, Affine<F>* d_out);
-template <class Fr> int launch_vec_binary(hipStream_t st, int op, Fr* out, const Fr* a, const Fr* b, size_t n);
-int chacha12_fr_rand_launch(hipStream_t st, const uint32_t* key8, const uint32_t* mod8, int modulus_bits, uint64_t word_pos, uint64_t n_pairs, uint64_t n,
-                            void* d_cand, uint32_t* d_tiles, unsigned long long* d_result, void* d_out);   // chacha_rand.hip
-template <class Fr> int launch_rep3_mul_local(hipStream_t st, Fr* out, const Fr* aa, const Fr* ab, const Fr* ba, const Fr* bb, const Fr* mask, size_t n);
-template <class Fr> int launch_distribute_powers(hipStream_t st, Fr* v, size_t n, const Fr* lo, const Fr* hi, int log_lo);
-template <class Fr> int launch_vec_count_noncanonical(hipStream_t st, const Fr* v, size_t n, unsigned long long* n_bad);
-template <class Fr> int launch_vec_fill(hipStream_t st, Fr* v, size_t n, const Fr& value);
-template <class Fr> int launch_vec_affine(hipStream_t st, Fr* out, const Fr* a, size_t n, const Fr& c, const Fr& d);
-template <class Fr> int launch_vec_gather_strided(hipStream_t st, Fr* out, const Fr* in, size_t n, size_t offset, size_t stride);
-template <class Fr> int launch_vec_lincomb(hipStream_t st, Fr* out, long long out_off, long long out_stride, size_t n, const LincombArgs<Fr>& a);
-template <class Fr> int launch_prefix_scan(hipStream_t st, int op, Fr* out, const Fr* in, size_t n, Fr* scratch);
-template <class Fr> int launch_vec_inverse(hipStream_t st, Fr* out, const Fr* in, size_t n);
-template <class Fr> int launch_spmv_csr(hipStream_t st, const uint32_t* row_ptr, const uint32_t* col, const Fr* coeff, size_t n_rows, const Fr* pub,
-                                        uint32_t n_inputs, int party, const Fr* wit_a, const Fr* wit_b, Fr* out_a, Fr* out_b);
-template <class Fr> int launch_build_twiddles(hipStream_t st, Fr* tw, size_t m, int log_m, const Fr* lo, const Fr* hi, int log_lo);
-template <class Fr> int launch_build_twiddles_lazy(hipStream_t st, void* tw, size_t m, int log_m, const Fr* lo, const Fr* hi, int log_lo, const Fr& c32);
-template <class Fr> int launch_ntt_ct_pass(hipStream_t st, bool first, NttVecs src, NttVecs dst, int nvec, size_t n, int log_m, int s0, int k, int t, const void* tw);
-template <class Fr> int launch_build_twiddles_lazy_natural(hipStream_t st, void* tw, size_t m, const Fr* lo, const Fr* hi, int log_lo, const Fr& c32);
-template <class Fr> int launch_ntt_dit_pass(hipStream_t st, bool first, bool last, NttVecs out, NttVecs tmp, int nvec, size_t n, int log_m, int s0, int k, int t, const void* tw,
-                                            const Fr* c_lo, const Fr* c_hi, int log_lo, const Fr& c32);
-template <class Fr> int launch_bitrev_finish_lazy(hipStream_t st, NttVecs dst, NttVecs src, int nvec, size_t n, int log_m, const Fr* scale, const Fr* c_lo, const Fr* c_hi, int log_lo);
-template <class Fr> int launch_ntt_dif_pass(hipStream_t st, NttVecs src, NttVecs dst, int nvec, size_t n, int log_m, int s0, int k, int t, const Fr* tw);
-template <class Fr> int launch_bitrev_scale(hipStream_t st, NttVecs dst, NttVecs src, int nvec, size_t n, int log_m, const Fr* scale, const Fr* c_lo, const Fr* c_hi, int log_lo);
-}  // namespace cg
-
-// every device allocation of the library outside cg_dev_alloc: hipMalloc that, when the device is out of memory, gives back the blocks
-// parked by cg_dev_free on the current device (up to CG_DEV_CACHE_MB of them) and tries once more
-hipError_t hip_malloc_flush(void** p, size_t bytes);
-template <class T> hipError_t hip_malloc_flush(T** p, size_t bytes) { return hip_malloc_flush((void**)p, bytes); }
-
-namespace {
-
-struct Arena {
-    char* base = nullptr; size_t cap = 0, used = 0;
-    void* take(size_t bytes) { void* p = base + used; used += align_up(bytes); return p; }
-};
-
-struct TwKey { int curve; int log_m; uint32_t gen[8]; int kind = 0;   // kind 0: stage-major packed tables (DIF passes), 1: bit-reversed limb-form table (lazy passes)
-    bool operator<(const TwKey& o) const { if (curve != o.curve) return curve < o.curve; if (log_m != o.log_m) return log_m < o.log_m; if (kind != o.kind) return kind < o.kind; return memcmp(gen, o.gen, sizeof gen) < 0; } };
-struct CosetKey { TwKey k; uint32_t scale[8]; bool operator<(const CosetKey& o) const { if (k < o.k) return true; if (o.k < k) return false; return memcmp(scale, o.scale, sizeof scale) < 0; } };
-struct CosetTables { void* lo; void* hi; int log_lo; };
-
-enum { TAG_MSM = 0, TAG_NTT, TAG_VEC, TAG_SPMV, TAG_SORT, TAG_ACC_G1, TAG_ACC_G2, TAG_REDUCE, TAG_COUNT };
-struct EvPair { hipEvent_t a, b; int tag; };
-
-struct MsmTicket {
-    bool live = false;
-    int curve = 0, group = 0, k = 0, c = 0, nwin = 0;
-    // optimistic one-pass scatter: per-component overflow flags (pinned) + what is needed to redo the MSM exactly if one is set
-    uint32_t* h_flags = nullptr; bool optimistic = false;
-    const cg_bases* bases = nullptr; size_t offset = 0, n = 0; std::vector<const void*> scalars;
-    int nsums = 0;            // partial sums per component delivered by the GPU
-    bool plain_fold = false;  // true: add them (precomputed tables); false: Horner with c doublings (classic)
-    bool bit_fold = false;    // the sums are the per-bit sums T_k of a small shared bucket set: Horner with ONE doubling per step
-    bool grid_fold = false; int log_l = 0, log_h = 0; uint32_t gc = 1, gr = 1;   // row / column bit sums of a large shared bucket set (k_msm_grid_*)
-    void* h_pinned = nullptr; size_t pinned_bytes = 0;   // k * nwin window sums (XYZZ)
-    hipEvent_t done = nullptr;
-};
-
-}  // namespace
-
-struct cg_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool owns_stream = true;
-    // second stream for the latency-bound bucket reductions, two rotating scratch slots, and the events that order them
-    hipStream_t aux = nullptr;
-    static constexpr int ACC_SLOTS_MAX = 8;                // rotating scratch slots of the accumulate / reduce pipeline (4 in use, see msm_begin_multi_impl)
-    hipEvent_t ev_acc[ACC_SLOTS_MAX] = {}, ev_red[ACC_SLOTS_MAX] = {};
-    bool slot_busy[ACC_SLOTS_MAX] = {};
-    bool aux_pending = false; int last_slot = 0;
-    // third stream for the scalar-side sort (HBM/latency bound): the schedule of component j+1 is built while component j is
-    // accumulated (integer-VALU bound) on the main stream; two rotating schedule slots
-    hipStream_t sortst = nullptr;
-    hipEvent_t ev_in = nullptr, ev_sorted[2] = {nullptr, nullptr}, ev_sched_free[2] = {nullptr, nullptr};
-    // the merge kernels on the aux stream are the last readers of a schedule: [slot] = the most recent one per schedule slot
-    // ([reduction stream: 0 = aux, 1 = the sort stream (wide mode runs the G1 batch there beside the G2 batch on aux)][schedule slot]: one event
-    // per stream, so that the later record of one batch cannot replace the other batch's mark)
-    hipEvent_t ev_merged[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; bool merged_pending[2][2] = {{false, false}, {false, false}};
-    // copy streams of the asynchronous host <-> device transfers (cg_dev_*_begin): MPC exchanges move under the compute
-    static constexpr int COPY_TICKETS = 256;
-    hipStream_t h2d = nullptr, d2h = nullptr;
-    // ticket = running copy number (31 bits); slot = ticket % COPY_TICKETS holds its event.  A slot is recycled only after its
-    // previous copy has completed (copy_begin waits for it), so a ticket older than the slot's current owner names a finished copy.
-    hipEvent_t copy_ev[COPY_TICKETS] = {}; uint32_t copy_id[COPY_TICKETS] = {}; hipEvent_t ev_copy_order = nullptr; uint32_t copy_next = 0;
-    static constexpr int MARKS = 16;                      // cg_stream_mark: points of the stream order that downloads can be ordered behind
-    hipEvent_t mark_ev[MARKS] = {}; uint32_t mark_next = 0;
-    // cg_chacha12_fr_rand_dev_begin / _finish: draws in flight (candidate buffers, the event behind the count's download, the page-locked count)
-    struct RandDraw { bool live = false; void* d_cand = nullptr; void* d_small = nullptr; hipEvent_t ev = nullptr; uint64_t word_pos = 0; size_t n = 0; };
-    static constexpr int RAND_DRAWS = 8;
-    RandDraw rand_draw[RAND_DRAWS]; unsigned long long* rand_result = nullptr;   // [RAND_DRAWS][2] page-locked: accepted candidates, index of the last pair used
-    // cg_msm_scalars_after: the scalar-side schedule of component j of the NEXT begin call waits for this event (an upload still in flight)
-    hipEvent_t comp_after[4] = {};
-    hipStream_t joinst = nullptr; hipEvent_t park_ev[5] = {};   // cg_dev_free: a work-free stream that joins the context's streams behind a released block
-    // priority class of each stream: +1 high, 0 normal, -1 low (pooled_stream)
-    int prio_main = 0, prio_side = 1, prio_copy = 0;
-    uint32_t msm_chunk = 0;                               // cg_msm_set_chunk / CG_OPT_MSM_CHUNK
-    int solo_log = 18;                                    // CG_OPT_MSM_SOLO_LOG: `solo` calls (msm_begin_multi_impl_) of at most 2^this entries
-    int off_main_log = 22;                                // CG_MSM_OFF_MAIN_LOG: wide calls of at most 2^this entries keep their accumulations OFF the main stream (0 = never), see msm_begin_multi_impl_
-    int one_stream_log = 0;                               // CG_MSM_ONE_STREAM_LOG: calls of at most 2^this entries run on the main stream alone (0 = never, the default: measured slower)
-    int table_order = 0, g2_after = -1, g2_slices = 0, red_batch = 2, acc_slots = 4, wide_small = 22;   // CG_OPT_MSM_TABLE_ORDER / _G2_SLICES / _REDUCE_BATCH / _ACC_SLOTS (cg_ctx_set_option)
-    hipEvent_t ev_peer = nullptr;                         // cg_dev_copy_peer: "source stream reached this point"
-    Arena arena;
-    Arena ntt_arena;                                      // limb-form scratch of the transforms: NOT the MSM arena (ensure_ntt_arena)
-    Arena solo_arena;                                     // scratch of tiny single-field MSM calls that run in stream order on the main stream (`solo` in msm_begin_multi_impl_)
-    std::vector<void*> retired;                        // outgrown arena blocks that enqueued kernels may still use
-    void* gather_buf = nullptr; size_t gather_cap = 0;   // scalars gathered for compacted tables (see cg_bases::compact)
-    bool sorts_unordered = false;                         // the last call's sorts ran off the main stream and the main stream has not waited for them (off_main): the next gather must
-    std::map<TwKey, void*> twiddles;
-    std::map<CosetKey, CosetTables> cosets;
-    std::vector<MsmTicket> tickets;
-    int msm_window = 0;
-    int scatter_cap = -1;     // < 0 = exact two-pass sort (default: measured equally fast), 0 = optimistic one-pass scatter with automatic capacity, > 0 = forced capacity (tests)
-    bool stats_on = false;
-    cg_stage_times stats{};
-    std::vector<EvPair> ev_live, ev_free;
-};
-
-struct cg_bases {
-    int device, curve, group;
-    size_t n, pt_bytes;
-    void* d_pts;
-    int pre_c = 0, pre_nwin = 0;   // per-window precomputed tables (cg_bases_precompute): d_pre = [pre_nwin][n] points, window 0 = d_pts copy
-    void* d_pre = nullptr;
-    // Real zkey queries are sparse in points: variables that occur in no B constraint leave the point at infinity in b_g1_query /
-    // b_g2_query (34 % of the poseidon fixture).  When >= 1/8 of a table is infinity the MSMs run over a COMPACTED copy: `compact`
-    // holds the non-infinity records, `h_live` / `d_live` their original indices (ascending), and the scalars are gathered to match.
-    cg_bases* compact = nullptr;
-    std::vector<uint32_t> h_live; uint32_t* d_live = nullptr; uint64_t live_sig = 0;
-    bool no_inf = false;          // registration census found no point at infinity: the accumulate kernel skips its per-point test
-};
-
-namespace {
-
-int ensure_arena(cg_ctx* ctx, size_t bytes) {
-    ctx->arena.used = 0;
-    if (ctx->aux_pending) {   // reductions of an earlier MSM may still be reading the arena on the aux stream
-        for (int sl = 0; sl < cg_ctx::ACC_SLOTS_MAX; sl++) if (ctx->slot_busy[sl]) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_red[sl], 0)); ctx->slot_busy[sl] = false; }
-        ctx->aux_pending = false;
-    }
-    if (bytes <= ctx->arena.cap) return 0;
-    // grow WITHOUT draining the streams (a host that blocks here stalls the exchange pipeline of the drivers): kernels already
-    // enqueued keep their pointers into the old block, which is retired and freed once the streams are idle
-    const bool idle = hipStreamQuery(ctx->stream) == hipSuccess && (!ctx->aux || hipStreamQuery(ctx->aux) == hipSuccess) && (!ctx->sortst || hipStreamQuery(ctx->sortst) == hipSuccess);
-    (void)hipGetLastError();                                // hipErrorNotReady from the queries is not an error
-    if (idle) { for (void* p : ctx->retired) HIPCHK(hipFree(p)); ctx->retired.clear(); }
-    if (ctx->arena.base) { if (idle) HIPCHK(hipFree(ctx->arena.base)); else ctx->retired.push_back(ctx->arena.base); }
-    ctx->arena.base = nullptr; ctx->arena.cap = 0;
-    size_t want = align_up(bytes + bytes / 8, 1 << 20);
-    HIPCHK(hip_malloc_flush((void**)&ctx->arena.base, want));
-    ctx->arena.cap = want;
-    return 0;
-}
-
-// The transforms' scratch is a block of its own.  It used to be the front of the MSM arena, and a transform therefore had to wait for every bucket
-// reduction still reading that arena on the side streams: a one-context party's witness map — constraint rows, product, TRANSFORMS, first
-// exchange — stood still until the witness-independent MSMs it had started first were completely done (Poseidon fixture: the first exchange's
-// download waited 0.2-0.46 ms of a 1.5 ms proof; with the reductions switched off it took 45 us).  Transforms run on the main stream only,
-// so successive users of this block are ordered by the stream itself.
-int ensure_main_stream_block(cg_ctx* ctx, Arena& a, size_t bytes) {
-    if (bytes <= a.cap) return 0;
-    const bool idle = hipStreamQuery(ctx->stream) == hipSuccess;
-    (void)hipGetLastError();
-    if (a.base) { if (idle) HIPCHK(hipFree(a.base)); else ctx->retired.push_back(a.base); }   // (enqueued kernels keep the old block: freed when the context is idle or goes away)
-    a.base = nullptr; a.cap = 0;
-    const size_t want = align_up(bytes + bytes / 8, 1 << 20);
-    HIPCHK(hip_malloc_flush((void**)&a.base, want));
-    a.cap = want;
-    return 0;
-}
-int ensure_ntt_arena(cg_ctx* ctx, size_t bytes) { return ensure_main_stream_block(ctx, ctx->ntt_arena, bytes); }
-
-// non-blocking timing: a pair of events per measured span, drained in cg_stats()
-hipEvent_t ev_new(cg_ctx* ctx) { hipEvent_t e = nullptr; hipEventCreate(&e); return e; }
-int ev_open(cg_ctx* ctx, int tag) {
-    if (!ctx->stats_on) return -1;
-    EvPair p;
-    if (!ctx->ev_free.empty()) { p = ctx->ev_free.back(); ctx->ev_free.pop_back(); } else { p.a = ev_new(ctx); p.b = ev_new(ctx); }
-    p.tag = tag;
-    ctx->ev_live.push_back(p);
-    return (int)ctx->ev_live.size() - 1;
-}
-struct StatScope {
-    cg_ctx* ctx; int idx;
-    StatScope(cg_ctx* c, int tag) : ctx(c), idx(ev_open(c, tag)) { if (idx >= 0) hipEventRecord(ctx->ev_live[idx].a, ctx->stream); }
-    ~StatScope() { if (idx >= 0) hipEventRecord(ctx->ev_live[idx].b, ctx->stream); }
-};
-
-template <class Fn> int with_fr(int curve, Fn&& fn) {
-    if (curve == CG_BN254) return fn(Bn254Fr{});
-#if CG_WITH_BLS
-    if (curve == CG_BLS12_381) return fn(Bls381Fr{});
-#else
-    if (curve == CG_BLS12_381) return fail(CG_ERR_ARG, "library built without BLS12-381 (make BLS=1)");
-#endif
-    return fail(CG_ERR_ARG, "unknown curve id");
-}
-template <class Fn> int with_fq(int curve, Fn&& fn) {
-    if (curve == CG_BN254) return fn(Bn254Fq{});
-#if CG_WITH_BLS
-    if (curve == CG_BLS12_381) return fn(Bls381Fq{});
-#else
-    if (curve == CG_BLS12_381) return fail(CG_ERR_ARG, "library built without BLS12-381 (make BLS=1)");
-#endif
-    return fail(CG_ERR_ARG, "unknown curve id");
-}
-template <class Fn> int with_group(int curve, int group, Fn&& fn) {
-    if (curve == CG_BN254 && group == CG_G1) return fn(Bn254Fq{}, Bn254Fr{});
-    if (curve == CG_BN254 && group == CG_G2) return fn(Fp2<Bn254Fq>{}, Bn254Fr{});
-#if CG_WITH_BLS
-    if (curve == CG_BLS12_381 && group == CG_G1) return fn(Bls381Fq{}, Bls381Fr{});
-    if (curve == CG_BLS12_381 && group == CG_G2) return fn(Fp2<Bls381Fq>{}, Bls381Fr{});
-#else
-    if (curve == CG_BLS12_381) return fail(CG_ERR_ARG, "library built without BLS12-381 (make BLS=1)");
-#endif
-    return fail(CG_ERR_ARG, "unknown curve/group id");
-}
-
-// ------------------------------------------------------------------------------------------------ MSM
-// Window size of the classic path (one bucket set per window), measured on MI355X for both groups (scripts/sweep_classic_window.py):
-// what matters besides the add count is that the TOP window is nearly full — with bits = c*q + t it has only t (+1 carry) bits, all n
-// entries of that window fall into 2^t buckets, and a tiny t (c = 14: t = 2) leaves a few huge buckets whose pieces are merged by
-// few lanes.  c = 8 (t = 6), 13 (t = 7), 15 (t = 14) and 16 (t = 14) are the good choices for 254/255-bit scalars:
-//   n <= 2^12: 8   |   2^13: 13   |   2^14 .. 2^18: 15   |   larger: 16        (2^16 points: 1.75 ms at c = 15 against 5.7 ms at c = 8 or 11)
-int auto_window(size_t n, int bits) {
-    const int lg = log2_floor(std::max<size_t>(n, 1));
-    int c = lg <= 12 ? 8 : lg == 13 ? 13 : lg <= 18 ? 15 : 16;
-    auto ok = [&](int w) { const int t = bits % w; return t != 0 && t >= w - 3 - (w >= 13 ? 6 : 0); };   // other scalar sizes: nudge to a window with a usable top
-    if (!ok(c)) for (int d : {1, -1, 2, -2, 3, -3}) { if (c + d >= 3 && c + d <= 17 && ok(c + d)) { c += d; break; } }
-    return c;
-}
-
-template <class F>
-Jacobian<F> msm_fold_windows(const XYZZ<F>* w, int nwin, int c) {
-    XYZZ<F> acc = w[nwin - 1];
-    for (int i = nwin - 2; i >= 0; i--) {
-        for (int d = 0; d < c; d++) acc = xyzz_dbl(acc);
-        acc = xyzz_add(acc, w[i]);
-    }
-    return xyzz_to_jacobian(acc);
-}
-
-int ticket_slot(cg_ctx* ctx) {
-    for (size_t i = 0; i < ctx->tickets.size(); i++) if (!ctx->tickets[i].live) return (int)i;
-    ctx->tickets.emplace_back();
-    return (int)ctx->tickets.size() - 1;
-}
-
-template <class Fn> int with_coord_field(int curve, int group, Fn&& fn) {   // group-only dispatch (the scalar field is fixed by the curve)
-    return with_group(curve, group, [&](auto ftag, auto) -> int { return fn(ftag); });
-}
-
-// One digit/sort schedule per scalar vector, then one accumulate+reduce per base table: `nb` tables (same curve, any groups)
-// multiplied by the SAME k scalar vectors.  tickets_out[b] collects the k results for table b.
-int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, const size_t* offsets, size_t n, const void* const* d_scalars, int k, int* tickets_out, bool force_exact);
-int msm_begin_multi_impl(cg_ctx* ctx, int nb, const cg_bases* const* bases, const size_t* offsets, size_t n, const void* const* d_scalars, int k, int* tickets_out, bool force_exact = false) {
-    return msm_begin_multi_impl_(ctx, nb, bases, offsets, n, d_scalars, k, tickets_out, force_exact);
-}
-int msm_begin_multi_impl_(cg_ctx* ctx, int nb, const cg_bases* const* bases, const size_t* offsets, size_t n, const void* const* d_scalars, int k, int* tickets_out, bool force_exact) {
-    const uint32_t chunk_request = ctx ? ctx->msm_chunk : 0;   // cg_msm_set_chunk: handed to every geometry computation of this call
-    if (!ctx || !bases || !tickets_out || (n && !d_scalars)) return fail(CG_ERR_ARG, "null argument");
-    if (nb < 1 || nb > 16) return fail(CG_ERR_ARG, "number of base tables out of range");
-    if (k < 1 || k > 8) return fail(CG_ERR_ARG, "k out of range");
-    for (int b = 0; b < nb; b++) {
-        if (!bases[b]) return fail(CG_ERR_ARG, "null bases");
-        if ((offsets ? offsets[b] : 0) + n > bases[b]->n) return fail(CG_ERR_ARG, "bases slice out of range");
-        if (bases[b]->device != ctx->device) return fail(CG_ERR_ARG, "bases live on another device");
-        if (bases[b]->curve != bases[0]->curve) return fail(CG_ERR_ARG, "all tables of one call must be on the same curve");
-    }
-    HIPCHK(hipSetDevice(ctx->device));
-    {   // tables with a compacted copy: map (offset, n) into the compacted index space, gather the scalars, and run the groups of tables
-        // that ended up with the same scalar set (same infinity pattern and range, e.g. b_g1_query and b_g2_query) as one schedule each
-        bool any = false;
-        for (int b = 0; b < nb; b++) any = any || bases[b]->compact != nullptr;
-        if (any) {
-            struct Grp { uint64_t sig; size_t off, cnt, caller_off; std::vector<int> members; };
-            std::vector<Grp> groups;
-            std::vector<size_t> off_c(nb), cnt_c(nb);
-            for (int b = 0; b < nb; b++) {
-                const size_t off = offsets ? offsets[b] : 0;
-                uint64_t sig = 0; size_t o = off, cn = n;
-                if (bases[b]->compact) {
-                    const auto& lv = bases[b]->h_live;
-                    o = (size_t)(std::lower_bound(lv.begin(), lv.end(), (uint32_t)off) - lv.begin());
-                    cn = (size_t)(std::lower_bound(lv.begin(), lv.end(), (uint32_t)std::min<size_t>(off + n, 0xffffffffu)) - lv.begin()) - o;
-                    sig = bases[b]->live_sig;
-                }
-                off_c[b] = o; cnt_c[b] = cn;
-                bool placed = false;
-                // one gather serves a group: same caller offset (the gather's index base), same compacted range, and the same live
-                // indices inside it — compared element by element, the 64-bit signature only short-cuts the mismatch
-                for (auto& g : groups) {
-                    if (g.sig != sig || g.cnt != cn) continue;
-                    if (sig != 0) {
-                        if (g.off != o || g.caller_off != off) continue;
-                        const auto& la = bases[g.members[0]]->h_live; const auto& lb = bases[b]->h_live;
-                        if (memcmp(la.data() + o, lb.data() + o, cn * sizeof(uint32_t)) != 0) continue;
-                    }
-                    g.members.push_back(b); placed = true; break;
-                }
-                if (!placed) groups.push_back(Grp{sig, o, cn, off, {b}});
-            }
-            size_t need = 0;
-            for (auto& g : groups) if (g.sig) need += align_up((size_t)k * g.cnt * 32);
-            if (need > ctx->gather_cap) {
-                HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->sortst));
-                if (ctx->gather_buf) HIPCHK(hipFree(ctx->gather_buf));
-                ctx->gather_buf = nullptr; ctx->gather_cap = 0;
-                HIPCHK(hip_malloc_flush(&ctx->gather_buf, need)); ctx->gather_cap = need;
-            }
-            // gather_buf is rewritten from offset 0 by this call: an off-main call before it (no cg_msm_end in between) may still be reading it in
-            // its digit / sort kernels, which the main stream no longer waits for — a stream wait, no host stall
-            if (ctx->sorts_unordered) { for (int j = 0; j < 2; j++) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[j], 0)); ctx->sorts_unordered = false; }
-            size_t used = 0;
-            for (auto& g : groups) {
-                std::vector<const cg_bases*> gb; std::vector<size_t> go; std::vector<const void*> gs(k);
-                const int first = g.members[0];
-                for (int m : g.members) { gb.push_back(bases[m]->compact ? bases[m]->compact : bases[m]); go.push_back(bases[m]->compact ? off_c[m] : (offsets ? offsets[m] : 0)); }
-                if (g.sig) {
-                    const size_t off = offsets ? offsets[first] : 0;
-                    for (int j = 0; j < k; j++) {
-                        void* dst = (char*)ctx->gather_buf + used + (size_t)j * g.cnt * 32;
-                        int rc = with_fr(bases[first]->curve, [&](auto tag) -> int {
-                            typedef decltype(tag) Fr;
-                            return launch_vec_gather_idx<Fr>(ctx->stream, (Fr*)dst, (const Fr*)d_scalars[j], bases[first]->d_live + g.off, g.cnt, (uint32_t)off);
-                        });
-                        if (rc) return rc;
-                        gs[j] = dst;
-                    }
-                    used += align_up((size_t)k * g.cnt * 32);
-                } else for (int j = 0; j < k; j++) gs[j] = d_scalars[j];
-                std::vector<int> tk(g.members.size());
-                int rc = msm_begin_multi_impl(ctx, (int)g.members.size(), gb.data(), go.data(), g.cnt, gs.data(), k, tk.data(), true);
-                if (rc) return rc;
-                for (size_t i = 0; i < g.members.size(); i++) tickets_out[g.members[i]] = tk[i];
-            }
-            return 0;
-        }
-    }
-    {   // a schedule depends on the window: tables precomputed with different windows (the automatic choice differs between G1 and
-        // G2 for 1.5-3 M points), or a mix of precomputed and plain tables, run as one sub-call per window
-        bool mixed = false;
-        for (int b = 1; b < nb; b++) mixed = mixed || bases[b]->pre_c != bases[0]->pre_c;
-        if (mixed) {
-            std::vector<char> done(nb, 0);
-            for (int b = 0; b < nb; b++) {
-                if (done[b]) continue;
-                std::vector<const cg_bases*> gb; std::vector<size_t> go; std::vector<int> idx;
-                for (int m = b; m < nb; m++) if (!done[m] && bases[m]->pre_c == bases[b]->pre_c) { gb.push_back(bases[m]); go.push_back(offsets ? offsets[m] : 0); idx.push_back(m); done[m] = 1; }
-                std::vector<int> tk(idx.size());
-                int rc = msm_begin_multi_impl(ctx, (int)idx.size(), gb.data(), go.data(), n, d_scalars, k, tk.data(), force_exact);
-                if (rc) return rc;
-                for (size_t i = 0; i < idx.size(); i++) tickets_out[idx[i]] = tk[i];
-            }
-            return 0;
-        }
-    }
-    const int curve = bases[0]->curve;
-    const bool shared = bases[0]->pre_c != 0;          // per-window precomputed tables: one bucket set for all windows
-    if (shared && n > ((size_t)1 << 24)) return fail(CG_ERR_ARG, "precomputed-table MSM supports at most 2^24 points per call");
-    int bits = 0;
-    { int rc = with_fr(curve, [&](auto tag) -> int { bits = decltype(tag)::Params::BITS; return 0; }); if (rc) return rc; }
-    const int c = shared ? bases[0]->pre_c : (n ? (ctx->msm_window ? ctx->msm_window : auto_window(n, bits)) : 2);
-    const int nwin = bits / c + 1;
-    if (shared && nwin != bases[0]->pre_nwin) return fail(CG_ERR_ARG, "internal: window count mismatch");
-    if ((uint64_t)nwin * n >= ((uint64_t)1 << 32))        // schedule positions are 32-bit
-        return fail(CG_ERR_ARG, "MSM of more than 2^32 / windows points in one call (about 2^27): pass the table in slices and add the partial sums");
-    // optimistic scatter capacity: expected heaviest bucket (regular windows + the narrower top window) + 25 % + 6 sigma
-    uint32_t cap = 0;
-    if (n && !force_exact && ctx->scatter_cap >= 0) {
-        if (ctx->scatter_cap > 0) cap = (uint32_t)ctx->scatter_cap;
-        else {
-            const int t = bits % c;
-            const double nbk = (double)((size_t)1 << (c - 1));
-            const double top = t == 0 ? (double)n : (double)n / (double)((size_t)1 << std::min(c - 1, t));
-            const double avg = shared ? (double)(nwin - 1) * (double)n / nbk + top : std::max((double)n / nbk, top);
-            const double want = 1.25 * avg + 6.0 * std::sqrt(avg) + 16.0;
-            if (want <= 4096.0) { cap = 16; while ((double)cap < want) cap <<= 1; }
-        }
-    }
-    const MsmGeom geom = msm_geom(std::max<size_t>(n, 1), c, nwin, shared, 0, chunk_request);   // what is read here (sums per component, reduction kind) does not depend on the chunking
-    const int nsums = geom.ngroups;
-    // tickets + pinned result buffers
-    std::vector<int> slots(nb);
-    size_t acc_bytes = 0;
-    for (int b = 0; b < nb; b++) {
-        slots[b] = ticket_slot(ctx);
-        MsmTicket& t = ctx->tickets[slots[b]];
-        t.live = true;   // reserve before asking for the next slot
-        t.curve = curve; t.group = bases[b]->group; t.k = k; t.c = c; t.nwin = nwin; t.nsums = nsums; t.plain_fold = shared && !geom.bitsum && !geom.grid; t.bit_fold = geom.bitsum;
-        t.grid_fold = geom.grid; t.log_l = geom.log_l; t.log_h = geom.log_h; t.gc = geom.gc; t.gr = geom.gr;
-        t.optimistic = cap != 0; t.bases = bases[b]; t.offset = offsets ? offsets[b] : 0; t.n = n; t.scalars.assign(d_scalars, d_scalars + (n ? k : 0));
-        if (!t.h_flags) HIPCHK(hipHostMalloc((void**)&t.h_flags, 8 * sizeof(uint32_t), hipHostMallocDefault));
-        for (int i = 0; i < 8; i++) t.h_flags[i] = 0;
-        int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
-            typedef decltype(ftag) F;
-            const size_t need = (size_t)k * nsums * sizeof(XYZZ<F>);
-            if (t.pinned_bytes < need) {
-                if (t.h_pinned) HIPCHK(hipHostFree(t.h_pinned));
-                t.h_pinned = nullptr; t.pinned_bytes = 0;
-                HIPCHK(hipHostMalloc(&t.h_pinned, need, hipHostMallocDefault));
-                t.pinned_bytes = need;
-            }
-            if (n == 0) { XYZZ<F>* h = (XYZZ<F>*)t.h_pinned; for (int i = 0; i < k * nsums; i++) h[i] = XYZZ<F>::infinity(); }
-            else acc_bytes = std::max(acc_bytes, msm_acc_scratch_bytes<F>(n, c, nwin, shared, chunk_request));
-            return 0;
-        });
-        if (rc) return rc;
-        if (!t.done) HIPCHK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
-    }
-    if (n) {
-        StatScope ss(ctx, TAG_MSM);
-        const size_t sort_bytes = align_up(cap ? msm_sort_direct_scratch_bytes(n, c, nwin, shared ? 1 : 0, cap) : msm_sort_scratch_bytes(n, c, nwin));
-        const size_t acc_slot = align_up(acc_bytes);
-        const int nsched = k > 1 ? 2 : 1;                  // two schedule slots so that sort j+1 overlaps accumulate j
-        // Four rotating scratch slots: an accumulation waits for the bucket reduction that used its slot, and beside the accumulations the
-        // reduction chain of one MSM (merge, segment sums, window sums; 1 ms alone) takes 3-8 ms — with two slots the main stream stalled
-        // on it (2^22 step: 71.0 -> 69.95 ms with four, no further gain with six or eight; CG_ACC_SLOTS = 2 .. 8 for A/B runs)
-        const int acc_slots_min = std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(2, ctx->acc_slots));
-        // Reduction batching (CG_OPT_MSM_REDUCE_BATCH): 2 (default) = the bucket sets of a call that share a coordinate field are merged and reduced TOGETHER,
-        // after the last accumulation of that field in the call (with the G2 table first in every component, the G2 sets go while the
-        // last component's G1 tables are still accumulated; only the G1 batch trails the call); 1 = per share component; 0 = every set on
-        // its own right behind its accumulation (rounds 1-3).  Beside lock-stepped accumulations a reduction costs the step its stand-alone
-        // duration whatever its width: 2^22 step with ten reductions 6.2 ms, with three.  A batch holds its sets' scratch slots until it has run: one slot per set.
-        const int red_batch = ctx->red_batch;
-        // CG_OPT_MSM_WIDE_SMALL: 0 = off, 1 = calls of at most 2^20 (point, window) entries, 10 .. 30 = log2 of that bound
-        const uint64_t wide_max = ctx->wide_small == 0 ? 0 : (uint64_t)1 << (ctx->wide_small == 1 ? 20 : ctx->wide_small);
-        const bool small_call = k <= 2 && (uint64_t)nwin * n <= wide_max;            // see `wide` below
-        // A/B knob CG_MSM_ONE_STREAM_LOG (off by default): tiny calls with schedule, accumulation and reduction in stream order on the MAIN stream.
-        // It takes the context's hardware-queue placement out of the picture — the same Poseidon-fixture party takes 1.9 to 3.7 ms from one
-        // session of a process to the next with three streams, 2.5-2.8 ms with one — but the G2 reduction then no longer runs under the G1
-        // accumulation, and the best placement is what the default keeps (profiles/r05_small_circuit_ab3.txt).
-        // ... except for a tiny call whose tables all lie in ONE coordinate field (the quotient's MSM at the end of a small proof): nothing would run
-        // beside anything, and on the main stream — another priority class than the side streams, so never on their hardware queues — its
-        // schedule, accumulation and reduction do not queue behind the G2 reductions of the call before (the same Poseidon party waited 14 or
-        // 200 us for this result, depending on where the two side streams had landed)
-        bool single_field = true;
-        for (int b = 1; b < nb; b++) single_field = single_field && bases[b]->group == bases[0]->group;
-        const int acc_slots = red_batch || small_call ? std::min((int)cg_ctx::ACC_SLOTS_MAX, std::max(acc_slots_min, red_batch >= 2 || small_call ? nb * k : nb + 1)) : acc_slots_min;
-        const bool wide = k <= 2 && nb * k <= std::min(acc_slots, (int)ACC_MAX_SETS) && (uint64_t)nwin * n <= wide_max;      // see the WIDE mode below
-        // `solo`: such a call is a closed sequence on ONE stream — it takes its scratch from a block of its own (ordered by that stream alone) and
-        // leaves the context's cross-stream bookkeeping (slot / schedule events of the shared arena) untouched: it neither waits for the
-        // reductions of the call before, which still read the shared arena, nor hides them from the call after
-        const bool solo = wide && small_call && single_field && ctx->solo_log > 0 && (uint64_t)nwin * n <= ((uint64_t)1 << ctx->solo_log);
-        const bool one_stream = solo || (small_call && ctx->one_stream_log > 0 && (uint64_t)nwin * n <= ((uint64_t)1 << ctx->one_stream_log));
-        const hipStream_t sortst = one_stream ? ctx->stream : ctx->sortst, auxst = one_stream ? ctx->stream : ctx->aux;
-        { int rc = solo ? ensure_main_stream_block(ctx, ctx->solo_arena, nsched * sort_bytes + (size_t)acc_slots * acc_slot) : ensure_arena(ctx, nsched * sort_bytes + (size_t)acc_slots * acc_slot); if (rc) return rc; }
-        char* const arena_base = solo ? ctx->solo_arena.base : ctx->arena.base;
-        char* acc_scratch = arena_base + nsched * sort_bytes;
-        if (!solo) {
-        HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));   // scalars (and the arena) are ready once the main stream gets here
-        HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_in, 0));
-        for (int rs = 0; rs < 2; rs++) for (int i = 0; i < 2; i++) if (ctx->merged_pending[rs][i]) { HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_merged[rs][i], 0)); ctx->merged_pending[rs][i] = false; }   // ... and the previous call's merges have read the old schedules
-        }
-        std::vector<MsmSortPtrs> sps(k);
-        auto launch_sort = [&](int j) -> int {             // scalar side: once per scalar vector, on the sort stream
-            const int ss_ = j % nsched;
-            if (j < 4 && ctx->comp_after[j]) HIPCHK(hipStreamWaitEvent(sortst, ctx->comp_after[j], 0));   // this component's scalars are still on their way up
-            if (j >= nsched && !solo) {                          // accumulates and merges of component j-2 have consumed the slot
-                HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_sched_free[ss_], 0));
-                for (int rs = 0; rs < 2; rs++) if (ctx->merged_pending[rs][ss_]) HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_merged[rs][ss_], 0));
-            }
-            hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
-            if (ctx->stats_on) { const int i0 = ev_open(ctx, TAG_SORT); evs[0] = ctx->ev_live[i0].a; evs[1] = ctx->ev_live[i0].b; pev = evs; }
-            char* sort_scratch = arena_base + (size_t)ss_ * sort_bytes;
-            int rc = with_fr(curve, [&](auto tag) -> int {
-                typedef decltype(tag) Fr;
-                return cap ? msm_sort_direct_launch<Fr>(sortst, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, cap, sort_scratch, &sps[j], pev)
-                           : msm_sort_launch<Fr>(sortst, (const Fr*)d_scalars[j], n, c, nwin, shared ? 1 : 0, sort_scratch, &sps[j], pev);
-            });
-            if (rc) return rc;
-            if (cap) for (int b = 0; b < nb; b++) HIPCHK(hipMemcpyAsync(ctx->tickets[slots[b]].h_flags + j, sps[j].overflow, 4, hipMemcpyDeviceToHost, sortst));
-            if (!solo) HIPCHK(hipEventRecord(ctx->ev_sorted[ss_], sortst));
-            return 0;
-        };
-        int iter = 0;
-        { int rc = launch_sort(0); if (rc) return rc; }
-        // bucket sets accumulated but not yet merged / reduced, by coordinate field (group) of their table
-        struct PendSet { MsmRedSet set; int slot, sched, table, comp; };
-        std::vector<PendSet> pend[2];
-        int tables_of_group[2] = {0, 0};
-        for (int b = 0; b < nb; b++) tables_of_group[bases[b]->group == CG_G1 ? 0 : 1]++;
-        std::vector<int> comps_left(nb, k);
-        hipStream_t red_stream[2] = {auxst, auxst};      // reduction stream per field (wide mode: G1 on the idle sort stream, beside G2 on aux)
-        hipStream_t acc_stream[2] = {ctx->stream, ctx->stream};   // accumulation stream per field (the main stream, except for tiny wide calls: see `off_main`)
-        hipEvent_t last_acc[2] = {nullptr, nullptr};      // behind the last accumulation of a field's flushed batch
-        auto flush = [&](int gi) -> int {
-            std::vector<PendSet>& pd = pend[gi];
-            if (pd.empty()) return 0;
-            hipStream_t rst = red_stream[gi];
-            // every accumulation of the batch sits on the main stream in front of this point: the reduction stream waits for the last one
-            hipEvent_t ea = ctx->ev_acc[pd.back().slot];
-            if (!solo) {
-                HIPCHK(hipEventRecord(ea, acc_stream[gi]));
-                if (rst != acc_stream[gi]) HIPCHK(hipStreamWaitEvent(rst, ea, 0));
-                last_acc[gi] = ea;
-            }
-            hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
-            if (ctx->stats_on) { const int i2 = ev_open(ctx, TAG_REDUCE); evs[0] = ctx->ev_live[i2].a; evs[1] = ctx->ev_live[i2].b; pev = evs; }
-            hipEvent_t evm[2]; int nm = 0; bool seen[2] = {false, false};
-            std::vector<MsmRedSet> sets;
-            const int rs = rst == sortst ? 1 : 0;
-            for (const PendSet& ps : pd) { sets.push_back(ps.set); if (!solo && !seen[ps.sched]) { seen[ps.sched] = true; evm[nm++] = ctx->ev_merged[rs][ps.sched]; } }
-            int rc = with_coord_field(curve, gi == 0 ? CG_G1 : CG_G2, [&](auto ftag) -> int {
-                typedef decltype(ftag) F;
-                return msm_reduce_batch<F>(rst, sets.data(), (int)sets.size(), n, c, nwin, shared, sps[pd[0].comp].cap, evm, nm, pev, chunk_request);
-            });
-            if (rc) return rc;
-            if (!solo) for (const PendSet& ps : pd) {
-                HIPCHK(hipEventRecord(ctx->ev_red[ps.slot], rst));
-                ctx->slot_busy[ps.slot] = true; ctx->aux_pending = true; ctx->last_slot = ps.slot; ctx->merged_pending[rs][ps.sched] = true;
-            }
-            // a table's results are complete when the batch holding its LAST outstanding component has run (components may sit in different batches)
-            for (const PendSet& ps : pd) if (--comps_left[ps.table] == 0) HIPCHK(hipEventRecord(ctx->tickets[slots[ps.table]].done, rst));
-            pd.clear();
-            return 0;
-        };
-        auto acc_set = [&](int b, int j, char* scratch) -> MsmAccSet {
-            const char* pts = (const char*)(shared ? bases[b]->d_pre : bases[b]->d_pts) + (offsets ? offsets[b] : 0) * bases[b]->pt_bytes;
-            return MsmAccSet{pts, shared ? bases[b]->n : 0, sps[j].sorted, sps[j].offsets, sps[j].counts, scratch, !bases[b]->no_inf};
-        };
-        auto red_set = [&](int b, int j, char* scratch) -> MsmRedSet {
-            const MsmTicket& t = ctx->tickets[slots[b]];
-            const size_t pinned_stride = (size_t)(t.group == CG_G1 ? 4 : 8) * (bases[b]->pt_bytes / (t.group == CG_G1 ? 2 : 4));     // sizeof(XYZZ<F>): four coordinates
-            return MsmRedSet{scratch, sps[j].offsets, sps[j].counts, (char*)t.h_pinned + (size_t)j * nsums * pinned_stride};
-        };
-        // WIDE mode (small calls, <= 2 share components, one scratch slot per set): all accumulations of a coordinate field in ONE launch
-        // (blockIdx.y = table x component), the G2 launch first and its reduction on the aux stream while the G1 launch runs, whose
-        // reduction goes to the then idle sort stream.  A 2^16-point launch is 256 workgroups and lasts as long as one lane's chain of
-        // additions; eight in a row cost eight chains (2^16 step: 3.2 ms), side by side one.
-        // (measured, round 4: 2^14 step 2.63 -> 2.14 ms, 2^16 3.30 -> 3.09 ms and one REP3 party 5.85 -> 5.54 ms; from 2^17 points on — 2^21 entries — no gain)
-        // Wide calls up to CG_MSM_OFF_MAIN_LOG entries (default 2^22: 2^18 points) keep the main stream free: the G2 sets are accumulated on the aux stream
-        // and the G1 sets on the sort stream, each in front of its own reduction, and the main stream only marks where the scalars are
-        // ready.  Such a call fills a fraction of the chip, so nothing is gained by queueing the caller's next kernels behind its accumulations
-        // — a one-context party's witness map (a chain of short kernels and two host round trips) started 0.3 ms late behind the
-        // witness-independent MSMs, and later still whenever their streams had fallen onto a shared hardware queue.  Beside a chain context the
-        // gain is the two fields' accumulations running side by side instead of one after the other (one REP3 party, bounds 2^20 / 2^19 -> 2^22 / 2^22
-        // entries for wide / off-main: 2^16 3.23 -> 2.78 ms, 2^17 4.97 -> 4.50, 2^18 7.3 -> 6.9.  Not beyond: with 2^24 the 2^19 / 2^20 parties stand
-        // at 12.1 -> 12.0 / 21.8 -> 21.2 ms, but a party over four devices (2^20-point slices) goes from 23.0 to 24.5 ms, and 2^21 / 2^22 lose 0.3 / 1.8 ms).
-        const bool off_main = wide && !one_stream && ctx->off_main_log > 0 && (uint64_t)nwin * n <= ((uint64_t)1 << ctx->off_main_log);
-        if (wide) {
-            if (k == 2) { int rc = launch_sort(1); if (rc) return rc; }
-            if (off_main) { acc_stream[0] = sortst; acc_stream[1] = auxst; }
-            if (!solo) for (int j = 0; j < k; j++) HIPCHK(hipStreamWaitEvent(acc_stream[1], ctx->ev_sorted[j], 0));      // (main stream, or aux; the sort stream is behind its own sorts anyway)
-            red_stream[0] = sortst;
-            for (int gi : {1, 0}) {
-                std::vector<MsmAccSet> sets;
-                for (int j = 0; j < k; j++) for (int b = 0; b < nb; b++) {
-                    if ((bases[b]->group == CG_G1 ? 0 : 1) != gi) continue;
-                    const int slot = iter++ % acc_slots;
-                    if (!solo && ctx->slot_busy[slot]) HIPCHK(hipStreamWaitEvent(acc_stream[gi], ctx->ev_red[slot], 0));
-                    char* scratch = acc_scratch + (size_t)slot * acc_slot;
-                    sets.push_back(acc_set(b, j, scratch));
-                    pend[gi].push_back(PendSet{red_set(b, j, scratch), slot, j, b, j});
-                }
-                if (sets.empty()) continue;
-                hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
-                if (ctx->stats_on) { const int i1 = ev_open(ctx, gi == 0 ? TAG_ACC_G1 : TAG_ACC_G2); evs[0] = ctx->ev_live[i1].a; evs[1] = ctx->ev_live[i1].b; pev = evs; }
-                int rc = with_coord_field(curve, gi == 0 ? CG_G1 : CG_G2, [&](auto ftag) -> int {
-                    typedef decltype(ftag) F;
-                    return msm_accumulate_batch<F>(acc_stream[gi], sets.data(), (int)sets.size(), n, c, nwin, shared, sps[0].cap, pev, chunk_request, false);
-                });
-                if (rc) return rc;
-                if (gi == 0 && !solo) HIPCHK(hipStreamWaitEvent(sortst, ctx->ev_sorted[k - 1], 0));     // (the sort stream has nothing else left in this call)
-                { int rc2 = flush(gi); if (rc2) return rc2; }
-            }
-            // the schedules are free once every accumulation has read them: behind them all on the main stream, or (off the main stream) on the
-            // sort stream, which holds the G1 accumulations itself and waits here for the G2 ones
-            if (off_main && last_acc[1]) HIPCHK(hipStreamWaitEvent(sortst, last_acc[1], 0));
-            if (off_main) ctx->sorts_unordered = true;
-            if (!solo) for (int j = 0; j < k; j++) HIPCHK(hipEventRecord(ctx->ev_sched_free[j], off_main ? sortst : ctx->stream));
-        }
-        // one accumulation: table b, share component j, into the next rotating scratch slot; its bucket set joins the batch of its field
-        auto do_acc = [&](int b, int j) -> int {
-            const MsmSortPtrs& sp = sps[j];
-            MsmTicket& t = ctx->tickets[slots[b]];
-            const int gi = t.group == CG_G1 ? 0 : 1;
-            hipEvent_t evs[2]; hipEvent_t* pev = nullptr;
-            if (ctx->stats_on) { const int i1 = ev_open(ctx, t.group == CG_G1 ? TAG_ACC_G1 : TAG_ACC_G2); evs[0] = ctx->ev_live[i1].a; evs[1] = ctx->ev_live[i1].b; pev = evs; }
-            const int slot = iter++ % acc_slots;
-            for (int g2 = 0; g2 < 2; g2++) {                 // the slot still holds a set that waits for its batch: run that batch now
-                bool held = false;
-                for (const PendSet& ps : pend[g2]) held = held || ps.slot == slot;
-                if (held) { int rc = flush(g2); if (rc) return rc; }
-            }
-            if (ctx->slot_busy[slot]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_red[slot], 0));   // slot's previous reduction must be done
-            char* scratch = acc_scratch + (size_t)slot * acc_slot;
-            const MsmAccSet as = acc_set(b, j, scratch);
-            int rc = with_coord_field(curve, t.group, [&](auto ftag) -> int {
-                typedef decltype(ftag) F;
-                return msm_accumulate_batch<F>(ctx->stream, &as, 1, n, c, nwin, shared, sp.cap, pev, chunk_request, ctx->g2_slices != 0);
-            });
-            if (rc) return rc;
-            pend[gi].push_back(PendSet{red_set(b, j, scratch), slot, j % nsched, b, j});
-            return 0;
-        };
-        if (wide) {}
-        else if (k <= 2 && ctx->table_order == 2) {
-            // CG_OPT_MSM_TABLE_ORDER = 2: ONE launch order over (table, component) pairs — the G1 pairs in serpentine order, the G2 pairs together
-            // after `g2_after` of them (CG_OPT_MSM_G2_AFTER; beyond the G1 count: at the end).  Both schedules are built up front.
-            if (k == 2) { int rc = launch_sort(1); if (rc) return rc; }
-            std::vector<std::pair<int, int>> g1o, g2o, order;
-            for (int j = 0; j < k; j++) for (int bi = 0; bi < nb; bi++) {
-                const int b = (j & 1) ? nb - 1 - bi : bi;
-                (bases[b]->group == CG_G1 ? g1o : g2o).push_back({b, j});
-            }
-            const size_t at = ctx->g2_after < 0 ? g1o.size() : std::min<size_t>((size_t)ctx->g2_after, g1o.size());
-            order.insert(order.end(), g1o.begin(), g1o.begin() + at); order.insert(order.end(), g2o.begin(), g2o.end()); order.insert(order.end(), g1o.begin() + at, g1o.end());
-            bool waited[2] = {false, false};
-            int left[2] = {(int)g1o.size(), (int)g2o.size()}, left_sched[2] = {0, 0};
-            for (auto& pr : order) left_sched[pr.second]++;
-            for (size_t i = 0; i < order.size(); i++) {
-                const int b = order[i].first, j = order[i].second, gi = bases[b]->group == CG_G1 ? 0 : 1;
-                if (!waited[j]) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[j], 0)); waited[j] = true; }
-                { int rc = do_acc(b, j); if (rc) return rc; }
-                const bool last_of_field = --left[gi] == 0;
-                const bool comp_changes = i + 1 == order.size() || order[i + 1].second != j || (bases[order[i + 1].first]->group == CG_G1 ? 0 : 1) != gi;
-                if (red_batch == 0 || (red_batch == 1 && comp_changes) || (last_of_field && red_batch != 3) || (int)pend[gi].size() == RED_MAX_SETS) { int rc3 = flush(gi); if (rc3) return rc3; }
-                if (--left_sched[j] == 0) HIPCHK(hipEventRecord(ctx->ev_sched_free[j], ctx->stream));
-            }
-        } else
-        for (int j = 0; j < k; j++) {
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sorted[j % nsched], 0));
-            // the next component's schedule is enqueued BEFORE this component's accumulates so that the two streams run side by side
-            if (j + 1 < k && nsched == 2 && j + 1 < nsched) { int rc = launch_sort(j + 1); if (rc) return rc; }
-            int left_in_comp[2] = {tables_of_group[0], tables_of_group[1]};
-            for (int bi = 0; bi < nb; bi++) {   // group side: once per table, reusing the schedule
-                const int b = (ctx->table_order >= 1 && (j & 1)) ? nb - 1 - bi : bi;      // serpentine: odd components run the tables in reverse
-                const int gi = bases[b]->group == CG_G1 ? 0 : 1;
-                { int rc = do_acc(b, j); if (rc) return rc; }
-                const bool last_here = --left_in_comp[gi] == 0;                           // this field's last table of the component
-                if (red_batch == 0 || (red_batch == 1 && last_here) || (last_here && j == k - 1 && red_batch != 3) || (int)pend[gi].size() == RED_MAX_SETS) { int rc3 = flush(gi); if (rc3) return rc3; }
-            }
-            HIPCHK(hipEventRecord(ctx->ev_sched_free[j % nsched], ctx->stream));
-            if (j + 2 < k && nsched == 2) {                      // needs the schedule slot this component just released: its pending sets are merged first
-                for (int g2 = 0; g2 < 2; g2++) { int rc = flush(g2); if (rc) return rc; }
-                int rc = launch_sort(j + 2); if (rc) return rc;
-            }
-        }
-        for (int g2 = 0; g2 < 2; g2++) { int rc = flush(g2); if (rc) return rc; }
-    }
-    for (int b = 0; b < nb; b++) { if (n == 0) HIPCHK(hipEventRecord(ctx->tickets[slots[b]].done, ctx->stream)); tickets_out[b] = slots[b]; }
-    return 0;
-}
-
-int msm_begin_impl(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* d_scalars, int k, int* ticket_out) {
-    if (!ticket_out) return fail(CG_ERR_ARG, "null argument");
-    return msm_begin_multi_impl(ctx, 1, &bases, &offset, n, d_scalars, k, ticket_out);
-}
-
-// ---- 64-bit-limb host arithmetic for the O(1) scalar multiplications of proof assembly (host_ec64.hpp)
-namespace {
-template <class P32, int N64> struct ModTag {
-    static constexpr int N = N64;
-    static const cg64::Mod<N64>& mod() { static const cg64::Mod<N64> m = [] { cg64::Mod<N64> x; x.init(P32::P); return x; }(); return m; }
-};
-typedef cg64::Fp<ModTag<Bn254Fq::Params, 4>> H64BnFq;
-typedef cg64::Fp<ModTag<Bn254Fr::Params, 4>> H64BnFr;
-#if CG_WITH_BLS
-typedef cg64::Fp<ModTag<Bls381Fq::Params, 6>> H64BlsFq;
-typedef cg64::Fp<ModTag<Bls381Fr::Params, 4>> H64BlsFr;
-#endif
-template <class Fn> int with_group64(int curve, int group, Fn&& fn) {
-    if (curve == CG_BN254 && group == CG_G1) return fn(H64BnFq{}, H64BnFr{});
-    if (curve == CG_BN254 && group == CG_G2) return fn(cg64::Fp2<H64BnFq>{}, H64BnFr{});
-#if CG_WITH_BLS
-    if (curve == CG_BLS12_381 && group == CG_G1) return fn(H64BlsFq{}, H64BlsFr{});
-    if (curve == CG_BLS12_381 && group == CG_G2) return fn(cg64::Fp2<H64BlsFq>{}, H64BlsFr{});
-#else
-    if (curve == CG_BLS12_381) return fail(CG_ERR_ARG, "library built without BLS12-381 (make BLS=1)");
-#endif
-    return fail(CG_ERR_ARG, "unknown curve/group id");
-}
-}  // namespace
-int msm_end_impl(cg_ctx* ctx, int ticket, void* h_out);
-int msm_end_impl(cg_ctx* ctx, int ticket, void* h_out) {
-    if (!ctx || !h_out) return fail(CG_ERR_ARG, "null argument");
-    if (ticket < 0 || ticket >= (int)ctx->tickets.size() || !ctx->tickets[ticket].live) return fail(CG_ERR_ARG, "bad MSM ticket");
-    MsmTicket& t = ctx->tickets[ticket];
-    HIPCHK(hipEventSynchronize(t.done));
-    t.live = false;
-    if (t.optimistic) {   // a bucket overflowed its guessed capacity (non-uniform scalars): redo this MSM with the exact schedule
-        bool over = false;
-        for (int j = 0; j < t.k; j++) over = over || t.h_flags[j] != 0;
-        if (over) {
-            const cg_bases* b = t.bases; const size_t off = t.offset, n = t.n; const int k = t.k;
-            std::vector<const void*> sc = t.scalars;
-            int t2 = -1;
-            int rc = msm_begin_multi_impl(ctx, 1, &b, &off, n, sc.data(), k, &t2, true);
-            if (rc) return rc;
-            return msm_end_impl(ctx, t2, h_out);
-        }
-    }
-    // the host's share of an MSM: ~100 point additions per result (the partial sums of the reduction kernels), on 64-bit limbs (host_ec64.hpp:
-    // the same bytes as the kernels' 32-bit limbs; 3x the 32-bit host code, 0.2 ms less at the tail of a 2^22 proof, 0.5 ms per 2^16 proof)
-    return with_group64(t.curve, t.group, [&](auto ftag, auto) -> int {
-        typedef decltype(ftag) F;
-        typedef cg64::Xyzz<F> X;
-        const X* h = (const X*)t.h_pinned;
-        cg64::Jac<F>* out = (cg64::Jac<F>*)h_out;
-        for (int j = 0; j < t.k; j++) {
-            const X* hs = h + (size_t)j * t.nsums;
-            X acc;
-            if (t.grid_fold) {
-                // sum_b (b + 1) B_b = sum_k 2^k TC_k + 2^log_l sum_k 2^k TR_k: bit sums of the column side (k <= log_l, gc partial sums each)
-                // then of the row side (k < log_h, gr each), merged into one sequence U_k and folded with one doubling per bit
-                std::vector<X> U((size_t)t.log_l + t.log_h + 1, X::inf());
-                size_t at = 0;
-                for (int kk = 0; kk <= t.log_l; kk++) for (uint32_t g = 0; g < t.gc; g++) U[kk] = cg64::add(U[kk], hs[at++]);
-                for (int kk = 0; kk < t.log_h; kk++) for (uint32_t g = 0; g < t.gr; g++) U[t.log_l + kk] = cg64::add(U[t.log_l + kk], hs[at++]);
-                acc = U.back();
-                for (size_t i = U.size() - 1; i-- > 0;) acc = cg64::add(cg64::dbl(acc), U[i]);
-            } else if (t.bit_fold) {                            // sum_k 2^k T_k
-                acc = hs[t.nsums - 1];
-                for (int i = t.nsums - 2; i >= 0; i--) acc = cg64::add(cg64::dbl(acc), hs[i]);
-            } else if (t.plain_fold) { acc = hs[0]; for (int i = 1; i < t.nsums; i++) acc = cg64::add(acc, hs[i]); }
-            else {                                              // classic windows: Horner with c doublings per window
-                acc = hs[t.nsums - 1];
-                for (int i = t.nsums - 2; i >= 0; i--) { for (int d = 0; d < t.c; d++) acc = cg64::dbl(acc); acc = cg64::add(acc, hs[i]); }
-            }
-            const cg64::Jac<F> r = cg64::to_jac(acc);
-            memcpy(out + j, &r, sizeof r);
-        }
-        return 0;
-    });
-}
-
-// ------------------------------------------------------------------------------------------------ NTT
-// lo[j] = first * w^j (j < 2^log_lo), hi[j] = w^(j << log_lo) (j < hi_n): w^e * first = lo[e & mask] * hi[e >> log_lo]
-template <class Fr>
-void host_pow_tables(const Fr& w, const Fr& first, int log_lo, size_t hi_n, std::vector<Fr>& lo, std::vector<Fr>& hi) {
-    lo.resize((size_t)1 << log_lo); hi.resize(hi_n);
-    Fr acc = first, step = Fr::one();
-    for (size_t j = 0; j < lo.size(); j++) { lo[j] = acc; acc = acc * w; step = step * w; }
-    Fr h = Fr::one();
-    for (size_t j = 0; j < hi_n; j++) { hi[j] = h; h = h * step; }
-}
-
-// Twiddle tables depend only on (device, curve, size, generator): contexts of one process share them (three co-located parties, a
-// prover serving many proofs).  A table is complete before it is published (the builder synchronises its stream); unused tables
-// stay cached up to 1 GiB per process, least recently used first out.
-struct SharedTwiddles { void* p; size_t bytes; int refs; uint64_t stamp; };
-std::mutex g_tw_mu;
-std::map<std::pair<int, TwKey>, SharedTwiddles> g_tw;
-uint64_t g_tw_clock = 0;
-void* shared_twiddles_acquire(int device, const TwKey& key) {
-    std::lock_guard<std::mutex> l(g_tw_mu);
-    auto it = g_tw.find({device, key});
-    if (it == g_tw.end()) return nullptr;
-    it->second.refs++; it->second.stamp = ++g_tw_clock;
-    return it->second.p;
-}
-void* shared_twiddles_publish(int device, const TwKey& key, void* p, size_t bytes) {
-    std::lock_guard<std::mutex> l(g_tw_mu);
-    auto it = g_tw.find({device, key});
-    if (it != g_tw.end()) { hipFree(p); it->second.refs++; it->second.stamp = ++g_tw_clock; return it->second.p; }   // another context was faster
-    g_tw[{device, key}] = SharedTwiddles{p, bytes, 1, ++g_tw_clock};
-    return p;
-}
-void shared_twiddles_release(int device, const TwKey& key) {
-    std::lock_guard<std::mutex> l(g_tw_mu);
-    auto it = g_tw.find({device, key});
-    if (it != g_tw.end() && it->second.refs > 0) it->second.refs--;
-    for (;;) {                                            // trim the idle tables
-        size_t idle = 0; auto victim = g_tw.end();
-        for (auto j = g_tw.begin(); j != g_tw.end(); ++j) if (j->second.refs == 0) { idle += j->second.bytes; if (victim == g_tw.end() || j->second.stamp < victim->second.stamp) victim = j; }
-        if (idle <= ((size_t)1 << 30) || victim == g_tw.end()) break;
-        hipFree(victim->second.p); g_tw.erase(victim);
-    }
-}
-
-template <class Fr>
-int get_twiddles(cg_ctx* ctx, int curve, int log_m, const Fr& w, const Fr** out) {
-    TwKey key; key.curve = curve; key.log_m = log_m; memcpy(key.gen, w.v, sizeof key.gen);
-    auto it = ctx->twiddles.find(key);
-    if (it != ctx->twiddles.end()) { *out = (const Fr*)it->second; return 0; }
-    if (void* shared = shared_twiddles_acquire(ctx->device, key)) { ctx->twiddles[key] = shared; *out = (const Fr*)shared; return 0; }
-    const size_t m = (size_t)1 << log_m;
-    const int log_lo = std::min(11, std::max(0, log_m - 1));
-    const size_t hi_n = std::max<size_t>(1, (m / 2) >> log_lo);
-    std::vector<Fr> lo, hi;
-    host_pow_tables(w, Fr::one(), log_lo, hi_n, lo, hi);
-    Fr *d_lo = nullptr, *d_hi = nullptr, *d_tw = nullptr;
-    HIPCHK(hip_malloc_flush((void**)&d_lo, lo.size() * sizeof(Fr)));
-    HIPCHK(hip_malloc_flush((void**)&d_hi, hi.size() * sizeof(Fr)));
-    HIPCHK(hip_malloc_flush((void**)&d_tw, std::max<size_t>(m - 1, 1) * sizeof(Fr)));
-    HIPCHK(hipMemcpyAsync(d_lo, lo.data(), lo.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_hi, hi.data(), hi.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    { int rc = launch_build_twiddles<Fr>(ctx->stream, d_tw, m, log_m, d_lo, d_hi, log_lo); if (rc) return rc; }
-    HIPCHK(hipStreamSynchronize(ctx->stream));   // lo/hi host vectors and temporaries die here
-    HIPCHK(hipFree(d_lo)); HIPCHK(hipFree(d_hi));
-    d_tw = (Fr*)shared_twiddles_publish(ctx->device, key, d_tw, std::max<size_t>(m - 1, 1) * sizeof(Fr));
-    ctx->twiddles[key] = d_tw;
-    *out = d_tw;
-    return 0;
-}
-
-// limb-form table of the lazy passes: tw[i] = 32 * w^bitrev(i), i < m/2 (ntt_kernels.hpp)
-template <class Fr>
-int get_twiddles_lazy(cg_ctx* ctx, int curve, int log_m, const Fr& w, const void** out) {
-    TwKey key; key.curve = curve; key.log_m = log_m; key.kind = 1; memcpy(key.gen, w.v, sizeof key.gen);
-    auto it = ctx->twiddles.find(key);
-    if (it != ctx->twiddles.end()) { *out = it->second; return 0; }
-    if (void* shared = shared_twiddles_acquire(ctx->device, key)) { ctx->twiddles[key] = shared; *out = shared; return 0; }
-    const size_t m = (size_t)1 << log_m;
-    const int log_lo = std::min(11, std::max(0, log_m - 1));
-    const size_t hi_n = std::max<size_t>(1, (m / 2) >> log_lo);
-    std::vector<Fr> lo, hi;
-    host_pow_tables(w, Fr::one(), log_lo, hi_n, lo, hi);
-    Fr c32 = Fr::one(); for (int i = 0; i < 5; i++) c32 = c32 + c32;
-    Fr *d_lo = nullptr, *d_hi = nullptr; void* d_tw = nullptr;
-    const size_t bytes = lazy29_bytes(std::max<size_t>(m / 2, 1));
-    HIPCHK(hip_malloc_flush((void**)&d_lo, lo.size() * sizeof(Fr)));
-    HIPCHK(hip_malloc_flush((void**)&d_hi, hi.size() * sizeof(Fr)));
-    HIPCHK(hip_malloc_flush(&d_tw, bytes));
-    HIPCHK(hipMemcpyAsync(d_lo, lo.data(), lo.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_hi, hi.data(), hi.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    { int rc = launch_build_twiddles_lazy<Fr>(ctx->stream, d_tw, m, log_m, d_lo, d_hi, log_lo, c32); if (rc) return rc; }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipFree(d_lo)); HIPCHK(hipFree(d_hi));
-    d_tw = shared_twiddles_publish(ctx->device, key, d_tw, bytes);
-    ctx->twiddles[key] = d_tw;
-    *out = d_tw;
-    return 0;
-}
-
-// natural-order limb-form table of the decimation-in-time passes: tw[e] = 32 * w^e, e < m/2 (ntt_kernels.hpp, k_ntt_dit_pass)
-template <class Fr>
-int get_twiddles_lazy_natural(cg_ctx* ctx, int curve, int log_m, const Fr& w, const void** out) {
-    TwKey key; key.curve = curve; key.log_m = log_m; key.kind = 2; memcpy(key.gen, w.v, sizeof key.gen);
-    auto it = ctx->twiddles.find(key);
-    if (it != ctx->twiddles.end()) { *out = it->second; return 0; }
-    if (void* shared = shared_twiddles_acquire(ctx->device, key)) { ctx->twiddles[key] = shared; *out = shared; return 0; }
-    const size_t m = (size_t)1 << log_m;
-    const int log_lo = std::min(11, std::max(0, log_m - 1));
-    const size_t hi_n = std::max<size_t>(1, (m / 2) >> log_lo);
-    std::vector<Fr> lo, hi;
-    host_pow_tables(w, Fr::one(), log_lo, hi_n, lo, hi);
-    Fr c32 = Fr::one(); for (int i = 0; i < 5; i++) c32 = c32 + c32;
-    Fr *d_lo = nullptr, *d_hi = nullptr; void* d_tw = nullptr;
-    const size_t bytes = lazy29_bytes(std::max<size_t>(m / 2, 1));
-    HIPCHK(hip_malloc_flush((void**)&d_lo, lo.size() * sizeof(Fr)));
-    HIPCHK(hip_malloc_flush((void**)&d_hi, hi.size() * sizeof(Fr)));
-    HIPCHK(hip_malloc_flush(&d_tw, bytes));
-    HIPCHK(hipMemcpyAsync(d_lo, lo.data(), lo.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_hi, hi.data(), hi.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    { int rc = launch_build_twiddles_lazy_natural<Fr>(ctx->stream, d_tw, m, d_lo, d_hi, log_lo, c32); if (rc) return rc; }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipFree(d_lo)); HIPCHK(hipFree(d_hi));
-    d_tw = shared_twiddles_publish(ctx->device, key, d_tw, bytes);
-    ctx->twiddles[key] = d_tw;
-    *out = d_tw;
-    return 0;
-}
-
-// tables with lo[j] = scale * g^j, hi[j] = g^(j << log_lo), covering exponents < 2^log_m
-template <class Fr>
-int get_coset_tables(cg_ctx* ctx, int curve, int log_m, const Fr& g, const Fr& scale, CosetTables* out) {
-    CosetKey key; key.k.curve = curve; key.k.log_m = log_m; memcpy(key.k.gen, g.v, sizeof key.k.gen); memcpy(key.scale, scale.v, sizeof key.scale);
-    auto it = ctx->cosets.find(key);
-    if (it != ctx->cosets.end()) { *out = it->second; return 0; }
-    const size_t m = (size_t)1 << log_m;
-    const int log_lo = std::min(11, log_m);
-    const size_t hi_n = std::max<size_t>(1, m >> log_lo);
-    std::vector<Fr> lo, hi;
-    host_pow_tables(g, scale, log_lo, hi_n, lo, hi);
-    CosetTables t; t.log_lo = log_lo;
-    HIPCHK(hip_malloc_flush(&t.lo, lo.size() * sizeof(Fr)));
-    HIPCHK(hip_malloc_flush(&t.hi, hi.size() * sizeof(Fr)));
-    HIPCHK(hipMemcpy(t.lo, lo.data(), lo.size() * sizeof(Fr), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(t.hi, hi.data(), hi.size() * sizeof(Fr), hipMemcpyHostToDevice));
-    if (ctx->cosets.size() >= 64) {   // callers that scale by per-proof challenges would otherwise grow the cache without bound
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
-        ctx->cosets.clear();
-    }
-    ctx->cosets[key] = t;
-    *out = t;
-    return 0;
-}
-
-struct NttPass { int s0, k, t; };
-std::vector<NttPass> ntt_plan(int log_m, int tile_log = NTT_TILE_LOG) {
-    std::vector<NttPass> plan;
-    const int k_last = std::min(log_m, tile_log);
-    const int rest = log_m - k_last;
-    int s0 = 0;
-    if (rest > 0) {
-        const int np = (rest + 6) / 7;
-        for (int i = 0; i < np; i++) {
-            int k = rest / np + (i < rest % np ? 1 : 0);
-            plan.push_back({s0, k, tile_log - k});       // lo_bits >= tile_log here, so t = tile_log - k fits
-            s0 += k;
-        }
-    }
-    plan.push_back({s0, k_last, 0});
-    return plan;
-}
-
-template <class Fr>
-int ntt_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_t n, const Fr& gen, bool inverse, const Fr* coset, size_t arena_off) {
-    const int log_m = log2_floor(n);
-    if (((size_t)1 << log_m) != n) return fail(CG_ERR_ARG, "NTT length must be a power of two");
-    if (k < 1 || k > NTT_MAX_VECS) return fail(CG_ERR_ARG, "k out of range");
-    if (n == 1) return 0;
-    const Fr w = inverse ? fp_inverse(gen) : gen;
-    static const bool legacy = tune_env("CG_NTT_DIF") != nullptr;                 // A/B knob: the canonical DIF passes
-    if (!legacy) {
-        // lazy Cooley-Tukey passes (ntt_kernels.hpp): packed vectors -> limb-form scratch -> ... -> permutation back into the vectors,
-        // which multiplies by 32 * (1/m) * coset power (32: the lazy core divides by 2^261, the ABI's R is 2^256)
-        if (!inverse && coset) return fail(CG_ERR_ARG, "coset_gen is only supported with inverse != 0");
-        const void* twl = nullptr;
-        int rc = get_twiddles_lazy<Fr>(ctx, curve, log_m, w, &twl);
-        if (rc) return rc;
-        NttVecs data{}, tmp{};
-        for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->ntt_arena.base + arena_off + (size_t)j * lazy29_bytes(n); }
-        hipStream_t st = ctx->stream;
-        bool first = true;
-        static const int lazy_tile = [] { const char* e = tune_env("CG_NTT_TILE"); const int v = e ? atoi(e) : NTT_TILE_LOG_LAZY; return std::min(NTT_TILE_LOG, std::max(8, v)); }();   // tuning knob
-        for (const NttPass& p : ntt_plan(log_m, lazy_tile)) { rc = launch_ntt_ct_pass<Fr>(st, first, first ? data : tmp, tmp, k, n, log_m, p.s0, p.k, p.t, twl); if (rc) return rc; first = false; }
-        Fr scale32 = Fr::one(); for (int i = 0; i < 5; i++) scale32 = scale32 + scale32;
-        if (inverse) {
-            uint32_t e[Fr::N] = {0}; e[log_m / 32] = 1u << (log_m % 32);
-            Fr nn; for (int i = 0; i < Fr::N; i++) nn.v[i] = e[i];
-            scale32 = scale32 * fp_inverse(nn.to_mont());
-        }
-        CosetTables t;
-        const Fr* d_scale = nullptr; const Fr* c_lo = nullptr; const Fr* c_hi = nullptr; int log_lo = 0;
-        if (coset) { rc = get_coset_tables<Fr>(ctx, curve, log_m, *coset, scale32, &t); if (rc) return rc; c_lo = (const Fr*)t.lo; c_hi = (const Fr*)t.hi; log_lo = t.log_lo; }
-        else { rc = get_coset_tables<Fr>(ctx, curve, 0, Fr::one(), scale32, &t); if (rc) return rc; d_scale = (const Fr*)t.lo; }
-        return launch_bitrev_finish_lazy<Fr>(st, data, tmp, k, n, log_m, d_scale, c_lo, c_hi, log_lo);
-    }
-    const Fr* tw = nullptr;
-    int rc = get_twiddles<Fr>(ctx, curve, log_m, w, &tw);
-    if (rc) return rc;
-    NttVecs data{}, tmp{};
-    for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->ntt_arena.base + arena_off + (size_t)j * n * sizeof(Fr); }
-    hipStream_t st = ctx->stream;
-    {   // first pass reads the caller's vectors and writes the scratch copies; later passes run in the scratch copies
-        bool first = true;
-        for (const NttPass& p : ntt_plan(log_m)) { rc = launch_ntt_dif_pass<Fr>(st, first ? data : tmp, tmp, k, n, log_m, p.s0, p.k, p.t, tw); if (rc) return rc; first = false; }
-    }
-    const Fr* d_scale = nullptr; const Fr* c_lo = nullptr; const Fr* c_hi = nullptr; int log_lo = 0;
-    if (inverse) {
-        Fr ninv = Fr::one();   // n^-1: halve log_m times  (x/2 = (x + (x odd ? p : 0)) >> 1 in Montgomery form as well)
-        {
-            uint32_t e[Fr::N] = {0}; e[log_m / 32] = 1u << (log_m % 32);
-            Fr nn; for (int i = 0; i < Fr::N; i++) nn.v[i] = e[i];
-            ninv = fp_inverse(nn.to_mont());
-        }
-        CosetTables t;
-        if (coset) { rc = get_coset_tables<Fr>(ctx, curve, log_m, *coset, ninv, &t); if (rc) return rc; c_lo = (const Fr*)t.lo; c_hi = (const Fr*)t.hi; log_lo = t.log_lo; }
-        else { rc = get_coset_tables<Fr>(ctx, curve, 0, Fr::one(), ninv, &t); if (rc) return rc; d_scale = (const Fr*)t.lo; }
-    } else if (coset) return fail(CG_ERR_ARG, "coset_gen is only supported with inverse != 0");
-    // the permutation brings the result back: tmp -> data (natural order), fused with 1/m and the coset powers
-    return launch_bitrev_scale<Fr>(st, data, tmp, k, n, log_m, d_scale, c_lo, c_hi, log_lo);
-}
-
-// v <- NTT_w( g^i * (iNTT_w v)_i ): the inverse transform's passes leave the coefficients bit-reversed in limb-form scratch, the
-// decimation-in-time passes take them from there (scaling by (1/m) g^i on the way in) and write the natural-order result
-template <class Fr>
-int ntt_coset_pair_run(cg_ctx* ctx, int curve, void* const* d_vecs, int k, size_t n, const Fr& gen, const Fr& coset, size_t arena_off) {
-    const int log_m = log2_floor(n);
-    if (((size_t)1 << log_m) != n) return fail(CG_ERR_ARG, "NTT length must be a power of two");
-    if (k < 1 || k > NTT_MAX_VECS) return fail(CG_ERR_ARG, "k out of range");
-    if (n == 1) return 0;                                                       // both transforms and g^0 are the identity
-    const void* tw_inv = nullptr; const void* tw_fwd = nullptr;
-    int rc = get_twiddles_lazy<Fr>(ctx, curve, log_m, fp_inverse(gen), &tw_inv); if (rc) return rc;
-    rc = get_twiddles_lazy_natural<Fr>(ctx, curve, log_m, gen, &tw_fwd); if (rc) return rc;
-    Fr c32 = Fr::one(); for (int i = 0; i < 5; i++) c32 = c32 + c32;
-    uint32_t e[Fr::N] = {0}; e[log_m / 32] = 1u << (log_m % 32);
-    Fr nn; for (int i = 0; i < Fr::N; i++) nn.v[i] = e[i];
-    CosetTables ct;
-    rc = get_coset_tables<Fr>(ctx, curve, log_m, coset, c32 * fp_inverse(nn.to_mont()), &ct); if (rc) return rc;
-    NttVecs data{}, tmp{};
-    for (int j = 0; j < k; j++) { data.p[j] = d_vecs[j]; tmp.p[j] = ctx->ntt_arena.base + arena_off + (size_t)j * lazy29_bytes(n); }
-    hipStream_t st = ctx->stream;
-    static const int lazy_tile = [] { const char* e_ = tune_env("CG_NTT_TILE"); const int v = e_ ? atoi(e_) : NTT_TILE_LOG_LAZY; return std::min(NTT_TILE_LOG, std::max(8, v)); }();
-    const std::vector<NttPass> plan = ntt_plan(log_m, lazy_tile);
-    bool first = true;
-    for (const NttPass& p : plan) { rc = launch_ntt_ct_pass<Fr>(st, first, first ? data : tmp, tmp, k, n, log_m, p.s0, p.k, p.t, tw_inv); if (rc) return rc; first = false; }
-    for (size_t i = plan.size(); i-- > 0;) {
-        const NttPass& p = plan[i];
-        rc = launch_ntt_dit_pass<Fr>(st, i + 1 == plan.size(), i == 0, data, tmp, k, n, log_m, p.s0, p.k, p.t, tw_fwd, (const Fr*)ct.lo, (const Fr*)ct.hi, ct.log_lo, c32);
-        if (rc) return rc;
-    }
-    return 0;
-}
-
-template <class F> void copy_in(F& dst, const void* src) { memcpy(dst.v, src, sizeof dst.v); }
-
-}  // namespace
 
 template <int OP>
 int32_t vec_binary(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_a, const void* d_b, size_t n) {
@@ -1126,700 +94,6 @@ extern "C" {
 
 const char* cg_last_error(void) { return g_err.c_str(); }
 const char* cg_version(void) { return "cogroth16-hip 0.1 (gfx950)"; }
-
-// Creating a HIP stream costs 4-10 ms on this platform (measured), a context has three to five of them: streams of destroyed
-// contexts are parked per (device, priority class) and handed to the next context of the process (a prover that serves many proofs,
-// the test-suite) instead of being destroyed.  A parked stream is idle: cg_ctx_destroy synchronises it first.
-namespace {
-std::mutex g_stream_pool_mu;
-// cls: +1 high, 0 normal, -1 low.  The runtime keeps one set of (four) hardware queues per priority and hands a NEW stream the least used
-// queue of its set, so the k-th stream this library creates in a class sits on queue k mod 4 of that class (other users of the process
-// shift the numbering, not the spacing).  A queue serves its streams' packets in order — two busy streams on one queue wait for each
-// other — so which parked stream a new context gets matters: last-in-first-out handed a process's second session pairs of streams on
-// the same queue (a 2^22 resident step made after a session had come and gone: 70.6 ms against 66.3).  The pool therefore remembers each
-// stream's slot (creation number mod 4) and hands out the idle stream whose slot has the fewest streams checked out.
-constexpr int HWQ = 4;
-struct StreamClassPool { std::vector<std::pair<hipStream_t, int>> idle; int created = 0; int out[HWQ] = {0, 0, 0, 0}; };
-std::map<std::pair<int, int>, StreamClassPool> g_stream_pool;      // (device, priority class)
-std::map<hipStream_t, int> g_stream_slot;                         // every stream made here -> its slot
-// cg_stream_group_begin / _end (per thread): the contexts made in between belong to ONE party — within each priority class their streams
-// get slots of their own as long as the class has any left (the streams they then share a queue with belong to somebody else's, mostly
-// idle, contexts): a chain context's sort stream must not sit behind the bulk context's reduction batch and vice versa.
-thread_local int g_group_depth = 0;
-thread_local std::map<int, std::array<uint8_t, 3>> g_group_used_by_device;   // device -> [class + 1]: slots taken by the group so far
-#define g_group_used (g_group_used_by_device[device])
-int new_stream(int cls, hipStream_t* out) {
-    if (cls == 0) { HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking)); return 0; }
-    int prio_least = 0, prio_greatest = 0;                           // numerically: least >= greatest
-    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, cls > 0 ? prio_greatest : prio_least));
-    return 0;
-}
-// The queues of the three classes that carry the same index sit on one PIPE of the command processor, and streams on one pipe delay each other's
-// dispatches by ~25 us even across classes (scripts/queue_map.hip: 140 us for two 120 us spin kernels side by side, 165 on one pipe, 260 on one queue).
-// measured_pipe() finds the pipe of a new stream against idle reference streams (defined below, with the probe kernel); `want` asks for a stream on
-// a given pipe: a parked one, or new ones until one lands there (the others are parked for later).
-int measured_pipe(int device, int cls, hipStream_t st);
-thread_local int g_group_rot = 0;                                     // pipes of this thread's stream group are rotated by this (parties of one process differ)
-int pooled_stream(int device, int cls, hipStream_t* out, int want = -1) {
-    std::lock_guard<std::mutex> l(g_stream_pool_mu);
-    StreamClassPool& p = g_stream_pool[{device, cls}];
-    if (want >= 0 && cls >= -1 && cls <= 1) {
-        // (a pipe the group already uses in this class on this device — a second chain / bulk pair on the SAME device, as the tests' shared-device
-        // sessions make them — would be the same hardware queue: the next pipe the class has left)
-        if (g_group_depth > 0) for (int k = 0; k < HWQ && ((g_group_used[cls + 1] >> want) & 1u); k++) want = (want + 1) % HWQ;
-        for (int tries = 0; tries < 2 * HWQ; tries++) {
-            for (size_t i = 0; i < p.idle.size(); i++) if (p.idle[i].second == want) {
-                *out = p.idle[i].first; p.out[want]++; if (g_group_depth > 0) g_group_used[cls + 1] |= (uint8_t)(1u << want);
-                if (getenv("CG_DEBUG_STREAMS")) fprintf(stderr, "stream: class %d on pipe %d as asked (idle %zu)\n", cls, want, p.idle.size() - 1);
-                p.idle.erase(p.idle.begin() + i);
-                return 0;
-            }
-            hipStream_t st = nullptr;
-            if (int rc = new_stream(cls, &st)) return rc;
-            const int model = p.created++ % HWQ, seen = measured_pipe(device, cls, st);
-            if (seen < 0) { g_stream_slot[st] = model; p.idle.push_back({st, model}); break; }      // no map on this device: the choice below
-            g_stream_slot[st] = seen; p.idle.push_back({st, seen});
-        }
-    }
-    const bool grp = g_group_depth > 0 && cls >= -1 && cls <= 1;
-    uint8_t none = 0; uint8_t& used = grp ? g_group_used[cls + 1] : none;
-    const bool slots_left = grp && used != (1u << HWQ) - 1;
-    auto taken = [&](int slot) { return slots_left && ((used >> slot) & 1u); };
-    for (int tries = 0; tries <= HWQ; tries++) {
-        long best = -1;
-        for (size_t i = 0; i < p.idle.size(); i++) {
-            if (taken(p.idle[i].second)) continue;
-            if (best < 0 || p.out[p.idle[i].second] < p.out[p.idle[best].second]) best = (long)i;                     // (ties: the longest parked)
-        }
-        if (best >= 0) {
-            const int slot = p.idle[best].second;
-            *out = p.idle[best].first; p.out[slot]++; if (grp) used |= (uint8_t)(1u << slot);
-            if (getenv("CG_DEBUG_STREAMS")) fprintf(stderr, "stream: class %d slot %d (out %d %d %d %d, idle %zu%s)\n", cls, slot, p.out[0], p.out[1], p.out[2], p.out[3], p.idle.size() - 1, grp ? ", group" : "");
-            p.idle.erase(p.idle.begin() + best);
-            return 0;
-        }
-        hipStream_t st = nullptr;                                    // nothing suitable parked: a new stream joins the idle list and the choice is made again
-        if (int rc = new_stream(cls, &st)) return rc;
-        const int model = p.created++ % HWQ, seen = measured_pipe(device, cls, st);
-        const int slot = seen >= 0 ? seen : model;
-        g_stream_slot[st] = slot; p.idle.push_back({st, slot});
-    }
-    return fail(CG_ERR_HIP, "internal: stream pool");
-}
-void park_stream(int device, int cls, hipStream_t st) {
-    if (!st) return;
-    std::lock_guard<std::mutex> l(g_stream_pool_mu);
-    StreamClassPool& p = g_stream_pool[{device, cls}];
-    auto it = g_stream_slot.find(st);
-    if (it == g_stream_slot.end()) { hipStreamDestroy(st); return; }             // not one of ours
-    if (p.out[it->second] > 0) p.out[it->second]--;
-    if (p.idle.size() < 32) p.idle.push_back({st, it->second}); else { g_stream_slot.erase(it); hipStreamDestroy(st); }
-}
-int make_copy_streams(cg_ctx* c, int want_h2d = -1, int want_d2h = -1) {
-    { int rc = pooled_stream(c->device, c->prio_copy, &c->h2d, want_h2d); if (rc) return rc; }
-    { int rc = pooled_stream(c->device, c->prio_copy, &c->d2h, want_d2h); if (rc) return rc; }
-    HIPCHK(hipEventCreateWithFlags(&c->ev_copy_order, hipEventDisableTiming));
-    return 0;
-}
-}  // namespace
-
-// ---- which streams share a hardware queue?  Measured, not guessed.  The runtime maps streams onto a few hardware queues per priority class, and
-// two busy streams on one queue wait for each other's packets — in particular for each other's WAITS: a context whose reduction stream shares
-// a queue with its sort stream has the next schedule's kernels parked behind "wait for the accumulation" (the same small proof took 1.9 or
-// 3.7 ms from one session of a process to the next).  The slot bookkeeping of the pool above is a model of the runtime's choice; the probe is
-// the fact: two 120 us spin kernels, one per stream, started together — side by side they take 120 us, on one queue 240.
-__global__ void k_probe_spin(unsigned long long ticks) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) { } }
-namespace {
-bool streams_share_queue(hipStream_t a, hipStream_t b) {
-    if (!a || !b || a == b) return false;
-    double best = 1e9;
-    for (int rep = 0; rep < 2 && best > 190.0; rep++) {                          // (a second try settles a launch hiccup)
-        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return false; }
-        const auto t0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, 12000ull);     // wall_clock64 ticks at 100 MHz: 120 us
-        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, b, 12000ull);
-        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return false; }
-        best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
-    }
-    return best > 190.0 && best < 420.0;        // (far beyond 240 us: the device is busy with somebody else's work and the probe says nothing)
-}
-// ---- the pipe of a stream (see pooled_stream).  Per device, once: four idle reference streams of the low class and four of the high class, each set on
-// four different queues; the low set names the pipes, the high set is matched to it.  A new stream of the normal or high class is timed against the low
-// set, one of the low class against the high set: the one pair that takes ~165 us instead of ~140 names its pipe.  Anything inconsistent (another party's
-// work on the device, a runtime that maps differently) gives -1: the pool then falls back on its creation-order model.  CG_NO_PIPE_MAP: off.
-struct PipeRefs { hipStream_t low[HWQ] = {nullptr, nullptr, nullptr, nullptr}, high[HWQ] = {nullptr, nullptr, nullptr, nullptr}; bool ok = false; int attempts = 0; };
-std::map<int, PipeRefs> g_pipe_refs;
-std::mutex g_pipe_mu;
-double spin_pair_us(hipStream_t a, hipStream_t b) {
-    double best = 1e9;
-    for (int rep = 0; rep < 3; rep++) {
-        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
-        const auto t0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, 12000ull);
-        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, b, 12000ull);
-        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
-        best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
-    }
-    return best;
-}
-// index of the ONE reference the stream is coupled to (same pipe: >= 152 us; same queue, 260 us, counts as well), -1 if none or several
-int coupled_reference(const hipStream_t* refs, hipStream_t st) {
-    int found = -1;
-    for (int i = 0; i < HWQ; i++) {
-        const double us = spin_pair_us(refs[i], st);
-        if (us < 0 || us > 420.0) return -1;                                         // the device is busy: the probe says nothing
-        if (us >= 152.0) { if (found >= 0) return -1; found = i; }
-    }
-    return found;
-}
-int measured_pipe(int device, int cls, hipStream_t st) {
-    static const bool off = tune_env("CG_NO_PIPE_MAP") != nullptr || tune_env("CG_NO_STREAM_PROBE") != nullptr;
-    if (off || cls < -1 || cls > 1) return -1;
-    std::lock_guard<std::mutex> l(g_pipe_mu);
-    PipeRefs& r = g_pipe_refs[device];
-    if (!r.ok && r.attempts < 3) {                                                     // (an attempt made while somebody else's work held the device may fail: twice more, later)
-        r.attempts++;
-        for (hipStream_t& x : r.low) if (x) { hipStreamDestroy(x); x = nullptr; }
-        for (hipStream_t& x : r.high) if (x) { hipStreamDestroy(x); x = nullptr; }
-        bool ok = true;
-        for (int i = 0; i < HWQ && ok; i++) ok = new_stream(-1, &r.low[i]) == 0;
-        for (int i = 0; i < HWQ && ok; i++) ok = new_stream(1, &r.high[i]) == 0;
-        for (int i = 0; i < HWQ && ok; i++) for (int j = i + 1; j < HWQ && ok; j++) {   // each set on four different queues
-            const double a = spin_pair_us(r.low[i], r.low[j]), b = spin_pair_us(r.high[i], r.high[j]);
-            ok = a > 0 && a < 152.0 && b > 0 && b < 152.0;
-        }
-        hipStream_t matched[HWQ] = {nullptr, nullptr, nullptr, nullptr};
-        for (int j = 0; j < HWQ && ok; j++) {                                          // every high reference on the pipe of exactly one low reference, and all four used
-            const int pipe = coupled_reference(r.low, r.high[j]);
-            ok = pipe >= 0 && !matched[pipe];
-            if (ok) matched[pipe] = r.high[j];
-        }
-        if (ok) for (int i = 0; i < HWQ; i++) r.high[i] = matched[i];
-        r.ok = ok;
-        if (getenv("CG_DEBUG_STREAMS")) fprintf(stderr, "pipe map of device %d: %s\n", device, ok ? "references in place" : "not available (the pool keeps its creation-order model)");
-    }
-    if (!r.ok) return -1;
-    int pipe = coupled_reference(cls == -1 ? r.high : r.low, st);
-    if (pipe < 0) pipe = coupled_reference(cls == -1 ? r.high : r.low, st);             // (a second try settles a launch hiccup)
-    return pipe;
-}
-// make `moving` not share a queue with any of `fixed` (same priority class): streams that do are parked again and others tried
-thread_local std::vector<hipStream_t> g_group_busy[3];                        // [class + 1]: streams of the contexts made so far in this thread's stream group
-int separate_stream(int device, int cls, hipStream_t* moving, std::vector<hipStream_t> fixed) {
-    static const bool off = tune_env("CG_NO_STREAM_PROBE") != nullptr;            // A/B knob
-    if (off) return 0;
-    std::vector<hipStream_t> rejected;
-    for (int tries = 0; tries < 6; tries++) {
-        bool clash = false;
-        for (hipStream_t f : fixed) clash = clash || streams_share_queue(f, *moving);
-        if (!clash) break;
-        if (getenv("CG_DEBUG_STREAMS")) fprintf(stderr, "stream probe: class %d stream shares a hardware queue with another stream of its context: replaced (try %d)\n", cls, tries);
-        rejected.push_back(*moving);                                              // (kept out of the pool until the choice is made)
-        hipStream_t st = nullptr;
-        if (int rc = pooled_stream(device, cls, &st)) { for (hipStream_t r : rejected) park_stream(device, cls, r); return rc; }   // a parked stream first, a new one (4-10 ms) only when none is left
-        *moving = st;
-    }
-    for (hipStream_t r : rejected) park_stream(device, cls, r);
-    return 0;
-}
-}  // namespace
-
-int32_t cg_stream_group_begin(void) {
-    static std::atomic<int> groups{0};
-    if (g_group_depth++ == 0) { g_group_used_by_device.clear(); for (auto& v : g_group_busy) v.clear(); g_group_rot = groups.fetch_add(1) % HWQ; }
-    return 0;
-}
-int32_t cg_stream_group_end(void) { if (g_group_depth > 0) g_group_depth--; return 0; }
-int32_t cg_ctx_create(int32_t device, cg_ctx** out) { return cg_ctx_create_ex(device, 0, out); }
-// flags bit 0 ("chain"): for the context that carries a dependency chain (witness map with its party-to-party exchanges) while another
-// context of the same party keeps the chip full with independent bucket accumulations — main stream and copy streams (created here,
-// one after the other: three different hardware queues) get high priority, the side streams normal priority.
-// flags bit 1 ("bulk"): the context next to a chain context — main stream low priority, side streams normal: its kernels fill what
-// the chain leaves free and share no hardware queue with it.
-int32_t cg_ctx_create_ex(int32_t device, uint32_t flags, cg_ctx** out) {
-    if (!out) return fail(CG_ERR_ARG, "null out");
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
-        return fail(CG_ERR_NODEVICE, "no HIP device visible: this backend has no CPU fallback");
-    if (device < 0 || device >= count) return fail(CG_ERR_ARG, "device index out of range");
-    HIPCHK(hipSetDevice(device));
-    {   // the kernels are written for 64-lane wavefronts (ballots, shuffles across 64 lanes, LDS tiles sized per wave): refuse anything else loudly
-        int ws = 0; HIPCHK(hipDeviceGetAttribute(&ws, hipDeviceAttributeWarpSize, device));
-        if (ws != 64) return fail(CG_ERR_NODEVICE, "device " + std::to_string(device) + " has " + std::to_string(ws) + "-lane wavefronts: this backend is written for wave64 (gfx950)");
-    }
-    cg_ctx* c = new cg_ctx();
-    c->device = device;
-    {   // planning builds (-DCG_DEBUG_KNOBS) only: environment variables seed the option table of new contexts (cg_ctx_set_option is the release interface)
-        auto seed = [](const char* name, int lo, int hi, int& field) { if (const char* e = tune_env(name)) { const int v = atoi(e); if (v >= lo && v <= hi) field = v; } };
-        seed("CG_MSM_TABLE_ORDER", 0, 2, c->table_order); seed("CG_MSM_G2_AFTER", -1, 64, c->g2_after); seed("CG_MSM_G2_SLICES", 0, 1, c->g2_slices);
-        seed("CG_MSM_REDUCE_BATCH", 0, 3, c->red_batch); seed("CG_MSM_ACC_SLOTS", 2, cg_ctx::ACC_SLOTS_MAX, c->acc_slots); seed("CG_MSM_WIDE_SMALL", 0, 30, c->wide_small); seed("CG_MSM_ONE_STREAM_LOG", 0, 30, c->one_stream_log); seed("CG_MSM_OFF_MAIN_LOG", 0, 30, c->off_main_log); seed("CG_MSM_SOLO_LOG", 0, 30, c->solo_log);
-    }
-    if (flags & 1u) { c->prio_main = 1; c->prio_copy = 1; c->prio_side = 0; }
-    else if (flags & 2u) { static const int bulk_cls = tune_env("CG_BULK_CLASS") ? atoi(tune_env("CG_BULK_CLASS")) : -1; c->prio_main = bulk_cls; c->prio_side = 0; }   // CG_BULK_CLASS: tuning knob
-    // Inside a stream group (one party's contexts) every stream is asked for on a PIPE: the chain's main stream alone on one (the streams it shares it
-    // with is idle while it works: its own sort stream), the bulk context's main, sort and reduction streams on the three others — the reduction stream
-    // NOT on the pipe of the main stream, whose accumulations it runs beside at large sizes (one REP3 party, reduction stream on the main stream's pipe /
-    // on its own: 2^22 73.2, 72.3 / 71.5, 71.6 ms, 2^20 23.3, 23.5 / 23.1, 23.1) — the copy streams beside the sort and reduction streams.  A party with
-    // one context: main, aux and sort stream on three pipes.  (The first session of a process used to fall into this arrangement by the order in
-    // which its streams were created — a 2^16 party 2.9 ms — and later ones did not: 3.2-3.5 ms.)
-    const bool piped = g_group_depth > 0;
-    auto pipe = [&](int k) { return piped ? (k + g_group_rot) % HWQ : -1; };
-    const int w_main = (flags & 1u) ? pipe(0) : (flags & 2u) ? pipe(1) : pipe(0), w_aux = (flags & 1u) ? pipe(1) : (flags & 2u) ? pipe(3) : pipe(1), w_sort = (flags & 1u) ? pipe(0) : pipe(2);
-    const int w_join = (flags & 1u) ? pipe(3) : (flags & 2u) ? pipe(2) : pipe(3);
-    { int rc = pooled_stream(device, c->prio_main, &c->stream, w_main); if (rc) return rc; }
-    if (flags & 1u) { int rc = make_copy_streams(c, pipe(3), pipe(2)); if (rc) return rc; }
-    // the side streams carry short, latency-bound kernels the main stream's next accumulate waits for: let their workgroups
-    // jump the backlog of accumulate workgroups (one priority class above the main stream's, except next to a chain)
-    { int rc = pooled_stream(device, c->prio_side, &c->aux, w_aux); if (rc) return rc; }
-    { int rc = pooled_stream(device, c->prio_side, &c->sortst, w_sort); if (rc) return rc; }
-    // the work-free stream behind released blocks (cg_dev_free) is made here, not at the first release: inside a stream group it then gets a
-    // queue apart from a bulk context's low-priority main stream (its packets are waits for OTHER streams' progress: nothing may queue behind them)
-    { int rc = pooled_stream(device, -1, &c->joinst, w_join); if (rc) return rc; }
-    // the context's busy streams of one priority class on hardware queues of their own (measured, see streams_share_queue): the two side
-    // streams against each other and against whatever else of the context lives in their class; a chain context's copy streams against its main stream
-    // Inside a stream group (one party's chain + bulk contexts) the streams of the contexts made before count as well: a class has four
-    // hardware queues, a pair of contexts puts at most four streams into one class.
-    {
-        // one context at a time: three parties of one process make their contexts at the same moment, and two threads' spin kernels on one
-        // queue read as "shared" (or as "busy") for both
-        static std::mutex probe_mu;
-        std::lock_guard<std::mutex> probing(probe_mu);
-        const bool grp = g_group_depth > 0;
-        auto others = [&](int cls, std::initializer_list<hipStream_t> own) {
-            std::vector<hipStream_t> v;
-            for (hipStream_t o : own) if (o) v.push_back(o);
-            if (grp && cls >= -1 && cls <= 1) for (hipStream_t o : g_group_busy[cls + 1]) if (v.size() < (size_t)HWQ - 1) v.push_back(o);
-            return v;
-        };
-        auto placed = [&](int cls, hipStream_t st) { if (grp && cls >= -1 && cls <= 1) g_group_busy[cls + 1].push_back(st); };
-        if (int rc = separate_stream(device, c->prio_main, &c->stream, others(c->prio_main, {}))) return rc;
-        placed(c->prio_main, c->stream);
-        if (int rc = separate_stream(device, c->prio_side, &c->aux, others(c->prio_side, {c->prio_side == c->prio_main ? c->stream : nullptr}))) return rc;
-        placed(c->prio_side, c->aux);
-        if (int rc = separate_stream(device, c->prio_side, &c->sortst, others(c->prio_side, {c->aux, c->prio_side == c->prio_main ? c->stream : nullptr}))) return rc;
-        placed(c->prio_side, c->sortst);
-        if (c->h2d) {
-            if (int rc = separate_stream(device, c->prio_copy, &c->h2d, others(c->prio_copy, {c->prio_copy == c->prio_main ? c->stream : nullptr}))) return rc;
-            placed(c->prio_copy, c->h2d);
-            if (int rc = separate_stream(device, c->prio_copy, &c->d2h, others(c->prio_copy, {c->h2d, c->prio_copy == c->prio_main ? c->stream : nullptr}))) return rc;
-            placed(c->prio_copy, c->d2h);
-        }
-        // the work-free join stream carries only waits for the context's other streams: it must not sit in front of a BUSY stream of its class
-        // (a bulk context's low-priority main stream)
-        if (int rc = separate_stream(device, -1, &c->joinst, others(-1, {c->prio_main == -1 ? c->stream : nullptr}))) return rc;
-        placed(-1, c->joinst);                                                      // (a later busy stream of the group keeps off its queue as well)
-    }
-    for (hipEvent_t& e : c->park_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-    for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_sorted[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_sched_free[i], hipEventDisableTiming)); for (int rs = 0; rs < 2; rs++) HIPCHK(hipEventCreateWithFlags(&c->ev_merged[rs][i], hipEventDisableTiming)); }
-    for (int i = 0; i < cg_ctx::ACC_SLOTS_MAX; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming)); }
-    *out = c;
-    return 0;
-}
-int32_t cg_ctx_destroy(cg_ctx* ctx) {
-    if (!ctx) return 0;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    hipStreamSynchronize(ctx->aux);
-    hipStreamSynchronize(ctx->sortst);
-    for (int i = 0; i < cg_ctx::ACC_SLOTS_MAX; i++) { hipEventDestroy(ctx->ev_acc[i]); hipEventDestroy(ctx->ev_red[i]); }
-    for (hipEvent_t e : ctx->mark_ev) if (e) hipEventDestroy(e);
-    for (auto& d : ctx->rand_draw) { if (d.live) { cg_dev_free(ctx, d.d_cand); cg_dev_free(ctx, d.d_small); d.live = false; } if (d.ev) hipEventDestroy(d.ev); }   // (draws begun and never finished)
-    if (ctx->rand_result) hipHostFree(ctx->rand_result);
-    for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_sorted[i]); hipEventDestroy(ctx->ev_sched_free[i]); for (int rs = 0; rs < 2; rs++) hipEventDestroy(ctx->ev_merged[rs][i]); }
-    hipEventDestroy(ctx->ev_in);
-    if (ctx->h2d) {
-        hipStreamSynchronize(ctx->h2d); hipStreamSynchronize(ctx->d2h);
-        for (hipEvent_t e : ctx->copy_ev) if (e) hipEventDestroy(e);
-        if (ctx->ev_peer) hipEventDestroy(ctx->ev_peer);
-        hipEventDestroy(ctx->ev_copy_order);
-        park_stream(ctx->device, ctx->prio_copy, ctx->h2d); park_stream(ctx->device, ctx->prio_copy, ctx->d2h);
-    }
-    park_stream(ctx->device, ctx->prio_side, ctx->aux);
-    park_stream(ctx->device, ctx->prio_side, ctx->sortst);
-    if (ctx->joinst) { hipStreamSynchronize(ctx->joinst); for (hipEvent_t e : ctx->park_ev) if (e) hipEventDestroy(e); park_stream(ctx->device, -1, ctx->joinst); }
-    for (auto& kv : ctx->twiddles) shared_twiddles_release(ctx->device, kv.first);
-    for (auto& kv : ctx->cosets) { hipFree(kv.second.lo); hipFree(kv.second.hi); }
-    for (auto& t : ctx->tickets) { if (t.h_pinned) hipHostFree(t.h_pinned); if (t.h_flags) hipHostFree(t.h_flags); if (t.done) hipEventDestroy(t.done); }
-    if (ctx->arena.base) hipFree(ctx->arena.base);
-    if (ctx->ntt_arena.base) hipFree(ctx->ntt_arena.base);
-    if (ctx->solo_arena.base) hipFree(ctx->solo_arena.base);
-    for (void* p : ctx->retired) hipFree(p);
-    if (ctx->gather_buf) hipFree(ctx->gather_buf);
-    for (auto& p : ctx->ev_live) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
-    for (auto& p : ctx->ev_free) { if (p.a) hipEventDestroy(p.a); if (p.b) hipEventDestroy(p.b); }
-    if (ctx->owns_stream) park_stream(ctx->device, ctx->prio_main, ctx->stream);
-    delete ctx;
-    return 0;
-}
-int32_t cg_ctx_sync(cg_ctx* ctx) {
-    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
-    HIPCHK(hipStreamSynchronize(ctx->sortst)); HIPCHK(hipStreamSynchronize(ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->aux));
-    if (ctx->h2d) { HIPCHK(hipStreamSynchronize(ctx->h2d)); HIPCHK(hipStreamSynchronize(ctx->d2h)); }
-    return 0;
-}
-void* cg_ctx_stream(cg_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
-int32_t cg_ctx_set_stream(cg_ctx* ctx, void* hip_stream) {
-    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
-    HIPCHK(hipStreamSynchronize(ctx->sortst));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->aux));
-    if (ctx->owns_stream) park_stream(ctx->device, ctx->prio_main, ctx->stream);
-    ctx->stream = (hipStream_t)hip_stream;
-    ctx->owns_stream = false;
-    return 0;
-}
-
-// ---- device blocks.  hipFree waits for every stream of the device (measured: a prover freeing its witness-map vectors stalled for
-// 25 ms behind another context's MSM), so blocks released with cg_dev_free are parked per device with an event recorded behind the
-// work of the releasing context's streams and handed out again, to any context of the device, once that event has completed — from
-// then on nothing enqueued before the release can touch the block.  CG_DEV_CACHE_MB bounds the parked bytes per device (default 32768,
-// 0 = release at once); when an allocation fails the parked blocks are released and it is tried again.
-namespace {
-// the release mark of one cg_dev_free / cg_dev_free_many call: one event behind the context's streams, shared by every block of the call
-struct ReleaseMark { hipEvent_t ev; int refs; };
-struct ParkedBlock { void* p; ReleaseMark* mark; };
-struct DevCache {
-    std::mutex mu;
-    std::multimap<size_t, ParkedBlock> parked; size_t parked_bytes = 0;
-    std::map<void*, size_t> live;                        // blocks handed out by cg_dev_alloc -> rounded size
-    std::vector<hipEvent_t> spare;
-    unsigned long long n_hit = 0, n_pending = 0, n_fresh = 0, n_sync_free = 0;   // CG_DEBUG_ALLOC: reuse / same size parked but still busy / nothing of that size / releases that took the synchronising path
-};
-DevCache& dev_cache(int device) {
-    static std::mutex mu; static std::map<int, DevCache*> m;
-    std::lock_guard<std::mutex> l(mu);
-    DevCache*& c = m[device]; if (!c) c = new DevCache(); return *c;
-}
-size_t dev_cache_cap() { static const size_t cap = [] { const char* e = getenv("CG_DEV_CACHE_MB"); return (e ? (size_t)atoll(e) : (size_t)32768) << 20; }(); return cap; }
-size_t dev_round(size_t bytes) { const size_t q = bytes >= (64u << 10) ? 4096 : 256; return (std::max<size_t>(bytes, 16) + q - 1) / q * q; }
-void mark_unref(DevCache& dc, ReleaseMark* m) { if (--m->refs == 0) { dc.spare.push_back(m->ev); delete m; } }   // caller holds dc.mu
-void dev_cache_flush(DevCache& dc) {                     // caller holds dc.mu
-    for (auto& kv : dc.parked) { (void)hipFree(kv.second.p); mark_unref(dc, kv.second.mark); }
-    dc.parked.clear(); dc.parked_bytes = 0;
-}
-}  // namespace
-extern "C++" hipError_t hip_malloc_flush(void** p, size_t bytes) {
-    hipError_t e = hipMalloc(p, bytes);
-    if (e != hipErrorOutOfMemory) return e;
-    int d = 0;
-    if (hipGetDevice(&d) != hipSuccess) return e;
-    DevCache& dc = dev_cache(d);
-    std::lock_guard<std::mutex> l(dc.mu);
-    if (dc.parked.empty()) return e;
-    (void)hipGetLastError();
-    dev_cache_flush(dc);
-    return hipMalloc(p, bytes);
-}
-int32_t cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** d_ptr) {
-    if (!ctx || !d_ptr) return fail(CG_ERR_ARG, "null argument");
-    HIPCHK(hipSetDevice(ctx->device));
-    const size_t rb = dev_round(bytes);
-    DevCache& dc = dev_cache(ctx->device);
-    std::lock_guard<std::mutex> l(dc.mu);
-    auto range = dc.parked.equal_range(rb);
-    bool pending = false; auto first_pending = range.second;
-    for (auto it = range.first; it != range.second; ++it) {
-        if (hipEventQuery(it->second.mark->ev) != hipSuccess) { (void)hipGetLastError(); if (!pending) first_pending = it; pending = true; continue; }
-        *d_ptr = it->second.p; mark_unref(dc, it->second.mark); dc.parked.erase(it); dc.parked_bytes -= rb; dc.live[*d_ptr] = rb;
-        dc.n_hit++;
-        return 0;
-    }
-    // SMALL blocks whose size is parked but still behind its release mark: give the mark a moment (at most 40 us of polling) before asking the
-    // runtime for a new block.  When the next proof of a small circuit asks for the same sizes again the mark stands behind the tail of the
-    // previous proof, a few tens of microseconds of work, and hipMalloc costs 100-200 us (a Poseidon-sized party took that path 1.5 times per
-    // proof).  The wait is BOUNDED: a mark may just as well stand behind tens of milliseconds of another context's accumulations (an
-    // unbounded wait made a four-device 2^18 proof 155 ms).
-    if (pending && rb <= ((size_t)1 << 20)) {
-        const auto t0 = std::chrono::steady_clock::now();
-        while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(40)) {
-            if (hipEventQuery(first_pending->second.mark->ev) == hipSuccess) {
-                *d_ptr = first_pending->second.p; mark_unref(dc, first_pending->second.mark); dc.parked.erase(first_pending); dc.parked_bytes -= rb; dc.live[*d_ptr] = rb;
-                dc.n_hit++;
-                return 0;
-            }
-        }
-    }
-    (void)hipGetLastError();
-    if (pending) dc.n_pending++; else dc.n_fresh++;
-    hipError_t e = hipMalloc(d_ptr, rb);
-    if (e == hipErrorOutOfMemory && !dc.parked.empty()) { (void)hipGetLastError(); dev_cache_flush(dc); e = hipMalloc(d_ptr, rb); }
-    HIPCHK(e);
-    dc.live[*d_ptr] = rb;
-    return 0;
-}
-int32_t cg_dev_cache_trim(int32_t device, size_t* bytes) {
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return fail(CG_ERR_ARG, "device index out of range");
-    HIPCHK(hipSetDevice(device));
-    DevCache& dc = dev_cache(device);
-    std::lock_guard<std::mutex> l(dc.mu);
-    if (bytes) *bytes = dc.parked_bytes;
-    if (getenv("CG_DEBUG_ALLOC")) { fprintf(stderr, "dev cache: %llu reused, %llu found their size parked but busy, %llu found nothing parked, %llu synchronising releases; %zu MB parked\n", dc.n_hit, dc.n_pending, dc.n_fresh, dc.n_sync_free, dc.parked_bytes >> 20); dc.n_hit = dc.n_pending = dc.n_fresh = dc.n_sync_free = 0; }
-    dev_cache_flush(dc);
-    return 0;
-}
-int32_t cg_dev_free(cg_ctx* ctx, void* d_ptr) { return cg_dev_free_many(ctx, &d_ptr, 1); }
-// Several blocks released at one point of the context's work share ONE release mark: the join of the context's streams (an event
-// recorded on each, a wait for each on the work-free stream, the mark behind it) costs eleven runtime calls whatever the number of blocks —
-// a proof that gives back twenty vectors one by one spent 0.5 ms of host time on it, an eight-device proof 4 ms.
-int32_t cg_dev_free_many(cg_ctx* ctx, void* const* d_ptrs, size_t n) {
-    if (!ctx || (n && !d_ptrs)) return fail(CG_ERR_ARG, "null argument");
-    HIPCHK(hipSetDevice(ctx->device));
-    DevCache& dc = dev_cache(ctx->device);
-    std::unique_lock<std::mutex> l(dc.mu);
-    std::vector<std::pair<void*, size_t>> park_list; std::vector<void*> sync_list;
-    size_t parked_after = dc.parked_bytes;
-    for (size_t i = 0; i < n; i++) {
-        void* p = d_ptrs[i];
-        if (!p) continue;
-        auto it = dc.live.find(p);
-        const size_t rb = it == dc.live.end() ? 0 : it->second;
-        if (it != dc.live.end()) dc.live.erase(it);
-        if (!rb || parked_after + rb > dev_cache_cap()) { sync_list.push_back(p); dc.n_sync_free++; }   // not one of ours, or no room to park it: the synchronising release
-        else { park_list.push_back({p, rb}); parked_after += rb; }
-    }
-    // The blocks' last users may sit on any of the context's streams.  None of them is made to wait for another (a chain context's main
-    // stream must not queue behind its pending copies): a stream of the context that carries no work (`joinst`, low priority) waits for
-    // the five, and ONE event behind it marks the blocks as free (an event per stream and block ran the runtime out of signals).
-    // The blocks have left `live`: whatever fails from here on, they are released the synchronising way instead of being lost.
-    auto park = [&]() -> bool {
-        if (park_list.empty()) return true;
-        if (!ctx->joinst) {
-            if (pooled_stream(ctx->device, -1, &ctx->joinst)) return false;
-            for (hipEvent_t& e : ctx->park_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
-        }
-        int i = 0;
-        for (hipStream_t st : {ctx->stream, ctx->aux, ctx->sortst, ctx->h2d, ctx->d2h}) {
-            if (st && (!ctx->park_ev[i] || hipEventRecord(ctx->park_ev[i], st) != hipSuccess || hipStreamWaitEvent(ctx->joinst, ctx->park_ev[i], 0) != hipSuccess)) return false;
-            i++;
-        }
-        hipEvent_t ev = nullptr;
-        if (!dc.spare.empty()) { ev = dc.spare.back(); dc.spare.pop_back(); } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
-        if (hipEventRecord(ev, ctx->joinst) != hipSuccess) { dc.spare.push_back(ev); return false; }
-        ReleaseMark* m = new ReleaseMark{ev, (int)park_list.size()};
-        for (auto& pr : park_list) { dc.parked.insert({pr.second, ParkedBlock{pr.first, m}}); dc.parked_bytes += pr.second; }
-        return true;
-    };
-    if (!park()) { (void)hipGetLastError(); for (auto& pr : park_list) sync_list.push_back(pr.first); }
-    l.unlock();
-    if (!sync_list.empty()) {
-        HIPCHK(hipDeviceSynchronize());
-        for (void* p : sync_list) HIPCHK(hipFree(p));
-    }
-    return 0;
-}
-int32_t cg_dev_upload(cg_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
-    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
-    HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return 0;
-}
-int32_t cg_dev_download(cg_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
-    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
-    HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return 0;
-}
-// ---- page-locked staging and asynchronous copies (the mul_vec / degree_reduce exchanges move in chunks under the compute)
-// Page-locking and releasing host memory is slow (measured: hipHostMalloc of a 32 MB exchange ring 8 ms, hipHostFree 11-14 ms, each
-// proof of a session used to pay both twice): released blocks are parked by size and handed out again.  CG_HOST_CACHE_MB bounds the
-// parked bytes (default 2048, 0 = release at once).  The caller releases a block only when no copy uses it any more, as before.
-namespace {
-struct HostCache { std::mutex mu; std::multimap<size_t, void*> parked; size_t parked_bytes = 0; std::map<void*, size_t> live; };
-HostCache& host_cache() { static HostCache* c = new HostCache(); return *c; }
-size_t host_cache_cap() { static const size_t cap = [] { const char* e = getenv("CG_HOST_CACHE_MB"); return (e ? (size_t)atoll(e) : (size_t)2048) << 20; }(); return cap; }
-}  // namespace
-int32_t cg_host_alloc(size_t bytes, void** h_ptr) {
-    if (!h_ptr) return fail(CG_ERR_ARG, "null argument");
-    const size_t rb = (std::max<size_t>(bytes, 16) + 4095) / 4096 * 4096;
-    HostCache& hc = host_cache();
-    {
-        std::lock_guard<std::mutex> l(hc.mu);
-        auto it = hc.parked.find(rb);
-        if (it != hc.parked.end()) { *h_ptr = it->second; hc.parked.erase(it); hc.parked_bytes -= rb; hc.live[*h_ptr] = rb; return 0; }
-    }
-    hipError_t e = hipHostMalloc(h_ptr, rb, hipHostMallocDefault);
-    if (e != hipSuccess) {                                  // make room and try once more
-        (void)hipGetLastError();
-        std::vector<void*> drop;
-        { std::lock_guard<std::mutex> l(hc.mu); for (auto& kv : hc.parked) drop.push_back(kv.second); hc.parked.clear(); hc.parked_bytes = 0; }
-        for (void* p : drop) (void)hipHostFree(p);
-        e = hipHostMalloc(h_ptr, rb, hipHostMallocDefault);
-    }
-    HIPCHK(e);
-    std::lock_guard<std::mutex> l(hc.mu);
-    hc.live[*h_ptr] = rb;
-    return 0;
-}
-int32_t cg_host_free(void* h_ptr) {
-    if (!h_ptr) return 0;
-    HostCache& hc = host_cache();
-    {
-        std::lock_guard<std::mutex> l(hc.mu);
-        auto it = hc.live.find(h_ptr);
-        if (it != hc.live.end()) {
-            const size_t rb = it->second; hc.live.erase(it);
-            if (hc.parked_bytes + rb <= host_cache_cap()) { hc.parked.insert({rb, h_ptr}); hc.parked_bytes += rb; return 0; }
-        }
-    }
-    HIPCHK(hipHostFree(h_ptr));
-    return 0;
-}
-int32_t cg_host_is_pinned(const void* h_ptr) {
-    if (!h_ptr) return 0;
-    hipPointerAttribute_t a{};
-    if (hipPointerGetAttributes(&a, h_ptr) != hipSuccess) { (void)hipGetLastError(); return 0; }   // ordinary pageable memory is unknown to the runtime
-    return a.type == hipMemoryTypeHost ? 1 : 0;
-}
-static int32_t copy_begin(cg_ctx* ctx, bool up, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, bool after_stream, int32_t* ticket, hipEvent_t after_mark = nullptr) {
-    if (!ctx || !ticket || ((!dst || !src) && bytes)) return fail(CG_ERR_ARG, "null argument");
-    HIPCHK(hipSetDevice(ctx->device));
-    if (!ctx->h2d) { int rc = make_copy_streams(ctx); if (rc) return rc; }   // the copy streams exist from the first asynchronous copy on
-    hipStream_t st = up ? ctx->h2d : ctx->d2h;
-    if (after_mark) HIPCHK(hipStreamWaitEvent(st, after_mark, 0));       // behind a marked point of the stream order, not behind its tail
-    else if (after_stream) {                                     // everything enqueued on the context's stream so far comes first
-        HIPCHK(hipEventRecord(ctx->ev_copy_order, ctx->stream));
-        HIPCHK(hipStreamWaitEvent(st, ctx->ev_copy_order, 0));
-    }
-    if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, kind, st));
-    const uint32_t id = ctx->copy_next++ & 0x7fffffffu, slot = id % cg_ctx::COPY_TICKETS;
-    if (!ctx->copy_ev[slot]) HIPCHK(hipEventCreateWithFlags(&ctx->copy_ev[slot], hipEventDisableTiming));
-    else HIPCHK(hipEventSynchronize(ctx->copy_ev[slot]));     // the copy that owned the slot 256 copies ago (long finished in practice)
-    HIPCHK(hipEventRecord(ctx->copy_ev[slot], st));
-    ctx->copy_id[slot] = id;
-    *ticket = (int32_t)id;
-    return 0;
-}
-int32_t cg_dev_download_begin(cg_ctx* ctx, void* h_dst_pinned, const void* d_src, size_t bytes, int32_t* ticket) {
-    return copy_begin(ctx, false, h_dst_pinned, d_src, bytes, hipMemcpyDeviceToHost, true, ticket);
-}
-int32_t cg_stream_mark(cg_ctx* ctx, int32_t* mark) {
-    if (!ctx || !mark) return fail(CG_ERR_ARG, "null argument");
-    HIPCHK(hipSetDevice(ctx->device));
-    const uint32_t id = ctx->mark_next++ & 0x7fffffffu, slot = id % cg_ctx::MARKS;
-    if (!ctx->mark_ev[slot]) HIPCHK(hipEventCreateWithFlags(&ctx->mark_ev[slot], hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ctx->mark_ev[slot], ctx->stream));
-    *mark = (int32_t)id;
-    return 0;
-}
-int32_t cg_dev_download_begin_after(cg_ctx* ctx, void* h_dst_pinned, const void* d_src, size_t bytes, int32_t mark, int32_t* ticket) {
-    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
-    if (mark < 0 || (uint32_t)mark >= ctx->mark_next || ctx->mark_next - (uint32_t)mark > (uint32_t)cg_ctx::MARKS || !ctx->mark_ev[mark % cg_ctx::MARKS]) return fail(CG_ERR_ARG, "bad or expired stream mark");
-    return copy_begin(ctx, false, h_dst_pinned, d_src, bytes, hipMemcpyDeviceToHost, false, ticket, ctx->mark_ev[mark % cg_ctx::MARKS]);
-}
-int32_t cg_dev_upload_begin(cg_ctx* ctx, void* d_dst, const void* h_src_pinned, size_t bytes, int32_t after_stream, int32_t* ticket) {
-    return copy_begin(ctx, true, d_dst, h_src_pinned, bytes, hipMemcpyHostToDevice, after_stream != 0, ticket);
-}
-int32_t cg_copy_wait(cg_ctx* ctx, int32_t ticket) {
-    if (!ctx || ticket < 0 || !ctx->copy_ev[ticket % cg_ctx::COPY_TICKETS]) return fail(CG_ERR_ARG, "bad copy ticket");
-    const int slot = ticket % cg_ctx::COPY_TICKETS;
-    if (ctx->copy_id[slot] != (uint32_t)ticket) return 0;       // recycled since: that copy completed before the slot was reused
-    HIPCHK(hipEventSynchronize(ctx->copy_ev[slot]));
-    return 0;
-}
-int32_t cg_copy_fence(cg_ctx* ctx, int32_t ticket) {
-    if (!ctx || ticket < 0 || !ctx->copy_ev[ticket % cg_ctx::COPY_TICKETS]) return fail(CG_ERR_ARG, "bad copy ticket");
-    const int slot = ticket % cg_ctx::COPY_TICKETS;
-    if (ctx->copy_id[slot] != (uint32_t)ticket) return 0;       // recycled since: that copy completed before the slot was reused
-    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->copy_ev[slot], 0));
-    return 0;
-}
-// device -> device between two contexts (same or different GPUs): enqueued on the destination context's stream behind everything the
-// source context's stream holds so far.  Different devices: peer access is switched on at first use (xGMI), hipMemcpyPeerAsync.
-int32_t cg_dev_copy_peer(cg_ctx* dst, void* d_dst, cg_ctx* src, const void* d_src, size_t bytes) {
-    if (!dst || !src || ((!d_dst || !d_src) && bytes)) return fail(CG_ERR_ARG, "null argument");
-    if (!src->ev_peer) { HIPCHK(hipSetDevice(src->device)); HIPCHK(hipEventCreateWithFlags(&src->ev_peer, hipEventDisableTiming)); }
-    HIPCHK(hipSetDevice(src->device));
-    HIPCHK(hipEventRecord(src->ev_peer, src->stream));
-    HIPCHK(hipSetDevice(dst->device));
-    HIPCHK(hipStreamWaitEvent(dst->stream, src->ev_peer, 0));
-    if (!bytes) return 0;
-    if (dst->device == src->device) { HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, dst->stream)); return 0; }
-    {
-        static std::mutex mu; static std::set<std::pair<int, int>> enabled;
-        std::lock_guard<std::mutex> l(mu);
-        if (!enabled.count({dst->device, src->device})) {
-            int can = 0; HIPCHK(hipDeviceCanAccessPeer(&can, dst->device, src->device));
-            if (can) { hipError_t e = hipDeviceEnablePeerAccess(src->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCHK(e); (void)hipGetLastError(); }
-            enabled.insert({dst->device, src->device});      // without peer access the runtime stages the copy through the host
-        }
-    }
-    HIPCHK(hipMemcpyPeerAsync(d_dst, dst->device, d_src, src->device, bytes, dst->stream));
-    return 0;
-}
-int32_t cg_ctx_device(const cg_ctx* ctx) { return ctx ? ctx->device : -1; }
-int32_t cg_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
-// First contact with a multi-GPU node (VERDICT r5 #4c): before a session spreads a party over `n` devices — and before a benchmark prints
-// a number for them — prove that they ARE n GPUs and that every pair moves data correctly: distinct PCI bus ids, peer access, and one 1 MiB
-// peer copy per ordered pair whose contents are compared word for word with the pattern the source was filled with (pattern = f(src, dst,
-// index), so a copy that silently came from the wrong device fails too).  `report` (optional) receives one JSON object: bus ids, peer
-// access and the copy rate of every pair.  flags: CG_PREFLIGHT_ALLOW_SHARED lets a device appear more than once (one-GPU tests: such
-// pairs are local copies and say so); CG_PREFLIGHT_ALLOW_STAGED accepts pairs without peer access (copies staged through the host).
-__global__ void k_preflight_fill(uint32_t* p, uint32_t n, uint32_t seed) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = (i * 2654435761u) ^ seed;
-}
-int32_t cg_device_preflight(const int32_t* devices, int32_t n, uint32_t flags, char* report, size_t report_cap) {
-    if (!devices || n < 1 || n > 64) return fail(CG_ERR_ARG, "cg_device_preflight: bad device list");
-    int have = 0; HIPCHK(hipGetDeviceCount(&have));
-    std::vector<std::string> bus((size_t)n);
-    for (int i = 0; i < n; i++) {
-        if (devices[i] < 0 || devices[i] >= have) return fail(CG_ERR_ARG, "cg_device_preflight: device " + std::to_string(devices[i]) + " does not exist (" + std::to_string(have) + " visible)");
-        char id[64] = {0}; HIPCHK(hipDeviceGetPCIBusId(id, sizeof id, devices[i])); bus[i] = id;
-    }
-    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++)
-        if ((devices[i] == devices[j] || bus[i] == bus[j]) && !(flags & CG_PREFLIGHT_ALLOW_SHARED))
-            return fail(CG_ERR_ARG, "cg_device_preflight: entries " + std::to_string(i) + " and " + std::to_string(j) + " of the device list are the SAME GPU (device " + std::to_string(devices[i]) + " / " +
-                                    std::to_string(devices[j]) + ", PCI " + bus[i] + "): a party's devices must be distinct");
-    const uint32_t words = 1u << 18;                                               // 1 MiB
-    struct Block { int dev; void* p = nullptr; ~Block() { if (p) { hipSetDevice(dev); hipFree(p); } } };
-    std::string js = "{\"devices\":[";
-    for (int i = 0; i < n; i++) js += std::string(i ? "," : "") + "{\"device\":" + std::to_string(devices[i]) + ",\"pci\":\"" + bus[i] + "\"}";
-    js += "],\"pairs\":[";
-    std::vector<uint32_t> back(words);
-    bool first = true;
-    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) {
-        if (i == j) continue;
-        const int sd = devices[i], dd = devices[j];
-        const bool local = sd == dd;
-        int can = 1;
-        if (!local) {
-            HIPCHK(hipDeviceCanAccessPeer(&can, dd, sd));
-            if (!can && !(flags & CG_PREFLIGHT_ALLOW_STAGED)) return fail(CG_ERR_HIP, "cg_device_preflight: device " + std::to_string(dd) + " has no peer access to device " + std::to_string(sd) + " (no xGMI / P2P path)");
-            if (can) { HIPCHK(hipSetDevice(dd)); hipError_t e = hipDeviceEnablePeerAccess(sd, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCHK(e); (void)hipGetLastError(); }
-        }
-        Block src{sd}, dst{dd};
-        const uint32_t seed = 0x9e3779b9u * (uint32_t)(i * 64 + j + 1);
-        HIPCHK(hipSetDevice(sd)); HIPCHK(hipMalloc(&src.p, words * 4));
-        hipLaunchKernelGGL(k_preflight_fill, dim3(words / 256), dim3(256), 0, 0, (uint32_t*)src.p, words, seed);
-        HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
-        HIPCHK(hipSetDevice(dd)); HIPCHK(hipMalloc(&dst.p, words * 4)); HIPCHK(hipMemset(dst.p, 0, words * 4)); HIPCHK(hipDeviceSynchronize());
-        hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-        HIPCHK(hipEventRecord(e0, 0));
-        if (local) HIPCHK(hipMemcpyAsync(dst.p, src.p, words * 4, hipMemcpyDeviceToDevice, 0));
-        else HIPCHK(hipMemcpyPeerAsync(dst.p, dd, src.p, sd, words * 4, 0));
-        HIPCHK(hipEventRecord(e1, 0)); HIPCHK(hipEventSynchronize(e1));
-        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); hipEventDestroy(e0); hipEventDestroy(e1);
-        HIPCHK(hipMemcpy(back.data(), dst.p, words * 4, hipMemcpyDeviceToHost));
-        uint64_t bad = 0, sum = 0;
-        for (uint32_t w = 0; w < words; w++) { bad += back[w] != ((w * 2654435761u) ^ seed); sum += back[w]; }
-        if (bad) return fail(CG_ERR_HIP, "cg_device_preflight: the 1 MiB copy from device " + std::to_string(sd) + " to device " + std::to_string(dd) + " arrived with " + std::to_string(bad) + " wrong words");
-        char line[256];
-        snprintf(line, sizeof line, "%s{\"src\":%d,\"dst\":%d,\"peer_access\":%s,\"same_gpu\":%s,\"copy_us\":%.1f,\"GBs\":%.2f,\"checksum\":%llu}", first ? "" : ",", sd, dd, can ? "true" : "false",
-                 local ? "true" : "false", ms * 1e3, words * 4 / (ms * 1e-3) / 1e9, (unsigned long long)sum);
-        js += line; first = false;
-    }
-    js += "]}";
-    if (report && report_cap) { strncpy(report, js.c_str(), report_cap - 1); report[report_cap - 1] = 0; }
-    return 0;
-}
-int32_t cg_dev_memset_zero(cg_ctx* ctx, void* d_dst, size_t bytes) {
-    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
-    HIPCHK(hipMemsetAsync(d_dst, 0, bytes, ctx->stream));
-    return 0;
-}
 
 // ---------------------------------------------------------------------------------------------------- bases / MSM
 static int32_t bases_register_impl(cg_ctx* ctx, int32_t curve, int32_t group, const void* src, bool src_on_device, size_t n, size_t stride, int64_t inf_off, cg_bases** out) {
@@ -2033,18 +307,6 @@ int32_t cg_bases_download(cg_ctx* ctx, const cg_bases* bases, size_t offset, siz
     return 0;
 }
 
-int32_t cg_msm_set_scatter_capacity(cg_ctx* ctx, int32_t cap) {
-    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
-    if (cap > 65536) return fail(CG_ERR_ARG, "capacity out of range");
-    ctx->scatter_cap = cap;
-    return 0;
-}
-int32_t cg_msm_set_chunk(cg_ctx* ctx, int32_t entries_per_lane) {
-    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
-    if (entries_per_lane < 0 || entries_per_lane > 4096) return fail(CG_ERR_ARG, "chunk length out of range");
-    ctx->msm_chunk = (uint32_t)entries_per_lane;
-    return 0;
-}
 int32_t cg_ctx_set_option(cg_ctx* ctx, int32_t option, int64_t value) {
     if (!ctx) return fail(CG_ERR_ARG, "null ctx");
     switch (option) {
@@ -2091,92 +353,6 @@ int32_t cg_get_option(int32_t option, int64_t* value) {
     if (option < 1 || option >= CG_GOPT_COUNT || !value) return fail(CG_ERR_ARG, "cg_get_option: unknown option");
     *value = g_options.v[option].load(); return 0;
 }
-int32_t cg_msm_set_window(cg_ctx* ctx, int32_t c) {
-    if (!ctx) return fail(CG_ERR_ARG, "null ctx");
-    if (c != 0 && (c < 2 || c > 20)) return fail(CG_ERR_ARG, "window size must be 0 (auto) or in [2, 20]");
-    ctx->msm_window = c;
-    return 0;
-}
-int32_t cg_msm_scalars_after(cg_ctx* ctx, int32_t component, cg_ctx* owner, int32_t copy_ticket) {
-    if (!ctx || !owner || component < 0 || component >= 4) return fail(CG_ERR_ARG, "bad argument");
-    if (copy_ticket < 0 || !owner->copy_ev[copy_ticket % cg_ctx::COPY_TICKETS]) return fail(CG_ERR_ARG, "bad copy ticket");
-    const int slot = copy_ticket % cg_ctx::COPY_TICKETS;
-    ctx->comp_after[component] = owner->copy_id[slot] == (uint32_t)copy_ticket ? owner->copy_ev[slot] : nullptr;   // recycled: completed long ago
-    return 0;
-}
-int32_t cg_msm_dev_begin(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* d_scalars, int32_t k, int32_t* ticket) {
-    const int rc = msm_begin_impl(ctx, bases, offset, n, d_scalars, k, ticket);
-    if (ctx) for (hipEvent_t& e : ctx->comp_after) e = nullptr;
-    return rc;
-}
-int32_t cg_msm_dev_begin_multi(cg_ctx* ctx, int32_t n_tables, const cg_bases* const* bases, const size_t* offsets, size_t n,
-                               const void* const* d_scalars, int32_t k, int32_t* tickets) {
-    const int rc = msm_begin_multi_impl(ctx, n_tables, bases, offsets, n, d_scalars, k, tickets);
-    if (ctx) for (hipEvent_t& e : ctx->comp_after) e = nullptr;
-    return rc;
-}
-int32_t cg_msm_end(cg_ctx* ctx, int32_t ticket, void* h_out_jacobian) { return msm_end_impl(ctx, ticket, h_out_jacobian); }
-int32_t cg_msm_dev(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* d_scalars, int32_t k, void* h_out) {
-    int32_t t = -1;
-    int rc = msm_begin_impl(ctx, bases, offset, n, d_scalars, k, &t);
-    if (rc) return rc;
-    return msm_end_impl(ctx, t, h_out);
-}
-int32_t cg_msm(cg_ctx* ctx, const cg_bases* bases, size_t offset, size_t n, const void* const* h_scalars, int32_t k, void* h_out) {
-    if (!ctx || !bases || !h_scalars) return fail(CG_ERR_ARG, "null argument");
-    if (k < 1 || k > 8) return fail(CG_ERR_ARG, "k out of range");
-    HIPCHK(hipSetDevice(ctx->device));
-    std::vector<void*> d(k, nullptr);
-    const size_t bytes = std::max<size_t>(n * 32, 16);
-    for (int j = 0; j < k; j++) {
-        HIPCHK(hip_malloc_flush(&d[j], bytes));
-        if (n) HIPCHK(hipMemcpyAsync(d[j], h_scalars[j], n * 32, hipMemcpyHostToDevice, ctx->stream));
-    }
-    int rc = cg_msm_dev(ctx, bases, offset, n, (const void* const*)d.data(), k, h_out);
-    hipStreamSynchronize(ctx->stream);
-    for (int j = 0; j < k; j++) hipFree(d[j]);
-    return rc;
-}
-
-// ---------------------------------------------------------------------------------------------------- NTT
-int32_t cg_ntt_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, int32_t k, size_t n, const void* h_group_gen, int32_t inverse, const void* h_coset_gen) {
-    if (!ctx || !d_vecs || !h_group_gen) return fail(CG_ERR_ARG, "null argument");
-    HIPCHK(hipSetDevice(ctx->device));
-    return with_fr(curve, [&](auto tag) -> int {
-        typedef decltype(tag) Fr;
-        Fr gen, cos; copy_in(gen, h_group_gen);
-        if (h_coset_gen) copy_in(cos, h_coset_gen);
-        if (n > 1) { int rc = ensure_ntt_arena(ctx, (size_t)k * lazy29_bytes(n)); if (rc) return rc; }
-        StatScope ss(ctx, TAG_NTT);
-        return ntt_run<Fr>(ctx, curve, d_vecs, k, n, gen, inverse != 0, h_coset_gen ? &cos : nullptr, 0);
-    });
-}
-int32_t cg_ntt_coset_pair_dev(cg_ctx* ctx, int32_t curve, void* const* d_vecs, int32_t k, size_t n, const void* h_group_gen, const void* h_coset_gen) {
-    if (!ctx || !d_vecs || !h_group_gen || !h_coset_gen) return fail(CG_ERR_ARG, "null argument");
-    HIPCHK(hipSetDevice(ctx->device));
-    static const bool two_calls = tune_env("CG_NTT_NO_PAIR") != nullptr;         // A/B knob: the two separate transforms
-    if (two_calls) { int rc = cg_ntt_dev(ctx, curve, d_vecs, k, n, h_group_gen, 1, h_coset_gen); return rc ? rc : cg_ntt_dev(ctx, curve, d_vecs, k, n, h_group_gen, 0, nullptr); }
-    return with_fr(curve, [&](auto tag) -> int {
-        typedef decltype(tag) Fr;
-        Fr gen, cos; copy_in(gen, h_group_gen); copy_in(cos, h_coset_gen);
-        if (n > 1) { int rc = ensure_ntt_arena(ctx, (size_t)k * lazy29_bytes(n)); if (rc) return rc; }
-        StatScope ss(ctx, TAG_NTT);
-        return ntt_coset_pair_run<Fr>(ctx, curve, d_vecs, k, n, gen, cos, 0);
-    });
-}
-int32_t cg_ntt(cg_ctx* ctx, int32_t curve, void* const* h_vecs, int32_t k, size_t n, const void* h_group_gen, int32_t inverse, const void* h_coset_gen) {
-    if (!ctx || !h_vecs) return fail(CG_ERR_ARG, "null argument");
-    if (k < 1 || k > NTT_MAX_VECS) return fail(CG_ERR_ARG, "k out of range");
-    HIPCHK(hipSetDevice(ctx->device));
-    std::vector<void*> d(k, nullptr);
-    for (int j = 0; j < k; j++) { HIPCHK(hip_malloc_flush(&d[j], std::max<size_t>(n * 32, 16))); HIPCHK(hipMemcpyAsync(d[j], h_vecs[j], n * 32, hipMemcpyHostToDevice, ctx->stream)); }
-    int rc = cg_ntt_dev(ctx, curve, d.data(), k, n, h_group_gen, inverse, h_coset_gen);
-    if (!rc) for (int j = 0; j < k; j++) { hipError_t e = hipMemcpyAsync(h_vecs[j], d[j], n * 32, hipMemcpyDeviceToHost, ctx->stream); if (e != hipSuccess) rc = fail(CG_ERR_HIP, hipGetErrorString(e)); }
-    hipStreamSynchronize(ctx->stream);
-    for (int j = 0; j < k; j++) hipFree(d[j]);
-    return rc;
-}
-
 // ---------------------------------------------------------------------------------------------------- vector ops
 int32_t cg_vec_add_dev(cg_ctx* ctx, int32_t curve, void* o, const void* a, const void* b, size_t n) { return vec_binary<0>(ctx, curve, o, a, b, n); }
 int32_t cg_vec_sub_dev(cg_ctx* ctx, int32_t curve, void* o, const void* a, const void* b, size_t n) { return vec_binary<1>(ctx, curve, o, a, b, n); }
@@ -2280,21 +456,6 @@ int32_t cg_vec_check_canonical_dev(cg_ctx* ctx, int32_t curve, const void* d_vec
         typedef decltype(tag) Fr;
         StatScope ss(ctx, TAG_VEC);
         return launch_vec_count_noncanonical<Fr>(ctx->stream, (const Fr*)d_vec, n, (unsigned long long*)d_count);
-    });
-}
-int32_t cg_vec_distribute_powers_dev(cg_ctx* ctx, int32_t curve, void* d_v, size_t n, const void* h_g, const void* h_c) {
-    if (!ctx || !d_v || !h_g || !h_c) return fail(CG_ERR_ARG, "null argument");
-    HIPCHK(hipSetDevice(ctx->device));
-    if (n == 0) return 0;
-    return with_fr(curve, [&](auto tag) -> int {
-        typedef decltype(tag) Fr;
-        Fr g, c; copy_in(g, h_g); copy_in(c, h_c);
-        int log_m = log2_floor(n); if (((size_t)1 << log_m) < n) log_m++;
-        CosetTables t;
-        int rc = get_coset_tables<Fr>(ctx, curve, log_m, g, c, &t);
-        if (rc) return rc;
-        StatScope ss(ctx, TAG_VEC);
-        return launch_distribute_powers<Fr>(ctx->stream, (Fr*)d_v, n, (const Fr*)t.lo, (const Fr*)t.hi, t.log_lo);
     });
 }
 int32_t cg_vec_affine_dev(cg_ctx* ctx, int32_t curve, void* d_out, const void* d_a, size_t n, const void* h_c, const void* h_d) {
