@@ -617,7 +617,7 @@ def entry_leg(ctx, log_m, device, proofs, warmup, curve=None, extras=True, barri
         else:
             t0 = time.perf_counter(); cg.host_synth_circuit(curve, log_m, 0xC0C1C0DE, zp, wp, device=device.index); t_gen = time.perf_counter() - t0
         pre = int(os.environ["BENCH_PRECOMPUTE"]) if os.environ.get("BENCH_PRECOMPUTE") else True      # A/B knob (scripts/): window of the precomputed tables, 0 = none
-        t0 = time.perf_counter(); ses = cg.ProvingSession(curve, zp, precompute=pre, device=device.index, devices=devs, shared_devices=len(set(devs)) < len(devs)); t_open = time.perf_counter() - t0
+        t0 = time.perf_counter(); ses = cg.ProvingSession(curve, zp, precompute=pre, device=device.index, devices=devs, shared_devices=bool(devs) and len(set(devs)) < len(devs)); t_open = time.perf_counter() - t0
         zkey_bytes = os.path.getsize(zp)
         w = cg.host_read_wtns(curve, wp)
         info = cg.host_zkey_info(curve, zp)

@@ -667,7 +667,7 @@ def host_set_zkey_validation(on):
 
 
 # process-wide options of the host library (include/cogroth16_host.h: cgh_set_option)
-HOST_OPT_XCHG_ASYNC_MIN, HOST_OPT_DEVICE_MASKS_MIN, HOST_OPT_XCHG_COPY_STREAM_MIN, HOST_OPT_SECOND_CONTEXT_MIN_LOG, HOST_OPT_DISTRIBUTED_MAP, HOST_OPT_ONE_CONTEXT, HOST_OPT_SPLIT_FIRST_MSM_MIN = 1, 2, 3, 4, 5, 6, 7
+HOST_OPT_XCHG_ASYNC_MIN, HOST_OPT_DEVICE_MASKS_MIN, HOST_OPT_XCHG_COPY_STREAM_MIN, HOST_OPT_SECOND_CONTEXT_MIN_LOG, HOST_OPT_DISTRIBUTED_MAP, HOST_OPT_ONE_CONTEXT, HOST_OPT_SPLIT_FIRST_MSM_MIN, HOST_OPT_CTX_WIDE_LOG, HOST_OPT_CTX_OFF_MAIN_LOG, HOST_OPT_CTX_SOLO_LOG = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 
 def host_set_option(option, value):

@@ -124,7 +124,7 @@ struct HostOptions {
         v[CGH_OPT_SECOND_CONTEXT_MIN_LOG].store(15);
         v[CGH_OPT_DISTRIBUTED_MAP].store(1);
         v[CGH_OPT_ONE_CONTEXT].store(0);
-        v[CGH_OPT_SPLIT_FIRST_MSM_MIN].store((int64_t)1 << 21);
+        v[CGH_OPT_SPLIT_FIRST_MSM_MIN].store(0);                 // measured SLOWER (2^22: 73.4 against 70.9 ms, 2^20 23.7 / 23.1, 2^24 280.5 / 278.2; profiles/r06_split_first_msm_ab.txt): off
     }
 };
 inline HostOptions g_host_options;

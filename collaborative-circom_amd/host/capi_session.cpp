@@ -39,6 +39,9 @@ struct cgh_session {
         static const uint32_t chain_flag = cgh::tune_env("CGH_CHAIN_FLAG") ? (uint32_t)atoi(cgh::tune_env("CGH_CHAIN_FLAG")) : 1u;     // tuning knobs (scripts/party_knobs_ab.sh)
         static const uint32_t bulk_flag = cgh::tune_env("CGH_BULK_FLAG") ? (uint32_t)atoi(cgh::tune_env("CGH_BULK_FLAG")) : 2u;
         cg_ctx* c = nullptr; if (cg_ctx_create_ex(devices[slot], chain ? chain_flag : (bulk_second ? bulk_flag : 0u), &c)) cgh::die("cg_ctx_create");
+        if (const int64_t w = cgh::host_option(CGH_OPT_CTX_WIDE_LOG)) cg_ctx_set_option(c, CG_OPT_MSM_WIDE_SMALL, w);
+        if (const int64_t o = cgh::host_option(CGH_OPT_CTX_OFF_MAIN_LOG)) cg_ctx_set_option(c, CG_OPT_MSM_OFF_MAIN_LOG, o);
+        if (const int64_t o = cgh::host_option(CGH_OPT_CTX_SOLO_LOG)) cg_ctx_set_option(c, CG_OPT_MSM_SOLO_LOG, o);
         { std::lock_guard<std::mutex> l(mu); serial[c] = next_serial++; }
         return c;
     }

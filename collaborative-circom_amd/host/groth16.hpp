@@ -259,8 +259,23 @@ static bool validate_by_default() {
 }
 struct DeviceZKeyGuard;
 static void release_zkey(cg_ctx* ctx, DeviceZKey& d);
-// slice `rank` of `world` of a range of n items (sizes differ by at most one)
+// Slice `rank` of `world` of a range of n items.  Devices of a party are NOT equally loaded: the six vector pipelines of the witness map
+// (iNTT -> coset shift -> NTT of a.a, a.b, b.a, b.b, c.a, c.b) run one per device on device (v + 1) mod world (DistributedWitnessMap::owner),
+// each worth ~1 % of the proof's MSM work (emulated 8-device REP3 party at 2^22: owners 13.6-14.1 ms, the two devices without a pipeline
+// 13.0-13.1, profiles/r06_multigpu_inlibrary_emulation.txt).  A device's share of every sliced range — its MSM table slices and its rows
+// of the witness map — is therefore 1/world of (1 + PIPE * 6) minus PIPE per pipeline it owns (VERDICT r5 #4b).  Small ranges (fewer
+// than 2^16 items) are cut evenly: sizes then differ by at most one and empty slices only appear when there are fewer items than devices.
+static constexpr double PIPELINE_SHARE = 0.01;
+static int pipelines_owned(int rank, int world) { int c = 0; for (int v = 0; v < 6; v++) c += (v + 1) % world == rank; return c; }
 static std::pair<size_t, size_t> slice_of(size_t n, int rank, int world) {
+    if (world > 1 && n >= ((size_t)1 << 16)) {
+        auto upto = [&](int r) {                                                     // items of ranks 0 .. r-1
+            double share = 0;
+            for (int d = 0; d < r; d++) share += (1.0 + PIPELINE_SHARE * 6) / world - PIPELINE_SHARE * pipelines_owned(d, world);
+            return r >= world ? n : std::min(n, (size_t)(share * (double)n) / 64 * 64);
+        };
+        return {upto(rank), upto(rank + 1)};
+    }
     const size_t base = n / world, rem = n % world, lo = (size_t)rank * base + std::min<size_t>((size_t)rank, rem);
     return {lo, lo + base + ((size_t)rank < rem ? 1 : 0)};
 }

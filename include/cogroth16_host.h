@@ -52,10 +52,16 @@ int32_t cgh_set_zkey_validation(int32_t on);
  *   CGH_OPT_DISTRIBUTED_MAP          multi-device sessions spread the witness map over the devices (read per proof);        1
  *                                    0 = the whole map on the primary device (round-2 layout)
  *   CGH_OPT_ONE_CONTEXT              1 = one context per proof (no second context for the witness-independent MSMs)         0
- *   CGH_OPT_SPLIT_FIRST_MSM_MIN      private-witness elements from which a page-locked witness goes up with component a in  2^21
- *                                    two pieces and the first aux MSM starts on the first piece (HipDriver::msm_begin_aux_split); 0 = never */
+ *   CGH_OPT_SPLIT_FIRST_MSM_MIN      private-witness elements from which a page-locked witness goes up with component a in  0
+ *                                    two pieces and the first aux MSM starts on the first piece (HipDriver::msm_begin_aux_split); 0 = never
+ *                                    (the default: measured slower on MI355X at 2^20 .. 2^24 — two more schedules and bucket sets cost
+ *                                    more than the ~1.6 ms of idle chip they fill)
+ *   CGH_OPT_CTX_WIDE_LOG             CG_OPT_MSM_WIDE_SMALL of the contexts a session makes from now on (0 = the library's default)   0
+ *   CGH_OPT_CTX_OFF_MAIN_LOG         CG_OPT_MSM_OFF_MAIN_LOG of those contexts (0 = the library's default)                           0
+ *   CGH_OPT_CTX_SOLO_LOG             CG_OPT_MSM_SOLO_LOG of those contexts (0 = the library's default)                               0 */
 enum { CGH_OPT_XCHG_ASYNC_MIN = 1, CGH_OPT_DEVICE_MASKS_MIN = 2, CGH_OPT_XCHG_COPY_STREAM_MIN = 3, CGH_OPT_SECOND_CONTEXT_MIN_LOG = 4,
-       CGH_OPT_DISTRIBUTED_MAP = 5, CGH_OPT_ONE_CONTEXT = 6, CGH_OPT_SPLIT_FIRST_MSM_MIN = 7, CGH_OPT_COUNT = 8 };
+       CGH_OPT_DISTRIBUTED_MAP = 5, CGH_OPT_ONE_CONTEXT = 6, CGH_OPT_SPLIT_FIRST_MSM_MIN = 7, CGH_OPT_CTX_WIDE_LOG = 8, CGH_OPT_CTX_OFF_MAIN_LOG = 9,
+       CGH_OPT_CTX_SOLO_LOG = 10, CGH_OPT_COUNT = 11 };
 int32_t cgh_set_option(int32_t option, int64_t value);
 int32_t cgh_get_option(int32_t option, int64_t* value);
 /* witness.rs:51-91: n values in Montgomery form; out == NULL: only *n */

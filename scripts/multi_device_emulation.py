@@ -32,8 +32,11 @@ a, b, c = pin(host(da)), pin(host(db)), pin(host(dc))
 streams = [pin(host(bench.rand_fr(2 * m + 4, dev, g))) for _ in range(3)]
 del da, db, dc, dw
 tag = ", additive-quotient variant" if additive else ""
+for name, opt in (("WIDE_LOG", cg.HOST_OPT_CTX_WIDE_LOG), ("OFF_MAIN_LOG", cg.HOST_OPT_CTX_OFF_MAIN_LOG)):     # A/B: session contexts' wide / off-main bounds
+    if os.environ.get(name): cg.host_set_option(opt, int(os.environ[name])); tag += f", {name}={os.environ[name]}"
+if os.environ.get("PRECOMPUTE"): tag += f", window {os.environ['PRECOMPUTE']}"
 for world in worlds:
-    ses = cg.ProvingSession(cg.BN254, zp, precompute=True, devices=[0] * world, shared_devices=True, validate=False, additive_h=additive)
+    ses = cg.ProvingSession(cg.BN254, zp, precompute=int(os.environ.get('PRECOMPUTE', 0)) or True, devices=[0] * world, shared_devices=True, validate=False, additive_h=additive)
     plain, party = [], []
     only = os.environ.get("EMU_DEVICES")                      # e.g. EMU_DEVICES=7 under rocprofv3: the trace then ends with device 7's REP3 party
     for d in ([int(x) for x in only.split(",")] if only else range(world)):
