@@ -4,7 +4,9 @@
     /root/reference/co-circom/co-circom/examples/groth16/test_vectors/{kyc/bn254, kyc/bls12, poseidon, sum_arrays, multiplier2}
     /root/reference/test_vectors/benches/poseidon_hash2/bn254/groth16/poseidon.zkey      (byte-identical to examples/.../poseidon/poseidon.zkey)
 
-into tests/golden/groth16/<curve>/<circuit>/{circuit.zkey, verification_key.json, witness.wtns}.  The zkey and verification key are copied
+into tests/golden/groth16/<curve>/<circuit>/{circuit.zkey, verification_key.json, witness.wtns}, and the PLONK keys of the same example circuits
+(co-circom/co-circom/examples/plonk/test_vectors/{kyc/bn254, kyc/bls12, multiplier2, sum_arrays}: zkey + verification key as shipped, the
+circuit's witness as above — a circom witness does not depend on the proof system) into tests/golden/plonk/<curve>/<circuit>/.  The zkey and verification key are copied
 as shipped.  A witness ships only for kyc/bls12 and poseidon; for the others it is DERIVED here from the shipped .r1cs and the example's own
 input.json by propagating the constraints (one unknown wire at a time), and for kyc/bn254 by taking the field-independent small values
 (inputs, comparator bits) of the shipped BLS12-381 witness of the same circuit and solving the field-dependent wires (the IsZero inverses)
@@ -19,7 +21,9 @@ import sys
 
 REF = "/root/reference"
 EX = os.path.join(REF, "co-circom/co-circom/examples/groth16/test_vectors")
+EXP = os.path.join(REF, "co-circom/co-circom/examples/plonk/test_vectors")
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "groth16")
+OUTP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plonk")
 
 
 def sections(b, magic):
@@ -109,15 +113,15 @@ def solve(r, known):
     return [w[i] for i in range(r["n_wires"])]
 
 
-def put(curve, circuit, zkey, vk, prime, witness, origin):
-    d = os.path.join(OUT, curve, circuit)
+def put(curve, circuit, zkey, vk, prime, witness, origin, out=None):
+    d = os.path.join(out or OUT, curve, circuit)
     os.makedirs(d, exist_ok=True)
     shutil.copyfile(zkey, os.path.join(d, "circuit.zkey"))
     shutil.copyfile(vk, os.path.join(d, "verification_key.json"))
     write_wtns(os.path.join(d, "witness.wtns"), prime, witness)
     with open(os.path.join(d, "ORIGIN.json"), "w") as f:
         json.dump(origin, f, indent=1); f.write("\n")
-    print(f"{curve}/{circuit}: {len(witness)} wires, witness {origin['witness']}")
+    print(f"{'plonk' if out else 'groth16'} {curve}/{circuit}: {len(witness)} wires, witness {origin['witness']}")
 
 
 def main():
@@ -131,6 +135,9 @@ def main():
     assert satisfied(r, w) and w[1] == int(inp["a"]) * int(inp["b"]) % p
     put("bn254", "multiplier2_example", f"{EX}/multiplier2/multiplier2.zkey", f"{EX}/multiplier2/verification_key.json", p, w,
         {"zkey": "examples/groth16/test_vectors/multiplier2/multiplier2.zkey (as shipped)", "witness": "derived from multiplier2.r1cs + input.json (a = 3, b = -11)"})
+    assert open(f"{EXP}/multiplier2/multiplier2.r1cs", "rb").read() == open(f"{EX}/multiplier2/multiplier2.r1cs", "rb").read()
+    put("bn254", "multiplier2_example", f"{EXP}/multiplier2/multiplier2.zkey", f"{EXP}/multiplier2/verification_key.json", p, w,
+        {"zkey": "examples/plonk/test_vectors/multiplier2/multiplier2.zkey (as shipped)", "witness": "derived from multiplier2.r1cs + input.json (a = 3, b = -11)"}, OUTP)
     # -- sum_arrays (main {public [b, c]} = Main(3)): the optimiser removed every (linear) constraint and the unused a[]: wires 1, b[0..2], c[0..2]
     r = read_r1cs(f"{EX}/sum_arrays/sum_arrays.r1cs"); p = r["prime"]
     inp = json.load(open(f"{EX}/sum_arrays/input.json"))
@@ -140,6 +147,9 @@ def main():
     put("bn254", "sum_arrays", f"{EX}/sum_arrays/sum_arrays.zkey", f"{EX}/sum_arrays/verification_key.json", p, w,
         {"zkey": "examples/groth16/test_vectors/sum_arrays/sum_arrays.zkey (as shipped; 0 constraints, 6 public inputs, no private wire)",
          "witness": "derived from sum_arrays.r1cs + input.json (every wire is a public input)"})
+    assert open(f"{EXP}/sum_arrays/sum_arrays.r1cs", "rb").read() == open(f"{EX}/sum_arrays/sum_arrays.r1cs", "rb").read()
+    put("bn254", "sum_arrays", f"{EXP}/sum_arrays/sum_arrays.zkey", f"{EXP}/sum_arrays/verification_key.json", p, w,
+        {"zkey": "examples/plonk/test_vectors/sum_arrays/sum_arrays.zkey (as shipped)", "witness": "derived from sum_arrays.r1cs + input.json (every wire is a public input)"}, OUTP)
     # -- poseidon (examples) = the criterion bench's key (tests/benches/poseidon_hash2.rs:175-223): zkey + witness as shipped
     r = read_r1cs(f"{EX}/poseidon/poseidon.r1cs")
     p, w = read_wtns(f"{EX}/poseidon/witness.wtns")
@@ -154,6 +164,9 @@ def main():
     assert p381 == r["prime"] and satisfied(r, w381)
     put("bls12_381", "kyc", f"{EX}/kyc/bls12/kyc.zkey", f"{EX}/kyc/bls12/verification_key.json", p381, w381,
         {"zkey": "examples/groth16/test_vectors/kyc/bls12/kyc.zkey (as shipped)", "witness": "examples/groth16/test_vectors/kyc/bls12/witness.wtns (as shipped; satisfies kyc.r1cs)"})
+    assert read_wtns(f"{EXP}/kyc/bls12/witness.wtns") == (p381, w381)
+    put("bls12_381", "kyc", f"{EXP}/kyc/bls12/kyc.zkey", f"{EXP}/kyc/bls12/verification_key.json", p381, w381,
+        {"zkey": "examples/plonk/test_vectors/kyc/bls12/kyc.zkey (as shipped)", "witness": "examples/plonk/test_vectors/kyc/bls12/witness.wtns (as shipped)"}, OUTP)
     # -- kyc on BN254: no witness ships.  Same circuit, same input.json: the small values of the BLS12-381 witness (inputs, comparator bits) are
     # field-independent; the two IsZero inverses that are not 1 are solved from the BN254 constraints
     r = read_r1cs(f"{EX}/kyc/bn254/kyc.r1cs"); p = r["prime"]
@@ -165,6 +178,9 @@ def main():
     put("bn254", "kyc", f"{EX}/kyc/bn254/kyc.zkey", f"{EX}/kyc/bn254/verification_key.json", p, w,
         {"zkey": "examples/groth16/test_vectors/kyc/bn254/kyc.zkey (as shipped)",
          "witness": "derived: small (field-independent) wires of the shipped BLS12-381 witness of the same circuit and input.json; wires 7, 8 (IsZero inverses) solved from kyc/bn254/kyc.r1cs"})
+    assert open(f"{EXP}/kyc/bn254/kyc.r1cs", "rb").read() == open(f"{EX}/kyc/bn254/kyc.r1cs", "rb").read()
+    put("bn254", "kyc", f"{EXP}/kyc/bn254/kyc.zkey", f"{EXP}/kyc/bn254/verification_key.json", p, w,
+        {"zkey": "examples/plonk/test_vectors/kyc/bn254/kyc.zkey (as shipped)", "witness": "derived as for the Groth16 fixture of the same circuit (tests/golden/groth16/bn254/kyc)"}, OUTP)
 
 
 if __name__ == "__main__":
