@@ -4,6 +4,7 @@ sources as the device code) agree with the oracle."""
 import ctypes
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -185,3 +186,40 @@ def test_host_fr_ops_match_oracle(curve):
     np.testing.assert_array_equal(cg.fr_op(curve, "add", p1, one), zero)
     np.testing.assert_array_equal(cg.fr_op(curve, "sub", zero, one), p1)
     np.testing.assert_array_equal(cg.fr_op(curve, "mul", p1, p1), one)
+
+
+def test_process_wide_options_round_trip_and_refuse_unknown_ids():
+    """cg_set_option / cgh_set_option (the homes of what used to be environment variables): defaults as documented in the headers, values
+    round-trip, unknown options and out-of-range values are errors, not silent no-ops.  No device needed."""
+    ensure_built()
+    assert [cg.get_option(o) for o in (cg.GOPT_SUBGROUP_FULL, cg.GOPT_COMPACT_MIN_LOG, cg.GOPT_SORT_STAGING, cg.GOPT_SORT_SMALL, cg.GOPT_MSM_STAGED_OUT)] == [0, 14, 1, 1, 0]
+    cg.set_option(cg.GOPT_COMPACT_MIN_LOG, 64); assert cg.get_option(cg.GOPT_COMPACT_MIN_LOG) == 64
+    cg.set_option(cg.GOPT_COMPACT_MIN_LOG, 14)
+    for bad in ((0, 1), (99, 1), (cg.GOPT_SUBGROUP_FULL, 2), (cg.GOPT_SORT_SMALL, -1), (cg.GOPT_COMPACT_MIN_LOG, 65)):
+        with pytest.raises(cg.BackendError):
+            cg.set_option(*bad)
+    defaults = {cg.HOST_OPT_XCHG_ASYNC_MIN: 1 << 17, cg.HOST_OPT_DEVICE_MASKS_MIN: 1 << 11, cg.HOST_OPT_XCHG_COPY_STREAM_MIN: 1 << 14, cg.HOST_OPT_SECOND_CONTEXT_MIN_LOG: 15,
+                cg.HOST_OPT_DISTRIBUTED_MAP: 1, cg.HOST_OPT_ONE_CONTEXT: 0, cg.HOST_OPT_SPLIT_FIRST_MSM_MIN: 0, cg.HOST_OPT_CTX_WIDE_LOG: 0, cg.HOST_OPT_CTX_OFF_MAIN_LOG: 0,
+                cg.HOST_OPT_CTX_SOLO_LOG: 0}
+    for opt, want in defaults.items():
+        assert cg.host_get_option(opt) == want, opt
+    with cg.host_options({cg.HOST_OPT_XCHG_ASYNC_MIN: 4096}):
+        assert cg.host_get_option(cg.HOST_OPT_XCHG_ASYNC_MIN) == 4096
+    assert cg.host_get_option(cg.HOST_OPT_XCHG_ASYNC_MIN) == 1 << 17
+    for bad in ((0, 1), (len(defaults) + 1, 1), (cg.HOST_OPT_ONE_CONTEXT, -1)):
+        with pytest.raises(cg.BackendError):
+            cg.host_set_option(*bad)
+
+
+def test_planning_build_of_the_host_library_holds_the_knobs():
+    """`make -C collaborative-circom_amd/host KNOBS=1` (what scripts/multi_device_emulation.py needs) still builds, exports the same entry points and is
+    the one place where CGH_EMULATE_DEVICE and the A/B knobs exist"""
+    ensure_built()
+    host_dir = os.path.join(ROOT, "collaborative-circom_amd", "host")
+    subprocess.run(["make", "-C", host_dir, "KNOBS=1", "-j4"], check=True, capture_output=True)
+    knobs = os.path.join(ROOT, "collaborative-circom_amd", "libcogroth16_host_knobs.so")
+    blob = open(knobs, "rb").read()
+    for name in (b"CGH_EMULATE_DEVICE", b"CGH_BULK_CHUNK", b"CGH_G2_AFTER"):
+        assert name in blob, name
+    sym = lambda path: sorted(set(re.findall(r"\bT (cgh_[a-z0-9_]+)$", subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout, flags=re.M)))
+    assert sym(knobs) == sym(cg.HOST_LIB_PATH if not os.environ.get("COGROTH16_HOST_LIB") else os.path.join(ROOT, "collaborative-circom_amd", "libcogroth16_host.so"))
