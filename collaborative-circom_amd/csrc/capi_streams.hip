@@ -110,14 +110,28 @@ extern "C" {
 // the fact: two 120 us spin kernels, one per stream, started together — side by side they take 120 us, on one queue 240.
 __global__ void k_probe_spin(unsigned long long ticks) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) { } }
 namespace {
+// 120 us in ticks of wall_clock64 ON THE CURRENT DEVICE: the rate comes from the runtime (hipDeviceAttributeWallClockRate, kHz; 100 MHz on
+// MI355X today) instead of being assumed — the probes' thresholds below are in microseconds of host time
+unsigned long long probe_ticks() {
+    static std::atomic<unsigned long long> cached[64] = {};
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 12000ull; }
+    unsigned long long t = cached[dev].load(std::memory_order_relaxed);
+    if (!t) {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+        t = (unsigned long long)khz * 120ull / 1000ull;
+        cached[dev].store(t, std::memory_order_relaxed);
+    }
+    return t;
+}
 bool streams_share_queue(hipStream_t a, hipStream_t b) {
     if (!a || !b || a == b) return false;
     double best = 1e9;
     for (int rep = 0; rep < 2 && best > 190.0; rep++) {                          // (a second try settles a launch hiccup)
         if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return false; }
         const auto t0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, 12000ull);     // wall_clock64 ticks at 100 MHz: 120 us
-        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, b, 12000ull);
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, probe_ticks());  // 120 us
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, b, probe_ticks());
         if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return false; }
         best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     }
@@ -135,8 +149,8 @@ double spin_pair_us(hipStream_t a, hipStream_t b) {
     for (int rep = 0; rep < 3; rep++) {
         if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
         const auto t0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, 12000ull);
-        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, b, 12000ull);
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, probe_ticks());
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, b, probe_ticks());
         if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
         best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     }
