@@ -128,3 +128,23 @@ def test_party_entry_on_a_validated_session_of_the_examples(curve_name, circuit)
     finally:
         for x in rands: x.close()
         hub.close(); ses.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_name,circuit", EXAMPLES)
+def test_shamir_parties_on_the_examples(curve_name, circuit):
+    """co-circom's second protocol (examples/groth16/run_full_kyc_shamir_bls.sh, run_full_poseidon_shamir.sh): three Shamir parties, threshold 1, on the
+    example circuits == the oracle's Shamir proofs, verifying under the shipped keys"""
+    ensure_built()
+    curve = CURVES[curve_name]
+    z = orc.ZKey(curve, fx(curve_name, circuit, "circuit.zkey")); w = orc.read_wtns(curve, fx(curve_name, circuit, "witness.wtns"))
+    rng = np.random.default_rng(33)
+    n, t = 3, 1
+    wits = orc.shamir_share(curve, w[z.n_public + 1:], n, t, rng)
+    need = (2 * z.domain_size + 4) // (1024 * (t + 1)) + 1
+    streams = [orc.random_field(curve, FR, need * 1024 * (1 + 3 * t) + t * (2 * z.domain_size + 8), rng) for _ in range(n)]
+    want = orc.prove_shamir(z, n, t, w[:z.n_public + 1], wits, streams)
+    got = cg.prove_shamir(curve, fx(curve_name, circuit, "circuit.zkey"), n, t, w[:z.n_public + 1], wits, streams)
+    np.testing.assert_array_equal(got, want)
+    vk = orc.vk_from_json(curve, fx(curve_name, circuit, "verification_key.json"))
+    assert orc.verify(curve, vk, w[1:1 + z.n_public], want[0])
