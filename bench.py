@@ -508,7 +508,7 @@ def compact_line(out, detail_path):
         line["speedup_vs_cpu_baseline"] = {k: _r(v) for k, v in sp.items()} if isinstance(sp, dict) else _r(sp)
     if isinstance(out.get("preflight"), dict):
         pf = out["preflight"]; pairs = [p for p in pf.get("pairs", []) if not p.get("same_gpu")]
-        line["preflight"] = {"distinct_gpus": len({d["pci"] for d in pf.get("devices", [])}), "peer_pairs_checked": len(pairs),
+        line["preflight"] = {"distinct_gpus": len({d["pci"] for d in pf.get("devices", [])}), "peer_pairs_checked": len(pairs), "pairs_without_peer_access": sum(1 for p in pairs if not p.get("peer_access")),
                              "min_pair_GBs": _r(min((p["GBs"] for p in pairs), default=None))}
     line["detail"] = detail_path
     text = json.dumps(line, separators=(",", ":"))
@@ -1046,8 +1046,11 @@ def main():
     preflight = None
     if world > 1 and rank == 0:
         devs = [0] * world if args.shared_device else list(range(world))
-        preflight = cg.device_preflight(devs, allow_shared=args.shared_device)
+        preflight = cg.device_preflight(devs, allow_shared=args.shared_device, allow_staged=True)
         pairs = [p for p in preflight["pairs"] if not p["same_gpu"]]
+        if any(not p["peer_access"] for p in pairs):
+            print("bench.py preflight: WARNING — " + ", ".join(f"{p['src']}->{p['dst']}" for p in pairs if not p["peer_access"]) +
+                  " have NO peer access: device-to-device copies are staged through the host (not xGMI)", file=sys.stderr)
         print(f"bench.py preflight: {len(set(d['pci'] for d in preflight['devices']))} distinct GPU(s) for {world} rank(s), {len(pairs)} peer pairs checked"
               + (f", slowest 1 MiB copy {min(p['GBs'] for p in pairs):.1f} GB/s" if pairs else " (shared-device test mode)"), file=sys.stderr)
     comm = Comm(dist, world, device)

@@ -123,7 +123,9 @@ int32_t cgh_session_open_multi(const int32_t* devices, int32_t n_dev, int32_t cu
         s = new cgh_session(); s->device = devices[0];
         s->devices.assign(devices, devices + n_dev); s->ctx0.assign(n_dev, nullptr); s->dzs.resize(n_dev); s->idle.resize(n_dev); s->idle_chain.resize(n_dev);
         // first contact with the node: the list names n DISTINCT GPUs that reach each other, or the session does not open (cg_device_preflight)
-        if (n_dev > 1) CG(cg_device_preflight(devices, n_dev, (flags & CGH_SESSION_SHARED_DEVICES) ? CG_PREFLIGHT_ALLOW_SHARED : 0u, nullptr, 0));
+        // (pairs without peer access are accepted — cg_dev_copy_peer then goes through the host, slower but correct, and the checked copy has
+        // shown that it arrives intact; a repeated GPU or a corrupted copy is not)
+        if (n_dev > 1) CG(cg_device_preflight(devices, n_dev, CG_PREFLIGHT_ALLOW_STAGED | ((flags & CGH_SESSION_SHARED_DEVICES) ? CG_PREFLIGHT_ALLOW_SHARED : 0u), nullptr, 0));
         s->z = read_zkey(curve, zkey_path);
         std::vector<Fr> pub(s->z.n_public + 1);
         for (int d = 0; d < n_dev; d++) {

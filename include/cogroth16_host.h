@@ -110,8 +110,8 @@ int32_t cgh_session_open(int32_t device, int32_t curve, const char* zkey_path, i
  * Randomness is drawn exactly as in the reference.  All three parties must open their sessions with the same flag. */
 #define CGH_SESSION_SKIP_VALIDATION 1u
 #define CGH_SESSION_ADDITIVE_H 2u
-/* cgh_session_open_multi with more than one device first runs cg_device_preflight (distinct GPUs, peer access, one checked 1 MiB copy per
- * pair) and refuses the list if it fails.  CGH_SESSION_SHARED_DEVICES: the list may name a GPU more than once (one-GPU tests and planning
+/* cgh_session_open_multi with more than one device first runs cg_device_preflight (distinct GPUs, one checked 1 MiB copy per ordered pair;
+ * pairs WITHOUT peer access are accepted — their copies go through the host, slower but checked) and refuses the list if it fails.  CGH_SESSION_SHARED_DEVICES: the list may name a GPU more than once (one-GPU tests and planning
  * runs: every "device" is then a context pair on that GPU) — pairs on one GPU are checked as local copies. */
 #define CGH_SESSION_SHARED_DEVICES 4u
 int32_t cgh_session_open_ex(int32_t device, int32_t curve, const char* zkey_path, int32_t precompute, uint32_t flags, void** out_session);
