@@ -44,7 +44,7 @@ def build(bls=True, jobs=8):
 OPT_MSM_CHUNK, OPT_MSM_WINDOW, OPT_MSM_SCATTER_CAP, OPT_MSM_TABLE_ORDER, OPT_MSM_G2_SLICES, OPT_MSM_REDUCE_BATCH, OPT_MSM_ACC_SLOTS, OPT_MSM_G2_AFTER, OPT_MSM_WIDE_SMALL = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPT_MSM_ONE_STREAM_LOG, OPT_MSM_OFF_MAIN_LOG, OPT_MSM_SOLO_LOG = 10, 11, 12
 # process-wide options (cg_set_option)
-GOPT_SUBGROUP_FULL, GOPT_COMPACT_MIN_LOG, GOPT_SORT_STAGING, GOPT_SORT_SMALL, GOPT_MSM_STAGED_OUT = 1, 2, 3, 4, 5
+GOPT_SUBGROUP_FULL, GOPT_COMPACT_MIN_LOG, GOPT_SORT_STAGING, GOPT_SORT_SMALL, GOPT_MSM_STAGED_OUT, GOPT_STREAM_PROBES = 1, 2, 3, 4, 5, 6
 
 # every symbol include/cogroth16_hip.h declares (checked by tests/test_abi_surface.py)
 ABI_SYMBOLS = [

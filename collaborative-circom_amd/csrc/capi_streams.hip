@@ -168,7 +168,7 @@ int coupled_reference(const hipStream_t* refs, hipStream_t st) {
 }
 int measured_pipe(int device, int cls, hipStream_t st) {
     static const bool off = tune_env("CG_NO_PIPE_MAP") != nullptr || tune_env("CG_NO_STREAM_PROBE") != nullptr;
-    if (off || cls < -1 || cls > 1) return -1;
+    if (off || !global_option(CG_GOPT_STREAM_PROBES) || cls < -1 || cls > 1) return -1;
     std::lock_guard<std::mutex> l(g_pipe_mu);
     PipeRefs& r = g_pipe_refs[device];
     if (!r.ok && r.attempts < 3) {                                                     // (an attempt made while somebody else's work held the device may fail: twice more, later)
@@ -201,7 +201,7 @@ int measured_pipe(int device, int cls, hipStream_t st) {
 thread_local std::vector<hipStream_t> g_group_busy[3];                        // [class + 1]: streams of the contexts made so far in this thread's stream group
 int separate_stream(int device, int cls, hipStream_t* moving, std::vector<hipStream_t> fixed) {
     static const bool off = tune_env("CG_NO_STREAM_PROBE") != nullptr;            // A/B knob
-    if (off) return 0;
+    if (off || !global_option(CG_GOPT_STREAM_PROBES)) return 0;
     std::vector<hipStream_t> rejected;
     for (int tries = 0; tries < 6; tries++) {
         bool clash = false;

@@ -36,7 +36,7 @@ struct GlobalOptions {
     std::atomic<int64_t> v[CG_GOPT_COUNT];
     GlobalOptions() {
         for (auto& x : v) x.store(0);
-        v[CG_GOPT_COMPACT_MIN_LOG].store(14); v[CG_GOPT_SORT_STAGING].store(1); v[CG_GOPT_SORT_SMALL].store(1);
+        v[CG_GOPT_COMPACT_MIN_LOG].store(14); v[CG_GOPT_SORT_STAGING].store(1); v[CG_GOPT_SORT_SMALL].store(1); v[CG_GOPT_STREAM_PROBES].store(1);
     }
 };
 inline GlobalOptions g_options;

@@ -228,8 +228,12 @@ int32_t cg_ctx_get_option(const cg_ctx* ctx, int32_t option, int64_t* value);
  *   CG_GOPT_SORT_SMALL             0 = small scalar vectors go through the general six-launch schedule instead of the             1
  *                                  one-workgroup kernel
  *   CG_GOPT_MSM_STAGED_OUT         1 = the sums of a bucket reduction are written to device scratch and copied to the ticket's   0
- *                                  page-locked buffer (one copy per bucket set) instead of being written there by the last kernel */
-enum { CG_GOPT_SUBGROUP_FULL = 1, CG_GOPT_COMPACT_MIN_LOG = 2, CG_GOPT_SORT_STAGING = 3, CG_GOPT_SORT_SMALL = 4, CG_GOPT_MSM_STAGED_OUT = 5, CG_GOPT_COUNT = 6 };
+ *                                  page-locked buffer (one copy per bucket set) instead of being written there by the last kernel
+ *   CG_GOPT_STREAM_PROBES          0 = NEW contexts take their streams from the pool by creation order, without the spin-kernel   1
+ *                                  probes that measure which streams share a hardware queue / a pipe of the command processor (the
+ *                                  probes rest on behaviour the runtime does not document: the switch for a runtime that changes it) */
+enum { CG_GOPT_SUBGROUP_FULL = 1, CG_GOPT_COMPACT_MIN_LOG = 2, CG_GOPT_SORT_STAGING = 3, CG_GOPT_SORT_SMALL = 4, CG_GOPT_MSM_STAGED_OUT = 5,
+       CG_GOPT_STREAM_PROBES = 6, CG_GOPT_COUNT = 7 };
 int32_t cg_set_option(int32_t option, int64_t value);
 int32_t cg_get_option(int32_t option, int64_t* value);
 /* window size override (0 = automatic); tuning knob only, never changes results */

@@ -192,7 +192,7 @@ def test_process_wide_options_round_trip_and_refuse_unknown_ids():
     """cg_set_option / cgh_set_option (the homes of what used to be environment variables): defaults as documented in the headers, values
     round-trip, unknown options and out-of-range values are errors, not silent no-ops.  No device needed."""
     ensure_built()
-    assert [cg.get_option(o) for o in (cg.GOPT_SUBGROUP_FULL, cg.GOPT_COMPACT_MIN_LOG, cg.GOPT_SORT_STAGING, cg.GOPT_SORT_SMALL, cg.GOPT_MSM_STAGED_OUT)] == [0, 14, 1, 1, 0]
+    assert [cg.get_option(o) for o in (cg.GOPT_SUBGROUP_FULL, cg.GOPT_COMPACT_MIN_LOG, cg.GOPT_SORT_STAGING, cg.GOPT_SORT_SMALL, cg.GOPT_MSM_STAGED_OUT, cg.GOPT_STREAM_PROBES)] == [0, 14, 1, 1, 0, 1]
     cg.set_option(cg.GOPT_COMPACT_MIN_LOG, 64); assert cg.get_option(cg.GOPT_COMPACT_MIN_LOG) == 64
     cg.set_option(cg.GOPT_COMPACT_MIN_LOG, 14)
     for bad in ((0, 1), (99, 1), (cg.GOPT_SUBGROUP_FULL, 2), (cg.GOPT_SORT_SMALL, -1), (cg.GOPT_COMPACT_MIN_LOG, 65)):

@@ -304,7 +304,7 @@ print("child ok")
     assert r.returncode == 0 and "child ok" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("knobs", [{"staged_out": 1}, {"off_main_log": 0}, {"solo_log": 0}, {"staged_out": 1, "off_main_log": 0, "sort_small": 0}, {"one_stream_log": 20}])
+@pytest.mark.parametrize("knobs", [{"staged_out": 1}, {"off_main_log": 0}, {"solo_log": 0}, {"staged_out": 1, "off_main_log": 0, "sort_small": 0}, {"one_stream_log": 20}, {"stream_probes": 0}])
 def test_small_call_options_do_not_change_results_in_a_fresh_process(built, knobs):
     """the defaults for small MSM calls — sums written straight into the ticket's page-locked buffer, accumulations off the main stream, the
     closed main-stream sequence of single-field calls, the one-workgroup schedule kernel — against the other value of their options
@@ -324,6 +324,7 @@ _, roots, _ = orc.roots_of_unity(BN254)
 knobs = KNOBS
 if "staged_out" in knobs: cg.set_option(cg.GOPT_MSM_STAGED_OUT, knobs["staged_out"])
 if "sort_small" in knobs: cg.set_option(cg.GOPT_SORT_SMALL, knobs["sort_small"])
+if "stream_probes" in knobs: cg.set_option(cg.GOPT_STREAM_PROBES, knobs["stream_probes"])
 c = cg.Context(0)
 for name, opt in (("off_main_log", cg.OPT_MSM_OFF_MAIN_LOG), ("solo_log", cg.OPT_MSM_SOLO_LOG), ("one_stream_log", cg.OPT_MSM_ONE_STREAM_LOG)):
     if name in knobs:
