@@ -155,6 +155,62 @@ struct L29 {
 #undef CG_CHAIN
         ab.l[NL - 1] = (int32_t)T; cd.l[NL - 1] = (int32_t)U;
     }
+    // ---- column engine: several INDEPENDENT Montgomery products run column by column, their multiply-adds interleaved chain by chain
+    // (a dependent v_mad_u64_u32 needs two independent instructions in front of it: two chains leave one wait state per pair, three none).
+    // A chain is one running accumulator; its column k takes the chain's own products (`prod`), the reduction terms m_i p_(k-i) (`red`) and
+    // yields m_k or result limb k - NL (`finish`).  The order of the additions is pinned (see mul_cols).  Same values and bounds as the row forms.
+#define CG_CHAIN(x) asm("" : "+v"(x))
+    // (column and slot indices are template parameters: every condition below folds at compile time, every p_j is an immediate)
+    struct ColBase {
+        int64_t T = 0; int32_t m[NL]; L29 r;
+        template <int K, int I> __device__ __forceinline__ void red() { if constexpr (I < K && I < NL && K - I < NL) { T += (int64_t)m[I] * pl(K - I); CG_CHAIN(T); } }
+        template <int K, int I> __device__ __forceinline__ void prod2() {}               // second product of a slot (fused chains only)
+        template <int K> __device__ __forceinline__ void finish() {
+            if constexpr (K < NL) { m[K] = (int32_t)(((uint32_t)T * (P::INV & MASK)) & MASK); T += (int64_t)m[K] * pl(0); T >>= W; CG_CHAIN(T); }
+            else if constexpr (K < 2 * NL - 2) { r.l[K - NL] = (int32_t)((uint32_t)T & MASK); T >>= W; CG_CHAIN(T); }
+            else { r.l[K - NL] = (int32_t)((uint32_t)T & MASK); r.l[NL - 1] = (int32_t)(T >> W); }
+        }
+    };
+    struct ColMul : ColBase {          // a * b
+        const L29& a; const L29& b;
+        __device__ __forceinline__ ColMul(const L29& a_, const L29& b_) : a(a_), b(b_) {}
+        template <int K, int I> __device__ __forceinline__ void prod() { if constexpr (K - I >= 0 && K - I < NL) { this->T += (int64_t)a.l[I] * b.l[K - I]; CG_CHAIN(this->T); } }
+    };
+    struct ColSqr : ColBase {          // a * a, off-diagonal products once, doubled
+        const L29& a; int32_t a2[NL];
+        __device__ __forceinline__ ColSqr(const L29& a_) : a(a_) { _Pragma("unroll") for (int k = 0; k < NL; k++) a2[k] = a_.l[k] * 2; }
+        template <int K, int I> __device__ __forceinline__ void prod() {
+            if constexpr (K - I >= 0 && K - I < NL && I <= K - I) { this->T += I == K - I ? (int64_t)a.l[I] * a.l[I] : (int64_t)a2[I] * a.l[K - I]; CG_CHAIN(this->T); }
+        }
+    };
+    struct ColMulSub : ColBase {       // a * b - c * d in ONE reduction
+        const L29& a; const L29& b; const L29& c; const L29& d;
+        __device__ __forceinline__ ColMulSub(const L29& a_, const L29& b_, const L29& c_, const L29& d_) : a(a_), b(b_), c(c_), d(d_) {}
+        template <int K, int I> __device__ __forceinline__ void prod() {
+            if constexpr (K - I >= 0 && K - I < NL) { this->T += (int64_t)a.l[I] * b.l[K - I]; CG_CHAIN(this->T); }
+        }
+        template <int K, int I> __device__ __forceinline__ void prod2() {
+            if constexpr (K - I >= 0 && K - I < NL) { this->T += (int64_t)(-c.l[I]) * d.l[K - I]; CG_CHAIN(this->T); }
+        }
+    };
+    struct ColMulAdd : ColBase {       // a * b + c * d in ONE reduction
+        const L29& a; const L29& b; const L29& c; const L29& d;
+        __device__ __forceinline__ ColMulAdd(const L29& a_, const L29& b_, const L29& c_, const L29& d_) : a(a_), b(b_), c(c_), d(d_) {}
+        template <int K, int I> __device__ __forceinline__ void prod() {
+            if constexpr (K - I >= 0 && K - I < NL) { this->T += (int64_t)a.l[I] * b.l[K - I]; CG_CHAIN(this->T); }
+        }
+        template <int K, int I> __device__ __forceinline__ void prod2() {
+            if constexpr (K - I >= 0 && K - I < NL) { this->T += (int64_t)c.l[I] * d.l[K - I]; CG_CHAIN(this->T); }
+        }
+    };
+    template <int K, int I, class... C> __device__ __forceinline__ static void col_prods(C&... c) { (c.template prod<K, I>(), ...); (c.template prod2<K, I>(), ...); if constexpr (I + 1 < NL) col_prods<K, I + 1>(c...); }
+    template <int K, int I, class... C> __device__ __forceinline__ static void col_reds(C&... c) { (c.template red<K, I>(), ...); if constexpr (I + 1 < NL) col_reds<K, I + 1>(c...); }
+    template <int K, class... C> __device__ __forceinline__ static void col_step(C&... c) {
+        col_prods<K, 0>(c...); col_reds<K, 0>(c...); (c.template finish<K>(), ...);
+        if constexpr (K + 1 < 2 * NL - 1) col_step<K + 1>(c...);
+    }
+    template <class... C> __device__ __forceinline__ static void run_cols(C&... c) { col_step<0>(c...); }
+#undef CG_CHAIN
     // cheap necessary condition for x = 0 (mod p) on an UNNORMALISED value: carries only travel upwards, so the lowest W bits of
     // limb 0 already are the normalised limb 0 and must equal limb 0 of one of the candidates k*p (a non-zero residue passes with
     // probability ~10 / 2^W).  Lets the hot loop skip the carry propagation it would otherwise do only for this test.

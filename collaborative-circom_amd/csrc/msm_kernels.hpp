@@ -143,6 +143,17 @@ struct L29x2 {
         L s = (a.c0 + a.c1).norm(), d = (a.c0 - a.c1).norm();     // limb magnitude back to 2^29 before multiplying
         return {L::mul(s, d), L::mul(a.c0.dbl(), a.c1)};
     }
+    // column-engine chains (L29::run_cols): an Fq2 product = two fused chains, a squaring = two plain ones
+    struct Col2Mul {
+        typename L::ColMulSub c0; typename L::ColMulAdd c1;
+        __device__ __forceinline__ Col2Mul(const L29x2& a, const L29x2& b) : c0(a.c0, b.c0, a.c1, b.c1), c1(a.c0, b.c1, a.c1, b.c0) {}
+        __device__ __forceinline__ L29x2 res() const { return {c0.r, c1.r}; }
+    };
+    struct Col2Sqr {
+        L s, d, a0d; const L& a1; typename L::ColMul c0, c1;
+        __device__ __forceinline__ Col2Sqr(const L29x2& a) : s((a.c0 + a.c1).norm()), d((a.c0 - a.c1).norm()), a0d(a.c0.dbl()), a1(a.c1), c0(s, d), c1(a0d, a1) {}
+        __device__ __forceinline__ L29x2 res() const { return {c0.r, c1.r}; }
+    };
     // a*b - c*d: kept as two products here (four signed products per column would not fit 63 bits)
     __device__ __forceinline__ static L29x2 mul_sub(const L29x2& a, const L29x2& b, const L29x2& c, const L29x2& d) { return (mul(a, b) - mul(c, d)).norm(); }
     __device__ __forceinline__ static bool is_zero_mod_p(const L29x2& x) { return L::is_zero_mod_p(x.c0) && L::is_zero_mod_p(x.c1); }
@@ -235,6 +246,9 @@ template <class F> __device__ __attribute__((noinline)) XYZZL<F> bk_dbl(const XY
 // segment per lane in the merge and reduction kernels, ~30 scratch accesses on the hot path of each addition).  Out of line, both operands and the result travel through scratch memory
 // (3 x 144 / 288 bytes per call and lane): in the reduction kernels, whose lanes run short serial chains of additions at one wave
 // per SIMD, those round trips are on the critical path.
+// (Round 6 measured the column form of acc_madd_lazy_cols for this full addition as well — groups of three independent chains, no wait states: the
+// merge / reduction kernels go from 138-149 to 176-179 VGPRs and get no faster: reduce stage of a 2^22 G1 set 0.427-0.431 -> 0.438-0.454 ms, BLS12-381
+// 0.770 -> 0.87; profiles/r06_acc_cols_ab.txt.  Row form kept.)
 template <class F>
 __device__ __forceinline__ XYZZL<F> bk_add_inl(const XYZZL<F>& a, const XYZZL<F>& b) {
     typedef typename LazyOf<F>::type L;
@@ -285,6 +299,76 @@ template <class F> __device__ __forceinline__ XYZZ<F> bk_to_xyzz(const XYZZL<F>&
     return {L::to_fp(a.c[0]), L::to_fp(a.c[1]), L::to_fp(a.c[2]), L::to_fp(a.c[3])};
 }
 
+// The same addition with the products run by COLUMNS and interleaved (L29::run_cols; round 6): -34 vector instructions per product, 153 instead of
+// 164 VGPRs; 2^22-point launch 4.04-4.26 -> 3.90-4.10 ms (BN254 G1), 12.04 -> 11.6-11.7 (G2), 8.98-9.10 -> 8.85-8.87 (BLS12-381 G1) on the boxes of the
+// round (profiles/r06_acc_cols_ab.txt).  Rounds 2-3 had measured product scanning with inline-asm multiply-adds and found nothing: left alone, the
+// compiler re-associates the column sums (the saved 64-bit additions come back), and inline-asm multiply-adds each drag a wait state behind them;
+// here the products stay C++ and only the ORDER of the additions is pinned (empty asm statements).  The nine products of madd-2008-s
+// fall into four groups of independent ones — (U2, S2), (P^2, R^2), (P PP, X PP, ZZ PP), (ZZZ PPP, R (Q - X3) - Y PPP).
+template <class L> struct HasColEngine { static constexpr bool value = false; };
+template <class F> struct HasColEngine<L29<F>> { static constexpr bool value = true; };
+template <class F, class Acc, class L>
+__device__ __forceinline__ void acc_madd_lazy_cols(Acc& acc, const F& x2f, const F& y2f, const L& x2, const L& y2, bool negate) {
+    const L X = acc.get(0), Y = acc.get(1), ZZ = acc.get(2), ZZZ = acc.get(3);
+    typename L::ColMul u2(x2, ZZ), s2(y2, ZZZ);
+    L::run_cols(u2, s2);
+    const L P = u2.r - X, R = s2.r - Y;
+    if (L::maybe_zero_mod_p(P) && L::is_zero_mod_p(P.norm())) {   // same x: doubling or cancellation (rare)
+        if (L::is_zero_mod_p(R.norm())) {
+            XYZZ<F> d = L::dbl_affine(x2f, negate ? y2f.neg() : y2f);
+            acc.inf = d.is_inf();
+            if (!acc.inf) {
+                const L one = L::one();
+                constexpr int SH = LazyShift<L>::value;
+                acc.set(0, L::mul(L::template unpack<SH>(d.x), one)); acc.set(1, L::mul(L::template unpack<SH>(d.y), one));
+                acc.set(2, L::mul(L::template unpack<SH>(d.zz), one)); acc.set(3, L::mul(L::template unpack<SH>(d.zzz), one));
+            }
+        } else acc.inf = true;
+        return;
+    }
+    typename L::ColSqr pp(P), rr(R);
+    L::run_cols(pp, rr);
+    typename L::ColMul ppp(P, pp.r), q(X, pp.r), zz(ZZ, pp.r);
+    L::run_cols(ppp, q, zz);
+    const L X3 = (rr.r - ppp.r - q.r.dbl()).norm();
+    const L QX = q.r - X3;
+    typename L::ColMul zzz(ZZZ, ppp.r); typename L::ColMulSub y3(R, QX, Y, ppp.r);
+    L::run_cols(zzz, y3);
+    acc.set(2, zz.r); acc.set(3, zzz.r); acc.set(1, y3.r); acc.set(0, X3);
+}
+// ... and in Fq2: every product is two fused chains (c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0), interleaved product by product
+// (BN254 only: on BLS12-381's 14-limb Fq2 the kernel already runs at one wave per SIMD with 321 registers, and the two chains' state pushes
+// the mixed addition into scratch — a 2^22-point launch 25.9 -> 75.5 ms, measured)
+template <class F2> struct HasColEngine<L29x2<F2>> { static constexpr bool value = F2::Base::N == 8; };
+template <class F, class Acc, class F2>
+__device__ __forceinline__ void acc_madd_lazy_cols(Acc& acc, const F& x2f, const F& y2f, const L29x2<F2>& x2, const L29x2<F2>& y2, bool negate) {
+    typedef L29x2<F2> L; typedef typename L::L L1;
+    auto mul = [](const L& a, const L& b) { typename L::Col2Mul c(a, b); L1::run_cols(c.c0, c.c1); return c.res(); };      // one Fq2 product = two interleaved chains
+    auto sqr = [](const L& a) { typename L::Col2Sqr c(a); L1::run_cols(c.c0, c.c1); return c.res(); };
+    const L P = mul(x2, acc.get(2)) - acc.get(0);
+    const L R = mul(y2, acc.get(3)) - acc.get(1);
+    if (L::maybe_zero_mod_p(P) && L::is_zero_mod_p(P.norm())) {   // same x: doubling or cancellation (rare)
+        if (L::is_zero_mod_p(R.norm())) {
+            XYZZ<F> d = L::dbl_affine(x2f, negate ? y2f.neg() : y2f);
+            acc.inf = d.is_inf();
+            if (!acc.inf) {
+                const L one = L::one();
+                constexpr int SH = LazyShift<L>::value;
+                acc.set(0, L::mul(L::template unpack<SH>(d.x), one)); acc.set(1, L::mul(L::template unpack<SH>(d.y), one));
+                acc.set(2, L::mul(L::template unpack<SH>(d.zz), one)); acc.set(3, L::mul(L::template unpack<SH>(d.zzz), one));
+            }
+        } else acc.inf = true;
+        return;
+    }
+    const L PP = sqr(P);
+    const L PPP = mul(P, PP);
+    const L Q = mul(acc.get(0), PP);
+    acc.set(2, mul(acc.get(2), PP));
+    acc.set(3, mul(acc.get(3), PPP));
+    const L X3 = (sqr(R) - PPP - Q.dbl()).norm();
+    acc.set(1, (mul(R, Q - X3) - mul(acc.get(1), PPP)).norm());
+    acc.set(0, X3);
+}
 // acc += (x2, y2): madd-2008-s on lazy signed limbs (see the bounds above); coordinates 0..3 = X, Y, ZZ, ZZZ
 template <class F, class Acc>
 __device__ __forceinline__ void acc_madd_lazy(Acc& acc, const F& x2f, const F& y2f, bool negate) {
@@ -300,6 +384,9 @@ __device__ __forceinline__ void acc_madd_lazy(Acc& acc, const F& x2f, const F& y
         acc.set(0, L::unpack_small(x2f)); acc.set(1, negate ? ys.neg().norm() : ys); acc.set(2, one); acc.set(3, one); acc.inf = false;
         return;
     }
+#if !defined(CG_ACC_ROWS)                        // round 6 default: products by columns (-DCG_ACC_ROWS: the row form of rounds 2-5, for A/B runs)
+    if constexpr (HasColEngine<L>::value) { acc_madd_lazy_cols<F>(acc, x2f, y2f, x2, y2, negate); return; }
+#endif
     L P = L::mul(x2, acc.get(2)) - acc.get(0);
     L R = L::mul(y2, acc.get(3)) - acc.get(1);
     if (L::maybe_zero_mod_p(P) && L::is_zero_mod_p(P.norm())) {   // same x: doubling or cancellation (rare)
