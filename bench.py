@@ -1213,7 +1213,7 @@ def main():
                               "achieved": (mads * iso_pts * nwin_g1 / (iso_ms * 1e-3) / 1e12) if iso_ms else None,
                               "peak": MAD_PEAK_T, "frac": (mads * iso_pts * nwin_g1 / (iso_ms * 1e-3) / 1e12 / MAD_PEAK_T) if iso_ms else None,
                               "launch_ms": iso_ms, "note": "isolated launches; peak = sustained rate of a pure v_mad_u64_u32 loop at the 2.3 GHz it holds; the launch itself "
-                                                             "holds ~1.9 GHz and issues ~750 other vector instructions per BN254 addition beside the multiply-adds"},
+                                                             "holds ~1.9 GHz and issues ~570 other vector instructions (and ~390 wait states) per BN254 addition beside the multiply-adds (round 6: products by columns; ~750 before)"},
             "isolated_ms": iso,
             "stages": stage_table(iso),
             "hbm_footprint": {"device_bytes_in_use": int(total_b - free_b), "device_bytes_total": int(total_b),
